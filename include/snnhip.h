@@ -1,0 +1,191 @@
+/*
+ * snnhip.h -- thin C-ABI between ShaderNN's C++ host side and the MI355X (gfx950) HIP operator kernels.
+ *
+ * This is the drop-in boundary: plain pointers and sizes only, no C++ or
+ * torch types.  Everything the reference's per-layer "render pass" does on the GPU is reachable through these
+ * entry points:
+ *
+ *   reference interface being replaced                                   | entry point here
+ *   ---------------------------------------------------------------------+------------------------------------------
+ *   createDefaultContext / VulkanBackend ctor                            | snnhip_ctx_create / _create_on_stream
+ *     core/src/contextFactory.cpp:21-32, core/src/ic2/vulkanBackend.cpp:28-41
+ *   ImageTextureVulkan::resetTexture / upload / download / attach        | snnhip_tensor_alloc / _upload* / _download* / _wrap
+ *     core/src/imageTextureVulkan.cpp:188-243, core/inc/snn/imageTexture.h:69-147,301-313
+ *   Conv2DLayerVulkan::createCS + VulkanRenderPass ctor (weights, spec    | snnhip_conv2d_plan_create
+ *     constants, pipeline)  core/src/ic2/conv2dVulkan.cpp:38-239, vulkanRenderpass.cpp:103-178
+ *   SeparableConv2DLayerVulkan::createCS                                 | snnhip_depthwise_plan_create
+ *     core/src/ic2/separableconvolutionVulkan.cpp:32-160
+ *   DenseLayerVulkan::createCS / DenseLayer::computeImageTexture         | snnhip_dense_plan_create
+ *     core/src/ic2/denselayerVulkan.cpp:33-126, denselayer.cpp:27-38
+ *   SubpixelLayerVulkan::createCS                                        | snnhip_subpixel_plan_create
+ *     core/src/ic2/subpixelmergeVulkan.cpp:29-91
+ *   Add/Activation/BatchNorm/Pooling/Pad/Upsample/InstanceNorm/Concat    | snnhip_eltwise_plan_create ... (section "next ops")
+ *   VulkanRenderPass::run (bind + Dispatch + barrier)                    | snnhip_plan_run
+ *     core/src/ic2/vulkanRenderpass.cpp:181-260
+ *   VulkanBackend::sync (QueueSubmitAndWait)                             | snnhip_sync
+ *     core/src/ic2/vulkanBackend.cpp:97-106
+ *   DeviceTimer (timestamp query pool)  core/inc/snn/deviceTimer.h:20-51 | snnhip_timer_*
+ *
+ * Conventions: every function returns 0 (SNNHIP_OK) or a negative SNNHIP_E_* code; snnhip_last_error() gives a
+ * thread-local human-readable message.  The C++ wrapper turns non-zero into SNN_RIP to keep the reference's
+ * abort-on-error behaviour (core/inc/snn/utils.h:57-62).  Tensors are plain NHWC fp32 buffers in HBM (the
+ * reference's RGBA "C4HW4" 3-D textures exist only at the API edge: *_c4hw4 upload/download convert).
+ * All work is enqueued on the context's HIP stream; nothing synchronises except snnhip_sync, the download
+ * functions and snnhip_timer_elapsed_ms.
+ */
+#ifndef SNNHIP_H
+#define SNNHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNNHIP_OK 0
+#define SNNHIP_E_INVALID (-1)     /* bad argument / shape mismatch                          */
+#define SNNHIP_E_HIP (-2)         /* a HIP runtime call failed (message has the hipError)   */
+#define SNNHIP_E_UNSUPPORTED (-3) /* valid request that no kernel variant implements        */
+#define SNNHIP_E_NOMEM (-4)
+
+typedef struct snnhip_ctx snnhip_ctx;
+typedef struct snnhip_tensor snnhip_tensor;
+typedef struct snnhip_plan snnhip_plan;
+typedef struct snnhip_timer snnhip_timer;
+
+/* activation ids: specialisation constant 15 of the conv shaders (conv2dVulkan.cpp:58-72) */
+enum {
+    SNNHIP_ACT_NONE = 0,
+    SNNHIP_ACT_RELU = 1,
+    SNNHIP_ACT_RELU6 = 2,
+    SNNHIP_ACT_TANH = 3,
+    SNNHIP_ACT_SIGMOID = 4,
+    SNNHIP_ACT_LEAKY = 5,
+    SNNHIP_ACT_SILU = 6,       /* x*sigmoid(x) */
+    SNNHIP_ACT_SILU_QUIRK = 7  /* bit-for-bit model of the reference SiLU bug (vk_conv2d.comp:336-339) */
+};
+/* padding mode: specialisation constant 16 (conv2dVulkan.cpp:74-81) */
+enum { SNNHIP_PAD_NONE = 0, SNNHIP_PAD_CONSTANT = 1, SNNHIP_PAD_REPLICATE = 2, SNNHIP_PAD_REFLECT = 3 };
+enum { SNNHIP_F32 = 0 };
+
+/* ---- context -------------------------------------------------------------------------------------- */
+
+typedef struct {
+    char name[128];
+    int compute_units;
+    int lds_bytes_per_cu;
+    size_t hbm_bytes;
+    int device;
+} snnhip_device_info;
+
+int snnhip_ctx_create(int device, snnhip_ctx** out);
+/* Uses a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of creating one. */
+int snnhip_ctx_create_on_stream(int device, void* hip_stream, snnhip_ctx** out);
+int snnhip_ctx_destroy(snnhip_ctx* ctx);
+int snnhip_ctx_info(snnhip_ctx* ctx, snnhip_device_info* info);
+void* snnhip_ctx_stream(snnhip_ctx* ctx);
+int snnhip_sync(snnhip_ctx* ctx);
+const char* snnhip_last_error(void);
+const char* snnhip_version(void);
+
+/* ---- tensors: NHWC fp32 in HBM ------------------------------------------------------------------- */
+
+int snnhip_tensor_alloc(snnhip_ctx* ctx, int n, int h, int w, int c, int dtype, snnhip_tensor** out);
+/* Borrow device memory owned by someone else (a torch tensor, another tensor's storage). Never freed here. */
+int snnhip_tensor_wrap(snnhip_ctx* ctx, void* device_ptr, int n, int h, int w, int c, int dtype, snnhip_tensor** out);
+int snnhip_tensor_free(snnhip_tensor* t);
+int snnhip_tensor_dims(const snnhip_tensor* t, int dims_nhwc[4]);
+void* snnhip_tensor_data(const snnhip_tensor* t);
+size_t snnhip_tensor_bytes(const snnhip_tensor* t);
+int snnhip_tensor_upload(snnhip_tensor* t, const float* host_nhwc);          /* H2D, synchronous */
+int snnhip_tensor_download(const snnhip_tensor* t, float* host_nhwc);        /* stream sync + D2H */
+/* Reference texture layout [ceil(C/4)][H][W][4] per image (shaderUnitTest.cpp:87-129, image.cpp:216-245). */
+int snnhip_tensor_upload_c4hw4(snnhip_tensor* t, const float* host_c4hw4);
+int snnhip_tensor_download_c4hw4(const snnhip_tensor* t, float* host_c4hw4);
+int snnhip_tensor_fill(snnhip_tensor* t, float value);
+
+/* ---- plans ---------------------------------------------------------------------------------------- */
+
+/* Mirror of the conv shaders' 20 specialisation constants (conv2dVulkan.cpp:182-203) plus batch. */
+typedef struct {
+    int N, H, W, IC, OC;
+    int kh, kw, sh, sw;
+    int padT, padB, padL, padR; /* getPaddingOffset order; like the reference the kernel offsets x by padT and y
+                                   by padL (conv2dVulkan.cpp:183-184) */
+    int padMode;                /* SNNHIP_PAD_* ; ignored for 1x1 (vk_conv2d_1x1.comp has no padding) */
+    int act;                    /* SNNHIP_ACT_* */
+    float leaky;
+    int useBias, useBN;
+    int dtype;                  /* SNNHIP_F32 */
+    int OH, OW;                 /* 0 => derived with the reference's float rule (conv2d.cpp:102-113) */
+} snnhip_conv2d_desc;
+
+/* w_oihw [OC][IC][kh][kw]; bias [OC] or NULL; BN arrays [OC] or NULL (required when useBN). Host pointers. */
+int snnhip_conv2d_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, const float* w_oihw, const float* bias,
+                              const float* bn_beta, const float* bn_gamma, const float* bn_mean, const float* bn_var,
+                              snnhip_plan** out);
+
+/* depthwise: IC == OC == channels, w_chw [C][kh][kw]; zero padding by tap clipping (vk_depthwise.comp:77-78) */
+int snnhip_depthwise_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, const float* w_chw, const float* bias,
+                                 const float* bn_beta, const float* bn_gamma, const float* bn_mean, const float* bn_var,
+                                 snnhip_plan** out);
+
+/* dense activations follow the reference CPU path (cpulayer.h:38-42,199-261) */
+enum {
+    SNNHIP_DENSE_IDENTITY = 0,
+    SNNHIP_DENSE_RELU = 1,
+    SNNHIP_DENSE_LEAKY = 2,
+    SNNHIP_DENSE_SIGMOID = 3,
+    SNNHIP_DENSE_SOFTMAX = 4,
+    SNNHIP_DENSE_TANH = 5,
+    SNNHIP_DENSE_SILU_NOOP = 6
+};
+typedef struct {
+    int batch, in_units, out_units;
+    int act;
+    float leaky;
+    int useBias;
+} snnhip_dense_desc;
+/* w_flat: the JSON "kernel" array exactly as stored; read as [Out][In] (cpulayer.h:162, vk_dense.comp:69-72).
+ * Input tensor: any NHWC tensor with H*W*C == in_units per image (flatten order HWC, cpulayer.h:94-113).
+ * Output tensor: [batch][1][1][out_units]. */
+int snnhip_dense_plan_create(snnhip_ctx* ctx, const snnhip_dense_desc* desc, const float* w_flat, const float* bias,
+                             snnhip_plan** out);
+
+enum { SNNHIP_SUBPIXEL_D2S = 0, SNNHIP_SUBPIXEL_VK_QUIRK = 1 };
+typedef struct {
+    int N, H, W, C;
+    int factor; /* reference hard-codes 2 (subpixelmerge.h:26-33) */
+    int mode;   /* SNNHIP_SUBPIXEL_* ; tanh is always applied (vk_subpixel.comp:64-66) */
+} snnhip_subpixel_desc;
+int snnhip_subpixel_plan_create(snnhip_ctx* ctx, const snnhip_subpixel_desc* desc, snnhip_plan** out);
+
+/* Try to replace a linear chain of plans (plan[i+1] consumes only plan[i]'s output) by fused kernels.
+ * On success *out runs the whole chain in <= n launches; intermediate tensors that become internal are never
+ * materialised.  Returns SNNHIP_E_UNSUPPORTED when no fusion rule matches (callers keep the unfused plans).
+ * Implemented rule set: see DESIGN.md section 4 (ESPCN: conv5x5(1->16)+conv3x3(16->16), conv3x3(16->4)+subpixel). */
+int snnhip_chain_plan_create(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_plan** out);
+
+int snnhip_plan_run(snnhip_plan* plan, const snnhip_tensor* in, snnhip_tensor* out);
+/* multi-input ops (add, concat): inputs[n_in] */
+int snnhip_plan_run_n(snnhip_plan* plan, const snnhip_tensor* const* inputs, int n_in, snnhip_tensor* out);
+int snnhip_plan_output_dims(const snnhip_plan* plan, int dims_nhwc[4]);
+/* Human-readable kernel-variant description ("conv2d_mfma_f32 tile=...") for logs and tests. */
+int snnhip_plan_describe(const snnhip_plan* plan, char* buf, size_t buflen);
+/* Algorithmic work of one run: flops and true-channel HBM bytes (inputs once + outputs once + weights once). */
+int snnhip_plan_cost(const snnhip_plan* plan, double* flops, double* bytes);
+int snnhip_plan_destroy(snnhip_plan* plan);
+
+/* ---- device timers (hipEvent pairs on the context stream) ---------------------------------------- */
+
+int snnhip_timer_create(snnhip_ctx* ctx, snnhip_timer** out);
+int snnhip_timer_start(snnhip_timer* t);
+int snnhip_timer_stop(snnhip_timer* t);
+int snnhip_timer_elapsed_ms(snnhip_timer* t, float* ms); /* waits for the stop event */
+int snnhip_timer_destroy(snnhip_timer* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

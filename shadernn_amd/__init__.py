@@ -1,0 +1,8 @@
+"""shadernn_amd -- MI355X-native backend for ShaderNN's conv / depthwise / dense operator hot path.
+
+Python here is test/bench plumbing over the C-ABI (include/snnhip.h -> lib/libsnnhip.so) and over the C++ host mirror
+of the reference API (lib/libsnn_core.so).  There is no CPU fallback anywhere in this package.
+"""
+from .capi import (ACT, DENSE_ACT, PAD_MODE, Context, Plan, SnnHipError, Tensor, Timer, chain_plan, conv2d_plan, dense_plan, lib, load_library,  # noqa: F401
+                   same_padding, subpixel_plan)
+from .runner import ChainRunner, EspcnRunner  # noqa: F401

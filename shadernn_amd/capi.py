@@ -1,0 +1,347 @@
+"""ctypes binding of the C-ABI in include/snnhip.h (libsnnhip.so).
+
+This is host-side plumbing only: every operator call goes through the C entry points, exactly what a cgo/JNI/C++
+caller would bind.  The library is mandatory -- there is no CPU or torch fallback; a missing or broken library raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsnnhip.so")
+
+OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4
+
+ACT = {"": 0, "linear": 0, "none": 0, "relu": 1, "relu6": 2, "tanh": 3, "sigmoid": 4, "leakyRelu": 5, "SiLU": 6, "SiLU_quirk": 7}
+PAD_MODE = {"none": 0, "constant": 1, "replicate": 2, "reflect": 3}
+DENSE_ACT = {"identity": 0, "": 0, "relu": 1, "leakyRelu": 2, "sigmoid": 3, "softmax": 4, "tanh": 5, "SiLU": 6}
+
+
+class SnnHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("snnhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "IC", "OC", "kh", "kw", "sh", "sw", "padT", "padB", "padL", "padR", "padMode", "act")] + [
+        ("leaky", C.c_float), ("useBias", C.c_int), ("useBN", C.c_int), ("dtype", C.c_int), ("OH", C.c_int), ("OW", C.c_int)]
+
+
+class DenseDesc(C.Structure):
+    _fields_ = [("batch", C.c_int), ("in_units", C.c_int), ("out_units", C.c_int), ("act", C.c_int), ("leaky", C.c_float), ("useBias", C.c_int)]
+
+
+class SubpixelDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "factor", "mode")]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("compute_units", C.c_int), ("lds_bytes_per_cu", C.c_int), ("hbm_bytes", C.c_size_t), ("device", C.c_int)]
+
+
+_lib = None
+
+_P = C.c_void_p
+_FP = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); must list every symbol include/snnhip.h declares (tests/test_abi.py checks that)
+SIGNATURES = {
+    "snnhip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "snnhip_ctx_create_on_stream": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "snnhip_ctx_destroy": (C.c_int, [_P]),
+    "snnhip_ctx_info": (C.c_int, [_P, C.POINTER(DeviceInfo)]),
+    "snnhip_ctx_stream": (_P, [_P]),
+    "snnhip_sync": (C.c_int, [_P]),
+    "snnhip_last_error": (C.c_char_p, []),
+    "snnhip_version": (C.c_char_p, []),
+    "snnhip_tensor_alloc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "snnhip_tensor_wrap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "snnhip_tensor_free": (C.c_int, [_P]),
+    "snnhip_tensor_dims": (C.c_int, [_P, C.POINTER(C.c_int * 4)]),
+    "snnhip_tensor_data": (_P, [_P]),
+    "snnhip_tensor_bytes": (C.c_size_t, [_P]),
+    "snnhip_tensor_upload": (C.c_int, [_P, _FP]),
+    "snnhip_tensor_download": (C.c_int, [_P, _FP]),
+    "snnhip_tensor_upload_c4hw4": (C.c_int, [_P, _FP]),
+    "snnhip_tensor_download_c4hw4": (C.c_int, [_P, _FP]),
+    "snnhip_tensor_fill": (C.c_int, [_P, C.c_float]),
+    "snnhip_conv2d_plan_create": (C.c_int, [_P, C.POINTER(ConvDesc), _FP, _FP, _FP, _FP, _FP, _FP, C.POINTER(_P)]),
+    "snnhip_depthwise_plan_create": (C.c_int, [_P, C.POINTER(ConvDesc), _FP, _FP, _FP, _FP, _FP, _FP, C.POINTER(_P)]),
+    "snnhip_dense_plan_create": (C.c_int, [_P, C.POINTER(DenseDesc), _FP, _FP, C.POINTER(_P)]),
+    "snnhip_subpixel_plan_create": (C.c_int, [_P, C.POINTER(SubpixelDesc), C.POINTER(_P)]),
+    "snnhip_chain_plan_create": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(_P)]),
+    "snnhip_plan_run": (C.c_int, [_P, _P, _P]),
+    "snnhip_plan_run_n": (C.c_int, [_P, C.POINTER(_P), C.c_int, _P]),
+    "snnhip_plan_output_dims": (C.c_int, [_P, C.POINTER(C.c_int * 4)]),
+    "snnhip_plan_describe": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
+    "snnhip_plan_cost": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "snnhip_plan_destroy": (C.c_int, [_P]),
+    "snnhip_timer_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "snnhip_timer_start": (C.c_int, [_P]),
+    "snnhip_timer_stop": (C.c_int, [_P]),
+    "snnhip_timer_elapsed_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "snnhip_timer_destroy": (C.c_int, [_P]),
+}
+
+
+def load_library():
+    """Loads libsnnhip.so (built in-tree by __graft_entry__.build()).  torch is imported first so that the process has
+    ONE HIP runtime: torch's bundled libamdhip64 has SONAME libamdhip64.so.7, which satisfies this library's
+    DT_NEEDED; loading in the other order would map a second runtime."""
+    global _lib
+    if _lib is not None:
+        return LIB_PATH
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first" % LIB_PATH)
+    import torch  # noqa: F401
+
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return LIB_PATH
+
+
+def lib():
+    load_library()
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise SnnHipError(rc, lib().snnhip_last_error().decode("utf-8", "replace"))
+
+
+def _fptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(_FP)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        h = _P()
+        if stream is None:
+            check(lib().snnhip_ctx_create(device, C.byref(h)))
+        else:
+            check(lib().snnhip_ctx_create_on_stream(device, _P(stream), C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def info(self):
+        di = DeviceInfo()
+        check(lib().snnhip_ctx_info(self.h, C.byref(di)))
+        return {"name": di.name.decode(), "compute_units": di.compute_units, "lds_bytes_per_cu": di.lds_bytes_per_cu, "hbm_bytes": di.hbm_bytes}
+
+    def sync(self):
+        check(lib().snnhip_sync(self.h))
+
+    def stream(self):
+        return lib().snnhip_ctx_stream(self.h)
+
+    def close(self):
+        if self.h:
+            lib().snnhip_ctx_destroy(self.h)
+            self.h = None
+
+
+class Tensor:
+    """NHWC fp32 tensor in HBM."""
+
+    def __init__(self, ctx, n, h, w, c, device_ptr=None, keepalive=None):
+        self.ctx = ctx
+        self.shape = (n, h, w, c)
+        hh = _P()
+        if device_ptr is None:
+            check(lib().snnhip_tensor_alloc(ctx.h, n, h, w, c, 0, C.byref(hh)))
+        else:
+            check(lib().snnhip_tensor_wrap(ctx.h, _P(device_ptr), n, h, w, c, 0, C.byref(hh)))
+        self.h = hh
+        self._keepalive = keepalive
+
+    @staticmethod
+    def from_numpy(ctx, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.ndim == 4, "expected NHWC"
+        t = Tensor(ctx, *a.shape)
+        t.upload(a)
+        return t
+
+    @staticmethod
+    def from_torch(ctx, tt):
+        """Borrows the storage of a contiguous NHWC float32 torch tensor living on the context's device."""
+        assert tt.is_contiguous() and tt.dim() == 4 and str(tt.dtype) == "torch.float32"
+        n, h, w, c = tt.shape
+        return Tensor(ctx, n, h, w, c, device_ptr=tt.data_ptr(), keepalive=tt)
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.size == int(np.prod(self.shape)), (a.shape, self.shape)
+        check(lib().snnhip_tensor_upload(self.h, _fptr(a)))
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=np.float32)
+        check(lib().snnhip_tensor_download(self.h, _fptr(out)))
+        return out
+
+    def upload_c4hw4(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        check(lib().snnhip_tensor_upload_c4hw4(self.h, _fptr(a)))
+
+    def numpy_c4hw4(self):
+        n, h, w, c = self.shape
+        out = np.empty((n, (c + 3) // 4, h, w, 4), dtype=np.float32)
+        check(lib().snnhip_tensor_download_c4hw4(self.h, _fptr(out)))
+        return out
+
+    def fill(self, v):
+        check(lib().snnhip_tensor_fill(self.h, float(v)))
+
+    def data_ptr(self):
+        return lib().snnhip_tensor_data(self.h)
+
+    def free(self):
+        if self.h:
+            lib().snnhip_tensor_free(self.h)
+            self.h = None
+
+
+class Plan:
+    def __init__(self, ctx, handle, keep=()):
+        self.ctx = ctx
+        self.h = handle
+        self._keep = keep
+
+    def out_shape(self):
+        d = (C.c_int * 4)()
+        check(lib().snnhip_plan_output_dims(self.h, C.byref(d)))
+        return tuple(d)
+
+    def describe(self):
+        buf = C.create_string_buffer(512)
+        check(lib().snnhip_plan_describe(self.h, buf, 512))
+        return buf.value.decode()
+
+    def cost(self):
+        f, b = C.c_double(), C.c_double()
+        check(lib().snnhip_plan_cost(self.h, C.byref(f), C.byref(b)))
+        return f.value, b.value
+
+    def run(self, x, y):
+        if isinstance(x, (list, tuple)):
+            arr = (_P * len(x))(*[t.h for t in x])
+            check(lib().snnhip_plan_run_n(self.h, arr, len(x), y.h))
+        else:
+            check(lib().snnhip_plan_run(self.h, x.h, y.h))
+
+    def __call__(self, x, y=None):
+        if y is None:
+            y = Tensor(self.ctx, *self.out_shape())
+        self.run(x, y)
+        return y
+
+    def destroy(self):
+        if self.h:
+            lib().snnhip_plan_destroy(self.h)
+            self.h = None
+
+
+def _conv_desc(N, H, W, IC, OC, k, stride, pads, pad_mode, act, leaky, use_bias, use_bn, OH=0, OW=0):
+    d = ConvDesc()
+    d.N, d.H, d.W, d.IC, d.OC = N, H, W, IC, OC
+    kh, kw = (k, k) if isinstance(k, int) else k
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    d.kh, d.kw, d.sh, d.sw = kh, kw, sh, sw
+    d.padT, d.padB, d.padL, d.padR = pads
+    d.padMode = PAD_MODE[pad_mode] if isinstance(pad_mode, str) else pad_mode
+    d.act = ACT[act] if isinstance(act, str) else act
+    d.leaky = leaky
+    d.useBias, d.useBN, d.dtype, d.OH, d.OW = int(use_bias), int(use_bn), 0, OH, OW
+    return d
+
+
+def same_padding(k):
+    """Conv2DLayer::getPaddingOffset for padding "same" (reference conv2d.cpp:57-66): returns (T, B, L, R)."""
+    if k > 1:
+        p = max(k // 2, 1)
+        t = [p, p, p, p]
+        if k % 2 == 0:
+            t[0] -= 1
+            t[2] -= 1
+        return tuple(t)
+    return (0, 0, 0, 0)
+
+
+def conv2d_plan(ctx, N, H, W, w_oihw, bias=None, stride=1, pads=None, pad_mode="constant", act="", leaky=0.0, bn=None, depthwise=False):
+    """w_oihw: [OC][IC][kh][kw] (depthwise: [C][kh][kw]). bn: dict beta/gamma/mean/var or None. pads: (T,B,L,R) or None=same."""
+    w = _f32(w_oihw)
+    if depthwise:
+        OC, kh, kw = w.shape
+        IC = OC
+    else:
+        OC, IC, kh, kw = w.shape
+    if pads is None:
+        pads = same_padding(kh)
+    b = _f32(bias)
+    bnp = [None] * 4
+    if bn is not None:
+        bnp = [_f32(bn[k]) for k in ("beta", "gamma", "mean", "var")]
+    d = _conv_desc(N, H, W, IC, OC, (kh, kw), stride, pads, pad_mode, act, leaky, b is not None, bn is not None)
+    h = _P()
+    fn = lib().snnhip_depthwise_plan_create if depthwise else lib().snnhip_conv2d_plan_create
+    check(fn(ctx.h, C.byref(d), _fptr(w), _fptr(b), _fptr(bnp[0]), _fptr(bnp[1]), _fptr(bnp[2]), _fptr(bnp[3]), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def dense_plan(ctx, batch, w_flat, out_units, bias=None, act="", leaky=0.0):
+    w = _f32(w_flat).reshape(-1)
+    in_units = w.size // out_units
+    d = DenseDesc(batch, in_units, out_units, DENSE_ACT[act] if isinstance(act, str) else act, leaky, int(bias is not None))
+    b = _f32(bias)
+    h = _P()
+    check(lib().snnhip_dense_plan_create(ctx.h, C.byref(d), _fptr(w), _fptr(b), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def subpixel_plan(ctx, N, H, W, Cc, factor=2, mode=0):
+    d = SubpixelDesc(N, H, W, Cc, factor, mode)
+    h = _P()
+    check(lib().snnhip_subpixel_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def chain_plan(ctx, plans):
+    arr = (_P * len(plans))(*[p.h for p in plans])
+    h = _P()
+    check(lib().snnhip_chain_plan_create(ctx.h, arr, len(plans), C.byref(h)))
+    return Plan(ctx, h, keep=tuple(plans))
+
+
+class Timer:
+    def __init__(self, ctx):
+        self.h = _P()
+        check(lib().snnhip_timer_create(ctx.h, C.byref(self.h)))
+
+    def start(self):
+        check(lib().snnhip_timer_start(self.h))
+
+    def stop(self):
+        check(lib().snnhip_timer_stop(self.h))
+
+    def elapsed_ms(self):
+        ms = C.c_float()
+        check(lib().snnhip_timer_elapsed_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def destroy(self):
+        if self.h:
+            lib().snnhip_timer_destroy(self.h)
+            self.h = None

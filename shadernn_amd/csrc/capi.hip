@@ -1,0 +1,393 @@
+// capi.hip -- implementation of the C-ABI declared in include/snnhip.h: contexts, NHWC tensors, timers and the
+// plan dispatcher that picks a kernel variant for each operator.
+#include <cmath>
+#include <new>
+
+#include "snnhip_internal.h"
+
+namespace snnhip {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+std::vector<float> make_epilogue_table(int OC, int padTo, int useBias, const float* bias, int useBN, const float* beta, const float* gamma,
+                                       const float* mean, const float* var) {
+    const int n = round_up(OC, padTo);
+    std::vector<float> t(static_cast<size_t>(n) * 4, 0.0f);
+    for (int o = 0; o < OC; ++o) {
+        t[o * 4 + 0] = (useBias && bias) ? bias[o] : 0.0f;
+        if (useBN) {
+            float sqrtVar = sqrtf(var[o] + 0.001f);      // vk_conv2d.comp:282
+            if (sqrtVar < 0.0001f) sqrtVar = 0.0001f;     // :283
+            t[o * 4 + 1] = gamma[o] / sqrtVar;
+            t[o * 4 + 2] = mean[o];
+            t[o * 4 + 3] = beta[o];
+        } else {
+            t[o * 4 + 1] = 1.0f;
+        }
+    }
+    return t;
+}
+
+int resolve_conv_geom(const snnhip_conv2d_desc* d, bool depthwise, ConvGeom* g) {
+    SNNHIP_REQUIRE(d->dtype == SNNHIP_F32, "only fp32 tensors are implemented (dtype=%d)", d->dtype);
+    SNNHIP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->IC > 0 && d->OC > 0, "conv desc: non-positive dims N=%d H=%d W=%d IC=%d OC=%d", d->N, d->H,
+                   d->W, d->IC, d->OC);
+    SNNHIP_REQUIRE(d->kh > 0 && d->kw > 0 && d->sh > 0 && d->sw > 0, "conv desc: bad kernel/stride %dx%d / %dx%d", d->kh, d->kw, d->sh, d->sw);
+    SNNHIP_REQUIRE(d->padT >= 0 && d->padB >= 0 && d->padL >= 0 && d->padR >= 0, "conv desc: negative padding");
+    SNNHIP_REQUIRE(d->padMode >= 0 && d->padMode <= 3, "conv desc: padMode %d", d->padMode);
+    SNNHIP_REQUIRE(d->act >= 0 && d->act <= 7, "conv desc: activation id %d", d->act);
+    if (depthwise) SNNHIP_REQUIRE(d->IC == d->OC, "depthwise: IC (%d) must equal OC (%d)", d->IC, d->OC);
+    g->N = d->N; g->H = d->H; g->W = d->W; g->IC = d->IC; g->OC = d->OC;
+    g->kh = d->kh; g->kw = d->kw; g->sh = d->sh; g->sw = d->sw;
+    const bool is1x1 = !depthwise && d->kh == 1 && d->kw == 1;
+    // conv2dVulkan.cpp:154-171: the 1x1 shader gets no padding constants at all; :183-184: uPadx <- T, uPady <- L
+    g->padx = is1x1 ? 0 : d->padT;
+    g->pady = is1x1 ? 0 : d->padL;
+    g->padMode = is1x1 ? SNNHIP_PAD_NONE : d->padMode;
+    g->act = d->act;
+    g->useBN = d->useBN;
+    g->leaky = d->leaky;
+    g->OH = d->OH > 0 ? d->OH : conv_out_dim(d->H, d->kh, d->sh, d->padT, d->padB);
+    g->OW = d->OW > 0 ? d->OW : conv_out_dim(d->W, d->kw, d->sw, d->padT, d->padB); // reference uses offsets[0]+offsets[1] for both axes
+    SNNHIP_REQUIRE(g->OH > 0 && g->OW > 0, "conv desc: empty output %dx%d", g->OH, g->OW);
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip
+
+int snnhip_plan::upload(const float* host, size_t count, float** dev) {
+    void* p = nullptr;
+    SNNHIP_CHECK_HIP(hipMalloc(&p, count ? count * sizeof(float) : 4));
+    deviceAllocs.push_back(p);
+    if (count) SNNHIP_CHECK_HIP(hipMemcpy(p, host, count * sizeof(float), hipMemcpyHostToDevice));
+    *dev = static_cast<float*>(p);
+    return SNNHIP_OK;
+}
+
+using namespace snnhip;
+
+extern "C" {
+
+const char* snnhip_last_error(void) { return g_err; }
+const char* snnhip_version(void) { return "snnhip 0.1 (gfx950)"; }
+
+static int ctx_create_common(int device, hipStream_t stream, bool own, snnhip_ctx** out) {
+    SNNHIP_REQUIRE(out != nullptr, "ctx_create: null out");
+    int count = 0;
+    SNNHIP_CHECK_HIP(hipGetDeviceCount(&count));
+    SNNHIP_REQUIRE(device >= 0 && device < count, "ctx_create: device %d out of range (%d devices)", device, count);
+    SNNHIP_CHECK_HIP(hipSetDevice(device));
+    auto* ctx = new (std::nothrow) snnhip_ctx();
+    if (!ctx) return SNNHIP_E_NOMEM;
+    ctx->device = device;
+    hipError_t e = hipGetDeviceProperties(&ctx->props, device);
+    if (e != hipSuccess) {
+        delete ctx;
+        set_error("hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+        return SNNHIP_E_HIP;
+    }
+    if (own) {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return SNNHIP_E_HIP;
+        }
+        ctx->ownsStream = true;
+    } else {
+        ctx->stream = stream;
+    }
+    *out = ctx;
+    return SNNHIP_OK;
+}
+
+int snnhip_ctx_create(int device, snnhip_ctx** out) { return ctx_create_common(device, nullptr, true, out); }
+
+int snnhip_ctx_create_on_stream(int device, void* hip_stream, snnhip_ctx** out) {
+    return ctx_create_common(device, static_cast<hipStream_t>(hip_stream), false, out);
+}
+
+int snnhip_ctx_destroy(snnhip_ctx* ctx) {
+    if (!ctx) return SNNHIP_OK;
+    if (ctx->ownsStream && ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SNNHIP_OK;
+}
+
+int snnhip_ctx_info(snnhip_ctx* ctx, snnhip_device_info* info) {
+    SNNHIP_REQUIRE(ctx && info, "ctx_info: null argument");
+    memset(info, 0, sizeof(*info));
+    snprintf(info->name, sizeof(info->name), "%s (%s)", ctx->props.name, ctx->props.gcnArchName);
+    info->compute_units = ctx->props.multiProcessorCount;
+    info->lds_bytes_per_cu = static_cast<int>(ctx->props.maxSharedMemoryPerMultiProcessor);
+    info->hbm_bytes = ctx->props.totalGlobalMem;
+    info->device = ctx->device;
+    return SNNHIP_OK;
+}
+
+void* snnhip_ctx_stream(snnhip_ctx* ctx) { return ctx ? ctx->stream : nullptr; }
+
+int snnhip_sync(snnhip_ctx* ctx) {
+    SNNHIP_REQUIRE(ctx, "sync: null ctx");
+    SNNHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return SNNHIP_OK;
+}
+
+/* ---- tensors ---- */
+
+int snnhip_tensor_alloc(snnhip_ctx* ctx, int n, int h, int w, int c, int dtype, snnhip_tensor** out) {
+    SNNHIP_REQUIRE(ctx && out, "tensor_alloc: null argument");
+    SNNHIP_REQUIRE(dtype == SNNHIP_F32, "tensor_alloc: dtype %d not implemented", dtype);
+    SNNHIP_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "tensor_alloc: bad dims %dx%dx%dx%d", n, h, w, c);
+    auto* t = new (std::nothrow) snnhip_tensor();
+    if (!t) return SNNHIP_E_NOMEM;
+    t->ctx = ctx; t->n = n; t->h = h; t->w = w; t->c = c; t->owns = true;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, t->count() * sizeof(float));
+    if (e != hipSuccess) {
+        delete t;
+        set_error("hipMalloc(%zu) failed: %s", t->count() * sizeof(float), hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? SNNHIP_E_NOMEM : SNNHIP_E_HIP;
+    }
+    t->data = static_cast<float*>(p);
+    *out = t;
+    return SNNHIP_OK;
+}
+
+int snnhip_tensor_wrap(snnhip_ctx* ctx, void* device_ptr, int n, int h, int w, int c, int dtype, snnhip_tensor** out) {
+    SNNHIP_REQUIRE(ctx && out && device_ptr, "tensor_wrap: null argument");
+    SNNHIP_REQUIRE(dtype == SNNHIP_F32, "tensor_wrap: dtype %d not implemented", dtype);
+    SNNHIP_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "tensor_wrap: bad dims %dx%dx%dx%d", n, h, w, c);
+    SNNHIP_REQUIRE((reinterpret_cast<uintptr_t>(device_ptr) & 15) == 0, "tensor_wrap: pointer must be 16-byte aligned");
+    auto* t = new (std::nothrow) snnhip_tensor();
+    if (!t) return SNNHIP_E_NOMEM;
+    t->ctx = ctx; t->n = n; t->h = h; t->w = w; t->c = c; t->owns = false;
+    t->data = static_cast<float*>(device_ptr);
+    *out = t;
+    return SNNHIP_OK;
+}
+
+int snnhip_tensor_free(snnhip_tensor* t) {
+    if (!t) return SNNHIP_OK;
+    if (t->owns && t->data) (void) hipFree(t->data);
+    delete t;
+    return SNNHIP_OK;
+}
+
+int snnhip_tensor_dims(const snnhip_tensor* t, int dims[4]) {
+    SNNHIP_REQUIRE(t && dims, "tensor_dims: null argument");
+    dims[0] = t->n; dims[1] = t->h; dims[2] = t->w; dims[3] = t->c;
+    return SNNHIP_OK;
+}
+
+void* snnhip_tensor_data(const snnhip_tensor* t) { return t ? t->data : nullptr; }
+size_t snnhip_tensor_bytes(const snnhip_tensor* t) { return t ? t->count() * sizeof(float) : 0; }
+
+int snnhip_tensor_upload(snnhip_tensor* t, const float* host) {
+    SNNHIP_REQUIRE(t && host, "tensor_upload: null argument");
+    SNNHIP_CHECK_HIP(hipMemcpyAsync(t->data, host, t->count() * sizeof(float), hipMemcpyHostToDevice, t->ctx->stream));
+    SNNHIP_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
+    return SNNHIP_OK;
+}
+
+int snnhip_tensor_download(const snnhip_tensor* t, float* host) {
+    SNNHIP_REQUIRE(t && host, "tensor_download: null argument");
+    SNNHIP_CHECK_HIP(hipMemcpyAsync(host, t->data, t->count() * sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
+    SNNHIP_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
+    return SNNHIP_OK;
+}
+
+// C4HW4 <-> NHWC conversion happens on the host: it is an API-edge format (uploads of test inputs, dumps), never
+// on the inference path.
+int snnhip_tensor_upload_c4hw4(snnhip_tensor* t, const float* c4) {
+    SNNHIP_REQUIRE(t && c4, "tensor_upload_c4hw4: null argument");
+    std::vector<float> nhwc(t->count());
+    const size_t hw = static_cast<size_t>(t->h) * t->w;
+    const int planes = up_div(t->c, 4);
+    for (int n = 0; n < t->n; ++n) {
+        const float* src = c4 + static_cast<size_t>(n) * planes * hw * 4;
+        float* dst = nhwc.data() + static_cast<size_t>(n) * hw * t->c;
+        for (size_t i = 0; i < hw; ++i)
+            for (int c = 0; c < t->c; ++c) dst[i * t->c + c] = src[(static_cast<size_t>(c / 4) * hw + i) * 4 + (c % 4)];
+    }
+    return snnhip_tensor_upload(t, nhwc.data());
+}
+
+int snnhip_tensor_download_c4hw4(const snnhip_tensor* t, float* c4) {
+    SNNHIP_REQUIRE(t && c4, "tensor_download_c4hw4: null argument");
+    std::vector<float> nhwc(t->count());
+    int rc = snnhip_tensor_download(t, nhwc.data());
+    if (rc != SNNHIP_OK) return rc;
+    const size_t hw = static_cast<size_t>(t->h) * t->w;
+    const int planes = up_div(t->c, 4);
+    memset(c4, 0, static_cast<size_t>(t->n) * planes * hw * 4 * sizeof(float));
+    for (int n = 0; n < t->n; ++n) {
+        float* dst = c4 + static_cast<size_t>(n) * planes * hw * 4;
+        const float* src = nhwc.data() + static_cast<size_t>(n) * hw * t->c;
+        for (size_t i = 0; i < hw; ++i)
+            for (int c = 0; c < t->c; ++c) dst[(static_cast<size_t>(c / 4) * hw + i) * 4 + (c % 4)] = src[i * t->c + c];
+    }
+    return SNNHIP_OK;
+}
+
+__global__ void fill_kernel(float* p, size_t n, float v) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = v;
+}
+
+int snnhip_tensor_fill(snnhip_tensor* t, float value) {
+    SNNHIP_REQUIRE(t, "tensor_fill: null argument");
+    size_t n = t->count();
+    unsigned blocks = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 4096));
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, t->data, n, value);
+    SNNHIP_CHECK_HIP(hipGetLastError());
+    return SNNHIP_OK;
+}
+
+/* ---- plans ---- */
+
+static int check_conv_args(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, const float* w, const float* bn_beta, const float* bn_gamma,
+                           const float* bn_mean, const float* bn_var, snnhip_plan** out) {
+    SNNHIP_REQUIRE(ctx && desc && w && out, "plan_create: null argument");
+    if (desc->useBN) SNNHIP_REQUIRE(bn_beta && bn_gamma && bn_mean && bn_var, "plan_create: useBN set but a BN array is null");
+    return SNNHIP_OK;
+}
+
+int snnhip_conv2d_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, const float* w_oihw, const float* bias, const float* bn_beta,
+                              const float* bn_gamma, const float* bn_mean, const float* bn_var, snnhip_plan** out) {
+    int rc = check_conv_args(ctx, desc, w_oihw, bn_beta, bn_gamma, bn_mean, bn_var, out);
+    if (rc != SNNHIP_OK) return rc;
+    ConvGeom g;
+    rc = resolve_conv_geom(desc, false, &g);
+    if (rc != SNNHIP_OK) return rc;
+    SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    std::vector<float> epi = make_epilogue_table(g.OC, 16, desc->useBias, bias, desc->useBN, bn_beta, bn_gamma, bn_mean, bn_var);
+    // GEMM-shaped layers go to the fp32-MFMA implicit GEMM; everything else (and anything it declines) to the
+    // direct VALU kernel.
+    rc = make_conv2d_mfma_plan(ctx, g, w_oihw, epi, out);
+    if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_generic_plan(ctx, g, w_oihw, epi, out);
+    return rc;
+}
+
+int snnhip_depthwise_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, const float* w_chw, const float* bias, const float* bn_beta,
+                                 const float* bn_gamma, const float* bn_mean, const float* bn_var, snnhip_plan** out) {
+    int rc = check_conv_args(ctx, desc, w_chw, bn_beta, bn_gamma, bn_mean, bn_var, out);
+    if (rc != SNNHIP_OK) return rc;
+    ConvGeom g;
+    rc = resolve_conv_geom(desc, true, &g);
+    if (rc != SNNHIP_OK) return rc;
+    SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    // the depthwise shader always reads the bias buffer (vk_depthwise.comp:79); a null pointer means zeros
+    std::vector<float> epi = make_epilogue_table(g.OC, 16, bias != nullptr, bias, desc->useBN, bn_beta, bn_gamma, bn_mean, bn_var);
+    return make_depthwise_plan(ctx, g, w_chw, epi, out);
+}
+
+int snnhip_dense_plan_create(snnhip_ctx* ctx, const snnhip_dense_desc* desc, const float* w_flat, const float* bias, snnhip_plan** out) {
+    SNNHIP_REQUIRE(ctx && desc && w_flat && out, "dense_plan_create: null argument");
+    SNNHIP_REQUIRE(desc->batch > 0 && desc->in_units > 0 && desc->out_units > 0, "dense desc: bad dims batch=%d in=%d out=%d", desc->batch,
+                   desc->in_units, desc->out_units);
+    SNNHIP_REQUIRE(desc->act >= 0 && desc->act <= 6, "dense desc: activation id %d", desc->act);
+    SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    return make_dense_plan(ctx, *desc, w_flat, bias, out);
+}
+
+int snnhip_subpixel_plan_create(snnhip_ctx* ctx, const snnhip_subpixel_desc* desc, snnhip_plan** out) {
+    SNNHIP_REQUIRE(ctx && desc && out, "subpixel_plan_create: null argument");
+    SNNHIP_REQUIRE(desc->N > 0 && desc->H > 0 && desc->W > 0 && desc->C > 0 && desc->factor > 0, "subpixel desc: bad dims");
+    SNNHIP_REQUIRE(desc->mode == SNNHIP_SUBPIXEL_D2S || desc->mode == SNNHIP_SUBPIXEL_VK_QUIRK, "subpixel desc: mode %d", desc->mode);
+    return make_subpixel_plan(ctx, *desc, out);
+}
+
+int snnhip_chain_plan_create(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_plan** out) {
+    SNNHIP_REQUIRE(ctx && plans && out && n > 0, "chain_plan_create: bad argument");
+    for (int i = 0; i < n; ++i) SNNHIP_REQUIRE(plans[i] != nullptr, "chain_plan_create: plan %d is null", i);
+    SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    return make_chain_plan(ctx, plans, n, out);
+}
+
+int snnhip_plan_run_n(snnhip_plan* plan, const snnhip_tensor* const* inputs, int n_in, snnhip_tensor* out) {
+    SNNHIP_REQUIRE(plan && inputs && out && n_in > 0, "plan_run: null argument");
+    for (int i = 0; i < n_in; ++i) SNNHIP_REQUIRE(inputs[i] && inputs[i]->data, "plan_run: input %d is null", i);
+    SNNHIP_REQUIRE(out->data, "plan_run: output has no storage");
+    return plan->run(inputs, n_in, out);
+}
+
+int snnhip_plan_run(snnhip_plan* plan, const snnhip_tensor* in, snnhip_tensor* out) { return snnhip_plan_run_n(plan, &in, 1, out); }
+
+int snnhip_plan_output_dims(const snnhip_plan* plan, int dims[4]) {
+    SNNHIP_REQUIRE(plan && dims, "plan_output_dims: null argument");
+    memcpy(dims, plan->outDims, sizeof(int) * 4);
+    return SNNHIP_OK;
+}
+
+int snnhip_plan_describe(const snnhip_plan* plan, char* buf, size_t buflen) {
+    SNNHIP_REQUIRE(plan && buf && buflen > 0, "plan_describe: null argument");
+    snprintf(buf, buflen, "%s", plan->desc.c_str());
+    return SNNHIP_OK;
+}
+
+int snnhip_plan_cost(const snnhip_plan* plan, double* flops, double* bytes) {
+    SNNHIP_REQUIRE(plan, "plan_cost: null argument");
+    if (flops) *flops = plan->flops;
+    if (bytes) *bytes = plan->bytes;
+    return SNNHIP_OK;
+}
+
+int snnhip_plan_destroy(snnhip_plan* plan) {
+    delete plan;
+    return SNNHIP_OK;
+}
+
+/* ---- timers ---- */
+
+int snnhip_timer_create(snnhip_ctx* ctx, snnhip_timer** out) {
+    SNNHIP_REQUIRE(ctx && out, "timer_create: null argument");
+    auto* t = new (std::nothrow) snnhip_timer();
+    if (!t) return SNNHIP_E_NOMEM;
+    t->ctx = ctx;
+    hipError_t e = hipEventCreate(&t->start);
+    if (e == hipSuccess) e = hipEventCreate(&t->stop);
+    if (e != hipSuccess) {
+        if (t->start) (void) hipEventDestroy(t->start);
+        delete t;
+        set_error("hipEventCreate failed: %s", hipGetErrorString(e));
+        return SNNHIP_E_HIP;
+    }
+    *out = t;
+    return SNNHIP_OK;
+}
+
+int snnhip_timer_start(snnhip_timer* t) {
+    SNNHIP_REQUIRE(t, "timer_start: null");
+    SNNHIP_CHECK_HIP(hipEventRecord(t->start, t->ctx->stream));
+    return SNNHIP_OK;
+}
+
+int snnhip_timer_stop(snnhip_timer* t) {
+    SNNHIP_REQUIRE(t, "timer_stop: null");
+    SNNHIP_CHECK_HIP(hipEventRecord(t->stop, t->ctx->stream));
+    return SNNHIP_OK;
+}
+
+int snnhip_timer_elapsed_ms(snnhip_timer* t, float* ms) {
+    SNNHIP_REQUIRE(t && ms, "timer_elapsed: null");
+    SNNHIP_CHECK_HIP(hipEventSynchronize(t->stop));
+    SNNHIP_CHECK_HIP(hipEventElapsedTime(ms, t->start, t->stop));
+    return SNNHIP_OK;
+}
+
+int snnhip_timer_destroy(snnhip_timer* t) {
+    if (!t) return SNNHIP_OK;
+    (void) hipEventDestroy(t->start);
+    (void) hipEventDestroy(t->stop);
+    delete t;
+    return SNNHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,196 @@
+// dense_subpixel.hip -- fully connected layer and the ESPCN depth-to-space tail.
+//
+// dense: replaces the reference's CPU/Eigen path DenseLayer::computeImageTexture -> CPUCommonUtil::transform
+//   (core/src/ic2/denselayer.cpp:27-38, cpulayer.h:136-171) and its GPU twin shadertemplate_vk_dense.comp:53-79.
+//   y[b][o] = act(sum_i W[o*In+i] * x[b][i] + bias[o]).  One wave64 per output row: lanes stride over In with 16-byte
+//   loads, wave-level xor-shuffle reduction, lane 0 applies the epilogue (the reference's shader is 1 thread/output).
+//   Activation semantics follow the CPU path (cpulayer.h:185-261), including softmax over the output row.
+// subpixel: replaces shadertemplate_vk_subpixel.comp:43-71 (depth-to-space(2) + tanh), both the true d2s channel
+//   selection (fs_subpixel.glsl:41-64) and the Vulkan shader's depth-slice quirk.
+#include "snnhip_internal.h"
+
+namespace snnhip {
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void dense_kernel(int In, int Out, int act, float leaky, const float* __restrict__ x,
+                                                    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (o >= Out) return;
+    const float* wr = w + static_cast<size_t>(o) * In;
+    const float* xb = x + static_cast<size_t>(b) * In;
+    float acc = 0.0f;
+    if (VEC) {
+        const float4* w4 = reinterpret_cast<const float4*>(wr);
+        const float4* x4 = reinterpret_cast<const float4*>(xb);
+        for (int i = lane; i < In / 4; i += 64) {
+            const float4 a = w4[i], v = x4[i];
+            acc = fmaf(a.x, v.x, acc);
+            acc = fmaf(a.y, v.y, acc);
+            acc = fmaf(a.z, v.z, acc);
+            acc = fmaf(a.w, v.w, acc);
+        }
+    } else {
+        for (int i = lane; i < In; i += 64) acc = fmaf(wr[i], xb[i], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float v = acc + bias[o];
+        switch (act) {
+        case SNNHIP_DENSE_RELU: v = v > 0 ? v : 0.0f * v; break;            // leakyRelu(val, 0.0) cpulayer.h:187,204
+        case SNNHIP_DENSE_LEAKY: v = v > 0 ? v : leaky * v; break;
+        case SNNHIP_DENSE_SIGMOID: v = 1.0f / (1.0f + expf(-v)); break;
+        case SNNHIP_DENSE_TANH: v = (expf(2 * v) - 1) / (expf(2 * v) + 1); break; // cpulayer.h:195
+        default: break; // identity, SiLU (no-op in the reference), softmax (second kernel)
+        }
+        y[static_cast<size_t>(b) * Out + o] = v;
+    }
+}
+
+// softmax over one output row per block (cpulayer.h:173-189): max, exp(x-max), sum, divide
+__global__ __launch_bounds__(256) void softmax_rows_kernel(int Out, float* __restrict__ y) {
+    __shared__ float red[4];
+    float* row = y + static_cast<size_t>(blockIdx.x) * Out;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float m = -3.402823466e+38f;
+    for (int i = threadIdx.x; i < Out; i += 256) m = fmaxf(m, row[i]);
+    m = wave_max(m);
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < Out; i += 256) {
+        const float e = expf(row[i] - m);
+        row[i] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    for (int i = threadIdx.x; i < Out; i += 256) row[i] = row[i] / s;
+}
+
+struct DensePlan : snnhip_plan {
+    snnhip_dense_desc d;
+    float* d_w = nullptr;
+    float* d_b = nullptr;
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "dense: expects 1 input, got %d", nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == d.batch && static_cast<size_t>(x->h) * x->w * x->c == static_cast<size_t>(d.in_units),
+                       "dense: input %dx%dx%dx%d does not flatten to %d x %d", x->n, x->h, x->w, x->c, d.batch, d.in_units);
+        SNNHIP_REQUIRE(out->count() == static_cast<size_t>(d.batch) * d.out_units, "dense: output has %zu elements, expected %d x %d", out->count(),
+                       d.batch, d.out_units);
+        dim3 grid(up_div(d.out_units, 4), d.batch);
+        const bool vec = (d.in_units % 4) == 0;
+        if (vec) {
+            hipLaunchKernelGGL(dense_kernel<true>, grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.act, d.leaky, x->data, d_w, d_b,
+                               out->data);
+        } else {
+            hipLaunchKernelGGL(dense_kernel<false>, grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.act, d.leaky, x->data, d_w, d_b,
+                               out->data);
+        }
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        if (d.act == SNNHIP_DENSE_SOFTMAX) {
+            hipLaunchKernelGGL(softmax_rows_kernel, dim3(d.batch), dim3(256), 0, ctx->stream, d.out_units, out->data);
+            SNNHIP_CHECK_HIP(hipGetLastError());
+        }
+        return SNNHIP_OK;
+    }
+};
+
+__global__ __launch_bounds__(256) void subpixel_kernel(int N, int H, int W, int C, int f, int mode, const float* __restrict__ x,
+                                                       float* __restrict__ y) {
+    const int OH = H * f, OW = W * f;
+    const size_t total = static_cast<size_t>(N) * OH * OW;
+    const int depth = (C + 3) / 4;
+    for (size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; idx < total; idx += static_cast<size_t>(gridDim.x) * 256) {
+        const int ox = static_cast<int>(idx % OW);
+        const size_t r = idx / OW;
+        const int oy = static_cast<int>(r % OH);
+        const int n = static_cast<int>(r / OH);
+        const int x1 = min(ox / f, W - 1), y1 = min(oy / f, H - 1);
+        const int z1 = (ox % f) + (oy % f) * f;
+        const int ch = (mode == SNNHIP_SUBPIXEL_VK_QUIRK) ? min(z1, depth - 1) * 4 : z1;
+        const float v = ch < C ? x[((static_cast<size_t>(n) * H + y1) * W + x1) * C + ch] : 0.0f;
+        y[idx] = tanhf(v);
+    }
+}
+
+struct SubpixelPlan : SubpixelPlanBase {
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "subpixel: expects 1 input, got %d", nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == d.N && x->h == d.H && x->w == d.W && x->c == d.C, "subpixel: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h,
+                       x->w, x->c, d.N, d.H, d.W, d.C);
+        SNNHIP_REQUIRE(out->n == d.N && out->h == d.H * d.factor && out->w == d.W * d.factor && out->c == 1,
+                       "subpixel: output dims %dx%dx%dx%d != %dx%dx%dx1", out->n, out->h, out->w, out->c, d.N, d.H * d.factor, d.W * d.factor);
+        const size_t total = out->count();
+        size_t blocks = (total + 255) / 256;
+        const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount) * 16;
+        if (blocks > cap) blocks = cap;
+        if (blocks == 0) return SNNHIP_OK;
+        hipLaunchKernelGGL(subpixel_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, d.factor, d.mode,
+                           x->data, out->data);
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+} // namespace
+
+int make_dense_plan(snnhip_ctx* ctx, const snnhip_dense_desc& d, const float* w_flat, const float* bias, snnhip_plan** out) {
+    auto* plan = new DensePlan();
+    plan->ctx = ctx;
+    plan->d = d;
+    std::vector<float> b(static_cast<size_t>(d.out_units), 0.0f);
+    if (d.useBias && bias) b.assign(bias, bias + d.out_units);
+    int rc = plan->upload(w_flat, static_cast<size_t>(d.in_units) * d.out_units, &plan->d_w);
+    if (rc == SNNHIP_OK) rc = plan->upload(b.data(), b.size(), &plan->d_b);
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    plan->inDims[0] = d.batch; plan->inDims[1] = 1; plan->inDims[2] = 1; plan->inDims[3] = d.in_units;
+    plan->outDims[0] = d.batch; plan->outDims[1] = 1; plan->outDims[2] = 1; plan->outDims[3] = d.out_units;
+    plan->flops = 2.0 * d.batch * static_cast<double>(d.in_units) * d.out_units;
+    plan->bytes = 4.0 * (static_cast<double>(d.in_units) * d.out_units + static_cast<double>(d.batch) * (d.in_units + d.out_units) + d.out_units);
+    char buf[160];
+    snprintf(buf, sizeof(buf), "dense_f32 wave-per-row in=%d out=%d batch=%d act=%d", d.in_units, d.out_units, d.batch, d.act);
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+int make_subpixel_plan(snnhip_ctx* ctx, const snnhip_subpixel_desc& d, snnhip_plan** out) {
+    auto* plan = new SubpixelPlan();
+    plan->ctx = ctx;
+    plan->d = d;
+    plan->inDims[0] = d.N; plan->inDims[1] = d.H; plan->inDims[2] = d.W; plan->inDims[3] = d.C;
+    plan->outDims[0] = d.N; plan->outDims[1] = d.H * d.factor; plan->outDims[2] = d.W * d.factor; plan->outDims[3] = 1;
+    plan->flops = 0;
+    plan->bytes = 4.0 * (static_cast<double>(d.N) * d.H * d.W * d.C + static_cast<double>(d.N) * d.H * d.W * d.factor * d.factor);
+    char buf[128];
+    snprintf(buf, sizeof(buf), "subpixel_f32 f=%d mode=%d c=%d", d.factor, d.mode, d.C);
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip

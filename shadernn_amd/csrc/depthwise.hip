@@ -1,0 +1,136 @@
+// depthwise.hip -- NHWC fp32 depthwise convolution (the reference's "SeparableConv2D"/"DepthwiseConv2D" layer).
+//
+// Replaces shadertemplate_vk_depthwise.comp:64-137: taps that fall outside the image are skipped (zero padding
+// by clipping, :77-78), bias buffer always added (:79), fused BN (:91-99) and activation (:101-134).
+// HBM-bound: each thread produces 1 pixel x 4 channels with 16-byte channel-contiguous loads/stores; the k*k input
+// re-reads of neighbouring pixels are served by L1/L2 (a row of C<=960 channels is <= 3.8 KB per pixel).
+#include "epilogue.h"
+#include "snnhip_internal.h"
+
+namespace snnhip {
+namespace {
+
+struct DwParams {
+    int N, H, W, C, kh, kw, sh, sw, padx, pady, act, useBN, OH, OW;
+    float leaky;
+    int C4; // ceil(C/4)
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void depthwise_kernel(DwParams p, const float* __restrict__ x, const float* __restrict__ wpk,
+                                                        const float4* __restrict__ epi, float* __restrict__ y) {
+    const size_t total = static_cast<size_t>(p.N) * p.OH * p.OW * p.C4;
+    for (size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; idx < total; idx += static_cast<size_t>(gridDim.x) * 256) {
+        const int cq = static_cast<int>(idx % p.C4);
+        size_t px = idx / p.C4;
+        const int ox = static_cast<int>(px % p.OW);
+        px /= p.OW;
+        const int oy = static_cast<int>(px % p.OH);
+        const int n = static_cast<int>(px / p.OH);
+        const int s0x = ox * p.sw - p.padx, s0y = oy * p.sh - p.pady;
+        const int sfx = max(0, -s0x), sfy = max(0, -s0y);
+        const int efx = min(p.kw, p.W - s0x), efy = min(p.kh, p.H - s0y);
+        const int c0 = cq * 4;
+        float acc[4] = {0, 0, 0, 0};
+        const float* xn = x + static_cast<size_t>(n) * p.H * p.W * p.C;
+        for (int fy = sfy; fy < efy; ++fy) {
+            for (int fx = sfx; fx < efx; ++fx) {
+                const float* xp = xn + (static_cast<size_t>(s0y + fy) * p.W + (s0x + fx)) * p.C + c0;
+                const float4 w = *reinterpret_cast<const float4*>(wpk + (static_cast<size_t>(fy) * p.kw + fx) * p.C4 * 4 + c0);
+                if (VEC) {
+                    const float4 v = *reinterpret_cast<const float4*>(xp);
+                    acc[0] = fmaf(v.x, w.x, acc[0]);
+                    acc[1] = fmaf(v.y, w.y, acc[1]);
+                    acc[2] = fmaf(v.z, w.z, acc[2]);
+                    acc[3] = fmaf(v.w, w.w, acc[3]);
+                } else {
+                    const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (c0 + b < p.C) acc[b] = fmaf(xp[b], wv[b], acc[b]);
+                }
+            }
+        }
+        float o[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float4 e = epi[c0 + b];
+            float v = epi_affine(acc[b], e, p.useBN);
+            o[b] = epi_act(p.act == SNNHIP_ACT_SILU_QUIRK ? SNNHIP_ACT_SILU : p.act, p.leaky, v, v);
+        }
+        float* yo = y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox) * p.C + c0;
+        if (VEC) {
+            *reinterpret_cast<float4*>(yo) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (c0 + b < p.C) yo[b] = o[b];
+        }
+    }
+}
+
+struct DepthwisePlan : ConvPlanBase {
+    DwParams p;
+    float* d_w = nullptr;
+    float* d_epi = nullptr;
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "depthwise: expects 1 input, got %d", nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == p.N && x->h == p.H && x->w == p.W && x->c == p.C, "depthwise: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n,
+                       x->h, x->w, x->c, p.N, p.H, p.W, p.C);
+        SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.C, "depthwise: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
+                       out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.C);
+        const size_t total = static_cast<size_t>(p.N) * p.OH * p.OW * p.C4;
+        size_t blocks = (total + 255) / 256;
+        const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount) * 16;
+        if (blocks > cap) blocks = cap;
+        if (blocks == 0) return SNNHIP_OK;
+        const bool vec = (p.C % 4) == 0;
+        if (vec) {
+            hipLaunchKernelGGL(depthwise_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, p, x->data, d_w,
+                               reinterpret_cast<const float4*>(d_epi), out->data);
+        } else {
+            hipLaunchKernelGGL(depthwise_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, p, x->data, d_w,
+                               reinterpret_cast<const float4*>(d_epi), out->data);
+        }
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+} // namespace
+
+int make_depthwise_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_chw, const std::vector<float>& epi4, snnhip_plan** out) {
+    auto* plan = new DepthwisePlan();
+    plan->ctx = ctx;
+    plan->g = g;
+    plan->depthwise = true;
+    const int C = g.OC, taps = g.kh * g.kw;
+    plan->w_oihw.assign(w_chw, w_chw + static_cast<size_t>(C) * taps);
+    plan->epi4 = epi4;
+    DwParams& p = plan->p;
+    p.N = g.N; p.H = g.H; p.W = g.W; p.C = C; p.kh = g.kh; p.kw = g.kw; p.sh = g.sh; p.sw = g.sw; p.padx = g.padx; p.pady = g.pady;
+    p.act = g.act; p.useBN = g.useBN; p.OH = g.OH; p.OW = g.OW; p.leaky = g.leaky; p.C4 = up_div(C, 4);
+    // pack [fy][fx][C4*4] -- the same order SeparableConv2DLayer::oihw2hwo4i4 produces (separableconvolution.cpp:88-111)
+    std::vector<float> wpk(static_cast<size_t>(taps) * p.C4 * 4, 0.0f);
+    for (int c = 0; c < C; ++c)
+        for (int t = 0; t < taps; ++t) wpk[static_cast<size_t>(t) * p.C4 * 4 + c] = w_chw[static_cast<size_t>(c) * taps + t];
+    int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
+    if (rc == SNNHIP_OK) rc = plan->upload(epi4.data(), epi4.size(), &plan->d_epi);
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    plan->inDims[0] = g.N; plan->inDims[1] = g.H; plan->inDims[2] = g.W; plan->inDims[3] = C;
+    plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = C;
+    plan->flops = 2.0 * taps * C * static_cast<double>(g.OH) * g.OW * g.N;
+    plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * C + static_cast<double>(g.N) * g.OH * g.OW * C + static_cast<double>(C) * taps);
+    char buf[200];
+    snprintf(buf, sizeof(buf), "depthwise_f32 k=%dx%d s=%d c=%d %s", g.kh, g.kw, g.sh, C, (C % 4) == 0 ? "vec4" : "scalar");
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip

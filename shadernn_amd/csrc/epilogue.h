@@ -1,0 +1,42 @@
+// epilogue.h -- fused bias -> batch-norm -> activation epilogue shared by the conv kernels (device code).
+// Restates shadertemplate_vk_conv2d.comp:276-340 of the reference for fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/snnhip.h"
+
+namespace snnhip {
+
+// epi = {bias, bnScale, bnMean, bnBeta} for this output channel; acc excludes the bias.
+__device__ __forceinline__ float epi_affine(float acc, const float4& epi, int useBN) {
+    float v = acc + epi.x;
+    if (useBN) v = (epi.y * (v - epi.z)) + epi.w;
+    return v;
+}
+
+// `first` = post-activation value of pixel 0 of the aligned 4-pixel x group, used only by SILU_QUIRK for the other
+// three pixels (the reference overwrites color1 before re-using it: vk_conv2d.comp:336-339).
+__device__ __forceinline__ float epi_act(int act, float leaky, float v, float first) {
+    switch (act) {
+    case SNNHIP_ACT_RELU: return fmaxf(v, 0.0f);
+    case SNNHIP_ACT_RELU6: return fminf(fmaxf(v, 0.0f), 6.0f);
+    case SNNHIP_ACT_TANH: return tanhf(v);
+    case SNNHIP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case SNNHIP_ACT_LEAKY: return fmaxf(v, v * leaky);
+    case SNNHIP_ACT_SILU: return v * 1.0f / (1.0f + expf(-v));
+    case SNNHIP_ACT_SILU_QUIRK: return v * 1.0f / (1.0f + expf(-first));
+    default: return v;
+    }
+}
+
+// coordinate resolution of vk_conv2d.comp:168-218; returns -1 when the fetch yields 0
+__device__ __forceinline__ int resolve_coord(int s, int size, int padMode) {
+    if (padMode == SNNHIP_PAD_REPLICATE) return min(max(s, 0), size - 1);
+    if (padMode == SNNHIP_PAD_REFLECT) {
+        s = s < 0 ? -s : s;
+        s = s >= size ? 2 * size - 2 - s : s;
+    }
+    return (s >= 0 && s < size) ? s : -1;
+}
+
+} // namespace snnhip

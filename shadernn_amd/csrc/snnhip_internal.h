@@ -1,0 +1,129 @@
+// snnhip_internal.h -- shared declarations of the HIP operator library behind include/snnhip.h.
+// gfx950 (MI355X) only: wave64, 160 KiB LDS/CU, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/snnhip.h"
+
+namespace snnhip {
+
+void set_error(const char* fmt, ...);
+
+#define SNNHIP_CHECK_HIP(expr)                                                                         \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            ::snnhip::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SNNHIP_E_HIP;                                                                       \
+        }                                                                                              \
+    } while (0)
+
+#define SNNHIP_REQUIRE(cond, ...)              \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::snnhip::set_error(__VA_ARGS__);  \
+            return SNNHIP_E_INVALID;           \
+        }                                      \
+    } while (0)
+
+inline int up_div(int x, int y) { return (x + y - 1) / y; }
+inline int round_up(int x, int y) { return up_div(x, y) * y; }
+
+// Conv2DLayer::getOutputScaleDimAdjustment + GenericModelLayer::getOutputDims restated (reference
+// core/src/ic2/conv2d.cpp:102-113, genericlayer.cpp:64-90): float arithmetic, truncating conversion.
+inline int conv_out_dim(int in, int kernel, int stride, int padA, int padB) {
+    float scale = 1 / static_cast<float>(stride);
+    float translation = (kernel % 2 != 0)
+                            ? 1 + (static_cast<float>(static_cast<unsigned>(padA + padB)) - static_cast<float>(kernel)) / static_cast<float>(stride)
+                            : 1 + (static_cast<float>(static_cast<unsigned>(padA + padB - 1)) - static_cast<float>(kernel)) / static_cast<float>(stride);
+    float s = scale * static_cast<float>(in);
+    if (s < 0.0f) s = 0.0f;
+    float t = translation < 0.0f ? 0.0f : translation;
+    return static_cast<int>(static_cast<unsigned>(s + t));
+}
+
+} // namespace snnhip
+
+struct snnhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownsStream = false;
+    hipDeviceProp_t props;
+};
+
+struct snnhip_tensor {
+    snnhip_ctx* ctx = nullptr;
+    float* data = nullptr;
+    bool owns = false;
+    int n = 0, h = 0, w = 0, c = 0;
+    size_t count() const { return static_cast<size_t>(n) * h * w * c; }
+};
+
+struct snnhip_timer {
+    snnhip_ctx* ctx = nullptr;
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+// One executable operator: device-resident parameters + a launch recipe (the reference's InferencePass +
+// RenderPass rolled into one object: core/src/ic2/inferencepass.h:31-62, vulkanRenderpass.cpp:103-260).
+struct snnhip_plan {
+    snnhip_ctx* ctx = nullptr;
+    int inDims[4] = {0, 0, 0, 0};   // N,H,W,C of input 0
+    int outDims[4] = {0, 0, 0, 0};
+    int numInputs = 1;
+    std::string desc;
+    double flops = 0, bytes = 0;
+    std::vector<void*> deviceAllocs; // freed in the destructor
+
+    virtual ~snnhip_plan() {
+        for (void* p : deviceAllocs) (void) hipFree(p);
+    }
+    virtual int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) = 0;
+
+    // uploads host floats into a fresh device buffer owned by the plan
+    int upload(const float* host, size_t count, float** dev);
+};
+
+namespace snnhip {
+
+// Per-output-channel epilogue parameters {bias, bnScale, bnMean, bnBeta}; bnScale = gamma / max(sqrt(var+1e-3), 1e-4)
+// (reference shadertemplate_vk_conv2d.comp:277-288).  Padded with zeros to `padTo` channels.
+std::vector<float> make_epilogue_table(int OC, int padTo, int useBias, const float* bias, int useBN, const float* beta,
+                                       const float* gamma, const float* mean, const float* var);
+
+struct ConvGeom {
+    int N, H, W, IC, OC, kh, kw, sh, sw;
+    int padx, pady; // already resolved: 1x1 => 0 (vk_conv2d_1x1.comp:74-75); else padT / padL (conv2dVulkan.cpp:183-184)
+    int padMode, act, useBN;
+    float leaky;
+    int OH, OW;
+};
+int resolve_conv_geom(const snnhip_conv2d_desc* d, bool depthwise, ConvGeom* g);
+
+// factories implemented in the .hip translation units
+int make_conv2d_generic_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out);
+int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out);
+int make_depthwise_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_chw, const std::vector<float>& epi4, snnhip_plan** out);
+int make_dense_plan(snnhip_ctx* ctx, const snnhip_dense_desc& d, const float* w_flat, const float* bias, snnhip_plan** out);
+int make_subpixel_plan(snnhip_ctx* ctx, const snnhip_subpixel_desc& d, snnhip_plan** out);
+int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_plan** out);
+
+// Conv plans keep their host-side description so that chain fusion can re-pack weights.
+struct ConvPlanBase : snnhip_plan {
+    ConvGeom g;
+    std::vector<float> w_oihw; // host copy
+    std::vector<float> epi4;   // host copy of the epilogue table, padded to a multiple of 16
+    bool depthwise = false;
+};
+struct SubpixelPlanBase : snnhip_plan {
+    snnhip_subpixel_desc d;
+};
+
+} // namespace snnhip

@@ -1,0 +1,228 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU checker.  Test infrastructure: imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_DENSE = os.path.join(ORACLE_DIR, "_ref", "ref_dense")
+
+ACT = {"": 0, "linear": 0, "none": 0, "relu": 1, "relu6": 2, "tanh": 3, "sigmoid": 4, "leakyRelu": 5, "SiLU": 6, "SiLU_quirk": 7}
+PAD_MODE = {"none": 0, "constant": 1, "replicate": 2, "reflect": 3}
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "IC", "OC", "kh", "kw", "sh", "sw", "padT", "padB", "padL", "padR", "padMode", "act")] + [
+        ("leaky", C.c_float), ("useBias", C.c_int), ("useBN", C.c_int), ("OH", C.c_int), ("OW", C.c_int)]
+
+
+_FP = C.POINTER(C.c_float)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"])
+        l = C.CDLL(LIB)
+        l.snn_oracle_out_dim.restype = C.c_int
+        l.snn_oracle_out_dim.argtypes = [C.c_int] * 5
+        l.snn_oracle_padding_offsets.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int * 4)]
+        l.snn_oracle_to_medium_precision.restype = C.c_float
+        l.snn_oracle_to_medium_precision.argtypes = [C.c_float]
+        l.snn_oracle_random_float.restype = C.c_float
+        l.snn_oracle_random_float.argtypes = [C.c_float, C.c_float]
+        l.snn_oracle_srand.argtypes = [C.c_uint64]
+        l.snn_oracle_dense_act_from_string.restype = C.c_int
+        l.snn_oracle_dense_act_from_string.argtypes = [C.c_char_p]
+        _lib = l
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_FP)
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def padding_offsets(padding, kernel):
+    o = (C.c_int * 4)()
+    lib().snn_oracle_padding_offsets(padding.encode(), kernel, C.byref(o))
+    return tuple(o)
+
+
+def out_dim(n, k, s, pa, pb):
+    return lib().snn_oracle_out_dim(n, k, s, pa, pb)
+
+
+def make_desc(N, H, W, IC, OC, k, stride, pads, pad_mode="constant", act="", leaky=0.0, use_bias=True, use_bn=False):
+    d = ConvDesc()
+    d.N, d.H, d.W, d.IC, d.OC = N, H, W, IC, OC
+    d.kh = d.kw = k
+    d.sh = d.sw = stride
+    d.padT, d.padB, d.padL, d.padR = pads
+    d.padMode = PAD_MODE[pad_mode] if isinstance(pad_mode, str) else pad_mode
+    d.act = ACT[act] if isinstance(act, str) else act
+    d.leaky = leaky
+    d.useBias, d.useBN = int(use_bias), int(use_bn)
+    d.OH = out_dim(H, k, stride, pads[0], pads[1])
+    d.OW = out_dim(W, k, stride, pads[0], pads[1])
+    return d
+
+
+def conv2d(x, w_oihw, bias=None, stride=1, pads=None, pad_mode="constant", act="", leaky=0.0, bn=None, threads=1):
+    """NHWC walk. x [N,H,W,IC], w [OC,IC,k,k]."""
+    x, w = _f(x), _f(w_oihw)
+    N, H, W, IC = x.shape
+    OC, _, k, _ = w.shape
+    if pads is None:
+        pads = padding_offsets("same", k)
+    d = make_desc(N, H, W, IC, OC, k, stride, pads, pad_mode, act, leaky, bias is not None, bn is not None)
+    y = np.empty((N, d.OH, d.OW, OC), dtype=np.float32)
+    b = _f(bias)
+    bnp = [None] * 4 if bn is None else [_f(bn[q]) for q in ("beta", "gamma", "mean", "var")]
+    lib().snn_oracle_conv2d_nhwc_mt(C.byref(d), _p(x), _p(w), _p(b), _p(bnp[0]), _p(bnp[1]), _p(bnp[2]), _p(bnp[3]), _p(y), C.c_int(threads))
+    return y
+
+
+def _pad4(a, n4):
+    out = np.zeros(n4, dtype=np.float32)
+    if a is not None:
+        out[: len(a)] = a
+    return out
+
+
+def conv2d_texel(x, w_oihw, bias=None, stride=1, pads=None, pad_mode="constant", act="", leaky=0.0, bn=None):
+    """C4HW4 walk in GLSL loop order, batch 1; returns NHWC for comparison."""
+    x, w = _f(x), _f(w_oihw)
+    N, H, W, IC = x.shape
+    assert N == 1
+    OC, _, k, _ = w.shape
+    if pads is None:
+        pads = padding_offsets("same", k)
+    d = make_desc(1, H, W, IC, OC, k, stride, pads, pad_mode, act, leaky, True, bn is not None)
+    ic4, oc4 = (IC + 3) // 4 * 4, (OC + 3) // 4 * 4
+    xc4 = np.empty((ic4 // 4, H, W, 4), dtype=np.float32)
+    lib().snn_oracle_hwc_to_c4hw4(_p(x), H, W, IC, _p(xc4))
+    wp = np.empty(oc4 * k * k * ic4, dtype=np.float32)
+    lib().snn_oracle_pack_conv_weights(_p(w), IC, OC, k, k, _p(wp))
+    b4 = _pad4(_f(bias), oc4)
+    bn4 = [_pad4(None if bn is None else _f(bn[q]), oc4) for q in ("beta", "gamma", "mean", "var")]
+    yc4 = np.zeros((oc4 // 4, d.OH, d.OW, 4), dtype=np.float32)
+    lib().snn_oracle_conv2d_texel(C.byref(d), _p(xc4), _p(wp), _p(b4), _p(bn4[0]), _p(bn4[1]), _p(bn4[2]), _p(bn4[3]), _p(yc4))
+    y = np.empty((1, d.OH, d.OW, OC), dtype=np.float32)
+    lib().snn_oracle_c4hw4_to_hwc(_p(yc4), d.OH, d.OW, OC, _p(y))
+    return y
+
+
+def depthwise(x, w_chw, bias=None, stride=1, pads=None, act="", leaky=0.0, bn=None):
+    x, w = _f(x), _f(w_chw)
+    N, H, W, Cc = x.shape
+    _, k, _ = w.shape
+    if pads is None:
+        pads = padding_offsets("same", k)
+    d = make_desc(N, H, W, Cc, Cc, k, stride, pads, "constant", act, leaky, True, bn is not None)
+    y = np.empty((N, d.OH, d.OW, Cc), dtype=np.float32)
+    b = _f(bias)
+    bnp = [None] * 4 if bn is None else [_f(bn[q]) for q in ("beta", "gamma", "mean", "var")]
+    lib().snn_oracle_depthwise_nhwc(C.byref(d), _p(x), _p(w), _p(b), _p(bnp[0]), _p(bnp[1]), _p(bnp[2]), _p(bnp[3]), _p(y))
+    return y
+
+
+def depthwise_texel(x, w_chw, bias=None, stride=1, pads=None, act="", leaky=0.0, bn=None):
+    x, w = _f(x), _f(w_chw)
+    N, H, W, Cc = x.shape
+    assert N == 1
+    _, k, _ = w.shape
+    if pads is None:
+        pads = padding_offsets("same", k)
+    d = make_desc(1, H, W, Cc, Cc, k, stride, pads, "constant", act, leaky, True, bn is not None)
+    c4 = (Cc + 3) // 4 * 4
+    xc4 = np.empty((c4 // 4, H, W, 4), dtype=np.float32)
+    lib().snn_oracle_hwc_to_c4hw4(_p(x), H, W, Cc, _p(xc4))
+    wp = np.empty(c4 * k * k, dtype=np.float32)
+    lib().snn_oracle_pack_depthwise_weights(_p(w), Cc, k, k, _p(wp))
+    b4 = _pad4(_f(bias), c4)
+    bn4 = [_pad4(None if bn is None else _f(bn[q]), c4) for q in ("beta", "gamma", "mean", "var")]
+    yc4 = np.zeros((c4 // 4, d.OH, d.OW, 4), dtype=np.float32)
+    lib().snn_oracle_depthwise_texel(C.byref(d), _p(xc4), _p(wp), _p(b4), _p(bn4[0]), _p(bn4[1]), _p(bn4[2]), _p(bn4[3]), _p(yc4))
+    y = np.empty((1, d.OH, d.OW, Cc), dtype=np.float32)
+    lib().snn_oracle_c4hw4_to_hwc(_p(yc4), d.OH, d.OW, Cc, _p(y))
+    return y
+
+
+def dense(x, w_flat, out_units, bias=None, act="", leaky=0.0):
+    """x [batch, In] (or any [batch, ...] flattened HWC); activation mapped like CPUCommonUtil (unknown -> relu)."""
+    x = _f(x)
+    batch = x.shape[0]
+    x2 = x.reshape(batch, -1)
+    In = x2.shape[1]
+    w = _f(w_flat).reshape(-1)
+    assert w.size == In * out_units
+    a = lib().snn_oracle_dense_act_from_string(act.encode()) if isinstance(act, str) else act
+    y = np.empty((batch, out_units), dtype=np.float32)
+    b = _f(bias)
+    lib().snn_oracle_dense(_p(x2), batch, In, out_units, _p(w), _p(b), a, C.c_float(leaky), _p(y))
+    return y
+
+
+def subpixel(x, factor=2, mode=0):
+    x = _f(x)
+    N, H, W, Cc = x.shape
+    y = np.empty((N, H * factor, W * factor, 1), dtype=np.float32)
+    lib().snn_oracle_subpixel_nhwc(_p(x), N, H, W, Cc, factor, mode, _p(y))
+    return y
+
+
+def to_medium_precision(v):
+    return lib().snn_oracle_to_medium_precision(C.c_float(v))
+
+
+def reference_rand(seed, count, a=-1.2, b=1.2):
+    """The reference tests' generator: SRAND(seed) then RandomFloat(a, b) x count (demo/common/testutil.cpp:41-46)."""
+    lib().snn_oracle_srand(seed)
+    return np.array([lib().snn_oracle_random_float(a, b) for _ in range(count)], dtype=np.float32)
+
+
+def ref_dense(In, Out, act, alpha, w_flat, bias, x):
+    """Runs the REFERENCE's own Eigen dense path (oracle/_ref/ref_dense, built from /root/reference)."""
+    if not os.path.exists(REF_DENSE):
+        return None
+    txt = "%d %d %s %r\n" % (In, Out, act if act else "-", float(alpha))
+    txt += " ".join("%.9g" % v for v in np.asarray(w_flat, dtype=np.float32).reshape(-1)) + "\n"
+    txt += " ".join("%.9g" % v for v in np.asarray(bias, dtype=np.float32)) + "\n"
+    txt += " ".join("%.9g" % v for v in np.asarray(x, dtype=np.float32).reshape(-1)) + "\n"
+    out = subprocess.run([REF_DENSE], input=txt, stdout=subprocess.PIPE, text=True, check=True).stdout
+    return np.array([float(t) for t in out.split()], dtype=np.float32)
+
+
+def forward(net, x, threads=1, return_layers=False):
+    """Runs a models.py chain net on the oracle."""
+    outs = []
+    for l in net["layers"]:
+        t = l["type"]
+        if t == "Conv2D":
+            pads = padding_offsets(l["padding"], l["kernel"])
+            x = conv2d(x, l["w"], l["b"], l["stride"], pads, l.get("pad_mode", "constant"), l["activation"], l.get("alpha", 0.0), l["bn"], threads)
+        elif t == "DepthwiseConv2D":
+            pads = padding_offsets(l["padding"], l["kernel"])
+            x = depthwise(x, l["w"], l["b"], l["stride"], pads, l["activation"], l.get("alpha", 0.0), l["bn"])
+        elif t == "Dense":
+            x = dense(x, l["w"], l["units"], l["b"], l["activation"]).reshape(x.shape[0], 1, 1, -1)
+        elif t == "Subpixel":
+            x = subpixel(x, 2, l.get("mode", 0))
+        else:
+            raise ValueError(t)
+        outs.append(x)
+    return (x, outs) if return_layers else x
+
+
+def espcn_forward(net, x, threads=1):
+    return forward(net, x, threads)

@@ -2,8 +2,4 @@
 #include "snnhip_internal.h"
 namespace snnhip {
 int make_conv2d_mfma_plan(snnhip_ctx*, const ConvGeom&, const float*, const std::vector<float>&, snnhip_plan**) { return SNNHIP_E_UNSUPPORTED; }
-int make_chain_plan(snnhip_ctx*, snnhip_plan* const*, int, snnhip_plan**) {
-    set_error("chain fusion: no rule matches");
-    return SNNHIP_E_UNSUPPORTED;
-}
 } // namespace snnhip

@@ -1,0 +1,420 @@
+// espcn_fused.hip -- chain fusion for the ESPCN-shaped part of the hot path (BASELINE config 2), fp32.
+//
+// The reference runs one compute dispatch + one full barrier per layer (core/src/ic2/vulkanRenderpass.cpp:257-259)
+// and round-trips every intermediate through a texture.  Here a linear chain of plans is rewritten into two kernels:
+//
+//   kernel A  conv KxK (IC=1 -> 16, K in {3,5}) + act  ->  conv 3x3 (16 -> 16) + act       [fp32 MFMA, LDS-resident mid tensor]
+//             replaces two passes of shadertemplate_vk_conv2d.comp:148-347
+//   kernel B  conv 3x3 (16 -> 4) + act  ->  depth-to-space(2) + tanh                         [VALU, HBM-bound]
+//             replaces shadertemplate_vk_conv2d.comp + shadertemplate_vk_subpixel.comp:43-71
+//
+// Kernel A, per 64x8 output tile (256 threads = 4 waves, 46 KB LDS, 3 blocks/CU):
+//   phase 0  input halo tile (70x14, 1 channel) -> LDS, zero outside the image (constant padding)
+//   phase 1  conv1 on the 66x10 halo region as a GEMM  D[oc][px] = W1[oc][tap] * im2col[tap][px]  with
+//            v_mfma_f32_16x16x4_f32 (K = 25 taps padded to 28), bias/BN/act fused, zeroed outside the image (it is
+//            conv2's zero padding), written to LDS as [row][col][16ch] with a 16-byte-slot XOR swizzle
+//   phase 2  conv2 as 9 taps x 4 MFMAs per 16-pixel group: B operand = one ds_read_b128 (4 input channels of one
+//            pixel), A operand = weights held in 36 VGPRs for the whole kernel; 8 groups (=accumulators) per wave
+//   epilogue bias/BN/act, 16-byte stores: one wave store = 16 pixels x 64 B contiguous NHWC
+// fp32 MFMA is bit-for-bit an fp32 fma chain (no reduced precision), so the 1e-4 parity bound holds as for VALU code.
+#include "epilogue.h"
+#include "snnhip_internal.h"
+
+namespace snnhip {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_plain(int act, float leaky, float v) { return epi_act(act, leaky, v, v); }
+
+struct FusedAParams {
+    int N, H, W, tilesX, tilesY;
+    int act1, act2;
+    float leaky1, leaky2;
+};
+
+// K1 = first conv's kernel size (3 or 5), pad = K1/2.  TW multiple of 16, TH multiple of 4.
+template <int K1, int TW, int TH>
+__global__ __launch_bounds__(256) void conv_kxk_c1o16_conv3x3_c16o16_kernel(FusedAParams p, const float* __restrict__ x,
+                                                                            const float* __restrict__ wA1, const float* __restrict__ wA2,
+                                                                            const float* __restrict__ ep1, const float* __restrict__ ep2,
+                                                                            float* __restrict__ y) {
+    constexpr int P1 = K1 / 2;
+    constexpr int C1W = TW + 2, C1H = TH + 2;                 // conv1 output region needed by conv2 (halo 1)
+    constexpr int INW = TW + 2 + 2 * P1, INH = TH + 2 + 2 * P1; // input region needed by conv1 on that region
+    constexpr int KS1 = (K1 * K1 + 3) / 4;                    // MFMA K-steps of conv1
+    constexpr int NG1 = (C1H * C1W + 15) / 16;                // 16-pixel groups of phase 1
+    constexpr int GPR = TW / 16;                              // groups per output row
+    constexpr int RPW = TH / 4;                               // output rows per wave
+    constexpr int G = GPR * RPW;                              // groups (= accumulators) per wave in phase 2
+
+    __shared__ __attribute__((aligned(16))) float smem[C1H * C1W * 16 + INH * INW];
+    float* s_c1 = smem;
+    float* s_in = smem + C1H * C1W * 16;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int px = lane & 15, g = lane >> 4;
+
+    int b = blockIdx.x;
+    const int tx = b % p.tilesX;
+    b /= p.tilesX;
+    const int ty = b % p.tilesY;
+    const int n = b / p.tilesY;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const float* xn = x + static_cast<size_t>(n) * p.H * p.W;
+
+    // ---- phase 0: input tile (origin y0-1-P1, x0-1-P1), zero padded
+    for (int idx = tid; idx < INH * INW; idx += 256) {
+        const int r = idx / INW, c = idx - r * INW;
+        const int gy = y0 - 1 - P1 + r, gx = x0 - 1 - P1 + c;
+        float v = 0.0f;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = xn[static_cast<size_t>(gy) * p.W + gx];
+        s_in[idx] = v;
+    }
+
+    // ---- weights -> registers (host packed them in lane order)
+    float a1[KS1];
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) a1[s] = wA1[s * 64 + lane];
+    float a2[36];
+#pragma unroll
+    for (int t = 0; t < 36; ++t) a2[t] = wA2[t * 64 + lane];
+    float sc1[4], sh1[4], sc2[4], sh2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sc1[r] = ep1[(4 * g + r) * 2];
+        sh1[r] = ep1[(4 * g + r) * 2 + 1];
+        sc2[r] = ep2[(4 * g + r) * 2];
+        sh2[r] = ep2[(4 * g + r) * 2 + 1];
+    }
+    // this lane's tap offsets for conv1: K-step s covers taps 4s..4s+3, lane group g supplies tap 4s+g
+    int off1[KS1];
+    bool tapok[KS1];
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+        int t = 4 * s + g;
+        tapok[s] = t < K1 * K1;
+        if (!tapok[s]) t = K1 * K1 - 1;
+        off1[s] = (t / K1) * INW + (t % K1);
+    }
+    __syncthreads();
+
+    // ---- phase 1: conv1 over the C1H x C1W halo region, pixels flattened into 16-wide groups
+    for (int grp = wv; grp < NG1; grp += 4) {
+        const int pi = grp * 16 + px;
+        const bool valid = pi < C1H * C1W;
+        const int pc = valid ? pi : C1H * C1W - 1;
+        const int r = pc / C1W, c = pc - r * C1W;
+        const float* src = s_in + r * INW + c;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            float bv = src[off1[s]];
+            if (!tapok[s]) bv = 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bv, acc, 0, 0, 0);
+        }
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        float4 o;
+        o.x = inside ? act_plain(p.act1, p.leaky1, fmaf(acc[0], sc1[0], sh1[0])) : 0.0f;
+        o.y = inside ? act_plain(p.act1, p.leaky1, fmaf(acc[1], sc1[1], sh1[1])) : 0.0f;
+        o.z = inside ? act_plain(p.act1, p.leaky1, fmaf(acc[2], sc1[2], sh1[2])) : 0.0f;
+        o.w = inside ? act_plain(p.act1, p.leaky1, fmaf(acc[3], sc1[3], sh1[3])) : 0.0f;
+        if (valid) {
+            const int slot = g ^ (((c >> 2) & 1) << 1); // conflict-free ds_read_b128 in phase 2 for every tap shift
+            *reinterpret_cast<float4*>(s_c1 + (r * C1W + c) * 16 + slot * 4) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: conv2, G accumulators per wave
+    f32x4 acc2[G];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) acc2[gi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int fy = tap / 3, fx = tap % 3;
+        float4 bv[G];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const int row = wv * RPW + gi / GPR, col0 = (gi % GPR) * 16;
+            const int cc = col0 + px + fx;
+            const int slot = g ^ (((cc >> 2) & 1) << 1);
+            bv[gi] = *reinterpret_cast<const float4*>(s_c1 + ((row + fy) * C1W + cc) * 16 + slot * 4);
+        }
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) acc2[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tap * 4 + 0], bv[gi].x, acc2[gi], 0, 0, 0);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) acc2[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tap * 4 + 1], bv[gi].y, acc2[gi], 0, 0, 0);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) acc2[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tap * 4 + 2], bv[gi].z, acc2[gi], 0, 0, 0);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) acc2[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tap * 4 + 3], bv[gi].w, acc2[gi], 0, 0, 0);
+    }
+
+    // ---- epilogue: lane holds output channels 4g..4g+3 of pixel (row, col0+px)
+    float* yn = y + static_cast<size_t>(n) * p.H * p.W * 16;
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        const int gy = y0 + wv * RPW + gi / GPR, gx = x0 + (gi % GPR) * 16 + px;
+        if (gy < p.H && gx < p.W) {
+            float4 o;
+            o.x = act_plain(p.act2, p.leaky2, fmaf(acc2[gi][0], sc2[0], sh2[0]));
+            o.y = act_plain(p.act2, p.leaky2, fmaf(acc2[gi][1], sc2[1], sh2[1]));
+            o.z = act_plain(p.act2, p.leaky2, fmaf(acc2[gi][2], sc2[2], sh2[2]));
+            o.w = act_plain(p.act2, p.leaky2, fmaf(acc2[gi][3], sc2[3], sh2[3]));
+            *reinterpret_cast<float4*>(yn + (static_cast<size_t>(gy) * p.W + gx) * 16 + g * 4) = o;
+        }
+    }
+}
+
+struct FusedBParams {
+    int N, H, W, tilesX, tilesY;
+    int act;
+    float leaky;
+};
+
+// conv 3x3 (16 -> 4, zero padding 1) + act, then depth-to-space(2) + tanh.  One thread = one input-resolution pixel
+// = a 2x2 block of the output image.  LDS tile [TH+2][TW+2] pixels at a 20-float pitch (conflict-free b128 reads
+// for 64 consecutive pixels); weights are wave-uniform => scalar loads, FMAs take them as SGPR operands.
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ w,
+                                                                     const float* __restrict__ ep, float* __restrict__ y) {
+    constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 20;
+    static_assert(TW * TH == 256, "one thread per pixel");
+    __shared__ __attribute__((aligned(16))) float s_x[THH * TWH * PITCH];
+
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % p.tilesX;
+    b /= p.tilesX;
+    const int ty = b % p.tilesY;
+    const int n = b / p.tilesY;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
+
+    for (int idx = tid; idx < THH * TWH * 4; idx += 256) {
+        const int q = idx & 3, pix = idx >> 2;
+        const int r = pix / TWH, c = pix - r * TWH;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
+        *reinterpret_cast<float4*>(s_x + pix * PITCH + q * 4) = v;
+    }
+    __syncthreads();
+
+    const int c = tid % TW, r = tid / TW;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // one tap (64 uniform weights = 64 SGPRs) per iteration: unrolling further only spills SGPRs
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int fy = tap / 3, fx = tap - fy * 3;
+        const float* src = s_x + ((r + fy) * TWH + c + fx) * PITCH;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 xv = *reinterpret_cast<const float4*>(src + q * 4);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* wr = w + (tap * 16 + q * 4 + i) * 4; // uniform address -> s_load
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = fmaf(xs[i], wr[o], acc[o]);
+            }
+        }
+    }
+    const int gy = y0 + r, gx = x0 + c;
+    if (gy < p.H && gx < p.W) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = tanhf(act_plain(p.act, p.leaky, fmaf(acc[k], ep[2 * k], ep[2 * k + 1])));
+        float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
+        // channel 2*dy+dx -> output pixel (2y+dy, 2x+dx)  (depth_to_space, fs_subpixel.glsl:41-64)
+        *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
+        *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
+    }
+}
+
+// (scale, shift) per channel so that epilogue = act(acc*scale + shift):  scale = bnScale, shift = bnScale*(bias-mean)+beta
+std::vector<float> fold_epilogue(const std::vector<float>& epi4, int OC, int useBN) {
+    std::vector<float> out(static_cast<size_t>(OC) * 2);
+    for (int o = 0; o < OC; ++o) {
+        const float bias = epi4[o * 4 + 0], sc = epi4[o * 4 + 1], mean = epi4[o * 4 + 2], beta = epi4[o * 4 + 3];
+        out[o * 2 + 0] = useBN ? sc : 1.0f;
+        out[o * 2 + 1] = useBN ? sc * (bias - mean) + beta : bias;
+    }
+    return out;
+}
+
+bool plain_act(int act) { return act >= 0 && act <= SNNHIP_ACT_SILU; }
+
+bool is_same_conv(const ConvGeom& g, int k, int ic, int oc) {
+    return g.kh == k && g.kw == k && g.IC == ic && g.OC == oc && g.sh == 1 && g.sw == 1 && g.padx == k / 2 && g.pady == k / 2 &&
+           (g.padMode == SNNHIP_PAD_CONSTANT || g.padMode == SNNHIP_PAD_NONE) && g.OH == g.H && g.OW == g.W && plain_act(g.act);
+}
+
+constexpr int A_TW = 64, A_TH = 8;
+constexpr int B_TW = 32, B_TH = 8;
+
+struct ChainPlan : snnhip_plan {
+    enum Kind { PLAIN, FUSED_A, FUSED_B };
+    struct Step {
+        Kind kind = PLAIN;
+        snnhip_plan* plain = nullptr; // borrowed
+        FusedAParams a{};
+        FusedBParams b{};
+        int k1 = 5;
+        float *w1 = nullptr, *w2 = nullptr, *e1 = nullptr, *e2 = nullptr;
+        int outDims[4] = {0, 0, 0, 0};
+        std::string desc;
+    };
+    std::vector<Step> steps;
+    std::vector<snnhip_tensor*> mids; // owned intermediates between steps
+
+    ~ChainPlan() override {
+        for (auto* t : mids) snnhip_tensor_free(t);
+    }
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "chain: expects 1 input, got %d", nIn);
+        const snnhip_tensor* src = in[0];
+        SNNHIP_REQUIRE(src->n == inDims[0] && src->h == inDims[1] && src->w == inDims[2] && src->c == inDims[3],
+                       "chain: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", src->n, src->h, src->w, src->c, inDims[0], inDims[1], inDims[2], inDims[3]);
+        SNNHIP_REQUIRE(out->n == outDims[0] && out->h == outDims[1] && out->w == outDims[2] && out->c == outDims[3],
+                       "chain: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, outDims[0], outDims[1], outDims[2],
+                       outDims[3]);
+        for (size_t i = 0; i < steps.size(); ++i) {
+            Step& s = steps[i];
+            snnhip_tensor* dst = (i + 1 == steps.size()) ? out : mids[i];
+            if (s.kind == PLAIN) {
+                int rc = s.plain->run(&src, 1, dst);
+                if (rc != SNNHIP_OK) return rc;
+            } else if (s.kind == FUSED_A) {
+                dim3 grid(s.a.tilesX * s.a.tilesY * s.a.N);
+                if (s.k1 == 5) {
+                    hipLaunchKernelGGL((conv_kxk_c1o16_conv3x3_c16o16_kernel<5, A_TW, A_TH>), grid, dim3(256), 0, ctx->stream, s.a, src->data, s.w1, s.w2,
+                                       s.e1, s.e2, dst->data);
+                } else {
+                    hipLaunchKernelGGL((conv_kxk_c1o16_conv3x3_c16o16_kernel<3, A_TW, A_TH>), grid, dim3(256), 0, ctx->stream, s.a, src->data, s.w1, s.w2,
+                                       s.e1, s.e2, dst->data);
+                }
+                SNNHIP_CHECK_HIP(hipGetLastError());
+            } else {
+                dim3 grid(s.b.tilesX * s.b.tilesY * s.b.N);
+                hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_kernel<B_TW, B_TH>), grid, dim3(256), 0, ctx->stream, s.b, src->data, s.w1, s.e1, dst->data);
+                SNNHIP_CHECK_HIP(hipGetLastError());
+            }
+            src = dst;
+        }
+        return SNNHIP_OK;
+    }
+};
+
+} // namespace
+
+int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_plan** out) {
+    auto* chain = new ChainPlan();
+    chain->ctx = ctx;
+    memcpy(chain->inDims, plans[0]->inDims, sizeof(chain->inDims));
+    memcpy(chain->outDims, plans[n - 1]->outDims, sizeof(chain->outDims));
+    int fusedCount = 0;
+    int rc = SNNHIP_OK;
+    for (int i = 0; i < n && rc == SNNHIP_OK;) {
+        ChainPlan::Step st;
+        auto* c0 = dynamic_cast<ConvPlanBase*>(plans[i]);
+        auto* c1 = (i + 1 < n) ? dynamic_cast<ConvPlanBase*>(plans[i + 1]) : nullptr;
+        auto* sp1 = (i + 1 < n) ? dynamic_cast<SubpixelPlanBase*>(plans[i + 1]) : nullptr;
+        // the chain must be shape-consistent
+        if (i + 1 < n && memcmp(plans[i]->outDims, plans[i + 1]->inDims, sizeof(int) * 4) != 0) {
+            set_error("chain: plan %d output %dx%dx%dx%d does not feed plan %d input %dx%dx%dx%d", i, plans[i]->outDims[0], plans[i]->outDims[1],
+                      plans[i]->outDims[2], plans[i]->outDims[3], i + 1, plans[i + 1]->inDims[0], plans[i + 1]->inDims[1], plans[i + 1]->inDims[2],
+                      plans[i + 1]->inDims[3]);
+            rc = SNNHIP_E_INVALID;
+            break;
+        }
+        if (c0 && c1 && !c0->depthwise && !c1->depthwise && (is_same_conv(c0->g, 5, 1, 16) || is_same_conv(c0->g, 3, 1, 16)) &&
+            is_same_conv(c1->g, 3, 16, 16)) {
+            // ---- rule A
+            const ConvGeom& g0 = c0->g;
+            const int K1 = g0.kh, taps1 = K1 * K1, ks1 = (taps1 + 3) / 4;
+            st.kind = ChainPlan::FUSED_A;
+            st.k1 = K1;
+            st.a = FusedAParams{g0.N, g0.H, g0.W, up_div(g0.W, A_TW), up_div(g0.H, A_TH), g0.act, c1->g.act, g0.leaky, c1->g.leaky};
+            std::vector<float> wA1(static_cast<size_t>(ks1) * 64, 0.0f), wA2(36 * 64);
+            for (int s = 0; s < ks1; ++s)
+                for (int l = 0; l < 64; ++l) {
+                    const int oc = l & 15, t = 4 * s + (l >> 4);
+                    if (t < taps1) wA1[s * 64 + l] = c0->w_oihw[static_cast<size_t>(oc) * taps1 + t];
+                }
+            for (int tap = 0; tap < 9; ++tap)
+                for (int j = 0; j < 4; ++j)
+                    for (int l = 0; l < 64; ++l) {
+                        const int oc = l & 15, ic = 4 * (l >> 4) + j;
+                        wA2[(tap * 4 + j) * 64 + l] = c1->w_oihw[(static_cast<size_t>(oc) * 16 + ic) * 9 + tap];
+                    }
+            std::vector<float> e1 = fold_epilogue(c0->epi4, 16, g0.useBN), e2 = fold_epilogue(c1->epi4, 16, c1->g.useBN);
+            rc = chain->upload(wA1.data(), wA1.size(), &st.w1);
+            if (rc == SNNHIP_OK) rc = chain->upload(wA2.data(), wA2.size(), &st.w2);
+            if (rc == SNNHIP_OK) rc = chain->upload(e1.data(), e1.size(), &st.e1);
+            if (rc == SNNHIP_OK) rc = chain->upload(e2.data(), e2.size(), &st.e2);
+            memcpy(st.outDims, c1->outDims, sizeof(st.outDims));
+            char buf[200];
+            snprintf(buf, sizeof(buf), "fused[conv%dx%d(1->16)+conv3x3(16->16)] mfma_f32_16x16x4 tile=%dx%d", K1, K1, A_TW, A_TH);
+            st.desc = buf;
+            i += 2;
+            ++fusedCount;
+        } else if (c0 && sp1 && !c0->depthwise && is_same_conv(c0->g, 3, 16, 4) && sp1->d.factor == 2 && sp1->d.mode == SNNHIP_SUBPIXEL_D2S &&
+                   sp1->d.C == 4) {
+            // ---- rule B
+            const ConvGeom& g0 = c0->g;
+            st.kind = ChainPlan::FUSED_B;
+            st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, B_TW), up_div(g0.H, B_TH), g0.act, g0.leaky};
+            std::vector<float> wB(9 * 16 * 4);
+            for (int tap = 0; tap < 9; ++tap)
+                for (int ic = 0; ic < 16; ++ic)
+                    for (int o = 0; o < 4; ++o) wB[(tap * 16 + ic) * 4 + o] = c0->w_oihw[(static_cast<size_t>(o) * 16 + ic) * 9 + tap];
+            std::vector<float> e1 = fold_epilogue(c0->epi4, 4, g0.useBN);
+            rc = chain->upload(wB.data(), wB.size(), &st.w1);
+            if (rc == SNNHIP_OK) rc = chain->upload(e1.data(), e1.size(), &st.e1);
+            memcpy(st.outDims, sp1->outDims, sizeof(st.outDims));
+            char buf[200];
+            snprintf(buf, sizeof(buf), "fused[conv3x3(16->4)+depth_to_space(2)+tanh] valu_f32 tile=%dx%d", B_TW, B_TH);
+            st.desc = buf;
+            i += 2;
+            ++fusedCount;
+        } else {
+            st.kind = ChainPlan::PLAIN;
+            st.plain = plans[i];
+            memcpy(st.outDims, plans[i]->outDims, sizeof(st.outDims));
+            st.desc = plans[i]->desc;
+            i += 1;
+        }
+        chain->steps.push_back(st);
+    }
+    if (rc == SNNHIP_OK && fusedCount == 0) {
+        set_error("chain fusion: no rule matches these %d plans", n);
+        rc = SNNHIP_E_UNSUPPORTED;
+    }
+    for (size_t i = 0; rc == SNNHIP_OK && i + 1 < chain->steps.size(); ++i) {
+        snnhip_tensor* t = nullptr;
+        const int* d = chain->steps[i].outDims;
+        rc = snnhip_tensor_alloc(ctx, d[0], d[1], d[2], d[3], SNNHIP_F32, &t);
+        if (rc == SNNHIP_OK) chain->mids.push_back(t);
+    }
+    if (rc != SNNHIP_OK) {
+        delete chain;
+        return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        chain->flops += plans[i]->flops;
+        chain->bytes += plans[i]->bytes;
+    }
+    std::string d = "chain{";
+    for (size_t i = 0; i < chain->steps.size(); ++i) d += (i ? " -> " : "") + chain->steps[i].desc;
+    chain->desc = d + "}";
+    *out = chain;
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip

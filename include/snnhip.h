@@ -177,6 +177,16 @@ int snnhip_plan_describe(const snnhip_plan* plan, char* buf, size_t buflen);
 int snnhip_plan_cost(const snnhip_plan* plan, double* flops, double* bytes);
 int snnhip_plan_destroy(snnhip_plan* plan);
 
+/* A plan executes as one or more kernel launches ("steps": 1 for plain operators, one per fused kernel for chains).
+ * With profiling enabled every launch is bracketed by a hipEvent pair on the context stream (the analogue of the
+ * reference's per-stage DeviceTimer, core/src/ic2/core.cpp:140-153).  snnhip_plan_profile_read waits for the
+ * recorded events, returns the summed duration and launch count of step `step` since the last read, and resets. */
+int snnhip_plan_num_steps(const snnhip_plan* plan);
+int snnhip_plan_step_describe(const snnhip_plan* plan, int step, char* buf, size_t buflen);
+int snnhip_plan_step_cost(const snnhip_plan* plan, int step, double* flops, double* bytes);
+int snnhip_plan_profile_enable(snnhip_plan* plan, int enable);
+int snnhip_plan_profile_read(snnhip_plan* plan, int step, double* total_ms, int* launches);
+
 /* ---- device timers (hipEvent pairs on the context stream) ---------------------------------------- */
 
 int snnhip_timer_create(snnhip_ctx* ctx, snnhip_timer** out);

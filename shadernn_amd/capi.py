@@ -78,6 +78,11 @@ SIGNATURES = {
     "snnhip_plan_describe": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "snnhip_plan_cost": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "snnhip_plan_destroy": (C.c_int, [_P]),
+    "snnhip_plan_num_steps": (C.c_int, [_P]),
+    "snnhip_plan_step_describe": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t]),
+    "snnhip_plan_step_cost": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "snnhip_plan_profile_enable": (C.c_int, [_P, C.c_int]),
+    "snnhip_plan_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "snnhip_timer_create": (C.c_int, [_P, C.POINTER(_P)]),
     "snnhip_timer_start": (C.c_int, [_P]),
     "snnhip_timer_stop": (C.c_int, [_P]),
@@ -247,6 +252,28 @@ class Plan:
             y = Tensor(self.ctx, *self.out_shape())
         self.run(x, y)
         return y
+
+    def num_steps(self):
+        return lib().snnhip_plan_num_steps(self.h)
+
+    def step_describe(self, i):
+        buf = C.create_string_buffer(512)
+        check(lib().snnhip_plan_step_describe(self.h, i, buf, 512))
+        return buf.value.decode()
+
+    def step_cost(self, i):
+        f, b = C.c_double(), C.c_double()
+        check(lib().snnhip_plan_step_cost(self.h, i, C.byref(f), C.byref(b)))
+        return f.value, b.value
+
+    def profile(self, enable=True):
+        check(lib().snnhip_plan_profile_enable(self.h, int(enable)))
+
+    def profile_read(self, i):
+        """(total_ms, launches) of step i since the last read."""
+        ms, n = C.c_double(), C.c_int()
+        check(lib().snnhip_plan_profile_read(self.h, i, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def destroy(self):
         if self.h:

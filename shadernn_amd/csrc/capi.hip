@@ -71,6 +71,28 @@ int snnhip_plan::upload(const float* host, size_t count, float** dev) {
     return SNNHIP_OK;
 }
 
+int snnhip_plan::profBegin(int step) {
+    if (stepEvents.size() < static_cast<size_t>(numSteps())) {
+        stepEvents.resize(numSteps());
+        stepUsed.resize(numSteps(), 0);
+    }
+    auto& pool = stepEvents[step];
+    if (stepUsed[step] == pool.size()) {
+        EventPair e;
+        SNNHIP_CHECK_HIP(hipEventCreate(&e.start));
+        SNNHIP_CHECK_HIP(hipEventCreate(&e.stop));
+        pool.push_back(e);
+    }
+    SNNHIP_CHECK_HIP(hipEventRecord(pool[stepUsed[step]].start, ctx->stream));
+    return SNNHIP_OK;
+}
+
+int snnhip_plan::profEnd(int step) {
+    SNNHIP_CHECK_HIP(hipEventRecord(stepEvents[step][stepUsed[step]].stop, ctx->stream));
+    ++stepUsed[step];
+    return SNNHIP_OK;
+}
+
 using namespace snnhip;
 
 extern "C" {
@@ -315,7 +337,54 @@ int snnhip_plan_run_n(snnhip_plan* plan, const snnhip_tensor* const* inputs, int
     SNNHIP_REQUIRE(plan && inputs && out && n_in > 0, "plan_run: null argument");
     for (int i = 0; i < n_in; ++i) SNNHIP_REQUIRE(inputs[i] && inputs[i]->data, "plan_run: input %d is null", i);
     SNNHIP_REQUIRE(out->data, "plan_run: output has no storage");
+    if (plan->profiling && !plan->profilesItself()) {
+        int rc = plan->profBegin(0);
+        if (rc != SNNHIP_OK) return rc;
+        rc = plan->run(inputs, n_in, out);
+        if (rc != SNNHIP_OK) return rc;
+        return plan->profEnd(0);
+    }
     return plan->run(inputs, n_in, out);
+}
+
+int snnhip_plan_num_steps(const snnhip_plan* plan) { return plan ? plan->numSteps() : 0; }
+
+int snnhip_plan_step_describe(const snnhip_plan* plan, int step, char* buf, size_t buflen) {
+    SNNHIP_REQUIRE(plan && buf && buflen > 0 && step >= 0 && step < plan->numSteps(), "plan_step_describe: bad argument");
+    snprintf(buf, buflen, "%s", plan->stepDesc(step).c_str());
+    return SNNHIP_OK;
+}
+
+int snnhip_plan_step_cost(const snnhip_plan* plan, int step, double* flops, double* bytes) {
+    SNNHIP_REQUIRE(plan && step >= 0 && step < plan->numSteps(), "plan_step_cost: bad argument");
+    double f = 0, b = 0;
+    plan->stepCost(step, &f, &b);
+    if (flops) *flops = f;
+    if (bytes) *bytes = b;
+    return SNNHIP_OK;
+}
+
+int snnhip_plan_profile_enable(snnhip_plan* plan, int enable) {
+    SNNHIP_REQUIRE(plan, "plan_profile_enable: null plan");
+    plan->profiling = enable != 0;
+    return SNNHIP_OK;
+}
+
+int snnhip_plan_profile_read(snnhip_plan* plan, int step, double* total_ms, int* launches) {
+    SNNHIP_REQUIRE(plan && total_ms && launches && step >= 0 && step < plan->numSteps(), "plan_profile_read: bad argument");
+    *total_ms = 0;
+    *launches = 0;
+    if (plan->stepEvents.size() <= static_cast<size_t>(step)) return SNNHIP_OK;
+    for (size_t i = 0; i < plan->stepUsed[step]; ++i) {
+        auto& e = plan->stepEvents[step][i];
+        SNNHIP_CHECK_HIP(hipEventSynchronize(e.stop));
+        float ms = 0;
+        SNNHIP_CHECK_HIP(hipEventElapsedTime(&ms, e.start, e.stop));
+        *total_ms += ms;
+        ++*launches;
+    }
+    plan->stepUsed[step] = 0;
+    return SNNHIP_OK;
 }
 
 int snnhip_plan_run(snnhip_plan* plan, const snnhip_tensor* in, snnhip_tensor* out) { return snnhip_plan_run_n(plan, &in, 1, out); }

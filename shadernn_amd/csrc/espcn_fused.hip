@@ -268,6 +268,7 @@ struct ChainPlan : snnhip_plan {
         float *w1 = nullptr, *w2 = nullptr, *e1 = nullptr, *e2 = nullptr;
         int outDims[4] = {0, 0, 0, 0};
         std::string desc;
+        double flops = 0, bytes = 0; // algorithmic work of this launch (fused steps: inputs once + outputs once + weights)
     };
     std::vector<Step> steps;
     std::vector<snnhip_tensor*> mids; // owned intermediates between steps
@@ -275,6 +276,13 @@ struct ChainPlan : snnhip_plan {
     ~ChainPlan() override {
         for (auto* t : mids) snnhip_tensor_free(t);
     }
+    int numSteps() const override { return static_cast<int>(steps.size()); }
+    std::string stepDesc(int i) const override { return steps[i].desc; }
+    void stepCost(int i, double* f, double* b) const override {
+        *f = steps[i].flops;
+        *b = steps[i].bytes;
+    }
+    bool profilesItself() const override { return true; }
 
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "chain: expects 1 input, got %d", nIn);
@@ -287,6 +295,10 @@ struct ChainPlan : snnhip_plan {
         for (size_t i = 0; i < steps.size(); ++i) {
             Step& s = steps[i];
             snnhip_tensor* dst = (i + 1 == steps.size()) ? out : mids[i];
+            if (profiling) {
+                int rc = profBegin(static_cast<int>(i));
+                if (rc != SNNHIP_OK) return rc;
+            }
             if (s.kind == PLAIN) {
                 int rc = s.plain->run(&src, 1, dst);
                 if (rc != SNNHIP_OK) return rc;
@@ -304,6 +316,10 @@ struct ChainPlan : snnhip_plan {
                 dim3 grid(s.b.tilesX * s.b.tilesY * s.b.N);
                 hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_kernel<B_TW, B_TH>), grid, dim3(256), 0, ctx->stream, s.b, src->data, s.w1, s.e1, dst->data);
                 SNNHIP_CHECK_HIP(hipGetLastError());
+            }
+            if (profiling) {
+                int rc = profEnd(static_cast<int>(i));
+                if (rc != SNNHIP_OK) return rc;
             }
             src = dst;
         }
@@ -362,6 +378,8 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             char buf[200];
             snprintf(buf, sizeof(buf), "fused[conv%dx%d(1->16)+conv3x3(16->16)] mfma_f32_16x16x4 tile=%dx%d", K1, K1, A_TW, A_TH);
             st.desc = buf;
+            st.flops = c0->flops + c1->flops;
+            st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (1 + 16) + 16.0 * taps1 + 16.0 * 16 * 9);
             i += 2;
             ++fusedCount;
         } else if (c0 && sp1 && !c0->depthwise && is_same_conv(c0->g, 3, 16, 4) && sp1->d.factor == 2 && sp1->d.mode == SNNHIP_SUBPIXEL_D2S &&
@@ -381,6 +399,8 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             char buf[200];
             snprintf(buf, sizeof(buf), "fused[conv3x3(16->4)+depth_to_space(2)+tanh] valu_f32 tile=%dx%d", B_TW, B_TH);
             st.desc = buf;
+            st.flops = c0->flops;
+            st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);
             i += 2;
             ++fusedCount;
         } else {
@@ -388,6 +408,8 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.plain = plans[i];
             memcpy(st.outDims, plans[i]->outDims, sizeof(st.outDims));
             st.desc = plans[i]->desc;
+            st.flops = plans[i]->flops;
+            st.bytes = plans[i]->bytes;
             i += 1;
         }
         chain->steps.push_back(st);

@@ -82,10 +82,33 @@ struct snnhip_plan {
     double flops = 0, bytes = 0;
     std::vector<void*> deviceAllocs; // freed in the destructor
 
+    // per-launch profiling (hipEvent pairs on ctx->stream), see snnhip_plan_profile_enable
+    bool profiling = false;
+    struct EventPair {
+        hipEvent_t start, stop;
+    };
+    std::vector<std::vector<EventPair>> stepEvents; // [step][launch]
+    std::vector<size_t> stepUsed;                   // pairs recorded since the last read
+
     virtual ~snnhip_plan() {
         for (void* p : deviceAllocs) (void) hipFree(p);
+        for (auto& v : stepEvents)
+            for (auto& e : v) {
+                (void) hipEventDestroy(e.start);
+                (void) hipEventDestroy(e.stop);
+            }
     }
     virtual int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) = 0;
+    virtual int numSteps() const { return 1; }
+    virtual std::string stepDesc(int) const { return desc; }
+    virtual void stepCost(int, double* f, double* b) const {
+        *f = flops;
+        *b = bytes;
+    }
+    // true when run() brackets its own launches (chains); otherwise snnhip_plan_run_n brackets the single launch
+    virtual bool profilesItself() const { return false; }
+    int profBegin(int step); // records the start event of a fresh pair
+    int profEnd(int step);
 
     // uploads host floats into a fresh device buffer owned by the plan
     int upload(const float* host, size_t count, float** dev);

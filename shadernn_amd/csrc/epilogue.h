@@ -29,6 +29,36 @@ __device__ __forceinline__ float epi_act(int act, float leaky, float v, float fi
     }
 }
 
+// The cheap activation family {none, relu, relu6, leakyRelu} as ONE branch-free expression
+//     y = med3(max(v, v*alpha), lo, hi)
+// none: (1,-inf,+inf)  relu: (1,0,+inf)  relu6: (1,0,6)  leaky: (alpha,-inf,+inf) == the shader's max(c, c*alpha).
+// Kernels are instantiated twice: SIMPLE (this, 3 VALU ops, no branches in the hot loops -- a run-time switch costs
+// ~16 taken branches per 16-pixel group and made the fused ESPCN kernel 2x slower) and generic (epi_act switch).
+struct ActCfg {
+    int act;
+    float leaky;
+    float alpha, lo, hi;
+};
+
+inline bool act_is_simple(int act) { return act == SNNHIP_ACT_NONE || act == SNNHIP_ACT_RELU || act == SNNHIP_ACT_RELU6 || act == SNNHIP_ACT_LEAKY; }
+
+inline ActCfg make_act_cfg(int act, float leaky) {
+    ActCfg a{act, leaky, 1.0f, -__builtin_huge_valf(), __builtin_huge_valf()};
+    if (act == SNNHIP_ACT_RELU) a.lo = 0.0f;
+    if (act == SNNHIP_ACT_RELU6) {
+        a.lo = 0.0f;
+        a.hi = 6.0f;
+    }
+    if (act == SNNHIP_ACT_LEAKY) a.alpha = leaky;
+    return a;
+}
+
+template <bool SIMPLE>
+__device__ __forceinline__ float apply_act(const ActCfg& a, float v, float first) {
+    if (SIMPLE) return __builtin_amdgcn_fmed3f(fmaxf(v, v * a.alpha), a.lo, a.hi);
+    return epi_act(a.act, a.leaky, v, first);
+}
+
 // coordinate resolution of vk_conv2d.comp:168-218; returns -1 when the fetch yields 0
 __device__ __forceinline__ int resolve_coord(int s, int size, int padMode) {
     if (padMode == SNNHIP_PAD_REPLICATE) return min(max(s, 0), size - 1);

@@ -8,7 +8,7 @@
 //   kernel B  conv 3x3 (16 -> 4) + act  ->  depth-to-space(2) + tanh                         [VALU, HBM-bound]
 //             replaces shadertemplate_vk_conv2d.comp + shadertemplate_vk_subpixel.comp:43-71
 //
-// Kernel A, per 64x8 output tile (256 threads = 4 waves, 46 KB LDS, 3 blocks/CU):
+// Kernel A, per 64x8 output tile (256 threads = 4 waves, 46 KB LDS, 3 blocks/CU = __launch_bounds__(256, 3)):
 //   phase 0  input halo tile (70x14, 1 channel) -> LDS, zero outside the image (constant padding)
 //   phase 1  conv1 on the 66x10 halo region as a GEMM  D[oc][px] = W1[oc][tap] * im2col[tap][px]  with
 //            v_mfma_f32_16x16x4_f32 (K = 25 taps padded to 28), bias/BN/act fused, zeroed outside the image (it is
@@ -20,22 +20,24 @@
 #include "epilogue.h"
 #include "snnhip_internal.h"
 
+// developer hook: tools/tune_espcn.hip defines SNNHIP_STAMP(k) to record s_memtime per wave and phase
+#ifndef SNNHIP_STAMP
+#define SNNHIP_STAMP(k)
+#endif
+
 namespace snnhip {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float act_plain(int act, float leaky, float v) { return epi_act(act, leaky, v, v); }
-
 struct FusedAParams {
     int N, H, W, tilesX, tilesY;
-    int act1, act2;
-    float leaky1, leaky2;
+    ActCfg act1, act2;
 };
 
 // K1 = first conv's kernel size (3 or 5), pad = K1/2.  TW multiple of 16, TH multiple of 4.
-template <int K1, int TW, int TH>
-__global__ __launch_bounds__(256) void conv_kxk_c1o16_conv3x3_c16o16_kernel(FusedAParams p, const float* __restrict__ x,
+template <int K1, int TW, int TH, bool SIMPLE, int U = 3, int WPS = 3>
+__global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_conv3x3_c16o16_kernel(FusedAParams p, const float* __restrict__ x,
                                                                             const float* __restrict__ wA1, const float* __restrict__ wA2,
                                                                             const float* __restrict__ ep1, const float* __restrict__ ep2,
                                                                             float* __restrict__ y) {
@@ -64,13 +66,22 @@ __global__ __launch_bounds__(256) void conv_kxk_c1o16_conv3x3_c16o16_kernel(Fuse
     const int x0 = tx * TW, y0 = ty * TH;
     const float* xn = x + static_cast<size_t>(n) * p.H * p.W;
 
+    SNNHIP_STAMP(0);
     // ---- phase 0: input tile (origin y0-1-P1, x0-1-P1), zero padded
-    for (int idx = tid; idx < INH * INW; idx += 256) {
-        const int r = idx / INW, c = idx - r * INW;
-        const int gy = y0 - 1 - P1 + r, gx = x0 - 1 - P1 + c;
-        float v = 0.0f;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = xn[static_cast<size_t>(gy) * p.W + gx];
-        s_in[idx] = v;
+    {
+        constexpr int NLD = (INH * INW + 255) / 256;
+        float v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { // all loads in flight before the first use
+            const int idx = tid + k * 256;
+            const int r = idx / INW, c = idx - r * INW;
+            const int gy = y0 - 1 - P1 + r, gx = x0 - 1 - P1 + c;
+            v[k] = 0.0f;
+            if (idx < INH * INW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v[k] = xn[static_cast<size_t>(gy) * p.W + gx];
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (tid + k * 256 < INH * INW) s_in[tid + k * 256] = v[k];
     }
 
     // ---- weights -> registers (host packed them in lane order)
@@ -98,35 +109,57 @@ __global__ __launch_bounds__(256) void conv_kxk_c1o16_conv3x3_c16o16_kernel(Fuse
         if (!tapok[s]) t = K1 * K1 - 1;
         off1[s] = (t / K1) * INW + (t % K1);
     }
+    SNNHIP_STAMP(1);
     __syncthreads();
+    SNNHIP_STAMP(2);
 
-    // ---- phase 1: conv1 over the C1H x C1W halo region, pixels flattened into 16-wide groups
-    for (int grp = wv; grp < NG1; grp += 4) {
-        const int pi = grp * 16 + px;
-        const bool valid = pi < C1H * C1W;
-        const int pc = valid ? pi : C1H * C1W - 1;
-        const int r = pc / C1W, c = pc - r * C1W;
-        const float* src = s_in + r * INW + c;
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    // ---- phase 1: conv1 over the C1H x C1W halo region, pixels flattened into 16-wide groups.
+    // U groups per iteration = U independent MFMA accumulation chains (one chain alone is bound by the 40-cycle
+    // dependent-accumulator latency of v_mfma_f32_16x16x4_f32).
+    for (int grp0 = wv * U; grp0 < NG1; grp0 += 4 * U) {
+        f32x4 acc[U];
+        const float* src[U];
+        int rr[U], cc[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pi = (grp0 + u) * 16 + px;
+            valid[u] = pi < C1H * C1W;
+            const int pc = valid[u] ? pi : C1H * C1W - 1;
+            rr[u] = pc / C1W;
+            cc[u] = pc - rr[u] * C1W;
+            src[u] = s_in + rr[u] * INW + cc[u];
+            acc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
 #pragma unroll
         for (int s = 0; s < KS1; ++s) {
-            float bv = src[off1[s]];
-            if (!tapok[s]) bv = 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bv, acc, 0, 0, 0);
+            float bv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                bv[u] = src[u][off1[s]];
+                if (!tapok[s]) bv[u] = 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bv[u], acc[u], 0, 0, 0);
         }
-        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-        const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        float4 o;
-        o.x = inside ? act_plain(p.act1, p.leaky1, fmaf(acc[0], sc1[0], sh1[0])) : 0.0f;
-        o.y = inside ? act_plain(p.act1, p.leaky1, fmaf(acc[1], sc1[1], sh1[1])) : 0.0f;
-        o.z = inside ? act_plain(p.act1, p.leaky1, fmaf(acc[2], sc1[2], sh1[2])) : 0.0f;
-        o.w = inside ? act_plain(p.act1, p.leaky1, fmaf(acc[3], sc1[3], sh1[3])) : 0.0f;
-        if (valid) {
-            const int slot = g ^ (((c >> 2) & 1) << 1); // conflict-free ds_read_b128 in phase 2 for every tap shift
-            *reinterpret_cast<float4*>(s_c1 + (r * C1W + c) * 16 + slot * 4) = o;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int gy = y0 - 1 + rr[u], gx = x0 - 1 + cc[u];
+            const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            float4 o;
+            o.x = inside ? apply_act<SIMPLE>(p.act1, fmaf(acc[u][0], sc1[0], sh1[0]), 0.0f) : 0.0f;
+            o.y = inside ? apply_act<SIMPLE>(p.act1, fmaf(acc[u][1], sc1[1], sh1[1]), 0.0f) : 0.0f;
+            o.z = inside ? apply_act<SIMPLE>(p.act1, fmaf(acc[u][2], sc1[2], sh1[2]), 0.0f) : 0.0f;
+            o.w = inside ? apply_act<SIMPLE>(p.act1, fmaf(acc[u][3], sc1[3], sh1[3]), 0.0f) : 0.0f;
+            if (valid[u]) {
+                const int slot = g ^ (((cc[u] >> 2) & 1) << 1); // conflict-free ds_read_b128 in phase 2 for every tap shift
+                *reinterpret_cast<float4*>(s_c1 + (rr[u] * C1W + cc[u]) * 16 + slot * 4) = o;
+            }
         }
     }
+    SNNHIP_STAMP(3);
     __syncthreads();
+    SNNHIP_STAMP(4);
 
     // ---- phase 2: conv2, G accumulators per wave
     f32x4 acc2[G];
@@ -154,6 +187,7 @@ __global__ __launch_bounds__(256) void conv_kxk_c1o16_conv3x3_c16o16_kernel(Fuse
         for (int gi = 0; gi < G; ++gi) acc2[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tap * 4 + 3], bv[gi].w, acc2[gi], 0, 0, 0);
     }
 
+    SNNHIP_STAMP(5);
     // ---- epilogue: lane holds output channels 4g..4g+3 of pixel (row, col0+px)
     float* yn = y + static_cast<size_t>(n) * p.H * p.W * 16;
 #pragma unroll
@@ -161,25 +195,25 @@ __global__ __launch_bounds__(256) void conv_kxk_c1o16_conv3x3_c16o16_kernel(Fuse
         const int gy = y0 + wv * RPW + gi / GPR, gx = x0 + (gi % GPR) * 16 + px;
         if (gy < p.H && gx < p.W) {
             float4 o;
-            o.x = act_plain(p.act2, p.leaky2, fmaf(acc2[gi][0], sc2[0], sh2[0]));
-            o.y = act_plain(p.act2, p.leaky2, fmaf(acc2[gi][1], sc2[1], sh2[1]));
-            o.z = act_plain(p.act2, p.leaky2, fmaf(acc2[gi][2], sc2[2], sh2[2]));
-            o.w = act_plain(p.act2, p.leaky2, fmaf(acc2[gi][3], sc2[3], sh2[3]));
+            o.x = apply_act<SIMPLE>(p.act2, fmaf(acc2[gi][0], sc2[0], sh2[0]), 0.0f);
+            o.y = apply_act<SIMPLE>(p.act2, fmaf(acc2[gi][1], sc2[1], sh2[1]), 0.0f);
+            o.z = apply_act<SIMPLE>(p.act2, fmaf(acc2[gi][2], sc2[2], sh2[2]), 0.0f);
+            o.w = apply_act<SIMPLE>(p.act2, fmaf(acc2[gi][3], sc2[3], sh2[3]), 0.0f);
             *reinterpret_cast<float4*>(yn + (static_cast<size_t>(gy) * p.W + gx) * 16 + g * 4) = o;
         }
     }
+    SNNHIP_STAMP(6);
 }
 
 struct FusedBParams {
     int N, H, W, tilesX, tilesY;
-    int act;
-    float leaky;
+    ActCfg act;
 };
 
 // conv 3x3 (16 -> 4, zero padding 1) + act, then depth-to-space(2) + tanh.  One thread = one input-resolution pixel
 // = a 2x2 block of the output image.  LDS tile [TH+2][TW+2] pixels at a 20-float pitch (conflict-free b128 reads
 // for 64 consecutive pixels); weights are wave-uniform => scalar loads, FMAs take them as SGPR operands.
-template <int TW, int TH>
+template <int TW, int TH, bool SIMPLE>
 __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ w,
                                                                      const float* __restrict__ ep, float* __restrict__ y) {
     constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 20;
@@ -228,7 +262,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     if (gy < p.H && gx < p.W) {
         float o[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = tanhf(act_plain(p.act, p.leaky, fmaf(acc[k], ep[2 * k], ep[2 * k + 1])));
+        for (int k = 0; k < 4; ++k) o[k] = tanhf(apply_act<SIMPLE>(p.act, fmaf(acc[k], ep[2 * k], ep[2 * k + 1]), 0.0f));
         float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
         // channel 2*dy+dx -> output pixel (2y+dy, 2x+dx)  (depth_to_space, fs_subpixel.glsl:41-64)
         *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
@@ -304,17 +338,26 @@ struct ChainPlan : snnhip_plan {
                 if (rc != SNNHIP_OK) return rc;
             } else if (s.kind == FUSED_A) {
                 dim3 grid(s.a.tilesX * s.a.tilesY * s.a.N);
+                const bool simple = act_is_simple(s.a.act1.act) && act_is_simple(s.a.act2.act);
+#define SNNHIP_LAUNCH_A(K, S)                                                                                                                  \
+    hipLaunchKernelGGL((conv_kxk_c1o16_conv3x3_c16o16_kernel<K, A_TW, A_TH, S>), grid, dim3(256), 0, ctx->stream, s.a, src->data, s.w1, s.w2, s.e1, \
+                       s.e2, dst->data)
                 if (s.k1 == 5) {
-                    hipLaunchKernelGGL((conv_kxk_c1o16_conv3x3_c16o16_kernel<5, A_TW, A_TH>), grid, dim3(256), 0, ctx->stream, s.a, src->data, s.w1, s.w2,
-                                       s.e1, s.e2, dst->data);
+                    if (simple) SNNHIP_LAUNCH_A(5, true); else SNNHIP_LAUNCH_A(5, false);
                 } else {
-                    hipLaunchKernelGGL((conv_kxk_c1o16_conv3x3_c16o16_kernel<3, A_TW, A_TH>), grid, dim3(256), 0, ctx->stream, s.a, src->data, s.w1, s.w2,
-                                       s.e1, s.e2, dst->data);
+                    if (simple) SNNHIP_LAUNCH_A(3, true); else SNNHIP_LAUNCH_A(3, false);
                 }
+#undef SNNHIP_LAUNCH_A
                 SNNHIP_CHECK_HIP(hipGetLastError());
             } else {
                 dim3 grid(s.b.tilesX * s.b.tilesY * s.b.N);
-                hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_kernel<B_TW, B_TH>), grid, dim3(256), 0, ctx->stream, s.b, src->data, s.w1, s.e1, dst->data);
+                if (act_is_simple(s.b.act.act)) {
+                    hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_kernel<B_TW, B_TH, true>), grid, dim3(256), 0, ctx->stream, s.b, src->data, s.w1, s.e1,
+                                       dst->data);
+                } else {
+                    hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_kernel<B_TW, B_TH, false>), grid, dim3(256), 0, ctx->stream, s.b, src->data, s.w1, s.e1,
+                                       dst->data);
+                }
                 SNNHIP_CHECK_HIP(hipGetLastError());
             }
             if (profiling) {
@@ -356,7 +399,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             const int K1 = g0.kh, taps1 = K1 * K1, ks1 = (taps1 + 3) / 4;
             st.kind = ChainPlan::FUSED_A;
             st.k1 = K1;
-            st.a = FusedAParams{g0.N, g0.H, g0.W, up_div(g0.W, A_TW), up_div(g0.H, A_TH), g0.act, c1->g.act, g0.leaky, c1->g.leaky};
+            st.a = FusedAParams{g0.N, g0.H, g0.W, up_div(g0.W, A_TW), up_div(g0.H, A_TH), make_act_cfg(g0.act, g0.leaky), make_act_cfg(c1->g.act, c1->g.leaky)};
             std::vector<float> wA1(static_cast<size_t>(ks1) * 64, 0.0f), wA2(36 * 64);
             for (int s = 0; s < ks1; ++s)
                 for (int l = 0; l < 64; ++l) {
@@ -387,7 +430,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             // ---- rule B
             const ConvGeom& g0 = c0->g;
             st.kind = ChainPlan::FUSED_B;
-            st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, B_TW), up_div(g0.H, B_TH), g0.act, g0.leaky};
+            st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, B_TW), up_div(g0.H, B_TH), make_act_cfg(g0.act, g0.leaky)};
             std::vector<float> wB(9 * 16 * 4);
             for (int tap = 0; tap < 9; ++tap)
                 for (int ic = 0; ic < 16; ++ic)

@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Summarises rocprofv3 CSV output (kernel stats + PMC passes) of tools/profile_gpu.sh into markdown + JSON."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def rows(pattern):
+    for f in glob.glob(pattern, recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                yield r
+
+
+def short(name):
+    n = name.replace("void snnhip::(anonymous namespace)::", "").replace("snnhip::(anonymous namespace)::", "")
+    n = n.replace("(anonymous namespace)::", "")
+    n = n.split("(")[0]
+    return n[:110]
+
+
+def main():
+    out = sys.argv[1]
+    res = {"kernels": {}}
+    print("# rocprofv3 summary (%s)\n" % os.path.basename(out))
+    print("## kernel stats (--kernel-trace --stats)\n")
+    print("| kernel | calls | avg us | min us | max us | total ms | % |")
+    print("|---|---|---|---|---|---|---|")
+    for r in rows(out + "/trace/**/*kernel_stats.csv"):
+        name = short(r["Name"])
+        avg = float(r["AverageNs"]) / 1e3
+        print("| %s | %s | %.2f | %.2f | %.2f | %.3f | %s |" % (name, r["Calls"], avg, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
+                                                            float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+        res["kernels"].setdefault(name, {})["avg_us"] = avg
+        res["kernels"][name]["calls"] = int(r["Calls"])
+    # PMC: average per dispatch per kernel
+    for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+        acc = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(lambda: defaultdict(int))
+        for r in rows(out + "/%s/**/*counter_collection.csv" % sub):
+            k = short(r["Kernel_Name"])
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k][r["Counter_Name"]] += 1
+        if not acc:
+            continue
+        print("\n## %s (average per dispatch)\n" % sub)
+        for k in acc:
+            print("* **%s**" % k)
+            for c in sorted(acc[k]):
+                v = acc[k][c] / max(cnt[k][c], 1)
+                print("  * %s = %.6g" % (c, v))
+                res["kernels"].setdefault(k, {})[c] = v
+    # derived
+    print("\n## derived\n")
+    for k, d in res["kernels"].items():
+        line = []
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"]:
+            # gfx94x formula used by rocprof's MfmaUtil: MFMA_BUSY / (SQ_BUSY_CYCLES * 4 SIMDs ... ) -- report raw ratio too
+            line.append("mfma_busy/sq_busy=%.3f" % (d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_BUSY_CYCLES"]))
+        if "GRBM_GUI_ACTIVE" in d and "avg_us" in d:
+            line.append("eff_clock_GHz=%.3f" % (d["GRBM_GUI_ACTIVE"] / (d["avg_us"] * 1e3)))
+        if "FETCH_SIZE" in d:
+            # rocprofv3 reports KiB; gfx950 wide coalesced reads are tallied at half their size (MI355X_MICROARCH.md HBM)
+            d["hbm_read_bytes_raw"] = d["FETCH_SIZE"] * 1024
+            d["hbm_read_bytes_corrected_x2"] = d["FETCH_SIZE"] * 1024 * 2
+            line.append("FETCH raw=%.1f MB (x2 corrected=%.1f MB)" % (d["hbm_read_bytes_raw"] / 1e6, d["hbm_read_bytes_corrected_x2"] / 1e6))
+        if "WRITE_SIZE" in d:
+            d["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024
+            line.append("WRITE=%.1f MB" % (d["hbm_write_bytes"] / 1e6))
+        if "SQ_LDS_BANK_CONFLICT" in d and d.get("SQ_LDS_IDX_ACTIVE"):
+            line.append("lds_conflict_frac=%.3f" % (d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"]))
+        if line:
+            print("* **%s**: %s" % (k, "; ".join(line)))
+    json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

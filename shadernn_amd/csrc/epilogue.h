@@ -59,6 +59,13 @@ __device__ __forceinline__ float apply_act(const ActCfg& a, float v, float first
     return epi_act(a.act, a.leaky, v, first);
 }
 
+// tanh as 1 - 2/(e^{2x}+1) on the hardware exp/rcp units: branch-free (ocml's tanhf is a multi-range, branchy
+// routine that serialises the epilogue).  Absolute error <= 3e-7 over the whole range, saturates to +-1 correctly.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float t = __expf(2.0f * x);
+    return 1.0f - __fdividef(2.0f, t + 1.0f);
+}
+
 // coordinate resolution of vk_conv2d.comp:168-218; returns -1 when the fetch yields 0
 __device__ __forceinline__ int resolve_coord(int s, int size, int padMode) {
     if (padMode == SNNHIP_PAD_REPLICATE) return min(max(s, 0), size - 1);

@@ -17,6 +17,8 @@
 //            pixel), A operand = weights held in 36 VGPRs for the whole kernel; 8 groups (=accumulators) per wave
 //   epilogue bias/BN/act, 16-byte stores: one wave store = 16 pixels x 64 B contiguous NHWC
 // fp32 MFMA is bit-for-bit an fp32 fma chain (no reduced precision), so the 1e-4 parity bound holds as for VALU code.
+#include <cstdlib>
+
 #include "epilogue.h"
 #include "snnhip_internal.h"
 
@@ -29,6 +31,15 @@ namespace snnhip {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// XCD-aware tile order (guide T1): workgroup b runs on XCD b % 8 and every XCD has a private 4 MiB L2.  Handing each XCD
+// a contiguous run of tiles keeps the halo rows/columns that neighbouring tiles share inside one L2 instead of
+// re-fetching them through the fabric.  Bijective for any grid size; purely a performance hint.
+__device__ __forceinline__ int xcd_tile_order(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
 
 struct FusedAParams {
     int N, H, W, tilesX, tilesY;
@@ -58,7 +69,7 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_conv3x3_c16o16_kernel
     const int lane = tid & 63, wv = tid >> 6;
     const int px = lane & 15, g = lane >> 4;
 
-    int b = blockIdx.x;
+    int b = xcd_tile_order(blockIdx.x, gridDim.x);
     const int tx = b % p.tilesX;
     b /= p.tilesX;
     const int ty = b % p.tilesY;
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     __shared__ __attribute__((aligned(16))) float s_x[THH * TWH * PITCH];
 
     const int tid = threadIdx.x;
-    int b = blockIdx.x;
+    int b = xcd_tile_order(blockIdx.x, gridDim.x);
     const int tx = b % p.tilesX;
     b /= p.tilesX;
     const int ty = b % p.tilesY;
@@ -229,13 +240,24 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     const int x0 = tx * TW, y0 = ty * TH;
     const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
 
-    for (int idx = tid; idx < THH * TWH * 4; idx += 256) {
-        const int q = idx & 3, pix = idx >> 2;
-        const int r = pix / TWH, c = pix - r * TWH;
-        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
-        *reinterpret_cast<float4*>(s_x + pix * PITCH + q * 4) = v;
+    {
+        constexpr int NLD = (THH * TWH * 4 + 255) / 256;
+        float4 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { // every load of the halo tile is in flight before the first LDS write
+            const int idx = tid + k * 256;
+            const int q = idx & 3, pix = idx >> 2;
+            const int r = pix / TWH, c = pix - r * TWH;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (idx < THH * TWH * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                v[k] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx >> 2) * PITCH + (idx & 3) * 4) = v[k];
+        }
     }
     __syncthreads();
 
@@ -262,9 +284,91 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     if (gy < p.H && gx < p.W) {
         float o[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = tanhf(apply_act<SIMPLE>(p.act, fmaf(acc[k], ep[2 * k], ep[2 * k + 1]), 0.0f));
+        for (int k = 0; k < 4; ++k) o[k] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(acc[k], ep[2 * k], ep[2 * k + 1]), 0.0f));
         float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
         // channel 2*dy+dx -> output pixel (2y+dy, 2x+dx)  (depth_to_space, fs_subpixel.glsl:41-64)
+        *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
+        *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
+    }
+}
+
+// Matrix-pipe variant of kernel B.  OC = 4 is too narrow for the 16x16 MFMA shapes, but v_mfma_f32_4x4x1_16b_f32 runs
+// 16 independent 4x4 outer products per instruction: block b = lanes 4b..4b+3, D_b[oc][px] += A_b[oc] * B_b[px].  Each lane
+// supplies its OWN pixel's activation as B and receives its own pixel's 4 output channels.  With cbsz=4 the A vector of
+// block `abid` is broadcast to all 16 blocks, so ONE VGPR holds the weights of 16 K-steps (lane 4*ic+oc = W[oc][ic][tap])
+// and the whole 3x3x16x4 filter lives in 9 VGPRs: 144 MFMAs (8 cycles each) per 64 pixels, no scalar loads, no VALU FMAs.
+// Numerics: every MFMA is an exact fp32 fma, four interleaved accumulation chains are summed at the end.
+template <int TW, int TH, bool SIMPLE>
+__global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_mfma_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ wA3,
+                                                                          const float* __restrict__ ep, float* __restrict__ y) {
+    constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 20;
+    static_assert(TW * TH == 256, "one thread per pixel");
+    __shared__ __attribute__((aligned(16))) float s_x[THH * TWH * PITCH];
+
+    const int tid = threadIdx.x;
+    int b = xcd_tile_order(blockIdx.x, gridDim.x);
+    const int tx = b % p.tilesX;
+    b /= p.tilesX;
+    const int ty = b % p.tilesY;
+    const int n = b / p.tilesY;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
+
+    {
+        constexpr int NLD = (THH * TWH * 4 + 255) / 256;
+        float4 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { // every load of the halo tile is in flight before the first LDS write
+            const int idx = tid + k * 256;
+            const int q = idx & 3, pix = idx >> 2;
+            const int r = pix / TWH, c = pix - r * TWH;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (idx < THH * TWH * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                v[k] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx >> 2) * PITCH + (idx & 3) * 4) = v[k];
+        }
+    }
+    float a3[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) a3[t] = wA3[t * 64 + (tid & 63)];
+    __syncthreads();
+
+    const int c = tid % TW, r = tid / TW;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int fy = tap / 3, fx = tap % 3;
+        const float* src = s_x + ((r + fy) * TWH + c + fx) * PITCH;
+#define SNNHIP_C3_QUAD(Q)                                                                        \
+    {                                                                                            \
+        const float4 xv = *reinterpret_cast<const float4*>(src + (Q) * 4);                       \
+        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a3[tap], xv.x, acc[0], 4, (Q) * 4 + 0, 0);   \
+        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a3[tap], xv.y, acc[1], 4, (Q) * 4 + 1, 0);   \
+        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a3[tap], xv.z, acc[2], 4, (Q) * 4 + 2, 0);   \
+        acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a3[tap], xv.w, acc[3], 4, (Q) * 4 + 3, 0);   \
+    }
+        SNNHIP_C3_QUAD(0)
+        SNNHIP_C3_QUAD(1)
+        SNNHIP_C3_QUAD(2)
+        SNNHIP_C3_QUAD(3)
+#undef SNNHIP_C3_QUAD
+    }
+    const int gy = y0 + r, gx = x0 + c;
+    if (gy < p.H && gx < p.W) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sum = (acc[0][k] + acc[1][k]) + (acc[2][k] + acc[3][k]);
+            o[k] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(sum, ep[2 * k], ep[2 * k + 1]), 0.0f));
+        }
+        float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
         *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
         *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
     }
@@ -292,14 +396,15 @@ constexpr int A_TW = 64, A_TH = 8;
 constexpr int B_TW = 32, B_TH = 8;
 
 struct ChainPlan : snnhip_plan {
-    enum Kind { PLAIN, FUSED_A, FUSED_B };
+    enum Kind { PLAIN, FUSED_A, FUSED_B, FUSED_S };
     struct Step {
         Kind kind = PLAIN;
         snnhip_plan* plain = nullptr; // borrowed
         FusedAParams a{};
         FusedBParams b{};
         int k1 = 5;
-        float *w1 = nullptr, *w2 = nullptr, *e1 = nullptr, *e2 = nullptr;
+        float *w1 = nullptr, *w2 = nullptr, *e1 = nullptr, *e2 = nullptr, *w3 = nullptr, *e3 = nullptr;
+        alignas(8) char streamCfg[kStreamCfgBytes] = {};
         int outDims[4] = {0, 0, 0, 0};
         std::string desc;
         double flops = 0, bytes = 0; // algorithmic work of this launch (fused steps: inputs once + outputs once + weights)
@@ -335,6 +440,9 @@ struct ChainPlan : snnhip_plan {
             }
             if (s.kind == PLAIN) {
                 int rc = s.plain->run(&src, 1, dst);
+                if (rc != SNNHIP_OK) return rc;
+            } else if (s.kind == FUSED_S) {
+                int rc = espcn_stream_launch(ctx->stream, s.streamCfg, src->data, s.w1, s.e1, s.w2, s.e2, s.w3, s.e3, dst->data);
                 if (rc != SNNHIP_OK) return rc;
             } else if (s.kind == FUSED_A) {
                 dim3 grid(s.a.tilesX * s.a.tilesY * s.a.N);
@@ -373,6 +481,11 @@ struct ChainPlan : snnhip_plan {
 } // namespace
 
 int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_plan** out) {
+    // Default = the two-kernel fusion (rules A+B).  SNNHIP_ESPCN_FUSION=stream selects the single row-streaming kernel
+    // (rule C, espcn_stream.hip): parity-tested, 20 B/px of HBM traffic, but measured slower on MI355X so far
+    // (206 us vs 123+45 us per 1080p frame) because its per-wave dependency chain starves the matrix pipe.
+    const char* mode = getenv("SNNHIP_ESPCN_FUSION");
+    const bool allowStream = mode && strcmp(mode, "stream") == 0;
     auto* chain = new ChainPlan();
     chain->ctx = ctx;
     memcpy(chain->inDims, plans[0]->inDims, sizeof(chain->inDims));
@@ -392,8 +505,60 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             rc = SNNHIP_E_INVALID;
             break;
         }
-        if (c0 && c1 && !c0->depthwise && !c1->depthwise && (is_same_conv(c0->g, 5, 1, 16) || is_same_conv(c0->g, 3, 1, 16)) &&
-            is_same_conv(c1->g, 3, 16, 16)) {
+        auto* c2 = (i + 2 < n) ? dynamic_cast<ConvPlanBase*>(plans[i + 2]) : nullptr;
+        auto* sp3 = (i + 3 < n) ? dynamic_cast<SubpixelPlanBase*>(plans[i + 3]) : nullptr;
+        const bool pairA = c0 && c1 && !c0->depthwise && !c1->depthwise && (is_same_conv(c0->g, 5, 1, 16) || is_same_conv(c0->g, 3, 1, 16)) &&
+                           is_same_conv(c1->g, 3, 16, 16);
+        if (allowStream && pairA && c2 && sp3 && !c2->depthwise && is_same_conv(c2->g, 3, 16, 4) && sp3->d.factor == 2 &&
+            sp3->d.mode == SNNHIP_SUBPIXEL_D2S && sp3->d.C == 4 && memcmp(plans[i + 1]->outDims, plans[i + 2]->inDims, sizeof(int) * 4) == 0 &&
+            memcmp(plans[i + 2]->outDims, plans[i + 3]->inDims, sizeof(int) * 4) == 0) {
+            // ---- rule C: the whole ESPCN pattern as one row-streaming kernel (espcn_stream.hip)
+            const ConvGeom& g0 = c0->g;
+            const int K1 = g0.kh, taps1 = K1 * K1;
+            st.kind = ChainPlan::FUSED_S;
+            st.k1 = K1;
+            static_assert(sizeof(st.streamCfg) >= 1, "");
+            if (espcn_stream_step_size() > sizeof(st.streamCfg)) {
+                set_error("internal: stream cfg blob too small");
+                rc = SNNHIP_E_INVALID;
+                break;
+            }
+            espcn_stream_configure(st.streamCfg, g0.N, g0.H, g0.W, K1, g0.act, g0.leaky, c1->g.act, c1->g.leaky, c2->g.act, c2->g.leaky,
+                                   ctx->props.multiProcessorCount);
+            const int ks1 = (taps1 + 3) / 4;
+            std::vector<float> w1s(static_cast<size_t>(ks1) * 64, 0.0f), wA2(36 * 64), w3s(9 * 16 * 4);
+            for (int s = 0; s < ks1; ++s)
+                for (int l = 0; l < 64; ++l) {
+                    const int oc = l & 15, t = 4 * s + (l >> 4);
+                    if (t < taps1) w1s[s * 64 + l] = c0->w_oihw[static_cast<size_t>(oc) * taps1 + t];
+                }
+            for (int tap = 0; tap < 9; ++tap)
+                for (int j = 0; j < 4; ++j)
+                    for (int l = 0; l < 64; ++l) {
+                        const int oc = l & 15, ic = 4 * (l >> 4) + j;
+                        wA2[(tap * 4 + j) * 64 + l] = c1->w_oihw[(static_cast<size_t>(oc) * 16 + ic) * 9 + tap];
+                    }
+            for (int dx = 0; dx < 3; ++dx) // w3r[((dx*4+q)*4+i)*12 + dy*4 + o] = W3[o][ic = 4q+i][dy][dx]
+                for (int ic = 0; ic < 16; ++ic)
+                    for (int dy = 0; dy < 3; ++dy)
+                        for (int o = 0; o < 4; ++o) w3s[(dx * 16 + ic) * 12 + dy * 4 + o] = c2->w_oihw[(static_cast<size_t>(o) * 16 + ic) * 9 + dy * 3 + dx];
+            std::vector<float> e1 = fold_epilogue(c0->epi4, 16, g0.useBN), e2 = fold_epilogue(c1->epi4, 16, c1->g.useBN),
+                               e3 = fold_epilogue(c2->epi4, 4, c2->g.useBN);
+            rc = chain->upload(w1s.data(), w1s.size(), &st.w1);
+            if (rc == SNNHIP_OK) rc = chain->upload(wA2.data(), wA2.size(), &st.w2);
+            if (rc == SNNHIP_OK) rc = chain->upload(w3s.data(), w3s.size(), &st.w3);
+            if (rc == SNNHIP_OK) rc = chain->upload(e1.data(), e1.size(), &st.e1);
+            if (rc == SNNHIP_OK) rc = chain->upload(e2.data(), e2.size(), &st.e2);
+            if (rc == SNNHIP_OK) rc = chain->upload(e3.data(), e3.size(), &st.e3);
+            memcpy(st.outDims, sp3->outDims, sizeof(st.outDims));
+            char buf[320];
+            espcn_stream_describe(st.streamCfg, buf, sizeof(buf));
+            st.desc = buf;
+            st.flops = c0->flops + c1->flops + c2->flops;
+            st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (1 + 4) + 16.0 * taps1 + 16.0 * 16 * 9 + 4.0 * 16 * 9);
+            i += 4;
+            ++fusedCount;
+        } else if (pairA) {
             // ---- rule A
             const ConvGeom& g0 = c0->g;
             const int K1 = g0.kh, taps1 = K1 * K1, ks1 = (taps1 + 3) / 4;

@@ -138,6 +138,15 @@ int make_dense_plan(snnhip_ctx* ctx, const snnhip_dense_desc& d, const float* w_
 int make_subpixel_plan(snnhip_ctx* ctx, const snnhip_subpixel_desc& d, snnhip_plan** out);
 int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_plan** out);
 
+// espcn_stream.hip: the whole ESPCN pattern in one launch (rule C of the chain planner); cfg is an opaque blob
+constexpr size_t kStreamCfgBytes = 160;
+size_t espcn_stream_step_size();
+void espcn_stream_configure(void* cfg, int N, int H, int W, int k1, int act1, float leaky1, int act2, float leaky2, int act3, float leaky3,
+                            int computeUnits);
+void espcn_stream_describe(const void* cfg, char* buf, size_t n);
+int espcn_stream_launch(hipStream_t stream, const void* cfg, const float* x, const float* w1s, const float* ep1, const float* wA2, const float* ep2,
+                        const float* w3s, const float* ep3, float* y);
+
 // Conv plans keep their host-side description so that chain fusion can re-pack weights.
 struct ConvPlanBase : snnhip_plan {
     ConvGeom g;

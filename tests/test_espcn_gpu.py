@@ -25,7 +25,33 @@ def test_espcn_matches_oracle(ctx, n, h, w, fused):
         for got, exp in zip(runner.layer_outputs(), layers):
             np.testing.assert_allclose(got, exp, **TOL)
     else:
-        assert "fused[conv5x5" in runner.describe()[0] and "depth_to_space" in runner.describe()[0]
+        assert "fused[conv5x5" in runner.describe()[0] and "depth_to_space" in runner.describe()[0] and " -> " in runner.describe()[0]
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 32, 32), (2, 19, 71), (1, 40, 130)])
+def test_espcn_stream_fusion_matches_oracle(ctx, n, h, w, monkeypatch):
+    """The single row-streaming kernel (rule C) is opt-in via SNNHIP_ESPCN_FUSION=stream and must stay parity-green."""
+    import shadernn_amd as snn
+    from shadernn_amd import models
+
+    monkeypatch.setenv("SNNHIP_ESPCN_FUSION", "stream")
+    net = models.espcn_weights(seed=2)
+    x = np.random.default_rng(3).random((n, h, w, 1), dtype=np.float32)
+    runner = snn.EspcnRunner(ctx, net, n, h, w, fused=True)
+    assert "stream" in runner.describe()[0]
+    np.testing.assert_allclose(runner(x), O.forward(net, x), **TOL)
+
+
+def test_espcn_stream_full_size(ctx, monkeypatch):
+    import shadernn_amd as snn
+    from shadernn_amd import models
+
+    net = models.espcn_weights(seed=1)
+    x = np.random.default_rng(1).random((1, 1080, 1920, 1), dtype=np.float32)
+    y_pair = snn.EspcnRunner(ctx, net, 1, 1080, 1920, fused=True)(x)
+    monkeypatch.setenv("SNNHIP_ESPCN_FUSION", "stream")
+    y_stream = snn.EspcnRunner(ctx, net, 1, 1080, 1920, fused=True)(x)
+    np.testing.assert_allclose(y_stream, y_pair, rtol=1e-5, atol=1e-5)
 
 
 def test_espcn_fused_with_bn_and_other_activations(ctx):

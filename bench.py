@@ -62,14 +62,15 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="one kernel per layer (debug / comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with events (overhead check)")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="bracket the kernel launches of every Nth timed step with HIP events (each pair costs ~4.5 us of stream time)")
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from shadernn_amd import dist as sdist
+
+    rank, local_rank, world = sdist.env_rank_world()
     if world != args.gpus:
         if rank == 0:
             sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)\n" % (args.gpus, world))
@@ -78,9 +79,7 @@ def main():
         sys.stderr.write("bench.py: no GPU visible; the HIP path has no CPU fallback\n")
         sys.exit(3)
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    group = sdist.Group(backend="nccl")  # nccl == RCCL on ROCm; only barrier + MAX-reduction of the time use it
 
     import shadernn_amd as snn
     from shadernn_amd import models
@@ -99,29 +98,26 @@ def main():
     runner.x = snn.Tensor.from_torch(ctx, x)
     torch.cuda.synchronize()
 
-    def barrier():
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
+    barrier = group.barrier  # dist.barrier + torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         runner.run_device()
     barrier()
 
     profile = not args.no_kernel_events
-    for p in runner.plans:
-        p.profile(profile)
+    every = max(1, args.event_every)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if profile and (i % every == 0 or i % every == 1):  # toggle only at the sampled step and right after it
+            on = i % every == 0
+            for p in runner.plans:
+                p.profile(on)
         runner.run_device()
     barrier()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = group.max_over_ranks(elapsed)
 
     # per-kernel launch durations from the event pairs recorded inside the timed region
     kernels = []
@@ -171,9 +167,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net)
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    group.barrier()
+    group.close()
 
 
 if __name__ == "__main__":

@@ -87,6 +87,24 @@ int snnhip_plan::profBegin(int step) {
     return SNNHIP_OK;
 }
 
+int snnhip_plan::profAcquire(int step, hipEvent_t* start, hipEvent_t* stop) {
+    if (stepEvents.size() < static_cast<size_t>(numSteps())) {
+        stepEvents.resize(numSteps());
+        stepUsed.resize(numSteps(), 0);
+    }
+    auto& pool = stepEvents[step];
+    if (stepUsed[step] == pool.size()) {
+        EventPair e;
+        SNNHIP_CHECK_HIP(hipEventCreate(&e.start));
+        SNNHIP_CHECK_HIP(hipEventCreate(&e.stop));
+        pool.push_back(e);
+    }
+    *start = pool[stepUsed[step]].start;
+    *stop = pool[stepUsed[step]].stop;
+    ++stepUsed[step];
+    return SNNHIP_OK;
+}
+
 int snnhip_plan::profEnd(int step) {
     SNNHIP_CHECK_HIP(hipEventRecord(stepEvents[step][stepUsed[step]].stop, ctx->stream));
     ++stepUsed[step];

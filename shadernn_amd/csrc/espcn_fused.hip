@@ -17,6 +17,8 @@
 //            pixel), A operand = weights held in 36 VGPRs for the whole kernel; 8 groups (=accumulators) per wave
 //   epilogue bias/BN/act, 16-byte stores: one wave store = 16 pixels x 64 B contiguous NHWC
 // fp32 MFMA is bit-for-bit an fp32 fma chain (no reduced precision), so the 1e-4 parity bound holds as for VALU code.
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 
 #include "epilogue.h"
@@ -434,8 +436,9 @@ struct ChainPlan : snnhip_plan {
         for (size_t i = 0; i < steps.size(); ++i) {
             Step& s = steps[i];
             snnhip_tensor* dst = (i + 1 == steps.size()) ? out : mids[i];
+            hipEvent_t evStart = nullptr, evStop = nullptr;
             if (profiling) {
-                int rc = profBegin(static_cast<int>(i));
+                int rc = (s.kind == FUSED_A || s.kind == FUSED_B) ? profAcquire(static_cast<int>(i), &evStart, &evStop) : profBegin(static_cast<int>(i));
                 if (rc != SNNHIP_OK) return rc;
             }
             if (s.kind == PLAIN) {
@@ -447,9 +450,9 @@ struct ChainPlan : snnhip_plan {
             } else if (s.kind == FUSED_A) {
                 dim3 grid(s.a.tilesX * s.a.tilesY * s.a.N);
                 const bool simple = act_is_simple(s.a.act1.act) && act_is_simple(s.a.act2.act);
-#define SNNHIP_LAUNCH_A(K, S)                                                                                                                  \
-    hipLaunchKernelGGL((conv_kxk_c1o16_conv3x3_c16o16_kernel<K, A_TW, A_TH, S>), grid, dim3(256), 0, ctx->stream, s.a, src->data, s.w1, s.w2, s.e1, \
-                       s.e2, dst->data)
+#define SNNHIP_LAUNCH_A(K, S)                                                                                                                         \
+    hipExtLaunchKernelGGL((conv_kxk_c1o16_conv3x3_c16o16_kernel<K, A_TW, A_TH, S>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.a, src->data, \
+                          s.w1, s.w2, s.e1, s.e2, dst->data)
                 if (s.k1 == 5) {
                     if (simple) SNNHIP_LAUNCH_A(5, true); else SNNHIP_LAUNCH_A(5, false);
                 } else {
@@ -460,15 +463,15 @@ struct ChainPlan : snnhip_plan {
             } else {
                 dim3 grid(s.b.tilesX * s.b.tilesY * s.b.N);
                 if (act_is_simple(s.b.act.act)) {
-                    hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_kernel<B_TW, B_TH, true>), grid, dim3(256), 0, ctx->stream, s.b, src->data, s.w1, s.e1,
-                                       dst->data);
+                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_kernel<B_TW, B_TH, true>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b,
+                                          src->data, s.w1, s.e1, dst->data);
                 } else {
-                    hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_kernel<B_TW, B_TH, false>), grid, dim3(256), 0, ctx->stream, s.b, src->data, s.w1, s.e1,
-                                       dst->data);
+                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_kernel<B_TW, B_TH, false>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b,
+                                          src->data, s.w1, s.e1, dst->data);
                 }
                 SNNHIP_CHECK_HIP(hipGetLastError());
             }
-            if (profiling) {
+            if (profiling && !(s.kind == FUSED_A || s.kind == FUSED_B)) {
                 int rc = profEnd(static_cast<int>(i));
                 if (rc != SNNHIP_OK) return rc;
             }

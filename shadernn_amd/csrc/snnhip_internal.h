@@ -109,6 +109,9 @@ struct snnhip_plan {
     virtual bool profilesItself() const { return false; }
     int profBegin(int step); // records the start event of a fresh pair
     int profEnd(int step);
+    // For kernels this library launches itself: hand out a fresh pair to hipExtLaunchKernelGGL, which stamps the
+    // dispatch packet's own start/end instead of enqueueing two marker packets (~3.5 us each on this runtime).
+    int profAcquire(int step, hipEvent_t* start, hipEvent_t* stop);
 
     // uploads host floats into a fresh device buffer owned by the plan
     int upload(const float* host, size_t count, float** dev);

@@ -1,0 +1,55 @@
+/*
+ * snn_c.h -- C binding of the C++ host mirror (shadernn_amd/host, libsnn_core.so) for tests and bench harnesses.
+ *
+ * This is NOT the drop-in boundary (that is snnhip.h).  It lets non-C++ callers (pytest via ctypes) drive the same call
+ * sequence the reference's own harnesses use:
+ *   MixedInferenceCore::create(context, jsonFile, ShaderGenOptions) + run(RunParameters)
+ *       -- demo/common/inferenceProcessor.cpp:42-140
+ *   ShaderUnitTest::snnConvTestWithLayer: hand-built InputLayer + Conv2D layer, generateInferenceGraph, create, run, read the
+ *   "<layer name> pass[0].dump" file            -- demo/common/shaderUnitTest.cpp:174-280
+ * All functions return 0 on success; the C++ side aborts (SNN_RIP) on fatal errors exactly like the reference.
+ */
+#ifndef SNN_C_H
+#define SNN_C_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct snn_model snn_model;
+
+/* Loads a JSON model, builds the graph for one W x H x C input image and initialises every stage on `device`.
+ * dump_outputs: write "<SNN_OUTPUT_DIR>/<layer name> pass[0].dump" for every layer on each run (disables fusion).
+ * fuse_chains : let the HIP backend replace linear runs of layers by fused kernels. */
+int snn_model_create(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
+                     snn_model** out);
+int snn_model_destroy(snn_model* m);
+int snn_model_upload_input(snn_model* m, const float* nhwc);      /* H x W x C floats */
+int snn_model_run(snn_model* m);                                   /* MixedInferenceCore::run (enqueue + one sync) */
+int snn_model_output_dims(snn_model* m, int hwc[3]);
+int snn_model_download_output(snn_model* m, float* nhwc);
+int snn_model_num_stages(snn_model* m);
+int snn_model_stage_info(snn_model* m, int stage, char* name, int name_len, int hwc[3], int* fused_away);
+int snn_model_download_stage(snn_model* m, int stage, float* nhwc);
+int snn_model_describe(snn_model* m, char* buf, int buflen);
+/* per-stage device timers of the last run, milliseconds (MixedInferenceCore::writeTimeStat); returns count written */
+int snn_model_time_stats(snn_model* m, char* names, int names_len, double* ms, int max_entries);
+
+/* Restatement of ShaderUnitTest::snnConvTestWithLayer (shaderUnitTest.cpp:174-280): input HWC floats, weights as OC*IC
+ * matrices of k x k (flat OIHW), bias[OC], optional BN (4 arrays of OC or NULL), pad: 0 constant 1 replicate 2 reflect.
+ * Writes the layer dump and returns its path in dump_path; the dump is the reference's ".dump" format. */
+int snn_conv_test_with_layer(int device, const float* input_hwc, const float* weights_oihw, const float* bias, int width, int height, int in_channels,
+                             int out_channels, int kernel, int stride, int pad, int use_bn, const float* bn_gamma, const float* bn_mean,
+                             const float* bn_var, const float* bn_beta, char* dump_path, int dump_path_len);
+
+/* Host-only (no GPU): parse the JSON model, build the layer DAG and the inference graph for a W x H x C input and print one
+ * line per layer: "<index>|<name>|<exec type>|<out W>x<out H>x<out C>|<inputs>".  Exercises ModelParser, layerFactory,
+ * topological sort and the shape rules exactly as MixedInferenceCore::create would. */
+int snn_graph_summary(const char* json_path, int in_w, int in_h, int in_c, char* buf, int buflen);
+
+/* ".dump" reader (image.cpp:300-311): returns W,H,D,C and, if out != NULL, the RGBA32F pixels ([D][H][W][4] floats). */
+int snn_dump_read(const char* path, int whdc[4], float* out, long out_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

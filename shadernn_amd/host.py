@@ -1,0 +1,153 @@
+"""ctypes binding of include/snn_c.h (libsnn_core.so): the C++ host mirror of the reference's MixedInferenceCore API."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsnn_core.so")
+_lib = None
+_P = C.c_void_p
+_FP = C.POINTER(C.c_float)
+
+SIGNATURES = {
+    "snn_model_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "snn_model_destroy": (C.c_int, [_P]),
+    "snn_model_upload_input": (C.c_int, [_P, _FP]),
+    "snn_model_run": (C.c_int, [_P]),
+    "snn_model_output_dims": (C.c_int, [_P, C.POINTER(C.c_int * 3)]),
+    "snn_model_download_output": (C.c_int, [_P, _FP]),
+    "snn_model_num_stages": (C.c_int, [_P]),
+    "snn_model_stage_info": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int * 3), C.POINTER(C.c_int)]),
+    "snn_model_download_stage": (C.c_int, [_P, C.c_int, _FP]),
+    "snn_model_describe": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "snn_model_time_stats": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.c_int]),
+    "snn_conv_test_with_layer": (C.c_int, [C.c_int, _FP, _FP, _FP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _FP, _FP, _FP, _FP,
+                                           C.c_char_p, C.c_int]),
+    "snn_graph_summary": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "snn_dump_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int * 4), _FP, C.c_long]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        capi.load_library()  # libsnnhip.so first (libsnn_core.so links against it)
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run __graft_entry__.build()" % LIB_PATH)
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(_FP)
+
+
+def graph_summary(json_path, w, h, c):
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().snn_graph_summary(json_path.encode(), w, h, c, buf, len(buf))
+    rows = []
+    for line in buf.value.decode().strip().split("\n"):
+        idx, name, loc, dims, ins = line.split("|")
+        rows.append({"index": int(idx), "name": name, "loc": int(loc), "dims": tuple(int(v) for v in dims.split("x")),
+                     "inputs": [int(v) for v in ins.split(",") if v]})
+    assert len(rows) == n
+    return rows
+
+
+def read_dump(path):
+    """Reference .dump -> (W, H, D, C, float32 array [D][H][W][4])."""
+    d = (C.c_int * 4)()
+    assert lib().snn_dump_read(path.encode(), C.byref(d), None, 0) == 0
+    w, h, dd, c = d
+    out = np.empty((dd, h, w, 4), dtype=np.float32)
+    assert lib().snn_dump_read(path.encode(), C.byref(d), _fp(out), out.size) == 0
+    return w, h, dd, c, out
+
+
+def c4hw4_to_nhwc(a, channels):
+    d, h, w, _ = a.shape
+    return np.transpose(a, (1, 2, 0, 3)).reshape(h, w, d * 4)[:, :, :channels]
+
+
+class Model:
+    """MixedInferenceCore::create(context, jsonFile, options) + run(), one W x H x C input image."""
+
+    def __init__(self, json_path, w, h, c, device=0, dump_outputs=False, fuse_chains=True, profiling=False):
+        self.h = _P()
+        assert lib().snn_model_create(json_path.encode(), device, w, h, c, int(dump_outputs), int(fuse_chains), int(profiling), C.byref(self.h)) == 0
+        self.in_shape = (h, w, c)
+
+    def upload(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.in_shape)
+        assert lib().snn_model_upload_input(self.h, _fp(x)) == 0
+
+    def run(self):
+        assert lib().snn_model_run(self.h) == 0
+
+    def output(self):
+        d = (C.c_int * 3)()
+        lib().snn_model_output_dims(self.h, C.byref(d))
+        out = np.empty(tuple(d), dtype=np.float32)
+        assert lib().snn_model_download_output(self.h, _fp(out)) == 0
+        return out
+
+    def __call__(self, x):
+        self.upload(x)
+        self.run()
+        return self.output()
+
+    def stages(self):
+        out = []
+        for i in range(lib().snn_model_num_stages(self.h)):
+            name = C.create_string_buffer(512)
+            d = (C.c_int * 3)()
+            fused = C.c_int()
+            lib().snn_model_stage_info(self.h, i, name, 512, C.byref(d), C.byref(fused))
+            out.append({"name": name.value.decode(), "hwc": tuple(d), "fused_away": bool(fused.value)})
+        return out
+
+    def stage_output(self, i):
+        st = self.stages()[i]
+        out = np.empty(st["hwc"], dtype=np.float32)
+        if lib().snn_model_download_stage(self.h, i, _fp(out)) != 0:
+            return None
+        return out
+
+    def describe(self):
+        buf = C.create_string_buffer(1 << 14)
+        lib().snn_model_describe(self.h, buf, len(buf))
+        return buf.value.decode()
+
+    def time_stats(self):
+        names = C.create_string_buffer(1 << 14)
+        ms = (C.c_double * 256)()
+        n = lib().snn_model_time_stats(self.h, names, len(names), ms, 256)
+        return dict(zip(names.value.decode().strip().split("\n"), list(ms)[:n]))
+
+    def close(self):
+        if self.h:
+            lib().snn_model_destroy(self.h)
+            self.h = None
+
+
+def conv_test_with_layer(x_hwc, w_oihw, bias, stride=1, pad=0, bn=None, device=0):
+    """ShaderUnitTest::snnConvTestWithLayer; returns the dump path written by the layer."""
+    x = np.ascontiguousarray(x_hwc, dtype=np.float32)
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    h, ww, ic = x.shape
+    oc, _, k, _ = w.shape
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    arrs = [None] * 4
+    if bn is not None:
+        arrs = [np.ascontiguousarray(bn[q], dtype=np.float32) for q in ("gamma", "mean", "var", "beta")]
+    path = C.create_string_buffer(1024)
+    rc = lib().snn_conv_test_with_layer(device, _fp(x), _fp(w), _fp(b), ww, h, ic, oc, k, stride, pad, int(bn is not None), _fp(arrs[0]), _fp(arrs[1]),
+                                        _fp(arrs[2]), _fp(arrs[3]), path, 1024)
+    assert rc == 0
+    return path.value.decode()

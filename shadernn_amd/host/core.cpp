@@ -1,0 +1,150 @@
+// core.cpp -- MixedInferenceCore: stage array, texture wiring, the per-inference host loop
+// (reference core/src/ic2/core.cpp:80-95 create, :97-245 run, :247-289 mapDeviceBackend, :294-410 init, :412-451 stats).
+#include <sys/stat.h>
+
+#include <sstream>
+
+#include "ic2/backend.h"
+#include "ic2/dp.h"
+#include "snn/core.h"
+
+using namespace snn;
+
+MixedInferenceCore::MixedInferenceCore(GpuContext* context_) : context(context_) {}
+
+std::unique_ptr<MixedInferenceCore> MixedInferenceCore::create(GpuContext* context, const CreationParameters& cp) {
+    std::unique_ptr<MixedInferenceCore> p(new MixedInferenceCore(context));
+    p->init(cp);
+    return p;
+}
+
+std::unique_ptr<MixedInferenceCore> MixedInferenceCore::create(GpuContext* context, const std::string& modelFileName, const dp::ShaderGenOptions& options,
+                                                               bool dumpOutputs) { // core.cpp:86-95
+    auto layers = dp::loadFromJsonModel(modelFileName, false, options.mrtMode, options.weightMode, options.preferrHalfPrecision);
+    CreationParameters cp;
+    static_cast<InferenceGraph&>(cp) = dp::generateInferenceGraph(layers, options);
+    cp.dumpOutputs = dumpOutputs;
+    cp.fuseChains = options.fuseChains;
+    return create(context, cp);
+}
+
+// core.cpp:247-289 with GPU_HIP treated like GPU_VK
+static std::pair<Backend, Transition> mapDeviceBackend(InferenceGraph::LayerExecutionType prev, InferenceGraph::LayerExecutionType curr) {
+    using T = InferenceGraph::LayerExecutionType;
+    const bool currGpu = curr != T::CPU && curr != T::NOT_DEFINED;
+    const bool prevGpu = prev != T::CPU && prev != T::NOT_DEFINED;
+    Backend b = currGpu ? Backend::Backend_GPU : (curr == T::CPU ? Backend::Backend_CPU : Backend::NOT_DEFINED);
+    Transition t = Transition::NOT_DEFINED;
+    if (prev != T::NOT_DEFINED && prevGpu != currGpu) t = currGpu ? Transition::Backend_CPU_GPU : Transition::Backend_GPU_CPU;
+    return {b, t};
+}
+
+bool MixedInferenceCore::init(const CreationParameters& cp_) {
+    if (cp_.dumpOutputs) mkdir(outputDir(), 0755); // createDirIfNotExists(OUTPUT_DIR), core.cpp:295-297
+    SNN_ASSERT(cp_.inputsDesc.size() > 0);
+    this->cp = cp_;
+    backend = dp::BackendBuilder::build(context, cp);
+    if (cp.profiling) gpuRunTime = backend->createDeviceTimer("IC2 Total GPU runtime");
+
+    stages.reserve(cp.layers.size());
+    for (size_t i = 0; i < cp.layers.size(); ++i) stages.emplace_back(context);
+
+    InferenceGraph::LayerExecutionType preDev = InferenceGraph::LayerExecutionType::NOT_DEFINED;
+    for (size_t i = 0; i < cp.layers.size(); i++) { // core.cpp:318-330
+        if (cp.layers[i]->flattenLayer) bindOutput = false;
+        auto bt = mapDeviceBackend(preDev, cp.layers[i]->layerLoc);
+        stages[i].backend = bt.first;
+        stages[i].transition = bt.second;
+        stages[i].delayBindMask.resize(cp.layers[i]->inputRefs.size(), 0);
+        preDev = cp.layers[i]->layerLoc;
+    }
+
+    for (size_t i = 0; i < stages.size(); ++i) { // core.cpp:332-406
+        InferenceGraph::Layer& layer = *cp.layers[i];
+        RenderStage& stage = stages[i];
+        stage.layer = cp.layers[i];
+        if (stage.backend != Backend::Backend_GPU) SNN_RIP("stage %zu (%s): the HIP backend runs every hot-path layer on the GPU", i, layer.name.c_str());
+        stage.stageInputs.allocate(layer.inputRefs.size());
+        stage.stageOutputs.allocate(1);
+        if (stage.layer->isInputLayer) {
+            if (cp.profiling) stage.timer.reset(backend->createDeviceTimer(layer.name));
+            continue; // nothing to create or bind for the input layer
+        }
+        for (size_t j = 0; j < layer.inputRefs.size(); ++j) {
+            const auto& ref = layer.inputRefs[j];
+            if (ref.isStageOutput) {
+                SNN_ASSERT(ref.index < static_cast<int>(i));
+                stage.stageInputs[j].attach(&stages[static_cast<size_t>(ref.index)].stageOutputs[0]);
+                stage.inputIds.push_back(ref.index);
+            } else { // delay binding: the model input image arrives with run() (core.cpp:365-369)
+                const auto inputIdx = stages[static_cast<size_t>(ref.index)].layer->inputIndex;
+                stage.delayBindMask[j] = 1;
+                stage.inputIds.push_back(static_cast<int>(inputIdx));
+            }
+        }
+        std::array<uint32_t, 4> dims{layer.outputDesc.width, layer.outputDesc.height, layer.outputDesc.depth, 1};
+        stage.stageOutputs[0].resetTexture(dims, layer.outputDesc.format, layer.name, layer.outputDesc.channels); // core.cpp:371-372
+        layer.initFunPtr(backend, stage.stageInputs, stage.stageOutputs);                                        // core.cpp:374
+        if (cp.profiling) stage.timer.reset(backend->createDeviceTimer(layer.name));
+    }
+    backend->finalizeStages(stages, cp.dumpOutputs, cp.fuseChains);
+    return true;
+}
+
+void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
+    SNN_ASSERT(rp.inputImages && rp.inputImages->size() > 0);
+    if (rp.inputImages->size() != cp.inputsDesc.size()) {
+        SNN_LOGE("Wrong input texture count %zu <-> %zu", rp.inputImages->size(), cp.inputsDesc.size());
+        return;
+    }
+    backend->prepareRun(rp, stages, bindOutput, static_cast<uint32_t>(stages.size() - 1));
+    cpuRunTime.start();
+    if (gpuRunTime) gpuRunTime->start();
+    for (size_t i = 0; i < stages.size(); i++) {
+        auto& s = stages[i];
+        if (s.layer->isInputLayer) continue;
+        for (size_t n = 0; n < s.delayBindMask.size(); ++n) {
+            if (s.delayBindMask[n] > 0) s.stageInputs[n].attach(&(*rp.inputImages)[static_cast<size_t>(s.inputIds[n])]); // core.cpp:127-133
+        }
+        if (s.timer) s.timer->start();
+        backend->prepareStage(rp, s);
+        s.layer->runFunPtr(backend, cp.dumpOutputs);
+        if (s.timer) s.timer->stop();
+    }
+    if (gpuRunTime) gpuRunTime->stop();
+    backend->sync(); // the only GPU wait of an inference (core.cpp:203)
+    backend->postRun(stages, cp.dumpOutputs, outputDir());
+    for (auto& s : stages)
+        if (s.timer && !s.layer->isInputLayer) s.timer->getTime();
+    if (gpuRunTime) gpuRunTime->getTime();
+    cpuRunTime.stop();
+    if (rp.outputImages && rp.outputImages->size() > 0 && bindOutput) {
+        // the reference binds the last stage's texture to the caller's output image (Android path); here the caller's
+        // texture simply aliases the last stage output
+        (*rp.outputImages)[0].attach(&stages.back().stageOutputs[0]);
+    }
+    backend->cleanupRun();
+}
+
+void MixedInferenceCore::writeTimeStat(std::map<std::string, std::vector<double>>& timeArray) { // core.cpp:437-442
+    if (gpuRunTime) timeArray[gpuRunTime->getName()].push_back(gpuRunTime->duration() / 1000000.0);
+    for (auto& s : stages)
+        if (s.timer) timeArray[s.timer->getName()].push_back(s.timer->duration() / 1000000.0);
+}
+
+std::string MixedInferenceCore::describe() const {
+    std::ostringstream ss;
+    for (size_t i = 0; i < stages.size(); ++i) {
+        ss << "[" << i << "] " << stages[i].layer->name;
+        if (stages[i].fusedAway) ss << "  (fused into an earlier stage)";
+        ss << "\n";
+    }
+    return ss.str();
+}
+
+MixedInferenceCore::~MixedInferenceCore() {
+    stages.clear();
+    cp.layers.clear();
+    delete backend;
+    delete gpuRunTime;
+}

@@ -1,0 +1,245 @@
+// ic2/genericlayer.h -- layer base classes and the per-operator layer definitions of the hot path
+// (reference core/src/ic2/genericlayer.h:36-197, conv2d.h, separableconvolution.h, denselayer.h, subpixelmerge.h, inputlayer.h).
+// createCS() builds an executable HIP plan through the C-ABI instead of a SPIR-V pass.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ic2/backend.h"
+#include "ic2/modelparser.h"
+#include "snn/inferencegraph.h"
+#include "snn/layeroption.h"
+
+namespace snn {
+namespace dp {
+
+struct CommonLayerDesc {
+    bool isRange01 = false;
+    uint32_t numOutputPlanes = 0;
+    uint32_t numInputPlanes = 0;
+    uint32_t kernelSize = 0;
+    MRTMode mrtMode = MRTMode::NO;
+    WeightAccessMethod weightMode = WeightAccessMethod::CONSTANTS;
+    bool preferHp = false;
+    bool isInputLayer = false;
+    uint32_t inputIndex = 0;
+    void parse(ModelParser& parser, int layerId) {
+        isRange01 = parser.isInputRange01();
+        numOutputPlanes = static_cast<uint32_t>(parser.getOutputPlanes(layerId));
+        numInputPlanes = static_cast<uint32_t>(parser.getInputPlanes(layerId));
+        preferHp = parser.getPrecision();
+        mrtMode = parser.getMRTMode();
+        weightMode = parser.getWeightMode();
+    }
+};
+
+class GenericModelLayer {
+public:
+    struct LayerGenOptions : ShaderGenOptions {
+        uint32_t desiredOutputWidth = 0, desiredOutputHeight = 0;
+        bool isFirstLayer = false, isLastLayer = false;
+    };
+    explicit GenericModelLayer(CommonLayerDesc d) : _desc(d) {}
+    GenericModelLayer(const GenericModelLayer&) = delete;
+    GenericModelLayer& operator=(const GenericModelLayer&) = delete;
+    virtual ~GenericModelLayer();
+
+    const CommonLayerDesc& getDesc() const { return _desc; }
+    const std::string& getName() const { return name; }
+    void setName(const std::string& n) { name = n; }
+    const InferencePasses* getPasses() const { return passes.get(); }
+    std::vector<std::shared_ptr<RenderPass>>& getRenderPasses() { return renderPasses; }
+    bool isInputLayer() const { return _desc.isInputLayer; }
+    uint32_t getInputIndex() const { return _desc.inputIndex; }
+    void addInputDim(const InferenceGraph::IODesc& dim) { inputDims.push_back(dim); }
+    void setMRTMode(const MRTMode& m) { _desc.mrtMode = m; }
+    void setWeightAccessMode(const WeightAccessMethod& m) { _desc.weightMode = m; }
+
+    virtual void init(DeviceBackend* backend, ImageTextureArray& inputMat, ImageTextureArray& outputMat);
+    virtual void run(DeviceBackend* backend, bool dumpOutputs);
+    virtual void getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const;
+    virtual void computeImageTexture(ImageTextureArray&, ImageTextureArray&) {}
+    virtual void createInferencePasses(const LayerGenOptions& options) = 0;
+    virtual InferenceGraph::LayerExecutionType getLayerExecutionType() const = 0;
+    virtual void setLayerExecutionType(InferenceGraph::LayerExecutionType) = 0;
+
+    std::vector<std::shared_ptr<GenericModelLayer>> prevLayers;
+    std::vector<std::shared_ptr<GenericModelLayer>> nextLayers;
+
+protected:
+    std::string name;
+    CommonLayerDesc _desc;
+    std::vector<InferenceGraph::IODesc> inputDims;
+    InferencePassesSptr passes;
+    std::vector<std::shared_ptr<RenderPass>> renderPasses;
+
+private:
+    virtual InferenceGraph::Transform getOutputScaleDimAdjustment() const = 0;
+};
+
+struct GenericConvDesc : CommonLayerDesc {
+    std::vector<WeightMat> weightsCvM; // OC*IC (depthwise: C) matrices of k x k; the field name the reference tests fill
+    std::vector<double> biases;
+    std::string activation;
+    uint32_t stride = 0;
+    void parse(ModelParser& parser, int layerId) { CommonLayerDesc::parse(parser, layerId); }
+};
+
+class ShaderLayer : public GenericModelLayer {
+public:
+    explicit ShaderLayer(CommonLayerDesc d) : GenericModelLayer(d) {}
+    void createInferencePasses(const LayerGenOptions& options) override; // genericlayer.cpp:92-114
+    InferenceGraph::LayerExecutionType getLayerExecutionType() const override { return executeBackend; }
+    void setLayerExecutionType(InferenceGraph::LayerExecutionType e) override { executeBackend = e; }
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override { return InferenceGraph::Transform::identity(); }
+    virtual InferencePassesSptr createCS(const LayerGenOptions&) const = 0;
+    InferenceGraph::LayerExecutionType executeBackend = InferenceGraph::LayerExecutionType::GPU_HIP;
+};
+
+// ---- InputLayer (inputlayer.h)
+struct InputLayerDesc : CommonLayerDesc {
+    uint32_t inputHeight = 0, inputWidth = 0, inputChannels = 0;
+    void parse(ModelParser& parser, int layerId) {
+        CommonLayerDesc::parse(parser, layerId);
+        parser.getInputLayer(layerId, inputWidth, inputHeight, inputChannels, inputIndex);
+        isInputLayer = true;
+    }
+};
+class InputLayerLayer : public ShaderLayer {
+public:
+    explicit InputLayerLayer(InputLayerDesc d) : ShaderLayer(d), desc(d) {}
+
+private:
+    InferencePassesSptr createCS(const LayerGenOptions&) const override { SNN_RIP("Not implemented !"); }
+    InputLayerDesc desc;
+};
+
+// ---- Conv2D (conv2d.h, conv2d.cpp, conv2dVulkan.cpp)
+struct Conv2DDesc : GenericConvDesc {
+    bool useBatchNormalization = false;
+    bool useMultiInputs = false;
+    std::map<std::string, std::vector<float>> batchNormalization;
+    float leakyReluAlpha = 0.0f;
+    std::string padding;
+    bool useUniformShaders = true;
+    std::string paddingT, paddingB, paddingL, paddingR;
+    std::string paddingMode = "constant";
+    void parse(ModelParser& parser, int layerId);
+};
+class Conv2DLayer : public ShaderLayer {
+public:
+    explicit Conv2DLayer(Conv2DDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+    void getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const override;
+    const Conv2DDesc& convDesc() const { return _desc; }
+
+protected:
+    Conv2DDesc _desc;
+    void getPaddingOffset(uint32_t (&offsets)[4]) const; // conv2d.cpp:39-74
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override; // conv2d.cpp:102-113
+};
+class Conv2DLayerHip : public Conv2DLayer {
+public:
+    explicit Conv2DLayerHip(Conv2DDesc&& d) : Conv2DLayer(std::move(d)) {}
+
+private:
+    InferencePassesSptr createCS(const LayerGenOptions&) const override;
+};
+
+// ---- SeparableConv2D == depthwise (separableconvolution.h/.cpp, separableconvolutionVulkan.cpp)
+struct SeparableConv2DDesc : GenericConvDesc {
+    bool useBatchNormalization = false;
+    std::map<std::string, std::vector<float>> batchNormalization;
+    float leakyReluAlpha = 0.0f;
+    std::string paddingT, paddingB, paddingL, paddingR;
+    void parse(ModelParser& parser, int layerId);
+};
+class SeparableConv2DLayer : public ShaderLayer {
+public:
+    explicit SeparableConv2DLayer(SeparableConv2DDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+    void getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const override; // separableconvolution.cpp:77-86
+
+protected:
+    SeparableConv2DDesc _desc;
+    void getPaddingOffset(uint32_t (&offsets)[4]) const;
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override;
+};
+class SeparableConv2DLayerHip : public SeparableConv2DLayer {
+public:
+    explicit SeparableConv2DLayerHip(SeparableConv2DDesc&& d) : SeparableConv2DLayer(std::move(d)) {}
+
+private:
+    InferencePassesSptr createCS(const LayerGenOptions&) const override;
+};
+
+// ---- Dense (denselayer.h/.cpp, denselayerVulkan.cpp, cpulayer.h)
+struct DenseDesc : CommonLayerDesc {
+    std::vector<std::vector<float>> weights; // [In][Out]-shaped rows of the FLAT kernel; consumed flat as [Out][In]
+    std::vector<float> biases;
+    std::string activation;
+    int numInputUnits = 0, numOutputUnits = 0;
+    float leakyReluAlpha = 0.0f;
+    void parse(ModelParser& parser, int layerId) {
+        CommonLayerDesc::parse(parser, layerId);
+        parser.getDenseLayer(layerId, numOutputUnits, numInputUnits, activation, weights, biases, leakyReluAlpha);
+    }
+};
+class DenseLayer : public ShaderLayer {
+public:
+    explicit DenseLayer(DenseDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+    void getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const override; // denselayer.cpp:51-55
+
+protected:
+    DenseDesc _desc;
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override;
+};
+class DenseLayerHip : public DenseLayer {
+public:
+    explicit DenseLayerHip(DenseDesc&& d) : DenseLayer(std::move(d)) {}
+
+private:
+    InferencePassesSptr createCS(const LayerGenOptions&) const override;
+};
+
+// ---- Subpixel (subpixelmerge.h, subpixelmergeVulkan.cpp)
+struct SubpixelDesc : CommonLayerDesc {
+    uint32_t kernelSize = 2;
+    std::vector<double> biases;
+    void parse(ModelParser& parser, int layerId) {
+        CommonLayerDesc::parse(parser, layerId);
+        kernelSize = 2; // hard-coded in the reference (subpixelmerge.h:26-33)
+    }
+};
+class SubpixelLayer : public ShaderLayer {
+public:
+    explicit SubpixelLayer(SubpixelDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    SubpixelDesc _desc;
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override {
+        InferenceGraph::Transform t = InferenceGraph::Transform::identity();
+        t.scaleWidth = t.scaleHeight = static_cast<float>(_desc.kernelSize);
+        return t;
+    }
+};
+class SubpixelLayerHip : public SubpixelLayer {
+public:
+    explicit SubpixelLayerHip(SubpixelDesc&& d) : SubpixelLayer(std::move(d)) {}
+
+private:
+    InferencePassesSptr createCS(const LayerGenOptions&) const override;
+};
+
+} // namespace dp
+} // namespace snn

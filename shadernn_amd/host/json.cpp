@@ -1,0 +1,153 @@
+// json.cpp -- recursive-descent JSON parser for model files (see ic2/json.h).
+#include <cctype>
+#include <cstdlib>
+
+#include "ic2/json.h"
+
+namespace snn {
+namespace json {
+namespace {
+struct P {
+    const std::string& s;
+    size_t i = 0;
+    std::string err;
+    explicit P(const std::string& t) : s(t) {}
+    void ws() {
+        while (i < s.size() && isspace(static_cast<unsigned char>(s[i]))) ++i;
+    }
+    bool fail(const char* m) {
+        if (err.empty()) err = std::string(m) + " at offset " + std::to_string(i);
+        return false;
+    }
+    bool str(std::string& out) {
+        if (s[i] != '"') return fail("expected string");
+        ++i;
+        out.clear();
+        while (i < s.size() && s[i] != '"') {
+            if (s[i] == '\\' && i + 1 < s.size()) {
+                char c = s[i + 1];
+                i += 2;
+                switch (c) {
+                case 'n': out += '\n'; break;
+                case 't': out += '\t'; break;
+                case 'r': out += '\r'; break;
+                case 'b': out += '\b'; break;
+                case 'f': out += '\f'; break;
+                case 'u':
+                    if (i + 4 <= s.size()) {
+                        out += static_cast<char>(strtol(s.substr(i, 4).c_str(), nullptr, 16) & 0x7F);
+                        i += 4;
+                    }
+                    break;
+                default: out += c;
+                }
+            } else {
+                out += s[i++];
+            }
+        }
+        if (i >= s.size()) return fail("unterminated string");
+        ++i;
+        return true;
+    }
+    bool value(Value& v) {
+        ws();
+        if (i >= s.size()) return fail("unexpected end");
+        const char c = s[i];
+        if (c == '{') {
+            ++i;
+            v.type = Value::ObjectT;
+            v.obj = std::make_shared<Object>();
+            ws();
+            if (i < s.size() && s[i] == '}') {
+                ++i;
+                return true;
+            }
+            while (true) {
+                ws();
+                std::string k;
+                if (i >= s.size() || !str(k)) return fail("expected key");
+                ws();
+                if (i >= s.size() || s[i] != ':') return fail("expected ':'");
+                ++i;
+                Value child;
+                if (!value(child)) return false;
+                (*v.obj)[k] = std::move(child);
+                ws();
+                if (i < s.size() && s[i] == ',') {
+                    ++i;
+                    continue;
+                }
+                if (i < s.size() && s[i] == '}') {
+                    ++i;
+                    return true;
+                }
+                return fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            ++i;
+            v.type = Value::ArrayT;
+            v.arr = std::make_shared<Array>();
+            ws();
+            if (i < s.size() && s[i] == ']') {
+                ++i;
+                return true;
+            }
+            while (true) {
+                Value child;
+                if (!value(child)) return false;
+                v.arr->push_back(std::move(child));
+                ws();
+                if (i < s.size() && s[i] == ',') {
+                    ++i;
+                    continue;
+                }
+                if (i < s.size() && s[i] == ']') {
+                    ++i;
+                    return true;
+                }
+                return fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') {
+            v.type = Value::String;
+            return str(v.str);
+        }
+        if (!s.compare(i, 4, "true")) {
+            v.type = Value::Bool;
+            v.b = true;
+            i += 4;
+            return true;
+        }
+        if (!s.compare(i, 5, "false")) {
+            v.type = Value::Bool;
+            v.b = false;
+            i += 5;
+            return true;
+        }
+        if (!s.compare(i, 4, "null")) {
+            v.type = Value::Null;
+            i += 4;
+            return true;
+        }
+        const char* b = s.c_str() + i;
+        char* e = nullptr;
+        const double d = strtod(b, &e);
+        if (e == b) return fail("unexpected character");
+        v.type = Value::Number;
+        v.num = d;
+        i += static_cast<size_t>(e - b);
+        return true;
+    }
+};
+} // namespace
+
+std::string parse(Value& out, const std::string& text) {
+    P p(text);
+    if (!p.value(out)) return p.err;
+    p.ws();
+    if (p.i != text.size()) return "trailing characters at offset " + std::to_string(p.i);
+    return "";
+}
+} // namespace json
+} // namespace snn

@@ -1,0 +1,397 @@
+// layers.cpp -- layer definitions of the hot path + the layer factory
+// (reference core/src/ic2/genericlayer.cpp, conv2d.cpp, conv2dVulkan.cpp, separableconvolution*.cpp, denselayer*.cpp,
+//  subpixelmergeVulkan.cpp, layerFactory.cpp).  createCS() packs a host-side recipe; the backend turns it into a HIP plan.
+#include <algorithm>
+#include <unordered_map>
+
+#include "../../include/snnhip.h"
+#include "ic2/genericlayer.h"
+#include "ic2/layerFactory.h"
+
+using namespace snn;
+using namespace snn::dp;
+
+// ------------------------------------------------------------------------------------------------ GenericModelLayer
+
+GenericModelLayer::~GenericModelLayer() {
+    prevLayers.clear();
+    nextLayers.clear();
+}
+
+void GenericModelLayer::init(DeviceBackend* backend, ImageTextureArray& inputMat, ImageTextureArray& outputMat) {
+    SNN_LOGD("Layer initialized: %s", name.c_str());
+    backend->initRenderPasses(this, inputMat, outputMat);
+}
+
+void GenericModelLayer::run(DeviceBackend*, bool dumpOutputs) { // genericlayer.cpp:39-62
+    for (size_t passCount = 0; passCount < renderPasses.size(); ++passCount) {
+        auto& renderPass = renderPasses[passCount];
+        const bool lastPass = passCount == renderPasses.size() - 1;
+        if (dumpOutputs && lastPass) {
+            if (!renderPass->debugPassInputs(outputDir())) SNN_LOGE("Error dumping inputs for layer %s", name.c_str());
+            if (!renderPass->debugPassWeights(outputDir(), static_cast<int>(passCount))) SNN_LOGE("Error dumping weights for layer %s", name.c_str());
+        }
+        renderPass->run();
+        if (dumpOutputs && lastPass) {
+            if (!renderPass->debugPassOutput(outputDir())) SNN_LOGE("Error dumping outputs for layer %s", name.c_str());
+        }
+    }
+}
+
+// genericlayer.cpp:64-90: float arithmetic, max() accumulation (a negative translation is clamped to 0), truncation
+void GenericModelLayer::getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const {
+    width = height = depth = 0U;
+    InferenceGraph::Transform acc;
+    acc.isFixed = false;
+    acc.scaleWidth = acc.scaleHeight = acc.translateWidth = acc.translateHeight = 0.0f;
+    const InferenceGraph::Transform t = getOutputScaleDimAdjustment();
+    for (auto& dim : inputDims) {
+        if (!t.isFixed) {
+            acc.scaleWidth = std::max(acc.scaleWidth, t.scaleWidth * dim.width);
+            acc.translateWidth = std::max(acc.translateWidth, t.translateWidth);
+            acc.scaleHeight = std::max(acc.scaleHeight, t.scaleHeight * dim.height);
+            acc.translateHeight = std::max(acc.translateHeight, t.translateHeight);
+            width = static_cast<uint32_t>(acc.scaleWidth + acc.translateWidth);
+            height = static_cast<uint32_t>(acc.scaleHeight + acc.translateHeight);
+            depth = std::max(depth, dim.channels);
+        } else {
+            width = t.fixedWidth;
+            height = t.fixedHeight;
+            depth = std::max(depth, dim.channels);
+        }
+    }
+}
+
+void ShaderLayer::createInferencePasses(const LayerGenOptions& options) { // genericlayer.cpp:92-114 (vulkan/compute/FS choice collapses to HIP)
+    InferencePassesSptr ret = createCS(options);
+    setLayerExecutionType(InferenceGraph::LayerExecutionType::GPU_HIP);
+    SNN_ASSERT(ret);
+    passes = ret;
+}
+
+// ------------------------------------------------------------------------------------------------ shared helpers
+
+static void paddingOffsets(const std::string& paddingT, const std::string& paddingB, const std::string& paddingL, const std::string& paddingR,
+                           uint32_t kernelSize, uint32_t (&offsets)[4]) { // conv2d.cpp:39-74 == separableconvolution.cpp:27-62
+    const bool isdigit = std::all_of(paddingT.begin(), paddingT.end(), ::isdigit);
+    if (isdigit && !paddingT.empty()) {
+        offsets[0] = static_cast<uint32_t>(std::stoul(paddingT));
+        offsets[1] = static_cast<uint32_t>(std::stoul(paddingB));
+        offsets[2] = static_cast<uint32_t>(std::stoul(paddingL));
+        offsets[3] = static_cast<uint32_t>(std::stoul(paddingR));
+    } else if (paddingT == "valid" || paddingT == "none") {
+        offsets[0] = offsets[1] = offsets[2] = offsets[3] = 0;
+    } else if (kernelSize > 1) {
+        offsets[0] = offsets[1] = offsets[2] = offsets[3] = std::max(kernelSize / 2, 1u);
+        if (kernelSize % 2 == 0) {
+            offsets[0] -= 1;
+            offsets[2] -= 1;
+        }
+    } else {
+        offsets[0] = offsets[1] = offsets[2] = offsets[3] = 0;
+    }
+}
+
+static InferenceGraph::Transform convTransform(const uint32_t (&offset)[4], uint32_t kernelSize, uint32_t stride) { // conv2d.cpp:102-113
+    InferenceGraph::Transform t = InferenceGraph::Transform::identity();
+    const float scale = 1 / static_cast<float>(stride);
+    float translation;
+    if (kernelSize % 2 != 0) {
+        translation = 1 + (static_cast<float>(offset[0] + offset[1]) - static_cast<float>(kernelSize)) / static_cast<float>(stride);
+    } else {
+        translation = 1 + (static_cast<float>(offset[0] + offset[1] - 1) - static_cast<float>(kernelSize)) / static_cast<float>(stride);
+    }
+    t.scaleWidth = t.scaleHeight = scale;
+    t.translateWidth = t.translateHeight = translation;
+    return t;
+}
+
+static int activationId(const std::string& a) { // conv2dVulkan.cpp:58-72
+    if (a == "relu") return SNNHIP_ACT_RELU;
+    if (a == "relu6") return SNNHIP_ACT_RELU6;
+    if (a == "tanh") return SNNHIP_ACT_TANH;
+    if (a == "sigmoid") return SNNHIP_ACT_SIGMOID;
+    if (a == "leakyRelu") return SNNHIP_ACT_LEAKY;
+    if (a == "SiLU") return getenv("SNN_SILU_QUIRK") ? SNNHIP_ACT_SILU_QUIRK : SNNHIP_ACT_SILU;
+    return SNNHIP_ACT_NONE;
+}
+
+static int paddingModeId(const std::string& m) { // conv2dVulkan.cpp:74-81
+    if (m == "constant") return SNNHIP_PAD_CONSTANT;
+    if (m == "replicate") return SNNHIP_PAD_REPLICATE;
+    if (m == "reflect") return SNNHIP_PAD_REFLECT;
+    return SNNHIP_PAD_NONE;
+}
+
+struct BnArrays {
+    std::vector<float> beta, gamma, mean, var;
+};
+static BnArrays bnArrays(bool use, const std::map<std::string, std::vector<float>>& bn) {
+    BnArrays a;
+    if (use) {
+        a.beta = bn.at("beta");
+        a.gamma = bn.at("gamma");
+        a.mean = bn.at("movingMean");
+        a.var = bn.at("movingVariance");
+    }
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------------ Conv2D
+
+void Conv2DDesc::parse(ModelParser& parser, int layerId) { // conv2d.cpp:22-32
+    GenericConvDesc::parse(parser, layerId);
+    int oc = 0, ic = 0, k = 0, s = 0;
+    parser.getConvolutionLayer(layerId, oc, ic, activation, k, s, biases, weightsCvM, useBatchNormalization, batchNormalization, leakyReluAlpha,
+                               paddingT, paddingB, paddingL, paddingR, paddingMode, useMultiInputs);
+    numOutputPlanes = static_cast<uint32_t>(oc);
+    numInputPlanes = static_cast<uint32_t>(ic);
+    kernelSize = static_cast<uint32_t>(k);
+    stride = static_cast<uint32_t>(s);
+}
+
+void Conv2DLayer::getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const { // conv2d.cpp:34-37
+    GenericModelLayer::getOutputDims(width, height, depth);
+    depth = _desc.numOutputPlanes;
+}
+
+void Conv2DLayer::getPaddingOffset(uint32_t (&offsets)[4]) const {
+    paddingOffsets(_desc.paddingT, _desc.paddingB, _desc.paddingL, _desc.paddingR, _desc.kernelSize, offsets);
+}
+
+InferenceGraph::Transform Conv2DLayer::getOutputScaleDimAdjustment() const {
+    uint32_t offset[4];
+    getPaddingOffset(offset);
+    return convTransform(offset, _desc.kernelSize, _desc.stride);
+}
+
+InferencePassesSptr Conv2DLayerHip::createCS(const LayerGenOptions&) const { // counterpart of conv2dVulkan.cpp:38-239
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    uint32_t ow = 0, oh = 0, od = 0;
+    getOutputDims(ow, oh, od);
+    uint32_t pad[4];
+    getPaddingOffset(pad);
+    snnhip_conv2d_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(inputDims[0].height);
+    d.W = static_cast<int>(inputDims[0].width);
+    d.IC = static_cast<int>(_desc.numInputPlanes);
+    d.OC = static_cast<int>(_desc.numOutputPlanes);
+    d.kh = d.kw = static_cast<int>(_desc.kernelSize);
+    d.sh = d.sw = static_cast<int>(_desc.stride);
+    d.padT = static_cast<int>(pad[0]);
+    d.padB = static_cast<int>(pad[1]);
+    d.padL = static_cast<int>(pad[2]);
+    d.padR = static_cast<int>(pad[3]);
+    d.padMode = paddingModeId(_desc.paddingMode);
+    d.act = activationId(_desc.activation);
+    d.leaky = _desc.leakyReluAlpha;
+    d.useBias = _desc.biases.empty() ? 0 : 1; // conv2dVulkan.cpp:118-121
+    d.useBN = _desc.useBatchNormalization ? 1 : 0;
+    d.dtype = SNNHIP_F32;
+    d.OH = static_cast<int>(oh);
+    d.OW = static_cast<int>(ow);
+    const int taps = d.kh * d.kw;
+    SNN_CHK(_desc.weightsCvM.size() == static_cast<size_t>(d.OC) * d.IC);
+    std::vector<float> oihw(static_cast<size_t>(d.OC) * d.IC * taps);
+    for (size_t m = 0; m < _desc.weightsCvM.size(); ++m)
+        for (int t = 0; t < taps; ++t) oihw[m * taps + t] = _desc.weightsCvM[m].at<float>(t);
+    std::vector<float> bias(static_cast<size_t>(d.OC), 0.0f);
+    for (size_t i = 0; i < _desc.biases.size() && i < bias.size(); ++i) bias[i] = static_cast<float>(_desc.biases[i]);
+    BnArrays bn = bnArrays(_desc.useBatchNormalization, _desc.batchNormalization);
+    InferencePass& pass = ret->passes[0];
+    pass.source = formatString("Conv2D k=%d s=%d %d->%d act=%s", d.kh, d.sh, d.IC, d.OC, _desc.activation.c_str());
+    pass.createPlan = [d, oihw, bias, bn](snnhip_ctx* ctx, snnhip_plan** out) {
+        return snnhip_conv2d_plan_create(ctx, &d, oihw.data(), bias.data(), d.useBN ? bn.beta.data() : nullptr, d.useBN ? bn.gamma.data() : nullptr,
+                                         d.useBN ? bn.mean.data() : nullptr, d.useBN ? bn.var.data() : nullptr, out);
+    };
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------------ SeparableConv2D (depthwise)
+
+void SeparableConv2DDesc::parse(ModelParser& parser, int layerId) { // separableconvolution.h:38-42
+    GenericConvDesc::parse(parser, layerId);
+    int oc = 0, ic = 0, k = 0, s = 0;
+    parser.getDepthwiseConvolutionLayer(layerId, oc, ic, activation, k, s, biases, weightsCvM, useBatchNormalization, batchNormalization,
+                                        leakyReluAlpha, paddingT, paddingB, paddingL, paddingR);
+    numOutputPlanes = static_cast<uint32_t>(oc);
+    numInputPlanes = static_cast<uint32_t>(ic);
+    kernelSize = static_cast<uint32_t>(k);
+    stride = static_cast<uint32_t>(s);
+}
+
+void SeparableConv2DLayer::getPaddingOffset(uint32_t (&offsets)[4]) const {
+    paddingOffsets(_desc.paddingT, _desc.paddingB, _desc.paddingL, _desc.paddingR, _desc.kernelSize, offsets);
+}
+
+InferenceGraph::Transform SeparableConv2DLayer::getOutputScaleDimAdjustment() const { // separableconvolution.cpp:64-75
+    uint32_t offset[4];
+    getPaddingOffset(offset);
+    return convTransform(offset, _desc.kernelSize, _desc.stride);
+}
+
+void SeparableConv2DLayer::getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const { // separableconvolution.cpp:77-86 (integer rule)
+    uint32_t p[4];
+    getPaddingOffset(p);
+    for (auto& dim : inputDims) {
+        width = (dim.width - _desc.kernelSize + p[0] + p[2]) / _desc.stride + 1;
+        height = (dim.height - _desc.kernelSize + p[1] + p[3]) / _desc.stride + 1;
+        depth = dim.depth;
+        break;
+    }
+}
+
+InferencePassesSptr SeparableConv2DLayerHip::createCS(const LayerGenOptions&) const { // separableconvolutionVulkan.cpp:32-160
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    uint32_t ow = 0, oh = 0, od = 0;
+    GenericModelLayer::getOutputDims(ow, oh, od); // the Vulkan pass uses the GENERIC float rule here (:50), not the integer one above
+    uint32_t pad[4];
+    getPaddingOffset(pad);
+    snnhip_conv2d_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(inputDims[0].height);
+    d.W = static_cast<int>(inputDims[0].width);
+    d.IC = d.OC = static_cast<int>(_desc.numOutputPlanes);
+    d.kh = d.kw = static_cast<int>(_desc.kernelSize);
+    d.sh = d.sw = static_cast<int>(_desc.stride);
+    d.padT = static_cast<int>(pad[0]);
+    d.padB = static_cast<int>(pad[1]);
+    d.padL = static_cast<int>(pad[2]);
+    d.padR = static_cast<int>(pad[3]);
+    d.padMode = SNNHIP_PAD_CONSTANT; // spec id 16 is never set: always zero padding by tap clipping (:111-135)
+    d.act = activationId(_desc.activation);
+    d.leaky = _desc.leakyReluAlpha;
+    d.useBias = 1; // no useBias constant: the bias buffer is always read
+    d.useBN = _desc.useBatchNormalization ? 1 : 0;
+    d.dtype = SNNHIP_F32;
+    d.OH = static_cast<int>(oh);
+    d.OW = static_cast<int>(ow);
+    const int taps = d.kh * d.kw;
+    SNN_CHK(_desc.weightsCvM.size() == static_cast<size_t>(d.OC));
+    std::vector<float> chw(static_cast<size_t>(d.OC) * taps);
+    for (size_t m = 0; m < _desc.weightsCvM.size(); ++m)
+        for (int t = 0; t < taps; ++t) chw[m * taps + t] = _desc.weightsCvM[m].at<float>(t);
+    std::vector<float> bias(static_cast<size_t>(d.OC), 0.0f);
+    for (size_t i = 0; i < _desc.biases.size() && i < bias.size(); ++i) bias[i] = static_cast<float>(_desc.biases[i]);
+    BnArrays bn = bnArrays(_desc.useBatchNormalization, _desc.batchNormalization);
+    InferencePass& pass = ret->passes[0];
+    pass.source = formatString("DepthwiseConv2D k=%d s=%d c=%d act=%s", d.kh, d.sh, d.OC, _desc.activation.c_str());
+    pass.createPlan = [d, chw, bias, bn](snnhip_ctx* ctx, snnhip_plan** out) {
+        return snnhip_depthwise_plan_create(ctx, &d, chw.data(), bias.data(), d.useBN ? bn.beta.data() : nullptr, d.useBN ? bn.gamma.data() : nullptr,
+                                            d.useBN ? bn.mean.data() : nullptr, d.useBN ? bn.var.data() : nullptr, out);
+    };
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------------ Dense
+
+InferenceGraph::Transform DenseLayer::getOutputScaleDimAdjustment() const { // denselayer.cpp:40-49
+    InferenceGraph::Transform ret;
+    ret.isFixed = true;
+    ret.fixedWidth = static_cast<uint32_t>(_desc.biases.size());
+    ret.fixedHeight = 1;
+    ret.fixedDepth = 1;
+    ret.fixedBatch = 1;
+    return ret;
+}
+
+void DenseLayer::getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const {
+    width = static_cast<uint32_t>(_desc.biases.size());
+    height = 1;
+    depth = 1;
+}
+
+// The reference runs Dense on the CPU through Eigen (denselayer.cpp:27-38, cpulayer.h:136-266) after a sync + download.
+// Here it is a GPU plan with the CPU path's semantics: flat kernel read as [Out][In], HWC flatten order, CPU activation
+// table -- including unordered_map::operator[] turning unknown names ("linear", "relu6") into RELU (cpulayer.h:38-42,200).
+InferencePassesSptr DenseLayerHip::createCS(const LayerGenOptions&) const {
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    snnhip_dense_desc d = {};
+    d.batch = 1;
+    d.out_units = static_cast<int>(_desc.biases.size());
+    std::vector<float> flat;
+    for (auto& row : _desc.weights) flat.insert(flat.end(), row.begin(), row.end()); // CPUCommonUtil::flatten2d
+    SNN_CHK(d.out_units > 0 && flat.size() % static_cast<size_t>(d.out_units) == 0);
+    d.in_units = static_cast<int>(flat.size() / static_cast<size_t>(d.out_units));
+    const std::string& a = _desc.activation;
+    if (a == "relu") d.act = SNNHIP_DENSE_RELU;
+    else if (a == "leakyRelu") d.act = SNNHIP_DENSE_LEAKY;
+    else if (a == "sigmoid") d.act = SNNHIP_DENSE_SIGMOID;
+    else if (a == "softmax") d.act = SNNHIP_DENSE_SOFTMAX;
+    else if (a == "tanh") d.act = SNNHIP_DENSE_TANH;
+    else if (a == "SiLU") d.act = SNNHIP_DENSE_SILU_NOOP;
+    else if (a == "identity" || a.empty()) d.act = SNNHIP_DENSE_IDENTITY;
+    else {
+        SNN_LOGW("Dense activation \"%s\" is not in the reference CPU table: it becomes ReLU there (cpulayer.h:38-42), reproduced", a.c_str());
+        d.act = SNNHIP_DENSE_RELU;
+    }
+    d.leaky = _desc.leakyReluAlpha;
+    d.useBias = 1;
+    std::vector<float> bias = _desc.biases;
+    InferencePass& pass = ret->passes[0];
+    pass.source = formatString("Dense %d->%d act=%s", d.in_units, d.out_units, a.c_str());
+    pass.createPlan = [d, flat, bias](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_dense_plan_create(ctx, &d, flat.data(), bias.data(), out); };
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------------ Subpixel
+
+InferencePassesSptr SubpixelLayerHip::createCS(const LayerGenOptions&) const { // subpixelmergeVulkan.cpp:29-91
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    snnhip_subpixel_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(inputDims[0].height);
+    d.W = static_cast<int>(inputDims[0].width);
+    d.C = static_cast<int>(inputDims[0].channels);
+    d.factor = 2;
+    // default = true depth-to-space (GL shader / Keras); SNN_SUBPIXEL_VK_QUIRK=1 reproduces vk_subpixel.comp:57-66
+    d.mode = getenv("SNN_SUBPIXEL_VK_QUIRK") ? SNNHIP_SUBPIXEL_VK_QUIRK : SNNHIP_SUBPIXEL_D2S;
+    InferencePass& pass = ret->passes[0];
+    pass.source = "Subpixel depth_to_space(2)+tanh";
+    pass.createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_subpixel_plan_create(ctx, &d, out); };
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------------ layer factory
+
+static std::unordered_map<std::string, LayerCreator> LayerRegistryDict;
+
+static GenericModelLayer* InputLayerCreator(ModelParser& parser, int i, bool) {
+    InputLayerDesc desc;
+    desc.parse(parser, i);
+    return new InputLayerLayer(desc);
+}
+#define DEFINE_HIP_CREATOR(layer)                                                   \
+    static GenericModelLayer* layer##Creator(ModelParser& parser, int i, bool) {    \
+        layer##Desc desc;                                                           \
+        desc.parse(parser, i);                                                      \
+        return new layer##LayerHip(std::move(desc));                                \
+    }                                                                               \
+    GenericModelLayer* snn::dp::layer##Creator1(layer##Desc&& desc, bool) { return new layer##LayerHip(std::move(desc)); }
+DEFINE_HIP_CREATOR(Conv2D)
+DEFINE_HIP_CREATOR(SeparableConv2D)
+DEFINE_HIP_CREATOR(Dense)
+DEFINE_HIP_CREATOR(Subpixel)
+
+void snn::dp::registerLayer(const std::string& layerName, LayerCreator creator) { LayerRegistryDict.emplace(layerName, creator); }
+
+void snn::dp::initLayerRegisty() { // layerFactory.cpp:109-129 (only the hot-path operators exist in this backend)
+    registerLayer("InputLayer", InputLayerCreator);
+    registerLayer("Conv2D", Conv2DCreator);
+    registerLayer("SeparableConv2D", SeparableConv2DCreator);
+    registerLayer("Dense", DenseCreator);
+    registerLayer("Subpixel", SubpixelCreator);
+}
+
+GenericModelLayer* snn::dp::createLayerInstance(std::string layerName, ModelParser& parser, int i, bool useVulkan) { // layerFactory.cpp:136-159
+    if (layerName == "DepthwiseConv2D" || layerName == "Depthwise") layerName = "SeparableConv2D";
+    if (layerName == "subpixel" || layerName == "depth_to_space") layerName = "Subpixel";
+    auto it = LayerRegistryDict.find(layerName);
+    if (it == LayerRegistryDict.end()) SNN_RIP("Not found layer: %s", layerName.c_str());
+    return it->second(parser, i, useVulkan);
+}

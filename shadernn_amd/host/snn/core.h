@@ -1,0 +1,71 @@
+// snn/core.h -- MixedInferenceCore / RenderStage (reference core/inc/snn/core.h:37-146).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "snn/deviceTimer.h"
+#include "snn/inferencegraph.h"
+#include "snn/layeroption.h"
+#include "snn/snn.h"
+
+namespace snn {
+namespace dp {
+class DeviceBackend;
+}
+typedef enum class Transition { Backend_CPU_GPU, Backend_GPU_CPU, NOT_DEFINED = 200 } Transition;
+
+struct RenderStage {
+    explicit RenderStage(GpuContext* context) : stageInputs(context), stageOutputs(context) {}
+    std::shared_ptr<InferenceGraph::Layer> layer;
+    bool flattenLayer = false;
+    std::shared_ptr<DeviceTimer> timer;
+    Backend backend = Backend::Backend_GPU;
+    Transition transition = Transition::NOT_DEFINED;
+    ImageTextureArray stageInputs;
+    ImageTextureArray stageOutputs;
+    std::vector<int> inputIds;
+    std::vector<int> delayBindMask;
+    bool fusedAway = false; // HIP extension: this stage's work is done by a chain plan launched from an earlier stage
+};
+typedef std::vector<RenderStage> RenderStagesArray;
+
+class MixedInferenceCore {
+public:
+    virtual ~MixedInferenceCore();
+    SNN_NO_COPY(MixedInferenceCore);
+    struct RunParameters {
+        ImageTextureArray* inputImages = nullptr;
+        ImageTextureArray* outputImages = nullptr;
+        std::vector<std::vector<std::vector<float>>> inputMatrix;
+        std::vector<std::vector<std::vector<float>>> output;
+        SNNModelOutput modelOutput;
+    };
+    void run(RunParameters& rp);
+    struct CreationParameters : InferenceGraph {
+        uint32_t outputWidth = 0, outputHeight = 0, outputDepth = 0;
+        bool dumpOutputs = false;
+        bool fuseChains = true;
+        bool profiling = false; // the reference enables per-stage timers at compile time (-DPROFILING, CMakeLists.txt:44-46)
+    };
+    static std::unique_ptr<MixedInferenceCore> create(GpuContext* context, const CreationParameters& cp);
+    static std::unique_ptr<MixedInferenceCore> create(GpuContext* context, const std::string& modelFileName, const dp::ShaderGenOptions& options,
+                                                      bool dumpOutputs = false);
+    void writeTimeStat(std::map<std::string, std::vector<double>>& timeArray);
+    size_t numStages() const { return stages.size(); }
+    RenderStage& stage(size_t i) { return stages[i]; }
+    std::string describe() const; // HIP extension: which kernel variant each stage runs
+
+private:
+    GpuContext* context;
+    bool bindOutput = true;
+    CreationParameters cp;
+    RenderStagesArray stages;
+    dp::DeviceBackend* backend = nullptr;
+    DeviceTimer* gpuRunTime = nullptr;
+    Timer cpuRunTime = Timer("IC2 Total CPU Runtime");
+    explicit MixedInferenceCore(GpuContext* context_);
+    bool init(const CreationParameters& cp);
+};
+} // namespace snn

@@ -1,0 +1,242 @@
+// snn_c.cpp -- C binding of the host mirror for tests / harnesses (see include/snn_c.h).
+#include <cstring>
+
+#include "../../include/snn_c.h"
+#include "ic2/backend.h"
+#include "ic2/dp.h"
+#include "ic2/layerFactory.h"
+#include "snn/contextFactory.h"
+#include "snn/core.h"
+
+using namespace snn;
+
+struct snn_model {
+    GpuContext* context = nullptr;
+    std::unique_ptr<MixedInferenceCore> core;
+    ImageTextureArray inputs{nullptr};
+    ImageTextureArray outputs{nullptr};
+    int inW = 0, inH = 0, inC = 0;
+};
+
+static dp::ShaderGenOptions makeOptions(int w, int h, int c, bool fuse) {
+    dp::ShaderGenOptions sgo;
+    InferenceGraph::IODesc in{ColorFormat::RGBA32F, static_cast<uint32_t>(w), static_cast<uint32_t>(h), static_cast<uint32_t>(UP_DIV(c, 4)),
+                              static_cast<uint32_t>(c)};
+    sgo.desiredInput.push_back(in);
+    sgo.desiredOutputFormat = ColorFormat::RGBA32F;
+    sgo.compute = true;
+    sgo.fuseChains = fuse;
+    return sgo;
+}
+
+static void makeIO(snn_model* m) {
+    m->inputs = ImageTextureArray(m->context);
+    m->outputs = ImageTextureArray(m->context);
+    m->inputs.push_back(ImageTextureFactory::createImageTexture(m->context, {static_cast<uint32_t>(m->inW), static_cast<uint32_t>(m->inH),
+                                                                             static_cast<uint32_t>(UP_DIV(m->inC, 4)), 1},
+                                                                ColorFormat::RGBA32F, nullptr, static_cast<uint32_t>(m->inC)));
+    m->outputs.allocate(1);
+}
+
+extern "C" {
+
+int snn_model_create(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
+                     snn_model** out) {
+    auto* m = new snn_model();
+    m->context = createHipContext(device);
+    m->inW = in_w;
+    m->inH = in_h;
+    m->inC = in_c;
+    dp::ShaderGenOptions sgo = makeOptions(in_w, in_h, in_c, fuse_chains != 0);
+    auto layers = dp::loadFromJsonModel(json_path, false, sgo.mrtMode, sgo.weightMode, false);
+    MixedInferenceCore::CreationParameters cp;
+    static_cast<InferenceGraph&>(cp) = dp::generateInferenceGraph(layers, sgo);
+    cp.dumpOutputs = dump_outputs != 0;
+    cp.fuseChains = fuse_chains != 0;
+    cp.profiling = profiling != 0;
+    m->core = MixedInferenceCore::create(m->context, cp);
+    makeIO(m);
+    *out = m;
+    return 0;
+}
+
+int snn_model_destroy(snn_model* m) {
+    if (!m) return 0;
+    m->core.reset();
+    m->inputs = ImageTextureArray(nullptr);
+    m->outputs = ImageTextureArray(nullptr);
+    delete m->context;
+    delete m;
+    return 0;
+}
+
+int snn_model_upload_input(snn_model* m, const float* nhwc) {
+    m->inputs[0].uploadNHWC(nhwc);
+    return 0;
+}
+
+int snn_model_run(snn_model* m) {
+    MixedInferenceCore::RunParameters rp;
+    rp.inputImages = &m->inputs;
+    rp.outputImages = &m->outputs;
+    m->core->run(rp);
+    return 0;
+}
+
+static ImageTexture& lastOutput(snn_model* m) { return m->core->stage(m->core->numStages() - 1).stageOutputs[0]; }
+
+int snn_model_output_dims(snn_model* m, int hwc[3]) {
+    ImageTexture& t = lastOutput(m);
+    hwc[0] = static_cast<int>(t.height());
+    hwc[1] = static_cast<int>(t.width());
+    hwc[2] = static_cast<int>(t.channels());
+    return 0;
+}
+
+int snn_model_download_output(snn_model* m, float* nhwc) {
+    lastOutput(m).downloadNHWC(nhwc);
+    return 0;
+}
+
+int snn_model_num_stages(snn_model* m) { return static_cast<int>(m->core->numStages()); }
+
+int snn_model_stage_info(snn_model* m, int stage, char* name, int name_len, int hwc[3], int* fused_away) {
+    RenderStage& s = m->core->stage(static_cast<size_t>(stage));
+    snprintf(name, static_cast<size_t>(name_len), "%s", s.layer->name.c_str());
+    hwc[0] = static_cast<int>(s.layer->outputDesc.height);
+    hwc[1] = static_cast<int>(s.layer->outputDesc.width);
+    hwc[2] = static_cast<int>(s.layer->outputDesc.channels);
+    *fused_away = s.fusedAway ? 1 : 0;
+    return 0;
+}
+
+int snn_model_download_stage(snn_model* m, int stage, float* nhwc) {
+    RenderStage& s = m->core->stage(static_cast<size_t>(stage));
+    if (s.layer->isInputLayer || s.stageOutputs.size() == 0 || !s.stageOutputs[0].isValid()) return -1;
+    s.stageOutputs[0].downloadNHWC(nhwc);
+    return 0;
+}
+
+int snn_model_describe(snn_model* m, char* buf, int buflen) {
+    snprintf(buf, static_cast<size_t>(buflen), "%s", m->core->describe().c_str());
+    return 0;
+}
+
+int snn_model_time_stats(snn_model* m, char* names, int names_len, double* ms, int max_entries) {
+    std::map<std::string, std::vector<double>> t;
+    m->core->writeTimeStat(t);
+    int n = 0;
+    std::string all;
+    for (auto& kv : t) {
+        if (n >= max_entries) break;
+        ms[n++] = kv.second.empty() ? 0.0 : kv.second.back();
+        all += kv.first + "\n";
+    }
+    snprintf(names, static_cast<size_t>(names_len), "%s", all.c_str());
+    return n;
+}
+
+int snn_conv_test_with_layer(int device, const float* input_hwc, const float* weights_oihw, const float* bias, int width, int height, int in_channels,
+                             int out_channels, int kernel, int stride, int pad, int use_bn, const float* bn_gamma, const float* bn_mean,
+                             const float* bn_var, const float* bn_beta, char* dump_path, int dump_path_len) {
+    // ---- shaderUnitTest.cpp:192-230: hand-built InputLayer + Conv2D
+    dp::InputLayerDesc inputDesc;
+    inputDesc.inputHeight = static_cast<uint32_t>(width); // (sic) the reference swaps the two, shaderUnitTest.cpp:193-194
+    inputDesc.inputWidth = static_cast<uint32_t>(height);
+    inputDesc.inputChannels = static_cast<uint32_t>(in_channels);
+    inputDesc.numInputPlanes = inputDesc.numOutputPlanes = static_cast<uint32_t>(in_channels);
+    inputDesc.isInputLayer = true;
+    auto inputLayer = std::make_shared<dp::InputLayerLayer>(inputDesc);
+    inputLayer->setName("resnet18_cifar10_0223.json layer [00] InputLayerLayer");
+
+    dp::Conv2DDesc desc;
+    desc.isRange01 = false;
+    desc.numOutputPlanes = static_cast<uint32_t>(out_channels);
+    desc.numInputPlanes = static_cast<uint32_t>(in_channels);
+    for (int p = 0; p < in_channels * out_channels; ++p) {
+        WeightMat m(kernel, kernel);
+        memcpy(m.data.data(), weights_oihw + static_cast<size_t>(p) * kernel * kernel, sizeof(float) * kernel * kernel);
+        desc.weightsCvM.push_back(m);
+    }
+    for (int o = 0; o < out_channels; ++o) desc.biases.push_back(bias ? bias[o] : 0.0);
+    desc.activation = "";
+    desc.kernelSize = static_cast<uint32_t>(kernel);
+    desc.stride = static_cast<uint32_t>(stride);
+    desc.useBatchNormalization = use_bn != 0;
+    if (use_bn) {
+        desc.batchNormalization["gamma"].assign(bn_gamma, bn_gamma + out_channels);
+        desc.batchNormalization["movingMean"].assign(bn_mean, bn_mean + out_channels);
+        desc.batchNormalization["movingVariance"].assign(bn_var, bn_var + out_channels);
+        desc.batchNormalization["beta"].assign(bn_beta, bn_beta + out_channels);
+    }
+    desc.useMultiInputs = false;
+    desc.padding = "same";
+    desc.paddingT = desc.paddingB = desc.paddingL = desc.paddingR = std::to_string(kernel / 2);
+    desc.paddingMode = pad == 0 ? "constant" : pad == 1 ? "replicate" : "reflect";
+    desc.weightMode = WeightAccessMethod::TEXTURES;
+    std::shared_ptr<dp::GenericModelLayer> layer(dp::Conv2DCreator1(std::move(desc), false));
+    layer->prevLayers.push_back(inputLayer);
+    layer->setName("resnet18_cifar10_0223.json layer [01] Conv2D");
+    inputLayer->nextLayers.push_back(layer);
+    std::vector<std::shared_ptr<dp::GenericModelLayer>> layers{inputLayer, layer};
+
+    // ---- :248-273: options, graph, textures, create, run
+    snn_model m;
+    m.context = createHipContext(device);
+    m.inW = width;
+    m.inH = height;
+    m.inC = in_channels;
+    dp::ShaderGenOptions sgo = makeOptions(width, height, in_channels, false);
+    MixedInferenceCore::CreationParameters graph;
+    static_cast<InferenceGraph&>(graph) = dp::generateInferenceGraph(layers, sgo);
+    graph.dumpOutputs = true;
+    makeIO(&m);
+    m.inputs[0].uploadNHWC(input_hwc); // hwcToC4 + upload in the reference (:244-246, :265)
+    m.core = MixedInferenceCore::create(m.context, graph);
+    MixedInferenceCore::RunParameters rp;
+    rp.inputImages = &m.inputs;
+    rp.outputImages = &m.outputs;
+    m.core->run(rp);
+    snprintf(dump_path, static_cast<size_t>(dump_path_len), "%s/%s pass[0].dump", outputDir(), layer->getName().c_str()); // :275
+    m.core.reset();
+    m.inputs = ImageTextureArray(nullptr);
+    m.outputs = ImageTextureArray(nullptr);
+    layers.clear();
+    layer.reset();
+    inputLayer->nextLayers.clear();
+    inputLayer.reset();
+    delete m.context;
+    return 0;
+}
+
+int snn_graph_summary(const char* json_path, int in_w, int in_h, int in_c, char* buf, int buflen) {
+    dp::ShaderGenOptions sgo = makeOptions(in_w, in_h, in_c, true);
+    auto layers = dp::loadFromJsonModel(json_path, false, sgo.mrtMode, sgo.weightMode, false);
+    InferenceGraph g = dp::generateInferenceGraph(layers, sgo);
+    std::string out;
+    for (size_t i = 0; i < g.layers.size(); ++i) {
+        auto& l = *g.layers[i];
+        std::string ins;
+        for (auto& r : l.inputRefs) ins += (ins.empty() ? "" : ",") + std::to_string(r.index);
+        out += formatString("%zu|%s|%d|%ux%ux%u|%s\n", i, l.name.c_str(), static_cast<int>(l.layerLoc), l.outputDesc.width, l.outputDesc.height,
+                            l.outputDesc.channels, ins.c_str());
+    }
+    snprintf(buf, static_cast<size_t>(buflen), "%s", out.c_str());
+    return static_cast<int>(g.layers.size());
+}
+
+int snn_dump_read(const char* path, int whdc[4], float* out, long out_floats) {
+    RawImage img = RawImage::loadFromBIN(path);
+    whdc[0] = static_cast<int>(img.width());
+    whdc[1] = static_cast<int>(img.height());
+    whdc[2] = static_cast<int>(img.depth());
+    whdc[3] = static_cast<int>(img.channels());
+    if (out) {
+        const long n = static_cast<long>(img.size() / sizeof(float));
+        if (n > out_floats) return -1;
+        memcpy(out, img.data(), img.size());
+    }
+    return 0;
+}
+
+} // extern "C"

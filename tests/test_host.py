@@ -1,0 +1,168 @@
+"""The C++ host mirror of the reference API (shadernn_amd/host -> libsnn_core.so) driven the way the reference's harnesses drive
+the original: JSON model -> ModelParser -> layer DAG -> InferenceGraph -> MixedInferenceCore::create/run -> .dump files."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def _json(tmp_path, net, w, h):
+    from shadernn_amd import models
+
+    return models.write_json(net, w, h, str(tmp_path / (net["name"] + ".json")))
+
+
+def test_core_library_exports_declared_symbols(built):
+    from shadernn_amd import host
+
+    l = host.lib()
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "snn_c.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(snn_[a-z0-9_]+)\s*\(", txt)))
+    assert declared == sorted(host.SIGNATURES)
+    for name in declared:
+        assert hasattr(ctypes.CDLL(host.LIB_PATH), name)
+    assert l is not None
+
+
+def test_parser_and_graph_on_cpu(built, tmp_path):
+    """No GPU needed: plan creation is deferred to the backend, like pipeline creation in the reference."""
+    from shadernn_amd import host, models
+
+    net = models.espcn_weights(seed=1)
+    rows = host.graph_summary(_json(tmp_path, net, 96, 72), 96, 72, 1)
+    assert [r["name"].split("] ")[1] for r in rows] == ["InputLayer", "Conv2D", "Conv2D", "Conv2D", "subpixel"]  # 5 layers
+    assert rows[0]["name"].endswith("layer [00] InputLayer")
+    assert [r["dims"] for r in rows] == [(96, 72, 1), (96, 72, 16), (96, 72, 16), (96, 72, 4), (192, 144, 1)]
+    assert [r["inputs"] for r in rows] == [[-1], [0], [1], [2], [3]]
+    assert all(r["loc"] == 4 for r in rows)  # LayerExecutionType::GPU_HIP
+
+
+def test_parser_shape_rules_on_cpu(built, tmp_path):
+    from shadernn_amd import host, models
+
+    rng = np.random.default_rng(0)
+    net = {"name": "shapes", "input_channels": 3, "layers": [
+        models._conv(rng, "c7", 3, 8, 7, "relu", stride=2, bn=True),      # 224 -> 112 (float rule)
+        models._depthwise(rng, "dw", 8, 3, "relu6", stride=2, bn=True),   # 112 -> 56
+        models._conv(rng, "pw", 8, 12, 1, "linear", stride=2),            # 56 -> 28, 1x1 has no padding
+        models._conv(rng, "k4", 12, 4, 4, "leakyRelu"),                   # even kernel: asymmetric padding, same size
+        models._conv(rng, "valid", 4, 4, 3, "relu", padding="valid"),     # Q20: "valid" keeps the size
+    ]}
+    net["layers"][3]["alpha"] = 0.2
+    rows = host.graph_summary(_json(tmp_path, net, 224, 224), 224, 224, 3)
+    assert [r["dims"] for r in rows] == [(224, 224, 3), (112, 112, 8), (56, 56, 8), (28, 28, 12), (28, 28, 4), (28, 28, 4)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [False, True])
+def test_espcn_json_model_end_to_end(ctx, tmp_path, fuse):
+    from shadernn_amd import host, models
+
+    net = models.espcn_weights(seed=1)
+    W, H = 96, 72
+    x = np.random.default_rng(7767517).random((1, H, W, 1), dtype=np.float32)
+    m = host.Model(_json(tmp_path, net, W, H), W, H, 1, fuse_chains=fuse, profiling=True)
+    y = m(x)
+    want, layers = O.forward(net, x, return_layers=True)
+    np.testing.assert_allclose(y, want[0], **TOL)
+    st = m.stages()
+    assert len(st) == 5
+    if fuse:
+        assert [s["fused_away"] for s in st] == [False, False, True, True, True]
+    else:
+        for i in range(1, 5):  # layer-by-layer, like resnet18Test.cpp:84-140
+            np.testing.assert_allclose(m.stage_output(i), layers[i - 1][0], **TOL)
+    stats = m.time_stats()
+    assert any("Conv2D" in k for k in stats) and all(v >= 0 for v in stats.values())
+    y2 = m(x)  # run() is repeatable
+    np.testing.assert_array_equal(y, y2)
+    m.close()
+
+
+@pytest.mark.gpu
+def test_layer_dumps_match_reference_format(ctx, tmp_path, monkeypatch):
+    """dumpOutputs: '<dir>/<layer name> pass[0].dump', 32-byte header + RGBA32F [D][H][W][4] (image.cpp:216-245)."""
+    from shadernn_amd import host, models
+
+    monkeypatch.setenv("SNN_OUTPUT_DIR", str(tmp_path / "dump"))
+    net = models.espcn_weights(seed=1)
+    W, H = 40, 24
+    x = np.random.default_rng(3).random((1, H, W, 1), dtype=np.float32)
+    path = _json(tmp_path, net, W, H)
+    m = host.Model(path, W, H, 1, dump_outputs=True)
+    m(x)
+    _, layers = O.forward(net, x, return_layers=True)
+    names = ["[01] Conv2D", "[02] Conv2D", "[03] Conv2D", "[04] subpixel"]
+    for name, exp in zip(names, layers):
+        f = str(tmp_path / "dump" / ("ESPCN_2X.json layer %s pass[0].dump" % name))
+        raw = open(f, "rb").read()
+        w, h, d, c, px = host.read_dump(f)
+        assert raw[:32].rstrip(b"\0").decode() == "%d %d %d %d" % (w, h, d, c) and len(raw) == 32 + w * h * d * 16
+        assert (h, w) == exp.shape[1:3] and d == (exp.shape[3] + 3) // 4 and c == 4 * d
+        np.testing.assert_allclose(host.c4hw4_to_nhwc(px, exp.shape[3]), exp[0], **TOL)
+        assert os.path.exists(f.replace("pass[0].dump", "pass[0]_input.dump"))
+    m.close()
+
+
+@pytest.mark.gpu
+def test_conv_test_with_layer_reference_defaults(ctx, tmp_path, monkeypatch):
+    """convolutionTest.cpp main(): 8x8x128 -> 1, k=1, all-ones input, weights from SRAND(7767517), bias 0, identity BN."""
+    from shadernn_amd import host
+
+    monkeypatch.setenv("SNN_OUTPUT_DIR", str(tmp_path))
+    os.makedirs(str(tmp_path), exist_ok=True)
+    w = O.reference_rand(7767517, 128).reshape(1, 128, 1, 1)
+    x = np.ones((8, 8, 128), np.float32)
+    bn = {"gamma": np.ones(1, np.float32), "mean": np.zeros(1, np.float32), "var": np.ones(1, np.float32), "beta": np.zeros(1, np.float32)}
+    f = host.conv_test_with_layer(x, w, np.zeros(1, np.float32), stride=1, pad=0, bn=bn)
+    assert f.endswith("resnet18_cifar10_0223.json layer [01] Conv2D pass[0].dump")
+    _, _, d, c, px = host.read_dump(f)
+    assert (d, c) == (1, 4)
+    want = O.conv2d(x[None], w, np.zeros(1, np.float32), 1, (0, 0, 0, 0), "constant", "", 0.0,
+                    {"beta": bn["beta"], "gamma": bn["gamma"], "mean": bn["mean"], "var": bn["var"]})
+    np.testing.assert_allclose(host.c4hw4_to_nhwc(px, 1), want[0], **TOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,stride,pad", [(3, 1, 0), (3, 2, 1), (5, 1, 2), (3, 1, 2)])
+def test_conv_test_with_layer_variants(ctx, tmp_path, monkeypatch, k, stride, pad):
+    from shadernn_amd import host
+
+    monkeypatch.setenv("SNN_OUTPUT_DIR", str(tmp_path))
+    rng = np.random.default_rng(k * 10 + stride)
+    x = rng.standard_normal((9, 11, 5)).astype(np.float32)
+    w = (rng.standard_normal((7, 5, k, k)) * 0.2).astype(np.float32)
+    b = (rng.standard_normal(7) * 0.1).astype(np.float32)
+    f = host.conv_test_with_layer(x, w, b, stride=stride, pad=pad)
+    _, _, _, _, px = host.read_dump(f)
+    p = k // 2
+    want = O.conv2d(x[None], w, b, stride, (p, p, p, p), ["constant", "replicate", "reflect"][pad], "")
+    np.testing.assert_allclose(host.c4hw4_to_nhwc(px, 7), want[0], **TOL)
+
+
+@pytest.mark.gpu
+def test_mixed_model_with_depthwise_and_dense(ctx, tmp_path):
+    """A MobileNet-style fragment through the JSON loader: conv(bn,relu6) -> depthwise(bn,relu6) -> 1x1 conv -> dense(softmax)."""
+    from shadernn_amd import host, models
+
+    rng = np.random.default_rng(11)
+    net = {"name": "frag", "input_channels": 3, "layers": [
+        models._conv(rng, "stem", 3, 8, 3, "relu6", stride=2, bn=True),
+        models._depthwise(rng, "dw", 8, 3, "relu6", stride=1, bn=True),
+        models._conv(rng, "pw", 8, 12, 1, "linear", bn=True),
+        models._dense(rng, "fc", 8 * 8 * 12, 10, "softmax"),
+    ]}
+    x = rng.random((1, 16, 16, 3), dtype=np.float32)
+    m = host.Model(_json(tmp_path, net, 16, 16), 16, 16, 3)
+    y = m(x)
+    want = O.forward(net, x)
+    np.testing.assert_allclose(y.reshape(-1), want.reshape(-1), **TOL)
+    assert abs(float(y.sum()) - 1.0) < 1e-5
+    m.close()

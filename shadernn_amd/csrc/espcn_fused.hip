@@ -501,7 +501,9 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         auto* c1 = (i + 1 < n) ? dynamic_cast<ConvPlanBase*>(plans[i + 1]) : nullptr;
         auto* sp1 = (i + 1 < n) ? dynamic_cast<SubpixelPlanBase*>(plans[i + 1]) : nullptr;
         // the chain must be shape-consistent
-        if (i + 1 < n && memcmp(plans[i]->outDims, plans[i + 1]->inDims, sizeof(int) * 4) != 0) {
+        // (a dense layer consumes any [N,H,W,C] tensor flattened in HWC order: same batch, same element count)
+        auto count3 = [](const int* d) { return static_cast<long long>(d[1]) * d[2] * d[3]; };
+        if (i + 1 < n && (plans[i]->outDims[0] != plans[i + 1]->inDims[0] || count3(plans[i]->outDims) != count3(plans[i + 1]->inDims))) {
             set_error("chain: plan %d output %dx%dx%dx%d does not feed plan %d input %dx%dx%dx%d", i, plans[i]->outDims[0], plans[i]->outDims[1],
                       plans[i]->outDims[2], plans[i]->outDims[3], i + 1, plans[i + 1]->inDims[0], plans[i + 1]->inDims[1], plans[i + 1]->inDims[2],
                       plans[i + 1]->inDims[3]);

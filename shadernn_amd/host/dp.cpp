@@ -158,8 +158,13 @@ InferenceGraph snn::dp::generateInferenceGraph(std::vector<std::shared_ptr<Gener
             igLayer->outputDesc = {fmt, width, height, static_cast<uint32_t>(DIV_4_ROUND_UP(modelLayer->getDesc().numOutputPlanes)),
                                    modelLayer->getDesc().numOutputPlanes}; // dp.cpp:328-332
             if (modelLayer->isInputLayer()) igLayer->outputDesc = inputDesc(modelLayer->getInputIndex());
+            if (dynamic_cast<DenseLayer*>(modelLayer.get())) {
+                // Dense output is a units x 1 x 1 single-channel image in the reference (denselayer.cpp:40-55, CPU-stage
+                // descriptor dp.cpp:365-367); it runs on the GPU here but keeps that shape
+                igLayer->outputDesc = {fmt, width, 1, 1, 1};
+                igLayer->flattenLayer = true;
+            }
             SNN_ASSERT(igLayer->outputDesc.width > 0 && igLayer->outputDesc.height > 0);
-            igLayer->flattenLayer = false;
         } else {
             if (i == 0) SNN_RIP("CPU layer currently cannot cannot be the 1-st layer in the graph !");
             igLayer->outputDesc = {fmt, width, height, depth, modelLayer->getDesc().numOutputPlanes};

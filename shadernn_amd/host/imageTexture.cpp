@@ -60,6 +60,7 @@ void ImageTexture::reset(const std::array<uint32_t, 4>& dims, ColorFormat format
     _format = format;
     _name = name;
     _channels = channels ? channels : 4 * dims[2];
+    if (_channels > 4 * dims[2]) SNN_RIP("texture with %u channels needs more than %u texel planes", _channels, dims[2]);
     ImageDesc d;
     d.format = format;
     d.width = dims[0];

@@ -224,12 +224,12 @@ struct FusedBParams {
 };
 
 // conv 3x3 (16 -> 4, zero padding 1) + act, then depth-to-space(2) + tanh.  One thread = one input-resolution pixel
-// = a 2x2 block of the output image.  LDS tile [TH+2][TW+2] pixels at a 20-float pitch (conflict-free b128 reads
-// for 64 consecutive pixels); weights are wave-uniform => scalar loads, FMAs take them as SGPR operands.
+// = a 2x2 block of the output image.  LDS tile [TH+2][TW+2] pixels, 64 B each, 16-byte slots XOR-swizzled (conflict-free
+// b128 reads for 64 consecutive pixels, 21.8 KB per block -> 7 blocks/CU); weights are wave-uniform => scalar loads, FMAs take them as SGPR operands.
 template <int TW, int TH, bool SIMPLE>
 __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ w,
                                                                      const float* __restrict__ ep, float* __restrict__ y) {
-    constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 20;
+    constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 16; // 64 B per pixel; the 16-byte slot is XOR-swizzled with (pixel>>2)&3
     static_assert(TW * TH == 256, "one thread per pixel");
     __shared__ __attribute__((aligned(16))) float s_x[THH * TWH * PITCH];
 
@@ -258,30 +258,39 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int idx = tid + k * 256;
-            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx >> 2) * PITCH + (idx & 3) * 4) = v[k];
+            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx >> 2) * PITCH + (((idx & 3) ^ ((idx >> 4) & 3)) * 4)) = v[k];
         }
     }
     __syncthreads();
 
     const int c = tid % TW, r = tid / TW;
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // Packed fp32 FMAs: a wave64 v_fma_f32 occupies the VALU for 4 cycles on this kernel (measured: 20.3 M VALU instructions
+    // = 20.6 M quad-cycles busy), v_pk_fma_f32 retires two FMAs per lane in the same slot.  The accumulators are kept as two
+    // float2 so that every FMA is a v_pk_fma_f32 with the weight pair in an SGPR pair.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
     // one tap (64 uniform weights = 64 SGPRs) per iteration: unrolling further only spills SGPRs
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
         const int fy = tap / 3, fx = tap - fy * 3;
-        const float* src = s_x + ((r + fy) * TWH + c + fx) * PITCH;
+        const int pixIdx = (r + fy) * TWH + c + fx;
+        const float* src = s_x + pixIdx * PITCH;
+        const int sw = (pixIdx >> 2) & 3; // conflict-free ds_read_b128 for 64 consecutive pixels at a 64-byte pitch
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 xv = *reinterpret_cast<const float4*>(src + q * 4);
+            const float4 xv = *reinterpret_cast<const float4*>(src + ((q ^ sw) * 4));
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float* wr = w + (tap * 16 + q * 4 + i) * 4; // uniform address -> s_load
-#pragma unroll
-                for (int o = 0; o < 4; ++o) acc[o] = fmaf(xs[i], wr[o], acc[o]);
+                const f32x2 xx = {xs[i], xs[i]};
+                const f32x2 w01 = {wr[0], wr[1]}, w23 = {wr[2], wr[3]};
+                acc01 = __builtin_elementwise_fma(xx, w01, acc01);
+                acc23 = __builtin_elementwise_fma(xx, w23, acc23);
             }
         }
     }
+    const float acc[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
     const int gy = y0 + r, gx = x0 + c;
     if (gy < p.H && gx < p.W) {
         float o[4];
@@ -289,88 +298,6 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
         for (int k = 0; k < 4; ++k) o[k] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(acc[k], ep[2 * k], ep[2 * k + 1]), 0.0f));
         float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
         // channel 2*dy+dx -> output pixel (2y+dy, 2x+dx)  (depth_to_space, fs_subpixel.glsl:41-64)
-        *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
-        *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
-    }
-}
-
-// Matrix-pipe variant of kernel B.  OC = 4 is too narrow for the 16x16 MFMA shapes, but v_mfma_f32_4x4x1_16b_f32 runs
-// 16 independent 4x4 outer products per instruction: block b = lanes 4b..4b+3, D_b[oc][px] += A_b[oc] * B_b[px].  Each lane
-// supplies its OWN pixel's activation as B and receives its own pixel's 4 output channels.  With cbsz=4 the A vector of
-// block `abid` is broadcast to all 16 blocks, so ONE VGPR holds the weights of 16 K-steps (lane 4*ic+oc = W[oc][ic][tap])
-// and the whole 3x3x16x4 filter lives in 9 VGPRs: 144 MFMAs (8 cycles each) per 64 pixels, no scalar loads, no VALU FMAs.
-// Numerics: every MFMA is an exact fp32 fma, four interleaved accumulation chains are summed at the end.
-template <int TW, int TH, bool SIMPLE>
-__global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_mfma_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ wA3,
-                                                                          const float* __restrict__ ep, float* __restrict__ y) {
-    constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 20;
-    static_assert(TW * TH == 256, "one thread per pixel");
-    __shared__ __attribute__((aligned(16))) float s_x[THH * TWH * PITCH];
-
-    const int tid = threadIdx.x;
-    int b = xcd_tile_order(blockIdx.x, gridDim.x);
-    const int tx = b % p.tilesX;
-    b /= p.tilesX;
-    const int ty = b % p.tilesY;
-    const int n = b / p.tilesY;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
-
-    {
-        constexpr int NLD = (THH * TWH * 4 + 255) / 256;
-        float4 v[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) { // every load of the halo tile is in flight before the first LDS write
-            const int idx = tid + k * 256;
-            const int q = idx & 3, pix = idx >> 2;
-            const int r = pix / TWH, c = pix - r * TWH;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (idx < THH * TWH * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                v[k] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx >> 2) * PITCH + (idx & 3) * 4) = v[k];
-        }
-    }
-    float a3[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) a3[t] = wA3[t * 64 + (tid & 63)];
-    __syncthreads();
-
-    const int c = tid % TW, r = tid / TW;
-    f32x4 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int fy = tap / 3, fx = tap % 3;
-        const float* src = s_x + ((r + fy) * TWH + c + fx) * PITCH;
-#define SNNHIP_C3_QUAD(Q)                                                                        \
-    {                                                                                            \
-        const float4 xv = *reinterpret_cast<const float4*>(src + (Q) * 4);                       \
-        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a3[tap], xv.x, acc[0], 4, (Q) * 4 + 0, 0);   \
-        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a3[tap], xv.y, acc[1], 4, (Q) * 4 + 1, 0);   \
-        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a3[tap], xv.z, acc[2], 4, (Q) * 4 + 2, 0);   \
-        acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a3[tap], xv.w, acc[3], 4, (Q) * 4 + 3, 0);   \
-    }
-        SNNHIP_C3_QUAD(0)
-        SNNHIP_C3_QUAD(1)
-        SNNHIP_C3_QUAD(2)
-        SNNHIP_C3_QUAD(3)
-#undef SNNHIP_C3_QUAD
-    }
-    const int gy = y0 + r, gx = x0 + c;
-    if (gy < p.H && gx < p.W) {
-        float o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float sum = (acc[0][k] + acc[1][k]) + (acc[2][k] + acc[3][k]);
-            o[k] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(sum, ep[2 * k], ep[2 * k + 1]), 0.0f));
-        }
-        float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
         *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
         *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
     }

@@ -35,6 +35,7 @@ std::vector<float> make_epilogue_table(int, int, int, const float*, int, const f
 int snnhip_plan::upload(const float*, size_t, float**) { return 0; }
 int snnhip_plan::profBegin(int) { return 0; }
 int snnhip_plan::profEnd(int) { return 0; }
+int snnhip_plan::profAcquire(int, hipEvent_t*, hipEvent_t*) { return 0; }
 extern "C" int snnhip_tensor_alloc(snnhip_ctx*, int, int, int, int, int, snnhip_tensor**) { return 0; }
 extern "C" int snnhip_tensor_free(snnhip_tensor*) { return 0; }
 namespace snnhip {
@@ -64,24 +65,6 @@ float timeA(const float* x, const float* w1, const float* w2, const float* e1, c
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
     for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((conv_kxk_c1o16_conv3x3_c16o16_kernel<K1, TW, TH, true, U, WPS>), grid, dim3(256), 0, 0, p, x, w1, w2, e1, e2, y);
-    CK(hipEventRecord(b));
-    CK(hipEventSynchronize(b));
-    float ms;
-    CK(hipEventElapsedTime(&ms, a, b));
-    return ms * 1000.f / reps;
-}
-
-template <int TW, int TH>
-float timeBM(const float* x, const float* w, const float* e, float* y, int H, int W, int reps) {
-    FusedBParams p{1, H, W, (W + TW - 1) / TW, (H + TH - 1) / TH, make_act_cfg(0, 0.f)};
-    dim3 grid(p.tilesX * p.tilesY);
-    hipEvent_t a, b;
-    CK(hipEventCreate(&a));
-    CK(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_mfma_kernel<TW, TH, true>), grid, dim3(256), 0, 0, p, x, w, e, y);
-    CK(hipDeviceSynchronize());
-    CK(hipEventRecord(a));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_mfma_kernel<TW, TH, true>), grid, dim3(256), 0, 0, p, x, w, e, y);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms;
@@ -183,9 +166,6 @@ int main() {
     TUNE_VARIANTS
 #else
     printf("A<5,64,8,U3,W3>  %.1f us\n", timeA<5, 64, 8, 3, 3>(x, w, w, w, w, mid, H, W, R));
-    printf("BM<32,8>   %.1f us\n", timeBM<32, 8>(mid, w, w, y, H, W, R));
-    printf("BM<64,4>   %.1f us\n", timeBM<64, 4>(mid, w, w, y, H, W, R));
-    printf("BM<16,16>  %.1f us\n", timeBM<16, 16>(mid, w, w, y, H, W, R));
     printf("B<32,8>    %.1f us\n", timeB<32, 8>(mid, w, w, y, H, W, R));
     printf("B<64,4>    %.1f us\n", timeB<64, 4>(mid, w, w, y, H, W, R));
     printf("B<16,16>   %.1f us\n", timeB<16, 16>(mid, w, w, y, H, W, R));

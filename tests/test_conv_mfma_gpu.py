@@ -1,0 +1,119 @@
+"""GPU parity tests of the fp32-MFMA implicit-GEMM convolution (conv2d_mfma.hip) vs the CPU oracle, through the C-ABI.
+SNNHIP_CONV=mfma|generic pins the routing so both kernels are checked on the same inputs (and against each other)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_ops_gpu import TOL, _bn, _rand, run_conv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def force():
+    old = os.environ.get("SNNHIP_CONV")
+
+    def _set(v):
+        if v is None:
+            os.environ.pop("SNNHIP_CONV", None)
+        else:
+            os.environ["SNNHIP_CONV"] = v
+
+    yield _set
+    _set(old)
+
+
+MFMA_CASES = [
+    # (N, H, W, IC, OC, k, stride)            shape class
+    (2, 56, 56, 64, 64, 3, 1),    # ResNet-18 layer1
+    (2, 28, 28, 128, 128, 3, 1),  # ResNet-18 layer2
+    (2, 56, 56, 64, 128, 3, 2),   # ResNet-18 layer2 first conv (stride 2, 128-wide N block)
+    (2, 56, 56, 64, 128, 1, 2),   # ResNet-18 downsample 1x1 s2
+    (3, 14, 14, 256, 256, 3, 1),  # layer3: tile spans 14x14
+    (5, 7, 7, 512, 512, 3, 1),    # layer4: several images per pixel tile
+    (1, 30, 30, 3, 64, 7, 2),     # stem (IC=3, forced: one 8-channel chunk mostly padding)
+    (2, 28, 28, 32, 192, 1, 1),   # MobileNetV2 expand
+    (2, 28, 28, 192, 32, 1, 1),   # MobileNetV2 project (N block 32)
+    (1, 14, 14, 96, 576, 1, 1), (1, 7, 7, 320, 1280, 1, 1),
+    (1, 17, 23, 24, 144, 1, 1),   # ragged, OC not a multiple of 32, IC not a multiple of 16
+    (2, 9, 11, 20, 33, 3, 1),     # IC%16 != 0, OC%32 != 0
+    (1, 12, 12, 10, 18, 3, 2),    # IC not a multiple of 4: scalar staging path
+    (1, 20, 24, 32, 32, 5, 1), (1, 16, 20, 16, 16, 9, 1),  # 5x5 and 9x9 (Candy)
+    (1, 9, 9, 8, 16, 4, 1),       # even kernel, asymmetric padding; IC == 8 -> one 8-channel chunk
+    (1, 40, 130, 16, 16, 3, 1),   # wide image: 1x1x128 / 1x2x64 pixel tiles
+]
+
+
+@pytest.mark.parametrize("case", MFMA_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_mfma_conv_matches_oracle(ctx, force, case):
+    N, H, W, IC, OC, k, s = case
+    x = _rand((N, H, W, IC), 41)
+    w = _rand((OC, IC, k, k), 42, 1.0 / np.sqrt(IC * k * k))
+    b = _rand((OC,), 43, 0.1)
+    bn = _bn(OC, 44)
+    pads = O.padding_offsets("same", k)
+    force("mfma")
+    y, desc = run_conv(ctx, x, w, b, s, pads, "constant", "relu", 0.0, bn)
+    assert "mfma" in desc, desc
+    want = O.conv2d(x, w, b, s, pads, "constant", "relu", 0.0, bn)
+    assert y.shape == want.shape, desc
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
+    force("generic")
+    yg, descg = run_conv(ctx, x, w, b, s, pads, "constant", "relu", 0.0, bn)
+    assert "generic" in descg, descg
+    np.testing.assert_allclose(y, yg, err_msg=desc + " vs " + descg, **TOL)
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "replicate", "reflect", "none"])
+@pytest.mark.parametrize("act", ["", "relu", "relu6", "tanh", "sigmoid", "leakyRelu", "SiLU", "SiLU_quirk"])
+def test_mfma_conv_padding_modes_activations(ctx, force, pad_mode, act):
+    x = _rand((2, 13, 18, 24), 45)
+    w = _rand((40, 24, 3, 3), 46, 0.1)
+    b = _rand((40,), 47, 0.1)
+    bn = _bn(40, 48)
+    force("mfma")
+    y, desc = run_conv(ctx, x, w, b, 1, (1, 1, 1, 1), pad_mode, act, 0.1, bn)
+    assert "mfma" in desc, desc
+    want = O.conv2d(x, w, b, 1, (1, 1, 1, 1), pad_mode, act, 0.1, bn)
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
+
+
+def test_default_routing(ctx, force):
+    """GEMM-shaped layers go to the MFMA kernel, thin ones (IC < 8 or OC < 16) to the VALU kernel."""
+    force(None)
+    for (ic, oc, want) in [(64, 64, "mfma"), (3, 64, "generic"), (16, 4, "generic"), (128, 1, "generic"), (8, 16, "mfma")]:
+        x = _rand((1, 8, 8, ic), 1)
+        w = _rand((oc, ic, 3, 3), 2, 0.1)
+        _, desc = run_conv(ctx, x, w, None, 1, (1, 1, 1, 1), "constant", "relu", 0.0, None)
+        assert want in desc, (ic, oc, desc)
+
+
+def test_mfma_conv_linearity_at_scale(ctx, force):
+    """Size-independent property at a ResNet-18 batch-32 layer size (too big for the oracle in seconds):
+    conv(a*x1 + x2) == a*conv(x1) + conv(x2) with no bias/activation, and a sampled window equals the oracle."""
+    import shadernn_amd as snn
+
+    force("mfma")
+    N, H, W, IC, OC = 32, 56, 56, 64, 64
+    x1 = _rand((N, H, W, IC), 51)
+    x2 = _rand((N, H, W, IC), 52)
+    w = _rand((OC, IC, 3, 3), 53, 1.0 / 24.0)
+    plan = snn.conv2d_plan(ctx, N, H, W, w, None, stride=1, pads=(1, 1, 1, 1), pad_mode="constant", act="", leaky=0.0, bn=None)
+    assert "mfma" in plan.describe()
+
+    def run(x):
+        xt = snn.Tensor.from_numpy(ctx, x)
+        yt = plan(xt)
+        y = yt.numpy()
+        xt.free()
+        yt.free()
+        return y
+
+    y1, y2, y3 = run(x1), run(x2), run(2.5 * x1 + x2)
+    np.testing.assert_allclose(y3, 2.5 * y1 + y2, rtol=1e-4, atol=2e-4)
+    # window: image 17, rows 20..27 == interior rows 2..9 of the oracle run on input rows 18..29
+    want = O.conv2d(x1[17:18, 18:30], w, None, 1, (1, 1, 1, 1), "constant", "")
+    np.testing.assert_allclose(y1[17:18, 20:28], want[:, 2:10], **TOL)
+    plan.destroy()

@@ -218,6 +218,283 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_conv3x3_c16o16_kernel
     SNNHIP_STAMP(6);
 }
 
+// Kernel A, Winograd variant (default): same fusion, but conv2 (3x3, 16 -> 16) is evaluated as F(2x2, 3x3):
+//     Y = At [ (G g Gt) .* (Bt d B) ] A      per 2x2 output block and (oc, ic) pair            (Lavin & Gray 2016)
+// which needs 16 multiplies per 4 outputs instead of 36 -> 2.25x fewer MFMA flops for the layer that owns 70 % of the
+// network's arithmetic.  All transform coefficients are 0, +-1 (input/output) or +-1/2 (weights, done on the host in
+// double precision), so the fp32 result differs from the direct sum by a few ulp (parity tests: <= 1e-4 as before).
+//   block   = 32x16 output pixels = 16x8 Winograd tiles; 256 threads = 4 waves; 58.6 KB LDS -> 2 blocks/CU
+//   phase 1 = conv1 (MFMA, as in the direct kernel) into LDS [row][col parity][col/2][16ch]; the column de-interleave makes
+//             the stride-2 tile reads of phase 2 consecutive, the slot XOR (bit 2 of the linear pixel index) makes them
+//             conflict-free for the ds_read_b128 lane groups
+//   phase 2 = per wave 2 groups of 16 tiles (one tile row each): lane (tile t = lane%16, g = lane/16) loads its 4x4 input
+//             patch for channels 4g..4g+3 (16 ds_read_b128), then per transform column nu: input transform (VALU, float4
+//             adds), 16 MFMAs  M[xi][oc][tile] += U[xi,nu][oc][ic] * V[xi,nu][ic][tile]  (v_mfma_f32_16x16x4_f32, U read
+//             from LDS as one b128 per position), output transform folded into the 2x2x4 result registers
+//   epilogue= bias/BN/act, four 16-byte stores per lane
+struct WinoTile {
+    static constexpr int TW = 32;
+};
+
+// conv1 K-step -> tap assignment of the Winograd kernel: K-step s, lane group g (= MFMA k index) handle
+//   s <  K1        : tap (row g, col s)            valid iff g < K1          -> LDS address = base + g*INW + s   (s is an immediate)
+//   s == K1 + j    : tap (row 4, col 4j + g)       valid iff K1 == 5, col < 5 -> LDS address = base + 4*INW + g + 4j
+// (invalid (s, g) carry a zero weight and read an initialised location).  Returns the tap index or -1.
+inline int wino_conv1_tap(int K1, int s, int g) {
+    if (s < K1) return g < K1 ? g * K1 + s : -1;
+    const int col = 4 * (s - K1) + g;
+    return (K1 > 4 && col < K1) ? 4 * K1 + col : -1;
+}
+constexpr int wino_conv1_ksteps(int K1) { return K1 + (K1 > 4 ? 2 : 0); }
+
+// AM: 0 = any activation (run-time switch), 1 = cheap family (branch-free med3 form), 2 = both layers ReLU
+template <int AM>
+__device__ __forceinline__ float act_mode(const ActCfg& a, float v) {
+    if (AM == 2) return fmaxf(v, 0.0f);
+    if (AM == 1) return apply_act<true>(a, v, 0.0f);
+    return epi_act(a.act, a.leaky, v, 0.0f);
+}
+
+template <int K1, int TH, int AM, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel(FusedAParams p, const float* __restrict__ x,
+                                                                           const float* __restrict__ wA1, const float* __restrict__ wU,
+                                                                           const float* __restrict__ ep1, const float* __restrict__ ep2,
+                                                                           float* __restrict__ y) {
+    constexpr int TW = WinoTile::TW, U = 2;
+    constexpr int P1 = K1 / 2;
+    constexpr int C1W = TW + 2, C1H = TH + 2;
+    constexpr int C1P = 40, HALFP = 20;                        // LDS row pitch / odd-column plane offset, in pixels (see phase 2)
+    constexpr int INW = TW + 2 + 2 * P1, INH = TH + 2 + 2 * P1;
+    constexpr int KS1 = wino_conv1_ksteps(K1);
+    constexpr int NG1 = (C1H * C1W + 15) / 16;                 // 16-pixel groups of phase 1
+    constexpr int GPW = (NG1 + 3) / 4;                         // groups per wave (contiguous range)
+    constexpr int NIT = (GPW + U - 1) / U;
+    constexpr int GROUPS2 = TH / 8;                            // Winograd tile rows (= phase-2 groups) per wave
+    constexpr int NLD = (INH * INW + 8 + 255) / 256;
+    static_assert(C1W / 2 + 1 <= HALFP && HALFP + C1W / 2 <= C1P, "plane layout");
+
+    __shared__ __attribute__((aligned(16))) float smem[C1H * C1P * 16 + 4096 + INH * INW + 8];
+    float* s_c1 = smem;
+    float* s_U = smem + C1H * C1P * 16;
+    float* s_in = s_U + 4096;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int px = lane & 15, g = lane >> 4;
+    const int ntiles = p.tilesX * p.tilesY * p.N;
+
+    // Persistent blocks (grid = WPS per CU): weights / epilogue constants are loaded once per block and the input tile of the
+    // NEXT tile is fetched into NLD registers while this tile is computed, so no wave ever waits on HBM inside the loop.
+    auto tile_origin = [&](int t, int& n, int& x0, int& y0) {
+        int b = xcd_tile_order(t, ntiles);
+        const int tx = b % p.tilesX;
+        b /= p.tilesX;
+        const int ty = b % p.tilesY;
+        n = b / p.tilesY;
+        x0 = tx * TW;
+        y0 = ty * TH;
+    };
+    float vin[NLD];
+    auto issue_loads = [&](int t) { // input tile (origin y0-1-P1, x0-1-P1), zero padded (+8 zero floats: invalid taps read them)
+        int n, x0, y0;
+        tile_origin(t, n, x0, y0);
+        const float* xn = x + static_cast<size_t>(n) * p.H * p.W;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256;
+            const int r = idx / INW, c = idx - r * INW;
+            const int gy = y0 - 1 - P1 + r, gx = x0 - 1 - P1 + c;
+            vin[k] = 0.0f;
+            if (idx < INH * INW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) vin[k] = xn[static_cast<size_t>(gy) * p.W + gx];
+        }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (tid + k * 256 < INH * INW + 8) s_in[tid + k * 256] = vin[k];
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    SNNHIP_STAMP(0);
+    issue_loads(tile);
+    {
+        float4 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = reinterpret_cast<const float4*>(wU)[tid + k * 256];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reinterpret_cast<float4*>(s_U)[tid + k * 256] = u[k];
+    }
+    store_input();
+
+    float a1[KS1];
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) a1[s] = wA1[s * 64 + lane];
+    float sc1[4], sh1[4], sc2[4], sh2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sc1[r] = ep1[(4 * g + r) * 2];
+        sh1[r] = ep1[(4 * g + r) * 2 + 1];
+        sc2[r] = ep2[(4 * g + r) * 2];
+        sh2[r] = ep2[(4 * g + r) * 2 + 1];
+    }
+    const int rowTap = (g < K1 ? g : 0) * INW; // K-steps s < K1: tap row g (invalid g: zero weight, any initialised row)
+    const int lastTap = 4 * INW + g;           // K-steps s >= K1 (K1 == 5): tap row 4, col g (+4)
+    SNNHIP_STAMP(1);
+    __syncthreads();
+    SNNHIP_STAMP(2);
+
+  for (;;) {
+    int n, x0, y0;
+    tile_origin(tile, n, x0, y0);
+    const int next = tile + gridDim.x;
+    const bool more = next < ntiles;
+    if (more) issue_loads(next);
+
+    // ---- phase 1: conv1 over the C1H x C1W region, pixels flattened into 16-wide groups; wave wv owns groups
+    // [wv*GPW, wv*GPW+GPW), two per iteration (two independent MFMA chains).  The LDS operands of iteration it+1 are
+    // fetched before the MFMAs of iteration it (the loop is fully unrolled, so this is register renaming, not copies).
+    {
+        float bv[2][U][KS1];
+        int rr[2][U], cc[2][U];
+        bool valid[2][U];
+        auto fetch = [&](int it, int buf) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int grp = wv * GPW + it * U + u;
+                const int pi = grp * 16 + px;
+                valid[buf][u] = (it * U + u < GPW) && pi < C1H * C1W;
+                const int pc = valid[buf][u] ? pi : 0;
+                rr[buf][u] = pc / C1W;
+                cc[buf][u] = pc - rr[buf][u] * C1W;
+                const float* src = s_in + rr[buf][u] * INW + cc[buf][u];
+                const float* srcRow = src + rowTap;
+#pragma unroll
+                for (int s = 0; s < KS1; ++s) bv[buf][u][s] = s < K1 ? srcRow[s] : src[lastTap + 4 * (s - K1)];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int cur = it & 1;
+            if (it + 1 < NIT) fetch(it + 1, cur ^ 1);
+            f32x4 acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], bv[cur][u][0], f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < KS1; ++s)
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bv[cur][u][s], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int gy = y0 - 1 + rr[cur][u], gx = x0 - 1 + cc[cur][u];
+                const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W; // outside the image: conv2's zero padding
+                float4 o;
+                o.x = inside ? act_mode<AM>(p.act1, fmaf(acc[u][0], sc1[0], sh1[0])) : 0.0f;
+                o.y = inside ? act_mode<AM>(p.act1, fmaf(acc[u][1], sc1[1], sh1[1])) : 0.0f;
+                o.z = inside ? act_mode<AM>(p.act1, fmaf(acc[u][2], sc1[2], sh1[2])) : 0.0f;
+                o.w = inside ? act_mode<AM>(p.act1, fmaf(acc[u][3], sc1[3], sh1[3])) : 0.0f;
+                if (valid[cur][u]) {
+                    const int c = cc[cur][u];
+                    const int pl = rr[cur][u] * C1P + (c & 1) * HALFP + (c >> 1);
+                    const int slot = g ^ (((pl >> 2) & 1) << 1);
+                    *reinterpret_cast<float4*>(s_c1 + pl * 16 + slot * 4) = o;
+                }
+            }
+        }
+    }
+    SNNHIP_STAMP(3);
+    __syncthreads(); // c1 complete; every wave is done reading s_in
+    if (more) store_input();
+    SNNHIP_STAMP(4);
+
+    // ---- phase 2: Winograd conv2.  Lane = (tile column t = px, channel quad g).
+    // c1 pixel (r, c) lives at linear pixel pl = r*C1P + (c&1)*HALFP + (c>>1), 16-byte slot  q ^ 2*((pl>>2)&1).
+    // Patch element (i, j) of tile (trow, t): pl = (2 trow + i)*C1P + (j&1)*HALFP + t + (j>>1).  C1P = 40 leaves bit 2 of
+    // pl alone, HALFP = 20 flips it, so the swizzle term is one of two per-lane values and everything else is an
+    // immediate offset: 4 address registers serve all 16 patch loads.
+    const float* uBase = s_U + (px * 4 + (g ^ (((px >> 2) & 1) << 1))) * 4; // + pos*256: U[pos][oc = px][ic = 4g..4g+3]
+    const float* dBase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = px + (j >> 1);
+        const int slot = g ^ ((((t >> 2) & 1) ^ (j & 1)) << 1);
+        dBase[j] = s_c1 + (wv * (2 * GROUPS2) * C1P + (j & 1) * HALFP + t) * 16 + slot * 4;
+    }
+    float* yn = y + static_cast<size_t>(n) * p.H * p.W * 16;
+#pragma unroll
+    for (int gi = 0; gi < GROUPS2; ++gi) {
+        const int trow = wv * GROUPS2 + gi; // tile row: output rows 2*trow, 2*trow+1; patch rows 2*trow .. 2*trow+3 of the c1 tile
+        f32x4 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(dBase[j] + (2 * gi + i) * C1P * 16);
+        f32x4 Y[2][2];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            // (d B)[:, nu], then V[xi] = (Bt (dB))[xi]
+            f32x4 e[4], V[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                e[i] = nu == 0 ? d[i][0] - d[i][2] : nu == 1 ? d[i][1] + d[i][2] : nu == 2 ? d[i][2] - d[i][1] : d[i][1] - d[i][3];
+            V[0] = e[0] - e[2];
+            V[1] = e[1] + e[2];
+            V[2] = e[2] - e[1];
+            V[3] = e[1] - e[3];
+            f32x4 u4[4], m[4];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) u4[xi] = *reinterpret_cast<const f32x4*>(uBase + (xi * 4 + nu) * 256);
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) m[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(u4[xi][0], V[xi][0], f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+#pragma unroll
+            for (int kk = 1; kk < 4; ++kk)
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) m[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(u4[xi][kk], V[xi][kk], m[xi], 0, 0, 0);
+            // output transform: T[a] = (At M)[a][nu];  Y[a][b] += T[a] * At[b][nu]
+            const f32x4 T0 = m[0] + m[1] + m[2];
+            const f32x4 T1 = m[1] - m[2] - m[3];
+            if (nu == 0) {
+                Y[0][0] = T0;
+                Y[1][0] = T1;
+            } else if (nu == 1) {
+                Y[0][0] += T0;
+                Y[1][0] += T1;
+                Y[0][1] = T0;
+                Y[1][1] = T1;
+            } else if (nu == 2) {
+                Y[0][0] += T0;
+                Y[1][0] += T1;
+                Y[0][1] -= T0;
+                Y[1][1] -= T1;
+            } else {
+                Y[0][1] -= T0;
+                Y[1][1] -= T1;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int gy = y0 + 2 * trow + a, gx = x0 + 2 * px + bb;
+                if (gy < p.H && gx < p.W) {
+                    float4 o;
+                    o.x = act_mode<AM>(p.act2, fmaf(Y[a][bb][0], sc2[0], sh2[0]));
+                    o.y = act_mode<AM>(p.act2, fmaf(Y[a][bb][1], sc2[1], sh2[1]));
+                    o.z = act_mode<AM>(p.act2, fmaf(Y[a][bb][2], sc2[2], sh2[2]));
+                    o.w = act_mode<AM>(p.act2, fmaf(Y[a][bb][3], sc2[3], sh2[3]));
+                    *reinterpret_cast<float4*>(yn + (static_cast<size_t>(gy) * p.W + gx) * 16 + g * 4) = o;
+                }
+            }
+    }
+    SNNHIP_STAMP(5);
+    if (!more) break;
+    __syncthreads(); // c1 consumed, next input tile visible
+    tile = next;
+  }
+    SNNHIP_STAMP(6);
+}
+
 struct FusedBParams {
     int N, H, W, tilesX, tilesY;
     ActCfg act;
@@ -303,6 +580,229 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     }
 }
 
+// Kernel B, Winograd variant (default): conv 3x3 (16 -> 4) as F(2x2, 3x3) on the matrix cores, then depth-to-space(2) + tanh.
+// With only 4 output channels a 16-wide MFMA tile would be 3/4 padding; v_mfma_f32_4x4x1_16B_f32 instead runs 16
+// independent 4x4x1 outer products per instruction: block = 4 Winograd tiles, rows = the 4 output channels, one input
+// channel per instruction.  Lane l is Winograd tile l of its wave (64 tiles = 32 x 2), so both transforms are lane-local:
+//   per channel quad q: 16 ds_read_b128 (the tile's 4x4 input patch), Bt d B (32 float4 adds), then per transform
+//   position 4 MFMAs  M[pos][oc][tile] += U[pos][oc][ic] * V[pos][ic][tile]   (U: one broadcast ds_read_b128 per position)
+//   after the 4 quads: At M A (24 float4 adds), bias/BN/act, tanh, and the 4x4 block of output pixels the tile maps to
+//   under depth-to-space is written as four 16-byte stores.
+// 256 MFMAs (8 cycles each) + ~800 VALU per 256 pixels instead of 9216 scalar FMAs.  fp32 MFMA executes on the same FMA
+// lanes as VALU code (tools/ubench_issue.hip: their issue times add up), so the win is the 2.25x cut in multiplies plus the
+// removal of the per-tap scalar weight loads.  Block = 64 x 16 pixels, 80 KB LDS -> 2 blocks/CU.
+template <bool SIMPLE>
+__global__ __launch_bounds__(256, 2) void conv3x3_c16o4_wino_d2s_tanh_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ wU,
+                                                                        const float* __restrict__ ep, float* __restrict__ y) {
+    constexpr int TW = 64, TH = 16, XW = TW + 2, XH = TH + 2, HALF = XW / 2;
+    constexpr int NPIX = XH * XW, NLD = (NPIX + 255) / 256; // halo pixels per tile; float4 per thread and channel quad
+    __shared__ __attribute__((aligned(16))) float s_x[NPIX * 16];
+    __shared__ __attribute__((aligned(16))) float s_U[1024];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ntiles = p.tilesX * p.tilesY * p.N;
+
+    // Persistent blocks (grid = 2 per CU) with a quad-granular software pipeline: the tile is consumed one channel quad
+    // (16-byte slot of every pixel) at a time, so as soon as all waves are done with quad q of this tile, quad q of the NEXT
+    // tile -- fetched into 5 float4 registers per thread while quad q was being computed -- overwrites it.  The HBM/MALL stream
+    // and the MFMA/VALU work overlap inside every block; without this all blocks of a launch load together and compute
+    // together (measured: 44 % of the block lifetime in the load phase).
+    // Halo tile layout: pixel (r, c) at linear index pl = r*XW + (c&1)*HALF + (c>>1) (columns de-interleaved so that the
+    // stride-2 patch reads of 32 adjacent tiles are consecutive), 16-byte slot q ^ ((pl>>2)&3) (conflict-free ds_read_b128).
+    auto tile_origin = [&](int t, int& n, int& x0, int& y0) {
+        int b = xcd_tile_order(t, ntiles);
+        const int tx = b % p.tilesX;
+        b /= p.tilesX;
+        const int ty = b % p.tilesY;
+        n = b / p.tilesY;
+        x0 = tx * TW;
+        y0 = ty * TH;
+    };
+    // tile-independent staging descriptors of this thread's halo pixels
+    int rc[NLD], ldst[NLD]; // (r << 8) | c   and   byte offset of slot bits 0 of the pixel, swizzle term folded in
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int pix = tid + k * 256;
+        const int pp = pix < NPIX ? pix : 0;
+        const int r = pp / XW, c = pp - r * XW;
+        const int pl = r * XW + (c & 1) * HALF + (c >> 1);
+        rc[k] = pix < NPIX ? ((r << 8) | c) : -1;
+        ldst[k] = pl * 64 + (((pl >> 2) & 3) << 4);
+    }
+    float4 v[NLD];
+    const float* xt = nullptr; // image base of the tile being fetched
+    int fx0 = 0, fy0 = 0;
+    auto begin_fetch = [&](int t) {
+        int n;
+        tile_origin(t, n, fx0, fy0);
+        xt = x + static_cast<size_t>(n) * p.H * p.W * 16;
+    };
+    auto issue_loads = [&](int q) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int gy = fy0 - 1 + (rc[k] >> 8), gx = fx0 - 1 + (rc[k] & 255);
+            v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (rc[k] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                v[k] = *reinterpret_cast<const float4*>(xt + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
+        }
+    };
+    auto store_lds = [&](int q) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (rc[k] >= 0) *reinterpret_cast<float4*>(reinterpret_cast<char*>(s_x) + (ldst[k] ^ (q << 4))) = v[k];
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    SNNHIP_STAMP(0);
+    begin_fetch(tile);
+    reinterpret_cast<float4*>(s_U)[tid] = reinterpret_cast<const float4*>(wU)[tid];
+    { // first tile: all four quads in flight at once
+        float4 v0[4][NLD];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            issue_loads(q);
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) v0[q][k] = v[k];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) v[k] = v0[q][k];
+            store_lds(q);
+        }
+    }
+    SNNHIP_STAMP(1);
+    __syncthreads();
+    SNNHIP_STAMP(2);
+
+    float sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sc[k] = ep[2 * k];
+        sh[k] = ep[2 * k + 1];
+    }
+    const int tcol = lane & 31, trow = 2 * wv + (lane >> 5); // this lane's Winograd tile: output pixels (2 trow + a, 2 tcol + b)
+    int off[4][4];                                             // byte offset of patch pixel (i, j), slot bits of quad 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pl = (2 * trow + i) * XW + (j & 1) * HALF + tcol + (j >> 1);
+            off[i][j] = pl * 64 + (((pl >> 2) & 3) << 4);
+        }
+    const char* sxb = reinterpret_cast<const char*>(s_x);
+    const float* uLane = s_U + (lane & 3) * 4; // + (pos*4 + q)*16 floats: U[pos][oc = lane&3][ic = 4q .. 4q+3]
+
+    for (;;) {
+        int n, x0, y0;
+        tile_origin(tile, n, x0, y0);
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;
+        if (more) begin_fetch(next);
+
+        f32x4 M[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (more) issue_loads(q);
+            f32x4 d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(sxb + (off[i][j] ^ (q << 4)));
+                // V = Bt d B, in place: columns first (d B), then rows
+#ifndef SNNHIP_BW_SKIP_TRANSFORM
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 e0 = d[i][0] - d[i][2], e1 = d[i][1] + d[i][2], e2 = d[i][2] - d[i][1], e3 = d[i][1] - d[i][3];
+                d[i][0] = e0;
+                d[i][1] = e1;
+                d[i][2] = e2;
+                d[i][3] = e3;
+            }
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                const f32x4 v0 = d[0][nu] - d[2][nu], v1 = d[1][nu] + d[2][nu], v2 = d[2][nu] - d[1][nu], v3 = d[1][nu] - d[3][nu];
+                d[0][nu] = v0;
+                d[1][nu] = v1;
+                d[2][nu] = v2;
+                d[3][nu] = v3;
+            }
+#endif
+            // 16 positions x 4 channels; 4 positions in flight so consecutive MFMAs never share an accumulator
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                f32x4 u4[4];
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) u4[nu] = *reinterpret_cast<const f32x4*>(uLane + ((xi * 4 + nu) * 4 + q) * 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int nu = 0; nu < 4; ++nu) {
+                        const int pos = xi * 4 + nu;
+                        if (q == 0 && k == 0)
+                            M[pos] = __builtin_amdgcn_mfma_f32_4x4x1f32(u4[nu][k], d[xi][nu][k], f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                        else
+                            M[pos] = __builtin_amdgcn_mfma_f32_4x4x1f32(u4[nu][k], d[xi][nu][k], M[pos], 0, 0, 0);
+                    }
+            }
+            if (more) {
+                __syncthreads(); // every wave has consumed quad q of this tile
+                store_lds(q);
+            }
+        }
+        SNNHIP_STAMP(3);
+
+        // ---- Y = At M A  (per output channel = accumulator register)
+        f32x4 Y[2][2];
+        {
+            f32x4 T[2][4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                T[0][nu] = M[0 * 4 + nu] + M[1 * 4 + nu] + M[2 * 4 + nu];
+                T[1][nu] = M[1 * 4 + nu] - M[2 * 4 + nu] - M[3 * 4 + nu];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                Y[a][0] = T[a][0] + T[a][1] + T[a][2];
+                Y[a][1] = T[a][1] - T[a][2] - T[a][3];
+            }
+        }
+        SNNHIP_STAMP(4);
+        // ---- epilogue: bias/BN/act, tanh; channel 2*dy+dx of input pixel (yy, xx) -> output pixel (2yy+dy, 2xx+dx)
+        // (depth_to_space, fs_subpixel.glsl:41-64): the tile's 2x2 pixels x 4 channels are a 4x4 block of the output image
+        float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
+        const int gy0 = y0 + 2 * trow, gx0 = x0 + 2 * tcol;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                float o[4];
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int oc = 2 * dy + dx;
+                        o[2 * bb + dx] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(Y[a][bb][oc], sc[oc], sh[oc]), 0.0f));
+                    }
+                const int gy = gy0 + a;
+                float* row = yn + static_cast<size_t>(2 * gy + dy) * (2 * p.W) + 2 * gx0;
+                if (gy < p.H) {
+                    if (gx0 + 1 < p.W) {
+                        *reinterpret_cast<float4*>(row) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else if (gx0 < p.W) {
+                        *reinterpret_cast<float2*>(row) = make_float2(o[0], o[1]);
+                    }
+                }
+            }
+        SNNHIP_STAMP(5);
+        if (!more) break;
+        __syncthreads(); // the last quad of the next tile is in place
+        tile = next;
+    }
+    SNNHIP_STAMP(6);
+}
+
 // (scale, shift) per channel so that epilogue = act(acc*scale + shift):  scale = bnScale, shift = bnScale*(bias-mean)+beta
 std::vector<float> fold_epilogue(const std::vector<float>& epi4, int OC, int useBN) {
     std::vector<float> out(static_cast<size_t>(OC) * 2);
@@ -322,6 +822,7 @@ bool is_same_conv(const ConvGeom& g, int k, int ic, int oc) {
 }
 
 constexpr int A_TW = 64, A_TH = 8;
+constexpr int W_TH = 16, W_WPS = 2; // Winograd kernel A: tile 32 x W_TH, W_WPS blocks (waves/SIMD) per CU
 constexpr int B_TW = 32, B_TH = 8;
 
 struct ChainPlan : snnhip_plan {
@@ -332,6 +833,8 @@ struct ChainPlan : snnhip_plan {
         FusedAParams a{};
         FusedBParams b{};
         int k1 = 5;
+        bool persistent = false;
+        bool wino = false; // FUSED_A / FUSED_B: the 3x3 conv as Winograd F(2x2,3x3) (default) or direct (SNNHIP_ESPCN_A / _B = direct)
         float *w1 = nullptr, *w2 = nullptr, *e1 = nullptr, *e2 = nullptr, *w3 = nullptr, *e3 = nullptr;
         alignas(8) char streamCfg[kStreamCfgBytes] = {};
         int outDims[4] = {0, 0, 0, 0};
@@ -374,6 +877,22 @@ struct ChainPlan : snnhip_plan {
             } else if (s.kind == FUSED_S) {
                 int rc = espcn_stream_launch(ctx->stream, s.streamCfg, src->data, s.w1, s.e1, s.w2, s.e2, s.w3, s.e3, dst->data);
                 if (rc != SNNHIP_OK) return rc;
+            } else if (s.kind == FUSED_A && s.wino) {
+                const int ntilesA = s.a.tilesX * s.a.tilesY * s.a.N;
+                const int slotsA = W_WPS * (ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256);
+                dim3 grid(ntilesA < slotsA ? ntilesA : slotsA); // persistent: W_WPS blocks per CU walk the tile list
+                const bool simple = act_is_simple(s.a.act1.act) && act_is_simple(s.a.act2.act);
+#define SNNHIP_LAUNCH_W(K, AM)                                                                                                                        \
+    hipExtLaunchKernelGGL((conv_kxk_c1o16_wino3x3_c16o16_kernel<K, W_TH, AM, W_WPS>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.a, src->data, \
+                          s.w1, s.w2, s.e1, s.e2, dst->data)
+                const int am = (s.a.act1.act == SNNHIP_ACT_RELU && s.a.act2.act == SNNHIP_ACT_RELU) ? 2 : (simple ? 1 : 0);
+                if (s.k1 == 5) {
+                    if (am == 2) SNNHIP_LAUNCH_W(5, 2); else if (am == 1) SNNHIP_LAUNCH_W(5, 1); else SNNHIP_LAUNCH_W(5, 0);
+                } else {
+                    if (am == 2) SNNHIP_LAUNCH_W(3, 2); else if (am == 1) SNNHIP_LAUNCH_W(3, 1); else SNNHIP_LAUNCH_W(3, 0);
+                }
+#undef SNNHIP_LAUNCH_W
+                SNNHIP_CHECK_HIP(hipGetLastError());
             } else if (s.kind == FUSED_A) {
                 dim3 grid(s.a.tilesX * s.a.tilesY * s.a.N);
                 const bool simple = act_is_simple(s.a.act1.act) && act_is_simple(s.a.act2.act);
@@ -386,6 +905,20 @@ struct ChainPlan : snnhip_plan {
                     if (simple) SNNHIP_LAUNCH_A(3, true); else SNNHIP_LAUNCH_A(3, false);
                 }
 #undef SNNHIP_LAUNCH_A
+                SNNHIP_CHECK_HIP(hipGetLastError());
+            } else if (s.wino) {
+                // one block per tile by default; SNNHIP_ESPCN_B=wino_persistent launches 2 blocks per CU that walk the tile list with
+                // the quad-granular prefetch pipeline (measured slower so far: 50 vs 45 us)
+                const int ntiles = s.b.tilesX * s.b.tilesY * s.b.N;
+                const int slots = s.persistent ? 2 * (ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) : ntiles;
+                dim3 grid(ntiles < slots ? ntiles : slots);
+                if (act_is_simple(s.b.act.act)) {
+                    hipExtLaunchKernelGGL((conv3x3_c16o4_wino_d2s_tanh_kernel<true>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b, src->data,
+                                          s.w1, s.e1, dst->data);
+                } else {
+                    hipExtLaunchKernelGGL((conv3x3_c16o4_wino_d2s_tanh_kernel<false>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b, src->data,
+                                          s.w1, s.e1, dst->data);
+                }
                 SNNHIP_CHECK_HIP(hipGetLastError());
             } else {
                 dim3 grid(s.b.tilesX * s.b.tilesY * s.b.N);
@@ -496,19 +1029,48 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             const int K1 = g0.kh, taps1 = K1 * K1, ks1 = (taps1 + 3) / 4;
             st.kind = ChainPlan::FUSED_A;
             st.k1 = K1;
-            st.a = FusedAParams{g0.N, g0.H, g0.W, up_div(g0.W, A_TW), up_div(g0.H, A_TH), make_act_cfg(g0.act, g0.leaky), make_act_cfg(c1->g.act, c1->g.leaky)};
+            const char* amode = getenv("SNNHIP_ESPCN_A");
+            st.wino = !(amode && strcmp(amode, "direct") == 0);
+            const int aTW = st.wino ? WinoTile::TW : A_TW, aTH = st.wino ? W_TH : A_TH;
+            st.a = FusedAParams{g0.N, g0.H, g0.W, up_div(g0.W, aTW), up_div(g0.H, aTH), make_act_cfg(g0.act, g0.leaky), make_act_cfg(c1->g.act, c1->g.leaky)};
             std::vector<float> wA1(static_cast<size_t>(ks1) * 64, 0.0f), wA2(36 * 64);
             for (int s = 0; s < ks1; ++s)
                 for (int l = 0; l < 64; ++l) {
                     const int oc = l & 15, t = 4 * s + (l >> 4);
                     if (t < taps1) wA1[s * 64 + l] = c0->w_oihw[static_cast<size_t>(oc) * taps1 + t];
                 }
-            for (int tap = 0; tap < 9; ++tap)
-                for (int j = 0; j < 4; ++j)
+            if (st.wino) {
+                wA1.assign(static_cast<size_t>(wino_conv1_ksteps(K1)) * 64, 0.0f);
+                for (int s = 0; s < wino_conv1_ksteps(K1); ++s)
                     for (int l = 0; l < 64; ++l) {
-                        const int oc = l & 15, ic = 4 * (l >> 4) + j;
-                        wA2[(tap * 4 + j) * 64 + l] = c1->w_oihw[(static_cast<size_t>(oc) * 16 + ic) * 9 + tap];
+                        const int t = wino_conv1_tap(K1, s, l >> 4);
+                        if (t >= 0) wA1[s * 64 + l] = c0->w_oihw[static_cast<size_t>(l & 15) * taps1 + t];
                     }
+                // U[pos = xi*4+nu][oc][ic] = (G g Gt)[xi][nu], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], in double, stored as the
+                // kernel's LDS image: float4 index (pos*16 + oc)*4 + (q ^ 2*((oc>>2)&1)) holds ic = 4q .. 4q+3
+                static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+                wA2.assign(4096, 0.0f);
+                for (int oc = 0; oc < 16; ++oc)
+                    for (int ic = 0; ic < 16; ++ic) {
+                        const float* gk = &c1->w_oihw[(static_cast<size_t>(oc) * 16 + ic) * 9];
+                        double tmp[4][3];
+                        for (int xi = 0; xi < 4; ++xi)
+                            for (int v = 0; v < 3; ++v) tmp[xi][v] = Gm[xi][0] * gk[0 * 3 + v] + Gm[xi][1] * gk[1 * 3 + v] + Gm[xi][2] * gk[2 * 3 + v];
+                        for (int xi = 0; xi < 4; ++xi)
+                            for (int nu = 0; nu < 4; ++nu) {
+                                const double u = tmp[xi][0] * Gm[nu][0] + tmp[xi][1] * Gm[nu][1] + tmp[xi][2] * Gm[nu][2];
+                                const int q = ic >> 2, slot = q ^ (((oc >> 2) & 1) << 1);
+                                wA2[(((xi * 4 + nu) * 16 + oc) * 4 + slot) * 4 + (ic & 3)] = static_cast<float>(u);
+                            }
+                    }
+            } else {
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int j = 0; j < 4; ++j)
+                        for (int l = 0; l < 64; ++l) {
+                            const int oc = l & 15, ic = 4 * (l >> 4) + j;
+                            wA2[(tap * 4 + j) * 64 + l] = c1->w_oihw[(static_cast<size_t>(oc) * 16 + ic) * 9 + tap];
+                        }
+            }
             std::vector<float> e1 = fold_epilogue(c0->epi4, 16, g0.useBN), e2 = fold_epilogue(c1->epi4, 16, c1->g.useBN);
             rc = chain->upload(wA1.data(), wA1.size(), &st.w1);
             if (rc == SNNHIP_OK) rc = chain->upload(wA2.data(), wA2.size(), &st.w2);
@@ -516,7 +1078,8 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             if (rc == SNNHIP_OK) rc = chain->upload(e2.data(), e2.size(), &st.e2);
             memcpy(st.outDims, c1->outDims, sizeof(st.outDims));
             char buf[200];
-            snprintf(buf, sizeof(buf), "fused[conv%dx%d(1->16)+conv3x3(16->16)] mfma_f32_16x16x4 tile=%dx%d", K1, K1, A_TW, A_TH);
+            snprintf(buf, sizeof(buf), "fused[conv%dx%d(1->16)+conv3x3(16->16)%s] mfma_f32_16x16x4 tile=%dx%d", K1, K1,
+                     st.wino ? " winograd F(2x2,3x3)" : "", aTW, aTH);
             st.desc = buf;
             st.flops = c0->flops + c1->flops;
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (1 + 16) + 16.0 * taps1 + 16.0 * 16 * 9);
@@ -527,17 +1090,42 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             // ---- rule B
             const ConvGeom& g0 = c0->g;
             st.kind = ChainPlan::FUSED_B;
-            st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, B_TW), up_div(g0.H, B_TH), make_act_cfg(g0.act, g0.leaky)};
+            // default: the direct VALU kernel (43 us per 1080p frame); SNNHIP_ESPCN_B=wino | wino_persistent selects the Winograd /
+            // 4x4x1-MFMA kernel (45 / 50 us: fewer instructions, but its 80 KB tile limits residency to 2 blocks per CU and the
+            // load phases of co-resident blocks coincide)
+            const char* bmode = getenv("SNNHIP_ESPCN_B");
+            st.wino = bmode && strncmp(bmode, "wino", 4) == 0;
+            st.persistent = bmode && strcmp(bmode, "wino_persistent") == 0;
+            const int bTW = st.wino ? 64 : B_TW, bTH = st.wino ? 16 : B_TH;
+            st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, bTW), up_div(g0.H, bTH), make_act_cfg(g0.act, g0.leaky)};
             std::vector<float> wB(9 * 16 * 4);
             for (int tap = 0; tap < 9; ++tap)
                 for (int ic = 0; ic < 16; ++ic)
                     for (int o = 0; o < 4; ++o) wB[(tap * 16 + ic) * 4 + o] = c0->w_oihw[(static_cast<size_t>(o) * 16 + ic) * 9 + tap];
+            if (st.wino) {
+                // U[pos][oc][ic] = (G g Gt)[xi][nu] as the kernel's LDS image: float index ((pos*4 + ic/4)*4 + oc)*4 + ic%4
+                static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+                wB.assign(1024, 0.0f);
+                for (int oc = 0; oc < 4; ++oc)
+                    for (int ic = 0; ic < 16; ++ic) {
+                        const float* gk = &c0->w_oihw[(static_cast<size_t>(oc) * 16 + ic) * 9];
+                        double tmp[4][3];
+                        for (int xi = 0; xi < 4; ++xi)
+                            for (int v = 0; v < 3; ++v) tmp[xi][v] = Gm[xi][0] * gk[0 * 3 + v] + Gm[xi][1] * gk[1 * 3 + v] + Gm[xi][2] * gk[2 * 3 + v];
+                        for (int xi = 0; xi < 4; ++xi)
+                            for (int nu = 0; nu < 4; ++nu) {
+                                const double u = tmp[xi][0] * Gm[nu][0] + tmp[xi][1] * Gm[nu][1] + tmp[xi][2] * Gm[nu][2];
+                                wB[(((xi * 4 + nu) * 4 + (ic >> 2)) * 4 + oc) * 4 + (ic & 3)] = static_cast<float>(u);
+                            }
+                    }
+            }
             std::vector<float> e1 = fold_epilogue(c0->epi4, 4, g0.useBN);
             rc = chain->upload(wB.data(), wB.size(), &st.w1);
             if (rc == SNNHIP_OK) rc = chain->upload(e1.data(), e1.size(), &st.e1);
             memcpy(st.outDims, sp1->outDims, sizeof(st.outDims));
             char buf[200];
-            snprintf(buf, sizeof(buf), "fused[conv3x3(16->4)+depth_to_space(2)+tanh] valu_f32 tile=%dx%d", B_TW, B_TH);
+            snprintf(buf, sizeof(buf), "fused[conv3x3(16->4)%s+depth_to_space(2)+tanh] %s tile=%dx%d", st.wino ? " winograd F(2x2,3x3)" : "",
+                     st.wino ? "mfma_f32_4x4x1" : "valu_f32", bTW, bTH);
             st.desc = buf;
             st.flops = c0->flops;
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);

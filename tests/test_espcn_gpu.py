@@ -104,3 +104,41 @@ def test_chain_rejects_unfusable(ctx):
     with pytest.raises(snn.SnnHipError) as e:
         snn.chain_plan(ctx, [p])
     assert e.value.code == -3
+
+
+VARIANTS = [("direct", "direct"), ("wino", "direct"), ("wino", "wino"), ("direct", "wino_persistent")]
+
+
+@pytest.mark.parametrize("a_mode,b_mode", VARIANTS)
+@pytest.mark.parametrize("n,h,w", [(1, 72, 96), (2, 19, 71), (1, 33, 130), (1, 16, 32)])
+def test_espcn_kernel_variants_match_oracle(ctx, monkeypatch, a_mode, b_mode, n, h, w):
+    """Every selectable kernel of the fused chain (SNNHIP_ESPCN_A = wino | direct, SNNHIP_ESPCN_B = direct | wino |
+    wino_persistent) against the oracle: the Winograd F(2x2,3x3) evaluations stay inside the same 1e-4 bound."""
+    import shadernn_amd as snn
+    from shadernn_amd import models
+
+    monkeypatch.setenv("SNNHIP_ESPCN_A", a_mode)
+    monkeypatch.setenv("SNNHIP_ESPCN_B", b_mode)
+    net = models.espcn_weights(seed=4)
+    x = np.random.default_rng(11).random((n, h, w, 1), dtype=np.float32)
+    runner = snn.EspcnRunner(ctx, net, n, h, w, fused=True)
+    desc = runner.describe()[0]
+    assert ("winograd" in desc.split(" -> ")[0]) == (a_mode == "wino"), desc
+    assert ("mfma_f32_4x4x1" in desc) == b_mode.startswith("wino"), desc
+    np.testing.assert_allclose(runner(x), O.forward(net, x), err_msg=desc, **TOL)
+
+
+@pytest.mark.parametrize("a_mode,b_mode", [("direct", "direct"), ("wino", "wino"), ("wino", "wino_persistent")])
+def test_espcn_kernel_variants_full_size(ctx, monkeypatch, a_mode, b_mode):
+    """1080p: the persistent tile loops (4080 / 2040 tiles over 512 resident blocks) agree with the per-layer path."""
+    import shadernn_amd as snn
+    from shadernn_amd import models
+
+    net = models.espcn_weights(seed=1)
+    H, W = 1080, 1920
+    x = np.random.default_rng(2).random((1, H, W, 1), dtype=np.float32)
+    y_u = snn.EspcnRunner(ctx, net, 1, H, W, fused=False)(x)
+    monkeypatch.setenv("SNNHIP_ESPCN_A", a_mode)
+    monkeypatch.setenv("SNNHIP_ESPCN_B", b_mode)
+    y_f = snn.EspcnRunner(ctx, net, 1, H, W, fused=True)(x)
+    np.testing.assert_allclose(y_f, y_u, rtol=2e-5, atol=2e-5)

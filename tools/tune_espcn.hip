@@ -54,6 +54,39 @@ int espcn_stream_launch(hipStream_t, const void*, const float*, const float*, co
         }                                                                     \
     } while (0)
 
+float timeBW(const float* x, const float* w, const float* e, float* y, int H, int W, int reps) {
+    FusedBParams p{1, H, W, (W + 63) / 64, (H + 15) / 16, make_act_cfg(0, 0.f)};
+    dim3 grid(512);
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((conv3x3_c16o4_wino_d2s_tanh_kernel<true>), grid, dim3(256), 0, 0, p, x, w, e, y);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((conv3x3_c16o4_wino_d2s_tanh_kernel<true>), grid, dim3(256), 0, 0, p, x, w, e, y);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return 1e3f * ms / reps;
+}
+
+template <int K1, int WTH, int WWPS>
+float timeW(const float* x, const float* w1, const float* w2, const float* e1, const float* e2, float* y, int H, int W, int reps) {
+    FusedAParams p{1, H, W, (W + WinoTile::TW - 1) / WinoTile::TW, (H + WTH - 1) / WTH, make_act_cfg(1, 0.f), make_act_cfg(1, 0.f)};
+    dim3 grid(256 * WWPS);
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((conv_kxk_c1o16_wino3x3_c16o16_kernel<K1, WTH, 2, WWPS>), grid, dim3(256), 0, 0, p, x, w1, w2, e1, e2, y);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((conv_kxk_c1o16_wino3x3_c16o16_kernel<K1, WTH, 2, WWPS>), grid, dim3(256), 0, 0, p, x, w1, w2, e1, e2, y);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return 1e3f * ms / reps;
+}
+
 template <int K1, int TW, int TH, int U = 3, int WPS = 2>
 float timeA(const float* x, const float* w1, const float* w2, const float* e1, const float* e2, float* y, int H, int W, int reps) {
     FusedAParams p{1, H, W, (W + TW - 1) / TW, (H + TH - 1) / TH, make_act_cfg(1, 0.f), make_act_cfg(1, 0.f)};
@@ -116,12 +149,32 @@ int main() {
     }
 #ifdef PHASE_TIMING
     {
+#ifdef PHASE_BW
+        FusedBParams p{1, H, W, (W + 63) / 64, (H + 15) / 16, make_act_cfg(0, 0.f)};
+        int nb = p.tilesX * p.tilesY;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL((conv_kxk_c1o16_wino3x3_c16o16_kernel<5, 16, 2, 2>), dim3(512), dim3(256), 0, 0,
+                               FusedAParams{1, H, W, 60, 68, make_act_cfg(1, 0.f), make_act_cfg(1, 0.f)}, x, w, w, w, w, mid);
+            hipLaunchKernelGGL((conv3x3_c16o4_wino_d2s_tanh_kernel<true>), dim3(512), dim3(256), 0, 0, p, mid, w, w, y);
+            nb = 512;
+            CK(hipDeviceSynchronize());
+        }
+#elif defined(PHASE_WINO)
+        constexpr int WTH = PHASE_WINO_TH, WWPS = PHASE_WINO_WPS;
+        FusedAParams p{1, H, W, (W + WinoTile::TW - 1) / WinoTile::TW, (H + WTH - 1) / WTH, make_act_cfg(1, 0.f), make_act_cfg(1, 0.f)};
+        int nb = 256 * WWPS;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL((conv_kxk_c1o16_wino3x3_c16o16_kernel<5, WTH, 2, WWPS>), dim3(nb), dim3(256), 0, 0, p, x, w, w, w, w, mid);
+            CK(hipDeviceSynchronize());
+        }
+#else
         FusedAParams p{1, H, W, (W + 63) / 64, (H + 7) / 8, make_act_cfg(1, 0.f), make_act_cfg(1, 0.f)};
         int nb = p.tilesX * p.tilesY;
         hipLaunchKernelGGL((conv_kxk_c1o16_conv3x3_c16o16_kernel<5, 64, 8, true, 3, 3>), dim3(nb), dim3(256), 0, 0, p, x, w, w, w, w, mid);
         CK(hipDeviceSynchronize());
         hipLaunchKernelGGL((conv_kxk_c1o16_conv3x3_c16o16_kernel<5, 64, 8, true, 3, 3>), dim3(nb), dim3(256), 0, 0, p, x, w, w, w, w, mid);
         CK(hipDeviceSynchronize());
+#endif
         std::vector<long long> st((size_t) 8192 * 4 * 8);
         CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
         long long tmin = st[0];
@@ -165,7 +218,10 @@ int main() {
 #ifdef TUNE_VARIANTS
     TUNE_VARIANTS
 #else
+    printf("W<5> wino  %.1f us\n", timeW<5, 16, 2>(x, w, w, w, w, mid, H, W, R));
+    printf("W<5,8,3> wino  %.1f us\n", timeW<5, 8, 3>(x, w, w, w, w, mid, H, W, R));
     printf("A<5,64,8,U3,W3>  %.1f us\n", timeA<5, 64, 8, 3, 3>(x, w, w, w, w, mid, H, W, R));
+    printf("BW wino    %.1f us\n", timeBW(mid, w, w, y, H, W, R));
     printf("B<32,8>    %.1f us\n", timeB<32, 8>(mid, w, w, y, H, W, R));
     printf("B<64,4>    %.1f us\n", timeB<64, 4>(mid, w, w, y, H, W, R));
     printf("B<16,16>   %.1f us\n", timeB<16, 16>(mid, w, w, y, H, W, R));

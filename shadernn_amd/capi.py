@@ -231,8 +231,8 @@ class Plan:
         return tuple(d)
 
     def describe(self):
-        buf = C.create_string_buffer(512)
-        check(lib().snnhip_plan_describe(self.h, buf, 512))
+        buf = C.create_string_buffer(2048)
+        check(lib().snnhip_plan_describe(self.h, buf, 2048))
         return buf.value.decode()
 
     def cost(self):
@@ -257,8 +257,8 @@ class Plan:
         return lib().snnhip_plan_num_steps(self.h)
 
     def step_describe(self, i):
-        buf = C.create_string_buffer(512)
-        check(lib().snnhip_plan_step_describe(self.h, i, buf, 512))
+        buf = C.create_string_buffer(1024)
+        check(lib().snnhip_plan_step_describe(self.h, i, buf, 1024))
         return buf.value.decode()
 
     def step_cost(self, i):

@@ -265,15 +265,18 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
     constexpr int C1W = TW + 2, C1H = TH + 2;
     constexpr int C1P = 40, HALFP = 20;                        // LDS row pitch / odd-column plane offset, in pixels (see phase 2)
     constexpr int INW = TW + 2 + 2 * P1, INH = TH + 2 + 2 * P1;
+    constexpr int INP = 48;                                    // LDS row pitch of the input tile: == 16 (mod 32) puts the four tap rows a
+                                                               // wave reads in one ds_read_b32 (lane group g -> row g) on disjoint banks
     constexpr int KS1 = wino_conv1_ksteps(K1);
     constexpr int NG1 = (C1H * C1W + 15) / 16;                 // 16-pixel groups of phase 1
     constexpr int GPW = (NG1 + 3) / 4;                         // groups per wave (contiguous range)
     constexpr int NIT = (GPW + U - 1) / U;
     constexpr int GROUPS2 = TH / 8;                            // Winograd tile rows (= phase-2 groups) per wave
-    constexpr int NLD = (INH * INW + 8 + 255) / 256;
+    constexpr int NLD = (INH * INP + 8 + 255) / 256;
+    static_assert(INW <= INP, "input pitch");
     static_assert(C1W / 2 + 1 <= HALFP && HALFP + C1W / 2 <= C1P, "plane layout");
 
-    __shared__ __attribute__((aligned(16))) float smem[C1H * C1P * 16 + 4096 + INH * INW + 8];
+    __shared__ __attribute__((aligned(16))) float smem[C1H * C1P * 16 + 4096 + INH * INP + 8];
     float* s_c1 = smem;
     float* s_U = smem + C1H * C1P * 16;
     float* s_in = s_U + 4096;
@@ -302,16 +305,16 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int idx = tid + k * 256;
-            const int r = idx / INW, c = idx - r * INW;
+            const int r = idx / INP, c = idx - r * INP;
             const int gy = y0 - 1 - P1 + r, gx = x0 - 1 - P1 + c;
             vin[k] = 0.0f;
-            if (idx < INH * INW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) vin[k] = xn[static_cast<size_t>(gy) * p.W + gx];
+            if (r < INH && c < INW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) vin[k] = xn[static_cast<size_t>(gy) * p.W + gx];
         }
     };
     auto store_input = [&]() {
 #pragma unroll
         for (int k = 0; k < NLD; ++k)
-            if (tid + k * 256 < INH * INW + 8) s_in[tid + k * 256] = vin[k];
+            if (tid + k * 256 < INH * INP + 8) s_in[tid + k * 256] = vin[k];
     };
 
     int tile = blockIdx.x;
@@ -338,8 +341,8 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
         sc2[r] = ep2[(4 * g + r) * 2];
         sh2[r] = ep2[(4 * g + r) * 2 + 1];
     }
-    const int rowTap = (g < K1 ? g : 0) * INW; // K-steps s < K1: tap row g (invalid g: zero weight, any initialised row)
-    const int lastTap = 4 * INW + g;           // K-steps s >= K1 (K1 == 5): tap row 4, col g (+4)
+    const int rowTap = (g < K1 ? g : 0) * INP; // K-steps s < K1: tap row g (invalid g: zero weight, any initialised row)
+    const int lastTap = 4 * INP + g;           // K-steps s >= K1 (K1 == 5): tap row 4, col g (+4)
     SNNHIP_STAMP(1);
     __syncthreads();
     SNNHIP_STAMP(2);
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
     const int next = tile + gridDim.x;
     const bool more = next < ntiles;
     if (more) issue_loads(next);
+    const bool border = x0 == 0 || y0 == 0 || x0 + TW >= p.W || y0 + TH >= p.H; // wave-uniform
 
     // ---- phase 1: conv1 over the C1H x C1W region, pixels flattened into 16-wide groups; wave wv owns groups
     // [wv*GPW, wv*GPW+GPW), two per iteration (two independent MFMA chains).  The LDS operands of iteration it+1 are
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
                 const int pc = valid[buf][u] ? pi : 0;
                 rr[buf][u] = pc / C1W;
                 cc[buf][u] = pc - rr[buf][u] * C1W;
-                const float* src = s_in + rr[buf][u] * INW + cc[buf][u];
+                const float* src = s_in + rr[buf][u] * INP + cc[buf][u];
                 const float* srcRow = src + rowTap;
 #pragma unroll
                 for (int s = 0; s < KS1; ++s) bv[buf][u][s] = s < K1 ? srcRow[s] : src[lastTap + 4 * (s - K1)];
@@ -387,13 +391,15 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
                 for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bv[cur][u][s], acc[u], 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int gy = y0 - 1 + rr[cur][u], gx = x0 - 1 + cc[cur][u];
-                const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W; // outside the image: conv2's zero padding
                 float4 o;
-                o.x = inside ? act_mode<AM>(p.act1, fmaf(acc[u][0], sc1[0], sh1[0])) : 0.0f;
-                o.y = inside ? act_mode<AM>(p.act1, fmaf(acc[u][1], sc1[1], sh1[1])) : 0.0f;
-                o.z = inside ? act_mode<AM>(p.act1, fmaf(acc[u][2], sc1[2], sh1[2])) : 0.0f;
-                o.w = inside ? act_mode<AM>(p.act1, fmaf(acc[u][3], sc1[3], sh1[3])) : 0.0f;
+                o.x = act_mode<AM>(p.act1, fmaf(acc[u][0], sc1[0], sh1[0]));
+                o.y = act_mode<AM>(p.act1, fmaf(acc[u][1], sc1[1], sh1[1]));
+                o.z = act_mode<AM>(p.act1, fmaf(acc[u][2], sc1[2], sh1[2]));
+                o.w = act_mode<AM>(p.act1, fmaf(acc[u][3], sc1[3], sh1[3]));
+                if (border) { // only tiles on the image border have conv1 pixels outside the image: they are conv2's zero padding
+                    const int gy = y0 - 1 + rr[cur][u], gx = x0 - 1 + cc[cur][u];
+                    if (!(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)) o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
                 if (valid[cur][u]) {
                     const int c = cc[cur][u];
                     const int pl = rr[cur][u] * C1P + (c & 1) * HALFP + (c >> 1);
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 const int gy = y0 + 2 * trow + a, gx = x0 + 2 * px + bb;
-                if (gy < p.H && gx < p.W) {
+                if (!border || (gy < p.H && gx < p.W)) {
                     float4 o;
                     o.x = act_mode<AM>(p.act2, fmaf(Y[a][bb][0], sc2[0], sh2[0]));
                     o.y = act_mode<AM>(p.act2, fmaf(Y[a][bb][1], sc2[1], sh2[1]));
@@ -1077,9 +1083,20 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             if (rc == SNNHIP_OK) rc = chain->upload(e1.data(), e1.size(), &st.e1);
             if (rc == SNNHIP_OK) rc = chain->upload(e2.data(), e2.size(), &st.e2);
             memcpy(st.outDims, c1->outDims, sizeof(st.outDims));
-            char buf[200];
-            snprintf(buf, sizeof(buf), "fused[conv%dx%d(1->16)+conv3x3(16->16)%s] mfma_f32_16x16x4 tile=%dx%d", K1, K1,
-                     st.wino ? " winograd F(2x2,3x3)" : "", aTW, aTH);
+            char buf[320];
+            // MFMA flops actually issued (2048 per v_mfma_f32_16x16x4_f32): conv1 on the halo region with K padded to a multiple
+            // of 4, conv2 either direct (36 per 16 pixels) or Winograd (64 per 16 tiles = 64 pixels)
+            double mfmaFlops;
+            {
+                const double tiles = static_cast<double>(st.a.tilesX) * st.a.tilesY * g0.N;
+                const int c1px = (aTW + 2) * (aTH + 2);
+                const double conv1 = st.wino ? 4.0 * (((((c1px + 15) / 16) + 3) / 4 + 1) / 2 * 2) * wino_conv1_ksteps(K1) : ((c1px + 15) / 16) * ks1;
+                const double conv2 = st.wino ? (aTW / 2) * (aTH / 2) / 16 * 64.0 : aTW * aTH / 16 * 36.0;
+                mfmaFlops = tiles * (conv1 + conv2) * 2048.0;
+            }
+            snprintf(buf, sizeof(buf), "fused[conv%dx%d(1->16)+conv3x3(16->16)%s] mfma_f32_16x16x4 tile=%dx%d kernel=%s mfma_flops=%.6g", K1, K1,
+                     st.wino ? " winograd F(2x2,3x3)" : "", aTW, aTH,
+                     st.wino ? "conv_kxk_c1o16_wino3x3_c16o16_kernel" : "conv_kxk_c1o16_conv3x3_c16o16_kernel", mfmaFlops);
             st.desc = buf;
             st.flops = c0->flops + c1->flops;
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (1 + 16) + 16.0 * taps1 + 16.0 * 16 * 9);
@@ -1124,8 +1141,8 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             if (rc == SNNHIP_OK) rc = chain->upload(e1.data(), e1.size(), &st.e1);
             memcpy(st.outDims, sp1->outDims, sizeof(st.outDims));
             char buf[200];
-            snprintf(buf, sizeof(buf), "fused[conv3x3(16->4)%s+depth_to_space(2)+tanh] %s tile=%dx%d", st.wino ? " winograd F(2x2,3x3)" : "",
-                     st.wino ? "mfma_f32_4x4x1" : "valu_f32", bTW, bTH);
+            snprintf(buf, sizeof(buf), "fused[conv3x3(16->4)%s+depth_to_space(2)+tanh] %s tile=%dx%d kernel=%s", st.wino ? " winograd F(2x2,3x3)" : "",
+                     st.wino ? "mfma_f32_4x4x1" : "valu_f32", bTW, bTH, st.wino ? "conv3x3_c16o4_wino_d2s_tanh_kernel" : "conv3x3_c16o4_d2s_tanh_kernel");
             st.desc = buf;
             st.flops = c0->flops;
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);

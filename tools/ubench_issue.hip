@@ -11,16 +11,23 @@ __global__ __launch_bounds__(256) void kern(float* out, long long* cyc, int iter
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = a + i;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 pk[8], pb = {b, a};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pk[i] = f32x2{a + i, b + i};
     long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             if (KIND == 0) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m], 0, 0, 0);
+            if (KIND == 2 || KIND == 3) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m], 0, 0, 0);
             if (KIND == 1) acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[m], 0, 0, 0);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int r = (m * K + k) & 15;
-                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(b), "v"(a));
+                if (KIND < 2) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(b), "v"(a));
+                if (KIND == 2) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[r]) : "v"(b));
+                if (KIND == 3) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(pk[r & 7]) : "v"(pb));
             }
         }
     }
@@ -28,6 +35,8 @@ __global__ __launch_bounds__(256) void kern(float* out, long long* cyc, int iter
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += v[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += pk[i].x + pk[i].y;
 #pragma unroll
     for (int m = 0; m < 4; ++m) s += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -44,7 +53,7 @@ void run(float* out, long long* cyc, int blocksPerCU) {
     hipMemcpy(h, cyc, nb * 8, hipMemcpyDeviceToHost);
     double s = 0;
     for (int i = 0; i < nb; ++i) s += h[i];
-    printf("%s K=%2d VALU per MFMA, %d wave(s)/SIMD: %.1f cycles per MFMA per wave\n", KIND ? "4x4x1  " : "16x16x4", K, blocksPerCU, s / nb / iters / 4);
+    printf("%s K=%2d VALU per MFMA, %d wave(s)/SIMD: %.1f cycles per MFMA per wave\n", KIND == 1 ? "4x4x1  " : KIND == 2 ? "16x16x4+v_sub" : KIND == 3 ? "16x16x4+v_pk_add(neg)" : "16x16x4", K, blocksPerCU, s / nb / iters / 4);
 }
 
 int main() {
@@ -53,6 +62,10 @@ int main() {
     hipMalloc(&out, 4096 * 256 * 4);
     hipMalloc(&cyc, 4096 * 8);
     for (int w = 1; w <= 3; ++w) {
+        run<8, 2>(out, cyc, w);
+        run<8, 3>(out, cyc, w);
+        run<16, 2>(out, cyc, w);
+        run<16, 3>(out, cyc, w);
         run<0, 1>(out, cyc, w);
         run<2, 1>(out, cyc, w);
         run<4, 1>(out, cyc, w);

@@ -308,7 +308,9 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     const char* force = getenv("SNNHIP_CONV");
     if (force && strcmp(force, "generic") == 0) return SNNHIP_E_UNSUPPORTED;
     const bool forced = force && strcmp(force, "mfma") == 0;
-    if (!forced && (g.IC < 8 || g.OC < 16)) return SNNHIP_E_UNSUPPORTED;
+    // measured (tools/bench_layers.py): even IC = 3 layers (one 8-channel chunk, 5/8 of it padding) run 1.4-2.3x faster here than
+    // on the VALU kernel, so only the channel-thin outputs (OC < 16: most of a 32-wide MFMA column block would be padding) stay there
+    if (!forced && g.OC < 16) return SNNHIP_E_UNSUPPORTED;
     const double inCount = static_cast<double>(g.N) * g.H * g.W * g.IC;
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED; // 32-bit element offsets in the kernel
@@ -346,7 +348,8 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         const TileLayout L = layout(shapes[s][0], shapes[s][1], shapes[s][2]);
         if (L.total > 9 * 256 || L.ldsBytes > 150 * 1024) continue; // staging registers / LDS (two buffers)
         const double tiles = static_cast<double>(up_div(g.N, TB)) * up_div(g.OH, TH) * up_div(g.OW, TW);
-        const double cost = tiles * (128.0 * taps + L.total / (2.0 * C8) * 0.5); // MFMA work dominates, staging breaks ties
+        double cost = tiles * (128.0 * taps + L.total / (2.0 * C8) * 0.5); // MFMA work dominates, staging breaks ties
+        if (L.ldsBytes > 80 * 1024) cost *= 1.4;                          // only one block per CU would fit
         if (best < 0 || cost < bestCost) {
             best = s;
             bestCost = cost;

@@ -161,6 +161,67 @@ typedef struct {
 } snnhip_subpixel_desc;
 int snnhip_subpixel_plan_create(snnhip_ctx* ctx, const snnhip_subpixel_desc* desc, snnhip_plan** out);
 
+/* ---- element-wise, pooling and shape operators next to the conv path: what a ResNet-18 /
+ * MobileNetV2 / Candy graph needs between its convolutions.  All are HBM-bound NHWC kernels (16-byte channel-contiguous accesses).
+ *   reference interface replaced (core/src/ic2, core/data/assets/shaders)         | entry point
+ *   AddLayerVulkan::createCS addlayerVulkan.cpp:33-114 + vk_add.comp:41-88        | snnhip_add_plan_create (two inputs: snnhip_plan_run_n)
+ *   ActivationLayerVulkan activationVulkan.cpp + vk_activation.comp:41-86         | snnhip_activation_plan_create
+ *   BatchNormalizationLayerVulkan batchnormVulkan.cpp + vk_batchnorm.comp:54-104  | snnhip_batchnorm_plan_create
+ *   MaxPooling2DLayerVulkan maxpool2dVulkan.cpp:33-130 + vk_maxpool2d.comp:42-74  | snnhip_pool2d_plan_create (type 0)
+ *   AveragePooling2DLayerVulkan avgpool2dVulkan.cpp + vk_avgpool2d.comp:42-69     | snnhip_pool2d_plan_create (type 1)
+ *   AdaptiveAvgPool2dLayerGl adaptiveavgpool2dGL.cpp (mean over the whole image)  | snnhip_pool2d_plan_create (type 1, kernel = input size)
+ *   PadLayerVulkan padlayerVulkan.cpp:33-110 + vk_pad.comp:42-71                  | snnhip_pad_plan_create
+ *   UpSampling2DLayerVulkan upsampling2dVulkan.cpp:35-123 + vk_upsampling2d_{nearest,bilinear}.comp | snnhip_upsample_plan_create
+ *   InstanceNormLayerVulkan instancenormVulkan.cpp + vk_instancenorm.comp:53-160  | snnhip_instancenorm_plan_create */
+typedef struct {
+    int N, H, W, C;
+    int act;      /* SNNHIP_ACT_* (0..6; the quirk id 7 is conv-only) */
+    float leaky;
+} snnhip_eltwise_desc;
+int snnhip_add_plan_create(snnhip_ctx* ctx, const snnhip_eltwise_desc* desc, snnhip_plan** out);
+int snnhip_activation_plan_create(snnhip_ctx* ctx, const snnhip_eltwise_desc* desc, snnhip_plan** out);
+/* y = act(gamma / max(sqrt(var + 1e-3), 1e-4) * (x - mean) + beta), per channel (vk_batchnorm.comp:63-68) */
+int snnhip_batchnorm_plan_create(snnhip_ctx* ctx, const snnhip_eltwise_desc* desc, const float* beta, const float* gamma, const float* mean,
+                                 const float* var, snnhip_plan** out);
+
+#define SNNHIP_POOL_MAX 0
+#define SNNHIP_POOL_AVG 1
+typedef struct {
+    int N, H, W, C;
+    int kh, kw, sh, sw;
+    int padT, padL; /* the Vulkan layers force both to 0 ("not padding on top left", maxpool2dVulkan.cpp:62-64); kept as parameters */
+    int OH, OW;     /* 0 = derive with the reference's float rule: in/stride + max(0, 1 - k/stride | 1 - 1/stride) (maxpool2d.cpp:26-36) */
+    int same;       /* padding mode for the OH/OW rule: 0 "valid"/"none"/"0", 1 anything else */
+    int type;       /* SNNHIP_POOL_*: window clipped to the image; max starts at -100000.0, avg divides by the clipped count */
+} snnhip_pool2d_desc;
+int snnhip_pool2d_plan_create(snnhip_ctx* ctx, const snnhip_pool2d_desc* desc, snnhip_plan** out);
+
+typedef struct {
+    int N, H, W, C;
+    int padT, padB, padL, padR; /* output = (H + padT + padB) x (W + padL + padR) (padlayer.cpp:58-67) */
+    int mode;                   /* 0 constant (zeros), 1 replicate, 2 reflect (vk_pad.comp:55-66) */
+} snnhip_pad_desc;
+/* reference quirk kept: the shader shifts x by padT and y by padL (padlayerVulkan.cpp:81-82 feeds uPad = {offsets[0], offsets[2]}) */
+int snnhip_pad_plan_create(snnhip_ctx* ctx, const snnhip_pad_desc* desc, snnhip_plan** out);
+
+#define SNNHIP_UPSAMPLE_NEAREST 0
+#define SNNHIP_UPSAMPLE_BILINEAR 1
+typedef struct {
+    int N, H, W, C;
+    float scale; /* output = trunc(in * scale) (upsampling2d.h:41-44); the shaders sample at pos * (1/scale) */
+    int mode;    /* SNNHIP_UPSAMPLE_* */
+} snnhip_upsample_desc;
+int snnhip_upsample_plan_create(snnhip_ctx* ctx, const snnhip_upsample_desc* desc, snnhip_plan** out);
+
+typedef struct {
+    int N, H, W, C;
+    int act;
+    float leaky;
+    float eps; /* the Vulkan shader hard-codes 1e-5 and ignores the parsed epsilon (vk_instancenorm.comp:118); pass 1e-5f for parity */
+} snnhip_instancenorm_desc;
+/* y = act((x - mean_hw) * gamma / sqrt(var_hw + eps) + beta), statistics per image and channel, biased variance */
+int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_desc* desc, const float* beta, const float* gamma, snnhip_plan** out);
+
 /* Try to replace a linear chain of plans (plan[i+1] consumes only plan[i]'s output) by fused kernels.
  * On success *out runs the whole chain in <= n launches; intermediate tensors that become internal are never
  * materialised.  Returns SNNHIP_E_UNSUPPORTED when no fusion rule matches (callers keep the unfused plans).

@@ -574,6 +574,151 @@ void snn_oracle_subpixel_nhwc(const float* x, int N, int H, int W, int C, int fa
 /* algorithm demo/common/prng.h states; RandomFloat as demo/common/testutil.cpp:41-46.               */
 /* ------------------------------------------------------------------------------------------------ */
 
+/* ===================================================================================================== */
+/* element-wise / pooling / shape operators                                         */
+/* ===================================================================================================== */
+
+/* shadertemplate_vk_add.comp:47-88 (the same ladder is in vk_activation.comp:52-86 and vk_batchnorm.comp:70-103) */
+void snn_oracle_add_act(const float* a, const float* b, long count, int act, float leaky, float* y) {
+    for (long i = 0; i < count; ++i) {
+        float v = a[i];
+        if (b) v = v + b[i];
+        y[i] = act_apply(act, leaky, v, 0.0f);
+    }
+}
+
+/* shadertemplate_vk_batchnorm.comp:61-68 */
+void snn_oracle_batchnorm(const float* x, long pixels, int C, const float* beta, const float* gamma, const float* mean, const float* var, int act,
+                          float leaky, float* y) {
+    for (long p = 0; p < pixels; ++p)
+        for (int c = 0; c < C; ++c) {
+            float sqrtVar = sqrtf(var[c] + 0.001f);
+            sqrtVar = sqrtVar > 0.0001f ? sqrtVar : 0.0001f;
+            float v = ((gamma[c] / sqrtVar) * (x[p * C + c] - mean[c])) + beta[c];
+            y[p * C + c] = act_apply(act, leaky, v, 0.0f);
+        }
+}
+
+/* maxpool2d.cpp:26-36 / avgpool2d.cpp:20-29 + genericlayer.cpp:64-90 (translation accumulated with max(0, .), truncating uint32 store) */
+int snn_oracle_pool_out_dim(int in, int kernel, int stride, int same) {
+    float scale = 1.0f / (float) stride;
+    float translation = same ? 1.0f - 1.0f / (float) stride : 1.0f - ((float) kernel / (float) stride);
+    float s = scale * (float) in;
+    if (s < 0.0f) s = 0.0f;
+    float t = translation < 0.0f ? 0.0f : translation;
+    return (int) (uint32_t) (s + t);
+}
+
+/* shadertemplate_vk_maxpool2d.comp:52-73 / shadertemplate_vk_avgpool2d.comp:52-68 */
+void snn_oracle_pool2d(const float* x, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int padT, int padL, int OH, int OW, int type,
+                       float* y) {
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox) {
+                int sx = ox * sw - padL, sy = oy * sh - padT;     /* spos = pos.xy*stride - pad */
+                int sfx = 0 > -sx ? 0 : -sx, sfy = 0 > -sy ? 0 : -sy; /* sfxy = max(0, -spos) */
+                int efx = kw < W - sx ? kw : W - sx, efy = kh < H - sy ? kh : H - sy; /* efxy = min(kernelSize, inputSize - spos) */
+                for (int c = 0; c < C; ++c) {
+                    float color = type == 0 ? -100000.0f : 0.0f, num = 0.0f;
+                    for (int fy = sfy; fy < efy; ++fy)
+                        for (int fx = sfx; fx < efx; ++fx) {
+                            float v = x[(((long) n * H + sy + fy) * W + sx + fx) * C + c];
+                            if (type == 0) color = color > v ? color : v;
+                            else color += v;
+                            num += 1.0f;
+                        }
+                    y[(((long) n * OH + oy) * OW + ox) * C + c] = type == 0 ? color : color / num;
+                }
+            }
+}
+
+/* shadertemplate_vk_pad.comp:50-70 */
+void snn_oracle_pad(const float* x, int N, int H, int W, int C, int padT, int padB, int padL, int padR, int mode, float* y) {
+    int OH = H + padT + padB, OW = W + padL + padR;
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox) {
+                int sx = ox - padT, sy = oy - padL; /* s0 = pos.xy - uPad, uPad = {offsets[0], offsets[2]} = {T, L} */
+                if (mode == 0) {
+                    sx = (sx >= 0 && sx < W) ? sx : W;
+                    sy = (sy >= 0 && sy < H) ? sy : H;
+                } else if (mode == 1) {
+                    sx = sx < 0 ? 0 : (sx > W - 1 ? W - 1 : sx);
+                    sy = sy < 0 ? 0 : (sy > H - 1 ? H - 1 : sy);
+                } else {
+                    sx = sx < 0 ? -sx : sx;
+                    sx = sx >= W ? 2 * W - 2 - sx : sx;
+                    sy = sy < 0 ? -sy : sy;
+                    sy = sy >= H ? 2 * H - 2 - sy : sy;
+                }
+                int inside = sx >= 0 && sx < W && sy >= 0 && sy < H; /* texelFetch outside the texture: 0 */
+                for (int c = 0; c < C; ++c) y[(((long) n * OH + oy) * OW + ox) * C + c] = inside ? x[(((long) n * H + sy) * W + sx) * C + c] : 0.0f;
+            }
+}
+
+static float up_fetch(const float* x, int H, int W, int C, int px, int py, int c) {
+    return (px >= 0 && px < W && py >= 0 && py < H) ? x[((long) py * W + px) * C + c] : 0.0f;
+}
+
+/* shadertemplate_vk_upsampling2d_nearest.comp:50-65 / shadertemplate_vk_upsampling2d_bilinear.comp:49-74 (means 0, norms 1) */
+void snn_oracle_upsample(const float* x, int N, int H, int W, int C, float scale, int mode, float* y) {
+    int OH = (int) (uint32_t) (scale * (float) H), OW = (int) (uint32_t) (scale * (float) W);
+    float inv = 1.0f / scale;
+    for (int n = 0; n < N; ++n) {
+        const float* xn = x + (long) n * H * W * C;
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox)
+                for (int c = 0; c < C; ++c) {
+                    float out;
+                    if (mode == 0) {
+                        int x1 = (int) floorf((float) ox * inv), y1 = (int) floorf((float) oy * inv);
+                        x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+                        y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+                        out = up_fetch(xn, H, W, C, x1, y1, c);
+                    } else {
+                        float off = 0.5f - 0.5f * inv;
+                        float srcX = (float) ox * inv - off;
+                        srcX = srcX < 0.0f ? 0.0f : (srcX > (float) (W - 1) ? (float) (W - 1) : srcX);
+                        int x11 = (int) floorf(srcX), x12 = x11 + 1;
+                        float srcY = (float) oy * inv - off;
+                        srcY = srcY < 0.0f ? 0.0f : (srcY > (float) (H - 1) ? (float) (H - 1) : srcY);
+                        int y11 = (int) floorf(srcY), y12 = y11 + 1;
+                        float r4 = up_fetch(xn, H, W, C, x11, y12, c), r3 = up_fetch(xn, H, W, C, x12, y12, c);
+                        float r1 = up_fetch(xn, H, W, C, x11, y11, c), r2 = up_fetch(xn, H, W, C, x12, y11, c);
+                        out = r1 * (((float) x12 - srcX) * ((float) y12 - srcY)) + r2 * ((srcX - (float) x11) * ((float) y12 - srcY)) +
+                              r3 * ((srcX - (float) x11) * (srcY - (float) y11)) + r4 * (((float) x12 - srcX) * (srcY - (float) y11));
+                    }
+                    y[(((long) n * OH + oy) * OW + ox) * C + c] = out;
+                }
+    }
+}
+
+/* shadertemplate_vk_instancenorm.comp:70-160; the sums are accumulated in double here (the shader's 256-thread tree in fp32
+ * has no defined order to copy) and rounded to float where the shader stores them */
+void snn_oracle_instancenorm(const float* x, int N, int H, int W, int C, const float* beta, const float* gamma, float eps, int act, float leaky,
+                             float* y) {
+    long HW = (long) H * W;
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c) {
+            const float* xn = x + (long) n * HW * C + c;
+            double sum = 0.0;
+            for (long p = 0; p < HW; ++p) sum += xn[p * C];
+            float mean = (float) (sum / (double) HW);
+            double sq = 0.0;
+            for (long p = 0; p < HW; ++p) {
+                float dv = xn[p * C] - mean;
+                sq += (double) (dv * dv);
+            }
+            float var = (float) (sq / (double) HW);
+            float sigma = sqrtf(var + eps);
+            float multiplier = gamma[c] / sigma;
+            for (long p = 0; p < HW; ++p) {
+                float color = (xn[p * C] - mean) * multiplier + beta[c];
+                y[((long) n * HW + p) * C + c] = act_apply(act, leaky, color, 0.0f);
+            }
+        }
+}
+
 static struct {
     uint64_t s[64];
     unsigned i, c;

@@ -146,6 +146,34 @@ enum {
 void snn_oracle_subpixel_nhwc(const float* x, int N, int H, int W, int C, int factor, int mode, float* y);
 
 /* ---- deterministic generators shared by tests / bench (reference demo/common/prng.h, testutil.cpp:41-46) */
+/* ---- element-wise / pooling / shape operators, NHWC ------------------------------- */
+/* restatements of the Vulkan compute shaders, one output element at a time in the shader's own order of operations.
+ * PARITY UNPINNED by reference fixtures (the reference tests them against ncnn layers on a GPU); cross-checked
+ * against torch CPU ops in tests/test_oracle.py. */
+
+/* vk_add.comp:41-88 / vk_activation.comp:41-86: y = act(a + b) (b may be NULL: y = act(a)) */
+void snn_oracle_add_act(const float* a, const float* b, long count, int act, float leaky, float* y);
+/* vk_batchnorm.comp:54-104: y = act(gamma / max(sqrt(var + 1e-3), 1e-4) * (x - mean) + beta), channel = index % C */
+void snn_oracle_batchnorm(const float* x, long pixels, int C, const float* beta, const float* gamma, const float* mean, const float* var, int act,
+                          float leaky, float* y);
+/* MaxPooling2DLayer / AveragePooling2DLayer::getOutputScaleDimAdjustment (maxpool2d.cpp:26-36, avgpool2d.cpp:20-29) through
+ * GenericModelLayer::getOutputDims (genericlayer.cpp:64-90): trunc(in / stride + max(0, same ? 1 - 1/stride : 1 - k/stride)) */
+int snn_oracle_pool_out_dim(int in, int kernel, int stride, int same);
+/* vk_maxpool2d.comp:42-74 (type 0, starts at -100000.0) / vk_avgpool2d.comp:42-69 (type 1, divides by the clipped tap count);
+ * padT / padL are what the host puts into uConstant.pad (the Vulkan layers force 0: maxpool2dVulkan.cpp:62-64) */
+void snn_oracle_pool2d(const float* x, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int padT, int padL, int OH, int OW, int type,
+                       float* y);
+/* vk_pad.comp:42-71 with uPad = {padT, padL} as padlayerVulkan.cpp:81-82 passes it (x is shifted by padT, y by padL);
+ * mode 0 constant (zeros), 1 replicate, 2 reflect; output (H+padT+padB) x (W+padL+padR) (padlayer.cpp:58-67) */
+void snn_oracle_pad(const float* x, int N, int H, int W, int C, int padT, int padB, int padL, int padR, int mode, float* y);
+/* vk_upsampling2d_nearest.comp:43-66 (mode 0) / vk_upsampling2d_bilinear.comp:43-76 (mode 1); the shader samples at
+ * pos * (1/scale) (upsampling2dVulkan.cpp:101); output trunc(in * scale) (upsampling2d.h:41-44) */
+void snn_oracle_upsample(const float* x, int N, int H, int W, int C, float scale, int mode, float* y);
+/* vk_instancenorm.comp:53-160: per image and channel mean over H*W, biased variance around that mean, eps as given
+ * (the shader hard-codes 1e-5), y = act((x - mean) * gamma / sqrt(var + eps) + beta) */
+void snn_oracle_instancenorm(const float* x, int N, int H, int W, int C, const float* beta, const float* gamma, float eps, int act, float leaky,
+                             float* y);
+
 void snn_oracle_srand(uint64_t seed);
 float snn_oracle_random_float(float a, float b);
 

@@ -37,6 +37,26 @@ class SubpixelDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "factor", "mode")]
 
 
+class EltwiseDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("act", C.c_int), ("leaky", C.c_float)]
+
+
+class Pool2dDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "kh", "kw", "sh", "sw", "padT", "padL", "OH", "OW", "same", "type")]
+
+
+class PadDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "padT", "padB", "padL", "padR", "mode")]
+
+
+class UpsampleDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("scale", C.c_float), ("mode", C.c_int)]
+
+
+class InstanceNormDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("act", C.c_int), ("leaky", C.c_float), ("eps", C.c_float)]
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("compute_units", C.c_int), ("lds_bytes_per_cu", C.c_int), ("hbm_bytes", C.c_size_t), ("device", C.c_int)]
 
@@ -71,6 +91,13 @@ SIGNATURES = {
     "snnhip_depthwise_plan_create": (C.c_int, [_P, C.POINTER(ConvDesc), _FP, _FP, _FP, _FP, _FP, _FP, C.POINTER(_P)]),
     "snnhip_dense_plan_create": (C.c_int, [_P, C.POINTER(DenseDesc), _FP, _FP, C.POINTER(_P)]),
     "snnhip_subpixel_plan_create": (C.c_int, [_P, C.POINTER(SubpixelDesc), C.POINTER(_P)]),
+    "snnhip_add_plan_create": (C.c_int, [_P, C.POINTER(EltwiseDesc), C.POINTER(_P)]),
+    "snnhip_activation_plan_create": (C.c_int, [_P, C.POINTER(EltwiseDesc), C.POINTER(_P)]),
+    "snnhip_batchnorm_plan_create": (C.c_int, [_P, C.POINTER(EltwiseDesc), _FP, _FP, _FP, _FP, C.POINTER(_P)]),
+    "snnhip_pool2d_plan_create": (C.c_int, [_P, C.POINTER(Pool2dDesc), C.POINTER(_P)]),
+    "snnhip_pad_plan_create": (C.c_int, [_P, C.POINTER(PadDesc), C.POINTER(_P)]),
+    "snnhip_upsample_plan_create": (C.c_int, [_P, C.POINTER(UpsampleDesc), C.POINTER(_P)]),
+    "snnhip_instancenorm_plan_create": (C.c_int, [_P, C.POINTER(InstanceNormDesc), _FP, _FP, C.POINTER(_P)]),
     "snnhip_chain_plan_create": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(_P)]),
     "snnhip_plan_run": (C.c_int, [_P, _P, _P]),
     "snnhip_plan_run_n": (C.c_int, [_P, C.POINTER(_P), C.c_int, _P]),
@@ -342,6 +369,73 @@ def subpixel_plan(ctx, N, H, W, Cc, factor=2, mode=0):
     d = SubpixelDesc(N, H, W, Cc, factor, mode)
     h = _P()
     check(lib().snnhip_subpixel_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def _act_id(act):
+    ids = {"": 0, "linear": 0, "none": 0, "relu": 1, "relu6": 2, "tanh": 3, "sigmoid": 4, "leakyRelu": 5, "SiLU": 6}
+    return ids[act]
+
+
+def add_plan(ctx, N, H, W, Cc, act="", leaky=0.0):
+    """y = act(a + b); run with plan([a, b]).  (AddLayerVulkan, vk_add.comp)"""
+    d = EltwiseDesc(N, H, W, Cc, _act_id(act), leaky)
+    h = _P()
+    check(lib().snnhip_add_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def activation_plan(ctx, N, H, W, Cc, act, leaky=0.0):
+    d = EltwiseDesc(N, H, W, Cc, _act_id(act), leaky)
+    h = _P()
+    check(lib().snnhip_activation_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def batchnorm_plan(ctx, N, H, W, Cc, bn, act="", leaky=0.0):
+    d = EltwiseDesc(N, H, W, Cc, _act_id(act), leaky)
+    arrs = [_f32(bn[k]) for k in ("beta", "gamma", "mean", "var")]
+    h = _P()
+    check(lib().snnhip_batchnorm_plan_create(ctx.h, C.byref(d), *[_fptr(a) for a in arrs], C.byref(h)))
+    return Plan(ctx, h)
+
+
+def pool2d_plan(ctx, N, H, W, Cc, k, stride, kind="max", same=True, pad_t=0, pad_l=0, OH=0, OW=0):
+    """kind 'max' | 'avg'.  `same` only selects the reference's output-size rule; the window is always clipped to the image."""
+    d = Pool2dDesc(N, H, W, Cc, k, k, stride, stride, pad_t, pad_l, OH, OW, int(bool(same)), 0 if kind == "max" else 1)
+    h = _P()
+    check(lib().snnhip_pool2d_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def global_avgpool_plan(ctx, N, H, W, Cc):
+    """AdaptiveAvgPool2d with target 1: the mean over the whole image (adaptiveavgpool2dGL.cpp)."""
+    d = Pool2dDesc(N, H, W, Cc, H, W, H, W, 0, 0, 1, 1, 0, 1)
+    h = _P()
+    check(lib().snnhip_pool2d_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def pad_plan(ctx, N, H, W, Cc, pads, mode="constant"):
+    """pads = (T, B, L, R); mode constant | replicate | reflect."""
+    d = PadDesc(N, H, W, Cc, pads[0], pads[1], pads[2], pads[3], {"constant": 0, "replicate": 1, "reflect": 2}[mode])
+    h = _P()
+    check(lib().snnhip_pad_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def upsample_plan(ctx, N, H, W, Cc, scale=2.0, mode="nearest"):
+    d = UpsampleDesc(N, H, W, Cc, scale, {"nearest": 0, "bilinear": 1}[mode])
+    h = _P()
+    check(lib().snnhip_upsample_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def instancenorm_plan(ctx, N, H, W, Cc, beta, gamma, act="", leaky=0.0, eps=1e-5):
+    d = InstanceNormDesc(N, H, W, Cc, _act_id(act), leaky, eps)
+    b, g = _f32(beta), _f32(gamma)
+    h = _P()
+    check(lib().snnhip_instancenorm_plan_create(ctx.h, C.byref(d), _fptr(b), _fptr(g), C.byref(h)))
     return Plan(ctx, h)
 
 

@@ -1,0 +1,608 @@
+// eltwise_pool.hip -- the element-wise, pooling and shape operators that sit between the convolutions of a ResNet-18 /
+// MobileNetV2 / Candy graph.  All are HBM-bound: NHWC fp32, 16-byte channel-contiguous
+// accesses whenever C % 4 == 0 (scalar path otherwise), grid-stride loops sized to a few waves per SIMD.
+//
+// Replaces (core/data/assets/shaders): shadertemplate_vk_add.comp:41-88, vk_activation.comp:41-86, vk_batchnorm.comp:54-104,
+// vk_maxpool2d.comp:42-74, vk_avgpool2d.comp:42-69, vk_pad.comp:42-71, vk_upsampling2d_nearest.comp:43-66,
+// vk_upsampling2d_bilinear.comp:43-76, vk_instancenorm.comp:53-160 and their createCS hosts in core/src/ic2.
+#include "epilogue.h"
+#include "snnhip_internal.h"
+
+namespace snnhip {
+namespace {
+
+__device__ __forceinline__ float act1(int act, float leaky, float v) { return epi_act(act, leaky, v, 0.0f); }
+__device__ __forceinline__ float4 act4(int act, float leaky, float4 v) {
+    return make_float4(act1(act, leaky, v.x), act1(act, leaky, v.y), act1(act, leaky, v.z), act1(act, leaky, v.w));
+}
+
+// ------------------------------------------------------------------------------------------------ add / activation / batch-norm
+// mode 0: y = act(a + b)   mode 1: y = act(a)   mode 2: y = act(scale[c] * (a - mean[c]) + beta[c]),  tab[c] = {scale, mean, beta, 0}
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void eltwise_kernel(size_t count, int C, int act, float leaky, const float* __restrict__ a,
+                                                     const float* __restrict__ b, const float4* __restrict__ tab, float* __restrict__ y) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+    if (VEC) {
+        const size_t n4 = count >> 2;
+        const int c4 = C >> 2;
+        for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += stride) {
+            float4 v = reinterpret_cast<const float4*>(a)[i];
+            if (MODE == 0) {
+                const float4 w = reinterpret_cast<const float4*>(b)[i];
+                v = make_float4(v.x + w.x, v.y + w.y, v.z + w.z, v.w + w.w);
+            }
+            if (MODE == 2) {
+                const int c = static_cast<int>(i % c4) * 4;
+                const float4 t0 = tab[c], t1 = tab[c + 1], t2 = tab[c + 2], t3 = tab[c + 3];
+                v.x = t0.x * (v.x - t0.y) + t0.z;
+                v.y = t1.x * (v.y - t1.y) + t1.z;
+                v.z = t2.x * (v.z - t2.y) + t2.z;
+                v.w = t3.x * (v.w - t3.y) + t3.z;
+            }
+            reinterpret_cast<float4*>(y)[i] = act4(act, leaky, v);
+        }
+    } else {
+        for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += stride) {
+            float v = a[i];
+            if (MODE == 0) v += b[i];
+            if (MODE == 2) {
+                const float4 t = tab[i % C];
+                v = t.x * (v - t.y) + t.z;
+            }
+            y[i] = act1(act, leaky, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+// one thread = one output pixel x CV channels; window clipped to the image exactly as the shader does
+template <int TYPE, int CV>
+__global__ __launch_bounds__(256) void pool2d_kernel(snnhip_pool2d_desc d, const float* __restrict__ x, float* __restrict__ y) {
+    const int cg = d.C / CV;
+    const size_t total = static_cast<size_t>(d.N) * d.OH * d.OW * cg;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+        const int c = static_cast<int>(i % cg) * CV;
+        size_t r = i / cg;
+        const int ox = static_cast<int>(r % d.OW);
+        r /= d.OW;
+        const int oy = static_cast<int>(r % d.OH);
+        const int n = static_cast<int>(r / d.OH);
+        const int sx = ox * d.sw - d.padL, sy = oy * d.sh - d.padT;
+        const int fx0 = max(0, -sx), fy0 = max(0, -sy);
+        const int fx1 = min(d.kw, d.W - sx), fy1 = min(d.kh, d.H - sy);
+        float acc[CV];
+#pragma unroll
+        for (int k = 0; k < CV; ++k) acc[k] = TYPE == SNNHIP_POOL_MAX ? -100000.0f : 0.0f;
+        float num = 0.0f;
+        for (int fy = fy0; fy < fy1; ++fy)
+            for (int fx = fx0; fx < fx1; ++fx) {
+                const float* src = x + ((static_cast<size_t>(n) * d.H + sy + fy) * d.W + sx + fx) * d.C + c;
+                float v[CV];
+                if (CV == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src);
+                    v[0] = t.x;
+                    v[1 % CV] = t.y;
+                    v[2 % CV] = t.z;
+                    v[3 % CV] = t.w;
+                } else {
+                    v[0] = src[0];
+                }
+#pragma unroll
+                for (int k = 0; k < CV; ++k) acc[k] = TYPE == SNNHIP_POOL_MAX ? fmaxf(acc[k], v[k]) : acc[k] + v[k];
+                num += 1.0f;
+            }
+        if (TYPE == SNNHIP_POOL_AVG) {
+#pragma unroll
+            for (int k = 0; k < CV; ++k) acc[k] = acc[k] / num; // an empty window divides 0 by 0 like the shader (vk_avgpool2d.comp:66)
+        }
+        float* dst = y + ((static_cast<size_t>(n) * d.OH + oy) * d.OW + ox) * d.C + c;
+        if (CV == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1 % CV], acc[2 % CV], acc[3 % CV]);
+        } else {
+            dst[0] = acc[0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pad
+template <int CV>
+__global__ __launch_bounds__(256) void pad_kernel(snnhip_pad_desc d, int OH, int OW, const float* __restrict__ x, float* __restrict__ y) {
+    const int cg = d.C / CV;
+    const size_t total = static_cast<size_t>(d.N) * OH * OW * cg;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+        const int c = static_cast<int>(i % cg) * CV;
+        size_t r = i / cg;
+        const int ox = static_cast<int>(r % OW);
+        r /= OW;
+        const int oy = static_cast<int>(r % OH);
+        const int n = static_cast<int>(r / OH);
+        int sx = ox - d.padT, sy = oy - d.padL; // sic: x shifted by the TOP pad, y by the LEFT pad (padlayerVulkan.cpp:81-82)
+        bool zero = false;
+        if (d.mode == 0) {
+            zero = !(sx >= 0 && sx < d.W && sy >= 0 && sy < d.H); // the shader fetches texel (W, H): out of range -> 0
+        } else if (d.mode == 1) {
+            sx = min(max(sx, 0), d.W - 1);
+            sy = min(max(sy, 0), d.H - 1);
+        } else {
+            sx = sx < 0 ? -sx : sx;
+            sx = sx >= d.W ? 2 * d.W - 2 - sx : sx;
+            sy = sy < 0 ? -sy : sy;
+            sy = sy >= d.H ? 2 * d.H - 2 - sy : sy;
+            zero = !(sx >= 0 && sx < d.W && sy >= 0 && sy < d.H); // pads wider than the image leave the texture range
+        }
+        float* dst = y + ((static_cast<size_t>(n) * OH + oy) * OW + ox) * d.C + c;
+        const float* src = x + ((static_cast<size_t>(n) * d.H + sy) * d.W + sx) * d.C + c;
+        if (CV == 4) {
+            *reinterpret_cast<float4*>(dst) = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(src);
+        } else {
+            dst[0] = zero ? 0.0f : src[0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ upsampling
+template <int MODE, int CV>
+__global__ __launch_bounds__(256) void upsample_kernel(snnhip_upsample_desc d, int OH, int OW, float inv, const float* __restrict__ x,
+                                                      float* __restrict__ y) {
+    const int cg = d.C / CV;
+    const size_t total = static_cast<size_t>(d.N) * OH * OW * cg;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+        const int c = static_cast<int>(i % cg) * CV;
+        size_t r = i / cg;
+        const int ox = static_cast<int>(r % OW);
+        r /= OW;
+        const int oy = static_cast<int>(r % OH);
+        const int n = static_cast<int>(r / OH);
+        const float* xn = x + static_cast<size_t>(n) * d.H * d.W * d.C + c;
+        float o[CV];
+        auto fetch = [&](int px, int py, float (&v)[CV]) { // texelFetch outside the texture returns 0
+            const bool ok = px >= 0 && px < d.W && py >= 0 && py < d.H;
+            const float* src = xn + (static_cast<size_t>(ok ? py : 0) * d.W + (ok ? px : 0)) * d.C;
+            if (CV == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                v[0] = ok ? t.x : 0.0f;
+                v[1 % CV] = ok ? t.y : 0.0f;
+                v[2 % CV] = ok ? t.z : 0.0f;
+                v[3 % CV] = ok ? t.w : 0.0f;
+            } else {
+                v[0] = ok ? src[0] : 0.0f;
+            }
+        };
+        if (MODE == SNNHIP_UPSAMPLE_NEAREST) {
+            const int x1 = min(max(static_cast<int>(floorf(static_cast<float>(ox) * inv)), 0), d.W - 1);
+            const int y1 = min(max(static_cast<int>(floorf(static_cast<float>(oy) * inv)), 0), d.H - 1);
+            fetch(x1, y1, o);
+        } else {
+            const float off = 0.5f - 0.5f * inv;
+            float srcX = static_cast<float>(ox) * inv - off;
+            srcX = fminf(fmaxf(srcX, 0.0f), static_cast<float>(d.W - 1));
+            const int x11 = static_cast<int>(floorf(srcX)), x12 = x11 + 1;
+            float srcY = static_cast<float>(oy) * inv - off;
+            srcY = fminf(fmaxf(srcY, 0.0f), static_cast<float>(d.H - 1));
+            const int y11 = static_cast<int>(floorf(srcY)), y12 = y11 + 1;
+            float r1[CV], r2[CV], r3[CV], r4[CV];
+            fetch(x11, y11, r1);
+            fetch(x12, y11, r2);
+            fetch(x12, y12, r3);
+            fetch(x11, y12, r4);
+            const float w1 = (static_cast<float>(x12) - srcX) * (static_cast<float>(y12) - srcY);
+            const float w2 = (srcX - static_cast<float>(x11)) * (static_cast<float>(y12) - srcY);
+            const float w3 = (srcX - static_cast<float>(x11)) * (srcY - static_cast<float>(y11));
+            const float w4 = (static_cast<float>(x12) - srcX) * (srcY - static_cast<float>(y11));
+#pragma unroll
+            for (int k = 0; k < CV; ++k) o[k] = r1[k] * w1 + r2[k] * w2 + r3[k] * w3 + r4[k] * w4;
+        }
+        float* dst = y + ((static_cast<size_t>(n) * OH + oy) * OW + ox) * d.C + c;
+        if (CV == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1 % CV], o[2 % CV], o[3 % CV]);
+        } else {
+            dst[0] = o[0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ instance norm
+// Statistics per (image, channel) over H*W, two passes like the shader (mean, then sum (x-mean)^2, biased).  Work split:
+// block = (image n, row slab s): 256 threads = 64 pixel lanes x 4 channel lanes sweep the slab for every group of 4*CV channels,
+// partial sums go to part[n][s][C]; the consumer kernel folds the S partials (S <= 64) itself.
+// stage 0: part = sum x      stage 1: part = sum (x - mean)^2 with mean from part0      stage 2: normalise + activation
+template <int STAGE, int CV>
+__global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int rowsPerSlab, const float* __restrict__ x,
+                                                          const float* __restrict__ part0, const float* __restrict__ part1, const float* __restrict__ beta,
+                                                          const float* __restrict__ gamma, float* __restrict__ partOut, float* __restrict__ y) {
+    __shared__ float red[256 * CV];
+    const int n = blockIdx.x / S, s = blockIdx.x % S;
+    const int tid = threadIdx.x, cl = tid & 3, pl = tid >> 2; // channel lane, pixel lane
+    const int r0 = s * rowsPerSlab, r1 = min(d.H, r0 + rowsPerSlab);
+    const size_t p0 = static_cast<size_t>(r0) * d.W, p1 = static_cast<size_t>(r1) * d.W;
+    const float invHW = 1.0f / (static_cast<float>(d.H) * static_cast<float>(d.W));
+    const float* xn = x + static_cast<size_t>(n) * d.H * d.W * d.C;
+    for (int c0 = 0; c0 < d.C; c0 += 4 * CV) {
+        const int c = c0 + cl * CV;
+        const bool cok = c < d.C;
+        float mean[CV], mul[CV], bt[CV];
+#pragma unroll
+        for (int k = 0; k < CV; ++k) {
+            mean[k] = 0.0f;
+            mul[k] = 0.0f;
+            bt[k] = 0.0f;
+        }
+        if (STAGE >= 1 && cok) {
+#pragma unroll
+            for (int k = 0; k < CV; ++k) {
+                float sm = 0.0f;
+                for (int j = 0; j < S; ++j) sm += part0[(static_cast<size_t>(n) * S + j) * d.C + c + k];
+                mean[k] = sm * invHW; // == sum / float(width*height) up to the rounding of the reciprocal; both are fp32 estimates
+                if (STAGE == 2) {
+                    float sv = 0.0f;
+                    for (int j = 0; j < S; ++j) sv += part1[(static_cast<size_t>(n) * S + j) * d.C + c + k];
+                    mul[k] = gamma[c + k] / sqrtf(sv * invHW + d.eps);
+                    bt[k] = beta[c + k];
+                }
+            }
+        }
+        float acc[CV];
+#pragma unroll
+        for (int k = 0; k < CV; ++k) acc[k] = 0.0f;
+        if (cok) {
+            for (size_t p = p0 + pl; p < p1; p += 64) {
+                float v[CV];
+                const float* src = xn + p * d.C + c;
+                if (CV == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src);
+                    v[0] = t.x;
+                    v[1 % CV] = t.y;
+                    v[2 % CV] = t.z;
+                    v[3 % CV] = t.w;
+                } else {
+                    v[0] = src[0];
+                }
+                if (STAGE == 0) {
+#pragma unroll
+                    for (int k = 0; k < CV; ++k) acc[k] += v[k];
+                } else if (STAGE == 1) {
+#pragma unroll
+                    for (int k = 0; k < CV; ++k) acc[k] += (v[k] - mean[k]) * (v[k] - mean[k]);
+                } else {
+                    float o[CV];
+#pragma unroll
+                    for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, (v[k] - mean[k]) * mul[k] + bt[k]);
+                    float* dst = y + (static_cast<size_t>(n) * d.H * d.W + p) * d.C + c;
+                    if (CV == 4) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1 % CV], o[2 % CV], o[3 % CV]);
+                    } else {
+                        dst[0] = o[0];
+                    }
+                }
+            }
+        }
+        if (STAGE < 2) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < CV; ++k) red[tid * CV + k] = acc[k];
+            __syncthreads();
+            if (tid < 4 * CV) { // thread -> (channel lane tid / CV, component tid % CV): fold the 64 pixel lanes in a fixed order
+                const int lane = tid / CV, k = tid % CV;
+                float sm = 0.0f;
+                for (int j = 0; j < 64; ++j) sm += red[(j * 4 + lane) * CV + k];
+                const int cc = c0 + lane * CV + k;
+                if (cc < d.C) partOut[(static_cast<size_t>(n) * S + s) * d.C + cc] = sm;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ plans
+unsigned grid_for(const snnhip_ctx* ctx, size_t items) {
+    size_t blocks = (items + 255) / 256;
+    const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) * 16;
+    if (blocks > cap) blocks = cap;
+    return static_cast<unsigned>(blocks ? blocks : 1);
+}
+
+bool dims_match(const snnhip_tensor* t, int n, int h, int w, int c) { return t->n == n && t->h == h && t->w == w && t->c == c; }
+
+struct EltwisePlan : snnhip_plan {
+    snnhip_eltwise_desc d;
+    int mode = 0;
+    float* d_tab = nullptr;
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        const int want = mode == 0 ? 2 : 1;
+        SNNHIP_REQUIRE(nIn == want, "%s: expects %d input(s), got %d", desc.c_str(), want, nIn);
+        for (int i = 0; i < nIn; ++i)
+            SNNHIP_REQUIRE(dims_match(in[i], d.N, d.H, d.W, d.C), "%s: input %d dims %dx%dx%dx%d != plan %dx%dx%dx%d", desc.c_str(), i, in[i]->n, in[i]->h,
+                           in[i]->w, in[i]->c, d.N, d.H, d.W, d.C);
+        SNNHIP_REQUIRE(dims_match(out, d.N, d.H, d.W, d.C), "%s: output dims mismatch", desc.c_str());
+        const size_t count = out->count();
+        const bool vec = (d.C & 3) == 0;
+        const unsigned g = grid_for(ctx, vec ? count / 4 : count);
+        const float* b = mode == 0 ? in[1]->data : nullptr;
+        const float4* tab = reinterpret_cast<const float4*>(d_tab);
+#define SNNHIP_ELT(M)                                                                                                                       \
+    if (vec)                                                                                                                                \
+        hipLaunchKernelGGL((eltwise_kernel<M, true>), dim3(g), dim3(256), 0, ctx->stream, count, d.C, d.act, d.leaky, in[0]->data, b, tab, out->data); \
+    else                                                                                                                                    \
+        hipLaunchKernelGGL((eltwise_kernel<M, false>), dim3(g), dim3(256), 0, ctx->stream, count, d.C, d.act, d.leaky, in[0]->data, b, tab, out->data)
+        if (mode == 0) {
+            SNNHIP_ELT(0);
+        } else if (mode == 1) {
+            SNNHIP_ELT(1);
+        } else {
+            SNNHIP_ELT(2);
+        }
+#undef SNNHIP_ELT
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+int make_eltwise(snnhip_ctx* ctx, const snnhip_eltwise_desc* d, int mode, const std::vector<float>* tab, const char* name, snnhip_plan** out) {
+    auto* plan = new EltwisePlan();
+    plan->ctx = ctx;
+    plan->d = *d;
+    plan->mode = mode;
+    plan->numInputs = mode == 0 ? 2 : 1;
+    if (tab) {
+        int rc = plan->upload(tab->data(), tab->size(), &plan->d_tab);
+        if (rc != SNNHIP_OK) {
+            delete plan;
+            return rc;
+        }
+    }
+    const double cnt = static_cast<double>(d->N) * d->H * d->W * d->C;
+    plan->inDims[0] = plan->outDims[0] = d->N; plan->inDims[1] = plan->outDims[1] = d->H;
+    plan->inDims[2] = plan->outDims[2] = d->W; plan->inDims[3] = plan->outDims[3] = d->C;
+    plan->flops = cnt * (mode == 2 ? 3 : 1);
+    plan->bytes = 4.0 * cnt * (mode == 0 ? 3 : 2);
+    char buf[160];
+    snprintf(buf, sizeof(buf), "%s_f32 %dx%dx%dx%d act=%d%s", name, d->N, d->H, d->W, d->C, d->act, (d->C & 3) ? " scalar" : " vec4");
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+struct PoolPlan : snnhip_plan {
+    snnhip_pool2d_desc d;
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "pool2d: expects 1 input, got %d", nIn);
+        SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C), "pool2d: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", in[0]->n, in[0]->h, in[0]->w,
+                       in[0]->c, d.N, d.H, d.W, d.C);
+        SNNHIP_REQUIRE(dims_match(out, d.N, d.OH, d.OW, d.C), "pool2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, d.N,
+                       d.OH, d.OW, d.C);
+        const bool vec = (d.C & 3) == 0;
+        const unsigned g = grid_for(ctx, out->count() / (vec ? 4 : 1));
+        if (d.type == SNNHIP_POOL_MAX) {
+            if (vec) hipLaunchKernelGGL((pool2d_kernel<SNNHIP_POOL_MAX, 4>), dim3(g), dim3(256), 0, ctx->stream, d, in[0]->data, out->data);
+            else hipLaunchKernelGGL((pool2d_kernel<SNNHIP_POOL_MAX, 1>), dim3(g), dim3(256), 0, ctx->stream, d, in[0]->data, out->data);
+        } else {
+            if (vec) hipLaunchKernelGGL((pool2d_kernel<SNNHIP_POOL_AVG, 4>), dim3(g), dim3(256), 0, ctx->stream, d, in[0]->data, out->data);
+            else hipLaunchKernelGGL((pool2d_kernel<SNNHIP_POOL_AVG, 1>), dim3(g), dim3(256), 0, ctx->stream, d, in[0]->data, out->data);
+        }
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+struct PadPlan : snnhip_plan {
+    snnhip_pad_desc d;
+    int OH = 0, OW = 0;
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "pad: expects 1 input, got %d", nIn);
+        SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, OH, OW, d.C), "pad: tensor dims do not match the plan");
+        const bool vec = (d.C & 3) == 0;
+        const unsigned g = grid_for(ctx, out->count() / (vec ? 4 : 1));
+        if (vec) hipLaunchKernelGGL((pad_kernel<4>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, in[0]->data, out->data);
+        else hipLaunchKernelGGL((pad_kernel<1>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, in[0]->data, out->data);
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+struct UpsamplePlan : snnhip_plan {
+    snnhip_upsample_desc d;
+    int OH = 0, OW = 0;
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "upsample: expects 1 input, got %d", nIn);
+        SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, OH, OW, d.C), "upsample: tensor dims do not match the plan");
+        const bool vec = (d.C & 3) == 0;
+        const unsigned g = grid_for(ctx, out->count() / (vec ? 4 : 1));
+        const float inv = 1.0f / d.scale; // upsampling2dVulkan.cpp:101
+#define SNNHIP_UP(M)                                                                                                                  \
+    if (vec) hipLaunchKernelGGL((upsample_kernel<M, 4>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, inv, in[0]->data, out->data); \
+    else hipLaunchKernelGGL((upsample_kernel<M, 1>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, inv, in[0]->data, out->data)
+        if (d.mode == SNNHIP_UPSAMPLE_NEAREST) {
+            SNNHIP_UP(SNNHIP_UPSAMPLE_NEAREST);
+        } else {
+            SNNHIP_UP(SNNHIP_UPSAMPLE_BILINEAR);
+        }
+#undef SNNHIP_UP
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+struct InstanceNormPlan : snnhip_plan {
+    snnhip_instancenorm_desc d;
+    int S = 1, rowsPerSlab = 1;
+    float *d_beta = nullptr, *d_gamma = nullptr, *d_part0 = nullptr, *d_part1 = nullptr;
+    int numSteps() const override { return 1; }
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "instancenorm: expects 1 input, got %d", nIn);
+        SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, d.H, d.W, d.C), "instancenorm: tensor dims do not match the plan");
+        const dim3 g(static_cast<unsigned>(d.N * S));
+#define SNNHIP_IN(ST, CVV)                                                                                                                     \
+    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV>), g, dim3(256), 0, ctx->stream, d, S, rowsPerSlab, in[0]->data, d_part0, d_part1, d_beta, d_gamma, \
+                       ST == 0 ? d_part0 : d_part1, out->data)
+        if ((d.C & 3) == 0) {
+            SNNHIP_IN(0, 4);
+            SNNHIP_IN(1, 4);
+            SNNHIP_IN(2, 4);
+        } else {
+            SNNHIP_IN(0, 1);
+            SNNHIP_IN(1, 1);
+            SNNHIP_IN(2, 1);
+        }
+#undef SNNHIP_IN
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+} // namespace
+} // namespace snnhip
+
+using namespace snnhip;
+
+static int check_eltwise(const snnhip_ctx* ctx, const snnhip_eltwise_desc* d, snnhip_plan** out, const char* what) {
+    SNNHIP_REQUIRE(ctx && d && out, "%s: null argument", what);
+    SNNHIP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0, "%s: bad dims %dx%dx%dx%d", what, d->N, d->H, d->W, d->C);
+    SNNHIP_REQUIRE(d->act >= SNNHIP_ACT_NONE && d->act <= SNNHIP_ACT_SILU, "%s: activation id %d", what, d->act);
+    return SNNHIP_OK;
+}
+
+extern "C" {
+
+int snnhip_add_plan_create(snnhip_ctx* ctx, const snnhip_eltwise_desc* desc, snnhip_plan** out) {
+    int rc = check_eltwise(ctx, desc, out, "add_plan_create");
+    return rc != SNNHIP_OK ? rc : make_eltwise(ctx, desc, 0, nullptr, "add", out);
+}
+
+int snnhip_activation_plan_create(snnhip_ctx* ctx, const snnhip_eltwise_desc* desc, snnhip_plan** out) {
+    int rc = check_eltwise(ctx, desc, out, "activation_plan_create");
+    return rc != SNNHIP_OK ? rc : make_eltwise(ctx, desc, 1, nullptr, "activation", out);
+}
+
+int snnhip_batchnorm_plan_create(snnhip_ctx* ctx, const snnhip_eltwise_desc* desc, const float* beta, const float* gamma, const float* mean,
+                                 const float* var, snnhip_plan** out) {
+    int rc = check_eltwise(ctx, desc, out, "batchnorm_plan_create");
+    if (rc != SNNHIP_OK) return rc;
+    SNNHIP_REQUIRE(beta && gamma && mean && var, "batchnorm_plan_create: null parameter array");
+    std::vector<float> tab(static_cast<size_t>(desc->C) * 4, 0.0f);
+    for (int c = 0; c < desc->C; ++c) {
+        float sq = sqrtf(var[c] + 0.001f);
+        sq = sq > 0.0001f ? sq : 0.0001f; // vk_batchnorm.comp:66-67
+        tab[4 * c + 0] = gamma[c] / sq;
+        tab[4 * c + 1] = mean[c];
+        tab[4 * c + 2] = beta[c];
+    }
+    return make_eltwise(ctx, desc, 2, &tab, "batchnorm", out);
+}
+
+int snnhip_pool2d_plan_create(snnhip_ctx* ctx, const snnhip_pool2d_desc* desc, snnhip_plan** out) {
+    SNNHIP_REQUIRE(ctx && desc && out, "pool2d_plan_create: null argument");
+    SNNHIP_REQUIRE(desc->N > 0 && desc->H > 0 && desc->W > 0 && desc->C > 0 && desc->kh > 0 && desc->kw > 0 && desc->sh > 0 && desc->sw > 0,
+                   "pool2d desc: bad dims");
+    SNNHIP_REQUIRE(desc->type == SNNHIP_POOL_MAX || desc->type == SNNHIP_POOL_AVG, "pool2d desc: type %d", desc->type);
+    SNNHIP_REQUIRE(desc->padT >= 0 && desc->padL >= 0, "pool2d desc: negative padding");
+    auto* plan = new PoolPlan();
+    plan->ctx = ctx;
+    plan->d = *desc;
+    auto outdim = [&](int in, int k, int s) { // maxpool2d.cpp:26-36 / avgpool2d.cpp:20-29 through genericlayer.cpp:64-90 (max(0, translation))
+        const float scale = 1.0f / static_cast<float>(s);
+        float tr = desc->same ? 1.0f - 1.0f / static_cast<float>(s) : 1.0f - static_cast<float>(k) / static_cast<float>(s);
+        if (tr < 0.0f) tr = 0.0f;
+        return static_cast<int>(static_cast<unsigned>(scale * static_cast<float>(in) + tr));
+    };
+    if (plan->d.OH <= 0) plan->d.OH = outdim(desc->H, desc->kh, desc->sh);
+    if (plan->d.OW <= 0) plan->d.OW = outdim(desc->W, desc->kw, desc->sw);
+    if (plan->d.OH <= 0 || plan->d.OW <= 0) {
+        set_error("pool2d desc: empty output %dx%d", plan->d.OH, plan->d.OW);
+        delete plan;
+        return SNNHIP_E_INVALID;
+    }
+    const snnhip_pool2d_desc& d = plan->d;
+    plan->inDims[0] = d.N; plan->inDims[1] = d.H; plan->inDims[2] = d.W; plan->inDims[3] = d.C;
+    plan->outDims[0] = d.N; plan->outDims[1] = d.OH; plan->outDims[2] = d.OW; plan->outDims[3] = d.C;
+    plan->flops = static_cast<double>(d.N) * d.OH * d.OW * d.C * d.kh * d.kw;
+    plan->bytes = 4.0 * (static_cast<double>(d.N) * d.H * d.W * d.C + static_cast<double>(d.N) * d.OH * d.OW * d.C);
+    char buf[160];
+    snprintf(buf, sizeof(buf), "%spool2d_f32 k=%dx%d s=%d c=%d %dx%d->%dx%d%s", d.type == SNNHIP_POOL_MAX ? "max" : "avg", d.kh, d.kw, d.sh, d.C, d.H, d.W,
+             d.OH, d.OW, (d.C & 3) ? " scalar" : " vec4");
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+int snnhip_pad_plan_create(snnhip_ctx* ctx, const snnhip_pad_desc* desc, snnhip_plan** out) {
+    SNNHIP_REQUIRE(ctx && desc && out, "pad_plan_create: null argument");
+    SNNHIP_REQUIRE(desc->N > 0 && desc->H > 0 && desc->W > 0 && desc->C > 0, "pad desc: bad dims");
+    SNNHIP_REQUIRE(desc->padT >= 0 && desc->padB >= 0 && desc->padL >= 0 && desc->padR >= 0, "pad desc: negative padding");
+    SNNHIP_REQUIRE(desc->mode >= 0 && desc->mode <= 2, "pad desc: mode %d", desc->mode);
+    auto* plan = new PadPlan();
+    plan->ctx = ctx;
+    plan->d = *desc;
+    plan->OH = desc->H + desc->padT + desc->padB;
+    plan->OW = desc->W + desc->padL + desc->padR;
+    plan->inDims[0] = desc->N; plan->inDims[1] = desc->H; plan->inDims[2] = desc->W; plan->inDims[3] = desc->C;
+    plan->outDims[0] = desc->N; plan->outDims[1] = plan->OH; plan->outDims[2] = plan->OW; plan->outDims[3] = desc->C;
+    plan->bytes = 4.0 * desc->N * desc->C * (static_cast<double>(desc->H) * desc->W + static_cast<double>(plan->OH) * plan->OW);
+    char buf[160];
+    snprintf(buf, sizeof(buf), "pad_f32 mode=%d t%d b%d l%d r%d c=%d %dx%d->%dx%d", desc->mode, desc->padT, desc->padB, desc->padL, desc->padR, desc->C,
+             desc->H, desc->W, plan->OH, plan->OW);
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+int snnhip_upsample_plan_create(snnhip_ctx* ctx, const snnhip_upsample_desc* desc, snnhip_plan** out) {
+    SNNHIP_REQUIRE(ctx && desc && out, "upsample_plan_create: null argument");
+    SNNHIP_REQUIRE(desc->N > 0 && desc->H > 0 && desc->W > 0 && desc->C > 0 && desc->scale > 0.0f, "upsample desc: bad dims / scale");
+    SNNHIP_REQUIRE(desc->mode == SNNHIP_UPSAMPLE_NEAREST || desc->mode == SNNHIP_UPSAMPLE_BILINEAR, "upsample desc: mode %d", desc->mode);
+    auto* plan = new UpsamplePlan();
+    plan->ctx = ctx;
+    plan->d = *desc;
+    plan->OH = static_cast<int>(static_cast<unsigned>(desc->scale * static_cast<float>(desc->H))); // genericlayer.cpp:76-77, translation 0
+    plan->OW = static_cast<int>(static_cast<unsigned>(desc->scale * static_cast<float>(desc->W)));
+    if (plan->OH <= 0 || plan->OW <= 0) {
+        set_error("upsample desc: empty output");
+        delete plan;
+        return SNNHIP_E_INVALID;
+    }
+    plan->inDims[0] = desc->N; plan->inDims[1] = desc->H; plan->inDims[2] = desc->W; plan->inDims[3] = desc->C;
+    plan->outDims[0] = desc->N; plan->outDims[1] = plan->OH; plan->outDims[2] = plan->OW; plan->outDims[3] = desc->C;
+    plan->bytes = 4.0 * desc->N * desc->C * (static_cast<double>(desc->H) * desc->W + static_cast<double>(plan->OH) * plan->OW);
+    char buf[160];
+    snprintf(buf, sizeof(buf), "upsample_%s_f32 x%g c=%d %dx%d->%dx%d", desc->mode ? "bilinear" : "nearest", desc->scale, desc->C, desc->H, desc->W, plan->OH,
+             plan->OW);
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_desc* desc, const float* beta, const float* gamma, snnhip_plan** out) {
+    SNNHIP_REQUIRE(ctx && desc && out && beta && gamma, "instancenorm_plan_create: null argument");
+    SNNHIP_REQUIRE(desc->N > 0 && desc->H > 0 && desc->W > 0 && desc->C > 0, "instancenorm desc: bad dims");
+    SNNHIP_REQUIRE(desc->act >= SNNHIP_ACT_NONE && desc->act <= SNNHIP_ACT_SILU, "instancenorm desc: activation id %d", desc->act);
+    auto* plan = new InstanceNormPlan();
+    plan->ctx = ctx;
+    plan->d = *desc;
+    // row slabs: enough blocks to cover the chip a few times, at most 64 partials per image
+    const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+    int S = (4 * cus + desc->N - 1) / desc->N;
+    if (S > 64) S = 64;
+    if (S > desc->H) S = desc->H;
+    if (S < 1) S = 1;
+    plan->rowsPerSlab = (desc->H + S - 1) / S;
+    plan->S = (desc->H + plan->rowsPerSlab - 1) / plan->rowsPerSlab;
+    int rc = plan->upload(beta, desc->C, &plan->d_beta);
+    if (rc == SNNHIP_OK) rc = plan->upload(gamma, desc->C, &plan->d_gamma);
+    std::vector<float> zeros(static_cast<size_t>(desc->N) * plan->S * desc->C, 0.0f);
+    if (rc == SNNHIP_OK) rc = plan->upload(zeros.data(), zeros.size(), &plan->d_part0);
+    if (rc == SNNHIP_OK) rc = plan->upload(zeros.data(), zeros.size(), &plan->d_part1);
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    const double cnt = static_cast<double>(desc->N) * desc->H * desc->W * desc->C;
+    plan->inDims[0] = plan->outDims[0] = desc->N; plan->inDims[1] = plan->outDims[1] = desc->H;
+    plan->inDims[2] = plan->outDims[2] = desc->W; plan->inDims[3] = plan->outDims[3] = desc->C;
+    plan->flops = cnt * 7;
+    plan->bytes = 4.0 * cnt * 2; // algorithmic: read once, write once (the two-pass statistics re-read the tensor: 4x in practice)
+    char buf[160];
+    snprintf(buf, sizeof(buf), "instancenorm_f32 %dx%dx%dx%d act=%d slabs=%d (3 launches)", desc->N, desc->H, desc->W, desc->C, desc->act, plan->S);
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+} // extern "C"

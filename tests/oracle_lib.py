@@ -181,6 +181,72 @@ def subpixel(x, factor=2, mode=0):
     return y
 
 
+def add_act(a, b=None, act="", leaky=0.0):
+    a = _f(a)
+    b = _f(b)
+    y = np.empty_like(a)
+    lib().snn_oracle_add_act(_p(a), _p(b), C.c_long(a.size), ACT[act], C.c_float(leaky), _p(y))
+    return y
+
+
+def batchnorm(x, bn, act="", leaky=0.0):
+    x = _f(x)
+    Cc = x.shape[-1]
+    y = np.empty_like(x)
+    arrs = [_f(bn[k]) for k in ("beta", "gamma", "mean", "var")]
+    lib().snn_oracle_batchnorm(_p(x), C.c_long(x.size // Cc), Cc, *[_p(a) for a in arrs], ACT[act], C.c_float(leaky), _p(y))
+    return y
+
+
+def pool_out_dim(n, k, s, same):
+    l = lib()
+    l.snn_oracle_pool_out_dim.restype = C.c_int
+    return l.snn_oracle_pool_out_dim(n, k, s, int(bool(same)))
+
+
+def pool2d(x, k, stride, kind="max", same=True, pad_t=0, pad_l=0, OH=0, OW=0):
+    x = _f(x)
+    N, H, W, Cc = x.shape
+    OH = OH or pool_out_dim(H, k, stride, same)
+    OW = OW or pool_out_dim(W, k, stride, same)
+    y = np.empty((N, OH, OW, Cc), np.float32)
+    lib().snn_oracle_pool2d(_p(x), N, H, W, Cc, k, k, stride, stride, pad_t, pad_l, OH, OW, 0 if kind == "max" else 1, _p(y))
+    return y
+
+
+def global_avgpool(x):
+    x = _f(x)
+    N, H, W, Cc = x.shape
+    y = np.empty((N, 1, 1, Cc), np.float32)
+    lib().snn_oracle_pool2d(_p(x), N, H, W, Cc, H, W, H, W, 0, 0, 1, 1, 1, _p(y))
+    return y
+
+
+def pad(x, pads, mode="constant"):
+    x = _f(x)
+    N, H, W, Cc = x.shape
+    y = np.empty((N, H + pads[0] + pads[1], W + pads[2] + pads[3], Cc), np.float32)
+    lib().snn_oracle_pad(_p(x), N, H, W, Cc, pads[0], pads[1], pads[2], pads[3], {"constant": 0, "replicate": 1, "reflect": 2}[mode], _p(y))
+    return y
+
+
+def upsample(x, scale=2.0, mode="nearest"):
+    x = _f(x)
+    N, H, W, Cc = x.shape
+    OH, OW = int(np.float32(scale) * np.float32(H)), int(np.float32(scale) * np.float32(W))
+    y = np.empty((N, OH, OW, Cc), np.float32)
+    lib().snn_oracle_upsample(_p(x), N, H, W, Cc, C.c_float(scale), {"nearest": 0, "bilinear": 1}[mode], _p(y))
+    return y
+
+
+def instancenorm(x, beta, gamma, act="", leaky=0.0, eps=1e-5):
+    x = _f(x)
+    N, H, W, Cc = x.shape
+    y = np.empty_like(x)
+    lib().snn_oracle_instancenorm(_p(x), N, H, W, Cc, _p(_f(beta)), _p(_f(gamma)), C.c_float(eps), ACT[act], C.c_float(leaky), _p(y))
+    return y
+
+
 def to_medium_precision(v):
     return lib().snn_oracle_to_medium_precision(C.c_float(v))
 

@@ -1,0 +1,120 @@
+"""GPU parity tests of the element-wise / pooling / shape operators through the C-ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_ops_gpu import TOL, _bn, _rand
+
+pytestmark = pytest.mark.gpu
+ACTS = ["", "relu", "relu6", "tanh", "sigmoid", "leakyRelu", "SiLU"]
+
+
+def _run(ctx, plan, *xs):
+    import shadernn_amd as snn
+
+    ts = [snn.Tensor.from_numpy(ctx, x) for x in xs]
+    yt = plan(ts if len(ts) > 1 else ts[0])
+    y = yt.numpy()
+    for t in ts + [yt]:
+        t.free()
+    desc = plan.describe()
+    plan.destroy()
+    return y, desc
+
+
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("shape", [(2, 9, 11, 16), (1, 7, 5, 3)])
+def test_add_matches_oracle(ctx, act, shape):
+    import shadernn_amd as snn
+
+    a, b = _rand(shape, 1), _rand(shape, 2)
+    y, desc = _run(ctx, snn.add_plan(ctx, *shape, act=act, leaky=0.2), a, b)
+    np.testing.assert_allclose(y, O.add_act(a, b, act, 0.2), err_msg=desc, **TOL)
+
+
+@pytest.mark.parametrize("act", ACTS[1:])
+def test_activation_matches_oracle(ctx, act):
+    import shadernn_amd as snn
+
+    a = _rand((2, 6, 7, 12), 3, 3.0)
+    y, desc = _run(ctx, snn.activation_plan(ctx, 2, 6, 7, 12, act, 0.3), a)
+    np.testing.assert_allclose(y, O.add_act(a, None, act, 0.3), err_msg=desc, **TOL)
+
+
+@pytest.mark.parametrize("act", ["", "relu", "relu6"])
+@pytest.mark.parametrize("shape", [(2, 5, 6, 24), (1, 4, 9, 7)])
+def test_batchnorm_matches_oracle(ctx, act, shape):
+    import shadernn_amd as snn
+
+    x = _rand(shape, 4)
+    bn = _bn(shape[3], 5)
+    y, desc = _run(ctx, snn.batchnorm_plan(ctx, *shape, bn, act=act), x)
+    np.testing.assert_allclose(y, O.batchnorm(x, bn, act), err_msg=desc, **TOL)
+
+
+@pytest.mark.parametrize("kind", ["max", "avg"])
+@pytest.mark.parametrize("n,h,w,c,k,s,same", [(2, 112, 112, 64, 3, 2, True),   # ResNet-18 stem pool
+                                               (1, 9, 11, 8, 2, 2, False), (1, 9, 11, 8, 3, 2, False), (2, 8, 8, 5, 3, 1, True),
+                                               (1, 7, 7, 12, 7, 7, False), (3, 5, 6, 4, 2, 1, True)])
+def test_pool2d_matches_oracle(ctx, kind, n, h, w, c, k, s, same):
+    import shadernn_amd as snn
+
+    x = _rand((n, h, w, c), 6)
+    y, desc = _run(ctx, snn.pool2d_plan(ctx, n, h, w, c, k, s, kind=kind, same=same), x)
+    want = O.pool2d(x, k, s, kind, same)
+    assert y.shape == want.shape, desc
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
+
+
+def test_global_avgpool_matches_oracle_and_mean(ctx):
+    import shadernn_amd as snn
+
+    x = _rand((4, 7, 7, 512), 7)
+    y, desc = _run(ctx, snn.global_avgpool_plan(ctx, 4, 7, 7, 512), x)
+    np.testing.assert_allclose(y, O.global_avgpool(x), err_msg=desc, **TOL)
+    np.testing.assert_allclose(y[:, 0, 0, :], x.mean(axis=(1, 2)), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["constant", "replicate", "reflect"])
+@pytest.mark.parametrize("shape,pads", [((1, 10, 12, 3), (4, 4, 4, 4)), ((2, 6, 7, 8), (1, 2, 3, 0)), ((1, 5, 5, 4), (2, 2, 2, 2))])
+def test_pad_matches_oracle(ctx, mode, shape, pads):
+    import shadernn_amd as snn
+
+    x = _rand(shape, 8)
+    y, desc = _run(ctx, snn.pad_plan(ctx, *shape, pads, mode), x)
+    want = O.pad(x, pads, mode)
+    assert y.shape == want.shape
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+@pytest.mark.parametrize("shape,scale", [((1, 9, 11, 8), 2.0), ((2, 5, 7, 3), 2.0), ((1, 6, 6, 4), 3.0), ((1, 8, 8, 4), 1.5)])
+def test_upsample_matches_oracle(ctx, mode, shape, scale):
+    import shadernn_amd as snn
+
+    x = _rand(shape, 9)
+    y, desc = _run(ctx, snn.upsample_plan(ctx, *shape, scale, mode), x)
+    want = O.upsample(x, scale, mode)
+    assert y.shape == want.shape
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
+
+
+@pytest.mark.parametrize("act", ["", "relu"])
+@pytest.mark.parametrize("shape", [(2, 45, 80, 32), (1, 17, 23, 5), (3, 4, 4, 128), (1, 180, 320, 16)])
+def test_instancenorm_matches_oracle(ctx, act, shape):
+    import shadernn_amd as snn
+
+    x = _rand(shape, 10, 2.0) + 0.7
+    r = np.random.default_rng(11)
+    beta, gamma = r.uniform(-0.5, 0.5, shape[3]).astype(np.float32), r.uniform(0.5, 1.5, shape[3]).astype(np.float32)
+    y, desc = _run(ctx, snn.instancenorm_plan(ctx, *shape, beta, gamma, act=act), x)
+    np.testing.assert_allclose(y, O.instancenorm(x, beta, gamma, act), err_msg=desc, **TOL)
+
+
+def test_input_count_is_checked(ctx):
+    import shadernn_amd as snn
+
+    p = snn.add_plan(ctx, 1, 4, 4, 4)
+    t = snn.Tensor.from_numpy(ctx, np.zeros((1, 4, 4, 4), np.float32))
+    with pytest.raises(snn.SnnHipError):
+        p(t)

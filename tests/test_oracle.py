@@ -178,3 +178,49 @@ def test_dense_against_reference_eigen_path(act):
         pytest.skip("oracle/_ref/ref_dense not built (needs /root/reference)")
     got = O.dense(x[None], w, Out, b, act, 0.3)[0]
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+
+
+# ---- element-wise / pooling / shape operators: the C restatements vs torch CPU ops ------------------------------
+
+def test_pool_restatement_against_torch():
+    import torch
+    import torch.nn.functional as F
+
+    x = np.random.default_rng(3).standard_normal((2, 12, 14, 6)).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    # k=2 s=2 valid: identical to torch; k=3 s=2 "same": the reference pads bottom/right only (top/left forced to 0)
+    np.testing.assert_allclose(O.pool2d(x, 2, 2, "max", same=False), F.max_pool2d(xt, 2, 2).permute(0, 2, 3, 1).numpy(), rtol=1e-6)
+    np.testing.assert_allclose(O.pool2d(x, 2, 2, "avg", same=False), F.avg_pool2d(xt, 2, 2).permute(0, 2, 3, 1).numpy(), rtol=1e-6, atol=1e-7)
+    want = F.max_pool2d(F.pad(xt, (0, 1, 0, 1), value=-1e30), 3, 2).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(O.pool2d(x, 3, 2, "max", same=True), want, rtol=1e-6)
+    assert O.pool_out_dim(112, 3, 2, True) == 56 and O.pool_out_dim(12, 3, 2, False) == 6  # Q20: "valid" is not shrunk
+    np.testing.assert_allclose(O.global_avgpool(x)[:, 0, 0], x.mean(axis=(1, 2)), rtol=1e-5, atol=1e-6)
+
+
+def test_pad_upsample_instancenorm_restatements_against_torch():
+    import torch
+    import torch.nn.functional as F
+
+    x = np.random.default_rng(4).standard_normal((2, 9, 11, 5)).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    for mode, tmode in (("constant", "constant"), ("replicate", "replicate"), ("reflect", "reflect")):
+        want = F.pad(xt, (3, 3, 3, 3), mode=tmode).permute(0, 2, 3, 1).numpy()
+        np.testing.assert_array_equal(O.pad(x, (3, 3, 3, 3), mode), want)
+    np.testing.assert_array_equal(O.upsample(x, 2.0, "nearest"), F.interpolate(xt, scale_factor=2, mode="nearest").permute(0, 2, 3, 1).numpy())
+    want = F.interpolate(xt, scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(O.upsample(x, 2.0, "bilinear"), want, rtol=1e-5, atol=1e-6)
+    g, b = np.linspace(0.5, 1.5, 5, dtype=np.float32), np.linspace(-0.2, 0.2, 5, dtype=np.float32)
+    want = F.instance_norm(xt, weight=torch.from_numpy(g), bias=torch.from_numpy(b), eps=1e-5).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(O.instancenorm(x, b, g), want, rtol=1e-4, atol=1e-5)
+    # asymmetric pads expose the reference's swapped offsets: x is shifted by the TOP pad, y by the LEFT pad
+    y = O.pad(x, (1, 0, 2, 0), "constant")
+    assert y.shape == (2, 10, 13, 5)
+    np.testing.assert_array_equal(y[:, 2:, 1:12, :], x[:, :8, :, :])
+
+
+def test_add_batchnorm_restatements():
+    a = np.random.default_rng(5).standard_normal((1, 3, 4, 6)).astype(np.float32)
+    b = np.random.default_rng(6).standard_normal((1, 3, 4, 6)).astype(np.float32)
+    np.testing.assert_allclose(O.add_act(a, b, "relu"), np.maximum(a + b, 0), rtol=1e-7)
+    bn = {"beta": np.full(6, 0.1, np.float32), "gamma": np.full(6, 2.0, np.float32), "mean": np.full(6, 0.5, np.float32), "var": np.full(6, 4.0, np.float32)}
+    np.testing.assert_allclose(O.batchnorm(a, bn), 2.0 / np.sqrt(np.float32(4.001)) * (a - 0.5) + 0.1, rtol=1e-6, atol=1e-6)

@@ -6,4 +6,4 @@ of the reference API (lib/libsnn_core.so).  There is no CPU fallback anywhere in
 from .capi import (ACT, DENSE_ACT, PAD_MODE, Context, Plan, SnnHipError, Tensor, Timer, activation_plan, add_plan, batchnorm_plan, chain_plan,  # noqa: F401
                    conv2d_plan, dense_plan, global_avgpool_plan, instancenorm_plan, lib, load_library, pad_plan, pool2d_plan, same_padding,
                    subpixel_plan, upsample_plan)
-from .runner import ChainRunner, EspcnRunner  # noqa: F401
+from .runner import ChainRunner, EspcnRunner, GraphRunner  # noqa: F401

@@ -312,7 +312,9 @@ struct EltwisePlan : snnhip_plan {
         for (int i = 0; i < nIn; ++i)
             SNNHIP_REQUIRE(dims_match(in[i], d.N, d.H, d.W, d.C), "%s: input %d dims %dx%dx%dx%d != plan %dx%dx%dx%d", desc.c_str(), i, in[i]->n, in[i]->h,
                            in[i]->w, in[i]->c, d.N, d.H, d.W, d.C);
-        SNNHIP_REQUIRE(dims_match(out, d.N, d.H, d.W, d.C), "%s: output dims mismatch", desc.c_str());
+        // the output may be any reshape of the same batch (Flatten writes [N,1,1,H*W*C] / [N,1,H*W*C,1]; NHWC memory is the HWC flatten order)
+        SNNHIP_REQUIRE(out->n == d.N && out->count() == in[0]->count(), "%s: output %dx%dx%dx%d is not a reshape of the input", desc.c_str(), out->n,
+                       out->h, out->w, out->c);
         const size_t count = out->count();
         const bool vec = (d.C & 3) == 0;
         const unsigned g = grid_for(ctx, vec ? count / 4 : count);

@@ -164,6 +164,10 @@ InferenceGraph snn::dp::generateInferenceGraph(std::vector<std::shared_ptr<Gener
                 igLayer->outputDesc = {fmt, width, 1, 1, 1};
                 igLayer->flattenLayer = true;
             }
+            if (dynamic_cast<FlattenLayer*>(modelLayer.get())) { // W*H*C x 1 x 1, one channel (flattenlayer.cpp:48-62)
+                igLayer->outputDesc = {fmt, width, 1, 1, 1};
+                igLayer->flattenLayer = true;
+            }
             SNN_ASSERT(igLayer->outputDesc.width > 0 && igLayer->outputDesc.height > 0);
         } else {
             if (i == 0) SNN_RIP("CPU layer currently cannot cannot be the 1-st layer in the graph !");

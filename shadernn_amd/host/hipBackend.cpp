@@ -20,7 +20,13 @@ HipRenderPass::~HipRenderPass() {
 
 void HipRenderPass::run() {
     if (skip) return;
-    hipChk(snnhip_plan_run(plan, input->tensor(), output->tensor()), "snnhip_plan_run");
+    if (extraInputs.empty()) {
+        hipChk(snnhip_plan_run(plan, input->tensor(), output->tensor()), "snnhip_plan_run");
+    } else {
+        std::vector<const snnhip_tensor*> ins{input->tensor()};
+        for (auto* t : extraInputs) ins.push_back(t->tensor());
+        hipChk(snnhip_plan_run_n(plan, ins.data(), static_cast<int>(ins.size()), output->tensor()), "snnhip_plan_run_n");
+    }
 }
 
 bool HipRenderPass::debugPassOutput(const std::string& folder) { // vulkanBackend.cpp:132-134 naming
@@ -63,7 +69,9 @@ void HipBackend::initRenderPasses(GenericModelLayer* layer, ImageTextureArrayAcc
         const size_t want = static_cast<size_t>(od[0]) * od[1] * od[2] * od[3];
         const size_t have = static_cast<size_t>(o.width()) * o.height() * o.channels();
         if (want != have) SNN_RIP("%s: plan output %dx%dx%dx%d does not match texture %s", layer->getName().c_str(), od[0], od[1], od[2], od[3], o.getTextureInfo2().c_str());
-        rps.push_back(std::make_shared<HipRenderPass>(plan, &in[0], &o, layer->getName(), true));
+        auto rp = std::make_shared<HipRenderPass>(plan, &in[0], &o, layer->getName(), true);
+        for (size_t k = 1; k < in.size(); ++k) rp->extraInputs.push_back(&in[k]);
+        rps.push_back(rp);
         char buf[256];
         snnhip_plan_describe(plan, buf, sizeof(buf));
         SNN_LOGD("%s -> %s", layer->getName().c_str(), buf);
@@ -97,7 +105,7 @@ void HipBackend::finalizeStages(RenderStagesArray& stages, bool dumpOutputs, boo
     };
     size_t i = 0;
     while (i < stages.size()) {
-        if (!passOf(i)) {
+        if (!passOf(i) || stages[i].inputIds.size() != 1) { // a chain starts at a single-input stage (Add has two)
             ++i;
             continue;
         }

@@ -64,6 +64,7 @@ class HipRenderPass : public RenderPass {
 public:
     HipRenderPass(snnhip_plan* p, ImageTexture* in, ImageTexture* out, const std::string& layerName, bool ownsPlan = false)
         : plan(p), input(in), output(out), name(layerName), owns(ownsPlan) {}
+    std::vector<ImageTexture*> extraInputs; // inputs 1.. of multi-input operators (Add: addlayerVulkan.cpp:98 binds uInput0, uInput1)
     ~HipRenderPass() override;
     void run() override;                                   // enqueue only (vulkanRenderpass.cpp:257-259 records Dispatch + barrier)
     bool debugPassOutput(const std::string& folder) override; // "<folder>/<layer name> pass[0].dump" (vulkanBackend.cpp:132-134)

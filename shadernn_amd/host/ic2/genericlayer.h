@@ -241,5 +241,256 @@ private:
     InferencePassesSptr createCS(const LayerGenOptions&) const override;
 };
 
+// ------------------------------------------------------------------------------------------------------------------
+// Operators between the convolutions.  Desc = the reference's struct (same fields / parse calls), one
+// Layer base per operator with the reference's output-size rule, and a Hip flavour whose createCS() builds the plan.
+
+// ---- Add (addlayer.h:27-46, addlayerVulkan.cpp:33-114)
+struct AddDesc : CommonLayerDesc {
+    std::string activation;
+    float leakyReluAlpha = 0.0f;
+    void parse(ModelParser& parser, int layerId) {
+        CommonLayerDesc::parse(parser, layerId);
+        parser.getAddLayer(layerId, activation, leakyReluAlpha);
+    }
+};
+class AddLayer : public ShaderLayer {
+public:
+    explicit AddLayer(AddDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    AddDesc _desc;
+};
+class AddLayerHip : public AddLayer {
+public:
+    explicit AddLayerHip(AddDesc&& d) : AddLayer(std::move(d)) {}
+
+private:
+    InferencePassesSptr createCS(const LayerGenOptions&) const override;
+};
+
+// ---- Activation (activation.h, activationVulkan.cpp)
+struct ActivationDesc : CommonLayerDesc {
+    std::string activation;
+    float leakyReluAlpha = 0.0f;
+    void parse(ModelParser& parser, int layerId) {
+        CommonLayerDesc::parse(parser, layerId);
+        parser.getActivationLayer(layerId, activation, leakyReluAlpha);
+    }
+};
+class ActivationLayer : public ShaderLayer {
+public:
+    explicit ActivationLayer(ActivationDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    ActivationDesc _desc;
+};
+class ActivationLayerHip : public ActivationLayer {
+public:
+    explicit ActivationLayerHip(ActivationDesc&& d) : ActivationLayer(std::move(d)) {}
+
+private:
+    InferencePassesSptr createCS(const LayerGenOptions&) const override;
+};
+
+// ---- BatchNormalization (batchnorm.h:27-50, batchnormVulkan.cpp)
+struct BatchNormalizationDesc : GenericConvDesc {
+    float leakyReluAlpha = 0.0f;
+    std::map<std::string, std::vector<float>> batchNormalization;
+    void parse(ModelParser& parser, int layerId) {
+        GenericConvDesc::parse(parser, layerId);
+        int oc = 0, ic = 0;
+        parser.getBatchNormLayer(layerId, oc, ic, batchNormalization, activation, leakyReluAlpha);
+        numOutputPlanes = static_cast<uint32_t>(oc);
+        numInputPlanes = static_cast<uint32_t>(ic);
+    }
+};
+class BatchNormalizationLayer : public ShaderLayer {
+public:
+    explicit BatchNormalizationLayer(BatchNormalizationDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    BatchNormalizationDesc _desc;
+};
+class BatchNormalizationLayerHip : public BatchNormalizationLayer {
+public:
+    explicit BatchNormalizationLayerHip(BatchNormalizationDesc&& d) : BatchNormalizationLayer(std::move(d)) {}
+
+private:
+    InferencePassesSptr createCS(const LayerGenOptions&) const override;
+};
+
+// ---- MaxPooling2D / AveragePooling2D / AdaptiveAvgPool2d (maxpool2d.h/.cpp, avgpool2d.h/.cpp, adaptiveavgpool2d.h)
+struct MaxPooling2DDesc : GenericConvDesc {
+    std::string padding, paddingValue, paddingT, paddingB, paddingL, paddingR;
+    void parse(ModelParser& parser, int layerId) {
+        GenericConvDesc::parse(parser, layerId);
+        int oc = 0, ic = 0, k = 0, s = 0;
+        parser.getMaxPoolLayer(layerId, oc, ic, k, s, padding, paddingValue, paddingT, paddingB, paddingL, paddingR);
+        numOutputPlanes = static_cast<uint32_t>(oc);
+        numInputPlanes = static_cast<uint32_t>(ic);
+        kernelSize = static_cast<uint32_t>(k);
+        stride = static_cast<uint32_t>(s);
+    }
+};
+struct AveragePooling2DDesc : GenericConvDesc {
+    std::string padding;
+    void parse(ModelParser& parser, int layerId) {
+        GenericConvDesc::parse(parser, layerId);
+        int oc = 0, ic = 0, k = 0, s = 0;
+        parser.getAvgPoolLayer(layerId, oc, ic, k, s, padding);
+        numOutputPlanes = static_cast<uint32_t>(oc);
+        numInputPlanes = static_cast<uint32_t>(ic);
+        kernelSize = static_cast<uint32_t>(k);
+        stride = static_cast<uint32_t>(s);
+    }
+};
+struct AdaptiveAvgPool2dDesc : GenericConvDesc {
+    std::string padding;
+    int targetSize = 1;
+    void parse(ModelParser& parser, int layerId) {
+        GenericConvDesc::parse(parser, layerId);
+        int oc = 0, ic = 0;
+        parser.getAdaptiveAvgPoolLayer(layerId, oc, ic, targetSize);
+        numOutputPlanes = static_cast<uint32_t>(oc);
+        numInputPlanes = static_cast<uint32_t>(ic);
+    }
+};
+class MaxPooling2DLayer : public ShaderLayer {
+public:
+    explicit MaxPooling2DLayer(MaxPooling2DDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    MaxPooling2DDesc _desc;
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override; // maxpool2d.cpp:26-36
+};
+class AveragePooling2DLayer : public ShaderLayer {
+public:
+    explicit AveragePooling2DLayer(AveragePooling2DDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    AveragePooling2DDesc _desc;
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override; // avgpool2d.cpp:20-29
+};
+class AdaptiveAvgPool2dLayer : public ShaderLayer {
+public:
+    explicit AdaptiveAvgPool2dLayer(AdaptiveAvgPool2dDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+    void getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const override;
+
+protected:
+    AdaptiveAvgPool2dDesc _desc;
+};
+#define SNN_DECLARE_HIP_FLAVOUR(layer)                                                    \
+    class layer##LayerHip : public layer##Layer {                                         \
+    public:                                                                               \
+        explicit layer##LayerHip(layer##Desc&& d) : layer##Layer(std::move(d)) {}         \
+                                                                                          \
+    private:                                                                              \
+        InferencePassesSptr createCS(const LayerGenOptions&) const override;              \
+    };
+SNN_DECLARE_HIP_FLAVOUR(MaxPooling2D)
+SNN_DECLARE_HIP_FLAVOUR(AveragePooling2D)
+SNN_DECLARE_HIP_FLAVOUR(AdaptiveAvgPool2d)
+
+// ---- Flatten (flattenlayer.h/.cpp: HWC order, optional activation; a CPU layer in the reference)
+struct FlattenDesc : CommonLayerDesc {
+    std::string activation;
+    float leakyReluAlpha = 0.0f;
+    void parse(ModelParser& parser, int layerId) {
+        CommonLayerDesc::parse(parser, layerId);
+        int oc = 0, ic = 0;
+        parser.getFlattenLayer(layerId, oc, ic, activation);
+        numOutputPlanes = static_cast<uint32_t>(oc);
+        numInputPlanes = static_cast<uint32_t>(ic);
+    }
+};
+class FlattenLayer : public ShaderLayer {
+public:
+    explicit FlattenLayer(FlattenDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+    void getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const override; // flattenlayer.cpp:58-62
+
+protected:
+    FlattenDesc _desc;
+};
+SNN_DECLARE_HIP_FLAVOUR(Flatten)
+
+// ---- Pad (padlayer.h/.cpp, padlayerVulkan.cpp)
+struct PadDesc : GenericConvDesc {
+    float constant = 0.0f;
+    std::string paddingT, paddingB, paddingL, paddingR;
+    std::string mode = "constant";
+    void parse(ModelParser& parser, int layerId) {
+        GenericConvDesc::parse(parser, layerId);
+        int oc = 0, ic = 0;
+        parser.getPaddingLayer(layerId, oc, ic, paddingT, paddingB, paddingL, paddingR, mode, constant);
+        numOutputPlanes = static_cast<uint32_t>(oc);
+        numInputPlanes = static_cast<uint32_t>(ic);
+    }
+};
+class PadLayer : public ShaderLayer {
+public:
+    explicit PadLayer(PadDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    PadDesc _desc;
+    void getPaddingOffset(uint32_t (&offsets)[4]) const; // padlayer.cpp:27-56
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override; // padlayer.cpp:58-67
+};
+SNN_DECLARE_HIP_FLAVOUR(Pad)
+
+// ---- InstanceNorm (instancenorm.h, instancenormVulkan.cpp)
+struct InstanceNormDesc : GenericConvDesc {
+    std::map<std::string, std::vector<float>> instanceNormalization;
+    float leakyReluAlpha = 0.0f;
+    float epsilon = 1e-5f;
+    void parse(ModelParser& parser, int layerId) {
+        GenericConvDesc::parse(parser, layerId);
+        int oc = 0, ic = 0;
+        parser.getInstanceNormalizationLayer(layerId, oc, ic, epsilon, instanceNormalization, activation, leakyReluAlpha);
+        numOutputPlanes = static_cast<uint32_t>(oc);
+        numInputPlanes = static_cast<uint32_t>(ic);
+    }
+};
+class InstanceNormLayer : public ShaderLayer {
+public:
+    explicit InstanceNormLayer(InstanceNormDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    InstanceNormDesc _desc;
+};
+SNN_DECLARE_HIP_FLAVOUR(InstanceNorm)
+
+// ---- UpSampling2D (upsampling2d.h, upsampling2dVulkan.cpp)
+struct UpSampling2DDesc : CommonLayerDesc {
+    float scale = 2.0f;
+    std::string interpolationType;
+    void parse(ModelParser& parser, int layerId) {
+        CommonLayerDesc::parse(parser, layerId);
+        scale = parser.getUpSamplingScale(layerId);
+        interpolationType = parser.getUpSampling2DInterpolation(layerId);
+    }
+};
+class UpSampling2DLayer : public ShaderLayer {
+public:
+    explicit UpSampling2DLayer(UpSampling2DDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    UpSampling2DDesc _desc;
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override { // upsampling2d.h:41-44
+        InferenceGraph::Transform t = InferenceGraph::Transform::identity();
+        t.scaleWidth = t.scaleHeight = _desc.scale;
+        return t;
+    }
+};
+SNN_DECLARE_HIP_FLAVOUR(UpSampling2D)
+
 } // namespace dp
 } // namespace snn

@@ -15,5 +15,15 @@ GenericModelLayer* Conv2DCreator1(Conv2DDesc&& desc, bool useVulkan);
 GenericModelLayer* SeparableConv2DCreator1(SeparableConv2DDesc&& desc, bool useVulkan);
 GenericModelLayer* DenseCreator1(DenseDesc&& desc, bool useVulkan);
 GenericModelLayer* SubpixelCreator1(SubpixelDesc&& desc, bool useVulkan);
+GenericModelLayer* AddCreator1(AddDesc&& desc, bool useVulkan);
+GenericModelLayer* ActivationCreator1(ActivationDesc&& desc, bool useVulkan);
+GenericModelLayer* BatchNormalizationCreator1(BatchNormalizationDesc&& desc, bool useVulkan);
+GenericModelLayer* MaxPooling2DCreator1(MaxPooling2DDesc&& desc, bool useVulkan);
+GenericModelLayer* AveragePooling2DCreator1(AveragePooling2DDesc&& desc, bool useVulkan);
+GenericModelLayer* AdaptiveAvgPool2dCreator1(AdaptiveAvgPool2dDesc&& desc, bool useVulkan);
+GenericModelLayer* FlattenCreator1(FlattenDesc&& desc, bool useVulkan);
+GenericModelLayer* PadCreator1(PadDesc&& desc, bool useVulkan);
+GenericModelLayer* InstanceNormCreator1(InstanceNormDesc&& desc, bool useVulkan);
+GenericModelLayer* UpSampling2DCreator1(UpSampling2DDesc&& desc, bool useVulkan);
 } // namespace dp
 } // namespace snn

@@ -68,6 +68,22 @@ public:
     int getDenseLayer(int& layerID, int& numOutputUnits, int& numInputUnits, std::string& activation, std::vector<std::vector<float>>& weights,
                       std::vector<float>& biases, float& leakyReluAlpha);
     int getInputLayer(int& layerId, uint32_t& inputWidth, uint32_t& inputHeight, uint32_t& inputChannels, uint32_t& inputIndex);
+    // ---- the operators between the convolutions: same getter names / JSON keys as the reference (modelparser.cpp:304-497,987-1201)
+    int getMaxPoolLayer(int& layerID, int& numOutputPlanes, int& numInputPlanes, int& poolSize, int& stride, std::string& paddingMode,
+                        std::string& paddingValue, std::string& paddingT, std::string& paddingB, std::string& paddingL, std::string& paddingR);
+    int getAvgPoolLayer(int& layerID, int& numOutputPlanes, int& numInputPlanes, int& poolSize, int& stride, std::string& padding);
+    int getAdaptiveAvgPoolLayer(int& layerID, int& numOutputPlanes, int& numInputPlanes, int& poolSize);
+    int getAddLayer(int& layerID, std::string& activation, float& leakyReluAlpha);
+    int getActivationLayer(int& layerID, std::string& activation, float& leakyReluAlpha);
+    int getFlattenLayer(int& layerId, int& numOutputPlanes, int& numInputPlanes, std::string& activation);
+    int getBatchNormLayer(int& layerId, int& numOutputPlanes, int& numInputPlanes, std::map<std::string, std::vector<float>>& batchNormalization,
+                          std::string& activation, float& leakyReluAlpha);
+    int getPaddingLayer(int& layerId, int& numOutputPlanes, int& numInputPlanes, std::string& paddingT, std::string& paddingB, std::string& paddingL,
+                        std::string& paddingR, std::string& mode, float& constant);
+    int getInstanceNormalizationLayer(int& layerId, int& numOutputPlanes, int& numInputPlanes, float& epsilon,
+                                      std::map<std::string, std::vector<float>>& batchNormalization, std::string& activation, float& leakyReluAlpha);
+    float getUpSamplingScale(int layerId);
+    std::string getUpSampling2DInterpolation(int layerId);
 
 private:
     json::Value _modelOb;

@@ -357,6 +357,208 @@ InferencePassesSptr SubpixelLayerHip::createCS(const LayerGenOptions&) const { /
     return ret;
 }
 
+// ------------------------------------------------------------------------------------------------ operators between the convolutions
+
+static snnhip_eltwise_desc eltwiseDesc(const InferenceGraph::IODesc& in, const std::string& activation, float leaky) {
+    snnhip_eltwise_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(in.height);
+    d.W = static_cast<int>(in.width);
+    d.C = static_cast<int>(in.channels);
+    int act = activationId(activation);
+    if (act == SNNHIP_ACT_SILU_QUIRK) act = SNNHIP_ACT_SILU; // the 4-pixel quirk exists in the conv shader only
+    d.act = act;
+    d.leaky = leaky;
+    return d;
+}
+
+InferencePassesSptr AddLayerHip::createCS(const LayerGenOptions&) const { // addlayerVulkan.cpp:33-114
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    SNN_CHK(inputDims.size() == 2);
+    const snnhip_eltwise_desc d = eltwiseDesc(inputDims[0], _desc.activation, _desc.leakyReluAlpha);
+    ret->passes[0].source = formatString("Add act=%s", _desc.activation.c_str());
+    ret->passes[0].createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_add_plan_create(ctx, &d, out); };
+    return ret;
+}
+
+InferencePassesSptr ActivationLayerHip::createCS(const LayerGenOptions&) const { // activationVulkan.cpp
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    const snnhip_eltwise_desc d = eltwiseDesc(inputDims[0], _desc.activation, _desc.leakyReluAlpha);
+    ret->passes[0].source = formatString("Activation %s", _desc.activation.c_str());
+    ret->passes[0].createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_activation_plan_create(ctx, &d, out); };
+    return ret;
+}
+
+InferencePassesSptr BatchNormalizationLayerHip::createCS(const LayerGenOptions&) const { // batchnormVulkan.cpp
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    const snnhip_eltwise_desc d = eltwiseDesc(inputDims[0], _desc.activation, _desc.leakyReluAlpha);
+    const BnArrays bn = bnArrays(true, _desc.batchNormalization);
+    SNN_CHK(bn.beta.size() >= static_cast<size_t>(d.C) && bn.var.size() >= static_cast<size_t>(d.C));
+    ret->passes[0].source = formatString("BatchNormalization c=%d act=%s", d.C, _desc.activation.c_str());
+    ret->passes[0].createPlan = [d, bn](snnhip_ctx* ctx, snnhip_plan** out) {
+        return snnhip_batchnorm_plan_create(ctx, &d, bn.beta.data(), bn.gamma.data(), bn.mean.data(), bn.var.data(), out);
+    };
+    return ret;
+}
+
+static InferenceGraph::Transform poolTransform(const std::string& padding, uint32_t kernelSize, uint32_t stride) { // maxpool2d.cpp:26-36 == avgpool2d.cpp:20-29
+    InferenceGraph::Transform t = InferenceGraph::Transform::identity();
+    const float scale = 1.0f / static_cast<float>(stride);
+    float translation;
+    if (padding == "0" || padding == "valid" || padding == "none") translation = 1.0f - (static_cast<float>(kernelSize) / static_cast<float>(stride));
+    else translation = 1.0f - 1.0f / static_cast<float>(stride);
+    t.scaleWidth = t.scaleHeight = scale;
+    t.translateWidth = t.translateHeight = translation;
+    return t;
+}
+
+InferenceGraph::Transform MaxPooling2DLayer::getOutputScaleDimAdjustment() const { return poolTransform(_desc.paddingT, _desc.kernelSize, _desc.stride); }
+InferenceGraph::Transform AveragePooling2DLayer::getOutputScaleDimAdjustment() const { return poolTransform(_desc.padding, _desc.kernelSize, _desc.stride); }
+
+static InferencePassesSptr poolPasses(const InferenceGraph::IODesc& in, uint32_t ow, uint32_t oh, int kh, int kw, int sh, int sw, int type, const char* what) {
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    snnhip_pool2d_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(in.height);
+    d.W = static_cast<int>(in.width);
+    d.C = static_cast<int>(in.channels);
+    d.kh = kh;
+    d.kw = kw;
+    d.sh = sh;
+    d.sw = sw;
+    d.padT = d.padL = 0; // "Hack it. Looks like not padding on top left in NCNN" (maxpool2dVulkan.cpp:62-64, avgpool2dVulkan.cpp:58-60)
+    d.OH = static_cast<int>(oh);
+    d.OW = static_cast<int>(ow);
+    d.type = type;
+    ret->passes[0].source = formatString("%s k=%dx%d s=%d c=%d", what, kh, kw, sh, d.C);
+    ret->passes[0].createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_pool2d_plan_create(ctx, &d, out); };
+    return ret;
+}
+
+InferencePassesSptr MaxPooling2DLayerHip::createCS(const LayerGenOptions&) const { // maxpool2dVulkan.cpp:33-130
+    uint32_t ow = 0, oh = 0, od = 0;
+    GenericModelLayer::getOutputDims(ow, oh, od);
+    const int k = static_cast<int>(_desc.kernelSize), s = static_cast<int>(_desc.stride);
+    return poolPasses(inputDims[0], ow, oh, k, k, s, s, SNNHIP_POOL_MAX, "MaxPooling2D");
+}
+
+InferencePassesSptr AveragePooling2DLayerHip::createCS(const LayerGenOptions&) const { // avgpool2dVulkan.cpp
+    uint32_t ow = 0, oh = 0, od = 0;
+    GenericModelLayer::getOutputDims(ow, oh, od);
+    const int k = static_cast<int>(_desc.kernelSize), s = static_cast<int>(_desc.stride);
+    return poolPasses(inputDims[0], ow, oh, k, k, s, s, SNNHIP_POOL_AVG, "AveragePooling2D");
+}
+
+// adaptiveavgpool2dGL.cpp averages the whole input (N_DIMS = width*height taps): target size 1
+void AdaptiveAvgPool2dLayer::getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const {
+    width = height = 1;
+    depth = inputDims.empty() ? _desc.numOutputPlanes : inputDims[0].channels;
+}
+
+InferencePassesSptr AdaptiveAvgPool2dLayerHip::createCS(const LayerGenOptions&) const {
+    if (_desc.targetSize != 1) SNN_LOGW("AdaptiveAvgPool2d: target size %d requested; like the reference shader this averages the whole image", _desc.targetSize);
+    const int h = static_cast<int>(inputDims[0].height), w = static_cast<int>(inputDims[0].width);
+    return poolPasses(inputDims[0], 1, 1, h, w, h, w, SNNHIP_POOL_AVG, "AdaptiveAvgPool2d");
+}
+
+void FlattenLayer::getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const { // flattenlayer.cpp:58-62
+    width = inputDims[0].width * inputDims[0].height * inputDims[0].channels;
+    height = 1;
+    depth = 1;
+}
+
+// The reference flattens on the CPU in HWC order with an optional activation (flattenlayer.cpp:29-46, cpulayer.h:94-113).  NHWC
+// memory already is that order, so this is one activation kernel writing into the W*H*C x 1 x 1 output tensor (no download).
+InferencePassesSptr FlattenLayerHip::createCS(const LayerGenOptions&) const {
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    std::string act = _desc.activation == "linear" ? std::string() : _desc.activation;
+    const snnhip_eltwise_desc d = eltwiseDesc(inputDims[0], act, _desc.leakyReluAlpha);
+    ret->passes[0].source = "Flatten (HWC)";
+    ret->passes[0].createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_activation_plan_create(ctx, &d, out); };
+    return ret;
+}
+
+void PadLayer::getPaddingOffset(uint32_t (&offsets)[4]) const { // padlayer.cpp:27-56 (no even-kernel correction here)
+    const std::string& paddingT = _desc.paddingT;
+    const bool isdigit = !paddingT.empty() && std::all_of(paddingT.begin(), paddingT.end(), ::isdigit);
+    if (isdigit) {
+        offsets[0] = static_cast<uint32_t>(std::stoul(_desc.paddingT));
+        offsets[1] = static_cast<uint32_t>(std::stoul(_desc.paddingB));
+        offsets[2] = static_cast<uint32_t>(std::stoul(_desc.paddingL));
+        offsets[3] = static_cast<uint32_t>(std::stoul(_desc.paddingR));
+    } else if (paddingT == "valid" || paddingT == "none" || _desc.kernelSize <= 1) {
+        offsets[0] = offsets[1] = offsets[2] = offsets[3] = 0;
+    } else {
+        offsets[0] = offsets[1] = offsets[2] = offsets[3] = std::max(_desc.kernelSize / 2, 1u);
+    }
+}
+
+InferenceGraph::Transform PadLayer::getOutputScaleDimAdjustment() const { // padlayer.cpp:58-67
+    uint32_t offset[4];
+    getPaddingOffset(offset);
+    InferenceGraph::Transform t = InferenceGraph::Transform::identity();
+    t.translateWidth = static_cast<float>(offset[2] + offset[3]);
+    t.translateHeight = static_cast<float>(offset[0] + offset[1]);
+    return t;
+}
+
+InferencePassesSptr PadLayerHip::createCS(const LayerGenOptions&) const { // padlayerVulkan.cpp:33-110
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    uint32_t p[4];
+    getPaddingOffset(p);
+    snnhip_pad_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(inputDims[0].height);
+    d.W = static_cast<int>(inputDims[0].width);
+    d.C = static_cast<int>(inputDims[0].channels);
+    d.padT = static_cast<int>(p[0]);
+    d.padB = static_cast<int>(p[1]);
+    d.padL = static_cast<int>(p[2]);
+    d.padR = static_cast<int>(p[3]);
+    d.mode = _desc.mode == "replicate" ? 1 : (_desc.mode == "reflect" ? 2 : 0); // padlayerVulkan.cpp:53-60
+    ret->passes[0].source = formatString("Pad %s t%d b%d l%d r%d", _desc.mode.c_str(), d.padT, d.padB, d.padL, d.padR);
+    ret->passes[0].createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_pad_plan_create(ctx, &d, out); };
+    return ret;
+}
+
+InferencePassesSptr InstanceNormLayerHip::createCS(const LayerGenOptions&) const { // instancenormVulkan.cpp
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    const snnhip_eltwise_desc e = eltwiseDesc(inputDims[0], _desc.activation == "Relu" ? std::string("relu") : _desc.activation, _desc.leakyReluAlpha);
+    snnhip_instancenorm_desc d = {};
+    d.N = e.N; d.H = e.H; d.W = e.W; d.C = e.C; d.act = e.act; d.leaky = e.leaky;
+    d.eps = 1e-5f; // the shader hard-codes 0.00001 and ignores the parsed epsilon (vk_instancenorm.comp:118)
+    if (_desc.epsilon != 1e-5f) SNN_LOGW("InstanceNorm: epsilon %g in the model; the reference shader uses 1e-5 regardless, reproduced", _desc.epsilon);
+    const std::vector<float> beta = _desc.instanceNormalization.at("beta"), gamma = _desc.instanceNormalization.at("gamma");
+    SNN_CHK(beta.size() >= static_cast<size_t>(d.C) && gamma.size() >= static_cast<size_t>(d.C));
+    ret->passes[0].source = formatString("InstanceNorm c=%d act=%s", d.C, _desc.activation.c_str());
+    ret->passes[0].createPlan = [d, beta, gamma](snnhip_ctx* ctx, snnhip_plan** out) {
+        return snnhip_instancenorm_plan_create(ctx, &d, beta.data(), gamma.data(), out);
+    };
+    return ret;
+}
+
+InferencePassesSptr UpSampling2DLayerHip::createCS(const LayerGenOptions&) const { // upsampling2dVulkan.cpp:35-123
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    snnhip_upsample_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(inputDims[0].height);
+    d.W = static_cast<int>(inputDims[0].width);
+    d.C = static_cast<int>(inputDims[0].channels);
+    d.scale = _desc.scale;
+    d.mode = _desc.interpolationType == "bilinear" ? SNNHIP_UPSAMPLE_BILINEAR : SNNHIP_UPSAMPLE_NEAREST; // :58-70
+    ret->passes[0].source = formatString("UpSampling2D %s x%g", _desc.interpolationType.c_str(), d.scale);
+    ret->passes[0].createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_upsample_plan_create(ctx, &d, out); };
+    return ret;
+}
+
 // ------------------------------------------------------------------------------------------------ layer factory
 
 static std::unordered_map<std::string, LayerCreator> LayerRegistryDict;
@@ -377,20 +579,42 @@ DEFINE_HIP_CREATOR(Conv2D)
 DEFINE_HIP_CREATOR(SeparableConv2D)
 DEFINE_HIP_CREATOR(Dense)
 DEFINE_HIP_CREATOR(Subpixel)
+DEFINE_HIP_CREATOR(Add)
+DEFINE_HIP_CREATOR(Activation)
+DEFINE_HIP_CREATOR(BatchNormalization)
+DEFINE_HIP_CREATOR(MaxPooling2D)
+DEFINE_HIP_CREATOR(AveragePooling2D)
+DEFINE_HIP_CREATOR(AdaptiveAvgPool2d)
+DEFINE_HIP_CREATOR(Flatten)
+DEFINE_HIP_CREATOR(Pad)
+DEFINE_HIP_CREATOR(InstanceNorm)
+DEFINE_HIP_CREATOR(UpSampling2D)
 
 void snn::dp::registerLayer(const std::string& layerName, LayerCreator creator) { LayerRegistryDict.emplace(layerName, creator); }
 
-void snn::dp::initLayerRegisty() { // layerFactory.cpp:109-129 (only the hot-path operators exist in this backend)
+void snn::dp::initLayerRegisty() { // layerFactory.cpp:109-129 (the hot-path operators + the element-wise / pooling / shape operators around them)
     registerLayer("InputLayer", InputLayerCreator);
     registerLayer("Conv2D", Conv2DCreator);
     registerLayer("SeparableConv2D", SeparableConv2DCreator);
     registerLayer("Dense", DenseCreator);
     registerLayer("Subpixel", SubpixelCreator);
+    registerLayer("Add", AddCreator);
+    registerLayer("Activation", ActivationCreator);
+    registerLayer("BatchNormalization", BatchNormalizationCreator);
+    registerLayer("MaxPooling2D", MaxPooling2DCreator);
+    registerLayer("AveragePooling2D", AveragePooling2DCreator);
+    registerLayer("AdaptiveAvgPool2d", AdaptiveAvgPool2dCreator);
+    registerLayer("Flatten", FlattenCreator);
+    registerLayer("Pad", PadCreator);
+    registerLayer("InstanceNorm", InstanceNormCreator);
+    registerLayer("UpSampling2D", UpSampling2DCreator);
 }
 
 GenericModelLayer* snn::dp::createLayerInstance(std::string layerName, ModelParser& parser, int i, bool useVulkan) { // layerFactory.cpp:136-159
     if (layerName == "DepthwiseConv2D" || layerName == "Depthwise") layerName = "SeparableConv2D";
     if (layerName == "subpixel" || layerName == "depth_to_space") layerName = "Subpixel";
+    if (layerName == "InstanceNormalization") layerName = "InstanceNorm";
+    if (layerName == "ZeroPadding2D") layerName = "Pad";
     auto it = LayerRegistryDict.find(layerName);
     if (it == LayerRegistryDict.end()) SNN_RIP("Not found layer: %s", layerName.c_str());
     return it->second(parser, i, useVulkan);

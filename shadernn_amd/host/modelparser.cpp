@@ -282,3 +282,192 @@ int ModelParser::getDenseLayer(int& layerID, int& numOutputUnits, int& numInputU
         return -1;
     }
 }
+
+// ------------------------------------------------------------------------------------------------ operators between the convolutions
+
+static int strideOf(const json::Value& o, int fallback) { // modelparser.cpp:313-334: "stride" | "strides", number or [n, n]
+    for (const char* key : {"stride", "strides"}) {
+        if (!o.has(key)) continue;
+        const json::Value& v = o.at(key);
+        if (v.isNumber()) return static_cast<int>(v.asNumber());
+        if (v.isArray()) return static_cast<int>(v.asArray().at(0).asNumber());
+    }
+    return fallback;
+}
+
+int ModelParser::getMaxPoolLayer(int& layerID, int& numOutputPlanes, int& numInputPlanes, int& poolSize, int& stride, std::string& paddingMode,
+                                 std::string& paddingValue, std::string& paddingT, std::string& paddingB, std::string& paddingL, std::string& paddingR) { // :304-371
+    try {
+        const json::Value& o = layer(layerID);
+        numOutputPlanes = static_cast<int>(o.at("outputPlanes").asNumber());
+        numInputPlanes = static_cast<int>(o.at("inputPlanes").asNumber());
+        poolSize = static_cast<int>(o.at("pool").asArray().at(0).asNumber());
+        stride = strideOf(o, poolSize);
+        parsePadding(o, paddingT, paddingB, paddingL, paddingR, nullptr);
+        const json::Value& p = o.at("padding");
+        if (!p.isArray()) paddingMode = paddingT;
+        paddingValue = o.has("padding_value") ? o.at("padding_value").asString() : "constant";
+    } catch (std::exception& e) {
+        SNN_LOGE("ModelParser::getMaxPoolLayer : Issues parsing layer %d, %s", layerID, e.what());
+        return -1;
+    }
+    return 0;
+}
+
+int ModelParser::getAvgPoolLayer(int& layerID, int& numOutputPlanes, int& numInputPlanes, int& poolSize, int& stride, std::string& padding) { // :373-397
+    try {
+        const json::Value& o = layer(layerID);
+        numOutputPlanes = static_cast<int>(o.at("outputPlanes").asNumber());
+        numInputPlanes = static_cast<int>(o.at("inputPlanes").asNumber());
+        const json::Value& pool = o.has("pool") ? o.at("pool") : o.at("pool_size");
+        poolSize = static_cast<int>(pool.asArray().at(0).asNumber());
+        stride = o.has("stride") ? strideOf(o, poolSize) : poolSize;
+        padding = o.at("padding").asString();
+    } catch (std::exception& e) {
+        SNN_LOGE("ModelParser::getAvgPoolLayer : Issues parsing layer %d, %s", layerID, e.what());
+        return -1;
+    }
+    return 0;
+}
+
+int ModelParser::getAdaptiveAvgPoolLayer(int& layerID, int& numOutputPlanes, int& numInputPlanes, int& poolSize) { // :439-451
+    try {
+        const json::Value& o = layer(layerID);
+        numOutputPlanes = static_cast<int>(o.at("outputPlanes").asNumber());
+        numInputPlanes = static_cast<int>(o.at("inputPlanes").asNumber());
+        poolSize = static_cast<int>(o.at("pool").asArray().at(0).asNumber());
+    } catch (std::exception& e) {
+        SNN_LOGE("ModelParser::getAdaptiveAvgPoolLayer : Issues parsing layer %d, %s", layerID, e.what());
+        return -1;
+    }
+    return 0;
+}
+
+static void activationOf(const json::Value& o, std::string& activation, float& leakyReluAlpha) { // :399-437 (note the "leaky_relu" spelling there)
+    activation = o.has("activation") ? o.at("activation").asString() : "linear";
+    if (activation == "leaky_relu" || activation == "leakyRelu") {
+        if (o.has("leakyReluAlpha")) leakyReluAlpha = static_cast<float>(o.at("leakyReluAlpha").asNumber());
+        else if (o.has("alpha")) leakyReluAlpha = static_cast<float>(o.at("alpha").asNumber());
+        else leakyReluAlpha = 0.3f;
+    }
+}
+
+int ModelParser::getAddLayer(int& layerID, std::string& activation, float& leakyReluAlpha) {
+    try {
+        activationOf(layer(layerID), activation, leakyReluAlpha);
+    } catch (std::exception& e) {
+        SNN_LOGE("ModelParser::getAddLayer : Issues parsing layer %d, %s", layerID, e.what());
+        return -1;
+    }
+    return 0;
+}
+
+int ModelParser::getActivationLayer(int& layerID, std::string& activation, float& leakyReluAlpha) { return getAddLayer(layerID, activation, leakyReluAlpha); }
+
+int ModelParser::getFlattenLayer(int& layerId, int& numOutputPlanes, int& numInputPlanes, std::string& activation) { // :453-466
+    try {
+        const json::Value& o = layer(layerId);
+        numOutputPlanes = static_cast<int>(o.at("outputPlanes").asNumber());
+        numInputPlanes = static_cast<int>(o.at("inputPlanes").asNumber());
+        activation = o.has("activation") ? o.at("activation").asString() : "linear";
+    } catch (std::exception& e) {
+        SNN_LOGE("ModelParser::getFlattenLayer : Issues parsing layer %d, %s", layerId, e.what());
+        return -1;
+    }
+    return 0;
+}
+
+int ModelParser::getBatchNormLayer(int& layerId, int& numOutputPlanes, int& numInputPlanes, std::map<std::string, std::vector<float>>& batchNormalization,
+                                   std::string& activation, float& leakyReluAlpha) { // :1011-1110 (inline arrays; missing beta/gamma default to 0/1)
+    try {
+        const json::Value& o = layer(layerId);
+        numOutputPlanes = static_cast<int>(o.at("outputPlanes").asNumber());
+        numInputPlanes = static_cast<int>(o.at("inputPlanes").asNumber());
+        const json::Value& bn = o.at("batchNormalization");
+        auto cvt = [&](double v) { return preferHp ? convertToMediumPrecision(static_cast<float>(v)) : static_cast<float>(v); };
+        auto arr = [&](const char* a, const char* b, bool required, float dflt) {
+            std::vector<float> out(static_cast<size_t>(numOutputPlanes), cvt(dflt));
+            const json::Value* v = bn.has(a) ? &bn.at(a) : (b && bn.has(b) ? &bn.at(b) : nullptr);
+            if (!v) {
+                if (required) throw std::runtime_error(std::string("json: missing key ") + a);
+                return out;
+            }
+            for (int i = 0; i < numOutputPlanes; ++i) out[static_cast<size_t>(i)] = cvt(v->asArray().at(static_cast<size_t>(i)).asNumber());
+            return out;
+        };
+        batchNormalization["beta"] = arr("beta", nullptr, false, 0.0f);
+        batchNormalization["gamma"] = arr("gamma", nullptr, false, 1.0f);
+        batchNormalization["movingMean"] = arr("moving_mean", "movingMean", true, 0.0f);
+        batchNormalization["movingVariance"] = arr("moving_variance", "movingVariance", true, 0.0f);
+        if (o.has("activation")) activation = o.at("activation").asString();
+        if (activation == "leakyRelu") leakyReluAlpha = cvt(o.has("leakyReluAlpha") ? o.at("leakyReluAlpha").asNumber() : o.at("alpha").asNumber());
+    } catch (std::exception& e) {
+        SNN_LOGE("ModelParser::BatchNormLayer : Issues parsing layer %d, %s", layerId, e.what());
+        return -1;
+    }
+    return 0;
+}
+
+int ModelParser::getPaddingLayer(int& layerId, int& numOutputPlanes, int& numInputPlanes, std::string& paddingT, std::string& paddingB, std::string& paddingL,
+                                 std::string& paddingR, std::string& mode, float& constant) { // :1112-1147
+    try {
+        const json::Value& o = layer(layerId);
+        numOutputPlanes = static_cast<int>(o.at("outputPlanes").asNumber());
+        numInputPlanes = static_cast<int>(o.at("inputPlanes").asNumber());
+        if (o.has("pads")) { // ONNX order [n, c, h, w] begin then end
+            const json::Array& a = o.at("pads").asArray();
+            paddingT = std::to_string(static_cast<uint32_t>(a.at(2).asNumber()));
+            paddingB = std::to_string(static_cast<uint32_t>(a.at(6).asNumber()));
+            paddingL = std::to_string(static_cast<uint32_t>(a.at(3).asNumber()));
+            paddingR = std::to_string(static_cast<uint32_t>(a.at(7).asNumber()));
+        } else {
+            parsePadding(o, paddingT, paddingB, paddingL, paddingR, nullptr);
+        }
+        // the reference getter drops "mode"/"constant" on the floor (unnamed parameters, :1113), which leaves PadDesc::mode at its
+        // "constant" default for every JSON model; here the key is honoured when present
+        if (o.has("mode")) mode = o.at("mode").asString();
+        if (o.has("constant")) constant = static_cast<float>(o.at("constant").asNumber());
+    } catch (std::exception& e) {
+        SNN_LOGE("ModelParser::getPaddingLayer : Issues parsing layer %d, %s", layerId, e.what());
+        return -1;
+    }
+    return 0;
+}
+
+int ModelParser::getInstanceNormalizationLayer(int& layerId, int& numOutputPlanes, int& numInputPlanes, float& epsilon,
+                                               std::map<std::string, std::vector<float>>& batchNormalization, std::string& activation,
+                                               float& leakyReluAlpha) { // :1149-1201
+    try {
+        const json::Value& o = layer(layerId);
+        numOutputPlanes = static_cast<int>(o.at("outputPlanes").asNumber());
+        numInputPlanes = static_cast<int>(o.at("inputPlanes").asNumber());
+        if (o.has("activation")) activation = o.at("activation").asString();
+        epsilon = static_cast<float>(o.at("epsilon").asNumber());
+        const json::Value& w = o.at("weights");
+        auto cvt = [&](double v) { return preferHp ? convertToMediumPrecision(static_cast<float>(v)) : static_cast<float>(v); };
+        std::vector<float> bias(static_cast<size_t>(numOutputPlanes)), scale(static_cast<size_t>(numOutputPlanes));
+        for (int i = 0; i < numOutputPlanes; ++i) {
+            bias[static_cast<size_t>(i)] = cvt(w.at("bias").asArray().at(static_cast<size_t>(i)).asNumber());
+            scale[static_cast<size_t>(i)] = cvt(w.at("scale").asArray().at(static_cast<size_t>(i)).asNumber());
+        }
+        batchNormalization["beta"] = bias;
+        batchNormalization["gamma"] = scale;
+        if (activation == "leakyRelu") leakyReluAlpha = cvt(o.at("leakyReluAlpha").asNumber());
+    } catch (std::exception& e) {
+        SNN_LOGE("ModelParser::getInstanceNormLayer : Issues parsing layer %d, %s", layerId, e.what());
+        return -1;
+    }
+    return 0;
+}
+
+float ModelParser::getUpSamplingScale(int layerId) { // :987-997
+    if (getLayerName(layerId) == "UpSampling2D") return static_cast<float>(layer(layerId).at("scaleFactor").asNumber());
+    SNN_LOGW("ModelParser:: accessing scale in a non upsampling2D layer");
+    return 0;
+}
+
+std::string ModelParser::getUpSampling2DInterpolation(int layerId) { // :999-1009
+    if (getLayerName(layerId) == "UpSampling2D") return layer(layerId).at("interpolation").asString();
+    SNN_LOGW("ModelParser:: accessing interpolation in a non upsampling2D layer");
+    return "";
+}

@@ -51,14 +51,122 @@ def single_conv(seed=1, ic=3, oc=64, k=3, act="relu", stride=1, bn=False):
     return {"name": "single_conv", "input_channels": ic, "layers": [_conv(rng, "conv2d", ic, oc, k, act, stride=stride, bn=bn)]}
 
 
+# ---- graph-shaped nets: a layer may name its producers in "inputs" (default: the previous layer; "input" = the model input) ----
+
+def _op(t, name, c, inputs=None, **kw):
+    d = {"type": t, "name": name, "ic": c, "oc": c}
+    if inputs is not None:
+        d["inputs"] = list(inputs)
+    d.update(kw)
+    return d
+
+
+def resnet18(seed=1, num_classes=1000, width=64, in_channels=3):
+    """ResNet-18 as the reference's converter emits it (BN + ReLU fused into Conv2D, ReLU fused into Add; resnet18Test.cpp:84-140):
+    conv7x7/2 -> maxpool3/2 -> 4 stages x 2 basic blocks (1x1/2 downsample at the stage entry) -> global average pool -> flatten -> dense.
+    `width` scales the channel counts (64 = the real model)."""
+    rng = np.random.default_rng(seed)
+    L = [_conv(rng, "conv1", in_channels, width, 7, "relu", stride=2, bn=True), _op("MaxPooling2D", "pool1", width, pool=3, stride=2, padding="same")]
+    prev, c = "pool1", width
+    for stage in range(4):
+        oc = width << stage
+        for blk in range(2):
+            stride = 2 if (stage > 0 and blk == 0) else 1
+            tag = "l%d_b%d" % (stage + 1, blk)
+            a = _conv(rng, tag + "_conv1", c, oc, 3, "relu", stride=stride, bn=True)
+            a["inputs"] = [prev]
+            b = _conv(rng, tag + "_conv2", oc, oc, 3, "linear", bn=True)
+            L += [a, b]
+            skip = prev
+            if stride != 1 or c != oc:
+                d = _conv(rng, tag + "_down", c, oc, 1, "linear", stride=stride, bn=True)
+                d["inputs"] = [prev]
+                L.append(d)
+                skip = d["name"]
+            L.append(_op("Add", tag + "_add", oc, inputs=[b["name"], skip], activation="relu"))
+            prev, c = tag + "_add", oc
+    L += [_op("AdaptiveAvgPool2d", "avgpool", c, pool=1), _op("Flatten", "flatten", c), _dense(rng, "fc", c, num_classes, "softmax")]
+    return {"name": "resnet18", "input_channels": in_channels, "layers": L}
+
+
+def mobilenetv2(seed=1, num_classes=1000, width_mult=1.0, in_channels=3):
+    """MobileNetV2 (relu6, BN fused): conv3x3/2 -> 17 inverted-residual blocks (expand 1x1, depthwise 3x3, project 1x1, Add when
+    stride 1 and equal widths) -> conv1x1 1280 -> global average pool -> flatten -> dense."""
+    rng = np.random.default_rng(seed)
+    ch = lambda c: max(8, int(c * width_mult + 4) // 8 * 8)
+    c = ch(32)
+    L = [_conv(rng, "conv_stem", in_channels, c, 3, "relu6", stride=2, bn=True)]
+    prev = "conv_stem"
+    idx = 0
+    for t, oc_, n, s in [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]:
+        oc = ch(oc_)
+        for i in range(n):
+            stride = s if i == 0 else 1
+            tag = "b%02d" % idx
+            idx += 1
+            x = prev
+            hid = c * t
+            if t != 1:
+                e = _conv(rng, tag + "_expand", c, hid, 1, "relu6", bn=True)
+                e["inputs"] = [x]
+                L.append(e)
+                x = e["name"]
+            dw = _depthwise(rng, tag + "_dw", hid, 3, "relu6", stride=stride, bn=True)
+            dw["inputs"] = [x]
+            pj = _conv(rng, tag + "_project", hid, oc, 1, "linear", bn=True)
+            L += [dw, pj]
+            out = pj["name"]
+            if stride == 1 and c == oc:
+                L.append(_op("Add", tag + "_add", oc, inputs=[out, prev], activation="linear"))
+                out = tag + "_add"
+            prev, c = out, oc
+    last = ch(1280) if width_mult > 1.0 else max(8, int(1280 * min(width_mult, 1.0)) // 8 * 8) if width_mult < 1.0 else 1280
+    hd = _conv(rng, "conv_head", c, last, 1, "relu6", bn=True)
+    hd["inputs"] = [prev]
+    L += [hd, _op("AdaptiveAvgPool2d", "avgpool", last, pool=1), _op("Flatten", "flatten", last), _dense(rng, "fc", last, num_classes, "softmax")]
+    return {"name": "mobilenetv2", "input_channels": in_channels, "layers": L}
+
+
+def style_net(seed=1, width=16, in_channels=3):
+    """A small Candy-shaped style-transfer net (fast-neural-style): reflect pads + convs + instance norm, one residual block,
+    nearest upsampling -- every operator of BASELINE config 5 at toy size (the real candy-9 graph has 16 convs / 15 instance norms)."""
+    rng = np.random.default_rng(seed)
+    inorm = lambda name, c, act: _op("InstanceNorm", name, c, beta=rng.uniform(-0.2, 0.2, c).astype(np.float32), gamma=rng.uniform(0.5, 1.5, c).astype(np.float32),
+                                     epsilon=1e-5, activation=act)
+    pad = lambda name, c, p: _op("Pad", name, c, padding=[[p, p], [p, p]], mode="reflect")
+    w = width
+    L = [pad("pad1", in_channels, 4), _conv(rng, "conv1", in_channels, w, 9, "linear", padding="valid"), inorm("in1", w, "relu"),
+         pad("pad2", w, 1), _conv(rng, "conv2", w, 2 * w, 3, "linear", stride=2, padding="valid"), inorm("in2", 2 * w, "relu"),
+         # residual block: zero-padded "same" convs -- under the reference's size rule a Pad layer grows the tensor and a "valid"
+         # conv does not shrink it back (SURVEY Q20), so pad+valid inside a skip connection would not line up with the skip
+         _conv(rng, "r_conv1", 2 * w, 2 * w, 3, "linear"), inorm("r_in1", 2 * w, "relu"),
+         _conv(rng, "r_conv2", 2 * w, 2 * w, 3, "linear"), inorm("r_in2", 2 * w, "linear"),
+         _op("Add", "r_add", 2 * w, inputs=["r_in2", "in2"], activation="linear"),
+         _op("UpSampling2D", "up1", 2 * w, scaleFactor=2.0, interpolation="nearest"),
+         pad("pad3", 2 * w, 1), _conv(rng, "conv3", 2 * w, w, 3, "linear", padding="valid"), inorm("in3", w, "relu"),
+         pad("pad4", w, 4), _conv(rng, "conv4", w, in_channels, 9, "linear", padding="valid")]
+    return {"name": "style_net", "input_channels": in_channels, "layers": L}
+
+
+def producers(net):
+    """[(layer, [producer names])] with the chain default made explicit."""
+    out, prev = [], "input"
+    for l in net["layers"]:
+        out.append((l, list(l.get("inputs", [prev]))))
+        prev = l["name"]
+    return out
+
+
 def to_json_dict(net, width, height):
-    """The reference's JSON model: Layer_0 is the InputLayer, layer i consumes layer i-1 (all nets here are chains)."""
+    """The reference's JSON model: Layer_0 is the InputLayer; "inputId" lists the producer layers (modelparser.cpp:133-143)."""
     layers = net["layers"]
     out = {"numLayers": {"count": len(layers) + 1}, "inputRange": "[0,1]",
            "Layer_0": {"name": "input_1", "type": "InputLayer", "Input Width": int(width), "Input Height": int(height),
                        "outputPlanes": int(net["input_channels"]), "numInputs": 0, "inputId": []}}
-    for i, l in enumerate(layers, start=1):
-        o = {"name": l["name"], "numInputs": 1, "inputId": [i - 1], "inputPlanes": int(l["ic"]), "outputPlanes": int(l["oc"])}
+    ids = {"input": 0}
+    for i, (l, ins) in enumerate(producers(net), start=1):
+        ids[l["name"]] = i
+        o = {"name": l["name"], "numInputs": len(ins), "inputId": [ids[n] for n in ins], "inputPlanes": int(l["ic"]), "outputPlanes": int(l["oc"])}
         t = l["type"]
         if t in ("Conv2D", "DepthwiseConv2D"):
             o["type"] = t
@@ -82,6 +190,25 @@ def to_json_dict(net, width, height):
         elif t == "Subpixel":
             o["type"] = "Lambda"  # dispatched by NAME (modelparser.cpp:82-84, layerFactory.cpp:147-149)
             o["name"] = "subpixel"
+        elif t in ("MaxPooling2D", "AveragePooling2D", "AdaptiveAvgPool2d"):
+            o.update({"type": t, "pool": [int(l["pool"]), int(l["pool"])]})
+            if t != "AdaptiveAvgPool2d":
+                o.update({"stride": int(l["stride"]), "padding": l["padding"]})
+        elif t in ("Add", "Activation", "Flatten"):
+            o.update({"type": t, "activation": l.get("activation", "linear")})
+            if l.get("activation") == "leakyRelu":
+                o["leakyReluAlpha"] = float(l.get("alpha", 0.1))
+        elif t == "BatchNormalization":
+            o.update({"type": t, "activation": l.get("activation", "linear"),
+                      "batchNormalization": {"beta": [float(v) for v in l["bn"]["beta"]], "gamma": [float(v) for v in l["bn"]["gamma"]],
+                                             "moving_mean": [float(v) for v in l["bn"]["mean"]], "moving_variance": [float(v) for v in l["bn"]["var"]]}})
+        elif t == "Pad":
+            o.update({"type": "Pad", "padding": l["padding"], "mode": l["mode"]})
+        elif t == "InstanceNorm":
+            o.update({"type": "InstanceNormalization", "epsilon": float(l["epsilon"]), "activation": l["activation"],
+                      "weights": {"bias": [float(v) for v in l["beta"]], "scale": [float(v) for v in l["gamma"]]}})
+        elif t == "UpSampling2D":
+            o.update({"type": t, "scaleFactor": float(l["scaleFactor"]), "interpolation": l["interpolation"]})
         else:
             o["type"] = t
             for k, v in l.items():

@@ -20,7 +20,29 @@ def _layer_plan(ctx, layer, shape):
         return capi.dense_plan(ctx, n, layer["w"], layer["units"], layer["b"], act=layer["activation"] if layer["activation"] in capi.DENSE_ACT else "relu")
     if t == "Subpixel":
         return capi.subpixel_plan(ctx, n, h, w, c, 2, layer.get("mode", 0))
+    if t in ("MaxPooling2D", "AveragePooling2D"):
+        return capi.pool2d_plan(ctx, n, h, w, c, layer["pool"], layer["stride"], kind="max" if t == "MaxPooling2D" else "avg",
+                                same=layer["padding"] not in ("valid", "none", "0"))
+    if t == "AdaptiveAvgPool2d":
+        return capi.global_avgpool_plan(ctx, n, h, w, c)
+    if t == "Add":
+        return capi.add_plan(ctx, n, h, w, c, act=_plain(layer.get("activation", "")), leaky=layer.get("alpha", 0.0))
+    if t in ("Activation", "Flatten"):
+        return capi.activation_plan(ctx, n, h, w, c, _plain(layer.get("activation", "")), layer.get("alpha", 0.0))
+    if t == "BatchNormalization":
+        return capi.batchnorm_plan(ctx, n, h, w, c, layer["bn"], act=_plain(layer.get("activation", "")), leaky=layer.get("alpha", 0.0))
+    if t == "Pad":
+        (pt, pb), (pl, pr) = layer["padding"]
+        return capi.pad_plan(ctx, n, h, w, c, (pt, pb, pl, pr), layer["mode"])
+    if t == "InstanceNorm":
+        return capi.instancenorm_plan(ctx, n, h, w, c, layer["beta"], layer["gamma"], act=_plain(layer.get("activation", "")), leaky=layer.get("alpha", 0.0))
+    if t == "UpSampling2D":
+        return capi.upsample_plan(ctx, n, h, w, c, layer["scaleFactor"], layer["interpolation"])
     raise ValueError("unsupported layer type " + t)
+
+
+def _plain(act):
+    return "" if act in ("linear", "none", None) else act
 
 
 class ChainRunner:
@@ -75,3 +97,53 @@ class ChainRunner:
 
 class EspcnRunner(ChainRunner):
     pass
+
+
+class GraphRunner:
+    """Graph-shaped nets (models.resnet18 / mobilenetv2 / style_net): one plan per layer at any batch size, producers by name.
+    Tensors are allocated once; run_device() only enqueues kernels.  (The C++ host mirror runs the same graphs at batch 1 from JSON.)"""
+
+    def __init__(self, ctx, net, n, h, w):
+        from . import models
+
+        self.ctx, self.net = ctx, net
+        self.in_shape = (n, h, w, net["input_channels"])
+        self.x = capi.Tensor(ctx, *self.in_shape)
+        shapes, self.tensors = {"input": self.in_shape}, {"input": self.x}
+        self.steps = []  # (plan, [input tensors], output tensor, layer)
+        for layer, ins in models.producers(net):
+            shape = shapes[ins[0]]
+            if layer["type"] == "Dense":  # consumes the flattened producer
+                shape = (shape[0], 1, 1, shape[1] * shape[2] * shape[3])
+            plan = _layer_plan(ctx, layer, shape)
+            out_shape = plan.out_shape()
+            if layer["type"] == "Flatten":
+                out_shape = (shape[0], 1, 1, shape[1] * shape[2] * shape[3])
+            t = capi.Tensor(ctx, *out_shape)
+            shapes[layer["name"]], self.tensors[layer["name"]] = out_shape, t
+            self.steps.append((plan, [self.tensors[i] for i in ins], t, layer))
+        self.y = self.steps[-1][2]
+        self.out_shape = shapes[net["layers"][-1]["name"]]
+
+    def describe(self):
+        return ["%s: %s" % (l["name"], p.describe()) for p, _, _, l in self.steps]
+
+    def cost(self):
+        f = b = 0.0
+        for p, _, _, _ in self.steps:
+            pf, pb = p.cost()
+            f += pf
+            b += pb
+        return f, b
+
+    def run_device(self):
+        for plan, ins, out, _ in self.steps:
+            plan.run(ins if len(ins) > 1 else ins[0], out)
+
+    def __call__(self, x):
+        self.x.upload(np.ascontiguousarray(x, dtype=np.float32))
+        self.run_device()
+        return self.y.numpy()
+
+    def output_of(self, name):
+        return self.tensors[name].numpy()

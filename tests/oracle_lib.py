@@ -184,6 +184,7 @@ def subpixel(x, factor=2, mode=0):
 def add_act(a, b=None, act="", leaky=0.0):
     a = _f(a)
     b = _f(b)
+    assert b is None or b.shape == a.shape, (a.shape, b.shape)
     y = np.empty_like(a)
     lib().snn_oracle_add_act(_p(a), _p(b), C.c_long(a.size), ACT[act], C.c_float(leaky), _p(y))
     return y
@@ -269,11 +270,14 @@ def ref_dense(In, Out, act, alpha, w_flat, bias, x):
     return np.array([float(t) for t in out.split()], dtype=np.float32)
 
 
-def forward(net, x, threads=1, return_layers=False):
-    """Runs a models.py chain net on the oracle."""
-    outs = []
+def forward(net, x, threads=1, return_layers=False, return_named=False):
+    """Runs a models.py net (chain or graph: layers may name their producers in "inputs") on the oracle."""
+    outs, named, prev = [], {"input": _f(x)}, "input"
     for l in net["layers"]:
+        ins = [named[n] for n in l.get("inputs", [prev])]
+        x = ins[0]
         t = l["type"]
+        plain = lambda a: "" if a in ("linear", "none", None) else a
         if t == "Conv2D":
             pads = padding_offsets(l["padding"], l["kernel"])
             x = conv2d(x, l["w"], l["b"], l["stride"], pads, l.get("pad_mode", "constant"), l["activation"], l.get("alpha", 0.0), l["bn"], threads)
@@ -281,12 +285,35 @@ def forward(net, x, threads=1, return_layers=False):
             pads = padding_offsets(l["padding"], l["kernel"])
             x = depthwise(x, l["w"], l["b"], l["stride"], pads, l["activation"], l.get("alpha", 0.0), l["bn"])
         elif t == "Dense":
-            x = dense(x, l["w"], l["units"], l["b"], l["activation"]).reshape(x.shape[0], 1, 1, -1)
+            x = dense(x.reshape(x.shape[0], -1), l["w"], l["units"], l["b"], l["activation"]).reshape(x.shape[0], 1, 1, -1)
         elif t == "Subpixel":
             x = subpixel(x, 2, l.get("mode", 0))
+        elif t in ("MaxPooling2D", "AveragePooling2D"):
+            x = pool2d(x, l["pool"], l["stride"], "max" if t == "MaxPooling2D" else "avg", l["padding"] not in ("valid", "none", "0"))
+        elif t == "AdaptiveAvgPool2d":
+            x = global_avgpool(x)
+        elif t == "Add":
+            x = add_act(ins[0], ins[1], plain(l.get("activation", "")), l.get("alpha", 0.0))
+        elif t == "Activation":
+            x = add_act(x, None, plain(l.get("activation", "")), l.get("alpha", 0.0))
+        elif t == "Flatten":
+            x = add_act(x, None, plain(l.get("activation", "")), l.get("alpha", 0.0)).reshape(x.shape[0], 1, 1, -1)
+        elif t == "BatchNormalization":
+            x = batchnorm(x, l["bn"], plain(l.get("activation", "")), l.get("alpha", 0.0))
+        elif t == "Pad":
+            (pt, pb), (pl, pr) = l["padding"]
+            x = pad(x, (pt, pb, pl, pr), l["mode"])
+        elif t == "InstanceNorm":
+            x = instancenorm(x, l["beta"], l["gamma"], plain(l.get("activation", "")), l.get("alpha", 0.0))
+        elif t == "UpSampling2D":
+            x = upsample(x, l["scaleFactor"], l["interpolation"])
         else:
             raise ValueError(t)
         outs.append(x)
+        named[l["name"]] = x
+        prev = l["name"]
+    if return_named:
+        return x, named
     return (x, outs) if return_layers else x
 
 

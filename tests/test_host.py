@@ -166,3 +166,71 @@ def test_mixed_model_with_depthwise_and_dense(ctx, tmp_path):
     np.testing.assert_allclose(y.reshape(-1), want.reshape(-1), **TOL)
     assert abs(float(y.sum()) - 1.0) < 1e-5
     m.close()
+
+
+# ---- graph-shaped models with the element-wise / pooling / shape operators ---------------------------------------
+
+def _small_nets():
+    from shadernn_amd import models
+
+    return [(models.resnet18(seed=2, num_classes=10, width=8), 64, 64), (models.mobilenetv2(seed=3, num_classes=10, width_mult=0.25), 64, 64),
+            (models.style_net(seed=4, width=8), 32, 24)]
+
+
+def test_graph_models_parse_on_cpu(built, tmp_path):
+    """ResNet-18 / MobileNetV2 / style-net topologies through ModelParser + the graph builder: layer types, DAG edges, shape rules."""
+    from shadernn_amd import host, models
+
+    net, w, h = _small_nets()[0]
+    rows = host.graph_summary(_json(tmp_path, net, w, h), w, h, 3)
+    names = [r["name"].split("] ")[1] for r in rows]
+    assert names[:3] == ["InputLayer", "Conv2D", "MaxPooling2D"] and names[-3:] == ["AdaptiveAvgPool2d", "Flatten", "Dense"]
+    assert names.count("Add") == 8 and names.count("Conv2D") == 20
+    assert rows[1]["dims"] == (32, 32, 8) and rows[2]["dims"] == (16, 16, 8)       # conv7x7/2, maxpool3/2 "same" (float rule)
+    assert rows[-3]["dims"] == (1, 1, 64) and rows[-2]["dims"][0] == 64 and rows[-1]["dims"][0] == 10
+    adds = [r for r in rows if "Add" in r["name"]]
+    assert all(len(r["inputs"]) == 2 for r in adds)
+    net, w, h = _small_nets()[2]
+    rows = host.graph_summary(_json(tmp_path, net, w, h), w, h, 3)
+    dims = {r["name"].split("] ")[1] + str(i): r["dims"] for i, r in enumerate(rows)}
+    assert rows[1]["dims"] == (40, 32, 3)        # reflect pad 4
+    assert rows[2]["dims"] == (40, 32, 8)        # Q20: the "valid" 9x9 conv keeps the padded size
+    assert any("UpSampling2D" in k for k in dims) and any("InstanceNorm" in k for k in dims)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1, 2], ids=["resnet18", "mobilenetv2", "style_net"])
+def test_graph_models_json_end_to_end(ctx, tmp_path, which):
+    """JSON -> C++ host mirror -> HIP plans (batch 1), every stage output against the oracle's (layer-by-layer, resnet18Test.cpp:84-140 style)."""
+    from shadernn_amd import host
+
+    net, w, h = _small_nets()[which]
+    x = np.random.default_rng(5).random((1, h, w, 3), dtype=np.float32)
+    m = host.Model(_json(tmp_path, net, w, h), w, h, 3, fuse_chains=False)
+    y = m(x)
+    want, named = O.forward(net, x, return_named=True)
+    st = m.stages()
+    assert len(st) == len(net["layers"]) + 1
+    seen = set()
+    for i in range(1, len(st)):  # stages are in topological order (dp.cpp:389-429); the layer id is in the stage name
+        lid = int(re.search(r"layer \[(\d+)\]", st[i]["name"]).group(1))
+        seen.add(lid)
+        exp = named[net["layers"][lid - 1]["name"]]
+        np.testing.assert_allclose(m.stage_output(i).reshape(-1), exp.reshape(-1), err_msg="stage %d %s" % (i, st[i]["name"]), **TOL)
+    assert seen == set(range(1, len(net["layers"]) + 1))
+    np.testing.assert_allclose(y.reshape(-1), want.reshape(-1), **TOL)
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1, 2], ids=["resnet18", "mobilenetv2", "style_net"])
+def test_graph_runner_batched(ctx, which):
+    """The same graphs at batch 3 through per-layer C-ABI plans (what tools/bench_models.py times at batch 32)."""
+    import shadernn_amd as snn
+
+    net, w, h = _small_nets()[which]
+    x = np.random.default_rng(6).random((3, h, w, 3), dtype=np.float32)
+    r = snn.GraphRunner(ctx, net, 3, h, w)
+    y = r(x)
+    want = O.forward(net, x)
+    np.testing.assert_allclose(y.reshape(3, -1), want.reshape(3, -1), **TOL)

@@ -53,8 +53,10 @@ struct MfmaParams {
 // section LDS) is conflict-free iff its 16 pixels are distinct mod 16, which the row/image pitches guarantee.
 template <int C8>
 __device__ __forceinline__ int lds_off(int pl, int slot) {
-    if (C8 == 2) return (pl << 4) + ((slot ^ ((pl >> 2) & 3)) << 2);
-    return (pl << 3) + ((slot ^ ((pl >> 3) & 1)) << 2);
+    // Q = 2*C8 slots per pixel (2, 4, 8 or 16): slot ^ ((pl >> (4 - log2 Q)) & (Q-1)) makes (address / 16) mod 16 a bijection of pl mod 16
+    constexpr int Q = 2 * C8;
+    constexpr int LQ = Q == 2 ? 1 : Q == 4 ? 2 : Q == 8 ? 3 : 4;
+    return pl * (4 * Q) + ((slot ^ ((pl >> (4 - LQ)) & (Q - 1))) << 2);
 }
 
 template <int WM, int WN, int MT, int NT, int C8, int R, bool SIMPLE>
@@ -296,6 +298,9 @@ KernelFn pick_kernel(int c8, int r, bool simple) {
     SNNHIP_PICK(2, 3)
     SNNHIP_PICK(2, 5)
     SNNHIP_PICK(2, 9)
+    SNNHIP_PICK(4, 5)
+    SNNHIP_PICK(4, 9)
+    SNNHIP_PICK(8, 9)
 #undef SNNHIP_PICK
     return nullptr;
 }
@@ -316,7 +321,12 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED; // 32-bit element offsets in the kernel
 
     const int taps = g.kh * g.kw;
-    const int C8 = g.IC <= 8 ? 1 : 2;
+    // channels per LDS chunk: 16 (8 when IC <= 8).  Wider chunks (the kernel is instantiated up to 64 channels; SNNHIP_CONV_C8=4|8 selects
+    // them for pointwise stride-1 layers) were measured on the MobileNetV2 layers: fewer barriers per MFMA, but the 4x staging registers and
+    // LDS cost more residency than they save (1x1 960->320 @7x7 b32: 58.7 -> 51.7 us, 144->24 @56x56: 27.9 -> 45.3 us), so 16 stays the default
+    int C8 = g.IC <= 8 ? 1 : 2;
+    if (const char* e = getenv("SNNHIP_CONV_C8"))
+        if (taps == 1 && g.sh == 1 && g.sw == 1 && (atoi(e) == 4 || atoi(e) == 8) && g.IC >= 8 * atoi(e)) C8 = atoi(e);
     const int ICc = 8 * C8;
 
     if (g.sw < 1 || g.sw > 2 || g.sh < 1 || g.sh > 2) return SNNHIP_E_UNSUPPORTED;
@@ -369,7 +379,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.total = L.total;
     p.bufFloats = TB * L.imgPitch * ICc;
     const int rNeed = up_div(p.total, 256);
-    const int R = rNeed <= 3 ? 3 : (rNeed <= 5 ? 5 : 9);
+    const int R = (rNeed <= 3 && C8 <= 2) ? 3 : ((rNeed <= 5 && C8 <= 4) ? 5 : 9);
     const size_t ldsBytes = L.ldsBytes;
 
     // block N: minimise (rounds of blocks over the CUs) x (work per block); narrower blocks re-stage A more often

@@ -203,19 +203,19 @@ __global__ __launch_bounds__(256) void upsample_kernel(snnhip_upsample_desc d, i
 
 // ------------------------------------------------------------------------------------------------ instance norm
 // Statistics per (image, channel) over H*W, two passes like the shader (mean, then sum (x-mean)^2, biased).  Work split:
-// block = (image n, row slab s): 256 threads = 64 pixel lanes x 4 channel lanes sweep the slab for every group of 4*CV channels,
-// partial sums go to part[n][s][C]; the consumer kernel folds the S partials (S <= 64) itself.
-// stage 0: part = sum x      stage 1: part = sum (x - mean)^2 with mean from part0      stage 2: normalise + activation
+// block = (image n, row slab s): 256 threads = 64 pixel lanes x 4 channel lanes sweep the slab for every group of 4*CV channels
+// and write partial sums part[n][s][C]; a tiny fold kernel turns the S partials into stat[n][C] in a fixed order (deterministic).
+// launches: sum -> fold(mean) -> squares -> fold(multiplier, beta) -> normalise + activation
+// STAGE 0: part = sum x      STAGE 1: part = sum (x - mean)^2      STAGE 2: y = act((x - mean) * mul + beta)
 template <int STAGE, int CV>
 __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int rowsPerSlab, const float* __restrict__ x,
-                                                          const float* __restrict__ part0, const float* __restrict__ part1, const float* __restrict__ beta,
-                                                          const float* __restrict__ gamma, float* __restrict__ partOut, float* __restrict__ y) {
+                                                          const float* __restrict__ statMean, const float* __restrict__ statMul,
+                                                          const float* __restrict__ beta, float* __restrict__ partOut, float* __restrict__ y) {
     __shared__ float red[256 * CV];
     const int n = blockIdx.x / S, s = blockIdx.x % S;
     const int tid = threadIdx.x, cl = tid & 3, pl = tid >> 2; // channel lane, pixel lane
     const int r0 = s * rowsPerSlab, r1 = min(d.H, r0 + rowsPerSlab);
     const size_t p0 = static_cast<size_t>(r0) * d.W, p1 = static_cast<size_t>(r1) * d.W;
-    const float invHW = 1.0f / (static_cast<float>(d.H) * static_cast<float>(d.W));
     const float* xn = x + static_cast<size_t>(n) * d.H * d.W * d.C;
     for (int c0 = 0; c0 < d.C; c0 += 4 * CV) {
         const int c = c0 + cl * CV;
@@ -223,23 +223,9 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
         float mean[CV], mul[CV], bt[CV];
 #pragma unroll
         for (int k = 0; k < CV; ++k) {
-            mean[k] = 0.0f;
-            mul[k] = 0.0f;
-            bt[k] = 0.0f;
-        }
-        if (STAGE >= 1 && cok) {
-#pragma unroll
-            for (int k = 0; k < CV; ++k) {
-                float sm = 0.0f;
-                for (int j = 0; j < S; ++j) sm += part0[(static_cast<size_t>(n) * S + j) * d.C + c + k];
-                mean[k] = sm * invHW; // == sum / float(width*height) up to the rounding of the reciprocal; both are fp32 estimates
-                if (STAGE == 2) {
-                    float sv = 0.0f;
-                    for (int j = 0; j < S; ++j) sv += part1[(static_cast<size_t>(n) * S + j) * d.C + c + k];
-                    mul[k] = gamma[c + k] / sqrtf(sv * invHW + d.eps);
-                    bt[k] = beta[c + k];
-                }
-            }
+            mean[k] = (STAGE >= 1 && cok) ? statMean[static_cast<size_t>(n) * d.C + c + k] : 0.0f;
+            mul[k] = (STAGE == 2 && cok) ? statMul[static_cast<size_t>(n) * d.C + c + k] : 0.0f;
+            bt[k] = (STAGE == 2 && cok) ? beta[c + k] : 0.0f;
         }
         float acc[CV];
 #pragma unroll
@@ -290,6 +276,19 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
             }
         }
     }
+}
+
+// MODE 0: stat[n][c] = (sum_s part) / (H*W)            (the mean)
+// MODE 1: stat[n][c] = gamma[c] / sqrt((sum_s part) / (H*W) + eps)
+template <int MODE>
+__global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, int S, float invHW, float eps, const float* __restrict__ part,
+                                                               const float* __restrict__ gamma, float* __restrict__ stat) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NC) return;
+    const int n = i / C, c = i % C;
+    float sm = 0.0f;
+    for (int j = 0; j < S; ++j) sm += part[(static_cast<size_t>(n) * S + j) * C + c];
+    stat[i] = MODE == 0 ? sm * invHW : gamma[c] / sqrtf(sm * invHW + eps);
 }
 
 // ------------------------------------------------------------------------------------------------ plans
@@ -426,25 +425,32 @@ struct UpsamplePlan : snnhip_plan {
 struct InstanceNormPlan : snnhip_plan {
     snnhip_instancenorm_desc d;
     int S = 1, rowsPerSlab = 1;
-    float *d_beta = nullptr, *d_gamma = nullptr, *d_part0 = nullptr, *d_part1 = nullptr;
-    int numSteps() const override { return 1; }
+    float *d_beta = nullptr, *d_gamma = nullptr, *d_part = nullptr, *d_mean = nullptr, *d_mul = nullptr;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "instancenorm: expects 1 input, got %d", nIn);
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, d.H, d.W, d.C), "instancenorm: tensor dims do not match the plan");
         const dim3 g(static_cast<unsigned>(d.N * S));
-#define SNNHIP_IN(ST, CVV)                                                                                                                     \
-    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV>), g, dim3(256), 0, ctx->stream, d, S, rowsPerSlab, in[0]->data, d_part0, d_part1, d_beta, d_gamma, \
-                       ST == 0 ? d_part0 : d_part1, out->data)
+        const int NC = d.N * d.C;
+        const dim3 gf(static_cast<unsigned>((NC + 255) / 256));
+        const float invHW = 1.0f / (static_cast<float>(d.H) * static_cast<float>(d.W));
+#define SNNHIP_IN(ST, CVV) \
+    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV>), g, dim3(256), 0, ctx->stream, d, S, rowsPerSlab, in[0]->data, d_mean, d_mul, d_beta, d_part, out->data)
+#define SNNHIP_FOLD(M) hipLaunchKernelGGL((instancenorm_fold_kernel<M>), gf, dim3(256), 0, ctx->stream, NC, d.C, S, invHW, d.eps, d_part, d_gamma, M == 0 ? d_mean : d_mul)
         if ((d.C & 3) == 0) {
             SNNHIP_IN(0, 4);
+            SNNHIP_FOLD(0);
             SNNHIP_IN(1, 4);
+            SNNHIP_FOLD(1);
             SNNHIP_IN(2, 4);
         } else {
             SNNHIP_IN(0, 1);
+            SNNHIP_FOLD(0);
             SNNHIP_IN(1, 1);
+            SNNHIP_FOLD(1);
             SNNHIP_IN(2, 1);
         }
 #undef SNNHIP_IN
+#undef SNNHIP_FOLD
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -578,10 +584,9 @@ int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_d
     auto* plan = new InstanceNormPlan();
     plan->ctx = ctx;
     plan->d = *desc;
-    // row slabs: enough blocks to cover the chip a few times, at most 64 partials per image
+    // row slabs: enough blocks to cover the chip about 8 times (HBM-bound sweeps want many waves in flight)
     const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
-    int S = (4 * cus + desc->N - 1) / desc->N;
-    if (S > 64) S = 64;
+    int S = (8 * cus + desc->N - 1) / desc->N;
     if (S > desc->H) S = desc->H;
     if (S < 1) S = 1;
     plan->rowsPerSlab = (desc->H + S - 1) / S;
@@ -589,8 +594,9 @@ int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_d
     int rc = plan->upload(beta, desc->C, &plan->d_beta);
     if (rc == SNNHIP_OK) rc = plan->upload(gamma, desc->C, &plan->d_gamma);
     std::vector<float> zeros(static_cast<size_t>(desc->N) * plan->S * desc->C, 0.0f);
-    if (rc == SNNHIP_OK) rc = plan->upload(zeros.data(), zeros.size(), &plan->d_part0);
-    if (rc == SNNHIP_OK) rc = plan->upload(zeros.data(), zeros.size(), &plan->d_part1);
+    if (rc == SNNHIP_OK) rc = plan->upload(zeros.data(), zeros.size(), &plan->d_part);
+    if (rc == SNNHIP_OK) rc = plan->upload(zeros.data(), static_cast<size_t>(desc->N) * desc->C, &plan->d_mean);
+    if (rc == SNNHIP_OK) rc = plan->upload(zeros.data(), static_cast<size_t>(desc->N) * desc->C, &plan->d_mul);
     if (rc != SNNHIP_OK) {
         delete plan;
         return rc;
@@ -601,7 +607,7 @@ int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_d
     plan->flops = cnt * 7;
     plan->bytes = 4.0 * cnt * 2; // algorithmic: read once, write once (the two-pass statistics re-read the tensor: 4x in practice)
     char buf[160];
-    snprintf(buf, sizeof(buf), "instancenorm_f32 %dx%dx%dx%d act=%d slabs=%d (3 launches)", desc->N, desc->H, desc->W, desc->C, desc->act, plan->S);
+    snprintf(buf, sizeof(buf), "instancenorm_f32 %dx%dx%dx%d act=%d slabs=%d (3 sweeps + 2 folds)", desc->N, desc->H, desc->W, desc->C, desc->act, plan->S);
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""bench_models.py -- whole-model throughput of BASELINE configs 3-5 shapes on one MI355X through per-layer C-ABI plans:
+ResNet-18 224x224 batch 32 (config 3), MobileNetV2 224x224 batch 32 (= the per-GPU share of config 4's batch 256 / 8 GPUs) and
+the toy style net at 720p batch 1 (the operator set of config 5, fp32).  Synthetic weights of the real topologies (models.py).
+Prints images/s, achieved TFLOP/s and GB/s on the algorithmic (per-layer, unfused) accounting, and the slowest layers.
+
+    python tools/bench_models.py [--reps 20] [--model resnet18|mobilenetv2|style] [--batch N] [--json out.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PEAK_TF, PEAK_GBS = 157.3, 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    import shadernn_amd as snn
+    from shadernn_amd import models
+
+    snn.load_library()
+    ctx = snn.Context(0)
+    cases = [("resnet18", lambda: models.resnet18(seed=1), 32, 224, 224), ("mobilenetv2", lambda: models.mobilenetv2(seed=1), 32, 224, 224),
+             ("style", lambda: models.style_net(seed=1, width=32), 1, 720, 1280)]
+    out = []
+    for name, make, batch, h, w in cases:
+        if args.model and args.model != name:
+            continue
+        batch = args.batch or batch
+        net = make()
+        r = snn.GraphRunner(ctx, net, batch, h, w)
+        r.x.upload(np.random.default_rng(1).random(r.in_shape, dtype=np.float32))
+        for _ in range(3):
+            r.run_device()
+        ctx.sync()
+        t = snn.Timer(ctx)
+        t.start()
+        for _ in range(args.reps):
+            r.run_device()
+        t.stop()
+        ctx.sync()
+        ms = t.elapsed_ms() / args.reps
+        # per-layer times: one timed loop per plan
+        rows = []
+        for plan, ins, o, layer in r.steps:
+            t.start()
+            for _ in range(5):
+                plan.run(ins if len(ins) > 1 else ins[0], o)
+            t.stop()
+            ctx.sync()
+            f, b = plan.cost()
+            rows.append((t.elapsed_ms() / 5 * 1e3, layer["name"], f, b, plan.describe()))
+        fl, by = r.cost()
+        res = {"model": name, "batch": batch, "input": [batch, h, w, 3], "ms_per_batch": ms, "images_per_s": batch / ms * 1e3, "gflop_per_image": fl / batch / 1e9,
+               "mb_per_image_unfused": by / batch / 1e6, "tflops": fl / ms / 1e9, "gbps_unfused": by / ms / 1e6,
+               "roofline_ms": max(fl / PEAK_TF / 1e9, by / PEAK_GBS / 1e6), "layers": len(r.steps)}
+        res["frac_of_roofline"] = res["roofline_ms"] / ms
+        print("%-12s batch %3d: %8.2f ms/batch  %9.1f images/s  %6.2f TFLOP/s  %7.1f GB/s (unfused accounting)  roofline %.2f ms -> %.1f%%  (%d launches)" %
+              (name, batch, ms, res["images_per_s"], res["tflops"], res["gbps_unfused"], res["roofline_ms"], 100 * res["frac_of_roofline"], len(r.steps)), flush=True)
+        rows.sort(reverse=True)
+        tot = sum(x[0] for x in rows)
+        for us, lname, f, b, desc in rows[:8]:
+            print("     %8.1f us %5.1f%%  %-16s %6.2f TF/s %7.1f GB/s | %s" % (us, 100 * us / tot, lname, f / us / 1e6, b / us / 1e3, desc[:110]))
+        res["top_layers"] = [{"us": us, "layer": lname, "kernel": desc} for us, lname, f, b, desc in rows[:8]]
+        out.append(res)
+    if args.json:
+        json.dump(out, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

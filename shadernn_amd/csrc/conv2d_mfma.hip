@@ -45,6 +45,8 @@ struct MfmaParams {
     int OCp;             // OC padded to a multiple of the block's BN
     int total;           // float4 elements staged per chunk
     int bufFloats;       // floats per LDS buffer
+    int splitK;          // > 1: blockIdx.z owns chunks [z*chunksPerSplit, ...) and stores raw partial sums to the workspace
+    int chunksPerSplit;
 };
 
 // LDS layout of the staged activations.  A pixel owns ICc floats = ICc/4 16-byte slots; the slot is XOR-swizzled with
@@ -137,8 +139,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
         apix[t] = b * p.imgPitch + py * p.sh * p.rowPitch + (p.evenCols ? px : px * p.sw); // sw==2: column 2px+fx -> plane (fx&1), index px+(fx>>1)
     }
     const int n0 = blockIdx.y * BN + wn * (NT * 32);
-    const float* bptr = wp + (static_cast<size_t>(h) * p.OCp + n0 + l32) * 4;
     const size_t bstep = static_cast<size_t>(2) * p.OCp * 4;
+    const int chunk0 = blockIdx.z * p.chunksPerSplit, chunk1 = min(p.nChunks, chunk0 + p.chunksPerSplit);
+    const float* bptr = wp + (static_cast<size_t>(h) * p.OCp + n0 + l32) * 4 + static_cast<size_t>(chunk0) * taps * C8 * bstep;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -157,13 +160,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
         bptr += bstep;
     }
 
-    stage_load(0);
-    stage_store(smem);
+    stage_load(chunk0 * 8 * C8);
+    stage_store(smem + (chunk0 & 1) * p.bufFloats);
     __syncthreads();
 
-    for (int chunk = 0; chunk < p.nChunks; ++chunk) {
+    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         const float* cur = smem + (chunk & 1) * p.bufFloats;
-        const bool more = chunk + 1 < p.nChunks;
+        const bool more = chunk + 1 < chunk1;
         if (more) stage_load((chunk + 1) * 8 * C8);
 
         float4 an[MT];
@@ -245,6 +248,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                 const int oc = n0 + u * 32 + l32;
                 const float4 e = epi[oc]; // table padded to OCp
                 const bool ok = rowOk && oc < p.OC;
+                if (p.splitK > 1) { // y is the workspace [splitK][N*OH*OW][OC]: raw partial sums, epilogue in splitk_reduce_kernel
+                    float* ws = y + static_cast<size_t>(blockIdx.z) * p.N * p.OH * p.OW * p.OC;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (ok && ox + k < p.OW) ws[pofs + k * p.OC + oc] = acc[t][u][4 * g + k];
+                    continue;
+                }
                 float first = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -263,7 +273,20 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
     }
 }
 
+// split-K second pass: y[m][oc] = act(BN(bias + sum_z ws[z][m][oc])), summed in a fixed order (deterministic)
+template <bool SIMPLE>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(size_t MN, int OC, int splitK, int useBN, ActCfg ac, const float* __restrict__ ws,
+                                                           const float4* __restrict__ epi, float* __restrict__ y) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < MN; i += static_cast<size_t>(gridDim.x) * 256) {
+        float v = 0.0f;
+        for (int z = 0; z < splitK; ++z) v += ws[static_cast<size_t>(z) * MN + i];
+        v = epi_affine(v, epi[i % OC], useBN);
+        y[i] = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+    }
+}
+
 struct MfmaConvPlan : ConvPlanBase {
+    float* d_ws = nullptr; // split-K workspace
     MfmaParams p;
     ActCfg ac;
     float* d_w = nullptr;
@@ -279,7 +302,20 @@ struct MfmaConvPlan : ConvPlanBase {
                        x->n, x->h, x->w, x->c, p.N, p.H, p.W, p.IC);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
                        out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
-        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, x->data, d_w, reinterpret_cast<const float4*>(d_epi), out->data);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, x->data, d_w, reinterpret_cast<const float4*>(d_epi),
+                           p.splitK > 1 ? d_ws : out->data);
+        if (p.splitK > 1) {
+            const size_t MN = out->count();
+            size_t blocks = (MN + 255) / 256;
+            const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) * 8;
+            if (blocks > cap) blocks = cap;
+            if (act_is_simple(ac.act))
+                hipLaunchKernelGGL((splitk_reduce_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac,
+                                   d_ws, reinterpret_cast<const float4*>(d_epi), out->data);
+            else
+                hipLaunchKernelGGL((splitk_reduce_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac,
+                                   d_ws, reinterpret_cast<const float4*>(d_epi), out->data);
+        }
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -400,6 +436,23 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         }
     }
     p.OCp = round_up(g.OC, BN);
+    // split-K: deep-K layers with few output tiles (ResNet 14x14 / 7x7 stages at batch 32, MobileNetV2's last pointwise convs) leave most
+    // CUs with at most one wave per SIMD; splitting the channel chunks over blockIdx.z gives every SIMD 2+ waves.  Partial sums go to a
+    // workspace and a second (element-wise, deterministic) pass applies bias/BN/activation.  SNNHIP_CONV_SPLITK=n forces n (1 = off).
+    p.splitK = 1;
+    {
+        const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+        const double blocks = static_cast<double>(p.tilesX) * p.tilesY * up_div(g.N, TB) * (p.OCp / BN);
+        int want = 1;
+        if (blocks < 1.5 * cus && p.nChunks >= 8) want = static_cast<int>(std::ceil(2.0 * cus / blocks));
+        if (want > 8) want = 8;
+        if (want > p.nChunks / 4) want = p.nChunks / 4;
+        if (const char* e = getenv("SNNHIP_CONV_SPLITK")) want = atoi(e);
+        if (want < 1 || g.act == SNNHIP_ACT_SILU_QUIRK) want = 1; // the quirk couples 4 adjacent pixels in the epilogue
+        if (want > p.nChunks) want = p.nChunks;
+        p.chunksPerSplit = up_div(p.nChunks, want);
+        p.splitK = up_div(p.nChunks, p.chunksPerSplit);
+    }
     const bool simple = act_is_simple(g.act);
     KernelFn fn = nullptr;
     if (BN == 128) fn = pick_kernel<2, 2, 2, 2>(C8, R, simple);
@@ -416,7 +469,18 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->ac = make_act_cfg(g.act, g.leaky);
     plan->kernel = fn;
     plan->ldsBytes = ldsBytes;
-    plan->grid = dim3(p.tilesX * p.tilesY * up_div(g.N, TB), p.OCp / BN, 1);
+    plan->grid = dim3(p.tilesX * p.tilesY * up_div(g.N, TB), p.OCp / BN, p.splitK);
+    if (p.splitK > 1) {
+        void* ws = nullptr;
+        const size_t wsBytes = static_cast<size_t>(p.splitK) * g.N * g.OH * g.OW * g.OC * sizeof(float);
+        if (hipMalloc(&ws, wsBytes) != hipSuccess) {
+            set_error("conv2d_mfma: split-K workspace of %zu bytes", wsBytes);
+            delete plan;
+            return SNNHIP_E_HIP;
+        }
+        plan->deviceAllocs.push_back(ws);
+        plan->d_ws = static_cast<float*>(ws);
+    }
     if (ldsBytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsBytes));
         if (e != hipSuccess) {
@@ -453,8 +517,8 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC +
                          static_cast<double>(g.OC) * g.IC * taps);
     char buf[256];
-    snprintf(buf, sizeof(buf), "conv2d_mfma_f32_32x32x2 k=%dx%d s=%d ic=%d oc=%d tile=%dx%dx%dpx x %doc chunk=%d lds=%zuB", g.kh, g.kw, g.sh, g.IC,
-             g.OC, TB, TH, TW, BN, ICc, ldsBytes);
+    snprintf(buf, sizeof(buf), "conv2d_mfma_f32_32x32x2 k=%dx%d s=%d ic=%d oc=%d tile=%dx%dx%dpx x %doc chunk=%d lds=%zuB splitK=%d", g.kh, g.kw, g.sh,
+             g.IC, g.OC, TB, TH, TW, BN, ICc, ldsBytes, p.splitK);
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

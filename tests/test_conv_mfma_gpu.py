@@ -117,3 +117,26 @@ def test_mfma_conv_linearity_at_scale(ctx, force):
     want = O.conv2d(x1[17:18, 18:30], w, None, 1, (1, 1, 1, 1), "constant", "")
     np.testing.assert_allclose(y1[17:18, 20:28], want[:, 2:10], **TOL)
     plan.destroy()
+
+
+@pytest.mark.parametrize("case,split", [((5, 7, 7, 512, 512, 3, 1), None), ((2, 14, 14, 256, 256, 3, 1), None), ((2, 9, 11, 80, 33, 3, 1), "3"),
+                                        ((1, 7, 7, 320, 1280, 1, 1), "4"), ((2, 28, 28, 64, 128, 3, 2), "2")])
+def test_mfma_conv_split_k(ctx, force, monkeypatch, case, split):
+    """Split-K (deep K, few output tiles): partial sums + deterministic reduce pass give the same result as the oracle; the default
+    heuristic turns it on for the ResNet 7x7 / 14x14 stages."""
+    N, H, W, IC, OC, k, s = case
+    if split is not None:
+        monkeypatch.setenv("SNNHIP_CONV_SPLITK", split)
+    x = _rand((N, H, W, IC), 61)
+    w = _rand((OC, IC, k, k), 62, 1.0 / np.sqrt(IC * k * k))
+    b = _rand((OC,), 63, 0.1)
+    bn = _bn(OC, 64)
+    pads = O.padding_offsets("same", k)
+    force("mfma")
+    for act in ("relu", "tanh"):
+        y, desc = run_conv(ctx, x, w, b, s, pads, "constant", act, 0.0, bn)
+        assert "splitK=1" not in desc, desc
+        want = O.conv2d(x, w, b, s, pads, "constant", act, 0.0, bn)
+        np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
+    y2, _ = run_conv(ctx, x, w, b, s, pads, "constant", "tanh", 0.0, bn)
+    np.testing.assert_array_equal(y, y2)  # deterministic

@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="one kernel per layer (debug / comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with events (overhead check)")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the kernel launches of every Nth timed step with HIP events (each pair costs ~4.5 us of stream time)")
     args = ap.parse_args()
 

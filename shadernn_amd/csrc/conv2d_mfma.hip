@@ -351,7 +351,9 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     const bool forced = force && strcmp(force, "mfma") == 0;
     // measured (tools/bench_layers.py): even IC = 3 layers (one 8-channel chunk, 5/8 of it padding) run 1.4-2.3x faster here than
     // on the VALU kernel, so only the channel-thin outputs (OC < 16: most of a 32-wide MFMA column block would be padding) stay there
-    if (!forced && g.OC < 16) return SNNHIP_E_UNSUPPORTED;
+    // and the 16-wide thin layers (OC < 32 with IC < 32, e.g. ESPCN's 16->16: half of the narrowest 32-wide block is padding) measured
+    // faster there too (241 vs 276 us at 1080p)
+    if (!forced && (g.OC < 16 || (g.OC < 32 && g.IC < 32))) return SNNHIP_E_UNSUPPORTED;
     const double inCount = static_cast<double>(g.N) * g.H * g.W * g.IC;
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED; // 32-bit element offsets in the kernel

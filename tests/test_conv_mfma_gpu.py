@@ -81,9 +81,10 @@ def test_mfma_conv_padding_modes_activations(ctx, force, pad_mode, act):
 
 
 def test_default_routing(ctx, force):
-    """Layers with >= 16 output channels go to the MFMA kernel (even IC = 3: measured faster), channel-thin outputs to the VALU kernel."""
+    """Layers with >= 32 output channels (or >= 16 with >= 32 input channels) go to the MFMA kernel, even IC = 3 (measured faster);
+    channel-thin ones to the VALU kernel."""
     force(None)
-    for (ic, oc, want) in [(64, 64, "mfma"), (3, 64, "mfma"), (16, 4, "generic"), (128, 1, "generic"), (8, 16, "mfma")]:
+    for (ic, oc, want) in [(64, 64, "mfma"), (3, 64, "mfma"), (16, 4, "generic"), (128, 1, "generic"), (16, 16, "generic"), (64, 16, "mfma"), (8, 32, "mfma")]:
         x = _rand((1, 8, 8, ic), 1)
         w = _rand((oc, ic, 3, 3), 2, 0.1)
         _, desc = run_conv(ctx, x, w, None, 1, (1, 1, 1, 1), "constant", "relu", 0.0, None)

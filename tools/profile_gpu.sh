@@ -8,7 +8,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH=${PROF_CMD:-"python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline $*"}
+BENCH=${PROF_CMD:-"python $REPO/bench.py --no-cpu-baseline $*"}   # same steps/warmup as the default bench line
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $OUT/pmc_sq --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY -- $BENCH > $OUT/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $OUT/pmc_sq2 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- $BENCH > $OUT/pmc_sq2.log 2>&1

@@ -70,6 +70,37 @@ float timeBW(const float* x, const float* w, const float* e, float* y, int H, in
     return 1e3f * ms / reps;
 }
 
+// two-stream experiment: kernel A of image i+1 next to kernel B of image i (no dependency here: upper bound of what cross-step
+// pipelining could give)
+template <int BTW, int BTH>
+float timeOverlap(const float* x, const float* w, float* mid, float* mid2, float* y, int H, int W, int reps, bool twoStreams) {
+    FusedAParams pa{1, H, W, (W + WinoTile::TW - 1) / WinoTile::TW, (H + 15) / 16, make_act_cfg(1, 0.f), make_act_cfg(1, 0.f)};
+    FusedBParams pb{1, H, W, (W + BTW - 1) / BTW, (H + BTH - 1) / BTH, make_act_cfg(0, 0.f)};
+    hipStream_t s1, s2;
+    CK(hipStreamCreate(&s1));
+    CK(hipStreamCreate(&s2));
+    hipEvent_t a, b, e2;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    CK(hipEventCreate(&e2));
+    auto once = [&](int i) {
+        hipLaunchKernelGGL((conv_kxk_c1o16_wino3x3_c16o16_kernel<5, 16, 2, 2>), dim3(512), dim3(256), 0, s1, pa, x, w, w, w, w, (i & 1) ? mid2 : mid);
+        hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_kernel<BTW, BTH, true>), dim3(pb.tilesX * pb.tilesY), dim3(256), 0, twoStreams ? s2 : s1, pb,
+                           (i & 1) ? mid : mid2, w, w, y);
+    };
+    for (int i = 0; i < 6; ++i) once(i);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, s1));
+    for (int i = 0; i < reps; ++i) once(i);
+    CK(hipEventRecord(e2, s2));
+    CK(hipStreamWaitEvent(s1, e2, 0));
+    CK(hipEventRecord(b, s1));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return 1e3f * ms / reps;
+}
+
 template <int K1, int WTH, int WWPS>
 float timeW(const float* x, const float* w1, const float* w2, const float* e1, const float* e2, float* y, int H, int W, int reps) {
     FusedAParams p{1, H, W, (W + WinoTile::TW - 1) / WinoTile::TW, (H + WTH - 1) / WTH, make_act_cfg(1, 0.f), make_act_cfg(1, 0.f)};
@@ -218,6 +249,13 @@ int main() {
 #ifdef TUNE_VARIANTS
     TUNE_VARIANTS
 #else
+    {
+        float* mid2;
+        CK(hipMalloc(&mid2, (size_t) H * W * 16 * 4));
+        CK(hipMemset(mid2, 0, (size_t) H * W * 16 * 4));
+        printf("A+B one stream  %.1f us/step\n", timeOverlap<32, 8>(x, w, mid, mid2, y, H, W, R, false));
+        printf("A|B two streams %.1f us/step\n", timeOverlap<32, 8>(x, w, mid, mid2, y, H, W, R, true));
+    }
     printf("W<5> wino  %.1f us\n", timeW<5, 16, 2>(x, w, w, w, w, mid, H, W, R));
     printf("W<5,8,3> wino  %.1f us\n", timeW<5, 8, 3>(x, w, w, w, w, mid, H, W, R));
     printf("A<5,64,8,U3,W3>  %.1f us\n", timeA<5, 64, 8, 3, 3>(x, w, w, w, w, mid, H, W, R));

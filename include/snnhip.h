@@ -178,6 +178,8 @@ typedef struct {
     int act;      /* SNNHIP_ACT_* (0..6; the quirk id 7 is conv-only) */
     float leaky;
 } snnhip_eltwise_desc;
+/* Add: desc = OUTPUT dims = max over the two inputs (genericlayer.cpp:64-90).  Inputs smaller than that are accepted at run time with the
+ * reference's semantics: the sum is evaluated over the first input's extent, the second input reads 0 outside its own (vk_add.comp:47-49) */
 int snnhip_add_plan_create(snnhip_ctx* ctx, const snnhip_eltwise_desc* desc, snnhip_plan** out);
 int snnhip_activation_plan_create(snnhip_ctx* ctx, const snnhip_eltwise_desc* desc, snnhip_plan** out);
 /* y = act(gamma / max(sqrt(var + 1e-3), 1e-4) * (x - mean) + beta), per channel (vk_batchnorm.comp:63-68) */

@@ -587,6 +587,22 @@ void snn_oracle_add_act(const float* a, const float* b, long count, int act, flo
     }
 }
 
+void snn_oracle_add_ragged(const float* a, int H0, int W0, const float* b, int H1, int W1, int N, int C, int act, float leaky, float* y) {
+    int H = H0 > H1 ? H0 : H1, W = W0 > W1 ? W0 : W1;
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < H; ++oy)
+            for (int ox = 0; ox < W; ++ox)
+                for (int c = 0; c < C; ++c) {
+                    float v = 0.0f;
+                    if (oy < H0 && ox < W0) { /* all(lessThan(pos, inSize)), inSize = first input */
+                        v = a[(((long) n * H0 + oy) * W0 + ox) * C + c];
+                        if (oy < H1 && ox < W1) v = v + b[(((long) n * H1 + oy) * W1 + ox) * C + c];
+                        v = act_apply(act, leaky, v, 0.0f);
+                    }
+                    y[(((long) n * H + oy) * W + ox) * C + c] = v;
+                }
+}
+
 /* shadertemplate_vk_batchnorm.comp:61-68 */
 void snn_oracle_batchnorm(const float* x, long pixels, int C, const float* beta, const float* gamma, const float* mean, const float* var, int act,
                           float leaky, float* y) {

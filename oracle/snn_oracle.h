@@ -153,6 +153,10 @@ void snn_oracle_subpixel_nhwc(const float* x, int N, int H, int W, int C, int fa
 
 /* vk_add.comp:41-88 / vk_activation.comp:41-86: y = act(a + b) (b may be NULL: y = act(a)) */
 void snn_oracle_add_act(const float* a, const float* b, long count, int act, float leaky, float* y);
+/* Add with inputs of different extent: output H x W = max over the inputs (genericlayer.cpp:64-90); the shader runs over the first
+ * input's extent only and fetches of the second input outside its texture return 0 (addlayerVulkan.cpp:44-46, vk_add.comp:47-49);
+ * the rest of the output texture is never written by the reference -- zeros here */
+void snn_oracle_add_ragged(const float* a, int H0, int W0, const float* b, int H1, int W1, int N, int C, int act, float leaky, float* y);
 /* vk_batchnorm.comp:54-104: y = act(gamma / max(sqrt(var + 1e-3), 1e-4) * (x - mean) + beta), channel = index % C */
 void snn_oracle_batchnorm(const float* x, long pixels, int C, const float* beta, const float* gamma, const float* mean, const float* var, int act,
                           float leaky, float* y);

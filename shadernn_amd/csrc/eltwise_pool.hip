@@ -54,6 +54,41 @@ __global__ __launch_bounds__(256) void eltwise_kernel(size_t count, int C, int a
     }
 }
 
+// Add with inputs of different spatial size (same N, C).  The reference sizes the output as the MAX over its inputs
+// (genericlayer.cpp:64-90) but dispatches the sum only over the FIRST input's extent, and the second input's out-of-range fetches
+// return 0 (addlayerVulkan.cpp:44-46,89-91; vk_add.comp:47-49).  Candy's residual blocks rely on this: a Pad + "valid" conv branch is
+// 4 pixels larger than its skip under the reference's size rule.  Outside the first input's extent the reference leaves
+// the texture untouched (undefined); zeros are written here.
+template <int CV>
+__global__ __launch_bounds__(256) void add_ragged_kernel(int N, int H, int W, int C, int H0, int W0, int H1, int W1, int act, float leaky,
+                                                        const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y) {
+    const int cg = C / CV;
+    const size_t total = static_cast<size_t>(N) * H * W * cg;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+        const int c = static_cast<int>(i % cg) * CV;
+        size_t r = i / cg;
+        const int ox = static_cast<int>(r % W);
+        r /= W;
+        const int oy = static_cast<int>(r % H);
+        const int n = static_cast<int>(r / H);
+        const bool in0 = oy < H0 && ox < W0, in1 = oy < H1 && ox < W1;
+        float v[CV];
+#pragma unroll
+        for (int k = 0; k < CV; ++k) {
+            float s = 0.0f;
+            if (in0) {
+                s = a[((static_cast<size_t>(n) * H0 + oy) * W0 + ox) * C + c + k];
+                if (in1) s += b[((static_cast<size_t>(n) * H1 + oy) * W1 + ox) * C + c + k];
+                s = act1(act, leaky, s);
+            }
+            v[k] = s;
+        }
+        float* dst = y + ((static_cast<size_t>(n) * H + oy) * W + ox) * C + c;
+#pragma unroll
+        for (int k = 0; k < CV; ++k) dst[k] = v[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ pooling
 // one thread = one output pixel x CV channels; window clipped to the image exactly as the shader does
 template <int TYPE, int CV>
@@ -308,6 +343,23 @@ struct EltwisePlan : snnhip_plan {
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         const int want = mode == 0 ? 2 : 1;
         SNNHIP_REQUIRE(nIn == want, "%s: expects %d input(s), got %d", desc.c_str(), want, nIn);
+        if (mode == 0 && !(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(in[1], d.N, d.H, d.W, d.C))) {
+            // inputs of different extent: output = the plan's dims = max over the inputs (see add_ragged_kernel)
+            for (int i = 0; i < 2; ++i)
+                SNNHIP_REQUIRE(in[i]->n == d.N && in[i]->c == d.C && in[i]->h <= d.H && in[i]->w <= d.W, "%s: input %d dims %dx%dx%dx%d do not fit %dx%dx%dx%d",
+                               desc.c_str(), i, in[i]->n, in[i]->h, in[i]->w, in[i]->c, d.N, d.H, d.W, d.C);
+            SNNHIP_REQUIRE(dims_match(out, d.N, d.H, d.W, d.C), "%s: output dims mismatch", desc.c_str());
+            const bool v4 = (d.C & 3) == 0;
+            const unsigned gg = grid_for(ctx, out->count() / (v4 ? 4 : 1));
+            if (v4)
+                hipLaunchKernelGGL((add_ragged_kernel<4>), dim3(gg), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, in[0]->h, in[0]->w, in[1]->h, in[1]->w, d.act,
+                                   d.leaky, in[0]->data, in[1]->data, out->data);
+            else
+                hipLaunchKernelGGL((add_ragged_kernel<1>), dim3(gg), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, in[0]->h, in[0]->w, in[1]->h, in[1]->w, d.act,
+                                   d.leaky, in[0]->data, in[1]->data, out->data);
+            SNNHIP_CHECK_HIP(hipGetLastError());
+            return SNNHIP_OK;
+        }
         for (int i = 0; i < nIn; ++i)
             SNNHIP_REQUIRE(dims_match(in[i], d.N, d.H, d.W, d.C), "%s: input %d dims %dx%dx%dx%d != plan %dx%dx%dx%d", desc.c_str(), i, in[i]->n, in[i]->h,
                            in[i]->w, in[i]->c, d.N, d.H, d.W, d.C);

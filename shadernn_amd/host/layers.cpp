@@ -376,7 +376,11 @@ InferencePassesSptr AddLayerHip::createCS(const LayerGenOptions&) const { // add
     auto ret = std::make_shared<InferencePasses>();
     ret->passes.resize(1);
     SNN_CHK(inputDims.size() == 2);
-    const snnhip_eltwise_desc d = eltwiseDesc(inputDims[0], _desc.activation, _desc.leakyReluAlpha);
+    snnhip_eltwise_desc d = eltwiseDesc(inputDims[0], _desc.activation, _desc.leakyReluAlpha);
+    uint32_t ow = 0, oh = 0, od = 0;
+    GenericModelLayer::getOutputDims(ow, oh, od); // max over the inputs (addlayerVulkan.cpp:48-52); the plan handles smaller inputs
+    d.W = static_cast<int>(ow);
+    d.H = static_cast<int>(oh);
     ret->passes[0].source = formatString("Add act=%s", _desc.activation.c_str());
     ret->passes[0].createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_add_plan_create(ctx, &d, out); };
     return ret;

@@ -113,6 +113,8 @@ class GraphRunner:
         self.steps = []  # (plan, [input tensors], output tensor, layer)
         for layer, ins in models.producers(net):
             shape = shapes[ins[0]]
+            if layer["type"] == "Add":  # output extent = max over the inputs (genericlayer.cpp:64-90)
+                shape = (shape[0], max(shapes[i][1] for i in ins), max(shapes[i][2] for i in ins), shape[3])
             if layer["type"] == "Dense":  # consumes the flattened producer
                 shape = (shape[0], 1, 1, shape[1] * shape[2] * shape[3])
             plan = _layer_plan(ctx, layer, shape)

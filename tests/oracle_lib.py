@@ -184,7 +184,11 @@ def subpixel(x, factor=2, mode=0):
 def add_act(a, b=None, act="", leaky=0.0):
     a = _f(a)
     b = _f(b)
-    assert b is None or b.shape == a.shape, (a.shape, b.shape)
+    if b is not None and b.shape != a.shape:  # the reference's max-extent Add (see snn_oracle_add_ragged)
+        assert a.ndim == 4 and a.shape[0] == b.shape[0] and a.shape[3] == b.shape[3], (a.shape, b.shape)
+        y = np.empty((a.shape[0], max(a.shape[1], b.shape[1]), max(a.shape[2], b.shape[2]), a.shape[3]), np.float32)
+        lib().snn_oracle_add_ragged(_p(a), a.shape[1], a.shape[2], _p(b), b.shape[1], b.shape[2], a.shape[0], a.shape[3], ACT[act], C.c_float(leaky), _p(y))
+        return y
     y = np.empty_like(a)
     lib().snn_oracle_add_act(_p(a), _p(b), C.c_long(a.size), ACT[act], C.c_float(leaky), _p(y))
     return y

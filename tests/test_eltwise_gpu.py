@@ -118,3 +118,23 @@ def test_input_count_is_checked(ctx):
     t = snn.Tensor.from_numpy(ctx, np.zeros((1, 4, 4, 4), np.float32))
     with pytest.raises(snn.SnnHipError):
         p(t)
+
+
+@pytest.mark.parametrize("s0,s1", [((2, 9, 11, 8), (2, 5, 7, 8)), ((1, 5, 7, 3), (1, 9, 11, 3)), ((1, 6, 9, 4), (1, 8, 5, 4))])
+def test_add_with_different_extents(ctx, s0, s1):
+    """Output = max extent; the sum runs over the first input's extent, the second reads 0 outside its own (vk_add.comp:47-49)."""
+    import shadernn_amd as snn
+
+    a, b = _rand(s0, 21), _rand(s1, 22)
+    H, W = max(s0[1], s1[1]), max(s0[2], s1[2])
+    y, desc = _run(ctx, snn.add_plan(ctx, s0[0], H, W, s0[3], act="relu"), a, b)
+    want = O.add_act(a, b, "relu")
+    assert y.shape == want.shape == (s0[0], H, W, s0[3])
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
+    ref = np.zeros_like(want)
+    ref[:, : s0[1], : s0[2]] = a
+    ref[:, : min(s0[1], s1[1]), : min(s0[2], s1[2])] += b[:, : min(s0[1], s1[1]), : min(s0[2], s1[2])]
+    ref[:, : s0[1], : s0[2]] = np.maximum(ref[:, : s0[1], : s0[2]], 0)
+    ref[:, s0[1]:, :] = 0
+    ref[:, :, s0[2]:] = 0
+    np.testing.assert_allclose(want, ref, rtol=1e-6, atol=1e-6)

@@ -258,6 +258,18 @@ int snnhip_timer_stop(snnhip_timer* t);
 int snnhip_timer_elapsed_ms(snnhip_timer* t, float* ms); /* waits for the stop event */
 int snnhip_timer_destroy(snnhip_timer* t);
 
+/* ---- launch graphs ------------------------------------------------------------------------------------
+ * The reference records one command buffer per inference and replays it (vulkanBackend.cpp:80-106: prepareRun records, sync submits).
+ * The HIP counterpart is a captured hipGraph: every snnhip_plan_run* between begin and end is recorded instead of executed (plans must
+ * be run with the same tensors they will be replayed on; profiling must be off), and snnhip_graph_launch replays the whole sequence with
+ * one host call -- what a 65-kernel MobileNetV2 or a 54-kernel Candy inference needs to stop being launch-bound. */
+typedef struct snnhip_graph snnhip_graph;
+int snnhip_graph_begin_capture(snnhip_ctx* ctx);
+int snnhip_graph_end_capture(snnhip_ctx* ctx, snnhip_graph** out);
+int snnhip_graph_launch(snnhip_graph* g); /* enqueues on the context stream */
+int snnhip_graph_num_nodes(const snnhip_graph* g);
+int snnhip_graph_destroy(snnhip_graph* g);
+
 #ifdef __cplusplus
 }
 #endif

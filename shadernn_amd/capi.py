@@ -110,6 +110,11 @@ SIGNATURES = {
     "snnhip_plan_step_cost": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "snnhip_plan_profile_enable": (C.c_int, [_P, C.c_int]),
     "snnhip_plan_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "snnhip_graph_begin_capture": (C.c_int, [_P]),
+    "snnhip_graph_end_capture": (C.c_int, [_P, C.POINTER(_P)]),
+    "snnhip_graph_launch": (C.c_int, [_P]),
+    "snnhip_graph_num_nodes": (C.c_int, [_P]),
+    "snnhip_graph_destroy": (C.c_int, [_P]),
     "snnhip_timer_create": (C.c_int, [_P, C.POINTER(_P)]),
     "snnhip_timer_start": (C.c_int, [_P]),
     "snnhip_timer_stop": (C.c_int, [_P]),
@@ -444,6 +449,42 @@ def chain_plan(ctx, plans):
     h = _P()
     check(lib().snnhip_chain_plan_create(ctx.h, arr, len(plans), C.byref(h)))
     return Plan(ctx, h, keep=tuple(plans))
+
+
+class Graph:
+    """A captured launch sequence (hipGraph): `with Graph.capture(ctx) as g: runner.run_device()`, then g.launch() replays it."""
+
+    def __init__(self, ctx):
+        self.ctx, self.h = ctx, _P()
+
+    class _Cap:
+        def __init__(self, g):
+            self.g = g
+
+        def __enter__(self):
+            check(lib().snnhip_graph_begin_capture(self.g.ctx.h))
+            return self.g
+
+        def __exit__(self, et, ev, tb):
+            rc = lib().snnhip_graph_end_capture(self.g.ctx.h, C.byref(self.g.h))
+            if et is None:
+                check(rc)
+            return False
+
+    @staticmethod
+    def capture(ctx):
+        return Graph._Cap(Graph(ctx))
+
+    def launch(self):
+        check(lib().snnhip_graph_launch(self.h))
+
+    def num_nodes(self):
+        return lib().snnhip_graph_num_nodes(self.h)
+
+    def destroy(self):
+        if self.h:
+            lib().snnhip_graph_destroy(self.h)
+            self.h = _P()
 
 
 class Timer:

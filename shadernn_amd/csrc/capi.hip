@@ -180,6 +180,52 @@ int snnhip_sync(snnhip_ctx* ctx) {
     return SNNHIP_OK;
 }
 
+/* ---- launch graphs ---- */
+
+int snnhip_graph_begin_capture(snnhip_ctx* ctx) {
+    SNNHIP_REQUIRE(ctx, "graph_begin_capture: null ctx");
+    SNNHIP_CHECK_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return SNNHIP_OK;
+}
+
+int snnhip_graph_end_capture(snnhip_ctx* ctx, snnhip_graph** out) {
+    SNNHIP_REQUIRE(ctx && out, "graph_end_capture: null argument");
+    hipGraph_t graph = nullptr;
+    SNNHIP_CHECK_HIP(hipStreamEndCapture(ctx->stream, &graph));
+    SNNHIP_REQUIRE(graph != nullptr, "graph_end_capture: the capture was invalidated (a synchronising call or profiling events inside it)");
+    auto* g = new snnhip_graph();
+    g->ctx = ctx;
+    g->graph = graph;
+    size_t n = 0;
+    (void) hipGraphGetNodes(graph, nullptr, &n);
+    g->nodes = static_cast<int>(n);
+    hipError_t e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        (void) hipGraphDestroy(graph);
+        delete g;
+        return SNNHIP_E_HIP;
+    }
+    *out = g;
+    return SNNHIP_OK;
+}
+
+int snnhip_graph_launch(snnhip_graph* g) {
+    SNNHIP_REQUIRE(g && g->exec, "graph_launch: null graph");
+    SNNHIP_CHECK_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
+    return SNNHIP_OK;
+}
+
+int snnhip_graph_num_nodes(const snnhip_graph* g) { return g ? g->nodes : 0; }
+
+int snnhip_graph_destroy(snnhip_graph* g) {
+    if (!g) return SNNHIP_OK;
+    if (g->exec) (void) hipGraphExecDestroy(g->exec);
+    if (g->graph) (void) hipGraphDestroy(g->graph);
+    delete g;
+    return SNNHIP_OK;
+}
+
 /* ---- tensors ---- */
 
 int snnhip_tensor_alloc(snnhip_ctx* ctx, int n, int h, int w, int c, int dtype, snnhip_tensor** out) {

@@ -66,6 +66,13 @@ struct snnhip_tensor {
     size_t count() const { return static_cast<size_t>(n) * h * w * c; }
 };
 
+struct snnhip_graph {
+    snnhip_ctx* ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int nodes = 0;
+};
+
 struct snnhip_timer {
     snnhip_ctx* ctx = nullptr;
     hipEvent_t start = nullptr, stop = nullptr;

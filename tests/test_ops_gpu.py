@@ -161,3 +161,26 @@ def test_bad_arguments_fail_loudly(ctx):
     out = snn.Tensor(ctx, 1, 8, 8, 4)
     with pytest.raises(snn.SnnHipError):
         plan.run(bad, out)
+
+
+def test_graph_capture_replays_a_layer_sequence(ctx):
+    """snnhip_graph_*: plans run between begin/end are recorded, one launch replays them (the command-buffer replay of the reference)."""
+    import shadernn_amd as snn
+    from shadernn_amd import models
+
+    net = models.resnet18(seed=5, num_classes=10, width=8)
+    x = np.random.default_rng(1).random((2, 64, 64, 3), dtype=np.float32)
+    r = snn.GraphRunner(ctx, net, 2, 64, 64)
+    want = r(x)
+    with snn.Graph.capture(ctx) as g:
+        r.run_device()
+    assert g.num_nodes() >= len(r.steps)
+    r.y.fill(0.0)
+    g.launch()
+    g.launch()
+    np.testing.assert_array_equal(r.y.numpy(), want)
+    x2 = np.random.default_rng(2).random((2, 64, 64, 3), dtype=np.float32)
+    r.x.upload(x2)  # same tensors, new contents
+    g.launch()
+    np.testing.assert_allclose(r.y.numpy(), O.forward(net, x2), **TOL)
+    g.destroy()

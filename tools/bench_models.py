@@ -30,7 +30,16 @@ def main():
 
     snn.load_library()
     ctx = snn.Context(0)
+    def zoo(name, shape):
+        from shadernn_amd import param_import
+
+        fx = json.load(open(os.path.join(ROOT, "tests", "golden", "zoo_topologies.json")))[name]
+        ops = [{"type": o["type"], "name": o["name"], "inputs": o["inputs"], "outputs": o["outputs"], "params": {int(k): v for k, v in o["params"].items()}}
+               for o in fx["ops"]]
+        return param_import.from_ops(ops, name=name, seed=1, input_shape=shape)
+
     cases = [("resnet18", lambda: models.resnet18(seed=1), 32, 224, 224), ("mobilenetv2", lambda: models.mobilenetv2(seed=1), 32, 224, 224),
+             ("candy", lambda: zoo("candy-9_simplified-opt", (720, 1280, 3)), 1, 720, 1280),   # the reference zoo's graph (config 5 topology), fp32
              ("style", lambda: models.style_net(seed=1, width=32), 1, 720, 1280)]
     out = []
     for name, make, batch, h, w in cases:
@@ -50,6 +59,20 @@ def main():
         t.stop()
         ctx.sync()
         ms = t.elapsed_ms() / args.reps
+        # the same inference as one captured hipGraph (one host call per batch instead of one per layer)
+        with snn.Graph.capture(ctx) as g:
+            r.run_device()
+        for _ in range(3):
+            g.launch()
+        ctx.sync()
+        t.start()
+        for _ in range(args.reps):
+            g.launch()
+        t.stop()
+        ctx.sync()
+        ms_graph = t.elapsed_ms() / args.reps
+        nodes = g.num_nodes()
+        g.destroy()
         # per-layer times: one timed loop per plan
         rows = []
         for plan, ins, o, layer in r.steps:
@@ -61,10 +84,13 @@ def main():
             f, b = plan.cost()
             rows.append((t.elapsed_ms() / 5 * 1e3, layer["name"], f, b, plan.describe()))
         fl, by = r.cost()
-        res = {"model": name, "batch": batch, "input": [batch, h, w, 3], "ms_per_batch": ms, "images_per_s": batch / ms * 1e3, "gflop_per_image": fl / batch / 1e9,
+        ms_eager, ms = ms, min(ms, ms_graph)
+        res = {"model": name, "batch": batch, "input": [batch, h, w, 3], "ms_per_batch": ms, "ms_per_batch_eager_launches": ms_eager,
+               "ms_per_batch_hipgraph": ms_graph, "graph_nodes": nodes, "images_per_s": batch / ms * 1e3, "gflop_per_image": fl / batch / 1e9,
                "mb_per_image_unfused": by / batch / 1e6, "tflops": fl / ms / 1e9, "gbps_unfused": by / ms / 1e6,
                "roofline_ms": max(fl / PEAK_TF / 1e9, by / PEAK_GBS / 1e6), "layers": len(r.steps)}
         res["frac_of_roofline"] = res["roofline_ms"] / ms
+        print("%-12s eager %.2f ms, hipGraph (%d nodes) %.2f ms" % (name, ms_eager, nodes, ms_graph))
         print("%-12s batch %3d: %8.2f ms/batch  %9.1f images/s  %6.2f TFLOP/s  %7.1f GB/s (unfused accounting)  roofline %.2f ms -> %.1f%%  (%d launches)" %
               (name, batch, ms, res["images_per_s"], res["tflops"], res["gbps_unfused"], res["roofline_ms"], 100 * res["frac_of_roofline"], len(r.steps)), flush=True)
         rows.sort(reverse=True)

@@ -354,9 +354,10 @@ int snnhip_conv2d_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, c
     if (rc != SNNHIP_OK) return rc;
     SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));
     std::vector<float> epi = make_epilogue_table(g.OC, 16, desc->useBias, bias, desc->useBN, bn_beta, bn_gamma, bn_mean, bn_var);
-    // GEMM-shaped layers go to the fp32-MFMA implicit GEMM; everything else (and anything it declines) to the
-    // direct VALU kernel.
-    rc = make_conv2d_mfma_plan(ctx, g, w_oihw, epi, out);
+    // image-producing layers (OC <= 4) go to the 4x4x1-MFMA kernel, GEMM-shaped layers to the fp32-MFMA implicit GEMM; everything else
+    // (and anything they decline) to the direct VALU kernel.
+    rc = make_conv2d_thin_plan(ctx, g, w_oihw, epi, out);
+    if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_mfma_plan(ctx, g, w_oihw, epi, out);
     if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_generic_plan(ctx, g, w_oihw, epi, out);
     return rc;
 }

@@ -84,7 +84,7 @@ def test_default_routing(ctx, force):
     """Layers with >= 32 output channels (or >= 16 with >= 32 input channels) go to the MFMA kernel, even IC = 3 (measured faster);
     channel-thin ones to the VALU kernel."""
     force(None)
-    for (ic, oc, want) in [(64, 64, "mfma"), (3, 64, "mfma"), (16, 4, "generic"), (128, 1, "generic"), (16, 16, "generic"), (64, 16, "mfma"), (8, 32, "mfma")]:
+    for (ic, oc, want) in [(64, 64, "mfma"), (3, 64, "mfma"), (16, 4, "thin"), (128, 1, "thin"), (3, 3, "generic"), (16, 16, "generic"), (64, 16, "mfma"), (8, 32, "mfma")]:
         x = _rand((1, 8, 8, ic), 1)
         w = _rand((oc, ic, 3, 3), 2, 0.1)
         _, desc = run_conv(ctx, x, w, None, 1, (1, 1, 1, 1), "constant", "relu", 0.0, None)
@@ -141,3 +141,26 @@ def test_mfma_conv_split_k(ctx, force, monkeypatch, case, split):
         np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
     y2, _ = run_conv(ctx, x, w, b, s, pads, "constant", "tanh", 0.0, bn)
     np.testing.assert_array_equal(y, y2)  # deterministic
+
+
+THIN_CASES = [(1, 40, 70, 32, 3, 9, 1), (2, 20, 40, 16, 4, 3, 1), (1, 17, 33, 24, 1, 5, 1), (1, 9, 9, 10, 2, 3, 1), (3, 5, 7, 64, 4, 1, 1), (1, 33, 65, 8, 3, 7, 1)]
+
+
+@pytest.mark.parametrize("case", THIN_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_thin_conv_matches_oracle(ctx, force, case):
+    """OC <= 4 layers on v_mfma_f32_4x4x1 (conv2d_thin.hip): Candy's 9x9 32->3 output conv, ESPCN's unfused 16->4, ..."""
+    N, H, W, IC, OC, k, s = case
+    x = _rand((N, H, W, IC), 71)
+    w = _rand((OC, IC, k, k), 72, 1.0 / np.sqrt(IC * k * k))
+    b = _rand((OC,), 73, 0.1)
+    bn = _bn(OC, 74)
+    pads = O.padding_offsets("same", k)
+    force("thin")
+    for pad_mode, act in (("constant", "tanh"), ("reflect", "relu"), ("replicate", "SiLU_quirk"), ("none", "")):
+        y, desc = run_conv(ctx, x, w, b, s, pads, pad_mode, act, 0.0, bn)
+        assert "thin" in desc, desc
+        want = O.conv2d(x, w, b, s, pads, pad_mode, act, 0.0, bn)
+        np.testing.assert_allclose(y, want, err_msg=desc + " " + pad_mode + " " + act, **TOL)
+    force(None)
+    _, desc = run_conv(ctx, x, w, b, s, pads, "constant", "relu", 0.0, None)
+    assert ("thin" in desc) == (IC >= 8), desc

@@ -221,7 +221,8 @@ typedef struct {
     float leaky;
     float eps; /* the Vulkan shader hard-codes 1e-5 and ignores the parsed epsilon (vk_instancenorm.comp:118); pass 1e-5f for parity */
 } snnhip_instancenorm_desc;
-/* y = act((x - mean_hw) * gamma / sqrt(var_hw + eps) + beta), statistics per image and channel, biased variance */
+/* y = act((x - mean_hw) * gamma / sqrt(var_hw + eps) + beta), statistics per image and channel, biased variance (computed in one sweep
+ * around a per-channel pivot: same value as the shader's two-pass form up to fp32 rounding) */
 int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_desc* desc, const float* beta, const float* gamma, snnhip_plan** out);
 
 /* Try to replace a linear chain of plans (plan[i+1] consumes only plan[i]'s output) by fused kernels.

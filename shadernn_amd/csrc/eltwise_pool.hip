@@ -237,36 +237,40 @@ __global__ __launch_bounds__(256) void upsample_kernel(snnhip_upsample_desc d, i
 }
 
 // ------------------------------------------------------------------------------------------------ instance norm
-// Statistics per (image, channel) over H*W, two passes like the shader (mean, then sum (x-mean)^2, biased).  Work split:
-// block = (image n, row slab s): 256 threads = 64 pixel lanes x 4 channel lanes sweep the slab for every group of 4*CV channels
-// and write partial sums part[n][s][C]; a tiny fold kernel turns the S partials into stat[n][C] in a fixed order (deterministic).
-// launches: sum -> fold(mean) -> squares -> fold(multiplier, beta) -> normalise + activation
-// STAGE 0: part = sum x      STAGE 1: part = sum (x - mean)^2      STAGE 2: y = act((x - mean) * mul + beta)
+// Statistics per (image, channel) over H*W.  The shader makes two passes (mean, then sum (x-mean)^2); here ONE statistics sweep
+// accumulates S1 = sum (x - p) and S2 = sum (x - p)^2 around a per-channel pivot p = x[n, 0, 0, c] (so that S2/HW - (S1/HW)^2 does not
+// cancel: the pivot is within a few standard deviations of the mean), then one sweep normalises: 2 reads + 1 write of the tensor
+// instead of 3 + 1.  Work split: block = (image n, row slab s); its 256 threads are CL channel lanes x 256/CL pixel lanes with
+// CL*CV >= min(C, 128) so that one wave instruction reads whole pixels (contiguous C*4 bytes) instead of half-lines.
+// Partials go to part[n][s][2][C]; a tiny fold kernel turns them into mean[n][C] and mul[n][C] in a fixed order (deterministic).
+// STAGE 0: partial S1, S2      STAGE 2: y = act((x - mean) * mul + beta)
 template <int STAGE, int CV>
-__global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int rowsPerSlab, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int rowsPerSlab, int CLs, const float* __restrict__ x,
                                                           const float* __restrict__ statMean, const float* __restrict__ statMul,
                                                           const float* __restrict__ beta, float* __restrict__ partOut, float* __restrict__ y) {
-    __shared__ float red[256 * CV];
+    __shared__ float red[2 * 256 * CV];
     const int n = blockIdx.x / S, s = blockIdx.x % S;
-    const int tid = threadIdx.x, cl = tid & 3, pl = tid >> 2; // channel lane, pixel lane
+    const int tid = threadIdx.x;
+    const int CL = 1 << CLs, PL = 256 >> CLs;       // channel lanes, pixel lanes
+    const int cl = tid & (CL - 1), pl = tid >> CLs;
     const int r0 = s * rowsPerSlab, r1 = min(d.H, r0 + rowsPerSlab);
     const size_t p0 = static_cast<size_t>(r0) * d.W, p1 = static_cast<size_t>(r1) * d.W;
     const float* xn = x + static_cast<size_t>(n) * d.H * d.W * d.C;
-    for (int c0 = 0; c0 < d.C; c0 += 4 * CV) {
+    for (int c0 = 0; c0 < d.C; c0 += CL * CV) {
         const int c = c0 + cl * CV;
         const bool cok = c < d.C;
-        float mean[CV], mul[CV], bt[CV];
+        float piv[CV], mul[CV], bt[CV];
 #pragma unroll
         for (int k = 0; k < CV; ++k) {
-            mean[k] = (STAGE >= 1 && cok) ? statMean[static_cast<size_t>(n) * d.C + c + k] : 0.0f;
+            piv[k] = cok ? (STAGE == 0 ? xn[c + k] : statMean[static_cast<size_t>(n) * d.C + c + k]) : 0.0f; // stage 0: pivot, stage 2: mean
             mul[k] = (STAGE == 2 && cok) ? statMul[static_cast<size_t>(n) * d.C + c + k] : 0.0f;
             bt[k] = (STAGE == 2 && cok) ? beta[c + k] : 0.0f;
         }
-        float acc[CV];
+        float s1[CV], s2[CV];
 #pragma unroll
-        for (int k = 0; k < CV; ++k) acc[k] = 0.0f;
+        for (int k = 0; k < CV; ++k) s1[k] = s2[k] = 0.0f;
         if (cok) {
-            for (size_t p = p0 + pl; p < p1; p += 64) {
+            for (size_t p = p0 + pl; p < p1; p += PL) {
                 float v[CV];
                 const float* src = xn + p * d.C + c;
                 if (CV == 4) {
@@ -280,14 +284,15 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
                 }
                 if (STAGE == 0) {
 #pragma unroll
-                    for (int k = 0; k < CV; ++k) acc[k] += v[k];
-                } else if (STAGE == 1) {
-#pragma unroll
-                    for (int k = 0; k < CV; ++k) acc[k] += (v[k] - mean[k]) * (v[k] - mean[k]);
+                    for (int k = 0; k < CV; ++k) {
+                        const float dv = v[k] - piv[k];
+                        s1[k] += dv;
+                        s2[k] += dv * dv;
+                    }
                 } else {
                     float o[CV];
 #pragma unroll
-                    for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, (v[k] - mean[k]) * mul[k] + bt[k]);
+                    for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, (v[k] - piv[k]) * mul[k] + bt[k]);
                     float* dst = y + (static_cast<size_t>(n) * d.H * d.W + p) * d.C + c;
                     if (CV == 4) {
                         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1 % CV], o[2 % CV], o[3 % CV]);
@@ -297,33 +302,51 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
                 }
             }
         }
-        if (STAGE < 2) {
+        if (STAGE == 0) {
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < CV; ++k) red[tid * CV + k] = acc[k];
+            for (int k = 0; k < CV; ++k) {
+                red[tid * CV + k] = s1[k];
+                red[256 * CV + tid * CV + k] = s2[k];
+            }
             __syncthreads();
-            if (tid < 4 * CV) { // thread -> (channel lane tid / CV, component tid % CV): fold the 64 pixel lanes in a fixed order
+            if (tid < CL * CV) { // thread -> (channel lane tid / CV, component tid % CV): fold the pixel lanes in a fixed order
                 const int lane = tid / CV, k = tid % CV;
-                float sm = 0.0f;
-                for (int j = 0; j < 64; ++j) sm += red[(j * 4 + lane) * CV + k];
+                float a1 = 0.0f, a2 = 0.0f;
+                for (int j = 0; j < PL; ++j) {
+                    a1 += red[(j * CL + lane) * CV + k];
+                    a2 += red[256 * CV + (j * CL + lane) * CV + k];
+                }
                 const int cc = c0 + lane * CV + k;
-                if (cc < d.C) partOut[(static_cast<size_t>(n) * S + s) * d.C + cc] = sm;
+                if (cc < d.C) {
+                    float* po = partOut + (static_cast<size_t>(n) * S + s) * 2 * d.C;
+                    po[cc] = a1;
+                    po[d.C + cc] = a2;
+                }
             }
         }
     }
 }
 
-// MODE 0: stat[n][c] = (sum_s part) / (H*W)            (the mean)
-// MODE 1: stat[n][c] = gamma[c] / sqrt((sum_s part) / (H*W) + eps)
-template <int MODE>
-__global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, int S, float invHW, float eps, const float* __restrict__ part,
-                                                               const float* __restrict__ gamma, float* __restrict__ stat) {
+// mean[n][c] = p + S1/HW,  mul[n][c] = gamma[c] / sqrt(S2/HW - (S1/HW)^2 + eps)   with S1, S2 summed over the slabs in order
+__global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, int S, int HW, float invHW, float eps, const float* __restrict__ x,
+                                                               const float* __restrict__ part, const float* __restrict__ gamma,
+                                                               float* __restrict__ mean, float* __restrict__ mul) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NC) return;
     const int n = i / C, c = i % C;
-    float sm = 0.0f;
-    for (int j = 0; j < S; ++j) sm += part[(static_cast<size_t>(n) * S + j) * C + c];
-    stat[i] = MODE == 0 ? sm * invHW : gamma[c] / sqrtf(sm * invHW + eps);
+    float a1 = 0.0f, a2 = 0.0f;
+    for (int j = 0; j < S; ++j) {
+        const float* po = part + (static_cast<size_t>(n) * S + j) * 2 * C;
+        a1 += po[c];
+        a2 += po[C + c];
+    }
+    const float piv = x[static_cast<size_t>(n) * HW * C + c];
+    const float m1 = a1 * invHW;
+    float var = a2 * invHW - m1 * m1;
+    var = var > 0.0f ? var : 0.0f;
+    mean[i] = piv + m1;
+    mul[i] = gamma[c] / sqrtf(var + eps);
 }
 
 // ------------------------------------------------------------------------------------------------ plans
@@ -476,29 +499,26 @@ struct UpsamplePlan : snnhip_plan {
 
 struct InstanceNormPlan : snnhip_plan {
     snnhip_instancenorm_desc d;
-    int S = 1, rowsPerSlab = 1;
+    int S = 1, rowsPerSlab = 1, CLs = 2;
     float *d_beta = nullptr, *d_gamma = nullptr, *d_part = nullptr, *d_mean = nullptr, *d_mul = nullptr;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "instancenorm: expects 1 input, got %d", nIn);
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, d.H, d.W, d.C), "instancenorm: tensor dims do not match the plan");
         const dim3 g(static_cast<unsigned>(d.N * S));
-        const int NC = d.N * d.C;
+        const int NC = d.N * d.C, HW = d.H * d.W;
         const dim3 gf(static_cast<unsigned>((NC + 255) / 256));
         const float invHW = 1.0f / (static_cast<float>(d.H) * static_cast<float>(d.W));
 #define SNNHIP_IN(ST, CVV) \
-    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV>), g, dim3(256), 0, ctx->stream, d, S, rowsPerSlab, in[0]->data, d_mean, d_mul, d_beta, d_part, out->data)
-#define SNNHIP_FOLD(M) hipLaunchKernelGGL((instancenorm_fold_kernel<M>), gf, dim3(256), 0, ctx->stream, NC, d.C, S, invHW, d.eps, d_part, d_gamma, M == 0 ? d_mean : d_mul)
+    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV>), g, dim3(256), 0, ctx->stream, d, S, rowsPerSlab, CLs, in[0]->data, d_mean, d_mul, d_beta, d_part, out->data)
+#define SNNHIP_FOLD() \
+    hipLaunchKernelGGL(instancenorm_fold_kernel, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, in[0]->data, d_part, d_gamma, d_mean, d_mul)
         if ((d.C & 3) == 0) {
             SNNHIP_IN(0, 4);
-            SNNHIP_FOLD(0);
-            SNNHIP_IN(1, 4);
-            SNNHIP_FOLD(1);
+            SNNHIP_FOLD();
             SNNHIP_IN(2, 4);
         } else {
             SNNHIP_IN(0, 1);
-            SNNHIP_FOLD(0);
-            SNNHIP_IN(1, 1);
-            SNNHIP_FOLD(1);
+            SNNHIP_FOLD();
             SNNHIP_IN(2, 1);
         }
 #undef SNNHIP_IN
@@ -645,7 +665,13 @@ int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_d
     plan->S = (desc->H + plan->rowsPerSlab - 1) / plan->rowsPerSlab;
     int rc = plan->upload(beta, desc->C, &plan->d_beta);
     if (rc == SNNHIP_OK) rc = plan->upload(gamma, desc->C, &plan->d_gamma);
-    std::vector<float> zeros(static_cast<size_t>(desc->N) * plan->S * desc->C, 0.0f);
+    {   // channel lanes: enough to read whole pixels (up to 128 channels = 512 contiguous bytes) per wave instruction
+        const int cv = (desc->C & 3) == 0 ? 4 : 1;
+        int cls = 2;
+        while ((1 << cls) * cv < desc->C && cls < (cv == 4 ? 5 : 6)) ++cls;
+        plan->CLs = cls;
+    }
+    std::vector<float> zeros(static_cast<size_t>(desc->N) * plan->S * desc->C * 2, 0.0f);
     if (rc == SNNHIP_OK) rc = plan->upload(zeros.data(), zeros.size(), &plan->d_part);
     if (rc == SNNHIP_OK) rc = plan->upload(zeros.data(), static_cast<size_t>(desc->N) * desc->C, &plan->d_mean);
     if (rc == SNNHIP_OK) rc = plan->upload(zeros.data(), static_cast<size_t>(desc->N) * desc->C, &plan->d_mul);
@@ -657,9 +683,9 @@ int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_d
     plan->inDims[0] = plan->outDims[0] = desc->N; plan->inDims[1] = plan->outDims[1] = desc->H;
     plan->inDims[2] = plan->outDims[2] = desc->W; plan->inDims[3] = plan->outDims[3] = desc->C;
     plan->flops = cnt * 7;
-    plan->bytes = 4.0 * cnt * 2; // algorithmic: read once, write once (the two-pass statistics re-read the tensor: 4x in practice)
+    plan->bytes = 4.0 * cnt * 2; // algorithmic: read once, write once (the statistics sweep reads it once more: 3x in practice)
     char buf[160];
-    snprintf(buf, sizeof(buf), "instancenorm_f32 %dx%dx%dx%d act=%d slabs=%d (3 sweeps + 2 folds)", desc->N, desc->H, desc->W, desc->C, desc->act, plan->S);
+    snprintf(buf, sizeof(buf), "instancenorm_f32 %dx%dx%dx%d act=%d slabs=%d (2 sweeps + fold)", desc->N, desc->H, desc->W, desc->C, desc->act, plan->S);
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

@@ -67,7 +67,10 @@ enum {
 };
 /* padding mode: specialisation constant 16 (conv2dVulkan.cpp:74-81) */
 enum { SNNHIP_PAD_NONE = 0, SNNHIP_PAD_CONSTANT = 1, SNNHIP_PAD_REPLICATE = 2, SNNHIP_PAD_REFLECT = 3 };
-enum { SNNHIP_F32 = 0 };
+/* element types.  SNNHIP_F16 = IEEE half storage (the reference's RGBA16F textures / "preferHp", inferencegraph.h ColorFormat::RGBA16F):
+ * tensors hold halfs in HBM, kernels convert on load, accumulate in fp32 (fp16-input MFMA for the convolutions) and round to nearest even
+ * on store.  The host-side upload / download entry points always speak fp32 and convert. */
+enum { SNNHIP_F32 = 0, SNNHIP_F16 = 1 };
 
 /* ---- context -------------------------------------------------------------------------------------- */
 
@@ -98,6 +101,7 @@ int snnhip_tensor_free(snnhip_tensor* t);
 int snnhip_tensor_dims(const snnhip_tensor* t, int dims_nhwc[4]);
 void* snnhip_tensor_data(const snnhip_tensor* t);
 size_t snnhip_tensor_bytes(const snnhip_tensor* t);
+int snnhip_tensor_dtype(const snnhip_tensor* t);
 int snnhip_tensor_upload(snnhip_tensor* t, const float* host_nhwc);          /* H2D, synchronous */
 int snnhip_tensor_download(const snnhip_tensor* t, float* host_nhwc);        /* stream sync + D2H */
 /* Reference texture layout [ceil(C/4)][H][W][4] per image (shaderUnitTest.cpp:87-129, image.cpp:216-245). */
@@ -117,7 +121,7 @@ typedef struct {
     int act;                    /* SNNHIP_ACT_* */
     float leaky;
     int useBias, useBN;
-    int dtype;                  /* SNNHIP_F32 */
+    int dtype;                  /* SNNHIP_F32 | SNNHIP_F16: type of the input and output tensors (weights are given in fp32 and converted) */
     int OH, OW;                 /* 0 => derived with the reference's float rule (conv2d.cpp:102-113) */
 } snnhip_conv2d_desc;
 

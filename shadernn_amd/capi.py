@@ -82,6 +82,7 @@ SIGNATURES = {
     "snnhip_tensor_dims": (C.c_int, [_P, C.POINTER(C.c_int * 4)]),
     "snnhip_tensor_data": (_P, [_P]),
     "snnhip_tensor_bytes": (C.c_size_t, [_P]),
+    "snnhip_tensor_dtype": (C.c_int, [_P]),
     "snnhip_tensor_upload": (C.c_int, [_P, _FP]),
     "snnhip_tensor_download": (C.c_int, [_P, _FP]),
     "snnhip_tensor_upload_c4hw4": (C.c_int, [_P, _FP]),
@@ -190,25 +191,29 @@ class Context:
             self.h = None
 
 
-class Tensor:
-    """NHWC fp32 tensor in HBM."""
+F32, F16 = 0, 1  # SNNHIP_F32 / SNNHIP_F16
 
-    def __init__(self, ctx, n, h, w, c, device_ptr=None, keepalive=None):
+
+class Tensor:
+    """NHWC tensor in HBM: fp32, or fp16 storage (dtype=F16; upload / numpy() still speak float32 and convert at the edge)."""
+
+    def __init__(self, ctx, n, h, w, c, device_ptr=None, keepalive=None, dtype=F32):
         self.ctx = ctx
         self.shape = (n, h, w, c)
+        self.dtype = dtype
         hh = _P()
         if device_ptr is None:
-            check(lib().snnhip_tensor_alloc(ctx.h, n, h, w, c, 0, C.byref(hh)))
+            check(lib().snnhip_tensor_alloc(ctx.h, n, h, w, c, dtype, C.byref(hh)))
         else:
-            check(lib().snnhip_tensor_wrap(ctx.h, _P(device_ptr), n, h, w, c, 0, C.byref(hh)))
+            check(lib().snnhip_tensor_wrap(ctx.h, _P(device_ptr), n, h, w, c, dtype, C.byref(hh)))
         self.h = hh
         self._keepalive = keepalive
 
     @staticmethod
-    def from_numpy(ctx, a):
+    def from_numpy(ctx, a, dtype=F32):
         a = np.ascontiguousarray(a, dtype=np.float32)
         assert a.ndim == 4, "expected NHWC"
-        t = Tensor(ctx, *a.shape)
+        t = Tensor(ctx, *a.shape, dtype=dtype)
         t.upload(a)
         return t
 
@@ -281,7 +286,8 @@ class Plan:
 
     def __call__(self, x, y=None):
         if y is None:
-            y = Tensor(self.ctx, *self.out_shape())
+            first = x[0] if isinstance(x, (list, tuple)) else x
+            y = Tensor(self.ctx, *self.out_shape(), dtype=first.dtype)
         self.run(x, y)
         return y
 
@@ -339,7 +345,7 @@ def same_padding(k):
     return (0, 0, 0, 0)
 
 
-def conv2d_plan(ctx, N, H, W, w_oihw, bias=None, stride=1, pads=None, pad_mode="constant", act="", leaky=0.0, bn=None, depthwise=False):
+def conv2d_plan(ctx, N, H, W, w_oihw, bias=None, stride=1, pads=None, pad_mode="constant", act="", leaky=0.0, bn=None, depthwise=False, dtype=F32):
     """w_oihw: [OC][IC][kh][kw] (depthwise: [C][kh][kw]). bn: dict beta/gamma/mean/var or None. pads: (T,B,L,R) or None=same."""
     w = _f32(w_oihw)
     if depthwise:
@@ -354,6 +360,7 @@ def conv2d_plan(ctx, N, H, W, w_oihw, bias=None, stride=1, pads=None, pad_mode="
     if bn is not None:
         bnp = [_f32(bn[k]) for k in ("beta", "gamma", "mean", "var")]
     d = _conv_desc(N, H, W, IC, OC, (kh, kw), stride, pads, pad_mode, act, leaky, b is not None, bn is not None)
+    d.dtype = dtype
     h = _P()
     fn = lib().snnhip_depthwise_plan_create if depthwise else lib().snnhip_conv2d_plan_create
     check(fn(ctx.h, C.byref(d), _fptr(w), _fptr(b), _fptr(bnp[0]), _fptr(bnp[1]), _fptr(bnp[2]), _fptr(bnp[3]), C.byref(h)))

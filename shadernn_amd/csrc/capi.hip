@@ -36,7 +36,7 @@ std::vector<float> make_epilogue_table(int OC, int padTo, int useBias, const flo
 }
 
 int resolve_conv_geom(const snnhip_conv2d_desc* d, bool depthwise, ConvGeom* g) {
-    SNNHIP_REQUIRE(d->dtype == SNNHIP_F32, "only fp32 tensors are implemented (dtype=%d)", d->dtype);
+    SNNHIP_REQUIRE(d->dtype == SNNHIP_F32 || d->dtype == SNNHIP_F16, "conv desc: dtype %d", d->dtype);
     SNNHIP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->IC > 0 && d->OC > 0, "conv desc: non-positive dims N=%d H=%d W=%d IC=%d OC=%d", d->N, d->H,
                    d->W, d->IC, d->OC);
     SNNHIP_REQUIRE(d->kh > 0 && d->kw > 0 && d->sh > 0 && d->sw > 0, "conv desc: bad kernel/stride %dx%d / %dx%d", d->kh, d->kw, d->sh, d->sw);
@@ -54,6 +54,7 @@ int resolve_conv_geom(const snnhip_conv2d_desc* d, bool depthwise, ConvGeom* g) 
     g->act = d->act;
     g->useBN = d->useBN;
     g->leaky = d->leaky;
+    g->dtype = d->dtype;
     g->OH = d->OH > 0 ? d->OH : conv_out_dim(d->H, d->kh, d->sh, d->padT, d->padB);
     g->OW = d->OW > 0 ? d->OW : conv_out_dim(d->W, d->kw, d->sw, d->padT, d->padB); // reference uses offsets[0]+offsets[1] for both axes
     SNNHIP_REQUIRE(g->OH > 0 && g->OW > 0, "conv desc: empty output %dx%d", g->OH, g->OW);
@@ -230,16 +231,17 @@ int snnhip_graph_destroy(snnhip_graph* g) {
 
 int snnhip_tensor_alloc(snnhip_ctx* ctx, int n, int h, int w, int c, int dtype, snnhip_tensor** out) {
     SNNHIP_REQUIRE(ctx && out, "tensor_alloc: null argument");
-    SNNHIP_REQUIRE(dtype == SNNHIP_F32, "tensor_alloc: dtype %d not implemented", dtype);
+    SNNHIP_REQUIRE(dtype == SNNHIP_F32 || dtype == SNNHIP_F16, "tensor_alloc: dtype %d not implemented", dtype);
     SNNHIP_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "tensor_alloc: bad dims %dx%dx%dx%d", n, h, w, c);
     auto* t = new (std::nothrow) snnhip_tensor();
     if (!t) return SNNHIP_E_NOMEM;
-    t->ctx = ctx; t->n = n; t->h = h; t->w = w; t->c = c; t->owns = true;
+    t->ctx = ctx; t->n = n; t->h = h; t->w = w; t->c = c; t->owns = true; t->dtype = dtype;
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, t->count() * sizeof(float));
+    const size_t nbytes = (t->bytes() + 15) & ~static_cast<size_t>(15);
+    hipError_t e = hipMalloc(&p, nbytes);
     if (e != hipSuccess) {
         delete t;
-        set_error("hipMalloc(%zu) failed: %s", t->count() * sizeof(float), hipGetErrorString(e));
+        set_error("hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? SNNHIP_E_NOMEM : SNNHIP_E_HIP;
     }
     t->data = static_cast<float*>(p);
@@ -249,12 +251,12 @@ int snnhip_tensor_alloc(snnhip_ctx* ctx, int n, int h, int w, int c, int dtype, 
 
 int snnhip_tensor_wrap(snnhip_ctx* ctx, void* device_ptr, int n, int h, int w, int c, int dtype, snnhip_tensor** out) {
     SNNHIP_REQUIRE(ctx && out && device_ptr, "tensor_wrap: null argument");
-    SNNHIP_REQUIRE(dtype == SNNHIP_F32, "tensor_wrap: dtype %d not implemented", dtype);
+    SNNHIP_REQUIRE(dtype == SNNHIP_F32 || dtype == SNNHIP_F16, "tensor_wrap: dtype %d not implemented", dtype);
     SNNHIP_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "tensor_wrap: bad dims %dx%dx%dx%d", n, h, w, c);
     SNNHIP_REQUIRE((reinterpret_cast<uintptr_t>(device_ptr) & 15) == 0, "tensor_wrap: pointer must be 16-byte aligned");
     auto* t = new (std::nothrow) snnhip_tensor();
     if (!t) return SNNHIP_E_NOMEM;
-    t->ctx = ctx; t->n = n; t->h = h; t->w = w; t->c = c; t->owns = false;
+    t->ctx = ctx; t->n = n; t->h = h; t->w = w; t->c = c; t->owns = false; t->dtype = dtype;
     t->data = static_cast<float*>(device_ptr);
     *out = t;
     return SNNHIP_OK;
@@ -274,18 +276,34 @@ int snnhip_tensor_dims(const snnhip_tensor* t, int dims[4]) {
 }
 
 void* snnhip_tensor_data(const snnhip_tensor* t) { return t ? t->data : nullptr; }
-size_t snnhip_tensor_bytes(const snnhip_tensor* t) { return t ? t->count() * sizeof(float) : 0; }
+size_t snnhip_tensor_bytes(const snnhip_tensor* t) { return t ? t->bytes() : 0; }
+int snnhip_tensor_dtype(const snnhip_tensor* t) { return t ? t->dtype : -1; }
 
+// fp32 <-> fp16 on the host (API edge only): round to nearest even, like the GPU's image stores
 int snnhip_tensor_upload(snnhip_tensor* t, const float* host) {
     SNNHIP_REQUIRE(t && host, "tensor_upload: null argument");
-    SNNHIP_CHECK_HIP(hipMemcpyAsync(t->data, host, t->count() * sizeof(float), hipMemcpyHostToDevice, t->ctx->stream));
+    if (t->dtype == SNNHIP_F16) {
+        std::vector<_Float16> tmp(t->count());
+        for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = static_cast<_Float16>(host[i]);
+        SNNHIP_CHECK_HIP(hipMemcpyAsync(t->data, tmp.data(), t->bytes(), hipMemcpyHostToDevice, t->ctx->stream));
+        SNNHIP_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
+        return SNNHIP_OK;
+    }
+    SNNHIP_CHECK_HIP(hipMemcpyAsync(t->data, host, t->bytes(), hipMemcpyHostToDevice, t->ctx->stream));
     SNNHIP_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
     return SNNHIP_OK;
 }
 
 int snnhip_tensor_download(const snnhip_tensor* t, float* host) {
     SNNHIP_REQUIRE(t && host, "tensor_download: null argument");
-    SNNHIP_CHECK_HIP(hipMemcpyAsync(host, t->data, t->count() * sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
+    if (t->dtype == SNNHIP_F16) {
+        std::vector<_Float16> tmp(t->count());
+        SNNHIP_CHECK_HIP(hipMemcpyAsync(tmp.data(), t->data, t->bytes(), hipMemcpyDeviceToHost, t->ctx->stream));
+        SNNHIP_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
+        for (size_t i = 0; i < tmp.size(); ++i) host[i] = static_cast<float>(tmp[i]);
+        return SNNHIP_OK;
+    }
+    SNNHIP_CHECK_HIP(hipMemcpyAsync(host, t->data, t->bytes(), hipMemcpyDeviceToHost, t->ctx->stream));
     SNNHIP_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
     return SNNHIP_OK;
 }
@@ -327,11 +345,18 @@ __global__ void fill_kernel(float* p, size_t n, float v) {
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = v;
 }
 
+__global__ void fill_half_kernel(_Float16* p, size_t n, float v) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = static_cast<_Float16>(v);
+}
+
 int snnhip_tensor_fill(snnhip_tensor* t, float value) {
     SNNHIP_REQUIRE(t, "tensor_fill: null argument");
     size_t n = t->count();
     unsigned blocks = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 4096));
-    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, t->data, n, value);
+    if (t->dtype == SNNHIP_F16)
+        hipLaunchKernelGGL(fill_half_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, reinterpret_cast<_Float16*>(t->data), n, value);
+    else
+        hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, t->data, n, value);
     SNNHIP_CHECK_HIP(hipGetLastError());
     return SNNHIP_OK;
 }
@@ -358,6 +383,10 @@ int snnhip_conv2d_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, c
     // (and anything they decline) to the direct VALU kernel.
     rc = make_conv2d_thin_plan(ctx, g, w_oihw, epi, out);
     if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_mfma_plan(ctx, g, w_oihw, epi, out);
+    if (rc == SNNHIP_E_UNSUPPORTED && g.dtype != SNNHIP_F32) {
+        set_error("conv2d: no fp16 kernel takes this shape (k=%dx%d stride %d, %d->%d)", g.kh, g.kw, g.sh, g.IC, g.OC);
+        return rc;
+    }
     if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_generic_plan(ctx, g, w_oihw, epi, out);
     return rc;
 }
@@ -367,6 +396,7 @@ int snnhip_depthwise_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc
     int rc = check_conv_args(ctx, desc, w_chw, bn_beta, bn_gamma, bn_mean, bn_var, out);
     if (rc != SNNHIP_OK) return rc;
     ConvGeom g;
+    SNNHIP_REQUIRE(desc->dtype == SNNHIP_F32, "depthwise_plan_create: only fp32 tensors are implemented for the depthwise operator");
     rc = resolve_conv_geom(desc, true, &g);
     if (rc != SNNHIP_OK) return rc;
     SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));
@@ -402,6 +432,12 @@ int snnhip_plan_run_n(snnhip_plan* plan, const snnhip_tensor* const* inputs, int
     SNNHIP_REQUIRE(plan && inputs && out && n_in > 0, "plan_run: null argument");
     for (int i = 0; i < n_in; ++i) SNNHIP_REQUIRE(inputs[i] && inputs[i]->data, "plan_run: input %d is null", i);
     SNNHIP_REQUIRE(out->data, "plan_run: output has no storage");
+    if (!plan->anyDtype) {
+        for (int i = 0; i < n_in; ++i)
+            SNNHIP_REQUIRE(inputs[i]->dtype == plan->dtype, "plan_run: input %d has dtype %d, the plan (%s) was built for %d", i, inputs[i]->dtype,
+                           plan->desc.c_str(), plan->dtype);
+        SNNHIP_REQUIRE(out->dtype == plan->dtype, "plan_run: output has dtype %d, the plan (%s) was built for %d", out->dtype, plan->desc.c_str(), plan->dtype);
+    }
     if (plan->profiling && !plan->profilesItself()) {
         int rc = plan->profBegin(0);
         if (rc != SNNHIP_OK) return rc;

@@ -26,6 +26,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace snnhip {
 
@@ -61,12 +62,21 @@ __device__ __forceinline__ int lds_off(int pl, int slot) {
     return pl * (4 * Q) + ((slot ^ ((pl >> (4 - LQ)) & (Q - 1))) << 2);
 }
 
-template <int WM, int WN, int MT, int NT, int C8, int R, bool SIMPLE>
-__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCfg ac, const float* __restrict__ x, const float* __restrict__ wp,
-                                                          const float4* __restrict__ epi, float* __restrict__ y) {
+// F16: tensors and packed weights hold halfs; a 16-byte slot is 8 channels instead of 4 and ONE v_mfma_f32_32x32x16_f16 consumes the slot pair
+// (h = 0, 1) that four v_mfma_f32_32x32x2_f32 consume in fp32, so a K-step is 16 channels; byte geometry (LDS tile, swizzle, weight stream,
+// 128-bit operand loads) is identical.  Accumulation and epilogue stay fp32; stores round to nearest even.
+template <int WM, int WN, int MT, int NT, int C8, int R, bool SIMPLE, bool F16>
+__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCfg ac, const void* __restrict__ xv, const void* __restrict__ wpv,
+                                                          const float4* __restrict__ epi, void* __restrict__ yv, float* __restrict__ ws) {
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(WM * MT == 4, "128 pixels per block");
-    constexpr int Q = 2 * C8;    // float4 per staged pixel
+    typedef typename std::conditional<F16, _Float16, float>::type T;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr int CH = F16 ? 8 : 4; // channels per 16-byte slot
+    const T* __restrict__ x = static_cast<const T*>(xv);
+    const float4* __restrict__ wp = static_cast<const float4*>(wpv);
+    T* __restrict__ y = static_cast<T*>(yv);
+    constexpr int Q = 2 * C8;    // 16-byte slots per staged pixel
     constexpr int BN = 32 * NT * WN;
     constexpr int D = (MT * NT >= 4) ? 2 : (MT * NT == 2 ? 3 : 4); // weight prefetch distance in K steps
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
     const int ox0 = tx << p.TWs, oy0 = ty << p.THs, b0 = tb << p.TBs;
     const int ix0 = ox0 * p.sw - p.padx, iy0 = oy0 * p.sh - p.pady;
     const int taps = p.kh * p.kw;
-    const bool vec4 = (p.IC & 3) == 0;
+    const bool vec4 = (p.IC % CH) == 0;
 
     // ---- staging descriptors: element e = tid + 256 r -> (pixel of the halo tile, channel quad q); q is the same for all r
     const int q = tid & (Q - 1);
@@ -101,24 +111,24 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
             const int n = b0 + b;
             const int cm = p.evenCols ? (c & 1) * p.evenCols + (c >> 1) : c;
             lofs[r] = lds_off<C8>(b * p.imgPitch + rr * p.rowPitch + cm, q);
-            if (sy >= 0 && sx >= 0 && n < p.N) gofs[r] = ((n * p.H + sy) * p.W + sx) * p.IC + q * 4;
+            if (sy >= 0 && sx >= 0 && n < p.N) gofs[r] = ((n * p.H + sy) * p.W + sx) * p.IC + q * CH;
         }
     }
     float4 stage[R];
     auto stage_load = [&](int ic0) {
-        const int icq = ic0 + q * 4;
+        const int icq = ic0 + q * CH;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gofs[r] >= 0 && icq < p.IC) {
-                const float* src = x + gofs[r] + ic0;
+                const T* src = x + gofs[r] + ic0;
                 if (vec4) {
                     v = *reinterpret_cast<const float4*>(src);
                 } else {
-                    v.x = src[0];
-                    if (icq + 1 < p.IC) v.y = src[1];
-                    if (icq + 2 < p.IC) v.z = src[2];
-                    if (icq + 3 < p.IC) v.w = src[3];
+                    T tmp[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) tmp[j] = icq + j < p.IC ? src[j] : static_cast<T>(0.0f);
+                    v = *reinterpret_cast<const float4*>(tmp);
                 }
             }
             stage[r] = v;
@@ -139,9 +149,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
         apix[t] = b * p.imgPitch + py * p.sh * p.rowPitch + (p.evenCols ? px : px * p.sw); // sw==2: column 2px+fx -> plane (fx&1), index px+(fx>>1)
     }
     const int n0 = blockIdx.y * BN + wn * (NT * 32);
-    const size_t bstep = static_cast<size_t>(2) * p.OCp * 4;
+    const size_t bstep = static_cast<size_t>(2) * p.OCp; // float4 (16-byte) units per K step
     const int chunk0 = blockIdx.z * p.chunksPerSplit, chunk1 = min(p.nChunks, chunk0 + p.chunksPerSplit);
-    const float* bptr = wp + (static_cast<size_t>(h) * p.OCp + n0 + l32) * 4 + static_cast<size_t>(chunk0) * taps * C8 * bstep;
+    const float4* bptr = wp + (static_cast<size_t>(h) * p.OCp + n0 + l32) + static_cast<size_t>(chunk0) * taps * C8 * bstep;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -156,18 +166,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 #pragma unroll
     for (int d = 0; d < D; ++d) {
 #pragma unroll
-        for (int u = 0; u < NT; ++u) bq[d][u] = *reinterpret_cast<const float4*>(bptr + u * 128);
+        for (int u = 0; u < NT; ++u) bq[d][u] = bptr[u * 32];
         bptr += bstep;
     }
 
-    stage_load(chunk0 * 8 * C8);
+    stage_load(chunk0 * 2 * CH * C8);
     stage_store(smem + (chunk0 & 1) * p.bufFloats);
     __syncthreads();
 
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         const float* cur = smem + (chunk & 1) * p.bufFloats;
         const bool more = chunk + 1 < chunk1;
-        if (more) stage_load((chunk + 1) * 8 * C8);
+        if (more) stage_load((chunk + 1) * 2 * CH * C8);
 
         float4 an[MT];
 #pragma unroll
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 #pragma unroll
                     for (int u = 0; u < NT; ++u) bq[d][u] = bq[d + 1][u];
 #pragma unroll
-                for (int u = 0; u < NT; ++u) bq[D - 1][u] = *reinterpret_cast<const float4*>(bptr + u * 128);
+                for (int u = 0; u < NT; ++u) bq[D - 1][u] = bptr[u * 32];
                 bptr += bstep;
                 {
                     const int dl = (c8 + 1 < C8) ? dcur : dnext;
@@ -207,22 +217,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 #pragma unroll
                     for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const float4*>(cur + lds_off<C8>(apix[t] + dl, slot));
                 }
+                if (F16) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+                    for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
+                        for (int u = 0; u < NT; ++u)
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+                    for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
+                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+                    for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
+                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+                    for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
+                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
+                }
             }
             fx = fxn;
             rowoff = rown;
@@ -248,11 +266,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                 const int oc = n0 + u * 32 + l32;
                 const float4 e = epi[oc]; // table padded to OCp
                 const bool ok = rowOk && oc < p.OC;
-                if (p.splitK > 1) { // y is the workspace [splitK][N*OH*OW][OC]: raw partial sums, epilogue in splitk_reduce_kernel
-                    float* ws = y + static_cast<size_t>(blockIdx.z) * p.N * p.OH * p.OW * p.OC;
+                if (p.splitK > 1) { // ws = fp32 workspace [splitK][N*OH*OW][OC]: raw partial sums, epilogue in splitk_reduce_kernel
+                    float* wz = ws + static_cast<size_t>(blockIdx.z) * p.N * p.OH * p.OW * p.OC;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (ok && ox + k < p.OW) ws[pofs + k * p.OC + oc] = acc[t][u][4 * g + k];
+                        if (ok && ox + k < p.OW) wz[pofs + k * p.OC + oc] = acc[t][u][4 * g + k];
                     continue;
                 }
                 float first = 0.0f;
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                         v = epi_act(act, ac.leaky, v, first);
                         if (k == 0) first = v;
                     }
-                    if (ok && ox + k < p.OW) y[pofs + k * p.OC + oc] = v;
+                    if (ok && ox + k < p.OW) y[pofs + k * p.OC + oc] = static_cast<T>(v);
                 }
             }
         }
@@ -274,14 +292,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 }
 
 // split-K second pass: y[m][oc] = act(BN(bias + sum_z ws[z][m][oc])), summed in a fixed order (deterministic)
-template <bool SIMPLE>
+template <bool SIMPLE, typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(size_t MN, int OC, int splitK, int useBN, ActCfg ac, const float* __restrict__ ws,
-                                                           const float4* __restrict__ epi, float* __restrict__ y) {
+                                                           const float4* __restrict__ epi, T* __restrict__ y) {
     for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < MN; i += static_cast<size_t>(gridDim.x) * 256) {
         float v = 0.0f;
         for (int z = 0; z < splitK; ++z) v += ws[static_cast<size_t>(z) * MN + i];
         v = epi_affine(v, epi[i % OC], useBN);
-        y[i] = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+        y[i] = static_cast<T>(SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f));
     }
 }
 
@@ -293,7 +311,7 @@ struct MfmaConvPlan : ConvPlanBase {
     float* d_epi = nullptr;
     size_t ldsBytes = 0;
     dim3 grid;
-    void (*kernel)(MfmaParams, ActCfg, const float*, const float*, const float4*, float*) = nullptr;
+    void (*kernel)(MfmaParams, ActCfg, const void*, const void*, const float4*, void*, float*) = nullptr;
 
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
@@ -302,32 +320,39 @@ struct MfmaConvPlan : ConvPlanBase {
                        x->n, x->h, x->w, x->c, p.N, p.H, p.W, p.IC);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
                        out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
-        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, x->data, d_w, reinterpret_cast<const float4*>(d_epi),
-                           p.splitK > 1 ? d_ws : out->data);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, static_cast<const void*>(x->data), static_cast<const void*>(d_w),
+                           reinterpret_cast<const float4*>(d_epi), static_cast<void*>(out->data), d_ws);
         if (p.splitK > 1) {
             const size_t MN = out->count();
             size_t blocks = (MN + 255) / 256;
             const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) * 8;
             if (blocks > cap) blocks = cap;
-            if (act_is_simple(ac.act))
-                hipLaunchKernelGGL((splitk_reduce_kernel<true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac,
-                                   d_ws, reinterpret_cast<const float4*>(d_epi), out->data);
-            else
-                hipLaunchKernelGGL((splitk_reduce_kernel<false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac,
-                                   d_ws, reinterpret_cast<const float4*>(d_epi), out->data);
+            const dim3 gr(static_cast<unsigned>(blocks));
+            const float4* e4 = reinterpret_cast<const float4*>(d_epi);
+            const bool simple = act_is_simple(ac.act);
+            if (dtype == SNNHIP_F16) {
+                _Float16* yo = reinterpret_cast<_Float16*>(out->data);
+                if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, _Float16>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, yo);
+                else hipLaunchKernelGGL((splitk_reduce_kernel<false, _Float16>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, yo);
+            } else {
+                if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, float>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, out->data);
+                else hipLaunchKernelGGL((splitk_reduce_kernel<false, float>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, out->data);
+            }
         }
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
 };
 
-typedef void (*KernelFn)(MfmaParams, ActCfg, const float*, const float*, const float4*, float*);
+typedef void (*KernelFn)(MfmaParams, ActCfg, const void*, const void*, const float4*, void*, float*);
 
 template <int WM, int WN, int MT, int NT>
-KernelFn pick_kernel(int c8, int r, bool simple) {
-#define SNNHIP_PICK(C8_, R_)                                                                  \
-    if (c8 == C8_ && r == R_)                                                                 \
-        return simple ? conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, true> : conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, false>;
+KernelFn pick_kernel(int c8, int r, bool simple, bool f16) {
+#define SNNHIP_PICK(C8_, R_)                                                                                                              \
+    if (c8 == C8_ && r == R_) {                                                                                                           \
+        if (f16) return simple ? conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, true, true> : conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, false, true>;   \
+        return simple ? conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, true, false> : conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, false, false>; \
+    }
     SNNHIP_PICK(1, 3)
     SNNHIP_PICK(1, 5)
     SNNHIP_PICK(1, 9)
@@ -353,7 +378,8 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     // on the VALU kernel, so only the channel-thin outputs (OC < 16: most of a 32-wide MFMA column block would be padding) stay there
     // and the 16-wide thin layers (OC < 32 with IC < 32, e.g. ESPCN's 16->16: half of the narrowest 32-wide block is padding) measured
     // faster there too (241 vs 276 us at 1080p)
-    if (!forced && (g.OC < 16 || (g.OC < 32 && g.IC < 32))) return SNNHIP_E_UNSUPPORTED;
+    const bool f16 = g.dtype == SNNHIP_F16; // fp16 tensors: this is the only general convolution kernel, it takes every shape
+    if (!forced && !f16 && (g.OC < 16 || (g.OC < 32 && g.IC < 32))) return SNNHIP_E_UNSUPPORTED;
     const double inCount = static_cast<double>(g.N) * g.H * g.W * g.IC;
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED; // 32-bit element offsets in the kernel
@@ -362,10 +388,11 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     // channels per LDS chunk: 16 (8 when IC <= 8).  Wider chunks (the kernel is instantiated up to 64 channels; SNNHIP_CONV_C8=4|8 selects
     // them for pointwise stride-1 layers) were measured on the MobileNetV2 layers: fewer barriers per MFMA, but the 4x staging registers and
     // LDS cost more residency than they save (1x1 960->320 @7x7 b32: 58.7 -> 51.7 us, 144->24 @56x56: 27.9 -> 45.3 us), so 16 stays the default
-    int C8 = g.IC <= 8 ? 1 : 2;
+    const int CH = f16 ? 8 : 4;                                  // channels per 16-byte slot
+    int C8 = g.IC <= 2 * CH ? 1 : 2;
     if (const char* e = getenv("SNNHIP_CONV_C8"))
-        if (taps == 1 && g.sh == 1 && g.sw == 1 && (atoi(e) == 4 || atoi(e) == 8) && g.IC >= 8 * atoi(e)) C8 = atoi(e);
-    const int ICc = 8 * C8;
+        if (taps == 1 && g.sh == 1 && g.sw == 1 && (atoi(e) == 4 || atoi(e) == 8) && g.IC >= 2 * CH * atoi(e)) C8 = atoi(e);
+    const int ICc = 2 * CH * C8;                                 // channels per LDS chunk: 16 fp32 / 32 fp16 (64 bytes per pixel either way)
 
     if (g.sw < 1 || g.sw > 2 || g.sh < 1 || g.sh > 2) return SNNHIP_E_UNSUPPORTED;
 
@@ -385,7 +412,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
             while ((g.sh * L.rowPitch) % 16 != TW % 16) ++L.rowPitch;
         L.imgPitch = round_up(L.tileH * L.rowPitch, 16);
         L.total = TB * L.tileH * L.tileW * (2 * C8);
-        L.ldsBytes = static_cast<size_t>(2) * TB * L.imgPitch * ICc * sizeof(float);
+        L.ldsBytes = static_cast<size_t>(2) * TB * L.imgPitch * (2 * C8) * 16;
         return L;
     };
     static const int shapes[][3] = {{0, 3, 4}, {0, 2, 5}, {0, 4, 3}, {1, 3, 3}, {2, 2, 3}, {3, 2, 2}, {0, 1, 6}, {0, 0, 7}};
@@ -415,7 +442,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.tilesY = up_div(g.OH, TH);
     p.nChunks = up_div(g.IC, ICc);
     p.total = L.total;
-    p.bufFloats = TB * L.imgPitch * ICc;
+    p.bufFloats = TB * L.imgPitch * (2 * C8) * 4;
     const int rNeed = up_div(p.total, 256);
     const int R = (rNeed <= 3 && C8 <= 2) ? 3 : ((rNeed <= 5 && C8 <= 4) ? 5 : 9);
     const size_t ldsBytes = L.ldsBytes;
@@ -457,9 +484,9 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     }
     const bool simple = act_is_simple(g.act);
     KernelFn fn = nullptr;
-    if (BN == 128) fn = pick_kernel<2, 2, 2, 2>(C8, R, simple);
-    if (BN == 64) fn = pick_kernel<2, 2, 2, 1>(C8, R, simple);
-    if (BN == 32) fn = pick_kernel<4, 1, 1, 1>(C8, R, simple);
+    if (BN == 128) fn = pick_kernel<2, 2, 2, 2>(C8, R, simple, f16);
+    if (BN == 64) fn = pick_kernel<2, 2, 2, 1>(C8, R, simple, f16);
+    if (BN == 32) fn = pick_kernel<4, 1, 1, 1>(C8, R, simple, f16);
     if (!fn) return SNNHIP_E_UNSUPPORTED;
 
     auto* plan = new MfmaConvPlan();
@@ -492,18 +519,25 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         }
     }
 
-    // weights: Wp[chunk][tap][c8][h][OCp][j], ic = chunk*ICc + c8*8 + h*4 + j (+ 4 zero steps: the prefetch ring reads up to 4 steps ahead)
+    // weights: Wp[chunk][tap][c8][h][OCp][j], ic = chunk*ICc + (c8*2 + h)*CH + j, j < CH (+ 4 zero steps: the prefetch ring reads up to 4
+    // steps ahead); 16 bytes per (h, oc): 4 floats or 8 halfs (fp32 -> fp16 rounds to nearest; weights that went through the reference's
+    // truncating convertToMediumPrecision are representable and convert exactly)
     const size_t steps = static_cast<size_t>(p.nChunks) * taps * C8;
-    std::vector<float> wpk((steps + 4) * 2 * p.OCp * 4, 0.0f);
+    std::vector<float> wpk((steps + 4) * 2 * p.OCp * 4, 0.0f); // 16 bytes per (step, h, oc) in both precisions
+    _Float16* wph = reinterpret_cast<_Float16*>(wpk.data());
     for (int chunk = 0; chunk < p.nChunks; ++chunk)
         for (int t = 0; t < taps; ++t)
             for (int c8 = 0; c8 < C8; ++c8)
                 for (int hh = 0; hh < 2; ++hh)
-                    for (int j = 0; j < 4; ++j) {
-                        const int ic = chunk * ICc + c8 * 8 + hh * 4 + j;
+                    for (int j = 0; j < CH; ++j) {
+                        const int ic = chunk * ICc + (c8 * 2 + hh) * CH + j;
                         if (ic >= g.IC) continue;
                         const size_t base = (((static_cast<size_t>(chunk) * taps + t) * C8 + c8) * 2 + hh) * p.OCp;
-                        for (int o = 0; o < g.OC; ++o) wpk[(base + o) * 4 + j] = w_oihw[(static_cast<size_t>(o) * g.IC + ic) * taps + t];
+                        for (int o = 0; o < g.OC; ++o) {
+                            const float wv = w_oihw[(static_cast<size_t>(o) * g.IC + ic) * taps + t];
+                            if (f16) wph[(base + o) * 8 + j] = static_cast<_Float16>(wv);
+                            else wpk[(base + o) * 4 + j] = wv;
+                        }
                     }
     std::vector<float> epiP(static_cast<size_t>(p.OCp) * 4, 0.0f);
     std::memcpy(epiP.data(), epi4.data(), sizeof(float) * 4 * static_cast<size_t>(g.OC));
@@ -519,8 +553,11 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC +
                          static_cast<double>(g.OC) * g.IC * taps);
     char buf[256];
-    snprintf(buf, sizeof(buf), "conv2d_mfma_f32_32x32x2 k=%dx%d s=%d ic=%d oc=%d tile=%dx%dx%dpx x %doc chunk=%d lds=%zuB splitK=%d", g.kh, g.kw, g.sh,
-             g.IC, g.OC, TB, TH, TW, BN, ICc, ldsBytes, p.splitK);
+    snprintf(buf, sizeof(buf), "conv2d_mfma_%s k=%dx%d s=%d ic=%d oc=%d tile=%dx%dx%dpx x %doc chunk=%d lds=%zuB splitK=%d",
+             f16 ? "f16_32x32x16" : "f32_32x32x2", g.kh, g.kw, g.sh, g.IC, g.OC, TB, TH, TW, BN, ICc, ldsBytes, p.splitK);
+    plan->dtype = g.dtype;
+    const double esz = f16 ? 2.0 : 4.0;
+    plan->bytes = esz * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * taps);
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

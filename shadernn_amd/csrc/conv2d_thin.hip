@@ -201,6 +201,7 @@ int make_conv2d_thin_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     const char* force = getenv("SNNHIP_CONV");
     if (force && strcmp(force, "thin") != 0) return SNNHIP_E_UNSUPPORTED; // generic / mfma forced
     if (g.OC > 4 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
+    if (g.dtype != SNNHIP_F32) return SNNHIP_E_UNSUPPORTED; // fp16 tensors: conv2d_mfma takes every shape (OC padded to 32)
     if (!force && g.IC < 8) return SNNHIP_E_UNSUPPORTED; // a handful of input channels: the VALU kernel is as good
     ThinParams p{};
     p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.kh = g.kh; p.kw = g.kw; p.padx = g.padx; p.pady = g.pady;

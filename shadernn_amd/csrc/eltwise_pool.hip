@@ -16,41 +16,76 @@ __device__ __forceinline__ float4 act4(int act, float leaky, float4 v) {
     return make_float4(act1(act, leaky, v.x), act1(act, leaky, v.y), act1(act, leaky, v.z), act1(act, leaky, v.w));
 }
 
-// ------------------------------------------------------------------------------------------------ add / activation / batch-norm
-// mode 0: y = act(a + b)   mode 1: y = act(a)   mode 2: y = act(scale[c] * (a - mean[c]) + beta[c]),  tab[c] = {scale, mean, beta, 0}
-template <int MODE, bool VEC>
-__global__ __launch_bounds__(256) void eltwise_kernel(size_t count, int C, int act, float leaky, const float* __restrict__ a,
-                                                     const float* __restrict__ b, const float4* __restrict__ tab, float* __restrict__ y) {
-    const size_t stride = static_cast<size_t>(gridDim.x) * 256;
-    if (VEC) {
-        const size_t n4 = count >> 2;
-        const int c4 = C >> 2;
-        for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += stride) {
-            float4 v = reinterpret_cast<const float4*>(a)[i];
-            if (MODE == 0) {
-                const float4 w = reinterpret_cast<const float4*>(b)[i];
-                v = make_float4(v.x + w.x, v.y + w.y, v.z + w.z, v.w + w.w);
-            }
-            if (MODE == 2) {
-                const int c = static_cast<int>(i % c4) * 4;
-                const float4 t0 = tab[c], t1 = tab[c + 1], t2 = tab[c + 2], t3 = tab[c + 3];
-                v.x = t0.x * (v.x - t0.y) + t0.z;
-                v.y = t1.x * (v.y - t1.y) + t1.z;
-                v.z = t2.x * (v.z - t2.y) + t2.z;
-                v.w = t3.x * (v.w - t3.y) + t3.z;
-            }
-            reinterpret_cast<float4*>(y)[i] = act4(act, leaky, v);
+// Element access: every kernel is instantiated for T = float and T = _Float16 (SNNHIP_F16 tensors: half storage, fp32 arithmetic,
+// round-to-nearest-even on store) and for CV = 4 (C % 4 == 0: one 16- or 8-byte access) or CV = 1.
+template <typename T, int CV>
+__device__ __forceinline__ void ldv(const T* __restrict__ p, float (&v)[CV]) {
+    if (CV == 4) {
+        if (sizeof(T) == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] = t.x;
+            v[1 % CV] = t.y;
+            v[2 % CV] = t.z;
+            v[3 % CV] = t.w;
+        } else {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 t = *reinterpret_cast<const h4*>(p);
+            v[0] = static_cast<float>(t[0]);
+            v[1 % CV] = static_cast<float>(t[1]);
+            v[2 % CV] = static_cast<float>(t[2]);
+            v[3 % CV] = static_cast<float>(t[3]);
         }
     } else {
-        for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += stride) {
-            float v = a[i];
-            if (MODE == 0) v += b[i];
-            if (MODE == 2) {
-                const float4 t = tab[i % C];
-                v = t.x * (v - t.y) + t.z;
-            }
-            y[i] = act1(act, leaky, v);
+        v[0] = static_cast<float>(p[0]);
+    }
+}
+template <typename T, int CV>
+__device__ __forceinline__ void stv(T* __restrict__ p, const float (&v)[CV]) {
+    if (CV == 4) {
+        if (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % CV], v[2 % CV], v[3 % CV]);
+        } else {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 t;
+            t[0] = static_cast<_Float16>(v[0]);
+            t[1] = static_cast<_Float16>(v[1 % CV]);
+            t[2] = static_cast<_Float16>(v[2 % CV]);
+            t[3] = static_cast<_Float16>(v[3 % CV]);
+            *reinterpret_cast<h4*>(p) = t;
         }
+    } else {
+        p[0] = static_cast<T>(v[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ add / activation / batch-norm
+// mode 0: y = act(a + b)   mode 1: y = act(a)   mode 2: y = act(scale[c] * (a - mean[c]) + beta[c]),  tab[c] = {scale, mean, beta, 0}
+template <int MODE, int CV, typename T>
+__global__ __launch_bounds__(256) void eltwise_kernel(size_t count, int C, int act, float leaky, const T* __restrict__ a, const T* __restrict__ b,
+                                                     const float4* __restrict__ tab, T* __restrict__ y) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+    const size_t ng = count / CV;
+    const int cg = C / CV;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < ng; i += stride) {
+        float v[CV];
+        ldv<T, CV>(a + i * CV, v);
+        if (MODE == 0) {
+            float w[CV];
+            ldv<T, CV>(b + i * CV, w);
+#pragma unroll
+            for (int k = 0; k < CV; ++k) v[k] += w[k];
+        }
+        if (MODE == 2) {
+            const int c = static_cast<int>(i % cg) * CV;
+#pragma unroll
+            for (int k = 0; k < CV; ++k) {
+                const float4 t = tab[c + k];
+                v[k] = t.x * (v[k] - t.y) + t.z;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CV; ++k) v[k] = act1(act, leaky, v[k]);
+        stv<T, CV>(y + i * CV, v);
     }
 }
 
@@ -59,9 +94,9 @@ __global__ __launch_bounds__(256) void eltwise_kernel(size_t count, int C, int a
 // return 0 (addlayerVulkan.cpp:44-46,89-91; vk_add.comp:47-49).  Candy's residual blocks rely on this: a Pad + "valid" conv branch is
 // 4 pixels larger than its skip under the reference's size rule.  Outside the first input's extent the reference leaves
 // the texture untouched (undefined); zeros are written here.
-template <int CV>
+template <int CV, typename T>
 __global__ __launch_bounds__(256) void add_ragged_kernel(int N, int H, int W, int C, int H0, int W0, int H1, int W1, int act, float leaky,
-                                                        const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y) {
+                                                        const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y) {
     const int cg = C / CV;
     const size_t total = static_cast<size_t>(N) * H * W * cg;
     for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
@@ -74,25 +109,26 @@ __global__ __launch_bounds__(256) void add_ragged_kernel(int N, int H, int W, in
         const bool in0 = oy < H0 && ox < W0, in1 = oy < H1 && ox < W1;
         float v[CV];
 #pragma unroll
-        for (int k = 0; k < CV; ++k) {
-            float s = 0.0f;
-            if (in0) {
-                s = a[((static_cast<size_t>(n) * H0 + oy) * W0 + ox) * C + c + k];
-                if (in1) s += b[((static_cast<size_t>(n) * H1 + oy) * W1 + ox) * C + c + k];
-                s = act1(act, leaky, s);
-            }
-            v[k] = s;
-        }
-        float* dst = y + ((static_cast<size_t>(n) * H + oy) * W + ox) * C + c;
+        for (int k = 0; k < CV; ++k) v[k] = 0.0f;
+        if (in0) {
+            ldv<T, CV>(a + ((static_cast<size_t>(n) * H0 + oy) * W0 + ox) * C + c, v);
+            if (in1) {
+                float w[CV];
+                ldv<T, CV>(b + ((static_cast<size_t>(n) * H1 + oy) * W1 + ox) * C + c, w);
 #pragma unroll
-        for (int k = 0; k < CV; ++k) dst[k] = v[k];
+                for (int k = 0; k < CV; ++k) v[k] += w[k];
+            }
+#pragma unroll
+            for (int k = 0; k < CV; ++k) v[k] = act1(act, leaky, v[k]);
+        }
+        stv<T, CV>(y + ((static_cast<size_t>(n) * H + oy) * W + ox) * C + c, v);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
 // one thread = one output pixel x CV channels; window clipped to the image exactly as the shader does
-template <int TYPE, int CV>
-__global__ __launch_bounds__(256) void pool2d_kernel(snnhip_pool2d_desc d, const float* __restrict__ x, float* __restrict__ y) {
+template <int TYPE, int CV, typename T>
+__global__ __launch_bounds__(256) void pool2d_kernel(snnhip_pool2d_desc d, const T* __restrict__ x, T* __restrict__ y) {
     const int cg = d.C / CV;
     const size_t total = static_cast<size_t>(d.N) * d.OH * d.OW * cg;
     for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
@@ -111,17 +147,8 @@ __global__ __launch_bounds__(256) void pool2d_kernel(snnhip_pool2d_desc d, const
         float num = 0.0f;
         for (int fy = fy0; fy < fy1; ++fy)
             for (int fx = fx0; fx < fx1; ++fx) {
-                const float* src = x + ((static_cast<size_t>(n) * d.H + sy + fy) * d.W + sx + fx) * d.C + c;
                 float v[CV];
-                if (CV == 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(src);
-                    v[0] = t.x;
-                    v[1 % CV] = t.y;
-                    v[2 % CV] = t.z;
-                    v[3 % CV] = t.w;
-                } else {
-                    v[0] = src[0];
-                }
+                ldv<T, CV>(x + ((static_cast<size_t>(n) * d.H + sy + fy) * d.W + sx + fx) * d.C + c, v);
 #pragma unroll
                 for (int k = 0; k < CV; ++k) acc[k] = TYPE == SNNHIP_POOL_MAX ? fmaxf(acc[k], v[k]) : acc[k] + v[k];
                 num += 1.0f;
@@ -130,18 +157,13 @@ __global__ __launch_bounds__(256) void pool2d_kernel(snnhip_pool2d_desc d, const
 #pragma unroll
             for (int k = 0; k < CV; ++k) acc[k] = acc[k] / num; // an empty window divides 0 by 0 like the shader (vk_avgpool2d.comp:66)
         }
-        float* dst = y + ((static_cast<size_t>(n) * d.OH + oy) * d.OW + ox) * d.C + c;
-        if (CV == 4) {
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1 % CV], acc[2 % CV], acc[3 % CV]);
-        } else {
-            dst[0] = acc[0];
-        }
+        stv<T, CV>(y + ((static_cast<size_t>(n) * d.OH + oy) * d.OW + ox) * d.C + c, acc);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ pad
-template <int CV>
-__global__ __launch_bounds__(256) void pad_kernel(snnhip_pad_desc d, int OH, int OW, const float* __restrict__ x, float* __restrict__ y) {
+template <int CV, typename T>
+__global__ __launch_bounds__(256) void pad_kernel(snnhip_pad_desc d, int OH, int OW, const T* __restrict__ x, T* __restrict__ y) {
     const int cg = d.C / CV;
     const size_t total = static_cast<size_t>(d.N) * OH * OW * cg;
     for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
@@ -165,20 +187,17 @@ __global__ __launch_bounds__(256) void pad_kernel(snnhip_pad_desc d, int OH, int
             sy = sy >= d.H ? 2 * d.H - 2 - sy : sy;
             zero = !(sx >= 0 && sx < d.W && sy >= 0 && sy < d.H); // pads wider than the image leave the texture range
         }
-        float* dst = y + ((static_cast<size_t>(n) * OH + oy) * OW + ox) * d.C + c;
-        const float* src = x + ((static_cast<size_t>(n) * d.H + sy) * d.W + sx) * d.C + c;
-        if (CV == 4) {
-            *reinterpret_cast<float4*>(dst) = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(src);
-        } else {
-            dst[0] = zero ? 0.0f : src[0];
-        }
+        float v[CV];
+#pragma unroll
+        for (int k = 0; k < CV; ++k) v[k] = 0.0f;
+        if (!zero) ldv<T, CV>(x + ((static_cast<size_t>(n) * d.H + sy) * d.W + sx) * d.C + c, v);
+        stv<T, CV>(y + ((static_cast<size_t>(n) * OH + oy) * OW + ox) * d.C + c, v);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ upsampling
-template <int MODE, int CV>
-__global__ __launch_bounds__(256) void upsample_kernel(snnhip_upsample_desc d, int OH, int OW, float inv, const float* __restrict__ x,
-                                                      float* __restrict__ y) {
+template <int MODE, int CV, typename T>
+__global__ __launch_bounds__(256) void upsample_kernel(snnhip_upsample_desc d, int OH, int OW, float inv, const T* __restrict__ x, T* __restrict__ y) {
     const int cg = d.C / CV;
     const size_t total = static_cast<size_t>(d.N) * OH * OW * cg;
     for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
@@ -188,20 +207,13 @@ __global__ __launch_bounds__(256) void upsample_kernel(snnhip_upsample_desc d, i
         r /= OW;
         const int oy = static_cast<int>(r % OH);
         const int n = static_cast<int>(r / OH);
-        const float* xn = x + static_cast<size_t>(n) * d.H * d.W * d.C + c;
+        const T* xn = x + static_cast<size_t>(n) * d.H * d.W * d.C + c;
         float o[CV];
         auto fetch = [&](int px, int py, float (&v)[CV]) { // texelFetch outside the texture returns 0
             const bool ok = px >= 0 && px < d.W && py >= 0 && py < d.H;
-            const float* src = xn + (static_cast<size_t>(ok ? py : 0) * d.W + (ok ? px : 0)) * d.C;
-            if (CV == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(src);
-                v[0] = ok ? t.x : 0.0f;
-                v[1 % CV] = ok ? t.y : 0.0f;
-                v[2 % CV] = ok ? t.z : 0.0f;
-                v[3 % CV] = ok ? t.w : 0.0f;
-            } else {
-                v[0] = ok ? src[0] : 0.0f;
-            }
+#pragma unroll
+            for (int k = 0; k < CV; ++k) v[k] = 0.0f;
+            if (ok) ldv<T, CV>(xn + (static_cast<size_t>(py) * d.W + px) * d.C, v);
         };
         if (MODE == SNNHIP_UPSAMPLE_NEAREST) {
             const int x1 = min(max(static_cast<int>(floorf(static_cast<float>(ox) * inv)), 0), d.W - 1);
@@ -227,12 +239,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(snnhip_upsample_desc d, i
 #pragma unroll
             for (int k = 0; k < CV; ++k) o[k] = r1[k] * w1 + r2[k] * w2 + r3[k] * w3 + r4[k] * w4;
         }
-        float* dst = y + ((static_cast<size_t>(n) * OH + oy) * OW + ox) * d.C + c;
-        if (CV == 4) {
-            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1 % CV], o[2 % CV], o[3 % CV]);
-        } else {
-            dst[0] = o[0];
-        }
+        stv<T, CV>(y + ((static_cast<size_t>(n) * OH + oy) * OW + ox) * d.C + c, o);
     }
 }
 
@@ -244,10 +251,10 @@ __global__ __launch_bounds__(256) void upsample_kernel(snnhip_upsample_desc d, i
 // CL*CV >= min(C, 128) so that one wave instruction reads whole pixels (contiguous C*4 bytes) instead of half-lines.
 // Partials go to part[n][s][2][C]; a tiny fold kernel turns them into mean[n][C] and mul[n][C] in a fixed order (deterministic).
 // STAGE 0: partial S1, S2      STAGE 2: y = act((x - mean) * mul + beta)
-template <int STAGE, int CV>
-__global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int rowsPerSlab, int CLs, const float* __restrict__ x,
+template <int STAGE, int CV, typename T>
+__global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int rowsPerSlab, int CLs, const T* __restrict__ x,
                                                           const float* __restrict__ statMean, const float* __restrict__ statMul,
-                                                          const float* __restrict__ beta, float* __restrict__ partOut, float* __restrict__ y) {
+                                                          const float* __restrict__ beta, float* __restrict__ partOut, T* __restrict__ y) {
     __shared__ float red[2 * 256 * CV];
     const int n = blockIdx.x / S, s = blockIdx.x % S;
     const int tid = threadIdx.x;
@@ -255,14 +262,14 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
     const int cl = tid & (CL - 1), pl = tid >> CLs;
     const int r0 = s * rowsPerSlab, r1 = min(d.H, r0 + rowsPerSlab);
     const size_t p0 = static_cast<size_t>(r0) * d.W, p1 = static_cast<size_t>(r1) * d.W;
-    const float* xn = x + static_cast<size_t>(n) * d.H * d.W * d.C;
+    const T* xn = x + static_cast<size_t>(n) * d.H * d.W * d.C;
     for (int c0 = 0; c0 < d.C; c0 += CL * CV) {
         const int c = c0 + cl * CV;
         const bool cok = c < d.C;
         float piv[CV], mul[CV], bt[CV];
 #pragma unroll
         for (int k = 0; k < CV; ++k) {
-            piv[k] = cok ? (STAGE == 0 ? xn[c + k] : statMean[static_cast<size_t>(n) * d.C + c + k]) : 0.0f; // stage 0: pivot, stage 2: mean
+            piv[k] = cok ? (STAGE == 0 ? static_cast<float>(xn[c + k]) : statMean[static_cast<size_t>(n) * d.C + c + k]) : 0.0f; // stage 0: pivot, stage 2: mean
             mul[k] = (STAGE == 2 && cok) ? statMul[static_cast<size_t>(n) * d.C + c + k] : 0.0f;
             bt[k] = (STAGE == 2 && cok) ? beta[c + k] : 0.0f;
         }
@@ -272,16 +279,7 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
         if (cok) {
             for (size_t p = p0 + pl; p < p1; p += PL) {
                 float v[CV];
-                const float* src = xn + p * d.C + c;
-                if (CV == 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(src);
-                    v[0] = t.x;
-                    v[1 % CV] = t.y;
-                    v[2 % CV] = t.z;
-                    v[3 % CV] = t.w;
-                } else {
-                    v[0] = src[0];
-                }
+                ldv<T, CV>(xn + p * d.C + c, v);
                 if (STAGE == 0) {
 #pragma unroll
                     for (int k = 0; k < CV; ++k) {
@@ -293,12 +291,7 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
                     float o[CV];
 #pragma unroll
                     for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, (v[k] - piv[k]) * mul[k] + bt[k]);
-                    float* dst = y + (static_cast<size_t>(n) * d.H * d.W + p) * d.C + c;
-                    if (CV == 4) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1 % CV], o[2 % CV], o[3 % CV]);
-                    } else {
-                        dst[0] = o[0];
-                    }
+                    stv<T, CV>(y + (static_cast<size_t>(n) * d.H * d.W + p) * d.C + c, o);
                 }
             }
         }
@@ -329,7 +322,8 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
 }
 
 // mean[n][c] = p + S1/HW,  mul[n][c] = gamma[c] / sqrt(S2/HW - (S1/HW)^2 + eps)   with S1, S2 summed over the slabs in order
-__global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, int S, int HW, float invHW, float eps, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, int S, int HW, float invHW, float eps, const T* __restrict__ x,
                                                                const float* __restrict__ part, const float* __restrict__ gamma,
                                                                float* __restrict__ mean, float* __restrict__ mul) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -341,7 +335,7 @@ __global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, i
         a1 += po[c];
         a2 += po[C + c];
     }
-    const float piv = x[static_cast<size_t>(n) * HW * C + c];
+    const float piv = static_cast<float>(x[static_cast<size_t>(n) * HW * C + c]);
     const float m1 = a1 * invHW;
     float var = a2 * invHW - m1 * m1;
     var = var > 0.0f ? var : 0.0f;
@@ -359,6 +353,27 @@ unsigned grid_for(const snnhip_ctx* ctx, size_t items) {
 
 bool dims_match(const snnhip_tensor* t, int n, int h, int w, int c) { return t->n == n && t->h == h && t->w == w && t->c == c; }
 
+// These plans take their element type from the tensors they are run on (fp32 or fp16, all tensors of one call alike).
+#define SNNHIP_SAME_DTYPE(what)                                                                                                   \
+    do {                                                                                                                          \
+        for (int _i = 0; _i < nIn; ++_i)                                                                                          \
+            SNNHIP_REQUIRE(in[_i]->dtype == out->dtype, "%s: input %d has dtype %d, output %d", what, _i, in[_i]->dtype, out->dtype); \
+    } while (0)
+#define SNNHIP_WITH_T(DT, ...)        \
+    do {                              \
+        if ((DT) == SNNHIP_F16) {     \
+            typedef _Float16 T;       \
+            __VA_ARGS__               \
+        } else {                      \
+            typedef float T;          \
+            __VA_ARGS__               \
+        }                             \
+    } while (0)
+template <typename T>
+const T* cptr(const snnhip_tensor* t) { return reinterpret_cast<const T*>(t->data); }
+template <typename T>
+T* mptr(snnhip_tensor* t) { return reinterpret_cast<T*>(t->data); }
+
 struct EltwisePlan : snnhip_plan {
     snnhip_eltwise_desc d;
     int mode = 0;
@@ -366,20 +381,20 @@ struct EltwisePlan : snnhip_plan {
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         const int want = mode == 0 ? 2 : 1;
         SNNHIP_REQUIRE(nIn == want, "%s: expects %d input(s), got %d", desc.c_str(), want, nIn);
+        SNNHIP_SAME_DTYPE(desc.c_str());
+        const bool v4 = (d.C & 3) == 0;
         if (mode == 0 && !(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(in[1], d.N, d.H, d.W, d.C))) {
             // inputs of different extent: output = the plan's dims = max over the inputs (see add_ragged_kernel)
             for (int i = 0; i < 2; ++i)
                 SNNHIP_REQUIRE(in[i]->n == d.N && in[i]->c == d.C && in[i]->h <= d.H && in[i]->w <= d.W, "%s: input %d dims %dx%dx%dx%d do not fit %dx%dx%dx%d",
                                desc.c_str(), i, in[i]->n, in[i]->h, in[i]->w, in[i]->c, d.N, d.H, d.W, d.C);
             SNNHIP_REQUIRE(dims_match(out, d.N, d.H, d.W, d.C), "%s: output dims mismatch", desc.c_str());
-            const bool v4 = (d.C & 3) == 0;
             const unsigned gg = grid_for(ctx, out->count() / (v4 ? 4 : 1));
-            if (v4)
-                hipLaunchKernelGGL((add_ragged_kernel<4>), dim3(gg), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, in[0]->h, in[0]->w, in[1]->h, in[1]->w, d.act,
-                                   d.leaky, in[0]->data, in[1]->data, out->data);
-            else
-                hipLaunchKernelGGL((add_ragged_kernel<1>), dim3(gg), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, in[0]->h, in[0]->w, in[1]->h, in[1]->w, d.act,
-                                   d.leaky, in[0]->data, in[1]->data, out->data);
+            SNNHIP_WITH_T(out->dtype,
+                if (v4) hipLaunchKernelGGL((add_ragged_kernel<4, T>), dim3(gg), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, in[0]->h, in[0]->w, in[1]->h,
+                                           in[1]->w, d.act, d.leaky, cptr<T>(in[0]), cptr<T>(in[1]), mptr<T>(out));
+                else hipLaunchKernelGGL((add_ragged_kernel<1, T>), dim3(gg), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, in[0]->h, in[0]->w, in[1]->h,
+                                        in[1]->w, d.act, d.leaky, cptr<T>(in[0]), cptr<T>(in[1]), mptr<T>(out)););
             SNNHIP_CHECK_HIP(hipGetLastError());
             return SNNHIP_OK;
         }
@@ -390,15 +405,14 @@ struct EltwisePlan : snnhip_plan {
         SNNHIP_REQUIRE(out->n == d.N && out->count() == in[0]->count(), "%s: output %dx%dx%dx%d is not a reshape of the input", desc.c_str(), out->n,
                        out->h, out->w, out->c);
         const size_t count = out->count();
-        const bool vec = (d.C & 3) == 0;
-        const unsigned g = grid_for(ctx, vec ? count / 4 : count);
-        const float* b = mode == 0 ? in[1]->data : nullptr;
+        const unsigned g = grid_for(ctx, v4 ? count / 4 : count);
         const float4* tab = reinterpret_cast<const float4*>(d_tab);
-#define SNNHIP_ELT(M)                                                                                                                       \
-    if (vec)                                                                                                                                \
-        hipLaunchKernelGGL((eltwise_kernel<M, true>), dim3(g), dim3(256), 0, ctx->stream, count, d.C, d.act, d.leaky, in[0]->data, b, tab, out->data); \
-    else                                                                                                                                    \
-        hipLaunchKernelGGL((eltwise_kernel<M, false>), dim3(g), dim3(256), 0, ctx->stream, count, d.C, d.act, d.leaky, in[0]->data, b, tab, out->data)
+#define SNNHIP_ELT(M)                                                                                                                            \
+    SNNHIP_WITH_T(out->dtype, const T* bb = M == 0 ? cptr<T>(in[1]) : nullptr;                                                                   \
+                  if (v4) hipLaunchKernelGGL((eltwise_kernel<M, 4, T>), dim3(g), dim3(256), 0, ctx->stream, count, d.C, d.act, d.leaky, cptr<T>(in[0]), bb, \
+                                             tab, mptr<T>(out));                                                                                 \
+                  else hipLaunchKernelGGL((eltwise_kernel<M, 1, T>), dim3(g), dim3(256), 0, ctx->stream, count, d.C, d.act, d.leaky, cptr<T>(in[0]), bb, tab, \
+                                          mptr<T>(out));)
         if (mode == 0) {
             SNNHIP_ELT(0);
         } else if (mode == 1) {
@@ -415,6 +429,7 @@ struct EltwisePlan : snnhip_plan {
 int make_eltwise(snnhip_ctx* ctx, const snnhip_eltwise_desc* d, int mode, const std::vector<float>* tab, const char* name, snnhip_plan** out) {
     auto* plan = new EltwisePlan();
     plan->ctx = ctx;
+    plan->anyDtype = true;
     plan->d = *d;
     plan->mode = mode;
     plan->numInputs = mode == 0 ? 2 : 1;
@@ -441,19 +456,22 @@ struct PoolPlan : snnhip_plan {
     snnhip_pool2d_desc d;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "pool2d: expects 1 input, got %d", nIn);
+        SNNHIP_SAME_DTYPE("pool2d");
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C), "pool2d: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", in[0]->n, in[0]->h, in[0]->w,
                        in[0]->c, d.N, d.H, d.W, d.C);
         SNNHIP_REQUIRE(dims_match(out, d.N, d.OH, d.OW, d.C), "pool2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, d.N,
                        d.OH, d.OW, d.C);
         const bool vec = (d.C & 3) == 0;
         const unsigned g = grid_for(ctx, out->count() / (vec ? 4 : 1));
+#define SNNHIP_POOL(TY)                                                                                                                   \
+    SNNHIP_WITH_T(out->dtype, if (vec) hipLaunchKernelGGL((pool2d_kernel<TY, 4, T>), dim3(g), dim3(256), 0, ctx->stream, d, cptr<T>(in[0]), mptr<T>(out)); \
+                  else hipLaunchKernelGGL((pool2d_kernel<TY, 1, T>), dim3(g), dim3(256), 0, ctx->stream, d, cptr<T>(in[0]), mptr<T>(out));)
         if (d.type == SNNHIP_POOL_MAX) {
-            if (vec) hipLaunchKernelGGL((pool2d_kernel<SNNHIP_POOL_MAX, 4>), dim3(g), dim3(256), 0, ctx->stream, d, in[0]->data, out->data);
-            else hipLaunchKernelGGL((pool2d_kernel<SNNHIP_POOL_MAX, 1>), dim3(g), dim3(256), 0, ctx->stream, d, in[0]->data, out->data);
+            SNNHIP_POOL(SNNHIP_POOL_MAX);
         } else {
-            if (vec) hipLaunchKernelGGL((pool2d_kernel<SNNHIP_POOL_AVG, 4>), dim3(g), dim3(256), 0, ctx->stream, d, in[0]->data, out->data);
-            else hipLaunchKernelGGL((pool2d_kernel<SNNHIP_POOL_AVG, 1>), dim3(g), dim3(256), 0, ctx->stream, d, in[0]->data, out->data);
+            SNNHIP_POOL(SNNHIP_POOL_AVG);
         }
+#undef SNNHIP_POOL
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -464,11 +482,12 @@ struct PadPlan : snnhip_plan {
     int OH = 0, OW = 0;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "pad: expects 1 input, got %d", nIn);
+        SNNHIP_SAME_DTYPE("pad");
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, OH, OW, d.C), "pad: tensor dims do not match the plan");
         const bool vec = (d.C & 3) == 0;
         const unsigned g = grid_for(ctx, out->count() / (vec ? 4 : 1));
-        if (vec) hipLaunchKernelGGL((pad_kernel<4>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, in[0]->data, out->data);
-        else hipLaunchKernelGGL((pad_kernel<1>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, in[0]->data, out->data);
+        SNNHIP_WITH_T(out->dtype, if (vec) hipLaunchKernelGGL((pad_kernel<4, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, cptr<T>(in[0]), mptr<T>(out));
+                      else hipLaunchKernelGGL((pad_kernel<1, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, cptr<T>(in[0]), mptr<T>(out)););
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -479,13 +498,15 @@ struct UpsamplePlan : snnhip_plan {
     int OH = 0, OW = 0;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "upsample: expects 1 input, got %d", nIn);
+        SNNHIP_SAME_DTYPE("upsample");
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, OH, OW, d.C), "upsample: tensor dims do not match the plan");
         const bool vec = (d.C & 3) == 0;
         const unsigned g = grid_for(ctx, out->count() / (vec ? 4 : 1));
         const float inv = 1.0f / d.scale; // upsampling2dVulkan.cpp:101
-#define SNNHIP_UP(M)                                                                                                                  \
-    if (vec) hipLaunchKernelGGL((upsample_kernel<M, 4>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, inv, in[0]->data, out->data); \
-    else hipLaunchKernelGGL((upsample_kernel<M, 1>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, inv, in[0]->data, out->data)
+#define SNNHIP_UP(M)                                                                                                                          \
+    SNNHIP_WITH_T(out->dtype,                                                                                                                 \
+                  if (vec) hipLaunchKernelGGL((upsample_kernel<M, 4, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, inv, cptr<T>(in[0]), mptr<T>(out)); \
+                  else hipLaunchKernelGGL((upsample_kernel<M, 1, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, inv, cptr<T>(in[0]), mptr<T>(out));)
         if (d.mode == SNNHIP_UPSAMPLE_NEAREST) {
             SNNHIP_UP(SNNHIP_UPSAMPLE_NEAREST);
         } else {
@@ -503,16 +524,17 @@ struct InstanceNormPlan : snnhip_plan {
     float *d_beta = nullptr, *d_gamma = nullptr, *d_part = nullptr, *d_mean = nullptr, *d_mul = nullptr;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "instancenorm: expects 1 input, got %d", nIn);
+        SNNHIP_SAME_DTYPE("instancenorm");
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, d.H, d.W, d.C), "instancenorm: tensor dims do not match the plan");
         const dim3 g(static_cast<unsigned>(d.N * S));
         const int NC = d.N * d.C, HW = d.H * d.W;
         const dim3 gf(static_cast<unsigned>((NC + 255) / 256));
         const float invHW = 1.0f / (static_cast<float>(d.H) * static_cast<float>(d.W));
 #define SNNHIP_IN(ST, CVV) \
-    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV>), g, dim3(256), 0, ctx->stream, d, S, rowsPerSlab, CLs, in[0]->data, d_mean, d_mul, d_beta, d_part, out->data)
+    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV, T>), g, dim3(256), 0, ctx->stream, d, S, rowsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta, d_part, mptr<T>(out))
 #define SNNHIP_FOLD() \
-    hipLaunchKernelGGL(instancenorm_fold_kernel, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, in[0]->data, d_part, d_gamma, d_mean, d_mul)
-        if ((d.C & 3) == 0) {
+    hipLaunchKernelGGL(instancenorm_fold_kernel<T>, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, cptr<T>(in[0]), d_part, d_gamma, d_mean, d_mul)
+        SNNHIP_WITH_T(out->dtype, if ((d.C & 3) == 0) {
             SNNHIP_IN(0, 4);
             SNNHIP_FOLD();
             SNNHIP_IN(2, 4);
@@ -520,7 +542,7 @@ struct InstanceNormPlan : snnhip_plan {
             SNNHIP_IN(0, 1);
             SNNHIP_FOLD();
             SNNHIP_IN(2, 1);
-        }
+        });
 #undef SNNHIP_IN
 #undef SNNHIP_FOLD
         SNNHIP_CHECK_HIP(hipGetLastError());
@@ -576,6 +598,7 @@ int snnhip_pool2d_plan_create(snnhip_ctx* ctx, const snnhip_pool2d_desc* desc, s
     SNNHIP_REQUIRE(desc->padT >= 0 && desc->padL >= 0, "pool2d desc: negative padding");
     auto* plan = new PoolPlan();
     plan->ctx = ctx;
+    plan->anyDtype = true;
     plan->d = *desc;
     auto outdim = [&](int in, int k, int s) { // maxpool2d.cpp:26-36 / avgpool2d.cpp:20-29 through genericlayer.cpp:64-90 (max(0, translation))
         const float scale = 1.0f / static_cast<float>(s);
@@ -610,6 +633,7 @@ int snnhip_pad_plan_create(snnhip_ctx* ctx, const snnhip_pad_desc* desc, snnhip_
     SNNHIP_REQUIRE(desc->mode >= 0 && desc->mode <= 2, "pad desc: mode %d", desc->mode);
     auto* plan = new PadPlan();
     plan->ctx = ctx;
+    plan->anyDtype = true;
     plan->d = *desc;
     plan->OH = desc->H + desc->padT + desc->padB;
     plan->OW = desc->W + desc->padL + desc->padR;
@@ -630,6 +654,7 @@ int snnhip_upsample_plan_create(snnhip_ctx* ctx, const snnhip_upsample_desc* des
     SNNHIP_REQUIRE(desc->mode == SNNHIP_UPSAMPLE_NEAREST || desc->mode == SNNHIP_UPSAMPLE_BILINEAR, "upsample desc: mode %d", desc->mode);
     auto* plan = new UpsamplePlan();
     plan->ctx = ctx;
+    plan->anyDtype = true;
     plan->d = *desc;
     plan->OH = static_cast<int>(static_cast<unsigned>(desc->scale * static_cast<float>(desc->H))); // genericlayer.cpp:76-77, translation 0
     plan->OW = static_cast<int>(static_cast<unsigned>(desc->scale * static_cast<float>(desc->W)));
@@ -655,6 +680,7 @@ int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_d
     SNNHIP_REQUIRE(desc->act >= SNNHIP_ACT_NONE && desc->act <= SNNHIP_ACT_SILU, "instancenorm desc: activation id %d", desc->act);
     auto* plan = new InstanceNormPlan();
     plan->ctx = ctx;
+    plan->anyDtype = true;
     plan->d = *desc;
     // row slabs: enough blocks to cover the chip about 8 times (HBM-bound sweeps want many waves in flight)
     const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;

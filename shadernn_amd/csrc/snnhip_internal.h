@@ -63,7 +63,10 @@ struct snnhip_tensor {
     float* data = nullptr;
     bool owns = false;
     int n = 0, h = 0, w = 0, c = 0;
+    int dtype = SNNHIP_F32; // SNNHIP_F16: `data` points at halfs
     size_t count() const { return static_cast<size_t>(n) * h * w * c; }
+    size_t elemSize() const { return dtype == SNNHIP_F16 ? 2 : 4; }
+    size_t bytes() const { return count() * elemSize(); }
 };
 
 struct snnhip_graph {
@@ -85,6 +88,8 @@ struct snnhip_plan {
     int inDims[4] = {0, 0, 0, 0};   // N,H,W,C of input 0
     int outDims[4] = {0, 0, 0, 0};
     int numInputs = 1;
+    int dtype = SNNHIP_F32;   // element type of the tensors this plan runs on ...
+    bool anyDtype = false;    // ... unless it adapts to the tensors of each call (element-wise / pooling / shape operators)
     std::string desc;
     double flops = 0, bytes = 0;
     std::vector<void*> deviceAllocs; // freed in the destructor
@@ -137,6 +142,7 @@ struct ConvGeom {
     int padMode, act, useBN;
     float leaky;
     int OH, OW;
+    int dtype; // SNNHIP_F32 | SNNHIP_F16
 };
 int resolve_conv_geom(const snnhip_conv2d_desc* d, bool depthwise, ConvGeom* g);
 

@@ -4,14 +4,14 @@ import numpy as np
 from . import capi
 
 
-def _layer_plan(ctx, layer, shape):
+def _layer_plan(ctx, layer, shape, dtype=capi.F32):
     n, h, w, c = shape
     t = layer["type"]
     if t == "Conv2D":
         assert c == layer["ic"], (c, layer["ic"])
         return capi.conv2d_plan(ctx, n, h, w, layer["w"], layer["b"], stride=layer["stride"],
                                 pads=capi.same_padding(layer["kernel"]) if layer["padding"] == "same" else (0, 0, 0, 0),
-                                pad_mode=layer.get("pad_mode", "constant"), act=layer["activation"], leaky=layer.get("alpha", 0.0), bn=layer["bn"])
+                                pad_mode=layer.get("pad_mode", "constant"), act=layer["activation"], leaky=layer.get("alpha", 0.0), bn=layer["bn"], dtype=dtype)
     if t == "DepthwiseConv2D":
         return capi.conv2d_plan(ctx, n, h, w, layer["w"], layer["b"], stride=layer["stride"],
                                 pads=capi.same_padding(layer["kernel"]) if layer["padding"] == "same" else (0, 0, 0, 0), act=layer["activation"],
@@ -103,12 +103,13 @@ class GraphRunner:
     """Graph-shaped nets (models.resnet18 / mobilenetv2 / style_net): one plan per layer at any batch size, producers by name.
     Tensors are allocated once; run_device() only enqueues kernels.  (The C++ host mirror runs the same graphs at batch 1 from JSON.)"""
 
-    def __init__(self, ctx, net, n, h, w):
+    def __init__(self, ctx, net, n, h, w, dtype=capi.F32):
+        """dtype=capi.F16: half tensors end to end (convolutions on the fp16 MFMA path, fp32 accumulation)."""
         from . import models
 
-        self.ctx, self.net = ctx, net
+        self.ctx, self.net, self.dtype = ctx, net, dtype
         self.in_shape = (n, h, w, net["input_channels"])
-        self.x = capi.Tensor(ctx, *self.in_shape)
+        self.x = capi.Tensor(ctx, *self.in_shape, dtype=dtype)
         shapes, self.tensors = {"input": self.in_shape}, {"input": self.x}
         self.steps = []  # (plan, [input tensors], output tensor, layer)
         for layer, ins in models.producers(net):
@@ -117,11 +118,11 @@ class GraphRunner:
                 shape = (shape[0], max(shapes[i][1] for i in ins), max(shapes[i][2] for i in ins), shape[3])
             if layer["type"] == "Dense":  # consumes the flattened producer
                 shape = (shape[0], 1, 1, shape[1] * shape[2] * shape[3])
-            plan = _layer_plan(ctx, layer, shape)
+            plan = _layer_plan(ctx, layer, shape, dtype)
             out_shape = plan.out_shape()
             if layer["type"] == "Flatten":
                 out_shape = (shape[0], 1, 1, shape[1] * shape[2] * shape[3])
-            t = capi.Tensor(ctx, *out_shape)
+            t = capi.Tensor(ctx, *out_shape, dtype=dtype)
             shapes[layer["name"]], self.tensors[layer["name"]] = out_shape, t
             self.steps.append((plan, [self.tensors[i] for i in ins], t, layer))
         self.y = self.steps[-1][2]

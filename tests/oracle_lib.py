@@ -274,8 +274,30 @@ def ref_dense(In, Out, act, alpha, w_flat, bias, x):
     return np.array([float(t) for t in out.split()], dtype=np.float32)
 
 
-def forward(net, x, threads=1, return_layers=False, return_named=False):
-    """Runs a models.py net (chain or graph: layers may name their producers in "inputs") on the oracle."""
+def _h(a):
+    """fp16 storage emulation: round to nearest even to half, back to float32."""
+    return None if a is None else np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def quantize_net_fp16(net):
+    """A copy of the net whose conv / dense weights are the fp16-representable values the fp16 kernels use (RNE conversion of the
+    given fp32 weights; bias / BN / instance-norm parameters stay fp32 -- the epilogue runs in fp32)."""
+    import copy
+
+    q = copy.deepcopy(net)
+    for l in q["layers"]:
+        if l["type"] in ("Conv2D", "DepthwiseConv2D", "Dense"):
+            l["w"] = _h(l["w"])
+    return q
+
+
+def forward(net, x, threads=1, return_layers=False, return_named=False, fp16=False):
+    """Runs a models.py net (chain or graph: layers may name their producers in "inputs") on the oracle.
+    fp16=True emulates the SNNHIP_F16 path: weights and every stored activation are rounded to half, arithmetic stays fp32
+    (what an RGBA16F texture chain with >= fp16 shader arithmetic computes)."""
+    if fp16:
+        net = quantize_net_fp16(net)
+        x = _h(x)
     outs, named, prev = [], {"input": _f(x)}, "input"
     for l in net["layers"]:
         ins = [named[n] for n in l.get("inputs", [prev])]
@@ -313,6 +335,8 @@ def forward(net, x, threads=1, return_layers=False, return_named=False):
             x = upsample(x, l["scaleFactor"], l["interpolation"])
         else:
             raise ValueError(t)
+        if fp16:
+            x = _h(x)
         outs.append(x)
         named[l["name"]] = x
         prev = l["name"]

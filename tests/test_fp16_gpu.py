@@ -1,0 +1,88 @@
+"""SNNHIP_F16 tensors (the reference's RGBA16F / preferHp path): half storage, fp16-input MFMA convolutions with fp32 accumulation,
+fp32 epilogues, round-to-nearest stores.  Checked against the oracle run with the same quantisation points (fp16 weights, every stored
+activation rounded to half) and, loosely, against the fp32 oracle (the reference's own fp16 tests use 0.1, resnet18Test.cpp)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_ops_gpu import _bn, _rand
+
+pytestmark = pytest.mark.gpu
+TOLH = dict(rtol=4e-3, atol=4e-3)   # ~4 half ulps at unit scale: summation order + rounding-boundary flips
+
+
+def _conv16(ctx, x, w, b, stride, pads, pad_mode, act, bn):
+    import shadernn_amd as snn
+
+    n, h, ww, _ = x.shape
+    plan = snn.conv2d_plan(ctx, n, h, ww, w, b, stride=stride, pads=pads, pad_mode=pad_mode, act=act, bn=bn, dtype=snn.F16)
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    yt = plan(xt)
+    assert yt.dtype == snn.F16
+    y, desc = yt.numpy(), plan.describe()
+    xt.free()
+    yt.free()
+    plan.destroy()
+    return y, desc
+
+
+CASES = [(2, 20, 24, 64, 64, 3, 1), (1, 30, 30, 3, 32, 9, 1), (2, 17, 23, 32, 64, 3, 2), (1, 12, 14, 128, 128, 3, 1), (2, 9, 11, 20, 33, 3, 1),
+         (1, 16, 20, 32, 3, 9, 1), (3, 7, 7, 256, 96, 1, 1), (1, 8, 8, 10, 16, 5, 1)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_fp16_conv_matches_quantised_oracle(ctx, case):
+    N, H, W, IC, OC, k, s = case
+    x = _rand((N, H, W, IC), 81)
+    w = _rand((OC, IC, k, k), 82, 1.0 / np.sqrt(IC * k * k))
+    b = _rand((OC,), 83, 0.1)
+    bn = _bn(OC, 84)
+    pads = O.padding_offsets("same", k)
+    for pad_mode, act in (("constant", "relu"), ("reflect", "tanh")):
+        y, desc = _conv16(ctx, x, w, b, s, pads, pad_mode, act, bn)
+        assert "f16" in desc, desc
+        want = O._h(O.conv2d(O._h(x), O._h(w), b, s, pads, pad_mode, act, 0.0, bn))
+        np.testing.assert_allclose(y, want, err_msg=desc, **TOLH)
+        full = O.conv2d(x, w, b, s, pads, pad_mode, act, 0.0, bn)
+        assert np.abs(y - full).max() < 0.05, desc
+
+
+def test_fp16_tensor_roundtrip_and_dtype_checks(ctx):
+    import shadernn_amd as snn
+
+    a = _rand((2, 5, 7, 12), 85, 3.0)
+    t = snn.Tensor.from_numpy(ctx, a, dtype=snn.F16)
+    np.testing.assert_array_equal(t.numpy(), a.astype(np.float16).astype(np.float32))
+    p32 = snn.conv2d_plan(ctx, 2, 5, 7, _rand((16, 12, 3, 3), 86, 0.1))
+    with pytest.raises(snn.SnnHipError):  # fp32 plan, fp16 tensor
+        p32(t)
+    with pytest.raises(snn.SnnHipError):  # depthwise has no fp16 kernel
+        snn.conv2d_plan(ctx, 2, 5, 7, _rand((12, 3, 3), 87, 0.1), depthwise=True, dtype=snn.F16)
+
+
+@pytest.mark.parametrize("which", ["style", "candy", "resnet_trunk"])
+def test_fp16_graphs_match_quantised_oracle(ctx, which):
+    """Whole graphs with half tensors: pad / conv / instance norm / add / upsample (Candy's operator set) and a ResNet trunk."""
+    import shadernn_amd as snn
+    from shadernn_amd import models
+    from test_param_import import _zoo
+
+    if which == "style":
+        net, (h, w) = models.style_net(seed=4, width=16), (24, 32)
+    elif which == "candy":
+        net, (h, w) = _zoo("candy-9_simplified-opt", input_shape=(32, 40, 3)), (32, 40)
+    else:
+        net = models.resnet18(seed=2, num_classes=10, width=16)
+        net["layers"] = net["layers"][:-3]  # up to the last residual Add (pooling / dense stay fp32-only)
+        h, w = 64, 64
+    x = np.random.default_rng(5).random((2, h, w, 3), dtype=np.float32)
+    r = snn.GraphRunner(ctx, net, 2, h, w, dtype=snn.F16)
+    y = r(x)
+    want = O.forward(net, x, fp16=True, threads=8)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert y.shape == want.shape
+    err = np.abs(y - want) / scale
+    # instance norm amplifies single half-ulp flips of its input; the bulk must agree to a few ulps, the tail stays small
+    assert np.quantile(err, 0.999) < 6e-3 and err.max() < 6e-2, (float(np.quantile(err, 0.999)), float(err.max()))
+    full = O.forward(net, x, threads=8)
+    assert np.abs(y - full).max() / scale < 0.1  # the reference's fp16 bound

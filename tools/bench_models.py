@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--model", default=None)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--fp16", action="store_true", help="half tensors + fp16 MFMA convolutions (graphs without depthwise / dense / pooling layers)")
     args = ap.parse_args()
     import shadernn_amd as snn
     from shadernn_amd import models
@@ -47,7 +48,7 @@ def main():
             continue
         batch = args.batch or batch
         net = make()
-        r = snn.GraphRunner(ctx, net, batch, h, w)
+        r = snn.GraphRunner(ctx, net, batch, h, w, dtype=snn.F16 if args.fp16 else snn.F32)
         r.x.upload(np.random.default_rng(1).random(r.in_shape, dtype=np.float32))
         for _ in range(3):
             r.run_device()
@@ -85,12 +86,16 @@ def main():
             rows.append((t.elapsed_ms() / 5 * 1e3, layer["name"], f, b, plan.describe()))
         fl, by = r.cost()
         ms_eager, ms = ms, min(ms, ms_graph)
-        res = {"model": name, "batch": batch, "input": [batch, h, w, 3], "ms_per_batch": ms, "ms_per_batch_eager_launches": ms_eager,
+        res = {"model": name, "dtype": "f16" if args.fp16 else "f32", "batch": batch, "input": [batch, h, w, 3], "ms_per_batch": ms, "ms_per_batch_eager_launches": ms_eager,
                "ms_per_batch_hipgraph": ms_graph, "graph_nodes": nodes, "images_per_s": batch / ms * 1e3, "gflop_per_image": fl / batch / 1e9,
                "mb_per_image_unfused": by / batch / 1e6, "tflops": fl / ms / 1e9, "gbps_unfused": by / ms / 1e6,
                "roofline_ms": max(fl / PEAK_TF / 1e9, by / PEAK_GBS / 1e6), "layers": len(r.steps)}
         res["frac_of_roofline"] = res["roofline_ms"] / ms
         print("%-12s eager %.2f ms, hipGraph (%d nodes) %.2f ms" % (name, ms_eager, nodes, ms_graph))
+        if args.fp16:
+            PEAK = 2500.0
+            res["roofline_ms"] = max(fl / PEAK / 1e9, by / PEAK_GBS / 1e6)
+            res["frac_of_roofline"] = res["roofline_ms"] / ms
         print("%-12s batch %3d: %8.2f ms/batch  %9.1f images/s  %6.2f TFLOP/s  %7.1f GB/s (unfused accounting)  roofline %.2f ms -> %.1f%%  (%d launches)" %
               (name, batch, ms, res["images_per_s"], res["tflops"], res["gbps_unfused"], res["roofline_ms"], 100 * res["frac_of_roofline"], len(r.steps)), flush=True)
         rows.sort(reverse=True)

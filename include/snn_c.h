@@ -22,6 +22,11 @@ typedef struct snn_model snn_model;
  * fuse_chains : let the HIP backend replace linear runs of layers by fused kernels. */
 int snn_model_create(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
                      snn_model** out);
+/* as snn_model_create, with the reference's preferHp / ShaderGenOptions::preferrHalfPrecision switch: RGBA16F textures (half tensors in HBM),
+ * weights truncated to fp16 at parse time (convertToMediumPrecision), fp16-MFMA convolutions.  Layers without an fp16 kernel (depthwise,
+ * dense) abort the run like an unsupported layer does in the reference. */
+int snn_model_create2(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
+                      int prefer_half, snn_model** out);
 int snn_model_destroy(snn_model* m);
 int snn_model_upload_input(snn_model* m, const float* nhwc);      /* H x W x C floats */
 int snn_model_run(snn_model* m);                                   /* MixedInferenceCore::run (enqueue + one sync) */

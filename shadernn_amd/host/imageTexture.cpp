@@ -62,7 +62,7 @@ void ImageTexture::reset(const std::array<uint32_t, 4>& dims, ColorFormat format
     _channels = channels ? channels : 4 * dims[2];
     if (_channels > 4 * dims[2]) SNN_RIP("texture with %u channels needs more than %u texel planes", _channels, dims[2]);
     ImageDesc d;
-    d.format = format;
+    d.format = ColorFormat::RGBA32F; // host staging is always fp32; an RGBA16F texture is a half tensor in HBM and converts at the C-ABI edge
     d.width = dims[0];
     d.height = dims[1];
     d.depth = dims[2];
@@ -71,10 +71,12 @@ void ImageTexture::reset(const std::array<uint32_t, 4>& dims, ColorFormat format
 }
 
 void ImageTexture::resetTexture(const std::array<uint32_t, 4>& dims, ColorFormat format, const std::string& name, uint32_t channels) {
-    if (format != ColorFormat::RGBA32F) SNN_RIP("HIP backend: only RGBA32F (fp32) textures are implemented, got %s", getColorFormatDesc(format).name);
+    if (format != ColorFormat::RGBA32F && format != ColorFormat::RGBA16F)
+        SNN_RIP("HIP backend: RGBA32F (fp32) and RGBA16F (fp16) textures are implemented, got %s", getColorFormatDesc(format).name);
     releaseTensor();
     reset(dims, format, nullptr, name, channels);
-    hipChk(snnhip_tensor_alloc(hipCtx(), 1, static_cast<int>(dims[1]), static_cast<int>(dims[0]), static_cast<int>(_channels), SNNHIP_F32, &_tensor),
+    hipChk(snnhip_tensor_alloc(hipCtx(), 1, static_cast<int>(dims[1]), static_cast<int>(dims[0]), static_cast<int>(_channels),
+                               format == ColorFormat::RGBA16F ? SNNHIP_F16 : SNNHIP_F32, &_tensor),
            "snnhip_tensor_alloc");
     _ownsTensor = true;
 }

@@ -189,7 +189,7 @@ InferencePassesSptr Conv2DLayerHip::createCS(const LayerGenOptions&) const { // 
     d.leaky = _desc.leakyReluAlpha;
     d.useBias = _desc.biases.empty() ? 0 : 1; // conv2dVulkan.cpp:118-121
     d.useBN = _desc.useBatchNormalization ? 1 : 0;
-    d.dtype = SNNHIP_F32;
+    d.dtype = _desc.preferHp ? SNNHIP_F16 : SNNHIP_F32; // conv2dVulkan.cpp:221-229 picks the _fp16 shader asset on preferHp
     d.OH = static_cast<int>(oh);
     d.OW = static_cast<int>(ow);
     const int taps = d.kh * d.kw;

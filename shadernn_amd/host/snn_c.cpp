@@ -18,23 +18,24 @@ struct snn_model {
     int inW = 0, inH = 0, inC = 0;
 };
 
-static dp::ShaderGenOptions makeOptions(int w, int h, int c, bool fuse) {
+static dp::ShaderGenOptions makeOptions(int w, int h, int c, bool fuse, bool half = false) {
     dp::ShaderGenOptions sgo;
-    InferenceGraph::IODesc in{ColorFormat::RGBA32F, static_cast<uint32_t>(w), static_cast<uint32_t>(h), static_cast<uint32_t>(UP_DIV(c, 4)),
-                              static_cast<uint32_t>(c)};
+    const ColorFormat fmt = half ? ColorFormat::RGBA16F : ColorFormat::RGBA32F;
+    InferenceGraph::IODesc in{fmt, static_cast<uint32_t>(w), static_cast<uint32_t>(h), static_cast<uint32_t>(UP_DIV(c, 4)), static_cast<uint32_t>(c)};
     sgo.desiredInput.push_back(in);
-    sgo.desiredOutputFormat = ColorFormat::RGBA32F;
+    sgo.desiredOutputFormat = fmt;
+    sgo.preferrHalfPrecision = half;
     sgo.compute = true;
     sgo.fuseChains = fuse;
     return sgo;
 }
 
-static void makeIO(snn_model* m) {
+static void makeIO(snn_model* m, bool half = false) {
     m->inputs = ImageTextureArray(m->context);
     m->outputs = ImageTextureArray(m->context);
     m->inputs.push_back(ImageTextureFactory::createImageTexture(m->context, {static_cast<uint32_t>(m->inW), static_cast<uint32_t>(m->inH),
                                                                              static_cast<uint32_t>(UP_DIV(m->inC, 4)), 1},
-                                                                ColorFormat::RGBA32F, nullptr, static_cast<uint32_t>(m->inC)));
+                                                                half ? ColorFormat::RGBA16F : ColorFormat::RGBA32F, nullptr, static_cast<uint32_t>(m->inC)));
     m->outputs.allocate(1);
 }
 
@@ -42,20 +43,26 @@ extern "C" {
 
 int snn_model_create(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
                      snn_model** out) {
+    return snn_model_create2(json_path, device, in_w, in_h, in_c, dump_outputs, fuse_chains, profiling, 0, out);
+}
+
+int snn_model_create2(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
+                      int prefer_half, snn_model** out) {
+    const bool half = prefer_half != 0;
     auto* m = new snn_model();
     m->context = createHipContext(device);
     m->inW = in_w;
     m->inH = in_h;
     m->inC = in_c;
-    dp::ShaderGenOptions sgo = makeOptions(in_w, in_h, in_c, fuse_chains != 0);
-    auto layers = dp::loadFromJsonModel(json_path, false, sgo.mrtMode, sgo.weightMode, false);
+    dp::ShaderGenOptions sgo = makeOptions(in_w, in_h, in_c, fuse_chains != 0, half);
+    auto layers = dp::loadFromJsonModel(json_path, false, sgo.mrtMode, sgo.weightMode, half); // preferHp: weights truncated to fp16 (Q13)
     MixedInferenceCore::CreationParameters cp;
     static_cast<InferenceGraph&>(cp) = dp::generateInferenceGraph(layers, sgo);
     cp.dumpOutputs = dump_outputs != 0;
     cp.fuseChains = fuse_chains != 0;
     cp.profiling = profiling != 0;
     m->core = MixedInferenceCore::create(m->context, cp);
-    makeIO(m);
+    makeIO(m, half);
     *out = m;
     return 0;
 }

@@ -86,3 +86,29 @@ def test_fp16_graphs_match_quantised_oracle(ctx, which):
     assert np.quantile(err, 0.999) < 6e-3 and err.max() < 6e-2, (float(np.quantile(err, 0.999)), float(err.max()))
     full = O.forward(net, x, threads=8)
     assert np.abs(y - full).max() / scale < 0.1  # the reference's fp16 bound
+
+
+def test_fp16_json_model_through_host_mirror(ctx, tmp_path):
+    """preferHp end to end: JSON -> ModelParser (weights truncated to fp16, Q13) -> RGBA16F stage textures -> fp16 plans."""
+    from shadernn_amd import host, models
+
+    net = models.style_net(seed=4, width=16)
+    w, h = 32, 24
+    path = models.write_json(net, w, h, str(tmp_path / "style16.json"))
+    x = np.random.default_rng(5).random((1, h, w, 3), dtype=np.float32)
+    m = host.Model(path, w, h, 3, fuse_chains=False, prefer_half=True)
+    y = m(x)
+    # the parser TRUNCATES weights / bias / norm parameters to half (convertToMediumPrecision); give the oracle the same values
+    import copy
+
+    q = copy.deepcopy(net)
+    trunc = np.vectorize(O.to_medium_precision, otypes=[np.float32])
+    for l in q["layers"]:
+        for k in ("w", "b", "beta", "gamma"):
+            if l.get(k) is not None:
+                l[k] = trunc(np.asarray(l[k], np.float32))
+    want = O.forward(q, x, fp16=True)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = np.abs(y.reshape(-1) - want.reshape(-1)) / scale
+    assert np.quantile(err, 0.999) < 6e-3 and err.max() < 6e-2, (float(np.quantile(err, 0.999)), float(err.max()))
+    m.close()

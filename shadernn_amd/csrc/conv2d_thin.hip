@@ -17,6 +17,7 @@
 #include "snnhip_internal.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace snnhip {
 namespace {
@@ -33,9 +34,17 @@ struct ThinParams {
     int xFloats;      // floats of the activation tile in LDS (the weight slab follows)
 };
 
-template <bool SIMPLE>
-__global__ __launch_bounds__(512) void conv2d_thin_kernel(ThinParams p, ActCfg ac, const float* __restrict__ x, const float* __restrict__ wp,
-                                                         const float4* __restrict__ epi, float* __restrict__ y) {
+// F16: half tensors and weights; a 16-byte slot holds 8 channels and feeds two v_mfma_f32_4x4x4f16 (4 channels each) instead of four
+// v_mfma_f32_4x4x1f32, so an LDS chunk is 32 channels in the same 64 bytes per pixel.
+template <bool SIMPLE, bool F16>
+__global__ __launch_bounds__(512) void conv2d_thin_kernel(ThinParams p, ActCfg ac, const void* __restrict__ xv, const void* __restrict__ wp,
+                                                         const float4* __restrict__ epi, void* __restrict__ yv) {
+    typedef typename std::conditional<F16, _Float16, float>::type T;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    constexpr int CH = F16 ? 8 : 4;        // channels per 16-byte slot
+    constexpr int CHUNK = 4 * CH;          // channels per LDS chunk
+    const T* __restrict__ x = static_cast<const T*>(xv);
+    T* __restrict__ y = static_cast<T*>(yv);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_x = smem;
     float* s_w = smem + p.xFloats;
@@ -48,9 +57,9 @@ __global__ __launch_bounds__(512) void conv2d_thin_kernel(ThinParams p, ActCfg a
     const int ox0 = tx * TW, oy0 = ty * p.TH;
     const int nthreads = blockDim.x;
     const int ix0 = ox0 - p.padx, iy0 = oy0 - p.pady;
-    const float* xn = x + static_cast<size_t>(n) * p.H * p.W * p.IC;
+    const T* xn = x + static_cast<size_t>(n) * p.H * p.W * p.IC;
     const int taps = p.kh * p.kw;
-    const bool vec4 = (p.IC & 3) == 0;
+    const bool vec4 = (p.IC % CH) == 0;
 
     // lane -> pixels: batch bt covers tile rows 4*wv + 2*bt + lane/32, column lane%32
     const int col = lane & 31, rsub = lane >> 5;
@@ -67,7 +76,7 @@ __global__ __launch_bounds__(512) void conv2d_thin_kernel(ThinParams p, ActCfg a
 
     const int npix = p.tileH * p.tileW;
     for (int chunk = 0; chunk < p.nChunks; ++chunk) {
-        const int ic0 = chunk * ICC;
+        const int ic0 = chunk * CHUNK;
         __syncthreads();
         // ---- stage the halo tile (padding resolved here) and this chunk's weights
         for (int e = tid; e < npix * 4; e += nthreads) {
@@ -75,16 +84,16 @@ __global__ __launch_bounds__(512) void conv2d_thin_kernel(ThinParams p, ActCfg a
             const int r = pl / p.tileW, c = pl - r * p.tileW;
             const int sy = resolve_coord(iy0 + r, p.H, p.padMode), sx = resolve_coord(ix0 + c, p.W, p.padMode);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int icq = ic0 + q * 4;
+            const int icq = ic0 + q * CH;
             if (sy >= 0 && sx >= 0 && icq < p.IC) {
-                const float* src = xn + (static_cast<size_t>(sy) * p.W + sx) * p.IC + icq;
+                const T* src = xn + (static_cast<size_t>(sy) * p.W + sx) * p.IC + icq;
                 if (vec4) {
                     v = *reinterpret_cast<const float4*>(src);
                 } else {
-                    v.x = src[0];
-                    if (icq + 1 < p.IC) v.y = src[1];
-                    if (icq + 2 < p.IC) v.z = src[2];
-                    if (icq + 3 < p.IC) v.w = src[3];
+                    T tmp[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) tmp[j] = icq + j < p.IC ? src[j] : static_cast<T>(0.0f);
+                    v = *reinterpret_cast<const float4*>(tmp);
                 }
             }
             *reinterpret_cast<float4*>(s_x + pl * 16 + ((q ^ ((pl >> 2) & 3)) << 2)) = v;
@@ -123,12 +132,22 @@ __global__ __launch_bounds__(512) void conv2d_thin_kernel(ThinParams p, ActCfg a
             }
             if (tap + 1 < taps) fetch(tap + 1, rowoff + fx);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                if (F16) {
+                    const h4* wh = reinterpret_cast<const h4*>(&wc[q]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                    for (int k = 0; k < 2; ++k)
 #pragma unroll
-                    for (int bt = 0; bt < 2; ++bt) // accumulator index is a compile-time constant (a run-time one costs a select per register)
-                        acc[bt][k & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[q][k], xc[bt][q][k], acc[bt][k & 1], 0, 0, 0);
+                        for (int bt = 0; bt < 2; ++bt)
+                            acc[bt][k] = __builtin_amdgcn_mfma_f32_4x4x4f16(wh[k], reinterpret_cast<const h4*>(&xc[bt][q])[k], acc[bt][k], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int bt = 0; bt < 2; ++bt) // accumulator index is a compile-time constant (a run-time one costs a select per register)
+                            acc[bt][k & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[q][k], xc[bt][q][k], acc[bt][k & 1], 0, 0, 0);
+                }
+            }
         }
     }
 
@@ -157,13 +176,13 @@ __global__ __launch_bounds__(512) void conv2d_thin_kernel(ThinParams p, ActCfg a
             o4[o] = v;
         }
         if (oy < p.OH && ox < p.OW) {
-            float* dst = y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox) * p.OC;
-            if (p.OC == 4) {
+            T* dst = y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox) * p.OC;
+            if (p.OC == 4 && !F16) {
                 *reinterpret_cast<float4*>(dst) = make_float4(o4[0], o4[1], o4[2], o4[3]);
             } else {
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
-                    if (o < p.OC) dst[o] = o4[o];
+                    if (o < p.OC) dst[o] = static_cast<T>(o4[o]);
             }
         }
     }
@@ -184,12 +203,18 @@ struct ThinConvPlan : ConvPlanBase {
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
                        out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
         const dim3 grid(static_cast<unsigned>(p.tilesX * p.tilesY * p.N));
-        if (act_is_simple(ac.act))
-            hipLaunchKernelGGL((conv2d_thin_kernel<true>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, x->data, d_w, reinterpret_cast<const float4*>(d_epi),
-                               out->data);
-        else
-            hipLaunchKernelGGL((conv2d_thin_kernel<false>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, x->data, d_w,
-                               reinterpret_cast<const float4*>(d_epi), out->data);
+        const void* xv = x->data;
+        const void* wv = d_w;
+        void* yv = out->data;
+        const float4* e4 = reinterpret_cast<const float4*>(d_epi);
+        const bool simple = act_is_simple(ac.act);
+        if (dtype == SNNHIP_F16) {
+            if (simple) hipLaunchKernelGGL((conv2d_thin_kernel<true, true>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
+            else hipLaunchKernelGGL((conv2d_thin_kernel<false, true>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
+        } else {
+            if (simple) hipLaunchKernelGGL((conv2d_thin_kernel<true, false>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
+            else hipLaunchKernelGGL((conv2d_thin_kernel<false, false>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
+        }
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -201,7 +226,6 @@ int make_conv2d_thin_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     const char* force = getenv("SNNHIP_CONV");
     if (force && strcmp(force, "thin") != 0) return SNNHIP_E_UNSUPPORTED; // generic / mfma forced
     if (g.OC > 4 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
-    if (g.dtype != SNNHIP_F32) return SNNHIP_E_UNSUPPORTED; // fp16 tensors: conv2d_mfma takes every shape (OC padded to 32)
     if (!force && g.IC < 8) return SNNHIP_E_UNSUPPORTED; // a handful of input channels: the VALU kernel is as good
     ThinParams p{};
     p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.kh = g.kh; p.kw = g.kw; p.padx = g.padx; p.pady = g.pady;
@@ -218,7 +242,9 @@ int make_conv2d_thin_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.tileW = TW + g.kw - 1;
     p.tilesX = up_div(g.OW, TW);
     p.tilesY = up_div(g.OH, p.TH);
-    p.nChunks = up_div(g.IC, ICC);
+    const bool f16 = g.dtype == SNNHIP_F16;
+    const int CH = f16 ? 8 : 4, CHUNK = 4 * CH;
+    p.nChunks = up_div(g.IC, CHUNK);
     p.xFloats = p.tileH * p.tileW * 16;
     const size_t ldsBytes = ldsFor(waves);
     auto* plan = new ThinConvPlan();
@@ -231,7 +257,8 @@ int make_conv2d_thin_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->ldsBytes = ldsBytes;
     plan->waves = waves;
     if (ldsBytes > 64 * 1024) {
-        for (const void* fn : {reinterpret_cast<const void*>(conv2d_thin_kernel<true>), reinterpret_cast<const void*>(conv2d_thin_kernel<false>)}) {
+        for (const void* fn : {reinterpret_cast<const void*>(conv2d_thin_kernel<true, false>), reinterpret_cast<const void*>(conv2d_thin_kernel<false, false>),
+                               reinterpret_cast<const void*>(conv2d_thin_kernel<true, true>), reinterpret_cast<const void*>(conv2d_thin_kernel<false, true>)}) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsBytes));
             if (e != hipSuccess) {
                 set_error("hipFuncSetAttribute(%zu) failed: %s", ldsBytes, hipGetErrorString(e));
@@ -240,13 +267,17 @@ int make_conv2d_thin_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
             }
         }
     }
-    // weights: Wp[chunk][tap][quad][oc(4)][4 ic], zero for oc >= OC and ic >= IC
+    // weights: Wp[chunk][tap][slot(4)][oc(4)][CH channels] (16 bytes per (slot, oc)), zero for oc >= OC and ic >= IC
     std::vector<float> wpk(static_cast<size_t>(p.nChunks) * taps * 64, 0.0f);
+    _Float16* wph = reinterpret_cast<_Float16*>(wpk.data());
     for (int o = 0; o < g.OC; ++o)
         for (int i = 0; i < g.IC; ++i)
             for (int t = 0; t < taps; ++t) {
-                const int chunk = i / ICC, q = (i % ICC) / 4, k = i % 4;
-                wpk[(((static_cast<size_t>(chunk) * taps + t) * 4 + q) * 4 + o) * 4 + k] = w_oihw[(static_cast<size_t>(o) * g.IC + i) * taps + t];
+                const int chunk = i / CHUNK, q = (i % CHUNK) / CH, k = i % CH;
+                const size_t slot = ((static_cast<size_t>(chunk) * taps + t) * 4 + q) * 4 + o;
+                const float wv = w_oihw[(static_cast<size_t>(o) * g.IC + i) * taps + t];
+                if (f16) wph[slot * 8 + k] = static_cast<_Float16>(wv);
+                else wpk[slot * 4 + k] = wv;
             }
     int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
     if (rc == SNNHIP_OK) rc = plan->upload(epi4.data(), epi4.size(), &plan->d_epi);
@@ -260,7 +291,10 @@ int make_conv2d_thin_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC +
                          static_cast<double>(g.OC) * g.IC * taps);
     char buf[200];
-    snprintf(buf, sizeof(buf), "conv2d_thin_mfma_f32_4x4x1 k=%dx%d s=1 ic=%d oc=%d tile=32x%d chunk=16 lds=%zuB", g.kh, g.kw, g.IC, g.OC, p.TH, ldsBytes);
+    snprintf(buf, sizeof(buf), "conv2d_thin_mfma_%s k=%dx%d s=1 ic=%d oc=%d tile=32x%d chunk=%d lds=%zuB", f16 ? "f16_4x4x4" : "f32_4x4x1", g.kh, g.kw, g.IC,
+             g.OC, p.TH, CHUNK, ldsBytes);
+    plan->dtype = g.dtype;
+    if (f16) plan->bytes *= 0.5;
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

@@ -446,7 +446,7 @@ int make_eltwise(snnhip_ctx* ctx, const snnhip_eltwise_desc* d, int mode, const 
     plan->flops = cnt * (mode == 2 ? 3 : 1);
     plan->bytes = 4.0 * cnt * (mode == 0 ? 3 : 2);
     char buf[160];
-    snprintf(buf, sizeof(buf), "%s_f32 %dx%dx%dx%d act=%d%s", name, d->N, d->H, d->W, d->C, d->act, (d->C & 3) ? " scalar" : " vec4");
+    snprintf(buf, sizeof(buf), "%s %dx%dx%dx%d act=%d%s", name, d->N, d->H, d->W, d->C, d->act, (d->C & 3) ? " scalar" : " vec4");
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;
@@ -619,7 +619,7 @@ int snnhip_pool2d_plan_create(snnhip_ctx* ctx, const snnhip_pool2d_desc* desc, s
     plan->flops = static_cast<double>(d.N) * d.OH * d.OW * d.C * d.kh * d.kw;
     plan->bytes = 4.0 * (static_cast<double>(d.N) * d.H * d.W * d.C + static_cast<double>(d.N) * d.OH * d.OW * d.C);
     char buf[160];
-    snprintf(buf, sizeof(buf), "%spool2d_f32 k=%dx%d s=%d c=%d %dx%d->%dx%d%s", d.type == SNNHIP_POOL_MAX ? "max" : "avg", d.kh, d.kw, d.sh, d.C, d.H, d.W,
+    snprintf(buf, sizeof(buf), "%spool2d k=%dx%d s=%d c=%d %dx%d->%dx%d%s", d.type == SNNHIP_POOL_MAX ? "max" : "avg", d.kh, d.kw, d.sh, d.C, d.H, d.W,
              d.OH, d.OW, (d.C & 3) ? " scalar" : " vec4");
     plan->desc = buf;
     *out = plan;
@@ -641,7 +641,7 @@ int snnhip_pad_plan_create(snnhip_ctx* ctx, const snnhip_pad_desc* desc, snnhip_
     plan->outDims[0] = desc->N; plan->outDims[1] = plan->OH; plan->outDims[2] = plan->OW; plan->outDims[3] = desc->C;
     plan->bytes = 4.0 * desc->N * desc->C * (static_cast<double>(desc->H) * desc->W + static_cast<double>(plan->OH) * plan->OW);
     char buf[160];
-    snprintf(buf, sizeof(buf), "pad_f32 mode=%d t%d b%d l%d r%d c=%d %dx%d->%dx%d", desc->mode, desc->padT, desc->padB, desc->padL, desc->padR, desc->C,
+    snprintf(buf, sizeof(buf), "pad mode=%d t%d b%d l%d r%d c=%d %dx%d->%dx%d", desc->mode, desc->padT, desc->padB, desc->padL, desc->padR, desc->C,
              desc->H, desc->W, plan->OH, plan->OW);
     plan->desc = buf;
     *out = plan;
@@ -667,7 +667,7 @@ int snnhip_upsample_plan_create(snnhip_ctx* ctx, const snnhip_upsample_desc* des
     plan->outDims[0] = desc->N; plan->outDims[1] = plan->OH; plan->outDims[2] = plan->OW; plan->outDims[3] = desc->C;
     plan->bytes = 4.0 * desc->N * desc->C * (static_cast<double>(desc->H) * desc->W + static_cast<double>(plan->OH) * plan->OW);
     char buf[160];
-    snprintf(buf, sizeof(buf), "upsample_%s_f32 x%g c=%d %dx%d->%dx%d", desc->mode ? "bilinear" : "nearest", desc->scale, desc->C, desc->H, desc->W, plan->OH,
+    snprintf(buf, sizeof(buf), "upsample_%s x%g c=%d %dx%d->%dx%d", desc->mode ? "bilinear" : "nearest", desc->scale, desc->C, desc->H, desc->W, plan->OH,
              plan->OW);
     plan->desc = buf;
     *out = plan;
@@ -711,7 +711,7 @@ int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_d
     plan->flops = cnt * 7;
     plan->bytes = 4.0 * cnt * 2; // algorithmic: read once, write once (the statistics sweep reads it once more: 3x in practice)
     char buf[160];
-    snprintf(buf, sizeof(buf), "instancenorm_f32 %dx%dx%dx%d act=%d slabs=%d (2 sweeps + fold)", desc->N, desc->H, desc->W, desc->C, desc->act, plan->S);
+    snprintf(buf, sizeof(buf), "instancenorm %dx%dx%dx%d act=%d slabs=%d (2 sweeps + fold)", desc->N, desc->H, desc->W, desc->C, desc->act, plan->S);
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

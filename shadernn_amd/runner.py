@@ -131,10 +131,18 @@ class GraphRunner:
     def describe(self):
         return ["%s: %s" % (l["name"], p.describe()) for p, _, _, l in self.steps]
 
+    def step_cost(self, i):
+        """(flops, bytes) of step i; the dtype-agnostic element-wise plans report fp32 bytes, halved here for half tensors."""
+        plan, _, _, layer = self.steps[i]
+        f, b = plan.cost()
+        if self.dtype == capi.F16 and layer["type"] not in ("Conv2D", "DepthwiseConv2D", "Dense"):
+            b *= 0.5
+        return f, b
+
     def cost(self):
         f = b = 0.0
-        for p, _, _, _ in self.steps:
-            pf, pb = p.cost()
+        for i in range(len(self.steps)):
+            pf, pb = self.step_cost(i)
             f += pf
             b += pb
         return f, b

@@ -76,13 +76,13 @@ def main():
         g.destroy()
         # per-layer times: one timed loop per plan
         rows = []
-        for plan, ins, o, layer in r.steps:
+        for si, (plan, ins, o, layer) in enumerate(r.steps):
             t.start()
             for _ in range(5):
                 plan.run(ins if len(ins) > 1 else ins[0], o)
             t.stop()
             ctx.sync()
-            f, b = plan.cost()
+            f, b = r.step_cost(si)
             rows.append((t.elapsed_ms() / 5 * 1e3, layer["name"], f, b, plan.describe()))
         fl, by = r.cost()
         ms_eager, ms = ms, min(ms, ms_graph)

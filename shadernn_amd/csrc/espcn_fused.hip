@@ -586,6 +586,116 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     }
 }
 
+// Kernel B with asynchronous staging: persistent blocks (3 per CU) walk the 32x8 tiles; while tile t is computed out of one LDS buffer,
+// the halo tile of t+1 lands in the other one through global_load_lds (LDS-DMA: no staging registers, no ds_write pass).  The DMA writes
+// lane-linearly (wave-uniform base + lane*16 B), so the slot swizzle of the tile goes on the per-lane SOURCE address (guide rule 21:
+// linear destination + permuted source + the same permutation on the read); out-of-image pixels read a zero page.
+// One vmcnt(0)+barrier per tile (the __syncthreads after the compute) retires the DMA before anybody reads the new buffer.
+template <bool SIMPLE>
+__global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_dma_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ w,
+                                                                         const float* __restrict__ ep, const float* __restrict__ zeros,
+                                                                         float* __restrict__ y) {
+    constexpr int TW = 32, TH = 8, TWH = TW + 2, THH = TH + 2;
+    constexpr int SLOTS = THH * TWH * 4;            // 16-byte slots per tile (1360)
+    constexpr int NDMA = (SLOTS + 63) / 64;         // wave-wide DMA instructions per tile (22)
+    constexpr int PER_WAVE = (NDMA + 3) / 4;        // per wave (6)
+    constexpr int BUF = NDMA * 64 * 4;              // floats per LDS buffer (rounded up to whole DMA instructions)
+    __shared__ __attribute__((aligned(16))) float s_x[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ntiles = p.tilesX * p.tilesY * p.N;
+    auto tile_origin = [&](int t, int& n, int& x0, int& y0) {
+        int b = xcd_tile_order(t, ntiles);
+        const int tx = b % p.tilesX;
+        b /= p.tilesX;
+        const int ty = b % p.tilesY;
+        n = b / p.tilesY;
+        x0 = tx * TW;
+        y0 = ty * TH;
+    };
+    // this lane's share of a tile: DMA instruction k of wave wv fills slots [(wv + 4k)*64, +64); slot -> (pixel, physical quad)
+    int rcq[PER_WAVE]; // (row << 16) | (col << 8) | source quad, or -1 past the end of the tile
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int ps = (wv + 4 * k) * 64 + lane;
+        const int pix = ps >> 2, pq = ps & 3;
+        const int r = pix / TWH, c = pix - r * TWH;
+        rcq[k] = (wv + 4 * k < NDMA && ps < SLOTS) ? ((r << 16) | (c << 8) | (pq ^ ((pix >> 2) & 3))) : -1;
+    }
+    auto issue_dma = [&](int t, float* buf) {
+        int n, x0, y0;
+        tile_origin(t, n, x0, y0);
+        const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            if (wv + 4 * k < NDMA) { // wave-uniform
+                const int gy = y0 - 1 + (rcq[k] >> 16), gx = x0 - 1 + ((rcq[k] >> 8) & 255);
+                const float* src = zeros;
+                if (rcq[k] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) src = xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + (rcq[k] & 3) * 4;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*) (buf + (wv + 4 * k) * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    issue_dma(tile, s_x);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sc[k] = ep[2 * k];
+        sh[k] = ep[2 * k + 1];
+    }
+    const int c = tid % TW, r = tid / TW;
+    __syncthreads(); // vmcnt(0) + barrier: the first tile is in place
+    int cur = 0;
+    for (;;) {
+        const int next = tile + gridDim.x;
+        const bool more = next < ntiles;
+        if (more) issue_dma(next, s_x + (cur ^ 1) * BUF);
+        int n, x0, y0;
+        tile_origin(tile, n, x0, y0);
+        const float* sx = s_x + cur * BUF;
+
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int fy = tap / 3, fx = tap - fy * 3;
+            const int pixIdx = (r + fy) * TWH + c + fx;
+            const float* src = sx + pixIdx * 16;
+            const int sw = (pixIdx >> 2) & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 xv = *reinterpret_cast<const float4*>(src + ((q ^ sw) * 4));
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* wr = w + (tap * 16 + q * 4 + i) * 4; // uniform address -> s_load
+                    const f32x2 xx = {xs[i], xs[i]};
+                    const f32x2 w01 = {wr[0], wr[1]}, w23 = {wr[2], wr[3]};
+                    acc01 = __builtin_elementwise_fma(xx, w01, acc01);
+                    acc23 = __builtin_elementwise_fma(xx, w23, acc23);
+                }
+            }
+        }
+        const float acc[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
+        const int gy = y0 + r, gx = x0 + c;
+        if (gy < p.H && gx < p.W) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(acc[k], sc[k], sh[k]), 0.0f));
+            float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
+            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
+            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
+        }
+        if (!more) break;
+        __syncthreads(); // every wave is done with buffer `cur`; vmcnt(0): the next tile has landed
+        cur ^= 1;
+        tile = next;
+    }
+}
+
 // Kernel B, Winograd variant (default): conv 3x3 (16 -> 4) as F(2x2, 3x3) on the matrix cores, then depth-to-space(2) + tanh.
 // With only 4 output channels a 16-wide MFMA tile would be 3/4 padding; v_mfma_f32_4x4x1_16B_f32 instead runs 16
 // independent 4x4x1 outer products per instruction: block = 4 Winograd tiles, rows = the 4 output channels, one input
@@ -840,6 +950,7 @@ struct ChainPlan : snnhip_plan {
         FusedBParams b{};
         int k1 = 5;
         bool persistent = false;
+        bool dma = false; // FUSED_B: persistent direct kernel with LDS-DMA double buffering (SNNHIP_ESPCN_B=dma)
         bool wino = false; // FUSED_A / FUSED_B: the 3x3 conv as Winograd F(2x2,3x3) (default) or direct (SNNHIP_ESPCN_A / _B = direct)
         float *w1 = nullptr, *w2 = nullptr, *e1 = nullptr, *e2 = nullptr, *w3 = nullptr, *e3 = nullptr;
         alignas(8) char streamCfg[kStreamCfgBytes] = {};
@@ -911,6 +1022,18 @@ struct ChainPlan : snnhip_plan {
                     if (simple) SNNHIP_LAUNCH_A(3, true); else SNNHIP_LAUNCH_A(3, false);
                 }
 #undef SNNHIP_LAUNCH_A
+                SNNHIP_CHECK_HIP(hipGetLastError());
+            } else if (s.dma) {
+                const int ntiles = s.b.tilesX * s.b.tilesY * s.b.N;
+                const int slots = 3 * (ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256);
+                dim3 grid(ntiles < slots ? ntiles : slots);
+                if (act_is_simple(s.b.act.act)) {
+                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_dma_kernel<true>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b, src->data, s.w1,
+                                          s.e1, s.w3, dst->data);
+                } else {
+                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_dma_kernel<false>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b, src->data, s.w1,
+                                          s.e1, s.w3, dst->data);
+                }
                 SNNHIP_CHECK_HIP(hipGetLastError());
             } else if (s.wino) {
                 // one block per tile by default; SNNHIP_ESPCN_B=wino_persistent launches 2 blocks per CU that walk the tile list with
@@ -1113,6 +1236,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             const char* bmode = getenv("SNNHIP_ESPCN_B");
             st.wino = bmode && strncmp(bmode, "wino", 4) == 0;
             st.persistent = bmode && strcmp(bmode, "wino_persistent") == 0;
+            st.dma = bmode && strcmp(bmode, "dma") == 0;
             const int bTW = st.wino ? 64 : B_TW, bTH = st.wino ? 16 : B_TH;
             st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, bTW), up_div(g0.H, bTH), make_act_cfg(g0.act, g0.leaky)};
             std::vector<float> wB(9 * 16 * 4);
@@ -1139,10 +1263,15 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             std::vector<float> e1 = fold_epilogue(c0->epi4, 4, g0.useBN);
             rc = chain->upload(wB.data(), wB.size(), &st.w1);
             if (rc == SNNHIP_OK) rc = chain->upload(e1.data(), e1.size(), &st.e1);
+            if (rc == SNNHIP_OK && st.dma) {
+                const std::vector<float> zeros(64, 0.0f); // the zero page out-of-image DMA lanes read
+                rc = chain->upload(zeros.data(), zeros.size(), &st.w3);
+            }
             memcpy(st.outDims, sp1->outDims, sizeof(st.outDims));
             char buf[200];
             snprintf(buf, sizeof(buf), "fused[conv3x3(16->4)%s+depth_to_space(2)+tanh] %s tile=%dx%d kernel=%s", st.wino ? " winograd F(2x2,3x3)" : "",
-                     st.wino ? "mfma_f32_4x4x1" : "valu_f32", bTW, bTH, st.wino ? "conv3x3_c16o4_wino_d2s_tanh_kernel" : "conv3x3_c16o4_d2s_tanh_kernel");
+                     st.wino ? "mfma_f32_4x4x1" : (st.dma ? "valu_f32 lds-dma persistent" : "valu_f32"), bTW, bTH,
+                     st.wino ? "conv3x3_c16o4_wino_d2s_tanh_kernel" : (st.dma ? "conv3x3_c16o4_d2s_tanh_dma_kernel" : "conv3x3_c16o4_d2s_tanh_kernel"));
             st.desc = buf;
             st.flops = c0->flops;
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);

@@ -38,6 +38,8 @@ LAYERS = [
     ("mbv2 dw 3x3 144 @56 b32", 32, 56, 56, 144, 144, 3, 1, True),
     ("mbv2 dw 3x3 384 @14 b32", 32, 14, 14, 384, 384, 3, 1, True),
     ("espcn conv2 3x3 16->16 @1080p b1", 1, 1080, 1920, 16, 16, 3, 1, False),
+    ("espcn conv3 3x3 16->4 @1080p b1", 1, 1080, 1920, 16, 4, 3, 1, False),
+    ("candy out 9x9 32->3 @720p b1", 1, 728, 1288, 32, 3, 9, 1, False),
 ]
 
 

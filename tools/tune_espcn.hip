@@ -101,6 +101,22 @@ float timeOverlap(const float* x, const float* w, float* mid, float* mid2, float
     return 1e3f * ms / reps;
 }
 
+float timeBD(const float* x, const float* w, const float* e, const float* zeros, float* y, int H, int W, int reps, int blocksPerCU) {
+    FusedBParams p{1, H, W, (W + 31) / 32, (H + 7) / 8, make_act_cfg(0, 0.f)};
+    dim3 grid(256 * blocksPerCU);
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_dma_kernel<true>), grid, dim3(256), 0, 0, p, x, w, e, zeros, y);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_dma_kernel<true>), grid, dim3(256), 0, 0, p, x, w, e, zeros, y);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return 1e3f * ms / reps;
+}
+
 template <int K1, int WTH, int WWPS>
 float timeW(const float* x, const float* w1, const float* w2, const float* e1, const float* e2, float* y, int H, int W, int reps) {
     FusedAParams p{1, H, W, (W + WinoTile::TW - 1) / WinoTile::TW, (H + WTH - 1) / WTH, make_act_cfg(1, 0.f), make_act_cfg(1, 0.f)};
@@ -260,6 +276,12 @@ int main() {
     printf("W<5,8,3> wino  %.1f us\n", timeW<5, 8, 3>(x, w, w, w, w, mid, H, W, R));
     printf("A<5,64,8,U3,W3>  %.1f us\n", timeA<5, 64, 8, 3, 3>(x, w, w, w, w, mid, H, W, R));
     printf("BW wino    %.1f us\n", timeBW(mid, w, w, y, H, W, R));
+    {
+        float* zeros;
+        CK(hipMalloc(&zeros, 256));
+        CK(hipMemset(zeros, 0, 256));
+        for (int bpc : {2, 3}) printf("BD dma persistent x%d %.1f us\n", bpc, timeBD(mid, w, w, zeros, y, H, W, R, bpc));
+    }
     printf("B<32,8>    %.1f us\n", timeB<32, 8>(mid, w, w, y, H, W, R));
     printf("B<64,4>    %.1f us\n", timeB<64, 4>(mid, w, w, y, H, W, R));
     printf("B<16,16>   %.1f us\n", timeB<16, 16>(mid, w, w, y, H, W, R));

@@ -396,7 +396,6 @@ int snnhip_depthwise_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc
     int rc = check_conv_args(ctx, desc, w_chw, bn_beta, bn_gamma, bn_mean, bn_var, out);
     if (rc != SNNHIP_OK) return rc;
     ConvGeom g;
-    SNNHIP_REQUIRE(desc->dtype == SNNHIP_F32, "depthwise_plan_create: only fp32 tensors are implemented for the depthwise operator");
     rc = resolve_conv_geom(desc, true, &g);
     if (rc != SNNHIP_OK) return rc;
     SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));

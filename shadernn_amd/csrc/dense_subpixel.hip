@@ -7,6 +7,7 @@
 //   Activation semantics follow the CPU path (cpulayer.h:185-261), including softmax over the output row.
 // subpixel: replaces shadertemplate_vk_subpixel.comp:43-71 (depth-to-space(2) + tanh), both the true d2s channel
 //   selection (fs_subpixel.glsl:41-64) and the Vulkan shader's depth-slice quirk.
+#include "epilogue.h"
 #include "snnhip_internal.h"
 
 namespace snnhip {
@@ -23,28 +24,31 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void dense_kernel(int In, int Out, int act, float leaky, const float* __restrict__ x,
+// TX: element type of the activations (float or half); weights, arithmetic and the output row stay fp32 -- a half output tensor is written
+// by convert_rows_kernel after the (optional) softmax so that no intermediate is rounded
+template <bool VEC, typename TX>
+__global__ __launch_bounds__(256) void dense_kernel(int In, int Out, int act, float leaky, const TX* __restrict__ x,
                                                     const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y) {
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
     if (o >= Out) return;
     const float* wr = w + static_cast<size_t>(o) * In;
-    const float* xb = x + static_cast<size_t>(b) * In;
+    const TX* xb = x + static_cast<size_t>(b) * In;
     float acc = 0.0f;
     if (VEC) {
         const float4* w4 = reinterpret_cast<const float4*>(wr);
-        const float4* x4 = reinterpret_cast<const float4*>(xb);
         for (int i = lane; i < In / 4; i += 64) {
-            const float4 a = w4[i], v = x4[i];
-            acc = fmaf(a.x, v.x, acc);
-            acc = fmaf(a.y, v.y, acc);
-            acc = fmaf(a.z, v.z, acc);
-            acc = fmaf(a.w, v.w, acc);
+            const float4 a = w4[i];
+            float v[4];
+            ldv<TX, 4>(xb + 4 * i, v);
+            acc = fmaf(a.x, v[0], acc);
+            acc = fmaf(a.y, v[1], acc);
+            acc = fmaf(a.z, v[2], acc);
+            acc = fmaf(a.w, v[3], acc);
         }
     } else {
-        for (int i = lane; i < In; i += 64) acc = fmaf(wr[i], xb[i], acc);
+        for (int i = lane; i < In; i += 64) acc = fmaf(wr[i], static_cast<float>(xb[i]), acc);
     }
     acc = wave_sum(acc);
     if (lane == 0) {
@@ -85,10 +89,15 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(int Out, float* __res
     for (int i = threadIdx.x; i < Out; i += 256) row[i] = row[i] / s;
 }
 
+__global__ __launch_bounds__(256) void convert_rows_kernel(size_t n, const float* __restrict__ src, _Float16* __restrict__ dst) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * 256) dst[i] = static_cast<_Float16>(src[i]);
+}
+
 struct DensePlan : snnhip_plan {
     snnhip_dense_desc d;
     float* d_w = nullptr;
     float* d_b = nullptr;
+    float* d_row = nullptr; // fp32 result rows when the output tensor holds halfs
 
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "dense: expects 1 input, got %d", nIn);
@@ -97,18 +106,28 @@ struct DensePlan : snnhip_plan {
                        "dense: input %dx%dx%dx%d does not flatten to %d x %d", x->n, x->h, x->w, x->c, d.batch, d.in_units);
         SNNHIP_REQUIRE(out->count() == static_cast<size_t>(d.batch) * d.out_units, "dense: output has %zu elements, expected %d x %d", out->count(),
                        d.batch, d.out_units);
+        SNNHIP_REQUIRE(x->dtype == out->dtype, "dense: input dtype %d, output dtype %d", x->dtype, out->dtype);
         dim3 grid(up_div(d.out_units, 4), d.batch);
         const bool vec = (d.in_units % 4) == 0;
-        if (vec) {
-            hipLaunchKernelGGL(dense_kernel<true>, grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.act, d.leaky, x->data, d_w, d_b,
-                               out->data);
+        const bool half = out->dtype == SNNHIP_F16;
+        float* rows = half ? d_row : out->data;
+        if (half) {
+            const _Float16* xh = reinterpret_cast<const _Float16*>(x->data);
+            if (vec) hipLaunchKernelGGL((dense_kernel<true, _Float16>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.act, d.leaky, xh, d_w, d_b, rows);
+            else hipLaunchKernelGGL((dense_kernel<false, _Float16>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.act, d.leaky, xh, d_w, d_b, rows);
         } else {
-            hipLaunchKernelGGL(dense_kernel<false>, grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.act, d.leaky, x->data, d_w, d_b,
-                               out->data);
+            if (vec) hipLaunchKernelGGL((dense_kernel<true, float>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.act, d.leaky, x->data, d_w, d_b, rows);
+            else hipLaunchKernelGGL((dense_kernel<false, float>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.act, d.leaky, x->data, d_w, d_b, rows);
         }
         SNNHIP_CHECK_HIP(hipGetLastError());
         if (d.act == SNNHIP_DENSE_SOFTMAX) {
-            hipLaunchKernelGGL(softmax_rows_kernel, dim3(d.batch), dim3(256), 0, ctx->stream, d.out_units, out->data);
+            hipLaunchKernelGGL(softmax_rows_kernel, dim3(d.batch), dim3(256), 0, ctx->stream, d.out_units, rows);
+            SNNHIP_CHECK_HIP(hipGetLastError());
+        }
+        if (half) {
+            const size_t n = static_cast<size_t>(d.batch) * d.out_units;
+            hipLaunchKernelGGL(convert_rows_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, n, rows,
+                               reinterpret_cast<_Float16*>(out->data));
             SNNHIP_CHECK_HIP(hipGetLastError());
         }
         return SNNHIP_OK;
@@ -163,6 +182,11 @@ int make_dense_plan(snnhip_ctx* ctx, const snnhip_dense_desc& d, const float* w_
     if (d.useBias && bias) b.assign(bias, bias + d.out_units);
     int rc = plan->upload(w_flat, static_cast<size_t>(d.in_units) * d.out_units, &plan->d_w);
     if (rc == SNNHIP_OK) rc = plan->upload(b.data(), b.size(), &plan->d_b);
+    if (rc == SNNHIP_OK) {
+        std::vector<float> z(static_cast<size_t>(d.batch) * d.out_units, 0.0f);
+        rc = plan->upload(z.data(), z.size(), &plan->d_row);
+    }
+    plan->anyDtype = true; // activations may be fp32 or half (weights and arithmetic are fp32 either way)
     if (rc != SNNHIP_OK) {
         delete plan;
         return rc;

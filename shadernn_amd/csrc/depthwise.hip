@@ -16,9 +16,9 @@ struct DwParams {
     int C4; // ceil(C/4)
 };
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void depthwise_kernel(DwParams p, const float* __restrict__ x, const float* __restrict__ wpk,
-                                                        const float4* __restrict__ epi, float* __restrict__ y) {
+template <bool VEC, typename T>
+__global__ __launch_bounds__(256) void depthwise_kernel(DwParams p, const T* __restrict__ x, const float* __restrict__ wpk,
+                                                        const float4* __restrict__ epi, T* __restrict__ y) {
     const size_t total = static_cast<size_t>(p.N) * p.OH * p.OW * p.C4;
     for (size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; idx < total; idx += static_cast<size_t>(gridDim.x) * 256) {
         const int cq = static_cast<int>(idx % p.C4);
@@ -32,22 +32,21 @@ __global__ __launch_bounds__(256) void depthwise_kernel(DwParams p, const float*
         const int efx = min(p.kw, p.W - s0x), efy = min(p.kh, p.H - s0y);
         const int c0 = cq * 4;
         float acc[4] = {0, 0, 0, 0};
-        const float* xn = x + static_cast<size_t>(n) * p.H * p.W * p.C;
+        const T* xn = x + static_cast<size_t>(n) * p.H * p.W * p.C;
         for (int fy = sfy; fy < efy; ++fy) {
             for (int fx = sfx; fx < efx; ++fx) {
-                const float* xp = xn + (static_cast<size_t>(s0y + fy) * p.W + (s0x + fx)) * p.C + c0;
+                const T* xp = xn + (static_cast<size_t>(s0y + fy) * p.W + (s0x + fx)) * p.C + c0;
                 const float4 w = *reinterpret_cast<const float4*>(wpk + (static_cast<size_t>(fy) * p.kw + fx) * p.C4 * 4 + c0);
+                const float wv[4] = {w.x, w.y, w.z, w.w};
                 if (VEC) {
-                    const float4 v = *reinterpret_cast<const float4*>(xp);
-                    acc[0] = fmaf(v.x, w.x, acc[0]);
-                    acc[1] = fmaf(v.y, w.y, acc[1]);
-                    acc[2] = fmaf(v.z, w.z, acc[2]);
-                    acc[3] = fmaf(v.w, w.w, acc[3]);
+                    float v[4];
+                    ldv<T, 4>(xp, v);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[b] = fmaf(v[b], wv[b], acc[b]);
                 } else {
-                    const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
-                        if (c0 + b < p.C) acc[b] = fmaf(xp[b], wv[b], acc[b]);
+                        if (c0 + b < p.C) acc[b] = fmaf(static_cast<float>(xp[b]), wv[b], acc[b]);
                 }
             }
         }
@@ -58,13 +57,13 @@ __global__ __launch_bounds__(256) void depthwise_kernel(DwParams p, const float*
             float v = epi_affine(acc[b], e, p.useBN);
             o[b] = epi_act(p.act == SNNHIP_ACT_SILU_QUIRK ? SNNHIP_ACT_SILU : p.act, p.leaky, v, v);
         }
-        float* yo = y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox) * p.C + c0;
+        T* yo = y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox) * p.C + c0;
         if (VEC) {
-            *reinterpret_cast<float4*>(yo) = make_float4(o[0], o[1], o[2], o[3]);
+            stv<T, 4>(yo, o);
         } else {
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                if (c0 + b < p.C) yo[b] = o[b];
+                if (c0 + b < p.C) yo[b] = static_cast<T>(o[b]);
         }
     }
 }
@@ -72,9 +71,9 @@ __global__ __launch_bounds__(256) void depthwise_kernel(DwParams p, const float*
 // 3x3, C % 4 == 0: one thread = a strip of 4 adjacent output pixels x 4 channels.  The 3 x (3*STRIDE + 3) input window is loaded once
 // (18 float4 for stride 1, 27 for stride 2, instead of 36) and the 9 weight quads once per strip instead of once per pixel; the
 // activation is the branch-free form when it is one of {none, relu, relu6, leakyRelu} (MobileNetV2: relu6 everywhere).
-template <int STRIDE, bool SIMPLE>
-__global__ __launch_bounds__(256) void depthwise3x3_strip_kernel(DwParams p, ActCfg ac, const float* __restrict__ x, const float* __restrict__ wpk,
-                                                                 const float4* __restrict__ epi, float* __restrict__ y) {
+template <int STRIDE, bool SIMPLE, typename T>
+__global__ __launch_bounds__(256) void depthwise3x3_strip_kernel(DwParams p, ActCfg ac, const T* __restrict__ x, const float* __restrict__ wpk,
+                                                                 const float4* __restrict__ epi, T* __restrict__ y) {
     constexpr int COLS = 3 * STRIDE + 3; // input columns feeding 4 outputs
     const int strips = (p.OW + 3) >> 2;
     const size_t total = static_cast<size_t>(p.N) * p.OH * strips * p.C4;
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_strip_kernel(DwParams p, Act
         const int n = static_cast<int>(r / p.OH);
         const int c0 = cq * 4, ox0 = st * 4;
         const int ix0 = ox0 * STRIDE - p.padx, iy0 = oy * STRIDE - p.pady;
-        const float* xn = x + static_cast<size_t>(n) * p.H * p.W * p.C + c0;
+        const T* xn = x + static_cast<size_t>(n) * p.H * p.W * p.C + c0;
         float4 w[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(wpk + static_cast<size_t>(t) * p.C4 * 4 + c0);
@@ -99,16 +98,21 @@ __global__ __launch_bounds__(256) void depthwise3x3_strip_kernel(DwParams p, Act
         for (int fy = 0; fy < 3; ++fy) {
             float4 v[COLS];
             const int sy = iy0 + fy;
+            auto ld4 = [&](const T* ptr) {
+                float t[4];
+                ldv<T, 4>(ptr, t);
+                return make_float4(t[0], t[1], t[2], t[3]);
+            };
             if (interior) {
-                const float* row = xn + (static_cast<size_t>(sy) * p.W + ix0) * p.C;
+                const T* row = xn + (static_cast<size_t>(sy) * p.W + ix0) * p.C;
 #pragma unroll
-                for (int c = 0; c < COLS; ++c) v[c] = *reinterpret_cast<const float4*>(row + static_cast<size_t>(c) * p.C);
+                for (int c = 0; c < COLS; ++c) v[c] = ld4(row + static_cast<size_t>(c) * p.C);
             } else {
 #pragma unroll
                 for (int c = 0; c < COLS; ++c) { // taps outside the image are skipped by the shader == zero contribution
                     const int sx = ix0 + c;
                     v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v[c] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(sy) * p.W + sx) * p.C);
+                    if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v[c] = ld4(xn + (static_cast<size_t>(sy) * p.W + sx) * p.C);
                 }
             }
 #pragma unroll
@@ -137,7 +141,8 @@ __global__ __launch_bounds__(256) void depthwise3x3_strip_kernel(DwParams p, Act
             } else {
                 o = make_float4(epi_act(act, ac.leaky, o.x, o.x), epi_act(act, ac.leaky, o.y, o.y), epi_act(act, ac.leaky, o.z, o.z), epi_act(act, ac.leaky, o.w, o.w));
             }
-            *reinterpret_cast<float4*>(y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox0 + a) * p.C + c0) = o;
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+            stv<T, 4>(y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox0 + a) * p.C + c0, ov);
         }
     }
 }
@@ -165,13 +170,16 @@ struct DepthwisePlan : ConvPlanBase {
             const dim3 g4(static_cast<unsigned>(blocks4));
             const float4* e4 = reinterpret_cast<const float4*>(d_epi);
             const bool simple = act_is_simple(p.act);
-            if (p.sh == 1) {
-                if (simple) hipLaunchKernelGGL((depthwise3x3_strip_kernel<1, true>), g4, dim3(256), 0, ctx->stream, p, ac, x->data, d_w, e4, out->data);
-                else hipLaunchKernelGGL((depthwise3x3_strip_kernel<1, false>), g4, dim3(256), 0, ctx->stream, p, ac, x->data, d_w, e4, out->data);
+#define SNNHIP_DW(ST, SI, TT) \
+    hipLaunchKernelGGL((depthwise3x3_strip_kernel<ST, SI, TT>), g4, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const TT*>(x->data), d_w, e4, reinterpret_cast<TT*>(out->data))
+            if (dtype == SNNHIP_F16) {
+                if (p.sh == 1) { if (simple) SNNHIP_DW(1, true, _Float16); else SNNHIP_DW(1, false, _Float16); }
+                else { if (simple) SNNHIP_DW(2, true, _Float16); else SNNHIP_DW(2, false, _Float16); }
             } else {
-                if (simple) hipLaunchKernelGGL((depthwise3x3_strip_kernel<2, true>), g4, dim3(256), 0, ctx->stream, p, ac, x->data, d_w, e4, out->data);
-                else hipLaunchKernelGGL((depthwise3x3_strip_kernel<2, false>), g4, dim3(256), 0, ctx->stream, p, ac, x->data, d_w, e4, out->data);
+                if (p.sh == 1) { if (simple) SNNHIP_DW(1, true, float); else SNNHIP_DW(1, false, float); }
+                else { if (simple) SNNHIP_DW(2, true, float); else SNNHIP_DW(2, false, float); }
             }
+#undef SNNHIP_DW
             SNNHIP_CHECK_HIP(hipGetLastError());
             return SNNHIP_OK;
         }
@@ -179,13 +187,15 @@ struct DepthwisePlan : ConvPlanBase {
         size_t blocks = (total + 255) / 256;
         if (blocks > cap) blocks = cap;
         if (blocks == 0) return SNNHIP_OK;
-        if (vec) {
-            hipLaunchKernelGGL(depthwise_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, p, x->data, d_w,
-                               reinterpret_cast<const float4*>(d_epi), out->data);
+        const dim3 gg(static_cast<unsigned>(blocks));
+        const float4* e4 = reinterpret_cast<const float4*>(d_epi);
+#define SNNHIP_DWG(V, TT) hipLaunchKernelGGL((depthwise_kernel<V, TT>), gg, dim3(256), 0, ctx->stream, p, reinterpret_cast<const TT*>(x->data), d_w, e4, reinterpret_cast<TT*>(out->data))
+        if (dtype == SNNHIP_F16) {
+            if (vec) SNNHIP_DWG(true, _Float16); else SNNHIP_DWG(false, _Float16);
         } else {
-            hipLaunchKernelGGL(depthwise_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, p, x->data, d_w,
-                               reinterpret_cast<const float4*>(d_epi), out->data);
+            if (vec) SNNHIP_DWG(true, float); else SNNHIP_DWG(false, float);
         }
+#undef SNNHIP_DWG
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -220,8 +230,10 @@ int make_depthwise_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_chw, 
     plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * C + static_cast<double>(g.N) * g.OH * g.OW * C + static_cast<double>(C) * taps);
     char buf[200];
     const bool strip = (C % 4) == 0 && g.kh == 3 && g.kw == 3 && g.sh == g.sw && (g.sh == 1 || g.sh == 2);
-    snprintf(buf, sizeof(buf), "depthwise_f32 k=%dx%d s=%d c=%d %s", g.kh, g.kw, g.sh, C, strip ? "vec4 strip4" : ((C % 4) == 0 ? "vec4" : "scalar"));
+    snprintf(buf, sizeof(buf), "depthwise_%s k=%dx%d s=%d c=%d %s", g.dtype == SNNHIP_F16 ? "f16" : "f32", g.kh, g.kw, g.sh, C, strip ? "vec4 strip4" : ((C % 4) == 0 ? "vec4" : "scalar"));
     plan->desc = buf;
+    plan->dtype = g.dtype;
+    if (g.dtype == SNNHIP_F16) plan->bytes *= 0.5;
     *out = plan;
     return SNNHIP_OK;
 }

@@ -16,48 +16,6 @@ __device__ __forceinline__ float4 act4(int act, float leaky, float4 v) {
     return make_float4(act1(act, leaky, v.x), act1(act, leaky, v.y), act1(act, leaky, v.z), act1(act, leaky, v.w));
 }
 
-// Element access: every kernel is instantiated for T = float and T = _Float16 (SNNHIP_F16 tensors: half storage, fp32 arithmetic,
-// round-to-nearest-even on store) and for CV = 4 (C % 4 == 0: one 16- or 8-byte access) or CV = 1.
-template <typename T, int CV>
-__device__ __forceinline__ void ldv(const T* __restrict__ p, float (&v)[CV]) {
-    if (CV == 4) {
-        if (sizeof(T) == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(p);
-            v[0] = t.x;
-            v[1 % CV] = t.y;
-            v[2 % CV] = t.z;
-            v[3 % CV] = t.w;
-        } else {
-            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-            const h4 t = *reinterpret_cast<const h4*>(p);
-            v[0] = static_cast<float>(t[0]);
-            v[1 % CV] = static_cast<float>(t[1]);
-            v[2 % CV] = static_cast<float>(t[2]);
-            v[3 % CV] = static_cast<float>(t[3]);
-        }
-    } else {
-        v[0] = static_cast<float>(p[0]);
-    }
-}
-template <typename T, int CV>
-__device__ __forceinline__ void stv(T* __restrict__ p, const float (&v)[CV]) {
-    if (CV == 4) {
-        if (sizeof(T) == 4) {
-            *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % CV], v[2 % CV], v[3 % CV]);
-        } else {
-            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-            h4 t;
-            t[0] = static_cast<_Float16>(v[0]);
-            t[1] = static_cast<_Float16>(v[1 % CV]);
-            t[2] = static_cast<_Float16>(v[2 % CV]);
-            t[3] = static_cast<_Float16>(v[3 % CV]);
-            *reinterpret_cast<h4*>(p) = t;
-        }
-    } else {
-        p[0] = static_cast<T>(v[0]);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ add / activation / batch-norm
 // mode 0: y = act(a + b)   mode 1: y = act(a)   mode 2: y = act(scale[c] * (a - mean[c]) + beta[c]),  tab[c] = {scale, mean, beta, 0}
 template <int MODE, int CV, typename T>

@@ -66,6 +66,48 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - __fdividef(2.0f, t + 1.0f);
 }
 
+// Element access: every kernel is instantiated for T = float and T = _Float16 (SNNHIP_F16 tensors: half storage, fp32 arithmetic,
+// round-to-nearest-even on store) and for CV = 4 (C % 4 == 0: one 16- or 8-byte access) or CV = 1.
+template <typename T, int CV>
+__device__ __forceinline__ void ldv(const T* __restrict__ p, float (&v)[CV]) {
+    if (CV == 4) {
+        if (sizeof(T) == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] = t.x;
+            v[1 % CV] = t.y;
+            v[2 % CV] = t.z;
+            v[3 % CV] = t.w;
+        } else {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 t = *reinterpret_cast<const h4*>(p);
+            v[0] = static_cast<float>(t[0]);
+            v[1 % CV] = static_cast<float>(t[1]);
+            v[2 % CV] = static_cast<float>(t[2]);
+            v[3 % CV] = static_cast<float>(t[3]);
+        }
+    } else {
+        v[0] = static_cast<float>(p[0]);
+    }
+}
+template <typename T, int CV>
+__device__ __forceinline__ void stv(T* __restrict__ p, const float (&v)[CV]) {
+    if (CV == 4) {
+        if (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % CV], v[2 % CV], v[3 % CV]);
+        } else {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 t;
+            t[0] = static_cast<_Float16>(v[0]);
+            t[1] = static_cast<_Float16>(v[1 % CV]);
+            t[2] = static_cast<_Float16>(v[2 % CV]);
+            t[3] = static_cast<_Float16>(v[3 % CV]);
+            *reinterpret_cast<h4*>(p) = t;
+        }
+    } else {
+        p[0] = static_cast<T>(v[0]);
+    }
+}
+
 // coordinate resolution of vk_conv2d.comp:168-218; returns -1 when the fetch yields 0
 __device__ __forceinline__ int resolve_coord(int s, int size, int padMode) {
     if (padMode == SNNHIP_PAD_REPLICATE) return min(max(s, 0), size - 1);

@@ -266,7 +266,7 @@ InferencePassesSptr SeparableConv2DLayerHip::createCS(const LayerGenOptions&) co
     d.leaky = _desc.leakyReluAlpha;
     d.useBias = 1; // no useBias constant: the bias buffer is always read
     d.useBN = _desc.useBatchNormalization ? 1 : 0;
-    d.dtype = SNNHIP_F32;
+    d.dtype = _desc.preferHp ? SNNHIP_F16 : SNNHIP_F32; // separableconvolutionVulkan.cpp:142 picks the _fp16 shader on preferHp
     d.OH = static_cast<int>(oh);
     d.OW = static_cast<int>(ow);
     const int taps = d.kh * d.kw;

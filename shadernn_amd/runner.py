@@ -15,7 +15,7 @@ def _layer_plan(ctx, layer, shape, dtype=capi.F32):
     if t == "DepthwiseConv2D":
         return capi.conv2d_plan(ctx, n, h, w, layer["w"], layer["b"], stride=layer["stride"],
                                 pads=capi.same_padding(layer["kernel"]) if layer["padding"] == "same" else (0, 0, 0, 0), act=layer["activation"],
-                                leaky=layer.get("alpha", 0.0), bn=layer["bn"], depthwise=True)
+                                leaky=layer.get("alpha", 0.0), bn=layer["bn"], depthwise=True, dtype=dtype)
     if t == "Dense":
         return capi.dense_plan(ctx, n, layer["w"], layer["units"], layer["b"], act=layer["activation"] if layer["activation"] in capi.DENSE_ACT else "relu")
     if t == "Subpixel":

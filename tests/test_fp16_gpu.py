@@ -56,8 +56,22 @@ def test_fp16_tensor_roundtrip_and_dtype_checks(ctx):
     p32 = snn.conv2d_plan(ctx, 2, 5, 7, _rand((16, 12, 3, 3), 86, 0.1))
     with pytest.raises(snn.SnnHipError):  # fp32 plan, fp16 tensor
         p32(t)
-    with pytest.raises(snn.SnnHipError):  # depthwise has no fp16 kernel
-        snn.conv2d_plan(ctx, 2, 5, 7, _rand((12, 3, 3), 87, 0.1), depthwise=True, dtype=snn.F16)
+
+
+@pytest.mark.parametrize("which", ["resnet18", "mobilenetv2"])
+def test_fp16_classifiers_match_quantised_oracle(ctx, which):
+    """Depthwise, pooling, flatten and dense also take half tensors: ResNet-18 / MobileNetV2 end to end in fp16."""
+    import shadernn_amd as snn
+    from shadernn_amd import models
+
+    net = models.resnet18(seed=2, num_classes=10, width=16) if which == "resnet18" else models.mobilenetv2(seed=3, num_classes=10, width_mult=0.5)
+    x = np.random.default_rng(7).random((2, 64, 64, 3), dtype=np.float32)
+    r = snn.GraphRunner(ctx, net, 2, 64, 64, dtype=snn.F16)
+    y = r(x).reshape(2, -1)
+    want = O.forward(net, x, fp16=True).reshape(2, -1)
+    np.testing.assert_allclose(y, want, rtol=2e-2, atol=4e-3)        # softmax outputs
+    np.testing.assert_allclose(y.sum(axis=1), 1.0, atol=4e-3)
+    np.testing.assert_allclose(y, O.forward(net, x).reshape(2, -1), atol=0.05)
 
 
 @pytest.mark.parametrize("which", ["style", "candy", "resnet_trunk"])

@@ -70,7 +70,7 @@ enum { SNNHIP_PAD_NONE = 0, SNNHIP_PAD_CONSTANT = 1, SNNHIP_PAD_REPLICATE = 2, S
 /* element types.  SNNHIP_F16 = IEEE half storage (the reference's RGBA16F textures / "preferHp", inferencegraph.h ColorFormat::RGBA16F):
  * tensors hold halfs in HBM, kernels convert on load, accumulate in fp32 (fp16-input MFMA for the convolutions) and round to nearest even
  * on store.  The host-side upload / download entry points always speak fp32 and convert. */
-enum { SNNHIP_F32 = 0, SNNHIP_F16 = 1 };
+enum { SNNHIP_F32 = 0, SNNHIP_F16 = 1, SNNHIP_U8 = 2 /* 8-bit image input of snnhip_image_u8_plan_create only */ };
 
 /* ---- context -------------------------------------------------------------------------------------- */
 
@@ -228,6 +228,79 @@ typedef struct {
 /* y = act((x - mean_hw) * gamma / sqrt(var_hw + eps) + beta), statistics per image and channel, biased variance (computed in one sweep
  * around a per-channel pivot: same value as the shader's two-pass form up to fp32 rounding) */
 int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_desc* desc, const float* beta, const float* gamma, snnhip_plan** out);
+
+/* ---- the remaining graph operators (U-Net / YOLOv3-tiny concat, unary, transposed convolution, the
+ * moonwellbox "Calculate" op) and the device-side step either side of a model run (input resize + normalise, u8 image -> tensor).
+ *   reference interface replaced                                                              | entry point
+ *   ConcatenateLayerVulkan::createCS concatenationVulkan.cpp:31-88 + vk_concat.comp:39-52      | snnhip_concat_plan_create (two inputs)
+ *   UnaryLayerVulkan::createCS unaryVulkan.cpp:30-83 + vk_unary.comp:40-90                     | snnhip_unary_plan_create
+ *   Conv2DTransposeLayerGl::createCS deconv2dGL.cpp:282-343 + cs_4x_deconv_2s_RGBA.glsl:150-195 | snnhip_deconv2d_plan_create
+ *   CalculateLayerGl::createFS calculationGL.cpp:28-57 + fs_calculation.glsl:25-41            | snnhip_calculate_plan_create
+ *   ImageTextureVulkan::resize imageTextureVulkan.cpp:137-183 + vk_resize.comp:41-62           | snnhip_resize_plan_create
+ *   snn::normalize / norm2rgba32f image.cpp:712-796 (ImageTexture::convertToRGBA32FAndNormalize) | snnhip_image_u8_plan_create */
+typedef struct {
+    int N, H, W;
+    int C0, C1; /* channels of input 0 / input 1 */
+    int OC;     /* the layer's "outputPlanes".  The shader concatenates TEXEL PLANES (4-channel groups), not channels: output plane p comes
+                   from input 0 while p < ceil(C0/4), else from input 1's plane p - ceil(C0/4) (vk_concat.comp:43-49).  For C0 % 4 == 0 that
+                   is the ordinary channel concat; otherwise input 1 starts at channel 4*ceil(C0/4), the gap reads 0, and whatever does
+                   not fit into ceil(OC/4) planes is dropped -- reproduced as is. */
+} snnhip_concat_desc;
+int snnhip_concat_plan_create(snnhip_ctx* ctx, const snnhip_concat_desc* desc, snnhip_plan** out);
+
+/* vk_unary.comp:46-88 (UnaryDesc::opType is never parsed from JSON, unary.h:27-32: models get 0 = copy) */
+enum { SNNHIP_UNARY_COPY = 0, SNNHIP_UNARY_FIXED = 1, SNNHIP_UNARY_NEG = 2, SNNHIP_UNARY_RCP = 3, SNNHIP_UNARY_SQUARE = 4, SNNHIP_UNARY_EXP = 5, SNNHIP_UNARY_ABS = 6 };
+typedef struct {
+    int N, H, W, C;
+    int op;      /* SNNHIP_UNARY_* */
+    float value; /* the constant of SNNHIP_UNARY_FIXED */
+} snnhip_unary_desc;
+int snnhip_unary_plan_create(snnhip_ctx* ctx, const snnhip_unary_desc* desc, snnhip_plan** out);
+
+/* Transposed convolution as the reference's compute shader states it for k=4, s=2 (cs_4x_deconv_2s_RGBA.glsl:150-182): a correlation of the
+ * kernel with the zero-stuffed input, zero outside the input (the GL sampler clamps to a transparent border, openGLBackend.cpp:41-43):
+ *     y[oy][ox][o] = act(BN(bias[o] + sum_{iy,ix,i} x[iy][ix][i] * w[o][i][(k-1-p) - oy + s*iy][(k-1-p) - ox + s*ix]))   (taps inside the kernel)
+ * with p = (k - s) / 2 and output s*H x s*W for "same", p = 0 and s*H + k - s for anything else (deconv2dGL.cpp:345-355).  The desc is the
+ * conv desc: kh == kw, sh == sw, padT carries p, padMode / padB / padL / padR are ignored, OH / OW = 0 derives the "same" extent.
+ * Activations: relu, tanh, sigmoid, leakyRelu (deconv2dGL.cpp:198-207); BN eps 1e-3 (cs_4x_deconv_2s_RGBA.glsl:190).
+ * Pinned against the reference arithmetic for k=4, s=2 only -- the 3x3 / 4x4 stride-1 GL shaders carry sampler-state-dependent texel
+ * tests (cs_3x_deconv_RGBA.glsl:77-87) that have no counterpart off the GL rasteriser; other (k, s) follow the formula above. */
+int snnhip_deconv2d_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, const float* w_oihw, const float* bias, const float* bn_beta,
+                                const float* bn_gamma, const float* bn_mean, const float* bn_var, snnhip_plan** out);
+
+/* fs_calculation.glsl:25-41: y[..][c] = x[..][c % 4] / x[..][8] for c % 4 < 3, else 0 (every 4-channel output pass repeats the same value) */
+typedef struct {
+    int N, H, W, C; /* C >= 9: the divisor is channel 8 (texel plane 2, .r) */
+    int OC;
+} snnhip_calculate_desc;
+int snnhip_calculate_plan_create(snnhip_ctx* ctx, const snnhip_calculate_desc* desc, snnhip_plan** out);
+
+/* Input pre-processing on the device: resample to OH x OW and normalise, y = (sample(x) - means[c % 4]) * norms[c % 4] (vk_resize.comp:48-60).
+ * Sample position of output pixel (x, y): ((x + 0.5) * W / OW, (y + 0.5) * H / OH) in input texel space, clamp-to-edge; linear = the Vulkan
+ * bilinear filter with exact fp32 weights (hardware uses 8-bit sub-texel weights: up to 2^-9 of the local range away), else nearest. */
+typedef struct {
+    int N, H, W, C;
+    int OH, OW; /* ImageTextureVulkan::resize: round(W / xScale), round(H / yScale) (imageTextureVulkan.cpp:150-151) */
+    float means[4], norms[4];
+    int linear;
+} snnhip_resize_desc;
+int snnhip_resize_plan_create(snnhip_ctx* ctx, const snnhip_resize_desc* desc, snnhip_plan** out);
+
+/* 8-bit image -> normalised 4-channel tensor, the device-side form of convertToRGBA32FAndNormalize (image.cpp:712-751):
+ *   src_channels 4 (RGBA8): y[c] = (u8[c] - means[c]) * norms[c];   3 (RGB8): same for c < 3, alpha = 1;
+ *   1 (R8): y[0] = (u8 - means[0]) * norms[0], y[1..3] = (0 - means[0]) * norms[0].
+ * The input of snnhip_plan_run is a tensor of dtype SNNHIP_U8 [N][H][W][src_channels]; the output is [N][H][W][4] fp32 or fp16. */
+typedef struct {
+    int N, H, W;
+    int src_channels;
+    float means[4], norms[4];
+} snnhip_image_u8_desc;
+int snnhip_image_u8_plan_create(snnhip_ctx* ctx, const snnhip_image_u8_desc* desc, snnhip_plan** out);
+/* raw byte upload for SNNHIP_U8 tensors (nbytes must equal snnhip_tensor_bytes) */
+int snnhip_tensor_upload_raw(snnhip_tensor* t, const void* host, size_t nbytes);
+/* index of the largest element of image n of t (first one on ties, like std::max_element in MixedInferenceCore::run, core.cpp:228-234,
+ * which reports index + 1 as classifierOutput); stream sync + a 4-byte D2H */
+int snnhip_tensor_argmax(const snnhip_tensor* t, int n, int* out_index);
 
 /* Try to replace a linear chain of plans (plan[i+1] consumes only plan[i]'s output) by fused kernels.
  * On success *out runs the whole chain in <= n launches; intermediate tensors that become internal are never

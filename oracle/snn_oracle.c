@@ -709,6 +709,167 @@ void snn_oracle_upsample(const float* x, int N, int H, int W, int C, float scale
     }
 }
 
+/* ---- SURVEY.md section 8(f) rank 4 ---- */
+
+void snn_oracle_concat(const float* x0, const float* x1, long pixels, int C0, int C1, int OC, float* y) {
+    int P0 = (C0 + 3) / 4, P1 = (C1 + 3) / 4;
+    for (long px = 0; px < pixels; ++px)
+        for (int c = 0; c < OC; ++c) {
+            int p = c / 4, l = c % 4;
+            float v = 0.0f;
+            if (p < P0) { /* vk_concat.comp:45-47 */
+                int ch = 4 * p + l;
+                if (ch < C0) v = x0[px * C0 + ch];
+            } else if (p - P0 < P1) { /* :48-49 */
+                int ch = 4 * (p - P0) + l;
+                if (ch < C1) v = x1[px * C1 + ch];
+            }
+            y[px * OC + c] = v;
+        }
+}
+
+void snn_oracle_unary(const float* x, long count, int op, float value, float* y) {
+    for (long i = 0; i < count; ++i) {
+        float c = x[i];
+        switch (op) {
+        case 1: c = value; break;
+        case 2: c = 0.0f - c; break;
+        case 3: c = 1.0f / c; break;
+        case 4: c = c * c; break;
+        case 5: c = expf(c); break;
+        case 6: c = fabsf(c); break;
+        default: break;
+        }
+        y[i] = c;
+    }
+}
+
+void snn_oracle_calculate(const float* x, long pixels, int C, int OC, float* y) {
+    for (long px = 0; px < pixels; ++px) {
+        float illumination = x[px * C + 8]; /* texelFetch(inputTextures, ivec3(uv, 2), 0).r */
+        for (int c = 0; c < OC; ++c) y[px * OC + c] = (c % 4 < 3) ? x[px * C + c % 4] / illumination : 0.0f;
+    }
+}
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void snn_oracle_resize(const float* x, int N, int H, int W, int C, int OH, int OW, const float* means4, const float* norms4, int linear, float* y) {
+    for (int n = 0; n < N; ++n) {
+        const float* img = x + (long) n * H * W * C;
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox) {
+                float u = ((float) ox + 0.5f) / (float) OW * (float) W; /* texCoords * textureSize */
+                float v = ((float) oy + 0.5f) / (float) OH * (float) H;
+                for (int c = 0; c < C; ++c) {
+                    float val;
+                    if (linear) {
+                        float fu = u - 0.5f, fv = v - 0.5f;
+                        float x0f = floorf(fu), y0f = floorf(fv);
+                        float ax = fu - x0f, ay = fv - y0f;
+                        int x0 = clampi((int) x0f, 0, W - 1), x1 = clampi((int) x0f + 1, 0, W - 1);
+                        int y0 = clampi((int) y0f, 0, H - 1), y1 = clampi((int) y0f + 1, 0, H - 1);
+                        float top = img[((long) y0 * W + x0) * C + c] * (1.0f - ax) + img[((long) y0 * W + x1) * C + c] * ax;
+                        float bot = img[((long) y1 * W + x0) * C + c] * (1.0f - ax) + img[((long) y1 * W + x1) * C + c] * ax;
+                        val = top * (1.0f - ay) + bot * ay;
+                    } else {
+                        val = img[((long) clampi((int) floorf(v), 0, H - 1) * W + clampi((int) floorf(u), 0, W - 1)) * C + c];
+                    }
+                    y[(((long) n * OH + oy) * OW + ox) * C + c] = (val - means4[c % 4]) * norms4[c % 4];
+                }
+            }
+    }
+}
+
+void snn_oracle_image_u8(const unsigned char* x, long pixels, int sc, const float* m, const float* s, float* y) {
+    for (long i = 0; i < pixels; ++i) {
+        const unsigned char* src = x + i * sc;
+        float* dst = y + i * 4;
+        if (sc == 4) {
+            for (int c = 0; c < 4; ++c) dst[c] = (float) (((float) src[c] - m[c]) * s[c]);
+        } else if (sc == 3) {
+            for (int c = 0; c < 3; ++c) dst[c] = (float) (((float) src[c] - m[c]) * s[c]);
+            dst[3] = 1.0f;
+        } else {
+            dst[0] = (float) (((float) src[0] - m[0]) * s[0]);
+            dst[1] = dst[2] = dst[3] = (float) ((0.0f - m[0]) * s[0]);
+        }
+    }
+}
+
+long snn_oracle_argmax(const float* x, long count) {
+    long best = 0;
+    for (long i = 1; i < count; ++i)
+        if (x[best] < x[i]) best = i; /* std::max_element keeps the first of equal elements */
+    return best;
+}
+
+void snn_oracle_deconv2d(const float* x, int N, int H, int W, int IC, int OC, int k, int s, int p, int OH, int OW, const float* w, const float* bias,
+                         const float* bn_beta, const float* bn_gamma, const float* bn_mean, const float* bn_var, int act, float leaky, float* y) {
+    int base = k - 1 - p;
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox)
+                for (int o = 0; o < OC; ++o) {
+                    float acc = 0.0f;
+                    for (int iy = 0; iy < H; ++iy) {
+                        int ky = base - oy + s * iy;
+                        if (ky < 0 || ky >= k) continue;
+                        for (int ix = 0; ix < W; ++ix) {
+                            int kx = base - ox + s * ix;
+                            if (kx < 0 || kx >= k) continue;
+                            const float* px = x + (((long) n * H + iy) * W + ix) * IC;
+                            for (int i = 0; i < IC; ++i) acc += px[i] * w[(((long) o * IC + i) * k + ky) * k + kx];
+                        }
+                    }
+                    float v = acc + (bias ? bias[o] : 0.0f);
+                    if (bn_beta) v = ((bn_gamma[o] / sqrtf(bn_var[o] + 0.001f)) * (v - bn_mean[o])) + bn_beta[o];
+                    y[(((long) n * OH + oy) * OW + ox) * OC + o] = act_apply(act, leaky, v, 0.0f);
+                }
+}
+
+static void deconv_fetch(const float* x, int H, int W, int IC, int px, int py, int layer, float t[4]) {
+    for (int j = 0; j < 4; ++j) {
+        int c = 4 * layer + j;
+        t[j] = (px >= 0 && px < W && py >= 0 && py < H && c < IC) ? x[((long) py * W + px) * IC + c] : 0.0f;
+    }
+}
+
+void snn_oracle_deconv4x4s2_shader(const float* x, int H, int W, int IC, int OC, const float* w_oihw, const float* bias, float* y) {
+    int layers = (IC + 3) / 4, OH = 2 * H, OW = 2 * W;
+    /* deconv2dGL.cpp:28-80: weightMatrix[o][16*layer + tap] = vec4 over the layer's 4 input channels */
+    float* wm = (float*) calloc((size_t) OC * layers * 16 * 4, sizeof(float));
+    for (int o = 0; o < OC; ++o)
+        for (int i = 0; i < IC; ++i)
+            for (int t = 0; t < 16; ++t) wm[(((long) o * layers + i / 4) * 16 + t) * 4 + i % 4] = w_oihw[((long) o * IC + i) * 16 + t];
+    for (int gy = 0; gy < OH; ++gy)
+        for (int gx = 0; gx < OW; ++gx) {
+            int bx = (gx + 1) / 2, by = (gy + 1) / 2;                 /* :151 */
+            int bw = (gx % 2) + 4 * (gy % 2);                         /* :156 */
+            int widx[4] = {0 + bw, 2 + bw, 8 + bw, 10 + bw};
+            for (int o = 0; o < OC; ++o) {
+                float s = bias ? bias[o] : 0.0f;                      /* :143 */
+                for (int layer = 0; layer < layers; ++layer) {        /* :172-187 */
+                    float t0[4], t1[4], t2[4], t3[4];
+                    deconv_fetch(x, H, W, IC, bx - 1, by - 1, layer, t0); /* texCoord_0 = baseCoord + (-0.5,-0.5): texel baseCoord - 1 */
+                    deconv_fetch(x, H, W, IC, bx, by - 1, layer, t1);
+                    deconv_fetch(x, H, W, IC, bx - 1, by, layer, t2);
+                    deconv_fetch(x, H, W, IC, bx, by, layer, t3);
+                    const float* wo = wm + ((long) o * layers + layer) * 16 * 4;
+                    float d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                    for (int j = 0; j < 4; ++j) {
+                        d0 += t0[j] * wo[widx[0] * 4 + j];
+                        d1 += t1[j] * wo[widx[1] * 4 + j];
+                        d2 += t2[j] * wo[widx[2] * 4 + j];
+                        d3 += t3[j] * wo[widx[3] * 4 + j];
+                    }
+                    s += d0 + d1 + d2 + d3;
+                }
+                y[((long) gy * OW + gx) * OC + o] = s;
+            }
+        }
+    free(wm);
+}
+
 /* shadertemplate_vk_instancenorm.comp:70-160; the sums are accumulated in double here (the shader's 256-thread tree in fp32
  * has no defined order to copy) and rounded to float where the shader stores them */
 void snn_oracle_instancenorm(const float* x, int N, int H, int W, int C, const float* beta, const float* gamma, float eps, int act, float leaky,

@@ -178,6 +178,36 @@ void snn_oracle_upsample(const float* x, int N, int H, int W, int C, float scale
 void snn_oracle_instancenorm(const float* x, int N, int H, int W, int C, const float* beta, const float* gamma, float eps, int act, float leaky,
                              float* y);
 
+/* ---- SURVEY.md section 8(f) rank 4 ---- */
+/* vk_concat.comp:39-52 with inImgDepths = {ceil(C0/4), ceil(C1/4)} (concatenationVulkan.cpp:50-57, dp.cpp:591-595): output TEXEL PLANE p
+ * comes from input 0 while p < ceil(C0/4), else from input 1's plane p - ceil(C0/4); lanes past an input's channel count read the
+ * texture's zero padding; the output keeps OC channels (ceil(OC/4) planes exist, writes past them are dropped) */
+void snn_oracle_concat(const float* x0, const float* x1, long pixels, int C0, int C1, int OC, float* y);
+/* vk_unary.comp:40-90: op 0 copy, 1 fixed value, 2 negate, 3 reciprocal, 4 square, 5 exp, 6 abs */
+void snn_oracle_unary(const float* x, long count, int op, float value, float* y);
+/* fs_calculation.glsl:25-41: y[c] = x[c % 4] / x[8] for c % 4 < 3, else 0 (every output pass of calculationGL.cpp:38-55 runs the same shader) */
+void snn_oracle_calculate(const float* x, long pixels, int C, int OC, float* y);
+/* vk_resize.comp:41-62 under the samplers of vulkanImageResizeOp.cpp:42-70 (linear, clamp to edge) / vulkanImageTransformShaderOp (nearest):
+ * sample at ((x + 0.5) / OW * W, (y + 0.5) / OH * H), then (value - means[c % 4]) * norms[c % 4].  Linear = the Vulkan bilinear
+ * definition with exact weights (hardware quantises them to 8 bits) */
+void snn_oracle_resize(const float* x, int N, int H, int W, int C, int OH, int OW, const float* means4, const float* norms4, int linear, float* y);
+/* image.cpp:712-751 (norm2rgba32f) for RGBA8 (sc 4), RGB8 (3, alpha = 1), R8 (1, the other lanes = (0 - means[0]) * norms[0]) */
+void snn_oracle_image_u8(const unsigned char* x, long pixels, int sc, const float* means4, const float* norms4, float* y);
+/* core.cpp:228-234: std::distance(begin, std::max_element(begin, end)) -- the first of equal maxima (the reference reports it + 1) */
+long snn_oracle_argmax(const float* x, long count);
+/* Transposed convolution, general form of the reference's k=4 s=2 compute shader (see snn_oracle_deconv4x4s2_shader):
+ * y[oy][ox][o] = act(BN(bias[o] + sum x[iy][ix][i] * w[o][i][k-1-p - oy + s*iy][k-1-p - ox + s*ix])), zero outside the input, BN as
+ * cs_4x_deconv_2s_RGBA.glsl:185-191 (gamma / sqrt(var + 1e-3)); bn arrays may be NULL */
+void snn_oracle_deconv2d(const float* x, int N, int H, int W, int IC, int OC, int k, int s, int p, int OH, int OW, const float* w_oihw,
+                         const float* bias, const float* bn_beta, const float* bn_gamma, const float* bn_mean, const float* bn_var, int act, float leaky,
+                         float* y);
+/* cs_4x_deconv_2s_RGBA.glsl:147-195 line by line for one image: baseCoord = floor((xy + 1) / 2), the four nearest-filtered fetches at
+ * baseCoord + {(-1,-1),(0,-1),(-1,0),(0,0)} (zero border: the input sampler clamps to a transparent border, openGLBackend.cpp:41-45),
+ * weight indices {0,2,8,10} + x%2 + 4*(y%2) + 16*layer into the per-output-channel vec4 arrays that deconv2dGL.cpp:28-80 builds
+ * (lane = input channel within the 4-channel layer, index = 16*layer + tap).  Output 2H x 2W.  No BN / activation (tested through
+ * snn_oracle_deconv2d). */
+void snn_oracle_deconv4x4s2_shader(const float* x, int H, int W, int IC, int OC, const float* w_oihw, const float* bias, float* y);
+
 void snn_oracle_srand(uint64_t seed);
 float snn_oracle_random_float(float a, float b);
 

@@ -57,6 +57,27 @@ class InstanceNormDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("act", C.c_int), ("leaky", C.c_float), ("eps", C.c_float)]
 
 
+class ConcatDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C0", C.c_int), ("C1", C.c_int), ("OC", C.c_int)]
+
+
+class UnaryDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("op", C.c_int), ("value", C.c_float)]
+
+
+class CalculateDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("OC", C.c_int)]
+
+
+class ResizeDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("OH", C.c_int), ("OW", C.c_int), ("means", C.c_float * 4),
+                ("norms", C.c_float * 4), ("linear", C.c_int)]
+
+
+class ImageU8Desc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("src_channels", C.c_int), ("means", C.c_float * 4), ("norms", C.c_float * 4)]
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("compute_units", C.c_int), ("lds_bytes_per_cu", C.c_int), ("hbm_bytes", C.c_size_t), ("device", C.c_int)]
 
@@ -99,6 +120,14 @@ SIGNATURES = {
     "snnhip_pad_plan_create": (C.c_int, [_P, C.POINTER(PadDesc), C.POINTER(_P)]),
     "snnhip_upsample_plan_create": (C.c_int, [_P, C.POINTER(UpsampleDesc), C.POINTER(_P)]),
     "snnhip_instancenorm_plan_create": (C.c_int, [_P, C.POINTER(InstanceNormDesc), _FP, _FP, C.POINTER(_P)]),
+    "snnhip_concat_plan_create": (C.c_int, [_P, C.POINTER(ConcatDesc), C.POINTER(_P)]),
+    "snnhip_unary_plan_create": (C.c_int, [_P, C.POINTER(UnaryDesc), C.POINTER(_P)]),
+    "snnhip_deconv2d_plan_create": (C.c_int, [_P, C.POINTER(ConvDesc), _FP, _FP, _FP, _FP, _FP, _FP, C.POINTER(_P)]),
+    "snnhip_calculate_plan_create": (C.c_int, [_P, C.POINTER(CalculateDesc), C.POINTER(_P)]),
+    "snnhip_resize_plan_create": (C.c_int, [_P, C.POINTER(ResizeDesc), C.POINTER(_P)]),
+    "snnhip_image_u8_plan_create": (C.c_int, [_P, C.POINTER(ImageU8Desc), C.POINTER(_P)]),
+    "snnhip_tensor_upload_raw": (C.c_int, [_P, _P, C.c_size_t]),
+    "snnhip_tensor_argmax": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "snnhip_chain_plan_create": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(_P)]),
     "snnhip_plan_run": (C.c_int, [_P, _P, _P]),
     "snnhip_plan_run_n": (C.c_int, [_P, C.POINTER(_P), C.c_int, _P]),
@@ -191,7 +220,7 @@ class Context:
             self.h = None
 
 
-F32, F16 = 0, 1  # SNNHIP_F32 / SNNHIP_F16
+F32, F16, U8 = 0, 1, 2  # SNNHIP_F32 / SNNHIP_F16 / SNNHIP_U8 (8-bit image input of image_u8_plan only)
 
 
 class Tensor:
@@ -233,6 +262,18 @@ class Tensor:
         out = np.empty(self.shape, dtype=np.float32)
         check(lib().snnhip_tensor_download(self.h, _fptr(out)))
         return out
+
+    def upload_u8(self, a):
+        """Raw byte upload of an 8-bit image tensor (dtype=U8)."""
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        assert self.dtype == U8 and a.size == int(np.prod(self.shape)), (a.shape, self.shape)
+        check(lib().snnhip_tensor_upload_raw(self.h, a.ctypes.data_as(_P), a.size))
+
+    def argmax(self, n=0):
+        """Index of the largest element of image n (first on ties) -- the reference reports this + 1 as classifierOutput (core.cpp:228-234)."""
+        out = C.c_int(-1)
+        check(lib().snnhip_tensor_argmax(self.h, n, C.byref(out)))
+        return out.value
 
     def upload_c4hw4(self, a):
         a = np.ascontiguousarray(a, dtype=np.float32)
@@ -448,6 +489,58 @@ def instancenorm_plan(ctx, N, H, W, Cc, beta, gamma, act="", leaky=0.0, eps=1e-5
     b, g = _f32(beta), _f32(gamma)
     h = _P()
     check(lib().snnhip_instancenorm_plan_create(ctx.h, C.byref(d), _fptr(b), _fptr(g), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def concat_plan(ctx, N, H, W, C0, C1, OC=None):
+    d = ConcatDesc(N, H, W, C0, C1, C0 + C1 if OC is None else OC)
+    h = _P()
+    check(lib().snnhip_concat_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+UNARY_OPS = {"copy": 0, "fixed": 1, "neg": 2, "rcp": 3, "square": 4, "exp": 5, "abs": 6}
+
+
+def unary_plan(ctx, N, H, W, Cc, op="copy", value=1.0):
+    d = UnaryDesc(N, H, W, Cc, UNARY_OPS[op] if isinstance(op, str) else int(op), value)
+    h = _P()
+    check(lib().snnhip_unary_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def calculate_plan(ctx, N, H, W, Cc, OC):
+    d = CalculateDesc(N, H, W, Cc, OC)
+    h = _P()
+    check(lib().snnhip_calculate_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def resize_plan(ctx, N, H, W, Cc, OH, OW, means=(0, 0, 0, 0), norms=(1, 1, 1, 1), linear=True):
+    d = ResizeDesc(N, H, W, Cc, OH, OW, (C.c_float * 4)(*means), (C.c_float * 4)(*norms), 1 if linear else 0)
+    h = _P()
+    check(lib().snnhip_resize_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def image_u8_plan(ctx, N, H, W, src_channels, means=(0, 0, 0, 0), norms=(1, 1, 1, 1)):
+    d = ImageU8Desc(N, H, W, src_channels, (C.c_float * 4)(*means), (C.c_float * 4)(*norms))
+    h = _P()
+    check(lib().snnhip_image_u8_plan_create(ctx.h, C.byref(d), C.byref(h)))
+    return Plan(ctx, h)
+
+
+def deconv2d_plan(ctx, N, H, W, w_oihw, bias=None, stride=2, same=True, act="", leaky=0.0, bn=None):
+    """Conv2DTranspose: w_oihw [OC][IC][k][k]; output s*H ("same") or s*H + k - s (deconv2dGL.cpp:345-355)."""
+    w = _f32(w_oihw)
+    OC, IC, k, _ = w.shape
+    p = (k - stride) // 2 if same else 0
+    OH, OW = (stride * H, stride * W) if same else (stride * H + k - stride, stride * W + k - stride)
+    d = _conv_desc(N, H, W, IC, OC, k, stride, (p, 0, 0, 0), "constant", act, leaky, bias is not None, bn is not None, OH, OW)
+    b = _f32(bias) if bias is not None else None
+    bnp = [_f32(bn[key]) for key in ("beta", "gamma", "mean", "var")] if bn is not None else [None] * 4
+    h = _P()
+    check(lib().snnhip_deconv2d_plan_create(ctx.h, C.byref(d), _fptr(w), _fptr(b), *[_fptr(a) for a in bnp], C.byref(h)))
     return Plan(ctx, h)
 
 

@@ -231,7 +231,7 @@ int snnhip_graph_destroy(snnhip_graph* g) {
 
 int snnhip_tensor_alloc(snnhip_ctx* ctx, int n, int h, int w, int c, int dtype, snnhip_tensor** out) {
     SNNHIP_REQUIRE(ctx && out, "tensor_alloc: null argument");
-    SNNHIP_REQUIRE(dtype == SNNHIP_F32 || dtype == SNNHIP_F16, "tensor_alloc: dtype %d not implemented", dtype);
+    SNNHIP_REQUIRE(dtype == SNNHIP_F32 || dtype == SNNHIP_F16 || dtype == SNNHIP_U8, "tensor_alloc: dtype %d not implemented", dtype);
     SNNHIP_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "tensor_alloc: bad dims %dx%dx%dx%d", n, h, w, c);
     auto* t = new (std::nothrow) snnhip_tensor();
     if (!t) return SNNHIP_E_NOMEM;
@@ -251,7 +251,7 @@ int snnhip_tensor_alloc(snnhip_ctx* ctx, int n, int h, int w, int c, int dtype, 
 
 int snnhip_tensor_wrap(snnhip_ctx* ctx, void* device_ptr, int n, int h, int w, int c, int dtype, snnhip_tensor** out) {
     SNNHIP_REQUIRE(ctx && out && device_ptr, "tensor_wrap: null argument");
-    SNNHIP_REQUIRE(dtype == SNNHIP_F32 || dtype == SNNHIP_F16, "tensor_wrap: dtype %d not implemented", dtype);
+    SNNHIP_REQUIRE(dtype == SNNHIP_F32 || dtype == SNNHIP_F16 || dtype == SNNHIP_U8, "tensor_wrap: dtype %d not implemented", dtype);
     SNNHIP_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "tensor_wrap: bad dims %dx%dx%dx%d", n, h, w, c);
     SNNHIP_REQUIRE((reinterpret_cast<uintptr_t>(device_ptr) & 15) == 0, "tensor_wrap: pointer must be 16-byte aligned");
     auto* t = new (std::nothrow) snnhip_tensor();
@@ -282,6 +282,7 @@ int snnhip_tensor_dtype(const snnhip_tensor* t) { return t ? t->dtype : -1; }
 // fp32 <-> fp16 on the host (API edge only): round to nearest even, like the GPU's image stores
 int snnhip_tensor_upload(snnhip_tensor* t, const float* host) {
     SNNHIP_REQUIRE(t && host, "tensor_upload: null argument");
+    SNNHIP_REQUIRE(t->dtype != SNNHIP_U8, "tensor_upload: 8-bit image tensors take snnhip_tensor_upload_raw");
     if (t->dtype == SNNHIP_F16) {
         std::vector<_Float16> tmp(t->count());
         for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = static_cast<_Float16>(host[i]);
@@ -296,6 +297,7 @@ int snnhip_tensor_upload(snnhip_tensor* t, const float* host) {
 
 int snnhip_tensor_download(const snnhip_tensor* t, float* host) {
     SNNHIP_REQUIRE(t && host, "tensor_download: null argument");
+    SNNHIP_REQUIRE(t->dtype != SNNHIP_U8, "tensor_download: not available for 8-bit image tensors");
     if (t->dtype == SNNHIP_F16) {
         std::vector<_Float16> tmp(t->count());
         SNNHIP_CHECK_HIP(hipMemcpyAsync(tmp.data(), t->data, t->bytes(), hipMemcpyDeviceToHost, t->ctx->stream));
@@ -304,6 +306,14 @@ int snnhip_tensor_download(const snnhip_tensor* t, float* host) {
         return SNNHIP_OK;
     }
     SNNHIP_CHECK_HIP(hipMemcpyAsync(host, t->data, t->bytes(), hipMemcpyDeviceToHost, t->ctx->stream));
+    SNNHIP_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
+    return SNNHIP_OK;
+}
+
+int snnhip_tensor_upload_raw(snnhip_tensor* t, const void* host, size_t nbytes) {
+    SNNHIP_REQUIRE(t && host, "tensor_upload_raw: null argument");
+    SNNHIP_REQUIRE(nbytes == t->bytes(), "tensor_upload_raw: %zu bytes given, the tensor holds %zu", nbytes, t->bytes());
+    SNNHIP_CHECK_HIP(hipMemcpyAsync(t->data, host, nbytes, hipMemcpyHostToDevice, t->ctx->stream));
     SNNHIP_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
     return SNNHIP_OK;
 }
@@ -351,6 +361,7 @@ __global__ void fill_half_kernel(_Float16* p, size_t n, float v) {
 
 int snnhip_tensor_fill(snnhip_tensor* t, float value) {
     SNNHIP_REQUIRE(t, "tensor_fill: null argument");
+    SNNHIP_REQUIRE(t->dtype != SNNHIP_U8, "tensor_fill: not available for 8-bit image tensors");
     size_t n = t->count();
     unsigned blocks = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 4096));
     if (t->dtype == SNNHIP_F16)
@@ -431,6 +442,10 @@ int snnhip_plan_run_n(snnhip_plan* plan, const snnhip_tensor* const* inputs, int
     SNNHIP_REQUIRE(plan && inputs && out && n_in > 0, "plan_run: null argument");
     for (int i = 0; i < n_in; ++i) SNNHIP_REQUIRE(inputs[i] && inputs[i]->data, "plan_run: input %d is null", i);
     SNNHIP_REQUIRE(out->data, "plan_run: output has no storage");
+    if (!plan->u8Input) {
+        for (int i = 0; i < n_in; ++i) SNNHIP_REQUIRE(inputs[i]->dtype != SNNHIP_U8, "plan_run: input %d is an 8-bit image tensor (%s)", i, plan->desc.c_str());
+    }
+    SNNHIP_REQUIRE(out->dtype != SNNHIP_U8, "plan_run: the output is an 8-bit image tensor (%s)", plan->desc.c_str());
     if (!plan->anyDtype) {
         for (int i = 0; i < n_in; ++i)
             SNNHIP_REQUIRE(inputs[i]->dtype == plan->dtype, "plan_run: input %d has dtype %d, the plan (%s) was built for %d", i, inputs[i]->dtype,

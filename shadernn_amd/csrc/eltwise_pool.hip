@@ -6,6 +6,7 @@
 // vk_maxpool2d.comp:42-74, vk_avgpool2d.comp:42-69, vk_pad.comp:42-71, vk_upsampling2d_nearest.comp:43-66,
 // vk_upsampling2d_bilinear.comp:43-76, vk_instancenorm.comp:53-160 and their createCS hosts in core/src/ic2.
 #include "epilogue.h"
+#include "plan_util.h"
 #include "snnhip_internal.h"
 
 namespace snnhip {
@@ -302,35 +303,6 @@ __global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, i
 }
 
 // ------------------------------------------------------------------------------------------------ plans
-unsigned grid_for(const snnhip_ctx* ctx, size_t items) {
-    size_t blocks = (items + 255) / 256;
-    const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) * 16;
-    if (blocks > cap) blocks = cap;
-    return static_cast<unsigned>(blocks ? blocks : 1);
-}
-
-bool dims_match(const snnhip_tensor* t, int n, int h, int w, int c) { return t->n == n && t->h == h && t->w == w && t->c == c; }
-
-// These plans take their element type from the tensors they are run on (fp32 or fp16, all tensors of one call alike).
-#define SNNHIP_SAME_DTYPE(what)                                                                                                   \
-    do {                                                                                                                          \
-        for (int _i = 0; _i < nIn; ++_i)                                                                                          \
-            SNNHIP_REQUIRE(in[_i]->dtype == out->dtype, "%s: input %d has dtype %d, output %d", what, _i, in[_i]->dtype, out->dtype); \
-    } while (0)
-#define SNNHIP_WITH_T(DT, ...)        \
-    do {                              \
-        if ((DT) == SNNHIP_F16) {     \
-            typedef _Float16 T;       \
-            __VA_ARGS__               \
-        } else {                      \
-            typedef float T;          \
-            __VA_ARGS__               \
-        }                             \
-    } while (0)
-template <typename T>
-const T* cptr(const snnhip_tensor* t) { return reinterpret_cast<const T*>(t->data); }
-template <typename T>
-T* mptr(snnhip_tensor* t) { return reinterpret_cast<T*>(t->data); }
 
 struct EltwisePlan : snnhip_plan {
     snnhip_eltwise_desc d;

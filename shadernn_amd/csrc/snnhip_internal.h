@@ -65,7 +65,7 @@ struct snnhip_tensor {
     int n = 0, h = 0, w = 0, c = 0;
     int dtype = SNNHIP_F32; // SNNHIP_F16: `data` points at halfs
     size_t count() const { return static_cast<size_t>(n) * h * w * c; }
-    size_t elemSize() const { return dtype == SNNHIP_F16 ? 2 : 4; }
+    size_t elemSize() const { return dtype == SNNHIP_F16 ? 2 : dtype == SNNHIP_U8 ? 1 : 4; }
     size_t bytes() const { return count() * elemSize(); }
 };
 
@@ -90,6 +90,7 @@ struct snnhip_plan {
     int numInputs = 1;
     int dtype = SNNHIP_F32;   // element type of the tensors this plan runs on ...
     bool anyDtype = false;    // ... unless it adapts to the tensors of each call (element-wise / pooling / shape operators)
+    bool u8Input = false;     // snnhip_image_u8_plan_create: the only plan that reads SNNHIP_U8 tensors
     std::string desc;
     double flops = 0, bytes = 0;
     std::vector<void*> deviceAllocs; // freed in the destructor

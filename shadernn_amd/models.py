@@ -148,6 +148,43 @@ def style_net(seed=1, width=16, in_channels=3):
     return {"name": "style_net", "input_channels": in_channels, "layers": L}
 
 
+def _deconv(rng, name, ic, oc, k, act, stride=2, bn=False, padding="same"):
+    """Conv2DTranspose (Conv2DTransposeDesc : Conv2DDesc, deconv2d.h:21): same JSON fields as Conv2D, weights flat OIHW."""
+    layer = _conv(rng, name, ic, oc, k, act, stride=stride, bn=bn, padding=padding)
+    layer["type"] = "Conv2DTranspose"
+    return layer
+
+
+def unet(seed=1, base=64, in_channels=1, depth=4):
+    """The zoo's U-Net shape (modelzoo/U-Net/unet.param): two 3x3 relu convs per level, 2x2 max-pool down, nearest 2x up + 2x2... the zoo
+    graph uses UpSampling2D + 3x3 conv, then Concatenate with the encoder skip; 1x1 sigmoid head."""
+    rng = np.random.default_rng(seed)
+    L, skips, c, prev = [], [], in_channels, "input"
+    for d in range(depth):
+        w = base << d
+        L += [_conv(rng, "enc%d_a" % d, c, w, 3, "relu"), _conv(rng, "enc%d_b" % d, w, w, 3, "relu")]
+        skips.append(("enc%d_b" % d, w))
+        L.append(_op("MaxPooling2D", "pool%d" % d, w, pool=2, stride=2, padding="same"))
+        c = w
+    w = base << depth
+    L += [_conv(rng, "mid_a", c, w, 3, "relu"), _conv(rng, "mid_b", w, w, 3, "relu")]
+    c = w
+    for d in reversed(range(depth)):
+        sk, w = skips[d]
+        L += [_op("UpSampling2D", "up%d" % d, c, scaleFactor=2.0, interpolation="nearest"), _conv(rng, "up%d_conv" % d, c, w, 3, "relu"),
+              _op("Concatenate", "cat%d" % d, 2 * w, inputs=["up%d_conv" % d, sk], c0=w, c1=w)]
+        L[-1]["ic"] = w
+        L += [_conv(rng, "dec%d_a" % d, 2 * w, w, 3, "relu"), _conv(rng, "dec%d_b" % d, w, w, 3, "relu")]
+        c = w
+    L.append(_conv(rng, "head", c, 1, 1, "sigmoid"))
+    return {"name": "unet", "input_channels": in_channels, "layers": L}
+
+
+def output_names(net):
+    """The net's result layers: net["outputs"] when it has several heads, else the last layer."""
+    return list(net.get("outputs", [net["layers"][-1]["name"]]))
+
+
 def producers(net):
     """[(layer, [producer names])] with the chain default made explicit."""
     out, prev = [], "input"
@@ -209,6 +246,17 @@ def to_json_dict(net, width, height):
                       "weights": {"bias": [float(v) for v in l["beta"]], "scale": [float(v) for v in l["gamma"]]}})
         elif t == "UpSampling2D":
             o.update({"type": t, "scaleFactor": float(l["scaleFactor"]), "interpolation": l["interpolation"]})
+        elif t == "Concatenate":
+            o.update({"type": t, "inputPlanes": int(l["c0"])})
+        elif t == "Conv2DTranspose":
+            o.update({"type": t, "activation": l["activation"], "padding": l["padding"], "kernel_size": int(l["kernel"]), "strides": int(l["stride"]),
+                      "useBias": "True" if l["b"] is not None else "False", "useBatchNormalization": "True" if l["bn"] else "False",
+                      "weights": {"kernel": [float(v) for v in l["w"].reshape(-1)], "bias": [float(v) for v in (l["b"] if l["b"] is not None else [])]}})
+            if l["bn"]:
+                o["batchNormalization"] = {"beta": [float(v) for v in l["bn"]["beta"]], "gamma": [float(v) for v in l["bn"]["gamma"]],
+                                           "moving_mean": [float(v) for v in l["bn"]["mean"]], "moving_variance": [float(v) for v in l["bn"]["var"]]}
+            if l["activation"] == "leakyRelu":
+                o["leakyReluAlpha"] = float(l.get("alpha", 0.1))
         else:
             o["type"] = t
             for k, v in l.items():

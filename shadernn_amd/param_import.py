@@ -135,6 +135,11 @@ def from_ops(ops, name="imported", seed=1, input_shape=None):
                 emit(d, [outs[0] + "#flat"], blob, oc)
                 continue
             bn, act, alpha, blob = fold_activation(outs[0])
+            fused = p.get(9, 0)  # ncnn's fused activation_type: 1 relu, 3 clip, 4 sigmoid (2 = leaky relu carries its slope in an array parameter)
+            if fused and act == "linear":
+                if fused not in (1, 4):
+                    raise ValueError("%s: fused activation_type %d" % (nm, fused))
+                act = {1: "relu", 4: "sigmoid"}[fused]
             pad = _same_or_valid(p.get(4, 0), k)
             if t == "ConvolutionDepthWise":
                 if p.get(7, 1) != ic or oc != ic:
@@ -205,14 +210,25 @@ def from_ops(ops, name="imported", seed=1, input_shape=None):
             if p.get(1, 1.0) != p.get(2, 1.0):
                 raise ValueError("%s: anisotropic resize" % nm)
             emit(models._op("UpSampling2D", nm, c, scaleFactor=float(p.get(1, 2.0)), interpolation="nearest" if p.get(0, 1) == 1 else "bilinear"), ins, outs[0], c)
+        elif t == "Concat":
+            if p.get(0, 0) != 0 or len(ins) != 2:
+                raise ValueError("%s: only the two-input channel concat exists in the reference (ConcatenateLayer, concatenation.h:33-37)" % nm)
+            c0, c1 = channels[ins[0]], channels[ins[1]]
+            emit(models._op("Concatenate", nm, c0 + c1, c0=c0, c1=c1), ins, outs[0], c0 + c1)
+            layers[-1]["ic"] = c0
         elif t == "Softmax":
             raise ValueError("%s: a Softmax that does not follow a dense layer has no layer in the reference" % nm)
         else:
             raise ValueError("%s: ncnn layer type %s has no counterpart in the HIP backend (reference layers: Conv2D, DepthwiseConv2D, Dense, Add, "
-                             "pooling, Flatten, Pad, InstanceNorm, UpSampling2D, BatchNormalization, Activation)" % (nm, t))
+                             "pooling, Flatten, Pad, InstanceNorm, UpSampling2D, BatchNormalization, Activation, Concatenate)" % (nm, t))
     if in_c is None:
         raise ValueError("no Input layer")
-    return {"name": name, "input_channels": in_c, "input_hw": in_hw, "layers": layers}
+    net = {"name": name, "input_channels": in_c, "input_hw": in_hw, "layers": layers}
+    consumed = {n for l in layers for n in l["inputs"]}
+    leaves = [l["name"] for l in layers if l["name"] not in consumed]
+    if len(leaves) > 1:  # YOLOv3-tiny: two detection heads (the reference joins them in its CPU YOLO layer, yololayer.cpp:177-226)
+        net["outputs"] = leaves
+    return net
 
 
 def import_param(path, seed=1, input_shape=None):

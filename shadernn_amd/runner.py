@@ -38,6 +38,13 @@ def _layer_plan(ctx, layer, shape, dtype=capi.F32):
         return capi.instancenorm_plan(ctx, n, h, w, c, layer["beta"], layer["gamma"], act=_plain(layer.get("activation", "")), leaky=layer.get("alpha", 0.0))
     if t == "UpSampling2D":
         return capi.upsample_plan(ctx, n, h, w, c, layer["scaleFactor"], layer["interpolation"])
+    if t == "Concatenate":
+        return capi.concat_plan(ctx, n, h, w, layer["c0"], layer["c1"], layer.get("oc"))
+    if t == "Unary":
+        return capi.unary_plan(ctx, n, h, w, c, layer.get("op", "copy"), layer.get("value", 1.0))
+    if t == "Conv2DTranspose":
+        return capi.deconv2d_plan(ctx, n, h, w, layer["w"], layer["b"], stride=layer["stride"], same=layer["padding"] == "same",
+                                  act=_plain(layer["activation"]), leaky=layer.get("alpha", 0.0), bn=layer["bn"])
     raise ValueError("unsupported layer type " + t)
 
 
@@ -127,6 +134,7 @@ class GraphRunner:
             self.steps.append((plan, [self.tensors[i] for i in ins], t, layer))
         self.y = self.steps[-1][2]
         self.out_shape = shapes[net["layers"][-1]["name"]]
+        self.output_names = models.output_names(net)  # several for multi-head graphs (YOLOv3-tiny)
 
     def describe(self):
         return ["%s: %s" % (l["name"], p.describe()) for p, _, _, l in self.steps]
@@ -135,7 +143,7 @@ class GraphRunner:
         """(flops, bytes) of step i; the dtype-agnostic element-wise plans report fp32 bytes, halved here for half tensors."""
         plan, _, _, layer = self.steps[i]
         f, b = plan.cost()
-        if self.dtype == capi.F16 and layer["type"] not in ("Conv2D", "DepthwiseConv2D", "Dense"):
+        if self.dtype == capi.F16 and layer["type"] not in ("Conv2D", "DepthwiseConv2D", "Dense", "Conv2DTranspose"):
             b *= 0.5
         return f, b
 
@@ -155,6 +163,9 @@ class GraphRunner:
         self.x.upload(np.ascontiguousarray(x, dtype=np.float32))
         self.run_device()
         return self.y.numpy()
+
+    def outputs(self):
+        return [self.tensors[n].numpy() for n in self.output_names]
 
     def output_of(self, name):
         return self.tensors[name].numpy()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Regenerates tests/golden/zoo_topologies.json from the reference's model zoo (run in the build container, where
-/root/reference exists): the ncnn `.param` text of the three BASELINE model graphs parsed into op lists (type, name, blobs,
+/root/reference exists): the ncnn `.param` text of the BASELINE model graphs plus U-Net and YOLOv3-tiny parsed into op lists (type, name, blobs,
 numeric parameters).  Data only -- the weights are Git-LFS pointers in the reference and are not needed for the topology."""
 import json
 import os
@@ -12,7 +12,8 @@ from shadernn_amd import param_import  # noqa: E402
 
 ZOO = "/root/reference/modelzoo"
 FILES = {"resnet18_cifar10": "Resnet18/resnet18_cifar10.param", "mobilenetV2": "MobileNetV2/mobilenetV2.param",
-         "candy-9_simplified-opt": "StyleTransfer/candy-9_simplified-opt.param"}
+         "candy-9_simplified-opt": "StyleTransfer/candy-9_simplified-opt.param", "unet": "U-Net/unet.param",
+         "yolov3-tiny": "Yolov3-tiny/yolov3-tiny.param"}
 
 out = {}
 for name, rel in FILES.items():

@@ -252,6 +252,126 @@ def instancenorm(x, beta, gamma, act="", leaky=0.0, eps=1e-5):
     return y
 
 
+def concat(x0, x1, OC=None):
+    x0, x1 = _f(x0), _f(x1)
+    N, H, W, C0 = x0.shape
+    C1 = x1.shape[-1]
+    OC = C0 + C1 if OC is None else OC
+    y = np.empty((N, H, W, OC), np.float32)
+    lib().snn_oracle_concat(_p(x0), _p(x1), C.c_long(N * H * W), C0, C1, OC, _p(y))
+    return y
+
+
+UNARY_OPS = {"copy": 0, "fixed": 1, "neg": 2, "rcp": 3, "square": 4, "exp": 5, "abs": 6}
+
+
+def unary(x, op="copy", value=1.0):
+    x = _f(x)
+    y = np.empty_like(x)
+    lib().snn_oracle_unary(_p(x), C.c_long(x.size), UNARY_OPS[op] if isinstance(op, str) else int(op), C.c_float(value), _p(y))
+    return y
+
+
+def calculate(x, OC):
+    x = _f(x)
+    N, H, W, Cc = x.shape
+    y = np.empty((N, H, W, OC), np.float32)
+    lib().snn_oracle_calculate(_p(x), C.c_long(N * H * W), Cc, OC, _p(y))
+    return y
+
+
+def resize(x, OH, OW, means=(0, 0, 0, 0), norms=(1, 1, 1, 1), linear=True):
+    x = _f(x)
+    N, H, W, Cc = x.shape
+    y = np.empty((N, OH, OW, Cc), np.float32)
+    lib().snn_oracle_resize(_p(x), N, H, W, Cc, OH, OW, _p(_f(means)), _p(_f(norms)), int(bool(linear)), _p(y))
+    return y
+
+
+def image_u8(img, means=(0, 0, 0, 0), norms=(1, 1, 1, 1)):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    N, H, W, sc = img.shape
+    y = np.empty((N, H, W, 4), np.float32)
+    lib().snn_oracle_image_u8(img.ctypes.data_as(C.c_void_p), C.c_long(N * H * W), sc, _p(_f(means)), _p(_f(norms)), _p(y))
+    return y
+
+
+def argmax(x):
+    x = _f(x).reshape(-1)
+    l = lib()
+    l.snn_oracle_argmax.restype = C.c_long
+    return int(l.snn_oracle_argmax(_p(x), C.c_long(x.size)))
+
+
+def deconv2d(x, w_oihw, bias=None, stride=2, same=True, act="", leaky=0.0, bn=None):
+    x, w = _f(x), _f(w_oihw)
+    N, H, W, IC = x.shape
+    OC, _, k, _ = w.shape
+    p = (k - stride) // 2 if same else 0
+    OH, OW = (stride * H, stride * W) if same else (stride * H + k - stride, stride * W + k - stride)
+    y = np.empty((N, OH, OW, OC), np.float32)
+    arrs = [_f(bn[key]) for key in ("beta", "gamma", "mean", "var")] if bn is not None else [None] * 4
+    b = _f(bias) if bias is not None else None
+    lib().snn_oracle_deconv2d(_p(x), N, H, W, IC, OC, k, stride, p, OH, OW, _p(w), _p(b), *[_p(a) for a in arrs], ACT[act], C.c_float(leaky), _p(y))
+    return y
+
+
+def deconv4x4s2_shader(x_hwc, w_oihw, bias=None):
+    """The k=4 s=2 compute shader of the reference restated line by line (one image)."""
+    x, w = _f(x_hwc), _f(w_oihw)
+    H, W, IC = x.shape
+    OC = w.shape[0]
+    y = np.empty((2 * H, 2 * W, OC), np.float32)
+    lib().snn_oracle_deconv4x4s2_shader(_p(x), H, W, IC, OC, _p(w), _p(_f(bias)) if bias is not None else None, _p(y))
+    return y
+
+
+# YOLO v3 tiny decode + NMS: numpy restatement of yololayer.cpp:27-226 (the reference runs this layer on the CPU)
+YOLO_ANCHORS = [10.0, 14.0, 23.0, 27.0, 37.0, 58.0, 81.0, 82.0, 135.0, 169.0, 344.0, 319.0]
+YOLO_MASKS = [3, 4, 5, 1, 2, 3]
+
+
+def yolo_decode(heads, conf=0.35, iou=0.45, net=416):
+    """heads: [grid13 NHWC (1,13,13,18), grid26 (1,26,26,18)] -> list of [classId, score, x, y, w, h] after NMS."""
+    boxes = []
+    for idx, scale in enumerate((32, 16)):
+        g = net // scale
+        d = _f(heads[idx]).reshape(g, g, -1)  # the reference walks the 4-channel-aligned texture; NHWC with C=18 holds the same 18 values
+        for gy in range(g):
+            for gx in range(g):
+                for gc in range(3):
+                    v = d[gy, gx, gc * 6:(gc + 1) * 6]
+                    cls_logit = v[5]
+                    a = YOLO_MASKS[gc + idx * 3]
+                    bw, bh = YOLO_ANCHORS[2 * a], YOLO_ANCHORS[2 * a + 1]
+                    # yololayer.cpp:147 as written: 1 / (1 + exp(-obj) * (1 + exp(-cls)))  (NOT sigmoid(obj) * sigmoid(cls))
+                    prob = np.float32(1.0) / (np.float32(1.0) + np.exp(-v[4], dtype=np.float32) * (np.float32(1.0) + np.exp(-cls_logit, dtype=np.float32)))
+                    if prob > conf:
+                        sig = lambda t: np.float32(1.0) / (np.float32(1.0) + np.exp(-t, dtype=np.float32))
+                        cx, cy = (gx + sig(v[0])) / g, (gy + sig(v[1])) / g
+                        w_, h_ = np.exp(v[2], dtype=np.float32) * bw / (scale * g), np.exp(v[3], dtype=np.float32) * bh / (scale * g)
+                        boxes.append([0, float(prob), float(cx - w_ / 2), float(cy - h_ / 2), float(w_), float(h_)])
+    boxes.sort(key=lambda b: -b[1])
+    merged, out = [False] * len(boxes), []
+
+    def iou_of(a, b):
+        x0, y0 = max(a[2], b[2]), max(a[3], b[3])
+        x1, y1 = min(a[2] + a[4], b[2] + b[4]), min(a[3] + a[5], b[3] + b[5])
+        if x1 < x0 or y1 < y0:
+            return 0.0
+        inter = (x1 - x0) * (y1 - y0)
+        return inter / (a[4] * a[5] + b[4] * b[5] - inter)
+
+    for i, b in enumerate(boxes):
+        if merged[i]:
+            continue
+        for j in range(i + 1, len(boxes)):
+            if not merged[j] and boxes[j][0] == b[0] and iou_of(b, boxes[j]) > iou:
+                merged[j] = True
+        out.append(b)
+    return out
+
+
 def to_medium_precision(v):
     return lib().snn_oracle_to_medium_precision(C.c_float(v))
 
@@ -286,7 +406,7 @@ def quantize_net_fp16(net):
 
     q = copy.deepcopy(net)
     for l in q["layers"]:
-        if l["type"] in ("Conv2D", "DepthwiseConv2D", "Dense"):
+        if l["type"] in ("Conv2D", "DepthwiseConv2D", "Dense", "Conv2DTranspose"):
             l["w"] = _h(l["w"])
     return q
 
@@ -333,6 +453,12 @@ def forward(net, x, threads=1, return_layers=False, return_named=False, fp16=Fal
             x = instancenorm(x, l["beta"], l["gamma"], plain(l.get("activation", "")), l.get("alpha", 0.0))
         elif t == "UpSampling2D":
             x = upsample(x, l["scaleFactor"], l["interpolation"])
+        elif t == "Concatenate":
+            x = concat(ins[0], ins[1], l.get("oc"))
+        elif t == "Unary":
+            x = unary(x, l.get("op", "copy"), l.get("value", 1.0))
+        elif t == "Conv2DTranspose":
+            x = deconv2d(x, l["w"], l["b"], l["stride"], l["padding"] == "same", plain(l["activation"]), l.get("alpha", 0.0), l["bn"])
         else:
             raise ValueError(t)
         if fp16:

@@ -82,3 +82,42 @@ def test_zoo_graphs_on_gpu_match_oracle(ctx, name, shape, batch):
     assert y.reshape(batch, -1).shape == want.reshape(batch, -1).shape
     scale = max(1.0, float(np.abs(want).max()))
     np.testing.assert_allclose(y.reshape(batch, -1) / scale, want.reshape(batch, -1) / scale, **TOL)
+
+
+def test_unet_and_yolo_graphs_import():
+    """the zoo's U-Net and YOLOv3-tiny graphs need Concatenate; YOLOv3-tiny keeps its two detection heads as outputs."""
+    from shadernn_amd import models
+
+    net = _zoo("unet")
+    c = Counter(l["type"] for l in net["layers"])
+    assert net["input_hw"] == (256, 256) and net["input_channels"] == 1
+    assert c == Counter({"Conv2D": 24, "MaxPooling2D": 4, "UpSampling2D": 4, "Concatenate": 4})
+    assert Counter(l["activation"] for l in net["layers"] if l["type"] == "Conv2D") == Counter({"relu": 23, "sigmoid": 1})  # ncnn's fused activation_type
+    cat = [l for l in net["layers"] if l["type"] == "Concatenate"][0]
+    assert (cat["c0"], cat["c1"], cat["oc"]) == (512, 512, 1024) and len(cat["inputs"]) == 2
+    assert models.output_names(net) == [net["layers"][-1]["name"]]
+    net = _zoo("yolov3-tiny", input_shape=(416, 416, 3))
+    c = Counter(l["type"] for l in net["layers"])
+    assert c == Counter({"Conv2D": 13, "MaxPooling2D": 6, "UpSampling2D": 1, "Concatenate": 1})
+    assert models.output_names(net) == ["conv2d_9", "conv2d_12"]
+    assert {l["activation"] for l in net["layers"] if l["type"] == "Conv2D"} == {"leakyRelu", "linear"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,shape", [("unet", (64, 48, 1)), ("yolov3-tiny", (96, 96, 3))])
+def test_unet_and_yolo_on_gpu_match_oracle(ctx, name, shape):
+    import shadernn_amd as snn
+
+    net = _zoo(name, input_shape=shape)
+    h, w = net["input_hw"]
+    x = np.random.default_rng(10).random((1, h, w, net["input_channels"]), dtype=np.float32)
+    r = snn.GraphRunner(ctx, net, 1, h, w)
+    r(x)
+    _, named = O.forward(net, x, threads=8, return_named=True)
+    for nm, y in zip(r.output_names, r.outputs()):
+        want = named[nm]
+        assert y.shape == want.shape
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(y / scale, want / scale, err_msg=nm, **TOL)
+    if name == "yolov3-tiny":
+        assert [o.shape for o in r.outputs()] == [(1, 3, 3, 255), (1, 6, 6, 255)]

@@ -32,6 +32,15 @@ int snn_model_upload_input(snn_model* m, const float* nhwc);      /* H x W x C f
 int snn_model_run(snn_model* m);                                   /* MixedInferenceCore::run (enqueue + one sync) */
 int snn_model_output_dims(snn_model* m, int hwc[3]);
 int snn_model_download_output(snn_model* m, float* nhwc);
+/* SNNModelOutput of the next runs (snn.h ModelType: 0 CLASSIFICATION, 1 DETECTION, 2 SEGMENTATION, 3 OTHER; MixedInferenceCore::run, core.cpp:228-237) */
+int snn_model_set_type(snn_model* m, int model_type);
+int snn_model_classifier_output(snn_model* m);                             /* 1-based arg-max of the last stage, 0 = none */
+int snn_model_detections(snn_model* m, float* rows6, int max_rows);         /* YOLO stage output {class, score, x, y, w, h}; returns the row count */
+/* Input pre-processing on the device, the demo's call sequence (modelInference.cpp:92-97): decoded 8-bit image (1 / 3 / 4 channels) ->
+ * convertToRGBA32FAndNormalize(means, norms) -> resize to the model's input size with (resize_means, resize_norms), bilinear.
+ * The model must take a 4-channel input (RGBA texture). */
+int snn_model_upload_input_u8(snn_model* m, const unsigned char* pixels, int w, int h, int channels, const float means[4], const float norms[4],
+                              const float resize_means[4], const float resize_norms[4]);
 int snn_model_num_stages(snn_model* m);
 int snn_model_stage_info(snn_model* m, int stage, char* name, int name_len, int hwc[3], int* fused_away);
 int snn_model_download_stage(snn_model* m, int stage, float* nhwc);
@@ -50,6 +59,9 @@ int snn_conv_test_with_layer(int device, const float* input_hwc, const float* we
  * line per layer: "<index>|<name>|<exec type>|<out W>x<out H>x<out C>|<inputs>".  Exercises ModelParser, layerFactory,
  * topological sort and the shape rules exactly as MixedInferenceCore::create would. */
 int snn_graph_summary(const char* json_path, int in_w, int in_h, int in_c, char* buf, int buflen);
+
+/* Host-only: YOLOLayer's decode + NMS (yololayer.cpp:114-226) on two NHWC heads of net/32 and net/16 cells x 18 channels */
+int snn_yolo_decode(const float* head_coarse, const float* head_fine, int net_size, float* rows6, int max_rows);
 
 /* ".dump" reader (image.cpp:300-311): returns W,H,D,C and, if out != NULL, the RGBA32F pixels ([D][H][W][4] floats). */
 int snn_dump_read(const char* path, int whdc[4], float* out, long out_floats);

@@ -19,6 +19,11 @@ SIGNATURES = {
     "snn_model_run": (C.c_int, [_P]),
     "snn_model_output_dims": (C.c_int, [_P, C.POINTER(C.c_int * 3)]),
     "snn_model_download_output": (C.c_int, [_P, _FP]),
+    "snn_model_set_type": (C.c_int, [_P, C.c_int]),
+    "snn_model_classifier_output": (C.c_int, [_P]),
+    "snn_model_detections": (C.c_int, [_P, _FP, C.c_int]),
+    "snn_model_upload_input_u8": (C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.c_int, _FP, _FP, _FP, _FP]),
+    "snn_yolo_decode": (C.c_int, [_FP, _FP, C.c_int, _FP, C.c_int]),
     "snn_model_num_stages": (C.c_int, [_P]),
     "snn_model_stage_info": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int * 3), C.POINTER(C.c_int)]),
     "snn_model_download_stage": (C.c_int, [_P, C.c_int, _FP]),
@@ -76,6 +81,14 @@ def c4hw4_to_nhwc(a, channels):
     return np.transpose(a, (1, 2, 0, 3)).reshape(h, w, d * 4)[:, :, :channels]
 
 
+def yolo_decode(head_coarse, head_fine, net_size=416, max_rows=100):
+    """YOLOLayer's CPU decode + NMS (host-only)."""
+    a, b = np.ascontiguousarray(head_coarse, dtype=np.float32), np.ascontiguousarray(head_fine, dtype=np.float32)
+    rows = np.zeros((max_rows, 6), np.float32)
+    n = lib().snn_yolo_decode(_fp(a), _fp(b), net_size, _fp(rows), max_rows)
+    return rows[:n].copy()
+
+
 class Model:
     """MixedInferenceCore::create(context, jsonFile, options) + run(), one W x H x C input image."""
 
@@ -88,6 +101,28 @@ class Model:
     def upload(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.in_shape)
         assert lib().snn_model_upload_input(self.h, _fp(x)) == 0
+
+    def upload_u8(self, img, means=(0, 0, 0, 0), norms=(1, 1, 1, 1), resize_means=(0, 0, 0, 0), resize_norms=(1, 1, 1, 1)):
+        """8-bit H x W x {1,3,4} image -> normalise -> bilinear resize to the model input, all on the device (modelInference.cpp:92-97)."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        ih, iw, ic = img.shape
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (means, norms, resize_means, resize_norms)]
+        rc = lib().snn_model_upload_input_u8(self.h, img.ctypes.data_as(C.c_void_p), iw, ih, ic, *[_fp(a) for a in arrs])
+        assert rc == 0, rc
+
+    MODEL_TYPES = {"classification": 0, "detection": 1, "segmentation": 2, "other": 3}
+
+    def set_type(self, model_type):
+        assert lib().snn_model_set_type(self.h, self.MODEL_TYPES[model_type]) == 0
+
+    def classifier_output(self):
+        """1-based class index of the last run (MixedInferenceCore::run, core.cpp:228-234); 0 = none."""
+        return lib().snn_model_classifier_output(self.h)
+
+    def detections(self, max_rows=100):
+        rows = np.zeros((max_rows, 6), np.float32)
+        n = lib().snn_model_detections(self.h, _fp(rows), max_rows)
+        return rows[:n].copy()
 
     def run(self):
         assert lib().snn_model_run(self.h) == 0

@@ -4,6 +4,7 @@
 
 #include <sstream>
 
+#include "../../include/snnhip.h"
 #include "ic2/backend.h"
 #include "ic2/dp.h"
 #include "snn/core.h"
@@ -63,7 +64,8 @@ bool MixedInferenceCore::init(const CreationParameters& cp_) {
         InferenceGraph::Layer& layer = *cp.layers[i];
         RenderStage& stage = stages[i];
         stage.layer = cp.layers[i];
-        if (stage.backend != Backend::Backend_GPU) SNN_RIP("stage %zu (%s): the HIP backend runs every hot-path layer on the GPU", i, layer.name.c_str());
+        // the only CPU stage of the HIP flavour is the YOLO head, a CPU layer in the reference as well (yololayer.h:38); Dense / Flatten run on the GPU
+        const bool cpuStage = stage.backend != Backend::Backend_GPU;
         stage.stageInputs.allocate(layer.inputRefs.size());
         stage.stageOutputs.allocate(1);
         if (stage.layer->isInputLayer) {
@@ -83,8 +85,10 @@ bool MixedInferenceCore::init(const CreationParameters& cp_) {
             }
         }
         std::array<uint32_t, 4> dims{layer.outputDesc.width, layer.outputDesc.height, layer.outputDesc.depth, 1};
-        stage.stageOutputs[0].resetTexture(dims, layer.outputDesc.format, layer.name, layer.outputDesc.channels); // core.cpp:371-372
-        layer.initFunPtr(backend, stage.stageInputs, stage.stageOutputs);                                        // core.cpp:374
+        if (!cpuStage) { // a CPU stage hands its result over as a host matrix (ImageTexture::setOutputMat), no device tensor
+            stage.stageOutputs[0].resetTexture(dims, layer.outputDesc.format, layer.name, layer.outputDesc.channels); // core.cpp:371-372
+            layer.initFunPtr(backend, stage.stageInputs, stage.stageOutputs);                                        // core.cpp:374
+        }
         if (cp.profiling) stage.timer.reset(backend->createDeviceTimer(layer.name));
     }
     backend->finalizeStages(stages, cp.dumpOutputs, cp.fuseChains);
@@ -108,7 +112,12 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
         }
         if (s.timer) s.timer->start();
         backend->prepareStage(rp, s);
-        s.layer->runFunPtr(backend, cp.dumpOutputs);
+        if (s.backend == Backend::Backend_GPU) {
+            s.layer->runFunPtr(backend, cp.dumpOutputs);
+        } else { // GPU -> CPU transition: wait for the producers, then the layer reads them back itself (core.cpp:141-199)
+            backend->sync();
+            s.layer->imageTextureFunPtr(s.stageInputs, s.stageOutputs);
+        }
         if (s.timer) s.timer->stop();
     }
     if (gpuRunTime) gpuRunTime->stop();
@@ -122,6 +131,16 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
         // the reference binds the last stage's texture to the caller's output image (Android path); here the caller's
         // texture simply aliases the last stage output
         (*rp.outputImages)[0].attach(&stages.back().stageOutputs[0]);
+    }
+    // core.cpp:228-237.  The classifier head (Dense + softmax) is a GPU stage here, so the arg-max is taken on the device tensor;
+    // like the reference the reported class is 1-based (0 = none)
+    if (rp.modelOutput.modelType == ModelType::CLASSIFICATION && stages.back().backend == Backend::Backend_GPU && stages.back().stageOutputs[0].tensor()) {
+        int idx = -1;
+        if (snnhip_tensor_argmax(stages.back().stageOutputs[0].tensor(), 0, &idx) != SNNHIP_OK) SNN_RIP("snnhip_tensor_argmax: %s", snnhip_last_error());
+        rp.modelOutput.classifierOutput = idx + 1;
+        SNN_LOGD("Classifier output: %d", rp.modelOutput.classifierOutput);
+    } else if (rp.modelOutput.modelType == ModelType::DETECTION && stages.back().backend == Backend::Backend_CPU) {
+        rp.modelOutput.detectionOutput = stages.back().stageOutputs[0].getOutputMat();
     }
     backend->cleanupRun();
 }

@@ -492,5 +492,93 @@ private:
 };
 SNN_DECLARE_HIP_FLAVOUR(UpSampling2D)
 
+// ---- SURVEY 8f rank 4 ----------------------------------------------------------------------------------------------------------
+
+// ---- Concatenate (concatenation.h:27-43, concatenationVulkan.cpp:31-88)
+struct ConcatenateDesc : CommonLayerDesc {};
+class ConcatenateLayer : public ShaderLayer {
+public:
+    explicit ConcatenateLayer(ConcatenateDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+    void getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depthOut) const override { // concatenation.h:33-37: depth = texel planes
+        width = inputDims[0].width;
+        height = inputDims[0].height;
+        depthOut = inputDims[0].depth + inputDims[1].depth;
+    }
+
+protected:
+    ConcatenateDesc _desc;
+};
+SNN_DECLARE_HIP_FLAVOUR(Concatenate)
+
+// ---- Unary (unary.h:26-42, unaryVulkan.cpp:30-83): opType / opValue are never read from the model file
+struct UnaryDesc : CommonLayerDesc {
+    int32_t opType = 0;
+    float opValue = 1.0f;
+    void parse(ModelParser& parser, int layerId) { CommonLayerDesc::parse(parser, layerId); }
+};
+class UnaryLayer : public ShaderLayer {
+public:
+    explicit UnaryLayer(UnaryDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    UnaryDesc _desc;
+};
+SNN_DECLARE_HIP_FLAVOUR(Unary)
+
+// ---- Calculate (calculation.h:23, calculationGL.cpp:28-57)
+struct CalculateDesc : CommonLayerDesc {};
+class CalculateLayer : public ShaderLayer {
+public:
+    explicit CalculateLayer(CalculateDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    CalculateDesc _desc;
+};
+SNN_DECLARE_HIP_FLAVOUR(Calculate)
+
+// ---- Conv2DTranspose (deconv2d.h:21, deconv2dGL.h:31-66, deconv2dGL.cpp:282-355)
+struct Conv2DTransposeDesc : Conv2DDesc {};
+class Conv2DTransposeLayer : public ShaderLayer {
+public:
+    explicit Conv2DTransposeLayer(Conv2DTransposeDesc&& d) : ShaderLayer(d), _desc(std::move(d)) {}
+
+protected:
+    Conv2DTransposeDesc _desc;
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override { // deconv2dGL.cpp:345-355
+        InferenceGraph::Transform t = InferenceGraph::Transform::identity();
+        t.scaleWidth = t.scaleHeight = static_cast<float>(_desc.stride);
+        t.translateWidth = t.translateHeight = _desc.paddingT == "same" ? 0.0f : static_cast<float>(_desc.kernelSize - _desc.stride);
+        return t;
+    }
+};
+SNN_DECLARE_HIP_FLAVOUR(Conv2DTranspose)
+
+// ---- YOLO (yololayer.h:33-65, yololayer.cpp:27-226): the final layer of YOLOv3-tiny, decoded and NMS-ed on the CPU in the reference too
+struct YOLODesc : CommonLayerDesc {
+    void parse(ModelParser& parser, int layerId) { CommonLayerDesc::parse(parser, layerId); } // yololayer.cpp:165-175: input / output planes only
+};
+class YOLOLayer : public GenericModelLayer {
+public:
+    explicit YOLOLayer(YOLODesc&& d) : GenericModelLayer(d), _yoloDesc(std::move(d)) {}
+    void getOutputDims(uint32_t& width, uint32_t& height, uint32_t& depth) const override { // yololayer.h:44-48
+        width = 100 * 6; // max 100 bounding boxes
+        height = 1;
+        depth = 1;
+    }
+    void computeImageTexture(ImageTextureArray& inputMat, ImageTextureArray& outputMat) override;
+    InferenceGraph::LayerExecutionType getLayerExecutionType() const override { return executeBackend; }
+    void setLayerExecutionType(InferenceGraph::LayerExecutionType e) override { executeBackend = e; }
+    void createInferencePasses(const LayerGenOptions&) override {}
+    // decode + NMS on host floats, heads in NHWC with the true channel count (3 x 6); returns rows {class, score, x, y, w, h}
+    static std::vector<std::vector<float>> decode(const std::vector<const float*>& heads, int netSize = 416);
+
+private:
+    InferenceGraph::Transform getOutputScaleDimAdjustment() const override { return InferenceGraph::Transform::identity(); }
+    YOLODesc _yoloDesc;
+    InferenceGraph::LayerExecutionType executeBackend = InferenceGraph::LayerExecutionType::CPU;
+};
+
 } // namespace dp
 } // namespace snn

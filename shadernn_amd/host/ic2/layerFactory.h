@@ -25,5 +25,9 @@ GenericModelLayer* FlattenCreator1(FlattenDesc&& desc, bool useVulkan);
 GenericModelLayer* PadCreator1(PadDesc&& desc, bool useVulkan);
 GenericModelLayer* InstanceNormCreator1(InstanceNormDesc&& desc, bool useVulkan);
 GenericModelLayer* UpSampling2DCreator1(UpSampling2DDesc&& desc, bool useVulkan);
+GenericModelLayer* ConcatenateCreator1(ConcatenateDesc&& desc, bool useVulkan);
+GenericModelLayer* UnaryCreator1(UnaryDesc&& desc, bool useVulkan);
+GenericModelLayer* CalculateCreator1(CalculateDesc&& desc, bool useVulkan);
+GenericModelLayer* Conv2DTransposeCreator1(Conv2DTransposeDesc&& desc, bool useVulkan);
 } // namespace dp
 } // namespace snn

@@ -1,5 +1,6 @@
 // imageTexture.cpp -- HIP flavour of ImageTexture, the context factory and the device timer
 // (reference core/src/imageTexture*.cpp, imageTextureFactory.cpp:27-85, contextFactory.cpp:21-32, vkUtils timers).
+#include <cmath>
 #include <cstring>
 
 #include "../../include/snnhip.h"
@@ -117,6 +118,61 @@ void ImageTexture::uploadNHWC(const float* nhwc) {
 void ImageTexture::downloadNHWC(float* nhwc) {
     SNN_CHK(_tensor);
     hipChk(snnhip_tensor_download(_tensor, nhwc), "snnhip_tensor_download");
+}
+
+void ImageTexture::loadU8AndNormalize(const uint8_t* pixels, uint32_t w, uint32_t h, uint32_t srcChannels, const std::array<float, 4>& means,
+                                      const std::array<float, 4>& norms) {
+    SNN_CHK(pixels && (srcChannels == 1 || srcChannels == 3 || srcChannels == 4));
+    const ColorFormat fmt = _format == ColorFormat::RGBA16F ? ColorFormat::RGBA16F : ColorFormat::RGBA32F;
+    resetTexture({w, h, 1, 1}, fmt, _name, 4);
+    snnhip_tensor* src = nullptr;
+    hipChk(snnhip_tensor_alloc(hipCtx(), 1, static_cast<int>(h), static_cast<int>(w), static_cast<int>(srcChannels), SNNHIP_U8, &src), "snnhip_tensor_alloc(u8)");
+    hipChk(snnhip_tensor_upload_raw(src, pixels, static_cast<size_t>(w) * h * srcChannels), "snnhip_tensor_upload_raw");
+    snnhip_image_u8_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(h);
+    d.W = static_cast<int>(w);
+    d.src_channels = static_cast<int>(srcChannels);
+    for (int i = 0; i < 4; ++i) {
+        d.means[i] = means[static_cast<size_t>(i)];
+        d.norms[i] = norms[static_cast<size_t>(i)];
+    }
+    snnhip_plan* plan = nullptr;
+    hipChk(snnhip_image_u8_plan_create(hipCtx(), &d, &plan), "snnhip_image_u8_plan_create");
+    hipChk(snnhip_plan_run(plan, src, _tensor), "snnhip_plan_run(image_u8)");
+    hipChk(snnhip_sync(hipCtx()), "snnhip_sync"); // src is freed below
+    snnhip_plan_destroy(plan);
+    snnhip_tensor_free(src);
+}
+
+bool ImageTexture::resize(float xScale, float yScale, const std::array<float, 4>& means, const std::array<float, 4>& norms, bool linearFilter) {
+    SNN_CHK(_tensor && xScale > 0.0f && yScale > 0.0f);
+    snnhip_resize_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(_dims[1]);
+    d.W = static_cast<int>(_dims[0]);
+    d.C = static_cast<int>(_channels);
+    d.OW = static_cast<int>(roundf(static_cast<float>(_dims[0]) / xScale)); // imageTextureVulkan.cpp:150-151
+    d.OH = static_cast<int>(roundf(static_cast<float>(_dims[1]) / yScale));
+    d.linear = linearFilter ? 1 : 0;
+    for (int i = 0; i < 4; ++i) {
+        d.means[i] = means[static_cast<size_t>(i)];
+        d.norms[i] = norms[static_cast<size_t>(i)];
+    }
+    snnhip_tensor* dst = nullptr;
+    hipChk(snnhip_tensor_alloc(hipCtx(), 1, d.OH, d.OW, d.C, _format == ColorFormat::RGBA16F ? SNNHIP_F16 : SNNHIP_F32, &dst), "snnhip_tensor_alloc");
+    snnhip_plan* plan = nullptr;
+    hipChk(snnhip_resize_plan_create(hipCtx(), &d, &plan), "snnhip_resize_plan_create");
+    hipChk(snnhip_plan_run(plan, _tensor, dst), "snnhip_plan_run(resize)");
+    hipChk(snnhip_sync(hipCtx()), "snnhip_sync");
+    snnhip_plan_destroy(plan);
+    releaseTensor(); // the resized image replaces the source (imageTextureVulkan.cpp:176-178)
+    _tensor = dst;
+    _ownsTensor = true;
+    _dims[0] = static_cast<uint32_t>(d.OW);
+    _dims[1] = static_cast<uint32_t>(d.OH);
+    _image = RawImage();
+    return false; // the reference returns 0 on success
 }
 
 std::string ImageTexture::getTextureInfo2() const {

@@ -2,6 +2,8 @@
 // (reference core/src/ic2/genericlayer.cpp, conv2d.cpp, conv2dVulkan.cpp, separableconvolution*.cpp, denselayer*.cpp,
 //  subpixelmergeVulkan.cpp, layerFactory.cpp).  createCS() packs a host-side recipe; the backend turns it into a HIP plan.
 #include <algorithm>
+#include <cfloat>
+#include <cmath>
 #include <unordered_map>
 
 #include "../../include/snnhip.h"
@@ -563,6 +565,161 @@ InferencePassesSptr UpSampling2DLayerHip::createCS(const LayerGenOptions&) const
     return ret;
 }
 
+// ------------------------------------------------------------------------------------------------ SURVEY 8f rank 4
+
+InferencePassesSptr ConcatenateLayerHip::createCS(const LayerGenOptions&) const { // concatenationVulkan.cpp:31-88
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    SNN_CHK(inputDims.size() == 2);
+    snnhip_concat_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(inputDims[0].height);
+    d.W = static_cast<int>(inputDims[0].width);
+    d.C0 = static_cast<int>(inputDims[0].channels);
+    d.C1 = static_cast<int>(inputDims[1].channels);
+    d.OC = static_cast<int>(_desc.numOutputPlanes); // :56
+    ret->passes[0].source = formatString("Concatenate %d+%d->%d", d.C0, d.C1, d.OC);
+    ret->passes[0].createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_concat_plan_create(ctx, &d, out); };
+    return ret;
+}
+
+InferencePassesSptr UnaryLayerHip::createCS(const LayerGenOptions&) const { // unaryVulkan.cpp:30-83
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    snnhip_unary_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(inputDims[0].height);
+    d.W = static_cast<int>(inputDims[0].width);
+    d.C = static_cast<int>(inputDims[0].channels);
+    d.op = _desc.opType;
+    d.value = _desc.opValue;
+    ret->passes[0].source = formatString("Unary op=%d", d.op);
+    ret->passes[0].createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_unary_plan_create(ctx, &d, out); };
+    return ret;
+}
+
+InferencePassesSptr CalculateLayerHip::createCS(const LayerGenOptions&) const { // calculationGL.cpp:28-57
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    snnhip_calculate_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(inputDims[0].height);
+    d.W = static_cast<int>(inputDims[0].width);
+    d.C = static_cast<int>(inputDims[0].channels);
+    d.OC = static_cast<int>(_desc.numOutputPlanes);
+    ret->passes[0].source = formatString("Calculate %d->%d", d.C, d.OC);
+    ret->passes[0].createPlan = [d](snnhip_ctx* ctx, snnhip_plan** out) { return snnhip_calculate_plan_create(ctx, &d, out); };
+    return ret;
+}
+
+InferencePassesSptr Conv2DTransposeLayerHip::createCS(const LayerGenOptions&) const { // deconv2dGL.cpp:282-343
+    auto ret = std::make_shared<InferencePasses>();
+    ret->passes.resize(1);
+    uint32_t ow = 0, oh = 0, od = 0;
+    getOutputDims(ow, oh, od);
+    snnhip_conv2d_desc d = {};
+    d.N = 1;
+    d.H = static_cast<int>(inputDims[0].height);
+    d.W = static_cast<int>(inputDims[0].width);
+    d.IC = static_cast<int>(_desc.numInputPlanes);
+    d.OC = static_cast<int>(_desc.numOutputPlanes);
+    d.kh = d.kw = static_cast<int>(_desc.kernelSize);
+    d.sh = d.sw = static_cast<int>(_desc.stride);
+    d.padT = _desc.paddingT == "same" ? static_cast<int>(_desc.kernelSize - _desc.stride) / 2 : 0;
+    const std::string& a = _desc.activation; // deconv2dGL.cpp:198-207: anything else leaves s untouched
+    d.act = a == "relu" ? SNNHIP_ACT_RELU : a == "tanh" ? SNNHIP_ACT_TANH : a == "sigmoid" ? SNNHIP_ACT_SIGMOID : a == "leakyRelu" ? SNNHIP_ACT_LEAKY : SNNHIP_ACT_NONE;
+    d.leaky = _desc.leakyReluAlpha;
+    d.useBias = _desc.biases.empty() ? 0 : 1;
+    d.useBN = _desc.useBatchNormalization ? 1 : 0;
+    d.OH = static_cast<int>(oh);
+    d.OW = static_cast<int>(ow);
+    const int taps = d.kh * d.kw;
+    SNN_CHK(_desc.weightsCvM.size() == static_cast<size_t>(d.OC) * d.IC); // weightMatrices[idxOutput * numInputPlanes + idxInput], deconv2dGL.cpp:93-96
+    std::vector<float> oihw(static_cast<size_t>(d.OC) * d.IC * taps);
+    for (size_t m = 0; m < _desc.weightsCvM.size(); ++m)
+        for (int t = 0; t < taps; ++t) oihw[m * taps + t] = _desc.weightsCvM[m].at<float>(t);
+    std::vector<float> bias(static_cast<size_t>(d.OC), 0.0f);
+    for (size_t i = 0; i < _desc.biases.size() && i < bias.size(); ++i) bias[i] = static_cast<float>(_desc.biases[i]);
+    BnArrays bn = bnArrays(_desc.useBatchNormalization, _desc.batchNormalization);
+    ret->passes[0].source = formatString("Conv2DTranspose k=%d s=%d %d->%d act=%s", d.kh, d.sh, d.IC, d.OC, a.c_str());
+    ret->passes[0].createPlan = [d, oihw, bias, bn](snnhip_ctx* ctx, snnhip_plan** out) {
+        return snnhip_deconv2d_plan_create(ctx, &d, oihw.data(), bias.data(), d.useBN ? bn.beta.data() : nullptr, d.useBN ? bn.gamma.data() : nullptr,
+                                           d.useBN ? bn.mean.data() : nullptr, d.useBN ? bn.var.data() : nullptr, out);
+    };
+    return ret;
+}
+
+// ---- YOLO v3 tiny head: decode + NMS on the CPU, as the reference does (yololayer.cpp:27-226)
+namespace {
+const int32_t kYoloGridScale[] = {32, 16};
+const int32_t kYoloGridChannel = 3, kYoloClasses = 1, kYoloFixed = 5, kYoloOutputs = kYoloClasses + kYoloFixed;
+const float kYoloAnchors[] = {10.f, 14.f, 23.f, 27.f, 37.f, 58.f, 81.f, 82.f, 135.f, 169.f, 344.f, 319.f};
+const int kYoloMasks[] = {3, 4, 5, 1, 2, 3};
+struct YoloBox {
+    int cls;
+    float score, x, y, w, h;
+};
+float yoloIoU(const YoloBox& a, const YoloBox& b) { // yololayer.cpp:57-72
+    const float x0 = std::max(a.x, b.x), y0 = std::max(a.y, b.y);
+    const float x1 = std::min(a.x + a.w, b.x + b.w), y1 = std::min(a.y + a.h, b.y + b.h);
+    if (x1 < x0 || y1 < y0) return 0.0f;
+    const float inter = (x1 - x0) * (y1 - y0);
+    return inter / (a.w * a.h + b.w * b.h - inter);
+}
+inline float sigmoidStd(float x) { return 1.0f / (1.0f + std::exp(-x)); }
+} // namespace
+
+std::vector<std::vector<float>> YOLOLayer::decode(const std::vector<const float*>& heads, int netSize) {
+    const float confidenceThreshold = 0.35f, iouThreshold = 0.45f; // yololayer.cpp:182-183
+    std::vector<YoloBox> boxes;
+    for (size_t idx = 0; idx < heads.size() && idx < 2; ++idx) {
+        const int grid = netSize / kYoloGridScale[idx];
+        const float* data = heads[idx];
+        size_t index = 0;
+        for (int gy = 0; gy < grid; ++gy)
+            for (int gx = 0; gx < grid; ++gx)
+                for (int gc = 0; gc < kYoloGridChannel; ++gc) { // yololayer.cpp:118-160
+                    int cls = 0;
+                    float maxLogit = -FLT_MAX;
+                    for (int i = kYoloFixed; i < kYoloOutputs; ++i)
+                        if (data[index + i] > maxLogit) {
+                            maxLogit = data[index + i];
+                            cls = i - kYoloFixed;
+                        }
+                    const int anchor = kYoloMasks[gc + static_cast<int>(idx) * kYoloGridChannel];
+                    const float prob = 1.f / ((1.f + std::exp(-data[index + 4]) * (1.f + std::exp(-maxLogit)))); // :147, as written
+                    if (prob > confidenceThreshold) {
+                        const float cx = (gx + sigmoidStd(data[index + 0])) / grid, cy = (gy + sigmoidStd(data[index + 1])) / grid;
+                        const float w = std::exp(data[index + 2]) * kYoloAnchors[anchor * 2] / static_cast<float>(kYoloGridScale[idx] * grid);
+                        const float h = std::exp(data[index + 3]) * kYoloAnchors[anchor * 2 + 1] / static_cast<float>(kYoloGridScale[idx] * grid);
+                        boxes.push_back({cls, prob, cx - w / 2, cy - h / 2, w, h});
+                    }
+                    index += kYoloOutputs; // the tensors here carry the true 18 channels: no 4-channel texture padding to skip (:158)
+                }
+    }
+    std::stable_sort(boxes.begin(), boxes.end(), [](const YoloBox& l, const YoloBox& r) { return l.score > r.score; });
+    std::vector<char> merged(boxes.size(), 0);
+    std::vector<std::vector<float>> out;
+    for (size_t i = 0; i < boxes.size(); ++i) { // Nms, yololayer.cpp:74-112
+        if (merged[i]) continue;
+        for (size_t j = i + 1; j < boxes.size(); ++j)
+            if (!merged[j] && boxes[i].cls == boxes[j].cls && yoloIoU(boxes[i], boxes[j]) > iouThreshold) merged[j] = 1;
+        out.push_back({static_cast<float>(boxes[i].cls), boxes[i].score, boxes[i].x, boxes[i].y, boxes[i].w, boxes[i].h});
+    }
+    return out;
+}
+
+void YOLOLayer::computeImageTexture(ImageTextureArray& inputTex, ImageTextureArray& outputTex) { // yololayer.cpp:177-226
+    std::vector<std::vector<float>> host(inputTex.size());
+    std::vector<const float*> heads;
+    for (size_t i = 0; i < inputTex.size(); ++i) {
+        host[i].resize(static_cast<size_t>(inputTex[i].width()) * inputTex[i].height() * inputTex[i].channels());
+        inputTex[i].downloadNHWC(host[i].data());
+        heads.push_back(host[i].data());
+    }
+    outputTex[0].setOutputMat(decode(heads));
+}
+
 // ------------------------------------------------------------------------------------------------ layer factory
 
 static std::unordered_map<std::string, LayerCreator> LayerRegistryDict;
@@ -593,6 +750,15 @@ DEFINE_HIP_CREATOR(Flatten)
 DEFINE_HIP_CREATOR(Pad)
 DEFINE_HIP_CREATOR(InstanceNorm)
 DEFINE_HIP_CREATOR(UpSampling2D)
+DEFINE_HIP_CREATOR(Concatenate)
+DEFINE_HIP_CREATOR(Unary)
+DEFINE_HIP_CREATOR(Calculate)
+DEFINE_HIP_CREATOR(Conv2DTranspose)
+static GenericModelLayer* YOLOCreator(ModelParser& parser, int i, bool) {
+    YOLODesc desc;
+    desc.parse(parser, i);
+    return new YOLOLayer(std::move(desc));
+}
 
 void snn::dp::registerLayer(const std::string& layerName, LayerCreator creator) { LayerRegistryDict.emplace(layerName, creator); }
 
@@ -612,6 +778,11 @@ void snn::dp::initLayerRegisty() { // layerFactory.cpp:109-129 (the hot-path ope
     registerLayer("Pad", PadCreator);
     registerLayer("InstanceNorm", InstanceNormCreator);
     registerLayer("UpSampling2D", UpSampling2DCreator);
+    registerLayer("Concatenate", ConcatenateCreator);
+    registerLayer("Unary", UnaryCreator);
+    registerLayer("Calculate", CalculateCreator);
+    registerLayer("Conv2DTranspose", Conv2DTransposeCreator);
+    registerLayer("YOLO", YOLOCreator);
 }
 
 GenericModelLayer* snn::dp::createLayerInstance(std::string layerName, ModelParser& parser, int i, bool useVulkan) { // layerFactory.cpp:136-159

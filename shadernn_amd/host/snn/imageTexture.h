@@ -33,6 +33,15 @@ public:
     void uploadNHWC(const float* nhwc);
     void downloadNHWC(float* nhwc);
 
+    // Pre-processing either side of a model run, on the device:
+    //  loadU8AndNormalize = loadFromFile's decoded 8-bit pixels + convertToRGBA32FAndNormalize (imageTexture.h:114, image.cpp:712-796): an
+    //      R8 / RGB8 / RGBA8 image becomes this texture's 4-channel tensor, y = (u8 - means) * norms (RGB8 alpha = 1, R8 see norm2rgba32f);
+    //  resize = ImageTextureVulkan::resize (imageTextureVulkan.cpp:137-183): the tensor is replaced by one of round(w / xScale) x
+    //      round(h / yScale), each texel (sample - means[c % 4]) * norms[c % 4], bilinear (clamp to edge) or nearest.
+    void loadU8AndNormalize(const uint8_t* pixels, uint32_t w, uint32_t h, uint32_t srcChannels, const std::array<float, 4>& means = {{0, 0, 0, 0}},
+                            const std::array<float, 4>& norms = {{1, 1, 1, 1}});
+    bool resize(float xScale, float yScale, const std::array<float, 4>& means, const std::array<float, 4>& norms, bool linearFilter = true);
+
     const std::array<uint32_t, 4>& getDims() const { return _dims; }
     uint32_t width() const { return _dims[0]; }
     uint32_t height() const { return _dims[1]; }

@@ -16,6 +16,8 @@ struct snn_model {
     ImageTextureArray inputs{nullptr};
     ImageTextureArray outputs{nullptr};
     int inW = 0, inH = 0, inC = 0;
+    bool half = false;
+    SNNModelOutput modelOutput;
 };
 
 static dp::ShaderGenOptions makeOptions(int w, int h, int c, bool fuse, bool half = false) {
@@ -63,6 +65,7 @@ int snn_model_create2(const char* json_path, int device, int in_w, int in_h, int
     cp.profiling = profiling != 0;
     m->core = MixedInferenceCore::create(m->context, cp);
     makeIO(m, half);
+    m->half = half;
     *out = m;
     return 0;
 }
@@ -86,8 +89,44 @@ int snn_model_run(snn_model* m) {
     MixedInferenceCore::RunParameters rp;
     rp.inputImages = &m->inputs;
     rp.outputImages = &m->outputs;
+    rp.modelOutput.modelType = m->modelOutput.modelType;
     m->core->run(rp);
+    m->modelOutput = rp.modelOutput;
     return 0;
+}
+
+int snn_model_set_type(snn_model* m, int model_type) {
+    if (model_type < 0 || model_type > 3) return -1;
+    m->modelOutput.modelType = static_cast<ModelType>(model_type);
+    return 0;
+}
+
+int snn_model_classifier_output(snn_model* m) { return m->modelOutput.classifierOutput; }
+
+static int copyRows(const std::vector<std::vector<float>>& rows, float* rows6, int max_rows) {
+    int n = 0;
+    for (auto& r : rows) {
+        if (n >= max_rows) break;
+        for (size_t k = 0; k < 6 && k < r.size(); ++k) rows6[n * 6 + static_cast<int>(k)] = r[k];
+        ++n;
+    }
+    return n;
+}
+
+int snn_model_detections(snn_model* m, float* rows6, int max_rows) { return copyRows(m->modelOutput.detectionOutput, rows6, max_rows); }
+
+int snn_yolo_decode(const float* head_coarse, const float* head_fine, int net_size, float* rows6, int max_rows) {
+    return copyRows(dp::YOLOLayer::decode({head_coarse, head_fine}, net_size), rows6, max_rows);
+}
+
+int snn_model_upload_input_u8(snn_model* m, const unsigned char* pixels, int w, int h, int channels, const float means[4], const float norms[4],
+                              const float resize_means[4], const float resize_norms[4]) {
+    if (m->inC != 4) return -1;
+    auto arr = [](const float* p, float dflt) { return std::array<float, 4>{{p ? p[0] : dflt, p ? p[1] : dflt, p ? p[2] : dflt, p ? p[3] : dflt}}; };
+    ImageTexture& t = m->inputs[0];
+    t.loadU8AndNormalize(pixels, static_cast<uint32_t>(w), static_cast<uint32_t>(h), static_cast<uint32_t>(channels), arr(means, 0.0f), arr(norms, 1.0f));
+    t.resize(static_cast<float>(w) / static_cast<float>(m->inW), static_cast<float>(h) / static_cast<float>(m->inH), arr(resize_means, 0.0f), arr(resize_norms, 1.0f));
+    return (static_cast<int>(t.width()) == m->inW && static_cast<int>(t.height()) == m->inH) ? 0 : -2;
 }
 
 static ImageTexture& lastOutput(snn_model* m) { return m->core->stage(m->core->numStages() - 1).stageOutputs[0]; }

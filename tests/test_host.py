@@ -234,3 +234,143 @@ def test_graph_runner_batched(ctx, which):
     y = r(x)
     want = O.forward(net, x)
     np.testing.assert_allclose(y.reshape(3, -1), want.reshape(3, -1), **TOL)
+
+
+# ---- Concatenate / Conv2DTranspose / Unary / YOLO through the host mirror, pre- and post-processing ----
+
+def _deconv_concat_net(seed=11):
+    from shadernn_amd import models
+
+    rng = np.random.default_rng(seed)
+    L = [models._conv(rng, "down", 4, 8, 3, "relu", stride=2),
+         models._deconv(rng, "up", 8, 8, 4, "relu", stride=2, bn=True),
+         models._conv(rng, "skip", 4, 12, 3, "leakyRelu"),
+         models._op("Concatenate", "cat", 20, inputs=["up", "skip"], c0=8, c1=12),
+         models._op("Unary", "copy", 20),
+         models._conv(rng, "head", 20, 4, 1, "tanh")]
+    L[2]["inputs"] = ["input"]
+    L[2]["alpha"] = 0.1
+    L[3]["ic"] = 8
+    return {"name": "deconv_concat", "input_channels": 4, "layers": L}
+
+
+def _yolo_net(seed=12):
+    """416 x 416 x 3 -> strided convs -> a 26 x 26 and a 13 x 13 head of 3 x 6 channels -> the CPU YOLO layer."""
+    from shadernn_amd import models
+
+    rng = np.random.default_rng(seed)
+    L, c = [], 3
+    for i, oc in enumerate([8, 8, 16, 16]):
+        L.append(models._conv(rng, "c%d" % i, c, oc, 3, "leakyRelu", stride=2))
+        L[-1]["alpha"] = 0.1
+        c = oc
+    fine = models._conv(rng, "fine", c, 18, 1, "linear")
+    coarse_f = models._conv(rng, "c4", c, 32, 3, "leakyRelu", stride=2)
+    coarse_f["inputs"], coarse_f["alpha"] = ["c3"], 0.1
+    coarse = models._conv(rng, "coarse", 32, 18, 1, "linear")
+    for hd in (fine, coarse):
+        hd["w"] *= 20.0 / 6.0
+        hd["b"] = rng.uniform(-1.0, 1.0, 18).astype(np.float32)
+    L += [fine, coarse_f, coarse, models._op("YOLO", "yolo", 18, inputs=["coarse", "fine"])]
+    return {"name": "yolo_mini", "input_channels": 3, "layers": L}
+
+
+def test_rank4_graphs_parse_on_cpu(built, tmp_path):
+    from shadernn_amd import host
+
+    net = _deconv_concat_net()
+    rows = host.graph_summary(_json(tmp_path, net, 16, 12), 16, 12, 4)
+    names = [r["name"].split("] ")[1] for r in rows]
+    assert names == ["InputLayer", "Conv2D", "Conv2D", "Conv2DTranspose", "Concatenate", "Unary", "Conv2D"] or names[1:4].count("Conv2DTranspose") == 1
+    by = {r["name"].split("] ")[1] + ":" + str(r["dims"]): r for r in rows}
+    assert any(k.startswith("Conv2DTranspose:(16, 12, 8)") for k in by)   # stride 2 "same": 2 x the 8 x 6 input (deconv2dGL.cpp:345-355)
+    cat = [r for r in rows if "Concatenate" in r["name"]][0]
+    assert cat["dims"] == (16, 12, 20) and len(cat["inputs"]) == 2
+    rows = host.graph_summary(_json(tmp_path, _yolo_net(), 416, 416), 416, 416, 3)
+    yolo = rows[-1]
+    assert "YOLO" in yolo["name"] and yolo["dims"][:2] == (600, 1) and len(yolo["inputs"]) == 2   # yololayer.h:44-48: 100 boxes x 6
+    assert yolo["loc"] != rows[-2]["loc"]                                                          # the one CPU stage
+
+
+def test_yolo_decode_host_vs_numpy_restatement(built):
+    from shadernn_amd import host
+
+    rng = np.random.default_rng(3)
+    heads = [rng.normal(-2.0, 2.5, (1, 13, 13, 18)).astype(np.float32), rng.normal(-2.0, 2.5, (1, 26, 26, 18)).astype(np.float32)]
+    want = np.array(O.yolo_decode(heads), np.float32).reshape(-1, 6)
+    got = host.yolo_decode(heads[0], heads[1], 416, max_rows=4096)
+    assert len(want) > 20 and got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_deconv_concat_unary_json_end_to_end(ctx, tmp_path):
+    from shadernn_amd import host
+
+    net = _deconv_concat_net()
+    x = np.random.default_rng(5).random((1, 12, 16, 4), dtype=np.float32)
+    m = host.Model(_json(tmp_path, net, 16, 12), 16, 12, 4, fuse_chains=False)
+    y = m(x)
+    want, named = O.forward(net, x, return_named=True)
+    st = m.stages()
+    for i in range(1, len(st)):
+        lid = int(re.search(r"layer \[(\d+)\]", st[i]["name"]).group(1))
+        exp = named[net["layers"][lid - 1]["name"]]
+        np.testing.assert_allclose(m.stage_output(i).reshape(-1), exp.reshape(-1), err_msg=st[i]["name"], **TOL)
+    np.testing.assert_allclose(y.reshape(-1), want.reshape(-1), **TOL)
+    m.close()
+
+
+@pytest.mark.gpu
+def test_classifier_output_is_one_based_argmax(ctx, tmp_path):
+    from shadernn_amd import host
+
+    net, w, h = _small_nets()[0]
+    x = np.random.default_rng(7).random((1, h, w, 3), dtype=np.float32)
+    m = host.Model(_json(tmp_path, net, w, h), w, h, 3)
+    m.set_type("classification")
+    y = m(x)
+    assert m.classifier_output() == int(np.argmax(y.reshape(-1))) + 1 == O.argmax(O.forward(net, x)) + 1
+    m.close()
+
+
+@pytest.mark.gpu
+def test_yolo_model_detections(ctx, tmp_path):
+    from shadernn_amd import host
+
+    net = _yolo_net()
+    x = np.random.default_rng(8).random((1, 416, 416, 3), dtype=np.float32)
+    m = host.Model(_json(tmp_path, net, 416, 416), 416, 416, 3)
+    m.set_type("detection")
+    m.upload(x)
+    m.run()
+    body = dict(net, layers=net["layers"][:-1])
+    _, named = O.forward(body, x, threads=8, return_named=True)
+    want = np.array(O.yolo_decode([named["coarse"], named["fine"]]), np.float32).reshape(-1, 6)
+    got = m.detections(max_rows=8192)
+    # the device heads agree with the oracle's to ~1e-4, so a box right at the confidence / IoU threshold may flip: match boxes by geometry
+    assert len(want) > 100 and abs(len(want) - len(got)) <= 0.01 * len(want)
+    d = np.abs(want[:, None, 2:6] - got[None, :, 2:6]).max(axis=2)
+    j = d.argmin(axis=1)
+    ok = (d[np.arange(len(want)), j] < 1e-3) & (np.abs(want[:, 1] - got[j, 1]) < 1e-3) & (want[:, 0] == got[j, 0])
+    assert ok.mean() >= 0.99, ok.mean()
+    assert np.all(np.diff(got[:, 1]) <= 1e-7)  # sorted by score, like Nms() leaves them
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch", [1, 3, 4])
+def test_u8_image_preprocessing_on_device(ctx, tmp_path, ch):
+    """8-bit image -> convertToRGBA32FAndNormalize -> ImageTexture::resize(1/255 norms) -> model, vs the oracle's restatements."""
+    from shadernn_amd import host, models
+
+    net = models.single_conv(seed=9, ic=4, oc=8, k=3, act="relu")
+    img = np.random.default_rng(ch).integers(0, 256, (45, 70, ch), dtype=np.uint8)
+    m = host.Model(_json(tmp_path, net, 32, 24), 32, 24, 4)
+    means, norms = (10.0, 20.0, 30.0, 0.0), (1.0, 1.0, 1.0, 1.0)
+    rn = (1 / 255.0,) * 4
+    m.upload_u8(img, means, norms, (0, 0, 0, 0), rn)
+    m.run()
+    t = O.resize(O.image_u8(img[None], means, norms), 24, 32, (0, 0, 0, 0), rn, True)
+    np.testing.assert_allclose(m.output().reshape(-1), O.forward(net, t).reshape(-1), rtol=1e-4, atol=1e-4)
+    m.close()

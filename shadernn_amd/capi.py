@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsnnhip.so")
+LIB_PATH = os.environ.get("SNNHIP_LIB_PATH") or os.path.join(_HERE, "lib", "libsnnhip.so")  # the override serves ablation builds (tools/)
 
 OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4
 

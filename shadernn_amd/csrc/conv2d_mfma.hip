@@ -28,6 +28,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef SNNHIP_ABL
+#define SNNHIP_ABL 0 // ablation builds only, see tools/ablate_conv.sh
+#endif
+
 namespace snnhip {
 
 namespace {
@@ -48,6 +52,7 @@ struct MfmaParams {
     int bufFloats;       // floats per LDS buffer
     int splitK;          // > 1: blockIdx.z owns chunks [z*chunksPerSplit, ...) and stores raw partial sums to the workspace
     int chunksPerSplit;
+    int ldsEpi;          // fp16, OC % 8 == 0, no split-K: the output tile leaves through LDS as 16-byte channel-contiguous stores
 };
 
 // LDS layout of the staged activations.  A pixel owns ICc floats = ICc/4 16-byte slots; the slot is XOR-swizzled with
@@ -65,7 +70,12 @@ __device__ __forceinline__ int lds_off(int pl, int slot) {
 // F16: tensors and packed weights hold halfs; a 16-byte slot is 8 channels instead of 4 and ONE v_mfma_f32_32x32x16_f16 consumes the slot pair
 // (h = 0, 1) that four v_mfma_f32_32x32x2_f32 consume in fp32, so a K-step is 16 channels; byte geometry (LDS tile, swizzle, weight stream,
 // 128-bit operand loads) is identical.  Accumulation and epilogue stay fp32; stores round to nearest even.
-template <int WM, int WN, int MT, int NT, int C8, int R, bool SIMPLE, bool F16>
+//
+// TAPS > 0 (fp16 only): the kernel-tap count is a compile-time constant and the K loop of a chunk (S = TAPS * C8 steps) is fully unrolled, so
+// the weight ring is addressed with static indices (no register shuffling) and can be D = 6..9 steps deep.  An fp16 K step is 4 MFMAs of
+// 32 cycles for a 2x2 register block -- the 2-step ring of the rolled loop (right for fp32, whose step is 8x longer) left the wave waiting
+// for L2 on every tap (s_waitcnt vmcnt(0) at the loop head, 32 % MFMA utilisation on the U-Net / ResNet 3x3 layers).
+template <int WM, int WN, int MT, int NT, int C8, int R, bool SIMPLE, bool F16, int TAPS = 0>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCfg ac, const void* __restrict__ xv, const void* __restrict__ wpv,
                                                           const float4* __restrict__ epi, void* __restrict__ yv, float* __restrict__ ws) {
     static_assert(WM * WN == 4, "4 waves per block");
@@ -78,7 +88,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
     T* __restrict__ y = static_cast<T*>(yv);
     constexpr int Q = 2 * C8;    // 16-byte slots per staged pixel
     constexpr int BN = 32 * NT * WN;
-    constexpr int D = (MT * NT >= 4) ? 2 : (MT * NT == 2 ? 3 : 4); // weight prefetch distance in K steps
+    constexpr int S = TAPS * C8; // K steps per chunk when the tap count is static
+    constexpr int DS = S % 6 == 0 ? 6 : (S == 9 ? 9 : (S == 8 ? 8 : (S % 4 == 0 ? 4 : (S % 3 == 0 ? 3 : (S % 2 == 0 ? 2 : 1))))); // divides S
+    constexpr int D = TAPS ? DS : ((MT * NT >= 4) ? 2 : (MT * NT == 2 ? 3 : 4)); // weight prefetch distance in K steps
+    static_assert(!TAPS || F16, "the unrolled K loop is instantiated for fp16 only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gofs[r] >= 0 && icq < p.IC) {
+            if (gofs[r] >= 0 && icq < p.IC && !(SNNHIP_ABL & 4)) { // ablation bit 4: no activation loads
                 const T* src = x + gofs[r] + ic0;
                 if (vec4) {
                     v = *reinterpret_cast<const float4*>(src);
@@ -161,6 +174,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
+    int tapDelta[TAPS > 0 ? TAPS : 1]; // LDS pixel delta of each tap (static tap count only)
+    if constexpr (TAPS > 0) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int fy = t / p.kw, fxx = t - fy * p.kw;
+            tapDelta[t] = fy * p.rowPitch + (p.evenCols ? (fxx & 1) * p.evenCols + (fxx >> 1) : fxx);
+        }
+    }
+
     // weight ring: bq[d] = step s+d (the packed array carries D extra zero steps at the end)
     float4 bq[D][NT];
 #pragma unroll
@@ -182,6 +204,37 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
         float4 an[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const float4*>(cur + lds_off<C8>(apix[t], h));
+        if constexpr (TAPS > 0) {
+            // S = TAPS * C8 steps, fully unrolled; D divides S, so step s of every chunk lives in ring slot s % D
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float4 a[MT], b[NT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a[t] = an[t];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) b[u] = bq[s % D][u];
+#if !(SNNHIP_ABL & 1) // ablation builds (tools/ablate_conv.sh): 1 = no weight refills, 2 = no LDS operand reads
+#pragma unroll
+                for (int u = 0; u < NT; ++u) bq[s % D][u] = bptr[u * 32];
+                bptr += bstep;
+#endif
+                __builtin_amdgcn_sched_barrier(0); // keep the refill D steps ahead of its use: the scheduler otherwise sinks it next to the consumer
+                if (s + 1 < S && !(SNNHIP_ABL & 2)) {
+                    const int dl = tapDelta[(s + 1) / C8];
+                    const int slot = ((s + 1) % C8) * 2 + h;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const float4*>(cur + lds_off<C8>(apix[t] + dl, slot));
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
+            }
+            if (more) stage_store(smem + ((chunk + 1) & 1) * p.bufFloats);
+            __syncthreads();
+            continue;
+        }
         int fx = 0, rowoff = 0;
 #pragma unroll 1
         for (int tap = 0; tap < taps; ++tap) {
@@ -251,6 +304,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 
     // ---- epilogue: bias -> BN -> activation, 128-byte channel-contiguous stores.  Rows r&3 of a lane are 4 adjacent
     // x pixels of one image row (TW >= 4, tile origins multiples of 4) -> one 32-bit offset per group of 4 rows.
+    // fp16 (p.ldsEpi): a lane's accumulators are single halfs of 16 different pixels -- stored directly they leave as 2-byte scatters in
+    // 64-byte runs (measured: 19 of 69 us of a 3x3 256->128 layer).  The tile is transposed through LDS instead ([pixel][BN halfs], row
+    // pitch BN*2+16 bytes so that the two half-waves hit disjoint banks) and written as 16-byte vectors, a pixel's BN channels contiguous.
+    constexpr int EPITCH = BN + 8; // halfs per LDS row of the output tile
+    _Float16* const otile = reinterpret_cast<_Float16*>(smem);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int ibase = (wm * MT + t) * 32 + 4 * h;
@@ -284,9 +342,28 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                         v = epi_act(act, ac.leaky, v, first);
                         if (k == 0) first = v;
                     }
-                    if (ok && ox + k < p.OW) y[pofs + k * p.OC + oc] = static_cast<T>(v);
+                    if (F16 && p.ldsEpi) {
+                        otile[(i + k) * EPITCH + wn * (NT * 32) + u * 32 + l32] = static_cast<_Float16>(v);
+                    } else if (ok && ox + k < p.OW && (!(SNNHIP_ABL & 8) || v == 12345.678f)) { // ablation bit 8: no output stores
+                        y[pofs + k * p.OC + oc] = static_cast<T>(v);
+                    }
                 }
             }
+        }
+    }
+    if (F16 && p.ldsEpi) {
+        __syncthreads();
+        constexpr int VPR = BN / 8; // 16-byte vectors per pixel row of the tile
+#pragma unroll
+        for (int j = 0; j < 128 * VPR / 256; ++j) {
+            const int v = tid + 256 * j;
+            const int i = v / VPR, c8 = v - i * VPR;
+            const int b = i >> (p.THs + p.TWs), py = (i >> p.TWs) & THm, px = i & TWm;
+            const int n = b0 + b, oy = oy0 + py, ox = ox0 + px;
+            const int oc = blockIdx.y * BN + c8 * 8;
+            if (n < p.N && oy < p.OH && ox < p.OW && oc < p.OC && !(SNNHIP_ABL & 8))
+                *reinterpret_cast<float4*>(y + (static_cast<size_t>((n * p.OH + oy) * p.OW + ox) * p.OC + oc)) =
+                    *reinterpret_cast<const float4*>(otile + i * EPITCH + c8 * 8);
         }
     }
 }
@@ -347,7 +424,18 @@ struct MfmaConvPlan : ConvPlanBase {
 typedef void (*KernelFn)(MfmaParams, ActCfg, const void*, const void*, const float4*, void*, float*);
 
 template <int WM, int WN, int MT, int NT>
-KernelFn pick_kernel(int c8, int r, bool simple, bool f16) {
+KernelFn pick_kernel(int c8, int r, bool simple, bool f16, int taps) {
+    // fp16, static tap count: 3x3 (and the 2x2 of U-Net's up-convolutions) with 16/32-channel chunks
+#define SNNHIP_PICK_T(C8_, R_, T_)                                                                                                          \
+    if (f16 && taps == T_ && c8 == C8_ && r == R_)                                                                                            \
+        return simple ? conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, true, true, T_> : conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, false, true, T_>;
+    if (!getenv("SNNHIP_CONV_ROLLED")) {
+        SNNHIP_PICK_T(1, 3, 9)
+        SNNHIP_PICK_T(2, 3, 9)
+        SNNHIP_PICK_T(2, 5, 9)
+        SNNHIP_PICK_T(2, 3, 4)
+    }
+#undef SNNHIP_PICK_T
 #define SNNHIP_PICK(C8_, R_)                                                                                                              \
     if (c8 == C8_ && r == R_) {                                                                                                           \
         if (f16) return simple ? conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, true, true> : conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, false, true>;   \
@@ -482,11 +570,15 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         p.chunksPerSplit = up_div(p.nChunks, want);
         p.splitK = up_div(p.nChunks, p.chunksPerSplit);
     }
+    // fp16 output tile through LDS (see the kernel's epilogue): needs whole 8-channel vectors and the direct (non split-K) epilogue
+    p.ldsEpi = (f16 && p.splitK == 1 && g.OC % 8 == 0 && !getenv("SNNHIP_CONV_DIRECT_STORE")) ? 1 : 0;
+    size_t ldsNeed = L.ldsBytes;
+    if (p.ldsEpi) ldsNeed = std::max(ldsNeed, static_cast<size_t>(128) * (BN + 8) * 2);
     const bool simple = act_is_simple(g.act);
     KernelFn fn = nullptr;
-    if (BN == 128) fn = pick_kernel<2, 2, 2, 2>(C8, R, simple, f16);
-    if (BN == 64) fn = pick_kernel<2, 2, 2, 1>(C8, R, simple, f16);
-    if (BN == 32) fn = pick_kernel<4, 1, 1, 1>(C8, R, simple, f16);
+    if (BN == 128) fn = pick_kernel<2, 2, 2, 2>(C8, R, simple, f16, taps);
+    if (BN == 64) fn = pick_kernel<2, 2, 2, 1>(C8, R, simple, f16, taps);
+    if (BN == 32) fn = pick_kernel<4, 1, 1, 1>(C8, R, simple, f16, taps);
     if (!fn) return SNNHIP_E_UNSUPPORTED;
 
     auto* plan = new MfmaConvPlan();
@@ -497,7 +589,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->p = p;
     plan->ac = make_act_cfg(g.act, g.leaky);
     plan->kernel = fn;
-    plan->ldsBytes = ldsBytes;
+    plan->ldsBytes = ldsNeed;
     plan->grid = dim3(p.tilesX * p.tilesY * up_div(g.N, TB), p.OCp / BN, p.splitK);
     if (p.splitK > 1) {
         void* ws = nullptr;
@@ -510,20 +602,20 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         plan->deviceAllocs.push_back(ws);
         plan->d_ws = static_cast<float*>(ws);
     }
-    if (ldsBytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsBytes));
+    if (ldsNeed > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsNeed));
         if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(%zu) failed: %s", ldsBytes, hipGetErrorString(e));
+            set_error("hipFuncSetAttribute(%zu) failed: %s", ldsNeed, hipGetErrorString(e));
             delete plan;
             return SNNHIP_E_HIP;
         }
     }
 
-    // weights: Wp[chunk][tap][c8][h][OCp][j], ic = chunk*ICc + (c8*2 + h)*CH + j, j < CH (+ 4 zero steps: the prefetch ring reads up to 4
+    // weights: Wp[chunk][tap][c8][h][OCp][j], ic = chunk*ICc + (c8*2 + h)*CH + j, j < CH (+ 10 zero steps: the prefetch ring reads up to 9
     // steps ahead); 16 bytes per (h, oc): 4 floats or 8 halfs (fp32 -> fp16 rounds to nearest; weights that went through the reference's
     // truncating convertToMediumPrecision are representable and convert exactly)
     const size_t steps = static_cast<size_t>(p.nChunks) * taps * C8;
-    std::vector<float> wpk((steps + 4) * 2 * p.OCp * 4, 0.0f); // 16 bytes per (step, h, oc) in both precisions
+    std::vector<float> wpk((steps + 10) * 2 * p.OCp * 4, 0.0f); // 16 bytes per (step, h, oc) in both precisions; 10 >= the deepest ring
     _Float16* wph = reinterpret_cast<_Float16*>(wpk.data());
     for (int chunk = 0; chunk < p.nChunks; ++chunk)
         for (int t = 0; t < taps; ++t)
@@ -554,7 +646,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
                          static_cast<double>(g.OC) * g.IC * taps);
     char buf[256];
     snprintf(buf, sizeof(buf), "conv2d_mfma_%s k=%dx%d s=%d ic=%d oc=%d tile=%dx%dx%dpx x %doc chunk=%d lds=%zuB splitK=%d",
-             f16 ? "f16_32x32x16" : "f32_32x32x2", g.kh, g.kw, g.sh, g.IC, g.OC, TB, TH, TW, BN, ICc, ldsBytes, p.splitK);
+             f16 ? "f16_32x32x16" : "f32_32x32x2", g.kh, g.kw, g.sh, g.IC, g.OC, TB, TH, TW, BN, ICc, ldsNeed, p.splitK);
     plan->dtype = g.dtype;
     const double esz = f16 ? 2.0 : 4.0;
     plan->bytes = esz * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * taps);

@@ -49,7 +49,15 @@ def main():
     ap.add_argument("--force", default=None)
     ap.add_argument("--json", default=None)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--fp16", action="store_true", help="half tensors (fp16 MFMA path; roofline against 2516 TFLOP/s)")
+    ap.add_argument("--shape", action="append", default=[], help="extra ad-hoc layer N,H,W,IC,OC,k,stride (repeatable; with --only=adhoc runs just these)")
     args = ap.parse_args()
+    global PEAK_TF
+    if args.fp16:
+        PEAK_TF = 2516.6
+    for sh in args.shape:
+        v = [int(t) for t in sh.split(",")]
+        LAYERS.append(("adhoc %dx%d s%d %d->%d @%dx%d b%d" % (v[5], v[5], v[6], v[3], v[4], v[1], v[2], v[0]), v[0], v[1], v[2], v[3], v[4], v[5], v[6], False))
     if args.force:
         os.environ["SNNHIP_CONV"] = args.force
     import shadernn_amd as snn
@@ -64,9 +72,10 @@ def main():
         x = rng.random((N, H, W, IC), dtype=np.float32)
         w = (rng.standard_normal((OC, k, k) if dw else (OC, IC, k, k)) / np.sqrt(k * k * (1 if dw else IC))).astype(np.float32)
         b = rng.uniform(-0.1, 0.1, OC).astype(np.float32)
-        plan = snn.conv2d_plan(ctx, N, H, W, w, b, stride=s, pads=snn.same_padding(k), pad_mode="constant", act="relu", depthwise=dw)
-        xt = snn.Tensor.from_numpy(ctx, x)
-        yt = snn.Tensor(ctx, *plan.out_shape())
+        dt = snn.F16 if args.fp16 else snn.F32
+        plan = snn.conv2d_plan(ctx, N, H, W, w, b, stride=s, pads=snn.same_padding(k), pad_mode="constant", act="relu", depthwise=dw, dtype=dt)
+        xt = snn.Tensor.from_numpy(ctx, x, dtype=dt)
+        yt = snn.Tensor(ctx, *plan.out_shape(), dtype=dt)
         for _ in range(5):
             plan.run(xt, yt)
         ctx.sync()

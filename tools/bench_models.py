@@ -4,7 +4,7 @@ ResNet-18 224x224 batch 32 (config 3), MobileNetV2 224x224 batch 32 (= the per-G
 the toy style net at 720p batch 1 (the operator set of config 5, fp32).  Synthetic weights of the real topologies (models.py).
 Prints images/s, achieved TFLOP/s and GB/s on the algorithmic (per-layer, unfused) accounting, and the slowest layers.
 
-    python tools/bench_models.py [--reps 20] [--model resnet18|mobilenetv2|style] [--batch N] [--json out.json]
+    python tools/bench_models.py [--reps 20] [--model resnet18|mobilenetv2|candy|style|unet|yolov3-tiny] [--batch N] [--json out.json]
 """
 import argparse
 import json
@@ -41,7 +41,9 @@ def main():
 
     cases = [("resnet18", lambda: models.resnet18(seed=1), 32, 224, 224), ("mobilenetv2", lambda: models.mobilenetv2(seed=1), 32, 224, 224),
              ("candy", lambda: zoo("candy-9_simplified-opt", (720, 1280, 3)), 1, 720, 1280),   # the reference zoo's graph (config 5 topology), fp32
-             ("style", lambda: models.style_net(seed=1, width=32), 1, 720, 1280)]
+             ("style", lambda: models.style_net(seed=1, width=32), 1, 720, 1280),
+             # the zoo's U-Net (256 x 256 x 1) and YOLOv3-tiny (416 x 416 x 3, two heads) graphs
+             ("unet", lambda: zoo("unet", None), 8, 256, 256), ("yolov3-tiny", lambda: zoo("yolov3-tiny", (416, 416, 3)), 8, 416, 416)]
     out = []
     for name, make, batch, h, w in cases:
         if args.model and args.model != name:

@@ -62,6 +62,7 @@ struct MfmaParams {
 template <int C8>
 __device__ __forceinline__ int lds_off(int pl, int slot) {
     // Q = 2*C8 slots per pixel (2, 4, 8 or 16): slot ^ ((pl >> (4 - log2 Q)) & (Q-1)) makes (address / 16) mod 16 a bijection of pl mod 16
+    if (C8 == 0) return pl * 4; // tap-pair mode: one 16-byte slot per pixel, consecutive pixels are consecutive bank slots
     constexpr int Q = 2 * C8;
     constexpr int LQ = Q == 2 ? 1 : Q == 4 ? 2 : Q == 8 ? 3 : 4;
     return pl * (4 * Q) + ((slot ^ ((pl >> (4 - LQ)) & (Q - 1))) << 2);
@@ -75,6 +76,11 @@ __device__ __forceinline__ int lds_off(int pl, int slot) {
 // the weight ring is addressed with static indices (no register shuffling) and can be D = 6..9 steps deep.  An fp16 K step is 4 MFMAs of
 // 32 cycles for a 2x2 register block -- the 2-step ring of the rolled loop (right for fp32, whose step is 8x longer) left the wave waiting
 // for L2 on every tap (s_waitcnt vmcnt(0) at the loop head, 32 % MFMA utilisation on the U-Net / ResNet 3x3 layers).
+//
+// C8 == 0, "tap-pair" mode for channel-thin inputs (IC <= 4 fp32 / <= 8 fp16: the RGB stems of ResNet / MobileNetV2 / YOLO / Candy): a pixel
+// is ONE 16-byte slot and the K axis runs over the taps instead of the channels -- the two lane halves of a K step read two DIFFERENT taps
+// (h = 0: tap 2j, h = 1: tap 2j+1) of the same pixel slot layout, so a 7x7x3 stem takes 25 K steps instead of 49 and 3 of every 4 (fp32)
+// operand lanes carry data instead of 3 of 8.  Weights are packed [step][h][oc] to match; an odd tap count pads the last h = 1 half with zeros.
 template <int WM, int WN, int MT, int NT, int C8, int R, bool SIMPLE, bool F16, int TAPS = 0>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCfg ac, const void* __restrict__ xv, const void* __restrict__ wpv,
                                                           const float4* __restrict__ epi, void* __restrict__ yv, float* __restrict__ ws) {
@@ -86,7 +92,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
     const T* __restrict__ x = static_cast<const T*>(xv);
     const float4* __restrict__ wp = static_cast<const float4*>(wpv);
     T* __restrict__ y = static_cast<T*>(yv);
-    constexpr int Q = 2 * C8;    // 16-byte slots per staged pixel
+    constexpr int Q = C8 ? 2 * C8 : 1; // 16-byte slots per staged pixel
+    constexpr bool PAIR = C8 == 0;
     constexpr int BN = 32 * NT * WN;
     constexpr int S = TAPS * C8; // K steps per chunk when the tap count is static
     constexpr int DS = S % 6 == 0 ? 6 : (S == 9 ? 9 : (S == 8 ? 8 : (S % 4 == 0 ? 4 : (S % 3 == 0 ? 3 : (S % 2 == 0 ? 2 : 1))))); // divides S
@@ -230,6 +237,66 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 #pragma unroll
                     for (int u = 0; u < NT; ++u)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
+            }
+            if (more) stage_store(smem + ((chunk + 1) & 1) * p.bufFloats);
+            __syncthreads();
+            continue;
+        }
+        if constexpr (PAIR) {
+            // this lane walks taps h, h+2, h+4, ...: (pfx, prow) = column and LDS row offset of its current tap
+            const int steps = (taps + 1) >> 1;
+            auto tap_delta = [&](int fxx, int row) { return row + (p.evenCols ? (fxx & 1) * p.evenCols + (fxx >> 1) : fxx); };
+            int ptap = h, pfx = h % p.kw, prow = (h / p.kw) * p.rowPitch;
+            if (ptap >= taps) pfx = prow = 0; // 1x1 never comes here (taps >= 2), an odd tap count ends on a zero-weight half: read tap 0
+#pragma unroll
+            for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const float4*>(cur + lds_off<0>(apix[t] + tap_delta(pfx, prow), 0));
+#pragma unroll 1
+            for (int j = 0; j < steps; ++j) {
+                float4 a[MT], b[NT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a[t] = an[t];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) b[u] = bq[0][u];
+#pragma unroll
+                for (int d = 0; d + 1 < D; ++d)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) bq[d][u] = bq[d + 1][u];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) bq[D - 1][u] = bptr[u * 32];
+                bptr += bstep;
+                ptap += 2;
+                pfx += 2;
+                while (pfx >= p.kw) {
+                    pfx -= p.kw;
+                    prow += p.rowPitch;
+                }
+                if (ptap >= taps) pfx = prow = 0;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const float4*>(cur + lds_off<0>(apix[t] + tap_delta(pfx, prow), 0));
+                if (F16) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u)
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
+                }
             }
             if (more) stage_store(smem + ((chunk + 1) & 1) * p.bufFloats);
             __syncthreads();
@@ -441,6 +508,8 @@ KernelFn pick_kernel(int c8, int r, bool simple, bool f16, int taps) {
         if (f16) return simple ? conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, true, true> : conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, false, true>;   \
         return simple ? conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, true, false> : conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, false, false>; \
     }
+    SNNHIP_PICK(0, 3)
+    SNNHIP_PICK(0, 5)
     SNNHIP_PICK(1, 3)
     SNNHIP_PICK(1, 5)
     SNNHIP_PICK(1, 9)
@@ -478,9 +547,13 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     // LDS cost more residency than they save (1x1 960->320 @7x7 b32: 58.7 -> 51.7 us, 144->24 @56x56: 27.9 -> 45.3 us), so 16 stays the default
     const int CH = f16 ? 8 : 4;                                  // channels per 16-byte slot
     int C8 = g.IC <= 2 * CH ? 1 : 2;
+    // tap-pair mode (C8 = 0, see the kernel): channel-thin inputs with at least two taps; SNNHIP_CONV_PAIR=0 keeps the channel-chunk path
+    const char* pairEnv = getenv("SNNHIP_CONV_PAIR");
+    if (g.IC <= CH && taps >= 2 && !(pairEnv && atoi(pairEnv) == 0)) C8 = 0;
     if (const char* e = getenv("SNNHIP_CONV_C8"))
         if (taps == 1 && g.sh == 1 && g.sw == 1 && (atoi(e) == 4 || atoi(e) == 8) && g.IC >= 2 * CH * atoi(e)) C8 = atoi(e);
-    const int ICc = 2 * CH * C8;                                 // channels per LDS chunk: 16 fp32 / 32 fp16 (64 bytes per pixel either way)
+    const int Qs = C8 ? 2 * C8 : 1;                              // 16-byte slots per staged pixel
+    const int ICc = C8 ? 2 * CH * C8 : CH;                       // channels per LDS chunk: 16 fp32 / 32 fp16 (64 bytes per pixel either way)
 
     if (g.sw < 1 || g.sw > 2 || g.sh < 1 || g.sh > 2) return SNNHIP_E_UNSUPPORTED;
 
@@ -499,8 +572,8 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         if (TW < 32)  // lanes of one 32-lane half span several tile rows: their row step must be == TW (mod 16)
             while ((g.sh * L.rowPitch) % 16 != TW % 16) ++L.rowPitch;
         L.imgPitch = round_up(L.tileH * L.rowPitch, 16);
-        L.total = TB * L.tileH * L.tileW * (2 * C8);
-        L.ldsBytes = static_cast<size_t>(2) * TB * L.imgPitch * (2 * C8) * 16;
+        L.total = TB * L.tileH * L.tileW * Qs;
+        L.ldsBytes = static_cast<size_t>(2) * TB * L.imgPitch * Qs * 16;
         return L;
     };
     static const int shapes[][3] = {{0, 3, 4}, {0, 2, 5}, {0, 4, 3}, {1, 3, 3}, {2, 2, 3}, {3, 2, 2}, {0, 1, 6}, {0, 0, 7}};
@@ -509,9 +582,9 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     for (int s = 0; s < static_cast<int>(sizeof(shapes) / sizeof(shapes[0])); ++s) {
         const int TB = 1 << shapes[s][0], TH = 1 << shapes[s][1], TW = 1 << shapes[s][2];
         const TileLayout L = layout(shapes[s][0], shapes[s][1], shapes[s][2]);
-        if (L.total > 9 * 256 || L.ldsBytes > 150 * 1024) continue; // staging registers / LDS (two buffers)
+        if (L.total > (C8 ? 9 : 5) * 256 || L.ldsBytes > 150 * 1024) continue; // staging registers / LDS (two buffers)
         const double tiles = static_cast<double>(up_div(g.N, TB)) * up_div(g.OH, TH) * up_div(g.OW, TW);
-        double cost = tiles * (128.0 * taps + L.total / (2.0 * C8) * 0.5); // MFMA work dominates, staging breaks ties
+        double cost = tiles * (128.0 * taps + L.total / static_cast<double>(Qs) * 0.5); // MFMA work dominates, staging breaks ties
         if (L.ldsBytes > 80 * 1024) cost *= 1.4;                          // only one block per CU would fit
         if (best < 0 || cost < bestCost) {
             best = s;
@@ -530,7 +603,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.tilesY = up_div(g.OH, TH);
     p.nChunks = up_div(g.IC, ICc);
     p.total = L.total;
-    p.bufFloats = TB * L.imgPitch * (2 * C8) * 4;
+    p.bufFloats = TB * L.imgPitch * Qs * 4;
     const int rNeed = up_div(p.total, 256);
     const int R = (rNeed <= 3 && C8 <= 2) ? 3 : ((rNeed <= 5 && C8 <= 4) ? 5 : 9);
     const size_t ldsBytes = L.ldsBytes;
@@ -614,9 +687,20 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     // weights: Wp[chunk][tap][c8][h][OCp][j], ic = chunk*ICc + (c8*2 + h)*CH + j, j < CH (+ 10 zero steps: the prefetch ring reads up to 9
     // steps ahead); 16 bytes per (h, oc): 4 floats or 8 halfs (fp32 -> fp16 rounds to nearest; weights that went through the reference's
     // truncating convertToMediumPrecision are representable and convert exactly)
-    const size_t steps = static_cast<size_t>(p.nChunks) * taps * C8;
+    const size_t steps = C8 ? static_cast<size_t>(p.nChunks) * taps * C8 : static_cast<size_t>((taps + 1) / 2);
     std::vector<float> wpk((steps + 10) * 2 * p.OCp * 4, 0.0f); // 16 bytes per (step, h, oc) in both precisions; 10 >= the deepest ring
     _Float16* wph = reinterpret_cast<_Float16*>(wpk.data());
+    if (C8 == 0) { // tap-pair mode: Wp[step j][h][OCp][ic], tap = 2j + h
+        for (int t = 0; t < taps; ++t)
+            for (int j = 0; j < g.IC; ++j) {
+                const size_t base = (static_cast<size_t>(t / 2) * 2 + (t & 1)) * p.OCp;
+                for (int o = 0; o < g.OC; ++o) {
+                    const float wv = w_oihw[(static_cast<size_t>(o) * g.IC + j) * taps + t];
+                    if (f16) wph[(base + o) * 8 + j] = static_cast<_Float16>(wv);
+                    else wpk[(base + o) * 4 + j] = wv;
+                }
+            }
+    }
     for (int chunk = 0; chunk < p.nChunks; ++chunk)
         for (int t = 0; t < taps; ++t)
             for (int c8 = 0; c8 < C8; ++c8)
@@ -645,8 +729,11 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC +
                          static_cast<double>(g.OC) * g.IC * taps);
     char buf[256];
-    snprintf(buf, sizeof(buf), "conv2d_mfma_%s k=%dx%d s=%d ic=%d oc=%d tile=%dx%dx%dpx x %doc chunk=%d lds=%zuB splitK=%d",
-             f16 ? "f16_32x32x16" : "f32_32x32x2", g.kh, g.kw, g.sh, g.IC, g.OC, TB, TH, TW, BN, ICc, ldsNeed, p.splitK);
+    char chunkDesc[24];
+    if (C8) snprintf(chunkDesc, sizeof(chunkDesc), "chunk=%d", ICc);
+    else snprintf(chunkDesc, sizeof(chunkDesc), "tap-pairs");
+    snprintf(buf, sizeof(buf), "conv2d_mfma_%s k=%dx%d s=%d ic=%d oc=%d tile=%dx%dx%dpx x %doc %s lds=%zuB splitK=%d",
+             f16 ? "f16_32x32x16" : "f32_32x32x2", g.kh, g.kw, g.sh, g.IC, g.OC, TB, TH, TW, BN, chunkDesc, ldsNeed, p.splitK);
     plan->dtype = g.dtype;
     const double esz = f16 ? 2.0 : 4.0;
     plan->bytes = esz * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * taps);

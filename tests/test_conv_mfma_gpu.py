@@ -164,3 +164,51 @@ def test_thin_conv_matches_oracle(ctx, force, case):
     force(None)
     _, desc = run_conv(ctx, x, w, b, s, pads, "constant", "relu", 0.0, None)
     assert ("thin" in desc) == (IC >= 8), desc
+
+
+PAIR_CASES = [
+    # (N, H, W, IC, OC, k, stride): channel-thin inputs -> the tap-pair K loop (two taps per MFMA K step)
+    (2, 37, 41, 3, 64, 7, 2),   # ResNet stem: 49 taps (odd: the last h=1 half is zero weights)
+    (1, 40, 56, 3, 32, 3, 2),   # MobileNetV2 stem
+    (1, 33, 47, 3, 16, 3, 1),   # YOLOv3-tiny first conv (OC 16: half of the 32-wide block is padding)
+    (1, 24, 40, 3, 32, 9, 1),   # Candy conv1 (81 taps)
+    (1, 21, 19, 4, 48, 4, 1),   # even kernel, IC == 4: vector staging
+    (1, 18, 22, 1, 32, 5, 1),   # single channel, 5x5
+    (2, 16, 16, 2, 40, 2, 2),   # 2x2 stride 2: two steps
+    (1, 15, 31, 3, 64, 1, 1),   # 1x1 stays on the channel-chunk path (one tap)
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+@pytest.mark.parametrize("case", PAIR_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_tap_pair_mode_matches_oracle(ctx, force, monkeypatch, case, pad_mode, dtype):
+    import shadernn_amd as snn
+
+    N, H, W, IC, OC, k, s = case
+    x = _rand((N, H, W, IC), 51)
+    w = _rand((OC, IC, k, k), 52, 1.0 / np.sqrt(IC * k * k))
+    b = _rand((OC,), 53, 0.1)
+    pads = O.padding_offsets("same", k)
+    force("mfma")
+    dt = snn.F16 if dtype == "f16" else snn.F32
+
+    def run():
+        plan = snn.conv2d_plan(ctx, N, H, W, w, b, stride=s, pads=pads, pad_mode=pad_mode, act="relu", dtype=dt)
+        xt = snn.Tensor.from_numpy(ctx, x, dtype=dt)
+        yt = plan(xt)
+        out, desc = yt.numpy(), plan.describe()
+        xt.free(), yt.free(), plan.destroy()
+        return out, desc
+
+    y, desc = run()
+    assert ("tap-pairs" in desc) == (k > 1), desc
+    if dtype == "f16":
+        want = O._h(O.conv2d(O._h(x), O._h(w), b, s, pads, pad_mode, "relu", 0.0, None))
+        np.testing.assert_allclose(y, want, err_msg=desc, rtol=2e-3, atol=2e-3)
+    else:
+        np.testing.assert_allclose(y, O.conv2d(x, w, b, s, pads, pad_mode, "relu", 0.0, None), err_msg=desc, **TOL)
+    monkeypatch.setenv("SNNHIP_CONV_PAIR", "0")  # the channel-chunk path on the same inputs
+    y2, desc2 = run()
+    assert "tap-pairs" not in desc2
+    np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-3 if dtype == "f16" else 1e-4, atol=2e-3 if dtype == "f16" else 1e-4)

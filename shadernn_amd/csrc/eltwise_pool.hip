@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(snnhip_upsample_desc d, i
 // Partials go to part[n][s][2][C]; a tiny fold kernel turns them into mean[n][C] and mul[n][C] in a fixed order (deterministic).
 // STAGE 0: partial S1, S2      STAGE 2: y = act((x - mean) * mul + beta)
 template <int STAGE, int CV, typename T>
-__global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int rowsPerSlab, int CLs, const T* __restrict__ x,
+__global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int pixelsPerSlab, int CLs, const T* __restrict__ x,
                                                           const float* __restrict__ statMean, const float* __restrict__ statMul,
                                                           const float* __restrict__ beta, float* __restrict__ partOut, T* __restrict__ y) {
     __shared__ float red[2 * 256 * CV];
@@ -219,9 +219,11 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
     const int tid = threadIdx.x;
     const int CL = 1 << CLs, PL = 256 >> CLs;       // channel lanes, pixel lanes
     const int cl = tid & (CL - 1), pl = tid >> CLs;
-    const int r0 = s * rowsPerSlab, r1 = min(d.H, r0 + rowsPerSlab);
-    const size_t p0 = static_cast<size_t>(r0) * d.W, p1 = static_cast<size_t>(r1) * d.W;
-    const T* xn = x + static_cast<size_t>(n) * d.H * d.W * d.C;
+    const size_t HW = static_cast<size_t>(d.H) * d.W;
+    const size_t p0 = static_cast<size_t>(s) * pixelsPerSlab, p1 = min(HW, p0 + pixelsPerSlab); // slab = a pixel range of the image
+    const T* xn = x + static_cast<size_t>(n) * HW * d.C;
+    T* yn = y + static_cast<size_t>(n) * HW * d.C;
+    constexpr int U = 4; // independent loads in flight per thread: the sweeps are latency-bound otherwise (measured 0.9 TB/s with one)
     for (int c0 = 0; c0 < d.C; c0 += CL * CV) {
         const int c = c0 + cl * CV;
         const bool cok = c < d.C;
@@ -235,23 +237,34 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
         float s1[CV], s2[CV];
 #pragma unroll
         for (int k = 0; k < CV; ++k) s1[k] = s2[k] = 0.0f;
+        auto consume = [&](const float (&v)[CV], size_t p) {
+            if (STAGE == 0) {
+#pragma unroll
+                for (int k = 0; k < CV; ++k) {
+                    const float dv = v[k] - piv[k];
+                    s1[k] += dv;
+                    s2[k] += dv * dv;
+                }
+            } else {
+                float o[CV];
+#pragma unroll
+                for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, (v[k] - piv[k]) * mul[k] + bt[k]);
+                stv<T, CV>(yn + p * d.C + c, o);
+            }
+        };
         if (cok) {
-            for (size_t p = p0 + pl; p < p1; p += PL) {
+            size_t p = p0 + pl;
+            for (; p + static_cast<size_t>(U - 1) * PL < p1; p += static_cast<size_t>(U) * PL) {
+                float v[U][CV];
+#pragma unroll
+                for (int u = 0; u < U; ++u) ldv<T, CV>(xn + (p + static_cast<size_t>(u) * PL) * d.C + c, v[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) consume(v[u], p + static_cast<size_t>(u) * PL); // same pixel order as the plain loop
+            }
+            for (; p < p1; p += PL) {
                 float v[CV];
                 ldv<T, CV>(xn + p * d.C + c, v);
-                if (STAGE == 0) {
-#pragma unroll
-                    for (int k = 0; k < CV; ++k) {
-                        const float dv = v[k] - piv[k];
-                        s1[k] += dv;
-                        s2[k] += dv * dv;
-                    }
-                } else {
-                    float o[CV];
-#pragma unroll
-                    for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, (v[k] - piv[k]) * mul[k] + bt[k]);
-                    stv<T, CV>(y + (static_cast<size_t>(n) * d.H * d.W + p) * d.C + c, o);
-                }
+                consume(v, p);
             }
         }
         if (STAGE == 0) {
@@ -280,20 +293,35 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
     }
 }
 
-// mean[n][c] = p + S1/HW,  mul[n][c] = gamma[c] / sqrt(S2/HW - (S1/HW)^2 + eps)   with S1, S2 summed over the slabs in order
+// mean[n][c] = p + S1/HW,  mul[n][c] = gamma[c] / sqrt(S2/HW - (S1/HW)^2 + eps)   with S1, S2 summed over the slabs in a fixed order:
+// one block per (image, channel), thread t adds slabs t, t+256, ..., then a shared-memory tree (deterministic; a single thread walking
+// ~1000 slab partials with dependent L2 loads took longer than both sweeps together)
 template <typename T>
 __global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, int S, int HW, float invHW, float eps, const T* __restrict__ x,
                                                                const float* __restrict__ part, const float* __restrict__ gamma,
                                                                float* __restrict__ mean, float* __restrict__ mul) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= NC) return;
+    __shared__ float r1[256], r2[256];
+    const int i = blockIdx.x;
     const int n = i / C, c = i % C;
     float a1 = 0.0f, a2 = 0.0f;
-    for (int j = 0; j < S; ++j) {
+    for (int j = threadIdx.x; j < S; j += 256) {
         const float* po = part + (static_cast<size_t>(n) * S + j) * 2 * C;
         a1 += po[c];
         a2 += po[C + c];
     }
+    r1[threadIdx.x] = a1;
+    r2[threadIdx.x] = a2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (static_cast<int>(threadIdx.x) < w) {
+            r1[threadIdx.x] += r1[threadIdx.x + w];
+            r2[threadIdx.x] += r2[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    a1 = r1[0];
+    a2 = r2[0];
     const float piv = static_cast<float>(x[static_cast<size_t>(n) * HW * C + c]);
     const float m1 = a1 * invHW;
     float var = a2 * invHW - m1 * m1;
@@ -450,7 +478,7 @@ struct UpsamplePlan : snnhip_plan {
 
 struct InstanceNormPlan : snnhip_plan {
     snnhip_instancenorm_desc d;
-    int S = 1, rowsPerSlab = 1, CLs = 2;
+    int S = 1, pixelsPerSlab = 1, CLs = 2;
     float *d_beta = nullptr, *d_gamma = nullptr, *d_part = nullptr, *d_mean = nullptr, *d_mul = nullptr;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "instancenorm: expects 1 input, got %d", nIn);
@@ -458,10 +486,10 @@ struct InstanceNormPlan : snnhip_plan {
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, d.H, d.W, d.C), "instancenorm: tensor dims do not match the plan");
         const dim3 g(static_cast<unsigned>(d.N * S));
         const int NC = d.N * d.C, HW = d.H * d.W;
-        const dim3 gf(static_cast<unsigned>((NC + 255) / 256));
+        const dim3 gf(static_cast<unsigned>(NC)); // one block per (image, channel)
         const float invHW = 1.0f / (static_cast<float>(d.H) * static_cast<float>(d.W));
 #define SNNHIP_IN(ST, CVV) \
-    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV, T>), g, dim3(256), 0, ctx->stream, d, S, rowsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta, d_part, mptr<T>(out))
+    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV, T>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta, d_part, mptr<T>(out))
 #define SNNHIP_FOLD() \
     hipLaunchKernelGGL(instancenorm_fold_kernel<T>, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, cptr<T>(in[0]), d_part, d_gamma, d_mean, d_mul)
         SNNHIP_WITH_T(out->dtype, if ((d.C & 3) == 0) {
@@ -612,13 +640,16 @@ int snnhip_instancenorm_plan_create(snnhip_ctx* ctx, const snnhip_instancenorm_d
     plan->ctx = ctx;
     plan->anyDtype = true;
     plan->d = *desc;
-    // row slabs: enough blocks to cover the chip about 8 times (HBM-bound sweeps want many waves in flight)
+    // slabs = pixel ranges of an image: enough blocks to cover the chip about 8 times (HBM-bound sweeps want many waves in flight), at least
+    // 4 pixels per pixel lane each (the unrolled loop) and a whole number of 64-pixel groups so that slab starts stay vector-aligned
     const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
-    int S = (8 * cus + desc->N - 1) / desc->N;
-    if (S > desc->H) S = desc->H;
-    if (S < 1) S = 1;
-    plan->rowsPerSlab = (desc->H + S - 1) / S;
-    plan->S = (desc->H + plan->rowsPerSlab - 1) / plan->rowsPerSlab;
+    const long long HWp = static_cast<long long>(desc->H) * desc->W;
+    long long S = (8LL * cus + desc->N - 1) / desc->N;
+    long long pps = (HWp + S - 1) / S;
+    if (pps < 256) pps = 256;
+    pps = (pps + 63) / 64 * 64;
+    plan->pixelsPerSlab = static_cast<int>(pps);
+    plan->S = static_cast<int>((HWp + pps - 1) / pps);
     int rc = plan->upload(beta, desc->C, &plan->d_beta);
     if (rc == SNNHIP_OK) rc = plan->upload(gamma, desc->C, &plan->d_gamma);
     {   // channel lanes: enough to read whole pixels (up to 128 channels = 512 contiguous bytes) per wave instruction

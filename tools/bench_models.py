@@ -77,7 +77,7 @@ def main():
         nodes = g.num_nodes()
         g.destroy()
         # per-layer times: one timed loop per plan
-        rows = []
+        rows, by_type = [], {}
         for si, (plan, ins, o, layer) in enumerate(r.steps):
             t.start()
             for _ in range(5):
@@ -86,6 +86,10 @@ def main():
             ctx.sync()
             f, b = r.step_cost(si)
             rows.append((t.elapsed_ms() / 5 * 1e3, layer["name"], f, b, plan.describe()))
+            by_type.setdefault(layer["type"], [0.0, 0, 0.0])
+            by_type[layer["type"]][0] += rows[-1][0]
+            by_type[layer["type"]][1] += 1
+            by_type[layer["type"]][2] += b
         fl, by = r.cost()
         ms_eager, ms = ms, min(ms, ms_graph)
         res = {"model": name, "dtype": "f16" if args.fp16 else "f32", "batch": batch, "input": [batch, h, w, 3], "ms_per_batch": ms, "ms_per_batch_eager_launches": ms_eager,
@@ -104,6 +108,8 @@ def main():
         tot = sum(x[0] for x in rows)
         for us, lname, f, b, desc in rows[:8]:
             print("     %8.1f us %5.1f%%  %-16s %6.2f TF/s %7.1f GB/s | %s" % (us, 100 * us / tot, lname, f / us / 1e6, b / us / 1e3, desc[:110]))
+        print("     by layer type: " + "  ".join("%s x%d %.0f us (%.0f GB/s)" % (k, v[1], v[0], v[2] / v[0] / 1e3) for k, v in sorted(by_type.items(), key=lambda kv: -kv[1][0])))
+        res["by_type_us"] = {k: v[0] for k, v in by_type.items()}
         res["top_layers"] = [{"us": us, "layer": lname, "kernel": desc} for us, lname, f, b, desc in rows[:8]]
         out.append(res)
     if args.json:

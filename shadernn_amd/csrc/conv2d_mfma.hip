@@ -53,6 +53,7 @@ struct MfmaParams {
     int splitK;          // > 1: blockIdx.z owns chunks [z*chunksPerSplit, ...) and stores raw partial sums to the workspace
     int chunksPerSplit;
     int ldsEpi;          // fp16, OC % 8 == 0, no split-K: the output tile leaves through LDS as 16-byte channel-contiguous stores
+    int preMode, preX, preY, srcH, srcW; // fused Pad layer (ConvGeom): H, W are the padded dims, the tensor is srcH x srcW (== H, W when preMode == 0)
 };
 
 // LDS layout of the staged activations.  A pixel owns ICc floats = ICc/4 16-byte slots; the slot is XOR-swizzled with
@@ -126,12 +127,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
             const int c = pix % p.tileW;
             const int t2 = pix / p.tileW;
             const int rr = t2 % p.tileH, b = t2 / p.tileH;
-            const int sy = resolve_coord(iy0 + rr, p.H, p.padMode);
-            const int sx = resolve_coord(ix0 + c, p.W, p.padMode);
+            int sy = resolve_coord(iy0 + rr, p.H, p.padMode);
+            int sx = resolve_coord(ix0 + c, p.W, p.padMode);
+            if (p.preMode && sy >= 0 && sx >= 0) { // a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied
+                sy = resolve_coord(sy - p.preY, p.srcH, p.preMode);
+                sx = resolve_coord(sx - p.preX, p.srcW, p.preMode);
+            }
             const int n = b0 + b;
             const int cm = p.evenCols ? (c & 1) * p.evenCols + (c >> 1) : c;
             lofs[r] = lds_off<C8>(b * p.imgPitch + rr * p.rowPitch + cm, q);
-            if (sy >= 0 && sx >= 0 && n < p.N) gofs[r] = ((n * p.H + sy) * p.W + sx) * p.IC + q * CH;
+            if (sy >= 0 && sx >= 0 && n < p.N) gofs[r] = ((n * p.srcH + sy) * p.srcW + sx) * p.IC + q * CH;
         }
     }
     float4 stage[R];
@@ -460,8 +465,8 @@ struct MfmaConvPlan : ConvPlanBase {
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
         const snnhip_tensor* x = in[0];
-        SNNHIP_REQUIRE(x->n == p.N && x->h == p.H && x->w == p.W && x->c == p.IC, "conv2d: input dims %dx%dx%dx%d != plan %dx%dx%dx%d",
-                       x->n, x->h, x->w, x->c, p.N, p.H, p.W, p.IC);
+        SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == p.IC, "conv2d: input dims %dx%dx%dx%d != plan %dx%dx%dx%d",
+                       x->n, x->h, x->w, x->c, p.N, p.srcH, p.srcW, p.IC);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
                        out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
         hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, static_cast<const void*>(x->data), static_cast<const void*>(d_w),
@@ -537,7 +542,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     // faster there too (241 vs 276 us at 1080p)
     const bool f16 = g.dtype == SNNHIP_F16; // fp16 tensors: this is the only general convolution kernel, it takes every shape
     if (!forced && !f16 && (g.OC < 16 || (g.OC < 32 && g.IC < 32))) return SNNHIP_E_UNSUPPORTED;
-    const double inCount = static_cast<double>(g.N) * g.H * g.W * g.IC;
+    const double inCount = static_cast<double>(g.N) * (g.preMode ? g.srcH : g.H) * (g.preMode ? g.srcW : g.W) * g.IC;
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED; // 32-bit element offsets in the kernel
 
@@ -595,6 +600,9 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     MfmaParams p{};
     p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.kh = g.kh; p.kw = g.kw; p.sh = g.sh; p.sw = g.sw;
     p.padx = g.padx; p.pady = g.pady; p.padMode = g.padMode; p.useBN = g.useBN; p.OH = g.OH; p.OW = g.OW;
+    p.preMode = g.preMode; p.preX = g.preX; p.preY = g.preY;
+    p.srcH = g.preMode ? g.srcH : g.H;
+    p.srcW = g.preMode ? g.srcW : g.W;
     p.TBs = shapes[best][0]; p.THs = shapes[best][1]; p.TWs = shapes[best][2];
     const int TB = 1 << p.TBs, TH = 1 << p.THs, TW = 1 << p.TWs;
     const TileLayout L = layout(p.TBs, p.THs, p.TWs);
@@ -723,7 +731,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         delete plan;
         return rc;
     }
-    plan->inDims[0] = g.N; plan->inDims[1] = g.H; plan->inDims[2] = g.W; plan->inDims[3] = g.IC;
+    plan->inDims[0] = g.N; plan->inDims[1] = p.srcH; plan->inDims[2] = p.srcW; plan->inDims[3] = g.IC;
     plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
     plan->flops = 2.0 * taps * g.IC * g.OC * static_cast<double>(g.OH) * g.OW * g.N;
     plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC +
@@ -736,8 +744,9 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
              f16 ? "f16_32x32x16" : "f32_32x32x2", g.kh, g.kw, g.sh, g.IC, g.OC, TB, TH, TW, BN, chunkDesc, ldsNeed, p.splitK);
     plan->dtype = g.dtype;
     const double esz = f16 ? 2.0 : 4.0;
-    plan->bytes = esz * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * taps);
+    plan->bytes = esz * (static_cast<double>(g.N) * p.srcH * p.srcW * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * taps);
     plan->desc = buf;
+    if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
     *out = plan;
     return SNNHIP_OK;
 }

@@ -204,6 +204,8 @@ struct DepthwisePlan : ConvPlanBase {
 } // namespace
 
 int make_depthwise_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_chw, const std::vector<float>& epi4, snnhip_plan** out) {
+    if (g.preMode) return SNNHIP_E_UNSUPPORTED; // the fused-Pad address path exists in the MFMA kernel only
+
     auto* plan = new DepthwisePlan();
     plan->ctx = ctx;
     plan->g = g;

@@ -435,9 +435,7 @@ struct PoolPlan : snnhip_plan {
     }
 };
 
-struct PadPlan : snnhip_plan {
-    snnhip_pad_desc d;
-    int OH = 0, OW = 0;
+struct PadPlan : PadPlanBase {
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "pad: expects 1 input, got %d", nIn);
         SNNHIP_SAME_DTYPE("pad");

@@ -932,8 +932,8 @@ std::vector<float> fold_epilogue(const std::vector<float>& epi4, int OC, int use
 
 bool plain_act(int act) { return act >= 0 && act <= SNNHIP_ACT_SILU; }
 
-bool is_same_conv(const ConvGeom& g, int k, int ic, int oc) {
-    return g.kh == k && g.kw == k && g.IC == ic && g.OC == oc && g.sh == 1 && g.sw == 1 && g.padx == k / 2 && g.pady == k / 2 &&
+bool is_same_conv(const ConvGeom& g, int k, int ic, int oc) { // the ESPCN kernels are fp32
+    return g.dtype == SNNHIP_F32 && g.preMode == 0 && g.kh == k && g.kw == k && g.IC == ic && g.OC == oc && g.sh == 1 && g.sw == 1 && g.padx == k / 2 && g.pady == k / 2 &&
            (g.padMode == SNNHIP_PAD_CONSTANT || g.padMode == SNNHIP_PAD_NONE) && g.OH == g.H && g.OW == g.W && plain_act(g.act);
 }
 
@@ -960,9 +960,11 @@ struct ChainPlan : snnhip_plan {
     };
     std::vector<Step> steps;
     std::vector<snnhip_tensor*> mids; // owned intermediates between steps
+    std::vector<snnhip_plan*> owned;  // plans built by the chain itself (rule D: a convolution with the Pad layer folded into its staging)
 
     ~ChainPlan() override {
         for (auto* t : mids) snnhip_tensor_free(t);
+        for (auto* q : owned) delete q;
     }
     int numSteps() const override { return static_cast<int>(steps.size()); }
     std::string stepDesc(int i) const override { return steps[i].desc; }
@@ -1277,6 +1279,39 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);
             i += 2;
             ++fusedCount;
+        } else if (auto* pd = dynamic_cast<PadPlanBase*>(plans[i]); pd && c1 && !c1->depthwise && c1->g.preMode == 0 && c1->g.N == pd->d.N &&
+                   c1->g.H == pd->OH && c1->g.W == pd->OW && c1->g.IC == pd->d.C && c1->desc.rfind("conv2d_mfma", 0) == 0 && !getenv("SNNHIP_NO_PAD_FUSION")) {
+            // ---- rule D: Pad + Conv2D -> the convolution stages its tiles straight from the unpadded tensor ("reflect Pad,
+            // better fused into the following conv's load stage"); only the MFMA kernel has the pre-pad address path, so a convolution that was
+            // routed to another kernel (the channel-thin image-producing layers) keeps its separate Pad launch
+            ConvGeom g2 = c1->g;
+            g2.preMode = pd->d.mode + 1; // pad desc 0/1/2 = constant / replicate / reflect -> SNNHIP_PAD_CONSTANT / _REPLICATE / _REFLECT
+            g2.preX = pd->d.padT;        // sic: the Pad shader shifts x by the top pad and y by the left pad (padlayerVulkan.cpp:81-82)
+            g2.preY = pd->d.padL;
+            g2.srcH = pd->d.H;
+            g2.srcW = pd->d.W;
+            snnhip_plan* fused = nullptr;
+            const int frc = make_conv2d_mfma_plan(ctx, g2, c1->w_oihw.data(), c1->epi4, &fused);
+            if (frc == SNNHIP_OK) {
+                fused->ctx = ctx;
+                chain->owned.push_back(fused);
+                st.kind = ChainPlan::PLAIN;
+                st.plain = fused;
+                memcpy(st.outDims, fused->outDims, sizeof(st.outDims));
+                st.desc = fused->desc;
+                st.flops = fused->flops;
+                st.bytes = fused->bytes;
+                i += 2;
+                ++fusedCount;
+            } else {
+                st.kind = ChainPlan::PLAIN;
+                st.plain = plans[i];
+                memcpy(st.outDims, plans[i]->outDims, sizeof(st.outDims));
+                st.desc = plans[i]->desc;
+                st.flops = plans[i]->flops;
+                st.bytes = plans[i]->bytes;
+                i += 1;
+            }
         } else {
             st.kind = ChainPlan::PLAIN;
             st.plain = plans[i];
@@ -1292,10 +1327,16 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         set_error("chain fusion: no rule matches these %d plans", n);
         rc = SNNHIP_E_UNSUPPORTED;
     }
+    // element type of the chain = that of its convolutions (the element-wise plans adapt to the tensors they are given)
+    for (int i = 0; i < n; ++i)
+        if (auto* c = dynamic_cast<ConvPlanBase*>(plans[i])) {
+            chain->dtype = c->g.dtype;
+            break;
+        }
     for (size_t i = 0; rc == SNNHIP_OK && i + 1 < chain->steps.size(); ++i) {
         snnhip_tensor* t = nullptr;
         const int* d = chain->steps[i].outDims;
-        rc = snnhip_tensor_alloc(ctx, d[0], d[1], d[2], d[3], SNNHIP_F32, &t);
+        rc = snnhip_tensor_alloc(ctx, d[0], d[1], d[2], d[3], chain->dtype, &t);
         if (rc == SNNHIP_OK) chain->mids.push_back(t);
     }
     if (rc != SNNHIP_OK) {

@@ -144,6 +144,9 @@ struct ConvGeom {
     float leaky;
     int OH, OW;
     int dtype; // SNNHIP_F32 | SNNHIP_F16
+    // fused Pad layer in front of the convolution (chain rule D): H, W above are the PADDED dims the convolution sees, the input tensor is
+    // srcH x srcW and padded pixel (y, x) reads source (y - preY, x - preX) resolved with preMode (SNNHIP_PAD_CONSTANT / REPLICATE / REFLECT)
+    int preMode = 0, preX = 0, preY = 0, srcH = 0, srcW = 0;
 };
 int resolve_conv_geom(const snnhip_conv2d_desc* d, bool depthwise, ConvGeom* g);
 
@@ -171,6 +174,10 @@ struct ConvPlanBase : snnhip_plan {
     std::vector<float> w_oihw; // host copy
     std::vector<float> epi4;   // host copy of the epilogue table, padded to a multiple of 16
     bool depthwise = false;
+};
+struct PadPlanBase : snnhip_plan {
+    snnhip_pad_desc d;
+    int OH = 0, OW = 0;
 };
 struct SubpixelPlanBase : snnhip_plan {
     snnhip_subpixel_desc d;

@@ -110,8 +110,10 @@ class GraphRunner:
     """Graph-shaped nets (models.resnet18 / mobilenetv2 / style_net): one plan per layer at any batch size, producers by name.
     Tensors are allocated once; run_device() only enqueues kernels.  (The C++ host mirror runs the same graphs at batch 1 from JSON.)"""
 
-    def __init__(self, ctx, net, n, h, w, dtype=capi.F32):
-        """dtype=capi.F16: half tensors end to end (convolutions on the fp16 MFMA path, fp32 accumulation)."""
+    def __init__(self, ctx, net, n, h, w, dtype=capi.F32, fuse=True):
+        """dtype=capi.F16: half tensors end to end (convolutions on the fp16 MFMA path, fp32 accumulation).
+        fuse=True: a Pad layer whose only consumer is a Conv2D is folded into that convolution's tile staging through
+        snnhip_chain_plan_create (rule D); the pad's own tensor is then never produced (output_of(pad) is unavailable)."""
         from . import models
 
         self.ctx, self.net, self.dtype = ctx, net, dtype
@@ -132,9 +134,44 @@ class GraphRunner:
             t = capi.Tensor(ctx, *out_shape, dtype=dtype)
             shapes[layer["name"]], self.tensors[layer["name"]] = out_shape, t
             self.steps.append((plan, [self.tensors[i] for i in ins], t, layer))
+        self.output_names = models.output_names(net)  # several for multi-head graphs (YOLOv3-tiny)
+        self.fused_pads = []
+        if fuse:
+            self._fuse_pads(models.producers(net))
         self.y = self.steps[-1][2]
         self.out_shape = shapes[net["layers"][-1]["name"]]
-        self.output_names = models.output_names(net)  # several for multi-head graphs (YOLOv3-tiny)
+
+    def _fuse_pads(self, prods):
+        consumers = {}
+        for layer, ins in prods:
+            for i in ins:
+                consumers.setdefault(i, []).append(layer["name"])
+        outputs = set(getattr(self, "output_names", []))
+        by_name = {l["name"]: k for k, (_, _, _, l) in enumerate(self.steps)}
+        drop = set()
+        for k, (plan, ins, out, layer) in enumerate(self.steps):
+            if layer["type"] != "Conv2D":
+                continue
+            src = [nm for nm, t in self.tensors.items() if t is ins[0]]
+            if not src or src[0] not in by_name:
+                continue
+            pk = by_name[src[0]]
+            pplan, pins, _, player = self.steps[pk]
+            if player["type"] != "Pad" or len(consumers.get(player["name"], [])) != 1 or player["name"] in outputs:
+                continue
+            try:
+                chain = capi.chain_plan(self.ctx, [pplan, plan])
+            except capi.SnnHipError as e:
+                if e.code != capi.E_UNSUPPORTED:
+                    raise
+                continue
+            if chain.num_steps() != 1:  # the conv kernel could not take the pad: keep the two launches
+                chain.destroy()
+                continue
+            self.steps[k] = (chain, pins, out, layer)
+            drop.add(pk)
+            self.fused_pads.append(player["name"])
+        self.steps = [st for k, st in enumerate(self.steps) if k not in drop]
 
     def describe(self):
         return ["%s: %s" % (l["name"], p.describe()) for p, _, _, l in self.steps]

@@ -138,3 +138,32 @@ def test_add_with_different_extents(ctx, s0, s1):
     ref[:, s0[1]:, :] = 0
     ref[:, :, s0[2]:] = 0
     np.testing.assert_allclose(want, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("mode", ["constant", "replicate", "reflect"])
+@pytest.mark.parametrize("n,h,w,ic,oc,k,s,pads,conv_pad", [(1, 40, 48, 32, 32, 3, 1, (1, 1, 1, 1), "valid"), (2, 21, 27, 3, 32, 9, 1, (4, 4, 4, 4), "valid"),
+                                                          (1, 33, 29, 32, 64, 3, 2, (1, 1, 1, 1), "valid"), (1, 18, 22, 64, 32, 3, 1, (2, 1, 3, 0), "same")])
+def test_pad_conv_chain_fusion(ctx, n, h, w, ic, oc, k, s, pads, conv_pad, mode, dtype):
+    """Chain rule D: Pad + Conv2D as ONE launch (the conv stages its tiles from the unpadded tensor), vs the oracle's pad then conv --
+    including the reference's swapped x/y pad offsets and the unshrunk "valid" output (Q20)."""
+    import shadernn_amd as snn
+
+    dt = snn.F16 if dtype == "f16" else snn.F32
+    x, wt, b = _rand((n, h, w, ic), 1), _rand((oc, ic, k, k), 2, 1.0 / np.sqrt(ic * k * k)), _rand((oc,), 3, 0.1)
+    ph, pw = h + pads[0] + pads[1], w + pads[2] + pads[3]
+    cp = O.padding_offsets(conv_pad, k)
+    pad = snn.pad_plan(ctx, n, h, w, ic, pads, mode)
+    conv = snn.conv2d_plan(ctx, n, ph, pw, wt, b, stride=s, pads=cp, act="relu", dtype=dt)
+    chain = snn.chain_plan(ctx, [pad, conv])
+    assert chain.num_steps() == 1 and "+pad(%s)" % mode in chain.describe(), chain.describe()
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=dt)
+    y = chain(xt)
+    if dtype == "f16":
+        want = O._h(O.conv2d(O._h(O.pad(O._h(x), pads, mode)), O._h(wt), b, s, cp, "constant", "relu", 0.0, None))
+        np.testing.assert_allclose(y.numpy(), want, err_msg=chain.describe(), rtol=2e-3, atol=2e-3)
+    else:
+        want = O.conv2d(O.pad(x, pads, mode), wt, b, s, cp, "constant", "relu", 0.0, None)
+        np.testing.assert_allclose(y.numpy(), want, err_msg=chain.describe(), **TOL)
+    two = conv(pad(xt))  # the unfused pair on the same input
+    np.testing.assert_allclose(y.numpy(), two.numpy(), rtol=2e-3 if dtype == "f16" else 1e-5, atol=2e-3 if dtype == "f16" else 1e-5)

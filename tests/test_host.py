@@ -374,3 +374,24 @@ def test_u8_image_preprocessing_on_device(ctx, tmp_path, ch):
     t = O.resize(O.image_u8(img[None], means, norms), 24, 32, (0, 0, 0, 0), rn, True)
     np.testing.assert_allclose(m.output().reshape(-1), O.forward(net, t).reshape(-1), rtol=1e-4, atol=1e-4)
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("half", [False, True])
+def test_style_net_with_chain_fusion_through_host(ctx, tmp_path, half):
+    """fuse_chains=True: HipBackend::finalizeStages hands the linear runs to snnhip_chain_plan_create, whose rule D folds every reflect Pad
+    into the convolution behind it; the result must not change."""
+    from shadernn_amd import host, models
+
+    net, w, h = models.style_net(seed=4, width=32), 40, 32  # 32+ channels: the convolutions run on the MFMA kernel, which has the fused-pad path
+    x = np.random.default_rng(15).random((1, h, w, 3), dtype=np.float32)
+    m = host.Model(_json(tmp_path, net, w, h), w, h, 3, fuse_chains=True, prefer_half=half)
+    y = m(x)
+    assert "+pad(reflect)" in m.describe() or any(s["fused_away"] for s in m.stages()), m.describe()
+    if half:
+        want = O.forward(net, x, fp16=True)
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(y.reshape(-1) / scale, want.reshape(-1) / scale, rtol=3e-2, atol=3e-2)
+    else:
+        np.testing.assert_allclose(y.reshape(-1), O.forward(net, x).reshape(-1), **TOL)
+    m.close()

@@ -205,11 +205,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
     }
 
     stage_load(chunk0 * 2 * CH * C8);
-    stage_store(smem + (chunk0 & 1) * p.bufFloats);
+    stage_store(smem); // buffer parity is relative to the split's first chunk: a single-chunk split needs one buffer only
     __syncthreads();
 
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
-        const float* cur = smem + (chunk & 1) * p.bufFloats;
+        const float* cur = smem + ((chunk - chunk0) & 1) * p.bufFloats;
         const bool more = chunk + 1 < chunk1;
         if (more) stage_load((chunk + 1) * 2 * CH * C8);
 
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                     for (int u = 0; u < NT; ++u)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
             }
-            if (more) stage_store(smem + ((chunk + 1) & 1) * p.bufFloats);
+            if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats);
             __syncthreads();
             continue;
         }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                         for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
                 }
             }
-            if (more) stage_store(smem + ((chunk + 1) & 1) * p.bufFloats);
+            if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats);
             __syncthreads();
             continue;
         }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
             fx = fxn;
             rowoff = rown;
         }
-        if (more) stage_store(smem + ((chunk + 1) & 1) * p.bufFloats);
+        if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats);
         __syncthreads();
     }
 
@@ -557,8 +557,8 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (g.IC <= CH && taps >= 2 && !(pairEnv && atoi(pairEnv) == 0)) C8 = 0;
     if (const char* e = getenv("SNNHIP_CONV_C8"))
         if (taps == 1 && g.sh == 1 && g.sw == 1 && (atoi(e) == 4 || atoi(e) == 8) && g.IC >= 2 * CH * atoi(e)) C8 = atoi(e);
-    const int Qs = C8 ? 2 * C8 : 1;                              // 16-byte slots per staged pixel
-    const int ICc = C8 ? 2 * CH * C8 : CH;                       // channels per LDS chunk: 16 fp32 / 32 fp16 (64 bytes per pixel either way)
+    int Qs = C8 ? 2 * C8 : 1;                                    // 16-byte slots per staged pixel
+    int ICc = C8 ? 2 * CH * C8 : CH;                             // channels per LDS chunk: 16 fp32 / 32 fp16 (64 bytes per pixel either way)
 
     if (g.sw < 1 || g.sw > 2 || g.sh < 1 || g.sh > 2) return SNNHIP_E_UNSUPPORTED;
 
@@ -584,17 +584,33 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     static const int shapes[][3] = {{0, 3, 4}, {0, 2, 5}, {0, 4, 3}, {1, 3, 3}, {2, 2, 3}, {3, 2, 2}, {0, 1, 6}, {0, 0, 7}};
     int best = -1;
     double bestCost = 0;
-    for (int s = 0; s < static_cast<int>(sizeof(shapes) / sizeof(shapes[0])); ++s) {
-        const int TB = 1 << shapes[s][0], TH = 1 << shapes[s][1], TW = 1 << shapes[s][2];
-        const TileLayout L = layout(shapes[s][0], shapes[s][1], shapes[s][2]);
-        if (L.total > (C8 ? 9 : 5) * 256 || L.ldsBytes > 150 * 1024) continue; // staging registers / LDS (two buffers)
-        const double tiles = static_cast<double>(up_div(g.N, TB)) * up_div(g.OH, TH) * up_div(g.OW, TW);
-        double cost = tiles * (128.0 * taps + L.total / static_cast<double>(Qs) * 0.5); // MFMA work dominates, staging breaks ties
-        if (L.ldsBytes > 80 * 1024) cost *= 1.4;                          // only one block per CU would fit
-        if (best < 0 || cost < bestCost) {
-            best = s;
-            bestCost = cost;
+    size_t bestLds = 0;
+    auto choose = [&]() {
+        best = -1;
+        const bool oneChunk = up_div(g.IC, ICc) == 1; // then the block stages once: no second buffer
+        for (int s = 0; s < static_cast<int>(sizeof(shapes) / sizeof(shapes[0])); ++s) {
+            const int TB = 1 << shapes[s][0], TH = 1 << shapes[s][1], TW = 1 << shapes[s][2];
+            const TileLayout L = layout(shapes[s][0], shapes[s][1], shapes[s][2]);
+            const size_t lds = oneChunk ? L.ldsBytes / 2 : L.ldsBytes;
+            if (L.total > (C8 ? 9 : 5) * 256 || lds > 150 * 1024) continue; // staging registers / LDS
+            const double tiles = static_cast<double>(up_div(g.N, TB)) * up_div(g.OH, TH) * up_div(g.OW, TW);
+            double cost = tiles * (128.0 * taps + L.total / static_cast<double>(Qs) * 0.5); // MFMA work dominates, staging breaks ties
+            if (lds > 80 * 1024) cost *= 1.4;                                 // only one block per CU would fit
+            if (best < 0 || cost < bestCost) {
+                best = s;
+                bestCost = cost;
+                bestLds = lds;
+            }
         }
+    };
+    choose();
+    // stride-2 halo tiles are ~4x the output tile: with 32-channel (fp32: 16) chunks they take > 80 KB and leave one block per CU (ResNet's
+    // downsampling 3x3 convs ran at 28 TF/s fp32 / 90 TF/s fp16).  Half-width chunks double the barriers but keep 2-3 blocks resident.
+    if (C8 == 2 && (best < 0 || bestLds > 80 * 1024) && !getenv("SNNHIP_CONV_WIDE_CHUNKS")) {
+        C8 = 1;
+        Qs = 2;
+        ICc = 2 * CH;
+        choose();
     }
     if (best < 0) return SNNHIP_E_UNSUPPORTED;
     MfmaParams p{};
@@ -653,7 +669,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     }
     // fp16 output tile through LDS (see the kernel's epilogue): needs whole 8-channel vectors and the direct (non split-K) epilogue
     p.ldsEpi = (f16 && p.splitK == 1 && g.OC % 8 == 0 && !getenv("SNNHIP_CONV_DIRECT_STORE")) ? 1 : 0;
-    size_t ldsNeed = L.ldsBytes;
+    size_t ldsNeed = p.chunksPerSplit == 1 ? L.ldsBytes / 2 : L.ldsBytes; // one chunk per block: no second staging buffer
     if (p.ldsEpi) ldsNeed = std::max(ldsNeed, static_cast<size_t>(128) * (BN + 8) * 2);
     const bool simple = act_is_simple(g.act);
     KernelFn fn = nullptr;

@@ -106,7 +106,7 @@ def main():
               (name, batch, ms, res["images_per_s"], res["tflops"], res["gbps_unfused"], res["roofline_ms"], 100 * res["frac_of_roofline"], len(r.steps)), flush=True)
         rows.sort(reverse=True)
         tot = sum(x[0] for x in rows)
-        for us, lname, f, b, desc in rows[:8]:
+        for us, lname, f, b, desc in rows[:(len(rows) if os.environ.get('BENCH_ALL') else 8)]:
             print("     %8.1f us %5.1f%%  %-16s %6.2f TF/s %7.1f GB/s | %s" % (us, 100 * us / tot, lname, f / us / 1e6, b / us / 1e3, desc[:110]))
         print("     by layer type: " + "  ".join("%s x%d %.0f us (%.0f GB/s)" % (k, v[1], v[0], v[2] / v[0] / 1e3) for k, v in sorted(by_type.items(), key=lambda kv: -kv[1][0])))
         res["by_type_us"] = {k: v[0] for k, v in by_type.items()}

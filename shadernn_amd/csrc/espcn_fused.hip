@@ -586,6 +586,97 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     }
 }
 
+// Two output rows per thread (SNNHIP_ESPCN_B=rows2).  The direct kernel above reads every activation from LDS once per (pixel, tap): 36
+// ds_read_b128 per pixel against 288 v_pk_fma_f32 -- LDS bandwidth and VALU issue are balanced 1:1 and each ends up ~40 % busy.  Here a
+// thread owns pixels (x, 2j) and (x, 2j+1): for one tap column it loads the 4 input rows once (16 b128 -> 64 VGPRs) and walks the 3 tap rows,
+// feeding row fy to the upper pixel and row fy+1 to the lower one with the SAME 64 scalar weights: 24 b128 per pixel, same FMA count.
+template <int TW, int TH, bool SIMPLE>
+__global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_rows2_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ w,
+                                                                          const float* __restrict__ ep, float* __restrict__ y) {
+    constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 16;
+    static_assert(TW * TH == 512, "two pixels per thread");
+    __shared__ __attribute__((aligned(16))) float s_x[THH * TWH * PITCH];
+
+    const int tid = threadIdx.x;
+    int b = xcd_tile_order(blockIdx.x, gridDim.x);
+    const int tx = b % p.tilesX;
+    b /= p.tilesX;
+    const int ty = b % p.tilesY;
+    const int n = b / p.tilesY;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
+    {
+        constexpr int NLD = (THH * TWH * 4 + 255) / 256;
+        float4 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256;
+            const int q = idx & 3, pix = idx >> 2;
+            const int r = pix / TWH, c = pix - r * TWH;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (idx < THH * TWH * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                v[k] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx >> 2) * PITCH + (((idx & 3) ^ ((idx >> 4) & 3)) * 4)) = v[k];
+        }
+    }
+    __syncthreads();
+
+    const int c = tid % TW, r = 2 * (tid / TW);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 u01 = {0.0f, 0.0f}, u23 = {0.0f, 0.0f}, l01 = {0.0f, 0.0f}, l23 = {0.0f, 0.0f}; // upper / lower pixel, channel pairs
+#pragma unroll 1
+    for (int fx = 0; fx < 3; ++fx) {
+        float4 rows[4][4]; // [input row r .. r+3][channel quad]
+#pragma unroll
+        for (int ir = 0; ir < 4; ++ir) {
+            const int pixIdx = (r + ir) * TWH + c + fx;
+            const float* src = s_x + pixIdx * PITCH;
+            const int sw = (pixIdx >> 2) & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rows[ir][q] = *reinterpret_cast<const float4*>(src + ((q ^ sw) * 4));
+        }
+#pragma unroll
+        for (int fy = 0; fy < 3; ++fy) { // unrolled: rows[fy] must be a static register index
+            const float* wt = w + ((fy * 3 + fx) * 16) * 4; // 64 uniform weights of this tap -> SGPRs
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 xu = rows[fy][q];
+                const float4 xl = rows[fy + 1][q];
+                const float us[4] = {xu.x, xu.y, xu.z, xu.w}, ls[4] = {xl.x, xl.y, xl.z, xl.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* wr = wt + (q * 4 + i) * 4;
+                    const f32x2 w01 = {wr[0], wr[1]}, w23 = {wr[2], wr[3]};
+                    const f32x2 xu2 = {us[i], us[i]}, xl2 = {ls[i], ls[i]};
+                    u01 = __builtin_elementwise_fma(xu2, w01, u01);
+                    u23 = __builtin_elementwise_fma(xu2, w23, u23);
+                    l01 = __builtin_elementwise_fma(xl2, w01, l01);
+                    l23 = __builtin_elementwise_fma(xl2, w23, l23);
+                }
+            }
+        }
+    }
+    const int gx = x0 + c;
+    float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int gy = y0 + r + half;
+        const float acc[4] = {half ? l01.x : u01.x, half ? l01.y : u01.y, half ? l23.x : u23.x, half ? l23.y : u23.y};
+        if (gy < p.H && gx < p.W) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(acc[k], ep[2 * k], ep[2 * k + 1]), 0.0f));
+            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
+            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
+        }
+    }
+}
+
 // Kernel B with asynchronous staging: persistent blocks (3 per CU) walk the 32x8 tiles; while tile t is computed out of one LDS buffer,
 // the halo tile of t+1 lands in the other one through global_load_lds (LDS-DMA: no staging registers, no ds_write pass).  The DMA writes
 // lane-linearly (wave-uniform base + lane*16 B), so the slot swizzle of the tile goes on the per-lane SOURCE address (guide rule 21:
@@ -951,6 +1042,7 @@ struct ChainPlan : snnhip_plan {
         int k1 = 5;
         bool persistent = false;
         bool dma = false; // FUSED_B: persistent direct kernel with LDS-DMA double buffering (SNNHIP_ESPCN_B=dma)
+        bool rows2 = false; // FUSED_B: two output rows per thread (SNNHIP_ESPCN_B=rows2)
         bool wino = false; // FUSED_A / FUSED_B: the 3x3 conv as Winograd F(2x2,3x3) (default) or direct (SNNHIP_ESPCN_A / _B = direct)
         float *w1 = nullptr, *w2 = nullptr, *e1 = nullptr, *e2 = nullptr, *w3 = nullptr, *e3 = nullptr;
         alignas(8) char streamCfg[kStreamCfgBytes] = {};
@@ -1049,6 +1141,16 @@ struct ChainPlan : snnhip_plan {
                 } else {
                     hipExtLaunchKernelGGL((conv3x3_c16o4_wino_d2s_tanh_kernel<false>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b, src->data,
                                           s.w1, s.e1, dst->data);
+                }
+                SNNHIP_CHECK_HIP(hipGetLastError());
+            } else if (s.rows2) {
+                dim3 grid(s.b.tilesX * s.b.tilesY * s.b.N);
+                if (act_is_simple(s.b.act.act)) {
+                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_rows2_kernel<B_TW, 2 * B_TH, true>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0,
+                                          s.b, src->data, s.w1, s.e1, dst->data);
+                } else {
+                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_rows2_kernel<B_TW, 2 * B_TH, false>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0,
+                                          s.b, src->data, s.w1, s.e1, dst->data);
                 }
                 SNNHIP_CHECK_HIP(hipGetLastError());
             } else {
@@ -1239,7 +1341,8 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.wino = bmode && strncmp(bmode, "wino", 4) == 0;
             st.persistent = bmode && strcmp(bmode, "wino_persistent") == 0;
             st.dma = bmode && strcmp(bmode, "dma") == 0;
-            const int bTW = st.wino ? 64 : B_TW, bTH = st.wino ? 16 : B_TH;
+            st.rows2 = bmode && strcmp(bmode, "rows2") == 0;
+            const int bTW = st.wino ? 64 : B_TW, bTH = st.wino ? 16 : (st.rows2 ? 2 * B_TH : B_TH);
             st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, bTW), up_div(g0.H, bTH), make_act_cfg(g0.act, g0.leaky)};
             std::vector<float> wB(9 * 16 * 4);
             for (int tap = 0; tap < 9; ++tap)
@@ -1272,8 +1375,9 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             memcpy(st.outDims, sp1->outDims, sizeof(st.outDims));
             char buf[200];
             snprintf(buf, sizeof(buf), "fused[conv3x3(16->4)%s+depth_to_space(2)+tanh] %s tile=%dx%d kernel=%s", st.wino ? " winograd F(2x2,3x3)" : "",
-                     st.wino ? "mfma_f32_4x4x1" : (st.dma ? "valu_f32 lds-dma persistent" : "valu_f32"), bTW, bTH,
-                     st.wino ? "conv3x3_c16o4_wino_d2s_tanh_kernel" : (st.dma ? "conv3x3_c16o4_d2s_tanh_dma_kernel" : "conv3x3_c16o4_d2s_tanh_kernel"));
+                     st.wino ? "mfma_f32_4x4x1" : (st.dma ? "valu_f32 lds-dma persistent" : (st.rows2 ? "valu_f32 2 rows/thread" : "valu_f32")), bTW, bTH,
+                     st.wino ? "conv3x3_c16o4_wino_d2s_tanh_kernel"
+                             : (st.dma ? "conv3x3_c16o4_d2s_tanh_dma_kernel" : (st.rows2 ? "conv3x3_c16o4_d2s_tanh_rows2_kernel" : "conv3x3_c16o4_d2s_tanh_kernel")));
             st.desc = buf;
             st.flops = c0->flops;
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);

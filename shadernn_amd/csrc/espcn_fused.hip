@@ -586,6 +586,94 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     }
 }
 
+// Persistent form of the direct kernel (SNNHIP_ESPCN_B=prefetch): WPS blocks per CU walk the tile list; the NEXT tile's halo is fetched
+// into NLD registers (24 VGPRs) right after this tile's LDS image is complete, so global loads are in flight during the whole compute
+// phase of every resident block instead of only while a block is in its load phase.  One LDS buffer, two barriers per tile.
+template <int TW, int TH, bool SIMPLE, int WPS>
+__global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_prefetch_kernel(FusedBParams p, int ntiles, const float* __restrict__ x,
+                                                                             const float* __restrict__ w, const float* __restrict__ ep,
+                                                                             float* __restrict__ y) {
+    constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 16;
+    static_assert(TW * TH == 256, "one thread per pixel");
+    __shared__ __attribute__((aligned(16))) float s_x[THH * TWH * PITCH];
+    constexpr int NLD = (THH * TWH * 4 + 255) / 256;
+    const int tid = threadIdx.x;
+
+    auto origin = [&](int t, int& n, int& x0, int& y0) {
+        int b = xcd_tile_order(t, ntiles);
+        const int tx = b % p.tilesX;
+        b /= p.tilesX;
+        const int ty = b % p.tilesY;
+        n = b / p.tilesY;
+        x0 = tx * TW;
+        y0 = ty * TH;
+    };
+    float4 v[NLD];
+    auto fetch = [&](int t) {
+        int n, x0, y0;
+        origin(t, n, x0, y0);
+        const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256;
+            const int q = idx & 3, pix = idx >> 2;
+            const int r = pix / TWH, c = pix - r * TWH;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (idx < THH * TWH * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                v[k] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) fetch(t);
+    const int c = tid % TW, r = tid / TW;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (; t < ntiles; t += gridDim.x) {
+        __syncthreads(); // every wave is done reading the previous tile
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx >> 2) * PITCH + (((idx & 3) ^ ((idx >> 4) & 3)) * 4)) = v[k];
+        }
+        __syncthreads();
+        if (t + static_cast<int>(gridDim.x) < ntiles) fetch(t + gridDim.x); // in flight during the 9 taps below
+
+        f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int fy = tap / 3, fx = tap - fy * 3;
+            const int pixIdx = (r + fy) * TWH + c + fx;
+            const float* src = s_x + pixIdx * PITCH;
+            const int sw = (pixIdx >> 2) & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 xv = *reinterpret_cast<const float4*>(src + ((q ^ sw) * 4));
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* wr = w + (tap * 16 + q * 4 + i) * 4;
+                    const f32x2 xx = {xs[i], xs[i]};
+                    const f32x2 w01 = {wr[0], wr[1]}, w23 = {wr[2], wr[3]};
+                    acc01 = __builtin_elementwise_fma(xx, w01, acc01);
+                    acc23 = __builtin_elementwise_fma(xx, w23, acc23);
+                }
+            }
+        }
+        int n, x0, y0;
+        origin(t, n, x0, y0);
+        const float acc[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
+        const int gy = y0 + r, gx = x0 + c;
+        if (gy < p.H && gx < p.W) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(acc[k], ep[2 * k], ep[2 * k + 1]), 0.0f));
+            float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
+            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
+            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
+        }
+    }
+}
+
 // Two output rows per thread (SNNHIP_ESPCN_B=rows2).  The direct kernel above reads every activation from LDS once per (pixel, tap): 36
 // ds_read_b128 per pixel against 288 v_pk_fma_f32 -- LDS bandwidth and VALU issue are balanced 1:1 and each ends up ~40 % busy.  Here a
 // thread owns pixels (x, 2j) and (x, 2j+1): for one tap column it loads the 4 input rows once (16 b128 -> 64 VGPRs) and walks the 3 tap rows,
@@ -1043,6 +1131,7 @@ struct ChainPlan : snnhip_plan {
         bool persistent = false;
         bool dma = false; // FUSED_B: persistent direct kernel with LDS-DMA double buffering (SNNHIP_ESPCN_B=dma)
         bool rows2 = false; // FUSED_B: two output rows per thread (SNNHIP_ESPCN_B=rows2)
+        int prefetch = 0;   // FUSED_B: persistent kernel with register prefetch, blocks per CU (SNNHIP_ESPCN_B=prefetch[N])
         bool wino = false; // FUSED_A / FUSED_B: the 3x3 conv as Winograd F(2x2,3x3) (default) or direct (SNNHIP_ESPCN_A / _B = direct)
         float *w1 = nullptr, *w2 = nullptr, *e1 = nullptr, *e2 = nullptr, *w3 = nullptr, *e3 = nullptr;
         alignas(8) char streamCfg[kStreamCfgBytes] = {};
@@ -1141,6 +1230,18 @@ struct ChainPlan : snnhip_plan {
                 } else {
                     hipExtLaunchKernelGGL((conv3x3_c16o4_wino_d2s_tanh_kernel<false>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b, src->data,
                                           s.w1, s.e1, dst->data);
+                }
+                SNNHIP_CHECK_HIP(hipGetLastError());
+            } else if (s.prefetch > 0) {
+                const int ntiles = s.b.tilesX * s.b.tilesY * s.b.N;
+                const int slots = s.prefetch * (ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256);
+                dim3 grid(ntiles < slots ? ntiles : slots);
+                if (act_is_simple(s.b.act.act)) {
+                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_prefetch_kernel<B_TW, B_TH, true, 6>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0,
+                                          s.b, ntiles, src->data, s.w1, s.e1, dst->data);
+                } else {
+                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_prefetch_kernel<B_TW, B_TH, false, 6>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0,
+                                          s.b, ntiles, src->data, s.w1, s.e1, dst->data);
                 }
                 SNNHIP_CHECK_HIP(hipGetLastError());
             } else if (s.rows2) {
@@ -1342,6 +1443,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.persistent = bmode && strcmp(bmode, "wino_persistent") == 0;
             st.dma = bmode && strcmp(bmode, "dma") == 0;
             st.rows2 = bmode && strcmp(bmode, "rows2") == 0;
+            if (bmode && strncmp(bmode, "prefetch", 8) == 0) st.prefetch = bmode[8] ? atoi(bmode + 8) : 6;
             const int bTW = st.wino ? 64 : B_TW, bTH = st.wino ? 16 : (st.rows2 ? 2 * B_TH : B_TH);
             st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, bTW), up_div(g0.H, bTH), make_act_cfg(g0.act, g0.leaky)};
             std::vector<float> wB(9 * 16 * 4);
@@ -1375,9 +1477,10 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             memcpy(st.outDims, sp1->outDims, sizeof(st.outDims));
             char buf[200];
             snprintf(buf, sizeof(buf), "fused[conv3x3(16->4)%s+depth_to_space(2)+tanh] %s tile=%dx%d kernel=%s", st.wino ? " winograd F(2x2,3x3)" : "",
-                     st.wino ? "mfma_f32_4x4x1" : (st.dma ? "valu_f32 lds-dma persistent" : (st.rows2 ? "valu_f32 2 rows/thread" : "valu_f32")), bTW, bTH,
+                     st.wino ? "mfma_f32_4x4x1" : (st.dma ? "valu_f32 lds-dma persistent" : (st.rows2 ? "valu_f32 2 rows/thread" : (st.prefetch ? "valu_f32 persistent reg-prefetch" : "valu_f32"))), bTW, bTH,
                      st.wino ? "conv3x3_c16o4_wino_d2s_tanh_kernel"
-                             : (st.dma ? "conv3x3_c16o4_d2s_tanh_dma_kernel" : (st.rows2 ? "conv3x3_c16o4_d2s_tanh_rows2_kernel" : "conv3x3_c16o4_d2s_tanh_kernel")));
+                             : (st.dma ? "conv3x3_c16o4_d2s_tanh_dma_kernel" : (st.rows2 ? "conv3x3_c16o4_d2s_tanh_rows2_kernel"
+                                                                                          : (st.prefetch ? "conv3x3_c16o4_d2s_tanh_prefetch_kernel" : "conv3x3_c16o4_d2s_tanh_kernel"))));
             st.desc = buf;
             st.flops = c0->flops;
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);

@@ -106,7 +106,7 @@ def test_chain_rejects_unfusable(ctx):
     assert e.value.code == -3
 
 
-VARIANTS = [("direct", "direct"), ("wino", "direct"), ("wino", "wino"), ("direct", "wino_persistent"), ("wino", "dma"), ("wino", "rows2")]
+VARIANTS = [("direct", "direct"), ("wino", "direct"), ("wino", "wino"), ("direct", "wino_persistent"), ("wino", "dma"), ("wino", "rows2"), ("wino", "prefetch")]
 
 
 @pytest.mark.parametrize("a_mode,b_mode", VARIANTS)
@@ -128,7 +128,7 @@ def test_espcn_kernel_variants_match_oracle(ctx, monkeypatch, a_mode, b_mode, n,
     np.testing.assert_allclose(runner(x), O.forward(net, x), err_msg=desc, **TOL)
 
 
-@pytest.mark.parametrize("a_mode,b_mode", [("direct", "direct"), ("wino", "wino"), ("wino", "wino_persistent"), ("wino", "dma"), ("wino", "rows2")])
+@pytest.mark.parametrize("a_mode,b_mode", [("direct", "direct"), ("wino", "wino"), ("wino", "wino_persistent"), ("wino", "dma"), ("wino", "rows2"), ("wino", "prefetch")])
 def test_espcn_kernel_variants_full_size(ctx, monkeypatch, a_mode, b_mode):
     """1080p: the persistent tile loops (4080 / 2040 tiles over 512 resident blocks) agree with the per-layer path."""
     import shadernn_amd as snn

@@ -38,7 +38,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct MfmaParams {
+struct MfmaParams { // (declared after ActCfg: epilogue.h)
     int N, H, W, IC, OC, kh, kw, sh, sw, padx, pady, padMode, useBN, OH, OW;
     int TBs, THs, TWs;   // log2 of the pixel-tile dims
     int tileH, tileW;    // staged input tile (per image of the tile)
@@ -54,6 +54,9 @@ struct MfmaParams {
     int chunksPerSplit;
     int ldsEpi;          // fp16, OC % 8 == 0, no split-K: the output tile leaves through LDS as 16-byte channel-contiguous stores
     int preMode, preX, preY, srcH, srcW; // fused Pad layer (ConvGeom): H, W are the padded dims, the tensor is srcH x srcW (== H, W when preMode == 0)
+    // fused residual Add (chain rule E): y = act2(conv_result + res), res = a tensor of the output's shape and type, set per launch
+    const void* res;
+    ActCfg ac2;
 };
 
 // LDS layout of the staged activations.  A pixel owns ICc floats = ICc/4 16-byte slots; the slot is XOR-swizzled with
@@ -417,6 +420,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                     if (F16 && p.ldsEpi) {
                         otile[(i + k) * EPITCH + wn * (NT * 32) + u * 32 + l32] = static_cast<_Float16>(v);
                     } else if (ok && ox + k < p.OW && (!(SNNHIP_ABL & 8) || v == 12345.678f)) { // ablation bit 8: no output stores
+                        if (p.res) { // the Add layer behind this convolution: same rounding points as the two separate launches
+                            const float cv = static_cast<float>(static_cast<T>(v));
+                            v = epi_act(p.ac2.act, p.ac2.leaky, cv + static_cast<float>(static_cast<const T*>(p.res)[pofs + k * p.OC + oc]), 0.0f);
+                        }
                         y[pofs + k * p.OC + oc] = static_cast<T>(v);
                     }
                 }
@@ -433,9 +440,20 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
             const int b = i >> (p.THs + p.TWs), py = (i >> p.TWs) & THm, px = i & TWm;
             const int n = b0 + b, oy = oy0 + py, ox = ox0 + px;
             const int oc = blockIdx.y * BN + c8 * 8;
-            if (n < p.N && oy < p.OH && ox < p.OW && oc < p.OC && !(SNNHIP_ABL & 8))
-                *reinterpret_cast<float4*>(y + (static_cast<size_t>((n * p.OH + oy) * p.OW + ox) * p.OC + oc)) =
-                    *reinterpret_cast<const float4*>(otile + i * EPITCH + c8 * 8);
+            if (n < p.N && oy < p.OH && ox < p.OW && oc < p.OC && !(SNNHIP_ABL & 8)) {
+                const size_t o = static_cast<size_t>((n * p.OH + oy) * p.OW + ox) * p.OC + oc;
+                float4 pack = *reinterpret_cast<const float4*>(otile + i * EPITCH + c8 * 8);
+                if (p.res) {
+                    const float4 rpack = *reinterpret_cast<const float4*>(static_cast<const T*>(p.res) + o);
+                    const _Float16* ch = reinterpret_cast<const _Float16*>(&pack);
+                    const _Float16* rh = reinterpret_cast<const _Float16*>(&rpack);
+                    _Float16 oh[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) oh[e] = static_cast<_Float16>(epi_act(p.ac2.act, p.ac2.leaky, static_cast<float>(ch[e]) + static_cast<float>(rh[e]), 0.0f));
+                    pack = *reinterpret_cast<const float4*>(oh);
+                }
+                *reinterpret_cast<float4*>(y + o) = pack;
+            }
         }
     }
 }
@@ -443,12 +461,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 // split-K second pass: y[m][oc] = act(BN(bias + sum_z ws[z][m][oc])), summed in a fixed order (deterministic)
 template <bool SIMPLE, typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(size_t MN, int OC, int splitK, int useBN, ActCfg ac, const float* __restrict__ ws,
-                                                           const float4* __restrict__ epi, T* __restrict__ y) {
+                                                           const float4* __restrict__ epi, T* __restrict__ y, const T* __restrict__ res, ActCfg ac2) {
     for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < MN; i += static_cast<size_t>(gridDim.x) * 256) {
         float v = 0.0f;
         for (int z = 0; z < splitK; ++z) v += ws[static_cast<size_t>(z) * MN + i];
         v = epi_affine(v, epi[i % OC], useBN);
-        y[i] = static_cast<T>(SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f));
+        v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+        if (res) v = epi_act(ac2.act, ac2.leaky, static_cast<float>(static_cast<T>(v)) + static_cast<float>(res[i]), 0.0f); // fused residual Add
+        y[i] = static_cast<T>(v);
     }
 }
 
@@ -462,9 +482,19 @@ struct MfmaConvPlan : ConvPlanBase {
     dim3 grid;
     void (*kernel)(MfmaParams, ActCfg, const void*, const void*, const float4*, void*, float*) = nullptr;
 
+    bool fusedAdd = false; // chain rule E: run(x, residual) -> act2(conv(x) + residual)
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
-        SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
+        SNNHIP_REQUIRE(nIn == (fusedAdd ? 2 : 1), "conv2d: expects %d input(s), got %d", fusedAdd ? 2 : 1, nIn);
         const snnhip_tensor* x = in[0];
+        MfmaParams p = this->p; // per-launch copy: the residual pointer travels in the kernel argument block
+        p.res = nullptr;
+        if (fusedAdd) {
+            const snnhip_tensor* r = in[1];
+            SNNHIP_REQUIRE(r->n == p.N && r->h == p.OH && r->w == p.OW && r->c == p.OC && r->dtype == dtype,
+                           "conv2d+add: residual %dx%dx%dx%d (dtype %d) does not match the output %dx%dx%dx%d", r->n, r->h, r->w, r->c, r->dtype, p.N, p.OH,
+                           p.OW, p.OC);
+            p.res = p.splitK > 1 ? nullptr : static_cast<const void*>(r->data); // split-K: the reduce pass adds it
+        }
         SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == p.IC, "conv2d: input dims %dx%dx%dx%d != plan %dx%dx%dx%d",
                        x->n, x->h, x->w, x->c, p.N, p.srcH, p.srcW, p.IC);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
@@ -481,11 +511,13 @@ struct MfmaConvPlan : ConvPlanBase {
             const bool simple = act_is_simple(ac.act);
             if (dtype == SNNHIP_F16) {
                 _Float16* yo = reinterpret_cast<_Float16*>(out->data);
-                if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, _Float16>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, yo);
-                else hipLaunchKernelGGL((splitk_reduce_kernel<false, _Float16>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, yo);
+                const _Float16* rr = fusedAdd ? reinterpret_cast<const _Float16*>(in[1]->data) : nullptr;
+                if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, _Float16>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, yo, rr, p.ac2);
+                else hipLaunchKernelGGL((splitk_reduce_kernel<false, _Float16>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, yo, rr, p.ac2);
             } else {
-                if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, float>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, out->data);
-                else hipLaunchKernelGGL((splitk_reduce_kernel<false, float>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, out->data);
+                const float* rr = fusedAdd ? in[1]->data : nullptr;
+                if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, float>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, out->data, rr, p.ac2);
+                else hipLaunchKernelGGL((splitk_reduce_kernel<false, float>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, out->data, rr, p.ac2);
             }
         }
         SNNHIP_CHECK_HIP(hipGetLastError());
@@ -619,6 +651,8 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.preMode = g.preMode; p.preX = g.preX; p.preY = g.preY;
     p.srcH = g.preMode ? g.srcH : g.H;
     p.srcW = g.preMode ? g.srcW : g.W;
+    p.res = nullptr;
+    p.ac2 = make_act_cfg(g.addAct >= 0 ? g.addAct : SNNHIP_ACT_NONE, g.addLeaky);
     p.TBs = shapes[best][0]; p.THs = shapes[best][1]; p.TWs = shapes[best][2];
     const int TB = 1 << p.TBs, TH = 1 << p.THs, TW = 1 << p.TWs;
     const TileLayout L = layout(p.TBs, p.THs, p.TWs);
@@ -687,6 +721,8 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->ac = make_act_cfg(g.act, g.leaky);
     plan->kernel = fn;
     plan->ldsBytes = ldsNeed;
+    plan->fusedAdd = g.addAct >= 0;
+    if (plan->fusedAdd) plan->numInputs = 2;
     plan->grid = dim3(p.tilesX * p.tilesY * up_div(g.N, TB), p.OCp / BN, p.splitK);
     if (p.splitK > 1) {
         void* ws = nullptr;
@@ -763,6 +799,10 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->bytes = esz * (static_cast<double>(g.N) * p.srcH * p.srcW * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * taps);
     plan->desc = buf;
     if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
+    if (plan->fusedAdd) {
+        plan->desc += " +add";
+        plan->bytes += esz * static_cast<double>(g.N) * g.OH * g.OW * g.OC; // the residual is read once
+    }
     *out = plan;
     return SNNHIP_OK;
 }

@@ -332,9 +332,7 @@ __global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, i
 
 // ------------------------------------------------------------------------------------------------ plans
 
-struct EltwisePlan : snnhip_plan {
-    snnhip_eltwise_desc d;
-    int mode = 0;
+struct EltwisePlan : EltwisePlanBase {
     float* d_tab = nullptr;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         const int want = mode == 0 ? 2 : 1;

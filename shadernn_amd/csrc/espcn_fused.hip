@@ -1281,6 +1281,19 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
     // Default = the two-kernel fusion (rules A+B).  SNNHIP_ESPCN_FUSION=stream selects the single row-streaming kernel
     // (rule C, espcn_stream.hip): parity-tested, 20 B/px of HBM traffic, but measured slower on MI355X so far
     // (206 us vs 123+45 us per 1080p frame) because its per-wave dependency chain starves the matrix pipe.
+    // ---- rule E: Conv2D (MFMA kernel) + Add -> one launch, the residual is added in the convolution's epilogue.  The fused plan takes TWO
+    // inputs, snnhip_plan_run_n(plan, {conv input, residual}, 2, out), so it is returned as is instead of being wrapped into a ChainPlan.
+    if (n == 2 && !getenv("SNNHIP_NO_ADD_FUSION")) {
+        auto* cv = dynamic_cast<ConvPlanBase*>(plans[0]);
+        auto* ad = dynamic_cast<EltwisePlanBase*>(plans[1]);
+        if (cv && ad && ad->mode == 0 && !cv->depthwise && cv->g.addAct < 0 && cv->desc.rfind("conv2d_mfma", 0) == 0 && cv->g.act != SNNHIP_ACT_SILU_QUIRK &&
+            ad->d.N == cv->g.N && ad->d.H == cv->g.OH && ad->d.W == cv->g.OW && ad->d.C == cv->g.OC) {
+            ConvGeom g2 = cv->g;
+            g2.addAct = ad->d.act;
+            g2.addLeaky = ad->d.leaky;
+            return make_conv2d_mfma_plan(ctx, g2, cv->w_oihw.data(), cv->epi4, out);
+        }
+    }
     const char* mode = getenv("SNNHIP_ESPCN_FUSION");
     const bool allowStream = mode && strcmp(mode, "stream") == 0;
     auto* chain = new ChainPlan();

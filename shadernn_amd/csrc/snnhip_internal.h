@@ -147,6 +147,9 @@ struct ConvGeom {
     // fused Pad layer in front of the convolution (chain rule D): H, W above are the PADDED dims the convolution sees, the input tensor is
     // srcH x srcW and padded pixel (y, x) reads source (y - preY, x - preX) resolved with preMode (SNNHIP_PAD_CONSTANT / REPLICATE / REFLECT)
     int preMode = 0, preX = 0, preY = 0, srcH = 0, srcW = 0;
+    // fused residual Add behind the convolution (chain rule E): y = addAct(conv(x) + residual); -1 = none
+    int addAct = -1;
+    float addLeaky = 0.0f;
 };
 int resolve_conv_geom(const snnhip_conv2d_desc* d, bool depthwise, ConvGeom* g);
 
@@ -174,6 +177,10 @@ struct ConvPlanBase : snnhip_plan {
     std::vector<float> w_oihw; // host copy
     std::vector<float> epi4;   // host copy of the epilogue table, padded to a multiple of 16
     bool depthwise = false;
+};
+struct EltwisePlanBase : snnhip_plan {
+    snnhip_eltwise_desc d;
+    int mode = 0; // 0 add, 1 activation, 2 batch-norm
 };
 struct PadPlanBase : snnhip_plan {
     snnhip_pad_desc d;

@@ -136,8 +136,10 @@ class GraphRunner:
             self.steps.append((plan, [self.tensors[i] for i in ins], t, layer))
         self.output_names = models.output_names(net)  # several for multi-head graphs (YOLOv3-tiny)
         self.fused_pads = []
+        self.fused_adds = []
         if fuse:
             self._fuse_pads(models.producers(net))
+            self._fuse_adds(models.producers(net))
         self.y = self.steps[-1][2]
         self.out_shape = shapes[net["layers"][-1]["name"]]
 
@@ -172,6 +174,42 @@ class GraphRunner:
             drop.add(pk)
             self.fused_pads.append(player["name"])
         self.steps = [st for k, st in enumerate(self.steps) if k not in drop]
+
+    def _fuse_adds(self, prods):
+        """Conv2D -> Add (the residual connections of ResNet / MobileNetV2): the add moves into the convolution's epilogue (chain rule E)."""
+        consumers = {}
+        for layer, ins in prods:
+            for i in ins:
+                consumers.setdefault(i, []).append(layer["name"])
+        outputs = set(self.output_names)
+        name_of = {id(t): nm for nm, t in self.tensors.items()}
+        by_name = {l["name"]: k for k, (_, _, _, l) in enumerate(self.steps)}
+        drop, replace = set(), {}
+        for k, (plan, ins, out, layer) in enumerate(self.steps):
+            if layer["type"] != "Add" or len(ins) != 2:
+                continue
+            for which in (0, 1):
+                src = name_of.get(id(ins[which]))
+                if src not in by_name or by_name[src] in drop:
+                    continue
+                ck = by_name[src]
+                cplan, cins, cout, clayer = self.steps[ck]
+                if clayer["type"] != "Conv2D" or len(consumers.get(src, [])) != 1 or src in outputs or cout.shape != out.shape:
+                    continue
+                try:
+                    fused = capi.chain_plan(self.ctx, [cplan, plan])
+                except capi.SnnHipError as e:
+                    if e.code != capi.E_UNSUPPORTED:
+                        raise
+                    continue
+                if fused.num_steps() != 1 or "+add" not in fused.describe():
+                    fused.destroy()
+                    continue
+                replace[k] = (fused, [cins[0], ins[1 - which]], out, dict(layer, type="Conv2D", fused="conv+add"))
+                drop.add(ck)
+                self.fused_adds.append(layer["name"])
+                break
+        self.steps = [replace.get(k, st) for k, st in enumerate(self.steps) if k not in drop]
 
     def describe(self):
         return ["%s: %s" % (l["name"], p.describe()) for p, _, _, l in self.steps]

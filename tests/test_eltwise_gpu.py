@@ -167,3 +167,37 @@ def test_pad_conv_chain_fusion(ctx, n, h, w, ic, oc, k, s, pads, conv_pad, mode,
         np.testing.assert_allclose(y.numpy(), want, err_msg=chain.describe(), **TOL)
     two = conv(pad(xt))  # the unfused pair on the same input
     np.testing.assert_allclose(y.numpy(), two.numpy(), rtol=2e-3 if dtype == "f16" else 1e-5, atol=2e-3 if dtype == "f16" else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("n,h,w,ic,oc,k,s,act,add_act,split", [(2, 28, 28, 64, 64, 3, 1, "", "relu", None), (2, 14, 14, 96, 32, 1, 1, "", "", None),
+                                                               (3, 7, 7, 512, 512, 3, 1, "", "relu", "2"), (1, 19, 23, 32, 40, 3, 1, "relu6", "leakyRelu", None),
+                                                               (2, 16, 16, 64, 36, 1, 1, "", "relu", None)])
+def test_conv_add_chain_fusion(ctx, monkeypatch, n, h, w, ic, oc, k, s, act, add_act, split, dtype):
+    """Chain rule E: Conv2D + Add as one launch (residual added in the convolution's epilogue / the split-K reduce pass), vs conv then add."""
+    import shadernn_amd as snn
+
+    if split:
+        monkeypatch.setenv("SNNHIP_CONV_SPLITK", split)
+    dt = snn.F16 if dtype == "f16" else snn.F32
+    x, wt, b = _rand((n, h, w, ic), 1), _rand((oc, ic, k, k), 2, 1.0 / np.sqrt(ic * k * k)), _rand((oc,), 3, 0.1)
+    skip = _rand((n, h, w, oc), 4)
+    bn = _bn(oc, 5)
+    pads = O.padding_offsets("same", k)
+    conv = snn.conv2d_plan(ctx, n, h, w, wt, b, stride=s, pads=pads, act=act, bn=bn, dtype=dt)
+    add = snn.add_plan(ctx, n, h, w, oc, act=add_act, leaky=0.2)
+    fused = snn.chain_plan(ctx, [conv, add])
+    assert fused.num_steps() == 1 and "+add" in fused.describe(), fused.describe()
+    if split:
+        assert "splitK=2" in fused.describe()
+    xt, st = snn.Tensor.from_numpy(ctx, x, dtype=dt), snn.Tensor.from_numpy(ctx, skip, dtype=dt)
+    y = fused([xt, st]).numpy()
+    two = add([conv(xt), st]).numpy()
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == "f16" else TOL
+    if dtype == "f16":
+        c = O._h(O.conv2d(O._h(x), O._h(wt), b, s, pads, "constant", act, 0.0, bn))
+        want = O._h(O.add_act(c, O._h(skip), add_act, 0.2))
+    else:
+        want = O.add_act(O.conv2d(x, wt, b, s, pads, "constant", act, 0.0, bn), skip, add_act, 0.2)
+    np.testing.assert_allclose(y, want, err_msg=fused.describe(), **tol)
+    np.testing.assert_allclose(y, two, rtol=1e-6 if dtype == "f32" else 2e-3, atol=1e-6 if dtype == "f32" else 2e-3)

@@ -54,6 +54,7 @@ struct MfmaParams { // (declared after ActCfg: epilogue.h)
     int chunksPerSplit;
     int ldsEpi;          // fp16, OC % 8 == 0, no split-K: the output tile leaves through LDS as 16-byte channel-contiguous stores
     int preMode, preX, preY, srcH, srcW; // fused Pad layer (ConvGeom): H, W are the padded dims, the tensor is srcH x srcW (== H, W when preMode == 0)
+    int preShift;                        // fused nearest x2 upsampling in front of the pad: resolve against (srcH, srcW) << 1, then >> 1
     // fused residual Add (chain rule E): y = act2(conv_result + res), res = a tensor of the output's shape and type, set per launch
     const void* res;
     ActCfg ac2;
@@ -133,8 +134,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
             int sy = resolve_coord(iy0 + rr, p.H, p.padMode);
             int sx = resolve_coord(ix0 + c, p.W, p.padMode);
             if (p.preMode && sy >= 0 && sx >= 0) { // a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied
-                sy = resolve_coord(sy - p.preY, p.srcH, p.preMode);
-                sx = resolve_coord(sx - p.preX, p.srcW, p.preMode);
+                sy = resolve_coord(sy - p.preY, p.srcH << p.preShift, p.preMode);
+                sx = resolve_coord(sx - p.preX, p.srcW << p.preShift, p.preMode);
+                if (sy >= 0) sy >>= p.preShift; // nearest x2: upsampled pixel (y, x) is source pixel (y / 2, x / 2) (vk_upsampling2d_nearest.comp:50-65)
+                if (sx >= 0) sx >>= p.preShift;
             }
             const int n = b0 + b;
             const int cm = p.evenCols ? (c & 1) * p.evenCols + (c >> 1) : c;
@@ -648,7 +651,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     MfmaParams p{};
     p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.kh = g.kh; p.kw = g.kw; p.sh = g.sh; p.sw = g.sw;
     p.padx = g.padx; p.pady = g.pady; p.padMode = g.padMode; p.useBN = g.useBN; p.OH = g.OH; p.OW = g.OW;
-    p.preMode = g.preMode; p.preX = g.preX; p.preY = g.preY;
+    p.preMode = g.preMode; p.preX = g.preX; p.preY = g.preY; p.preShift = g.preMode ? g.preShift : 0;
     p.srcH = g.preMode ? g.srcH : g.H;
     p.srcW = g.preMode ? g.srcW : g.W;
     p.res = nullptr;
@@ -799,6 +802,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->bytes = esz * (static_cast<double>(g.N) * p.srcH * p.srcW * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * taps);
     plan->desc = buf;
     if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
+    if (g.preMode && g.preShift) plan->desc += " +upsample(x2)";
     if (plan->fusedAdd) {
         plan->desc += " +add";
         plan->bytes += esz * static_cast<double>(g.N) * g.OH * g.OW * g.OC; // the residual is read once

@@ -447,9 +447,7 @@ struct PadPlan : PadPlanBase {
     }
 };
 
-struct UpsamplePlan : snnhip_plan {
-    snnhip_upsample_desc d;
-    int OH = 0, OW = 0;
+struct UpsamplePlan : UpsamplePlanBase {
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "upsample: expects 1 input, got %d", nIn);
         SNNHIP_SAME_DTYPE("upsample");

@@ -1499,6 +1499,40 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);
             i += 2;
             ++fusedCount;
+        } else if (auto* up = dynamic_cast<UpsamplePlanBase*>(plans[i]);
+                   up && up->d.mode == SNNHIP_UPSAMPLE_NEAREST && up->d.scale == 2.0f && up->OH == 2 * up->d.H && up->OW == 2 * up->d.W && i + 1 < n &&
+                   !getenv("SNNHIP_NO_PAD_FUSION")) {
+            // ---- rule D with a nearest x2 UpSampling2D in front: [UpSampling2D, Pad, Conv2D] or [UpSampling2D, Conv2D] -> one convolution launch
+            auto* pd2 = dynamic_cast<PadPlanBase*>(plans[i + 1]);
+            auto* cv = dynamic_cast<ConvPlanBase*>(plans[i + (pd2 ? 2 : 1) < n ? i + (pd2 ? 2 : 1) : i]);
+            const int span = pd2 ? 3 : 2;
+            snnhip_plan* fused = nullptr;
+            if (cv && i + span <= n && !cv->depthwise && cv->g.preMode == 0 && cv->desc.rfind("conv2d_mfma", 0) == 0 && cv->g.N == up->d.N &&
+                cv->g.IC == up->d.C && (pd2 ? (pd2->d.H == up->OH && pd2->d.W == up->OW && cv->g.H == pd2->OH && cv->g.W == pd2->OW)
+                                            : (cv->g.H == up->OH && cv->g.W == up->OW))) {
+                ConvGeom g2 = cv->g;
+                g2.preMode = pd2 ? pd2->d.mode + 1 : SNNHIP_PAD_CONSTANT; // no Pad layer: an identity pad (offsets 0) in front of the upsampling
+                g2.preX = pd2 ? pd2->d.padT : 0;
+                g2.preY = pd2 ? pd2->d.padL : 0;
+                g2.preShift = 1;
+                g2.srcH = up->d.H;
+                g2.srcW = up->d.W;
+                if (make_conv2d_mfma_plan(ctx, g2, cv->w_oihw.data(), cv->epi4, &fused) != SNNHIP_OK) fused = nullptr;
+            }
+            st.kind = ChainPlan::PLAIN;
+            if (fused) {
+                chain->owned.push_back(fused);
+                st.plain = fused;
+                i += span;
+                ++fusedCount;
+            } else {
+                st.plain = plans[i];
+                i += 1;
+            }
+            memcpy(st.outDims, st.plain->outDims, sizeof(st.outDims));
+            st.desc = st.plain->desc;
+            st.flops = st.plain->flops;
+            st.bytes = st.plain->bytes;
         } else if (auto* pd = dynamic_cast<PadPlanBase*>(plans[i]); pd && c1 && !c1->depthwise && c1->g.preMode == 0 && c1->g.N == pd->d.N &&
                    c1->g.H == pd->OH && c1->g.W == pd->OW && c1->g.IC == pd->d.C && c1->desc.rfind("conv2d_mfma", 0) == 0 && !getenv("SNNHIP_NO_PAD_FUSION")) {
             // ---- rule D: Pad + Conv2D -> the convolution stages its tiles straight from the unpadded tensor ("reflect Pad,

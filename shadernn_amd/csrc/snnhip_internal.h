@@ -147,6 +147,7 @@ struct ConvGeom {
     // fused Pad layer in front of the convolution (chain rule D): H, W above are the PADDED dims the convolution sees, the input tensor is
     // srcH x srcW and padded pixel (y, x) reads source (y - preY, x - preX) resolved with preMode (SNNHIP_PAD_CONSTANT / REPLICATE / REFLECT)
     int preMode = 0, preX = 0, preY = 0, srcH = 0, srcW = 0;
+    int preShift = 0; // 1: a nearest x2 UpSampling2D sits in front of the (optional) Pad: the pad resolves against 2*srcH x 2*srcW, then y, x >>= 1
     // fused residual Add behind the convolution (chain rule E): y = addAct(conv(x) + residual); -1 = none
     int addAct = -1;
     float addLeaky = 0.0f;
@@ -181,6 +182,10 @@ struct ConvPlanBase : snnhip_plan {
 struct EltwisePlanBase : snnhip_plan {
     snnhip_eltwise_desc d;
     int mode = 0; // 0 add, 1 activation, 2 batch-norm
+};
+struct UpsamplePlanBase : snnhip_plan {
+    snnhip_upsample_desc d;
+    int OH = 0, OW = 0;
 };
 struct PadPlanBase : snnhip_plan {
     snnhip_pad_desc d;

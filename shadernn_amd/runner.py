@@ -144,35 +144,56 @@ class GraphRunner:
         self.out_shape = shapes[net["layers"][-1]["name"]]
 
     def _fuse_pads(self, prods):
+        """[UpSampling2D(nearest x2) ->] [Pad ->] Conv2D: the convolution stages its tiles straight from the tensor in front of the pad /
+        upsampling (chain rule D); the folded layers need a single consumer each."""
         consumers = {}
         for layer, ins in prods:
             for i in ins:
                 consumers.setdefault(i, []).append(layer["name"])
-        outputs = set(getattr(self, "output_names", []))
+        outputs = set(self.output_names)
+        name_of = {id(t): nm for nm, t in self.tensors.items()}
         by_name = {l["name"]: k for k, (_, _, _, l) in enumerate(self.steps)}
         drop = set()
+
+        def foldable(nm, types):
+            if nm not in by_name or nm in outputs or len(consumers.get(nm, [])) != 1:
+                return None
+            st = self.steps[by_name[nm]]
+            return st if st[3]["type"] in types else None
+
         for k, (plan, ins, out, layer) in enumerate(self.steps):
             if layer["type"] != "Conv2D":
                 continue
-            src = [nm for nm, t in self.tensors.items() if t is ins[0]]
-            if not src or src[0] not in by_name:
-                continue
-            pk = by_name[src[0]]
-            pplan, pins, _, player = self.steps[pk]
-            if player["type"] != "Pad" or len(consumers.get(player["name"], [])) != 1 or player["name"] in outputs:
-                continue
-            try:
-                chain = capi.chain_plan(self.ctx, [pplan, plan])
-            except capi.SnnHipError as e:
-                if e.code != capi.E_UNSUPPORTED:
-                    raise
-                continue
-            if chain.num_steps() != 1:  # the conv kernel could not take the pad: keep the two launches
-                chain.destroy()
-                continue
-            self.steps[k] = (chain, pins, out, layer)
-            drop.add(pk)
-            self.fused_pads.append(player["name"])
+            chain_plans, first_ins, folded = [plan], ins, []
+            src = name_of.get(id(ins[0]))
+            st = foldable(src, ("Pad",))
+            if st:
+                chain_plans.insert(0, st[0])
+                first_ins, folded = st[1], [st[3]["name"]]
+                src = name_of.get(id(st[1][0]))
+            st = foldable(src, ("UpSampling2D",))
+            if st and st[3]["interpolation"] == "nearest" and float(st[3]["scaleFactor"]) == 2.0:
+                chain_plans.insert(0, st[0])
+                first_ins, folded = st[1], folded + [st[3]["name"]]
+            while len(chain_plans) > 1:
+                try:
+                    chain = capi.chain_plan(self.ctx, chain_plans)
+                except capi.SnnHipError as e:
+                    if e.code != capi.E_UNSUPPORTED:
+                        raise
+                    chain = None
+                if chain is not None and chain.num_steps() == 1:
+                    self.steps[k] = (chain, first_ins, out, layer)
+                    drop.update(by_name[nm] for nm in folded)
+                    self.fused_pads += folded
+                    break
+                if chain is not None:
+                    chain.destroy()
+                if len(chain_plans) == 3:  # the upsampling could not be folded: retry with the pad alone
+                    chain_plans, folded = chain_plans[1:], folded[:1]
+                    first_ins = self.steps[by_name[folded[0]]][1]
+                else:
+                    break
         self.steps = [st for k, st in enumerate(self.steps) if k not in drop]
 
     def _fuse_adds(self, prods):

@@ -201,3 +201,31 @@ def test_conv_add_chain_fusion(ctx, monkeypatch, n, h, w, ic, oc, k, s, act, add
         want = O.add_act(O.conv2d(x, wt, b, s, pads, "constant", act, 0.0, bn), skip, add_act, 0.2)
     np.testing.assert_allclose(y, want, err_msg=fused.describe(), **tol)
     np.testing.assert_allclose(y, two, rtol=1e-6 if dtype == "f32" else 2e-3, atol=1e-6 if dtype == "f32" else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("with_pad", [True, False])
+def test_upsample_pad_conv_chain_fusion(ctx, with_pad, dtype):
+    """Rule D with a nearest x2 UpSampling2D in front: [UpSampling2D, Pad(reflect), Conv2D] (Candy's decoder) as one convolution launch."""
+    import shadernn_amd as snn
+
+    dt = snn.F16 if dtype == "f16" else snn.F32
+    n, h, w, ic, oc = 1, 17, 23, 64, 32
+    x, wt, b = _rand((n, h, w, ic), 1), _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9)), _rand((oc,), 3, 0.1)
+    up = snn.upsample_plan(ctx, n, h, w, ic, 2.0, "nearest")
+    plans, ph, pw = [up], 2 * h, 2 * w
+    if with_pad:
+        plans.append(snn.pad_plan(ctx, n, ph, pw, ic, (1, 1, 1, 1), "reflect"))
+        ph, pw = ph + 2, pw + 2
+    cp = O.padding_offsets("valid" if with_pad else "same", 3)
+    plans.append(snn.conv2d_plan(ctx, n, ph, pw, wt, b, stride=1, pads=cp, act="relu", dtype=dt))
+    chain = snn.chain_plan(ctx, plans)
+    assert chain.num_steps() == 1 and "+upsample(x2)" in chain.describe(), chain.describe()
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=dt)
+    y = chain(xt).numpy()
+    q = O._h if dtype == "f16" else (lambda a: a)
+    t = O.upsample(q(x), 2.0, "nearest")
+    if with_pad:
+        t = O.pad(t, (1, 1, 1, 1), "reflect")
+    want = q(O.conv2d(t, q(wt), b, 1, cp, "constant", "relu", 0.0, None))
+    np.testing.assert_allclose(y, want, err_msg=chain.describe(), **(dict(rtol=2e-3, atol=2e-3) if dtype == "f16" else TOL))

@@ -686,6 +686,8 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
             }
         }
     }
+    if (const char* e = getenv("SNNHIP_CONV_BN")) // experiments: force the block's output-channel width
+        if (atoi(e) == 32 || atoi(e) == 64 || atoi(e) == 128) BN = atoi(e);
     p.OCp = round_up(g.OC, BN);
     // split-K: deep-K layers with few output tiles (ResNet 14x14 / 7x7 stages at batch 32, MobileNetV2's last pointwise convs) leave most
     // CUs with at most one wave per SIMD; splitting the channel chunks over blockIdx.z gives every SIMD 2+ waves.  Partial sums go to a

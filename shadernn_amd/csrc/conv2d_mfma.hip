@@ -55,6 +55,7 @@ struct MfmaParams { // (declared after ActCfg: epilogue.h)
     int ldsEpi;          // fp16, OC % 8 == 0, no split-K: the output tile leaves through LDS as 16-byte channel-contiguous stores
     int preMode, preX, preY, srcH, srcW; // fused Pad layer (ConvGeom): H, W are the padded dims, the tensor is srcH x srcW (== H, W when preMode == 0)
     int preShift;                        // fused nearest x2 upsampling in front of the pad: resolve against (srcH, srcW) << 1, then >> 1
+    unsigned magicW, magicH; // ceil(2^32 / tileW), ceil(2^32 / tileH): the prologue's divisions by run-time values become one v_mul_hi each
     // fused residual Add (chain rule E): y = act2(conv_result + res), res = a tensor of the output's shape and type, set per launch
     const void* res;
     ActCfg ac2;
@@ -128,9 +129,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
         lofs[r] = -1;
         if (e < p.total) {
             const int pix = e / Q;
-            const int c = pix % p.tileW;
-            const int t2 = pix / p.tileW;
-            const int rr = t2 % p.tileH, b = t2 / p.tileH;
+            // exact for pix < 2^16 and divisors < 2^16 (pix <= 9 * 256); a divisor of 1 has no 32-bit magic number
+            const int t2 = p.tileW == 1 ? pix : static_cast<int>(__umulhi(static_cast<unsigned>(pix), p.magicW));
+            const int c = pix - t2 * p.tileW;
+            const int b = p.tileH == 1 ? t2 : static_cast<int>(__umulhi(static_cast<unsigned>(t2), p.magicH));
+            const int rr = t2 - b * p.tileH;
             int sy = resolve_coord(iy0 + rr, p.H, p.padMode);
             int sx = resolve_coord(ix0 + c, p.W, p.padMode);
             if (p.preMode && sy >= 0 && sx >= 0) { // a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied
@@ -659,6 +662,8 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.TBs = shapes[best][0]; p.THs = shapes[best][1]; p.TWs = shapes[best][2];
     const int TB = 1 << p.TBs, TH = 1 << p.THs, TW = 1 << p.TWs;
     const TileLayout L = layout(p.TBs, p.THs, p.TWs);
+    p.magicW = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(L.tileW) - 1) / static_cast<unsigned>(L.tileW));
+    p.magicH = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(L.tileH) - 1) / static_cast<unsigned>(L.tileH));
     p.tileH = L.tileH; p.tileW = L.tileW; p.rowPitch = L.rowPitch; p.imgPitch = L.imgPitch; p.evenCols = L.evenCols;
     p.tilesX = up_div(g.OW, TW);
     p.tilesY = up_div(g.OH, TH);

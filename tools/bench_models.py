@@ -24,8 +24,11 @@ def main():
     ap.add_argument("--model", default=None)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--tune", action="store_true", help="SNNHIP_CONV_TUNE=1: time a few (block width, split-K) candidates per convolution at plan creation")
     ap.add_argument("--fp16", action="store_true", help="half tensors + fp16 MFMA convolutions (graphs without depthwise / dense / pooling layers)")
     args = ap.parse_args()
+    if args.tune:
+        os.environ["SNNHIP_CONV_TUNE"] = "1"
     import shadernn_amd as snn
     from shadernn_amd import models
 

@@ -690,7 +690,10 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
         const double mtiles = static_cast<double>(p.tilesX) * p.tilesY * up_div(g.N, TB);
         double bestT = 0;
         const int cands[3] = {128, 64, 32};
-        const double penalty[3] = {1.0, 1.08, 1.25};
+        // fp16: the autotuner (SNNHIP_CONV_TUNE) picks the 64-wide kernel on most layers, even the deepest U-Net ones -- its 2x1 register block
+        // leaves room for 3-4 resident blocks per CU where the 2x2 block of the 128-wide kernel (234 VGPRs) allows two
+        const double penaltyF32[3] = {1.0, 1.08, 1.25}, penaltyF16[3] = {1.15, 1.0, 1.2};
+        const double* penalty = f16 ? penaltyF16 : penaltyF32;
         for (int c = 0; c < 3; ++c) {
             const double blocks = mtiles * (round_up(g.OC, cands[c]) / cands[c]);
             const double t = std::ceil(blocks / cus) * cands[c] * penalty[c];
@@ -884,11 +887,15 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
             const snnhip_tensor* ins[2] = {&tx, &tr};
             const int nIn = g.addAct >= 0 ? 2 : 1;
             bool ok = cand->run(ins, nIn, &ty) == SNNHIP_OK; // warm-up
-            (void) hipEventRecord(e0, ctx->stream);
-            for (int r = 0; r < 5 && ok; ++r) ok = cand->run(ins, nIn, &ty) == SNNHIP_OK;
-            (void) hipEventRecord(e1, ctx->stream);
             float ms = 0.0f;
-            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ok = false;
+            for (int round = 0; round < 2 && ok; ++round) { // the better of two 5-launch timings: clocks wander on a busy box
+                (void) hipEventRecord(e0, ctx->stream);
+                for (int r = 0; r < 5 && ok; ++r) ok = cand->run(ins, nIn, &ty) == SNNHIP_OK;
+                (void) hipEventRecord(e1, ctx->stream);
+                float t = 0.0f;
+                if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) ok = false;
+                if (round == 0 || t < ms) ms = t;
+            }
             delete cand;
             if (ok && (bestMs < 0.0f || ms < bestMs)) {
                 bestMs = ms;

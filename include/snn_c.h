@@ -27,6 +27,9 @@ int snn_model_create(const char* json_path, int device, int in_w, int in_h, int 
  * dense) abort the run like an unsupported layer does in the reference. */
 int snn_model_create2(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
                       int prefer_half, snn_model** out);
+/* as snn_model_create2, plus capture_graph: record the first run's launches as a hipGraph and replay it afterwards (ignored with dumps / profiling) */
+int snn_model_create3(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
+                      int prefer_half, int capture_graph, snn_model** out);
 int snn_model_destroy(snn_model* m);
 int snn_model_upload_input(snn_model* m, const float* nhwc);      /* H x W x C floats */
 int snn_model_run(snn_model* m);                                   /* MixedInferenceCore::run (enqueue + one sync) */

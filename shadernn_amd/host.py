@@ -14,6 +14,7 @@ _FP = C.POINTER(C.c_float)
 SIGNATURES = {
     "snn_model_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "snn_model_create2": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "snn_model_create3": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "snn_model_destroy": (C.c_int, [_P]),
     "snn_model_upload_input": (C.c_int, [_P, _FP]),
     "snn_model_run": (C.c_int, [_P]),
@@ -92,10 +93,10 @@ def yolo_decode(head_coarse, head_fine, net_size=416, max_rows=100):
 class Model:
     """MixedInferenceCore::create(context, jsonFile, options) + run(), one W x H x C input image."""
 
-    def __init__(self, json_path, w, h, c, device=0, dump_outputs=False, fuse_chains=True, profiling=False, prefer_half=False):
+    def __init__(self, json_path, w, h, c, device=0, dump_outputs=False, fuse_chains=True, profiling=False, prefer_half=False, capture_graph=False):
         self.h = _P()
-        assert lib().snn_model_create2(json_path.encode(), device, w, h, c, int(dump_outputs), int(fuse_chains), int(profiling), int(prefer_half),
-                                       C.byref(self.h)) == 0
+        assert lib().snn_model_create3(json_path.encode(), device, w, h, c, int(dump_outputs), int(fuse_chains), int(profiling), int(prefer_half),
+                                       int(capture_graph), C.byref(self.h)) == 0
         self.in_shape = (h, w, c)
 
     def upload(self, x):

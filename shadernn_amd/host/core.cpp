@@ -92,6 +92,9 @@ bool MixedInferenceCore::init(const CreationParameters& cp_) {
         if (cp.profiling) stage.timer.reset(backend->createDeviceTimer(layer.name));
     }
     backend->finalizeStages(stages, cp.dumpOutputs, cp.fuseChains);
+    graphUsable = cp.captureGraph && !cp.dumpOutputs && !cp.profiling;
+    for (auto& s : stages)
+        if (!s.layer->isInputLayer && s.backend != Backend::Backend_GPU) graphUsable = false;
     return true;
 }
 
@@ -104,7 +107,18 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
     backend->prepareRun(rp, stages, bindOutput, static_cast<uint32_t>(stages.size() - 1));
     cpuRunTime.start();
     if (gpuRunTime) gpuRunTime->start();
-    for (size_t i = 0; i < stages.size(); i++) {
+    bool replayed = false, recordingNow = false;
+    if (graphUsable) {
+        std::vector<const void*> ins;
+        for (size_t k = 0; k < rp.inputImages->size(); ++k) ins.push_back((*rp.inputImages)[k].tensor());
+        if (ins == recordedInputs && backend->replay()) {
+            replayed = true; // same input textures as when the launch sequence was recorded: one host call
+        } else {
+            recordedInputs = ins;
+            recordingNow = backend->beginRecord();
+        }
+    }
+    for (size_t i = 0; i < stages.size() && !replayed; i++) {
         auto& s = stages[i];
         if (s.layer->isInputLayer) continue;
         for (size_t n = 0; n < s.delayBindMask.size(); ++n) {
@@ -119,6 +133,9 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
             s.layer->imageTextureFunPtr(s.stageInputs, s.stageOutputs);
         }
         if (s.timer) s.timer->stop();
+    }
+    if (recordingNow) { // the loop above only recorded: submit it now
+        if (!backend->endRecord() || !backend->replay()) SNN_RIP("hipGraph capture of the inference failed: %s", snnhip_last_error());
     }
     if (gpuRunTime) gpuRunTime->stop();
     backend->sync(); // the only GPU wait of an inference (core.cpp:203)

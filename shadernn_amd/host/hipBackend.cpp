@@ -47,6 +47,7 @@ HipBackend::HipBackend(GpuContext* context) {
 }
 
 HipBackend::~HipBackend() {
+    dropRecording();
     for (auto* p : chainPlans) snnhip_plan_destroy(p);
     replacedPasses.clear();
 }
@@ -81,6 +82,25 @@ void HipBackend::initRenderPasses(GenericModelLayer* layer, ImageTextureArrayAcc
 bool HipBackend::sync() {
     hipChk(snnhip_sync(ctx), "snnhip_sync");
     return true;
+}
+
+bool HipBackend::beginRecord() {
+    dropRecording();
+    return snnhip_graph_begin_capture(ctx) == SNNHIP_OK;
+}
+
+bool HipBackend::endRecord() {
+    snnhip_graph* g = nullptr;
+    if (snnhip_graph_end_capture(ctx, &g) != SNNHIP_OK) return false;
+    recording = g;
+    return true;
+}
+
+bool HipBackend::replay() { return recording && snnhip_graph_launch(static_cast<snnhip_graph*>(recording)) == SNNHIP_OK; }
+
+void HipBackend::dropRecording() {
+    if (recording) snnhip_graph_destroy(static_cast<snnhip_graph*>(recording));
+    recording = nullptr;
 }
 
 DeviceTimer* HipBackend::createDeviceTimer(const std::string& name) { return new HipDeviceTimer(ctx, name); }

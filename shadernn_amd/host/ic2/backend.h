@@ -58,6 +58,12 @@ public:
     virtual bool isProfilingEnabled(bool = false) { return true; }
     // HIP extension, called once after every stage is initialised: may replace linear runs of passes by fused plans
     virtual void finalizeStages(RenderStagesArray&, bool /*dumpOutputs*/, bool /*fuseChains*/) {}
+    // HIP extension: record the launches of one inference once and replay them (the counterpart of the Vulkan backend recording a command
+    // buffer, vulkanBackend.cpp:80-95).  beginRecord returns false when the backend cannot record; replay re-submits the last recording.
+    virtual bool beginRecord() { return false; }
+    virtual bool endRecord() { return false; }
+    virtual bool replay() { return false; }
+    virtual void dropRecording() {}
 };
 
 class HipRenderPass : public RenderPass {
@@ -84,10 +90,15 @@ public:
     bool sync() override; // hipStreamSynchronize == QueueSubmitAndWait (vulkanBackend.cpp:97-106)
     DeviceTimer* createDeviceTimer(const std::string& name) override;
     void finalizeStages(RenderStagesArray& stages, bool dumpOutputs, bool fuseChains) override;
+    bool beginRecord() override;
+    bool endRecord() override;
+    bool replay() override;
+    void dropRecording() override;
 
 private:
     snnhip_ctx* ctx;
     std::vector<snnhip_plan*> chainPlans; // owned
+    void* recording = nullptr;            // snnhip_graph* of the last recorded inference
     std::vector<std::shared_ptr<RenderPass>> replacedPasses; // their plans may still be referenced by a chain (unfused steps)
 public:
     ~HipBackend() override;

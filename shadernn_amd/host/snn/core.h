@@ -48,6 +48,9 @@ public:
         bool dumpOutputs = false;
         bool fuseChains = true;
         bool profiling = false; // the reference enables per-stage timers at compile time (-DPROFILING, CMakeLists.txt:44-46)
+        // HIP extension: record the launch sequence of the first run() as a hipGraph and replay it while the caller keeps feeding the same input
+        // textures (re-recorded when they change).  Ignored with dumpOutputs / profiling / CPU stages (those need the host between launches).
+        bool captureGraph = false;
     };
     static std::unique_ptr<MixedInferenceCore> create(GpuContext* context, const CreationParameters& cp);
     static std::unique_ptr<MixedInferenceCore> create(GpuContext* context, const std::string& modelFileName, const dp::ShaderGenOptions& options,
@@ -64,6 +67,8 @@ private:
     RenderStagesArray stages;
     dp::DeviceBackend* backend = nullptr;
     DeviceTimer* gpuRunTime = nullptr;
+    std::vector<const void*> recordedInputs; // device tensors the recording reads (delay-bound model inputs)
+    bool graphUsable = false;
     Timer cpuRunTime = Timer("IC2 Total CPU Runtime");
     explicit MixedInferenceCore(GpuContext* context_);
     bool init(const CreationParameters& cp);

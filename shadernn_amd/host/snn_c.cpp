@@ -50,6 +50,11 @@ int snn_model_create(const char* json_path, int device, int in_w, int in_h, int 
 
 int snn_model_create2(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
                       int prefer_half, snn_model** out) {
+    return snn_model_create3(json_path, device, in_w, in_h, in_c, dump_outputs, fuse_chains, profiling, prefer_half, 0, out);
+}
+
+int snn_model_create3(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
+                      int prefer_half, int capture_graph, snn_model** out) {
     const bool half = prefer_half != 0;
     auto* m = new snn_model();
     m->context = createHipContext(device);
@@ -63,6 +68,7 @@ int snn_model_create2(const char* json_path, int device, int in_w, int in_h, int
     cp.dumpOutputs = dump_outputs != 0;
     cp.fuseChains = fuse_chains != 0;
     cp.profiling = profiling != 0;
+    cp.captureGraph = capture_graph != 0;
     m->core = MixedInferenceCore::create(m->context, cp);
     makeIO(m, half);
     m->half = half;

@@ -395,3 +395,35 @@ def test_style_net_with_chain_fusion_through_host(ctx, tmp_path, half):
     else:
         np.testing.assert_allclose(y.reshape(-1), O.forward(net, x).reshape(-1), **TOL)
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1, 2], ids=["resnet18", "mobilenetv2", "style_net"])
+def test_host_graph_capture_replays_with_new_inputs(ctx, tmp_path, which):
+    """capture_graph: the first run() records the launch sequence as a hipGraph, later runs replay it -- new input data (same texture) must flow through,
+    and a replaced input texture (upload_u8 path) must trigger a re-recording."""
+    import time
+
+    from shadernn_amd import host
+
+    net, w, h = _small_nets()[which]
+    path = _json(tmp_path, net, w, h)
+    m = host.Model(path, w, h, 3, capture_graph=True)
+    ref = host.Model(path, w, h, 3)
+    for seed in (21, 22, 23):
+        x = np.random.default_rng(seed).random((1, h, w, 3), dtype=np.float32)
+        y = m(x)
+        np.testing.assert_allclose(y.reshape(-1), O.forward(net, x).reshape(-1), **TOL)
+        np.testing.assert_array_equal(y, ref(x))
+    # host-side cost of one run(): replay = one launch call instead of one per layer
+    for mm in (m, ref):
+        mm.run()
+    t = []
+    for mm in (m, ref):
+        t0 = time.perf_counter()
+        for _ in range(20):
+            mm.run()
+        t.append((time.perf_counter() - t0) / 20)
+    print("run(): graph replay %.1f us, per-layer launches %.1f us" % (t[0] * 1e6, t[1] * 1e6))
+    m.close()
+    ref.close()

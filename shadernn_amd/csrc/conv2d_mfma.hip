@@ -196,6 +196,35 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
+    // one K step: fp16 = one v_mfma_f32_32x32x16_f16 per (t, u) register tile (16 channels: both lane halves' 8 halfs); fp32 = four
+    // v_mfma_f32_32x32x2_f32, one per component of the 16-byte operands (8 channels)
+    auto k_step = [&](const float4 (&a)[MT], const float4 (&b)[NT]) {
+        if (F16) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
+        }
+    };
+
     int tapDelta[TAPS > 0 ? TAPS : 1]; // LDS pixel delta of each tap (static tap count only)
     if constexpr (TAPS > 0) {
 #pragma unroll
@@ -247,11 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 #pragma unroll
                     for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const float4*>(cur + lds_off<C8>(apix[t] + dl, slot));
                 }
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-#pragma unroll
-                    for (int u = 0; u < NT; ++u)
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
+                k_step(a, b);
             }
             if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats);
             __syncthreads();
@@ -288,30 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                 if (ptap >= taps) pfx = prow = 0;
 #pragma unroll
                 for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const float4*>(cur + lds_off<0>(apix[t] + tap_delta(pfx, prow), 0));
-                if (F16) {
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u)
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
-                }
+                k_step(a, b);
             }
             if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats);
             __syncthreads();
@@ -352,30 +354,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 #pragma unroll
                     for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const float4*>(cur + lds_off<C8>(apix[t] + dl, slot));
                 }
-                if (F16) {
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u)
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
-                }
+                k_step(a, b);
             }
             fx = fxn;
             rowoff = rown;
@@ -681,7 +660,6 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     p.bufFloats = TB * L.imgPitch * Qs * 4;
     const int rNeed = up_div(p.total, 256);
     const int R = (rNeed <= 3 && C8 <= 2) ? 3 : ((rNeed <= 5 && C8 <= 4) ? 5 : 9);
-    const size_t ldsBytes = L.ldsBytes;
 
     // block N: minimise (rounds of blocks over the CUs) x (work per block); narrower blocks re-stage A more often
     int BN = 128;

@@ -40,6 +40,8 @@ def _layer_plan(ctx, layer, shape, dtype=capi.F32):
         return capi.upsample_plan(ctx, n, h, w, c, layer["scaleFactor"], layer["interpolation"])
     if t == "Concatenate":
         return capi.concat_plan(ctx, n, h, w, layer["c0"], layer["c1"], layer.get("oc"))
+    if t == "Calculate":
+        return capi.calculate_plan(ctx, n, h, w, c, layer["oc"])
     if t == "Unary":
         return capi.unary_plan(ctx, n, h, w, c, layer.get("op", "copy"), layer.get("value", 1.0))
     if t == "Conv2DTranspose":

@@ -457,6 +457,8 @@ def forward(net, x, threads=1, return_layers=False, return_named=False, fp16=Fal
             x = concat(ins[0], ins[1], l.get("oc"))
         elif t == "Unary":
             x = unary(x, l.get("op", "copy"), l.get("value", 1.0))
+        elif t == "Calculate":
+            x = calculate(x, l["oc"])
         elif t == "Conv2DTranspose":
             x = deconv2d(x, l["w"], l["b"], l["stride"], l["padding"] == "same", plain(l["activation"]), l.get("alpha", 0.0), l["bn"])
         else:

@@ -427,3 +427,24 @@ def test_host_graph_capture_replays_with_new_inputs(ctx, tmp_path, which):
     print("run(): graph replay %.1f us, per-layer launches %.1f us" % (t[0] * 1e6, t[1] * 1e6))
     m.close()
     ref.close()
+
+
+@pytest.mark.gpu
+def test_calculate_layer_json_end_to_end(ctx, tmp_path):
+    """The moonwellbox "Calculate" layer (fs_calculation.glsl: rgb / illumination) through JSON -> host mirror -> HIP, and through GraphRunner."""
+    import shadernn_amd as snn
+    from shadernn_amd import host, models
+
+    rng = np.random.default_rng(31)
+    conv = models._conv(rng, "feat", 3, 12, 3, "sigmoid")  # strictly positive: the divisor is channel 8
+    calc = models._op("Calculate", "calc", 12)
+    calc["oc"] = 4
+    net = {"name": "calc_net", "input_channels": 3, "layers": [conv, calc]}
+    x = rng.random((1, 20, 28, 3), dtype=np.float32)
+    want = O.forward(net, x)
+    assert want.shape == (1, 20, 28, 4) and np.all(want[..., 3] == 0)
+    m = host.Model(_json(tmp_path, net, 28, 20), 28, 20, 3)
+    np.testing.assert_allclose(m(x).reshape(-1), want.reshape(-1), rtol=1e-4, atol=1e-4)
+    m.close()
+    r = snn.GraphRunner(ctx, net, 1, 20, 28)
+    np.testing.assert_allclose(r(x).reshape(-1), want.reshape(-1), rtol=1e-4, atol=1e-4)

@@ -504,6 +504,7 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
 struct FusedBParams {
     int N, H, W, tilesX, tilesY;
     ActCfg act;
+    unsigned magicX, magicY; // ceil(2^32 / tilesX), ceil(2^32 / tilesY): tile decode without integer division (exact for block ids < 2^16 * ...)
 };
 
 // conv 3x3 (16 -> 4, zero padding 1) + act, then depth-to-space(2) + tanh.  One thread = one input-resolution pixel
@@ -512,36 +513,54 @@ struct FusedBParams {
 template <int TW, int TH, bool SIMPLE>
 __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ w,
                                                                      const float* __restrict__ ep, float* __restrict__ y) {
-    constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 16; // 64 B per pixel; the 16-byte slot is XOR-swizzled with (pixel>>2)&3
+    // LDS tile as four channel-quad PLANES, s_x[q][pixel] float4: a wave's 64 pixels (2 rows x 32) read 512 contiguous bytes per row from one
+    // plane -- conflict-free without a swizzle -- and every operand address of the tap loop is ONE per-thread base + a wave-uniform tap offset + a
+    // compile-time plane offset.  (The kernel is VALU-issue bound: rocprofv3 counted 708 VALU instructions per wave of which 288 are the
+    // packed FMAs; the previous [pixel][quad ^ swizzle] layout spent 21 VALU instructions per tap on addresses, this one 2.)
+    constexpr int TWH = TW + 2, THH = TH + 2, PLANE = THH * TWH * 4; // floats per plane
     static_assert(TW * TH == 256, "one thread per pixel");
-    __shared__ __attribute__((aligned(16))) float s_x[THH * TWH * PITCH];
+    __shared__ __attribute__((aligned(16))) float s_x[4 * PLANE];
 
     const int tid = threadIdx.x;
-    int b = xcd_tile_order(blockIdx.x, gridDim.x);
-    const int tx = b % p.tilesX;
-    b /= p.tilesX;
-    const int ty = b % p.tilesY;
-    const int n = b / p.tilesY;
+    // tile decode on the scalar unit: the divisions by tilesX / tilesY are mul-hi by host-computed magic numbers (a run-time integer division of
+    // a uniform value still compiles to ~20 VALU instructions of float reciprocal arithmetic, and this kernel is VALU-issue bound)
+    const unsigned bid = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(xcd_tile_order(blockIdx.x, gridDim.x)));
+    const unsigned bq = p.tilesX == 1 ? bid : __umulhi(bid, p.magicX);
+    const int tx = static_cast<int>(bid - bq * p.tilesX);
+    const unsigned n_u = p.tilesY == 1 ? bq : __umulhi(bq, p.magicY);
+    const int ty = static_cast<int>(bq - n_u * p.tilesY), n = static_cast<int>(n_u);
     const int x0 = tx * TW, y0 = ty * TH;
     const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
 
     {
         constexpr int NLD = (THH * TWH * 4 + 255) / 256;
         float4 v[NLD];
+        const bool interior = x0 >= 1 && y0 >= 1 && x0 + TW + 1 <= p.W && y0 + TH + 1 <= p.H; // block-uniform: 95 % of the tiles at 1080p
+        if (interior) { // no bounds tests, no zero fill: 32-bit element offsets from the tile's first halo pixel
+            const float* t0 = xn + (static_cast<size_t>(y0 - 1) * p.W + (x0 - 1)) * 16;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) { // every load of the halo tile is in flight before the first LDS write
-            const int idx = tid + k * 256;
-            const int q = idx & 3, pix = idx >> 2;
-            const int r = pix / TWH, c = pix - r * TWH;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (idx < THH * TWH * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                v[k] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + k * 256;
+                const int q = idx & 3, pix = idx >> 2;
+                const int r = pix / TWH, c = pix - r * TWH;
+                if (idx < THH * TWH * 4) v[k] = *reinterpret_cast<const float4*>(t0 + static_cast<unsigned>((r * p.W + c) * 16 + q * 4));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) { // every load of the halo tile is in flight before the first LDS write
+                const int idx = tid + k * 256;
+                const int q = idx & 3, pix = idx >> 2;
+                const int r = pix / TWH, c = pix - r * TWH;
+                const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+                v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (idx < THH * TWH * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v[k] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
+            }
         }
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int idx = tid + k * 256;
-            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx >> 2) * PITCH + (((idx & 3) ^ ((idx >> 4) & 3)) * 4)) = v[k];
+            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx & 3) * PLANE + (idx >> 2) * 4) = v[k];
         }
     }
     __syncthreads();
@@ -552,24 +571,27 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     // float2 so that every FMA is a v_pk_fma_f32 with the weight pair in an SGPR pair.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
-    // one tap (64 uniform weights = 64 SGPRs) per iteration: unrolling further only spills SGPRs
+    const float* base = s_x + (r * TWH + c) * 4;
+    // one tap (64 uniform weights = 64 SGPRs) per iteration: unrolling further only spills SGPRs.  (Prefetching tap t+1's operand quads from
+    // LDS does not pay: LDS and scalar loads share lgkmcnt, so the wait for the next weights also waits for the prefetch.)
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        const int fy = tap / 3, fx = tap - fy * 3;
-        const int pixIdx = (r + fy) * TWH + c + fx;
-        const float* src = s_x + pixIdx * PITCH;
-        const int sw = (pixIdx >> 2) & 3; // conflict-free ds_read_b128 for 64 consecutive pixels at a 64-byte pitch
+    for (int fy = 0; fy < 3; ++fy) {
+#pragma unroll 1
+        for (int fx = 0; fx < 3; ++fx) {
+            const int tap = fy * 3 + fx;
+            const float* src = base + (fy * TWH + fx) * 4; // wave-uniform offset
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 xv = *reinterpret_cast<const float4*>(src + ((q ^ sw) * 4));
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            for (int q = 0; q < 4; ++q) {
+                const float4 xv = *reinterpret_cast<const float4*>(src + q * PLANE); // compile-time plane offset -> ds_read_b128 offset:
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float* wr = w + (tap * 16 + q * 4 + i) * 4; // uniform address -> s_load
-                const f32x2 xx = {xs[i], xs[i]};
-                const f32x2 w01 = {wr[0], wr[1]}, w23 = {wr[2], wr[3]};
-                acc01 = __builtin_elementwise_fma(xx, w01, acc01);
-                acc23 = __builtin_elementwise_fma(xx, w23, acc23);
+                for (int i = 0; i < 4; ++i) {
+                    const float* wr = w + (tap * 16 + q * 4 + i) * 4; // uniform address -> s_load
+                    const f32x2 xx = {xs[i], xs[i]};
+                    const f32x2 w01 = {wr[0], wr[1]}, w23 = {wr[2], wr[3]};
+                    acc01 = __builtin_elementwise_fma(xx, w01, acc01);
+                    acc23 = __builtin_elementwise_fma(xx, w23, acc23);
+                }
             }
         }
     }
@@ -1458,7 +1480,9 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.rows2 = bmode && strcmp(bmode, "rows2") == 0;
             if (bmode && strncmp(bmode, "prefetch", 8) == 0) st.prefetch = bmode[8] ? atoi(bmode + 8) : 6;
             const int bTW = st.wino ? 64 : B_TW, bTH = st.wino ? 16 : (st.rows2 ? 2 * B_TH : B_TH);
-            st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, bTW), up_div(g0.H, bTH), make_act_cfg(g0.act, g0.leaky)};
+            st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, bTW), up_div(g0.H, bTH), make_act_cfg(g0.act, g0.leaky), 0u, 0u};
+            st.b.magicX = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(st.b.tilesX) - 1) / static_cast<unsigned>(st.b.tilesX));
+            st.b.magicY = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(st.b.tilesY) - 1) / static_cast<unsigned>(st.b.tilesY));
             std::vector<float> wB(9 * 16 * 4);
             for (int tap = 0; tap < 9; ++tap)
                 for (int ic = 0; ic < 16; ++ic)

@@ -61,9 +61,12 @@ __device__ __forceinline__ float apply_act(const ActCfg& a, float v, float first
 
 // tanh as 1 - 2/(e^{2x}+1) on the hardware exp/rcp units: branch-free (ocml's tanhf is a multi-range, branchy
 // routine that serialises the epilogue).  Absolute error <= 3e-7 over the whole range, saturates to +-1 correctly.
+// Five instructions (v_mul, v_exp, v_add, v_rcp, v_fma): __fdividef compiles to the full IEEE division sequence (div_scale / div_fmas /
+// div_fixup, ~12 instructions per quotient) on this toolchain, which made the four tanh of the ESPCN tail a quarter of that kernel's
+// non-FMA instructions; v_rcp_f32 is accurate to 1 ulp, far inside the 3e-7 bound.
 __device__ __forceinline__ float fast_tanh(float x) {
-    const float t = __expf(2.0f * x);
-    return 1.0f - __fdividef(2.0f, t + 1.0f);
+    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f); // e^{2x} = 2^{2x log2(e)}
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
 }
 
 // Element access: every kernel is instantiated for T = float and T = _Float16 (SNNHIP_F16 tensors: half storage, fp32 arithmetic,

@@ -533,19 +533,23 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
 
     {
-        constexpr int NLD = (THH * TWH * 4 + 255) / 256;
-        float4 v[NLD];
         const bool interior = x0 >= 1 && y0 >= 1 && x0 + TW + 1 <= p.W && y0 + TH + 1 <= p.H; // block-uniform: 95 % of the tiles at 1080p
-        if (interior) { // no bounds tests, no zero fill: 32-bit element offsets from the tile's first halo pixel
-            const float* t0 = xn + (static_cast<size_t>(y0 - 1) * p.W + (x0 - 1)) * 16;
+        if (interior) {
+            // no bounds tests, no zero fill, no index arithmetic: thread t < 4*TWH owns float4 t of EVERY halo row (a row of the tile is 4*TWH
+            // contiguous float4 in memory), so its THH loads are one pointer walked by the image pitch and its THH LDS stores one offset walked by
+            // the tile pitch.  The other threads (the fourth wave entirely) skip the staging: fewer instructions issued in total is what counts.
+            if (tid < 4 * TWH) {
+                const float* src = xn + (static_cast<size_t>(y0 - 1) * p.W + (x0 - 1)) * 16 + tid * 4;
+                float4 rowv[THH];
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int idx = tid + k * 256;
-                const int q = idx & 3, pix = idx >> 2;
-                const int r = pix / TWH, c = pix - r * TWH;
-                if (idx < THH * TWH * 4) v[k] = *reinterpret_cast<const float4*>(t0 + static_cast<unsigned>((r * p.W + c) * 16 + q * 4));
+                for (int rr = 0; rr < THH; ++rr) rowv[rr] = *reinterpret_cast<const float4*>(src + static_cast<size_t>(rr) * p.W * 16);
+                float* dst = s_x + (tid & 3) * PLANE + (tid >> 2) * 4;
+#pragma unroll
+                for (int rr = 0; rr < THH; ++rr) *reinterpret_cast<float4*>(dst + rr * TWH * 4) = rowv[rr];
             }
         } else {
+            constexpr int NLD = (THH * TWH * 4 + 255) / 256;
+            float4 v[NLD];
 #pragma unroll
             for (int k = 0; k < NLD; ++k) { // every load of the halo tile is in flight before the first LDS write
                 const int idx = tid + k * 256;
@@ -556,11 +560,11 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
                 if (idx < THH * TWH * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
                     v[k] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
             }
-        }
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx & 3) * PLANE + (idx >> 2) * 4) = v[k];
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + k * 256;
+                if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx & 3) * PLANE + (idx >> 2) * 4) = v[k];
+            }
         }
     }
     __syncthreads();

@@ -218,17 +218,24 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     const int rNeed = up_div(p.total, 256);
     const int R = (rNeed <= 3 && C8 <= 2) ? 3 : ((rNeed <= 5 && C8 <= 4) ? 5 : 9);
 
-    // block N: minimise (rounds of blocks over the CUs) x (work per block); narrower blocks re-stage A more often
+    // Block width and split-K.  Fitted on `SNNHIP_CONV_TUNE=2` logs of the five benchmark graphs (tools/tune_report.py), fp32 and fp16:
+    //  * cost model = (rounds of blocks over the CUs) x (output channels per block) x a per-width penalty: narrower blocks re-stage the
+    //    activation tile once per block column (worse when the staging goes through a fused Pad / UpSampling address path), the fp16 128-wide
+    //    kernel's 2x2 register block (234 VGPRs) leaves two resident blocks per CU where the 64-wide one has three or four;
+    //  * fp32, few pixel tiles but a deep reduction (ResNet 14x14 / 7x7 stages, YOLO 13x13, U-Net 16x16): the 128-wide block with the channel
+    //    chunks split 4-8 ways over blockIdx.z beats narrow unsplit blocks by 10-25 % (each partial block still streams its A tile once);
+    //  (isolated-kernel timings do not transfer one to one: stricter fp16 / shallow-K split rules that won 5-15 % per layer in the tuner's
+    //  back-to-back launches lost 5 % on MobileNetV2 and YOLOv3-tiny in the graph, so the split rule below is the conservative one.)
     int BN = 128;
+    const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+    const double mtiles = static_cast<double>(p.tilesX) * p.tilesY * up_div(g.N, TB);
+    const int kdepth = g.IC * taps;
+    bool wideSplit = false;
     {
-        const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
-        const double mtiles = static_cast<double>(p.tilesX) * p.tilesY * up_div(g.N, TB);
         double bestT = 0;
         const int cands[3] = {128, 64, 32};
-        // fp16: the autotuner (SNNHIP_CONV_TUNE) picks the 64-wide kernel on most layers, even the deepest U-Net ones -- its 2x1 register block
-        // leaves room for 3-4 resident blocks per CU where the 2x2 block of the 128-wide kernel (234 VGPRs) allows two
-        const double penaltyF32[3] = {1.0, 1.08, 1.25}, penaltyF16[3] = {1.15, 1.0, 1.2};
-        const double* penalty = f16 ? penaltyF16 : penaltyF32;
+        const double penaltyF32[3] = {1.0, 1.08, 1.25}, penaltyF16[3] = {1.15, 1.0, 1.2}, penaltyF16Pre[3] = {1.0, 1.15, 1.4};
+        const double* penalty = f16 ? (g.preMode ? penaltyF16Pre : penaltyF16) : penaltyF32;
         for (int c = 0; c < 3; ++c) {
             const double blocks = mtiles * (round_up(g.OC, cands[c]) / cands[c]);
             const double t = std::ceil(blocks / cus) * cands[c] * penalty[c];
@@ -237,6 +244,10 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
                 BN = cands[c];
             }
         }
+        if (!f16 && kdepth >= 1024 && g.OC >= 128 && mtiles * up_div(g.OC, 128) < cus) { // split-K fills the chip instead of narrow blocks
+            BN = (round_up(g.OC, 128) - g.OC) * 8 > g.OC ? 64 : 128;                     // ... unless 128 pads the channels by > 12.5 %
+            wideSplit = true;
+        }
     }
     if (const char* e = getenv("SNNHIP_CONV_BN")) // experiments: force the block's output-channel width
         if (atoi(e) == 32 || atoi(e) == 64 || atoi(e) == 128) BN = atoi(e);
@@ -244,15 +255,17 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     p.OCp = round_up(g.OC, BN);
     // split-K: deep-K layers with few output tiles (ResNet 14x14 / 7x7 stages at batch 32, MobileNetV2's last pointwise convs) leave most
     // CUs with at most one wave per SIMD; splitting the channel chunks over blockIdx.z gives every SIMD 2+ waves.  Partial sums go to a
-    // workspace and a second (element-wise, deterministic) pass applies bias/BN/activation.  SNNHIP_CONV_SPLITK=n forces n (1 = off).
+    // workspace and a second (element-wise, deterministic) pass applies bias/BN/activation (and the fused residual add, which is cheaper
+    // there than in the convolution's epilogue).  SNNHIP_CONV_SPLITK=n forces n (1 = off).
     p.splitK = 1;
     {
-        const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
-        const double blocks = static_cast<double>(p.tilesX) * p.tilesY * up_div(g.N, TB) * (p.OCp / BN);
+        const double blocks = mtiles * (p.OCp / BN);
         int want = 1;
         if (blocks < 1.5 * cus && p.nChunks >= 8) want = static_cast<int>(std::ceil(2.0 * cus / blocks));
         if (want > 8) want = 8;
-        if (want > p.nChunks / 4) want = p.nChunks / 4;
+        const int cap = wideSplit ? p.nChunks / 2 : p.nChunks / 4; // the wide-block rule above relies on the split to fill the chip
+        if (want > cap) want = cap;
+        if (wideSplit) while (want & (want - 1)) want &= want - 1; // 3x3 layers: 3- / 5-way splits measured 10-25 % behind 2 / 4
         if (const char* e = getenv("SNNHIP_CONV_SPLITK")) want = atoi(e);
         if (ov.splitK) want = ov.splitK;
         if (want < 1 || g.act == SNNHIP_ACT_SILU_QUIRK) want = 1; // the quirk couples 4 adjacent pixels in the epilogue
@@ -431,6 +444,9 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
                 if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) ok = false;
                 if (round == 0 || t < ms) ms = t;
             }
+            if (atoi(tune) >= 2) // SNNHIP_CONV_TUNE=2: log every candidate (the data the heuristics above are fitted on)
+                fprintf(stderr, "[snnhip tune] N=%d %dx%d ic=%d oc=%d k=%d s=%d %s | bn=%d splitK=%d -> %s : %.1f us%s\n", g.N, g.H, g.W, g.IC, g.OC, g.kh, g.sh,
+                        g.dtype == SNNHIP_F16 ? "f16" : "f32", ov.bn, ov.splitK, cand->desc.c_str(), ok ? ms * 200.0f : -1.0f, (bi == 0 && si == 0) ? " (heuristic)" : "");
             delete cand;
             if (ok && (bestMs < 0.0f || ms < bestMs)) {
                 bestMs = ms;

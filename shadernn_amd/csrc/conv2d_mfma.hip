@@ -218,7 +218,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     const int rNeed = up_div(p.total, 256);
     const int R = (rNeed <= 3 && C8 <= 2) ? 3 : ((rNeed <= 5 && C8 <= 4) ? 5 : 9);
 
-    // Block width and split-K.  Fitted on `SNNHIP_CONV_TUNE=2` logs of the five benchmark graphs (tools/tune_report.py), fp32 and fp16:
+    // Block width and split-K.  Fitted on `SNNHIP_CONV_TUNE=2` logs of the five benchmark graphs (tools/report_tune.py), fp32 and fp16:
     //  * cost model = (rounds of blocks over the CUs) x (output channels per block) x a per-width penalty: narrower blocks re-stage the
     //    activation tile once per block column (worse when the staging goes through a fused Pad / UpSampling address path), the fp16 128-wide
     //    kernel's 2x2 register block (234 VGPRs) leaves two resident blocks per CU where the 64-wide one has three or four;

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--fp16", action="store_true", help="half tensors + fp16 MFMA convolutions (graphs without depthwise / dense / pooling layers)")
     args = ap.parse_args()
     if args.tune:
-        os.environ.setdefault("SNNHIP_CONV_TUNE", "1")  # =2 (set by the caller) also logs every candidate, see tools/tune_report.py
+        os.environ.setdefault("SNNHIP_CONV_TUNE", "1")  # =2 (set by the caller) also logs every candidate, see tools/report_tune.py
     import shadernn_amd as snn
     from shadernn_amd import models
 

@@ -36,6 +36,15 @@ int snnhip_plan::upload(const float*, size_t, float**) { return 0; }
 int snnhip_plan::profBegin(int) { return 0; }
 int snnhip_plan::profEnd(int) { return 0; }
 int snnhip_plan::profAcquire(int, hipEvent_t*, hipEvent_t*) { return 0; }
+namespace snnhip {
+int make_conv2d_mfma_plan(snnhip_ctx*, const ConvGeom&, const float*, const std::vector<float>&, snnhip_plan**) { return 0; }
+}
+static snnhip::FusedBParams mkB(int H, int W, int tw, int th) {
+    snnhip::FusedBParams p{1, H, W, (W + tw - 1) / tw, (H + th - 1) / th, snnhip::make_act_cfg(0, 0.f)};
+    p.magicX = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(p.tilesX) - 1) / static_cast<unsigned>(p.tilesX));
+    p.magicY = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(p.tilesY) - 1) / static_cast<unsigned>(p.tilesY));
+    return p;
+}
 extern "C" int snnhip_tensor_alloc(snnhip_ctx*, int, int, int, int, int, snnhip_tensor**) { return 0; }
 extern "C" int snnhip_tensor_free(snnhip_tensor*) { return 0; }
 namespace snnhip {
@@ -55,7 +64,7 @@ int espcn_stream_launch(hipStream_t, const void*, const float*, const float*, co
     } while (0)
 
 float timeBW(const float* x, const float* w, const float* e, float* y, int H, int W, int reps) {
-    FusedBParams p{1, H, W, (W + 63) / 64, (H + 15) / 16, make_act_cfg(0, 0.f)};
+    FusedBParams p = mkB(H, W, 64, 16);
     dim3 grid(512);
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
@@ -75,7 +84,7 @@ float timeBW(const float* x, const float* w, const float* e, float* y, int H, in
 template <int BTW, int BTH>
 float timeOverlap(const float* x, const float* w, float* mid, float* mid2, float* y, int H, int W, int reps, bool twoStreams) {
     FusedAParams pa{1, H, W, (W + WinoTile::TW - 1) / WinoTile::TW, (H + 15) / 16, make_act_cfg(1, 0.f), make_act_cfg(1, 0.f)};
-    FusedBParams pb{1, H, W, (W + BTW - 1) / BTW, (H + BTH - 1) / BTH, make_act_cfg(0, 0.f)};
+    FusedBParams pb = mkB(H, W, BTW, BTH);
     hipStream_t s1, s2;
     CK(hipStreamCreate(&s1));
     CK(hipStreamCreate(&s2));
@@ -102,7 +111,7 @@ float timeOverlap(const float* x, const float* w, float* mid, float* mid2, float
 }
 
 float timeBD(const float* x, const float* w, const float* e, const float* zeros, float* y, int H, int W, int reps, int blocksPerCU) {
-    FusedBParams p{1, H, W, (W + 31) / 32, (H + 7) / 8, make_act_cfg(0, 0.f)};
+    FusedBParams p = mkB(H, W, 32, 8);
     dim3 grid(256 * blocksPerCU);
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
@@ -154,7 +163,7 @@ float timeA(const float* x, const float* w1, const float* w2, const float* e1, c
 
 template <int TW, int TH>
 float timeB(const float* x, const float* w, const float* e, float* y, int H, int W, int reps) {
-    FusedBParams p{1, H, W, (W + TW - 1) / TW, (H + TH - 1) / TH, make_act_cfg(0, 0.f)};
+    FusedBParams p = mkB(H, W, TW, TH);
     dim3 grid(p.tilesX * p.tilesY);
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
@@ -197,7 +206,7 @@ int main() {
 #ifdef PHASE_TIMING
     {
 #ifdef PHASE_BW
-        FusedBParams p{1, H, W, (W + 63) / 64, (H + 15) / 16, make_act_cfg(0, 0.f)};
+        FusedBParams p = mkB(H, W, 64, 16);
         int nb = p.tilesX * p.tilesY;
         for (int rep = 0; rep < 2; ++rep) {
             hipLaunchKernelGGL((conv_kxk_c1o16_wino3x3_c16o16_kernel<5, 16, 2, 2>), dim3(512), dim3(256), 0, 0,

@@ -1,0 +1,248 @@
+// conv1x1_stream.hip -- pointwise (1x1, stride 1) fp32 convolution as a streaming GEMM on v_mfma_f32_32x32x2_f32, for the layers whose time is
+// their activation / output stream rather than their arithmetic: MobileNetV2's expand (16->96 ... 96->576) and project (96->24 ... 192->32)
+// convolutions at 112x112 .. 28x28 (BASELINE configs[3]).  Replaces shadertemplate_vk_conv2d_1x1.comp:68-210 of the reference for those
+// shapes; bias -> BN -> activation epilogue and the fused residual Add are those of conv2d_mfma_kernel (same helpers, same rounding points).
+//
+// Why a second kernel: for a 1x1 stride-1 layer the NHWC tensor IS the row-major GEMM operand (M = N*H*W pixels, K = IC contiguous), so the
+// halo-tile machinery of conv2d_mfma_kernel (LDS staging, a barrier per chunk, a prologue / epilogue per 128-pixel block) is pure overhead:
+// on 16->96 @112x112 b32 it reached 2.9 TB/s of unfused traffic, 40 % of what `tools/ubench_hbm.hip` measures for a copy.  Here
+//   * a wave owns one 32-pixel row tile; its A operands come straight from global memory in the MFMA's own layout (lane (row = l%32,
+//     h = l/32) loads the 16 bytes x[row][8c + 4h .. +3] of chunk c: the K order inside an 8-channel chunk is permuted so that four
+//     consecutive MFMAs consume the four components, exactly the packing conv2d_mfma uses), 4-8 chunks in flight per lane -- no LDS, no
+//     barrier on the activation path, and thousands of short independent waves for the memory system to overlap;
+//   * the block's weight slice [IC][32*NT oc] is staged ONCE per block in LDS in that packed order (one ds_read_b128 per chunk and MFMA column);
+//   * D: lane holds column oc = l%32 and rows 8g + 4h + k, so a store instruction writes 32 consecutive channels (128 B) of two pixels and
+//     the NT column tiles of a pixel are written back to back (a full 384-byte row for 96 channels).
+#include "epilogue.h"
+#include "snnhip_internal.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace snnhip {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct StreamParams {
+    int M;       // pixels = N*H*W
+    int IC, OC;
+    int nChunks; // IC / 8
+    int nTiles;  // ceil(M / 32)
+    int useBN;
+    const float* res; // fused residual Add (chain rule E), set per launch
+    ActCfg ac2;
+};
+
+// kDepth = activation chunks (8 channels = 16 bytes per lane each) in flight per lane: 4 next to 48 accumulators, 8 for the one-column
+// project layers (deep K, everything they move is the activation read)
+template <int NT, bool SIMPLE>
+__global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, ActCfg ac, const float* __restrict__ x, const float4* __restrict__ wp,
+                                                          const float4* __restrict__ epi, float* __restrict__ y) {
+    extern __shared__ float4 s_w[]; // [nChunks][2][BN]
+    constexpr int BN = 32 * NT;
+    constexpr int kDepth = NT == 1 ? 8 : 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    {
+        const int cnt = p.nChunks * 2 * BN;
+        const float4* src = wp + static_cast<size_t>(blockIdx.y) * cnt;
+        for (int i = tid; i < cnt; i += 256) s_w[i] = src[i];
+    }
+    float4 e[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) e[u] = epi[n0 + u * 32 + l32]; // table padded to the block grid's channel count
+    __syncthreads();
+
+    // one 32-pixel tile per wave.  (A persistent walk over several tiles per wave, with the next tile's first chunks requested before the
+    // epilogue, measured 10-100 % SLOWER the more tiles a wave owned: these layers live on memory-level parallelism, and a wave that is busy
+    // with its 48-store epilogue is not issuing loads -- many short waves keep more requests in flight than few long ones.)
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= p.nTiles) return;
+    // chunk c of the tile's row l32 for this lane's K half; rows past M and chunks past IC read as zero (their products vanish / are not stored)
+    const int arow = tile * 32 + l32;
+    const float* xrow = x + static_cast<size_t>(arow < p.M ? arow : 0) * p.IC + h * 4;
+    auto loadA = [&](int c) -> float4 {
+        if (arow < p.M && c < p.nChunks) return *reinterpret_cast<const float4*>(xrow + c * 8);
+        return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    float4 nxt[kDepth];
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) nxt[d] = loadA(d);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[u][i] = 0.0f;
+    for (int c0 = 0; c0 < p.nChunks; c0 += kDepth) {
+        float4 cur[kDepth];
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) cur[d] = nxt[d];
+        if (c0 + kDepth < p.nChunks) {
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) nxt[d] = loadA(c0 + kDepth + d);
+        }
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) {
+            if (c0 + d < p.nChunks) { // wave-uniform
+                float4 b[NT];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) b[u] = s_w[((c0 + d) * 2 + h) * BN + u * 32 + l32];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].x, b[u].x, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].y, b[u].y, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].z, b[u].z, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].w, b[u].w, acc[u], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: bias -> BN -> activation [-> + residual -> activation of the Add layer], 128-byte channel-contiguous stores
+    const int row0 = tile * 32 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = row0 + 8 * g + k;
+            if (row < p.M) {
+                const size_t o = static_cast<size_t>(row) * p.OC + n0 + l32;
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    if (n0 + u * 32 + l32 < p.OC) {
+                        float v = epi_affine(acc[u][4 * g + k], e[u], p.useBN);
+                        v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+                        if (p.res) v = epi_act(p.ac2.act, p.ac2.leaky, v + p.res[o + u * 32], 0.0f);
+                        y[o + u * 32] = v;
+                    }
+                }
+            }
+        }
+}
+
+struct Conv1x1StreamPlan : ConvPlanBase {
+    StreamParams p;
+    ActCfg ac;
+    float* d_w = nullptr;
+    float* d_epi = nullptr;
+    size_t ldsBytes = 0;
+    dim3 grid;
+    void (*kernel)(StreamParams, ActCfg, const float*, const float4*, const float4*, float*) = nullptr;
+    bool fusedAdd = false;
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == (fusedAdd ? 2 : 1), "conv2d: expects %d input(s), got %d", fusedAdd ? 2 : 1, nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == g.N && x->h == g.H && x->w == g.W && x->c == g.IC, "conv2d: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h, x->w, x->c,
+                       g.N, g.H, g.W, g.IC);
+        SNNHIP_REQUIRE(out->n == g.N && out->h == g.OH && out->w == g.OW && out->c == g.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n,
+                       out->h, out->w, out->c, g.N, g.OH, g.OW, g.OC);
+        StreamParams q = p;
+        q.res = nullptr;
+        if (fusedAdd) {
+            const snnhip_tensor* r = in[1];
+            SNNHIP_REQUIRE(r->n == g.N && r->h == g.OH && r->w == g.OW && r->c == g.OC && r->dtype == dtype,
+                           "conv2d+add: residual %dx%dx%dx%d (dtype %d) does not match the output %dx%dx%dx%d", r->n, r->h, r->w, r->c, r->dtype, g.N, g.OH, g.OW,
+                           g.OC);
+            q.res = r->data;
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, q, ac, static_cast<const float*>(x->data), reinterpret_cast<const float4*>(d_w),
+                           reinterpret_cast<const float4*>(d_epi), out->data);
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+template <int NT>
+decltype(Conv1x1StreamPlan::kernel) pick(bool simple) {
+    return simple ? conv1x1_stream_kernel<NT, true> : conv1x1_stream_kernel<NT, false>;
+}
+
+} // namespace
+
+// SNNHIP_E_UNSUPPORTED when the layer is not a large fp32 pointwise stream (the caller then takes the general MFMA kernel).
+// SNNHIP_CONV_1X1=0 switches the kernel off (A/B runs, tests of the general kernel on the same shapes), =2 also takes few-tile deep-K layers.
+int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
+    const char* sw = getenv("SNNHIP_CONV_1X1"); // 0: off; 2: also take few-tile deep-K layers (parity tests at oracle-sized shapes)
+    if (sw && atoi(sw) == 0) return SNNHIP_E_UNSUPPORTED;
+    if (g.dtype != SNNHIP_F32 || g.kh != 1 || g.kw != 1 || g.sh != 1 || g.sw != 1 || g.preMode != 0 || g.padx != 0 || g.pady != 0) return SNNHIP_E_UNSUPPORTED;
+    if (g.OH != g.H || g.OW != g.W || g.act == SNNHIP_ACT_SILU_QUIRK || g.IC < 8 || g.IC % 8 != 0 || g.OC < 16) return SNNHIP_E_UNSUPPORTED;
+    const double M = static_cast<double>(g.N) * g.H * g.W;
+    if (M * g.IC >= 2147483647.0 || M * g.OC >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
+    const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+    const int nTiles = static_cast<int>((static_cast<long long>(M) + 31) / 32);
+    // measured against the general kernel (tools/bench_layers.py --shape ..., SNNHIP_CONV_1X1=0 / 2): faster or equal on every MobileNetV2 /
+    // YOLO pointwise layer down to 7x7 maps (160->960 @7x7 b32: 25.0 -> 13.8 us) whose weight slice fits 80 KB of LDS; beyond that (576 ->
+    // 96+, 960 -> 160 ...) two resident blocks per CU are too few and the general kernel's split-K wins, as it does when a deep reduction
+    // meets a handful of tiles (checked after the column width is known)
+    // columns per block: the widest of 96 / 64 / 32 that pads the channel count by at most a third and whose weight slice fits the LDS budget
+    size_t ldsCap = 80 * 1024;
+    if (const char* e = getenv("SNNHIP_CONV_1X1_LDS_KB")) ldsCap = static_cast<size_t>(atoi(e)) * 1024; // experiments
+    int NT = 0;
+    for (int c = 3; c >= 1 && !NT; --c) {
+        const int ocp = (g.OC + 32 * c - 1) / (32 * c) * (32 * c);
+        if ((c == 1 || (ocp - g.OC) * 3 <= g.OC) && static_cast<size_t>(g.IC) * 32 * c * 4 <= ldsCap) NT = c;
+    }
+    if (!NT) return SNNHIP_E_UNSUPPORTED;
+    if (g.IC >= 128 && static_cast<long long>((nTiles + 3) / 4) * ((g.OC + 32 * NT - 1) / (32 * NT)) < cus / 4 && !(sw && atoi(sw) == 2)) return SNNHIP_E_UNSUPPORTED;
+    const int BN = 32 * NT, ocBlocks = (g.OC + BN - 1) / BN, OCp = ocBlocks * BN, nChunks = g.IC / 8;
+
+    auto* plan = new Conv1x1StreamPlan();
+    plan->ctx = ctx;
+    plan->g = g;
+    plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC);
+    plan->epi4 = epi4;
+    plan->p = StreamParams{static_cast<int>(M), g.IC, g.OC, nChunks, nTiles, g.useBN, nullptr, make_act_cfg(g.addAct >= 0 ? g.addAct : SNNHIP_ACT_NONE, g.addLeaky)};
+    plan->ac = make_act_cfg(g.act, g.leaky);
+    plan->fusedAdd = g.addAct >= 0;
+    if (plan->fusedAdd) plan->numInputs = 2;
+    plan->ldsBytes = static_cast<size_t>(g.IC) * BN * 4;
+    const bool simple = act_is_simple(g.act);
+    plan->kernel = NT == 3 ? pick<3>(simple) : NT == 2 ? pick<2>(simple) : pick<1>(simple);
+    const int gx = (nTiles + 3) / 4; // 4 waves = 4 tiles per block
+    plan->grid = dim3(gx, ocBlocks);
+    if (plan->ldsBytes > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(plan->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan->ldsBytes)) != hipSuccess) {
+        delete plan;
+        return SNNHIP_E_UNSUPPORTED;
+    }
+
+    // Wp[ocBlock][chunk][h][BN] float4: component j = w[oc][ic = 8*chunk + 4*h + j]
+    std::vector<float> wp(static_cast<size_t>(ocBlocks) * nChunks * 2 * BN * 4, 0.0f);
+    for (int ob = 0; ob < ocBlocks; ++ob)
+        for (int c = 0; c < nChunks; ++c)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int o = 0; o < BN; ++o) {
+                    const int oc = ob * BN + o;
+                    if (oc >= g.OC) continue;
+                    float* dst = &wp[(((static_cast<size_t>(ob) * nChunks + c) * 2 + hh) * BN + o) * 4];
+                    for (int j = 0; j < 4; ++j) dst[j] = w_oihw[static_cast<size_t>(oc) * g.IC + c * 8 + hh * 4 + j];
+                }
+    std::vector<float> epiP(static_cast<size_t>(OCp) * 4, 0.0f);
+    std::memcpy(epiP.data(), epi4.data(), sizeof(float) * 4 * static_cast<size_t>(g.OC));
+    int rc = plan->upload(wp.data(), wp.size(), &plan->d_w);
+    if (rc == SNNHIP_OK) rc = plan->upload(epiP.data(), epiP.size(), &plan->d_epi);
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    plan->inDims[0] = g.N; plan->inDims[1] = g.H; plan->inDims[2] = g.W; plan->inDims[3] = g.IC;
+    plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
+    plan->dtype = SNNHIP_F32;
+    plan->flops = 2.0 * g.IC * g.OC * M;
+    plan->bytes = 4.0 * (M * g.IC + M * g.OC + static_cast<double>(g.OC) * g.IC);
+    char buf[256];
+    snprintf(buf, sizeof(buf), "conv2d_mfma_f32_32x32x2 k=1x1 s=1 ic=%d oc=%d stream: wave = 32px x %doc, grid %dx%d, lds=%zuB", g.IC, g.OC, BN, gx, ocBlocks,
+             plan->ldsBytes);
+    plan->desc = buf;
+    if (plan->fusedAdd) {
+        plan->desc += " +add";
+        plan->bytes += 4.0 * M * g.OC;
+    }
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip

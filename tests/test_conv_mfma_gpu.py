@@ -212,3 +212,53 @@ def test_tap_pair_mode_matches_oracle(ctx, force, monkeypatch, case, pad_mode, d
     y2, desc2 = run()
     assert "tap-pairs" not in desc2
     np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-3 if dtype == "f16" else 1e-4, atol=2e-3 if dtype == "f16" else 1e-4)
+
+
+STREAM_CASES = [
+    # (N, H, W, IC, OC, act, bn)   pointwise stride-1 layers through conv1x1_stream.hip (SNNHIP_CONV_1X1=2 lifts its size threshold)
+    (2, 28, 28, 16, 96, "relu6", True),     # MobileNetV2 expand: 96-wide blocks
+    (2, 28, 28, 24, 144, "relu6", True),    # IC not a multiple of 16, OC padded 144 -> 192
+    (1, 33, 47, 32, 192, "relu", False),    # ragged pixel count (1551 = 48 tiles + 15 rows)
+    (2, 14, 14, 96, 24, "", True),          # project: one 32-wide block, 8 of its columns padding
+    (1, 19, 21, 144, 32, "", True), (1, 12, 12, 192, 64, "tanh", False),
+    (1, 9, 9, 8, 16, "leakyRelu", True),    # smallest supported: one chunk, 16 channels
+    (1, 10, 10, 40, 576, "SiLU", True),     # 6 channel blocks, non-simple activation
+    (3, 5, 7, 64, 100, "sigmoid", False),   # OC % 32 != 0 with 64-wide... (100 -> 128: falls to the 32-wide rule)
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_pointwise_stream_matches_oracle(ctx, monkeypatch, case):
+    N, H, W, IC, OC, act, use_bn = case
+    x = _rand((N, H, W, IC), 51)
+    w = _rand((OC, IC, 1, 1), 52, 1.0 / np.sqrt(IC))
+    b = _rand((OC,), 53, 0.1)
+    bn = _bn(OC, 54) if use_bn else None
+    monkeypatch.setenv("SNNHIP_CONV_1X1", "2")
+    y, desc = run_conv(ctx, x, w, b, 1, (0, 0, 0, 0), "constant", act, 0.1, bn)
+    assert "stream" in desc, desc
+    want = O.conv2d(x, w, b, 1, (0, 0, 0, 0), "constant", act, 0.1, bn)
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
+    monkeypatch.setenv("SNNHIP_CONV_1X1", "0")  # the general kernel on the same layer
+    y2, desc2 = run_conv(ctx, x, w, b, 1, (0, 0, 0, 0), "constant", act, 0.1, bn)
+    assert "stream" not in desc2, desc2
+    np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, **TOL)
+
+
+def test_pointwise_stream_full_size_and_fused_add(ctx):
+    """At MobileNetV2's own size the kernel is the default route; with an Add behind it (chain rule E) the residual goes through its epilogue."""
+    import shadernn_amd as snn
+
+    n, h, w, ic, oc = 16, 56, 56, 144, 24
+    x, wt, b = _rand((n, h, w, ic), 61), _rand((oc, ic, 1, 1), 62, 1.0 / np.sqrt(ic)), _rand((oc,), 63, 0.1)
+    skip, bn = _rand((n, h, w, oc), 64), _bn(oc, 65)
+    conv = snn.conv2d_plan(ctx, n, h, w, wt, b, stride=1, pads=(0, 0, 0, 0), act="", bn=bn)
+    assert "stream" in conv.describe(), conv.describe()
+    add = snn.add_plan(ctx, n, h, w, oc, act="relu")
+    fused = snn.chain_plan(ctx, [conv, add])
+    assert fused.num_steps() == 1 and "stream" in fused.describe() and "+add" in fused.describe(), fused.describe()
+    xt, st = snn.Tensor.from_numpy(ctx, x), snn.Tensor.from_numpy(ctx, skip)
+    y = fused([xt, st]).numpy()
+    want = O.add_act(O.conv2d(x, wt, b, 1, (0, 0, 0, 0), "constant", "", 0.0, bn), skip, "relu", 0.0)
+    np.testing.assert_allclose(y, want, err_msg=fused.describe(), **TOL)
+    np.testing.assert_allclose(y, add([conv(xt), st]).numpy(), rtol=1e-6, atol=1e-6)

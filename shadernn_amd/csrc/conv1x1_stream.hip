@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
     }
     // epilogue: bias -> BN -> activation [-> + residual -> activation of the Add layer], 128-byte channel-contiguous stores
     const int row0 = tile * 32 + 4 * h;
+    const bool addSimple = act_is_simple_dev(p.ac2.act);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
                     if (n0 + u * 32 + l32 < p.OC) {
                         float v = epi_affine(acc[u][4 * g + k], e[u], p.useBN);
                         v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
-                        if (p.res) v = epi_act(p.ac2.act, p.ac2.leaky, v + p.res[o + u * 32], 0.0f);
+                        if (p.res) v = add_act(p.ac2, addSimple, v + p.res[o + u * 32]);
                         y[o + u * 32] = v;
                     }
                 }

@@ -40,12 +40,13 @@ namespace {
 template <bool SIMPLE, typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(size_t MN, int OC, int splitK, int useBN, ActCfg ac, const float* __restrict__ ws,
                                                            const float4* __restrict__ epi, T* __restrict__ y, const T* __restrict__ res, ActCfg ac2) {
+    const bool addSimple = act_is_simple_dev(ac2.act);
     for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < MN; i += static_cast<size_t>(gridDim.x) * 256) {
         float v = 0.0f;
         for (int z = 0; z < splitK; ++z) v += ws[static_cast<size_t>(z) * MN + i];
         v = epi_affine(v, epi[i % OC], useBN);
         v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
-        if (res) v = epi_act(ac2.act, ac2.leaky, static_cast<float>(static_cast<T>(v)) + static_cast<float>(res[i]), 0.0f); // fused residual Add
+        if (res) v = add_act(ac2, addSimple, static_cast<float>(static_cast<T>(v)) + static_cast<float>(res[i])); // fused residual Add
         y[i] = static_cast<T>(v);
     }
 }

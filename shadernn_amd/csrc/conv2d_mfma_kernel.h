@@ -350,10 +350,33 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
     // 64-byte runs (measured: 19 of 69 us of a 3x3 256->128 layer).  The tile is transposed through LDS instead ([pixel][BN halfs], row
     // pitch BN*2+16 bytes so that the two half-waves hit disjoint banks) and written as 16-byte vectors, a pixel's BN channels contiguous.
     constexpr int EPITCH = BN + 8; // halfs per LDS row of the output tile
+    const bool addSimple = act_is_simple_dev(p.ac2.act);
     _Float16* const otile = reinterpret_cast<_Float16*>(smem);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int ibase = (wm * MT + t) * 32 + 4 * h;
+        // fused Add: this M-tile's 16*NT residual values are requested in one batch before the first store of the tile.  Interleaved with the
+        // stores (y may alias res as far as the compiler knows) every load waits out its full latency: the fused layer was SLOWER than
+        // convolution + separate Add launch (56x56 64->64 b32: 111 + 12 us apart, 131 us fused).
+        float rv[4][NT][4];
+        const bool resDirect = p.res && p.splitK == 1 && !(F16 && p.ldsEpi);
+        if (resDirect) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = ibase + 8 * g;
+                const int b = i >> (p.THs + p.TWs), py = (i >> p.TWs) & THm, px = i & TWm;
+                const int n = b0 + b, oy = oy0 + py, ox = ox0 + px;
+                const bool rowOk = n < p.N && oy < p.OH;
+                const int pofs = ((n * p.OH + oy) * p.OW + ox) * p.OC;
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const int oc = n0 + u * 32 + l32;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        rv[g][u][k] = (rowOk && oc < p.OC && ox + k < p.OW) ? static_cast<float>(static_cast<const T*>(p.res)[pofs + k * p.OC + oc]) : 0.0f;
+                }
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int i = ibase + 8 * g;
@@ -387,9 +410,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                     if (F16 && p.ldsEpi) {
                         otile[(i + k) * EPITCH + wn * (NT * 32) + u * 32 + l32] = static_cast<_Float16>(v);
                     } else if (ok && ox + k < p.OW && (!(SNNHIP_ABL & 8) || v == 12345.678f)) { // ablation bit 8: no output stores
-                        if (p.res) { // the Add layer behind this convolution: same rounding points as the two separate launches
+                        if (resDirect) { // the Add layer behind this convolution: same rounding points as the two separate launches
                             const float cv = static_cast<float>(static_cast<T>(v));
-                            v = epi_act(p.ac2.act, p.ac2.leaky, cv + static_cast<float>(static_cast<const T*>(p.res)[pofs + k * p.OC + oc]), 0.0f);
+                            v = add_act(p.ac2, addSimple, cv + rv[g][u][k]);
                         }
                         y[pofs + k * p.OC + oc] = static_cast<T>(v);
                     }
@@ -416,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                     const _Float16* rh = reinterpret_cast<const _Float16*>(&rpack);
                     _Float16 oh[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) oh[e] = static_cast<_Float16>(epi_act(p.ac2.act, p.ac2.leaky, static_cast<float>(ch[e]) + static_cast<float>(rh[e]), 0.0f));
+                    for (int e = 0; e < 8; ++e) oh[e] = static_cast<_Float16>(add_act(p.ac2, addSimple, static_cast<float>(ch[e]) + static_cast<float>(rh[e])));
                     pack = *reinterpret_cast<const float4*>(oh);
                 }
                 *reinterpret_cast<float4*>(y + o) = pack;

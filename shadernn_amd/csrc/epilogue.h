@@ -59,6 +59,17 @@ __device__ __forceinline__ float apply_act(const ActCfg& a, float v, float first
     return epi_act(a.act, a.leaky, v, first);
 }
 
+// Activation of a fused Add layer (chain rule E).  It is none / relu / relu6 / leakyRelu in every graph of the zoo: those go through the
+// branch-free med3 form (bit-identical to epi_act for them) instead of epi_act's run-time switch.  (Measured: not what made fused adds
+// slow -- that was the residual loads interleaved with the stores, see conv2d_mfma_kernel's epilogue -- but it keeps the switch out of the
+// unrolled store loops.)
+__device__ __forceinline__ bool act_is_simple_dev(int act) {
+    return act == SNNHIP_ACT_NONE || act == SNNHIP_ACT_RELU || act == SNNHIP_ACT_RELU6 || act == SNNHIP_ACT_LEAKY;
+}
+__device__ __forceinline__ float add_act(const ActCfg& a, bool simple, float v) {
+    return simple ? __builtin_amdgcn_fmed3f(fmaxf(v, v * a.alpha), a.lo, a.hi) : epi_act(a.act, a.leaky, v, 0.0f);
+}
+
 // tanh as 1 - 2/(e^{2x}+1) on the hardware exp/rcp units: branch-free (ocml's tanhf is a multi-range, branchy
 // routine that serialises the epilogue).  Absolute error <= 3e-7 over the whole range, saturates to +-1 correctly.
 // Five instructions (v_mul, v_exp, v_add, v_rcp, v_fma): __fdividef compiles to the full IEEE division sequence (div_scale / div_fmas /

@@ -190,7 +190,11 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     choose();
     // stride-2 halo tiles are ~4x the output tile: with 32-channel (fp32: 16) chunks they take > 80 KB and leave one block per CU (ResNet's
     // downsampling 3x3 convs ran at 28 TF/s fp32 / 90 TF/s fp16).  Half-width chunks double the barriers but keep 2-3 blocks resident.
-    if (C8 == 2 && (best < 0 || bestLds > 80 * 1024) && !getenv("SNNHIP_CONV_WIDE_CHUNKS")) {
+    // (fp32 also below 80 KB: with a 61 KB double buffer only two 128-pixel blocks fit a CU and the ResNet 56x56 / 7x7 3x3 layers averaged 1.2
+    // waves per SIMD; at 48 KB the graph is 1.7 % faster, at 24 KB U-Net loses 4 %.  fp16 layers were 1-2 % slower with the lower bound.)
+    size_t narrowAbove = (f16 ? 80 : 48) * 1024;
+    if (const char* e = getenv("SNNHIP_CONV_NARROW_KB")) narrowAbove = static_cast<size_t>(atoi(e)) * 1024; // experiments
+    if (C8 == 2 && (best < 0 || bestLds > narrowAbove) && !getenv("SNNHIP_CONV_WIDE_CHUNKS")) {
         C8 = 1;
         Qs = 2;
         ICc = 2 * CH;

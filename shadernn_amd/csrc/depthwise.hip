@@ -71,19 +71,21 @@ __global__ __launch_bounds__(256) void depthwise_kernel(DwParams p, const T* __r
 // 3x3, C % 4 == 0: one thread = a strip of 4 adjacent output pixels x 4 channels.  The 3 x (3*STRIDE + 3) input window is loaded once
 // (18 float4 for stride 1, 27 for stride 2, instead of 36) and the 9 weight quads once per strip instead of once per pixel; the
 // activation is the branch-free form when it is one of {none, relu, relu6, leakyRelu} (MobileNetV2: relu6 everywhere).
-template <int STRIDE, bool SIMPLE, typename T>
+// IDX = unsigned whenever the strip count fits 31 bits (every real layer): the index decomposition below is four divisions per strip, and as
+// 64-bit divisions they were a multi-hundred-instruction prologue in front of 18 loads and 108 FMAs.
+template <int STRIDE, bool SIMPLE, typename T, typename IDX>
 __global__ __launch_bounds__(256) void depthwise3x3_strip_kernel(DwParams p, ActCfg ac, const T* __restrict__ x, const float* __restrict__ wpk,
                                                                  const float4* __restrict__ epi, T* __restrict__ y) {
     constexpr int COLS = 3 * STRIDE + 3; // input columns feeding 4 outputs
     const int strips = (p.OW + 3) >> 2;
-    const size_t total = static_cast<size_t>(p.N) * p.OH * strips * p.C4;
-    for (size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; idx < total; idx += static_cast<size_t>(gridDim.x) * 256) {
-        const int cq = static_cast<int>(idx % p.C4);
-        size_t r = idx / p.C4;
-        const int st = static_cast<int>(r % strips);
-        r /= strips;
-        const int oy = static_cast<int>(r % p.OH);
-        const int n = static_cast<int>(r / p.OH);
+    const IDX total = static_cast<IDX>(p.N) * p.OH * strips * p.C4;
+    for (IDX idx = static_cast<IDX>(blockIdx.x) * 256 + threadIdx.x; idx < total; idx += static_cast<IDX>(gridDim.x) * 256) {
+        const int cq = static_cast<int>(idx % static_cast<IDX>(p.C4));
+        IDX r = idx / static_cast<IDX>(p.C4);
+        const int st = static_cast<int>(r % static_cast<IDX>(strips));
+        r /= static_cast<IDX>(strips);
+        const int oy = static_cast<int>(r % static_cast<IDX>(p.OH));
+        const int n = static_cast<int>(r / static_cast<IDX>(p.OH));
         const int c0 = cq * 4, ox0 = st * 4;
         const int ix0 = ox0 * STRIDE - p.padx, iy0 = oy * STRIDE - p.pady;
         const T* xn = x + static_cast<size_t>(n) * p.H * p.W * p.C + c0;
@@ -170,8 +172,16 @@ struct DepthwisePlan : ConvPlanBase {
             const dim3 g4(static_cast<unsigned>(blocks4));
             const float4* e4 = reinterpret_cast<const float4*>(d_epi);
             const bool simple = act_is_simple(p.act);
-#define SNNHIP_DW(ST, SI, TT) \
-    hipLaunchKernelGGL((depthwise3x3_strip_kernel<ST, SI, TT>), g4, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const TT*>(x->data), d_w, e4, reinterpret_cast<TT*>(out->data))
+            const bool small = total4 + static_cast<size_t>(blocks4) * 256 < 0x7fffffffull; // idx + stride never wraps 32 bits
+#define SNNHIP_DW(ST, SI, TT)                                                                                                                                  \
+    do {                                                                                                                                                       \
+        if (small)                                                                                                                                             \
+            hipLaunchKernelGGL((depthwise3x3_strip_kernel<ST, SI, TT, unsigned>), g4, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const TT*>(x->data), \
+                               d_w, e4, reinterpret_cast<TT*>(out->data));                                                                                     \
+        else                                                                                                                                                   \
+            hipLaunchKernelGGL((depthwise3x3_strip_kernel<ST, SI, TT, size_t>), g4, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const TT*>(x->data),   \
+                               d_w, e4, reinterpret_cast<TT*>(out->data));                                                                                     \
+    } while (0)
             if (dtype == SNNHIP_F16) {
                 if (p.sh == 1) { if (simple) SNNHIP_DW(1, true, _Float16); else SNNHIP_DW(1, false, _Float16); }
                 else { if (simple) SNNHIP_DW(2, true, _Float16); else SNNHIP_DW(2, false, _Float16); }

@@ -1,4 +1,4 @@
-// conv1x1_stream.hip -- pointwise (1x1, stride 1) fp32 convolution as a streaming GEMM on v_mfma_f32_32x32x2_f32, for the layers whose time is
+// conv1x1_stream.hip -- pointwise (1x1, stride 1 or 2) fp32 convolution as a streaming GEMM on v_mfma_f32_32x32x2_f32, for the layers whose time is
 // their activation / output stream rather than their arithmetic: MobileNetV2's expand (16->96 ... 96->576) and project (96->24 ... 192->32)
 // convolutions at 112x112 .. 28x28 (BASELINE configs[3]).  Replaces shadertemplate_vk_conv2d_1x1.comp:68-210 of the reference for those
 // shapes; bias -> BN -> activation epilogue and the fused residual Add are those of conv2d_mfma_kernel (same helpers, same rounding points).
@@ -31,6 +31,7 @@ struct StreamParams {
     int nChunks; // IC / 8
     int nTiles;  // ceil(M / 32)
     int useBN;
+    int stride, W, HW, OW, OHW; // stride > 1 (ResNet's 1x1 s2 downsample convolutions): output row -> input pixel (n, s*oy, s*ox); HW = H*W, OHW = OH*OW
     const float* res; // fused residual Add (chain rule E), set per launch
     ActCfg ac2;
 };
@@ -62,7 +63,13 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
     if (tile >= p.nTiles) return;
     // chunk c of the tile's row l32 for this lane's K half; rows past M and chunks past IC read as zero (their products vanish / are not stored)
     const int arow = tile * 32 + l32;
-    const float* xrow = x + static_cast<size_t>(arow < p.M ? arow : 0) * p.IC + h * 4;
+    int irow = arow < p.M ? arow : 0;
+    if (p.stride > 1) { // the lane addresses its own row anyway, so a strided layer is one index decode per lane, not a different access pattern
+        const unsigned n = static_cast<unsigned>(irow) / static_cast<unsigned>(p.OHW), rem = static_cast<unsigned>(irow) - n * p.OHW;
+        const unsigned oy = rem / static_cast<unsigned>(p.OW), ox = rem - oy * p.OW;
+        irow = static_cast<int>(n * p.HW + (oy * p.W + ox) * p.stride);
+    }
+    const float* xrow = x + static_cast<size_t>(irow) * p.IC + h * 4;
     auto loadA = [&](int c) -> float4 {
         if (arow < p.M && c < p.nChunks) return *reinterpret_cast<const float4*>(xrow + c * 8);
         return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -168,10 +175,11 @@ decltype(Conv1x1StreamPlan::kernel) pick(bool simple) {
 int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     const char* sw = getenv("SNNHIP_CONV_1X1"); // 0: off; 2: also take few-tile deep-K layers (parity tests at oracle-sized shapes)
     if (sw && atoi(sw) == 0) return SNNHIP_E_UNSUPPORTED;
-    if (g.dtype != SNNHIP_F32 || g.kh != 1 || g.kw != 1 || g.sh != 1 || g.sw != 1 || g.preMode != 0 || g.padx != 0 || g.pady != 0) return SNNHIP_E_UNSUPPORTED;
-    if (g.OH != g.H || g.OW != g.W || g.act == SNNHIP_ACT_SILU_QUIRK || g.IC < 8 || g.IC % 8 != 0 || g.OC < 16) return SNNHIP_E_UNSUPPORTED;
-    const double M = static_cast<double>(g.N) * g.H * g.W;
-    if (M * g.IC >= 2147483647.0 || M * g.OC >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
+    if (g.dtype != SNNHIP_F32 || g.kh != 1 || g.kw != 1 || g.sh != g.sw || g.sh < 1 || g.sh > 2 || g.preMode != 0 || g.padx != 0 || g.pady != 0) return SNNHIP_E_UNSUPPORTED;
+    if ((g.OH - 1) * g.sh >= g.H || (g.OW - 1) * g.sw >= g.W || (g.sh == 1 && (g.OH != g.H || g.OW != g.W))) return SNNHIP_E_UNSUPPORTED;
+    if (g.act == SNNHIP_ACT_SILU_QUIRK || g.IC < 8 || g.IC % 8 != 0 || g.OC < 16) return SNNHIP_E_UNSUPPORTED;
+    const double M = static_cast<double>(g.N) * g.OH * g.OW;
+    if (static_cast<double>(g.N) * g.H * g.W * g.IC >= 2147483647.0 || M * g.OC >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
     const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
     const int nTiles = static_cast<int>((static_cast<long long>(M) + 31) / 32);
     // measured against the general kernel (tools/bench_layers.py --shape ..., SNNHIP_CONV_1X1=0 / 2): faster or equal on every MobileNetV2 /
@@ -195,7 +203,8 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     plan->g = g;
     plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC);
     plan->epi4 = epi4;
-    plan->p = StreamParams{static_cast<int>(M), g.IC, g.OC, nChunks, nTiles, g.useBN, nullptr, make_act_cfg(g.addAct >= 0 ? g.addAct : SNNHIP_ACT_NONE, g.addLeaky)};
+    plan->p = StreamParams{static_cast<int>(M), g.IC, g.OC, nChunks, nTiles, g.useBN, g.sh, g.W, g.H * g.W, g.OW, g.OH * g.OW, nullptr,
+                           make_act_cfg(g.addAct >= 0 ? g.addAct : SNNHIP_ACT_NONE, g.addLeaky)};
     plan->ac = make_act_cfg(g.act, g.leaky);
     plan->fusedAdd = g.addAct >= 0;
     if (plan->fusedAdd) plan->numInputs = 2;
@@ -233,9 +242,9 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
     plan->dtype = SNNHIP_F32;
     plan->flops = 2.0 * g.IC * g.OC * M;
-    plan->bytes = 4.0 * (M * g.IC + M * g.OC + static_cast<double>(g.OC) * g.IC);
+    plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + M * g.OC + static_cast<double>(g.OC) * g.IC); // same accounting as the general kernel
     char buf[256];
-    snprintf(buf, sizeof(buf), "conv2d_mfma_f32_32x32x2 k=1x1 s=1 ic=%d oc=%d stream: wave = 32px x %doc, grid %dx%d, lds=%zuB", g.IC, g.OC, BN, gx, ocBlocks,
+    snprintf(buf, sizeof(buf), "conv2d_mfma_f32_32x32x2 k=1x1 s=%d ic=%d oc=%d stream: wave = 32px x %doc, grid %dx%d, lds=%zuB", g.sh, g.IC, g.OC, BN, gx, ocBlocks,
              plan->ldsBytes);
     plan->desc = buf;
     if (plan->fusedAdd) {

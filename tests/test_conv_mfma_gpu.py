@@ -245,6 +245,22 @@ def test_pointwise_stream_matches_oracle(ctx, monkeypatch, case):
     np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, **TOL)
 
 
+@pytest.mark.parametrize("case", [(2, 56, 56, 64, 128), (1, 27, 31, 32, 64), (3, 14, 14, 256, 512)], ids=lambda c: "x".join(map(str, c)))
+def test_pointwise_stream_stride2(ctx, monkeypatch, case):
+    """ResNet's 1x1 stride-2 downsample convolutions: the stream kernel decodes (n, 2*oy, 2*ox) per lane; odd sizes round the output up."""
+    N, H, W, IC, OC = case
+    x = _rand((N, H, W, IC), 71)
+    w = _rand((OC, IC, 1, 1), 72, 1.0 / np.sqrt(IC))
+    b = _rand((OC,), 73, 0.1)
+    bn = _bn(OC, 74)
+    monkeypatch.setenv("SNNHIP_CONV_1X1", "2")
+    y, desc = run_conv(ctx, x, w, b, 2, (0, 0, 0, 0), "constant", "", 0.0, bn)
+    assert "stream" in desc and "s=2" in desc, desc
+    want = O.conv2d(x, w, b, 2, (0, 0, 0, 0), "constant", "", 0.0, bn)
+    assert y.shape == want.shape, (y.shape, want.shape, desc)
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
+
+
 def test_pointwise_stream_full_size_and_fused_add(ctx):
     """At MobileNetV2's own size the kernel is the default route; with an Add behind it (chain rule E) the residual goes through its epilogue."""
     import shadernn_amd as snn

@@ -73,33 +73,38 @@ __global__ __launch_bounds__(256) void depthwise_kernel(DwParams p, const T* __r
 // activation is the branch-free form when it is one of {none, relu, relu6, leakyRelu} (MobileNetV2: relu6 everywhere).
 // IDX = unsigned whenever the strip count fits 31 bits (every real layer): the index decomposition below is four divisions per strip, and as
 // 64-bit divisions they were a multi-hundred-instruction prologue in front of 18 loads and 108 FMAs.
-template <int STRIDE, bool SIMPLE, typename T, typename IDX>
+// ROWS = 2 (stride 1): the thread also owns the strip of the next output row -- 4 input rows feed both (24 float4 for 8 outputs instead of 36).
+template <int STRIDE, bool SIMPLE, typename T, typename IDX, int ROWS>
 __global__ __launch_bounds__(256) void depthwise3x3_strip_kernel(DwParams p, ActCfg ac, const T* __restrict__ x, const float* __restrict__ wpk,
                                                                  const float4* __restrict__ epi, T* __restrict__ y) {
     constexpr int COLS = 3 * STRIDE + 3; // input columns feeding 4 outputs
+    constexpr int INR = 3 + (ROWS - 1) * STRIDE; // input rows feeding ROWS output rows
     const int strips = (p.OW + 3) >> 2;
-    const IDX total = static_cast<IDX>(p.N) * p.OH * strips * p.C4;
+    const int rowGroups = (p.OH + ROWS - 1) / ROWS;
+    const IDX total = static_cast<IDX>(p.N) * rowGroups * strips * p.C4;
     for (IDX idx = static_cast<IDX>(blockIdx.x) * 256 + threadIdx.x; idx < total; idx += static_cast<IDX>(gridDim.x) * 256) {
         const int cq = static_cast<int>(idx % static_cast<IDX>(p.C4));
         IDX r = idx / static_cast<IDX>(p.C4);
         const int st = static_cast<int>(r % static_cast<IDX>(strips));
         r /= static_cast<IDX>(strips);
-        const int oy = static_cast<int>(r % static_cast<IDX>(p.OH));
-        const int n = static_cast<int>(r / static_cast<IDX>(p.OH));
+        const int oy = static_cast<int>(r % static_cast<IDX>(rowGroups)) * ROWS;
+        const int n = static_cast<int>(r / static_cast<IDX>(rowGroups));
         const int c0 = cq * 4, ox0 = st * 4;
         const int ix0 = ox0 * STRIDE - p.padx, iy0 = oy * STRIDE - p.pady;
         const T* xn = x + static_cast<size_t>(n) * p.H * p.W * p.C + c0;
         float4 w[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(wpk + static_cast<size_t>(t) * p.C4 * 4 + c0);
-        float4 acc[4];
+        float4 acc[ROWS][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool interior = ix0 >= 0 && iy0 >= 0 && ix0 + COLS <= p.W && iy0 + 3 <= p.H;
+        for (int q = 0; q < ROWS; ++q)
 #pragma unroll
-        for (int fy = 0; fy < 3; ++fy) {
+            for (int a = 0; a < 4; ++a) acc[q][a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool interior = ix0 >= 0 && iy0 >= 0 && ix0 + COLS <= p.W && iy0 + INR <= p.H;
+#pragma unroll
+        for (int ry = 0; ry < INR; ++ry) {
             float4 v[COLS];
-            const int sy = iy0 + fy;
+            const int sy = iy0 + ry;
             auto ld4 = [&](const T* ptr) {
                 float t[4];
                 ldv<T, 4>(ptr, t);
@@ -118,33 +123,42 @@ __global__ __launch_bounds__(256) void depthwise3x3_strip_kernel(DwParams p, Act
                 }
             }
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int q = 0; q < ROWS; ++q) {
+                const int fy = ry - q * STRIDE; // this input row is tap row fy of output row q
+                if (fy < 0 || fy > 2) continue;
 #pragma unroll
-                for (int fx = 0; fx < 3; ++fx) {
-                    const float4 vv = v[a * STRIDE + fx], ww = w[fy * 3 + fx];
-                    acc[a].x = fmaf(vv.x, ww.x, acc[a].x);
-                    acc[a].y = fmaf(vv.y, ww.y, acc[a].y);
-                    acc[a].z = fmaf(vv.z, ww.z, acc[a].z);
-                    acc[a].w = fmaf(vv.w, ww.w, acc[a].w);
-                }
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int fx = 0; fx < 3; ++fx) {
+                        const float4 vv = v[a * STRIDE + fx], ww = w[fy * 3 + fx];
+                        acc[q][a].x = fmaf(vv.x, ww.x, acc[q][a].x);
+                        acc[q][a].y = fmaf(vv.y, ww.y, acc[q][a].y);
+                        acc[q][a].z = fmaf(vv.z, ww.z, acc[q][a].z);
+                        acc[q][a].w = fmaf(vv.w, ww.w, acc[q][a].w);
+                    }
+            }
         }
         const float4 e0 = epi[c0], e1 = epi[c0 + 1], e2 = epi[c0 + 2], e3 = epi[c0 + 3];
         const int act = ac.act == SNNHIP_ACT_SILU_QUIRK ? SNNHIP_ACT_SILU : ac.act;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            if (ox0 + a >= p.OW) break;
-            float4 o;
-            o.x = epi_affine(acc[a].x, e0, p.useBN);
-            o.y = epi_affine(acc[a].y, e1, p.useBN);
-            o.z = epi_affine(acc[a].z, e2, p.useBN);
-            o.w = epi_affine(acc[a].w, e3, p.useBN);
-            if (SIMPLE) {
-                o = make_float4(apply_act<true>(ac, o.x, 0.f), apply_act<true>(ac, o.y, 0.f), apply_act<true>(ac, o.z, 0.f), apply_act<true>(ac, o.w, 0.f));
-            } else {
-                o = make_float4(epi_act(act, ac.leaky, o.x, o.x), epi_act(act, ac.leaky, o.y, o.y), epi_act(act, ac.leaky, o.z, o.z), epi_act(act, ac.leaky, o.w, o.w));
+        for (int q = 0; q < ROWS; ++q) {
+            if (oy + q >= p.OH) break;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (ox0 + a >= p.OW) break;
+                float4 o;
+                o.x = epi_affine(acc[q][a].x, e0, p.useBN);
+                o.y = epi_affine(acc[q][a].y, e1, p.useBN);
+                o.z = epi_affine(acc[q][a].z, e2, p.useBN);
+                o.w = epi_affine(acc[q][a].w, e3, p.useBN);
+                if (SIMPLE) {
+                    o = make_float4(apply_act<true>(ac, o.x, 0.f), apply_act<true>(ac, o.y, 0.f), apply_act<true>(ac, o.z, 0.f), apply_act<true>(ac, o.w, 0.f));
+                } else {
+                    o = make_float4(epi_act(act, ac.leaky, o.x, o.x), epi_act(act, ac.leaky, o.y, o.y), epi_act(act, ac.leaky, o.z, o.z), epi_act(act, ac.leaky, o.w, o.w));
+                }
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+                stv<T, 4>(y + ((static_cast<size_t>(n) * p.OH + oy + q) * p.OW + ox0 + a) * p.C + c0, ov);
             }
-            const float ov[4] = {o.x, o.y, o.z, o.w};
-            stv<T, 4>(y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox0 + a) * p.C + c0, ov);
         }
     }
 }
@@ -164,7 +178,11 @@ struct DepthwisePlan : ConvPlanBase {
         const bool vec = (p.C % 4) == 0;
         const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount) * 16;
         if (vec && p.kh == 3 && p.kw == 3 && p.sh == p.sw && (p.sh == 1 || p.sh == 2)) {
-            const size_t total4 = static_cast<size_t>(p.N) * p.OH * ((p.OW + 3) / 4) * p.C4;
+            // output rows per thread: 2 for stride 1 while that still leaves two full blocks per CU (144 ch @56x56 b32: 36.5 -> 29.9 us fp32; the
+            // 14x14 layers lose parallelism instead: fp16 8.5 -> 9.5 us); SNNHIP_DW_ROWS1 pins 1
+            const size_t pairs = static_cast<size_t>(p.N) * ((p.OH + 1) / 2) * ((p.OW + 3) / 4) * p.C4;
+            const int rows = (p.sh == 1 && !getenv("SNNHIP_DW_ROWS1") && pairs >= static_cast<size_t>(ctx->props.multiProcessorCount) * 512) ? 2 : 1;
+            const size_t total4 = static_cast<size_t>(p.N) * ((p.OH + rows - 1) / rows) * ((p.OW + 3) / 4) * p.C4;
             size_t blocks4 = (total4 + 255) / 256;
             if (blocks4 > cap) blocks4 = cap;
             if (blocks4 == 0) return SNNHIP_OK;
@@ -173,14 +191,18 @@ struct DepthwisePlan : ConvPlanBase {
             const float4* e4 = reinterpret_cast<const float4*>(d_epi);
             const bool simple = act_is_simple(p.act);
             const bool small = total4 + static_cast<size_t>(blocks4) * 256 < 0x7fffffffull; // idx + stride never wraps 32 bits
-#define SNNHIP_DW(ST, SI, TT)                                                                                                                                  \
-    do {                                                                                                                                                       \
-        if (small)                                                                                                                                             \
-            hipLaunchKernelGGL((depthwise3x3_strip_kernel<ST, SI, TT, unsigned>), g4, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const TT*>(x->data), \
-                               d_w, e4, reinterpret_cast<TT*>(out->data));                                                                                     \
-        else                                                                                                                                                   \
-            hipLaunchKernelGGL((depthwise3x3_strip_kernel<ST, SI, TT, size_t>), g4, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const TT*>(x->data),   \
-                               d_w, e4, reinterpret_cast<TT*>(out->data));                                                                                     \
+#define SNNHIP_DW_(ST, SI, TT, IX, RW)                                                                                                             \
+    hipLaunchKernelGGL((depthwise3x3_strip_kernel<ST, SI, TT, IX, RW>), g4, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const TT*>(x->data), d_w, e4, \
+                       reinterpret_cast<TT*>(out->data))
+#define SNNHIP_DW(ST, SI, TT)                                \
+    do {                                                     \
+        if (ST == 1 && rows == 2) {                          \
+            if (small) SNNHIP_DW_(1, SI, TT, unsigned, 2);   \
+            else SNNHIP_DW_(1, SI, TT, size_t, 2);           \
+        } else {                                             \
+            if (small) SNNHIP_DW_(ST, SI, TT, unsigned, 1);  \
+            else SNNHIP_DW_(ST, SI, TT, size_t, 1);          \
+        }                                                    \
     } while (0)
             if (dtype == SNNHIP_F16) {
                 if (p.sh == 1) { if (simple) SNNHIP_DW(1, true, _Float16); else SNNHIP_DW(1, false, _Float16); }
@@ -190,6 +212,7 @@ struct DepthwisePlan : ConvPlanBase {
                 else { if (simple) SNNHIP_DW(2, true, float); else SNNHIP_DW(2, false, float); }
             }
 #undef SNNHIP_DW
+#undef SNNHIP_DW_
             SNNHIP_CHECK_HIP(hipGetLastError());
             return SNNHIP_OK;
         }

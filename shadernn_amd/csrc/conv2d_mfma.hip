@@ -62,6 +62,26 @@ struct MfmaConvPlan : ConvPlanBase {
     void (*kernel)(MfmaParams, ActCfg, const void*, const void*, const float4*, void*, float*) = nullptr;
 
     bool fusedAdd = false; // chain rule E: run(x, residual) -> act2(conv(x) + residual)
+    bool enableTileStats() override {
+        if (statPart) return true;
+        if (dtype != SNNHIP_F16 || !p.ldsEpi || p.splitK != 1 || p.TBs != 0 || fusedAdd) return false;
+        const int BN = p.OCp / static_cast<int>(grid.y);
+        const size_t need = std::max(static_cast<size_t>(128) * (BN + 8) * 2, static_cast<size_t>(2) * 256 * 8 * sizeof(float)); // output tile, then the fold scratch over it
+        if (need > ldsBytes) {
+            if (need > 64 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(need)) != hipSuccess)
+                return false;
+            ldsBytes = need;
+        }
+        void* buf = nullptr;
+        const size_t bytes = static_cast<size_t>(p.N) * p.tilesY * p.tilesX * 2 * p.OC * sizeof(float);
+        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        statPart = p.statPart = static_cast<float*>(buf);
+        statTilesX = p.tilesX; statTilesY = p.tilesY; statTH = 1 << p.THs; statTW = 1 << p.TWs;
+        desc += " +tile-stats";
+        return true;
+    }
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == (fusedAdd ? 2 : 1), "conv2d: expects %d input(s), got %d", fusedAdd ? 2 : 1, nIn);
         const snnhip_tensor* x = in[0];
@@ -208,6 +228,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     p.srcH = g.preMode ? g.srcH : g.H;
     p.srcW = g.preMode ? g.srcW : g.W;
     p.res = nullptr;
+    p.statPart = nullptr;
     p.ac2 = make_act_cfg(g.addAct >= 0 ? g.addAct : SNNHIP_ACT_NONE, g.addLeaky);
     p.TBs = shapes[best][0]; p.THs = shapes[best][1]; p.TWs = shapes[best][2];
     const int TB = 1 << p.TBs, TH = 1 << p.THs, TW = 1 << p.TWs;

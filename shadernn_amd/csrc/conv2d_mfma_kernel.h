@@ -41,6 +41,9 @@ struct MfmaParams { // (declared after ActCfg: epilogue.h)
     // fused residual Add (chain rule E): y = act2(conv_result + res), res = a tensor of the output's shape and type, set per launch
     const void* res;
     ActCfg ac2;
+    // per-tile output statistics for a following InstanceNorm (chain rule F; fp16 LDS epilogue, one image per pixel tile, no split-K):
+    // statPart[((n*tilesY + ty)*tilesX + tx)][2][OC] = {mean, sum of squared deviations} of the tile's valid pixels, per channel
+    float* statPart;
 };
 
 // LDS layout of the staged activations.  A pixel owns ICc floats = ICc/4 16-byte slots; the slot is XOR-swizzled with
@@ -423,6 +426,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
     if (F16 && p.ldsEpi) {
         __syncthreads();
         constexpr int VPR = BN / 8; // 16-byte vectors per pixel row of the tile
+        // chain rule F (p.statPart, block-uniform): a thread's vectors are 8 pixels of ONE 8-channel column (256 % VPR == 0), so the sums and
+        // sums of squares of the stored (rounded) values accumulate in 16 registers while the vectors pass through
+        float sa[8], sb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sa[e] = sb[e] = 0.0f;
 #pragma unroll
         for (int j = 0; j < 128 * VPR / 256; ++j) {
             const int v = tid + 256 * j;
@@ -433,6 +441,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
             if (n < p.N && oy < p.OH && ox < p.OW && oc < p.OC && !(SNNHIP_ABL & 8)) {
                 const size_t o = static_cast<size_t>((n * p.OH + oy) * p.OW + ox) * p.OC + oc;
                 float4 pack = *reinterpret_cast<const float4*>(otile + i * EPITCH + c8 * 8);
+                if (p.statPart) {
+                    const _Float16* ch = reinterpret_cast<const _Float16*>(&pack);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = static_cast<float>(ch[e]);
+                        sa[e] += f;
+                        sb[e] = fmaf(f, f, sb[e]);
+                    }
+                }
                 if (p.res) {
                     const float4 rpack = *reinterpret_cast<const float4*>(static_cast<const T*>(p.res) + o);
                     const _Float16* ch = reinterpret_cast<const _Float16*>(&pack);
@@ -443,6 +460,32 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                     pack = *reinterpret_cast<const float4*>(oh);
                 }
                 *reinterpret_cast<float4*>(y + o) = pack;
+            }
+        }
+        if (p.statPart) { // fold the 256 / VPR pixel groups per channel in a fixed order (the tile in LDS is dead by now: its space is the scratch)
+            constexpr int PG = 256 / VPR;
+            float* const sred = reinterpret_cast<float*>(smem);
+            __syncthreads();
+            {
+                const int c8 = tid % VPR, pg = tid / VPR;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sred[pg * BN + c8 * 8 + e] = sa[e];
+                    sred[PG * BN + pg * BN + c8 * 8 + e] = sb[e];
+                }
+            }
+            __syncthreads();
+            const int ocb = blockIdx.y * BN;
+            if (tid < BN && ocb + tid < p.OC) {
+                float a1 = 0.0f, a2 = 0.0f;
+                for (int j = 0; j < PG; ++j) {
+                    a1 += sred[j * BN + tid];
+                    a2 += sred[PG * BN + j * BN + tid];
+                }
+                const float an = static_cast<float>(min(1 << p.THs, p.OH - oy0) * min(1 << p.TWs, p.OW - ox0)); // valid pixels of this tile (TB == 1)
+                float* po = p.statPart + (static_cast<size_t>(b0 * p.tilesY + (oy0 >> p.THs)) * p.tilesX + (ox0 >> p.TWs)) * 2 * p.OC;
+                po[ocb + tid] = a1 / an;
+                po[p.OC + ocb + tid] = fmaxf(a2 - a1 * a1 / an, 0.0f);
             }
         }
     }

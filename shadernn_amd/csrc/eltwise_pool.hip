@@ -330,6 +330,93 @@ __global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, i
     mul[i] = gamma[c] / sqrtf(var + eps);
 }
 
+// Chain rule F: the producing convolution already reduced every output tile to (mean_t, M2_t) per channel (conv2d_mfma_kernel's LDS
+// epilogue), so the statistics sweep over the tensor is not needed.  The tile records are combined with the parallel-variance update
+//     n = na + nb,  d = mb - ma,  m = ma + d nb/n,  M2 = M2a + M2b + d^2 na nb/n
+// in a fixed order, in two levels so that the reads stay channel-contiguous and enough blocks are in flight (a 1378x818 image is ~9000
+// tiles; one block per (image, channel) walking them with a 2*C-float stride took longer than the sweep it replaced):
+//   level 1: block = (64-tile chunk, image); thread = (channel lane, 1 of 4 tile lanes) folds 16 tiles, the 4 lanes are folded through LDS
+//   level 2: block = image, thread = (channel lane, 1 of 4 chunk lanes): folds the chunk records, writes mean and gamma / sqrt(var + eps)
+struct RunStat {
+    float n, m, q;
+};
+__device__ __forceinline__ void stat_merge(RunStat& a, float nb, float mb, float qb) {
+    if (nb <= 0.0f) return;
+    const float n = a.n + nb, dm = mb - a.m, f = nb / n;
+    a.m += dm * f;
+    a.q += qb + dm * dm * a.n * f;
+    a.n = n;
+}
+
+constexpr int kFoldChunk = 64; // tiles per level-1 block
+
+__global__ __launch_bounds__(256) void instancenorm_fold_tiles1_kernel(int C, int H, int W, int tilesX, int tilesY, int TH, int TW, const float* __restrict__ part,
+                                                                      float* __restrict__ part2) {
+    __shared__ float red[3][256];
+    const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+    const int tiles = tilesX * tilesY;
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+    const float* pn = part + static_cast<size_t>(n) * tiles * 2 * C;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + cl;
+        RunStat a{0.0f, 0.0f, 0.0f};
+        if (c < C) {
+            const int t0 = chunk * kFoldChunk + tl * (kFoldChunk / 4);
+#pragma unroll 4
+            for (int j = 0; j < kFoldChunk / 4; ++j) {
+                const int t = t0 + j;
+                if (t < tiles) {
+                    const int ty = t / tilesX, tx = t - ty * tilesX;
+                    const float cnt = static_cast<float>(min(TH, H - ty * TH) * min(TW, W - tx * TW));
+                    stat_merge(a, cnt, pn[static_cast<size_t>(t) * 2 * C + c], pn[static_cast<size_t>(t) * 2 * C + C + c]);
+                }
+            }
+        }
+        __syncthreads();
+        red[0][threadIdx.x] = a.n;
+        red[1][threadIdx.x] = a.m;
+        red[2][threadIdx.x] = a.q;
+        __syncthreads();
+        if (tl == 0 && c < C) {
+#pragma unroll
+            for (int j = 1; j < 4; ++j) stat_merge(a, red[0][j * 64 + cl], red[1][j * 64 + cl], red[2][j * 64 + cl]);
+            float* po = part2 + (static_cast<size_t>(n) * chunks + chunk) * 3 * C;
+            po[c] = a.n;
+            po[C + c] = a.m;
+            po[2 * C + c] = a.q;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void instancenorm_fold_tiles2_kernel(int C, int chunks, float eps, const float* __restrict__ part2,
+                                                                      const float* __restrict__ gamma, float* __restrict__ mean, float* __restrict__ mul) {
+    __shared__ float red[3][256];
+    const int n = blockIdx.x;
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6; // channel lane, 1 of 4 chunk lanes (chunks kl, kl + 4, ...)
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + cl;
+        RunStat a{0.0f, 0.0f, 0.0f};
+        if (c < C)
+            for (int k = kl; k < chunks; k += 4) {
+                const float* po = part2 + (static_cast<size_t>(n) * chunks + k) * 3 * C;
+                stat_merge(a, po[c], po[C + c], po[2 * C + c]);
+            }
+        __syncthreads();
+        red[0][threadIdx.x] = a.n;
+        red[1][threadIdx.x] = a.m;
+        red[2][threadIdx.x] = a.q;
+        __syncthreads();
+        if (kl == 0 && c < C) {
+#pragma unroll
+            for (int j = 1; j < 4; ++j) stat_merge(a, red[0][j * 64 + cl], red[1][j * 64 + cl], red[2][j * 64 + cl]);
+            float var = a.q / a.n;
+            var = var > 0.0f ? var : 0.0f;
+            mean[n * C + c] = a.m;
+            mul[n * C + c] = gamma[c] / sqrtf(var + eps);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ plans
 
 struct EltwisePlan : EltwisePlanBase {
@@ -474,6 +561,8 @@ struct InstanceNormPlan : snnhip_plan {
     snnhip_instancenorm_desc d;
     int S = 1, pixelsPerSlab = 1, CLs = 2;
     float *d_beta = nullptr, *d_gamma = nullptr, *d_part = nullptr, *d_mean = nullptr, *d_mul = nullptr;
+    float* d_foldScratch = nullptr; // chain rule F: level-1 records of the tile-statistics fold
+    size_t foldScratchCount = 0;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "instancenorm: expects 1 input, got %d", nIn);
         SNNHIP_SAME_DTYPE("instancenorm");
@@ -503,6 +592,42 @@ struct InstanceNormPlan : snnhip_plan {
 };
 
 } // namespace
+
+bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d) {
+    const auto* q = dynamic_cast<const InstanceNormPlan*>(plan);
+    if (!q) return false;
+    if (d) *d = q->d;
+    return true;
+}
+
+int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const float* statPart, int tilesX, int tilesY, int TH, int TW, snnhip_tensor* xy) {
+    auto* q = dynamic_cast<InstanceNormPlan*>(inPlan);
+    SNNHIP_REQUIRE(q && statPart && xy, "instancenorm_apply_tile_stats: bad arguments");
+    const snnhip_instancenorm_desc& d = q->d;
+    SNNHIP_REQUIRE(dims_match(xy, d.N, d.H, d.W, d.C), "instancenorm: tensor dims do not match the plan");
+    snnhip_ctx* ctx = q->ctx;
+    const int tiles = tilesX * tilesY, chunks = (tiles + kFoldChunk - 1) / kFoldChunk;
+    const size_t need = static_cast<size_t>(d.N) * chunks * 3 * d.C;
+    if (q->foldScratchCount < need) { // level-1 records; sized on first use (the tile grid belongs to the convolution in front)
+        void* buf = nullptr;
+        SNNHIP_CHECK_HIP(hipMalloc(&buf, need * sizeof(float)));
+        q->deviceAllocs.push_back(buf);
+        q->d_foldScratch = static_cast<float*>(buf);
+        q->foldScratchCount = need;
+    }
+    hipLaunchKernelGGL(instancenorm_fold_tiles1_kernel, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, d.H, d.W,
+                       tilesX, tilesY, TH, TW, statPart, q->d_foldScratch);
+    hipLaunchKernelGGL(instancenorm_fold_tiles2_kernel, dim3(static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, chunks, d.eps, q->d_foldScratch, q->d_gamma,
+                       q->d_mean, q->d_mul);
+    const dim3 g(static_cast<unsigned>(d.N * q->S));
+#define SNNHIP_IN2(CVV) \
+    hipLaunchKernelGGL((instancenorm_kernel<2, CVV, T>), g, dim3(256), 0, ctx->stream, d, q->S, q->pixelsPerSlab, q->CLs, cptr<T>(xy), q->d_mean, q->d_mul, q->d_beta, q->d_part, mptr<T>(xy))
+    SNNHIP_WITH_T(xy->dtype, if ((d.C & 3) == 0) { SNNHIP_IN2(4); } else { SNNHIP_IN2(1); });
+#undef SNNHIP_IN2
+    SNNHIP_CHECK_HIP(hipGetLastError());
+    return SNNHIP_OK;
+}
+
 } // namespace snnhip
 
 using namespace snnhip;

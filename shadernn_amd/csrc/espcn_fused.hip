@@ -1146,6 +1146,19 @@ constexpr int A_TW = 64, A_TH = 8;
 constexpr int W_TH = 16, W_WPS = 2; // Winograd kernel A: tile 32 x W_TH, W_WPS blocks (waves/SIMD) per CU
 constexpr int B_TW = 32, B_TH = 8;
 
+// Chain rule F: Conv2D -> InstanceNorm.  The convolution (conv2d_mfma, fp16 LDS epilogue) leaves (mean, M2) of every output tile and channel
+// next to its output; the InstanceNorm's statistics sweep -- one of its three passes over the tensor -- is replaced by a fold over those
+// tile records, and its normalise pass runs in place on the convolution's output.  Both plans are borrowed (the chain or the caller owns them).
+struct ConvInstanceNormPlan : snnhip_plan {
+    ConvPlanBase* conv = nullptr;
+    snnhip_plan* norm = nullptr;
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        int rc = conv->run(in, nIn, out);
+        if (rc != SNNHIP_OK) return rc;
+        return instancenorm_apply_tile_stats(norm, conv->statPart, conv->statTilesX, conv->statTilesY, conv->statTH, conv->statTW, out);
+    }
+};
+
 struct ChainPlan : snnhip_plan {
     enum Kind { PLAIN, FUSED_A, FUSED_B, FUSED_S };
     struct Step {
@@ -1604,6 +1617,37 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             i += 1;
         }
         chain->steps.push_back(st);
+    }
+    // ---- rule F (opt-in, SNNHIP_NORM_FUSION=1): a convolution step (as given, or one a rule above built) followed by an InstanceNorm step ->
+    // one step.  Parity-tested, but not a win as measured (Candy 720p fp16: batch 8 9.08 -> 9.15 ms, batch 1 1.50 -> 1.70 ms): accumulating the
+    // tile statistics costs the convolution's epilogue 45-125 us per layer at batch 8 where the sweep it replaces costs 40 us, and at batch 1
+    // the two fold launches outweigh a sweep that reads the tensor out of the MALL.
+    const char* normFusion = getenv("SNNHIP_NORM_FUSION");
+    for (size_t k = 0; rc == SNNHIP_OK && k + 1 < chain->steps.size() && normFusion && atoi(normFusion) != 0; ++k) {
+        ChainPlan::Step &a = chain->steps[k], &b = chain->steps[k + 1];
+        if (a.kind != ChainPlan::PLAIN || b.kind != ChainPlan::PLAIN) continue;
+        auto* cv = dynamic_cast<ConvPlanBase*>(a.plain);
+        snnhip_instancenorm_desc nd;
+        if (!cv || cv->depthwise || cv->numInputs != 1 || !instancenorm_plan_desc(b.plain, &nd)) continue;
+        if (nd.N != cv->outDims[0] || nd.H != cv->outDims[1] || nd.W != cv->outDims[2] || nd.C != cv->outDims[3]) continue;
+        if (!cv->enableTileStats()) continue;
+        auto* both = new ConvInstanceNormPlan();
+        both->ctx = ctx;
+        both->conv = cv;
+        both->norm = b.plain;
+        both->dtype = cv->dtype;
+        memcpy(both->inDims, cv->inDims, sizeof(both->inDims));
+        memcpy(both->outDims, cv->outDims, sizeof(both->outDims));
+        both->flops = a.flops + b.flops;
+        both->bytes = a.bytes + b.bytes;
+        both->desc = cv->desc + " -> instancenorm(fold of tile stats + 1 sweep) act=" + std::to_string(nd.act);
+        chain->owned.push_back(both);
+        a.plain = both;
+        a.desc = both->desc;
+        a.flops = both->flops;
+        a.bytes = both->bytes;
+        chain->steps.erase(chain->steps.begin() + static_cast<long>(k) + 1);
+        ++fusedCount;
     }
     if (rc == SNNHIP_OK && fusedCount == 0) {
         set_error("chain fusion: no rule matches these %d plans", n);

@@ -179,7 +179,15 @@ struct ConvPlanBase : snnhip_plan {
     std::vector<float> w_oihw; // host copy
     std::vector<float> epi4;   // host copy of the epilogue table, padded to a multiple of 16
     bool depthwise = false;
+    // chain rule F (Conv2D -> InstanceNorm): a convolution that can emit per-tile output statistics switches them on here and publishes where
+    // they land (statPart[(n*statTilesY + ty)*statTilesX + tx][2][OC], tiles of statTH x statTW output pixels); false = not supported
+    float* statPart = nullptr;
+    int statTilesX = 0, statTilesY = 0, statTH = 0, statTW = 0;
+    virtual bool enableTileStats() { return false; }
 };
+// eltwise_pool.hip: identify an InstanceNorm plan / run its fold + normalise passes in place from a convolution's tile statistics
+bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d);
+int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const float* statPart, int tilesX, int tilesY, int TH, int TW, snnhip_tensor* xy);
 struct EltwisePlanBase : snnhip_plan {
     snnhip_eltwise_desc d;
     int mode = 0; // 0 add, 1 activation, 2 batch-norm

@@ -1,4 +1,6 @@
 """Runs a chain-shaped net (models.py layer lists) through C-ABI plans: one plan per layer, or fused chain plans."""
+import os
+
 import numpy as np
 
 from . import capi
@@ -138,6 +140,7 @@ class GraphRunner:
             self.steps.append((plan, [self.tensors[i] for i in ins], t, layer))
         self.output_names = models.output_names(net)  # several for multi-head graphs (YOLOv3-tiny)
         self.fused_pads = []
+        self.fused_norms = []
         self.fused_adds = []
         if fuse:
             self._fuse_pads(models.producers(net))
@@ -177,6 +180,26 @@ class GraphRunner:
             if st and st[3]["interpolation"] == "nearest" and float(st[3]["scaleFactor"]) == 2.0:
                 chain_plans.insert(0, st[0])
                 first_ins, folded = st[1], folded + [st[3]["name"]]
+            # chain rule F: an InstanceNorm that is the only consumer of this convolution takes its statistics from the convolution's epilogue
+            norm = None
+            users = consumers.get(layer["name"], [])
+            if len(users) == 1 and layer["name"] not in outputs and users[0] in by_name and self.steps[by_name[users[0]]][3]["type"] == "InstanceNorm":
+                norm = self.steps[by_name[users[0]]]
+            if norm is not None and os.environ.get("SNNHIP_NORM_FUSION", "0") not in ("", "0"):  # opt-in: measured neutral to negative
+                try:
+                    chain = capi.chain_plan(self.ctx, chain_plans + [norm[0]])
+                except capi.SnnHipError as e:
+                    if e.code != capi.E_UNSUPPORTED:
+                        raise
+                    chain = None
+                if chain is not None and chain.num_steps() == 1:
+                    self.steps[k] = (chain, first_ins, norm[2], norm[3])
+                    drop.update(by_name[nm] for nm in folded + [norm[3]["name"]])
+                    self.fused_pads += folded
+                    self.fused_norms.append(norm[3]["name"])
+                    continue
+                if chain is not None:
+                    chain.destroy()
             while len(chain_plans) > 1:
                 try:
                     chain = capi.chain_plan(self.ctx, chain_plans)

@@ -229,3 +229,61 @@ def test_upsample_pad_conv_chain_fusion(ctx, with_pad, dtype):
         t = O.pad(t, (1, 1, 1, 1), "reflect")
     want = q(O.conv2d(t, q(wt), b, 1, cp, "constant", "relu", 0.0, None))
     np.testing.assert_allclose(y, want, err_msg=chain.describe(), **(dict(rtol=2e-3, atol=2e-3) if dtype == "f16" else TOL))
+
+
+@pytest.mark.parametrize("with_pad", [False, True])
+@pytest.mark.parametrize("n,h,w,ic,oc,k,s", [(1, 40, 56, 32, 64, 3, 1), (2, 37, 45, 64, 32, 3, 1), (1, 64, 64, 32, 64, 3, 2), (1, 33, 70, 16, 128, 3, 1)])
+def test_conv_instancenorm_chain_fusion(ctx, monkeypatch, n, h, w, ic, oc, k, s, with_pad):
+    """Chain rule F (fp16, opt-in): [Pad ->] Conv2D -> InstanceNorm as one step; the norm's statistics come from the convolution's per-tile
+    records (fold + one in-place sweep) instead of a sweep over the tensor.  Checked against the unfused launches and the oracle."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_NORM_FUSION", "1")
+
+    dt = snn.F16
+    x, wt, b = _rand((n, h, w, ic), 1), _rand((oc, ic, k, k), 2, 1.0 / np.sqrt(ic * k * k)), _rand((oc,), 3, 0.5)
+    beta, gamma = _rand((oc,), 4, 0.3), 1.0 + _rand((oc,), 5, 0.2)
+    plans, hp, wp, cp = [], h, w, O.padding_offsets("same", k)
+    if with_pad:
+        pads = (1, 1, 1, 1)
+        plans.append(snn.pad_plan(ctx, n, h, w, ic, pads, "reflect"))
+        hp, wp, cp = h + 2, w + 2, (0, 0, 0, 0)
+    conv = snn.conv2d_plan(ctx, n, hp, wp, wt, b, stride=s, pads=cp, act="", dtype=dt)
+    oh, ow = conv.out_shape()[1:3]
+    norm = snn.instancenorm_plan(ctx, n, oh, ow, oc, beta, gamma, act="relu")
+    plans += [conv, norm]
+    fused = snn.chain_plan(ctx, plans)
+    assert fused.num_steps() == 1 and "tile stats" in fused.describe(), fused.describe()
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=dt)
+    y = fused(xt).numpy()
+    t = xt
+    for pl in plans:
+        t = pl(t)
+    two = t.numpy()
+    xin = O._h(x)
+    if with_pad:
+        xin = O.pad(xin, (1, 1, 1, 1), "reflect")
+    c = O._h(O.conv2d(xin, O._h(wt), b, s, cp, "constant", "", 0.0, None))
+    want = O._h(O.instancenorm(c, beta, gamma, "relu"))
+    np.testing.assert_allclose(y, want, err_msg=fused.describe(), rtol=4e-3, atol=4e-3)
+    np.testing.assert_allclose(y, two, rtol=3e-3, atol=3e-3)
+
+
+def test_conv_instancenorm_not_fused_in_fp32(ctx, monkeypatch):
+    """fp32 convolutions have no LDS output tile to take statistics from: the pair stays two launches (and correct)."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_NORM_FUSION", "1")
+
+    n, h, w, ic, oc = 1, 24, 24, 16, 32
+    x, wt, b = _rand((n, h, w, ic), 1), _rand((oc, ic, 3, 3), 2, 0.1), _rand((oc,), 3, 0.1)
+    beta, gamma = _rand((oc,), 4, 0.3), 1.0 + _rand((oc,), 5, 0.2)
+    pad = snn.pad_plan(ctx, n, h, w, ic, (1, 1, 1, 1), "reflect")
+    conv = snn.conv2d_plan(ctx, n, h + 2, w + 2, wt, b, stride=1, pads=(0, 0, 0, 0), act="")
+    oh, ow = conv.out_shape()[1:3]
+    norm = snn.instancenorm_plan(ctx, n, oh, ow, oc, beta, gamma, act="")
+    chain = snn.chain_plan(ctx, [pad, conv, norm])
+    assert chain.num_steps() == 2, chain.describe()
+    y = chain(snn.Tensor.from_numpy(ctx, x)).numpy()
+    want = O.instancenorm(O.conv2d(O.pad(x, (1, 1, 1, 1), "reflect"), wt, b, 1, (0, 0, 0, 0), "constant", "", 0.0, None), beta, gamma, "")
+    np.testing.assert_allclose(y, want, **TOL)

@@ -74,12 +74,18 @@ def test_fp16_classifiers_match_quantised_oracle(ctx, which):
     np.testing.assert_allclose(y, O.forward(net, x).reshape(2, -1), atol=0.05)
 
 
-@pytest.mark.parametrize("which", ["style", "candy", "resnet_trunk"])
-def test_fp16_graphs_match_quantised_oracle(ctx, which):
-    """Whole graphs with half tensors: pad / conv / instance norm / add / upsample (Candy's operator set) and a ResNet trunk."""
+@pytest.mark.parametrize("which", ["style", "candy", "resnet_trunk", "candy+normfusion"])
+def test_fp16_graphs_match_quantised_oracle(ctx, monkeypatch, which):
+    """Whole graphs with half tensors: pad / conv / instance norm / add / upsample (Candy's operator set) and a ResNet trunk; Candy also with
+    the opt-in Conv2D -> InstanceNorm fusion (chain rule F)."""
     import shadernn_amd as snn
     from shadernn_amd import models
     from test_param_import import _zoo
+
+    fuse_norms = which.endswith("+normfusion")
+    if fuse_norms:
+        monkeypatch.setenv("SNNHIP_NORM_FUSION", "1")
+        which = "candy"
 
     if which == "style":
         net, (h, w) = models.style_net(seed=4, width=16), (24, 32)
@@ -91,6 +97,7 @@ def test_fp16_graphs_match_quantised_oracle(ctx, which):
         h, w = 64, 64
     x = np.random.default_rng(5).random((2, h, w, 3), dtype=np.float32)
     r = snn.GraphRunner(ctx, net, 2, h, w, dtype=snn.F16)
+    assert bool(r.fused_norms) == fuse_norms, r.fused_norms
     y = r(x)
     want = O.forward(net, x, fp16=True, threads=8)
     scale = max(1.0, float(np.abs(want).max()))

@@ -38,6 +38,8 @@ int snnhip_plan::profEnd(int) { return 0; }
 int snnhip_plan::profAcquire(int, hipEvent_t*, hipEvent_t*) { return 0; }
 namespace snnhip {
 int make_conv2d_mfma_plan(snnhip_ctx*, const ConvGeom&, const float*, const std::vector<float>&, snnhip_plan**) { return 0; }
+bool instancenorm_plan_desc(const snnhip_plan*, snnhip_instancenorm_desc*) { return false; }
+int instancenorm_apply_tile_stats(snnhip_plan*, const float*, int, int, int, int, snnhip_tensor*) { return 0; }
 }
 static snnhip::FusedBParams mkB(int H, int W, int tw, int th) {
     snnhip::FusedBParams p{1, H, W, (W + tw - 1) / tw, (H + th - 1) / th, snnhip::make_act_cfg(0, 0.f)};

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
     // one 32-pixel tile per wave.  (A persistent walk over several tiles per wave, with the next tile's first chunks requested before the
     // epilogue, measured 10-100 % SLOWER the more tiles a wave owned: these layers live on memory-level parallelism, and a wave that is busy
     // with its 48-store epilogue is not issuing loads -- many short waves keep more requests in flight than few long ones.  Two tiles per wave
-    // side by side, sharing the LDS weight reads, also lost: 144->24 @56x56 b32 22.0 -> 23.6 us, 192->32 @28x28 9.2 -> 16.6 us.)
+    // side by side, sharing the LDS weight reads, also lost: 144->24 @56x56 b32 22.0 -> 23.6 us, 192->32 @28x28 9.2 -> 16.6 us.  So did
+    // requesting the first activation chunks BEFORE the weight staging above: vmcnt retires in order, so the L2-resident weights then wait for
+    // the HBM loads in front of them and the barrier moves out (16->96 @112x112 36.4 -> 42.2 us).)
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= p.nTiles) return;
     // chunk c of the tile's row l32 for this lane's K half; rows past M and chunks past IC read as zero (their products vanish / are not stored)

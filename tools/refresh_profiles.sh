@@ -1,8 +1,8 @@
 set -u
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01fin5
+O=gpurun_out/r01fin6
 mkdir -p $O
-timeout 900 tools/profile_gpu.sh r01fin5 > $O/profile.log 2>&1
+timeout 900 tools/profile_gpu.sh r01fin6 > $O/profile.log 2>&1
 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 300 python tools/bench_layers.py > $O/layers.txt 2>/dev/null
 timeout 300 python tools/bench_layers.py --fp16 > $O/layers_fp16.txt 2>/dev/null

@@ -1,4 +1,5 @@
-// conv1x1_stream.hip -- pointwise (1x1, stride 1 or 2) fp32 convolution as a streaming GEMM on v_mfma_f32_32x32x2_f32, for the layers whose time is
+// conv1x1_stream.hip -- pointwise (1x1, stride 1 or 2) convolution as a streaming GEMM on v_mfma_f32_32x32x2_f32 (fp32 tensors) or
+// v_mfma_f32_32x32x16_f16 (half tensors, see conv1x1_stream_f16_kernel), for the layers whose time is
 // their activation / output stream rather than their arithmetic: MobileNetV2's expand (16->96 ... 96->576) and project (96->24 ... 192->32)
 // convolutions at 112x112 .. 28x28 (BASELINE configs[3]).  Replaces shadertemplate_vk_conv2d_1x1.comp:68-210 of the reference for those
 // shapes; bias -> BN -> activation epilogue and the fused residual Add are those of conv2d_mfma_kernel (same helpers, same rounding points).
@@ -133,6 +134,115 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
         }
 }
 
+// fp16 tensors (half storage, fp32 accumulation on v_mfma_f32_32x32x16_f16): a chunk is 16 channels, lane (row, h) loads the 16 bytes
+// x[row][16c + 8h .. +7] and ONE MFMA consumes them.  A lane's results are single halfs of 16 different pixels; written directly they would
+// leave as 2-byte stores in 64-byte runs, so every wave transposes its 32 x BN tile through its own LDS region (no block barrier: the wave
+// only reads what it wrote itself) and stores 16-byte vectors, a pixel's BN channels contiguous.  The fused Add is applied there, on the
+// rounded convolution result, with conv2d_mfma's rounding points.  Needs OC % 8 == 0.
+template <int NT, bool SIMPLE>
+__global__ __launch_bounds__(256) void conv1x1_stream_f16_kernel(StreamParams p, ActCfg ac, const float* __restrict__ xv, const float4* __restrict__ wp,
+                                                              const float4* __restrict__ epi, float* __restrict__ yv) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    extern __shared__ float4 s_w[]; // [nChunks][2][BN] x 8 halfs, then 4 output tiles of 32 x (BN + 8) halfs
+    constexpr int BN = 32 * NT, EP = BN + 8;
+    constexpr int kDepth = NT == 1 ? 8 : 4;
+    const _Float16* __restrict__ x = reinterpret_cast<const _Float16*>(xv);
+    _Float16* __restrict__ y = reinterpret_cast<_Float16*>(yv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    {
+        const int cnt = p.nChunks * 2 * BN;
+        const float4* src = wp + static_cast<size_t>(blockIdx.y) * cnt;
+        for (int i = tid; i < cnt; i += 256) s_w[i] = src[i];
+    }
+    float4 e[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) e[u] = epi[n0 + u * 32 + l32];
+    __syncthreads();
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= p.nTiles) return;
+    const int arow = tile * 32 + l32;
+    int irow = arow < p.M ? arow : 0;
+    if (p.stride > 1) {
+        const unsigned n = static_cast<unsigned>(irow) / static_cast<unsigned>(p.OHW), rem = static_cast<unsigned>(irow) - n * p.OHW;
+        const unsigned oy = rem / static_cast<unsigned>(p.OW), ox = rem - oy * p.OW;
+        irow = static_cast<int>(n * p.HW + (oy * p.W + ox) * p.stride);
+    }
+    const _Float16* xrow = x + static_cast<size_t>(irow) * p.IC + h * 8;
+    auto loadA = [&](int c) -> float4 { // IC % 16 == 8: the upper half of the last chunk lies past the row and reads as zero
+        if (arow < p.M && c * 16 + h * 8 < p.IC) return *reinterpret_cast<const float4*>(xrow + c * 16);
+        return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    float4 nxt[kDepth];
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) nxt[d] = loadA(d);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[u][i] = 0.0f;
+    for (int c0 = 0; c0 < p.nChunks; c0 += kDepth) {
+        float4 cur[kDepth];
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) cur[d] = nxt[d];
+        if (c0 + kDepth < p.nChunks) {
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) nxt[d] = loadA(c0 + kDepth + d);
+        }
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) {
+            if (c0 + d < p.nChunks) { // wave-uniform
+                float4 b[NT];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) b[u] = s_w[((c0 + d) * 2 + h) * BN + u * 32 + l32];
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&cur[d]), *reinterpret_cast<const h8*>(&b[u]), acc[u], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: bias -> BN -> activation, rounded to half into the wave's own LDS tile [row][BN]
+    _Float16* const ot = reinterpret_cast<_Float16*>(s_w + p.nChunks * 2 * BN) + wave * 32 * EP;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 8 * g + 4 * h + k;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                float v = epi_affine(acc[u][4 * g + k], e[u], p.useBN);
+                v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+                ot[r * EP + u * 32 + l32] = static_cast<_Float16>(v);
+            }
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int VPR = BN / 8; // 16-byte vectors per row
+    const bool addSimple = act_is_simple_dev(p.ac2.act);
+    const _Float16* res = reinterpret_cast<const _Float16*>(p.res);
+#pragma unroll
+    for (int j = 0; j < 32 * VPR / 64; ++j) {
+        const int vi = lane + 64 * j;
+        const int r = vi / VPR, c8 = vi - r * VPR;
+        const int row = tile * 32 + r, oc = n0 + c8 * 8;
+        if (row < p.M && oc < p.OC) {
+            const size_t o = static_cast<size_t>(row) * p.OC + oc;
+            float4 pack = *reinterpret_cast<const float4*>(ot + r * EP + c8 * 8);
+            if (res) {
+                const float4 rpack = *reinterpret_cast<const float4*>(res + o);
+                const _Float16* ch = reinterpret_cast<const _Float16*>(&pack);
+                const _Float16* rh = reinterpret_cast<const _Float16*>(&rpack);
+                _Float16 oh[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) oh[q] = static_cast<_Float16>(add_act(p.ac2, addSimple, static_cast<float>(ch[q]) + static_cast<float>(rh[q])));
+                pack = *reinterpret_cast<const float4*>(oh);
+            }
+            *reinterpret_cast<float4*>(y + o) = pack;
+        }
+    }
+}
+
 struct Conv1x1StreamPlan : ConvPlanBase {
     StreamParams p;
     ActCfg ac;
@@ -170,6 +280,10 @@ template <int NT>
 decltype(Conv1x1StreamPlan::kernel) pick(bool simple) {
     return simple ? conv1x1_stream_kernel<NT, true> : conv1x1_stream_kernel<NT, false>;
 }
+template <int NT>
+decltype(Conv1x1StreamPlan::kernel) pick16(bool simple) {
+    return simple ? conv1x1_stream_f16_kernel<NT, true> : conv1x1_stream_f16_kernel<NT, false>;
+}
 
 } // namespace
 
@@ -178,7 +292,9 @@ decltype(Conv1x1StreamPlan::kernel) pick(bool simple) {
 int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     const char* sw = getenv("SNNHIP_CONV_1X1"); // 0: off; 2: also take few-tile deep-K layers (parity tests at oracle-sized shapes)
     if (sw && atoi(sw) == 0) return SNNHIP_E_UNSUPPORTED;
-    if (g.dtype != SNNHIP_F32 || g.kh != 1 || g.kw != 1 || g.sh != g.sw || g.sh < 1 || g.sh > 2 || g.preMode != 0 || g.padx != 0 || g.pady != 0) return SNNHIP_E_UNSUPPORTED;
+    const bool f16 = g.dtype == SNNHIP_F16;
+    if (f16 && g.OC % 8 != 0) return SNNHIP_E_UNSUPPORTED; // the fp16 variant stores 8-channel vectors
+    if ((g.dtype != SNNHIP_F32 && !f16) || g.kh != 1 || g.kw != 1 || g.sh != g.sw || g.sh < 1 || g.sh > 2 || g.preMode != 0 || g.padx != 0 || g.pady != 0) return SNNHIP_E_UNSUPPORTED;
     if ((g.OH - 1) * g.sh >= g.H || (g.OW - 1) * g.sw >= g.W || (g.sh == 1 && (g.OH != g.H || g.OW != g.W))) return SNNHIP_E_UNSUPPORTED;
     if (g.act == SNNHIP_ACT_SILU_QUIRK || g.IC < 8 || g.IC % 8 != 0 || g.OC < 16) return SNNHIP_E_UNSUPPORTED;
     const double M = static_cast<double>(g.N) * g.OH * g.OW;
@@ -195,11 +311,13 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     int NT = 0;
     for (int c = 3; c >= 1 && !NT; --c) {
         const int ocp = (g.OC + 32 * c - 1) / (32 * c) * (32 * c);
-        if ((c == 1 || (ocp - g.OC) * 3 <= g.OC) && static_cast<size_t>(g.IC) * 32 * c * 4 <= ldsCap) NT = c;
+        const size_t wBytes = f16 ? static_cast<size_t>((g.IC + 15) / 16) * 2 * 32 * c * 16 + static_cast<size_t>(4) * 32 * (32 * c + 8) * 2
+                                  : static_cast<size_t>(g.IC) * 32 * c * 4;
+        if ((c == 1 || (ocp - g.OC) * 3 <= g.OC) && wBytes <= ldsCap) NT = c;
     }
     if (!NT) return SNNHIP_E_UNSUPPORTED;
     if (g.IC >= 128 && static_cast<long long>((nTiles + 3) / 4) * ((g.OC + 32 * NT - 1) / (32 * NT)) < cus / 4 && !(sw && atoi(sw) == 2)) return SNNHIP_E_UNSUPPORTED;
-    const int BN = 32 * NT, ocBlocks = (g.OC + BN - 1) / BN, OCp = ocBlocks * BN, nChunks = g.IC / 8;
+    const int BN = 32 * NT, ocBlocks = (g.OC + BN - 1) / BN, OCp = ocBlocks * BN, nChunks = f16 ? (g.IC + 15) / 16 : g.IC / 8;
 
     auto* plan = new Conv1x1StreamPlan();
     plan->ctx = ctx;
@@ -211,9 +329,10 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     plan->ac = make_act_cfg(g.act, g.leaky);
     plan->fusedAdd = g.addAct >= 0;
     if (plan->fusedAdd) plan->numInputs = 2;
-    plan->ldsBytes = static_cast<size_t>(g.IC) * BN * 4;
+    plan->ldsBytes = static_cast<size_t>(nChunks) * 2 * BN * 16 + (f16 ? static_cast<size_t>(4) * 32 * (BN + 8) * 2 : 0);
     const bool simple = act_is_simple(g.act);
-    plan->kernel = NT == 3 ? pick<3>(simple) : NT == 2 ? pick<2>(simple) : pick<1>(simple);
+    if (f16) plan->kernel = NT == 3 ? pick16<3>(simple) : NT == 2 ? pick16<2>(simple) : pick16<1>(simple);
+    else plan->kernel = NT == 3 ? pick<3>(simple) : NT == 2 ? pick<2>(simple) : pick<1>(simple);
     const int gx = (nTiles + 3) / 4; // 4 waves = 4 tiles per block
     plan->grid = dim3(gx, ocBlocks);
     if (plan->ldsBytes > 64 * 1024 &&
@@ -222,16 +341,24 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
         return SNNHIP_E_UNSUPPORTED;
     }
 
-    // Wp[ocBlock][chunk][h][BN] float4: component j = w[oc][ic = 8*chunk + 4*h + j]
+    // Wp[ocBlock][chunk][h][BN] x 16 bytes: fp32 component j = w[oc][ic = 8*chunk + 4*h + j]; fp16 half j = w[oc][ic = 16*chunk + 8*h + j] (zero past IC)
     std::vector<float> wp(static_cast<size_t>(ocBlocks) * nChunks * 2 * BN * 4, 0.0f);
+    _Float16* wph = reinterpret_cast<_Float16*>(wp.data());
+    const int per = f16 ? 8 : 4;
     for (int ob = 0; ob < ocBlocks; ++ob)
         for (int c = 0; c < nChunks; ++c)
             for (int hh = 0; hh < 2; ++hh)
                 for (int o = 0; o < BN; ++o) {
                     const int oc = ob * BN + o;
                     if (oc >= g.OC) continue;
-                    float* dst = &wp[(((static_cast<size_t>(ob) * nChunks + c) * 2 + hh) * BN + o) * 4];
-                    for (int j = 0; j < 4; ++j) dst[j] = w_oihw[static_cast<size_t>(oc) * g.IC + c * 8 + hh * 4 + j];
+                    const size_t slot = ((static_cast<size_t>(ob) * nChunks + c) * 2 + hh) * BN + o;
+                    for (int j = 0; j < per; ++j) {
+                        const int ic = (c * 2 + hh) * per + j;
+                        if (ic >= g.IC) continue;
+                        const float wv = w_oihw[static_cast<size_t>(oc) * g.IC + ic];
+                        if (f16) wph[slot * 8 + j] = static_cast<_Float16>(wv);
+                        else wp[slot * 4 + j] = wv;
+                    }
                 }
     std::vector<float> epiP(static_cast<size_t>(OCp) * 4, 0.0f);
     std::memcpy(epiP.data(), epi4.data(), sizeof(float) * 4 * static_cast<size_t>(g.OC));
@@ -243,16 +370,17 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     }
     plan->inDims[0] = g.N; plan->inDims[1] = g.H; plan->inDims[2] = g.W; plan->inDims[3] = g.IC;
     plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
-    plan->dtype = SNNHIP_F32;
+    plan->dtype = g.dtype;
     plan->flops = 2.0 * g.IC * g.OC * M;
-    plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + M * g.OC + static_cast<double>(g.OC) * g.IC); // same accounting as the general kernel
+    const double esz = f16 ? 2.0 : 4.0;
+    plan->bytes = esz * (static_cast<double>(g.N) * g.H * g.W * g.IC + M * g.OC + static_cast<double>(g.OC) * g.IC); // same accounting as the general kernel
     char buf[256];
-    snprintf(buf, sizeof(buf), "conv2d_mfma_f32_32x32x2 k=1x1 s=%d ic=%d oc=%d stream: wave = 32px x %doc, grid %dx%d, lds=%zuB", g.sh, g.IC, g.OC, BN, gx, ocBlocks,
+    snprintf(buf, sizeof(buf), "conv2d_mfma_%s k=1x1 s=%d ic=%d oc=%d stream: wave = 32px x %doc, grid %dx%d, lds=%zuB", f16 ? "f16_32x32x16" : "f32_32x32x2", g.sh, g.IC, g.OC, BN, gx, ocBlocks,
              plan->ldsBytes);
     plan->desc = buf;
     if (plan->fusedAdd) {
         plan->desc += " +add";
-        plan->bytes += 4.0 * M * g.OC;
+        plan->bytes += esz * M * g.OC;
     }
     *out = plan;
     return SNNHIP_OK;

@@ -411,7 +411,8 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
 // heuristics were fitted on a handful of shapes; measured on the ResNet-18 body (fp16, batch 32) the best candidate is 10-25 % faster on
 // the 28x28 / 14x14 / 7x7 stages, where block count, residency and the split-K reduce pass trade against each other.
 int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
-    // large fp32 pointwise layers stream through conv1x1_stream.hip (no halo tile to stage); forcing a kernel or a configuration skips it
+    // pointwise layers (fp32, and fp16 with OC % 8 == 0) stream through conv1x1_stream.hip (no halo tile to stage); forcing a kernel or a
+    // configuration skips it
     if (!getenv("SNNHIP_CONV") && !getenv("SNNHIP_CONV_BN") && !getenv("SNNHIP_CONV_SPLITK") && !getenv("SNNHIP_CONV_C8")) {
         const int rc = make_conv1x1_stream_plan(ctx, g, w_oihw, epi4, out);
         if (rc != SNNHIP_E_UNSUPPORTED) return rc;

@@ -47,6 +47,52 @@ def test_fp16_conv_matches_quantised_oracle(ctx, case):
         assert np.abs(y - full).max() < 0.05, desc
 
 
+STREAM16 = [(2, 28, 28, 16, 96, 1, "relu6", True), (2, 28, 28, 24, 144, 1, "relu6", True), (1, 33, 47, 32, 192, 1, "relu", False),
+            (2, 14, 14, 96, 24, 1, "", True), (1, 19, 21, 144, 32, 1, "", True), (1, 9, 9, 8, 16, 1, "leakyRelu", True),
+            (1, 10, 10, 40, 576, 1, "SiLU", True), (2, 27, 31, 64, 128, 2, "", True), (1, 12, 12, 200, 64, 1, "tanh", False)]
+
+
+@pytest.mark.parametrize("case", STREAM16, ids=lambda c: "x".join(map(str, c)))
+def test_fp16_pointwise_stream_matches_quantised_oracle(ctx, monkeypatch, case):
+    """conv1x1_stream's fp16 variant: 16-channel chunks incl. a half-empty last one (IC % 16 == 8), the wave-local
+    LDS transpose of the output tile, stride 2; against the quantised oracle and the general fp16 kernel."""
+    N, H, W, IC, OC, s, act, use_bn = case
+    x = _rand((N, H, W, IC), 91)
+    w = _rand((OC, IC, 1, 1), 92, 1.0 / np.sqrt(IC))
+    b = _rand((OC,), 93, 0.1)
+    bn = _bn(OC, 94) if use_bn else None
+    monkeypatch.setenv("SNNHIP_CONV_1X1", "2")
+    y, desc = _conv16(ctx, x, w, b, s, (0, 0, 0, 0), "constant", act, bn)
+    assert "stream" in desc and "f16" in desc, desc
+    want = O._h(O.conv2d(O._h(x), O._h(w), b, s, (0, 0, 0, 0), "constant", act, 0.0, bn))
+    assert y.shape == want.shape, desc
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOLH)
+    monkeypatch.setenv("SNNHIP_CONV_1X1", "0")
+    y2, desc2 = _conv16(ctx, x, w, b, s, (0, 0, 0, 0), "constant", act, bn)
+    assert "stream" not in desc2, desc2
+    np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, **TOLH)
+
+
+def test_fp16_pointwise_stream_fused_add(ctx, monkeypatch):
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_CONV_1X1", "2")
+    n, h, w, ic, oc = 2, 28, 28, 144, 24
+    x, wt, b = _rand((n, h, w, ic), 61), _rand((oc, ic, 1, 1), 62, 1.0 / np.sqrt(ic)), _rand((oc,), 63, 0.1)
+    skip, bn = _rand((n, h, w, oc), 64), _bn(oc, 65)
+    conv = snn.conv2d_plan(ctx, n, h, w, wt, b, stride=1, pads=(0, 0, 0, 0), act="", bn=bn, dtype=snn.F16)
+    assert "stream" in conv.describe(), conv.describe()
+    add = snn.add_plan(ctx, n, h, w, oc, act="relu")
+    fused = snn.chain_plan(ctx, [conv, add])
+    assert fused.num_steps() == 1 and "stream" in fused.describe() and "+add" in fused.describe(), fused.describe()
+    xt, st = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16), snn.Tensor.from_numpy(ctx, skip, dtype=snn.F16)
+    y = fused([xt, st]).numpy()
+    c = O._h(O.conv2d(O._h(x), O._h(wt), b, 1, (0, 0, 0, 0), "constant", "", 0.0, bn))
+    want = O._h(O.add_act(c, O._h(skip), "relu", 0.0))
+    np.testing.assert_allclose(y, want, err_msg=fused.describe(), **TOLH)
+    np.testing.assert_allclose(y, add([conv(xt), st]).numpy(), **TOLH)
+
+
 def test_fp16_tensor_roundtrip_and_dtype_checks(ctx):
     import shadernn_amd as snn
 

@@ -30,6 +30,18 @@ from shadernn_amd import models  # noqa: E402
 
 REF = "/root/reference"
 
+C1_WINDOWS = {"interior": (slice(100, 104), slice(100, 104)), "top_left": (slice(0, 2), slice(0, 2)), "bottom_right": (slice(222, 224), slice(222, 224)),
+              "right_edge": (slice(60, 62), slice(222, 224))}
+
+
+def c1_inputs():
+    """C1 tensors from the reference tests' generator: SRAND(7767517); x ~ U(-1,1) [224*224*3], w ~ U(-1.2,1.2)/sqrt(27), b ~ U(-0.1,0.1)."""
+    v = O.reference_rand(7767517, 224 * 224 * 3 + 64 * 27 + 64, -1.0, 1.0)
+    x = v[: 224 * 224 * 3].reshape(1, 224, 224, 3).copy()
+    w = (v[224 * 224 * 3 : 224 * 224 * 3 + 64 * 27] * np.float32(1.2 / np.sqrt(27.0))).astype(np.float32).reshape(64, 3, 3, 3)
+    b = (v[-64:] * np.float32(0.1)).astype(np.float32)
+    return x, w, b
+
 
 def rnd(shape, seed, scale=1.0):
     return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
@@ -39,6 +51,29 @@ def bn(c, seed):
     r = np.random.default_rng(seed)
     return {"beta": r.uniform(-0.1, 0.1, c).astype(np.float32), "gamma": r.uniform(0.5, 1.5, c).astype(np.float32),
             "mean": r.uniform(-0.1, 0.1, c).astype(np.float32), "var": r.uniform(0.5, 1.5, c).astype(np.float32)}
+
+
+def torch_conv(x, w, b, stride, pads, pad_mode, act, leaky, bnp, out_hw):
+    """The same layer in plain torch CPU ops (F.pad + F.conv2d + the reference's BN / activation formulas): an implementation that
+    shares no code with oracle/snn_oracle.c.  Stored beside the oracle's output so the GPU tests compare against BOTH."""
+    import torch
+    import torch.nn.functional as F
+
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    pt, pb, pl, pr = pads
+    extra = 2 * max(w.shape[2], w.shape[3])  # room for the float output-size rule; cropped below
+    if pad_mode == "constant":
+        xt = F.pad(xt, (pl, pr + extra, pt, pb + extra))
+    else:
+        xt = F.pad(xt, (pl, pr, pt, pb), mode=pad_mode)
+        xt = F.pad(xt, (0, extra, 0, extra))
+    y = F.conv2d(xt, torch.from_numpy(w), None if b is None else torch.from_numpy(b), stride=stride)
+    if bnp is not None:  # vk_conv2d.comp:277-288: (v - mean) / max(sqrt(var + 1e-3), 1e-4) * gamma + beta
+        g = lambda k: torch.from_numpy(bnp[k]).view(1, -1, 1, 1)
+        y = (y - g("mean")) / torch.clamp(torch.sqrt(g("var") + 1e-3), min=1e-4) * g("gamma") + g("beta")
+    y = {"": lambda v: v, "relu": torch.relu, "relu6": lambda v: torch.clamp(v, 0, 6), "tanh": torch.tanh, "sigmoid": torch.sigmoid,
+         "leakyRelu": lambda v: torch.where(v > 0, v, v * leaky)}[act](y)
+    return y.permute(0, 2, 3, 1).numpy()[:, : out_hw[0], : out_hw[1]].copy()
 
 
 def main():
@@ -74,7 +109,9 @@ def main():
     x1 = np.ones((1, 8, 8, 128), np.float32)
     bn1 = {"beta": np.zeros(1, np.float32), "gamma": np.ones(1, np.float32), "mean": np.zeros(1, np.float32), "var": np.ones(1, np.float32)}
     y1 = O.conv2d(x1, w1, np.zeros(1, np.float32), 1, (0, 0, 0, 0), "constant", "", 0.0, bn1)
-    np.savez_compressed(os.path.join(HERE, "g1_convtest_8x8x128_k1.npz"), x=x1, w=w1, y=y1)
+    y1t = torch_conv(x1, w1, None, 1, (0, 0, 0, 0), "constant", "", 0.0, bn1, y1.shape[1:3])
+    assert np.allclose(y1, y1t, rtol=2e-5, atol=2e-5)
+    np.savez_compressed(os.path.join(HERE, "g1_convtest_8x8x128_k1.npz"), x=x1, w=w1, y=y1, y_torch=y1t)
 
     # ---- G2: 3x3 conv family
     import torch
@@ -95,8 +132,11 @@ def main():
                     y = O.conv2d(x, w, b, stride, (1, 1, 1, 1), pm, act, 0.1, bnp)
                     yt = O.conv2d_texel(x, w, b, stride, (1, 1, 1, 1), pm, act, 0.1, bnp)
                     assert np.allclose(y, yt, rtol=2e-5, atol=2e-6)
+                    ytorch = torch_conv(x, w, b, stride, (1, 1, 1, 1), pm, act, 0.1, bnp, y.shape[1:3])
+                    assert ytorch.shape == y.shape and np.allclose(y, ytorch, rtol=2e-5, atol=2e-5), (idx, np.abs(y - ytorch).max())
                     k = "c%d" % idx
                     g2[k + "_x"], g2[k + "_w"], g2[k + "_b"], g2[k + "_y"] = x, w, b, y
+                    g2[k + "_yt"] = ytorch
                     for q in ("beta", "gamma", "mean", "var"):
                         g2[k + "_bn_" + q] = bnp[q]
                     g2[k + "_meta"] = np.array([ic, oc, stride, {"constant": 1, "replicate": 2, "reflect": 3}[pm], O.ACT[act]])
@@ -116,6 +156,7 @@ def main():
         yt = torch.clamp(yt, 0, 6).permute(0, 2, 3, 1).numpy()[:, : y.shape[1], : y.shape[2]]
         assert np.allclose(y, yt, rtol=2e-5, atol=2e-5)
         g4["d%d_x" % i], g4["d%d_w" % i], g4["d%d_b" % i], g4["d%d_y" % i] = x, w, b, y
+        g4["d%d_yt" % i] = np.ascontiguousarray(yt)
         g4["d%d_meta" % i] = np.array([c, k, s])
     np.savez_compressed(os.path.join(HERE, "g4_depthwise.npz"), **g4)
 
@@ -130,8 +171,23 @@ def main():
     t = F.conv2d(t, torch.from_numpy(L[2]["w"]), torch.from_numpy(L[2]["b"]), padding=1)
     t = torch.tanh(F.pixel_shuffle(t, 2)).permute(0, 2, 3, 1).numpy()
     assert np.allclose(y, t, rtol=1e-5, atol=1e-5)
-    np.savez_compressed(os.path.join(HERE, "g6_espcn_32x32.npz"), x=x, y=y, conv1=layers[0], conv2=layers[1], conv3=layers[2],
+    np.savez_compressed(os.path.join(HERE, "g6_espcn_32x32.npz"), x=x, y=y, y_torch=np.ascontiguousarray(t), conv1=layers[0], conv2=layers[1], conv3=layers[2],
                         **{"w%d" % i: L[i]["w"] for i in range(3)}, **{"b%d" % i: L[i]["b"] for i in range(3)})
+    # ---- G3: BASELINE configs[0] (C1): 1x224x224x3 -> 64, 3x3 s1 same, relu.  Inputs come from the reference tests' generator
+    # (prng.h, pinned by prng_ref.json), so only the seed is stored; expected = checksums + sampled windows, from the
+    # oracle AND from torch.
+    x3, w3, b3 = c1_inputs()
+    y3 = O.conv2d(x3, w3, b3, 1, (1, 1, 1, 1), "constant", "relu", threads=8)
+    y3t = torch_conv(x3, w3, b3, 1, (1, 1, 1, 1), "constant", "relu", 0.0, None, (224, 224))
+    assert y3.shape == (1, 224, 224, 64) and np.allclose(y3, y3t, rtol=2e-5, atol=2e-5)
+    g3 = {"shape": np.array(y3.shape)}
+    for tag, yy in (("", y3), ("_torch", y3t)):
+        g3["sum" + tag], g3["abssum" + tag] = np.float64(yy.astype(np.float64).sum()), np.float64(np.abs(yy.astype(np.float64)).sum())
+        g3["rowsum" + tag] = yy.astype(np.float64).sum(axis=(0, 2, 3))   # 224 per-row sums: localises a wrong tile
+        g3["chansum" + tag] = yy.astype(np.float64).sum(axis=(0, 1, 2))  # 64 per-channel sums
+        for nm, (ys, xs) in C1_WINDOWS.items():
+            g3["win_" + nm + tag] = yy[0, ys, xs, :].copy()
+    np.savez_compressed(os.path.join(HERE, "g3_c1_224x224x3_64.npz"), **g3)
     print("golden vectors written to", HERE)
 
 

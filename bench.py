@@ -1,72 +1,238 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark: images/sec for ESPCN 2x super-resolution, 1080p -> 4K, fp32 (BASELINE configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c3|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path (conv5x5 1->16 relu, conv3x3 16->16 relu, conv3x3 16->4, depth-to-space(2)+tanh)
-over one synthetic 1x1080x1920x1 image per GPU, input already resident in HBM.  Multi-GPU = embarrassingly parallel
-batch split: every rank runs its own images, no data-path collective; RCCL is used only for the barrier / max-time
-reduction around the timed region.  Rank 0 prints ONE JSON line.
+`--gpus N` (N > 1) from a plain shell re-executes itself under torch.distributed.run with N ranks (one per GPU, RCCL).
+
+Configs (BASELINE.json `configs`, SURVEY 8d shapes; default c2 = the configuration the metric is quoted on):
+  c1  single 3x3 Conv2D, 1x224x224x3 -> 64, relu, fp32; one layer launch per step and rank                        (weak)
+  c2  ESPCN 2x 1080p -> 4K, batch 1 per rank, fp32 (conv5x5 1->16 relu, conv3x3 16->16 relu, conv3x3 16->4, d2s+tanh)  (weak)
+  c3  ResNet-18 224x224 fp32, batch 32 per rank                                                                    (weak)
+  c4  MobileNetV2 224x224 fp32, GLOBAL batch 256 sharded over the ranks (dist.shard_range), micro-batches of 32    (strong)
+  c5  Candy (fast-neural-style, the zoo graph) 720p fp16, GLOBAL batch 64 sharded over the ranks, micro-batches of 8 (strong)
+One "step" = one pass of the path over that batch, inputs already resident in HBM.  Multi-GPU = embarrassingly parallel batch
+split: no data-path collective; RCCL carries only the barrier / MAX-reduction of the elapsed time.
+Rank 0 prints ONE JSON line.
+
+Before the driver's `--warmup` steps a fixed time-based pre-heat (>= --preheat-ms of the workload, default 150 ms, reported as
+`preheat_ms`) brings the clocks up, so a 20-step run does not time the ramp.
 
 Extra objects on the line (prompt section 4):
-  roofline     -- dominant kernel (fused conv5x5+conv3x3, fp32 MFMA): algorithmic flops per launch / average launch
-                  duration measured live with HIP events on the launch stream over the timed region, vs the dense fp32
-                  MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md); plus the whole-step HBM view on the unfused accounting.
-                  The 3x3 layer runs as Winograd F(2x2,3x3): `achieved` counts the direct-convolution flops,
-                  `executed_mfma_*` the flops the matrix pipe really issues.
-  cpu_baseline -- the CPU oracle (kind "port": this repo's C restatement of the reference shaders; the reference has no
-                  CPU conv path) timed on this host on a bounded sample of the same workload.
+  roofline     -- dominant kernel of the step (largest average launch duration): algorithmic flops (or bytes) per launch / average
+                  launch duration measured live with HIP events on the launch stream inside the timed region, against the dense
+                  MFMA peak of the dtype (fp32 157.3 TFLOP/s, fp16 2500 TFLOP/s) or 8 TB/s HBM, whichever bounds that kernel.
+                  `traffic` = HBM bytes per launch from the committed PMC passes (profiles/pmc_latest.json), only when that file was
+                  taken with the kernel sources of this build (fingerprint match), else null.
+  cpu_baseline -- the CPU oracle (kind "port": this repo's C restatement of the reference shaders; the reference has no CPU conv
+                  path) timed on this host on a bounded sample of the same workload; for the configs with a Dense head also the
+                  reference's own Eigen dense path (oracle/_ref/ref_dense, kind "reference") timed beside it.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H, W = 1080, 1920
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
-PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 MFMA peak
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
+
+CONFIGS = {
+    "c1": {"workload": "single 3x3 Conv2D 1x224x224x3->64 relu fp32 (BASELINE configs[0])", "dtype": "f32", "scaling": "weak", "per_rank": 1, "micro": 1,
+           "hw": (224, 224), "cin": 3},
+    "c2": {"workload": "ESPCN 2x super-resolution 1080p->4K, batch 1 per GPU, fp32 (BASELINE configs[1])", "dtype": "f32", "scaling": "weak", "per_rank": 1,
+           "micro": 1, "hw": (1080, 1920), "cin": 1},
+    "c3": {"workload": "ResNet-18 224x224 fp32, batch 32 per GPU (BASELINE configs[2])", "dtype": "f32", "scaling": "weak", "per_rank": 32, "micro": 32,
+           "hw": (224, 224), "cin": 3},
+    "c4": {"workload": "MobileNetV2 224x224 fp32, global batch 256 sharded over the GPUs (BASELINE configs[3])", "dtype": "f32", "scaling": "strong",
+           "global": 256, "micro": 32, "hw": (224, 224), "cin": 3},
+    "c5": {"workload": "Candy fast-neural-style (zoo graph) 720p fp16, global batch 64 sharded over the GPUs (BASELINE configs[4])", "dtype": "f16",
+           "scaling": "strong", "global": 64, "micro": 8, "hw": (720, 1280), "cin": 3},
+}
 
 
-def cpu_baseline(net, images=2):
-    """Times the oracle on `images` full 1080p frames, single thread and all host threads (bounded: ~10-30 s)."""
+# ------------------------------------------------------------------------------------------------ workloads
+
+def zoo_net(name, shape):
+    from shadernn_amd import param_import
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "zoo_topologies.json")))[name]
+    ops = [{"type": o["type"], "name": o["name"], "inputs": o["inputs"], "outputs": o["outputs"], "params": {int(k): v for k, v in o["params"].items()}}
+           for o in fx["ops"]]
+    return param_import.from_ops(ops, name=name, seed=1, input_shape=shape)
+
+
+def make_net(config):
+    from shadernn_amd import models
+
+    if config == "c1":
+        return models.single_conv(seed=1)
+    if config == "c2":
+        return models.espcn_weights(seed=1)
+    if config == "c3":
+        return models.resnet18(seed=1)
+    if config == "c4":
+        return models.mobilenetv2(seed=1)
+    return zoo_net("candy-9_simplified-opt", (720, 1280, 3))
+
+
+def shard_plan(config, world, rank):
+    """(images of this rank per step, global batch, micro-batch sizes): c4 / c5 split a FIXED global batch with dist.shard_range
+    (GPU g of G gets images [g*B/G, (g+1)*B/G)), the other configs give every rank the same share."""
+    from shadernn_amd import dist as sdist
+
+    cfg = CONFIGS[config]
+    if "global" in cfg:
+        lo, hi = sdist.shard_range(cfg["global"], world, rank)
+        images, global_batch, first = hi - lo, cfg["global"], lo
+    else:
+        images, global_batch, first = cfg["per_rank"], cfg["per_rank"] * world, rank * cfg["per_rank"]
+    sizes, left = [], images
+    while left > 0:
+        sizes.append(min(cfg["micro"], left))
+        left -= sizes[-1]
+    return {"images": images, "global_batch": global_batch, "first_image": first, "micro_sizes": sizes}
+
+
+class Workload:
+    """The rank's share of one step: `images` images run as micro-batches through pre-built plans; run_device() only enqueues kernels."""
+
+    def __init__(self, ctx, config, net, sizes, unfused=False):
+        import shadernn_amd as snn
+
+        cfg = CONFIGS[config]
+        self.images = sum(sizes)
+        H, W = cfg["hw"]
+        dtype = snn.F16 if cfg["dtype"] == "f16" else snn.F32
+        self.runners, self.counts = [], []
+        for mb in sorted(set(sizes), reverse=True):
+            if config in ("c1", "c2"):
+                r = snn.ChainRunner(ctx, net, mb, H, W, fused=(config == "c2" and not unfused))
+                plans = list(r.plans)
+            else:
+                r = snn.GraphRunner(ctx, net, mb, H, W, dtype=dtype, fuse=not unfused)
+                plans = [st[0] for st in r.steps]
+            self.runners.append((r, plans))
+            self.counts.append(sizes.count(mb))
+        self.micro_sizes = sizes
+
+    def run_device(self):
+        for (r, _), n in zip(self.runners, self.counts):
+            for _ in range(n):
+                r.run_device()
+
+    def all_plans(self):
+        return [p for _, plans in self.runners for p in plans]
+
+    def cost(self):
+        f = b = 0.0
+        for (r, _), n in zip(self.runners, self.counts):
+            rf, rb = r.cost()
+            f += n * rf
+            b += n * rb
+        return f, b
+
+    def launches(self):
+        return sum(n * sum(p.num_steps() for p in plans) for (_, plans), n in zip(self.runners, self.counts))
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+
+def cpu_baseline(config, net):
+    """The oracle ("port") on a bounded sample of the workload, single thread and all host threads; dense heads also on the reference's
+    own Eigen path (oracle/_ref/ref_dense)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
 
     import oracle_lib
 
-    x = np.random.default_rng(7767517).random((1, H, W, 1), dtype=np.float32)
-    oracle_lib.forward(net, x[:, :64, :64, :])  # warm the library
-    t0 = time.perf_counter()
-    for _ in range(images):
-        oracle_lib.forward(net, x, threads=1)
-    t1 = time.perf_counter() - t0
+    cfg = CONFIGS[config]
+    H, W = cfg["hw"]
     cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    for _ in range(images):
-        oracle_lib.forward(net, x, threads=cores)
-    tn = time.perf_counter() - t0
-    best_t, best_c = (t1, 1) if t1 <= tn else (tn, cores)
-    return {"value": images / best_t, "unit": "images/s", "cores": best_c, "kind": "port",
-            "sample": "%d full 1x1080x1920x1 ESPCN frames through oracle/liboracle.so (C restatement of the reference shaders)" % images,
-            "single_thread_images_per_s": images / t1, "all_threads_images_per_s": images / tn, "host_threads": cores}
+    x = np.random.default_rng(7767517).random((1, H, W, cfg["cin"]), dtype=np.float32)
+    fp16 = cfg["dtype"] == "f16"
+    oracle_lib.forward(make_net("c2"), np.zeros((1, 32, 32, 1), np.float32))  # warm the library
+
+    def timed(threads, images):
+        t0 = time.perf_counter()
+        for _ in range(images):
+            oracle_lib.forward(net, x, threads=threads, fp16=fp16)
+        return (time.perf_counter() - t0) / images
+
+    # sample sizes chosen so the whole leg stays around 10-30 s of CPU work
+    n_multi = {"c1": 20, "c2": 2, "c3": 4, "c4": 8, "c5": 1}[config]
+    n_single = {"c1": 5, "c2": 2, "c3": 1, "c4": 2, "c5": 0}[config]
+    tn = timed(cores, n_multi)
+    t1 = timed(1, n_single) if n_single else None
+    best_t, best_c = (tn, cores) if (t1 is None or tn <= t1) else (t1, 1)
+    out = {"value": 1.0 / best_t, "unit": "images/s", "cores": best_c, "kind": "port",
+           "sample": "%d full-size image(s) of the workload (%s) through oracle/liboracle.so, the C restatement of the reference shaders, "
+                     "batch 1, all %d host threads%s" % (n_multi, cfg["workload"], cores, (" and %d single-threaded" % n_single) if n_single else ""),
+           "all_threads_images_per_s": 1.0 / tn, "single_thread_images_per_s": (1.0 / t1) if t1 else None, "host_threads": cores}
+    dense = [l for l in net["layers"] if l["type"] == "Dense"]
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_dense")
+    if dense and os.path.exists(ref):
+        l = dense[-1]
+        try:
+            act = l["activation"] if l["activation"] else "-"
+            sec = float(subprocess.run([ref, "--time", str(l["ic"]), str(l["units"]), act, "200"], stdout=subprocess.PIPE, text=True, timeout=120,
+                                       check=True).stdout.split()[0])
+            out["dense_reference"] = {"value": 1.0 / sec, "unit": "images/s (dense layer only)", "cores": 1, "kind": "reference",
+                                      "sample": "200 calls of the reference's CPUCommonUtil<float> (core/src/ic2/cpulayer.h:136-171, Eigen) on the %dx%d %s head, "
+                                                "batch 1, oracle/_ref/ref_dense --time" % (l["ic"], l["units"], l["activation"] or "linear"),
+                                      "us_per_call": sec * 1e6}
+        except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+            out["dense_reference"] = {"error": repr(e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def csrc_fingerprint():
+    from shadernn_amd import fingerprint
+
+    return fingerprint.csrc_sha16()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--unfused", action="store_true", help="one kernel per layer (debug / comparison)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--preheat-ms", type=float, default=150.0, help="run the workload untimed for at least this long before --warmup (clock ramp)")
+    ap.add_argument("--unfused", action="store_true", help="one kernel per layer, no chain fusion (debug / comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with events (overhead check)")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the kernel launches of every Nth timed step with HIP events (each pair costs ~4.5 us of stream time)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = {"c1": 500, "c2": 200, "c3": 50, "c4": 20, "c5": 10}[args.config]
+    if args.warmup is None:
+        args.warmup = {"c1": 50, "c2": 20, "c3": 5, "c4": 3, "c5": 2}[args.config]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started from a plain shell: become N ranks (one process per GPU) under torch.distributed.run
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     import torch
 
@@ -75,47 +241,68 @@ def main():
     rank, local_rank, world = sdist.env_rank_world()
     if world != args.gpus:
         if rank == 0:
-            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)\n" % (args.gpus, world))
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         sys.exit(2)
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; the HIP path has no CPU fallback\n")
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
+    if torch.cuda.device_count() < world and rank == 0:
+        sys.stderr.write("bench.py: %d ranks on %d visible GPU(s)\n" % (world, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     group = sdist.Group(backend="nccl")  # nccl == RCCL on ROCm; only barrier + MAX-reduction of the time use it
 
     import shadernn_amd as snn
-    from shadernn_amd import models
 
     snn.load_library()
-    stream = torch.cuda.Stream(device=local_rank)
-    ctx = snn.Context(local_rank, stream=stream.cuda_stream)
+    dev = torch.cuda.current_device()
+    stream = torch.cuda.Stream(device=dev)
+    ctx = snn.Context(dev, stream=stream.cuda_stream)
     info = ctx.info()
-    net = models.espcn_weights(seed=1)
-    runner = snn.EspcnRunner(ctx, net, 1, H, W, fused=not args.unfused)
+    net = make_net(args.config)
+    shard = shard_plan(args.config, world, rank)
+    images, global_batch = shard["images"], shard["global_batch"]
+    if images == 0:
+        sys.stderr.write("bench.py: rank %d has no images (global batch %d over %d ranks)\n" % (rank, global_batch, world))
+        sys.exit(2)
+    wl = Workload(ctx, args.config, net, shard["micro_sizes"], unfused=args.unfused)
 
-    # synthetic input, generated on the device (U(0,1), seed echoing the reference's SRAND(7767517)), resident in HBM
-    g = torch.Generator(device="cuda")
-    g.manual_seed(7767517 + rank)
-    x = torch.rand((1, H, W, 1), generator=g, device="cuda", dtype=torch.float32)
-    runner.x = snn.Tensor.from_torch(ctx, x)
+    # synthetic input (U(0,1), seed echoing the reference's SRAND(7767517), a different stream per rank), uploaded once: resident in HBM
+    import numpy as np
+
+    rng = np.random.default_rng(7767517 + rank)
+    for r, _ in wl.runners:
+        r.x.upload(rng.random(r.in_shape, dtype=np.float32))
+    ctx.sync()
     torch.cuda.synchronize()
 
     barrier = group.barrier  # dist.barrier + torch.cuda.synchronize()
 
+    # time-based pre-heat, then the driver's warmup steps
+    t0 = time.perf_counter()
+    pre_steps = 0
+    while True:
+        for _ in range(4):
+            wl.run_device()
+        pre_steps += 4
+        ctx.sync()
+        if 1e3 * (time.perf_counter() - t0) >= args.preheat_ms:
+            break
+    preheat_ms = 1e3 * (time.perf_counter() - t0)
     for _ in range(args.warmup):
-        runner.run_device()
+        wl.run_device()
     barrier()
 
     profile = not args.no_kernel_events
     every = max(1, args.event_every)
+    plans = wl.all_plans()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if profile and (i % every == 0 or i % every == 1):  # toggle only at the sampled step and right after it
             on = i % every == 0
-            for p in runner.plans:
+            for p in plans:
                 p.profile(on)
-        runner.run_device()
+        wl.run_device()
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -124,7 +311,7 @@ def main():
     # per-kernel launch durations from the event pairs recorded inside the timed region
     kernels = []
     if profile:
-        for p in runner.plans:
+        for p in plans:
             for i in range(p.num_steps()):
                 ms, n = p.profile_read(i)
                 fl, by = p.step_cost(i)
@@ -132,51 +319,69 @@ def main():
                     kernels.append({"kernel": p.step_describe(i), "launches": n, "avg_us": 1e3 * ms / n, "flops": fl, "bytes": by})
 
     if rank == 0:
-        flops, bytes_unfused = runner.cost()
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.steps / elapsed
+        flops, bytes_unfused = wl.cost()
+        flops_img, bytes_img = flops / images, bytes_unfused / images
+        step_s = elapsed / args.steps
+        value = global_batch * args.steps / elapsed
+        peak_tf = PEAK_F16_MFMA_TFLOPS if cfg["dtype"] == "f16" else PEAK_F32_MFMA_TFLOPS
+        H, W = cfg["hw"]
         out = {
-            "metric": "images/sec (1080p ESPCN 2x) at 1/2/4/8 MI355X; achieved HBM GB/s",
+            "metric": "images/sec (1080p ESPCN 2x) at 1/2/4/8 MI355X; achieved HBM GB/s" if args.config == "c2" else "images/sec (%s)" % cfg["workload"],
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ESPCN 2x super-resolution 1080p->4K, batch 1 per GPU, fp32 (BASELINE configs[1])",
-                       "global_batch": world, "input": [1, H, W, 1], "output": [1, 2 * H, 2 * W, 1],
-                       "parallelism": "dp%d (independent images per rank, no data-path collective)" % world,
-                       "path": "fused chain (2 kernels)" if not args.unfused else "one kernel per layer (4 kernels)",
+            "ms_per_step": 1e3 * step_s, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
+            "dtype": cfg["dtype"], "data": "synthetic", "preheat_ms": preheat_ms, "preheat_steps": pre_steps,
+            "config": {"workload": cfg["workload"], "config_id": args.config, "global_batch": global_batch, "images_per_rank_per_step": images,
+                       "micro_batches_per_rank": wl.micro_sizes, "input": [images, H, W, cfg["cin"]],
+                       "parallelism": "dp%d (batch split, weights replicated, no data-path collective)" % world,
+                       "path": ("fused chain plans" if not args.unfused else "one kernel per layer") + ", %d kernel launches per step" % wl.launches(),
                        "device": info["name"], "compute_units": info["compute_units"]},
-            "flops_per_image": flops, "bytes_per_image_unfused_accounting": bytes_unfused,
-            "achieved_tflops_per_gpu": flops / (elapsed / args.steps) / 1e12,
-            "achieved_hbm_gbps_unfused_accounting_per_gpu": bytes_unfused / (elapsed / args.steps) / 1e9,
-            "frac_hbm_roofline_unfused_accounting": bytes_unfused / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBPS,
-            "frac_f32_compute_roofline": flops / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "kernels": kernels,
+            "flops_per_image": flops_img, "bytes_per_image_unfused_accounting": bytes_img,
+            "achieved_tflops_per_gpu": flops / step_s / 1e12,
+            "achieved_hbm_gbps_unfused_accounting_per_gpu": bytes_unfused / step_s / 1e9,
+            "frac_hbm_roofline_unfused_accounting": bytes_unfused / step_s / 1e9 / PEAK_HBM_GBPS,
+            "frac_compute_roofline": flops / step_s / 1e12 / peak_tf,
+            "whole_step_roofline_ms": 1e3 * max(flops / peak_tf / 1e12, bytes_unfused / PEAK_HBM_GBPS / 1e9),
+            "kernels": sorted(kernels, key=lambda k: -k["avg_us"] * k["launches"])[:12],
         }
+        out["frac_of_whole_step_roofline"] = out["whole_step_roofline_ms"] / out["ms_per_step"]
         if kernels:
             dom = max(kernels, key=lambda k: k["avg_us"])
-            ach = dom["flops"] / (dom["avg_us"] * 1e-6) / 1e12
-            tags = dict(t.split("=", 1) for t in dom["kernel"].split(" ") if "=" in t and not t.startswith("tile"))
-            traffic = None
+            t = dom["avg_us"] * 1e-6
+            mfma_bound = dom["flops"] / (peak_tf * 1e12) >= dom["bytes"] / (PEAK_HBM_GBPS * 1e9)
+            tags = dict(tk.split("=", 1) for tk in dom["kernel"].split(" ") if "=" in tk and not tk.startswith("tile"))
+            traffic, traffic_source = None, "no PMC entry for this kernel in profiles/pmc_latest.json"
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")  # written by tools/profile_gpu.sh -> summarize_prof.py, keyed by kernel function
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(tags.get("kernel", ""), {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                               "traffic": traffic, "kernel": dom["kernel"], "avg_launch_us": dom["avg_us"],
-                               "algorithmic_flops_per_launch": dom["flops"], "algorithmic_bytes_per_launch": dom["bytes"],
-                               "hbm_gbps_of_this_kernel": dom["bytes"] / (dom["avg_us"] * 1e-6) / 1e9}
+                    ent = json.load(open(pmc)).get(tags.get("kernel", dom["kernel"].split(" ")[0]), None)
+                    if ent is not None:
+                        if ent.get("csrc_sha16") == csrc_fingerprint():
+                            traffic = ent.get("hbm_bytes_per_launch")
+                            traffic_source = "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s, commit %s)" % (
+                                ent.get("csrc_sha16"), ent.get("git_head"))
+                        else:
+                            traffic_source = "stale: profiles/pmc_latest.json was taken with kernel sources %s, this build is %s" % (ent.get("csrc_sha16"), csrc_fingerprint())
+                except Exception as e:
+                    traffic_source = "unreadable: %r" % (e,)
+            if mfma_bound:
+                ach = dom["flops"] / t / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
+            else:
+                ach = dom["bytes"] / t / 1e9
+                out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBPS}
+            out["roofline"].update({"traffic": traffic, "traffic_source": traffic_source, "kernel": dom["kernel"], "avg_launch_us": dom["avg_us"],
+                                    "algorithmic_flops_per_launch": dom["flops"], "algorithmic_bytes_per_launch": dom["bytes"],
+                                    "hbm_gbps_of_this_kernel": dom["bytes"] / t / 1e9})
             if "mfma_flops" in tags:
                 # `achieved` uses the ALGORITHMIC flops of the direct convolutions (2*k*k*IC*OC per output pixel).  The kernel
                 # evaluates its 3x3 layer as Winograd F(2x2,3x3) (2.25x fewer multiplies) but recomputes conv1 on the tile halo: the
                 # flops the matrix pipe really executes, and its utilisation, are reported next to it.
                 ex = float(tags["mfma_flops"])
                 out["roofline"]["executed_mfma_flops_per_launch"] = ex
-                out["roofline"]["executed_mfma_tflops"] = ex / (dom["avg_us"] * 1e-6) / 1e12
-                out["roofline"]["frac_executed"] = ex / (dom["avg_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                out["roofline"]["executed_mfma_tflops"] = ex / t / 1e12
+                out["roofline"]["frac_executed"] = ex / t / 1e12 / peak_tf
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(net)
+            out["cpu_baseline"] = cpu_baseline(args.config, net)
         print(json.dumps(out))
     group.barrier()
     group.close()

@@ -13,6 +13,9 @@
  * stdin : "<In> <Out> <activation|-> <leakyAlpha>\n" then Out*In kernel floats (the parser's FLAT kernel array),
  *         Out bias floats, In input floats.
  * stdout: Out result floats, %.9g, one per line.
+ * Timing mode (bench.py's cpu_baseline leg for the dense rows): `ref_dense --time <In> <Out> <activation|-> <reps>`
+ *         runs the same call sequence `reps` times on fixed pseudo-random data (a new CPUCommonUtil per call, as
+ *         DenseLayer::computeImageTexture does) and prints "<seconds per call> <checksum>".
  * Mirrors DenseLayer::computeImageTexture (core/src/ic2/denselayer.cpp:27-38) and ModelParser::getDenseLayer's
  * [In][Out]-shaped row split of the flat kernel (core/src/ic2/modelparser.cpp:527-535).
  */
@@ -21,8 +24,10 @@
 #include "snn/image.h"
 #include "ic2/cpulayer.h"
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -41,7 +46,34 @@ void rip() { abort(); }
 float convertToHighPrecision(uint16_t) { abort(); }
 } // namespace snn
 
-int main() {
+static int time_mode(int In, int Out, std::string act, int reps) {
+    if (act == "-") act = "";
+    std::vector<std::vector<float>> weights(In, std::vector<float>(Out));
+    std::vector<float> bias(Out), x(In);
+    unsigned s = 12345u;
+    auto rnd = [&s]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto& row : weights)
+        for (auto& v : row) v = rnd() * 0.1f;
+    for (auto& v : bias) v = rnd();
+    for (auto& v : x) v = rnd();
+    auto transformMats = std::pair<std::vector<std::vector<float>>, std::vector<float>>(weights, bias);
+    double checksum = 0.0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+        std::vector<std::vector<float>> inputMat(1, x);
+        auto cpuL = snn::dp::CPUCommonUtil<float> {act, 0.1f, true};
+        cpuL.inputMat.emplace(inputMat);
+        cpuL.run(transformMats);
+        auto out = cpuL.getOutputs();
+        checksum += out[0][r % Out];
+    }
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("%.9g %.9g\n", sec / reps, checksum);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc == 6 && strcmp(argv[1], "--time") == 0) return time_mode(atoi(argv[2]), atoi(argv[3]), argv[4], atoi(argv[5]));
     int In, Out;
     std::string act;
     float alpha;

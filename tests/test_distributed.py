@@ -77,3 +77,88 @@ def test_shard_range_covers_everything_once():
                 assert a[1] == b[0]
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- bench.py --config c4 / c5: a FIXED global batch sharded over the ranks (BASELINE configs[3], [4]) ----
+
+def _c4_worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import bench
+    import oracle_lib as O
+    from shadernn_amd import dist, models
+
+    g = dist.Group(backend="gloo")
+    shard = bench.shard_plan("c4", world, rank)  # the split bench.py times: 256 images -> 128 per rank, micro-batches of 32
+    assert shard["global_batch"] == 256 and shard["images"] == 128 and shard["micro_sizes"] == [32] * 4 and shard["first_image"] == 128 * rank
+    # compute stand-in (no GPU here): the oracle on a width-reduced MobileNetV2 at 16x16, image i = f(i) so the shard identity is checkable
+    net = models.mobilenetv2(seed=1, num_classes=4, width_mult=0.25)
+    rng = np.random.default_rng(7)
+    batch = rng.random((shard["global_batch"], 16, 16, 3), dtype=np.float32)
+    sums = np.zeros(shard["global_batch"], np.float32)
+    pos = shard["first_image"]
+    g.barrier()
+    for mb in shard["micro_sizes"]:
+        y = O.forward(net, batch[pos : pos + mb]).reshape(mb, -1)
+        sums[pos : pos + mb] = (y * np.arange(1, y.shape[1] + 1)).sum(axis=1)
+        pos += mb
+    g.barrier()
+    parts = g.gather_arrays(sums)  # check only: the timed path gathers nothing
+    n_total = g.sum_over_ranks(shard["images"])
+    if rank == 0:
+        merged = np.sum(parts, axis=0)  # every image is written by exactly one rank, zeros elsewhere
+        probe = [0, 31, 32, 127, 128, 200, 255]
+        want = np.array([(O.forward(net, batch[i : i + 1]).reshape(-1) * np.arange(1, 5)).sum() for i in probe], np.float32)
+        q.put((n_total, float(np.abs(merged[probe] - want).max()), int((merged != 0).sum())))
+    g.barrier()
+    g.close()
+
+
+def test_c4_global_batch_shards_over_two_ranks_gloo():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_c4_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n_total, err, nonzero = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert n_total == 256.0 and nonzero == 256
+    assert err < 1e-5            # an image's result does not depend on the rank / micro-batch it ran in
+
+
+def test_shard_plan_every_config_and_world():
+    import bench
+
+    for cfgname, cfg in bench.CONFIGS.items():
+        for world in (1, 2, 4, 8):
+            plans = [bench.shard_plan(cfgname, world, r) for r in range(world)]
+            assert sum(p["images"] for p in plans) == plans[0]["global_batch"]
+            assert [p["first_image"] for p in plans] == [sum(q["images"] for q in plans[:r]) for r in range(world)]
+            assert all(max(p["micro_sizes"]) <= cfg["micro"] and sum(p["micro_sizes"]) == p["images"] for p in plans)
+            if "global" in cfg:
+                assert plans[0]["global_batch"] == cfg["global"]  # strong scaling: total work fixed
+            else:
+                assert plans[0]["global_batch"] == world * cfg["per_rank"]
+    assert bench.shard_plan("c4", 8, 3) == {"images": 32, "global_batch": 256, "first_image": 96, "micro_sizes": [32]}
+    assert bench.shard_plan("c5", 8, 7) == {"images": 8, "global_batch": 64, "first_image": 56, "micro_sizes": [8]}
+
+
+def test_bench_self_spawns_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE re-executes under torch.distributed.run: both ranks start (and, with no GPU in this
+    container, both refuse to run: the HIP path has no CPU fallback)."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c4", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and '"n_gpus": 2' in r.stdout
+    elif not torch.cuda.is_available():
+        assert r.returncode != 0
+        assert r.stderr.count("no GPU visible") >= 2, r.stderr[-2000:]

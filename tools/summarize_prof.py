@@ -84,12 +84,17 @@ def main():
     # compact per-kernel HBM traffic, keyed by the bare kernel function name (template arguments stripped): bench.py reads
     # profiles/pmc_latest.json in this format for the `roofline.traffic` field
     pmc = {}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from shadernn_amd import fingerprint
+
+    sha = fingerprint.csrc_sha16()  # bench.py only reports `traffic` from a file taken with the kernel sources it runs
+    head = os.environ.get("SNN_GIT_HEAD", "")
     for k, d in res["kernels"].items():
         if "hbm_read_bytes_corrected_x2" in d and "hbm_write_bytes" in d:
             base = k.split("<")[0].strip()
             pmc[base] = {"hbm_bytes_per_launch": d["hbm_read_bytes_corrected_x2"] + d["hbm_write_bytes"],
                          "read_bytes_x2_corrected": d["hbm_read_bytes_corrected_x2"], "write_bytes": d["hbm_write_bytes"],
-                         "avg_us_kernel_trace": d.get("avg_us"), "mfma_pipe_util": d.get("mfma_pipe_util"), "eff_clock_ghz": d.get("eff_clock_ghz"),
+                         "csrc_sha16": sha, "git_head": head, "avg_us_kernel_trace": d.get("avg_us"), "mfma_pipe_util": d.get("mfma_pipe_util"), "eff_clock_ghz": d.get("eff_clock_ghz"),
                          "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_gpu.sh); FETCH_SIZE KiB x2 "
                                    "per MI355X_MICROARCH.md HBM section"}
     json.dump(pmc, open(os.path.join(out, "pmc_by_kernel.json"), "w"), indent=1)

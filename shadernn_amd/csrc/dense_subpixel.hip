@@ -8,6 +8,7 @@
 // subpixel: replaces shadertemplate_vk_subpixel.comp:43-71 (depth-to-space(2) + tanh), both the true d2s channel
 //   selection (fs_subpixel.glsl:41-64) and the Vulkan shader's depth-slice quirk.
 #include "epilogue.h"
+#include "plan_util.h"
 #include "snnhip_internal.h"
 
 namespace snnhip {
@@ -153,8 +154,9 @@ struct DensePlan : snnhip_plan {
     }
 };
 
-__global__ __launch_bounds__(256) void subpixel_kernel(int N, int H, int W, int C, int f, int mode, const float* __restrict__ x,
-                                                       float* __restrict__ y) {
+// T = float or _Float16 storage (the reference's RGBA16F path: ESPCN with preferHp); tanh in fp32, round-to-nearest store
+template <typename T>
+__global__ __launch_bounds__(256) void subpixel_kernel(int N, int H, int W, int C, int f, int mode, const T* __restrict__ x, T* __restrict__ y) {
     const int OH = H * f, OW = W * f;
     const size_t total = static_cast<size_t>(N) * OH * OW;
     const int depth = (C + 3) / 4;
@@ -166,14 +168,15 @@ __global__ __launch_bounds__(256) void subpixel_kernel(int N, int H, int W, int 
         const int x1 = min(ox / f, W - 1), y1 = min(oy / f, H - 1);
         const int z1 = (ox % f) + (oy % f) * f;
         const int ch = (mode == SNNHIP_SUBPIXEL_VK_QUIRK) ? min(z1, depth - 1) * 4 : z1;
-        const float v = ch < C ? x[((static_cast<size_t>(n) * H + y1) * W + x1) * C + ch] : 0.0f;
-        y[idx] = tanhf(v);
+        const float v = ch < C ? static_cast<float>(x[((static_cast<size_t>(n) * H + y1) * W + x1) * C + ch]) : 0.0f;
+        y[idx] = static_cast<T>(tanhf(v));
     }
 }
 
 struct SubpixelPlan : SubpixelPlanBase {
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "subpixel: expects 1 input, got %d", nIn);
+        SNNHIP_SAME_DTYPE("subpixel");
         const snnhip_tensor* x = in[0];
         SNNHIP_REQUIRE(x->n == d.N && x->h == d.H && x->w == d.W && x->c == d.C, "subpixel: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h,
                        x->w, x->c, d.N, d.H, d.W, d.C);
@@ -184,8 +187,8 @@ struct SubpixelPlan : SubpixelPlanBase {
         const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount) * 16;
         if (blocks > cap) blocks = cap;
         if (blocks == 0) return SNNHIP_OK;
-        hipLaunchKernelGGL(subpixel_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, d.factor, d.mode,
-                           x->data, out->data);
+        SNNHIP_WITH_T(out->dtype, hipLaunchKernelGGL((subpixel_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d.N, d.H, d.W,
+                                                     d.C, d.factor, d.mode, cptr<T>(x), mptr<T>(out)););
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -230,8 +233,9 @@ int make_subpixel_plan(snnhip_ctx* ctx, const snnhip_subpixel_desc& d, snnhip_pl
     plan->flops = 0;
     plan->bytes = 4.0 * (static_cast<double>(d.N) * d.H * d.W * d.C + static_cast<double>(d.N) * d.H * d.W * d.factor * d.factor);
     char buf[128];
-    snprintf(buf, sizeof(buf), "subpixel_f32 f=%d mode=%d c=%d", d.factor, d.mode, d.C);
+    snprintf(buf, sizeof(buf), "subpixel f=%d mode=%d c=%d", d.factor, d.mode, d.C);
     plan->desc = buf;
+    plan->anyDtype = true; // element type taken from the tensors of the call (fp32 or half)
     *out = plan;
     return SNNHIP_OK;
 }

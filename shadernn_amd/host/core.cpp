@@ -109,10 +109,22 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
     if (gpuRunTime) gpuRunTime->start();
     bool replayed = false, recordingNow = false;
     if (graphUsable) {
-        std::vector<const void*> ins;
-        for (size_t k = 0; k < rp.inputImages->size(); ++k) ins.push_back((*rp.inputImages)[k].tensor());
+        // The captured kernels hold DEVICE pointers: key the recording on (device address, dims, dtype) of every model input, not on
+        // the host-side tensor handle (an input texture that re-creates its tensor may get the same handle address back with another
+        // buffer behind it, and the other way round).
+        std::vector<InputKey> ins;
+        for (size_t k = 0; k < rp.inputImages->size(); ++k) {
+            const snnhip_tensor* t = (*rp.inputImages)[k].tensor();
+            InputKey key{};
+            if (t) {
+                key.data = snnhip_tensor_data(t);
+                snnhip_tensor_dims(t, key.dims);
+                key.dtype = snnhip_tensor_dtype(t);
+            }
+            ins.push_back(key);
+        }
         if (ins == recordedInputs && backend->replay()) {
-            replayed = true; // same input textures as when the launch sequence was recorded: one host call
+            replayed = true; // same input buffers as when the launch sequence was recorded: one host call
         } else {
             recordedInputs = ins;
             recordingNow = backend->beginRecord();

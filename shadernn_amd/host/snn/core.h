@@ -67,7 +67,15 @@ private:
     RenderStagesArray stages;
     dp::DeviceBackend* backend = nullptr;
     DeviceTimer* gpuRunTime = nullptr;
-    std::vector<const void*> recordedInputs; // device tensors the recording reads (delay-bound model inputs)
+    struct InputKey { // what a recorded launch sequence depends on: the device buffer (address), its extent and element type
+        const void* data;
+        int dims[4];
+        int dtype;
+        bool operator==(const InputKey& o) const {
+            return data == o.data && dims[0] == o.dims[0] && dims[1] == o.dims[1] && dims[2] == o.dims[2] && dims[3] == o.dims[3] && dtype == o.dtype;
+        }
+    };
+    std::vector<InputKey> recordedInputs; // device buffers the recording reads (delay-bound model inputs)
     bool graphUsable = false;
     Timer cpuRunTime = Timer("IC2 Total CPU Runtime");
     explicit MixedInferenceCore(GpuContext* context_);

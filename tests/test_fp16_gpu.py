@@ -179,3 +179,36 @@ def test_fp16_json_model_through_host_mirror(ctx, tmp_path):
     err = np.abs(y.reshape(-1) - want.reshape(-1)) / scale
     assert np.quantile(err, 0.999) < 6e-3 and err.max() < 6e-2, (float(np.quantile(err, 0.999)), float(err.max()))
     m.close()
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_fp16_espcn_json_model_through_host_mirror(ctx, tmp_path, fuse):
+    """The headline ESPCN model with preferHp (the reference's RGBA16F path): every layer incl. the Subpixel lambda takes half tensors
+    (the fp32-only fusion rules A/B/C step aside), against the oracle with the same quantisation points."""
+    import copy
+
+    import shadernn_amd as snn
+    from shadernn_amd import host, models
+
+    net = models.espcn_weights(seed=1)
+    w, h = 48, 40
+    path = models.write_json(net, w, h, str(tmp_path / "espcn16.json"))
+    x = np.random.default_rng(8).random((1, h, w, 1), dtype=np.float32)
+    m = host.Model(path, w, h, 1, fuse_chains=fuse, prefer_half=True)
+    y = m(x)
+    assert y.shape == (2 * h, 2 * w, 1) or y.shape == (1, 2 * h, 2 * w, 1)
+    q = copy.deepcopy(net)
+    trunc = np.vectorize(O.to_medium_precision, otypes=[np.float32])  # the parser truncates weights / bias to half (Q13)
+    for l in q["layers"]:
+        for k in ("w", "b"):
+            if l.get(k) is not None:
+                l[k] = trunc(np.asarray(l[k], np.float32))
+    want = O.forward(q, x, fp16=True)
+    np.testing.assert_allclose(y.reshape(-1), want.reshape(-1), rtol=4e-3, atol=4e-3)
+    np.testing.assert_allclose(y.reshape(-1), O.forward(net, x).reshape(-1), atol=0.02)
+    m.close()
+    # and the stand-alone Subpixel plan on half tensors
+    t = np.random.default_rng(9).standard_normal((2, 5, 7, 4)).astype(np.float32)
+    p = snn.subpixel_plan(ctx, 2, 5, 7, 4, 2, 0)
+    got = p(snn.Tensor.from_numpy(ctx, t, dtype=snn.F16)).numpy()
+    np.testing.assert_allclose(got, O._h(O.subpixel(O._h(t), 2, 0)), rtol=1e-3, atol=1e-3)

@@ -377,6 +377,36 @@ def test_u8_image_preprocessing_on_device(ctx, tmp_path, ch):
 
 
 @pytest.mark.gpu
+def test_graph_capture_with_u8_uploads_between_runs(ctx, tmp_path):
+    """capture_graph=True while snn_model_upload_input_u8 re-creates the input tensor before every run (loadU8AndNormalize + resize free and
+    re-allocate it): a recorded launch sequence is replayed only when the input's DEVICE buffer, extent and type are the recorded ones, so every
+    run must see the image just uploaded -- images of changing source size force changing intermediate allocations in between."""
+    from shadernn_amd import host, models
+
+    net = {"name": "two_convs", "input_channels": 4,
+           "layers": models.single_conv(seed=9, ic=4, oc=8, k=3, act="relu")["layers"] + models.single_conv(seed=10, ic=8, oc=4, k=3, act="tanh")["layers"]}
+    net["layers"][1]["name"] = "conv2d_b"
+    path = _json(tmp_path, net, 32, 24)
+    m = host.Model(path, 32, 24, 4, capture_graph=True)
+    ref = host.Model(path, 32, 24, 4)
+    rn = (1 / 255.0,) * 4
+    rng = np.random.default_rng(77)
+    for k, (ih, iw) in enumerate([(45, 70), (45, 70), (24, 32), (60, 33), (45, 70), (24, 32), (24, 32)]):
+        img = rng.integers(0, 256, (ih, iw, 4), dtype=np.uint8)
+        for mm in (m, ref):
+            mm.upload_u8(img, (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0), rn)
+            mm.run()
+        t = O.resize(O.image_u8(img[None], (0, 0, 0, 0), (1, 1, 1, 1)), 24, 32, (0, 0, 0, 0), rn, True)
+        np.testing.assert_array_equal(m.output(), ref.output(), err_msg="run %d" % k)
+        np.testing.assert_allclose(m.output().reshape(-1), O.forward(net, t).reshape(-1), rtol=1e-4, atol=1e-4, err_msg="run %d" % k)
+        # plain float uploads in between go to the same texture too
+        x = rng.random((1, 24, 32, 4), dtype=np.float32)
+        np.testing.assert_array_equal(m(x), ref(x))
+    m.close()
+    ref.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("half", [False, True])
 def test_style_net_with_chain_fusion_through_host(ctx, tmp_path, half):
     """fuse_chains=True: HipBackend::finalizeStages hands the linear runs to snnhip_chain_plan_create, whose rule D folds every reflect Pad

@@ -171,7 +171,7 @@ def test_c4_mobilenetv2_224_batch32_full_size(ctx, monkeypatch):
     net = models.mobilenetv2(seed=1)
     r = _check_classifier_full_size(ctx, net, 32, (0, 7, 31), monkeypatch)
     kinds = " ".join(r.describe())
-    assert "depthwise" in kinds and "conv1x1_stream" in kinds
+    assert "depthwise" in kinds and " stream:" in kinds  # the strip depthwise kernel and the streaming pointwise MFMA kernel
 
 
 # ------------------------------------------------------------------------------------------------ C5
@@ -188,9 +188,11 @@ def test_c5_candy_720p_fp16_full_size(ctx):
     x = np.random.default_rng(5).random((1, H, W, 3), dtype=np.float32)
     r = snn.GraphRunner(ctx, net, 2, H, W, dtype=snn.F16)
     y = r(np.repeat(x, 2, axis=0))
-    assert y.shape == (2, H, W, 3) and np.isfinite(y).all()
-    np.testing.assert_array_equal(y[0], y[1])
     want, named = O.forward(net, x, fp16=True, threads=THREADS, return_named=True)
+    # the graph's reflect Pads grow the tensor and its "valid" convolutions do not shrink it back under the reference's size rule (Q20)
+    assert want.shape == (1, 826, 1386, 3)
+    assert y.shape == (2,) + want.shape[1:] and np.isfinite(y).all()
+    np.testing.assert_array_equal(y[0], y[1])
     scale = max(1.0, float(np.abs(want).max()))
     err = np.abs(y[:1] - want) / scale
     # same acceptance as the reduced-size fp16 graph test: the bulk within a few half ulps, the instance-norm-amplified tail small

@@ -143,6 +143,84 @@ class Workload:
         return sum(n * sum(p.num_steps() for p in plans) for (_, plans), n in zip(self.runners, self.counts))
 
 
+class HostPlanView:
+    """One kernel-launching plan of a host.Model stage, with the Plan methods the timing loop uses."""
+
+    def __init__(self, model, stage, nsteps):
+        self.m, self.stage, self.n = model, stage, nsteps
+
+    def num_steps(self):
+        return self.n
+
+    def profile(self, on):
+        pass  # switched per model (HostWorkload.profile)
+
+    def profile_read(self, i):
+        return self.m.profile_read(self.stage, i)
+
+    def step_describe(self, i):
+        return [d for st, k, d, _, _ in self.m.plan_steps() if st == self.stage and k == i][0]
+
+    def step_cost(self, i):
+        return [(f, b) for st, k, _, f, b in self.m.plan_steps() if st == self.stage and k == i][0]
+
+
+class HostWorkload:
+    """The same share of a step through the C++ host mirror (libsnn_core.so): the net is written as the reference's .json + .bin model,
+    loaded by ModelParser / MixedInferenceCore at the micro-batch size (snn_model_create4), fused by HipBackend::finalizeStages, and every
+    inference is MixedInferenceCore::run -- one recorded hipGraph launch + the reference's one sync per inference."""
+
+    def __init__(self, config, net, sizes, device, tmpdir, unfused=False, capture=True):
+        from shadernn_amd import host, models
+
+        cfg = CONFIGS[config]
+        self.images = sum(sizes)
+        H, W = cfg["hw"]
+        path = models.write_json(net, W, H, os.path.join(tmpdir, "%s_rank%d.json" % (config, device)), bin_weights=True)
+        self.models, self.counts = [], []
+        for mb in sorted(set(sizes), reverse=True):
+            m = host.Model(path, W, H, cfg["cin"], device=device, fuse_chains=not unfused, prefer_half=cfg["dtype"] == "f16", capture_graph=capture, batch=mb)
+            self.models.append(m)
+            self.counts.append(sizes.count(mb))
+        self.micro_sizes = sizes
+        self.runners = [(m, None) for m in self.models]
+
+    def upload(self, rng):
+        import numpy as np
+
+        for m in self.models:
+            m.upload(rng.random((m.batch,) + tuple(m.in_shape[-3:]), dtype=np.float32))
+
+    def run_device(self):
+        for m, n in zip(self.models, self.counts):
+            for _ in range(n):
+                m.run()
+
+    def profile(self, on):
+        for m in self.models:
+            m.profile(on)
+
+    def all_plans(self):
+        out = []
+        for m in self.models:
+            stages = {}
+            for st, k, _, _, _ in m.plan_steps():
+                stages[st] = max(stages.get(st, 0), k + 1)
+            out += [HostPlanView(m, st, n) for st, n in sorted(stages.items())]
+        return out
+
+    def cost(self):
+        f = b = 0.0
+        for m, n in zip(self.models, self.counts):
+            mf, mb = m.cost()
+            f += n * mf
+            b += n * mb
+        return f, b
+
+    def launches(self):
+        return sum(n * len(m.plan_steps()) for m, n in zip(self.models, self.counts))
+
+
 # ------------------------------------------------------------------------------------------------ CPU baseline
 
 def cpu_baseline(config, net):
@@ -217,6 +295,10 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--preheat-ms", type=float, default=150.0, help="run the workload untimed for at least this long before --warmup (clock ramp)")
     ap.add_argument("--unfused", action="store_true", help="one kernel per layer, no chain fusion (debug / comparison)")
+    ap.add_argument("--through", choices=["auto", "host", "capi"], default="auto",
+                    help="host: the C++ host mirror (libsnn_core.so: JSON/.bin model -> MixedInferenceCore::run, default for c3-c5); "
+                         "capi: per-layer plans driven from Python through the C-ABI (default for c1, c2)")
+    ap.add_argument("--no-capture", action="store_true", help="host path: launch kernel by kernel instead of replaying the recorded hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with events (overhead check)")
     ap.add_argument("--event-every", type=int, default=8,
@@ -264,14 +346,22 @@ def main():
     if images == 0:
         sys.stderr.write("bench.py: rank %d has no images (global batch %d over %d ranks)\n" % (rank, global_batch, world))
         sys.exit(2)
-    wl = Workload(ctx, args.config, net, shard["micro_sizes"], unfused=args.unfused)
-
-    # synthetic input (U(0,1), seed echoing the reference's SRAND(7767517), a different stream per rank), uploaded once: resident in HBM
+    through = args.through if args.through != "auto" else ("host" if args.config in ("c3", "c4", "c5") else "capi")
     import numpy as np
+    import tempfile
 
     rng = np.random.default_rng(7767517 + rank)
-    for r, _ in wl.runners:
-        r.x.upload(rng.random(r.in_shape, dtype=np.float32))
+    tmpdir = tempfile.mkdtemp(prefix="snn_bench_")
+    if through == "host":
+        os.environ.setdefault("SNN_LOG_LEVEL", "2")
+        wl = HostWorkload(args.config, net, shard["micro_sizes"], dev, tmpdir, unfused=args.unfused, capture=not args.no_capture)
+        wl.upload(rng)
+    else:
+        wl = Workload(ctx, args.config, net, shard["micro_sizes"], unfused=args.unfused)
+        # synthetic input (U(0,1), seed echoing the reference's SRAND(7767517), a different stream per rank), uploaded once: resident in HBM
+        for r, _ in wl.runners:
+            r.x.upload(rng.random(r.in_shape, dtype=np.float32))
+
     ctx.sync()
     torch.cuda.synchronize()
 
@@ -300,8 +390,11 @@ def main():
     for i in range(args.steps):
         if profile and (i % every == 0 or i % every == 1):  # toggle only at the sampled step and right after it
             on = i % every == 0
-            for p in plans:
-                p.profile(on)
+            if through == "host":
+                wl.profile(on)
+            else:
+                for p in plans:
+                    p.profile(on)
         wl.run_device()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -333,7 +426,9 @@ def main():
             "config": {"workload": cfg["workload"], "config_id": args.config, "global_batch": global_batch, "images_per_rank_per_step": images,
                        "micro_batches_per_rank": wl.micro_sizes, "input": [images, H, W, cfg["cin"]],
                        "parallelism": "dp%d (batch split, weights replicated, no data-path collective)" % world,
-                       "path": ("fused chain plans" if not args.unfused else "one kernel per layer") + ", %d kernel launches per step" % wl.launches(),
+                       "path": ("C++ host mirror (libsnn_core.so, JSON + .bin model, MixedInferenceCore::run%s)" % ("" if args.no_capture else ", recorded hipGraph replay")
+                                if through == "host" else "per-layer plans through the C-ABI") +
+                               (", graph fusion (snnhip_graph_fuse)" if not args.unfused else ", one kernel per layer") + ", %d kernel launches per step" % wl.launches(),
                        "device": info["name"], "compute_units": info["compute_units"]},
             "flops_per_image": flops_img, "bytes_per_image_unfused_accounting": bytes_img,
             "achieved_tflops_per_gpu": flops / step_s / 1e12,

@@ -30,8 +30,13 @@ int snn_model_create2(const char* json_path, int device, int in_w, int in_h, int
 /* as snn_model_create2, plus capture_graph: record the first run's launches as a hipGraph and replay it afterwards (ignored with dumps / profiling) */
 int snn_model_create3(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
                       int prefer_half, int capture_graph, snn_model** out);
+/* as snn_model_create3, for a BATCH of `batch` images per inference: every stage tensor is [batch][H][W][C] (the reference fixes the 4th
+ * texture dimension to 1, core/src/ic2/core.cpp:371; here it carries the image count).  Uploads / downloads move batch x H x W x C floats. */
+int snn_model_create4(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
+                      int prefer_half, int capture_graph, int batch, snn_model** out);
+int snn_model_batch(snn_model* m);
 int snn_model_destroy(snn_model* m);
-int snn_model_upload_input(snn_model* m, const float* nhwc);      /* H x W x C floats */
+int snn_model_upload_input(snn_model* m, const float* nhwc);      /* [batch x] H x W x C floats */
 int snn_model_run(snn_model* m);                                   /* MixedInferenceCore::run (enqueue + one sync) */
 int snn_model_output_dims(snn_model* m, int hwc[3]);
 int snn_model_download_output(snn_model* m, float* nhwc);
@@ -48,6 +53,13 @@ int snn_model_num_stages(snn_model* m);
 int snn_model_stage_info(snn_model* m, int stage, char* name, int name_len, int hwc[3], int* fused_away);
 int snn_model_download_stage(snn_model* m, int stage, float* nhwc);
 int snn_model_describe(snn_model* m, char* buf, int buflen);
+/* The plan a stage launches after fusion (0 steps: input layer, CPU stage, or folded into a later stage's fused plan): kernel description and
+ * algorithmic cost of each of its launches, per-launch HIP-event profiling (snnhip_plan_profile_*) and the summed cost of one inference. */
+int snn_model_stage_plan_steps(snn_model* m, int stage);
+int snn_model_stage_plan_step(snn_model* m, int stage, int step, char* desc, int desc_len, double* flops, double* bytes);
+int snn_model_profile_enable(snn_model* m, int enable);
+int snn_model_profile_read(snn_model* m, int stage, int step, double* total_ms, int* launches);
+int snn_model_cost(snn_model* m, double* flops, double* bytes);
 /* per-stage device timers of the last run, milliseconds (MixedInferenceCore::writeTimeStat); returns count written */
 int snn_model_time_stats(snn_model* m, char* names, int names_len, double* ms, int max_entries);
 

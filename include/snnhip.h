@@ -308,6 +308,30 @@ int snnhip_tensor_argmax(const snnhip_tensor* t, int n, int* out_index);
  * Implemented rule set: see DESIGN.md section 4 (ESPCN: conv5x5(1->16)+conv3x3(16->16), conv3x3(16->4)+subpixel). */
 int snnhip_chain_plan_create(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_plan** out);
 
+/* Graph-level fusion: the ONE place where an operator DAG is searched for fusable groups (the host mirror's
+ * HipBackend::finalizeStages and the Python GraphRunner both call it; the rules themselves are snnhip_chain_plan_create's).
+ * nodes[i] describes operator i in execution order: its per-layer plan (NULL = opaque operator that never fuses: a CPU stage, a
+ * multi-pass layer), its producers (node index, or -(k+1) for model input k) and whether its tensor must exist (model output, dump).
+ * out[i] says what to run instead: plan == NULL -> node i's work moved into a later node's plan and its tensor is never produced;
+ * owned == 0 -> unchanged (plan == nodes[i].plan, inputs as given); owned == 1 -> a new fused plan the caller destroys with
+ * snnhip_plan_destroy, to be run with out[i].inputs (it produces node i's tensor).  The per-layer plans must outlive the fused ones.
+ * Groups searched: Conv2D -> Add where the Add is the convolution's only consumer (rule E, two-input fused plan), and maximal
+ * linear runs (each operator the sole consumer of the previous one) handed to the chain planner (rules A-D, F). */
+#define SNNHIP_GRAPH_MAX_INPUTS 4
+typedef struct snnhip_graph_node {
+    snnhip_plan* plan;
+    int n_inputs;
+    int inputs[SNNHIP_GRAPH_MAX_INPUTS];
+    int keep;
+} snnhip_graph_node;
+typedef struct snnhip_fused_node {
+    snnhip_plan* plan;
+    int owned;
+    int n_inputs;
+    int inputs[SNNHIP_GRAPH_MAX_INPUTS];
+} snnhip_fused_node;
+int snnhip_graph_fuse(snnhip_ctx* ctx, const snnhip_graph_node* nodes, int n, snnhip_fused_node* out);
+
 int snnhip_plan_run(snnhip_plan* plan, const snnhip_tensor* in, snnhip_tensor* out);
 /* multi-input ops (add, concat): inputs[n_in] */
 int snnhip_plan_run_n(snnhip_plan* plan, const snnhip_tensor* const* inputs, int n_in, snnhip_tensor* out);

@@ -87,6 +87,15 @@ _lib = None
 _P = C.c_void_p
 _FP = C.POINTER(C.c_float)
 
+
+class GraphNode(C.Structure):
+    _fields_ = [("plan", _P), ("n_inputs", C.c_int), ("inputs", C.c_int * 4), ("keep", C.c_int)]
+
+
+class FusedNode(C.Structure):
+    _fields_ = [("plan", _P), ("owned", C.c_int), ("n_inputs", C.c_int), ("inputs", C.c_int * 4)]
+
+
 # name -> (restype, argtypes); must list every symbol include/snnhip.h declares (tests/test_abi.py checks that)
 SIGNATURES = {
     "snnhip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
@@ -129,6 +138,7 @@ SIGNATURES = {
     "snnhip_tensor_upload_raw": (C.c_int, [_P, _P, C.c_size_t]),
     "snnhip_tensor_argmax": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "snnhip_chain_plan_create": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(_P)]),
+    "snnhip_graph_fuse": (C.c_int, [_P, C.POINTER(GraphNode), C.c_int, C.POINTER(FusedNode)]),
     "snnhip_plan_run": (C.c_int, [_P, _P, _P]),
     "snnhip_plan_run_n": (C.c_int, [_P, C.POINTER(_P), C.c_int, _P]),
     "snnhip_plan_output_dims": (C.c_int, [_P, C.POINTER(C.c_int * 4)]),
@@ -549,6 +559,31 @@ def chain_plan(ctx, plans):
     h = _P()
     check(lib().snnhip_chain_plan_create(ctx.h, arr, len(plans), C.byref(h)))
     return Plan(ctx, h, keep=tuple(plans))
+
+
+def graph_fuse(ctx, nodes):
+    """snnhip_graph_fuse: nodes = [(Plan, [producer index | -(k+1) for model input k], keep)] in execution order.
+    Returns [(Plan | None, inputs)] per node: None = folded into a later node's plan, the same Plan object = unchanged, a new Plan = fused."""
+    n = len(nodes)
+    arr = (GraphNode * n)()
+    for i, (plan, ins, keep) in enumerate(nodes):
+        arr[i].plan = plan.h if plan is not None else None
+        arr[i].n_inputs = len(ins)
+        for k, v in enumerate(ins):
+            arr[i].inputs[k] = v
+        arr[i].keep = int(bool(keep))
+    out = (FusedNode * n)()
+    check(lib().snnhip_graph_fuse(ctx.h, arr, n, out))
+    res = []
+    for i, (plan, ins, _) in enumerate(nodes):
+        o = out[i]
+        if not o.plan:
+            res.append((None, []))
+        elif o.owned:
+            res.append((Plan(ctx, _P(o.plan), keep=(plan,)), [o.inputs[k] for k in range(o.n_inputs)]))
+        else:
+            res.append((plan, list(ins)))
+    return res
 
 
 class Graph:

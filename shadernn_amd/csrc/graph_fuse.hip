@@ -1,0 +1,104 @@
+// graph_fuse.hip -- snnhip_graph_fuse: the single graph walk that looks for fusable operator groups (include/snnhip.h).
+//
+// The fusion RULES live in the chain planner (make_chain_plan, espcn_fused.hip: A/B/C ESPCN kernels, D [UpSampling2D ->] Pad -> Conv2D,
+// E Conv2D -> Add, F Conv2D -> InstanceNorm).  This file only decides which groups of a DAG are offered to it:
+//   1. residual pairs: an Add one of whose inputs is a convolution that nobody else reads (ResNet / MobileNetV2 skip connections);
+//   2. maximal linear runs: node t+1 reads only node t, node t is read only by node t+1 (Candy's pad -> conv -> norm strings, ESPCN).
+// Counterpart in the reference: none -- it dispatches one compute shader per layer (vulkanRenderpass.cpp:257-259).
+#include <vector>
+
+#include "snnhip_internal.h"
+
+using namespace snnhip;
+
+extern "C" int snnhip_graph_fuse(snnhip_ctx* ctx, const snnhip_graph_node* nodes, int n, snnhip_fused_node* out) {
+    SNNHIP_REQUIRE(ctx && nodes && out && n > 0, "graph_fuse: bad argument");
+    std::vector<int> consumers(static_cast<size_t>(n), 0);
+    for (int i = 0; i < n; ++i) {
+        SNNHIP_REQUIRE(nodes[i].n_inputs >= 0 && nodes[i].n_inputs <= SNNHIP_GRAPH_MAX_INPUTS, "graph_fuse: node %d has %d inputs", i, nodes[i].n_inputs);
+        for (int k = 0; k < nodes[i].n_inputs; ++k) {
+            const int src = nodes[i].inputs[k];
+            SNNHIP_REQUIRE(src < i, "graph_fuse: node %d reads node %d (nodes must be in execution order)", i, src);
+            if (src >= 0) consumers[static_cast<size_t>(src)]++;
+        }
+        out[i].plan = nodes[i].plan;
+        out[i].owned = 0;
+        out[i].n_inputs = nodes[i].n_inputs;
+        for (int k = 0; k < SNNHIP_GRAPH_MAX_INPUTS; ++k) out[i].inputs[k] = k < nodes[i].n_inputs ? nodes[i].inputs[k] : 0;
+    }
+    SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    std::vector<char> taken(static_cast<size_t>(n), 0); // member of a fused group already
+    auto foldable = [&](int i) { return i >= 0 && nodes[i].plan && !nodes[i].keep && consumers[static_cast<size_t>(i)] == 1 && !taken[static_cast<size_t>(i)]; };
+    auto fail = [&](int rc) { // hand back nothing half-built
+        for (int i = 0; i < n; ++i)
+            if (out[i].owned && out[i].plan) {
+                delete out[i].plan;
+                out[i].plan = nodes[i].plan;
+                out[i].owned = 0;
+            }
+        return rc;
+    };
+
+    // ---- 1. Conv2D -> Add (rule E): the fused plan sits at the Add node and reads {the convolution's input, the other summand}
+    for (int k = 0; k < n; ++k) {
+        if (!nodes[k].plan || nodes[k].n_inputs != 2 || taken[static_cast<size_t>(k)]) continue;
+        auto* add = dynamic_cast<EltwisePlanBase*>(nodes[k].plan);
+        if (!add || add->mode != 0) continue;
+        for (int which = 0; which < 2; ++which) {
+            const int src = nodes[k].inputs[which];
+            if (!foldable(src) || nodes[src].n_inputs != 1) continue;
+            auto* cv = dynamic_cast<ConvPlanBase*>(nodes[src].plan);
+            if (!cv || cv->depthwise) continue;
+            if (nodes[k].inputs[1 - which] == src) continue; // x + x
+            snnhip_plan* pair[2] = {nodes[src].plan, nodes[k].plan};
+            snnhip_plan* fused = nullptr;
+            const int rc = make_chain_plan(ctx, pair, 2, &fused);
+            if (rc == SNNHIP_E_UNSUPPORTED) continue;
+            if (rc != SNNHIP_OK) return fail(rc);
+            if (fused->numInputs != 2) { // the chain planner wrapped the pair without folding the add: not what this rule is for
+                delete fused;
+                continue;
+            }
+            out[k].plan = fused;
+            out[k].owned = 1;
+            out[k].n_inputs = 2;
+            out[k].inputs[0] = nodes[src].inputs[0];
+            out[k].inputs[1] = nodes[k].inputs[1 - which];
+            out[src].plan = nullptr;
+            out[src].n_inputs = 0;
+            taken[static_cast<size_t>(k)] = taken[static_cast<size_t>(src)] = 1;
+            break;
+        }
+    }
+
+    // ---- 2. maximal linear runs -> chain planner
+    for (int i = 0; i < n;) {
+        if (!nodes[i].plan || nodes[i].n_inputs != 1 || taken[static_cast<size_t>(i)]) {
+            ++i;
+            continue;
+        }
+        int j = i;
+        while (j + 1 < n && nodes[j + 1].plan && nodes[j + 1].n_inputs == 1 && nodes[j + 1].inputs[0] == j && foldable(j) && !taken[static_cast<size_t>(j + 1)]) ++j;
+        if (j > i) {
+            std::vector<snnhip_plan*> run;
+            for (int t = i; t <= j; ++t) run.push_back(nodes[t].plan);
+            snnhip_plan* chain = nullptr;
+            const int rc = make_chain_plan(ctx, run.data(), static_cast<int>(run.size()), &chain);
+            if (rc == SNNHIP_OK) {
+                out[j].plan = chain;
+                out[j].owned = 1;
+                out[j].n_inputs = 1;
+                out[j].inputs[0] = nodes[i].inputs[0];
+                for (int t = i; t < j; ++t) {
+                    out[t].plan = nullptr;
+                    out[t].n_inputs = 0;
+                }
+                for (int t = i; t <= j; ++t) taken[static_cast<size_t>(t)] = 1;
+            } else if (rc != SNNHIP_E_UNSUPPORTED) {
+                return fail(rc);
+            }
+        }
+        i = j + 1;
+    }
+    return SNNHIP_OK;
+}

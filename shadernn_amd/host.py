@@ -15,6 +15,13 @@ SIGNATURES = {
     "snn_model_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "snn_model_create2": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "snn_model_create3": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "snn_model_create4": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "snn_model_batch": (C.c_int, [_P]),
+    "snn_model_stage_plan_steps": (C.c_int, [_P, C.c_int]),
+    "snn_model_stage_plan_step": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "snn_model_profile_enable": (C.c_int, [_P, C.c_int]),
+    "snn_model_profile_read": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "snn_model_cost": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "snn_model_destroy": (C.c_int, [_P]),
     "snn_model_upload_input": (C.c_int, [_P, _FP]),
     "snn_model_run": (C.c_int, [_P]),
@@ -93,11 +100,14 @@ def yolo_decode(head_coarse, head_fine, net_size=416, max_rows=100):
 class Model:
     """MixedInferenceCore::create(context, jsonFile, options) + run(), one W x H x C input image."""
 
-    def __init__(self, json_path, w, h, c, device=0, dump_outputs=False, fuse_chains=True, profiling=False, prefer_half=False, capture_graph=False):
+    def __init__(self, json_path, w, h, c, device=0, dump_outputs=False, fuse_chains=True, profiling=False, prefer_half=False, capture_graph=False,
+                 batch=1):
+        """batch > 1: every stage tensor carries `batch` images (snn_model_create4); upload() takes and output() returns a leading batch axis."""
         self.h = _P()
-        assert lib().snn_model_create3(json_path.encode(), device, w, h, c, int(dump_outputs), int(fuse_chains), int(profiling), int(prefer_half),
-                                       int(capture_graph), C.byref(self.h)) == 0
-        self.in_shape = (h, w, c)
+        assert lib().snn_model_create4(json_path.encode(), device, w, h, c, int(dump_outputs), int(fuse_chains), int(profiling), int(prefer_half),
+                                       int(capture_graph), int(batch), C.byref(self.h)) == 0
+        self.batch = batch
+        self.in_shape = (h, w, c) if batch == 1 else (batch, h, w, c)
 
     def upload(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.in_shape)
@@ -131,7 +141,7 @@ class Model:
     def output(self):
         d = (C.c_int * 3)()
         lib().snn_model_output_dims(self.h, C.byref(d))
-        out = np.empty(tuple(d), dtype=np.float32)
+        out = np.empty(tuple(d) if self.batch == 1 else (self.batch,) + tuple(d), dtype=np.float32)
         assert lib().snn_model_download_output(self.h, _fp(out)) == 0
         return out
 
@@ -152,10 +162,34 @@ class Model:
 
     def stage_output(self, i):
         st = self.stages()[i]
-        out = np.empty(st["hwc"], dtype=np.float32)
+        out = np.empty(st["hwc"] if self.batch == 1 else (self.batch,) + tuple(st["hwc"]), dtype=np.float32)
         if lib().snn_model_download_stage(self.h, i, _fp(out)) != 0:
             return None
         return out
+
+    def plan_steps(self):
+        """[(stage, step, kernel description, flops, bytes)] of every kernel launch of one inference, after fusion."""
+        out = []
+        for i in range(lib().snn_model_num_stages(self.h)):
+            for k in range(lib().snn_model_stage_plan_steps(self.h, i)):
+                desc = C.create_string_buffer(1024)
+                f, b = C.c_double(), C.c_double()
+                assert lib().snn_model_stage_plan_step(self.h, i, k, desc, 1024, C.byref(f), C.byref(b)) == 0
+                out.append((i, k, desc.value.decode(), f.value, b.value))
+        return out
+
+    def profile(self, enable=True):
+        assert lib().snn_model_profile_enable(self.h, int(enable)) == 0
+
+    def profile_read(self, stage, step):
+        ms, n = C.c_double(), C.c_int()
+        assert lib().snn_model_profile_read(self.h, stage, step, C.byref(ms), C.byref(n)) == 0
+        return ms.value, n.value
+
+    def cost(self):
+        f, b = C.c_double(), C.c_double()
+        assert lib().snn_model_cost(self.h, C.byref(f), C.byref(b)) == 0
+        return f.value, b.value
 
     def describe(self):
         buf = C.create_string_buffer(1 << 14)

@@ -84,7 +84,7 @@ bool MixedInferenceCore::init(const CreationParameters& cp_) {
                 stage.inputIds.push_back(static_cast<int>(inputIdx));
             }
         }
-        std::array<uint32_t, 4> dims{layer.outputDesc.width, layer.outputDesc.height, layer.outputDesc.depth, 1};
+        std::array<uint32_t, 4> dims{layer.outputDesc.width, layer.outputDesc.height, layer.outputDesc.depth, layer.outputDesc.batch}; // the reference: {W,H,D,1}
         if (!cpuStage) { // a CPU stage hands its result over as a host matrix (ImageTexture::setOutputMat), no device tensor
             stage.stageOutputs[0].resetTexture(dims, layer.outputDesc.format, layer.name, layer.outputDesc.channels); // core.cpp:371-372
             layer.initFunPtr(backend, stage.stageInputs, stage.stageOutputs);                                        // core.cpp:374
@@ -108,7 +108,7 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
     cpuRunTime.start();
     if (gpuRunTime) gpuRunTime->start();
     bool replayed = false, recordingNow = false;
-    if (graphUsable) {
+    if (graphUsable && !replaySuspended) {
         // The captured kernels hold DEVICE pointers: key the recording on (device address, dims, dtype) of every model input, not on
         // the host-side tensor handle (an input texture that re-creates its tensor may get the same handle address back with another
         // buffer behind it, and the other way round).
@@ -184,7 +184,7 @@ std::string MixedInferenceCore::describe() const {
     std::ostringstream ss;
     for (size_t i = 0; i < stages.size(); ++i) {
         ss << "[" << i << "] " << stages[i].layer->name;
-        if (stages[i].fusedAway) ss << "  (fused into an earlier stage)";
+        if (stages[i].fusedAway) ss << "  (fused into a later stage's plan)";
         ss << "\n";
     }
     return ss.str();

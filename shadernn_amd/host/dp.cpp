@@ -98,7 +98,7 @@ InferenceGraph snn::dp::generateInferenceGraph(std::vector<std::shared_ptr<Gener
             const auto& di = options.desiredInput[idx];
             // the reference passes channels = 4*depth for model inputs (dp.cpp:506-508); the true count, when the caller
             // gives one, lets the NHWC tensors carry exactly C channels
-            return InferenceGraph::IODesc{fmt, di.width, di.height, di.depth, di.channels ? di.channels : 4 * di.depth};
+            return InferenceGraph::IODesc{fmt, di.width, di.height, di.depth, di.channels ? di.channels : 4 * di.depth, options.batch};
         };
         if (!modelLayer->prevLayers.empty()) {
             for (auto& prev : modelLayer->prevLayers) {
@@ -156,21 +156,22 @@ InferenceGraph snn::dp::generateInferenceGraph(std::vector<std::shared_ptr<Gener
             }
             igLayer->layerLoc = modelLayer->getLayerExecutionType();
             igLayer->outputDesc = {fmt, width, height, static_cast<uint32_t>(DIV_4_ROUND_UP(modelLayer->getDesc().numOutputPlanes)),
-                                   modelLayer->getDesc().numOutputPlanes}; // dp.cpp:328-332
+                                   modelLayer->getDesc().numOutputPlanes, options.batch}; // dp.cpp:328-332
             if (modelLayer->isInputLayer()) igLayer->outputDesc = inputDesc(modelLayer->getInputIndex());
             if (dynamic_cast<DenseLayer*>(modelLayer.get())) {
                 // Dense output is a units x 1 x 1 single-channel image in the reference (denselayer.cpp:40-55, CPU-stage
                 // descriptor dp.cpp:365-367); it runs on the GPU here but keeps that shape
-                igLayer->outputDesc = {fmt, width, 1, 1, 1};
+                igLayer->outputDesc = {fmt, width, 1, 1, 1, options.batch};
                 igLayer->flattenLayer = true;
             }
             if (dynamic_cast<FlattenLayer*>(modelLayer.get())) { // W*H*C x 1 x 1, one channel (flattenlayer.cpp:48-62)
-                igLayer->outputDesc = {fmt, width, 1, 1, 1};
+                igLayer->outputDesc = {fmt, width, 1, 1, 1, options.batch};
                 igLayer->flattenLayer = true;
             }
             SNN_ASSERT(igLayer->outputDesc.width > 0 && igLayer->outputDesc.height > 0);
         } else {
             if (i == 0) SNN_RIP("CPU layer currently cannot cannot be the 1-st layer in the graph !");
+            if (options.batch != 1) SNN_RIP("CPU layer %s: CPU stages (the YOLO head) take one image per inference, batch = %u", modelLayer->getName().c_str(), options.batch);
             igLayer->outputDesc = {fmt, width, height, depth, modelLayer->getDesc().numOutputPlanes};
         }
         modelFormat << "----------------------------------------------------------------\n";

@@ -68,7 +68,7 @@ void HipBackend::initRenderPasses(GenericModelLayer* layer, ImageTextureArrayAcc
         ImageTexture& o = out[0];
         // Dense produces [1][1][1][Out] while the reference's texture is Out x 1 x 1: accept both, reject real mismatches
         const size_t want = static_cast<size_t>(od[0]) * od[1] * od[2] * od[3];
-        const size_t have = static_cast<size_t>(o.width()) * o.height() * o.channels();
+        const size_t have = static_cast<size_t>(o.batch()) * o.width() * o.height() * o.channels();
         if (want != have) SNN_RIP("%s: plan output %dx%dx%dx%d does not match texture %s", layer->getName().c_str(), od[0], od[1], od[2], od[3], o.getTextureInfo2().c_str());
         auto rp = std::make_shared<HipRenderPass>(plan, &in[0], &o, layer->getName(), true);
         for (size_t k = 1; k < in.size(); ++k) rp->extraInputs.push_back(&in[k]);
@@ -110,54 +110,65 @@ void HipBackend::postRun(RenderStagesArray&, bool dumpOutput, const std::string&
     (void) dumpOutput; // dumps are written by the layers' render passes right after they run (GenericModelLayer::run)
 }
 
-// Replace linear runs of single-pass stages by fused plans (snnhip_chain_plan_create).  A stage can join a run when it has
-// exactly one input, that input is the previous stage's output, and nobody else consumes that output.
+// Hand the stage DAG to snnhip_graph_fuse (the library's single fusion pass: residual Conv2D -> Add pairs and linear runs, rules A-F of
+// snnhip_chain_plan_create) and install the fused plans it returns.  A fused plan sits at the LAST stage of its group and reads the
+// group's external inputs; the other stages of the group keep their textures un-produced and their passes skipped.
 void HipBackend::finalizeStages(RenderStagesArray& stages, bool dumpOutputs, bool fuseChains) {
     if (dumpOutputs || !fuseChains) return; // dumps need every intermediate tensor
-    std::vector<int> consumers(stages.size(), 0);
-    for (auto& s : stages)
-        for (size_t j = 0; j < s.inputIds.size(); ++j)
-            if (!s.delayBindMask[j] && s.inputIds[j] >= 0) consumers[static_cast<size_t>(s.inputIds[j])]++;
     auto passOf = [&](size_t i) -> HipRenderPass* {
         auto* ml = static_cast<GenericModelLayer*>(stages[i].layer->modelLayer);
-        if (!ml || stages[i].layer->isInputLayer || ml->getRenderPasses().size() != 1) return nullptr;
+        if (!ml || stages[i].layer->isInputLayer || stages[i].backend != Backend::Backend_GPU || ml->getRenderPasses().size() != 1) return nullptr;
         return dynamic_cast<HipRenderPass*>(ml->getRenderPasses()[0].get());
     };
-    size_t i = 0;
-    while (i < stages.size()) {
-        if (!passOf(i) || stages[i].inputIds.size() != 1) { // a chain starts at a single-input stage (Add has two)
-            ++i;
+    const int n = static_cast<int>(stages.size());
+    std::vector<snnhip_graph_node> nodes(stages.size());
+    std::vector<snnhip_fused_node> fused(stages.size());
+    for (size_t i = 0; i < stages.size(); ++i) {
+        snnhip_graph_node& nd = nodes[i];
+        nd = snnhip_graph_node{};
+        HipRenderPass* rp = passOf(i);
+        nd.plan = rp ? rp->plan : nullptr;
+        nd.keep = (i + 1 == stages.size()) ? 1 : 0; // the model output (the reference binds the last stage's texture, core.cpp:219-227)
+        if (stages[i].inputIds.size() > SNNHIP_GRAPH_MAX_INPUTS) nd.plan = nullptr;
+        nd.n_inputs = nd.plan ? static_cast<int>(stages[i].inputIds.size()) : 0;
+        for (int k = 0; k < nd.n_inputs; ++k) {
+            const bool modelInput = stages[i].delayBindMask[static_cast<size_t>(k)] != 0;
+            nd.inputs[k] = modelInput ? -(stages[i].inputIds[static_cast<size_t>(k)] + 1) : stages[i].inputIds[static_cast<size_t>(k)];
+        }
+    }
+    // an opaque stage (CPU layer, multi-pass layer) still consumes its producers: they must stay materialised
+    for (size_t i = 0; i < stages.size(); ++i)
+        if (!nodes[i].plan)
+            for (size_t k = 0; k < stages[i].inputIds.size(); ++k)
+                if (!stages[i].delayBindMask[k] && stages[i].inputIds[k] >= 0) nodes[static_cast<size_t>(stages[i].inputIds[k])].keep = 1;
+    hipChk(snnhip_graph_fuse(ctx, nodes.data(), n, fused.data()), "snnhip_graph_fuse");
+    // which texture carries input `id` of a fused plan: the stage output, or (model inputs, bound at run()) the input slot of the stage that named it
+    auto textureOf = [&](size_t groupLast, int id) -> ImageTexture* {
+        if (id >= 0) return &stages[static_cast<size_t>(id)].stageOutputs[0];
+        for (size_t s = 0; s <= groupLast; ++s)
+            for (size_t k = 0; k < stages[s].inputIds.size(); ++k)
+                if (stages[s].delayBindMask[k] && -(stages[s].inputIds[k] + 1) == id) return &stages[s].stageInputs[k];
+        SNN_RIP("finalizeStages: model input %d is not bound by any stage", -id - 1);
+        return nullptr;
+    };
+    for (size_t i = 0; i < stages.size(); ++i) {
+        if (!nodes[i].plan) continue;
+        HipRenderPass* rp = passOf(i);
+        if (!fused[i].plan) { // folded into a later stage's plan
+            rp->skip = true;
+            stages[i].fusedAway = true;
             continue;
         }
-        size_t j = i;
-        while (j + 1 < stages.size() && passOf(j + 1) && stages[j + 1].inputIds.size() == 1 && !stages[j + 1].delayBindMask[0] &&
-               stages[j + 1].inputIds[0] == static_cast<int>(j) && consumers[j] == 1)
-            ++j;
-        if (j > i) {
-            std::vector<snnhip_plan*> plans;
-            for (size_t k = i; k <= j; ++k) plans.push_back(passOf(k)->plan);
-            snnhip_plan* chain = nullptr;
-            const int rc = snnhip_chain_plan_create(ctx, plans.data(), static_cast<int>(plans.size()), &chain);
-            if (rc == SNNHIP_OK) {
-                chainPlans.push_back(chain);
-                HipRenderPass* first = passOf(i);
-                HipRenderPass* last = passOf(j);
-                // the first stage launches the whole chain straight into the last stage's output tensor
-                auto* ml = static_cast<GenericModelLayer*>(stages[i].layer->modelLayer);
-                replacedPasses.push_back(ml->getRenderPasses()[0]);
-                ml->getRenderPasses()[0] = std::make_shared<HipRenderPass>(chain, first->input, last->output, first->name + " (+fused chain)", false);
-                for (size_t k = i + 1; k <= j; ++k) {
-                    passOf(k)->skip = true;
-                    stages[k].fusedAway = true;
-                }
-                char buf[512];
-                snnhip_plan_describe(chain, buf, sizeof(buf));
-                SNN_LOGI("stages %zu..%zu fused: %s", i, j, buf);
-            } else if (rc != SNNHIP_E_UNSUPPORTED) {
-                hipChk(rc, "snnhip_chain_plan_create");
-            }
-        }
-        i = j + 1;
+        if (!fused[i].owned) continue;
+        chainPlans.push_back(fused[i].plan);
+        auto* ml = static_cast<GenericModelLayer*>(stages[i].layer->modelLayer);
+        replacedPasses.push_back(ml->getRenderPasses()[0]); // its plan may still be launched by the fused one (unfused steps of a chain)
+        auto np = std::make_shared<HipRenderPass>(fused[i].plan, textureOf(i, fused[i].inputs[0]), rp->output, rp->name + " (+fused)", false);
+        for (int k = 1; k < fused[i].n_inputs; ++k) np->extraInputs.push_back(textureOf(i, fused[i].inputs[k]));
+        ml->getRenderPasses()[0] = np;
+        char buf[512];
+        snnhip_plan_describe(fused[i].plan, buf, sizeof(buf));
+        SNN_LOGI("stage %zu runs a fused plan: %s", i, buf);
     }
 }
 

@@ -66,8 +66,8 @@ void ImageTexture::reset(const std::array<uint32_t, 4>& dims, ColorFormat format
     d.format = ColorFormat::RGBA32F; // host staging is always fp32; an RGBA16F texture is a half tensor in HBM and converts at the C-ABI edge
     d.width = dims[0];
     d.height = dims[1];
-    d.depth = dims[2];
-    d.channels = 4 * dims[2];
+    d.depth = dims[2] * batch(); // a batched texture stages (and dumps) its images as consecutive groups of depth texel planes
+    d.channels = 4 * d.depth;
     _image = RawImage(d, buffer);
 }
 
@@ -76,7 +76,7 @@ void ImageTexture::resetTexture(const std::array<uint32_t, 4>& dims, ColorFormat
         SNN_RIP("HIP backend: RGBA32F (fp32) and RGBA16F (fp16) textures are implemented, got %s", getColorFormatDesc(format).name);
     releaseTensor();
     reset(dims, format, nullptr, name, channels);
-    hipChk(snnhip_tensor_alloc(hipCtx(), 1, static_cast<int>(dims[1]), static_cast<int>(dims[0]), static_cast<int>(_channels),
+    hipChk(snnhip_tensor_alloc(hipCtx(), static_cast<int>(batch()), static_cast<int>(dims[1]), static_cast<int>(dims[0]), static_cast<int>(_channels),
                                format == ColorFormat::RGBA16F ? SNNHIP_F16 : SNNHIP_F32, &_tensor),
            "snnhip_tensor_alloc");
     _ownsTensor = true;
@@ -98,13 +98,13 @@ void ImageTexture::upload() {
 
 void ImageTexture::download() {
     SNN_CHK(_tensor);
-    if (_image.empty() || _image.width() != _dims[0] || _image.height() != _dims[1] || _image.depth() != _dims[2]) {
+    if (_image.empty() || _image.width() != _dims[0] || _image.height() != _dims[1] || _image.depth() != _dims[2] * batch()) {
         ImageDesc d;
         d.format = ColorFormat::RGBA32F;
         d.width = _dims[0];
         d.height = _dims[1];
-        d.depth = _dims[2];
-        d.channels = 4 * _dims[2];
+        d.depth = _dims[2] * batch();
+        d.channels = 4 * d.depth;
         _image = RawImage(d, nullptr);
     }
     hipChk(snnhip_tensor_download_c4hw4(_tensor, reinterpret_cast<float*>(_image.data())), "snnhip_tensor_download_c4hw4");
@@ -123,6 +123,7 @@ void ImageTexture::downloadNHWC(float* nhwc) {
 void ImageTexture::loadU8AndNormalize(const uint8_t* pixels, uint32_t w, uint32_t h, uint32_t srcChannels, const std::array<float, 4>& means,
                                       const std::array<float, 4>& norms) {
     SNN_CHK(pixels && (srcChannels == 1 || srcChannels == 3 || srcChannels == 4));
+    if (batch() != 1) SNN_RIP("loadU8AndNormalize: one image per call, this texture holds a batch of %u", batch());
     const ColorFormat fmt = _format == ColorFormat::RGBA16F ? ColorFormat::RGBA16F : ColorFormat::RGBA32F;
     resetTexture({w, h, 1, 1}, fmt, _name, 4);
     snnhip_tensor* src = nullptr;
@@ -147,6 +148,7 @@ void ImageTexture::loadU8AndNormalize(const uint8_t* pixels, uint32_t w, uint32_
 
 bool ImageTexture::resize(float xScale, float yScale, const std::array<float, 4>& means, const std::array<float, 4>& norms, bool linearFilter) {
     SNN_CHK(_tensor && xScale > 0.0f && yScale > 0.0f);
+    if (batch() != 1) SNN_RIP("resize: one image per call, this texture holds a batch of %u", batch());
     snnhip_resize_desc d = {};
     d.N = 1;
     d.H = static_cast<int>(_dims[1]);
@@ -176,8 +178,8 @@ bool ImageTexture::resize(float xScale, float yScale, const std::array<float, 4>
 }
 
 std::string ImageTexture::getTextureInfo2() const {
-    return formatString("%s %ux%ux%u (C=%u) %s tensor=%p", _name.c_str(), _dims[0], _dims[1], _dims[2], _channels, getColorFormatDesc(_format).name,
-                        static_cast<void*>(_tensor));
+    return formatString("%s %ux%ux%u (C=%u, batch %u) %s tensor=%p", _name.c_str(), _dims[0], _dims[1], _dims[2], _channels, batch(),
+                        getColorFormatDesc(_format).name, static_cast<void*>(_tensor));
 }
 
 void ImageTexture::saveToBIN(const std::string& filename) {

@@ -175,7 +175,7 @@ InferencePassesSptr Conv2DLayerHip::createCS(const LayerGenOptions&) const { // 
     uint32_t pad[4];
     getPaddingOffset(pad);
     snnhip_conv2d_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(inputDims[0].batch);
     d.H = static_cast<int>(inputDims[0].height);
     d.W = static_cast<int>(inputDims[0].width);
     d.IC = static_cast<int>(_desc.numInputPlanes);
@@ -253,7 +253,7 @@ InferencePassesSptr SeparableConv2DLayerHip::createCS(const LayerGenOptions&) co
     uint32_t pad[4];
     getPaddingOffset(pad);
     snnhip_conv2d_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(inputDims[0].batch);
     d.H = static_cast<int>(inputDims[0].height);
     d.W = static_cast<int>(inputDims[0].width);
     d.IC = d.OC = static_cast<int>(_desc.numOutputPlanes);
@@ -313,7 +313,7 @@ InferencePassesSptr DenseLayerHip::createCS(const LayerGenOptions&) const {
     auto ret = std::make_shared<InferencePasses>();
     ret->passes.resize(1);
     snnhip_dense_desc d = {};
-    d.batch = 1;
+    d.batch = inputDims.empty() ? 1 : static_cast<int>(inputDims[0].batch);
     d.out_units = static_cast<int>(_desc.biases.size());
     std::vector<float> flat;
     for (auto& row : _desc.weights) flat.insert(flat.end(), row.begin(), row.end()); // CPUCommonUtil::flatten2d
@@ -346,7 +346,7 @@ InferencePassesSptr SubpixelLayerHip::createCS(const LayerGenOptions&) const { /
     auto ret = std::make_shared<InferencePasses>();
     ret->passes.resize(1);
     snnhip_subpixel_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(inputDims[0].batch);
     d.H = static_cast<int>(inputDims[0].height);
     d.W = static_cast<int>(inputDims[0].width);
     d.C = static_cast<int>(inputDims[0].channels);
@@ -363,7 +363,7 @@ InferencePassesSptr SubpixelLayerHip::createCS(const LayerGenOptions&) const { /
 
 static snnhip_eltwise_desc eltwiseDesc(const InferenceGraph::IODesc& in, const std::string& activation, float leaky) {
     snnhip_eltwise_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(in.batch);
     d.H = static_cast<int>(in.height);
     d.W = static_cast<int>(in.width);
     d.C = static_cast<int>(in.channels);
@@ -428,7 +428,7 @@ static InferencePassesSptr poolPasses(const InferenceGraph::IODesc& in, uint32_t
     auto ret = std::make_shared<InferencePasses>();
     ret->passes.resize(1);
     snnhip_pool2d_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(in.batch);
     d.H = static_cast<int>(in.height);
     d.W = static_cast<int>(in.width);
     d.C = static_cast<int>(in.channels);
@@ -519,7 +519,7 @@ InferencePassesSptr PadLayerHip::createCS(const LayerGenOptions&) const { // pad
     uint32_t p[4];
     getPaddingOffset(p);
     snnhip_pad_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(inputDims[0].batch);
     d.H = static_cast<int>(inputDims[0].height);
     d.W = static_cast<int>(inputDims[0].width);
     d.C = static_cast<int>(inputDims[0].channels);
@@ -554,7 +554,7 @@ InferencePassesSptr UpSampling2DLayerHip::createCS(const LayerGenOptions&) const
     auto ret = std::make_shared<InferencePasses>();
     ret->passes.resize(1);
     snnhip_upsample_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(inputDims[0].batch);
     d.H = static_cast<int>(inputDims[0].height);
     d.W = static_cast<int>(inputDims[0].width);
     d.C = static_cast<int>(inputDims[0].channels);
@@ -572,7 +572,7 @@ InferencePassesSptr ConcatenateLayerHip::createCS(const LayerGenOptions&) const 
     ret->passes.resize(1);
     SNN_CHK(inputDims.size() == 2);
     snnhip_concat_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(inputDims[0].batch);
     d.H = static_cast<int>(inputDims[0].height);
     d.W = static_cast<int>(inputDims[0].width);
     d.C0 = static_cast<int>(inputDims[0].channels);
@@ -587,7 +587,7 @@ InferencePassesSptr UnaryLayerHip::createCS(const LayerGenOptions&) const { // u
     auto ret = std::make_shared<InferencePasses>();
     ret->passes.resize(1);
     snnhip_unary_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(inputDims[0].batch);
     d.H = static_cast<int>(inputDims[0].height);
     d.W = static_cast<int>(inputDims[0].width);
     d.C = static_cast<int>(inputDims[0].channels);
@@ -602,7 +602,7 @@ InferencePassesSptr CalculateLayerHip::createCS(const LayerGenOptions&) const { 
     auto ret = std::make_shared<InferencePasses>();
     ret->passes.resize(1);
     snnhip_calculate_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(inputDims[0].batch);
     d.H = static_cast<int>(inputDims[0].height);
     d.W = static_cast<int>(inputDims[0].width);
     d.C = static_cast<int>(inputDims[0].channels);
@@ -618,7 +618,7 @@ InferencePassesSptr Conv2DTransposeLayerHip::createCS(const LayerGenOptions&) co
     uint32_t ow = 0, oh = 0, od = 0;
     getOutputDims(ow, oh, od);
     snnhip_conv2d_desc d = {};
-    d.N = 1;
+    d.N = static_cast<int>(inputDims[0].batch);
     d.H = static_cast<int>(inputDims[0].height);
     d.W = static_cast<int>(inputDims[0].width);
     d.IC = static_cast<int>(_desc.numInputPlanes);

@@ -27,7 +27,7 @@ struct RenderStage {
     ImageTextureArray stageOutputs;
     std::vector<int> inputIds;
     std::vector<int> delayBindMask;
-    bool fusedAway = false; // HIP extension: this stage's work is done by a chain plan launched from an earlier stage
+    bool fusedAway = false; // HIP extension: this stage's work is done by the fused plan of a later stage (HipBackend::finalizeStages)
 };
 typedef std::vector<RenderStage> RenderStagesArray;
 
@@ -59,6 +59,8 @@ public:
     size_t numStages() const { return stages.size(); }
     RenderStage& stage(size_t i) { return stages[i]; }
     std::string describe() const; // HIP extension: which kernel variant each stage runs
+    // HIP extension: run the next inferences launch by launch even when a recording exists (per-launch profiling needs the plans to run)
+    void suspendReplay(bool suspend) { replaySuspended = suspend; }
 
 private:
     GpuContext* context;
@@ -77,6 +79,7 @@ private:
     };
     std::vector<InputKey> recordedInputs; // device buffers the recording reads (delay-bound model inputs)
     bool graphUsable = false;
+    bool replaySuspended = false;
     Timer cpuRunTime = Timer("IC2 Total CPU Runtime");
     explicit MixedInferenceCore(GpuContext* context_);
     bool init(const CreationParameters& cp);

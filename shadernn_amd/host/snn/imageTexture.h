@@ -47,6 +47,7 @@ public:
     uint32_t height() const { return _dims[1]; }
     uint32_t depth() const { return _dims[2]; }
     uint32_t channels() const { return _channels; }
+    uint32_t batch() const { return _dims[3] ? _dims[3] : 1; } // HIP extension: dims[3] (the reference's unused "planes" slot, always 1 there) = images
     ColorFormat getFormat() const { return _format; }
     const std::string& getName() const { return _name; }
     std::string getTextureInfo2() const;

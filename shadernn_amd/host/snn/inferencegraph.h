@@ -17,6 +17,7 @@ struct InferenceGraph {
     struct IODesc {
         ColorFormat format;
         uint32_t width, height, depth, channels;
+        uint32_t batch = 1; // HIP extension: images per inference (the reference fixes the 4th texture dim to 1, core.cpp:371)
     };
     struct LayerRef {
         bool isStageOutput = false;

@@ -18,6 +18,8 @@ struct ShaderGenOptions {
     WeightAccessMethod weightMode = WeightAccessMethod::TEXTURES;
     // HIP backend extension: fuse linear runs of plans (snnhip_chain_plan_create) when outputs are not dumped
     bool fuseChains = true;
+    // HIP backend extension: images per inference; every stage tensor is [batch][H][W][C] (the reference runs one image, core.cpp:371)
+    uint32_t batch = 1;
 };
 } // namespace dp
 } // namespace snn

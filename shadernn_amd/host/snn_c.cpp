@@ -2,6 +2,7 @@
 #include <cstring>
 
 #include "../../include/snn_c.h"
+#include "../../include/snnhip.h"
 #include "ic2/backend.h"
 #include "ic2/dp.h"
 #include "ic2/layerFactory.h"
@@ -15,12 +16,12 @@ struct snn_model {
     std::unique_ptr<MixedInferenceCore> core;
     ImageTextureArray inputs{nullptr};
     ImageTextureArray outputs{nullptr};
-    int inW = 0, inH = 0, inC = 0;
+    int inW = 0, inH = 0, inC = 0, batch = 1;
     bool half = false;
     SNNModelOutput modelOutput;
 };
 
-static dp::ShaderGenOptions makeOptions(int w, int h, int c, bool fuse, bool half = false) {
+static dp::ShaderGenOptions makeOptions(int w, int h, int c, bool fuse, bool half = false, int batch = 1) {
     dp::ShaderGenOptions sgo;
     const ColorFormat fmt = half ? ColorFormat::RGBA16F : ColorFormat::RGBA32F;
     InferenceGraph::IODesc in{fmt, static_cast<uint32_t>(w), static_cast<uint32_t>(h), static_cast<uint32_t>(UP_DIV(c, 4)), static_cast<uint32_t>(c)};
@@ -29,6 +30,7 @@ static dp::ShaderGenOptions makeOptions(int w, int h, int c, bool fuse, bool hal
     sgo.preferrHalfPrecision = half;
     sgo.compute = true;
     sgo.fuseChains = fuse;
+    sgo.batch = static_cast<uint32_t>(batch);
     return sgo;
 }
 
@@ -36,7 +38,7 @@ static void makeIO(snn_model* m, bool half = false) {
     m->inputs = ImageTextureArray(m->context);
     m->outputs = ImageTextureArray(m->context);
     m->inputs.push_back(ImageTextureFactory::createImageTexture(m->context, {static_cast<uint32_t>(m->inW), static_cast<uint32_t>(m->inH),
-                                                                             static_cast<uint32_t>(UP_DIV(m->inC, 4)), 1},
+                                                                             static_cast<uint32_t>(UP_DIV(m->inC, 4)), static_cast<uint32_t>(m->batch)},
                                                                 half ? ColorFormat::RGBA16F : ColorFormat::RGBA32F, nullptr, static_cast<uint32_t>(m->inC)));
     m->outputs.allocate(1);
 }
@@ -55,13 +57,20 @@ int snn_model_create2(const char* json_path, int device, int in_w, int in_h, int
 
 int snn_model_create3(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
                       int prefer_half, int capture_graph, snn_model** out) {
+    return snn_model_create4(json_path, device, in_w, in_h, in_c, dump_outputs, fuse_chains, profiling, prefer_half, capture_graph, 1, out);
+}
+
+int snn_model_create4(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
+                      int prefer_half, int capture_graph, int batch, snn_model** out) {
+    if (!json_path || !out || batch < 1 || in_w < 1 || in_h < 1 || in_c < 1) return -1;
     const bool half = prefer_half != 0;
     auto* m = new snn_model();
+    m->batch = batch;
     m->context = createHipContext(device);
     m->inW = in_w;
     m->inH = in_h;
     m->inC = in_c;
-    dp::ShaderGenOptions sgo = makeOptions(in_w, in_h, in_c, fuse_chains != 0, half);
+    dp::ShaderGenOptions sgo = makeOptions(in_w, in_h, in_c, fuse_chains != 0, half, batch);
     auto layers = dp::loadFromJsonModel(json_path, false, sgo.mrtMode, sgo.weightMode, half); // preferHp: weights truncated to fp16 (Q13)
     MixedInferenceCore::CreationParameters cp;
     static_cast<InferenceGraph&>(cp) = dp::generateInferenceGraph(layers, sgo);
@@ -145,6 +154,8 @@ int snn_model_output_dims(snn_model* m, int hwc[3]) {
     return 0;
 }
 
+int snn_model_batch(snn_model* m) { return m->batch; }
+
 int snn_model_download_output(snn_model* m, float* nhwc) {
     lastOutput(m).downloadNHWC(nhwc);
     return 0;
@@ -171,6 +182,56 @@ int snn_model_download_stage(snn_model* m, int stage, float* nhwc) {
 
 int snn_model_describe(snn_model* m, char* buf, int buflen) {
     snprintf(buf, static_cast<size_t>(buflen), "%s", m->core->describe().c_str());
+    return 0;
+}
+
+// the plan a stage really launches (nullptr: input layer, CPU stage, or folded into a later stage's fused plan)
+static snnhip_plan* stagePlan(snn_model* m, int stage) {
+    if (stage < 0 || stage >= static_cast<int>(m->core->numStages())) return nullptr;
+    RenderStage& s = m->core->stage(static_cast<size_t>(stage));
+    auto* ml = static_cast<dp::GenericModelLayer*>(s.layer->modelLayer);
+    if (!ml || s.layer->isInputLayer || s.fusedAway || ml->getRenderPasses().size() != 1) return nullptr;
+    auto* rp = dynamic_cast<dp::HipRenderPass*>(ml->getRenderPasses()[0].get());
+    return (rp && !rp->skip) ? rp->plan : nullptr;
+}
+
+int snn_model_stage_plan_steps(snn_model* m, int stage) {
+    snnhip_plan* p = stagePlan(m, stage);
+    return p ? snnhip_plan_num_steps(p) : 0;
+}
+
+int snn_model_stage_plan_step(snn_model* m, int stage, int step, char* desc, int desc_len, double* flops, double* bytes) {
+    snnhip_plan* p = stagePlan(m, stage);
+    if (!p) return -1;
+    if (desc && desc_len > 0 && snnhip_plan_step_describe(p, step, desc, static_cast<size_t>(desc_len)) != SNNHIP_OK) return -1;
+    return snnhip_plan_step_cost(p, step, flops, bytes) == SNNHIP_OK ? 0 : -1;
+}
+
+int snn_model_profile_enable(snn_model* m, int enable) {
+    m->core->suspendReplay(enable != 0); // a replayed hipGraph never calls the plans: profiled inferences run launch by launch
+    for (int i = 0; i < static_cast<int>(m->core->numStages()); ++i)
+        if (snnhip_plan* p = stagePlan(m, i))
+            if (snnhip_plan_profile_enable(p, enable) != SNNHIP_OK) return -1;
+    return 0;
+}
+
+int snn_model_profile_read(snn_model* m, int stage, int step, double* total_ms, int* launches) {
+    snnhip_plan* p = stagePlan(m, stage);
+    if (!p) return -1;
+    return snnhip_plan_profile_read(p, step, total_ms, launches) == SNNHIP_OK ? 0 : -1;
+}
+
+int snn_model_cost(snn_model* m, double* flops, double* bytes) {
+    double f = 0, b = 0;
+    for (int i = 0; i < static_cast<int>(m->core->numStages()); ++i)
+        if (snnhip_plan* p = stagePlan(m, i)) {
+            double pf = 0, pb = 0;
+            if (snnhip_plan_cost(p, &pf, &pb) != SNNHIP_OK) return -1;
+            f += pf;
+            b += pb;
+        }
+    if (flops) *flops = f;
+    if (bytes) *bytes = b;
     return 0;
 }
 

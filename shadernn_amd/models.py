@@ -266,7 +266,31 @@ def to_json_dict(net, width, height):
     return out
 
 
-def write_json(net, width, height, path):
+def write_json(net, width, height, path, bin_weights=False):
+    """Writes the reference's JSON model.  bin_weights=True: convolution / depthwise / transposed-convolution / dense parameters go to a
+    "<name>.bin" side file of raw float32 named by numLayers.bin_file_name (modelparser.cpp:234-257) instead of inline JSON arrays --
+    read back sequentially in layer order: kernel (Conv2D flat OIHW :617-658, depthwise CHW :826-840, dense [In][Out] rows :527-535),
+    bias when useBias, then BN as gamma, beta, mean, variance (:685-757).  What real-size models (ResNet-18: 11.7 M weights) need."""
+    d = to_json_dict(net, width, height)
+    if bin_weights:
+        bin_path = path[:-5] + ".bin" if path.endswith(".json") else path + ".bin"
+        import os
+
+        d["numLayers"]["bin_file_name"] = os.path.basename(bin_path)
+        with open(bin_path, "wb") as fb:
+            for i, l in enumerate(net["layers"], start=1):
+                o = d["Layer_%d" % i]
+                t = l["type"]
+                if t not in ("Conv2D", "DepthwiseConv2D", "Conv2DTranspose", "Dense"):
+                    continue
+                o.pop("weights", None)
+                o.pop("batchNormalization", None)
+                np.ascontiguousarray(l["w"], dtype=np.float32).tofile(fb)  # Conv2D: OIHW; depthwise: CHW; dense: the flat kernel
+                if l.get("b") is not None:
+                    np.ascontiguousarray(l["b"], dtype=np.float32).tofile(fb)
+                if l.get("bn"):
+                    for k in ("gamma", "beta", "mean", "var"):
+                        np.ascontiguousarray(l["bn"][k], dtype=np.float32).tofile(fb)
     with open(path, "w") as f:
-        json.dump(to_json_dict(net, width, height), f)
+        json.dump(d, f)
     return path

@@ -1,6 +1,4 @@
 """Runs a chain-shaped net (models.py layer lists) through C-ABI plans: one plan per layer, or fused chain plans."""
-import os
-
 import numpy as np
 
 from . import capi
@@ -112,20 +110,24 @@ class EspcnRunner(ChainRunner):
 
 class GraphRunner:
     """Graph-shaped nets (models.resnet18 / mobilenetv2 / style_net): one plan per layer at any batch size, producers by name.
-    Tensors are allocated once; run_device() only enqueues kernels.  (The C++ host mirror runs the same graphs at batch 1 from JSON.)"""
+    Tensors are allocated once; run_device() only enqueues kernels.  (The C++ host mirror runs the same graphs from JSON.)"""
 
     def __init__(self, ctx, net, n, h, w, dtype=capi.F32, fuse=True):
         """dtype=capi.F16: half tensors end to end (convolutions on the fp16 MFMA path, fp32 accumulation).
-        fuse=True: a Pad layer whose only consumer is a Conv2D is folded into that convolution's tile staging through
-        snnhip_chain_plan_create (rule D); the pad's own tensor is then never produced (output_of(pad) is unavailable)."""
+        fuse=True: the layer DAG goes through snnhip_graph_fuse -- the same single fusion pass the C++ host's HipBackend::finalizeStages
+        uses (residual Conv2D -> Add pairs, [UpSampling2D ->] Pad -> Conv2D strings, ...).  Layers folded into a fused plan produce no
+        tensor of their own (output_of() is unavailable for them); `steps` lists what really runs."""
         from . import models
 
         self.ctx, self.net, self.dtype = ctx, net, dtype
         self.in_shape = (n, h, w, net["input_channels"])
         self.x = capi.Tensor(ctx, *self.in_shape, dtype=dtype)
-        shapes, self.tensors = {"input": self.in_shape}, {"input": self.x}
-        self.steps = []  # (plan, [input tensors], output tensor, layer)
-        for layer, ins in models.producers(net):
+        shapes = {"input": self.in_shape}
+        prods = models.producers(net)
+        index = {"input": -1}
+        nodes, self.layer_plans = [], []
+        self.output_names = models.output_names(net)  # several for multi-head graphs (YOLOv3-tiny)
+        for k, (layer, ins) in enumerate(prods):
             shape = shapes[ins[0]]
             if layer["type"] == "Add":  # output extent = max over the inputs (genericlayer.cpp:64-90)
                 shape = (shape[0], max(shapes[i][1] for i in ins), max(shapes[i][2] for i in ins), shape[3])
@@ -135,127 +137,25 @@ class GraphRunner:
             out_shape = plan.out_shape()
             if layer["type"] == "Flatten":
                 out_shape = (shape[0], 1, 1, shape[1] * shape[2] * shape[3])
-            t = capi.Tensor(ctx, *out_shape, dtype=dtype)
-            shapes[layer["name"]], self.tensors[layer["name"]] = out_shape, t
-            self.steps.append((plan, [self.tensors[i] for i in ins], t, layer))
-        self.output_names = models.output_names(net)  # several for multi-head graphs (YOLOv3-tiny)
-        self.fused_pads = []
-        self.fused_norms = []
-        self.fused_adds = []
-        if fuse:
-            self._fuse_pads(models.producers(net))
-            self._fuse_adds(models.producers(net))
+            shapes[layer["name"]] = out_shape
+            index[layer["name"]] = k
+            self.layer_plans.append(plan)
+            nodes.append((plan, [index[i] for i in ins], layer["name"] in self.output_names))
+        fused = capi.graph_fuse(ctx, nodes) if fuse else [(p, i) for p, i, _ in nodes]
+        names = ["input"] + [l["name"] for l, _ in prods]  # node index + 1
+        self.tensors = {"input": self.x}
+        self.steps = []  # (plan, [input tensors], output tensor, layer)
+        self.fused_layers = []
+        for k, ((layer, _), (plan, ins)) in enumerate(zip(prods, fused)):
+            if plan is None:
+                self.fused_layers.append(layer["name"])
+                continue
+            t = capi.Tensor(ctx, *shapes[layer["name"]], dtype=dtype)
+            self.tensors[layer["name"]] = t
+            self.steps.append((plan, [self.tensors[names[i + 1]] for i in ins], t, layer))
+        self.fused_norms = [l["name"] for p, _, _, l in self.steps if "instancenorm(fold" in p.describe()]  # chain rule F (opt-in)
         self.y = self.steps[-1][2]
         self.out_shape = shapes[net["layers"][-1]["name"]]
-
-    def _fuse_pads(self, prods):
-        """[UpSampling2D(nearest x2) ->] [Pad ->] Conv2D: the convolution stages its tiles straight from the tensor in front of the pad /
-        upsampling (chain rule D); the folded layers need a single consumer each."""
-        consumers = {}
-        for layer, ins in prods:
-            for i in ins:
-                consumers.setdefault(i, []).append(layer["name"])
-        outputs = set(self.output_names)
-        name_of = {id(t): nm for nm, t in self.tensors.items()}
-        by_name = {l["name"]: k for k, (_, _, _, l) in enumerate(self.steps)}
-        drop = set()
-
-        def foldable(nm, types):
-            if nm not in by_name or nm in outputs or len(consumers.get(nm, [])) != 1:
-                return None
-            st = self.steps[by_name[nm]]
-            return st if st[3]["type"] in types else None
-
-        for k, (plan, ins, out, layer) in enumerate(self.steps):
-            if layer["type"] != "Conv2D":
-                continue
-            chain_plans, first_ins, folded = [plan], ins, []
-            src = name_of.get(id(ins[0]))
-            st = foldable(src, ("Pad",))
-            if st:
-                chain_plans.insert(0, st[0])
-                first_ins, folded = st[1], [st[3]["name"]]
-                src = name_of.get(id(st[1][0]))
-            st = foldable(src, ("UpSampling2D",))
-            if st and st[3]["interpolation"] == "nearest" and float(st[3]["scaleFactor"]) == 2.0:
-                chain_plans.insert(0, st[0])
-                first_ins, folded = st[1], folded + [st[3]["name"]]
-            # chain rule F: an InstanceNorm that is the only consumer of this convolution takes its statistics from the convolution's epilogue
-            norm = None
-            users = consumers.get(layer["name"], [])
-            if len(users) == 1 and layer["name"] not in outputs and users[0] in by_name and self.steps[by_name[users[0]]][3]["type"] == "InstanceNorm":
-                norm = self.steps[by_name[users[0]]]
-            if norm is not None and os.environ.get("SNNHIP_NORM_FUSION", "0") not in ("", "0"):  # opt-in: measured neutral to negative (DESIGN.md)
-                try:
-                    chain = capi.chain_plan(self.ctx, chain_plans + [norm[0]])
-                except capi.SnnHipError as e:
-                    if e.code != capi.E_UNSUPPORTED:
-                        raise
-                    chain = None
-                if chain is not None and chain.num_steps() == 1:
-                    self.steps[k] = (chain, first_ins, norm[2], norm[3])
-                    drop.update(by_name[nm] for nm in folded + [norm[3]["name"]])
-                    self.fused_pads += folded
-                    self.fused_norms.append(norm[3]["name"])
-                    continue
-                if chain is not None:
-                    chain.destroy()
-            while len(chain_plans) > 1:
-                try:
-                    chain = capi.chain_plan(self.ctx, chain_plans)
-                except capi.SnnHipError as e:
-                    if e.code != capi.E_UNSUPPORTED:
-                        raise
-                    chain = None
-                if chain is not None and chain.num_steps() == 1:
-                    self.steps[k] = (chain, first_ins, out, layer)
-                    drop.update(by_name[nm] for nm in folded)
-                    self.fused_pads += folded
-                    break
-                if chain is not None:
-                    chain.destroy()
-                if len(chain_plans) == 3:  # the upsampling could not be folded: retry with the pad alone
-                    chain_plans, folded = chain_plans[1:], folded[:1]
-                    first_ins = self.steps[by_name[folded[0]]][1]
-                else:
-                    break
-        self.steps = [st for k, st in enumerate(self.steps) if k not in drop]
-
-    def _fuse_adds(self, prods):
-        """Conv2D -> Add (the residual connections of ResNet / MobileNetV2): the add moves into the convolution's epilogue (chain rule E)."""
-        consumers = {}
-        for layer, ins in prods:
-            for i in ins:
-                consumers.setdefault(i, []).append(layer["name"])
-        outputs = set(self.output_names)
-        name_of = {id(t): nm for nm, t in self.tensors.items()}
-        by_name = {l["name"]: k for k, (_, _, _, l) in enumerate(self.steps)}
-        drop, replace = set(), {}
-        for k, (plan, ins, out, layer) in enumerate(self.steps):
-            if layer["type"] != "Add" or len(ins) != 2:
-                continue
-            for which in (0, 1):
-                src = name_of.get(id(ins[which]))
-                if src not in by_name or by_name[src] in drop:
-                    continue
-                ck = by_name[src]
-                cplan, cins, cout, clayer = self.steps[ck]
-                if clayer["type"] != "Conv2D" or len(consumers.get(src, [])) != 1 or src in outputs or cout.shape != out.shape:
-                    continue
-                try:
-                    fused = capi.chain_plan(self.ctx, [cplan, plan])
-                except capi.SnnHipError as e:
-                    if e.code != capi.E_UNSUPPORTED:
-                        raise
-                    continue
-                if fused.num_steps() != 1 or "+add" not in fused.describe():
-                    fused.destroy()
-                    continue
-                replace[k] = (fused, [cins[0], ins[1 - which]], out, dict(layer, type="Conv2D", fused="conv+add"))
-                drop.add(ck)
-                self.fused_adds.append(layer["name"])
-                break
-        self.steps = [replace.get(k, st) for k, st in enumerate(self.steps) if k not in drop]
 
     def describe(self):
         return ["%s: %s" % (l["name"], p.describe()) for p, _, _, l in self.steps]

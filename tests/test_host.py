@@ -260,6 +260,8 @@ def test_host_batched_graphs(ctx, tmp_path, which, fuse):
     from shadernn_amd import host, models
 
     net, w, h = _small_nets()[which]
+    if which == 2:  # 32+ channels: the convolutions run on the MFMA kernel, the one with the fused pad / upsampling staging path
+        net, w, h = models.style_net(seed=4, width=32), 40, 32
     B = 3
     x = np.random.default_rng(6).random((B, h, w, 3), dtype=np.float32)
     path = models.write_json(net, w, h, str(tmp_path / (net["name"] + "_b.json")), bin_weights=True)

@@ -51,6 +51,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(size_t MN, int OC, i
     }
 }
 
+} // namespace
+
+// Launches the split-K reduce / epilogue pass: out = [act2(] act(BN(bias + sum_z ws[z])) [+ res)], shared with conv2d_wino.hip.
+int launch_splitk_reduce(snnhip_ctx* ctx, int OC, int splitK, int useBN, const ActCfg& ac, const float* ws, const float4* e4, snnhip_tensor* out,
+                         const snnhip_tensor* res, const ActCfg& ac2) {
+    const size_t MN = out->count();
+    size_t blocks = (MN + 255) / 256;
+    const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) * 8;
+    if (blocks > cap) blocks = cap;
+    const dim3 gr(static_cast<unsigned>(blocks));
+    const bool simple = act_is_simple(ac.act);
+    if (out->dtype == SNNHIP_F16) {
+        _Float16* yo = reinterpret_cast<_Float16*>(out->data);
+        const _Float16* rr = res ? reinterpret_cast<const _Float16*>(res->data) : nullptr;
+        if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, _Float16>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, yo, rr, ac2);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<false, _Float16>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, yo, rr, ac2);
+    } else {
+        const float* rr = res ? res->data : nullptr;
+        if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, float>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, out->data, rr, ac2);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<false, float>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, out->data, rr, ac2);
+    }
+    SNNHIP_CHECK_HIP(hipGetLastError());
+    return SNNHIP_OK;
+}
+
+namespace {
+
 struct MfmaConvPlan : ConvPlanBase {
     float* d_ws = nullptr; // split-K workspace
     MfmaParams p;
@@ -100,25 +127,8 @@ struct MfmaConvPlan : ConvPlanBase {
                        out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
         hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, static_cast<const void*>(x->data), static_cast<const void*>(d_w),
                            reinterpret_cast<const float4*>(d_epi), static_cast<void*>(out->data), d_ws);
-        if (p.splitK > 1) {
-            const size_t MN = out->count();
-            size_t blocks = (MN + 255) / 256;
-            const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) * 8;
-            if (blocks > cap) blocks = cap;
-            const dim3 gr(static_cast<unsigned>(blocks));
-            const float4* e4 = reinterpret_cast<const float4*>(d_epi);
-            const bool simple = act_is_simple(ac.act);
-            if (dtype == SNNHIP_F16) {
-                _Float16* yo = reinterpret_cast<_Float16*>(out->data);
-                const _Float16* rr = fusedAdd ? reinterpret_cast<const _Float16*>(in[1]->data) : nullptr;
-                if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, _Float16>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, yo, rr, p.ac2);
-                else hipLaunchKernelGGL((splitk_reduce_kernel<false, _Float16>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, yo, rr, p.ac2);
-            } else {
-                const float* rr = fusedAdd ? in[1]->data : nullptr;
-                if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, float>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, out->data, rr, p.ac2);
-                else hipLaunchKernelGGL((splitk_reduce_kernel<false, float>), gr, dim3(256), 0, ctx->stream, MN, p.OC, p.splitK, p.useBN, ac, d_ws, e4, out->data, rr, p.ac2);
-            }
-        }
+        if (p.splitK > 1)
+            return launch_splitk_reduce(ctx, p.OC, p.splitK, p.useBN, ac, d_ws, reinterpret_cast<const float4*>(d_epi), out, fusedAdd ? in[1] : nullptr, p.ac2);
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -411,6 +421,19 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
 // heuristics were fitted on a handful of shapes; measured on the ResNet-18 body (fp16, batch 32) the best candidate is 10-25 % faster on
 // the 28x28 / 14x14 / 7x7 stages, where block count, residency and the split-K reduce pass trade against each other.
 int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
+    // fp32 3x3 stride-1 layers with GEMM-sized channel counts: Winograd F(2x2,3x3) on the matrix pipe (conv2d_wino.hip), 2.25x fewer MFMA
+    // flops than the implicit GEMM below.  SNNHIP_CONV=wino forces it for every eligible shape, SNNHIP_CONV=mfma / SNNHIP_CONV_WINO=0 keep
+    // the direct kernel (tests run both on the same inputs).
+    {
+        const char* force = getenv("SNNHIP_CONV");
+        const char* w = getenv("SNNHIP_CONV_WINO");
+        const bool forced = force && strcmp(force, "wino") == 0;
+        const bool allowed = !force && !(w && atoi(w) == 0) && !getenv("SNNHIP_CONV_BN") && !getenv("SNNHIP_CONV_C8") && g.IC >= 32 && g.OC >= 32;
+        if (forced || allowed) {
+            const int rc = make_conv2d_wino_plan(ctx, g, w_oihw, epi4, out);
+            if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
+        }
+    }
     // pointwise layers (fp32, and fp16 with OC % 8 == 0) stream through conv1x1_stream.hip (no halo tile to stage); forcing a kernel or a
     // configuration skips it
     if (!getenv("SNNHIP_CONV") && !getenv("SNNHIP_CONV_BN") && !getenv("SNNHIP_CONV_SPLITK") && !getenv("SNNHIP_CONV_C8")) {

@@ -37,6 +37,8 @@ LAYERS = [
     ("mbv2 dw 3x3s2 96 @112 b32", 32, 112, 112, 96, 96, 3, 2, True),
     ("mbv2 dw 3x3 144 @56 b32", 32, 56, 56, 144, 144, 3, 1, True),
     ("mbv2 dw 3x3 384 @14 b32", 32, 14, 14, 384, 384, 3, 1, True),
+    ("unet 3x3 128->128 @128 b8", 8, 128, 128, 128, 128, 3, 1, False),
+    ("unet 3x3 64->64 @256 b8", 8, 256, 256, 64, 64, 3, 1, False),
     ("espcn conv2 3x3 16->16 @1080p b1", 1, 1080, 1920, 16, 16, 3, 1, False),
     ("espcn conv3 3x3 16->4 @1080p b1", 1, 1080, 1920, 16, 4, 3, 1, False),
     ("candy out 9x9 32->3 @720p b1", 1, 728, 1288, 32, 3, 9, 1, False),

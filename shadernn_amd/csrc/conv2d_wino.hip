@@ -8,9 +8,9 @@
 // GEMM.  fp32 MFMA and the fp32 VALU share the FMA lanes on this chip (tools/ubench_issue.hip), so the transforms are kept to the
 // minimum: activations are only added / subtracted (Bt, At have entries 0, +-1), G g Gt is computed on the host in double.
 //
-// Work decomposition (one block = 512 threads = 8 waves, 2 per SIMD, one block per CU):
-//   block tile = 64 Winograd tiles (TB images x TTH x TTW tiles = TB x 2TTH x 2TTW output pixels) x 64 output channels
-//   wave (tg, op): tile group tg = 16 consecutive tiles (the N of the MFMA), channel pair op = 2 blocks of 16 channels (the M)
+// Work decomposition (default: one block = 256 threads = 4 waves, two blocks per CU; SNNHIP_WINO_OPB=2: 512 threads / 64 channels, one per CU):
+//   block tile = 64 Winograd tiles (TB images x TTH x TTW tiles = TB x 2TTH x 2TTW output pixels) x 32 output channels
+//   wave tg: tile group = 16 consecutive tiles (the N of the MFMA) x 2 blocks of 16 channels (the M)
 //   K loop over 8-channel chunks, double-buffered in LDS, one barrier per chunk:
 //     U slab   [16 positions][2 channel pairs][lane = (k, m)] float4 = the MFMA A operands of both K steps and both channel blocks of a wave,
 //              pre-packed on the host in exactly this order (a chunk's slab is 32 KB of contiguous global memory; a lane's read is
@@ -29,6 +29,10 @@
 
 #include "epilogue.h"
 #include "snnhip_internal.h"
+
+#ifndef SNNHIP_WINO_ABL
+#define SNNHIP_WINO_ABL 0 // ablation builds only (tools/ablate_wino.sh; results are wrong by construction): 1 no barrier in the chunk loop,
+#endif                    // 2 no LDS stores, 4 no global loads, 8 no input transform, 16 no U reads, 32 no patch reads, 64 no U DMA, 128 no activation loads
 
 namespace snnhip {
 
@@ -50,17 +54,21 @@ struct WinoParams {
     int total;             // float4 elements staged per chunk (TB * inH * inW * 2)
     int bufFloats;         // floats per LDS buffer (U slab + 4 planes)
     int nChunks, splitK, chunksPerSplit;
-    int OCblocks;          // ceil(OC / 64)
+    int OCblocks;          // ceil(OC / (32 * OPB))
     int useBN;
     const float* res;      // fused residual Add (chain rule E), or nullptr
     ActCfg ac2;
 };
 
-constexpr int kUFloats = 16 * 4 * 64 * 2; // U slab of one chunk: 8192 floats = 32 KB
-
-template <bool SIMPLE>
-__global__ __launch_bounds__(512) void conv2d_wino_kernel(WinoParams p, ActCfg ac, const float* __restrict__ x, const float4* __restrict__ ug,
-                                                          const float4* __restrict__ epi, float* __restrict__ y, float* __restrict__ ws) {
+// OPB = output-channel pairs (2 x 16 channels) per block: 2 -> 512 threads, 64 channels, one block per CU; 1 -> 256 threads, 32 channels,
+// two independent blocks per CU (their barriers and LDS-read bursts drift apart, the pair of waves on a SIMD is no longer in lock step)
+template <bool SIMPLE, int OPB>
+__global__ __launch_bounds__(256 * OPB, 3 - OPB) void conv2d_wino_kernel(WinoParams p, ActCfg ac, const float* __restrict__ x, const float4* __restrict__ ug,
+                                                                        const float4* __restrict__ epi, float* __restrict__ y, float* __restrict__ ws) {
+    constexpr int NT = 256 * OPB;            // threads
+    constexpr int kUFloats = 4096 * OPB;     // U slab of one chunk: 16 positions x OPB pairs x 64 lanes x float4 (16 / 32 KB)
+    constexpr int UQ = 1024 * OPB;           // ... in float4
+    constexpr int R = 4 / OPB;               // staged activation quads per thread (halo tile of up to 1024 quads)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tg = wave & 3, op = wave >> 2;
@@ -72,12 +80,14 @@ __global__ __launch_bounds__(512) void conv2d_wino_kernel(WinoParams p, ActCfg a
     const int ox0 = tx * 2 * TTW, oy0 = ty * 2 * TTH, b0 = tb << p.TBs;
     const int ix0 = ox0 - p.padx, iy0 = oy0 - p.pady;
 
-    // ---- staging descriptors: element e = tid + 512 r -> (pixel of the halo tile, channel quad q = e & 1)
+    // ---- staging descriptors: element e = tid + NT r -> (pixel of the halo tile, channel quad q = e & 1)
     const int q = tid & 1;
-    int gofs[2], lofs[2];
+    int gofs[4], lofs[4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int e = tid + 512 * r;
+    for (int r = 0; r < 4; ++r) {
+        gofs[r] = lofs[r] = -1;
+        if (r >= R) continue;
+        const int e = tid + NT * r;
         gofs[r] = -1;
         lofs[r] = -1;
         if (e < p.total) {
@@ -90,45 +100,54 @@ __global__ __launch_bounds__(512) void conv2d_wino_kernel(WinoParams p, ActCfg a
         }
     }
     const int chunk0 = blockIdx.z * p.chunksPerSplit, chunk1 = min(p.nChunks, chunk0 + p.chunksPerSplit);
-    // U slab of (oc block, chunk): 2048 float4, thread t copies float4 t + 512 j, j < 4
-    const float4* uptr = ug + (static_cast<size_t>(blockIdx.y) * p.nChunks + chunk0) * 2048 + tid;
+    // U slab of (oc block, chunk): UQ float4, thread t copies float4 t + NT j, j < 4
+    const float4* uptr = ug + (static_cast<size_t>(blockIdx.y) * p.nChunks + chunk0) * UQ + tid;
 
-    // staging registers: two activation quads and four U quads per thread and chunk (plain scalars: arrays captured by reference went to scratch)
-    float4 sxa = make_float4(0.f, 0.f, 0.f, 0.f), sxb = sxa, su0, su1, su2, su3;
-#define WINO_STAGE_LOAD(chunk_)                                                                  \
-    do {                                                                                         \
-        sxa = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
-        sxb = sxa;                                                                               \
-        if (gofs[0] >= 0) sxa = *reinterpret_cast<const float4*>(x + gofs[0] + (chunk_) * 8);    \
-        if (gofs[1] >= 0) sxb = *reinterpret_cast<const float4*>(x + gofs[1] + (chunk_) * 8);    \
-        const float4* u_ = uptr + static_cast<size_t>((chunk_) - chunk0) * 2048;                 \
-        su0 = u_[0];                                                                             \
-        su1 = u_[512];                                                                           \
-        su2 = u_[1024];                                                                          \
-        su3 = u_[1536];                                                                          \
+    // Staging.  U slab: LDS-DMA (global_load_lds_dwordx4: a wave copies 64 consecutive float4 = 1 KiB per instruction straight into the slab,
+    // no staging registers and -- what the ablation builds showed to matter -- no VGPR -> LDS store traffic: the four ds_write_b128 per thread
+    // and chunk it replaces cost the kernel 20 %).  Activations: R quads per thread through registers (zero fill outside the image, split into
+    // the channel-pair planes); plain scalars: arrays captured by reference went to scratch.
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sxa = zero4, sxb = zero4, sxc = zero4, sxd = zero4;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+#define WINO_STAGE_LOAD(chunk_, buf_)                                                                                             \
+    do {                                                                                                                          \
+        const float4* u_ = uptr + static_cast<size_t>((chunk_) - chunk0) * UQ;                                                    \
+        float* ub_ = (buf_) + 4 * (wave * 64);                                                                                    \
+        if (!(SNNHIP_WINO_ABL & 64)) {                                                                                            \
+            __builtin_amdgcn_global_load_lds(u_, (lds_ptr)(ub_), 16, 0, 0);                                                       \
+            __builtin_amdgcn_global_load_lds(u_ + NT, (lds_ptr)(ub_ + 4 * NT), 16, 0, 0);                                         \
+            __builtin_amdgcn_global_load_lds(u_ + 2 * NT, (lds_ptr)(ub_ + 8 * NT), 16, 0, 0);                                     \
+            __builtin_amdgcn_global_load_lds(u_ + 3 * NT, (lds_ptr)(ub_ + 12 * NT), 16, 0, 0);                                    \
+        }                                                                                                                         \
+        sxa = sxb = sxc = sxd = zero4;                                                                                            \
+        if (SNNHIP_WINO_ABL & 128) break;                                                                                         \
+        if (gofs[0] >= 0) sxa = *reinterpret_cast<const float4*>(x + gofs[0] + (chunk_) * 8);                                     \
+        if (gofs[1] >= 0) sxb = *reinterpret_cast<const float4*>(x + gofs[1] + (chunk_) * 8);                                     \
+        if (R > 2 && gofs[2] >= 0) sxc = *reinterpret_cast<const float4*>(x + gofs[2] + (chunk_) * 8);                            \
+        if (R > 2 && gofs[3] >= 0) sxd = *reinterpret_cast<const float4*>(x + gofs[3] + (chunk_) * 8);                            \
     } while (0)
+#define WINO_STORE_X(r_, v_)                                                                                     \
+    if (lofs[r_] >= 0) {                                                                                         \
+        *reinterpret_cast<float2*>(b_ + lofs[r_]) = make_float2(v_.x, v_.y);                                     \
+        *reinterpret_cast<float2*>(b_ + lofs[r_] + p.planeStride) = make_float2(v_.z, v_.w);                     \
+    }
 #define WINO_STAGE_STORE(buf_)                                                                                   \
     do {                                                                                                         \
         float* b_ = (buf_);                                                                                      \
-        if (lofs[0] >= 0) {                                                                                      \
-            *reinterpret_cast<float2*>(b_ + lofs[0]) = make_float2(sxa.x, sxa.y);                                \
-            *reinterpret_cast<float2*>(b_ + lofs[0] + p.planeStride) = make_float2(sxa.z, sxa.w);                \
+        WINO_STORE_X(0, sxa)                                                                                     \
+        WINO_STORE_X(1, sxb)                                                                                     \
+        if (R > 2) {                                                                                             \
+            WINO_STORE_X(2, sxc)                                                                                 \
+            WINO_STORE_X(3, sxd)                                                                                 \
         }                                                                                                        \
-        if (lofs[1] >= 0) {                                                                                      \
-            *reinterpret_cast<float2*>(b_ + lofs[1]) = make_float2(sxb.x, sxb.y);                                \
-            *reinterpret_cast<float2*>(b_ + lofs[1] + p.planeStride) = make_float2(sxb.z, sxb.w);                \
-        }                                                                                                        \
-        *reinterpret_cast<float4*>(b_ + 4 * tid) = su0;                                                          \
-        *reinterpret_cast<float4*>(b_ + 4 * (tid + 512)) = su1;                                                  \
-        *reinterpret_cast<float4*>(b_ + 4 * (tid + 1024)) = su2;                                                 \
-        *reinterpret_cast<float4*>(b_ + 4 * (tid + 1536)) = su3;                                                 \
     } while (0)
 
     // ---- this lane's tile: t = 16 tg + n16 -> (image b, tile row, tile column) of the block tile
     const int t = 16 * tg + n16;
     const int ttx = t & (TTW - 1), tty = (t >> p.TTWs) & (TTH - 1), tbi = t >> (p.TTWs + p.TTHs);
     const int patch = kUFloats + k * p.planeStride + ((tbi * p.inH + 2 * tty) * p.rowPitch + 2 * ttx) * 2; // + (dy*rowPitch + dx)*2
-    const int uoff = op * 256 + lane * 4;                                                                  // + pos * 512: float4 {U[2op].s0, .s1, U[2op+1].s0, .s1}
+    const int uoff = op * 256 + lane * 4;                                                                  // + pos * 256 * OPB: float4 {U[2op].s0, .s1, U[2op+1].s0, .s1}
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -136,29 +155,42 @@ __global__ __launch_bounds__(512) void conv2d_wino_kernel(WinoParams p, ActCfg a
 #pragma unroll
         for (int o = 0; o < 2; ++o) acc[i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    WINO_STAGE_LOAD(chunk0);
+    WINO_STAGE_LOAD(chunk0, smem);
     WINO_STAGE_STORE(smem);
     __syncthreads();
 
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         const float* buf = smem + ((chunk - chunk0) & 1) * p.bufFloats;
         const bool more = chunk + 1 < chunk1;
-        if (more) WINO_STAGE_LOAD(chunk + 1);
+        float* nbuf = smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats; // the buffer nobody reads during this chunk
+        if (more && !(SNNHIP_WINO_ABL & 4)) WINO_STAGE_LOAD(chunk + 1, nbuf);
 
+        // Issue order is pinned with sched_barrier: the patch and the first eight U operands are requested up front, the rest while the
+        // first MFMAs run, and the next chunk goes to the OTHER LDS buffer in the middle of the MFMA stream (its global loads were issued a
+        // thousand cycles earlier), so that the end of the chunk is only the barrier.  Left to itself the scheduler sinks every ds_read next
+        // to its use (fewest registers) and the wave eats one LDS latency per position: 31 % matrix-pipe utilisation (PMC), 48 % after.
+        float4 t4[4][2], u[16];
+#define WINO_LDU(i) u[i] = (SNNHIP_WINO_ABL & 16) ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(buf + uoff + (i) * (256 * OPB))
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) // one ds_read_b128 = two adjacent pixels of the pair plane
+                t4[dy][h2] = (SNNHIP_WINO_ABL & 32) ? make_float4(1.f + dy, 2.f, 3.f + h2, 4.f) : *reinterpret_cast<const float4*>(buf + patch + (dy * p.rowPitch + 2 * h2) * 2);
+        WINO_LDU(0); WINO_LDU(1); WINO_LDU(2); WINO_LDU(3); WINO_LDU(4); WINO_LDU(5); WINO_LDU(6); WINO_LDU(7);
+        __builtin_amdgcn_sched_barrier(0);
         // the 4x4 patch of (tile, channel pair), both channels of the pair
         float2 d[4][4];
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 4; dx += 2) { // one ds_read_b128 = two adjacent pixels of the pair plane
-                const float4 t4 = *reinterpret_cast<const float4*>(buf + patch + (dy * p.rowPitch + dx) * 2);
-                d[dy][dx] = make_float2(t4.x, t4.y);
-                d[dy][dx + 1] = make_float2(t4.z, t4.w);
+            for (int h2 = 0; h2 < 2; ++h2) {
+                d[dy][2 * h2] = make_float2(t4[dy][h2].x, t4[dy][h2].y);
+                d[dy][2 * h2 + 1] = make_float2(t4[dy][h2].z, t4[dy][h2].w);
             }
         // V = Bt d B, Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
         float2 v[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4 && !(SNNHIP_WINO_ABL & 8); ++j) {
             const float2 a0 = d[0][j], a1 = d[1][j], a2 = d[2][j], a3 = d[3][j];
             d[0][j] = make_float2(a0.x - a2.x, a0.y - a2.y);
             d[1][j] = make_float2(a1.x + a2.x, a1.y + a2.y);
@@ -168,23 +200,37 @@ __global__ __launch_bounds__(512) void conv2d_wino_kernel(WinoParams p, ActCfg a
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float2 a0 = d[i][0], a1 = d[i][1], a2 = d[i][2], a3 = d[i][3];
+            if (SNNHIP_WINO_ABL & 8) {
+                v[i][0] = a0; v[i][1] = a1; v[i][2] = a2; v[i][3] = a3;
+                continue;
+            }
             v[i][0] = make_float2(a0.x - a2.x, a0.y - a2.y);
             v[i][1] = make_float2(a1.x + a2.x, a1.y + a2.y);
             v[i][2] = make_float2(a2.x - a1.x, a2.y - a1.y);
             v[i][3] = make_float2(a1.x - a3.x, a1.y - a3.y);
         }
         // 16 positions x 2 channel blocks x 2 K steps: M[pos][oc][tile] += U[pos][oc][ic] V[pos][ic][tile]
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos) {
-            const float4 u = *reinterpret_cast<const float4*>(buf + uoff + pos * 512);
-            const float2 vv = v[pos >> 2][pos & 3];
-            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, vv.x, acc[pos][0], 0, 0, 0);
-            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, vv.x, acc[pos][1], 0, 0, 0);
-            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, vv.y, acc[pos][0], 0, 0, 0);
-            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, vv.y, acc[pos][1], 0, 0, 0);
-        }
-        if (more) WINO_STAGE_STORE(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats);
-        __syncthreads();
+#define WINO_STEP(pos)                                                                                       \
+    do {                                                                                                     \
+        const float2 vv_ = v[(pos) >> 2][(pos) & 3];                                                         \
+        acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[pos].x, vv_.x, acc[pos][0], 0, 0, 0);           \
+        acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[pos].z, vv_.x, acc[pos][1], 0, 0, 0);           \
+        acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[pos].y, vv_.y, acc[pos][0], 0, 0, 0);           \
+        acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[pos].w, vv_.y, acc[pos][1], 0, 0, 0);           \
+    } while (0)
+        WINO_STEP(0); WINO_STEP(1); WINO_STEP(2); WINO_STEP(3);
+        __builtin_amdgcn_sched_barrier(0);
+        WINO_LDU(8); WINO_LDU(9); WINO_LDU(10); WINO_LDU(11);
+        __builtin_amdgcn_sched_barrier(0);
+        WINO_STEP(4); WINO_STEP(5); WINO_STEP(6); WINO_STEP(7);
+        __builtin_amdgcn_sched_barrier(0);
+        WINO_LDU(12); WINO_LDU(13); WINO_LDU(14); WINO_LDU(15);
+        if (more && !(SNNHIP_WINO_ABL & 2)) WINO_STAGE_STORE(nbuf);
+        __builtin_amdgcn_sched_barrier(0);
+        WINO_STEP(8); WINO_STEP(9); WINO_STEP(10); WINO_STEP(11); WINO_STEP(12); WINO_STEP(13); WINO_STEP(14); WINO_STEP(15);
+#undef WINO_STEP
+#undef WINO_LDU
+        if (!(SNNHIP_WINO_ABL & 1)) __syncthreads();
     }
 
     // ---- Y = At M A, At = [1 1 1 0; 0 1 -1 -1]; lane holds output channels 4k..4k+3 of each 16-channel block for its tile
@@ -192,7 +238,7 @@ __global__ __launch_bounds__(512) void conv2d_wino_kernel(WinoParams p, ActCfg a
     const bool addSimple = act_is_simple_dev(p.ac2.act);
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
-        const int oc = blockIdx.y * 64 + (2 * op + o) * 16 + 4 * k;
+        const int oc = blockIdx.y * (32 * OPB) + (2 * op + o) * 16 + 4 * k;
         if (oc >= p.OC) continue;
         f32x4 yv[2][2];
 #pragma unroll
@@ -252,6 +298,7 @@ struct WinoConvPlan : ConvPlanBase {
     dim3 grid;
     bool fusedAdd = false;
     bool simple = true;
+    int opb = 1;
 
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == (fusedAdd ? 2 : 1), "conv2d: expects %d input(s), got %d", fusedAdd ? 2 : 1, nIn);
@@ -271,8 +318,13 @@ struct WinoConvPlan : ConvPlanBase {
                        out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
         const float4* u4 = reinterpret_cast<const float4*>(d_u);
         const float4* e4 = reinterpret_cast<const float4*>(d_epi);
-        if (simple) hipLaunchKernelGGL((conv2d_wino_kernel<true>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
-        else hipLaunchKernelGGL((conv2d_wino_kernel<false>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+        if (opb == 2) {
+            if (simple) hipLaunchKernelGGL((conv2d_wino_kernel<true, 2>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+            else hipLaunchKernelGGL((conv2d_wino_kernel<false, 2>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+        } else {
+            if (simple) hipLaunchKernelGGL((conv2d_wino_kernel<true, 1>), grid, dim3(256), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+            else hipLaunchKernelGGL((conv2d_wino_kernel<false, 1>), grid, dim3(256), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+        }
         SNNHIP_CHECK_HIP(hipGetLastError());
         if (p.splitK > 1) return launch_splitk_reduce(ctx, p.OC, p.splitK, p.useBN, ac, d_ws, e4, out, fusedAdd ? in[1] : nullptr, p.ac2);
         return SNNHIP_OK;
@@ -292,6 +344,10 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     // block tile: TB x TTH x TTW = 64 Winograd tiles, minimising padded tiles; a wave's 16 consecutive tiles must not straddle images
     // (TTH * TTW >= 16 and TTH >= 16 / TTW when TTW < 16: the bank analysis of the patch reads assumes whole tile rows of one image)
     const int tilesW = up_div(g.OW, 2), tilesH = up_div(g.OH, 2);
+    // OPB = 1 (default): 256-thread blocks of 32 output channels, two per CU; SNNHIP_WINO_OPB=2: 512-thread blocks of 64 channels, one per CU
+    int opb = 1;
+    if (const char* e = getenv("SNNHIP_WINO_OPB")) opb = atoi(e) == 2 ? 2 : 1;
+    const int ocPerBlock = 32 * opb, kUFloats = 4096 * opb;
     int best[3] = {0, 2, 4};
     double bestCost = 1e300;
     for (int ws = 2; ws <= 5; ++ws)
@@ -316,20 +372,24 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.inH = 2 * TTH + 2;
     p.inW = 2 * TTW + 2;
     p.rowPitch = p.inW;
-    if (TTW < 16)
-        while (p.rowPitch % 16 != TTW) ++p.rowPitch; // tile-row stride (4 * rowPitch floats) = 4 * TTW mod 64: the next tile row continues the bank sequence
+    // a wave's 16 tiles span 16 / TTW tile rows: their bank offsets (tile-row stride = 4 * rowPitch floats) must be distinct multiples of 4 * TTW
+    // mod 64 -> rowPitch = 8 mod 16 for TTW = 8, an odd multiple of 4 for TTW = 4
+    if (TTW == 8)
+        while (p.rowPitch % 16 != 8) ++p.rowPitch;
+    if (TTW == 4)
+        while (p.rowPitch % 8 != 4) ++p.rowPitch;
     p.planeStride = round_up(TB * p.inH * p.rowPitch * 2, 64); // 0 mod 64 floats: with ds_read_b128's lane groups the k and k+1 planes interleave bank-exactly
     p.total = TB * p.inH * p.inW * 2;
     p.bufFloats = kUFloats + 4 * p.planeStride;
     p.nChunks = g.IC / 8;
-    p.OCblocks = up_div(g.OC, 64);
+    p.OCblocks = up_div(g.OC, ocPerBlock);
     p.useBN = g.useBN;
     p.ac2 = make_act_cfg(g.addAct >= 0 ? g.addAct : 0, g.addLeaky);
     const size_t lds = static_cast<size_t>(2) * p.bufFloats * sizeof(float);
     if (lds > 160 * 1024) return SNNHIP_E_UNSUPPORTED;
 
-    // split-K: one block per CU and 256 CUs -- split the channel chunks while the layer has fewer block tiles than CUs
-    const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+    // split-K: split the channel chunks while the layer has fewer block tiles than resident block slots
+    const int cus = (ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) * (3 - opb);
     const int blocks = p.tilesX * p.tilesY * up_div(g.N, TB) * p.OCblocks;
     int splitK = 1;
     if (const char* e = getenv("SNNHIP_CONV_SPLITK")) splitK = std::max(1, atoi(e));
@@ -350,10 +410,12 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->ldsBytes = lds;
     plan->fusedAdd = g.addAct >= 0;
     if (plan->fusedAdd) plan->numInputs = 2;
+    plan->opb = opb;
     plan->grid = dim3(p.tilesX * p.tilesY * up_div(g.N, TB), p.OCblocks, p.splitK);
     plan->dtype = SNNHIP_F32;
     for (int s = 0; s < 2; ++s) {
-        const void* fn = s ? reinterpret_cast<const void*>(conv2d_wino_kernel<true>) : reinterpret_cast<const void*>(conv2d_wino_kernel<false>);
+        const void* fn = opb == 2 ? (s ? reinterpret_cast<const void*>(conv2d_wino_kernel<true, 2>) : reinterpret_cast<const void*>(conv2d_wino_kernel<false, 2>))
+                                  : (s ? reinterpret_cast<const void*>(conv2d_wino_kernel<true, 1>) : reinterpret_cast<const void*>(conv2d_wino_kernel<false, 1>));
         if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
             set_error("conv2d_wino: hipFuncSetAttribute(%zu) failed", lds);
             delete plan;
@@ -382,15 +444,15 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
             double Gg[4][3];
             for (int i = 0; i < 4; ++i)
                 for (int b = 0; b < 3; ++b) Gg[i][b] = G[i][0] * w[0 * 3 + b] + G[i][1] * w[1 * 3 + b] + G[i][2] * w[2 * 3 + b];
-            const int blk = oc / 64, ocb = (oc % 64) / 16, m = oc % 16, chunk = ic / 8, kk = (ic % 8) / 2, s = ic % 2;
+            const int blk = oc / ocPerBlock, ocb = (oc % ocPerBlock) / 16, m = oc % 16, chunk = ic / 8, kk = (ic % 8) / 2, s = ic % 2;
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) {
                     const double u = Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2];
-                    const size_t at = ((static_cast<size_t>(blk) * p.nChunks + chunk) * 32 + (i * 4 + j) * 2 + (ocb >> 1)) * 256 + (kk * 16 + m) * 4 + (ocb & 1) * 2 + s;
+                    const size_t at = ((static_cast<size_t>(blk) * p.nChunks + chunk) * 16 * opb + (i * 4 + j) * opb + (ocb >> 1)) * 256 + (kk * 16 + m) * 4 + (ocb & 1) * 2 + s;
                     U[at] = static_cast<float>(u);
                 }
         }
-    std::vector<float> epiP(static_cast<size_t>(p.OCblocks) * 64 * 4, 0.0f);
+    std::vector<float> epiP(static_cast<size_t>(p.OCblocks) * ocPerBlock * 4, 0.0f);
     std::memcpy(epiP.data(), epi4.data(), sizeof(float) * 4 * static_cast<size_t>(g.OC));
     int rc = plan->upload(U.data(), U.size(), &plan->d_u);
     if (rc == SNNHIP_OK) rc = plan->upload(epiP.data(), epiP.size(), &plan->d_epi);
@@ -402,10 +464,10 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
     plan->flops = 2.0 * 9 * g.IC * g.OC * static_cast<double>(g.OH) * g.OW * g.N; // algorithmic (direct-convolution) count, SURVEY 8d
     plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * 9);
-    const double mfmaFlops = 2.0 * 16 * 64 * 8 * 64 * static_cast<double>(plan->grid.x) * p.OCblocks * p.nChunks; // executed on the matrix pipe (padded tiles included)
+    const double mfmaFlops = 2.0 * 16 * 64 * 8 * ocPerBlock * static_cast<double>(plan->grid.x) * p.OCblocks * p.nChunks; // executed on the matrix pipe (padded tiles included)
     char buf[320];
-    snprintf(buf, sizeof(buf), "conv2d_mfma_wino_f32_16x16x4 F(2x2,3x3) k=3x3 s=1 ic=%d oc=%d tile=%dx%dx%dpx x 64oc chunk=8 lds=%zuB splitK=%d mfma_flops=%.6g",
-             g.IC, g.OC, TB, 2 * TTH, 2 * TTW, lds, p.splitK, mfmaFlops);
+    snprintf(buf, sizeof(buf), "conv2d_mfma_wino_f32_16x16x4 F(2x2,3x3) k=3x3 s=1 ic=%d oc=%d tile=%dx%dx%dpx x %doc chunk=8 lds=%zuB splitK=%d mfma_flops=%.6g",
+             g.IC, g.OC, TB, 2 * TTH, 2 * TTW, ocPerBlock, lds, p.splitK, mfmaFlops);
     plan->desc = buf;
     if (plan->fusedAdd) {
         plan->desc += " +add";

@@ -10,8 +10,10 @@ Configs (BASELINE.json `configs`, SURVEY 8d shapes; default c2 = the configurati
   c1  single 3x3 Conv2D, 1x224x224x3 -> 64, relu, fp32; one layer launch per step and rank                        (weak)
   c2  ESPCN 2x 1080p -> 4K, batch 1 per rank, fp32 (conv5x5 1->16 relu, conv3x3 16->16 relu, conv3x3 16->4, d2s+tanh)  (weak)
   c3  ResNet-18 224x224 fp32, batch 32 per rank                                                                    (weak)
-  c4  MobileNetV2 224x224 fp32, GLOBAL batch 256 sharded over the ranks (dist.shard_range), micro-batches of 32    (strong)
-  c5  Candy (fast-neural-style, the zoo graph) 720p fp16, GLOBAL batch 64 sharded over the ranks, micro-batches of 8 (strong)
+  c4  MobileNetV2 224x224 fp32, GLOBAL batch 256 sharded over the ranks (dist.shard_range), a rank's share in one pass (strong)
+  c5  Candy (fast-neural-style, the zoo graph) 720p fp16, GLOBAL batch 64 sharded over the ranks, micro-batches <= 16 (strong)
+      (--micro N overrides; measured on one MI355X: c4 as 8 x 32 images 9.4 ms, 4 x 64 6.6 ms, 2 x 128 5.6 ms, 1 x 256 5.0 ms per step --
+      the 14x14 / 7x7 layers of a 32-image batch do not fill 256 CUs)
 One "step" = one pass of the path over that batch, inputs already resident in HBM.  Multi-GPU = embarrassingly parallel batch
 split: no data-path collective; RCCL carries only the barrier / MAX-reduction of the elapsed time.
 Rank 0 prints ONE JSON line.
@@ -52,9 +54,9 @@ CONFIGS = {
     "c3": {"workload": "ResNet-18 224x224 fp32, batch 32 per GPU (BASELINE configs[2])", "dtype": "f32", "scaling": "weak", "per_rank": 32, "micro": 32,
            "hw": (224, 224), "cin": 3},
     "c4": {"workload": "MobileNetV2 224x224 fp32, global batch 256 sharded over the GPUs (BASELINE configs[3])", "dtype": "f32", "scaling": "strong",
-           "global": 256, "micro": 32, "hw": (224, 224), "cin": 3},
+           "global": 256, "micro": 256, "hw": (224, 224), "cin": 3},
     "c5": {"workload": "Candy fast-neural-style (zoo graph) 720p fp16, global batch 64 sharded over the GPUs (BASELINE configs[4])", "dtype": "f16",
-           "scaling": "strong", "global": 64, "micro": 8, "hw": (720, 1280), "cin": 3},
+           "scaling": "strong", "global": 64, "micro": 16, "hw": (720, 1280), "cin": 3},
 }
 
 
@@ -83,7 +85,7 @@ def make_net(config):
     return zoo_net("candy-9_simplified-opt", (720, 1280, 3))
 
 
-def shard_plan(config, world, rank):
+def shard_plan(config, world, rank, micro=0):
     """(images of this rank per step, global batch, micro-batch sizes): c4 / c5 split a FIXED global batch with dist.shard_range
     (GPU g of G gets images [g*B/G, (g+1)*B/G)), the other configs give every rank the same share."""
     from shadernn_amd import dist as sdist
@@ -96,7 +98,7 @@ def shard_plan(config, world, rank):
         images, global_batch, first = cfg["per_rank"], cfg["per_rank"] * world, rank * cfg["per_rank"]
     sizes, left = [], images
     while left > 0:
-        sizes.append(min(cfg["micro"], left))
+        sizes.append(min(micro or cfg["micro"], left))
         left -= sizes[-1]
     return {"images": images, "global_batch": global_batch, "first_image": first, "micro_sizes": sizes}
 
@@ -298,6 +300,7 @@ def main():
     ap.add_argument("--through", choices=["auto", "host", "capi"], default="auto",
                     help="host: the C++ host mirror (libsnn_core.so: JSON/.bin model -> MixedInferenceCore::run, default for c3-c5); "
                          "capi: per-layer plans driven from Python through the C-ABI (default for c1, c2)")
+    ap.add_argument("--micro", type=int, default=0, help="micro-batch size of the rank's share (default: the config's)")
     ap.add_argument("--no-capture", action="store_true", help="host path: launch kernel by kernel instead of replaying the recorded hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with events (overhead check)")
@@ -341,7 +344,7 @@ def main():
     ctx = snn.Context(dev, stream=stream.cuda_stream)
     info = ctx.info()
     net = make_net(args.config)
-    shard = shard_plan(args.config, world, rank)
+    shard = shard_plan(args.config, world, rank, args.micro)
     images, global_batch = shard["images"], shard["global_batch"]
     if images == 0:
         sys.stderr.write("bench.py: rank %d has no images (global batch %d over %d ranks)\n" % (rank, global_batch, world))

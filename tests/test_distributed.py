@@ -90,8 +90,9 @@ def _c4_worker(rank, world, port, q):
     from shadernn_amd import dist, models
 
     g = dist.Group(backend="gloo")
-    shard = bench.shard_plan("c4", world, rank)  # the split bench.py times: 256 images -> 128 per rank, micro-batches of 32
+    shard = bench.shard_plan("c4", world, rank, micro=32)  # the split bench.py times: 256 images -> 128 per rank (here as micro-batches of 32)
     assert shard["global_batch"] == 256 and shard["images"] == 128 and shard["micro_sizes"] == [32] * 4 and shard["first_image"] == 128 * rank
+    assert bench.shard_plan("c4", world, rank)["micro_sizes"] == [128]  # default: a rank's share in one pass
     # compute stand-in (no GPU here): the oracle on a width-reduced MobileNetV2 at 16x16, image i = f(i) so the shard identity is checkable
     net = models.mobilenetv2(seed=1, num_classes=4, width_mult=0.25)
     rng = np.random.default_rng(7)

@@ -1540,6 +1540,18 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);
             i += 2;
             ++fusedCount;
+        } else if (snnhip_plan* irb = nullptr; i + 2 < n && c0 && c1 && c2 && !c0->depthwise && c1->depthwise && !c2->depthwise &&
+                                        make_irb_plan(ctx, plans[i], plans[i + 1], plans[i + 2], nullptr, &irb) == SNNHIP_OK) {
+            // ---- rule G: Conv2D 1x1 -> DepthwiseConv2D 3x3 -> Conv2D 1x1 (an inverted-residual block without skip connection) -> one kernel
+            chain->owned.push_back(irb);
+            st.kind = ChainPlan::PLAIN;
+            st.plain = irb;
+            memcpy(st.outDims, irb->outDims, sizeof(st.outDims));
+            st.desc = irb->desc;
+            st.flops = irb->flops;
+            st.bytes = irb->bytes;
+            i += 3;
+            ++fusedCount;
         } else if (auto* up = dynamic_cast<UpsamplePlanBase*>(plans[i]);
                    up && up->d.mode == SNNHIP_UPSAMPLE_NEAREST && up->d.scale == 2.0f && up->OH == 2 * up->d.H && up->OW == 2 * up->d.W && i + 1 < n &&
                    !getenv("SNNHIP_NO_PAD_FUSION")) {

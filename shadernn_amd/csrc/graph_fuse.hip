@@ -2,7 +2,8 @@
 //
 // The fusion RULES live in the chain planner (make_chain_plan, espcn_fused.hip: A/B/C ESPCN kernels, D [UpSampling2D ->] Pad -> Conv2D,
 // E Conv2D -> Add, F Conv2D -> InstanceNorm).  This file only decides which groups of a DAG are offered to it:
-//   1. residual pairs: an Add one of whose inputs is a convolution that nobody else reads (ResNet / MobileNetV2 skip connections);
+//   0. inverted-residual blocks with a skip connection: Add(project(depthwise(expand(X))), X) (MobileNetV2);
+//   1. residual pairs: an Add one of whose inputs is a convolution that nobody else reads (ResNet skip connections);
 //   2. maximal linear runs: node t+1 reads only node t, node t is read only by node t+1 (Candy's pad -> conv -> norm strings, ESPCN).
 // Counterpart in the reference: none -- it dispatches one compute shader per layer (vulkanRenderpass.cpp:257-259).
 #include <vector>
@@ -38,6 +39,37 @@ extern "C" int snnhip_graph_fuse(snnhip_ctx* ctx, const snnhip_graph_node* nodes
             }
         return rc;
     };
+
+    // ---- 0. inverted-residual block with skip connection (rule G): X -> Conv2D 1x1 -> DepthwiseConv2D -> Conv2D 1x1 -> Add(., X) -> one plan at
+    // the Add node that reads X only
+    for (int r = 0; r < n; ++r) {
+        if (!nodes[r].plan || nodes[r].n_inputs != 2 || taken[static_cast<size_t>(r)]) continue;
+        auto* add = dynamic_cast<EltwisePlanBase*>(nodes[r].plan);
+        if (!add || add->mode != 0) continue;
+        for (int which = 0; which < 2; ++which) {
+            const int pj = nodes[r].inputs[which];
+            if (!foldable(pj) || nodes[pj].n_inputs != 1) continue;
+            const int dw = nodes[pj].inputs[0];
+            if (!foldable(dw) || nodes[dw].n_inputs != 1) continue;
+            const int ex = nodes[dw].inputs[0];
+            if (!foldable(ex) || nodes[ex].n_inputs != 1 || nodes[ex].inputs[0] != nodes[r].inputs[1 - which]) continue;
+            snnhip_plan* fused = nullptr;
+            const int rc = make_irb_plan(ctx, nodes[ex].plan, nodes[dw].plan, nodes[pj].plan, nodes[r].plan, &fused);
+            if (rc == SNNHIP_E_UNSUPPORTED) continue;
+            if (rc != SNNHIP_OK) return fail(rc);
+            out[r].plan = fused;
+            out[r].owned = 1;
+            out[r].n_inputs = 1;
+            out[r].inputs[0] = nodes[ex].inputs[0];
+            for (int t : {ex, dw, pj}) {
+                out[t].plan = nullptr;
+                out[t].n_inputs = 0;
+                taken[static_cast<size_t>(t)] = 1;
+            }
+            taken[static_cast<size_t>(r)] = 1;
+            break;
+        }
+    }
 
     // ---- 1. Conv2D -> Add (rule E): the fused plan sits at the Add node and reads {the convolution's input, the other summand}
     for (int k = 0; k < n; ++k) {

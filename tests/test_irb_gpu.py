@@ -1,0 +1,128 @@
+"""irb_fused.hip (chain rule G): Conv2D 1x1 -> DepthwiseConv2D 3x3 -> Conv2D 1x1 [-> Add with the block input] as one kernel, against the CPU
+oracle run layer by layer and against the three / four separate HIP layers: MobileNetV2's block shapes (BASELINE configs[3]), ragged extents,
+channel counts that are not multiples of 16, both strides."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_ops_gpu import _bn, _rand
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+# N, H, W, C, Ch, Co, stride, residual, (act1, act2, act3)
+CASES = [(2, 56, 56, 24, 144, 24, 1, True, ("relu6", "relu6", "")),      # MobileNetV2 b02
+         (2, 112, 112, 16, 96, 24, 2, False, ("relu6", "relu6", "")),    # b01 (stride 2, 8x8 tiles with 17x17 halo)
+         (3, 28, 28, 32, 192, 64, 2, False, ("relu6", "relu6", "")),     # b06
+         (2, 14, 14, 64, 384, 64, 1, True, ("relu6", "relu6", "")),      # b07 (ragged 14 = 8 + 6 rows)
+         (2, 14, 14, 64, 448, 160, 2, False, ("relu6", "relu6", "")),    # b13-like (the real b13, 96 -> 576 -> 160 s2: its 15x15x96 x tile does not fit LDS)
+         (3, 7, 7, 160, 960, 160, 1, True, ("relu6", "relu6", "")),      # b14
+         (2, 7, 7, 160, 960, 320, 1, False, ("relu6", "relu6", "")),     # b16 (20 output blocks)
+         (1, 19, 23, 8, 40, 12, 1, False, ("relu", "leakyRelu", "relu")),  # odd extents, Ch % 16 = 8, Co % 16 = 12
+         (2, 9, 33, 12, 56, 12, 1, True, ("", "relu6", "")),
+         (1, 21, 17, 20, 72, 36, 2, False, ("relu6", "", "leakyRelu"))]
+
+
+def _layers(case, seed):
+    N, H, W, C, Ch, Co, s, res, acts = case
+    we, be, bne = _rand((Ch, C, 1, 1), seed, 1.0 / np.sqrt(C)), _rand((Ch,), seed + 1, 0.1), _bn(Ch, seed + 2)
+    wd, bd, bnd = _rand((Ch, 3, 3), seed + 3, 1.0 / 3.0), _rand((Ch,), seed + 4, 0.1), _bn(Ch, seed + 5)
+    wp, bp, bnp = _rand((Co, Ch, 1, 1), seed + 6, 1.0 / np.sqrt(Ch)), _rand((Co,), seed + 7, 0.1), _bn(Co, seed + 8)
+    return (we, be, bne), (wd, bd, bnd), (wp, bp, bnp)
+
+
+def _oracle(case, x, L):
+    N, H, W, C, Ch, Co, s, res, acts = case
+    (we, be, bne), (wd, bd, bnd), (wp, bp, bnp) = L
+    h = O.conv2d(x, we, be, 1, (0, 0, 0, 0), "constant", acts[0], 0.1, bne, threads=8)
+    d = O.depthwise(h, wd, bd, s, O.padding_offsets("same", 3), acts[1], 0.1, bnd)
+    y = O.conv2d(d, wp, bp, 1, (0, 0, 0, 0), "constant", acts[2], 0.1, bnp, threads=8)
+    return O.add_act(y, x, "") if res else y
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%dx%d_%d-%d-%d_s%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], "_res" if c[7] else ""))
+def test_irb_fused_matches_oracle_and_separate_layers(ctx, case, monkeypatch):
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_IRB_FUSION", "all")  # by default only blocks on >= 28x28 maps fuse (where it is faster); the kernel takes them all
+
+    N, H, W, C, Ch, Co, s, res, acts = case
+    x = _rand((N, H, W, C), 71)
+    L = _layers(case, 80)
+    (we, be, bne), (wd, bd, bnd), (wp, bp, bnp) = L
+    pe = snn.conv2d_plan(ctx, N, H, W, we, be, act=acts[0], leaky=0.1, bn=bne)
+    pd = snn.conv2d_plan(ctx, N, H, W, wd, bd, stride=s, pads=O.padding_offsets("same", 3), act=acts[1], leaky=0.1, bn=bnd, depthwise=True)
+    _, OH, OW, _ = pd.out_shape()
+    pp = snn.conv2d_plan(ctx, N, OH, OW, wp, bp, act=acts[2], leaky=0.1, bn=bnp)
+    xt = snn.Tensor.from_numpy(ctx, x)
+    sep = pp(pd(pe(xt)))
+    want = _oracle(case, x, L)
+    if res:
+        pa = snn.add_plan(ctx, N, OH, OW, Co, act="")
+        sep = pa([sep, xt])
+        fused = snn.graph_fuse(ctx, [(pe, [-1], False), (pd, [0], False), (pp, [1], False), (pa, [2, -1], True)])
+        assert [f[0] is None for f in fused] == [True, True, True, False], [f[0] and f[0].describe() for f in fused]
+        plan, ins = fused[3]
+        assert ins == [-1]
+    else:
+        plan = snn.chain_plan(ctx, [pe, pd, pp])
+        assert plan.num_steps() == 1
+    assert "irb_fused" in plan.describe() and ("+ add" in plan.describe()) == res, plan.describe()
+    got = plan(xt).numpy()
+    assert got.shape == want.shape == (N, OH, OW, Co)
+    np.testing.assert_allclose(got, want, err_msg=plan.describe(), **TOL)
+    np.testing.assert_allclose(got, sep.numpy(), err_msg=plan.describe(), rtol=2e-5, atol=2e-5)
+    f, b = plan.cost()
+    assert f > 0 and b > 0
+
+
+def test_irb_fusion_can_be_switched_off_and_declines_what_it_cannot_do(ctx, monkeypatch):
+    import shadernn_amd as snn
+
+    case = (1, 32, 32, 16, 64, 16, 1, False, ("relu6", "relu6", ""))
+    (we, be, bne), (wd, bd, bnd), (wp, bp, bnp) = _layers(case, 90)
+    pe = snn.conv2d_plan(ctx, 1, 32, 32, we, be, act="relu6", bn=bne)
+    pd = snn.conv2d_plan(ctx, 1, 32, 32, wd, bd, pads=(1, 1, 1, 1), act="relu6", bn=bnd, depthwise=True)
+    pp = snn.conv2d_plan(ctx, 1, 32, 32, wp, bp, bn=bnp)
+    assert "irb_fused" in snn.chain_plan(ctx, [pe, pd, pp]).describe()
+    small = [snn.conv2d_plan(ctx, 1, 12, 12, we, be, act="relu6", bn=bne), snn.conv2d_plan(ctx, 1, 12, 12, wd, bd, pads=(1, 1, 1, 1), act="relu6", bn=bnd, depthwise=True),
+             snn.conv2d_plan(ctx, 1, 12, 12, wp, bp, bn=bnp)]
+    with pytest.raises(snn.SnnHipError):  # small maps stay unfused by default (the separate layers are faster there) ...
+        snn.chain_plan(ctx, small)
+    monkeypatch.setenv("SNNHIP_IRB_FUSION", "all")  # ... unless asked for
+    assert "irb_fused" in snn.chain_plan(ctx, small).describe()
+    monkeypatch.delenv("SNNHIP_IRB_FUSION")
+    monkeypatch.setenv("SNNHIP_NO_IRB_FUSION", "1")
+    with pytest.raises(snn.SnnHipError) as e:
+        snn.chain_plan(ctx, [pe, pd, pp])
+    assert e.value.code == snn.E_UNSUPPORTED
+    monkeypatch.delenv("SNNHIP_NO_IRB_FUSION")
+    pt = snn.conv2d_plan(ctx, 1, 32, 32, we, be, act="tanh", bn=bne)  # a non-"simple" activation: stays unfused
+    with pytest.raises(snn.SnnHipError):
+        snn.chain_plan(ctx, [pt, pd, pp])
+
+
+@pytest.mark.parametrize("mode", ["default", "all"])
+def test_mobilenetv2_graph_uses_the_fused_blocks(ctx, monkeypatch, mode):
+    """MobileNetV2 through GraphRunner (snnhip_graph_fuse): the inverted-residual blocks run as ONE kernel each -- by default those on maps of
+    28x28 and larger (b01-b06 at 224x224), with SNNHIP_IRB_FUSION=all every block that fits LDS; the result equals the unfused graph and the oracle."""
+    import shadernn_amd as snn
+    from shadernn_amd import models
+
+    if mode == "all":
+        monkeypatch.setenv("SNNHIP_IRB_FUSION", "all")
+    net = models.mobilenetv2(seed=3, num_classes=10)
+    x = np.random.default_rng(4).random((2, 96, 96, 3), dtype=np.float32)
+    r = snn.GraphRunner(ctx, net, 2, 96, 96)
+    y = r(x)
+    fused = [d for d in r.describe() if "irb_fused" in d]
+    if mode == "all":
+        assert 14 <= len(fused) <= 16 and sum("+ add" in d for d in fused) == 10, r.describe()
+    else:
+        assert len(fused) == 1 and "16->96" in fused[0], r.describe()  # at 96x96 only b01 (48x48) is on a large map
+    want = O.forward(net, x, threads=8)
+    np.testing.assert_allclose(y.reshape(2, -1), want.reshape(2, -1), **TOL)
+    y0 = snn.GraphRunner(ctx, net, 2, 96, 96, fuse=False)(x)
+    np.testing.assert_allclose(y, y0, rtol=2e-5, atol=2e-6)

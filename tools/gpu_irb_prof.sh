@@ -1,0 +1,13 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+python tools/bench_irb.py --batch 64
+O=$GRAFT_REPO_ROOT/gpurun_out/r02_prof_irb
+mkdir -p $O
+export PROF_CMD="python $GRAFT_REPO_ROOT/tools/bench_irb.py --batch 64 --only b01 --fused-only --reps 5"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $PROF_CMD > $O/trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/pmc_sq --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY -- $PROF_CMD > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/pmc_sq2 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -- $PROF_CMD > $O/pmc_sq2.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/summarize_prof.py $O > $O/summary.md 2>&1
+grep -A12 "irb_fused_kernel" $O/summary.md | grep -v "^$" | cut -c1-200 | head -50

@@ -21,6 +21,8 @@
 //     j) so that both operands of four consecutive MFMAs come from one 16-byte load.
 //   D: lane l holds column (oc) l%32 and rows 8*(r/4) + 4*(l/32) + r%4 -> a store instruction writes 32 consecutive
 //     channels of one pixel (128 B) per half-wave; the epilogue parameters are per-lane constants.
+#include <mutex>
+
 #include "conv2d_mfma_kernel.h"
 
 namespace snnhip {
@@ -442,12 +444,21 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     }
     const char* tune = getenv("SNNHIP_CONV_TUNE");
     if (!tune || atoi(tune) == 0 || getenv("SNNHIP_CONV_BN") || getenv("SNNHIP_CONV_SPLITK")) return make_conv2d_mfma_plan_ex(ctx, g, w_oihw, epi4, MfmaOverride(), out);
-    char key[256];
-    snprintf(key, sizeof(key), "%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d", g.N, g.H, g.W, g.IC, g.OC, g.kh, g.kw, g.sh, g.sw, g.padx, g.pady, g.dtype,
-             g.preMode, g.preShift, g.srcH, g.srcW, g.addAct >= 0);
+    // winners are cached per (device, full geometry incl. the output extent, epilogue shape); the cache is shared by every context of the
+    // process, so it is guarded (plan creation may run on several host threads, one per device)
+    char key[320];
+    snprintf(key, sizeof(key), "d%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d.%d", ctx->device, g.N, g.H, g.W, g.IC, g.OC, g.kh, g.kw, g.sh, g.sw,
+             g.padx, g.pady, g.dtype, g.preMode, g.preShift, g.srcH, g.srcW, g.addAct >= 0, g.OH, g.OW, g.act, g.useBN);
     static std::map<std::string, MfmaOverride> cache;
-    auto it = cache.find(key);
-    if (it != cache.end()) return make_conv2d_mfma_plan_ex(ctx, g, w_oihw, epi4, it->second, out);
+    static std::mutex cacheMutex;
+    {
+        std::lock_guard<std::mutex> lock(cacheMutex);
+        auto it = cache.find(key);
+        if (it != cache.end()) {
+            const MfmaOverride hit = it->second;
+            return make_conv2d_mfma_plan_ex(ctx, g, w_oihw, epi4, hit, out);
+        }
+    }
 
     const size_t esz = g.dtype == SNNHIP_F16 ? 2 : 4;
     const size_t inBytes = static_cast<size_t>(g.N) * (g.preMode ? g.srcH : g.H) * (g.preMode ? g.srcW : g.W) * g.IC * esz;
@@ -458,17 +469,24 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         if (dy) (void) hipFree(dy);
         return make_conv2d_mfma_plan_ex(ctx, g, w_oihw, epi4, MfmaOverride(), out);
     }
-    (void) hipMemsetAsync(dx, 0, inBytes, ctx->stream);
-    if (dr) (void) hipMemsetAsync(dr, 0, outBytes, ctx->stream);
+    bool hipOk = hipMemsetAsync(dx, 0, inBytes, ctx->stream) == hipSuccess;
+    if (dr) hipOk = hipOk && hipMemsetAsync(dr, 0, outBytes, ctx->stream) == hipSuccess;
     snnhip_tensor tx, ty, tr;
     tx.ctx = ty.ctx = tr.ctx = ctx;
     tx.n = g.N; tx.h = g.preMode ? g.srcH : g.H; tx.w = g.preMode ? g.srcW : g.W; tx.c = g.IC; tx.dtype = g.dtype; tx.data = static_cast<float*>(dx);
     ty.n = g.N; ty.h = g.OH; ty.w = g.OW; ty.c = g.OC; ty.dtype = g.dtype; ty.data = static_cast<float*>(dy);
     tr = ty;
     tr.data = static_cast<float*>(dr);
-    hipEvent_t e0, e1;
-    (void) hipEventCreate(&e0);
-    (void) hipEventCreate(&e1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipOk = hipOk && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    if (!hipOk) { // the tuner is an optimisation: any HIP failure here falls back to the heuristic configuration
+        if (e0) (void) hipEventDestroy(e0);
+        if (e1) (void) hipEventDestroy(e1);
+        (void) hipFree(dx);
+        (void) hipFree(dy);
+        if (dr) (void) hipFree(dr);
+        return make_conv2d_mfma_plan_ex(ctx, g, w_oihw, epi4, MfmaOverride(), out);
+    }
     MfmaOverride best;
     float bestMs = -1.0f;
     const int bns[4] = {0, 32, 64, 128};
@@ -514,7 +532,10 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     (void) hipFree(dx);
     (void) hipFree(dy);
     if (dr) (void) hipFree(dr);
-    cache[key] = best;
+    {
+        std::lock_guard<std::mutex> lock(cacheMutex);
+        cache[key] = best;
+    }
     return make_conv2d_mfma_plan_ex(ctx, g, w_oihw, epi4, best, out);
 }
 

@@ -600,6 +600,22 @@ bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d
     return true;
 }
 
+// sizes the level-1 fold records for a convolution tile grid of tilesX x tilesY (chain rule F calls it when the chain is created)
+int instancenorm_reserve_tile_stats(snnhip_plan* inPlan, int tilesX, int tilesY) {
+    auto* q = dynamic_cast<InstanceNormPlan*>(inPlan);
+    SNNHIP_REQUIRE(q && tilesX > 0 && tilesY > 0, "instancenorm_reserve_tile_stats: bad arguments");
+    const int tiles = tilesX * tilesY, chunks = (tiles + kFoldChunk - 1) / kFoldChunk;
+    const size_t need = static_cast<size_t>(q->d.N) * chunks * 3 * q->d.C;
+    if (q->foldScratchCount < need) {
+        void* buf = nullptr;
+        SNNHIP_CHECK_HIP(hipMalloc(&buf, need * sizeof(float)));
+        q->deviceAllocs.push_back(buf);
+        q->d_foldScratch = static_cast<float*>(buf);
+        q->foldScratchCount = need;
+    }
+    return SNNHIP_OK;
+}
+
 int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const float* statPart, int tilesX, int tilesY, int TH, int TW, snnhip_tensor* xy) {
     auto* q = dynamic_cast<InstanceNormPlan*>(inPlan);
     SNNHIP_REQUIRE(q && statPart && xy, "instancenorm_apply_tile_stats: bad arguments");
@@ -608,13 +624,7 @@ int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const float* statPart, in
     snnhip_ctx* ctx = q->ctx;
     const int tiles = tilesX * tilesY, chunks = (tiles + kFoldChunk - 1) / kFoldChunk;
     const size_t need = static_cast<size_t>(d.N) * chunks * 3 * d.C;
-    if (q->foldScratchCount < need) { // level-1 records; sized on first use (the tile grid belongs to the convolution in front)
-        void* buf = nullptr;
-        SNNHIP_CHECK_HIP(hipMalloc(&buf, need * sizeof(float)));
-        q->deviceAllocs.push_back(buf);
-        q->d_foldScratch = static_cast<float*>(buf);
-        q->foldScratchCount = need;
-    }
+    SNNHIP_REQUIRE(q->foldScratchCount >= need, "instancenorm: fold scratch not reserved for a %d x %d tile grid (instancenorm_reserve_tile_stats)", tilesX, tilesY);
     hipLaunchKernelGGL(instancenorm_fold_tiles1_kernel, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, d.H, d.W,
                        tilesX, tilesY, TH, TW, statPart, q->d_foldScratch);
     hipLaunchKernelGGL(instancenorm_fold_tiles2_kernel, dim3(static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, chunks, d.eps, q->d_foldScratch, q->d_gamma,

@@ -612,295 +612,6 @@ __global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_kernel(FusedBParam
     }
 }
 
-// Persistent form of the direct kernel (SNNHIP_ESPCN_B=prefetch): WPS blocks per CU walk the tile list; the NEXT tile's halo is fetched
-// into NLD registers (24 VGPRs) right after this tile's LDS image is complete, so global loads are in flight during the whole compute
-// phase of every resident block instead of only while a block is in its load phase.  One LDS buffer, two barriers per tile.
-template <int TW, int TH, bool SIMPLE, int WPS>
-__global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_prefetch_kernel(FusedBParams p, int ntiles, const float* __restrict__ x,
-                                                                             const float* __restrict__ w, const float* __restrict__ ep,
-                                                                             float* __restrict__ y) {
-    constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 16;
-    static_assert(TW * TH == 256, "one thread per pixel");
-    __shared__ __attribute__((aligned(16))) float s_x[THH * TWH * PITCH];
-    constexpr int NLD = (THH * TWH * 4 + 255) / 256;
-    const int tid = threadIdx.x;
-
-    auto origin = [&](int t, int& n, int& x0, int& y0) {
-        int b = xcd_tile_order(t, ntiles);
-        const int tx = b % p.tilesX;
-        b /= p.tilesX;
-        const int ty = b % p.tilesY;
-        n = b / p.tilesY;
-        x0 = tx * TW;
-        y0 = ty * TH;
-    };
-    float4 v[NLD];
-    auto fetch = [&](int t) {
-        int n, x0, y0;
-        origin(t, n, x0, y0);
-        const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256;
-            const int q = idx & 3, pix = idx >> 2;
-            const int r = pix / TWH, c = pix - r * TWH;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (idx < THH * TWH * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                v[k] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
-        }
-    };
-    int t = blockIdx.x;
-    if (t < ntiles) fetch(t);
-    const int c = tid % TW, r = tid / TW;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    for (; t < ntiles; t += gridDim.x) {
-        __syncthreads(); // every wave is done reading the previous tile
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx >> 2) * PITCH + (((idx & 3) ^ ((idx >> 4) & 3)) * 4)) = v[k];
-        }
-        __syncthreads();
-        if (t + static_cast<int>(gridDim.x) < ntiles) fetch(t + gridDim.x); // in flight during the 9 taps below
-
-        f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int fy = tap / 3, fx = tap - fy * 3;
-            const int pixIdx = (r + fy) * TWH + c + fx;
-            const float* src = s_x + pixIdx * PITCH;
-            const int sw = (pixIdx >> 2) & 3;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 xv = *reinterpret_cast<const float4*>(src + ((q ^ sw) * 4));
-                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float* wr = w + (tap * 16 + q * 4 + i) * 4;
-                    const f32x2 xx = {xs[i], xs[i]};
-                    const f32x2 w01 = {wr[0], wr[1]}, w23 = {wr[2], wr[3]};
-                    acc01 = __builtin_elementwise_fma(xx, w01, acc01);
-                    acc23 = __builtin_elementwise_fma(xx, w23, acc23);
-                }
-            }
-        }
-        int n, x0, y0;
-        origin(t, n, x0, y0);
-        const float acc[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
-        const int gy = y0 + r, gx = x0 + c;
-        if (gy < p.H && gx < p.W) {
-            float o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(acc[k], ep[2 * k], ep[2 * k + 1]), 0.0f));
-            float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
-            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
-            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
-        }
-    }
-}
-
-// Two output rows per thread (SNNHIP_ESPCN_B=rows2).  The direct kernel above reads every activation from LDS once per (pixel, tap): 36
-// ds_read_b128 per pixel against 288 v_pk_fma_f32 -- LDS bandwidth and VALU issue are balanced 1:1 and each ends up ~40 % busy.  Here a
-// thread owns pixels (x, 2j) and (x, 2j+1): for one tap column it loads the 4 input rows once (16 b128 -> 64 VGPRs) and walks the 3 tap rows,
-// feeding row fy to the upper pixel and row fy+1 to the lower one with the SAME 64 scalar weights: 24 b128 per pixel, same FMA count.
-template <int TW, int TH, bool SIMPLE>
-__global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_rows2_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ w,
-                                                                          const float* __restrict__ ep, float* __restrict__ y) {
-    constexpr int TWH = TW + 2, THH = TH + 2, PITCH = 16;
-    static_assert(TW * TH == 512, "two pixels per thread");
-    __shared__ __attribute__((aligned(16))) float s_x[THH * TWH * PITCH];
-
-    const int tid = threadIdx.x;
-    int b = xcd_tile_order(blockIdx.x, gridDim.x);
-    const int tx = b % p.tilesX;
-    b /= p.tilesX;
-    const int ty = b % p.tilesY;
-    const int n = b / p.tilesY;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
-    {
-        constexpr int NLD = (THH * TWH * 4 + 255) / 256;
-        float4 v[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256;
-            const int q = idx & 3, pix = idx >> 2;
-            const int r = pix / TWH, c = pix - r * TWH;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (idx < THH * TWH * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                v[k] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + q * 4);
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < THH * TWH * 4) *reinterpret_cast<float4*>(s_x + (idx >> 2) * PITCH + (((idx & 3) ^ ((idx >> 4) & 3)) * 4)) = v[k];
-        }
-    }
-    __syncthreads();
-
-    const int c = tid % TW, r = 2 * (tid / TW);
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 u01 = {0.0f, 0.0f}, u23 = {0.0f, 0.0f}, l01 = {0.0f, 0.0f}, l23 = {0.0f, 0.0f}; // upper / lower pixel, channel pairs
-#pragma unroll 1
-    for (int fx = 0; fx < 3; ++fx) {
-        float4 rows[4][4]; // [input row r .. r+3][channel quad]
-#pragma unroll
-        for (int ir = 0; ir < 4; ++ir) {
-            const int pixIdx = (r + ir) * TWH + c + fx;
-            const float* src = s_x + pixIdx * PITCH;
-            const int sw = (pixIdx >> 2) & 3;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rows[ir][q] = *reinterpret_cast<const float4*>(src + ((q ^ sw) * 4));
-        }
-#pragma unroll
-        for (int fy = 0; fy < 3; ++fy) { // unrolled: rows[fy] must be a static register index
-            const float* wt = w + ((fy * 3 + fx) * 16) * 4; // 64 uniform weights of this tap -> SGPRs
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 xu = rows[fy][q];
-                const float4 xl = rows[fy + 1][q];
-                const float us[4] = {xu.x, xu.y, xu.z, xu.w}, ls[4] = {xl.x, xl.y, xl.z, xl.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float* wr = wt + (q * 4 + i) * 4;
-                    const f32x2 w01 = {wr[0], wr[1]}, w23 = {wr[2], wr[3]};
-                    const f32x2 xu2 = {us[i], us[i]}, xl2 = {ls[i], ls[i]};
-                    u01 = __builtin_elementwise_fma(xu2, w01, u01);
-                    u23 = __builtin_elementwise_fma(xu2, w23, u23);
-                    l01 = __builtin_elementwise_fma(xl2, w01, l01);
-                    l23 = __builtin_elementwise_fma(xl2, w23, l23);
-                }
-            }
-        }
-    }
-    const int gx = x0 + c;
-    float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int gy = y0 + r + half;
-        const float acc[4] = {half ? l01.x : u01.x, half ? l01.y : u01.y, half ? l23.x : u23.x, half ? l23.y : u23.y};
-        if (gy < p.H && gx < p.W) {
-            float o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(acc[k], ep[2 * k], ep[2 * k + 1]), 0.0f));
-            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
-            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
-        }
-    }
-}
-
-// Kernel B with asynchronous staging: persistent blocks (3 per CU) walk the 32x8 tiles; while tile t is computed out of one LDS buffer,
-// the halo tile of t+1 lands in the other one through global_load_lds (LDS-DMA: no staging registers, no ds_write pass).  The DMA writes
-// lane-linearly (wave-uniform base + lane*16 B), so the slot swizzle of the tile goes on the per-lane SOURCE address (guide rule 21:
-// linear destination + permuted source + the same permutation on the read); out-of-image pixels read a zero page.
-// One vmcnt(0)+barrier per tile (the __syncthreads after the compute) retires the DMA before anybody reads the new buffer.
-template <bool SIMPLE>
-__global__ __launch_bounds__(256) void conv3x3_c16o4_d2s_tanh_dma_kernel(FusedBParams p, const float* __restrict__ x, const float* __restrict__ w,
-                                                                         const float* __restrict__ ep, const float* __restrict__ zeros,
-                                                                         float* __restrict__ y) {
-    constexpr int TW = 32, TH = 8, TWH = TW + 2, THH = TH + 2;
-    constexpr int SLOTS = THH * TWH * 4;            // 16-byte slots per tile (1360)
-    constexpr int NDMA = (SLOTS + 63) / 64;         // wave-wide DMA instructions per tile (22)
-    constexpr int PER_WAVE = (NDMA + 3) / 4;        // per wave (6)
-    constexpr int BUF = NDMA * 64 * 4;              // floats per LDS buffer (rounded up to whole DMA instructions)
-    __shared__ __attribute__((aligned(16))) float s_x[2 * BUF];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ntiles = p.tilesX * p.tilesY * p.N;
-    auto tile_origin = [&](int t, int& n, int& x0, int& y0) {
-        int b = xcd_tile_order(t, ntiles);
-        const int tx = b % p.tilesX;
-        b /= p.tilesX;
-        const int ty = b % p.tilesY;
-        n = b / p.tilesY;
-        x0 = tx * TW;
-        y0 = ty * TH;
-    };
-    // this lane's share of a tile: DMA instruction k of wave wv fills slots [(wv + 4k)*64, +64); slot -> (pixel, physical quad)
-    int rcq[PER_WAVE]; // (row << 16) | (col << 8) | source quad, or -1 past the end of the tile
-#pragma unroll
-    for (int k = 0; k < PER_WAVE; ++k) {
-        const int ps = (wv + 4 * k) * 64 + lane;
-        const int pix = ps >> 2, pq = ps & 3;
-        const int r = pix / TWH, c = pix - r * TWH;
-        rcq[k] = (wv + 4 * k < NDMA && ps < SLOTS) ? ((r << 16) | (c << 8) | (pq ^ ((pix >> 2) & 3))) : -1;
-    }
-    auto issue_dma = [&](int t, float* buf) {
-        int n, x0, y0;
-        tile_origin(t, n, x0, y0);
-        const float* xn = x + static_cast<size_t>(n) * p.H * p.W * 16;
-#pragma unroll
-        for (int k = 0; k < PER_WAVE; ++k) {
-            if (wv + 4 * k < NDMA) { // wave-uniform
-                const int gy = y0 - 1 + (rcq[k] >> 16), gx = x0 - 1 + ((rcq[k] >> 8) & 255);
-                const float* src = zeros;
-                if (rcq[k] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) src = xn + (static_cast<size_t>(gy) * p.W + gx) * 16 + (rcq[k] & 3) * 4;
-                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*) (buf + (wv + 4 * k) * 256), 16, 0, 0);
-            }
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    issue_dma(tile, s_x);
-    float sc[4], sh[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        sc[k] = ep[2 * k];
-        sh[k] = ep[2 * k + 1];
-    }
-    const int c = tid % TW, r = tid / TW;
-    __syncthreads(); // vmcnt(0) + barrier: the first tile is in place
-    int cur = 0;
-    for (;;) {
-        const int next = tile + gridDim.x;
-        const bool more = next < ntiles;
-        if (more) issue_dma(next, s_x + (cur ^ 1) * BUF);
-        int n, x0, y0;
-        tile_origin(tile, n, x0, y0);
-        const float* sx = s_x + cur * BUF;
-
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int fy = tap / 3, fx = tap - fy * 3;
-            const int pixIdx = (r + fy) * TWH + c + fx;
-            const float* src = sx + pixIdx * 16;
-            const int sw = (pixIdx >> 2) & 3;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 xv = *reinterpret_cast<const float4*>(src + ((q ^ sw) * 4));
-                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float* wr = w + (tap * 16 + q * 4 + i) * 4; // uniform address -> s_load
-                    const f32x2 xx = {xs[i], xs[i]};
-                    const f32x2 w01 = {wr[0], wr[1]}, w23 = {wr[2], wr[3]};
-                    acc01 = __builtin_elementwise_fma(xx, w01, acc01);
-                    acc23 = __builtin_elementwise_fma(xx, w23, acc23);
-                }
-            }
-        }
-        const float acc[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
-        const int gy = y0 + r, gx = x0 + c;
-        if (gy < p.H && gx < p.W) {
-            float o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = fast_tanh(apply_act<SIMPLE>(p.act, fmaf(acc[k], sc[k], sh[k]), 0.0f));
-            float* yn = y + static_cast<size_t>(n) * (2 * p.H) * (2 * p.W);
-            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy) * (2 * p.W) + 2 * gx) = make_float2(o[0], o[1]);
-            *reinterpret_cast<float2*>(yn + static_cast<size_t>(2 * gy + 1) * (2 * p.W) + 2 * gx) = make_float2(o[2], o[3]);
-        }
-        if (!more) break;
-        __syncthreads(); // every wave is done with buffer `cur`; vmcnt(0): the next tile has landed
-        cur ^= 1;
-        tile = next;
-    }
-}
-
 // Kernel B, Winograd variant (default): conv 3x3 (16 -> 4) as F(2x2, 3x3) on the matrix cores, then depth-to-space(2) + tanh.
 // With only 4 output channels a 16-wide MFMA tile would be 3/4 padding; v_mfma_f32_4x4x1_16B_f32 instead runs 16
 // independent 4x4x1 outer products per instruction: block = 4 Winograd tiles, rows = the 4 output channels, one input
@@ -1167,10 +878,6 @@ struct ChainPlan : snnhip_plan {
         FusedAParams a{};
         FusedBParams b{};
         int k1 = 5;
-        bool persistent = false;
-        bool dma = false; // FUSED_B: persistent direct kernel with LDS-DMA double buffering (SNNHIP_ESPCN_B=dma)
-        bool rows2 = false; // FUSED_B: two output rows per thread (SNNHIP_ESPCN_B=rows2)
-        int prefetch = 0;   // FUSED_B: persistent kernel with register prefetch, blocks per CU (SNNHIP_ESPCN_B=prefetch[N])
         bool wino = false; // FUSED_A / FUSED_B: the 3x3 conv as Winograd F(2x2,3x3) (default) or direct (SNNHIP_ESPCN_A / _B = direct)
         float *w1 = nullptr, *w2 = nullptr, *e1 = nullptr, *e2 = nullptr, *w3 = nullptr, *e3 = nullptr;
         alignas(8) char streamCfg[kStreamCfgBytes] = {};
@@ -1245,52 +952,16 @@ struct ChainPlan : snnhip_plan {
                 }
 #undef SNNHIP_LAUNCH_A
                 SNNHIP_CHECK_HIP(hipGetLastError());
-            } else if (s.dma) {
-                const int ntiles = s.b.tilesX * s.b.tilesY * s.b.N;
-                const int slots = 3 * (ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256);
-                dim3 grid(ntiles < slots ? ntiles : slots);
-                if (act_is_simple(s.b.act.act)) {
-                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_dma_kernel<true>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b, src->data, s.w1,
-                                          s.e1, s.w3, dst->data);
-                } else {
-                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_dma_kernel<false>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b, src->data, s.w1,
-                                          s.e1, s.w3, dst->data);
-                }
-                SNNHIP_CHECK_HIP(hipGetLastError());
             } else if (s.wino) {
-                // one block per tile by default; SNNHIP_ESPCN_B=wino_persistent launches 2 blocks per CU that walk the tile list with
-                // the quad-granular prefetch pipeline (measured slower so far: 50 vs 45 us)
+                // one block per tile
                 const int ntiles = s.b.tilesX * s.b.tilesY * s.b.N;
-                const int slots = s.persistent ? 2 * (ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) : ntiles;
-                dim3 grid(ntiles < slots ? ntiles : slots);
+                dim3 grid(ntiles);
                 if (act_is_simple(s.b.act.act)) {
                     hipExtLaunchKernelGGL((conv3x3_c16o4_wino_d2s_tanh_kernel<true>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b, src->data,
                                           s.w1, s.e1, dst->data);
                 } else {
                     hipExtLaunchKernelGGL((conv3x3_c16o4_wino_d2s_tanh_kernel<false>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0, s.b, src->data,
                                           s.w1, s.e1, dst->data);
-                }
-                SNNHIP_CHECK_HIP(hipGetLastError());
-            } else if (s.prefetch > 0) {
-                const int ntiles = s.b.tilesX * s.b.tilesY * s.b.N;
-                const int slots = s.prefetch * (ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256);
-                dim3 grid(ntiles < slots ? ntiles : slots);
-                if (act_is_simple(s.b.act.act)) {
-                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_prefetch_kernel<B_TW, B_TH, true, 6>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0,
-                                          s.b, ntiles, src->data, s.w1, s.e1, dst->data);
-                } else {
-                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_prefetch_kernel<B_TW, B_TH, false, 6>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0,
-                                          s.b, ntiles, src->data, s.w1, s.e1, dst->data);
-                }
-                SNNHIP_CHECK_HIP(hipGetLastError());
-            } else if (s.rows2) {
-                dim3 grid(s.b.tilesX * s.b.tilesY * s.b.N);
-                if (act_is_simple(s.b.act.act)) {
-                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_rows2_kernel<B_TW, 2 * B_TH, true>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0,
-                                          s.b, src->data, s.w1, s.e1, dst->data);
-                } else {
-                    hipExtLaunchKernelGGL((conv3x3_c16o4_d2s_tanh_rows2_kernel<B_TW, 2 * B_TH, false>), grid, dim3(256), 0, ctx->stream, evStart, evStop, 0,
-                                          s.b, src->data, s.w1, s.e1, dst->data);
                 }
                 SNNHIP_CHECK_HIP(hipGetLastError());
             } else {
@@ -1487,16 +1158,14 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             // ---- rule B
             const ConvGeom& g0 = c0->g;
             st.kind = ChainPlan::FUSED_B;
-            // default: the direct VALU kernel (43 us per 1080p frame); SNNHIP_ESPCN_B=wino | wino_persistent selects the Winograd /
-            // 4x4x1-MFMA kernel (45 / 50 us: fewer instructions, but its 80 KB tile limits residency to 2 blocks per CU and the
-            // load phases of co-resident blocks coincide)
+            // default: the direct VALU kernel (35 us per 1080p frame); SNNHIP_ESPCN_B=wino selects the Winograd / 4x4x1-MFMA kernel (45 us:
+            // fewer instructions, but its 80 KB tile limits residency to 2 blocks per CU and the load phases of co-resident blocks coincide).
+            // Variants measured in round 1 and removed (DESIGN.md section 5 keeps the findings): persistent + LDS-DMA double buffering 56-98 us,
+            // two rows per thread 36 us (same as the default: neither LDS bandwidth nor the scalar weight loads were the limiter), persistent
+            // with register prefetch 50 us, persistent Winograd with a quad-granular prefetch pipeline 50 us.
             const char* bmode = getenv("SNNHIP_ESPCN_B");
-            st.wino = bmode && strncmp(bmode, "wino", 4) == 0;
-            st.persistent = bmode && strcmp(bmode, "wino_persistent") == 0;
-            st.dma = bmode && strcmp(bmode, "dma") == 0;
-            st.rows2 = bmode && strcmp(bmode, "rows2") == 0;
-            if (bmode && strncmp(bmode, "prefetch", 8) == 0) st.prefetch = bmode[8] ? atoi(bmode + 8) : 6;
-            const int bTW = st.wino ? 64 : B_TW, bTH = st.wino ? 16 : (st.rows2 ? 2 * B_TH : B_TH);
+            st.wino = bmode && strcmp(bmode, "wino") == 0;
+            const int bTW = st.wino ? 64 : B_TW, bTH = st.wino ? 16 : B_TH;
             st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, bTW), up_div(g0.H, bTH), make_act_cfg(g0.act, g0.leaky), 0u, 0u};
             st.b.magicX = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(st.b.tilesX) - 1) / static_cast<unsigned>(st.b.tilesX));
             st.b.magicY = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(st.b.tilesY) - 1) / static_cast<unsigned>(st.b.tilesY));
@@ -1524,17 +1193,10 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             std::vector<float> e1 = fold_epilogue(c0->epi4, 4, g0.useBN);
             rc = chain->upload(wB.data(), wB.size(), &st.w1);
             if (rc == SNNHIP_OK) rc = chain->upload(e1.data(), e1.size(), &st.e1);
-            if (rc == SNNHIP_OK && st.dma) {
-                const std::vector<float> zeros(64, 0.0f); // the zero page out-of-image DMA lanes read
-                rc = chain->upload(zeros.data(), zeros.size(), &st.w3);
-            }
             memcpy(st.outDims, sp1->outDims, sizeof(st.outDims));
             char buf[200];
             snprintf(buf, sizeof(buf), "fused[conv3x3(16->4)%s+depth_to_space(2)+tanh] %s tile=%dx%d kernel=%s", st.wino ? " winograd F(2x2,3x3)" : "",
-                     st.wino ? "mfma_f32_4x4x1" : (st.dma ? "valu_f32 lds-dma persistent" : (st.rows2 ? "valu_f32 2 rows/thread" : (st.prefetch ? "valu_f32 persistent reg-prefetch" : "valu_f32"))), bTW, bTH,
-                     st.wino ? "conv3x3_c16o4_wino_d2s_tanh_kernel"
-                             : (st.dma ? "conv3x3_c16o4_d2s_tanh_dma_kernel" : (st.rows2 ? "conv3x3_c16o4_d2s_tanh_rows2_kernel"
-                                                                                          : (st.prefetch ? "conv3x3_c16o4_d2s_tanh_prefetch_kernel" : "conv3x3_c16o4_d2s_tanh_kernel"))));
+                     st.wino ? "mfma_f32_4x4x1" : "valu_f32", bTW, bTH, st.wino ? "conv3x3_c16o4_wino_d2s_tanh_kernel" : "conv3x3_c16o4_d2s_tanh_kernel");
             st.desc = buf;
             st.flops = c0->flops;
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);
@@ -1642,7 +1304,25 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         snnhip_instancenorm_desc nd;
         if (!cv || cv->depthwise || cv->numInputs != 1 || !instancenorm_plan_desc(b.plain, &nd)) continue;
         if (nd.N != cv->outDims[0] || nd.H != cv->outDims[1] || nd.W != cv->outDims[2] || nd.C != cv->outDims[3]) continue;
-        if (!cv->enableTileStats()) continue;
+        // The statistics epilogue changes the convolution plan (tile-stat buffer, LDS size, description): never switch it on in a plan the
+        // caller owns -- a borrowed per-layer plan stays what it was; the chain works on its own copy (rule D's product already is chain-owned).
+        bool borrowed = false;
+        for (int i = 0; i < n; ++i) borrowed = borrowed || plans[i] == a.plain;
+        if (borrowed) {
+            snnhip_plan* copy = nullptr;
+            if (make_conv2d_mfma_plan(ctx, cv->g, cv->w_oihw.data(), cv->epi4, &copy) != SNNHIP_OK) continue;
+            auto* cc = dynamic_cast<ConvPlanBase*>(copy);
+            if (!cc || !cc->enableTileStats()) {
+                delete copy;
+                continue;
+            }
+            chain->owned.push_back(copy);
+            cv = cc;
+        } else if (!cv->enableTileStats()) {
+            continue;
+        }
+        // the fold scratch of the norm is sized here, at plan creation: an allocation inside run() would break a hipGraph capture in progress
+        if (instancenorm_reserve_tile_stats(b.plain, cv->statTilesX, cv->statTilesY) != SNNHIP_OK) continue;
         auto* both = new ConvInstanceNormPlan();
         both->ctx = ctx;
         both->conv = cv;

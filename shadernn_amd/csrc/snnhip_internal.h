@@ -190,6 +190,7 @@ struct ConvPlanBase : snnhip_plan {
 };
 // eltwise_pool.hip: identify an InstanceNorm plan / run its fold + normalise passes in place from a convolution's tile statistics
 bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d);
+int instancenorm_reserve_tile_stats(snnhip_plan* inPlan, int tilesX, int tilesY);
 int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const float* statPart, int tilesX, int tilesY, int TH, int TW, snnhip_tensor* xy);
 struct EltwisePlanBase : snnhip_plan {
     snnhip_eltwise_desc d;

@@ -1,5 +1,7 @@
 // json.cpp -- recursive-descent JSON parser for model files (see ic2/json.h).
 #include <cctype>
+#include <charconv>
+#include <cmath>
 #include <cstdlib>
 
 #include "ic2/json.h"
@@ -10,6 +12,8 @@ namespace {
 struct P {
     const std::string& s;
     size_t i = 0;
+    int depth = 0;
+    static constexpr int kMaxDepth = 64;
     std::string err;
     explicit P(const std::string& t) : s(t) {}
     void ws() {
@@ -53,6 +57,12 @@ struct P {
         ws();
         if (i >= s.size()) return fail("unexpected end");
         const char c = s[i];
+        struct DepthGuard { // nesting is bounded: a hostile or corrupt file must not overflow the stack
+            int& d;
+            explicit DepthGuard(int& dd) : d(dd) { ++d; }
+            ~DepthGuard() { --d; }
+        } guard(depth);
+        if (depth > kMaxDepth) return fail("nesting deeper than 64 levels");
         if (c == '{') {
             ++i;
             v.type = Value::ObjectT;
@@ -130,13 +140,34 @@ struct P {
             i += 4;
             return true;
         }
-        const char* b = s.c_str() + i;
-        char* e = nullptr;
-        const double d = strtod(b, &e);
-        if (e == b) return fail("unexpected character");
+        // JSON number grammar, validated here: -? (0 | [1-9][0-9]*) (. [0-9]+)? ([eE] [+-]? [0-9]+)?  -- "nan", "inf", hex floats and a
+        // locale's decimal comma are not numbers (picojson, the reference's parser, rejects them too); the value itself is converted by
+        // std::from_chars, which does not look at the process locale (strtod does)
+        size_t j = i;
+        auto digits = [&]() {
+            const size_t j0 = j;
+            while (j < s.size() && s[j] >= '0' && s[j] <= '9') ++j;
+            return j > j0;
+        };
+        if (j < s.size() && s[j] == '-') ++j;
+        if (j < s.size() && s[j] == '0') ++j;
+        else if (!digits()) return fail("unexpected character");
+        if (j < s.size() && s[j] == '.') {
+            ++j;
+            if (!digits()) return fail("digits expected after the decimal point");
+        }
+        if (j < s.size() && (s[j] == 'e' || s[j] == 'E')) {
+            ++j;
+            if (j < s.size() && (s[j] == '+' || s[j] == '-')) ++j;
+            if (!digits()) return fail("digits expected in the exponent");
+        }
+        double d = 0.0;
+        const auto res = std::from_chars(s.data() + i, s.data() + j, d);
+        if (res.ec == std::errc::result_out_of_range) d = (s[i] == '-') ? -HUGE_VAL : HUGE_VAL; // like strtod: overflow saturates (underflow gives 0 / denormal)
+        else if (res.ec != std::errc() || res.ptr != s.data() + j) return fail("malformed number");
         v.type = Value::Number;
         v.num = d;
-        i += static_cast<size_t>(e - b);
+        i = j;
         return true;
     }
 };

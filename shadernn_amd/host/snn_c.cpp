@@ -65,22 +65,33 @@ int snn_model_create4(const char* json_path, int device, int in_w, int in_h, int
     if (!json_path || !out || batch < 1 || in_w < 1 || in_h < 1 || in_c < 1) return -1;
     const bool half = prefer_half != 0;
     auto* m = new snn_model();
-    m->batch = batch;
-    m->context = createHipContext(device);
-    m->inW = in_w;
-    m->inH = in_h;
-    m->inC = in_c;
-    dp::ShaderGenOptions sgo = makeOptions(in_w, in_h, in_c, fuse_chains != 0, half, batch);
-    auto layers = dp::loadFromJsonModel(json_path, false, sgo.mrtMode, sgo.weightMode, half); // preferHp: weights truncated to fp16 (Q13)
-    MixedInferenceCore::CreationParameters cp;
-    static_cast<InferenceGraph&>(cp) = dp::generateInferenceGraph(layers, sgo);
-    cp.dumpOutputs = dump_outputs != 0;
-    cp.fuseChains = fuse_chains != 0;
-    cp.profiling = profiling != 0;
-    cp.captureGraph = capture_graph != 0;
-    m->core = MixedInferenceCore::create(m->context, cp);
-    makeIO(m, half);
-    m->half = half;
+    // C++ exceptions (std::bad_alloc, a parser's std::out_of_range, ...) must not unwind through the C boundary: report -2 and free what was built.
+    // (SNN_RIP is the reference's abort-on-fatal-error convention, utils.h:57-62: it terminates the process and is not an exception.)
+    try {
+        m->batch = batch;
+        m->context = createHipContext(device);
+        m->inW = in_w;
+        m->inH = in_h;
+        m->inC = in_c;
+        dp::ShaderGenOptions sgo = makeOptions(in_w, in_h, in_c, fuse_chains != 0, half, batch);
+        auto layers = dp::loadFromJsonModel(json_path, false, sgo.mrtMode, sgo.weightMode, half); // preferHp: weights truncated to fp16 (Q13)
+        MixedInferenceCore::CreationParameters cp;
+        static_cast<InferenceGraph&>(cp) = dp::generateInferenceGraph(layers, sgo);
+        cp.dumpOutputs = dump_outputs != 0;
+        cp.fuseChains = fuse_chains != 0;
+        cp.profiling = profiling != 0;
+        cp.captureGraph = capture_graph != 0;
+        m->core = MixedInferenceCore::create(m->context, cp);
+        makeIO(m, half);
+        m->half = half;
+    } catch (const std::exception& e) {
+        SNN_LOGE("snn_model_create: %s", e.what());
+        snn_model_destroy(m);
+        return -2;
+    } catch (...) {
+        snn_model_destroy(m);
+        return -2;
+    }
     *out = m;
     return 0;
 }
@@ -101,12 +112,19 @@ int snn_model_upload_input(snn_model* m, const float* nhwc) {
 }
 
 int snn_model_run(snn_model* m) {
-    MixedInferenceCore::RunParameters rp;
-    rp.inputImages = &m->inputs;
-    rp.outputImages = &m->outputs;
-    rp.modelOutput.modelType = m->modelOutput.modelType;
-    m->core->run(rp);
-    m->modelOutput = rp.modelOutput;
+    try {
+        MixedInferenceCore::RunParameters rp;
+        rp.inputImages = &m->inputs;
+        rp.outputImages = &m->outputs;
+        rp.modelOutput.modelType = m->modelOutput.modelType;
+        m->core->run(rp);
+        m->modelOutput = rp.modelOutput;
+    } catch (const std::exception& e) {
+        SNN_LOGE("snn_model_run: %s", e.what());
+        return -2;
+    } catch (...) {
+        return -2;
+    }
     return 0;
 }
 

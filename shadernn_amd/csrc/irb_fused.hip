@@ -63,8 +63,8 @@ struct IrbParams {
 constexpr int kMaxNCB = 20; // Co <= 320
 constexpr int kMaxCj = 10;  // C <= 160
 
-template <int G /* 16-pixel output groups per wave: 1 (8x8 tile) or 2 (8x16) */, int NCBT /* compile-time bound on the output blocks */>
-__global__ __launch_bounds__(256) void irb_fused_kernel(IrbParams p, const float* __restrict__ x, const float4* __restrict__ weg, const float4* __restrict__ wpg,
+template <int G /* 16-pixel output groups per wave */, int NCBT /* compile-time bound on the output blocks */, int NW = 4 /* waves per block */>
+__global__ __launch_bounds__(64 * NW) void irb_fused_kernel(IrbParams p, const float* __restrict__ x, const float4* __restrict__ weg, const float4* __restrict__ wpg,
                                                         const float4* __restrict__ epi3, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, k = lane >> 4;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void irb_fused_kernel(IrbParams p, const float
 
     // LDS-DMA of slice blobs: wave w copies the 1 KiB pieces w, w + 4, ...
     auto dma = [&](const float4* g, float* dst, int pieces) {
-        for (int pc = wave; pc < pieces; pc += 4) __builtin_amdgcn_global_load_lds(g + pc * 64 + lane, (lds_ptr)(dst + pc * 256), 16, 0, 0);
+        for (int pc = wave; pc < pieces; pc += NW) __builtin_amdgcn_global_load_lds(g + pc * 64 + lane, (lds_ptr)(dst + pc * 256), 16, 0, 0);
     };
     const size_t weStride = static_cast<size_t>(p.wePieces) * 64, wpStride = static_cast<size_t>(p.wpPieces) * 64; // float4 per slice
     // two buffers per blob kind, requested one interval ahead of their use.  (Rings of three with a distance of two and counted s_waitcnt were
@@ -95,15 +95,29 @@ __global__ __launch_bounds__(256) void irb_fused_kernel(IrbParams p, const float
     {
         const int quads = 4 * p.Cj, cq = p.C >> 2;
         const int total = p.MT * 16 * quads;
-        for (int e = tid; e < total; e += 256) {
-            const int hp = e / quads, q = e - hp * quads;
-            const int hy = hp / p.HWd, hx = hp - hy * p.HWd;
-            const int iy = hy0 + hy, ix = hx0 + hx;
-            const bool in = hp < p.HP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in && q < cq) v = *reinterpret_cast<const float4*>(x + ((static_cast<size_t>(img) * p.H + iy) * p.W + ix) * p.C + 4 * q);
-            *reinterpret_cast<float4*>(xs + q * p.xPlane + hp * 4) = v;
-            if (q == 0) msk[hp] = in ? 1.0f : 0.0f;
+        // batches of 8 elements per thread: all eight global loads are requested before the first LDS store (one element per loop iteration
+        // serialised the HBM latency: 6-10 round trips per block with only two blocks per CU to hide them)
+        for (int base = tid; base < total; base += 8 * 64 * NW) {
+            float4 v[8];
+            int lo[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int e = base + r * 64 * NW;
+                v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                lo[r] = -1;
+                if (e < total) {
+                    const int hp = e / quads, q = e - hp * quads;
+                    const int hy = hp / p.HWd, hx = hp - hy * p.HWd;
+                    const int iy = hy0 + hy, ix = hx0 + hx;
+                    const bool in = hp < p.HP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    if (in && q < cq) v[r] = *reinterpret_cast<const float4*>(x + ((static_cast<size_t>(img) * p.H + iy) * p.W + ix) * p.C + 4 * q);
+                    lo[r] = q * p.xPlane + hp * 4;
+                    if (q == 0) msk[hp] = in ? 1.0f : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (lo[r] >= 0) *reinterpret_cast<float4*>(xs + lo[r]) = v[r];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the slice blobs requested above have landed in LDS ...
@@ -120,10 +134,10 @@ __global__ __launch_bounds__(256) void irb_fused_kernel(IrbParams p, const float
         const float4 sc = *reinterpret_cast<const float4*>(web + p.Cj * 256 + 4 * k);        // act1(scale * D + shift), channels 4k .. 4k+3 of the slice
         const float4 sh = *reinterpret_cast<const float4*>(web + p.Cj * 256 + 16 + 4 * k);
         // two MFMA tiles at a time: the second tile's MFMAs fill the 40-cycle dependent-accumulator latency of the first one's chain
-        for (int t = wave; t < p.MT; t += 8) {
+        for (int t = wave; t < p.MT; t += 2 * NW) {
             const int px0 = t * 16 + n16;
-            const bool two = t + 4 < p.MT;          // wave-uniform
-            const int px1 = two ? px0 + 64 : px0;
+            const bool two = t + NW < p.MT;         // wave-uniform
+            const int px1 = two ? px0 + 16 * NW : px0;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < kMaxCj; ++j)
@@ -262,7 +276,7 @@ struct IrbPlan : snnhip_plan {
     float* d_e3 = nullptr;
     size_t ldsBytes = 0;
     dim3 grid;
-    int G = 1, ncbt = 2;
+    int G = 1, ncbt = 2, threads = 256;
     void (*kernel)(IrbParams, const float*, const float4*, const float4*, const float4*, float*) = nullptr;
 
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
@@ -272,7 +286,7 @@ struct IrbPlan : snnhip_plan {
                        p.N, p.H, p.W, p.C);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.Co, "irb: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n,
                        out->h, out->w, out->c, p.N, p.OH, p.OW, p.Co);
-        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, x->data, reinterpret_cast<const float4*>(d_we),
+        hipLaunchKernelGGL(kernel, grid, dim3(static_cast<unsigned>(threads)), ldsBytes, ctx->stream, p, x->data, reinterpret_cast<const float4*>(d_we),
                            reinterpret_cast<const float4*>(d_wp), reinterpret_cast<const float4*>(d_e3), out->data);
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
@@ -289,7 +303,6 @@ IrbFn pick_irb(int ncb) {
     if (G == 1 && ncb <= 20) return irb_fused_kernel<1, 20>;
     return nullptr;
 }
-
 } // namespace
 
 // expand / dw / project: the three per-layer plans (borrowed; only read here); add: the residual Add plan or nullptr.
@@ -356,6 +369,8 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     // ... and it needs two workgroups per CU to hide its one-barrier-per-slice structure: 56x56 24->144->32 stride 2 (91 KB) measured 138 us
     // fused against 89 us for the separate layers at batch 64
     if (!fuseAll && lds > 80 * 1024) return SNNHIP_E_UNSUPPORTED;
+    // (512-thread blocks with one pixel group per wave were measured on the 8x16 tiles: slower, 494 -> 596 us on b02 at batch 256 -- the kernel is
+    // bound by its VALU work per slice (PMC: 2540 VALU and 162 MFMA instructions per wave on b01), not by latency that more waves could hide)
     IrbFn fn = wide ? pick_irb<2>(p.NCB) : pick_irb<1>(p.NCB);
     if (!fn) return SNNHIP_E_UNSUPPORTED;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
@@ -403,6 +418,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     plan->ctx = ctx;
     plan->p = p;
     plan->kernel = fn;
+    plan->threads = 256;
     plan->ldsBytes = lds;
     plan->grid = dim3(p.tilesX * p.tilesY * p.N);
     plan->dtype = SNNHIP_F32;
@@ -419,8 +435,8 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     plan->bytes = ce->bytes + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
     const double fusedBytes = 4.0 * (static_cast<double>(p.N) * p.H * p.W * C + static_cast<double>(p.N) * p.OH * p.OW * Co + static_cast<double>(Ch) * (C + Co + 9));
     char buf[320];
-    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] tile=8x%dpx halo=%dx%d slices=%d lds=%zuB hbm_bytes=%.6g kernel=irb_fused_kernel",
-             C, Ch, s, Ch, Co, addPlan ? " + add" : "", TW, p.HH, p.HWd, p.nChunks, lds, fusedBytes);
+    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] tile=8x%dpx halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_fused_kernel",
+             C, Ch, s, Ch, Co, addPlan ? " + add" : "", TW, p.HH, p.HWd, p.nChunks, 256, lds, fusedBytes);
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

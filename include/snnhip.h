@@ -313,7 +313,8 @@ int snnhip_chain_plan_create(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, 
  * nodes[i] describes operator i in execution order: its per-layer plan (NULL = opaque operator that never fuses: a CPU stage, a
  * multi-pass layer), its producers (node index, or -(k+1) for model input k) and whether its tensor must exist (model output, dump).
  * out[i] says what to run instead: plan == NULL -> node i's work moved into a later node's plan and its tensor is never produced;
- * owned == 0 -> unchanged (plan == nodes[i].plan, inputs as given); owned == 1 -> a new fused plan the caller destroys with
+ * owned == 0 -> the node's own plan (run it with out[i].inputs: a folded identity producer, e.g. a Flatten in front of a Dense layer, is
+ * skipped by re-wiring); owned == 1 -> a new fused plan the caller destroys with
  * snnhip_plan_destroy, to be run with out[i].inputs (it produces node i's tensor).  The per-layer plans must outlive the fused ones.
  * Groups searched: Conv2D -> Add where the Add is the convolution's only consumer (rule E, two-input fused plan), and maximal
  * linear runs (each operator the sole consumer of the previous one) handed to the chain planner (rules A-D, F). */

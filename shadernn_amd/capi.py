@@ -582,7 +582,7 @@ def graph_fuse(ctx, nodes):
         elif o.owned:
             res.append((Plan(ctx, _P(o.plan), keep=(plan,)), [o.inputs[k] for k in range(o.n_inputs)]))
         else:
-            res.append((plan, list(ins)))
+            res.append((plan, [o.inputs[k] for k in range(o.n_inputs)]))  # the node's own plan, possibly re-wired past a folded identity producer
     return res
 
 

@@ -120,6 +120,38 @@ __global__ __launch_bounds__(256) void pool2d_kernel(snnhip_pool2d_desc d, const
     }
 }
 
+// Whole-image average (AdaptiveAvgPool2d / a pooling window that covers the map: the classifier heads of ResNet-18 and MobileNetV2).  One thread
+// per output of pool2d_kernel walks the H*W pixels with one dependent load each (17 us for 32x7x7x512: pure latency); here 16 lanes share an
+// output quad, each sums every 16th pixel, and a 4-step xor-shuffle adds them up.  Same result up to the order of the fp32 additions.
+template <typename T>
+__global__ __launch_bounds__(256) void global_avgpool_kernel(int N, int HW, int C, const T* __restrict__ x, T* __restrict__ y) {
+    const int cg = C >> 2;
+    const int part = threadIdx.x & 15;
+    const size_t total = static_cast<size_t>(N) * cg; // outputs (channel quads)
+    const size_t o = static_cast<size_t>(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (o < total) {
+        const int n = static_cast<int>(o / cg), c = static_cast<int>(o % cg) * 4;
+        const T* px = x + static_cast<size_t>(n) * HW * C + c;
+        for (int i = part; i < HW; i += 16) {
+            float v[4];
+            ldv<T, 4>(px + static_cast<size_t>(i) * C, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += v[k];
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], m, 64);
+    if (o < total && part == 0) {
+        const float num = static_cast<float>(HW);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = acc[k] / num;
+        stv<T, 4>(y + o * 4, acc);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ pad
 template <int CV, typename T>
 __global__ __launch_bounds__(256) void pad_kernel(snnhip_pad_desc d, int OH, int OW, const T* __restrict__ x, T* __restrict__ y) {
@@ -505,6 +537,13 @@ struct PoolPlan : snnhip_plan {
         SNNHIP_REQUIRE(dims_match(out, d.N, d.OH, d.OW, d.C), "pool2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, d.N,
                        d.OH, d.OW, d.C);
         const bool vec = (d.C & 3) == 0;
+        if (vec && d.type == SNNHIP_POOL_AVG && d.OH == 1 && d.OW == 1 && d.padT == 0 && d.padL == 0 && d.kh >= d.H && d.kw >= d.W && d.H * d.W >= 16) {
+            const size_t outs = static_cast<size_t>(d.N) * (d.C >> 2);
+            SNNHIP_WITH_T(out->dtype, hipLaunchKernelGGL((global_avgpool_kernel<T>), dim3(static_cast<unsigned>((outs + 15) / 16)), dim3(256), 0, ctx->stream, d.N,
+                                                         d.H * d.W, d.C, cptr<T>(in[0]), mptr<T>(out)););
+            SNNHIP_CHECK_HIP(hipGetLastError());
+            return SNNHIP_OK;
+        }
         const unsigned g = grid_for(ctx, out->count() / (vec ? 4 : 1));
 #define SNNHIP_POOL(TY)                                                                                                                   \
     SNNHIP_WITH_T(out->dtype, if (vec) hipLaunchKernelGGL((pool2d_kernel<TY, 4, T>), dim3(g), dim3(256), 0, ctx->stream, d, cptr<T>(in[0]), mptr<T>(out)); \

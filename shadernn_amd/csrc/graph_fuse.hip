@@ -71,6 +71,20 @@ extern "C" int snnhip_graph_fuse(snnhip_ctx* ctx, const snnhip_graph_node* nodes
         }
     }
 
+    // ---- 0b. Flatten (an Activation with no activation) -> Dense: flattening contiguous NHWC memory in HWC order is the identity, and the dense plan
+    // takes any [N,H,W,C] tensor of the right element count -- it reads the Flatten's producer, the copy launch disappears
+    for (int dn = 0; dn < n; ++dn) {
+        if (!nodes[dn].plan || nodes[dn].n_inputs != 1 || taken[static_cast<size_t>(dn)] || nodes[dn].plan->desc.rfind("dense", 0) != 0) continue;
+        const int fl = nodes[dn].inputs[0];
+        if (!foldable(fl) || nodes[fl].n_inputs != 1) continue;
+        auto* id = dynamic_cast<EltwisePlanBase*>(nodes[fl].plan);
+        if (!id || id->mode != 1 || id->d.act != SNNHIP_ACT_NONE) continue;
+        out[dn].inputs[0] = nodes[fl].inputs[0];
+        out[fl].plan = nullptr;
+        out[fl].n_inputs = 0;
+        taken[static_cast<size_t>(fl)] = 1; // the Dense node itself stays available for other rules (none applies today)
+    }
+
     // ---- 1. Conv2D -> Add (rule E): the fused plan sits at the Add node and reads {the convolution's input, the other summand}
     for (int k = 0; k < n; ++k) {
         if (!nodes[k].plan || nodes[k].n_inputs != 2 || taken[static_cast<size_t>(k)]) continue;

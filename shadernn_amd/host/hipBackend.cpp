@@ -159,8 +159,10 @@ void HipBackend::finalizeStages(RenderStagesArray& stages, bool dumpOutputs, boo
             stages[i].fusedAway = true;
             continue;
         }
-        if (!fused[i].owned) continue;
-        chainPlans.push_back(fused[i].plan);
+        bool rewired = fused[i].n_inputs != nodes[i].n_inputs;
+        for (int k = 0; k < fused[i].n_inputs && !rewired; ++k) rewired = fused[i].inputs[k] != nodes[i].inputs[k];
+        if (!fused[i].owned && !rewired) continue;
+        if (fused[i].owned) chainPlans.push_back(fused[i].plan); // a re-wired own plan stays owned by the pass kept in replacedPasses
         auto* ml = static_cast<GenericModelLayer*>(stages[i].layer->modelLayer);
         replacedPasses.push_back(ml->getRenderPasses()[0]); // its plan may still be launched by the fused one (unfused steps of a chain)
         auto np = std::make_shared<HipRenderPass>(fused[i].plan, textureOf(i, fused[i].inputs[0]), rp->output, rp->name + " (+fused)", false);

@@ -73,6 +73,16 @@ def test_global_avgpool_matches_oracle_and_mean(ctx):
     y, desc = _run(ctx, snn.global_avgpool_plan(ctx, 4, 7, 7, 512), x)
     np.testing.assert_allclose(y, O.global_avgpool(x), err_msg=desc, **TOL)
     np.testing.assert_allclose(y[:, 0, 0, :], x.mean(axis=(1, 2)), rtol=1e-4, atol=1e-5)
+    # the 16-lanes-per-output kernel: pixel counts that are not multiples of 16, more outputs than one block, half tensors; maps below 16 pixels
+    # and channel counts that are not multiples of 4 stay on the general pooling kernel
+    for shape in [(3, 5, 9, 1280), (33, 7, 7, 64), (2, 3, 3, 32), (2, 6, 6, 6)]:
+        x = _rand(shape, 8)
+        y, desc = _run(ctx, snn.global_avgpool_plan(ctx, *shape), x)
+        np.testing.assert_allclose(y, O.global_avgpool(x), err_msg=str(shape), **TOL)
+    x = _rand((2, 7, 7, 128), 9)
+    p = snn.global_avgpool_plan(ctx, 2, 7, 7, 128)
+    y16 = p(snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)).numpy()
+    np.testing.assert_allclose(y16, O._h(O.global_avgpool(O._h(x))), rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize("mode", ["constant", "replicate", "reflect"])

@@ -300,6 +300,7 @@ def main():
     ap.add_argument("--through", choices=["auto", "host", "capi"], default="auto",
                     help="host: the C++ host mirror (libsnn_core.so: JSON/.bin model -> MixedInferenceCore::run, default for c3-c5); "
                          "capi: per-layer plans driven from Python through the C-ABI (default for c1, c2)")
+    ap.add_argument("--all-kernels", action="store_true", help="list every kernel of the step in `kernels` (default: the 12 most expensive)")
     ap.add_argument("--micro", type=int, default=0, help="micro-batch size of the rank's share (default: the config's)")
     ap.add_argument("--no-capture", action="store_true", help="host path: launch kernel by kernel instead of replaying the recorded hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -439,7 +440,7 @@ def main():
             "frac_hbm_roofline_unfused_accounting": bytes_unfused / step_s / 1e9 / PEAK_HBM_GBPS,
             "frac_compute_roofline": flops / step_s / 1e12 / peak_tf,
             "whole_step_roofline_ms": 1e3 * max(flops / peak_tf / 1e12, bytes_unfused / PEAK_HBM_GBPS / 1e9),
-            "kernels": sorted(kernels, key=lambda k: -k["avg_us"] * k["launches"])[:12],
+            "kernels": sorted(kernels, key=lambda k: -k["avg_us"] * k["launches"])[: (None if args.all_kernels else 12)],
         }
         out["frac_of_whole_step_roofline"] = out["whole_step_roofline_ms"] / out["ms_per_step"]
         if kernels:

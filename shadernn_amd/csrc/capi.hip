@@ -392,7 +392,8 @@ int snnhip_conv2d_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, c
     std::vector<float> epi = make_epilogue_table(g.OC, 16, desc->useBias, bias, desc->useBN, bn_beta, bn_gamma, bn_mean, bn_var);
     // image-producing layers (OC <= 4) go to the 4x4x1-MFMA kernel, GEMM-shaped layers to the fp32-MFMA implicit GEMM; everything else
     // (and anything they decline) to the direct VALU kernel.
-    rc = make_conv2d_thin_plan(ctx, g, w_oihw, epi, out);
+    rc = make_conv2d_rowfold_plan(ctx, g, w_oihw, epi, out); // fp16, wide kernel, k * OC <= 32: kernel columns folded into the MFMA's N
+    if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_thin_plan(ctx, g, w_oihw, epi, out);
     if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_mfma_plan(ctx, g, w_oihw, epi, out);
     if (rc == SNNHIP_E_UNSUPPORTED && g.dtype != SNNHIP_F32) {
         set_error("conv2d: no fp16 kernel takes this shape (k=%dx%d stride %d, %d->%d)", g.kh, g.kw, g.sh, g.IC, g.OC);

@@ -1249,7 +1249,8 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.flops = st.plain->flops;
             st.bytes = st.plain->bytes;
         } else if (auto* pd = dynamic_cast<PadPlanBase*>(plans[i]); pd && c1 && !c1->depthwise && c1->g.preMode == 0 && c1->g.N == pd->d.N &&
-                   c1->g.H == pd->OH && c1->g.W == pd->OW && c1->g.IC == pd->d.C && c1->desc.rfind("conv2d_mfma", 0) == 0 && !getenv("SNNHIP_NO_PAD_FUSION")) {
+                   c1->g.H == pd->OH && c1->g.W == pd->OW && c1->g.IC == pd->d.C &&
+                   (c1->desc.rfind("conv2d_mfma", 0) == 0 || c1->desc.rfind("conv2d_rowfold", 0) == 0) && !getenv("SNNHIP_NO_PAD_FUSION")) {
             // ---- rule D: Pad + Conv2D -> the convolution stages its tiles straight from the unpadded tensor ("reflect Pad,
             // better fused into the following conv's load stage"); only the MFMA kernel has the pre-pad address path, so a convolution that was
             // routed to another kernel (the channel-thin image-producing layers) keeps its separate Pad launch
@@ -1260,7 +1261,8 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             g2.srcH = pd->d.H;
             g2.srcW = pd->d.W;
             snnhip_plan* fused = nullptr;
-            const int frc = make_conv2d_mfma_plan(ctx, g2, c1->w_oihw.data(), c1->epi4, &fused);
+            const int frc = c1->desc.rfind("conv2d_rowfold", 0) == 0 ? make_conv2d_rowfold_plan(ctx, g2, c1->w_oihw.data(), c1->epi4, &fused)
+                                                                      : make_conv2d_mfma_plan(ctx, g2, c1->w_oihw.data(), c1->epi4, &fused);
             if (frc == SNNHIP_OK) {
                 fused->ctx = ctx;
                 chain->owned.push_back(fused);

@@ -212,3 +212,49 @@ def test_fp16_espcn_json_model_through_host_mirror(ctx, tmp_path, fuse):
     p = snn.subpixel_plan(ctx, 2, 5, 7, 4, 2, 0)
     got = p(snn.Tensor.from_numpy(ctx, t, dtype=snn.F16)).numpy()
     np.testing.assert_allclose(got, O._h(O.subpixel(O._h(t), 2, 0)), rtol=1e-3, atol=1e-3)
+
+
+# ---- conv2d_rowfold.hip: wide-kernel, channel-thin fp16 output layers with the kernel columns folded into the MFMA's N ----
+ROWFOLD = [(2, 40, 70, 32, 3, 9, "constant", ""), (1, 33, 61, 32, 3, 9, "reflect", "tanh"), (2, 20, 130, 16, 4, 7, "replicate", "relu"),
+           (1, 17, 19, 32, 6, 5, "constant", "sigmoid"), (3, 9, 9, 16, 1, 9, "constant", "")]
+
+
+@pytest.mark.parametrize("case", ROWFOLD, ids=lambda c: "x".join(map(str, c[:6])) + "_" + c[6])
+def test_fp16_rowfold_conv_matches_quantised_oracle_and_thin_kernel(ctx, monkeypatch, case):
+    import shadernn_amd as snn
+
+    N, H, W, IC, OC, k, pad_mode, act = case
+    x = _rand((N, H, W, IC), 201)
+    w = _rand((OC, IC, k, k), 202, 1.0 / np.sqrt(IC * k * k))
+    b = _rand((OC,), 203, 0.1)
+    bn = _bn(OC, 204)
+    pads = O.padding_offsets("same", k)
+    y, desc = _conv16(ctx, x, w, b, 1, pads, pad_mode, act, bn)
+    assert "conv2d_rowfold" in desc, desc
+    want = O._h(O.conv2d(O._h(x), O._h(w), b, 1, pads, pad_mode, act, 0.0, bn))
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOLH)
+    monkeypatch.setenv("SNNHIP_CONV", "thin" if OC <= 4 else "mfma")  # the kernels these layers ran on before
+    y2, desc2 = _conv16(ctx, x, w, b, 1, pads, pad_mode, act, bn)
+    assert "rowfold" not in desc2, desc2
+    np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=4e-3, atol=4e-3)
+
+
+def test_fp16_rowfold_with_fused_reflect_pad(ctx):
+    """Chain rule D on the row-fold kernel: Pad(reflect 4) -> Conv2D 9x9 "valid" 32 -> 3 (Candy's output layer) as one launch."""
+    import shadernn_amd as snn
+
+    N, H, W = 2, 30, 50
+    x = _rand((N, H, W, 32), 211)
+    w, b = _rand((3, 32, 9, 9), 212, 1.0 / np.sqrt(32 * 81)), _rand((3,), 213, 0.1)
+    pad = snn.pad_plan(ctx, N, H, W, 32, (4, 4, 4, 4), "reflect")
+    conv = snn.conv2d_plan(ctx, N, H + 8, W + 8, w, b, pads=(0, 0, 0, 0), dtype=snn.F16)
+    assert "conv2d_rowfold" in conv.describe()
+    chain = snn.chain_plan(ctx, [pad, conv])
+    assert chain.num_steps() == 1 and "rowfold" in chain.describe() and "+pad(reflect)" in chain.describe(), chain.describe()
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    got = chain(xt).numpy()
+    sep = conv(pad(xt)).numpy()
+    want = O._h(O.conv2d(O.pad(O._h(x), (4, 4, 4, 4), "reflect"), O._h(w), b, 1, (0, 0, 0, 0), "constant", ""))
+    assert got.shape == want.shape  # "valid" keeps the padded extent (Q20)
+    np.testing.assert_allclose(got, want, **TOLH)
+    np.testing.assert_array_equal(got, sep)

@@ -580,7 +580,7 @@ def graph_fuse(ctx, nodes):
         if not o.plan:
             res.append((None, []))
         elif o.owned:
-            res.append((Plan(ctx, _P(o.plan), keep=(plan,)), [o.inputs[k] for k in range(o.n_inputs)]))
+            res.append((Plan(ctx, _P(o.plan), keep=tuple(q for q, _, _ in nodes)), [o.inputs[k] for k in range(o.n_inputs)]))  # fused plans borrow their members
         else:
             res.append((plan, [o.inputs[k] for k in range(o.n_inputs)]))  # the node's own plan, possibly re-wired past a folded identity producer
     return res

@@ -242,10 +242,24 @@ __global__ __launch_bounds__(256) void upsample_kernel(snnhip_upsample_desc d, i
 // CL*CV >= min(C, 128) so that one wave instruction reads whole pixels (contiguous C*4 bytes) instead of half-lines.
 // Partials go to part[n][s][2][C]; a tiny fold kernel turns them into mean[n][C] and mul[n][C] in a fixed order (deterministic).
 // STAGE 0: partial S1, S2      STAGE 2: y = act((x - mean) * mul + beta)
+struct InResidual { // graph rule H: the Add behind an InstanceNorm, applied in the norm's normalise sweep
+    const void* p = nullptr;
+    int H = 0, W = 0;
+    int zeroOutside = 0; // the residual is the Add's first input: the reference dispatches over ITS extent only (zeros elsewhere, see add_ragged_kernel)
+    int act = 0;
+    float leaky = 0.0f;
+};
+
 template <int STAGE, int CV, typename T>
 __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int pixelsPerSlab, int CLs, const T* __restrict__ x,
                                                           const float* __restrict__ statMean, const float* __restrict__ statMul,
-                                                          const float* __restrict__ beta, float* __restrict__ partOut, T* __restrict__ y) {
+                                                          const float* __restrict__ beta, float* __restrict__ partOut, T* __restrict__ y,
+                                                          InResidual ra = InResidual()) {
+    // ra.p != nullptr (STAGE 2, graph rule H): the Add layer behind the norm is applied in the same sweep, y = addAct(T(act(norm(x))) + res) with the
+    // rounding point of the separate launches (the norm's result is rounded to the tensor type before the addition).  The residual may be smaller than
+    // the norm (top-left aligned, add_ragged_kernel's rule): outside it the sum is the norm alone, or 0 when the residual is the Add's FIRST input.
+    const T* __restrict__ res = static_cast<const T*>(ra.p);
+    const bool ragged = ra.p && (ra.H != d.H || ra.W != d.W);
     __shared__ float red[2 * 256 * CV];
     const int n = blockIdx.x / S, s = blockIdx.x % S;
     const int tid = threadIdx.x;
@@ -281,6 +295,24 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
                 float o[CV];
 #pragma unroll
                 for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, (v[k] - piv[k]) * mul[k] + bt[k]);
+                if (res) {
+                    float rv[CV];
+                    size_t rp = p;
+                    bool inside = true;
+                    if (ragged) {
+                        const int oy = static_cast<int>(p / d.W), ox = static_cast<int>(p - static_cast<size_t>(oy) * d.W);
+                        inside = oy < ra.H && ox < ra.W;
+                        rp = static_cast<size_t>(oy) * ra.W + ox;
+                    }
+                    if (inside) {
+                        ldv<T, CV>(res + (static_cast<size_t>(n) * ra.H * ra.W + rp) * d.C + c, rv);
+#pragma unroll
+                        for (int k = 0; k < CV; ++k) o[k] = act1(ra.act, ra.leaky, static_cast<float>(static_cast<T>(o[k])) + rv[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < CV; ++k) o[k] = ra.zeroOutside ? 0.0f : act1(ra.act, ra.leaky, static_cast<float>(static_cast<T>(o[k])));
+                    }
+                }
                 stv<T, CV>(yn + p * d.C + c, o);
             }
         };
@@ -604,14 +636,30 @@ struct InstanceNormPlan : snnhip_plan {
     size_t foldScratchCount = 0;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "instancenorm: expects 1 input, got %d", nIn);
+        return runWithResidual(in, nIn, out, nullptr, 0, 0.0f);
+    }
+    // res != nullptr: the Add layer behind this norm folded into the normalise sweep (chain rule H)
+    int runWithResidual(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out, const snnhip_tensor* res, int addAct, float addLeaky, bool resFirst = false) {
         SNNHIP_SAME_DTYPE("instancenorm");
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, d.H, d.W, d.C), "instancenorm: tensor dims do not match the plan");
+        SNNHIP_REQUIRE(!res || (res->n == d.N && res->c == d.C && res->h <= d.H && res->w <= d.W && res->dtype == out->dtype),
+                       "instancenorm+add: the residual does not fit the output");
+        InResidual ra;
+        if (res) {
+            ra.p = res->data;
+            ra.H = res->h;
+            ra.W = res->w;
+            ra.zeroOutside = resFirst ? 1 : 0;
+            ra.act = addAct;
+            ra.leaky = addLeaky;
+        }
         const dim3 g(static_cast<unsigned>(d.N * S));
         const int NC = d.N * d.C, HW = d.H * d.W;
         const dim3 gf(static_cast<unsigned>(NC)); // one block per (image, channel)
         const float invHW = 1.0f / (static_cast<float>(d.H) * static_cast<float>(d.W));
-#define SNNHIP_IN(ST, CVV) \
-    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV, T>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta, d_part, mptr<T>(out))
+#define SNNHIP_IN(ST, CVV)                                                                                                                                     \
+    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV, T>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta, d_part, \
+                       mptr<T>(out), ST == 2 ? ra : InResidual())
 #define SNNHIP_FOLD() \
     hipLaunchKernelGGL(instancenorm_fold_kernel<T>, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, cptr<T>(in[0]), d_part, d_gamma, d_mean, d_mul)
         SNNHIP_WITH_T(out->dtype, if ((d.C & 3) == 0) {
@@ -630,7 +678,41 @@ struct InstanceNormPlan : snnhip_plan {
     }
 };
 
+// chain rule H: InstanceNorm -> Add(., residual) as the norm's own three launches; borrows the norm plan (parameters and scratch)
+struct InstanceNormAddPlan : snnhip_plan {
+    InstanceNormPlan* norm = nullptr;
+    int addAct = 0;
+    float addLeaky = 0.0f;
+    bool resFirst = false; // the residual is the Add's first input (matters only when it is smaller than the norm)
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 2, "instancenorm+add: expects 2 inputs (x, residual), got %d", nIn);
+        return norm->runWithResidual(in, 1, out, in[1], addAct, addLeaky, resFirst);
+    }
+};
+
 } // namespace
+
+int make_instancenorm_add_plan(snnhip_ctx* ctx, snnhip_plan* normPlan, snnhip_plan* addPlan, bool normIsFirstInput, snnhip_plan** out) {
+    auto* q = dynamic_cast<InstanceNormPlan*>(normPlan);
+    auto* ad = dynamic_cast<EltwisePlanBase*>(addPlan);
+    if (!q || !ad || ad->mode != 0 || getenv("SNNHIP_NO_ADD_FUSION")) return SNNHIP_E_UNSUPPORTED;
+    if (ad->d.N != q->d.N || ad->d.H != q->d.H || ad->d.W != q->d.W || ad->d.C != q->d.C) return SNNHIP_E_UNSUPPORTED;
+    auto* plan = new InstanceNormAddPlan();
+    plan->ctx = ctx;
+    plan->norm = q;
+    plan->addAct = ad->d.act;
+    plan->addLeaky = ad->d.leaky;
+    plan->resFirst = !normIsFirstInput;
+    plan->anyDtype = true;
+    plan->numInputs = 2;
+    memcpy(plan->inDims, q->inDims, sizeof(plan->inDims));
+    memcpy(plan->outDims, q->outDims, sizeof(plan->outDims));
+    plan->flops = q->flops + ad->flops;
+    plan->bytes = q->bytes + ad->bytes;
+    plan->desc = q->desc + " +add act=" + std::to_string(ad->d.act) + (plan->resFirst ? " (residual first)" : "");
+    *out = plan;
+    return SNNHIP_OK;
+}
 
 bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d) {
     const auto* q = dynamic_cast<const InstanceNormPlan*>(plan);

@@ -117,6 +117,31 @@ extern "C" int snnhip_graph_fuse(snnhip_ctx* ctx, const snnhip_graph_node* nodes
         }
     }
 
+    // ---- 1b. InstanceNorm -> Add (rule H: the residual blocks of the style-transfer networks): the Add moves into the norm's normalise sweep
+    for (int k = 0; k < n; ++k) {
+        if (!nodes[k].plan || nodes[k].n_inputs != 2 || taken[static_cast<size_t>(k)]) continue;
+        auto* add = dynamic_cast<EltwisePlanBase*>(nodes[k].plan);
+        if (!add || add->mode != 0) continue;
+        for (int which = 0; which < 2; ++which) {
+            const int src = nodes[k].inputs[which];
+            if (!foldable(src) || nodes[src].n_inputs != 1 || !instancenorm_plan_desc(nodes[src].plan, nullptr)) continue;
+            if (nodes[k].inputs[1 - which] == src) continue;
+            snnhip_plan* fused = nullptr;
+            const int rc = make_instancenorm_add_plan(ctx, nodes[src].plan, nodes[k].plan, which == 0, &fused);
+            if (rc == SNNHIP_E_UNSUPPORTED) continue;
+            if (rc != SNNHIP_OK) return fail(rc);
+            out[k].plan = fused;
+            out[k].owned = 1;
+            out[k].n_inputs = 2;
+            out[k].inputs[0] = nodes[src].inputs[0];
+            out[k].inputs[1] = nodes[k].inputs[1 - which];
+            out[src].plan = nullptr;
+            out[src].n_inputs = 0;
+            taken[static_cast<size_t>(k)] = taken[static_cast<size_t>(src)] = 1;
+            break;
+        }
+    }
+
     // ---- 2. maximal linear runs -> chain planner
     for (int i = 0; i < n;) {
         if (!nodes[i].plan || nodes[i].n_inputs != 1 || taken[static_cast<size_t>(i)]) {

@@ -191,6 +191,9 @@ struct ConvPlanBase : snnhip_plan {
 };
 // eltwise_pool.hip: identify an InstanceNorm plan / run its fold + normalise passes in place from a convolution's tile statistics
 bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d);
+// chain rule H: InstanceNorm -> Add(., residual) folded into the norm's normalise sweep (two-input plan; borrows normPlan)
+// the Add's output must have the norm's extent (a smaller residual is added top-left aligned, the reference's ragged-Add rule)
+int make_instancenorm_add_plan(snnhip_ctx* ctx, snnhip_plan* normPlan, snnhip_plan* addPlan, bool normIsFirstInput, snnhip_plan** out);
 int instancenorm_reserve_tile_stats(snnhip_plan* inPlan, int tilesX, int tilesY);
 int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const float* statPart, int tilesX, int tilesY, int TH, int TW, snnhip_tensor* xy);
 struct EltwisePlanBase : snnhip_plan {

@@ -297,3 +297,51 @@ def test_conv_instancenorm_not_fused_in_fp32(ctx, monkeypatch):
     y = chain(snn.Tensor.from_numpy(ctx, x)).numpy()
     want = O.instancenorm(O.conv2d(O.pad(x, (1, 1, 1, 1), "reflect"), wt, b, 1, (0, 0, 0, 0), "constant", "", 0.0, None), beta, gamma, "")
     np.testing.assert_allclose(y, want, **TOL)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("n,h,w,c,act,add_act", [(1, 24, 40, 32, "", ""), (2, 19, 23, 64, "relu", ""), (1, 45, 80, 128, "", "relu"), (3, 7, 9, 4, "", "")])
+def test_instancenorm_add_graph_fusion(ctx, monkeypatch, n, h, w, c, act, add_act, dtype):
+    """Graph rule H (the residual blocks of the style networks): InstanceNorm -> Add(., skip) becomes the norm's own launches with the addition in
+    the normalise sweep.  Same rounding points as the two launches: bit-identical to the unfused pair, and within tolerance of the oracle."""
+    import shadernn_amd as snn
+
+    dt = snn.F16 if dtype == "f16" else snn.F32
+    x, skip = 2.0 * _rand((n, h, w, c), 1) + 0.3, _rand((n, h, w, c), 2)
+    beta, gamma = _rand((c,), 4, 0.3), 1.0 + _rand((c,), 5, 0.2)
+    pre = snn.activation_plan(ctx, n, h, w, c, "tanh")          # a producer in front, so that the norm's input is a graph tensor
+    norm = snn.instancenorm_plan(ctx, n, h, w, c, beta, gamma, act=act)
+    add = snn.add_plan(ctx, n, h, w, c, act=add_act)
+    for order in ([1, -2], [-2, 1]):                              # the skip connection may be either summand
+        nodes = [(pre, [-1], False), (norm, [0], False), (add, order, True)]
+        fused = snn.graph_fuse(ctx, nodes)
+        assert fused[1][0] is None and "+add" in fused[2][0].describe() and fused[2][1] == [0, -2], (fused[2][0].describe(), fused[2][1])
+        xt, st = snn.Tensor.from_numpy(ctx, x, dtype=dt), snn.Tensor.from_numpy(ctx, skip, dtype=dt)
+        t0 = pre(xt)
+        y = fused[2][0]([t0, st]).numpy()
+        two = add([norm(t0), st]).numpy()
+        np.testing.assert_array_equal(y, two)
+    q = O._h if dtype == "f16" else (lambda a: a)
+    t = q(O.add_act(q(x), None, "tanh"))
+    want = q(O.add_act(q(O.instancenorm(t, beta, gamma, act)), q(skip), add_act))
+    np.testing.assert_allclose(y, want, **(dict(rtol=4e-3, atol=4e-3) if dtype == "f16" else TOL))
+    # a skip smaller than the norm (Candy's residual blocks under the reference's size rule, SURVEY Q20): the ragged-Add rule, both input orders
+    if h > 8:
+        small = np.ascontiguousarray(skip[:, : h - 4, : w - 4, :])
+        st = snn.Tensor.from_numpy(ctx, small, dtype=dt)
+        for order in ([1, -2], [-2, 1]):
+            fused = snn.graph_fuse(ctx, [(pre, [-1], False), (norm, [0], False), (add, order, True)])
+            assert fused[1][0] is None and ("residual first" in fused[2][0].describe()) == (order[0] == -2)
+            y = fused[2][0]([t0, st]).numpy()
+            two = add([norm(t0), st] if order[0] == 1 else [st, norm(t0)]).numpy()
+            np.testing.assert_array_equal(y, two)
+            nrm = q(O.instancenorm(t, beta, gamma, act))
+            want = O.add_act(nrm, None, add_act) if order[0] == 1 else np.zeros_like(nrm)
+            want[:, : h - 4, : w - 4, :] = O.add_act(nrm[:, : h - 4, : w - 4, :], q(small), add_act)
+            np.testing.assert_allclose(y, q(want), **(dict(rtol=4e-3, atol=4e-3) if dtype == "f16" else TOL))
+    # a norm that somebody else reads as well stays a launch of its own
+    nodes = [(pre, [-1], False), (norm, [0], True), (add, [1, -2], True)]
+    assert all(p is not None for p, _ in snn.graph_fuse(ctx, nodes))
+    monkeypatch.setenv("SNNHIP_NO_ADD_FUSION", "1")
+    nodes = [(pre, [-1], False), (norm, [0], False), (add, [1, -2], True)]
+    assert all(p is not None for p, _ in snn.graph_fuse(ctx, nodes))

@@ -436,6 +436,18 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
             if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
         }
     }
+    // fp16 3x3 stride-1 layers on large maps: the 4 x 2 register-block kernel of conv2d_wide_f16.hip (SNNHIP_CONV=wide forces it for every
+    // eligible shape, SNNHIP_CONV=mfma / SNNHIP_CONV_WIDE=0 keep the 128-pixel kernel)
+    {
+        const char* force = getenv("SNNHIP_CONV");
+        const char* w = getenv("SNNHIP_CONV_WIDE");
+        const bool forced = force && strcmp(force, "wide") == 0;
+        const bool allowed = !force && !(w && atoi(w) == 0) && !getenv("SNNHIP_CONV_BN") && !getenv("SNNHIP_CONV_SPLITK") && !getenv("SNNHIP_CONV_C8");
+        if (forced || allowed) {
+            const int rc = make_conv2d_wide_plan(ctx, g, w_oihw, epi4, out);
+            if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
+        }
+    }
     // pointwise layers (fp32, and fp16 with OC % 8 == 0) stream through conv1x1_stream.hip (no halo tile to stage); forcing a kernel or a
     // configuration skips it
     if (!getenv("SNNHIP_CONV") && !getenv("SNNHIP_CONV_BN") && !getenv("SNNHIP_CONV_SPLITK") && !getenv("SNNHIP_CONV_C8")) {

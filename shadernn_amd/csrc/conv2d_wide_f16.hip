@@ -1,0 +1,380 @@
+// conv2d_wide_f16.hip -- fp16 3x3 stride-1 convolution for large feature maps (the bodies of the style-transfer / U-Net graphs): the implicit
+// GEMM of conv2d_mfma.hip with a 4 x NT register block of v_mfma_f32_32x32x16_f16 tiles per wave (128 pixels x 64 / 32 output channels)
+// instead of 2 x 2.
+//
+// Why a second kernel (measured on Candy 720p fp16, tools/gpu_candy_abl.sh): the 128-pixel blocks of conv2d_mfma_kernel reach 23 % of the
+// fp16 matrix peak on the 128 -> 128 layers and 57 % with every memory operation ablated.  One 32x32x16 MFMA consumes 2 KB of operands in 32
+// cycles; a CU's four SIMDs would need 256 B/clk with no reuse, LDS delivers 128 B/clk and the vector L1 64 B/clk.  With a 2 x 2 register
+// block the activation operands cost 64 B/clk of LDS reads and the weights (streamed per lane from L2) 64 B/clk of L1 -- the L1 is saturated
+// at HALF the matrix rate before the halo-tile staging asks for anything.  A 4 x 2 block halves the weight stream (32 B/clk) at the same LDS
+// rate, a 256-pixel block tile halves the weight traffic per output once more, and the unrolled K loop spends 8 MFMAs (256 cycles) per LDS /
+// L1 round trip instead of 4.
+//
+//   * block = 256 threads = WM x WN waves, pixel tile TH x 32 (TH = 8 or 16) of ONE image, BN = 32 NT WN output channels:
+//       WM=2 WN=2 NT=2: 256 px x 128 oc     WM=4 WN=1 NT=2: 512 px x 64 oc     WM=4 WN=1 NT=1: 512 px x 32 oc
+//   * halo tile staged through registers into LDS in channel chunks of 16 C8 (double-buffered, one barrier per chunk), XOR-swizzled 16-byte
+//     slots as in conv2d_mfma_kernel (lds_off); the fused Pad / UpSampling address path (ConvGeom::preMode / preShift) resolves here;
+//   * optional pre-normalisation (graph rule I): the InstanceNorm in front of the convolution applied to the staged values
+//     (act((x - mean) * mul + beta), fp32, rounded to half -- the rounding point of the separate normalise sweep), so the normalised tensor is
+//     never written: the norm runs its statistics sweep + fold only;
+//   * weights packed exactly as for conv2d_mfma_kernel ([chunk][tap][c8][h][OCp] x 8 halfs), streamed per lane with a 3-step ring;
+//   * epilogue: bias / BN / activation, the tile transposed through LDS and written as 16-byte channel-contiguous vectors, fused residual Add.
+#include "conv2d_mfma_kernel.h"
+
+#include <cstring>
+
+namespace snnhip {
+
+namespace {
+
+using mfma_detail::f32x16;
+
+struct WideParams {
+    int N, H, W, IC, OC, padx, pady, padMode, useBN, OH, OW;
+    int THs;             // log2 of the tile height; the tile is (1 << THs) x 32 pixels
+    int tileH, tileW;    // staged halo tile
+    int tilesX, tilesY;
+    int nChunks, OCp, total, bufFloats;
+    int zeroOfs;         // float4 offset (from the packed weights) of a block of zeros: source of the padding pixels' DMA
+    int preMode, preX, preY, srcH, srcW, preShift;
+    unsigned magicW;
+    const void* res; // fused residual Add (chain rule E)
+    ActCfg ac2;
+    // pre-normalisation (graph rule I): per (image, channel) mean and multiplier of the InstanceNorm in front, its beta and activation
+    const float* normMean;
+    const float* normMul;
+    const float* normBeta;
+    ActCfg normAc;
+};
+
+template <int WM, int WN, int NT, int C8, int R, bool SIMPLE, bool NORM>
+__global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
+                                                          const float4* __restrict__ epi, _Float16* __restrict__ y) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr int MT = 4;
+    constexpr int PIX = 32 * MT * WM;
+    constexpr int BN = 32 * NT * WN;
+    constexpr int Q = 2 * C8;  // 16-byte slots per staged pixel
+    constexpr int S = 9 * C8;  // K steps (16 channels each) per chunk
+    constexpr int D = 3;       // weight ring depth in K steps (divides S)
+    constexpr int kTileW = 34; // staged tile width: the 32-pixel tile row + the 3x3 halo
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l32 = lane & 31, h = lane >> 5;
+
+    const int mt = blockIdx.x;
+    const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, n = mt / (p.tilesX * p.tilesY);
+    const int ox0 = tx << 5, oy0 = ty << p.THs;
+    const int ix0 = ox0 - p.padx, iy0 = oy0 - p.pady;
+
+    // ---- staging.  LDS-DMA (lds_dma16): element e = tid + 256 r lands at 16-byte LDS slot e of the buffer (lane-contiguous, the only
+    // placement the instruction offers).  A pixel owns Q + 1 slots: Q of data and one of padding, so that the 32 pixels of an operand row sit
+    // (Q + 1) * 16 bytes apart -- an odd number of 16-byte bank slots, conflict-free for ds_read_b128 without an XOR swizzle, and every tap /
+    // channel-slot displacement is an immediate offset of the ds_read (with the swizzle of lds_off the unrolled loop kept 72 precomputed
+    // addresses in registers and spilled).  Pixels outside the image (zero padding), the padding slots and the slots past the tile read a
+    // block of zeros behind the packed weights.  No staging registers, no ds_write; the copy for chunk c+1 is issued at the top of chunk c
+    // and waited for with a COUNTED vmcnt before the closing barrier (the weight ring's youngest loads stay in flight).
+    constexpr int QP = Q + 1;
+    int gofs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = tid + 256 * r;
+        gofs[r] = -1;
+        if (e < p.total) {
+            const int pix = e / QP;
+            const int ql = e - pix * QP;
+            const int rr = static_cast<int>(__umulhi(static_cast<unsigned>(pix), p.magicW));
+            const int c = pix - rr * p.tileW;
+            int sy = resolve_coord(iy0 + rr, p.H, p.padMode);
+            int sx = resolve_coord(ix0 + c, p.W, p.padMode);
+            if (p.preMode && sy >= 0 && sx >= 0) {
+                sy = resolve_coord(sy - p.preY, p.srcH << p.preShift, p.preMode);
+                sx = resolve_coord(sx - p.preX, p.srcW << p.preShift, p.preMode);
+                if (sy >= 0) sy >>= p.preShift;
+                if (sx >= 0) sx >>= p.preShift;
+            }
+            if (sy >= 0 && sx >= 0 && ql < Q) gofs[r] = ((n * p.srcH + sy) * p.srcW + sx) * p.IC + ql * 8;
+        }
+    }
+    const _Float16* const zeros = reinterpret_cast<const _Float16*>(wp + p.zeroOfs);
+    auto stage_dma = [&](float* buf, int ic0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const _Float16* src = gofs[r] >= 0 ? x + gofs[r] + ic0 : zeros;
+            lds_dma16(src, buf + (wave * 64 + 256 * r) * 4);
+        }
+    };
+
+    // ---- MFMA operand addressing: lane (l32, h) reads pixel (row wm*MT + t of the tile, column l32), slot 2 c8 + h; aoff = float offset
+    int aoff[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) aoff[t] = (((wm * MT + t) * p.tileW + l32) * QP + h) * 4;
+    const int n0 = blockIdx.y * BN + wn * (NT * 32);
+    const size_t bstep = static_cast<size_t>(2) * p.OCp; // float4 units per K step
+    const float4* bptr = wp + (static_cast<size_t>(h) * p.OCp + n0 + l32);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    float4 bq[D][NT];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) bq[d][u] = bptr[u * 32];
+        bptr += bstep;
+    }
+
+    stage_dma(smem, 0);
+    lds_dma_wait();
+    __syncthreads();
+
+    float4 a[MT];
+    for (int chunk = 0; chunk < p.nChunks; ++chunk) {
+        const float* cur = smem + (chunk & 1) * p.bufFloats;
+        const bool more = chunk + 1 < p.nChunks;
+        if (more) stage_dma(smem + ((chunk + 1) & 1) * p.bufFloats, (chunk + 1) * 16 * C8);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4*>(cur + aoff[t]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            float4 b[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) b[u] = bq[s % D][u];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) bq[s % D][u] = bptr[u * 32];
+            bptr += bstep;
+            __builtin_amdgcn_sched_barrier(0); // the refill stays D steps ahead of its use
+            const int tap = (s + 1) / C8;
+            const int dl = (((tap / 3) * kTileW + (tap % 3)) * QP + ((s + 1) % C8) * 2) * 4; // compile-time: an immediate offset of the ds_read
+            // pixel-tile major: a[t] is dead after its NT MFMAs and is refilled for the next step at once -- no second operand set in registers
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
+                if (s + 1 < S) a[t] = *reinterpret_cast<const float4*>(cur + aoff[t] + dl);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the DMA of this chunk is older than every weight refill of the chunk; the ring keeps D * NT loads in flight
+        if (D * NT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias -> BN -> activation into the LDS tile [pixel][BN halfs] (pitch BN + 8: the two half-waves hit disjoint banks), then
+    // 16-byte channel-contiguous stores (+ the fused residual Add, same rounding points as the separate launches)
+    constexpr int EPITCH = BN + 8;
+    _Float16* const otile = reinterpret_cast<_Float16*>(smem);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int ibase = (wm * MT + t) * 32 + 4 * h;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float4 e = epi[n0 + u * 32 + l32]; // table padded to OCp
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = epi_affine(acc[t][u][4 * g + k], e, p.useBN);
+                    v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+                    otile[(ibase + 8 * g + k) * EPITCH + wn * (NT * 32) + u * 32 + l32] = static_cast<_Float16>(v);
+                }
+        }
+    }
+    __syncthreads();
+    constexpr int VPR = BN / 8; // 16-byte vectors per pixel of the tile
+    const bool addSimple = act_is_simple_dev(p.ac2.act);
+#pragma unroll 4
+    for (int j = 0; j < PIX * VPR / 256; ++j) {
+        const int v = tid + 256 * j;
+        const int i = v / VPR, c8 = v - i * VPR;
+        const int oy = oy0 + (i >> 5), ox = ox0 + (i & 31);
+        const int oc = blockIdx.y * BN + c8 * 8;
+        if (oy < p.OH && ox < p.OW && oc < p.OC) {
+            const size_t o = (static_cast<size_t>(n * p.OH + oy) * p.OW + ox) * p.OC + oc;
+            float4 pack = *reinterpret_cast<const float4*>(otile + i * EPITCH + c8 * 8);
+            if (p.res) {
+                const float4 rpack = *reinterpret_cast<const float4*>(static_cast<const _Float16*>(p.res) + o);
+                const _Float16* ch = reinterpret_cast<const _Float16*>(&pack);
+                const _Float16* rh = reinterpret_cast<const _Float16*>(&rpack);
+                _Float16 oh[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) oh[e] = static_cast<_Float16>(add_act(p.ac2, addSimple, static_cast<float>(ch[e]) + static_cast<float>(rh[e])));
+                pack = *reinterpret_cast<const float4*>(oh);
+            }
+            *reinterpret_cast<float4*>(y + o) = pack;
+        }
+    }
+}
+
+typedef void (*WideFn)(WideParams, ActCfg, const _Float16*, const float4*, const float4*, _Float16*);
+
+struct WideConvPlan : ConvPlanBase {
+    WideParams p;
+    ActCfg ac;
+    float* d_w = nullptr;
+    float* d_epi = nullptr;
+    size_t ldsBytes = 0;
+    dim3 grid;
+    WideFn kernel = nullptr, kernelNorm = nullptr;
+    bool fusedAdd = false;
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == (fusedAdd ? 2 : 1), "conv2d: expects %d input(s), got %d", fusedAdd ? 2 : 1, nIn);
+        const snnhip_tensor* x = in[0];
+        WideParams q = p;
+        q.res = nullptr;
+        if (fusedAdd) {
+            const snnhip_tensor* r = in[1];
+            SNNHIP_REQUIRE(r->n == p.N && r->h == p.OH && r->w == p.OW && r->c == p.OC && r->dtype == dtype,
+                           "conv2d+add: residual %dx%dx%dx%d (dtype %d) does not match the output %dx%dx%dx%d", r->n, r->h, r->w, r->c, r->dtype, p.N, p.OH,
+                           p.OW, p.OC);
+            q.res = r->data;
+        }
+        SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == p.IC && x->dtype == SNNHIP_F16,
+                       "conv2d: input dims %dx%dx%dx%d (dtype %d) != plan %dx%dx%dx%d fp16", x->n, x->h, x->w, x->c, x->dtype, p.N, p.srcH, p.srcW, p.IC);
+        SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC && out->dtype == SNNHIP_F16,
+                       "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, q, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
+                           reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+template <int WM, int WN, int NT, int C8, int R>
+WideFn pick_wide(bool simple, bool norm) {
+    if (norm) return nullptr; // (pre-normalising variant: see below)
+    return simple ? conv2d_wide_kernel<WM, WN, NT, C8, R, true, false> : conv2d_wide_kernel<WM, WN, NT, C8, R, false, false>;
+}
+
+} // namespace
+
+// fp16 3x3 stride-1 layers with IC % 16 == 0, OC % 32 == 0 and enough 256 / 512-pixel tiles to fill the chip; SNNHIP_CONV=wide forces it for
+// every eligible shape, SNNHIP_CONV_WIDE=0 keeps the 128-pixel kernel
+int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
+    if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
+    if (g.IC % 16 != 0 || g.OC % 32 != 0 || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED;
+    const double inCount = static_cast<double>(g.N) * (g.preMode ? g.srcH : g.H) * (g.preMode ? g.srcW : g.W) * g.IC;
+    const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
+    if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
+    const char* force = getenv("SNNHIP_CONV");
+    const bool forced = force && strcmp(force, "wide") == 0;
+
+    // block shape: 256 px x 128 oc when the channels fill it, else 512 px x 64 / 32 oc
+    int WM = 4, NT = 2, BN = 64;
+    if (g.OC % 128 == 0) { WM = 2; NT = 2; BN = 128; }
+    else if (g.OC % 64 != 0) { NT = 1; BN = 32; }
+    if (const char* e = getenv("SNNHIP_WIDE_BN")) { // experiments
+        const int v = atoi(e);
+        if (v == 128 && g.OC % 128 == 0) { WM = 2; NT = 2; BN = 128; }
+        if (v == 64 && g.OC % 64 == 0) { WM = 4; NT = 2; BN = 64; }
+        if (v == 32) { WM = 4; NT = 1; BN = 32; }
+    }
+    const int THs = WM == 2 ? 3 : 4, TH = 1 << THs, TW = 32;
+    const int C8 = (WM == 2 && g.IC % 32 == 0) ? 2 : 1;
+    const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+    const long tiles = static_cast<long>(g.N) * up_div(g.OH, TH) * up_div(g.OW, TW);
+    if (!forced && tiles * (g.OC / BN) < 3L * cus) return SNNHIP_E_UNSUPPORTED; // fewer than 1.5 rounds of resident blocks: the 128-pixel tiles fill the chip better
+
+    WideParams p{};
+    p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.padx = g.padx; p.pady = g.pady; p.padMode = g.padMode; p.useBN = g.useBN;
+    p.OH = g.OH; p.OW = g.OW; p.THs = THs;
+    p.tileH = TH + 2; p.tileW = TW + 2;
+    p.tilesX = up_div(g.OW, TW); p.tilesY = up_div(g.OH, TH);
+    p.nChunks = g.IC / (16 * C8);
+    p.OCp = g.OC;
+    p.total = p.tileH * p.tileW * (2 * C8 + 1); // 16-byte slots: Q of data + 1 of padding per pixel
+    const int R = up_div(p.total, 256);
+    p.bufFloats = R * 256 * 4; // every DMA lane has a slot
+    p.zeroOfs = static_cast<int>((static_cast<size_t>(p.nChunks) * 9 * C8 + 3) * 2 * g.OC); // the last of the 4 zero steps behind the weights
+    p.preMode = g.preMode; p.preX = g.preX; p.preY = g.preY; p.preShift = g.preMode ? g.preShift : 0;
+    p.srcH = g.preMode ? g.srcH : g.H;
+    p.srcW = g.preMode ? g.srcW : g.W;
+    p.magicW = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(p.tileW) - 1) / static_cast<unsigned>(p.tileW));
+    p.res = nullptr;
+    p.ac2 = make_act_cfg(g.addAct >= 0 ? g.addAct : SNNHIP_ACT_NONE, g.addLeaky);
+    p.normMean = p.normMul = p.normBeta = nullptr;
+    p.normAc = make_act_cfg(SNNHIP_ACT_NONE, 0.0f);
+
+    const bool simple = act_is_simple(g.act);
+    WideFn fn = nullptr, fnNorm = nullptr;
+    if (WM == 2 && C8 == 2 && R <= 7) { fn = pick_wide<2, 2, 2, 2, 7>(simple, false); fnNorm = pick_wide<2, 2, 2, 2, 7>(simple, true); }
+    if (WM == 2 && C8 == 1 && R <= 4) { fn = pick_wide<2, 2, 2, 1, 4>(simple, false); fnNorm = pick_wide<2, 2, 2, 1, 4>(simple, true); }
+    if (WM == 4 && NT == 2 && R <= 8) { fn = pick_wide<4, 1, 2, 1, 8>(simple, false); fnNorm = pick_wide<4, 1, 2, 1, 8>(simple, true); }
+    if (WM == 4 && NT == 1 && R <= 8) { fn = pick_wide<4, 1, 1, 1, 8>(simple, false); fnNorm = pick_wide<4, 1, 1, 1, 8>(simple, true); }
+    if (!fn) return SNNHIP_E_UNSUPPORTED;
+    const int PIX = 128 * WM;
+    size_t lds = std::max(static_cast<size_t>(2) * p.bufFloats * 4 + static_cast<size_t>(3) * g.IC * 4, static_cast<size_t>(PIX) * (BN + 8) * 2);
+    if (lds > 80 * 1024) return SNNHIP_E_UNSUPPORTED;
+
+    auto* plan = new WideConvPlan();
+    plan->ctx = ctx;
+    plan->g = g;
+    plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC * 9);
+    plan->epi4 = epi4;
+    plan->p = p;
+    plan->ac = make_act_cfg(g.act, g.leaky);
+    plan->kernel = fn;
+    plan->kernelNorm = fnNorm;
+    plan->ldsBytes = lds;
+    plan->fusedAdd = g.addAct >= 0;
+    if (plan->fusedAdd) plan->numInputs = 2;
+    plan->grid = dim3(static_cast<unsigned>(tiles), g.OC / BN, 1);
+    for (WideFn f : {fn, fnNorm})
+        if (f && lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+            set_error("conv2d_wide: hipFuncSetAttribute(%zu) failed", lds);
+            delete plan;
+            return SNNHIP_E_HIP;
+        }
+
+    // weights: Wp[chunk][tap][c8][h][OC] x 8 halfs, ic = chunk*16*C8 + (c8*2 + h)*8 + j  (+ D zero steps for the ring's read-ahead)
+    const size_t steps = static_cast<size_t>(p.nChunks) * 9 * C8;
+    std::vector<float> wpk((steps + 4) * 2 * g.OC * 4, 0.0f);
+    _Float16* wph = reinterpret_cast<_Float16*>(wpk.data());
+    for (int chunk = 0; chunk < p.nChunks; ++chunk)
+        for (int t = 0; t < 9; ++t)
+            for (int c8 = 0; c8 < C8; ++c8)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int j = 0; j < 8; ++j) {
+                        const int ic = chunk * 16 * C8 + (c8 * 2 + hh) * 8 + j;
+                        const size_t base = (((static_cast<size_t>(chunk) * 9 + t) * C8 + c8) * 2 + hh) * g.OC;
+                        for (int o = 0; o < g.OC; ++o) wph[(base + o) * 8 + j] = static_cast<_Float16>(w_oihw[(static_cast<size_t>(o) * g.IC + ic) * 9 + t]);
+                    }
+    std::vector<float> epiP(static_cast<size_t>(g.OC) * 4, 0.0f);
+    std::memcpy(epiP.data(), epi4.data(), sizeof(float) * 4 * static_cast<size_t>(g.OC));
+    int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
+    if (rc == SNNHIP_OK) rc = plan->upload(epiP.data(), epiP.size(), &plan->d_epi);
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    plan->inDims[0] = g.N; plan->inDims[1] = p.srcH; plan->inDims[2] = p.srcW; plan->inDims[3] = g.IC;
+    plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
+    plan->dtype = SNNHIP_F16;
+    plan->flops = 2.0 * 9 * g.IC * g.OC * static_cast<double>(g.OH) * g.OW * g.N;
+    plan->bytes = 2.0 * (static_cast<double>(g.N) * p.srcH * p.srcW * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * 9);
+    char buf[256];
+    snprintf(buf, sizeof(buf), "conv2d_mfma_wide_f16_32x32x16 k=3x3 s=1 ic=%d oc=%d tile=%dx32px x %doc (4x%d MFMA tiles per wave) chunk=%d lds=%zuB", g.IC, g.OC, TH, BN, NT,
+             16 * C8, lds);
+    plan->desc = buf;
+    if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
+    if (g.preMode && g.preShift) plan->desc += " +upsample(x2)";
+    if (plan->fusedAdd) {
+        plan->desc += " +add";
+        plan->bytes += 2.0 * static_cast<double>(g.N) * g.OH * g.OW * g.OC;
+    }
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip

@@ -115,10 +115,10 @@ __global__ __launch_bounds__(256 * OPB, 3 - OPB) void conv2d_wino_kernel(WinoPar
         const float4* u_ = uptr + static_cast<size_t>((chunk_) - chunk0) * UQ;                                                    \
         float* ub_ = (buf_) + 4 * (wave * 64);                                                                                    \
         if (!(SNNHIP_WINO_ABL & 64)) {                                                                                            \
-            __builtin_amdgcn_global_load_lds(u_, (lds_ptr)(ub_), 16, 0, 0);                                                       \
-            __builtin_amdgcn_global_load_lds(u_ + NT, (lds_ptr)(ub_ + 4 * NT), 16, 0, 0);                                         \
-            __builtin_amdgcn_global_load_lds(u_ + 2 * NT, (lds_ptr)(ub_ + 8 * NT), 16, 0, 0);                                     \
-            __builtin_amdgcn_global_load_lds(u_ + 3 * NT, (lds_ptr)(ub_ + 12 * NT), 16, 0, 0);                                    \
+            lds_dma16(u_, ub_);                                                                                                   \
+            lds_dma16(u_ + NT, ub_ + 4 * NT);                                                                                     \
+            lds_dma16(u_ + 2 * NT, ub_ + 8 * NT);                                                                                 \
+            lds_dma16(u_ + 3 * NT, ub_ + 12 * NT);                                                                                \
         }                                                                                                                         \
         sxa = sxb = sxc = sxd = zero4;                                                                                            \
         if (SNNHIP_WINO_ABL & 128) break;                                                                                         \
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256 * OPB, 3 - OPB) void conv2d_wino_kernel(WinoPar
 
     WINO_STAGE_LOAD(chunk0, smem);
     WINO_STAGE_STORE(smem);
+    lds_dma_wait();
     __syncthreads();
 
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256 * OPB, 3 - OPB) void conv2d_wino_kernel(WinoPar
         WINO_STEP(8); WINO_STEP(9); WINO_STEP(10); WINO_STEP(11); WINO_STEP(12); WINO_STEP(13); WINO_STEP(14); WINO_STEP(15);
 #undef WINO_STEP
 #undef WINO_LDU
+        lds_dma_wait(); // (free here: the activation loads issued after the DMA were waited for by the stage store above)
         if (!(SNNHIP_WINO_ABL & 1)) __syncthreads();
     }
 

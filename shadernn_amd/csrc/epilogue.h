@@ -122,6 +122,18 @@ __device__ __forceinline__ void stv(T* __restrict__ p, const float (&v)[CV]) {
     }
 }
 
+// LDS-DMA (global_load_lds_dwordx4): every lane copies 16 bytes from its own global address to LDS byte (wave-uniform base) + 16 * lane, no
+// staging registers and no ds_write.  Issued as inline assembly on purpose: behind __builtin_amdgcn_global_load_lds the compiler cannot tell
+// which LDS bytes the copy writes and puts s_waitcnt vmcnt(0) in front of the NEXT ds_read of the kernel -- the wave then sits out the full
+// latency of a prefetch it will not touch before the next barrier (seen in conv2d_wino's chunk loop).  The asm form is invisible to that
+// tracking: the caller waits with lds_dma_wait() (or any later wait for a younger load: vmcnt retires in order) before the barrier that
+// publishes the data.  m0 is not otherwise used by these kernels (gfx9 ds instructions do not read it).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, const void* ldsWaveBase) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)(ldsWaveBase))));
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(base) : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // coordinate resolution of vk_conv2d.comp:168-218; returns -1 when the fetch yields 0
 __device__ __forceinline__ int resolve_coord(int s, int size, int padMode) {
     if (padMode == SNNHIP_PAD_REPLICATE) return min(max(s, 0), size - 1);

@@ -1,0 +1,140 @@
+"""conv2d_wide_f16.hip: the fp16 3x3 stride-1 kernel with 4 x NT MFMA register blocks (256 / 512-pixel tiles), forced with SNNHIP_CONV=wide on
+shapes small enough for the oracle: ragged tile edges in both directions, every block shape (128 / 64 / 32 output channels per block, 16- and
+32-channel chunks), padding modes, epilogues, the fused Pad / UpSampling staging path and the fused residual Add -- against the quantised
+oracle and against the 128-pixel kernel (SNNHIP_CONV=mfma) on the same inputs."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_ops_gpu import _bn, _rand
+
+pytestmark = pytest.mark.gpu
+TOLH = dict(rtol=4e-3, atol=4e-3)
+
+# N, H, W, IC, OC
+SHAPES = [(1, 16, 64, 32, 128), (2, 19, 45, 64, 128), (1, 9, 33, 16, 128), (1, 37, 70, 128, 128), (2, 18, 40, 32, 64), (1, 33, 35, 48, 64), (1, 20, 66, 64, 32),
+          (3, 7, 9, 16, 96), (1, 8, 32, 256, 256)]
+
+
+def _run(ctx, x, w, b, pad_mode, act, bn, pads=None):
+    import shadernn_amd as snn
+
+    n, h, ww, _ = x.shape
+    plan = snn.conv2d_plan(ctx, n, h, ww, w, b, stride=1, pads=pads or O.padding_offsets("same", 3), pad_mode=pad_mode, act=act, bn=bn, dtype=snn.F16)
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    y, desc = plan(xt).numpy(), plan.describe()
+    plan.destroy()
+    return y, desc
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda c: "x".join(map(str, c)))
+def test_wide_matches_quantised_oracle_and_narrow_kernel(ctx, monkeypatch, shape):
+    N, H, W, IC, OC = shape
+    x = _rand((N, H, W, IC), 81)
+    w = _rand((OC, IC, 3, 3), 82, 1.0 / np.sqrt(IC * 9))
+    b = _rand((OC,), 83, 0.1)
+    bn = _bn(OC, 84)
+    pads = O.padding_offsets("same", 3)
+    for pad_mode, act, use_bn in (("constant", "relu", True), ("reflect", "tanh", False), ("replicate", "", True)):
+        monkeypatch.setenv("SNNHIP_CONV", "wide")
+        y, desc = _run(ctx, x, w, b, pad_mode, act, bn if use_bn else None)
+        assert "conv2d_mfma_wide_f16" in desc, desc
+        want = O._h(O.conv2d(O._h(x), O._h(w), b, 1, pads, pad_mode, act, 0.0, bn if use_bn else None))
+        np.testing.assert_allclose(y, want, err_msg=desc, **TOLH)
+        monkeypatch.setenv("SNNHIP_CONV", "mfma")
+        y2, desc2 = _run(ctx, x, w, b, pad_mode, act, bn if use_bn else None)
+        assert "wide" not in desc2, desc2
+        np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-3, atol=2e-3)
+
+
+def test_wide_valid_padding_and_block_widths(ctx, monkeypatch):
+    """'valid' convolutions (no border offsets; under the reference's size rule the output keeps the input extent and the taps past the bottom /
+    right edge read zeros) and the forced block widths of a 128-channel layer."""
+    x = _rand((1, 21, 50, 32), 5)
+    w = _rand((128, 32, 3, 3), 6, 1.0 / np.sqrt(32 * 9))
+    b = _rand((128,), 7, 0.1)
+    want = O._h(O.conv2d(O._h(x), O._h(w), b, 1, (0, 0, 0, 0), "constant", "relu", 0.0, None))
+    monkeypatch.setenv("SNNHIP_CONV", "wide")
+    for bn_w in ("128", "64", "32"):
+        monkeypatch.setenv("SNNHIP_WIDE_BN", bn_w)
+        y, desc = _run(ctx, x, w, b, "constant", "relu", None, pads=(0, 0, 0, 0))
+        assert "x %soc" % bn_w in desc, desc
+        assert y.shape == want.shape == (1, 21, 50, 128)
+        np.testing.assert_allclose(y, want, err_msg=desc, **TOLH)
+
+
+@pytest.mark.parametrize("with_up", [False, True])
+@pytest.mark.parametrize("oc", [128, 64, 32])
+def test_wide_with_fused_pad_upsample_and_add(ctx, monkeypatch, oc, with_up):
+    """The chain planner's fusions land on the wide kernel too: [UpSampling ->] reflect Pad -> Conv2D (rule D) and Conv2D -> Add (rule E)."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_CONV", "wide")
+    n, h, w_, ic = 2, 13, 21, 32
+    x, wt, b = _rand((n, h, w_, ic), 1), _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9)), _rand((oc,), 3, 0.2)
+    plans, hh, ww = [], h, w_
+    if with_up:
+        plans.append(snn.upsample_plan(ctx, n, h, w_, ic, 2.0, "nearest"))
+        hh, ww = 2 * h, 2 * w_
+    plans.append(snn.pad_plan(ctx, n, hh, ww, ic, (1, 1, 1, 1), "reflect"))
+    plans.append(snn.conv2d_plan(ctx, n, hh + 2, ww + 2, wt, b, stride=1, pads=(0, 0, 0, 0), act="relu", dtype=snn.F16))
+    chain = snn.chain_plan(ctx, plans)
+    assert chain.num_steps() == 1 and "wide" in chain.describe() and "+pad(reflect)" in chain.describe(), chain.describe()
+    assert ("+upsample" in chain.describe()) == with_up
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    y = chain(xt).numpy()
+    t = O._h(x)
+    if with_up:
+        t = O.upsample(t, 2.0, "nearest")
+    t = O.pad(t, (1, 1, 1, 1), "reflect")
+    want = O._h(O.conv2d(t, O._h(wt), b, 1, (0, 0, 0, 0), "constant", "relu", 0.0, None))
+    np.testing.assert_allclose(y, want, err_msg=chain.describe(), **TOLH)
+    # conv -> add
+    conv = snn.conv2d_plan(ctx, n, hh, ww, _rand((oc, oc, 3, 3), 4, 1.0 / np.sqrt(oc * 9)), _rand((oc,), 5, 0.2), stride=1, pads=(1, 1, 1, 1), act="", dtype=snn.F16) if oc % 16 == 0 else None
+    add = snn.add_plan(ctx, n, hh, ww, oc, act="relu")
+    fused = snn.chain_plan(ctx, [conv, add])
+    assert fused.num_steps() == 1 and "wide" in fused.describe() and "+add" in fused.describe(), fused.describe()
+    a, r = _rand((n, hh, ww, oc), 6), _rand((n, hh, ww, oc), 7)
+    at, rt = snn.Tensor.from_numpy(ctx, a, dtype=snn.F16), snn.Tensor.from_numpy(ctx, r, dtype=snn.F16)
+    got = fused([at, rt]).numpy()
+    two = add([conv(at), rt]).numpy()
+    np.testing.assert_array_equal(got, two)
+
+
+def test_wide_is_the_default_on_large_maps_only(ctx):
+    import shadernn_amd as snn
+
+    w = _rand((128, 128, 3, 3), 1, 0.03)
+    big = snn.conv2d_plan(ctx, 8, 180, 320, w, None, stride=1, pads=(1, 1, 1, 1), dtype=snn.F16)
+    small = snn.conv2d_plan(ctx, 1, 28, 28, w, None, stride=1, pads=(1, 1, 1, 1), dtype=snn.F16)
+    s2 = snn.conv2d_plan(ctx, 8, 180, 320, w, None, stride=2, pads=(1, 1, 1, 1), dtype=snn.F16)
+    f32 = snn.conv2d_plan(ctx, 8, 180, 320, w, None, stride=1, pads=(1, 1, 1, 1))
+    assert "wide" in big.describe(), big.describe()
+    for p in (small, s2, f32):
+        assert "wide" not in p.describe(), p.describe()
+
+
+def test_wide_full_size_layer_properties(ctx, monkeypatch):
+    """Candy's residual-block layer at its benchmark size (16 x 183 x 323 x 128 -> 128): translation equivariance against the oracle on crops
+    (corner + interior), batch-index property, agreement with the 128-pixel kernel everywhere."""
+    import shadernn_amd as snn
+
+    N, H, W, C = 4, 183, 323, 128
+    x1 = _rand((1, H, W, C), 11)
+    x = np.repeat(x1, N, axis=0)
+    w = _rand((C, C, 3, 3), 12, 1.0 / np.sqrt(C * 9))
+    b = _rand((C,), 13, 0.1)
+    y, desc = _run(ctx, x, w, b, "constant", "relu", None)
+    assert "wide" in desc, desc
+    for i in range(1, N):
+        np.testing.assert_array_equal(y[i], y[0])
+    monkeypatch.setenv("SNNHIP_CONV", "mfma")
+    y2, desc2 = _run(ctx, x1, w, b, "constant", "relu", None)
+    np.testing.assert_allclose(y[:1], y2, err_msg=desc + " vs " + desc2, rtol=2e-3, atol=2e-3)
+    pads = O.padding_offsets("same", 3)
+    crop = O._h(O.conv2d(O._h(x1[:, :20, :40]), O._h(w), b, 1, pads, "constant", "relu", 0.0, None))
+    np.testing.assert_allclose(y[:1, :19, :39], crop[:, :19, :39], **TOLH)
+    crop = O._h(O.conv2d(O._h(x1[:, H - 20 :, W - 40 :]), O._h(w), b, 1, pads, "constant", "relu", 0.0, None))
+    np.testing.assert_allclose(y[:1, H - 19 :, W - 39 :], crop[:, 1:, 1:], **TOLH)
+    crop = O._h(O.conv2d(O._h(x1[:, 90:120, 150:200]), O._h(w), b, 1, pads, "constant", "relu", 0.0, None))
+    np.testing.assert_allclose(y[:1, 91:119, 151:199], crop[:, 1:-1, 1:-1], **TOLH)

@@ -18,10 +18,15 @@
 //     (act((x - mean) * mul + beta), fp32, rounded to half -- the rounding point of the separate normalise sweep), so the normalised tensor is
 //     never written: the norm runs its statistics sweep + fold only;
 //   * weights packed exactly as for conv2d_mfma_kernel ([chunk][tap][c8][h][OCp] x 8 halfs), streamed per lane with a 3-step ring;
-//   * epilogue: bias / BN / activation, the tile transposed through LDS and written as 16-byte channel-contiguous vectors, fused residual Add.
+//   * the weights are the MFMA's A operand, the pixels its B operand: a lane ends up with runs of 4 consecutive output channels of its own
+//     pixel and the epilogue (bias / BN / activation / fused residual Add) stores them directly, 8 bytes per lane, without an LDS transpose.
 #include "conv2d_mfma_kernel.h"
 
 #include <cstring>
+
+#ifndef SNNHIP_WIDE_ABL
+#define SNNHIP_WIDE_ABL 0 // ablation builds only (tools/ablate_wide.sh): 1 no weight refills, 2 no LDS operand reads, 4 no activation DMA, 8 no output stores
+#endif
 
 namespace snnhip {
 
@@ -35,6 +40,7 @@ struct WideParams {
     int tileH, tileW;    // staged halo tile
     int tilesX, tilesY;
     int nChunks, OCp, total, bufFloats;
+    int epiOfs;          // float offset in LDS of the block's epilogue-table rows
     int zeroOfs;         // float4 offset (from the packed weights) of a block of zeros: source of the padding pixels' DMA
     int preMode, preX, preY, srcH, srcW, preShift;
     unsigned magicW;
@@ -47,7 +53,17 @@ struct WideParams {
     ActCfg normAc;
 };
 
-template <int WM, int WN, int NT, int C8, int R, bool SIMPLE, bool NORM>
+// resolve_coord (epilogue.h) without its switch: the prologue resolves 2 x 2 coordinates for each of R staging elements, and the taken
+// branches (the mode is uniform, but s_cbranch still drains the pipeline) were a visible part of a block's start-up
+__device__ __forceinline__ int resolve_nobranch(int s, int size, int mode) {
+    const int cl = min(max(s, 0), size - 1);
+    int rf = s < 0 ? -s : s;
+    rf = rf >= size ? 2 * size - 2 - rf : rf;
+    const int t = mode == SNNHIP_PAD_REPLICATE ? cl : (mode == SNNHIP_PAD_REFLECT ? rf : s);
+    return (t >= 0 && t < size) ? t : -1;
+}
+
+template <int WM, int WN, int NT, int C8, int R, bool SIMPLE, bool RES>
 __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
                                                           const float4* __restrict__ epi, _Float16* __restrict__ y) {
     static_assert(WM * WN == 4, "4 waves per block");
@@ -88,13 +104,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
             const int ql = e - pix * QP;
             const int rr = static_cast<int>(__umulhi(static_cast<unsigned>(pix), p.magicW));
             const int c = pix - rr * p.tileW;
-            int sy = resolve_coord(iy0 + rr, p.H, p.padMode);
-            int sx = resolve_coord(ix0 + c, p.W, p.padMode);
-            if (p.preMode && sy >= 0 && sx >= 0) {
-                sy = resolve_coord(sy - p.preY, p.srcH << p.preShift, p.preMode);
-                sx = resolve_coord(sx - p.preX, p.srcW << p.preShift, p.preMode);
-                if (sy >= 0) sy >>= p.preShift;
-                if (sx >= 0) sx >>= p.preShift;
+            int sy = resolve_nobranch(iy0 + rr, p.H, p.padMode);
+            int sx = resolve_nobranch(ix0 + c, p.W, p.padMode);
+            if (p.preMode) { // a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied (-1 stays -1: size <= 2^30)
+                const int py = resolve_nobranch(sy - p.preY, p.srcH << p.preShift, p.preMode), px = resolve_nobranch(sx - p.preX, p.srcW << p.preShift, p.preMode);
+                sy = sy < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
+                sx = sx < 0 ? -1 : (px < 0 ? -1 : px >> p.preShift);
             }
             if (sy >= 0 && sx >= 0 && ql < Q) gofs[r] = ((n * p.srcH + sy) * p.srcW + sx) * p.IC + ql * 8;
         }
@@ -132,6 +147,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         bptr += bstep;
     }
 
+    float* const epiTab = smem + p.epiOfs; // (behind the staging buffers AND the epilogue's output tile) this block's BN rows of the epilogue table {bias, bnScale, bnMean, bnBeta}
+    if (tid < BN) reinterpret_cast<float4*>(epiTab)[tid] = epi[blockIdx.y * BN + tid];
     stage_dma(smem, 0);
     lds_dma_wait();
     __syncthreads();
@@ -140,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     for (int chunk = 0; chunk < p.nChunks; ++chunk) {
         const float* cur = smem + (chunk & 1) * p.bufFloats;
         const bool more = chunk + 1 < p.nChunks;
-        if (more) stage_dma(smem + ((chunk + 1) & 1) * p.bufFloats, (chunk + 1) * 16 * C8);
+        if (more && !(SNNHIP_WIDE_ABL & 4)) stage_dma(smem + ((chunk + 1) & 1) * p.bufFloats, (chunk + 1) * 16 * C8);
 #pragma unroll
         for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4*>(cur + aoff[t]);
 #pragma unroll
@@ -148,9 +165,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
             float4 b[NT];
 #pragma unroll
             for (int u = 0; u < NT; ++u) b[u] = bq[s % D][u];
+            if (!(SNNHIP_WIDE_ABL & 1)) {
 #pragma unroll
-            for (int u = 0; u < NT; ++u) bq[s % D][u] = bptr[u * 32];
-            bptr += bstep;
+                for (int u = 0; u < NT; ++u) bq[s % D][u] = bptr[u * 32];
+                bptr += bstep;
+            }
             __builtin_amdgcn_sched_barrier(0); // the refill stays D steps ahead of its use
             const int tap = (s + 1) / C8;
             const int dl = (((tap / 3) * kTileW + (tap % 3)) * QP + ((s + 1) % C8) * 2) * 4; // compile-time: an immediate offset of the ds_read
@@ -159,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
             for (int t = 0; t < MT; ++t) {
 #pragma unroll
                 for (int u = 0; u < NT; ++u)
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a[t]), *reinterpret_cast<const h8*>(&b[u]), acc[t][u], 0, 0, 0);
-                if (s + 1 < S) a[t] = *reinterpret_cast<const float4*>(cur + aoff[t] + dl);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b[u]), *reinterpret_cast<const h8*>(&a[t]), acc[t][u], 0, 0, 0);
+                if (s + 1 < S && !(SNNHIP_WIDE_ABL & 2)) a[t] = *reinterpret_cast<const float4*>(cur + aoff[t] + dl);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -170,49 +189,67 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         __syncthreads();
     }
 
-    // ---- epilogue: bias -> BN -> activation into the LDS tile [pixel][BN halfs] (pitch BN + 8: the two half-waves hit disjoint banks), then
-    // 16-byte channel-contiguous stores (+ the fused residual Add, same rounding points as the separate launches)
-    constexpr int EPITCH = BN + 8;
+    // ---- epilogue.  The MFMAs ran with the WEIGHTS as the A operand (M = output channels) and the pixels as B (N = 32 pixels of a tile row), so
+    // a lane holds, for ITS pixel, runs of four consecutive output channels: acc[t][u][4g + k] = channel n0 + 32u + 8g + 4h + k of pixel
+    // (row wm*MT + t, column l32).  bias -> BN -> activation, each run goes to the LDS tile [pixel][BN halfs] as ONE ds_write_b64 (with the
+    // pixels in the accumulator rows it took 128 ds_write_b16 per wave and the epilogue ran as long as the block's MFMAs); the tile then leaves
+    // as 16-byte vectors, a pixel's BN channels contiguous (whole 128-byte lines -- storing the 8-byte runs directly was measured 10 % slower
+    // than this round trip: 32 partial lines per store instruction).  Fused residual Add on the way out, same rounding points as the separate
+    // launches; its loads are all issued before the first store (gfx9 counts loads and stores in one vmcnt and retires them out of order with
+    // respect to each other: a load behind a store can only be waited for with vmcnt(0), the full write round trip).
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    constexpr int EPITCH = BN + 8; // halfs per pixel row of the LDS tile: 8-byte runs of 16 consecutive pixels land in distinct banks
     _Float16* const otile = reinterpret_cast<_Float16*>(smem);
+    const float4* const etab = reinterpret_cast<const float4*>(epiTab) + wn * (NT * 32) + 4 * h;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const int ibase = (wm * MT + t) * 32 + 4 * h;
+    for (int u = 0; u < NT; ++u)
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const float4 e = epi[n0 + u * 32 + l32]; // table padded to OCp
+        for (int g = 0; g < 4; ++g) {
+            float4 e[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int k = 0; k < 4; ++k) e[k] = etab[u * 32 + 8 * g + k];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                h4 o;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float v = epi_affine(acc[t][u][4 * g + k], e, p.useBN);
+                    float v = epi_affine(acc[t][u][4 * g + k], e[k], p.useBN);
                     v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
-                    otile[(ibase + 8 * g + k) * EPITCH + wn * (NT * 32) + u * 32 + l32] = static_cast<_Float16>(v);
+                    o[k] = static_cast<_Float16>(v);
                 }
+                *reinterpret_cast<h4*>(otile + ((wm * MT + t) * 32 + l32) * EPITCH + wn * (NT * 32) + u * 32 + 8 * g + 4 * h) = o;
+            }
         }
-    }
-    __syncthreads();
-    constexpr int VPR = BN / 8; // 16-byte vectors per pixel of the tile
-    const bool addSimple = act_is_simple_dev(p.ac2.act);
-#pragma unroll 4
-    for (int j = 0; j < PIX * VPR / 256; ++j) {
+    constexpr int VPR = BN / 8;             // 16-byte vectors per pixel of the tile
+    constexpr int NV = PIX * VPR / 256;     // ... per thread
+    int oofs[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
         const int v = tid + 256 * j;
         const int i = v / VPR, c8 = v - i * VPR;
         const int oy = oy0 + (i >> 5), ox = ox0 + (i & 31);
-        const int oc = blockIdx.y * BN + c8 * 8;
-        if (oy < p.OH && ox < p.OW && oc < p.OC) {
-            const size_t o = (static_cast<size_t>(n * p.OH + oy) * p.OW + ox) * p.OC + oc;
-            float4 pack = *reinterpret_cast<const float4*>(otile + i * EPITCH + c8 * 8);
-            if (p.res) {
-                const float4 rpack = *reinterpret_cast<const float4*>(static_cast<const _Float16*>(p.res) + o);
-                const _Float16* ch = reinterpret_cast<const _Float16*>(&pack);
-                const _Float16* rh = reinterpret_cast<const _Float16*>(&rpack);
-                _Float16 oh[8];
+        oofs[j] = (oy < p.OH && ox < p.OW) ? ((n * p.OH + oy) * p.OW + ox) * p.OC + blockIdx.y * BN + c8 * 8 : -1;
+    }
+    float4 rpack[RES ? NV : 1];
+    if (RES) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) oh[e] = static_cast<_Float16>(add_act(p.ac2, addSimple, static_cast<float>(ch[e]) + static_cast<float>(rh[e])));
-                pack = *reinterpret_cast<const float4*>(oh);
-            }
-            *reinterpret_cast<float4*>(y + o) = pack;
+        for (int j = 0; j < NV; ++j) rpack[j] = oofs[j] >= 0 ? *reinterpret_cast<const float4*>(static_cast<const _Float16*>(p.res) + oofs[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int v = tid + 256 * j;
+        const int i = v / VPR, c8 = v - i * VPR;
+        float4 pack = *reinterpret_cast<const float4*>(otile + i * EPITCH + c8 * 8);
+        if (RES) {
+            const _Float16* ch = reinterpret_cast<const _Float16*>(&pack);
+            const _Float16* rh = reinterpret_cast<const _Float16*>(&rpack[RES ? j : 0]);
+            _Float16 oh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oh[e] = static_cast<_Float16>(add_act(p.ac2, true, static_cast<float>(ch[e]) + static_cast<float>(rh[e])));
+            pack = *reinterpret_cast<const float4*>(oh);
         }
+        if (oofs[j] >= 0 && !((SNNHIP_WIDE_ABL & 8) && p.OC != 12345)) *reinterpret_cast<float4*>(y + oofs[j]) = pack;
     }
 }
 
@@ -225,7 +262,7 @@ struct WideConvPlan : ConvPlanBase {
     float* d_epi = nullptr;
     size_t ldsBytes = 0;
     dim3 grid;
-    WideFn kernel = nullptr, kernelNorm = nullptr;
+    WideFn kernel = nullptr;
     bool fusedAdd = false;
 
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
@@ -252,8 +289,8 @@ struct WideConvPlan : ConvPlanBase {
 };
 
 template <int WM, int WN, int NT, int C8, int R>
-WideFn pick_wide(bool simple, bool norm) {
-    if (norm) return nullptr; // (pre-normalising variant: see below)
+WideFn pick_wide(bool simple, bool res) {
+    if (res) return simple ? conv2d_wide_kernel<WM, WN, NT, C8, R, true, true> : conv2d_wide_kernel<WM, WN, NT, C8, R, false, true>;
     return simple ? conv2d_wide_kernel<WM, WN, NT, C8, R, true, false> : conv2d_wide_kernel<WM, WN, NT, C8, R, false, false>;
 }
 
@@ -307,14 +344,17 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.normAc = make_act_cfg(SNNHIP_ACT_NONE, 0.0f);
 
     const bool simple = act_is_simple(g.act);
-    WideFn fn = nullptr, fnNorm = nullptr;
-    if (WM == 2 && C8 == 2 && R <= 7) { fn = pick_wide<2, 2, 2, 2, 7>(simple, false); fnNorm = pick_wide<2, 2, 2, 2, 7>(simple, true); }
-    if (WM == 2 && C8 == 1 && R <= 4) { fn = pick_wide<2, 2, 2, 1, 4>(simple, false); fnNorm = pick_wide<2, 2, 2, 1, 4>(simple, true); }
-    if (WM == 4 && NT == 2 && R <= 8) { fn = pick_wide<4, 1, 2, 1, 8>(simple, false); fnNorm = pick_wide<4, 1, 2, 1, 8>(simple, true); }
-    if (WM == 4 && NT == 1 && R <= 8) { fn = pick_wide<4, 1, 1, 1, 8>(simple, false); fnNorm = pick_wide<4, 1, 1, 1, 8>(simple, true); }
+    const bool withRes = g.addAct >= 0;
+    if (withRes && !act_is_simple(g.addAct)) return SNNHIP_E_UNSUPPORTED; // (no graph of the zoo has one)
+    WideFn fn = nullptr;
+    if (WM == 2 && C8 == 2 && R <= 7) fn = pick_wide<2, 2, 2, 2, 7>(simple, withRes);
+    if (WM == 2 && C8 == 1 && R <= 4) fn = pick_wide<2, 2, 2, 1, 4>(simple, withRes);
+    if (WM == 4 && NT == 2 && R <= 8) fn = pick_wide<4, 1, 2, 1, 8>(simple, withRes);
+    if (WM == 4 && NT == 1 && R <= 8) fn = pick_wide<4, 1, 1, 1, 8>(simple, withRes);
     if (!fn) return SNNHIP_E_UNSUPPORTED;
     const int PIX = 128 * WM;
-    size_t lds = std::max(static_cast<size_t>(2) * p.bufFloats * 4 + static_cast<size_t>(3) * g.IC * 4, static_cast<size_t>(PIX) * (BN + 8) * 2);
+    p.epiOfs = static_cast<int>(std::max(static_cast<size_t>(2) * p.bufFloats * 4, static_cast<size_t>(PIX) * (BN + 8) * 2) / 4);
+    const size_t lds = static_cast<size_t>(p.epiOfs) * 4 + static_cast<size_t>(BN) * 16;
     if (lds > 80 * 1024) return SNNHIP_E_UNSUPPORTED;
 
     auto* plan = new WideConvPlan();
@@ -325,17 +365,15 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->p = p;
     plan->ac = make_act_cfg(g.act, g.leaky);
     plan->kernel = fn;
-    plan->kernelNorm = fnNorm;
     plan->ldsBytes = lds;
     plan->fusedAdd = g.addAct >= 0;
     if (plan->fusedAdd) plan->numInputs = 2;
     plan->grid = dim3(static_cast<unsigned>(tiles), g.OC / BN, 1);
-    for (WideFn f : {fn, fnNorm})
-        if (f && lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
-            set_error("conv2d_wide: hipFuncSetAttribute(%zu) failed", lds);
-            delete plan;
-            return SNNHIP_E_HIP;
-        }
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+        set_error("conv2d_wide: hipFuncSetAttribute(%zu) failed", lds);
+        delete plan;
+        return SNNHIP_E_HIP;
+    }
 
     // weights: Wp[chunk][tap][c8][h][OC] x 8 halfs, ic = chunk*16*C8 + (c8*2 + h)*8 + j  (+ D zero steps for the ring's read-ahead)
     const size_t steps = static_cast<size_t>(p.nChunks) * 9 * C8;

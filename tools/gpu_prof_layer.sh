@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 TAG=$1; PAT=$2
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
-export PROF_CMD="python $GRAFT_REPO_ROOT/tools/bench_layers.py --only $PAT --reps 20"
+export PROF_CMD="python $GRAFT_REPO_ROOT/tools/bench_layers.py --only $PAT --reps ${REPS:-20}"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $PROF_CMD > $O/trace.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $O/pmc_sq --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY -- $PROF_CMD > $O/pmc_sq.log 2>&1

@@ -436,6 +436,11 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
             if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
         }
     }
+    // the fp16 RGB stem of the style graphs (9x9, stride 1, IC <= 4): conv2d_stem_f16.hip
+    {
+        const int rc = make_conv2d_stem_plan(ctx, g, w_oihw, epi4, out);
+        if (rc != SNNHIP_E_UNSUPPORTED) return rc;
+    }
     // fp16 3x3 stride-1 layers on large maps: the 4 x 2 register-block kernel of conv2d_wide_f16.hip (SNNHIP_CONV=wide forces it for every
     // eligible shape, SNNHIP_CONV=mfma / SNNHIP_CONV_WIDE=0 keep the 128-pixel kernel)
     {

@@ -1,0 +1,287 @@
+// conv2d_stem_f16.hip -- fp16 9x9 stride-1 convolution of a channel-thin image (IC <= 4: the RGB stem of the style-transfer graphs, 3 -> 32) on
+// v_mfma_f32_32x32x16_f16.
+//
+// conv2d_mfma_kernel's tap-pair mode spends one 16-channel K step on two taps of a 3-channel pixel (3 of 8 operand halfs carry data), reads one
+// LDS operand per MFMA and walks the taps with a rolled loop: 1.48 ms for 16 x 818 x 1378 x 32 outputs (157 TF/s) where the output alone is
+// 1.15 GB (~0.3 ms of HBM) -- and 0.55 ms with every memory operation ablated, i.e. bound by instruction issue.  This kernel instead
+//   * keeps a pixel as FOUR halfs (RGB0, 8 bytes) in LDS, so one K step = 4 horizontally adjacent taps x 4 channels: a lane half supplies two
+//     adjacent pixels = 16 contiguous bytes.  A 9-tap kernel row = 2 full steps + 1 left-over tap; the left-over taps of 4 kernel rows share a
+//     step (rows 0-3, 4-7, 8): 21 K steps per output instead of 41, 96 % of the operand slots carry a tap;
+//   * holds ALL weights of a 32-channel output block in registers (21 x 16 bytes per lane, the MFMA's A operand), loaded once per wave;
+//   * gives a wave 8 output rows x 32 columns (8 accumulator tiles): the operand of input row r and tap group j is read from LDS ONCE and
+//     feeds the MFMAs of every output row y with 0 <= r - y <= 8 -- 0.3 LDS operand reads per MFMA instead of 1;
+//   * is straight-line code: 168 MFMAs per wave, no loop, no address arithmetic beyond immediate offsets;
+//   * writes each output row through a wave-private LDS scratch (8-byte runs in, 32 contiguous bytes per lane out): a wave stores 2 KB
+//     contiguous per row.
+// The fused Pad in front (ConvGeom::preMode, reflect in the style graphs) resolves in the staging loop.  Bias / BN / activation as everywhere.
+#include "epilogue.h"
+#include "snnhip_internal.h"
+
+#include <cstring>
+
+namespace snnhip {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+struct StemParams {
+    int N, H, W, IC, OC, padx, pady, padMode, useBN, OH, OW;
+    int tilesX, tilesY;
+    int preMode, preX, preY, srcH, srcW;
+};
+
+constexpr int kK = 9;                 // kernel extent
+constexpr int kNR = 4;                // output rows per wave
+constexpr int kTH = 4 * kNR, kTW = 32; // block tile: 4 waves stacked in y
+constexpr int kInH = kTH + kK - 1, kInW = kTW + kK - 1; // staged halo tile
+constexpr int kSteps = 2 * kK + 3;    // 18 full steps + 3 left-over steps
+constexpr int kOutPitch = 40;         // halfs per pixel row of the wave's output scratch (80 bytes: 16-byte aligned rows, the 8-byte runs of 16 lanes on distinct banks)
+
+__device__ __forceinline__ int resolve_nb(int s, int size, int mode) {
+    const int cl = min(max(s, 0), size - 1);
+    int rf = s < 0 ? -s : s;
+    rf = rf >= size ? 2 * size - 2 - rf : rf;
+    const int t = mode == SNNHIP_PAD_REPLICATE ? cl : (mode == SNNHIP_PAD_REFLECT ? rf : s);
+    return (t >= 0 && t < size) ? t : -1;
+}
+
+template <bool SIMPLE>
+__global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
+                                                          const float4* __restrict__ epi, _Float16* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) _Float16 tile[kInH * kInW * 4];
+    __shared__ __attribute__((aligned(16))) _Float16 oscr[4][32 * kOutPitch];
+    __shared__ float4 etab[32]; // this block's rows of the epilogue table {bias, bnScale, bnMean, bnBeta}
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, h = lane >> 5;
+
+    // ---- weights of this block's 32 output channels: 21 x 16 bytes per lane, in registers for the life of the wave -- the block is persistent
+    // (grid = the resident block count) and walks the pixel tiles with stride gridDim.x, so the 21 KB per wave are fetched once per kernel, not
+    // once per 32 KB of output
+    float4 wa[kSteps];
+    {
+        const float4* wsrc = wp + static_cast<size_t>(blockIdx.y) * kSteps * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) wa[s] = wsrc[s * 64];
+    }
+    if (tid < 32) etab[tid] = epi[blockIdx.y * 32 + tid];
+
+    // staging: pixel -> 4 halfs (channels past IC are 0).  The loads of tile i+1 are issued before the MFMAs of tile i and written to LDS after
+    // them: no global-load latency on the critical path (a rolled load-store loop waited out 7 round trips per tile)
+    constexpr int kR = (kInH * kInW + 255) / 256;
+    _Float16 sv[kR][4];
+    auto stage_load = [&](int mt) {
+        const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, n = mt / (p.tilesX * p.tilesY);
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int e = tid + 256 * r;
+            const int rr = e / kInW, c = e - rr * kInW;
+            int sy = resolve_nb(ty * kTH - p.pady + rr, p.H, p.padMode);
+            int sx = resolve_nb(tx * kTW - p.padx + c, p.W, p.padMode);
+            if (p.preMode) {
+                const int py = resolve_nb(sy - p.preY, p.srcH, p.preMode), px = resolve_nb(sx - p.preX, p.srcW, p.preMode);
+                sy = sy < 0 ? -1 : py;
+                sx = sx < 0 ? -1 : px;
+            }
+            const bool ok = e < kInH * kInW && sy >= 0 && sx >= 0;
+            const _Float16* src = x + (static_cast<size_t>(n * p.srcH + (ok ? sy : 0)) * p.srcW + (ok ? sx : 0)) * p.IC;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[r][k] = (ok && k < p.IC) ? src[k] : static_cast<_Float16>(0.0f);
+        }
+    };
+    const int total = p.tilesX * p.tilesY * p.N;
+    int mt = blockIdx.x;
+    stage_load(mt);
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int e = tid + 256 * r;
+            if (e < kInH * kInW) *reinterpret_cast<h4*>(tile + e * 4) = h4{sv[r][0], sv[r][1], sv[r][2], sv[r][3]};
+        }
+        __syncthreads();
+        const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, n = mt / (p.tilesX * p.tilesY);
+        const int ox0 = tx * kTW, oy0 = ty * kTH;
+        const int next = mt + gridDim.x;
+        if (next < total) stage_load(next);
+
+        f32x16 acc[kNR];
+#pragma unroll
+        for (int i = 0; i < kNR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+        // operand base of this lane: pixel (row wave*kNR, column l32 + 2h) of the tile, in halfs
+        const _Float16* const tb = tile + ((wave * kNR) * kInW + l32 + 2 * h) * 4;
+        // ---- full steps: input row r (relative to the wave's first output row), tap group j = columns 4j .. 4j+3
+#pragma unroll
+        for (int r = 0; r < kNR + kK - 1; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // 16 contiguous bytes, 8-byte aligned: two ds_read_b64
+                const h4 lo = *reinterpret_cast<const h4*>(tb + (r * kInW + 4 * j) * 4);
+                const h4 hi = *reinterpret_cast<const h4*>(tb + (r * kInW + 4 * j + 1) * 4);
+                const h8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int yy = 0; yy < kNR; ++yy) {
+                    const int ky = r - yy;
+                    if (ky < 0 || ky >= kK) continue;
+                    acc[yy] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&wa[ky * 2 + j]), b, acc[yy], 0, 0, 0);
+                }
+            }
+        // ---- left-over tap (column 8) of 4 kernel rows per step: lane half h supplies input rows r0 + 2h, r0 + 2h + 1
+        const _Float16* const tl = tile + ((wave * kNR + 2 * h) * kInW + l32 + 8) * 4;
+#pragma unroll
+        for (int r0 = 0; r0 < kNR + 4; ++r0) { // groups 0 (kernel rows 0-3) and 1 (rows 4-7): output rows y = r0 and y = r0 - 4
+            const h4 lo = *reinterpret_cast<const h4*>(tl + (r0 * kInW) * 4);
+            const h4 hi = *reinterpret_cast<const h4*>(tl + ((r0 + 1) * kInW) * 4);
+            const h8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            if (r0 < kNR) acc[r0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&wa[2 * kK + 0]), b, acc[r0], 0, 0, 0);
+            if (r0 >= 4 && r0 - 4 < kNR) acc[r0 - 4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&wa[2 * kK + 1]), b, acc[r0 - 4], 0, 0, 0);
+        }
+        // group 2 = kernel row 8 alone: only the first slot of lane half 0 carries a tap, the other three are zeros (weights AND operand: a
+        // non-finite pixel outside the receptive field must not reach the accumulator as inf * 0)
+#pragma unroll
+        for (int yy = 0; yy < kNR; ++yy) {
+            h4 lo = *reinterpret_cast<const h4*>(tile + ((wave * kNR + yy + 8) * kInW + l32 + 8) * 4);
+            const h4 z = {0, 0, 0, 0};
+            if (h) lo = z;
+            const h8 b = __builtin_shufflevector(lo, z, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[yy] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&wa[2 * kK + 2]), b, acc[yy], 0, 0, 0);
+        }
+
+        // ---- epilogue: acc[yy][4g + k] = channel 8g + 4h + k of pixel (row yy, column l32).  Per row: 8-byte runs -> wave scratch -> 16-byte
+        // pieces, lane L = piece L % 4 of pixel L / 4 (+ 16): each store instruction of the wave writes 1 KB contiguous (OC == 32: the row's
+        // pixels are adjacent in memory)
+        _Float16* const sc = oscr[wave];
+#pragma unroll
+        for (int yy = 0; yy < kNR; ++yy) {
+            const int oy = oy0 + wave * kNR + yy;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = epi_affine(acc[yy][4 * g + k], etab[8 * g + 4 * h + k], p.useBN);
+                    v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+                    o[k] = static_cast<_Float16>(v);
+                }
+                *reinterpret_cast<h4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = o;
+            }
+            // (wave-private scratch: the LDS queue of a wave is in order, no barrier)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int opix = 16 * i + (lane >> 2), piece = lane & 3;
+                const float4 v = *reinterpret_cast<const float4*>(sc + opix * kOutPitch + 8 * piece);
+                const int ox = ox0 + opix;
+                if (oy < p.OH && ox < p.OW) *reinterpret_cast<float4*>(y + (static_cast<size_t>(n * p.OH + oy) * p.OW + ox) * p.OC + blockIdx.y * 32 + 8 * piece) = v;
+            }
+        }
+        if (next >= total) break;
+        mt = next;
+        __syncthreads(); // every wave is done with the tile before the next one is written
+    }
+}
+
+struct StemConvPlan : ConvPlanBase {
+    StemParams p;
+    ActCfg ac;
+    float* d_w = nullptr;
+    float* d_epi = nullptr;
+    dim3 grid;
+    bool simple = true;
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == p.IC && x->dtype == SNNHIP_F16,
+                       "conv2d: input dims %dx%dx%dx%d (dtype %d) != plan %dx%dx%dx%d fp16", x->n, x->h, x->w, x->c, x->dtype, p.N, p.srcH, p.srcW, p.IC);
+        SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC && out->dtype == SNNHIP_F16,
+                       "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
+        if (simple)
+            hipLaunchKernelGGL(conv2d_stem_kernel<true>, grid, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data),
+                               reinterpret_cast<const float4*>(d_w), reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
+        else
+            hipLaunchKernelGGL(conv2d_stem_kernel<false>, grid, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data),
+                               reinterpret_cast<const float4*>(d_w), reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+} // namespace
+
+// fp16, 9x9, stride 1, IC <= 4, OC % 32 == 0, no fused upsampling / residual; SNNHIP_CONV=stem forces nothing more (the shape rule is the
+// kernel's contract), SNNHIP_CONV_STEM=0 leaves the layer to conv2d_mfma's tap-pair mode
+int make_conv2d_stem_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
+    if (g.dtype != SNNHIP_F16 || g.kh != kK || g.kw != kK || g.sh != 1 || g.sw != 1 || g.IC > 4 || g.OC % 32 != 0) return SNNHIP_E_UNSUPPORTED;
+    if (g.addAct >= 0 || (g.preMode && g.preShift) || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED;
+    if (const char* e = getenv("SNNHIP_CONV_STEM"))
+        if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
+    if (const char* f = getenv("SNNHIP_CONV"))
+        if (strcmp(f, "stem") != 0) return SNNHIP_E_UNSUPPORTED; // another kernel is being forced
+    const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
+    if (outCount >= 2147483647.0 * 4) return SNNHIP_E_UNSUPPORTED;
+
+    StemParams p{};
+    p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.padx = g.padx; p.pady = g.pady; p.padMode = g.padMode; p.useBN = g.useBN;
+    p.OH = g.OH; p.OW = g.OW;
+    p.tilesX = up_div(g.OW, kTW); p.tilesY = up_div(g.OH, kTH);
+    p.preMode = g.preMode; p.preX = g.preX; p.preY = g.preY;
+    p.srcH = g.preMode ? g.srcH : g.H;
+    p.srcW = g.preMode ? g.srcW : g.W;
+
+    auto* plan = new StemConvPlan();
+    plan->ctx = ctx;
+    plan->g = g;
+    plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC * kK * kK);
+    plan->epi4 = epi4;
+    plan->p = p;
+    plan->ac = make_act_cfg(g.act, g.leaky);
+    plan->simple = act_is_simple(g.act);
+    {
+        const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+        const long tiles = static_cast<long>(p.tilesX) * p.tilesY * g.N;
+        plan->grid = dim3(static_cast<unsigned>(std::min<long>(tiles, 2L * cus)), g.OC / 32, 1); // persistent: two blocks per CU
+    }
+
+    // weights: Wp[oc block][step][lane = 32 hh + o] x 8 halfs.  Full step s = 2 ky + j: lane half hh holds taps (ky, 4j + 2hh) and (ky, 4j + 2hh + 1),
+    // 4 channels each.  Left-over step 18 + q: taps (4q + 2hh, 8) and (4q + 2hh + 1, 8); kernel rows past 8 are zeros.
+    const int ocb = g.OC / 32;
+    std::vector<float> wpk(static_cast<size_t>(ocb) * kSteps * 64 * 4, 0.0f);
+    _Float16* wph = reinterpret_cast<_Float16*>(wpk.data());
+    auto wv = [&](int o, int ic, int ky, int kx) { return w_oihw[((static_cast<size_t>(o) * g.IC + ic) * kK + ky) * kK + kx]; };
+    for (int b = 0; b < ocb; ++b)
+        for (int s = 0; s < kSteps; ++s)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int o = 0; o < 32; ++o)
+                    for (int slot = 0; slot < 2; ++slot) {
+                        int ky, kx;
+                        if (s < 2 * kK) { ky = s / 2; kx = 4 * (s % 2) + 2 * hh + slot; }
+                        else { ky = 4 * (s - 2 * kK) + 2 * hh + slot; kx = 8; }
+                        if (ky >= kK) continue;
+                        for (int ic = 0; ic < g.IC; ++ic)
+                            wph[((static_cast<size_t>(b) * kSteps + s) * 64 + 32 * hh + o) * 8 + slot * 4 + ic] = static_cast<_Float16>(wv(b * 32 + o, ic, ky, kx));
+                    }
+    int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
+    if (rc == SNNHIP_OK) rc = plan->upload(epi4.data(), epi4.size(), &plan->d_epi);
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    plan->inDims[0] = g.N; plan->inDims[1] = p.srcH; plan->inDims[2] = p.srcW; plan->inDims[3] = g.IC;
+    plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
+    plan->dtype = SNNHIP_F16;
+    plan->flops = 2.0 * kK * kK * g.IC * g.OC * static_cast<double>(g.OH) * g.OW * g.N;
+    plan->bytes = 2.0 * (static_cast<double>(g.N) * p.srcH * p.srcW * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * kK * kK);
+    char buf[256];
+    snprintf(buf, sizeof(buf), "conv2d_mfma_stem_f16_32x32x16 k=9x9 s=1 ic=%d oc=%d tile=%dx%dpx x 32oc (4 taps x 4 channels per K step, 21 steps, weights in registers)", g.IC,
+             g.OC, kTH, kTW);
+    plan->desc = buf;
+    if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip

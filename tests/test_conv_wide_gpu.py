@@ -138,3 +138,65 @@ def test_wide_full_size_layer_properties(ctx, monkeypatch):
     np.testing.assert_allclose(y[:1, H - 19 :, W - 39 :], crop[:, 1:, 1:], **TOLH)
     crop = O._h(O.conv2d(O._h(x1[:, 90:120, 150:200]), O._h(w), b, 1, pads, "constant", "relu", 0.0, None))
     np.testing.assert_allclose(y[:1, 91:119, 151:199], crop[:, 1:-1, 1:-1], **TOLH)
+
+
+# ---- conv2d_stem_f16.hip: the fp16 9x9 RGB stem (IC <= 4, 4 taps x 4 channels per K step, weights in registers)
+STEM = [(1, 40, 50, 3, 32), (2, 33, 31, 3, 32), (1, 9, 70, 1, 32), (1, 64, 64, 4, 64), (3, 5, 7, 3, 32), (1, 100, 37, 2, 96)]
+
+
+@pytest.mark.parametrize("shape", STEM, ids=lambda c: "x".join(map(str, c)))
+def test_stem_matches_quantised_oracle_and_tap_pair_kernel(ctx, monkeypatch, shape):
+    N, H, W, IC, OC = shape
+    x = _rand((N, H, W, IC), 31)
+    w = _rand((OC, IC, 9, 9), 32, 1.0 / np.sqrt(IC * 81))
+    b = _rand((OC,), 33, 0.1)
+    bn = _bn(OC, 34)
+    pads = O.padding_offsets("same", 9)
+
+    def run(pad_mode, act, bnp):
+        import shadernn_amd as snn
+
+        plan = snn.conv2d_plan(ctx, N, H, W, w, b, stride=1, pads=pads, pad_mode=pad_mode, act=act, bn=bnp, dtype=snn.F16)
+        y, d = plan(snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)).numpy(), plan.describe()
+        plan.destroy()
+        return y, d
+
+    for pad_mode, act, use_bn in (("constant", "relu", False), ("reflect", "tanh", True), ("replicate", "", False)):
+        if pad_mode == "reflect" and min(H, W) < 5:
+            continue  # a reflection needs the image to be wider than the border
+        monkeypatch.delenv("SNNHIP_CONV_STEM", raising=False)
+        y, desc = run(pad_mode, act, bn if use_bn else None)
+        assert "conv2d_mfma_stem_f16" in desc, desc
+        want = O._h(O.conv2d(O._h(x), O._h(w), b, 1, pads, pad_mode, act, 0.0, bn if use_bn else None))
+        np.testing.assert_allclose(y, want, err_msg=desc, **TOLH)
+        monkeypatch.setenv("SNNHIP_CONV_STEM", "0")
+        y2, desc2 = run(pad_mode, act, bn if use_bn else None)
+        assert "stem" not in desc2, desc2
+        np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-3, atol=2e-3)
+
+
+def test_stem_with_fused_reflect_pad_and_non_finite_neighbours(ctx):
+    """Candy's first layers: reflect Pad(4) -> 9x9 'valid' convolution as one launch (chain rule D).  An inf pixel reaches exactly the outputs whose
+    receptive field holds it (the zero-weight operand slots of the kernel's last K step must not turn it into NaN elsewhere)."""
+    import shadernn_amd as snn
+
+    n, h, w_, ic, oc = 1, 45, 52, 3, 32
+    x, wt, b = _rand((n, h, w_, ic), 1), _rand((oc, ic, 9, 9), 2, 1.0 / np.sqrt(ic * 81)), _rand((oc,), 3, 0.2)
+    pad = snn.pad_plan(ctx, n, h, w_, ic, (4, 4, 4, 4), "reflect")
+    conv = snn.conv2d_plan(ctx, n, h + 8, w_ + 8, wt, b, stride=1, pads=(0, 0, 0, 0), act="relu", dtype=snn.F16)
+    chain = snn.chain_plan(ctx, [pad, conv])
+    assert chain.num_steps() == 1 and "stem" in chain.describe() and "+pad(reflect)" in chain.describe(), chain.describe()
+    y = chain(snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)).numpy()
+    want = O._h(O.conv2d(O.pad(O._h(x), (4, 4, 4, 4), "reflect"), O._h(wt), b, 1, (0, 0, 0, 0), "constant", "relu", 0.0, None))
+    assert y.shape == want.shape
+    np.testing.assert_allclose(y, want, err_msg=chain.describe(), **TOLH)
+    xi = x.copy()
+    xi[0, 20, 30, 1] = np.inf
+    wpos = np.abs(wt) + 0.01  # every tap weight non-zero and positive: inf stays +inf inside the field
+    conv2 = snn.conv2d_plan(ctx, n, h, w_, wpos, b, stride=1, pads=O.padding_offsets("same", 9), act="", dtype=snn.F16)
+    assert "stem" in conv2.describe()
+    yi = conv2(snn.Tensor.from_numpy(ctx, xi, dtype=snn.F16)).numpy()
+    bad = ~np.isfinite(yi[0, :, :, 0])
+    field = np.zeros_like(bad)
+    field[20 - 4 : 20 + 5, 30 - 4 : 30 + 5] = True
+    assert (bad == field).all() and not np.isnan(yi).any()

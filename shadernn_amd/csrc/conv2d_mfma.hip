@@ -162,6 +162,10 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED; // 32-bit element offsets in the kernel
 
+    // graph rule I (InstanceNorm applied in the staging): the fp16 kernels with whole 8-channel slots, one image per pixel tile
+    const bool preNorm = g.normMean != nullptr;
+    if (preNorm && (!f16 || g.IC % 8 != 0 || !act_is_simple(g.normAct))) return SNNHIP_E_UNSUPPORTED;
+
     const int taps = g.kh * g.kw;
     // channels per LDS chunk: 16 (8 when IC <= 8).  Wider chunks (the kernel is instantiated up to 64 channels; SNNHIP_CONV_C8=4|8 selects
     // them for pointwise stride-1 layers) were measured on the MobileNetV2 layers: fewer barriers per MFMA, but the 4x staging registers and
@@ -170,7 +174,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     int C8 = g.IC <= 2 * CH ? 1 : 2;
     // tap-pair mode (C8 = 0, see the kernel): channel-thin inputs with at least two taps; SNNHIP_CONV_PAIR=0 keeps the channel-chunk path
     const char* pairEnv = getenv("SNNHIP_CONV_PAIR");
-    if (g.IC <= CH && taps >= 2 && !(pairEnv && atoi(pairEnv) == 0)) C8 = 0;
+    if (g.IC <= CH && taps >= 2 && !(pairEnv && atoi(pairEnv) == 0) && !preNorm) C8 = 0;
     if (const char* e = getenv("SNNHIP_CONV_C8"))
         if (taps == 1 && g.sh == 1 && g.sw == 1 && (atoi(e) == 4 || atoi(e) == 8) && g.IC >= 2 * CH * atoi(e)) C8 = atoi(e);
     int Qs = C8 ? 2 * C8 : 1;                                    // 16-byte slots per staged pixel
@@ -206,6 +210,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
         const bool oneChunk = up_div(g.IC, ICc) == 1; // then the block stages once: no second buffer
         for (int s = 0; s < static_cast<int>(sizeof(shapes) / sizeof(shapes[0])); ++s) {
             const int TB = 1 << shapes[s][0], TH = 1 << shapes[s][1], TW = 1 << shapes[s][2];
+            if (preNorm && shapes[s][0] != 0) continue; // the statistics table in LDS is one image's
             const TileLayout L = layout(shapes[s][0], shapes[s][1], shapes[s][2]);
             const size_t lds = oneChunk ? L.ldsBytes / 2 : L.ldsBytes;
             if (L.total > (C8 ? 9 : 5) * 256 || lds > 150 * 1024) continue; // staging registers / LDS
@@ -314,6 +319,10 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     // fp16 output tile through LDS (see the kernel's epilogue): needs whole 8-channel vectors and the direct (non split-K) epilogue
     p.ldsEpi = (f16 && p.splitK == 1 && g.OC % 8 == 0 && !getenv("SNNHIP_CONV_DIRECT_STORE")) ? 1 : 0;
     size_t ldsNeed = p.chunksPerSplit == 1 ? L.ldsBytes / 2 : L.ldsBytes; // one chunk per block: no second staging buffer
+    p.normMean = g.normMean; p.normMul = g.normMul; p.normBeta = g.normBeta;
+    p.normAc = make_act_cfg(preNorm ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
+    p.normTabOfs = static_cast<int>(ldsNeed / 4);
+    if (preNorm) ldsNeed += static_cast<size_t>(3) * g.IC * sizeof(float); // [mean | mul | beta] behind the staging buffers
     if (p.ldsEpi) ldsNeed = std::max(ldsNeed, static_cast<size_t>(128) * (BN + 8) * 2);
     const bool simple = act_is_simple(g.act);
     KernelFn fn = nullptr;
@@ -414,6 +423,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
         plan->desc += " +add";
         plan->bytes += esz * static_cast<double>(g.N) * g.OH * g.OW * g.OC; // the residual is read once
     }
+    if (preNorm) plan->desc = "instancenorm(act=" + std::to_string(g.normAct) + ", in the staging) -> " + plan->desc;
     *out = plan;
     return SNNHIP_OK;
 }
@@ -430,7 +440,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         const char* force = getenv("SNNHIP_CONV");
         const char* w = getenv("SNNHIP_CONV_WINO");
         const bool forced = force && strcmp(force, "wino") == 0;
-        const bool allowed = !force && !(w && atoi(w) == 0) && !getenv("SNNHIP_CONV_BN") && !getenv("SNNHIP_CONV_C8") && g.IC >= 32 && g.OC >= 32;
+        const bool allowed = !force && !(w && atoi(w) == 0) && !getenv("SNNHIP_CONV_BN") && !getenv("SNNHIP_CONV_C8") && g.IC >= 32 && g.OC >= 32 && !g.normMean;
         if (forced || allowed) {
             const int rc = make_conv2d_wino_plan(ctx, g, w_oihw, epi4, out);
             if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;

@@ -44,6 +44,12 @@ struct MfmaParams { // (declared after ActCfg: epilogue.h)
     // per-tile output statistics for a following InstanceNorm (chain rule F; fp16 LDS epilogue, one image per pixel tile, no split-K):
     // statPart[((n*tilesY + ty)*tilesX + tx)][2][OC] = {mean, sum of squared deviations} of the tile's valid pixels, per channel
     float* statPart;
+    // InstanceNorm in front of the convolution (graph rule I; fp16 kernels, one image per pixel tile, IC % 8 == 0): applied to the staged values
+    const float* normMean;
+    const float* normMul;
+    const float* normBeta;
+    ActCfg normAc;
+    int normTabOfs; // float offset in LDS of [mean | mul | beta] x IC of the tile's image
 };
 
 // LDS layout of the staged activations.  A pixel owns ICc floats = ICc/4 16-byte slots; the slot is XOR-swizzled with
@@ -153,7 +159,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
             stage[r] = v;
         }
     };
-    auto stage_store = [&](float* buf) {
+    auto stage_store = [&](float* buf, int ic0) {
+        if constexpr (F16) {
+            if (p.normMean && ic0 + q * CH < p.IC) { // block-uniform switch; a thread's elements share their 8 channels
+                const float* tab = smem + p.normTabOfs + ic0 + q * CH;
+                float mean[8], mul[8], bt[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    mean[k] = tab[k];
+                    mul[k] = tab[p.IC + k];
+                    bt[k] = tab[2 * p.IC + k];
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (gofs[r] >= 0) { // zero padding stays zero: the border applies to the NORMALISED tensor
+                        h8 hv = *reinterpret_cast<const h8*>(&stage[r]);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float v = (static_cast<float>(hv[k]) - mean[k]) * mul[k] + bt[k];
+                            hv[k] = static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(v, v * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                        }
+                        stage[r] = *reinterpret_cast<const float4*>(&hv);
+                    }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (lofs[r] >= 0) *reinterpret_cast<float4*>(buf + lofs[r]) = stage[r];
@@ -228,7 +257,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
     }
 
     stage_load(chunk0 * 2 * CH * C8);
-    stage_store(smem); // buffer parity is relative to the split's first chunk: a single-chunk split needs one buffer only
+    if constexpr (F16) {
+        if (p.normMean) { // the norm's statistics of this tile's image (TB == 1) and its beta -> LDS
+            float* tab = smem + p.normTabOfs;
+            const int n = min(b0, p.N - 1);
+            for (int i = tid; i < p.IC; i += 256) {
+                tab[i] = p.normMean[static_cast<size_t>(n) * p.IC + i];
+                tab[p.IC + i] = p.normMul[static_cast<size_t>(n) * p.IC + i];
+                tab[2 * p.IC + i] = p.normBeta[i];
+            }
+            __syncthreads();
+        }
+    }
+    stage_store(smem, chunk0 * 2 * CH * C8); // buffer parity is relative to the split's first chunk: a single-chunk split needs one buffer only
     __syncthreads();
 
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
@@ -262,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                 }
                 k_step(a, b);
             }
-            if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats);
+            if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats, (chunk + 1) * 2 * CH * C8);
             __syncthreads();
             continue;
         }
@@ -299,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
                 for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const float4*>(cur + lds_off<0>(apix[t] + tap_delta(pfx, prow), 0));
                 k_step(a, b);
             }
-            if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats);
+            if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats, (chunk + 1) * 2 * CH * C8);
             __syncthreads();
             continue;
         }
@@ -343,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
             fx = fxn;
             rowoff = rown;
         }
-        if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats);
+        if (more) stage_store(smem + ((chunk + 1 - chunk0) & 1) * p.bufFloats, (chunk + 1) * 2 * CH * C8);
         __syncthreads();
     }
 

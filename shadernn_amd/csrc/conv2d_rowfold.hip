@@ -30,6 +30,11 @@ struct RowfoldParams {
     int N, H, W, IC, OC, OH, OW, padx, pady, padMode, useBN;
     int preMode, preX, preY, srcH, srcW, preShift; // fused Pad / nearest x2 upsampling in front (ConvGeom)
     int tilesX, tilesY;
+    // InstanceNorm in front (graph rule I): normAc((x - mean[n][c]) * mul[n][c] + beta[c]) applied to the staged values; null = none
+    const float* normMean;
+    const float* normMul;
+    const float* normBeta;
+    ActCfg normAc;
 };
 
 constexpr int kTH = 8, kCols = 64;
@@ -59,9 +64,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_kernel(RowfoldParams p,
         constexpr int TOTAL = ROWS * kCols * Q;
         const _Float16* xn = x + static_cast<size_t>(n) * p.srcH * p.srcW * p.IC;
         // all of a thread's loads (16 for a 16 x 64 x 32-channel tile) are requested before the first LDS store: one HBM round trip per block
+        // graph rule I: a thread's elements all sit in channel slot tid % Q (256 % Q == 0), i.e. share their 8 channels and, within a block, the image
+        float nMean[8], nMul[8], nBeta[8];
+        if (p.normMean) {
+            const int cb = 8 * (tid % Q);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                nMean[k] = p.normMean[static_cast<size_t>(n) * p.IC + cb + k];
+                nMul[k] = p.normMul[static_cast<size_t>(n) * p.IC + cb + k];
+                nBeta[k] = p.normBeta[cb + k];
+            }
+        }
         for (int base = tid; base < TOTAL; base += 16 * 256) {
             float4 v[16];
             int lo[16];
+            unsigned live = 0; // elements that were read from the tensor (the others are padding zeros and stay zero)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int e = base + r * 256;
@@ -77,9 +94,25 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_kernel(RowfoldParams p,
                         if (sy >= 0) sy >>= p.preShift;
                         if (sx >= 0) sx >>= p.preShift;
                     }
-                    if (sy >= 0 && sx >= 0) v[r] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(sy) * p.srcW + sx) * p.IC + 8 * s);
+                    if (sy >= 0 && sx >= 0) {
+                        v[r] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(sy) * p.srcW + sx) * p.IC + 8 * s);
+                        live |= 1u << r;
+                    }
                     lo[r] = ((rr * kCols + c) * Q + (s ^ ((c >> (Q == 4 ? 2 : 3)) & (Q - 1)))) * 4;
                 }
+            }
+            if (p.normMean) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (live & (1u << r)) {
+                        h8 hv = *reinterpret_cast<const h8*>(&v[r]);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float f = (static_cast<float>(hv[k]) - nMean[k]) * nMul[k] + nBeta[k];
+                            hv[k] = static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                        }
+                        v[r] = *reinterpret_cast<const float4*>(&hv);
+                    }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -185,6 +218,7 @@ int make_conv2d_rowfold_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     // eligibility: half tensors, square odd kernel 5 / 7 / 9, stride 1, k * OC <= 32, IC = 16 or 32 (the weights of a lane stay in registers)
     const char* force = getenv("SNNHIP_CONV");
     if (force && strcmp(force, "rowfold") != 0) return SNNHIP_E_UNSUPPORTED;
+    if (g.normMean && !act_is_simple(g.normAct)) return SNNHIP_E_UNSUPPORTED;
     if (g.dtype != SNNHIP_F16 || g.kh != g.kw || (g.kh != 5 && g.kh != 7 && g.kh != 9) || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
     if (g.kh * g.OC > 32 || (g.IC != 16 && g.IC != 32) || g.act == SNNHIP_ACT_SILU_QUIRK || g.addAct >= 0) return SNNHIP_E_UNSUPPORTED;
     if (static_cast<double>(g.N) * g.H * g.W * g.IC >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
@@ -196,6 +230,8 @@ int make_conv2d_rowfold_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     p.srcW = g.preMode ? g.srcW : g.W;
     p.tilesX = up_div(g.OW, TW);
     p.tilesY = up_div(g.OH, kTH);
+    p.normMean = g.normMean; p.normMul = g.normMul; p.normBeta = g.normBeta;
+    p.normAc = make_act_cfg(g.normMean ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
     const size_t lds = std::max(static_cast<size_t>(kTH + K - 1) * kCols * g.IC * 2, static_cast<size_t>(kTH) * kCols * kPP * sizeof(float));
     const bool simple = act_is_simple(g.act);
     RowfoldFn fn = K == 9 ? pick_rowfold<9>(ICS, simple) : K == 7 ? pick_rowfold<7>(ICS, simple) : pick_rowfold<5>(ICS, simple);
@@ -242,6 +278,7 @@ int make_conv2d_rowfold_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     plan->desc = buf;
     if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
     if (g.preMode && g.preShift) plan->desc += " +upsample(x2)";
+    if (g.normMean) plan->desc = "instancenorm(act=" + std::to_string(g.normAct) + ", in the staging) -> " + plan->desc;
     *out = plan;
     return SNNHIP_OK;
 }

@@ -217,6 +217,7 @@ struct StemConvPlan : ConvPlanBase {
 int make_conv2d_stem_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.dtype != SNNHIP_F16 || g.kh != kK || g.kw != kK || g.sh != 1 || g.sw != 1 || g.IC > 4 || g.OC % 32 != 0) return SNNHIP_E_UNSUPPORTED;
     if (g.addAct >= 0 || (g.preMode && g.preShift) || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED;
+    if (g.normMean) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
     if (const char* e = getenv("SNNHIP_CONV_STEM"))
         if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
     if (const char* f = getenv("SNNHIP_CONV"))

@@ -301,6 +301,7 @@ WideFn pick_wide(bool simple, bool res) {
 int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
     if (g.IC % 16 != 0 || g.OC % 32 != 0 || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED;
+    if (g.normMean) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
     const double inCount = static_cast<double>(g.N) * (g.preMode ? g.srcH : g.H) * (g.preMode ? g.srcW : g.W) * g.IC;
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;

@@ -639,7 +639,10 @@ struct InstanceNormPlan : snnhip_plan {
         return runWithResidual(in, nIn, out, nullptr, 0, 0.0f);
     }
     // res != nullptr: the Add layer behind this norm folded into the normalise sweep (chain rule H)
-    int runWithResidual(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out, const snnhip_tensor* res, int addAct, float addLeaky, bool resFirst = false) {
+    // statsOnly (graph rule I): the statistics sweep and the fold only -- d_mean / d_mul are left for the convolution that normalises while it
+    // stages its input (`out` is not touched and may be the input itself)
+    int runWithResidual(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out, const snnhip_tensor* res, int addAct, float addLeaky, bool resFirst = false,
+                        bool statsOnly = false) {
         SNNHIP_SAME_DTYPE("instancenorm");
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, d.H, d.W, d.C), "instancenorm: tensor dims do not match the plan");
         SNNHIP_REQUIRE(!res || (res->n == d.N && res->c == d.C && res->h <= d.H && res->w <= d.W && res->dtype == out->dtype),
@@ -665,11 +668,11 @@ struct InstanceNormPlan : snnhip_plan {
         SNNHIP_WITH_T(out->dtype, if ((d.C & 3) == 0) {
             SNNHIP_IN(0, 4);
             SNNHIP_FOLD();
-            SNNHIP_IN(2, 4);
+            if (!statsOnly) SNNHIP_IN(2, 4);
         } else {
             SNNHIP_IN(0, 1);
             SNNHIP_FOLD();
-            SNNHIP_IN(2, 1);
+            if (!statsOnly) SNNHIP_IN(2, 1);
         });
 #undef SNNHIP_IN
 #undef SNNHIP_FOLD
@@ -712,6 +715,24 @@ int make_instancenorm_add_plan(snnhip_ctx* ctx, snnhip_plan* normPlan, snnhip_pl
     plan->desc = q->desc + " +add act=" + std::to_string(ad->d.act) + (plan->resFirst ? " (residual first)" : "");
     *out = plan;
     return SNNHIP_OK;
+}
+
+// graph rule I: where the norm's per-(image, channel) statistics and its beta live (device pointers, stable for the life of the plan), and the
+// two launches that fill them from a tensor
+bool instancenorm_stat_pointers(const snnhip_plan* plan, const float** mean, const float** mul, const float** beta) {
+    const auto* q = dynamic_cast<const InstanceNormPlan*>(plan);
+    if (!q) return false;
+    *mean = q->d_mean;
+    *mul = q->d_mul;
+    *beta = q->d_beta;
+    return true;
+}
+int instancenorm_run_stats(snnhip_plan* plan, const snnhip_tensor* x) {
+    auto* q = dynamic_cast<InstanceNormPlan*>(plan);
+    SNNHIP_REQUIRE(q && x, "instancenorm_run_stats: bad arguments");
+    snnhip_tensor alias = *x; // stage 2 does not run: the output is never written
+    const snnhip_tensor* ins[1] = {x};
+    return q->runWithResidual(ins, 1, &alias, nullptr, 0, 0.0f, false, true);
 }
 
 bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d) {

@@ -870,6 +870,18 @@ struct ConvInstanceNormPlan : snnhip_plan {
     }
 };
 
+// Graph rule I: InstanceNorm -> [UpSampling] -> [Pad] -> Conv2D.  The norm runs its statistics sweep and fold only; the convolution (a copy
+// the chain owns, built with ConvGeom::normMean...) reads the norm's INPUT and normalises while it stages -- the normalised tensor is never
+// written or re-read.  The norm plan is borrowed: its parameters and statistics buffers are the ones the convolution was given.
+struct InstanceNormConvPlan : snnhip_plan {
+    snnhip_plan* norm = nullptr;
+    snnhip_plan* conv = nullptr;
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        const int rc = instancenorm_run_stats(norm, in[0]);
+        return rc != SNNHIP_OK ? rc : conv->run(in, nIn, out);
+    }
+};
+
 struct ChainPlan : snnhip_plan {
     enum Kind { PLAIN, FUSED_A, FUSED_B, FUSED_S };
     struct Step {
@@ -1340,6 +1352,47 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         a.desc = both->desc;
         a.flops = both->flops;
         a.bytes = both->bytes;
+        chain->steps.erase(chain->steps.begin() + static_cast<long>(k) + 1);
+        ++fusedCount;
+    }
+    // ---- rule I: an InstanceNorm step followed by a convolution step (as given, or built by rule D above) whose kernel can normalise in its
+    // staging (today: conv2d_mfma's fp16 kernels).  SNNHIP_NO_NORM_FOLD keeps the norm's own normalise sweep.
+    for (size_t k = 0; rc == SNNHIP_OK && k + 1 < chain->steps.size() && !getenv("SNNHIP_NO_NORM_FOLD"); ++k) {
+        ChainPlan::Step &a = chain->steps[k], &b = chain->steps[k + 1];
+        if (a.kind != ChainPlan::PLAIN || b.kind != ChainPlan::PLAIN) continue;
+        snnhip_instancenorm_desc nd;
+        auto* cv = dynamic_cast<ConvPlanBase*>(b.plain);
+        if (!cv || cv->depthwise || cv->numInputs != 1 || cv->g.normMean || !instancenorm_plan_desc(a.plain, &nd) || !act_is_simple(nd.act)) continue;
+        if (nd.N != cv->inDims[0] || nd.H != cv->inDims[1] || nd.W != cv->inDims[2] || nd.C != cv->inDims[3]) continue;
+        // only where the convolution already runs on a kernel that can normalise: trading the 4 x 2-tile kernel (conv2d_wide_f16) for the
+        // 128-pixel one costs more than the normalise sweep saves (measured on Candy's residual blocks: 160 + 290 us apart, 600 us folded)
+        if (cv->desc.rfind("conv2d_mfma_f16_", 0) != 0 && cv->desc.rfind("conv2d_rowfold", 0) != 0) continue;
+        ConvGeom g2 = cv->g;
+        if (!instancenorm_stat_pointers(a.plain, &g2.normMean, &g2.normMul, &g2.normBeta)) continue;
+        g2.normAct = nd.act;
+        g2.normLeaky = nd.leaky;
+        snnhip_plan* fused = nullptr;
+        const int frc = cv->desc.rfind("conv2d_rowfold", 0) == 0 ? make_conv2d_rowfold_plan(ctx, g2, cv->w_oihw.data(), cv->epi4, &fused)
+                                                                 : make_conv2d_mfma_plan(ctx, g2, cv->w_oihw.data(), cv->epi4, &fused);
+        if (frc != SNNHIP_OK) continue;
+        chain->owned.push_back(fused);
+        auto* both = new InstanceNormConvPlan();
+        both->ctx = ctx;
+        both->norm = a.plain;
+        both->conv = fused;
+        both->dtype = fused->dtype;
+        both->numInputs = fused->numInputs;
+        memcpy(both->inDims, fused->inDims, sizeof(both->inDims));
+        memcpy(both->outDims, fused->outDims, sizeof(both->outDims));
+        both->flops = a.flops + b.flops;
+        both->bytes = a.bytes / 3.0 + b.bytes; // the norm's normalise sweep (one read + one write of its three passes) is gone
+        both->desc = "instancenorm(statistics sweep + fold) -> " + fused->desc;
+        chain->owned.push_back(both);
+        a.plain = both;
+        a.desc = both->desc;
+        a.flops = both->flops;
+        a.bytes = both->bytes;
+        memcpy(a.outDims, b.outDims, sizeof(a.outDims));
         chain->steps.erase(chain->steps.begin() + static_cast<long>(k) + 1);
         ++fusedCount;
     }

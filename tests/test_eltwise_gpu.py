@@ -345,3 +345,49 @@ def test_instancenorm_add_graph_fusion(ctx, monkeypatch, n, h, w, c, act, add_ac
     monkeypatch.setenv("SNNHIP_NO_ADD_FUSION", "1")
     nodes = [(pre, [-1], False), (norm, [0], False), (add, [1, -2], True)]
     assert all(p is not None for p, _ in snn.graph_fuse(ctx, nodes))
+
+
+@pytest.mark.parametrize("with_pad,with_up", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("n,h,w,ic,oc,k,s,act", [(1, 40, 56, 32, 64, 3, 2, "relu"), (2, 37, 45, 64, 128, 3, 2, "relu"), (1, 33, 70, 16, 32, 3, 1, ""), (2, 19, 23, 64, 64, 3, 1, "leakyRelu"),
+                                                (1, 30, 30, 8, 16, 5, 1, "relu"), (2, 21, 70, 32, 3, 9, 1, "relu"), (1, 17, 40, 16, 3, 7, 1, "")])
+def test_instancenorm_conv_chain_fusion(ctx, monkeypatch, n, h, w, ic, oc, k, s, act, with_pad, with_up):
+    """Graph rule I (fp16): InstanceNorm -> [UpSampling] -> [Pad] -> Conv2D as the norm's statistics sweep + fold and ONE convolution launch that
+    normalises while it stages its input.  Same arithmetic and rounding points as the separate launches: bit-identical to them (and within
+    tolerance of the oracle); zero padding of a 'same' convolution stays zero."""
+    import shadernn_amd as snn
+
+    if with_up and (s != 1 or oc == 3):
+        pytest.skip("the upsampling staging path: stride-1 layers of the general MFMA kernel")
+    monkeypatch.setenv("SNNHIP_CONV_WIDE", "0")  # (the wide kernel gets its own cases in test_conv_wide_gpu.py)
+    dt = snn.F16
+    x = 1.5 * _rand((n, h, w, ic), 1) + 0.2
+    wt, b = _rand((oc, ic, k, k), 2, 1.0 / np.sqrt(ic * k * k)), _rand((oc,), 3, 0.5)
+    beta, gamma = _rand((ic,), 4, 0.3), 1.0 + _rand((ic,), 5, 0.2)
+    norm = snn.instancenorm_plan(ctx, n, h, w, ic, beta, gamma, act=act, leaky=0.1)
+    plans, hh, ww = [norm], h, w
+    if with_up:
+        plans.append(snn.upsample_plan(ctx, n, h, w, ic, 2.0, "nearest"))
+        hh, ww = 2 * h, 2 * w
+    cp = O.padding_offsets("same", k)
+    if with_pad:
+        pd = k // 2
+        plans.append(snn.pad_plan(ctx, n, hh, ww, ic, (pd, pd, pd, pd), "reflect"))
+        hh, ww, cp = hh + 2 * pd, ww + 2 * pd, (0, 0, 0, 0)
+    plans.append(snn.conv2d_plan(ctx, n, hh, ww, wt, b, stride=s, pads=cp, act="relu", dtype=dt))
+    fused = snn.chain_plan(ctx, plans)
+    assert fused.num_steps() == 1 and "instancenorm(statistics sweep + fold) -> instancenorm(act=" in fused.describe(), fused.describe()
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=dt)
+    y = fused(xt).numpy()
+    t = xt
+    for pl in plans:
+        t = pl(t)
+    np.testing.assert_array_equal(y, t.numpy())
+    ref = O._h(O.instancenorm(O._h(x), beta, gamma, act, 0.1))
+    if with_up:
+        ref = O.upsample(ref, 2.0, "nearest")
+    if with_pad:
+        ref = O.pad(ref, (k // 2,) * 4, "reflect")
+    want = O._h(O.conv2d(ref, O._h(wt), b, s, cp, "constant", "relu", 0.0, None))
+    np.testing.assert_allclose(y, want, err_msg=fused.describe(), rtol=6e-3, atol=6e-3)
+    monkeypatch.setenv("SNNHIP_NO_NORM_FOLD", "1")
+    assert "statistics sweep" not in snn.chain_plan(ctx, plans).describe() if (with_pad or with_up) else True

@@ -296,7 +296,7 @@ WideFn pick_wide(bool simple, bool res) {
 
 } // namespace
 
-// fp16 3x3 stride-1 layers with IC % 16 == 0, OC % 32 == 0 and enough 256 / 512-pixel tiles to fill the chip; SNNHIP_CONV=wide forces it for
+// fp16 3x3 stride-1 layers with IC % 16 == 0, OC % 32 == 0 and at least 0.75 blocks of 256 / 512 pixels per CU; SNNHIP_CONV=wide forces it for
 // every eligible shape, SNNHIP_CONV_WIDE=0 keeps the 128-pixel kernel
 int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
@@ -322,7 +322,9 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     const int C8 = (WM == 2 && g.IC % 32 == 0) ? 2 : 1;
     const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
     const long tiles = static_cast<long>(g.N) * up_div(g.OH, TH) * up_div(g.OW, TW);
-    if (!forced && tiles * (g.OC / BN) < 3L * cus) return SNNHIP_E_UNSUPPORTED; // fewer than 1.5 rounds of resident blocks: the 128-pixel tiles fill the chip better
+    // measured down to one 183x323 image (230 blocks of 256 pixels on 256 CUs): 24 us here, 35 us with the 128-pixel blocks; below that the
+    // narrow blocks (and their split-K) fill the chip better
+    if (!forced && tiles * (g.OC / BN) * 4 < 3L * cus) return SNNHIP_E_UNSUPPORTED;
 
     WideParams p{};
     p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.padx = g.padx; p.pady = g.pady; p.padMode = g.padMode; p.useBN = g.useBN;

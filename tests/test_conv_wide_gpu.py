@@ -106,7 +106,9 @@ def test_wide_is_the_default_on_large_maps_only(ctx):
 
     w = _rand((128, 128, 3, 3), 1, 0.03)
     big = snn.conv2d_plan(ctx, 8, 180, 320, w, None, stride=1, pads=(1, 1, 1, 1), dtype=snn.F16)
-    small = snn.conv2d_plan(ctx, 1, 28, 28, w, None, stride=1, pads=(1, 1, 1, 1), dtype=snn.F16)
+    small = snn.conv2d_plan(ctx, 1, 56, 56, w, None, stride=1, pads=(1, 1, 1, 1), dtype=snn.F16)
+    one = snn.conv2d_plan(ctx, 1, 183, 323, w, None, stride=1, pads=(1, 1, 1, 1), dtype=snn.F16)
+    assert "wide" in one.describe(), one.describe()
     s2 = snn.conv2d_plan(ctx, 8, 180, 320, w, None, stride=2, pads=(1, 1, 1, 1), dtype=snn.F16)
     f32 = snn.conv2d_plan(ctx, 8, 180, 320, w, None, stride=1, pads=(1, 1, 1, 1))
     assert "wide" in big.describe(), big.describe()

@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     }
 
     float* const epiTab = smem + p.epiOfs; // (behind the staging buffers AND the epilogue's output tile) this block's BN rows of the epilogue table {bias, bnScale, bnMean, bnBeta}
-    if (tid < BN) reinterpret_cast<float4*>(epiTab)[tid] = epi[blockIdx.y * BN + tid];
+    float* const biasTab = epiTab + 4 * BN; // the biases alone, contiguous: the four of a lane's channel run are one ds_read_b128
+    if (tid < BN) {
+        const float4 e4 = epi[blockIdx.y * BN + tid];
+        reinterpret_cast<float4*>(epiTab)[tid] = e4;
+        biasTab[tid] = e4.x;
+    }
     stage_dma(smem, 0);
     lds_dma_wait();
     __syncthreads();
@@ -201,13 +206,27 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     constexpr int EPITCH = BN + 8; // halfs per pixel row of the LDS tile: 8-byte runs of 16 consecutive pixels land in distinct banks
     _Float16* const otile = reinterpret_cast<_Float16*>(smem);
     const float4* const etab = reinterpret_cast<const float4*>(epiTab) + wn * (NT * 32) + 4 * h;
+    // layers without batch norm (all of the style graphs): the lane's 8 NT biases are read BEFORE the first write of the output tile -- the
+    // compiler cannot tell the table from the tile (one LDS array) and serialises a read - wait - write round trip per channel run otherwise
+    float4 bias4[NT][4];
+    if (!p.useBN) {
+        const float4* const btab = reinterpret_cast<const float4*>(biasTab + wn * (NT * 32) + 4 * h);
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias4[u][g] = btab[u * 8 + 2 * g];
+    }
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 e[4];
+            if (p.useBN) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) e[k] = etab[u * 32 + 8 * g + k];
+                for (int k = 0; k < 4; ++k) e[k] = etab[u * 32 + 8 * g + k];
+            } else {
+                e[0].x = bias4[u][g].x; e[1].x = bias4[u][g].y; e[2].x = bias4[u][g].z; e[3].x = bias4[u][g].w;
+            }
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 h4 o;
@@ -357,7 +376,7 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (!fn) return SNNHIP_E_UNSUPPORTED;
     const int PIX = 128 * WM;
     p.epiOfs = static_cast<int>(std::max(static_cast<size_t>(2) * p.bufFloats * 4, static_cast<size_t>(PIX) * (BN + 8) * 2) / 4);
-    const size_t lds = static_cast<size_t>(p.epiOfs) * 4 + static_cast<size_t>(BN) * 16;
+    const size_t lds = static_cast<size_t>(p.epiOfs) * 4 + static_cast<size_t>(BN) * 20;
     if (lds > 80 * 1024) return SNNHIP_E_UNSUPPORTED;
 
     auto* plan = new WideConvPlan();

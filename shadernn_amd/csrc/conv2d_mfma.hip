@@ -446,9 +446,10 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
             if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
         }
     }
-    // the fp16 RGB stem of the style graphs (9x9, stride 1, IC <= 4): conv2d_stem_f16.hip
+    // the RGB stems (IC <= 4): conv2d_stem_f16.hip (fp16 9x9 stride 1) and conv2d_stem_f32.hip (fp32 3x3 stride 1 / 2, 7x7 stride 2)
     {
-        const int rc = make_conv2d_stem_plan(ctx, g, w_oihw, epi4, out);
+        int rc = make_conv2d_stem_plan(ctx, g, w_oihw, epi4, out);
+        if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_stem32_plan(ctx, g, w_oihw, epi4, out);
         if (rc != SNNHIP_E_UNSUPPORTED) return rc;
     }
     // fp16 3x3 stride-1 layers on large maps: the 4 x 2 register-block kernel of conv2d_wide_f16.hip (SNNHIP_CONV=wide forces it for every

@@ -1,0 +1,242 @@
+// conv2d_stem_f32.hip -- fp32 k x k convolution of a channel-thin image (IC <= 4) with 32 | OC: the RGB stems (ResNet-18 7x7 stride 2, MobileNetV2 /
+// YOLO 3x3 stride 2, BASELINE configs[0]'s 3x3 stride 1) on v_mfma_f32_32x32x2_f32.
+//
+// conv2d_mfma_kernel's tap-pair mode walks the taps with a rolled loop and one LDS operand read per MFMA: the 7x7 stem of ResNet-18 (batch 32) ran
+// at 58 TF/s, 130 us, bound by instruction issue.  The structure of conv2d_stem_f16.hip, for fp32:
+//   * a pixel = 4 floats in LDS, stored {c0, c2, c1, c3}: lane half h reads the 8 bytes {c_h, c_(2+h)} of a tap with ONE ds_read_b64 and feeds
+//     two MFMAs with them (K = 2 per MFMA: channel pair (0,1), then (2,3)); 2 MFMAs per tap, 3 of 4 operand slots carry data;
+//   * ALL weights of a 32-channel output block in registers (2 k^2 floats per lane: the MFMA's A operand is one VGPR), loaded once per wave;
+//   * a wave owns NR = 4 output rows x 32 columns: the operand of (input row r, tap column fx) is read ONCE and feeds the MFMAs of every output
+//     row y with r - s y a valid kernel row; straight-line code;
+//   * epilogue per output row through a wave-private LDS scratch: the lane's 16-byte channel runs in, 64 contiguous bytes per lane out (whole lines).
+// Same operator contract as the other convolution kernels (padding modes, bias -> BN -> activation).
+#include "epilogue.h"
+#include "snnhip_internal.h"
+
+#include <cstring>
+
+namespace snnhip {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Stem32Params {
+    int N, H, W, IC, OC, padx, pady, padMode, useBN, OH, OW;
+    int tilesX, tilesY;
+};
+
+constexpr int kNR = 4;                  // output rows per wave
+constexpr int kTH = 4 * kNR, kTW = 32;  // block tile: 4 waves stacked in y
+constexpr int kOutPitch = 36;           // floats per pixel row of a wave's output scratch (32 + 4: 16-byte aligned, the runs of 8 lanes on distinct banks)
+
+__device__ __forceinline__ int resolve_nb32(int s, int size, int mode) {
+    const int cl = min(max(s, 0), size - 1);
+    int rf = s < 0 ? -s : s;
+    rf = rf >= size ? 2 * size - 2 - rf : rf;
+    const int t = mode == SNNHIP_PAD_REPLICATE ? cl : (mode == SNNHIP_PAD_REFLECT ? rf : s);
+    return (t >= 0 && t < size) ? t : -1;
+}
+
+template <int K, int S, bool SIMPLE>
+__global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem32Params p, ActCfg ac, const float* __restrict__ x, const float* __restrict__ wp,
+                                                            const float4* __restrict__ epi, float* __restrict__ y) {
+    constexpr int IN_H = (kTH - 1) * S + K, IN_W = (kTW - 1) * S + K; // staged halo tile
+    constexpr int ROWS = (kNR - 1) * S + K;                           // input rows a wave touches
+    constexpr int NW = 2 * K * K;                                     // weight registers per lane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const tile = smem;                                         // [IN_H][IN_W][4]
+    float* const oscr = smem + IN_H * IN_W * 4;                       // [4 waves][32][kOutPitch]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, h = lane >> 5;
+    const int mt = blockIdx.x;
+    const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, n = mt / (p.tilesX * p.tilesY);
+    const int ox0 = tx * kTW, oy0 = ty * kTH;
+
+    // ---- weights: step s = 2 (fy K + fx) + m: lane (oc = l32, half h) holds W[oc][ic = 2m + h][fy][fx] (0 for ic >= IC)
+    float wa[NW];
+    {
+        const float* wsrc = wp + static_cast<size_t>(blockIdx.y) * NW * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NW; ++s) wa[s] = wsrc[s * 64];
+    }
+
+    // ---- stage the halo tile: pixel -> {c0, c2, c1, c3}; every load of the thread is issued before its first LDS write
+    constexpr int kR = (IN_H * IN_W + 255) / 256;
+    {
+        float sv[kR][4];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int e = tid + 256 * r;
+            const int rr = e / IN_W, c = e - rr * IN_W;
+            const int sy = resolve_nb32(oy0 * S - p.pady + rr, p.H, p.padMode);
+            const int sx = resolve_nb32(ox0 * S - p.padx + c, p.W, p.padMode);
+            const bool ok = e < IN_H * IN_W && sy >= 0 && sx >= 0;
+            const float* src = x + (static_cast<size_t>(n * p.H + (ok ? sy : 0)) * p.W + (ok ? sx : 0)) * p.IC;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[r][k] = (ok && k < p.IC) ? src[k] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int e = tid + 256 * r;
+            if (e < IN_H * IN_W) *reinterpret_cast<float4*>(tile + e * 4) = make_float4(sv[r][0], sv[r][2], sv[r][1], sv[r][3]);
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[kNR];
+#pragma unroll
+    for (int i = 0; i < kNR; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    // operand base of this lane: pixel (row wave*kNR*S, column l32*S) of the tile, floats {c_h, c_(2+h)}
+    const float* const tb = tile + ((wave * kNR * S) * IN_W + l32 * S) * 4 + 2 * h;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int fx = 0; fx < K; ++fx) {
+            const float2 b = *reinterpret_cast<const float2*>(tb + (r * IN_W + fx) * 4);
+#pragma unroll
+            for (int yy = 0; yy < kNR; ++yy) {
+                const int fy = r - yy * S;
+                if (fy < 0 || fy >= K) continue; // compile-time after unrolling
+                acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * (fy * K + fx)], b.x, acc[yy], 0, 0, 0);
+                acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * (fy * K + fx) + 1], b.y, acc[yy], 0, 0, 0);
+            }
+        }
+
+    // ---- epilogue: acc[yy][4g + k] = channel 8g + 4h + k of pixel (row yy, column l32)
+    float4 e[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[4 * g + k] = epi[blockIdx.y * 32 + 8 * g + 4 * h + k];
+    float* const sc = oscr + wave * (32 * kOutPitch);
+#pragma unroll
+    for (int yy = 0; yy < kNR; ++yy) {
+        const int oy = oy0 + wave * kNR + yy;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = epi_affine(acc[yy][4 * g + k], e[4 * g + k], p.useBN);
+                o[k] = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+            }
+            *reinterpret_cast<float4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        // (wave-private scratch: a wave's LDS operations complete in order).  Out: 16-byte pieces, lane L = piece L % 8 of pixel L / 8 (+ 8 i)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int opix = 8 * i + (lane >> 3), piece = lane & 7;
+            const float4 v = *reinterpret_cast<const float4*>(sc + opix * kOutPitch + 4 * piece);
+            const int ox = ox0 + opix;
+            if (oy < p.OH && ox < p.OW) *reinterpret_cast<float4*>(y + (static_cast<size_t>(n * p.OH + oy) * p.OW + ox) * p.OC + blockIdx.y * 32 + 4 * piece) = v;
+        }
+    }
+}
+
+typedef void (*Stem32Fn)(Stem32Params, ActCfg, const float*, const float*, const float4*, float*);
+
+struct Stem32Plan : ConvPlanBase {
+    Stem32Params p;
+    ActCfg ac;
+    float* d_w = nullptr;
+    float* d_epi = nullptr;
+    dim3 grid;
+    size_t ldsBytes = 0;
+    Stem32Fn kernel = nullptr;
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == p.N && x->h == p.H && x->w == p.W && x->c == p.IC && x->dtype == SNNHIP_F32, "conv2d: input dims %dx%dx%dx%d (dtype %d) != plan %dx%dx%dx%d fp32",
+                       x->n, x->h, x->w, x->c, x->dtype, p.N, p.H, p.W, p.IC);
+        SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC && out->dtype == SNNHIP_F32, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
+                       out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, x->data, d_w, reinterpret_cast<const float4*>(d_epi), out->data);
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+template <int K, int S>
+Stem32Fn pick_stem32(bool simple) {
+    return simple ? conv2d_stem32_kernel<K, S, true> : conv2d_stem32_kernel<K, S, false>;
+}
+
+} // namespace
+
+// fp32, IC <= 4, OC % 32 == 0, (k, stride) in {(3, 1), (3, 2), (7, 2)}, no fused Pad / residual; SNNHIP_CONV_STEM=0 leaves the layer to conv2d_mfma's
+// tap-pair mode
+int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
+    if (g.dtype != SNNHIP_F32 || g.kh != g.kw || g.sh != g.sw || g.IC > 4 || g.OC % 32 != 0) return SNNHIP_E_UNSUPPORTED;
+    if (g.addAct >= 0 || g.preMode || g.normMean || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED; // (the quirk couples 4 adjacent pixels)
+    if (const char* e = getenv("SNNHIP_CONV_STEM"))
+        if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
+    if (const char* f = getenv("SNNHIP_CONV"))
+        if (strcmp(f, "stem") != 0) return SNNHIP_E_UNSUPPORTED; // another kernel is being forced
+    const bool simple = act_is_simple(g.act);
+    Stem32Fn fn = nullptr;
+    int K = g.kh, S = g.sh;
+    if (K == 3 && S == 1) fn = pick_stem32<3, 1>(simple);
+    if (K == 3 && S == 2) fn = pick_stem32<3, 2>(simple);
+    if (K == 7 && S == 2) fn = pick_stem32<7, 2>(simple);
+    if (!fn) return SNNHIP_E_UNSUPPORTED;
+    if (static_cast<double>(g.N) * g.OH * g.OW * g.OC >= 2147483647.0 * 2) return SNNHIP_E_UNSUPPORTED;
+
+    Stem32Params p{};
+    p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.padx = g.padx; p.pady = g.pady; p.padMode = g.padMode; p.useBN = g.useBN;
+    p.OH = g.OH; p.OW = g.OW;
+    p.tilesX = up_div(g.OW, kTW); p.tilesY = up_div(g.OH, kTH);
+    const int IN_H = (kTH - 1) * S + K, IN_W = (kTW - 1) * S + K;
+    const size_t lds = (static_cast<size_t>(IN_H) * IN_W * 4 + 4 * 32 * kOutPitch) * sizeof(float);
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+        set_error("conv2d_stem32: hipFuncSetAttribute(%zu) failed", lds);
+        return SNNHIP_E_HIP;
+    }
+
+    auto* plan = new Stem32Plan();
+    plan->ctx = ctx;
+    plan->g = g;
+    plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC * K * K);
+    plan->epi4 = epi4;
+    plan->p = p;
+    plan->ac = make_act_cfg(g.act, g.leaky);
+    plan->kernel = fn;
+    plan->ldsBytes = lds;
+    plan->grid = dim3(static_cast<unsigned>(p.tilesX) * p.tilesY * g.N, g.OC / 32, 1);
+
+    // weights: Wp[oc block][step = 2 (fy K + fx) + m][lane = 32 hh + o] = W[32 b + o][ic = 2m + hh][fy][fx]
+    const int NW = 2 * K * K, ocb = g.OC / 32;
+    std::vector<float> wpk(static_cast<size_t>(ocb) * NW * 64, 0.0f);
+    for (int b = 0; b < ocb; ++b)
+        for (int t = 0; t < K * K; ++t)
+            for (int m = 0; m < 2; ++m)
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int ic = 2 * m + hh;
+                    if (ic >= g.IC) continue;
+                    for (int o = 0; o < 32; ++o)
+                        wpk[(static_cast<size_t>(b) * NW + 2 * t + m) * 64 + 32 * hh + o] = w_oihw[(static_cast<size_t>(b * 32 + o) * g.IC + ic) * K * K + t];
+                }
+    int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
+    if (rc == SNNHIP_OK) rc = plan->upload(epi4.data(), epi4.size(), &plan->d_epi);
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    plan->inDims[0] = g.N; plan->inDims[1] = g.H; plan->inDims[2] = g.W; plan->inDims[3] = g.IC;
+    plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
+    plan->dtype = SNNHIP_F32;
+    plan->flops = 2.0 * K * K * g.IC * g.OC * static_cast<double>(g.OH) * g.OW * g.N;
+    plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * K * K);
+    char buf[256];
+    snprintf(buf, sizeof(buf), "conv2d_mfma_stem_f32_32x32x2 k=%dx%d s=%d ic=%d oc=%d tile=%dx%dpx x 32oc (2 MFMAs per tap, weights in registers) lds=%zuB", K, K, S, g.IC, g.OC,
+             kTH, kTW, lds);
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip

@@ -30,8 +30,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // A wave owns one output unit for kBatchPerWave batch rows: the weight row is loaded once per group instead of once per batch row (at batch
 // 32 the 1280 x 1000 classifier pulled its 5 MB of weights through L2 32 times); per (row, unit) the lane partial sums are formed in the
 // same order as before, so results are bit-identical.
-constexpr int kBatchPerWave = 4;
-template <bool VEC, typename TX>
+// (GB = 4, or 16 from batch 64 on: the 256-image classifier of BASELINE config 4 read its weights 64 times with 4.)
+template <bool VEC, typename TX, int kBatchPerWave>
 __global__ __launch_bounds__(256) void dense_kernel(int In, int Out, int batch, int act, float leaky, const TX* __restrict__ x,
                                                     const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y) {
     const int lane = threadIdx.x & 63;
@@ -127,17 +127,24 @@ struct DensePlan : snnhip_plan {
         SNNHIP_REQUIRE(out->count() == static_cast<size_t>(d.batch) * d.out_units, "dense: output has %zu elements, expected %d x %d", out->count(),
                        d.batch, d.out_units);
         SNNHIP_REQUIRE(x->dtype == out->dtype, "dense: input dtype %d, output dtype %d", x->dtype, out->dtype);
-        dim3 grid(up_div(d.out_units, 4), up_div(d.batch, kBatchPerWave));
+        const int gb = d.batch >= 64 ? 16 : 4;
+        dim3 grid(up_div(d.out_units, 4), up_div(d.batch, gb));
         const bool vec = (d.in_units % 4) == 0;
         const bool half = out->dtype == SNNHIP_F16;
         float* rows = half ? d_row : out->data;
         if (half) {
             const _Float16* xh = reinterpret_cast<const _Float16*>(x->data);
-            if (vec) hipLaunchKernelGGL((dense_kernel<true, _Float16>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky, xh, d_w, d_b, rows);
-            else hipLaunchKernelGGL((dense_kernel<false, _Float16>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky, xh, d_w, d_b, rows);
+#define SNNHIP_DENSE(V, TXX, XP)                                                                                                                          \
+    do {                                                                                                                                             \
+        if (gb == 16) hipLaunchKernelGGL((dense_kernel<V, TXX, 16>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky, XP, d_w, d_b, rows); \
+        else hipLaunchKernelGGL((dense_kernel<V, TXX, 4>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky, XP, d_w, d_b, rows);           \
+    } while (0)
+            if (vec) SNNHIP_DENSE(true, _Float16, xh);
+            else SNNHIP_DENSE(false, _Float16, xh);
         } else {
-            if (vec) hipLaunchKernelGGL((dense_kernel<true, float>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky, x->data, d_w, d_b, rows);
-            else hipLaunchKernelGGL((dense_kernel<false, float>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky, x->data, d_w, d_b, rows);
+            if (vec) SNNHIP_DENSE(true, float, x->data);
+            else SNNHIP_DENSE(false, float, x->data);
+#undef SNNHIP_DENSE
         }
         SNNHIP_CHECK_HIP(hipGetLastError());
         if (d.act == SNNHIP_DENSE_SOFTMAX) {

@@ -202,3 +202,41 @@ def test_stem_with_fused_reflect_pad_and_non_finite_neighbours(ctx):
     field = np.zeros_like(bad)
     field[20 - 4 : 20 + 5, 30 - 4 : 30 + 5] = True
     assert (bad == field).all() and not np.isnan(yi).any()
+
+
+# ---- conv2d_stem_f32.hip: the fp32 RGB stems (IC <= 4; 3x3 stride 1 / 2, 7x7 stride 2), 2 MFMAs per tap, weights in registers
+STEM32 = [(1, 224, 224, 3, 64, 3, 1), (2, 64, 64, 3, 32, 3, 2), (2, 75, 61, 3, 64, 7, 2), (1, 33, 47, 1, 32, 3, 1), (1, 40, 40, 4, 96, 7, 2), (3, 9, 11, 3, 32, 3, 2),
+          (1, 17, 130, 2, 64, 3, 1)]
+
+
+@pytest.mark.parametrize("shape", STEM32, ids=lambda c: "x".join(map(str, c)))
+def test_stem32_matches_oracle_and_tap_pair_kernel(ctx, monkeypatch, shape):
+    import shadernn_amd as snn
+
+    N, H, W, IC, OC, k, s = shape
+    x = _rand((N, H, W, IC), 41)
+    w = _rand((OC, IC, k, k), 42, 1.0 / np.sqrt(IC * k * k))
+    b = _rand((OC,), 43, 0.1)
+    bn = _bn(OC, 44)
+    pads = O.padding_offsets("same", k)
+    tol = dict(rtol=1e-4, atol=1e-4)
+
+    def run(pad_mode, act, bnp):
+        plan = snn.conv2d_plan(ctx, N, H, W, w, b, stride=s, pads=pads, pad_mode=pad_mode, act=act, bn=bnp)
+        y, d = plan(snn.Tensor.from_numpy(ctx, x)).numpy(), plan.describe()
+        plan.destroy()
+        return y, d
+
+    for pad_mode, act, use_bn in (("constant", "relu", True), ("reflect", "tanh", False), ("replicate", "leakyRelu", True)):
+        if pad_mode == "reflect" and min(H, W) <= k // 2:
+            continue
+        monkeypatch.delenv("SNNHIP_CONV_STEM", raising=False)
+        y, desc = run(pad_mode, act, bn if use_bn else None)
+        assert "conv2d_mfma_stem_f32" in desc, desc
+        want = O.conv2d(x, w, b, s, pads, pad_mode, act, 0.0, bn if use_bn else None)
+        assert y.shape == want.shape
+        np.testing.assert_allclose(y, want, err_msg=desc, **tol)
+        monkeypatch.setenv("SNNHIP_CONV_STEM", "0")
+        y2, desc2 = run(pad_mode, act, bn if use_bn else None)
+        assert "stem" not in desc2, desc2
+        np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-5, atol=2e-5)

@@ -91,6 +91,11 @@ void* snnhip_ctx_stream(snnhip_ctx* ctx);
 int snnhip_sync(snnhip_ctx* ctx);
 const char* snnhip_last_error(void);
 const char* snnhip_version(void);
+/* Options: the kernel-selection / fusion switches of DESIGN.md section 8 (names "SNNHIP_..."), process-wide.  A value set here wins over the
+ * environment variable of the same name (the fallback, read when a plan is created); value == NULL removes the override.  The reference has no
+ * counterpart: its shader variants are picked by MixedInferenceCore's options struct (core/inc/snn/core.h: dumpOutputs, mrtMode, weightMode ...). */
+int snnhip_set_option(const char* name, const char* value);
+const char* snnhip_get_option(const char* name); /* the effective value (override, else environment), or NULL */
 
 /* ---- tensors: NHWC fp32 in HBM ------------------------------------------------------------------- */
 

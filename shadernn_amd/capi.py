@@ -106,6 +106,8 @@ SIGNATURES = {
     "snnhip_sync": (C.c_int, [_P]),
     "snnhip_last_error": (C.c_char_p, []),
     "snnhip_version": (C.c_char_p, []),
+    "snnhip_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "snnhip_get_option": (C.c_char_p, [C.c_char_p]),
     "snnhip_tensor_alloc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "snnhip_tensor_wrap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "snnhip_tensor_free": (C.c_int, [_P]),
@@ -186,6 +188,17 @@ def load_library():
 def lib():
     load_library()
     return _lib
+
+
+def set_option(name, value):
+    """snnhip_set_option: override a kernel-selection / fusion switch for this process; None removes the override (the environment
+    variable of the same name is the fallback)."""
+    check(lib().snnhip_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name):
+    v = lib().snnhip_get_option(name.encode())
+    return None if v is None else v.decode()
 
 
 def check(rc):

@@ -5,6 +5,29 @@
 
 #include "snnhip_internal.h"
 
+#include <map>
+#include <mutex>
+#include <string>
+
+namespace snnhip {
+std::mutex g_optMutex;
+namespace {
+std::map<std::string, std::string>& opt_map() {
+    static std::map<std::string, std::string> m;
+    return m;
+}
+} // namespace
+const char* option(const char* name) {
+    {
+        std::lock_guard<std::mutex> lock(g_optMutex);
+        auto it = opt_map().find(name);
+        if (it != opt_map().end()) return it->second.c_str(); // (stable until the same name is set again)
+    }
+    return getenv(name);
+}
+} // namespace snnhip
+
+
 namespace snnhip {
 
 static thread_local char g_err[1024] = "";
@@ -118,6 +141,15 @@ extern "C" {
 
 const char* snnhip_last_error(void) { return g_err; }
 const char* snnhip_version(void) { return "snnhip 0.1 (gfx950)"; }
+
+int snnhip_set_option(const char* name, const char* value) {
+    SNNHIP_REQUIRE(name && strncmp(name, "SNNHIP_", 7) == 0, "set_option: option names start with SNNHIP_");
+    std::lock_guard<std::mutex> lock(g_optMutex);
+    if (value) opt_map()[name] = value;
+    else opt_map().erase(name);
+    return SNNHIP_OK;
+}
+const char* snnhip_get_option(const char* name) { return name ? snnhip::option(name) : nullptr; }
 
 static int ctx_create_common(int device, hipStream_t stream, bool own, snnhip_ctx** out) {
     SNNHIP_REQUIRE(out != nullptr, "ctx_create: null out");

@@ -290,7 +290,7 @@ decltype(Conv1x1StreamPlan::kernel) pick16(bool simple) {
 // SNNHIP_E_UNSUPPORTED when the layer is not a large fp32 pointwise stream (the caller then takes the general MFMA kernel).
 // SNNHIP_CONV_1X1=0 switches the kernel off (A/B runs, tests of the general kernel on the same shapes), =2 also takes few-tile deep-K layers.
 int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
-    const char* sw = getenv("SNNHIP_CONV_1X1"); // 0: off; 2: also take few-tile deep-K layers (parity tests at oracle-sized shapes)
+    const char* sw = snnhip::option("SNNHIP_CONV_1X1"); // 0: off; 2: also take few-tile deep-K layers (parity tests at oracle-sized shapes)
     if (sw && atoi(sw) == 0) return SNNHIP_E_UNSUPPORTED;
     if (g.normMean) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
     const bool f16 = g.dtype == SNNHIP_F16;
@@ -308,7 +308,7 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     // meets a handful of tiles (checked after the column width is known)
     // columns per block: the widest of 96 / 64 / 32 that pads the channel count by at most a third and whose weight slice fits the LDS budget
     size_t ldsCap = 80 * 1024;
-    if (const char* e = getenv("SNNHIP_CONV_1X1_LDS_KB")) ldsCap = static_cast<size_t>(atoi(e)) * 1024; // experiments
+    if (const char* e = snnhip::option("SNNHIP_CONV_1X1_LDS_KB")) ldsCap = static_cast<size_t>(atoi(e)) * 1024; // experiments
     int NT = 0;
     for (int c = 3; c >= 1 && !NT; --c) {
         const int ocp = (g.OC + 32 * c - 1) / (32 * c) * (32 * c);

@@ -149,7 +149,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
                                     snnhip_plan** out) {
     // routing: GEMM-shaped layers only (north star: "MFMA used only for the dense 3x3/1x1 GEMM-shaped convs");
     // SNNHIP_CONV=generic|mfma forces a path (tests exercise both on the same inputs)
-    const char* force = getenv("SNNHIP_CONV");
+    const char* force = snnhip::option("SNNHIP_CONV");
     if (force && strcmp(force, "generic") == 0) return SNNHIP_E_UNSUPPORTED;
     const bool forced = force && strcmp(force, "mfma") == 0;
     // measured (tools/bench_layers.py): even IC = 3 layers (one 8-channel chunk, 5/8 of it padding) run 1.4-2.3x faster here than
@@ -173,9 +173,9 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     const int CH = f16 ? 8 : 4;                                  // channels per 16-byte slot
     int C8 = g.IC <= 2 * CH ? 1 : 2;
     // tap-pair mode (C8 = 0, see the kernel): channel-thin inputs with at least two taps; SNNHIP_CONV_PAIR=0 keeps the channel-chunk path
-    const char* pairEnv = getenv("SNNHIP_CONV_PAIR");
+    const char* pairEnv = snnhip::option("SNNHIP_CONV_PAIR");
     if (g.IC <= CH && taps >= 2 && !(pairEnv && atoi(pairEnv) == 0) && !preNorm) C8 = 0;
-    if (const char* e = getenv("SNNHIP_CONV_C8"))
+    if (const char* e = snnhip::option("SNNHIP_CONV_C8"))
         if (taps == 1 && g.sh == 1 && g.sw == 1 && (atoi(e) == 4 || atoi(e) == 8) && g.IC >= 2 * CH * atoi(e)) C8 = atoi(e);
     int Qs = C8 ? 2 * C8 : 1;                                    // 16-byte slots per staged pixel
     int ICc = C8 ? 2 * CH * C8 : CH;                             // channels per LDS chunk: 16 fp32 / 32 fp16 (64 bytes per pixel either way)
@@ -230,8 +230,8 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     // (fp32 also below 80 KB: with a 61 KB double buffer only two 128-pixel blocks fit a CU and the ResNet 56x56 / 7x7 3x3 layers averaged 1.2
     // waves per SIMD; at 48 KB the graph is 1.7 % faster, at 24 KB U-Net loses 4 %.  fp16 layers were 1-2 % slower with the lower bound.)
     size_t narrowAbove = (f16 ? 80 : 48) * 1024;
-    if (const char* e = getenv("SNNHIP_CONV_NARROW_KB")) narrowAbove = static_cast<size_t>(atoi(e)) * 1024; // experiments
-    if (C8 == 2 && (best < 0 || bestLds > narrowAbove) && !getenv("SNNHIP_CONV_WIDE_CHUNKS")) {
+    if (const char* e = snnhip::option("SNNHIP_CONV_NARROW_KB")) narrowAbove = static_cast<size_t>(atoi(e)) * 1024; // experiments
+    if (C8 == 2 && (best < 0 || bestLds > narrowAbove) && !snnhip::option("SNNHIP_CONV_WIDE_CHUNKS")) {
         C8 = 1;
         Qs = 2;
         ICc = 2 * CH;
@@ -292,7 +292,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
             wideSplit = true;
         }
     }
-    if (const char* e = getenv("SNNHIP_CONV_BN")) // experiments: force the block's output-channel width
+    if (const char* e = snnhip::option("SNNHIP_CONV_BN")) // experiments: force the block's output-channel width
         if (atoi(e) == 32 || atoi(e) == 64 || atoi(e) == 128) BN = atoi(e);
     if (ov.bn) BN = ov.bn;
     p.OCp = round_up(g.OC, BN);
@@ -309,7 +309,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
         const int cap = wideSplit ? p.nChunks / 2 : p.nChunks / 4; // the wide-block rule above relies on the split to fill the chip
         if (want > cap) want = cap;
         if (wideSplit) while (want & (want - 1)) want &= want - 1; // 3x3 layers: 3- / 5-way splits measured 10-25 % behind 2 / 4
-        if (const char* e = getenv("SNNHIP_CONV_SPLITK")) want = atoi(e);
+        if (const char* e = snnhip::option("SNNHIP_CONV_SPLITK")) want = atoi(e);
         if (ov.splitK) want = ov.splitK;
         if (want < 1 || g.act == SNNHIP_ACT_SILU_QUIRK) want = 1; // the quirk couples 4 adjacent pixels in the epilogue
         if (want > p.nChunks) want = p.nChunks;
@@ -317,7 +317,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
         p.splitK = up_div(p.nChunks, p.chunksPerSplit);
     }
     // fp16 output tile through LDS (see the kernel's epilogue): needs whole 8-channel vectors and the direct (non split-K) epilogue
-    p.ldsEpi = (f16 && p.splitK == 1 && g.OC % 8 == 0 && !getenv("SNNHIP_CONV_DIRECT_STORE")) ? 1 : 0;
+    p.ldsEpi = (f16 && p.splitK == 1 && g.OC % 8 == 0 && !snnhip::option("SNNHIP_CONV_DIRECT_STORE")) ? 1 : 0;
     size_t ldsNeed = p.chunksPerSplit == 1 ? L.ldsBytes / 2 : L.ldsBytes; // one chunk per block: no second staging buffer
     p.normMean = g.normMean; p.normMul = g.normMul; p.normBeta = g.normBeta;
     p.normAc = make_act_cfg(preNorm ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
@@ -437,10 +437,10 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     // flops than the implicit GEMM below.  SNNHIP_CONV=wino forces it for every eligible shape, SNNHIP_CONV=mfma / SNNHIP_CONV_WINO=0 keep
     // the direct kernel (tests run both on the same inputs).
     {
-        const char* force = getenv("SNNHIP_CONV");
-        const char* w = getenv("SNNHIP_CONV_WINO");
+        const char* force = snnhip::option("SNNHIP_CONV");
+        const char* w = snnhip::option("SNNHIP_CONV_WINO");
         const bool forced = force && strcmp(force, "wino") == 0;
-        const bool allowed = !force && !(w && atoi(w) == 0) && !getenv("SNNHIP_CONV_BN") && !getenv("SNNHIP_CONV_C8") && g.IC >= 32 && g.OC >= 32 && !g.normMean;
+        const bool allowed = !force && !(w && atoi(w) == 0) && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_C8") && g.IC >= 32 && g.OC >= 32 && !g.normMean;
         if (forced || allowed) {
             const int rc = make_conv2d_wino_plan(ctx, g, w_oihw, epi4, out);
             if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
@@ -455,10 +455,10 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     // fp16 3x3 stride-1 layers on large maps: the 4 x 2 register-block kernel of conv2d_wide_f16.hip (SNNHIP_CONV=wide forces it for every
     // eligible shape, SNNHIP_CONV=mfma / SNNHIP_CONV_WIDE=0 keep the 128-pixel kernel)
     {
-        const char* force = getenv("SNNHIP_CONV");
-        const char* w = getenv("SNNHIP_CONV_WIDE");
+        const char* force = snnhip::option("SNNHIP_CONV");
+        const char* w = snnhip::option("SNNHIP_CONV_WIDE");
         const bool forced = force && strcmp(force, "wide") == 0;
-        const bool allowed = !force && !(w && atoi(w) == 0) && !getenv("SNNHIP_CONV_BN") && !getenv("SNNHIP_CONV_SPLITK") && !getenv("SNNHIP_CONV_C8");
+        const bool allowed = !force && !(w && atoi(w) == 0) && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_SPLITK") && !snnhip::option("SNNHIP_CONV_C8");
         if (forced || allowed) {
             const int rc = make_conv2d_wide_plan(ctx, g, w_oihw, epi4, out);
             if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
@@ -466,12 +466,12 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     }
     // pointwise layers (fp32, and fp16 with OC % 8 == 0) stream through conv1x1_stream.hip (no halo tile to stage); forcing a kernel or a
     // configuration skips it
-    if (!getenv("SNNHIP_CONV") && !getenv("SNNHIP_CONV_BN") && !getenv("SNNHIP_CONV_SPLITK") && !getenv("SNNHIP_CONV_C8")) {
+    if (!snnhip::option("SNNHIP_CONV") && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_SPLITK") && !snnhip::option("SNNHIP_CONV_C8")) {
         const int rc = make_conv1x1_stream_plan(ctx, g, w_oihw, epi4, out);
         if (rc != SNNHIP_E_UNSUPPORTED) return rc;
     }
-    const char* tune = getenv("SNNHIP_CONV_TUNE");
-    if (!tune || atoi(tune) == 0 || getenv("SNNHIP_CONV_BN") || getenv("SNNHIP_CONV_SPLITK")) return make_conv2d_mfma_plan_ex(ctx, g, w_oihw, epi4, MfmaOverride(), out);
+    const char* tune = snnhip::option("SNNHIP_CONV_TUNE");
+    if (!tune || atoi(tune) == 0 || snnhip::option("SNNHIP_CONV_BN") || snnhip::option("SNNHIP_CONV_SPLITK")) return make_conv2d_mfma_plan_ex(ctx, g, w_oihw, epi4, MfmaOverride(), out);
     // winners are cached per (device, full geometry incl. the output extent, epilogue shape); the cache is shared by every context of the
     // process, so it is guarded (plan creation may run on several host threads, one per device)
     char key[320];

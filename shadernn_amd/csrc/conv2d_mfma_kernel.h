@@ -543,7 +543,7 @@ KernelFn pick_kernel(int c8, int r, bool simple, int taps) {
 #define SNNHIP_PICK_T(C8_, R_, T_)                                                                                                          \
     if (taps == T_ && c8 == C8_ && r == R_)                                                                                                   \
         return simple ? conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, true, true, T_> : conv2d_mfma_kernel<WM, WN, MT, NT, C8_, R_, false, true, T_>;
-        if (!getenv("SNNHIP_CONV_ROLLED")) {
+        if (!snnhip::option("SNNHIP_CONV_ROLLED")) {
             SNNHIP_PICK_T(1, 3, 9)
             SNNHIP_PICK_T(2, 3, 9)
             SNNHIP_PICK_T(2, 5, 9)

@@ -216,7 +216,7 @@ RowfoldFn pick_rowfold(int ics, bool simple) {
 
 int make_conv2d_rowfold_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     // eligibility: half tensors, square odd kernel 5 / 7 / 9, stride 1, k * OC <= 32, IC = 16 or 32 (the weights of a lane stay in registers)
-    const char* force = getenv("SNNHIP_CONV");
+    const char* force = snnhip::option("SNNHIP_CONV");
     if (force && strcmp(force, "rowfold") != 0) return SNNHIP_E_UNSUPPORTED;
     if (g.normMean && !act_is_simple(g.normAct)) return SNNHIP_E_UNSUPPORTED;
     if (g.dtype != SNNHIP_F16 || g.kh != g.kw || (g.kh != 5 && g.kh != 7 && g.kh != 9) || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;

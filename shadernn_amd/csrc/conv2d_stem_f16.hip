@@ -218,9 +218,9 @@ int make_conv2d_stem_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (g.dtype != SNNHIP_F16 || g.kh != kK || g.kw != kK || g.sh != 1 || g.sw != 1 || g.IC > 4 || g.OC % 32 != 0) return SNNHIP_E_UNSUPPORTED;
     if (g.addAct >= 0 || (g.preMode && g.preShift) || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED;
     if (g.normMean) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
-    if (const char* e = getenv("SNNHIP_CONV_STEM"))
+    if (const char* e = snnhip::option("SNNHIP_CONV_STEM"))
         if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
-    if (const char* f = getenv("SNNHIP_CONV"))
+    if (const char* f = snnhip::option("SNNHIP_CONV"))
         if (strcmp(f, "stem") != 0) return SNNHIP_E_UNSUPPORTED; // another kernel is being forced
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     if (outCount >= 2147483647.0 * 4) return SNNHIP_E_UNSUPPORTED;

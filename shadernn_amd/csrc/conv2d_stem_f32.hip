@@ -173,9 +173,9 @@ Stem32Fn pick_stem32(bool simple) {
 int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.dtype != SNNHIP_F32 || g.kh != g.kw || g.sh != g.sw || g.IC > 4 || g.OC % 32 != 0) return SNNHIP_E_UNSUPPORTED;
     if (g.addAct >= 0 || g.preMode || g.normMean || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED; // (the quirk couples 4 adjacent pixels)
-    if (const char* e = getenv("SNNHIP_CONV_STEM"))
+    if (const char* e = snnhip::option("SNNHIP_CONV_STEM"))
         if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
-    if (const char* f = getenv("SNNHIP_CONV"))
+    if (const char* f = snnhip::option("SNNHIP_CONV"))
         if (strcmp(f, "stem") != 0) return SNNHIP_E_UNSUPPORTED; // another kernel is being forced
     const bool simple = act_is_simple(g.act);
     Stem32Fn fn = nullptr;

@@ -226,7 +226,7 @@ int make_conv2d_thin_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (g.preMode) return SNNHIP_E_UNSUPPORTED; // the fused-Pad address path exists in the MFMA kernel only
     if (g.normMean) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
 
-    const char* force = getenv("SNNHIP_CONV");
+    const char* force = snnhip::option("SNNHIP_CONV");
     if (force && strcmp(force, "thin") != 0) return SNNHIP_E_UNSUPPORTED; // generic / mfma forced
     if (g.OC > 4 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
     if (!force && g.IC < 8) return SNNHIP_E_UNSUPPORTED; // a handful of input channels: the VALU kernel is as good

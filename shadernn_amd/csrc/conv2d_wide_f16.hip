@@ -324,14 +324,14 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     const double inCount = static_cast<double>(g.N) * (g.preMode ? g.srcH : g.H) * (g.preMode ? g.srcW : g.W) * g.IC;
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
-    const char* force = getenv("SNNHIP_CONV");
+    const char* force = snnhip::option("SNNHIP_CONV");
     const bool forced = force && strcmp(force, "wide") == 0;
 
     // block shape: 256 px x 128 oc when the channels fill it, else 512 px x 64 / 32 oc
     int WM = 4, NT = 2, BN = 64;
     if (g.OC % 128 == 0) { WM = 2; NT = 2; BN = 128; }
     else if (g.OC % 64 != 0) { NT = 1; BN = 32; }
-    if (const char* e = getenv("SNNHIP_WIDE_BN")) { // experiments
+    if (const char* e = snnhip::option("SNNHIP_WIDE_BN")) { // experiments
         const int v = atoi(e);
         if (v == 128 && g.OC % 128 == 0) { WM = 2; NT = 2; BN = 128; }
         if (v == 64 && g.OC % 64 == 0) { WM = 4; NT = 2; BN = 64; }

@@ -348,7 +348,7 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     const int tilesW = up_div(g.OW, 2), tilesH = up_div(g.OH, 2);
     // OPB = 1 (default): 256-thread blocks of 32 output channels, two per CU; SNNHIP_WINO_OPB=2: 512-thread blocks of 64 channels, one per CU
     int opb = 1;
-    if (const char* e = getenv("SNNHIP_WINO_OPB")) opb = atoi(e) == 2 ? 2 : 1;
+    if (const char* e = snnhip::option("SNNHIP_WINO_OPB")) opb = atoi(e) == 2 ? 2 : 1;
     const int ocPerBlock = 32 * opb, kUFloats = 4096 * opb;
     int best[3] = {0, 2, 4};
     double bestCost = 1e300;
@@ -394,7 +394,7 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     const int cus = (ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) * (3 - opb);
     const int blocks = p.tilesX * p.tilesY * up_div(g.N, TB) * p.OCblocks;
     int splitK = 1;
-    if (const char* e = getenv("SNNHIP_CONV_SPLITK")) splitK = std::max(1, atoi(e));
+    if (const char* e = snnhip::option("SNNHIP_CONV_SPLITK")) splitK = std::max(1, atoi(e));
     else
         while (blocks * splitK * 2 <= cus && splitK * 2 <= p.nChunks / 2) splitK *= 2; // doubling must still fit one round of blocks
     splitK = std::min(splitK, p.nChunks);

@@ -181,7 +181,7 @@ struct DepthwisePlan : ConvPlanBase {
             // output rows per thread: 2 for stride 1 while that still leaves two full blocks per CU (144 ch @56x56 b32: 36.5 -> 29.9 us fp32; the
             // 14x14 layers lose parallelism instead: fp16 8.5 -> 9.5 us); SNNHIP_DW_ROWS1 pins 1
             const size_t pairs = static_cast<size_t>(p.N) * ((p.OH + 1) / 2) * ((p.OW + 3) / 4) * p.C4;
-            const int rows = (p.sh == 1 && !getenv("SNNHIP_DW_ROWS1") && pairs >= static_cast<size_t>(ctx->props.multiProcessorCount) * 512) ? 2 : 1;
+            const int rows = (p.sh == 1 && !snnhip::option("SNNHIP_DW_ROWS1") && pairs >= static_cast<size_t>(ctx->props.multiProcessorCount) * 512) ? 2 : 1;
             const size_t total4 = static_cast<size_t>(p.N) * ((p.OH + rows - 1) / rows) * ((p.OW + 3) / 4) * p.C4;
             size_t blocks4 = (total4 + 255) / 256;
             if (blocks4 > cap) blocks4 = cap;

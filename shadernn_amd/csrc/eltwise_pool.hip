@@ -698,7 +698,7 @@ struct InstanceNormAddPlan : snnhip_plan {
 int make_instancenorm_add_plan(snnhip_ctx* ctx, snnhip_plan* normPlan, snnhip_plan* addPlan, bool normIsFirstInput, snnhip_plan** out) {
     auto* q = dynamic_cast<InstanceNormPlan*>(normPlan);
     auto* ad = dynamic_cast<EltwisePlanBase*>(addPlan);
-    if (!q || !ad || ad->mode != 0 || getenv("SNNHIP_NO_ADD_FUSION")) return SNNHIP_E_UNSUPPORTED;
+    if (!q || !ad || ad->mode != 0 || snnhip::option("SNNHIP_NO_ADD_FUSION")) return SNNHIP_E_UNSUPPORTED;
     if (ad->d.N != q->d.N || ad->d.H != q->d.H || ad->d.W != q->d.W || ad->d.C != q->d.C) return SNNHIP_E_UNSUPPORTED;
     auto* plan = new InstanceNormAddPlan();
     plan->ctx = ctx;

@@ -1005,7 +1005,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
     // (206 us vs 123+45 us per 1080p frame) because its per-wave dependency chain starves the matrix pipe.
     // ---- rule E: Conv2D (MFMA kernel) + Add -> one launch, the residual is added in the convolution's epilogue.  The fused plan takes TWO
     // inputs, snnhip_plan_run_n(plan, {conv input, residual}, 2, out), so it is returned as is instead of being wrapped into a ChainPlan.
-    if (n == 2 && !getenv("SNNHIP_NO_ADD_FUSION")) {
+    if (n == 2 && !snnhip::option("SNNHIP_NO_ADD_FUSION")) {
         auto* cv = dynamic_cast<ConvPlanBase*>(plans[0]);
         auto* ad = dynamic_cast<EltwisePlanBase*>(plans[1]);
         if (cv && ad && ad->mode == 0 && !cv->depthwise && cv->g.addAct < 0 && cv->desc.rfind("conv2d_mfma", 0) == 0 && cv->g.act != SNNHIP_ACT_SILU_QUIRK &&
@@ -1016,7 +1016,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             return make_conv2d_mfma_plan(ctx, g2, cv->w_oihw.data(), cv->epi4, out);
         }
     }
-    const char* mode = getenv("SNNHIP_ESPCN_FUSION");
+    const char* mode = snnhip::option("SNNHIP_ESPCN_FUSION");
     const bool allowStream = mode && strcmp(mode, "stream") == 0;
     auto* chain = new ChainPlan();
     chain->ctx = ctx;
@@ -1098,7 +1098,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             const int K1 = g0.kh, taps1 = K1 * K1, ks1 = (taps1 + 3) / 4;
             st.kind = ChainPlan::FUSED_A;
             st.k1 = K1;
-            const char* amode = getenv("SNNHIP_ESPCN_A");
+            const char* amode = snnhip::option("SNNHIP_ESPCN_A");
             st.wino = !(amode && strcmp(amode, "direct") == 0);
             const int aTW = st.wino ? WinoTile::TW : A_TW, aTH = st.wino ? W_TH : A_TH;
             st.a = FusedAParams{g0.N, g0.H, g0.W, up_div(g0.W, aTW), up_div(g0.H, aTH), make_act_cfg(g0.act, g0.leaky), make_act_cfg(c1->g.act, c1->g.leaky)};
@@ -1175,7 +1175,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             // Variants measured in round 1 and removed (DESIGN.md section 5 keeps the findings): persistent + LDS-DMA double buffering 56-98 us,
             // two rows per thread 36 us (same as the default: neither LDS bandwidth nor the scalar weight loads were the limiter), persistent
             // with register prefetch 50 us, persistent Winograd with a quad-granular prefetch pipeline 50 us.
-            const char* bmode = getenv("SNNHIP_ESPCN_B");
+            const char* bmode = snnhip::option("SNNHIP_ESPCN_B");
             st.wino = bmode && strcmp(bmode, "wino") == 0;
             const int bTW = st.wino ? 64 : B_TW, bTH = st.wino ? 16 : B_TH;
             st.b = FusedBParams{g0.N, g0.H, g0.W, up_div(g0.W, bTW), up_div(g0.H, bTH), make_act_cfg(g0.act, g0.leaky), 0u, 0u};
@@ -1228,7 +1228,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             ++fusedCount;
         } else if (auto* up = dynamic_cast<UpsamplePlanBase*>(plans[i]);
                    up && up->d.mode == SNNHIP_UPSAMPLE_NEAREST && up->d.scale == 2.0f && up->OH == 2 * up->d.H && up->OW == 2 * up->d.W && i + 1 < n &&
-                   !getenv("SNNHIP_NO_PAD_FUSION")) {
+                   !snnhip::option("SNNHIP_NO_PAD_FUSION")) {
             // ---- rule D with a nearest x2 UpSampling2D in front: [UpSampling2D, Pad, Conv2D] or [UpSampling2D, Conv2D] -> one convolution launch
             auto* pd2 = dynamic_cast<PadPlanBase*>(plans[i + 1]);
             auto* cv = dynamic_cast<ConvPlanBase*>(plans[i + (pd2 ? 2 : 1) < n ? i + (pd2 ? 2 : 1) : i]);
@@ -1262,7 +1262,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.bytes = st.plain->bytes;
         } else if (auto* pd = dynamic_cast<PadPlanBase*>(plans[i]); pd && c1 && !c1->depthwise && c1->g.preMode == 0 && c1->g.N == pd->d.N &&
                    c1->g.H == pd->OH && c1->g.W == pd->OW && c1->g.IC == pd->d.C &&
-                   (c1->desc.rfind("conv2d_mfma", 0) == 0 || c1->desc.rfind("conv2d_rowfold", 0) == 0) && !getenv("SNNHIP_NO_PAD_FUSION")) {
+                   (c1->desc.rfind("conv2d_mfma", 0) == 0 || c1->desc.rfind("conv2d_rowfold", 0) == 0) && !snnhip::option("SNNHIP_NO_PAD_FUSION")) {
             // ---- rule D: Pad + Conv2D -> the convolution stages its tiles straight from the unpadded tensor ("reflect Pad,
             // better fused into the following conv's load stage"); only the MFMA kernel has the pre-pad address path, so a convolution that was
             // routed to another kernel (the channel-thin image-producing layers) keeps its separate Pad launch
@@ -1310,7 +1310,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
     // one step.  Parity-tested, but not a win as measured (Candy 720p fp16: batch 8 9.08 -> 9.15 ms, batch 1 1.50 -> 1.70 ms): accumulating the
     // tile statistics costs the convolution's epilogue 45-125 us per layer at batch 8 where the sweep it replaces costs 40 us, and at batch 1
     // the two fold launches outweigh a sweep that reads the tensor out of the MALL.
-    const char* normFusion = getenv("SNNHIP_NORM_FUSION");
+    const char* normFusion = snnhip::option("SNNHIP_NORM_FUSION");
     for (size_t k = 0; rc == SNNHIP_OK && k + 1 < chain->steps.size() && normFusion && atoi(normFusion) != 0; ++k) {
         ChainPlan::Step &a = chain->steps[k], &b = chain->steps[k + 1];
         if (a.kind != ChainPlan::PLAIN || b.kind != ChainPlan::PLAIN) continue;
@@ -1357,7 +1357,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
     }
     // ---- rule I: an InstanceNorm step followed by a convolution step (as given, or built by rule D above) whose kernel can normalise in its
     // staging (today: conv2d_mfma's fp16 kernels).  SNNHIP_NO_NORM_FOLD keeps the norm's own normalise sweep.
-    for (size_t k = 0; rc == SNNHIP_OK && k + 1 < chain->steps.size() && !getenv("SNNHIP_NO_NORM_FOLD"); ++k) {
+    for (size_t k = 0; rc == SNNHIP_OK && k + 1 < chain->steps.size() && !snnhip::option("SNNHIP_NO_NORM_FOLD"); ++k) {
         ChainPlan::Step &a = chain->steps[k], &b = chain->steps[k + 1];
         if (a.kind != ChainPlan::PLAIN || b.kind != ChainPlan::PLAIN) continue;
         snnhip_instancenorm_desc nd;

@@ -307,8 +307,8 @@ IrbFn pick_irb(int ncb) {
 
 // expand / dw / project: the three per-layer plans (borrowed; only read here); add: the residual Add plan or nullptr.
 int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan, snnhip_plan* projectPlan, snnhip_plan* addPlan, snnhip_plan** out) {
-    if (getenv("SNNHIP_NO_IRB_FUSION")) return SNNHIP_E_UNSUPPORTED;
-    const char* irbMode = getenv("SNNHIP_IRB_FUSION"); // "all": also the 14x14 / 7x7 blocks, where the separate layers are faster (tools/bench_irb.py)
+    if (snnhip::option("SNNHIP_NO_IRB_FUSION")) return SNNHIP_E_UNSUPPORTED;
+    const char* irbMode = snnhip::option("SNNHIP_IRB_FUSION"); // "all": also the 14x14 / 7x7 blocks, where the separate layers are faster (tools/bench_irb.py)
     auto* ce = dynamic_cast<ConvPlanBase*>(expandPlan);
     auto* cd = dynamic_cast<ConvPlanBase*>(dwPlan);
     auto* cp = dynamic_cast<ConvPlanBase*>(projectPlan);

@@ -137,6 +137,10 @@ namespace snnhip {
 std::vector<float> make_epilogue_table(int OC, int padTo, int useBias, const float* bias, int useBN, const float* beta,
                                        const float* gamma, const float* mean, const float* var);
 
+// Options registry: the one place a switch is read.  A value set through snnhip_set_option() (C-ABI) wins; otherwise the environment variable of
+// the same name, looked up at the call (tests flip switches between plan creations).  DESIGN.md section 8 lists every name.
+const char* option(const char* name);
+
 struct ConvGeom {
     int N, H, W, IC, OC, kh, kw, sh, sw;
     int padx, pady; // already resolved: 1x1 => 0 (vk_conv2d_1x1.comp:74-75); else padT / padL (conv2dVulkan.cpp:183-184)

@@ -50,3 +50,27 @@ def test_errors_are_reported_not_swallowed(built):
         assert e.code in (-1, -2)
     else:
         raise AssertionError("Context(0) succeeded without a GPU")
+
+
+def test_options_registry_overrides_the_environment(built, monkeypatch):
+    """snnhip_set_option / snnhip_get_option (no GPU needed): an override wins over the environment variable of the same name, NULL removes it, names
+    outside the SNNHIP_ namespace are rejected."""
+    import shadernn_amd as snn
+
+    snn.load_library()
+    monkeypatch.delenv("SNNHIP_CONV", raising=False)
+    assert snn.get_option("SNNHIP_CONV") is None
+    monkeypatch.setenv("SNNHIP_CONV", "generic")
+    assert snn.get_option("SNNHIP_CONV") == "generic"
+    snn.set_option("SNNHIP_CONV", "mfma")
+    try:
+        assert snn.get_option("SNNHIP_CONV") == "mfma"
+    finally:
+        snn.set_option("SNNHIP_CONV", None)
+    assert snn.get_option("SNNHIP_CONV") == "generic"
+    try:
+        snn.set_option("PATH", "x")
+    except snn.SnnHipError as e:
+        assert e.code == -1
+    else:
+        raise AssertionError("set_option accepted a name outside SNNHIP_")

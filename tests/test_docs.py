@@ -20,6 +20,7 @@ def test_every_environment_switch_is_documented():
             with open(path, encoding="utf-8") as f:
                 src = f.read()
             names.update(re.findall(r'getenv\("(SNN[A-Z0-9_]+)"\)', src))
+            names.update(re.findall(r'option\("(SNN[A-Z0-9_]+)"\)', src))  # snnhip::option(): the options registry (override, else environment)
             names.update(re.findall(r'environ(?:\.get)?\(\s*"(SNN[A-Z0-9_]+)"', src))
     assert names, "no switches found: the scan is broken"
     missing = sorted(n for n in names if n not in design)

@@ -283,7 +283,13 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
         float s1[CV], s2[CV];
 #pragma unroll
         for (int k = 0; k < CV; ++k) s1[k] = s2[k] = 0.0f;
-        auto consume = [&](const float (&v)[CV], size_t p) {
+        // residual of pixel p (rule H): where it sits in the (possibly smaller) residual tensor, or -1 outside it.  32-bit arithmetic: H * W < 2^31.
+        auto res_pixel = [&](size_t p) -> long {
+            if (!ragged) return static_cast<long>(p);
+            const unsigned pu = static_cast<unsigned>(p), oy = pu / static_cast<unsigned>(d.W), ox = pu - oy * static_cast<unsigned>(d.W);
+            return (static_cast<int>(oy) < ra.H && static_cast<int>(ox) < ra.W) ? static_cast<long>(oy) * ra.W + ox : -1;
+        };
+        auto consume = [&](const float (&v)[CV], size_t p, const float (&rv)[CV], long rp) {
             if (STAGE == 0) {
 #pragma unroll
                 for (int k = 0; k < CV; ++k) {
@@ -296,16 +302,7 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
 #pragma unroll
                 for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, (v[k] - piv[k]) * mul[k] + bt[k]);
                 if (res) {
-                    float rv[CV];
-                    size_t rp = p;
-                    bool inside = true;
-                    if (ragged) {
-                        const int oy = static_cast<int>(p / d.W), ox = static_cast<int>(p - static_cast<size_t>(oy) * d.W);
-                        inside = oy < ra.H && ox < ra.W;
-                        rp = static_cast<size_t>(oy) * ra.W + ox;
-                    }
-                    if (inside) {
-                        ldv<T, CV>(res + (static_cast<size_t>(n) * ra.H * ra.W + rp) * d.C + c, rv);
+                    if (rp >= 0) {
 #pragma unroll
                         for (int k = 0; k < CV; ++k) o[k] = act1(ra.act, ra.leaky, static_cast<float>(static_cast<T>(o[k])) + rv[k]);
                     } else {
@@ -316,19 +313,40 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
                 stv<T, CV>(yn + p * d.C + c, o);
             }
         };
+        const T* const resn = (STAGE == 2 && res) ? res + static_cast<size_t>(n) * ra.H * ra.W * d.C + c : nullptr;
         if (cok) {
             size_t p = p0 + pl;
             for (; p + static_cast<size_t>(U - 1) * PL < p1; p += static_cast<size_t>(U) * PL) {
-                float v[U][CV];
+                float v[U][CV], rv[U][CV];
+                long rp[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) ldv<T, CV>(xn + (p + static_cast<size_t>(u) * PL) * d.C + c, v[u]);
+                if (STAGE == 2 && res) { // the residual loads travel with the tensor's (one latency per batch, not one per pixel)
 #pragma unroll
-                for (int u = 0; u < U; ++u) consume(v[u], p + static_cast<size_t>(u) * PL); // same pixel order as the plain loop
+                    for (int u = 0; u < U; ++u) {
+                        rp[u] = res_pixel(p + static_cast<size_t>(u) * PL);
+#pragma unroll
+                        for (int k = 0; k < CV; ++k) rv[u][k] = 0.0f;
+                        if (rp[u] >= 0) ldv<T, CV>(resn + static_cast<size_t>(rp[u]) * d.C, rv[u]);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) rp[u] = -1;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) consume(v[u], p + static_cast<size_t>(u) * PL, rv[u], rp[u]); // same pixel order as the plain loop
             }
             for (; p < p1; p += PL) {
-                float v[CV];
+                float v[CV], rv[CV];
+                long rp = -1;
                 ldv<T, CV>(xn + p * d.C + c, v);
-                consume(v, p);
+#pragma unroll
+                for (int k = 0; k < CV; ++k) rv[k] = 0.0f;
+                if (STAGE == 2 && res) {
+                    rp = res_pixel(p);
+                    if (rp >= 0) ldv<T, CV>(resn + static_cast<size_t>(rp) * d.C, rv);
+                }
+                consume(v, p, rv, rp);
             }
         }
         if (STAGE == 0) {

@@ -446,9 +446,10 @@ def main():
         if kernels:
             # the same bound launch by launch, on the FUSED graph's own accounting (a fused step counts its inputs and outputs once): fusion cannot
             # beat this one, and a compute-bound layer is not hidden behind the graph's HBM total
-            per_launch = sum(k["launches"] * max(k["flops"] / peak_tf / 1e12, k["bytes"] / PEAK_HBM_GBPS / 1e9) for k in kernels) / args.steps
-            out["sum_of_launch_rooflines_ms"] = 1e3 * per_launch
-            out["frac_of_sum_of_launch_rooflines"] = 1e3 * per_launch / out["ms_per_step"]
+            sampled = len([i for i in range(args.steps) if i % every == 0])  # steps whose launches carry event pairs (--event-every)
+            per_step = sum(k["launches"] * max(k["flops"] / peak_tf / 1e12, k["bytes"] / PEAK_HBM_GBPS / 1e9) for k in kernels) / sampled
+            out["sum_of_launch_rooflines_ms"] = 1e3 * per_step
+            out["frac_of_sum_of_launch_rooflines"] = 1e3 * per_step / out["ms_per_step"]
         if kernels:
             dom = max(kernels, key=lambda k: k["avg_us"])
             t = dom["avg_us"] * 1e-6

@@ -7,18 +7,18 @@
 // clipped taps = zero padding of the EXPANDED tensor, bias -> BN -> activation after each stage, vk_add.comp:41); BN is folded to
 // (scale, shift) per channel on the host.
 //
-// One block = 256 threads = 4 waves, one output tile of TH x TW pixels (8x16 for stride 1, 8x8 for stride 2 and for the 7x7 / 14x14 maps):
-//   x tile      the (TH-1)s+3 x (TW-1)s+3 halo tile of the block input, all C channels, staged ONCE in LDS as channel-quad planes
+// One WAVE = one output tile of 2G x 8 pixels (G = 2 for stride 1, 1 for stride 2), no barrier in the kernel (see irb_wave_kernel):
+//   x tile      the wave's (2G-1)s+3 x 7s+3 halo tile of the block input, all C channels, staged once in the wave's LDS slice as channel-quad planes
 //               [quad][pixel] float4 (consecutive pixels = consecutive 16-byte slots, planes 256-byte aligned: conflict-free ds_read_b128 for
 //               the 16 pixels x 4 quads of an MFMA operand); it also supplies the residual at the end
-//   loop over 16-channel slices c of the expanded tensor, software-pipelined so that ONE barrier per slice suffices:
-//     E(c+1)  expand, v_mfma_f32_16x16x4_f32: D[hc][px] = We[hc][ic] x[ic][px] over the halo tile's pixels (16 per MFMA tile, tiles dealt to
-//             the waves), K permuted so that one float4 per operand feeds four MFMAs; act1(scale*D + shift), ZEROED outside the image (the
-//             depthwise layer pads the expanded tensor with zeros, not with act1(shift)), written as quad planes to the other hidden buffer
+//   loop over 16-channel slices c of the expanded tensor:
+//     E(c)    expand, v_mfma_f32_16x16x4_f32: D[hc][px] = We[hc][ic] x[ic][px] over the halo tile's pixels (16 per MFMA tile, two tiles in
+//             flight), K permuted so that one float4 per operand feeds four MFMAs; act1(scale*D + shift), ZEROED outside the image (the
+//             depthwise layer pads the expanded tensor with zeros, not with act1(shift)), written as quad planes to the wave's hidden slice
 //     D(c)    depthwise: lane (pixel n of a 16-pixel group, quad k) reads its 9 taps (ds_read_b128), 36 FMAs, act2 -> a float4 that IS the
 //     P(c)    project MFMA's B operand (K = the slice's 16 channels, lane k owns 4k..4k+3): acc[co block][group] += Wp[co][hc] dw[hc][px]
-//   weights of slice c+2 (expand) / c+1 (depthwise + project) arrive by LDS-DMA while slice c is computed (two buffers each; pre-packed on the
-//   host as the LDS image, epilogue constants and depthwise taps riding in the same blobs)
+//   weights: pre-packed on the host in operand order (one 1 KiB piece per MFMA operand set, epilogue constants and depthwise taps riding in the same
+//   blobs), read by every wave straight from L1 / L2
 //   epilogue: act3(scale*acc + shift) [+ x from the tile -> act4], 16-byte channel-contiguous stores.
 #include <cstring>
 #include <vector>
@@ -55,7 +55,7 @@ struct IrbParams {
     int nChunks;       // ceil(Ch / 16)
     int wePieces, wpPieces;  // 256-float (1 KiB) pieces per slice blob
     int xPlane, hPlane;      // floats between quad planes of the x tile / a hidden buffer (multiples of 64)
-    int offH, offWe, offWp, offMask; // LDS map in floats: x planes at 0
+    int offH, offWe, offWp, offMask; // LDS map in floats: x planes at 0 (wave kernel: per wave; offWe = its mask, offMask = floats per wave)
     int hasRes;
     ActCfg ac1, ac2, ac3, ac4;
 };
@@ -63,46 +63,54 @@ struct IrbParams {
 constexpr int kMaxNCB = 20; // Co <= 320
 constexpr int kMaxCj = 10;  // C <= 160
 
-template <int G /* 16-pixel output groups per wave */, int NCBT /* compile-time bound on the output blocks */, int NW = 4 /* waves per block */>
-__global__ __launch_bounds__(64 * NW) void irb_fused_kernel(IrbParams p, const float* __restrict__ x, const float4* __restrict__ weg, const float4* __restrict__ wpg,
-                                                        const float4* __restrict__ epi3, float* __restrict__ y) {
+// The kernel is bound by VALU issue (PMC: 2540 VALU and 162 MFMA instructions per wave on MobileNetV2's b01), most of it the expand epilogue over
+// the halo tile and the depthwise epilogue: act(scale * D + shift) [* mask].  The general simple-activation form is three instructions
+// (mul, max, med3); ReLU6 -- every expand / depthwise activation of MobileNetV2 -- is ONE (med3(v, 0, 6)), so the hot epilogues are instantiated
+// for it (R6), and the border mask is only applied by tiles that touch the image border.
+template <bool R6>
+__device__ __forceinline__ float irb_act(const ActCfg& a, float v) {
+    return R6 ? __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f) : apply_act<true>(a, v, 0.f);
+}
+
+// Wave-autonomous: every WAVE owns one small output tile (4x8 pixels for stride 1, 2x8 for stride 2) from the x tile to the store, in its own
+// slice of LDS, and the kernel has NO barrier at all.  Its predecessor gave a 256-thread block one 8x16 / 8x8 tile and synchronised the four
+// waves once per 16-channel slice, with ~100 MFMAs of work between barriers: b01 / b02 of MobileNetV2 ran 528 / 495 us at batch 256 with the
+// matrix pipe 17 % busy and the waves waiting half of their cycles (PMC); shrinking its VALU work (ReLU6 as one med3, border mask only on
+// border tiles) did not move it -- it waited, it did not issue.  Here a wave's expand -> depthwise -> project chain depends only on its own
+// LDS traffic (in order per wave), the other waves of the SIMD fill its latencies, and the weights of a slice come straight from the packed
+// blobs in L1 / L2 (16 float4 per lane and slice).  What decides the speed is how many waves a CU's LDS holds: 8x8 tiles per wave (22 KB) ran
+// no faster than the block kernel, 4x8 / 2x8 tiles (12 KB, 12 waves per CU) 1.45x faster despite 1.9x instead of 1.56x halo work in the expand.
+// One lane = (pixel n16 of a 16-pixel group, channel quad k); weights pre-packed on the host in the MFMA operand order (K permuted so that one
+// float4 per operand feeds four v_mfma_f32_16x16x4_f32).
+template <int G /* 16-pixel output groups per wave: 4 = 8x8 tile, 2 = 4x8, 1 = 2x8 */, int NCBT /* compile-time bound on the output blocks */, int CJT /* ... on Cj */,
+          bool R6 /* expand and depthwise activations are ReLU6 */>
+__global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const float* __restrict__ x, const float4* __restrict__ weg, const float4* __restrict__ wpg,
+                                                       const float4* __restrict__ epi3, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, k = lane >> 4;
-    const int TW = 1 << p.TWs;
-    const int mt = blockIdx.x;
+    const int NWv = blockDim.x >> 6;
+    constexpr int TW = 8, TH = G * 2; // 16 G pixels
+    const int mt = blockIdx.x * NWv + wave;
+    if (mt >= p.tilesX * p.tilesY * p.N) return; // (no barrier in this kernel)
     const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, img = mt / (p.tilesX * p.tilesY);
-    const int ox0 = tx * TW, oy0 = ty * 8;
-    const int hx0 = ox0 * p.s - p.padx, hy0 = oy0 * p.s - p.pady; // image coordinates of the halo tile's origin
+    const int ox0 = tx * TW, oy0 = ty * TH;
+    const int hx0 = ox0 * p.s - p.padx, hy0 = oy0 * p.s - p.pady;
+    const bool border = hx0 < 0 || hy0 < 0 || hx0 + p.HWd > p.W || hy0 + p.HH > p.H; // (wave-uniform)
 
-    float* const xs = smem;
-    float* const hs = smem + p.offH;    // two hidden buffers of 4 planes
-    float* const wes = smem + p.offWe;  // two expand blobs
-    float* const wps = smem + p.offWp;  // two depthwise + project blobs
-    float* const msk = smem + p.offMask;
+    float* const xs = smem + wave * p.offMask; // offMask doubles as the per-wave LDS size in floats: [x planes | hidden planes | mask]
+    float* const hs = xs + p.offH;
+    float* const msk = xs + p.offWe;
 
-    // LDS-DMA of slice blobs: wave w copies the 1 KiB pieces w, w + 4, ...
-    auto dma = [&](const float4* g, float* dst, int pieces) {
-        for (int pc = wave; pc < pieces; pc += NW) __builtin_amdgcn_global_load_lds(g + pc * 64 + lane, (lds_ptr)(dst + pc * 256), 16, 0, 0);
-    };
-    const size_t weStride = static_cast<size_t>(p.wePieces) * 64, wpStride = static_cast<size_t>(p.wpPieces) * 64; // float4 per slice
-    // two buffers per blob kind, requested one interval ahead of their use.  (Rings of three with a distance of two and counted s_waitcnt were
-    // measured: no faster on the blocks that keep two workgroups per CU, and the extra LDS cost b01 its second workgroup: 162 -> 265 us.)
-    dma(weg, wes, p.wePieces);
-    if (p.nChunks > 1) dma(weg + weStride, wes + p.wePieces * 256, p.wePieces);
-    dma(wpg, wps, p.wpPieces);
-
-    // ---- x tile: HP pixels x 4*Cj quads (channels past C and pixels outside the image are zero) + the inside-the-image mask
+    // ---- x tile of this wave: HP pixels x 4*Cj quads (channels past C and pixels outside the image are zero) + the inside-the-image mask
     {
         const int quads = 4 * p.Cj, cq = p.C >> 2;
         const int total = p.MT * 16 * quads;
-        // batches of 8 elements per thread: all eight global loads are requested before the first LDS store (one element per loop iteration
-        // serialised the HBM latency: 6-10 round trips per block with only two blocks per CU to hide them)
-        for (int base = tid; base < total; base += 8 * 64 * NW) {
+        for (int base = lane; base < total; base += 8 * 64) {
             float4 v[8];
             int lo[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const int e = base + r * 64 * NW;
+                const int e = base + r * 64;
                 v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
                 lo[r] = -1;
                 if (e < total) {
@@ -120,65 +128,12 @@ __global__ __launch_bounds__(64 * NW) void irb_fused_kernel(IrbParams p, const f
                 if (lo[r] >= 0) *reinterpret_cast<float4*>(xs + lo[r]) = v[r];
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the slice blobs requested above have landed in LDS ...
-    __syncthreads();                                  // ... for every wave
 
-    // ---- expand of slice c into hidden buffer c & 1 (wave-strided over the halo tile's 16-pixel MFMA tiles)
-    auto expand = [&](int c) {
-        const float* web = wes + (c & 1) * (p.wePieces * 256);
-        float* hb = hs + (c & 1) * (4 * p.hPlane);
-        float4 a[kMaxCj];
-#pragma unroll
-        for (int j = 0; j < kMaxCj; ++j)
-            if (j < p.Cj) a[j] = *reinterpret_cast<const float4*>(web + j * 256 + lane * 4);
-        const float4 sc = *reinterpret_cast<const float4*>(web + p.Cj * 256 + 4 * k);        // act1(scale * D + shift), channels 4k .. 4k+3 of the slice
-        const float4 sh = *reinterpret_cast<const float4*>(web + p.Cj * 256 + 16 + 4 * k);
-        // two MFMA tiles at a time: the second tile's MFMAs fill the 40-cycle dependent-accumulator latency of the first one's chain
-        for (int t = wave; t < p.MT; t += 2 * NW) {
-            const int px0 = t * 16 + n16;
-            const bool two = t + NW < p.MT;         // wave-uniform
-            const int px1 = two ? px0 + 16 * NW : px0;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < kMaxCj; ++j)
-                if (j < p.Cj) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(xs + (4 * j + k) * p.xPlane + px0 * 4);
-                    const float4 b1 = *reinterpret_cast<const float4*>(xs + (4 * j + k) * p.xPlane + px1 * 4);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b1.x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b0.y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b1.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b0.z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b1.z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0.w, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1.w, acc1, 0, 0, 0);
-                }
-            const float m0 = msk[px0], m1 = msk[px1];
-            float4 h;
-            h.x = apply_act<true>(p.ac1, fmaf(sc.x, acc0[0], sh.x), 0.f) * m0;
-            h.y = apply_act<true>(p.ac1, fmaf(sc.y, acc0[1], sh.y), 0.f) * m0;
-            h.z = apply_act<true>(p.ac1, fmaf(sc.z, acc0[2], sh.z), 0.f) * m0;
-            h.w = apply_act<true>(p.ac1, fmaf(sc.w, acc0[3], sh.w), 0.f) * m0;
-            *reinterpret_cast<float4*>(hb + k * p.hPlane + px0 * 4) = h;
-            if (two) {
-                h.x = apply_act<true>(p.ac1, fmaf(sc.x, acc1[0], sh.x), 0.f) * m1;
-                h.y = apply_act<true>(p.ac1, fmaf(sc.y, acc1[1], sh.y), 0.f) * m1;
-                h.z = apply_act<true>(p.ac1, fmaf(sc.z, acc1[2], sh.z), 0.f) * m1;
-                h.w = apply_act<true>(p.ac1, fmaf(sc.w, acc1[3], sh.w), 0.f) * m1;
-                *reinterpret_cast<float4*>(hb + k * p.hPlane + px1 * 4) = h;
-            }
-        }
-    };
-
-    // ---- this lane's output pixels: group g of the wave -> tile-local (row, column) -> top-left pixel of its 3x3 window in the halo tile
-    int oyl[G], oxl[G], hp0[G];
+    int hp0[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const int grp = wave * G + g;                 // 16 consecutive pixels of the tile in row-major order
-        const int pl = grp * 16 + n16;
-        oyl[g] = pl >> p.TWs;
-        oxl[g] = pl & (TW - 1);
-        hp0[g] = oyl[g] * p.s * p.HWd + oxl[g] * p.s;
+        const int pl = g * 16 + n16; // 16 consecutive pixels of the tile in row-major order (two rows of 8)
+        hp0[g] = (pl >> 3) * p.s * p.HWd + (pl & 7) * p.s;
     }
     f32x4 acc[NCBT][G];
 #pragma unroll
@@ -186,66 +141,110 @@ __global__ __launch_bounds__(64 * NW) void irb_fused_kernel(IrbParams p, const f
 #pragma unroll
         for (int g = 0; g < G; ++g) acc[cb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    expand(0);
-    __syncthreads();
-
     for (int c = 0; c < p.nChunks; ++c) {
-        // slice blobs that the next interval needs: expand weights of c + 2 (their buffer was last read by E(c), before the barrier above),
-        // depthwise + project weights of c + 1 (buffer last read by D/P(c - 1))
-        if (c + 2 < p.nChunks) dma(weg + weStride * (c + 2), wes + (c & 1) * (p.wePieces * 256), p.wePieces);
-        if (c + 1 < p.nChunks) dma(wpg + wpStride * (c + 1), wps + ((c + 1) & 1) * (p.wpPieces * 256), p.wpPieces);
-
-        const float* hb = hs + (c & 1) * (4 * p.hPlane) + k * p.hPlane;
-        const float* wpb = wps + (c & 1) * (p.wpPieces * 256);
-        const float* dwb = wpb + p.NCB * 256; // [9 taps][16 channels], then scale[16], shift[16]
-        float4 wd[9];
+        const float4* web = weg + static_cast<size_t>(c) * p.wePieces * 64; // this slice's blobs (the LDS images of the block-tile kernel), read in place
+        const float4* wpb = wpg + static_cast<size_t>(c) * p.wpPieces * 64;
+        // ---- expand: hidden slice c over the wave's halo tile
+        {
+            float4 a[CJT];
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) wd[tp] = *reinterpret_cast<const float4*>(dwb + tp * 16 + 4 * k);
-        const float4 sc = *reinterpret_cast<const float4*>(dwb + 144 + 4 * k), sh = *reinterpret_cast<const float4*>(dwb + 160 + 4 * k);
-        float4 dv[G];
+            for (int j = 0; j < CJT; ++j)
+                if (j < p.Cj) a[j] = web[j * 64 + lane];
+            const float4 sc = web[p.Cj * 64 + k], sh = web[p.Cj * 64 + 4 + k];
+            for (int t = 0; t < p.MT; t += 2) {
+                const int px0 = t * 16 + n16;
+                const bool two = t + 1 < p.MT; // wave-uniform
+                const int px1 = two ? px0 + 16 : px0;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int fy = 0; fy < 3; ++fy)
-#pragma unroll
-                for (int fx = 0; fx < 3; ++fx) {
-                    const float4 h = *reinterpret_cast<const float4*>(hb + (hp0[g] + fy * p.HWd + fx) * 4);
-                    const float4 w = wd[fy * 3 + fx];
-                    s4.x = fmaf(h.x, w.x, s4.x);
-                    s4.y = fmaf(h.y, w.y, s4.y);
-                    s4.z = fmaf(h.z, w.z, s4.z);
-                    s4.w = fmaf(h.w, w.w, s4.w);
+                for (int j = 0; j < CJT; ++j)
+                    if (j < p.Cj) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(xs + (4 * j + k) * p.xPlane + px0 * 4);
+                        const float4 b1 = *reinterpret_cast<const float4*>(xs + (4 * j + k) * p.xPlane + px1 * 4);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0.x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b1.x, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b0.y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b1.y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b0.z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b1.z, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0.w, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1.w, acc1, 0, 0, 0);
+                    }
+                float4 h;
+                h.x = irb_act<R6>(p.ac1, fmaf(sc.x, acc0[0], sh.x));
+                h.y = irb_act<R6>(p.ac1, fmaf(sc.y, acc0[1], sh.y));
+                h.z = irb_act<R6>(p.ac1, fmaf(sc.z, acc0[2], sh.z));
+                h.w = irb_act<R6>(p.ac1, fmaf(sc.w, acc0[3], sh.w));
+                if (border) {
+                    const float m0 = msk[px0];
+                    h.x *= m0; h.y *= m0; h.z *= m0; h.w *= m0;
                 }
-            dv[g].x = apply_act<true>(p.ac2, fmaf(sc.x, s4.x, sh.x), 0.f);
-            dv[g].y = apply_act<true>(p.ac2, fmaf(sc.y, s4.y, sh.y), 0.f);
-            dv[g].z = apply_act<true>(p.ac2, fmaf(sc.z, s4.z, sh.z), 0.f);
-            dv[g].w = apply_act<true>(p.ac2, fmaf(sc.w, s4.w, sh.w), 0.f);
-        }
-#pragma unroll
-        for (int cb = 0; cb < NCBT; ++cb)
-            if (cb < p.NCB) {
-                const float4 a = *reinterpret_cast<const float4*>(wpb + cb * 256 + lane * 4);
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, dv[g].x, acc[cb][g], 0, 0, 0);
-                    acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, dv[g].y, acc[cb][g], 0, 0, 0);
-                    acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, dv[g].z, acc[cb][g], 0, 0, 0);
-                    acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, dv[g].w, acc[cb][g], 0, 0, 0);
+                *reinterpret_cast<float4*>(hs + k * p.hPlane + px0 * 4) = h;
+                if (two) {
+                    h.x = irb_act<R6>(p.ac1, fmaf(sc.x, acc1[0], sh.x));
+                    h.y = irb_act<R6>(p.ac1, fmaf(sc.y, acc1[1], sh.y));
+                    h.z = irb_act<R6>(p.ac1, fmaf(sc.z, acc1[2], sh.z));
+                    h.w = irb_act<R6>(p.ac1, fmaf(sc.w, acc1[3], sh.w));
+                    if (border) {
+                        const float m1 = msk[px1];
+                        h.x *= m1; h.y *= m1; h.z *= m1; h.w *= m1;
+                    }
+                    *reinterpret_cast<float4*>(hs + k * p.hPlane + px1 * 4) = h;
                 }
             }
-        if (c + 1 < p.nChunks) expand(c + 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        }
+        // ---- depthwise + project of slice c (the wave's LDS operations complete in order: the hidden slice above is visible to all its lanes)
+        {
+            const float* hb = hs + k * p.hPlane;
+            const float4* dwb = wpb + p.NCB * 64; // [9 taps][16 channels], then scale[16], shift[16]
+            float4 wd[9];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) wd[tp] = dwb[tp * 4 + k];
+            const float4 sc = dwb[36 + k], sh = dwb[40 + k];
+            float4 dv[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int fy = 0; fy < 3; ++fy)
+#pragma unroll
+                    for (int fx = 0; fx < 3; ++fx) {
+                        const float4 h = *reinterpret_cast<const float4*>(hb + (hp0[g] + fy * p.HWd + fx) * 4);
+                        const float4 w = wd[fy * 3 + fx];
+                        s4.x = fmaf(h.x, w.x, s4.x);
+                        s4.y = fmaf(h.y, w.y, s4.y);
+                        s4.z = fmaf(h.z, w.z, s4.z);
+                        s4.w = fmaf(h.w, w.w, s4.w);
+                    }
+                dv[g].x = irb_act<R6>(p.ac2, fmaf(sc.x, s4.x, sh.x));
+                dv[g].y = irb_act<R6>(p.ac2, fmaf(sc.y, s4.y, sh.y));
+                dv[g].z = irb_act<R6>(p.ac2, fmaf(sc.z, s4.z, sh.z));
+                dv[g].w = irb_act<R6>(p.ac2, fmaf(sc.w, s4.w, sh.w));
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCBT; ++cb)
+                if (cb < p.NCB) {
+                    const float4 a = wpb[cb * 64 + lane];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, dv[g].x, acc[cb][g], 0, 0, 0);
+                        acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, dv[g].y, acc[cb][g], 0, 0, 0);
+                        acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, dv[g].z, acc[cb][g], 0, 0, 0);
+                        acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, dv[g].w, acc[cb][g], 0, 0, 0);
+                    }
+                }
+        }
     }
 
     // ---- epilogue: lane holds output channels 16 cb + 4k .. + 3 of its pixels
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const int oy = oy0 + oyl[g], ox = ox0 + oxl[g];
+        const int pl = g * 16 + n16;
+        const int oyl = pl >> 3, oxl = pl & 7;
+        const int oy = oy0 + oyl, ox = ox0 + oxl;
         if (oy >= p.OH || ox >= p.OW) continue;
         float* yp = y + ((static_cast<size_t>(img) * p.OH + oy) * p.OW + ox) * p.Co;
-        const int hpc = (oyl[g] + p.pady) * p.HWd + oxl[g] + p.padx; // residual (stride 1): the block input at the output pixel
+        const int hpc = (oyl + p.pady) * p.HWd + oxl + p.padx; // residual (stride 1): the block input at the output pixel
 #pragma unroll
         for (int cb = 0; cb < NCBT; ++cb) {
             const int co = cb * 16 + 4 * k;
@@ -294,13 +293,22 @@ struct IrbPlan : snnhip_plan {
 };
 
 typedef void (*IrbFn)(IrbParams, const float*, const float4*, const float4*, const float4*, float*);
-template <int G>
-IrbFn pick_irb(int ncb) {
-    if (ncb <= 2) return irb_fused_kernel<G, 2>;
-    if (ncb <= 4) return irb_fused_kernel<G, 4>;
-    if (ncb <= 6) return irb_fused_kernel<G, 6>;
-    if (G == 1 && ncb <= 10) return irb_fused_kernel<1, 10>;
-    if (G == 1 && ncb <= 20) return irb_fused_kernel<1, 20>;
+template <int G, bool R6>
+IrbFn pick_irb_wave(int ncb, int cj) {
+#define SNNHIP_IRBW(NCBT_, CJT_) \
+    if (ncb <= NCBT_ && cj <= CJT_) return irb_wave_kernel<G, NCBT_, CJT_, R6>;
+    SNNHIP_IRBW(2, 1)
+    SNNHIP_IRBW(2, 2)
+    SNNHIP_IRBW(4, 2)
+    SNNHIP_IRBW(4, 4)
+    SNNHIP_IRBW(6, 4)
+    SNNHIP_IRBW(6, 6)
+    if constexpr (G == 1) { // the 14x14 / 7x7 blocks (SNNHIP_IRB_FUSION=all: slower than their separate layers, kept for the parity tests)
+        SNNHIP_IRBW(10, 6)
+        SNNHIP_IRBW(10, 10)
+        SNNHIP_IRBW(20, 10)
+    }
+#undef SNNHIP_IRBW
     return nullptr;
 }
 } // namespace
@@ -324,9 +332,9 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         return SNNHIP_E_UNSUPPORTED;
     if (gd.padx < 0 || gd.padx > 2 || gd.pady < 0 || gd.pady > 2) return SNNHIP_E_UNSUPPORTED;
     const int C = ge.IC, Ch = ge.OC, Co = gp.OC, s = gd.sh;
-    // Where it pays: the blocks whose expanded tensor is big (MobileNetV2 b01-b06, 112x112 .. 28x28 inputs).  On the 14x14 / 7x7 maps the
-    // separate layers win (measured at batch 64: 49 vs 88 us for 64->384->64 @14x14, 72 vs 245 us for 160->960->160 @7x7): few tiles per
-    // image, 24-60 slices of one barrier each, weights that no longer fit beside the x tile.
+    // Where it pays: the blocks whose expanded tensor is big (MobileNetV2 b01-b06, 112x112 .. 28x28 inputs).  Batch 256, us, separate layers /
+    // this kernel: b01 (112x112, stride 2) 787 / 364, b02 (56x56) 615 / 334, b03 (56x56 s2) 368 / 237, b04 (28x28) 201 / 129, b06 (28x28 s2) 124 / 99;
+    // from 14x14 down the separate layers win (b07 143 / 148, b10 149 / 170, b11 258 / 332): few tiles per image and 24-60 slices of weights.
     const bool fuseAll = irbMode && strcmp(irbMode, "all") == 0;
     if (!fuseAll && ge.H * ge.W < 28 * 28) return SNNHIP_E_UNSUPPORTED;
     if (C % 4 || Ch % 4 || Co % 4 || C > 16 * kMaxCj || Co > 16 * kMaxNCB) return SNNHIP_E_UNSUPPORTED;
@@ -340,38 +348,56 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     p.N = ge.N; p.H = ge.H; p.W = ge.W; p.C = C; p.Ch = Ch; p.Co = Co; p.OH = gd.OH; p.OW = gd.OW; p.s = s; p.padx = gd.padx; p.pady = gd.pady;
     p.Cj = up_div(C, 16);
     p.NCB = up_div(Co, 16);
-    // 8x16 output tiles (two pixel groups per wave) for stride-1 blocks on maps that have the columns, 8x8 otherwise
-    const bool wide = s == 1 && p.OW > 8 && p.NCB <= 6;
-    p.TWs = wide ? 4 : 3;
-    const int TW = 1 << p.TWs, TH = 8;
-    p.HH = (TH - 1) * s + 3;
-    p.HWd = (TW - 1) * s + 3;
-    p.HP = p.HH * p.HWd;
-    p.MT = up_div(p.HP, 16);
-    p.tilesX = up_div(p.OW, TW);
-    p.tilesY = up_div(p.OH, TH);
+    // tile per wave: 2 pixel groups (4x8) for stride 1, 1 (2x8) for stride 2 -- measured (tools/gpu_irb.sh): the small tiles' occupancy beats their extra
+    // halo work; a smaller tile when the per-wave LDS would leave fewer than 4 waves on a CU.  SNNHIP_IRB_WAVE_G=1|2|4 pins it (tests).
+    const char* gopt = snnhip::option("SNNHIP_IRB_WAVE_G");
+    int G = gopt ? atoi(gopt) : (s == 2 ? 1 : 2);
+    if (G != 1 && G != 2 && G != 4) G = s == 2 ? 1 : 2;
+    int NWv = 0, perWave = 0;
+    for (;; G >>= 1) {
+        const int TH = 2 * G, TWv = 8;
+        p.TWs = 3;
+        p.HH = (TH - 1) * s + 3;
+        p.HWd = (TWv - 1) * s + 3;
+        p.HP = p.HH * p.HWd;
+        p.MT = up_div(p.HP, 16);
+        p.tilesX = up_div(p.OW, TWv);
+        p.tilesY = up_div(p.OH, TH);
+        p.xPlane = round_up(p.MT * 16 * 4, 64);
+        p.hPlane = p.xPlane;
+        p.offH = 4 * p.Cj * p.xPlane;   // the wave's hidden slice (4 quad planes) behind its x planes
+        p.offWe = p.offH + 4 * p.hPlane; // ... and its inside-the-image mask
+        perWave = round_up(p.offWe + p.MT * 16, 64);
+        p.offMask = perWave;             // floats per wave
+        // waves per block: the block size (2..4 waves) that puts the most waves on a CU's 160 KB of LDS
+        int bestWaves = 0;
+        for (int nw = 4; nw >= 2; --nw) {
+            const int blocks = std::min(8, static_cast<int>((160 * 1024) / (static_cast<size_t>(nw) * perWave * sizeof(float))));
+            if (nw * blocks > bestWaves) {
+                bestWaves = nw * blocks;
+                NWv = nw;
+            }
+        }
+        if (bestWaves >= 4 || G == 1) {
+            if (bestWaves < 2) return SNNHIP_E_UNSUPPORTED; // the x tile of one wave does not fit LDS
+            break;
+        }
+    }
     p.nChunks = up_div(Ch, 16);
     p.wePieces = p.Cj + 1;
     p.wpPieces = p.NCB + 1;
-    p.xPlane = round_up(p.MT * 16 * 4, 64);
-    p.hPlane = p.xPlane;
-    p.offH = 4 * p.Cj * p.xPlane;
-    p.offWe = p.offH + 2 * 4 * p.hPlane;
-    p.offWp = p.offWe + 2 * p.wePieces * 256;
-    p.offMask = p.offWp + 2 * p.wpPieces * 256;
+    p.offWp = 0;
     p.hasRes = ad ? 1 : 0;
     p.ac1 = make_act_cfg(ge.act, ge.leaky);
     p.ac2 = make_act_cfg(gd.act, gd.leaky);
     p.ac3 = make_act_cfg(gp.act, gp.leaky);
     p.ac4 = make_act_cfg(ad ? ad->d.act : 0, ad ? ad->d.leaky : 0.0f);
-    const size_t lds = static_cast<size_t>(p.offMask + p.MT * 16) * sizeof(float);
-    if (lds > 160 * 1024) return SNNHIP_E_UNSUPPORTED;
-    // ... and it needs two workgroups per CU to hide its one-barrier-per-slice structure: 56x56 24->144->32 stride 2 (91 KB) measured 138 us
-    // fused against 89 us for the separate layers at batch 64
-    if (!fuseAll && lds > 80 * 1024) return SNNHIP_E_UNSUPPORTED;
-    // (512-thread blocks with one pixel group per wave were measured on the 8x16 tiles: slower, 494 -> 596 us on b02 at batch 256 -- the kernel is
-    // bound by its VALU work per slice (PMC: 2540 VALU and 162 MFMA instructions per wave on b01), not by latency that more waves could hide)
-    IrbFn fn = wide ? pick_irb<2>(p.NCB) : pick_irb<1>(p.NCB);
+    const size_t lds = static_cast<size_t>(NWv) * perWave * sizeof(float);
+    const bool r6 = ge.act == SNNHIP_ACT_RELU6 && gd.act == SNNHIP_ACT_RELU6;
+    IrbFn fn = nullptr;
+    if (G == 4) fn = r6 ? pick_irb_wave<4, true>(p.NCB, p.Cj) : pick_irb_wave<4, false>(p.NCB, p.Cj);
+    if (G == 2) fn = r6 ? pick_irb_wave<2, true>(p.NCB, p.Cj) : pick_irb_wave<2, false>(p.NCB, p.Cj);
+    if (G == 1) fn = r6 ? pick_irb_wave<1, true>(p.NCB, p.Cj) : pick_irb_wave<1, false>(p.NCB, p.Cj);
     if (!fn) return SNNHIP_E_UNSUPPORTED;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("irb_fused: hipFuncSetAttribute(%zu) failed", lds);
@@ -418,9 +444,9 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     plan->ctx = ctx;
     plan->p = p;
     plan->kernel = fn;
-    plan->threads = 256;
+    plan->threads = 64 * NWv;
     plan->ldsBytes = lds;
-    plan->grid = dim3(p.tilesX * p.tilesY * p.N);
+    plan->grid = dim3(static_cast<unsigned>(up_div(p.tilesX * p.tilesY * p.N, NWv)));
     plan->dtype = SNNHIP_F32;
     int rc = plan->upload(we.data(), we.size(), &plan->d_we);
     if (rc == SNNHIP_OK) rc = plan->upload(wp.data(), wp.size(), &plan->d_wp);
@@ -435,9 +461,10 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     plan->bytes = ce->bytes + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
     const double fusedBytes = 4.0 * (static_cast<double>(p.N) * p.H * p.W * C + static_cast<double>(p.N) * p.OH * p.OW * Co + static_cast<double>(Ch) * (C + Co + 9));
     char buf[320];
-    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] tile=8x%dpx halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_fused_kernel",
-             C, Ch, s, Ch, Co, addPlan ? " + add" : "", TW, p.HH, p.HWd, p.nChunks, 256, lds, fusedBytes);
+    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] tile=%dx8px per wave, halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_wave_kernel",
+             C, Ch, s, Ch, Co, addPlan ? " + add" : "", 2 * G, p.HH, p.HWd, p.nChunks, plan->threads, lds, fusedBytes);
     plan->desc = buf;
+    if (r6) plan->desc += " relu6-epilogues";
     *out = plan;
     return SNNHIP_OK;
 }

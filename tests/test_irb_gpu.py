@@ -126,3 +126,31 @@ def test_mobilenetv2_graph_uses_the_fused_blocks(ctx, monkeypatch, mode):
     np.testing.assert_allclose(y.reshape(2, -1), want.reshape(2, -1), **TOL)
     y0 = snn.GraphRunner(ctx, net, 2, 96, 96, fuse=False)(x)
     np.testing.assert_allclose(y, y0, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("G", [1, 2, 4])
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[7]], ids=["b02", "b01", "ragged"])
+def test_irb_every_wave_tile_size_matches_the_separate_layers(ctx, monkeypatch, case, G):
+    """The kernel's three tile sizes per wave (SNNHIP_IRB_WAVE_G = 1 | 2 | 4: 2x8, 4x8, 8x8 pixels; the default is 2 for stride 1 and 1 for stride
+    2) on the same inputs: tile decode, halo extents and the wave-per-block choice differ, the results must not."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_IRB_FUSION", "all")
+    monkeypatch.setenv("SNNHIP_IRB_WAVE_G", str(G))
+    N, H, W, C, Ch, Co, s, res, acts = case
+    x = _rand((N, H, W, C), 71)
+    (we, be, bne), (wd, bd, bnd), (wp, bp, bnp) = _layers(case, 80)
+    pe = snn.conv2d_plan(ctx, N, H, W, we, be, act=acts[0], leaky=0.1, bn=bne)
+    pd = snn.conv2d_plan(ctx, N, H, W, wd, bd, stride=s, pads=O.padding_offsets("same", 3), act=acts[1], leaky=0.1, bn=bnd, depthwise=True)
+    _, OH, OW, _ = pd.out_shape()
+    pp = snn.conv2d_plan(ctx, N, OH, OW, wp, bp, act=acts[2], leaky=0.1, bn=bnp)
+    xt = snn.Tensor.from_numpy(ctx, x)
+    sep = pp(pd(pe(xt)))
+    if res:
+        pa = snn.add_plan(ctx, N, OH, OW, Co, act="")
+        sep = pa([sep, xt])
+        plan = snn.graph_fuse(ctx, [(pe, [-1], False), (pd, [0], False), (pp, [1], False), (pa, [2, -1], True)])[3][0]
+    else:
+        plan = snn.chain_plan(ctx, [pe, pd, pp])
+    assert "tile=%dx8px per wave" % (2 * G) in plan.describe(), plan.describe()
+    np.testing.assert_allclose(plan(xt).numpy(), sep.numpy(), err_msg=plan.describe(), rtol=2e-5, atol=2e-5)

@@ -1,8 +1,8 @@
 #!/bin/bash
+# inverted-residual blocks: parity tests, then per-block timings (separate layers / the fused kernel at each tile size per wave)
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_irb_gpu.py -m gpu -q --timeout 600 2>&1 | tail -8 | cut -c1-250
-python tools/bench_irb.py --batch 256 --reps 5 | cut -c1-130
-for e in "" "SNNHIP_NO_IRB_FUSION=1"; do
-env $e timeout 600 python bench.py --config c4 --no-cpu-baseline --through capi 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('c4 $e', round(d['value']), d['ms_per_step'], d['frac_of_whole_step_roofline'])"
+timeout 900 python -m pytest tests/test_irb_gpu.py -m gpu -q --timeout 600 2>&1 | tail -3 | cut -c1-250
+SNNHIP_IRB_FUSION=all python tools/bench_irb.py --batch ${1:-256} --reps 5 | cut -c1-130
+for g in 4 2 1; do
+echo "== tile per wave: G=$g"; SNNHIP_IRB_FUSION=all SNNHIP_IRB_WAVE_G=$g python tools/bench_irb.py --batch ${1:-256} --reps 5 --fused-only | cut -c1-110
 done

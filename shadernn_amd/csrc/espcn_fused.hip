@@ -1226,6 +1226,18 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.bytes = irb->bytes;
             i += 3;
             ++fusedCount;
+        } else if (snnhip_plan* dwpw = nullptr; i + 1 < n && c0 && c1 && c0->depthwise && !c1->depthwise &&
+                                         make_irb_plan(ctx, nullptr, plans[i], plans[i + 1], nullptr, &dwpw) == SNNHIP_OK) {
+            // ---- rule G without an expand layer: DepthwiseConv2D 3x3 -> Conv2D 1x1 (MobileNetV2's first block) -> the same kernel, its hidden slice is the x tile
+            chain->owned.push_back(dwpw);
+            st.kind = ChainPlan::PLAIN;
+            st.plain = dwpw;
+            memcpy(st.outDims, dwpw->outDims, sizeof(st.outDims));
+            st.desc = dwpw->desc;
+            st.flops = dwpw->flops;
+            st.bytes = dwpw->bytes;
+            i += 2;
+            ++fusedCount;
         } else if (auto* up = dynamic_cast<UpsamplePlanBase*>(plans[i]);
                    up && up->d.mode == SNNHIP_UPSAMPLE_NEAREST && up->d.scale == 2.0f && up->OH == 2 * up->d.H && up->OW == 2 * up->d.W && i + 1 < n &&
                    !snnhip::option("SNNHIP_NO_PAD_FUSION")) {

@@ -57,6 +57,7 @@ struct IrbParams {
     int xPlane, hPlane;      // floats between quad planes of the x tile / a hidden buffer (multiples of 64)
     int offH, offWe, offWp, offMask; // LDS map in floats: x planes at 0 (wave kernel: per wave; offWe = its mask, offMask = floats per wave)
     int hasRes;
+    int noExpand;      // DepthwiseConv2D -> Conv2D 1x1 without an expand layer in front (MobileNetV2's first block): the 'hidden' slice is the x tile itself
     ActCfg ac1, ac2, ac3, ac4;
 };
 
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
         const float4* web = weg + static_cast<size_t>(c) * p.wePieces * 64; // this slice's blobs (the LDS images of the block-tile kernel), read in place
         const float4* wpb = wpg + static_cast<size_t>(c) * p.wpPieces * 64;
         // ---- expand: hidden slice c over the wave's halo tile
-        {
+        if (!p.noExpand) {
             float4 a[CJT];
 #pragma unroll
             for (int j = 0; j < CJT; ++j)
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
         }
         // ---- depthwise + project of slice c (the wave's LDS operations complete in order: the hidden slice above is visible to all its lanes)
         {
-            const float* hb = hs + k * p.hPlane;
+            const float* hb = p.noExpand ? xs + (4 * c + k) * p.xPlane : hs + k * p.hPlane; // (no expand layer: the block input, zero outside the image)
             const float4* dwb = wpb + p.NCB * 64; // [9 taps][16 channels], then scale[16], shift[16]
             float4 wd[9];
 #pragma unroll
@@ -313,7 +314,8 @@ IrbFn pick_irb_wave(int ncb, int cj) {
 }
 } // namespace
 
-// expand / dw / project: the three per-layer plans (borrowed; only read here); add: the residual Add plan or nullptr.
+// expand / dw / project: the three per-layer plans (borrowed; only read here; expand may be null: DepthwiseConv2D -> Conv2D 1x1, the expansion-factor-1
+// block at the head of MobileNetV2); add: the residual Add plan or nullptr.
 int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan, snnhip_plan* projectPlan, snnhip_plan* addPlan, snnhip_plan** out) {
     if (snnhip::option("SNNHIP_NO_IRB_FUSION")) return SNNHIP_E_UNSUPPORTED;
     const char* irbMode = snnhip::option("SNNHIP_IRB_FUSION"); // "all": also the 14x14 / 7x7 blocks, where the separate layers are faster (tools/bench_irb.py)
@@ -321,8 +323,19 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     auto* cd = dynamic_cast<ConvPlanBase*>(dwPlan);
     auto* cp = dynamic_cast<ConvPlanBase*>(projectPlan);
     auto* ad = addPlan ? dynamic_cast<EltwisePlanBase*>(addPlan) : nullptr;
-    if (!ce || !cd || !cp || ce->depthwise || !cd->depthwise || cp->depthwise || (addPlan && (!ad || ad->mode != 0))) return SNNHIP_E_UNSUPPORTED;
-    const ConvGeom &ge = ce->g, &gd = cd->g, &gp = cp->g;
+    const bool noExpand = expandPlan == nullptr; // DepthwiseConv2D -> Conv2D 1x1 (MobileNetV2's first block, expansion factor 1)
+    if ((!noExpand && !ce) || !cd || !cp || (ce && ce->depthwise) || !cd->depthwise || cp->depthwise || (addPlan && (!ad || ad->mode != 0))) return SNNHIP_E_UNSUPPORTED;
+    ConvGeom geId = cd->g; // stand-in geometry of the missing expand layer: identity on the depthwise layer's input
+    geId.kh = geId.kw = geId.sh = geId.sw = 1;
+    geId.OC = geId.IC;
+    geId.OH = geId.H;
+    geId.OW = geId.W;
+    geId.act = SNNHIP_ACT_NONE;
+    geId.useBN = 0;
+    geId.preMode = 0;
+    geId.addAct = -1;
+    const ConvGeom &ge = noExpand ? geId : ce->g, &gd = cd->g, &gp = cp->g;
+    if (noExpand && gd.IC % 16 != 0) return SNNHIP_E_UNSUPPORTED; // whole 16-channel slices of the x tile
     auto pointwise = [](const ConvGeom& g) { return g.kh == 1 && g.kw == 1 && g.sh == 1 && g.sw == 1 && g.preMode == 0 && g.addAct < 0 && g.dtype == SNNHIP_F32; };
     if (!pointwise(ge) || !pointwise(gp) || gd.dtype != SNNHIP_F32 || gd.kh != 3 || gd.kw != 3 || gd.sh != gd.sw || gd.sh < 1 || gd.sh > 2 || gd.preMode != 0)
         return SNNHIP_E_UNSUPPORTED;
@@ -366,7 +379,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         p.xPlane = round_up(p.MT * 16 * 4, 64);
         p.hPlane = p.xPlane;
         p.offH = 4 * p.Cj * p.xPlane;   // the wave's hidden slice (4 quad planes) behind its x planes
-        p.offWe = p.offH + 4 * p.hPlane; // ... and its inside-the-image mask
+        p.offWe = p.offH + (noExpand ? 0 : 4 * p.hPlane); // ... and its inside-the-image mask
         perWave = round_up(p.offWe + p.MT * 16, 64);
         p.offMask = perWave;             // floats per wave
         // waves per block: the block size (2..4 waves) that puts the most waves on a CU's 160 KB of LDS
@@ -388,6 +401,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     p.wpPieces = p.NCB + 1;
     p.offWp = 0;
     p.hasRes = ad ? 1 : 0;
+    p.noExpand = noExpand ? 1 : 0;
     p.ac1 = make_act_cfg(ge.act, ge.leaky);
     p.ac2 = make_act_cfg(gd.act, gd.leaky);
     p.ac3 = make_act_cfg(gp.act, gp.leaky);
@@ -405,7 +419,8 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     }
 
     // ---- slice blobs (the kernel's LDS images)
-    const std::vector<float> e1 = fold_epilogue(ce->epi4, Ch, ge.useBN), e2 = fold_epilogue(cd->epi4, Ch, gd.useBN), e3 = fold_epilogue(cp->epi4, Co, gp.useBN);
+    const std::vector<float> e1 = noExpand ? std::vector<float>(static_cast<size_t>(Ch) * 2, 0.0f) : fold_epilogue(ce->epi4, Ch, ge.useBN);
+    const std::vector<float> e2 = fold_epilogue(cd->epi4, Ch, gd.useBN), e3 = fold_epilogue(cp->epi4, Co, gp.useBN);
     std::vector<float> we(static_cast<size_t>(p.nChunks) * p.wePieces * 256, 0.0f), wp(static_cast<size_t>(p.nChunks) * p.wpPieces * 256, 0.0f);
     for (int c = 0; c < p.nChunks; ++c) {
         float* wb = we.data() + static_cast<size_t>(c) * p.wePieces * 256;
@@ -414,7 +429,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
             const int hc = 16 * c + m;
             if (hc >= Ch) continue;
             // expand: [j][lane = 16 kk + m] float4 {We[hc][16 j + 4 kk + jj]}
-            for (int ic = 0; ic < C; ++ic) {
+            for (int ic = 0; ic < C && !noExpand; ++ic) {
                 const int j = ic / 16, kk = (ic % 16) / 4, jj = ic % 4;
                 wb[j * 256 + (kk * 16 + m) * 4 + jj] = ce->w_oihw[static_cast<size_t>(hc) * C + ic];
             }
@@ -455,14 +470,17 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         delete plan;
         return rc;
     }
-    memcpy(plan->inDims, expandPlan->inDims, sizeof(plan->inDims));
+    memcpy(plan->inDims, noExpand ? dwPlan->inDims : expandPlan->inDims, sizeof(plan->inDims));
     memcpy(plan->outDims, projectPlan->outDims, sizeof(plan->outDims));
-    plan->flops = ce->flops + cd->flops + cp->flops;
-    plan->bytes = ce->bytes + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
+    plan->flops = (ce ? ce->flops : 0.0) + cd->flops + cp->flops;
+    plan->bytes = (ce ? ce->bytes : 0.0) + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
     const double fusedBytes = 4.0 * (static_cast<double>(p.N) * p.H * p.W * C + static_cast<double>(p.N) * p.OH * p.OW * Co + static_cast<double>(Ch) * (C + Co + 9));
     char buf[320];
-    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] tile=%dx8px per wave, halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_wave_kernel",
-             C, Ch, s, Ch, Co, addPlan ? " + add" : "", 2 * G, p.HH, p.HWd, p.nChunks, plan->threads, lds, fusedBytes);
+    char head[64];
+    if (noExpand) snprintf(head, sizeof(head), "depthwise3x3 %d s%d", Ch, s);
+    else snprintf(head, sizeof(head), "conv1x1 %d->%d + depthwise3x3 s%d", C, Ch, s);
+    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [%s + conv1x1 %d->%d%s] tile=%dx8px per wave, halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_wave_kernel",
+             head, Ch, Co, addPlan ? " + add" : "", 2 * G, p.HH, p.HWd, p.nChunks, plan->threads, lds, fusedBytes);
     plan->desc = buf;
     if (r6) plan->desc += " relu6-epilogues";
     *out = plan;

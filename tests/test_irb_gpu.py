@@ -99,9 +99,9 @@ def test_irb_fusion_can_be_switched_off_and_declines_what_it_cannot_do(ctx, monk
         snn.chain_plan(ctx, [pe, pd, pp])
     assert e.value.code == snn.E_UNSUPPORTED
     monkeypatch.delenv("SNNHIP_NO_IRB_FUSION")
-    pt = snn.conv2d_plan(ctx, 1, 32, 32, we, be, act="tanh", bn=bne)  # a non-"simple" activation: stays unfused
-    with pytest.raises(snn.SnnHipError):
-        snn.chain_plan(ctx, [pt, pd, pp])
+    pt = snn.conv2d_plan(ctx, 1, 32, 32, we, be, act="tanh", bn=bne)  # a non-"simple" activation: the expand layer stays a launch of its own ...
+    two = snn.chain_plan(ctx, [pt, pd, pp])                            # ... and the depthwise -> pointwise pair behind it still fuses
+    assert two.num_steps() == 2 and "[depthwise3x3" in two.describe(), two.describe()
 
 
 @pytest.mark.parametrize("mode", ["default", "all"])
@@ -154,3 +154,27 @@ def test_irb_every_wave_tile_size_matches_the_separate_layers(ctx, monkeypatch, 
         plan = snn.chain_plan(ctx, [pe, pd, pp])
     assert "tile=%dx8px per wave" % (2 * G) in plan.describe(), plan.describe()
     np.testing.assert_allclose(plan(xt).numpy(), sep.numpy(), err_msg=plan.describe(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 112, 112, 32, 16, 1, "relu6", ""), (1, 45, 37, 16, 24, 2, "relu6", "relu"), (2, 30, 30, 48, 8, 1, "", "")],
+                         ids=["mbv2_block0", "s2_ragged", "c48"])
+def test_depthwise_pointwise_pair_runs_as_one_kernel(ctx, case):
+    """Rule G without an expand layer: DepthwiseConv2D 3x3 -> Conv2D 1x1 (MobileNetV2's first block, expansion factor 1): the kernel's hidden slice is
+    the x tile itself.  Against the oracle and the two separate layers."""
+    import shadernn_amd as snn
+
+    N, H, W, C, Co, s, a1, a2 = case
+    x = _rand((N, H, W, C), 3)
+    wd, bd, bnd = _rand((C, 3, 3), 4, 1.0 / 3.0), _rand((C,), 5, 0.1), _bn(C, 6)
+    wp, bp, bnp = _rand((Co, C, 1, 1), 7, 1.0 / np.sqrt(C)), _rand((Co,), 8, 0.1), _bn(Co, 9)
+    pd = snn.conv2d_plan(ctx, N, H, W, wd, bd, stride=s, pads=O.padding_offsets("same", 3), act=a1, bn=bnd, depthwise=True)
+    _, OH, OW, _ = pd.out_shape()
+    pp = snn.conv2d_plan(ctx, N, OH, OW, wp, bp, act=a2, bn=bnp)
+    plan = snn.chain_plan(ctx, [pd, pp])
+    assert plan.num_steps() == 1 and "irb_fused" in plan.describe() and "[depthwise3x3 %d s%d + conv1x1" % (C, s) in plan.describe(), plan.describe()
+    xt = snn.Tensor.from_numpy(ctx, x)
+    got = plan(xt).numpy()
+    d = O.depthwise(x, wd, bd, s, O.padding_offsets("same", 3), a1, 0.0, bnd)
+    want = O.conv2d(d, wp, bp, 1, (0, 0, 0, 0), "constant", a2, 0.0, bnp, threads=8)
+    np.testing.assert_allclose(got, want, err_msg=plan.describe(), **TOL)
+    np.testing.assert_allclose(got, pp(pd(xt)).numpy(), err_msg=plan.describe(), rtol=2e-5, atol=2e-5)

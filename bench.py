@@ -413,7 +413,12 @@ def main():
                 ms, n = p.profile_read(i)
                 fl, by = p.step_cost(i)
                 if n:
-                    kernels.append({"kernel": p.step_describe(i), "launches": n, "avg_us": 1e3 * ms / n, "flops": fl, "bytes": by})
+                    desc = p.step_describe(i)
+                    # a fused plan's cost() keeps the SURVEY 8(d) accounting of the layers it replaces (the whole-step roofline is quoted on that); the
+                    # kernel-level roofline uses what the fused kernel itself has to move, which such plans publish as hbm_bytes=... in their description
+                    fused_bytes = [tk.split("=", 1)[1] for tk in desc.split(" ") if tk.startswith("hbm_bytes=")]
+                    kernels.append({"kernel": desc, "launches": n, "avg_us": 1e3 * ms / n, "flops": fl, "bytes": float(fused_bytes[0]) if fused_bytes else by,
+                                    "bytes_unfused_accounting": by})
 
     if rank == 0:
         flops, bytes_unfused = wl.cost()

@@ -292,7 +292,7 @@ decltype(Conv1x1StreamPlan::kernel) pick16(bool simple) {
 int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     const char* sw = snnhip::option("SNNHIP_CONV_1X1"); // 0: off; 2: also take few-tile deep-K layers (parity tests at oracle-sized shapes)
     if (sw && atoi(sw) == 0) return SNNHIP_E_UNSUPPORTED;
-    if (g.normMean) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
+    if (g.normShift) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
     const bool f16 = g.dtype == SNNHIP_F16;
     if (f16 && g.OC % 8 != 0) return SNNHIP_E_UNSUPPORTED; // the fp16 variant stores 8-channel vectors
     if ((g.dtype != SNNHIP_F32 && !f16) || g.kh != 1 || g.kw != 1 || g.sh != g.sw || g.sh < 1 || g.sh > 2 || g.preMode != 0 || g.padx != 0 || g.pady != 0) return SNNHIP_E_UNSUPPORTED;

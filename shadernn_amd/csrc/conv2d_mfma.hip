@@ -163,7 +163,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED; // 32-bit element offsets in the kernel
 
     // graph rule I (InstanceNorm applied in the staging): the fp16 kernels with whole 8-channel slots, one image per pixel tile
-    const bool preNorm = g.normMean != nullptr;
+    const bool preNorm = g.normShift != nullptr;
     if (preNorm && (!f16 || g.IC % 8 != 0 || !act_is_simple(g.normAct))) return SNNHIP_E_UNSUPPORTED;
 
     const int taps = g.kh * g.kw;
@@ -319,10 +319,10 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     // fp16 output tile through LDS (see the kernel's epilogue): needs whole 8-channel vectors and the direct (non split-K) epilogue
     p.ldsEpi = (f16 && p.splitK == 1 && g.OC % 8 == 0 && !snnhip::option("SNNHIP_CONV_DIRECT_STORE")) ? 1 : 0;
     size_t ldsNeed = p.chunksPerSplit == 1 ? L.ldsBytes / 2 : L.ldsBytes; // one chunk per block: no second staging buffer
-    p.normMean = g.normMean; p.normMul = g.normMul; p.normBeta = g.normBeta;
+    p.normShift = g.normShift; p.normMul = g.normMul;
     p.normAc = make_act_cfg(preNorm ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
     p.normTabOfs = static_cast<int>(ldsNeed / 4);
-    if (preNorm) ldsNeed += static_cast<size_t>(3) * g.IC * sizeof(float); // [mean | mul | beta] behind the staging buffers
+    if (preNorm) ldsNeed += static_cast<size_t>(2) * g.IC * sizeof(float); // [shift | mul] behind the staging buffers
     if (p.ldsEpi) ldsNeed = std::max(ldsNeed, static_cast<size_t>(128) * (BN + 8) * 2);
     const bool simple = act_is_simple(g.act);
     KernelFn fn = nullptr;
@@ -440,7 +440,7 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         const char* force = snnhip::option("SNNHIP_CONV");
         const char* w = snnhip::option("SNNHIP_CONV_WINO");
         const bool forced = force && strcmp(force, "wino") == 0;
-        const bool allowed = !force && !(w && atoi(w) == 0) && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_C8") && g.IC >= 32 && g.OC >= 32 && !g.normMean;
+        const bool allowed = !force && !(w && atoi(w) == 0) && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_C8") && g.IC >= 32 && g.OC >= 32 && !g.normShift;
         if (forced || allowed) {
             const int rc = make_conv2d_wino_plan(ctx, g, w_oihw, epi4, out);
             if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;

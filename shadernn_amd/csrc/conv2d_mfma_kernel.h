@@ -45,11 +45,10 @@ struct MfmaParams { // (declared after ActCfg: epilogue.h)
     // statPart[((n*tilesY + ty)*tilesX + tx)][2][OC] = {mean, sum of squared deviations} of the tile's valid pixels, per channel
     float* statPart;
     // InstanceNorm in front of the convolution (graph rule I; fp16 kernels, one image per pixel tile, IC % 8 == 0): applied to the staged values
-    const float* normMean;
+    const float* normShift; // y = normAc(x * mul[n][c] + shift[n][c]): the norm's own fma (eltwise_pool.hip)
     const float* normMul;
-    const float* normBeta;
     ActCfg normAc;
-    int normTabOfs; // float offset in LDS of [mean | mul | beta] x IC of the tile's image
+    int normTabOfs; // float offset in LDS of [shift | mul] x IC of the tile's image
 };
 
 // LDS layout of the staged activations.  A pixel owns ICc floats = ICc/4 16-byte slots; the slot is XOR-swizzled with
@@ -125,13 +124,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
             const int c = pix - t2 * p.tileW;
             const int b = p.tileH == 1 ? t2 : static_cast<int>(__umulhi(static_cast<unsigned>(t2), p.magicH));
             const int rr = t2 - b * p.tileH;
-            int sy = resolve_coord(iy0 + rr, p.H, p.padMode);
-            int sx = resolve_coord(ix0 + c, p.W, p.padMode);
-            if (p.preMode && sy >= 0 && sx >= 0) { // a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied
-                sy = resolve_coord(sy - p.preY, p.srcH << p.preShift, p.preMode);
-                sx = resolve_coord(sx - p.preX, p.srcW << p.preShift, p.preMode);
-                if (sy >= 0) sy >>= p.preShift; // nearest x2: upsampled pixel (y, x) is source pixel (y / 2, x / 2) (vk_upsampling2d_nearest.comp:50-65)
-                if (sx >= 0) sx >>= p.preShift;
+            int sy = resolve_nobranch(iy0 + rr, p.H, p.padMode);
+            int sx = resolve_nobranch(ix0 + c, p.W, p.padMode);
+            if (p.preMode) { // (uniform) a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied; -1 stays -1
+                const int py = resolve_nobranch(sy - p.preY, p.srcH << p.preShift, p.preMode), px = resolve_nobranch(sx - p.preX, p.srcW << p.preShift, p.preMode);
+                sy = sy < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift); // nearest x2: upsampled pixel (y, x) is source pixel (y / 2, x / 2) (vk_upsampling2d_nearest.comp:50-65)
+                sx = sx < 0 ? -1 : (px < 0 ? -1 : px >> p.preShift);
             }
             const int n = b0 + b;
             const int cm = p.evenCols ? (c & 1) * p.evenCols + (c >> 1) : c;
@@ -161,23 +159,23 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
     };
     auto stage_store = [&](float* buf, int ic0) {
         if constexpr (F16) {
-            if (p.normMean && ic0 + q * CH < p.IC) { // block-uniform switch; a thread's elements share their 8 channels
+            if (p.normShift && ic0 + q * CH < p.IC) { // block-uniform switch; a thread's elements share their 8 channels
                 const float* tab = smem + p.normTabOfs + ic0 + q * CH;
-                float mean[8], mul[8], bt[8];
+                float sh[8], mul[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    mean[k] = tab[k];
+                    sh[k] = tab[k];
                     mul[k] = tab[p.IC + k];
-                    bt[k] = tab[2 * p.IC + k];
                 }
+                const bool relu = p.normAc.act == SNNHIP_ACT_RELU; // (uniform) one instruction instead of the general mul / max / med3
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (gofs[r] >= 0) { // zero padding stays zero: the border applies to the NORMALISED tensor
                         h8 hv = *reinterpret_cast<const h8*>(&stage[r]);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                            const float v = (static_cast<float>(hv[k]) - mean[k]) * mul[k] + bt[k];
-                            hv[k] = static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(v, v * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                            const float v = fmaf(static_cast<float>(hv[k]), mul[k], sh[k]);
+                            hv[k] = static_cast<_Float16>(relu ? fmaxf(v, 0.0f) : __builtin_amdgcn_fmed3f(fmaxf(v, v * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
                         }
                         stage[r] = *reinterpret_cast<const float4*>(&hv);
                     }
@@ -258,13 +256,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
 
     stage_load(chunk0 * 2 * CH * C8);
     if constexpr (F16) {
-        if (p.normMean) { // the norm's statistics of this tile's image (TB == 1) and its beta -> LDS
+        if (p.normShift) { // the norm's (shift, multiplier) of this tile's image (TB == 1) -> LDS
             float* tab = smem + p.normTabOfs;
             const int n = min(b0, p.N - 1);
             for (int i = tid; i < p.IC; i += 256) {
-                tab[i] = p.normMean[static_cast<size_t>(n) * p.IC + i];
+                tab[i] = p.normShift[static_cast<size_t>(n) * p.IC + i];
                 tab[p.IC + i] = p.normMul[static_cast<size_t>(n) * p.IC + i];
-                tab[2 * p.IC + i] = p.normBeta[i];
             }
             __syncthreads();
         }

@@ -30,10 +30,9 @@ struct RowfoldParams {
     int N, H, W, IC, OC, OH, OW, padx, pady, padMode, useBN;
     int preMode, preX, preY, srcH, srcW, preShift; // fused Pad / nearest x2 upsampling in front (ConvGeom)
     int tilesX, tilesY;
-    // InstanceNorm in front (graph rule I): normAc((x - mean[n][c]) * mul[n][c] + beta[c]) applied to the staged values; null = none
-    const float* normMean;
+    // InstanceNorm in front (graph rule I): normAc(x * mul[n][c] + shift[n][c]) applied to the staged values; null = none
+    const float* normShift;
     const float* normMul;
-    const float* normBeta;
     ActCfg normAc;
 };
 
@@ -65,16 +64,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_kernel(RowfoldParams p,
         const _Float16* xn = x + static_cast<size_t>(n) * p.srcH * p.srcW * p.IC;
         // all of a thread's loads (16 for a 16 x 64 x 32-channel tile) are requested before the first LDS store: one HBM round trip per block
         // graph rule I: a thread's elements all sit in channel slot tid % Q (256 % Q == 0), i.e. share their 8 channels and, within a block, the image
-        float nMean[8], nMul[8], nBeta[8];
-        if (p.normMean) {
+        float nShift[8], nMul[8];
+        if (p.normShift) {
             const int cb = 8 * (tid % Q);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                nMean[k] = p.normMean[static_cast<size_t>(n) * p.IC + cb + k];
+                nShift[k] = p.normShift[static_cast<size_t>(n) * p.IC + cb + k];
                 nMul[k] = p.normMul[static_cast<size_t>(n) * p.IC + cb + k];
-                nBeta[k] = p.normBeta[cb + k];
             }
         }
+        const bool nRelu = p.normAc.act == SNNHIP_ACT_RELU; // (uniform) one instruction instead of the general mul / max / med3
         for (int base = tid; base < TOTAL; base += 16 * 256) {
             float4 v[16];
             int lo[16];
@@ -87,12 +86,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_kernel(RowfoldParams p,
                 if (e < TOTAL) {
                     const int s = e % Q, pc = e / Q;
                     const int c = pc % kCols, rr = pc / kCols;
-                    int sy = resolve_coord(iy0 + rr, p.H, p.padMode), sx = resolve_coord(ix0 + c, p.W, p.padMode);
-                    if (p.preMode && sy >= 0 && sx >= 0) {
-                        sy = resolve_coord(sy - p.preY, p.srcH << p.preShift, p.preMode);
-                        sx = resolve_coord(sx - p.preX, p.srcW << p.preShift, p.preMode);
-                        if (sy >= 0) sy >>= p.preShift;
-                        if (sx >= 0) sx >>= p.preShift;
+                    int sy = resolve_nobranch(iy0 + rr, p.H, p.padMode), sx = resolve_nobranch(ix0 + c, p.W, p.padMode);
+                    if (p.preMode) { // (uniform) a pixel of the padded image -> the source pixel the Pad layer would have copied; -1 stays -1
+                        const int py = resolve_nobranch(sy - p.preY, p.srcH << p.preShift, p.preMode), px = resolve_nobranch(sx - p.preX, p.srcW << p.preShift, p.preMode);
+                        sy = sy < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
+                        sx = sx < 0 ? -1 : (px < 0 ? -1 : px >> p.preShift);
                     }
                     if (sy >= 0 && sx >= 0) {
                         v[r] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(sy) * p.srcW + sx) * p.IC + 8 * s);
@@ -101,15 +99,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_kernel(RowfoldParams p,
                     lo[r] = ((rr * kCols + c) * Q + (s ^ ((c >> (Q == 4 ? 2 : 3)) & (Q - 1)))) * 4;
                 }
             }
-            if (p.normMean) {
+            if (p.normShift) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (live & (1u << r)) {
                         h8 hv = *reinterpret_cast<const h8*>(&v[r]);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                            const float f = (static_cast<float>(hv[k]) - nMean[k]) * nMul[k] + nBeta[k];
-                            hv[k] = static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                            const float f = fmaf(static_cast<float>(hv[k]), nMul[k], nShift[k]);
+                            hv[k] = static_cast<_Float16>(nRelu ? fmaxf(f, 0.0f) : __builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
                         }
                         v[r] = *reinterpret_cast<const float4*>(&hv);
                     }
@@ -218,7 +216,7 @@ int make_conv2d_rowfold_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     // eligibility: half tensors, square odd kernel 5 / 7 / 9, stride 1, k * OC <= 32, IC = 16 or 32 (the weights of a lane stay in registers)
     const char* force = snnhip::option("SNNHIP_CONV");
     if (force && strcmp(force, "rowfold") != 0) return SNNHIP_E_UNSUPPORTED;
-    if (g.normMean && !act_is_simple(g.normAct)) return SNNHIP_E_UNSUPPORTED;
+    if (g.normShift && !act_is_simple(g.normAct)) return SNNHIP_E_UNSUPPORTED;
     if (g.dtype != SNNHIP_F16 || g.kh != g.kw || (g.kh != 5 && g.kh != 7 && g.kh != 9) || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
     if (g.kh * g.OC > 32 || (g.IC != 16 && g.IC != 32) || g.act == SNNHIP_ACT_SILU_QUIRK || g.addAct >= 0) return SNNHIP_E_UNSUPPORTED;
     if (static_cast<double>(g.N) * g.H * g.W * g.IC >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
@@ -230,8 +228,8 @@ int make_conv2d_rowfold_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     p.srcW = g.preMode ? g.srcW : g.W;
     p.tilesX = up_div(g.OW, TW);
     p.tilesY = up_div(g.OH, kTH);
-    p.normMean = g.normMean; p.normMul = g.normMul; p.normBeta = g.normBeta;
-    p.normAc = make_act_cfg(g.normMean ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
+    p.normShift = g.normShift; p.normMul = g.normMul;
+    p.normAc = make_act_cfg(g.normShift ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
     const size_t lds = std::max(static_cast<size_t>(kTH + K - 1) * kCols * g.IC * 2, static_cast<size_t>(kTH) * kCols * kPP * sizeof(float));
     const bool simple = act_is_simple(g.act);
     RowfoldFn fn = K == 9 ? pick_rowfold<9>(ICS, simple) : K == 7 ? pick_rowfold<7>(ICS, simple) : pick_rowfold<5>(ICS, simple);
@@ -278,7 +276,7 @@ int make_conv2d_rowfold_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     plan->desc = buf;
     if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
     if (g.preMode && g.preShift) plan->desc += " +upsample(x2)";
-    if (g.normMean) plan->desc = "instancenorm(act=" + std::to_string(g.normAct) + ", in the staging) -> " + plan->desc;
+    if (g.normShift) plan->desc = "instancenorm(act=" + std::to_string(g.normAct) + ", in the staging) -> " + plan->desc;
     *out = plan;
     return SNNHIP_OK;
 }

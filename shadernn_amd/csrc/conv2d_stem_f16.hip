@@ -40,13 +40,6 @@ constexpr int kInH = kTH + kK - 1, kInW = kTW + kK - 1; // staged halo tile
 constexpr int kSteps = 2 * kK + 3;    // 18 full steps + 3 left-over steps
 constexpr int kOutPitch = 40;         // halfs per pixel row of the wave's output scratch (80 bytes: 16-byte aligned rows, the 8-byte runs of 16 lanes on distinct banks)
 
-__device__ __forceinline__ int resolve_nb(int s, int size, int mode) {
-    const int cl = min(max(s, 0), size - 1);
-    int rf = s < 0 ? -s : s;
-    rf = rf >= size ? 2 * size - 2 - rf : rf;
-    const int t = mode == SNNHIP_PAD_REPLICATE ? cl : (mode == SNNHIP_PAD_REFLECT ? rf : s);
-    return (t >= 0 && t < size) ? t : -1;
-}
 
 template <bool SIMPLE>
 __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
@@ -78,10 +71,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
         for (int r = 0; r < kR; ++r) {
             const int e = tid + 256 * r;
             const int rr = e / kInW, c = e - rr * kInW;
-            int sy = resolve_nb(ty * kTH - p.pady + rr, p.H, p.padMode);
-            int sx = resolve_nb(tx * kTW - p.padx + c, p.W, p.padMode);
+            int sy = resolve_nobranch(ty * kTH - p.pady + rr, p.H, p.padMode);
+            int sx = resolve_nobranch(tx * kTW - p.padx + c, p.W, p.padMode);
             if (p.preMode) {
-                const int py = resolve_nb(sy - p.preY, p.srcH, p.preMode), px = resolve_nb(sx - p.preX, p.srcW, p.preMode);
+                const int py = resolve_nobranch(sy - p.preY, p.srcH, p.preMode), px = resolve_nobranch(sx - p.preX, p.srcW, p.preMode);
                 sy = sy < 0 ? -1 : py;
                 sx = sx < 0 ? -1 : px;
             }
@@ -217,7 +210,7 @@ struct StemConvPlan : ConvPlanBase {
 int make_conv2d_stem_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.dtype != SNNHIP_F16 || g.kh != kK || g.kw != kK || g.sh != 1 || g.sw != 1 || g.IC > 4 || g.OC % 32 != 0) return SNNHIP_E_UNSUPPORTED;
     if (g.addAct >= 0 || (g.preMode && g.preShift) || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED;
-    if (g.normMean) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
+    if (g.normShift) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
     if (const char* e = snnhip::option("SNNHIP_CONV_STEM"))
         if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
     if (const char* f = snnhip::option("SNNHIP_CONV"))

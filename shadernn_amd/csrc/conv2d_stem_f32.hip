@@ -30,13 +30,6 @@ constexpr int kNR = 4;                  // output rows per wave
 constexpr int kTH = 4 * kNR, kTW = 32;  // block tile: 4 waves stacked in y
 constexpr int kOutPitch = 36;           // floats per pixel row of a wave's output scratch (32 + 4: 16-byte aligned, the runs of 8 lanes on distinct banks)
 
-__device__ __forceinline__ int resolve_nb32(int s, int size, int mode) {
-    const int cl = min(max(s, 0), size - 1);
-    int rf = s < 0 ? -s : s;
-    rf = rf >= size ? 2 * size - 2 - rf : rf;
-    const int t = mode == SNNHIP_PAD_REPLICATE ? cl : (mode == SNNHIP_PAD_REFLECT ? rf : s);
-    return (t >= 0 && t < size) ? t : -1;
-}
 
 template <int K, int S, bool SIMPLE>
 __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem32Params p, ActCfg ac, const float* __restrict__ x, const float* __restrict__ wp,
@@ -69,8 +62,8 @@ __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem
         for (int r = 0; r < kR; ++r) {
             const int e = tid + 256 * r;
             const int rr = e / IN_W, c = e - rr * IN_W;
-            const int sy = resolve_nb32(oy0 * S - p.pady + rr, p.H, p.padMode);
-            const int sx = resolve_nb32(ox0 * S - p.padx + c, p.W, p.padMode);
+            const int sy = resolve_nobranch(oy0 * S - p.pady + rr, p.H, p.padMode);
+            const int sx = resolve_nobranch(ox0 * S - p.padx + c, p.W, p.padMode);
             const bool ok = e < IN_H * IN_W && sy >= 0 && sx >= 0;
             const float* src = x + (static_cast<size_t>(n * p.H + (ok ? sy : 0)) * p.W + (ok ? sx : 0)) * p.IC;
 #pragma unroll
@@ -172,7 +165,7 @@ Stem32Fn pick_stem32(bool simple) {
 // tap-pair mode
 int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.dtype != SNNHIP_F32 || g.kh != g.kw || g.sh != g.sw || g.IC > 4 || g.OC % 32 != 0) return SNNHIP_E_UNSUPPORTED;
-    if (g.addAct >= 0 || g.preMode || g.normMean || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED; // (the quirk couples 4 adjacent pixels)
+    if (g.addAct >= 0 || g.preMode || g.normShift || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED; // (the quirk couples 4 adjacent pixels)
     if (const char* e = snnhip::option("SNNHIP_CONV_STEM"))
         if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
     if (const char* f = snnhip::option("SNNHIP_CONV"))

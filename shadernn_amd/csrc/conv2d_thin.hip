@@ -224,7 +224,7 @@ struct ThinConvPlan : ConvPlanBase {
 
 int make_conv2d_thin_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.preMode) return SNNHIP_E_UNSUPPORTED; // the fused-Pad address path exists in the MFMA kernel only
-    if (g.normMean) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
+    if (g.normShift) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
 
     const char* force = snnhip::option("SNNHIP_CONV");
     if (force && strcmp(force, "thin") != 0) return SNNHIP_E_UNSUPPORTED; // generic / mfma forced

@@ -14,9 +14,8 @@
 //       WM=2 WN=2 NT=2: 256 px x 128 oc     WM=4 WN=1 NT=2: 512 px x 64 oc     WM=4 WN=1 NT=1: 512 px x 32 oc
 //   * halo tile staged through registers into LDS in channel chunks of 16 C8 (double-buffered, one barrier per chunk), XOR-swizzled 16-byte
 //     slots as in conv2d_mfma_kernel (lds_off); the fused Pad / UpSampling address path (ConvGeom::preMode / preShift) resolves here;
-//   * optional pre-normalisation (graph rule I): the InstanceNorm in front of the convolution applied to the staged values
-//     (act((x - mean) * mul + beta), fp32, rounded to half -- the rounding point of the separate normalise sweep), so the normalised tensor is
-//     never written: the norm runs its statistics sweep + fold only;
+//   * (graph rule I, the InstanceNorm in front applied while staging, is NOT in this kernel: DMA staging has no registers to apply it in, and an
+//     in-LDS fix-up pass costs more than the norm's own normalise sweep on these layers -- conv2d_mfma / conv2d_rowfold have it)
 //   * weights packed exactly as for conv2d_mfma_kernel ([chunk][tap][c8][h][OCp] x 8 halfs), streamed per lane with a 3-step ring;
 //   * the weights are the MFMA's A operand, the pixels its B operand: a lane ends up with runs of 4 consecutive output channels of its own
 //     pixel and the epilogue (bias / BN / activation / fused residual Add) stores them directly, 8 bytes per lane, without an LDS transpose.
@@ -46,22 +45,7 @@ struct WideParams {
     unsigned magicW;
     const void* res; // fused residual Add (chain rule E)
     ActCfg ac2;
-    // pre-normalisation (graph rule I): per (image, channel) mean and multiplier of the InstanceNorm in front, its beta and activation
-    const float* normMean;
-    const float* normMul;
-    const float* normBeta;
-    ActCfg normAc;
 };
-
-// resolve_coord (epilogue.h) without its switch: the prologue resolves 2 x 2 coordinates for each of R staging elements, and the taken
-// branches (the mode is uniform, but s_cbranch still drains the pipeline) were a visible part of a block's start-up
-__device__ __forceinline__ int resolve_nobranch(int s, int size, int mode) {
-    const int cl = min(max(s, 0), size - 1);
-    int rf = s < 0 ? -s : s;
-    rf = rf >= size ? 2 * size - 2 - rf : rf;
-    const int t = mode == SNNHIP_PAD_REPLICATE ? cl : (mode == SNNHIP_PAD_REFLECT ? rf : s);
-    return (t >= 0 && t < size) ? t : -1;
-}
 
 template <int WM, int WN, int NT, int C8, int R, bool SIMPLE, bool RES>
 __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
@@ -320,7 +304,7 @@ WideFn pick_wide(bool simple, bool res) {
 int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
     if (g.IC % 16 != 0 || g.OC % 32 != 0 || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED;
-    if (g.normMean) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
+    if (g.normShift) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
     const double inCount = static_cast<double>(g.N) * (g.preMode ? g.srcH : g.H) * (g.preMode ? g.srcW : g.W) * g.IC;
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
@@ -362,8 +346,6 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.magicW = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(p.tileW) - 1) / static_cast<unsigned>(p.tileW));
     p.res = nullptr;
     p.ac2 = make_act_cfg(g.addAct >= 0 ? g.addAct : SNNHIP_ACT_NONE, g.addLeaky);
-    p.normMean = p.normMul = p.normBeta = nullptr;
-    p.normAc = make_act_cfg(SNNHIP_ACT_NONE, 0.0f);
 
     const bool simple = act_is_simple(g.act);
     const bool withRes = g.addAct >= 0;

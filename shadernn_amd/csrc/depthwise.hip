@@ -238,7 +238,7 @@ struct DepthwisePlan : ConvPlanBase {
 
 int make_depthwise_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_chw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.preMode) return SNNHIP_E_UNSUPPORTED; // the fused-Pad address path exists in the MFMA kernel only
-    if (g.normMean) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
+    if (g.normShift) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
 
     auto* plan = new DepthwisePlan();
     plan->ctx = ctx;

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
         float piv[CV], mul[CV], bt[CV];
 #pragma unroll
         for (int k = 0; k < CV; ++k) {
-            piv[k] = cok ? (STAGE == 0 ? static_cast<float>(xn[c + k]) : statMean[static_cast<size_t>(n) * d.C + c + k]) : 0.0f; // stage 0: pivot, stage 2: mean
+            piv[k] = cok ? (STAGE == 0 ? static_cast<float>(xn[c + k]) : statMean[static_cast<size_t>(n) * d.C + c + k]) : 0.0f; // stage 0: pivot, stage 2: shift
             mul[k] = (STAGE == 2 && cok) ? statMul[static_cast<size_t>(n) * d.C + c + k] : 0.0f;
             bt[k] = (STAGE == 2 && cok) ? beta[c + k] : 0.0f;
         }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
             } else {
                 float o[CV];
 #pragma unroll
-                for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, (v[k] - piv[k]) * mul[k] + bt[k]);
+                for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, fmaf(v[k], mul[k], piv[k])); // x * mul + shift (shift = beta - mean * mul, from the fold)
                 if (res) {
                     if (rp >= 0) {
 #pragma unroll
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
 // ~1000 slab partials with dependent L2 loads took longer than both sweeps together)
 template <typename T>
 __global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, int S, int HW, float invHW, float eps, const T* __restrict__ x,
-                                                               const float* __restrict__ part, const float* __restrict__ gamma,
-                                                               float* __restrict__ mean, float* __restrict__ mul) {
+                                                               const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ shift, float* __restrict__ mul) {
     __shared__ float r1[256], r2[256];
     const int i = blockIdx.x;
     const int n = i / C, c = i % C;
@@ -408,8 +408,11 @@ __global__ __launch_bounds__(256) void instancenorm_fold_kernel(int NC, int C, i
     const float m1 = a1 * invHW;
     float var = a2 * invHW - m1 * m1;
     var = var > 0.0f ? var : 0.0f;
-    mean[i] = piv + m1;
-    mul[i] = gamma[c] / sqrtf(var + eps);
+    // the normalisation as ONE multiply-add per value, y = x * mul + shift (every consumer -- the normalise sweep below and the convolutions that
+    // normalise while they stage, graph rule I -- evaluates exactly this fma, so they stay bit-identical to one another)
+    const float mu = gamma[c] / sqrtf(var + eps);
+    mul[i] = mu;
+    shift[i] = beta[c] - (piv + m1) * mu;
 }
 
 // Chain rule F: the producing convolution already reduced every output tile to (mean_t, M2_t) per channel (conv2d_mfma_kernel's LDS
@@ -471,7 +474,8 @@ __global__ __launch_bounds__(256) void instancenorm_fold_tiles1_kernel(int C, in
 }
 
 __global__ __launch_bounds__(256) void instancenorm_fold_tiles2_kernel(int C, int chunks, float eps, const float* __restrict__ part2,
-                                                                      const float* __restrict__ gamma, float* __restrict__ mean, float* __restrict__ mul) {
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ shift,
+                                                                      float* __restrict__ mul) {
     __shared__ float red[3][256];
     const int n = blockIdx.x;
     const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6; // channel lane, 1 of 4 chunk lanes (chunks kl, kl + 4, ...)
@@ -493,8 +497,9 @@ __global__ __launch_bounds__(256) void instancenorm_fold_tiles2_kernel(int C, in
             for (int j = 1; j < 4; ++j) stat_merge(a, red[0][j * 64 + cl], red[1][j * 64 + cl], red[2][j * 64 + cl]);
             float var = a.q / a.n;
             var = var > 0.0f ? var : 0.0f;
-            mean[n * C + c] = a.m;
-            mul[n * C + c] = gamma[c] / sqrtf(var + eps);
+            const float mu = gamma[c] / sqrtf(var + eps);
+            mul[n * C + c] = mu;
+            shift[n * C + c] = beta[c] - a.m * mu; // y = x * mul + shift (see instancenorm_fold_kernel)
         }
     }
 }
@@ -649,7 +654,7 @@ struct UpsamplePlan : UpsamplePlanBase {
 struct InstanceNormPlan : snnhip_plan {
     snnhip_instancenorm_desc d;
     int S = 1, pixelsPerSlab = 1, CLs = 2;
-    float *d_beta = nullptr, *d_gamma = nullptr, *d_part = nullptr, *d_mean = nullptr, *d_mul = nullptr;
+    float *d_beta = nullptr, *d_gamma = nullptr, *d_part = nullptr, *d_mean = nullptr /* shift[n][c] = beta - mean * mul */, *d_mul = nullptr;
     float* d_foldScratch = nullptr; // chain rule F: level-1 records of the tile-statistics fold
     size_t foldScratchCount = 0;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
@@ -682,7 +687,7 @@ struct InstanceNormPlan : snnhip_plan {
     hipLaunchKernelGGL((instancenorm_kernel<ST, CVV, T>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta, d_part, \
                        mptr<T>(out), ST == 2 ? ra : InResidual())
 #define SNNHIP_FOLD() \
-    hipLaunchKernelGGL(instancenorm_fold_kernel<T>, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, cptr<T>(in[0]), d_part, d_gamma, d_mean, d_mul)
+    hipLaunchKernelGGL(instancenorm_fold_kernel<T>, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, cptr<T>(in[0]), d_part, d_gamma, d_beta, d_mean, d_mul)
         SNNHIP_WITH_T(out->dtype, if ((d.C & 3) == 0) {
             SNNHIP_IN(0, 4);
             SNNHIP_FOLD();
@@ -735,14 +740,13 @@ int make_instancenorm_add_plan(snnhip_ctx* ctx, snnhip_plan* normPlan, snnhip_pl
     return SNNHIP_OK;
 }
 
-// graph rule I: where the norm's per-(image, channel) statistics and its beta live (device pointers, stable for the life of the plan), and the
+// graph rule I: where the norm's per-(image, channel) multiplier and shift (y = x * mul + shift) live (device pointers, stable for the life of the plan), and the
 // two launches that fill them from a tensor
-bool instancenorm_stat_pointers(const snnhip_plan* plan, const float** mean, const float** mul, const float** beta) {
+bool instancenorm_stat_pointers(const snnhip_plan* plan, const float** shift, const float** mul) {
     const auto* q = dynamic_cast<const InstanceNormPlan*>(plan);
     if (!q) return false;
-    *mean = q->d_mean;
+    *shift = q->d_mean;
     *mul = q->d_mul;
-    *beta = q->d_beta;
     return true;
 }
 int instancenorm_run_stats(snnhip_plan* plan, const snnhip_tensor* x) {
@@ -788,7 +792,7 @@ int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const float* statPart, in
     hipLaunchKernelGGL(instancenorm_fold_tiles1_kernel, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, d.H, d.W,
                        tilesX, tilesY, TH, TW, statPart, q->d_foldScratch);
     hipLaunchKernelGGL(instancenorm_fold_tiles2_kernel, dim3(static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, chunks, d.eps, q->d_foldScratch, q->d_gamma,
-                       q->d_mean, q->d_mul);
+                       q->d_beta, q->d_mean, q->d_mul);
     const dim3 g(static_cast<unsigned>(d.N * q->S));
 #define SNNHIP_IN2(CVV) \
     hipLaunchKernelGGL((instancenorm_kernel<2, CVV, T>), g, dim3(256), 0, ctx->stream, d, q->S, q->pixelsPerSlab, q->CLs, cptr<T>(xy), q->d_mean, q->d_mul, q->d_beta, q->d_part, mptr<T>(xy))

@@ -144,4 +144,14 @@ __device__ __forceinline__ int resolve_coord(int s, int size, int padMode) {
     return (s >= 0 && s < size) ? s : -1;
 }
 
+// resolve_coord without its switch, for staging code that resolves many coordinates per thread: the mode is uniform, but every taken s_cbranch
+// still drains the pipeline (conv2d_rowfold with a fused reflect Pad spent more on these branches than a separate Pad launch costs)
+__device__ __forceinline__ int resolve_nobranch(int s, int size, int mode) {
+    const int cl = min(max(s, 0), size - 1);
+    int rf = s < 0 ? -s : s;
+    rf = rf >= size ? 2 * size - 2 - rf : rf;
+    const int t = mode == SNNHIP_PAD_REPLICATE ? cl : (mode == SNNHIP_PAD_REFLECT ? rf : s);
+    return (t >= 0 && t < size) ? t : -1;
+}
+
 } // namespace snnhip

@@ -871,7 +871,7 @@ struct ConvInstanceNormPlan : snnhip_plan {
 };
 
 // Graph rule I: InstanceNorm -> [UpSampling] -> [Pad] -> Conv2D.  The norm runs its statistics sweep and fold only; the convolution (a copy
-// the chain owns, built with ConvGeom::normMean...) reads the norm's INPUT and normalises while it stages -- the normalised tensor is never
+// the chain owns, built with ConvGeom::normShift / normMul) reads the norm's INPUT and normalises while it stages -- the normalised tensor is never
 // written or re-read.  The norm plan is borrowed: its parameters and statistics buffers are the ones the convolution was given.
 struct InstanceNormConvPlan : snnhip_plan {
     snnhip_plan* norm = nullptr;
@@ -1374,13 +1374,13 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         if (a.kind != ChainPlan::PLAIN || b.kind != ChainPlan::PLAIN) continue;
         snnhip_instancenorm_desc nd;
         auto* cv = dynamic_cast<ConvPlanBase*>(b.plain);
-        if (!cv || cv->depthwise || cv->numInputs != 1 || cv->g.normMean || !instancenorm_plan_desc(a.plain, &nd) || !act_is_simple(nd.act)) continue;
+        if (!cv || cv->depthwise || cv->numInputs != 1 || cv->g.normShift || !instancenorm_plan_desc(a.plain, &nd) || !act_is_simple(nd.act)) continue;
         if (nd.N != cv->inDims[0] || nd.H != cv->inDims[1] || nd.W != cv->inDims[2] || nd.C != cv->inDims[3]) continue;
         // only where the convolution already runs on a kernel that can normalise: trading the 4 x 2-tile kernel (conv2d_wide_f16) for the
         // 128-pixel one costs more than the normalise sweep saves (measured on Candy's residual blocks: 160 + 290 us apart, 600 us folded)
         if (cv->desc.rfind("conv2d_mfma_f16_", 0) != 0 && cv->desc.rfind("conv2d_rowfold", 0) != 0) continue;
         ConvGeom g2 = cv->g;
-        if (!instancenorm_stat_pointers(a.plain, &g2.normMean, &g2.normMul, &g2.normBeta)) continue;
+        if (!instancenorm_stat_pointers(a.plain, &g2.normShift, &g2.normMul)) continue;
         g2.normAct = nd.act;
         g2.normLeaky = nd.leaky;
         snnhip_plan* fused = nullptr;

@@ -156,11 +156,10 @@ struct ConvGeom {
     int addAct = -1;
     float addLeaky = 0.0f;
     // InstanceNorm in front of the convolution [and of its fused Pad / UpSampling] (graph rule I): the kernel applies
-    // normAct((x - mean[n][c]) * mul[n][c] + beta[c]) to every value it stages (fp32 arithmetic, rounded to the tensor type: the rounding point of
-    // the norm's own normalise sweep); zero padding stays zero.  Device pointers owned by the InstanceNorm plan; null = none.
-    const float* normMean = nullptr;
+    // normAct(x * mul[n][c] + shift[n][c]) (one fp32 fma, rounded to the tensor type: the arithmetic and the rounding point of the norm's own
+    // normalise sweep) to every value it stages; zero padding stays zero.  Device pointers owned by the InstanceNorm plan; null = none.
+    const float* normShift = nullptr;
     const float* normMul = nullptr;
-    const float* normBeta = nullptr;
     int normAct = 0; // none / relu / relu6 / leakyRelu only
     float normLeaky = 0.0f;
 };
@@ -210,7 +209,7 @@ bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d
 // the Add's output must have the norm's extent (a smaller residual is added top-left aligned, the reference's ragged-Add rule)
 int make_instancenorm_add_plan(snnhip_ctx* ctx, snnhip_plan* normPlan, snnhip_plan* addPlan, bool normIsFirstInput, snnhip_plan** out);
 // graph rule I (InstanceNorm -> [Pad] -> Conv2D, the normalisation applied while the convolution stages its input)
-bool instancenorm_stat_pointers(const snnhip_plan* plan, const float** mean, const float** mul, const float** beta);
+bool instancenorm_stat_pointers(const snnhip_plan* plan, const float** shift, const float** mul);
 int instancenorm_run_stats(snnhip_plan* plan, const snnhip_tensor* x);
 int instancenorm_reserve_tile_stats(snnhip_plan* inPlan, int tilesX, int tilesY);
 int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const float* statPart, int tilesX, int tilesY, int TH, int TW, snnhip_tensor* xy);

@@ -45,6 +45,7 @@ struct WideParams {
     unsigned magicW;
     const void* res; // fused residual Add (chain rule E)
     ActCfg ac2;
+    float* statPart; // chain rule F: per (image, tile, channel) {mean, M2} of the stored values, [n][ty][tx][2][OC]; null = off
 };
 
 template <int WM, int WN, int NT, int C8, int R, bool SIMPLE, bool RES>
@@ -239,11 +240,32 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         for (int j = 0; j < NV; ++j) rpack[j] = oofs[j] >= 0 ? *reinterpret_cast<const float4*>(static_cast<const _Float16*>(p.res) + oofs[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    // chain rule F (p.statPart, uniform): the InstanceNorm behind this layer needs mean and variance per (image, channel).  A thread's NV vectors are
+    // NV pixels of ONE 8-channel column (256 % VPR == 0): sums of (v - pivot) and (v - pivot)^2 of the stored (rounded) values accumulate in
+    // registers while the vectors pass through, pivot = the thread's first pixel (the differences stay small: no cancellation in S2 - S1^2 / n)
+    float sPiv[8], sA[8], sB[8];
+    int sCnt = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sPiv[e] = sA[e] = sB[e] = 0.0f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int v = tid + 256 * j;
         const int i = v / VPR, c8 = v - i * VPR;
         float4 pack = *reinterpret_cast<const float4*>(otile + i * EPITCH + c8 * 8);
+        if (!RES && p.statPart && oofs[j] >= 0) {
+            const _Float16* ch = reinterpret_cast<const _Float16*>(&pack);
+            if (sCnt == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sPiv[e] = static_cast<float>(ch[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = static_cast<float>(ch[e]) - sPiv[e];
+                sA[e] += f;
+                sB[e] = fmaf(f, f, sB[e]);
+            }
+            ++sCnt;
+        }
         if (RES) {
             const _Float16* ch = reinterpret_cast<const _Float16*>(&pack);
             const _Float16* rh = reinterpret_cast<const _Float16*>(&rpack[RES ? j : 0]);
@@ -253,6 +275,72 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
             pack = *reinterpret_cast<const float4*>(oh);
         }
         if (oofs[j] >= 0 && !((SNNHIP_WIDE_ABL & 8) && p.OC != 12345)) *reinterpret_cast<float4*>(y + oofs[j]) = pack;
+    }
+    if (!RES && p.statPart) {
+        // thread record (count, mean, M2) per channel -> LDS (the output tile is dead); thread c < BN then merges the PG pixel groups of its channel in a
+        // fixed order with the parallel-variance update (n = na + nb, d = mb - ma, m = ma + d nb / n, M2 = M2a + M2b + d^2 na nb / n): deterministic,
+        // and as accurate as the two-pass form whatever the mean / deviation ratio of the layer
+        constexpr int PG = 256 / VPR;
+        float* const sred = smem; // [3][PG][BN]
+        __syncthreads();
+        {
+            const int c8 = tid % VPR, pg = tid / VPR;
+            const float cn = static_cast<float>(sCnt), inv = sCnt > 0 ? 1.0f / cn : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float m1 = sA[e] * inv;
+                sred[pg * BN + c8 * 8 + e] = sPiv[e] + m1;
+                sred[(PG + pg) * BN + c8 * 8 + e] = fmaxf(sB[e] - sA[e] * m1, 0.0f);
+            }
+            if (c8 == 0) sred[2 * PG * BN + pg] = cn;
+        }
+        __syncthreads();
+        // two levels, all loads ahead of the dependent arithmetic: thread (channel c, part q) merges 8 pixel groups, thread c < BN the 256 / BN parts
+        // (one thread per channel walking all PG = 16..64 groups was a 64-step chain of LDS round trips and divisions: +60 % on the 32-channel blocks)
+        constexpr int PARTS = 256 / BN, GP = PG / PARTS;
+        float* const sred2 = sred + 2 * PG * BN + PG; // [3][PARTS][BN]
+        {
+            const int c = tid % BN, q = tid / BN;
+            float nb[GP], mb[GP], qb[GP];
+#pragma unroll
+            for (int j = 0; j < GP; ++j) {
+                nb[j] = sred[2 * PG * BN + q * GP + j];
+                mb[j] = sred[(q * GP + j) * BN + c];
+                qb[j] = sred[(PG + q * GP + j) * BN + c];
+            }
+            float na = 0.0f, ma = 0.0f, M2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < GP; ++j) {
+                const float n2 = na + nb[j], d = mb[j] - ma, r = nb[j] * __builtin_amdgcn_rcpf(fmaxf(n2, 1.0f)); // nb = 0 (a group outside the image): no change
+                ma = fmaf(d, r, ma);
+                M2 += qb[j] + d * d * na * r;
+                na = n2;
+            }
+            sred2[q * BN + c] = na;
+            sred2[(PARTS + q) * BN + c] = ma;
+            sred2[(2 * PARTS + q) * BN + c] = M2;
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float nb[PARTS], mb[PARTS], qb[PARTS];
+#pragma unroll
+            for (int j = 0; j < PARTS; ++j) {
+                nb[j] = sred2[j * BN + tid];
+                mb[j] = sred2[(PARTS + j) * BN + tid];
+                qb[j] = sred2[(2 * PARTS + j) * BN + tid];
+            }
+            float na = 0.0f, ma = 0.0f, M2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PARTS; ++j) {
+                const float n2 = na + nb[j], d = mb[j] - ma, r = nb[j] * __builtin_amdgcn_rcpf(fmaxf(n2, 1.0f));
+                ma = fmaf(d, r, ma);
+                M2 += qb[j] + d * d * na * r;
+                na = n2;
+            }
+            float* po = p.statPart + (static_cast<size_t>(n * p.tilesY + ty) * p.tilesX + tx) * 2 * p.OC + blockIdx.y * BN;
+            po[tid] = ma;
+            po[p.OC + tid] = M2;
+        }
     }
 }
 
@@ -268,6 +356,19 @@ struct WideConvPlan : ConvPlanBase {
     WideFn kernel = nullptr;
     bool fusedAdd = false;
 
+    // chain rule F: {mean, M2} of every output tile and channel next to the output (the epilogue's LDS round trip carries them: conv2d_wide_kernel)
+    bool enableTileStats() override {
+        if (statPart) return true;
+        if (fusedAdd) return false; // (rule E: the kernel instantiation with the residual carries no statistics code)
+        void* buf = nullptr;
+        const size_t bytes = static_cast<size_t>(p.N) * p.tilesY * p.tilesX * 2 * p.OC * sizeof(float);
+        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        statPart = p.statPart = static_cast<float*>(buf);
+        statTilesX = p.tilesX; statTilesY = p.tilesY; statTH = 1 << p.THs; statTW = 32;
+        desc += " +tile-stats";
+        return true;
+    }
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == (fusedAdd ? 2 : 1), "conv2d: expects %d input(s), got %d", fusedAdd ? 2 : 1, nIn);
         const snnhip_tensor* x = in[0];

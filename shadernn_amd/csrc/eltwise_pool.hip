@@ -664,8 +664,9 @@ struct InstanceNormPlan : snnhip_plan {
     // res != nullptr: the Add layer behind this norm folded into the normalise sweep (chain rule H)
     // statsOnly (graph rule I): the statistics sweep and the fold only -- d_mean / d_mul are left for the convolution that normalises while it
     // stages its input (`out` is not touched and may be the input itself)
+    // tiles (chain rule F): the producing convolution left per-tile statistics -- a fold over those records replaces the statistics sweep
     int runWithResidual(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out, const snnhip_tensor* res, int addAct, float addLeaky, bool resFirst = false,
-                        bool statsOnly = false) {
+                        bool statsOnly = false, const TileStatsRef* tiles = nullptr) {
         SNNHIP_SAME_DTYPE("instancenorm");
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, d.H, d.W, d.C), "instancenorm: tensor dims do not match the plan");
         SNNHIP_REQUIRE(!res || (res->n == d.N && res->c == d.C && res->h <= d.H && res->w <= d.W && res->dtype == out->dtype),
@@ -688,13 +689,22 @@ struct InstanceNormPlan : snnhip_plan {
                        mptr<T>(out), ST == 2 ? ra : InResidual())
 #define SNNHIP_FOLD() \
     hipLaunchKernelGGL(instancenorm_fold_kernel<T>, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, cptr<T>(in[0]), d_part, d_gamma, d_beta, d_mean, d_mul)
+        const bool sweep = !(tiles && tiles->part);
+        if (!sweep) {
+            const int rc = foldTiles(*tiles);
+            if (rc != SNNHIP_OK) return rc;
+        }
         SNNHIP_WITH_T(out->dtype, if ((d.C & 3) == 0) {
-            SNNHIP_IN(0, 4);
-            SNNHIP_FOLD();
+            if (sweep) {
+                SNNHIP_IN(0, 4);
+                SNNHIP_FOLD();
+            }
             if (!statsOnly) SNNHIP_IN(2, 4);
         } else {
-            SNNHIP_IN(0, 1);
-            SNNHIP_FOLD();
+            if (sweep) {
+                SNNHIP_IN(0, 1);
+                SNNHIP_FOLD();
+            }
             if (!statsOnly) SNNHIP_IN(2, 1);
         });
 #undef SNNHIP_IN
@@ -702,6 +712,7 @@ struct InstanceNormPlan : snnhip_plan {
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
+    int foldTiles(const TileStatsRef& t); // below the fold kernels' launch geometry
 };
 
 // chain rule H: InstanceNorm -> Add(., residual) as the norm's own three launches; borrows the norm plan (parameters and scratch)
@@ -710,9 +721,10 @@ struct InstanceNormAddPlan : snnhip_plan {
     int addAct = 0;
     float addLeaky = 0.0f;
     bool resFirst = false; // the residual is the Add's first input (matters only when it is smaller than the norm)
+    TileStatsRef tiles;    // chain rule F: statistics from the producing convolution's tile records instead of a sweep
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 2, "instancenorm+add: expects 2 inputs (x, residual), got %d", nIn);
-        return norm->runWithResidual(in, 1, out, in[1], addAct, addLeaky, resFirst);
+        return norm->runWithResidual(in, 1, out, in[1], addAct, addLeaky, resFirst, false, &tiles);
     }
 };
 
@@ -749,12 +761,22 @@ bool instancenorm_stat_pointers(const snnhip_plan* plan, const float** shift, co
     *mul = q->d_mul;
     return true;
 }
-int instancenorm_run_stats(snnhip_plan* plan, const snnhip_tensor* x) {
+int instancenorm_run_stats(snnhip_plan* plan, const snnhip_tensor* x, const TileStatsRef* tiles) {
     auto* q = dynamic_cast<InstanceNormPlan*>(plan);
     SNNHIP_REQUIRE(q && x, "instancenorm_run_stats: bad arguments");
     snnhip_tensor alias = *x; // stage 2 does not run: the output is never written
     const snnhip_tensor* ins[1] = {x};
-    return q->runWithResidual(ins, 1, &alias, nullptr, 0, 0.0f, false, true);
+    return q->runWithResidual(ins, 1, &alias, nullptr, 0, 0.0f, false, true, tiles);
+}
+
+snnhip_plan* instancenorm_add_use_tile_stats(snnhip_plan* plan, const TileStatsRef& tiles) {
+    auto* q = dynamic_cast<InstanceNormAddPlan*>(plan);
+    if (!q) return nullptr;
+    q->tiles = tiles;
+    if (tiles.part)
+        q->desc = "instancenorm " + std::to_string(q->norm->d.N) + "x" + std::to_string(q->norm->d.H) + "x" + std::to_string(q->norm->d.W) + "x" + std::to_string(q->norm->d.C) +
+              " act=" + std::to_string(q->norm->d.act) + " (fold of tile stats + 1 sweep) +add act=" + std::to_string(q->addAct) + (q->resFirst ? " (residual first)" : "");
+    return q->norm;
 }
 
 bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d) {
@@ -780,26 +802,23 @@ int instancenorm_reserve_tile_stats(snnhip_plan* inPlan, int tilesX, int tilesY)
     return SNNHIP_OK;
 }
 
-int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const float* statPart, int tilesX, int tilesY, int TH, int TW, snnhip_tensor* xy) {
-    auto* q = dynamic_cast<InstanceNormPlan*>(inPlan);
-    SNNHIP_REQUIRE(q && statPart && xy, "instancenorm_apply_tile_stats: bad arguments");
-    const snnhip_instancenorm_desc& d = q->d;
-    SNNHIP_REQUIRE(dims_match(xy, d.N, d.H, d.W, d.C), "instancenorm: tensor dims do not match the plan");
-    snnhip_ctx* ctx = q->ctx;
-    const int tiles = tilesX * tilesY, chunks = (tiles + kFoldChunk - 1) / kFoldChunk;
+int InstanceNormPlan::foldTiles(const TileStatsRef& t) {
+    const int tiles = t.tilesX * t.tilesY, chunks = (tiles + kFoldChunk - 1) / kFoldChunk;
     const size_t need = static_cast<size_t>(d.N) * chunks * 3 * d.C;
-    SNNHIP_REQUIRE(q->foldScratchCount >= need, "instancenorm: fold scratch not reserved for a %d x %d tile grid (instancenorm_reserve_tile_stats)", tilesX, tilesY);
+    SNNHIP_REQUIRE(foldScratchCount >= need, "instancenorm: fold scratch not reserved for a %d x %d tile grid (instancenorm_reserve_tile_stats)", t.tilesX, t.tilesY);
     hipLaunchKernelGGL(instancenorm_fold_tiles1_kernel, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, d.H, d.W,
-                       tilesX, tilesY, TH, TW, statPart, q->d_foldScratch);
-    hipLaunchKernelGGL(instancenorm_fold_tiles2_kernel, dim3(static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, chunks, d.eps, q->d_foldScratch, q->d_gamma,
-                       q->d_beta, q->d_mean, q->d_mul);
-    const dim3 g(static_cast<unsigned>(d.N * q->S));
-#define SNNHIP_IN2(CVV) \
-    hipLaunchKernelGGL((instancenorm_kernel<2, CVV, T>), g, dim3(256), 0, ctx->stream, d, q->S, q->pixelsPerSlab, q->CLs, cptr<T>(xy), q->d_mean, q->d_mul, q->d_beta, q->d_part, mptr<T>(xy))
-    SNNHIP_WITH_T(xy->dtype, if ((d.C & 3) == 0) { SNNHIP_IN2(4); } else { SNNHIP_IN2(1); });
-#undef SNNHIP_IN2
+                       t.tilesX, t.tilesY, t.TH, t.TW, t.part, d_foldScratch);
+    hipLaunchKernelGGL(instancenorm_fold_tiles2_kernel, dim3(static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, chunks, d.eps, d_foldScratch, d_gamma, d_beta,
+                       d_mean, d_mul);
     SNNHIP_CHECK_HIP(hipGetLastError());
     return SNNHIP_OK;
+}
+
+int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const TileStatsRef& tiles, snnhip_tensor* xy) {
+    auto* q = dynamic_cast<InstanceNormPlan*>(inPlan);
+    SNNHIP_REQUIRE(q && tiles.part && xy, "instancenorm_apply_tile_stats: bad arguments");
+    const snnhip_tensor* ins[1] = {xy};
+    return q->runWithResidual(ins, 1, xy, nullptr, 0, 0.0f, false, false, &tiles); // fold, then the normalise sweep in place
 }
 
 } // namespace snnhip

@@ -866,7 +866,9 @@ struct ConvInstanceNormPlan : snnhip_plan {
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         int rc = conv->run(in, nIn, out);
         if (rc != SNNHIP_OK) return rc;
-        return instancenorm_apply_tile_stats(norm, conv->statPart, conv->statTilesX, conv->statTilesY, conv->statTH, conv->statTW, out);
+        TileStatsRef t;
+        t.part = conv->statPart; t.tilesX = conv->statTilesX; t.tilesY = conv->statTilesY; t.TH = conv->statTH; t.TW = conv->statTW;
+        return instancenorm_apply_tile_stats(norm, t, out);
     }
 };
 
@@ -876,8 +878,9 @@ struct ConvInstanceNormPlan : snnhip_plan {
 struct InstanceNormConvPlan : snnhip_plan {
     snnhip_plan* norm = nullptr;
     snnhip_plan* conv = nullptr;
+    TileStatsRef tiles; // rule F in front: the convolution that PRODUCED in[0] left tile statistics -- a fold over them instead of the sweep
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
-        const int rc = instancenorm_run_stats(norm, in[0]);
+        const int rc = instancenorm_run_stats(norm, in[0], &tiles);
         return rc != SNNHIP_OK ? rc : conv->run(in, nIn, out);
     }
 };
@@ -914,7 +917,7 @@ struct ChainPlan : snnhip_plan {
     bool profilesItself() const override { return true; }
 
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
-        SNNHIP_REQUIRE(nIn == 1, "chain: expects 1 input, got %d", nIn);
+        SNNHIP_REQUIRE(nIn == numInputs, "chain: expects %d input(s), got %d", numInputs, nIn);
         const snnhip_tensor* src = in[0];
         SNNHIP_REQUIRE(src->n == inDims[0] && src->h == inDims[1] && src->w == inDims[2] && src->c == inDims[3],
                        "chain: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", src->n, src->h, src->w, src->c, inDims[0], inDims[1], inDims[2], inDims[3]);
@@ -930,7 +933,9 @@ struct ChainPlan : snnhip_plan {
                 if (rc != SNNHIP_OK) return rc;
             }
             if (s.kind == PLAIN) {
-                int rc = s.plain->run(&src, 1, dst);
+                // a chain with two inputs: the second one belongs to its LAST step (InstanceNorm -> Add behind a run of layers, rules F + H)
+                const snnhip_tensor* two[2] = {src, nIn > 1 ? in[1] : nullptr};
+                int rc = s.plain->run(two, (i + 1 == steps.size()) ? nIn : 1, dst);
                 if (rc != SNNHIP_OK) return rc;
             } else if (s.kind == FUSED_S) {
                 int rc = espcn_stream_launch(ctx->stream, s.streamCfg, src->data, s.w1, s.e1, s.w2, s.e2, s.w3, s.e3, dst->data);
@@ -1016,10 +1021,16 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             return make_conv2d_mfma_plan(ctx, g2, cv->w_oihw.data(), cv->epi4, out);
         }
     }
+    for (int i = 0; i < n; ++i)
+        if (plans[i]->numInputs != 1 && !(i == n - 1 && plans[i]->numInputs == 2)) {
+            set_error("chain fusion: plan %d takes %d inputs (only the last plan of a chain may take two)", i, plans[i]->numInputs);
+            return SNNHIP_E_UNSUPPORTED;
+        }
     const char* mode = snnhip::option("SNNHIP_ESPCN_FUSION");
     const bool allowStream = mode && strcmp(mode, "stream") == 0;
     auto* chain = new ChainPlan();
     chain->ctx = ctx;
+    chain->numInputs = plans[n - 1]->numInputs;
     memcpy(chain->inDims, plans[0]->inDims, sizeof(chain->inDims));
     memcpy(chain->outDims, plans[n - 1]->outDims, sizeof(chain->outDims));
     int fusedCount = 0;
@@ -1318,55 +1329,6 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         }
         chain->steps.push_back(st);
     }
-    // ---- rule F (opt-in, SNNHIP_NORM_FUSION=1): a convolution step (as given, or one a rule above built) followed by an InstanceNorm step ->
-    // one step.  Parity-tested, but not a win as measured (Candy 720p fp16: batch 8 9.08 -> 9.15 ms, batch 1 1.50 -> 1.70 ms): accumulating the
-    // tile statistics costs the convolution's epilogue 45-125 us per layer at batch 8 where the sweep it replaces costs 40 us, and at batch 1
-    // the two fold launches outweigh a sweep that reads the tensor out of the MALL.
-    const char* normFusion = snnhip::option("SNNHIP_NORM_FUSION");
-    for (size_t k = 0; rc == SNNHIP_OK && k + 1 < chain->steps.size() && normFusion && atoi(normFusion) != 0; ++k) {
-        ChainPlan::Step &a = chain->steps[k], &b = chain->steps[k + 1];
-        if (a.kind != ChainPlan::PLAIN || b.kind != ChainPlan::PLAIN) continue;
-        auto* cv = dynamic_cast<ConvPlanBase*>(a.plain);
-        snnhip_instancenorm_desc nd;
-        if (!cv || cv->depthwise || cv->numInputs != 1 || !instancenorm_plan_desc(b.plain, &nd)) continue;
-        if (nd.N != cv->outDims[0] || nd.H != cv->outDims[1] || nd.W != cv->outDims[2] || nd.C != cv->outDims[3]) continue;
-        // The statistics epilogue changes the convolution plan (tile-stat buffer, LDS size, description): never switch it on in a plan the
-        // caller owns -- a borrowed per-layer plan stays what it was; the chain works on its own copy (rule D's product already is chain-owned).
-        bool borrowed = false;
-        for (int i = 0; i < n; ++i) borrowed = borrowed || plans[i] == a.plain;
-        if (borrowed) {
-            snnhip_plan* copy = nullptr;
-            if (make_conv2d_mfma_plan(ctx, cv->g, cv->w_oihw.data(), cv->epi4, &copy) != SNNHIP_OK) continue;
-            auto* cc = dynamic_cast<ConvPlanBase*>(copy);
-            if (!cc || !cc->enableTileStats()) {
-                delete copy;
-                continue;
-            }
-            chain->owned.push_back(copy);
-            cv = cc;
-        } else if (!cv->enableTileStats()) {
-            continue;
-        }
-        // the fold scratch of the norm is sized here, at plan creation: an allocation inside run() would break a hipGraph capture in progress
-        if (instancenorm_reserve_tile_stats(b.plain, cv->statTilesX, cv->statTilesY) != SNNHIP_OK) continue;
-        auto* both = new ConvInstanceNormPlan();
-        both->ctx = ctx;
-        both->conv = cv;
-        both->norm = b.plain;
-        both->dtype = cv->dtype;
-        memcpy(both->inDims, cv->inDims, sizeof(both->inDims));
-        memcpy(both->outDims, cv->outDims, sizeof(both->outDims));
-        both->flops = a.flops + b.flops;
-        both->bytes = a.bytes + b.bytes;
-        both->desc = cv->desc + " -> instancenorm(fold of tile stats + 1 sweep) act=" + std::to_string(nd.act);
-        chain->owned.push_back(both);
-        a.plain = both;
-        a.desc = both->desc;
-        a.flops = both->flops;
-        a.bytes = both->bytes;
-        chain->steps.erase(chain->steps.begin() + static_cast<long>(k) + 1);
-        ++fusedCount;
-    }
     // ---- rule I: an InstanceNorm step followed by a convolution step (as given, or built by rule D above) whose kernel can normalise in its
     // staging (today: conv2d_mfma's fp16 kernels).  SNNHIP_NO_NORM_FOLD keeps the norm's own normalise sweep.
     for (size_t k = 0; rc == SNNHIP_OK && k + 1 < chain->steps.size() && !snnhip::option("SNNHIP_NO_NORM_FOLD"); ++k) {
@@ -1408,6 +1370,84 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         chain->steps.erase(chain->steps.begin() + static_cast<long>(k) + 1);
         ++fusedCount;
     }
+    // ---- rule F: a convolution step (as given, or one a rule above built) whose kernel can reduce its output tiles to {mean, M2} records, followed by
+    // a step that starts with an InstanceNorm: the norm's statistics sweep becomes a fold over those records.  The consumer is the norm itself (the
+    // two steps become one: conv, fold, normalise in place), the norm + Add of rule H (last step of a two-input chain), or the norm -> convolution of
+    // rule I.  Default: conv2d_wide_f16 only -- its 256 / 512-pixel tiles pass through registers on their way out anyway (+3 % on the kernel, one
+    // tensor read saved).  SNNHIP_NORM_FUSION=1 also takes conv2d_mfma's fp16 kernel (measured a loss: its short blocks pay 45-125 us per layer
+    // for the statistics where the sweep costs 40), =0 switches the rule off.
+    const char* normFusion = snnhip::option("SNNHIP_NORM_FUSION");
+    const int normFusionMode = normFusion ? atoi(normFusion) : -1; // -1 default, 0 off, 1 every kernel that can
+    for (size_t k = 0; rc == SNNHIP_OK && k + 1 < chain->steps.size() && normFusionMode != 0; ++k) {
+        ChainPlan::Step &a = chain->steps[k], &b = chain->steps[k + 1];
+        if (a.kind != ChainPlan::PLAIN || b.kind != ChainPlan::PLAIN) continue;
+        auto* cv = dynamic_cast<ConvPlanBase*>(a.plain);
+        if (!cv || cv->depthwise || cv->numInputs != 1) continue;
+        if (normFusionMode < 0 && cv->desc.rfind("conv2d_mfma_wide_f16", 0) != 0) continue;
+        auto* inConv = dynamic_cast<InstanceNormConvPlan*>(b.plain);
+        snnhip_plan* normPlan = inConv ? inConv->norm : b.plain;
+        snnhip_instancenorm_desc nd;
+        bool normAdd = false;
+        if (!instancenorm_plan_desc(normPlan, &nd)) {
+            normPlan = instancenorm_add_use_tile_stats(b.plain, TileStatsRef()); // probe: which norm (the reference stays empty = a sweep)
+            if (!normPlan || !instancenorm_plan_desc(normPlan, &nd)) continue;
+            normAdd = true;
+        }
+        if (nd.N != cv->outDims[0] || nd.H != cv->outDims[1] || nd.W != cv->outDims[2] || nd.C != cv->outDims[3]) continue;
+        // The statistics epilogue changes the convolution plan (tile-stat buffer, LDS size, description): never switch it on in a plan the
+        // caller owns -- a borrowed per-layer plan stays what it was; the chain works on its own copy (rule D's product already is chain-owned).
+        bool borrowed = false;
+        for (int i = 0; i < n; ++i) borrowed = borrowed || plans[i] == a.plain;
+        if (borrowed) {
+            snnhip_plan* copy = nullptr;
+            if (make_conv2d_mfma_plan(ctx, cv->g, cv->w_oihw.data(), cv->epi4, &copy) != SNNHIP_OK) continue;
+            auto* cc = dynamic_cast<ConvPlanBase*>(copy);
+            if (!cc || !cc->enableTileStats()) {
+                delete copy;
+                continue;
+            }
+            chain->owned.push_back(copy);
+            cv = cc;
+        } else if (!cv->enableTileStats()) {
+            continue;
+        }
+        // the fold scratch of the norm is sized here, at plan creation: an allocation inside run() would break a hipGraph capture in progress
+        if (instancenorm_reserve_tile_stats(normPlan, cv->statTilesX, cv->statTilesY) != SNNHIP_OK) continue;
+        TileStatsRef tiles;
+        tiles.part = cv->statPart; tiles.tilesX = cv->statTilesX; tiles.tilesY = cv->statTilesY; tiles.TH = cv->statTH; tiles.TW = cv->statTW;
+        a.plain = cv;
+        a.desc = cv->desc;
+        ++fusedCount;
+        if (normAdd) { // rules F + H: the plan was built by the graph walk for this chain (it is the chain's to change)
+            instancenorm_add_use_tile_stats(b.plain, tiles);
+            b.desc = b.plain->desc;
+            b.bytes *= 0.75; // the statistics sweep (one read of its four passes) is gone
+            continue;
+        }
+        if (inConv) { // rules F + I
+            inConv->tiles = tiles;
+            inConv->desc = "instancenorm(fold of tile stats) -> " + inConv->conv->desc;
+            b.desc = inConv->desc;
+            b.bytes -= static_cast<double>(nd.N) * nd.H * nd.W * nd.C * (cv->dtype == SNNHIP_F16 ? 2.0 : 4.0);
+            continue;
+        }
+        auto* both = new ConvInstanceNormPlan();
+        both->ctx = ctx;
+        both->conv = cv;
+        both->norm = b.plain;
+        both->dtype = cv->dtype;
+        memcpy(both->inDims, cv->inDims, sizeof(both->inDims));
+        memcpy(both->outDims, cv->outDims, sizeof(both->outDims));
+        both->flops = a.flops + b.flops;
+        both->bytes = a.bytes + b.bytes * 2.0 / 3.0;
+        both->desc = cv->desc + " -> instancenorm(fold of tile stats + 1 sweep) act=" + std::to_string(nd.act);
+        chain->owned.push_back(both);
+        a.plain = both;
+        a.desc = both->desc;
+        a.flops = both->flops;
+        a.bytes = both->bytes;
+        chain->steps.erase(chain->steps.begin() + static_cast<long>(k) + 1);
+    }
     if (rc == SNNHIP_OK && fusedCount == 0) {
         set_error("chain fusion: no rule matches these %d plans", n);
         rc = SNNHIP_E_UNSUPPORTED;
@@ -1437,6 +1477,14 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
     chain->desc = d + "}";
     *out = chain;
     return SNNHIP_OK;
+}
+
+// graph walk: a plan it built for this chain (the InstanceNorm -> Add of rule H at the chain's end) becomes the chain's to delete
+bool chain_adopt_plan(snnhip_plan* chain, snnhip_plan* p) {
+    auto* c = dynamic_cast<ChainPlan*>(chain);
+    if (!c) return false;
+    c->owned.push_back(p);
+    return true;
 }
 
 } // namespace snnhip

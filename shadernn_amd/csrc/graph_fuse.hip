@@ -150,6 +150,34 @@ extern "C" int snnhip_graph_fuse(snnhip_ctx* ctx, const snnhip_graph_node* nodes
         }
         int j = i;
         while (j + 1 < n && nodes[j + 1].plan && nodes[j + 1].n_inputs == 1 && nodes[j + 1].inputs[0] == j && foldable(j) && !taken[static_cast<size_t>(j + 1)]) ++j;
+        // the run may end in front of an InstanceNorm -> Add node built in 1b (a residual block's tail): offered to the planner as the chain's
+        // two-input last step, so that the convolution in front can hand its tile statistics to the norm (rules F + H)
+        int tail = -1;
+        if (foldable(j))
+            for (int k = j + 1; k < n && tail < 0; ++k)
+                if (out[k].owned && out[k].plan && out[k].n_inputs == 2 && out[k].inputs[0] == j && out[k].inputs[1] != j && out[k].plan->numInputs == 2 &&
+                    instancenorm_add_use_tile_stats(out[k].plan, TileStatsRef()))
+                    tail = k;
+        if (tail >= 0) {
+            std::vector<snnhip_plan*> run;
+            for (int t = i; t <= j; ++t) run.push_back(nodes[t].plan);
+            run.push_back(out[tail].plan);
+            snnhip_plan* chain = nullptr;
+            const int rc = make_chain_plan(ctx, run.data(), static_cast<int>(run.size()), &chain);
+            if (rc == SNNHIP_OK && chain_adopt_plan(chain, out[tail].plan)) {
+                out[tail].plan = chain;
+                out[tail].inputs[0] = nodes[i].inputs[0];
+                for (int t = i; t <= j; ++t) {
+                    out[t].plan = nullptr;
+                    out[t].n_inputs = 0;
+                    taken[static_cast<size_t>(t)] = 1;
+                }
+                i = j + 1;
+                continue;
+            }
+            if (rc == SNNHIP_OK) delete chain; // (a plan that is not a chain: no rule of this walk builds one here)
+            else if (rc != SNNHIP_E_UNSUPPORTED) return fail(rc);
+        }
         if (j > i) {
             std::vector<snnhip_plan*> run;
             for (int t = i; t <= j; ++t) run.push_back(nodes[t].plan);

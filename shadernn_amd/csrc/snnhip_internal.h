@@ -179,6 +179,7 @@ int make_depthwise_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_chw, 
 int make_dense_plan(snnhip_ctx* ctx, const snnhip_dense_desc& d, const float* w_flat, const float* bias, snnhip_plan** out);
 int make_subpixel_plan(snnhip_ctx* ctx, const snnhip_subpixel_desc& d, snnhip_plan** out);
 int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_plan** out);
+bool chain_adopt_plan(snnhip_plan* chain, snnhip_plan* p); // the chain deletes p with itself; false if `chain` is not a ChainPlan
 // irb_fused.hip (chain rule G): Conv2D 1x1 -> DepthwiseConv2D 3x3 -> Conv2D 1x1 [-> Add with the block input] as one kernel; the plans are only read
 int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan, snnhip_plan* projectPlan, snnhip_plan* addPlan, snnhip_plan** out);
 
@@ -210,9 +211,18 @@ bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d
 int make_instancenorm_add_plan(snnhip_ctx* ctx, snnhip_plan* normPlan, snnhip_plan* addPlan, bool normIsFirstInput, snnhip_plan** out);
 // graph rule I (InstanceNorm -> [Pad] -> Conv2D, the normalisation applied while the convolution stages its input)
 bool instancenorm_stat_pointers(const snnhip_plan* plan, const float** shift, const float** mul);
-int instancenorm_run_stats(snnhip_plan* plan, const snnhip_tensor* x);
+// chain rule F: where a convolution left the {mean, M2} records of its output tiles (ConvPlanBase::statPart and its tile grid); part == null = none
+struct TileStatsRef {
+    const float* part = nullptr;
+    int tilesX = 0, tilesY = 0, TH = 0, TW = 0;
+};
+// the norm's shift / mul from a statistics sweep over x, or (tiles && tiles->part) from a fold over the producing convolution's tile records
+int instancenorm_run_stats(snnhip_plan* plan, const snnhip_tensor* x, const TileStatsRef* tiles = nullptr);
 int instancenorm_reserve_tile_stats(snnhip_plan* inPlan, int tilesX, int tilesY);
-int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const float* statPart, int tilesX, int tilesY, int TH, int TW, snnhip_tensor* xy);
+int instancenorm_apply_tile_stats(snnhip_plan* inPlan, const TileStatsRef& tiles, snnhip_tensor* xy);
+// rule F behind rule H: an InstanceNorm -> Add plan (make_instancenorm_add_plan) takes its statistics from tile records from now on; returns its
+// norm plan (for instancenorm_reserve_tile_stats), null if `plan` is not such a plan
+snnhip_plan* instancenorm_add_use_tile_stats(snnhip_plan* plan, const TileStatsRef& tiles);
 struct EltwisePlanBase : snnhip_plan {
     snnhip_eltwise_desc d;
     int mode = 0; // 0 add, 1 activation, 2 batch-norm

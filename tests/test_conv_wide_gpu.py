@@ -240,3 +240,105 @@ def test_stem32_matches_oracle_and_tap_pair_kernel(ctx, monkeypatch, shape):
         y2, desc2 = run(pad_mode, act, bn if use_bn else None)
         assert "stem" not in desc2, desc2
         np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("n,h,w,ic,oc,offset", [(2, 19, 45, 32, 128, 0.0), (1, 37, 70, 64, 64, 6.0), (3, 9, 33, 16, 32, 0.0), (1, 16, 64, 128, 128, 40.0)])
+def test_wide_tile_stats_feed_instancenorm(ctx, monkeypatch, n, h, w, ic, oc, offset):
+    """Chain rule F on the wide kernel (the default there): reflect Pad -> Conv2D -> InstanceNorm as ONE step -- the convolution's epilogue leaves
+    {mean, M2} of every output tile and channel, a fold over those records replaces the norm's statistics sweep.  Ragged tile edges in both
+    directions, several images, and a layer whose mean is far from zero compared with its deviation (the tile records are merged with the
+    parallel-variance update, not as raw sums).  Against the separate launches and the oracle."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_CONV", "wide")
+    x, wt = _rand((n, h, w, ic), 1), _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9))
+    b = _rand((oc,), 3, 0.5) + offset
+    beta, gamma = _rand((oc,), 4, 0.3), 1.0 + _rand((oc,), 5, 0.2)
+    pad = snn.pad_plan(ctx, n, h, w, ic, (1, 1, 1, 1), "reflect")
+    conv = snn.conv2d_plan(ctx, n, h + 2, w + 2, wt, b, stride=1, pads=(0, 0, 0, 0), act="", dtype=snn.F16)
+    oh, ow = conv.out_shape()[1:3]  # (the reference's size rule keeps the padded extent, SURVEY Q20)
+    norm = snn.instancenorm_plan(ctx, n, oh, ow, oc, beta, gamma, act="relu")
+    fused = snn.chain_plan(ctx, [pad, conv, norm])
+    d = fused.describe()
+    assert fused.num_steps() == 1 and "wide" in d and "+tile-stats" in d and "fold of tile stats + 1 sweep" in d, d
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    y = fused(xt).numpy()
+    two = norm(conv(pad(xt))).numpy()
+    c = O._h(O.conv2d(O.pad(O._h(x), (1, 1, 1, 1), "reflect"), O._h(wt), b, 1, (0, 0, 0, 0), "constant", "", 0.0, None))
+    want = O._h(O.instancenorm(c, beta, gamma, "relu"))
+    # with an offset the fp16 STORED values are coarse (ulp of 6 is 0.004, of 40 0.03): both paths normalise the same stored tensor, the oracle a
+    # differently rounded one -- the tight comparison is the one against the separate launches
+    np.testing.assert_allclose(y, two, rtol=2e-3, atol=2e-3, err_msg=d)
+    if offset == 0:
+        np.testing.assert_allclose(y, want, err_msg=d, rtol=6e-3, atol=6e-3)
+    # the caller's convolution plan is not changed by the fusion, and the rule can be switched off
+    assert "tile-stats" not in conv.describe()
+    monkeypatch.setenv("SNNHIP_NORM_FUSION", "0")
+    assert "tile stats" not in snn.chain_plan(ctx, [pad, conv, norm]).describe()
+
+
+@pytest.mark.parametrize("order", [[3, 0], [0, 3]])
+def test_wide_tile_stats_feed_instancenorm_add_at_the_end_of_a_graph_run(ctx, monkeypatch, order):
+    """Rules F + H: a residual block's tail Pad -> Conv2D -> InstanceNorm -> Add(., skip).  The graph walk folds the Add into the norm (H) and offers
+    the run in front + that two-input plan to the chain planner, where the convolution hands its tile statistics to the norm (F): one
+    two-input chain at the Add node, conv launch + fold + ONE sweep.  The skip is 2 pixels smaller (the reference's size rule)."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_CONV", "wide")
+    n, h, w, c = 2, 21, 37, 64
+    x, wt, b = _rand((n, h, w, c), 1), _rand((c, c, 3, 3), 2, 1.0 / np.sqrt(c * 9)), _rand((c,), 3, 0.5)
+    beta, gamma = _rand((c,), 4, 0.3), 1.0 + _rand((c,), 5, 0.2)
+    pre = snn.activation_plan(ctx, n, h, w, c, "relu")  # node 0: the block input (read by the run and by the Add)
+    pad = snn.pad_plan(ctx, n, h, w, c, (1, 1, 1, 1), "reflect")
+    conv = snn.conv2d_plan(ctx, n, h + 2, w + 2, wt, b, stride=1, pads=(0, 0, 0, 0), act="", dtype=snn.F16)
+    oh, ow = conv.out_shape()[1:3]
+    assert (oh, ow) == (h + 2, w + 2)
+    norm = snn.instancenorm_plan(ctx, n, oh, ow, c, beta, gamma, act="")
+    add = snn.add_plan(ctx, n, oh, ow, c, act="")
+    nodes = [(pre, [-1], False), (pad, [0], False), (conv, [1], False), (norm, [2], False), (add, order, True)]
+    fused = snn.graph_fuse(ctx, nodes)
+    assert [p is None for p, _ in fused] == [False, True, True, True, False], [p.describe() if p else None for p, _ in fused]
+    tail, ins = fused[4]
+    d = tail.describe()
+    assert ins == [0, 0] and "chain{" in d and "+tile-stats" in d and "(fold of tile stats + 1 sweep) +add" in d, (ins, d)
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    t0 = pre(xt)
+    y = tail([t0, t0]).numpy()
+    nrm = norm(conv(pad(t0)))
+    two = add([nrm, t0] if order[0] == 3 else [t0, nrm]).numpy()
+    np.testing.assert_allclose(y, two, rtol=2e-3, atol=2e-3, err_msg=d)
+    t = O._h(np.maximum(O._h(x), 0))
+    cc = O._h(O.conv2d(O.pad(t, (1, 1, 1, 1), "reflect"), O._h(wt), b, 1, (0, 0, 0, 0), "constant", "", 0.0, None))
+    nrm = O._h(O.instancenorm(cc, beta, gamma, ""))
+    want = nrm.copy() if order[0] == 3 else np.zeros_like(nrm)  # the ragged-Add rule: outside the FIRST input's extent nothing is summed
+    want[:, :h, :w, :] = O._h(nrm[:, :h, :w, :] + t)
+    np.testing.assert_allclose(y, want, rtol=6e-3, atol=6e-3, err_msg=d)
+
+
+def test_wide_tile_stats_feed_a_normalising_convolution(ctx, monkeypatch):
+    """Rules F + I: Conv2D (wide) -> InstanceNorm -> reflect Pad -> Conv2D 9x9 32 -> 3 (the tail of the style networks).  The second convolution
+    normalises while it stages (I) and the norm's statistics come from the first one's tile records (F): the norm is two tiny fold launches."""
+    import shadernn_amd as snn
+
+    n, h, w, ic, c = 2, 150, 340, 64, 32  # 220 blocks of 512 pixels: large enough for the wide kernel to be the default choice
+    x, w1, b1 = _rand((n, h, w, ic), 1), _rand((c, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9)), _rand((c,), 3, 0.5)
+    w2, b2 = _rand((3, c, 9, 9), 6, 1.0 / np.sqrt(c * 81)), _rand((3,), 7, 0.5)
+    beta, gamma = _rand((c,), 4, 0.3), 1.0 + _rand((c,), 5, 0.2)
+    conv2 = snn.conv2d_plan(ctx, n, h + 8, w + 8, w2, b2, stride=1, pads=(0, 0, 0, 0), act="tanh", dtype=snn.F16)
+    conv1 = snn.conv2d_plan(ctx, n, h, w, w1, b1, stride=1, pads=(1, 1, 1, 1), act="", dtype=snn.F16)
+    norm = snn.instancenorm_plan(ctx, n, h, w, c, beta, gamma, act="relu")
+    pad = snn.pad_plan(ctx, n, h, w, c, (4, 4, 4, 4), "reflect")
+    plans = [conv1, norm, pad, conv2]
+    fused = snn.chain_plan(ctx, plans)
+    d = fused.describe()
+    assert fused.num_steps() == 2 and "+tile-stats" in d and "instancenorm(fold of tile stats) -> " in d and "rowfold" in d, d
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    y = fused(xt).numpy()
+    t = xt
+    for pl in plans:
+        t = pl(t)
+    np.testing.assert_allclose(y, t.numpy(), rtol=3e-3, atol=3e-3, err_msg=d)
+    cc = O._h(O.conv2d(O._h(x), O._h(w1), b1, 1, (1, 1, 1, 1), "constant", "", 0.0, None))
+    r = O.pad(O._h(O.instancenorm(cc, beta, gamma, "relu")), (4, 4, 4, 4), "reflect")
+    want = O._h(O.conv2d(r, O._h(w2), b2, 1, (0, 0, 0, 0), "constant", "tanh", 0.0, None))
+    np.testing.assert_allclose(y, want, rtol=6e-3, atol=6e-3, err_msg=d)

@@ -20,6 +20,7 @@
 //   * the weights are the MFMA's A operand, the pixels its B operand: a lane ends up with runs of 4 consecutive output channels of its own
 //     pixel and the epilogue (bias / BN / activation / fused residual Add) stores them directly, 8 bytes per lane, without an LDS transpose.
 #include "conv2d_mfma_kernel.h"
+#include "norm_fold.h"
 
 #include <cstring>
 
@@ -46,6 +47,7 @@ struct WideParams {
     const void* res; // fused residual Add (chain rule E)
     ActCfg ac2;
     float* statPart; // chain rule F: per (image, tile, channel) {mean, M2} of the stored values, [n][ty][tx][2][OC]; null = off
+    NormFoldArgs fold; // ... and the last block of an image folds them into the norm's shift / mul (norm_fold.h); fold.counter == null = off
 };
 
 template <int WM, int WN, int NT, int C8, int R, bool SIMPLE, bool RES>
@@ -338,9 +340,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
                 na = n2;
             }
             float* po = p.statPart + (static_cast<size_t>(n * p.tilesY + ty) * p.tilesX + tx) * 2 * p.OC + blockIdx.y * BN;
-            po[tid] = ma;
-            po[p.OC + tid] = M2;
+            st_agent(po + tid, ma); // (read by another block of this launch when the kernel folds: norm_fold.h)
+            st_agent(po + p.OC + tid, M2);
         }
+        if (p.fold.counter) tile_stats_finish<BN>(p.fold, p.statPart, sred2 + 3 * 256, n, p.tilesX, p.tilesY, 1 << p.THs, 32, p.OH, p.OW, p.OC, blockIdx.y * BN);
     }
 }
 
@@ -367,6 +370,18 @@ struct WideConvPlan : ConvPlanBase {
         statPart = p.statPart = static_cast<float*>(buf);
         statTilesX = p.tilesX; statTilesY = p.tilesY; statTH = 1 << p.THs; statTW = 32;
         desc += " +tile-stats";
+        return true;
+    }
+    bool enableNormFold(const NormFoldTarget& t) override {
+        if (!statPart || p.fold.counter) return false;
+        void* buf = nullptr;
+        const size_t bytes = static_cast<size_t>(p.N) * grid.y * sizeof(unsigned);
+        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        if (hipMemset(buf, 0, bytes) != hipSuccess) return false;
+        p.fold.counter = static_cast<unsigned*>(buf);
+        p.fold.gamma = t.gamma; p.fold.beta = t.beta; p.fold.shift = t.shift; p.fold.mul = t.mul; p.fold.eps = t.eps;
+        desc += "+fold";
         return true;
     }
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {

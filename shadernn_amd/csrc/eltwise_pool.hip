@@ -269,7 +269,9 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
     const size_t p0 = static_cast<size_t>(s) * pixelsPerSlab, p1 = min(HW, p0 + pixelsPerSlab); // slab = a pixel range of the image
     const T* xn = x + static_cast<size_t>(n) * HW * d.C;
     T* yn = y + static_cast<size_t>(n) * HW * d.C;
-    constexpr int U = 4; // independent loads in flight per thread: the sweeps are latency-bound otherwise (measured 0.9 TB/s with one)
+    // independent loads in flight per thread: the sweeps are latency-bound otherwise (measured 0.9 TB/s with one).  More is not better: 8 in flight
+    // ran the fp16 normalise + Add sweep at 0.55x (400 vs 220 us for 3 x 285 MB), and so did 16-byte accesses (8 halfs per thread: 0.73x)
+    constexpr int U = 4;
     for (int c0 = 0; c0 < d.C; c0 += CL * CV) {
         const int c = c0 + cl * CV;
         const bool cok = c < d.C;
@@ -690,7 +692,7 @@ struct InstanceNormPlan : snnhip_plan {
 #define SNNHIP_FOLD() \
     hipLaunchKernelGGL(instancenorm_fold_kernel<T>, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, cptr<T>(in[0]), d_part, d_gamma, d_beta, d_mean, d_mul)
         const bool sweep = !(tiles && tiles->part);
-        if (!sweep) {
+        if (!sweep && !tiles->folded) {
             const int rc = foldTiles(*tiles);
             if (rc != SNNHIP_OK) return rc;
         }
@@ -769,13 +771,24 @@ int instancenorm_run_stats(snnhip_plan* plan, const snnhip_tensor* x, const Tile
     return q->runWithResidual(ins, 1, &alias, nullptr, 0, 0.0f, false, true, tiles);
 }
 
+bool instancenorm_fold_target(snnhip_plan* normPlan, NormFoldTarget* t) {
+    auto* q = dynamic_cast<InstanceNormPlan*>(normPlan);
+    if (!q) return false;
+    t->gamma = q->d_gamma;
+    t->beta = q->d_beta;
+    t->shift = q->d_mean;
+    t->mul = q->d_mul;
+    t->eps = q->d.eps;
+    return true;
+}
+
 snnhip_plan* instancenorm_add_use_tile_stats(snnhip_plan* plan, const TileStatsRef& tiles) {
     auto* q = dynamic_cast<InstanceNormAddPlan*>(plan);
     if (!q) return nullptr;
     q->tiles = tiles;
     if (tiles.part)
         q->desc = "instancenorm " + std::to_string(q->norm->d.N) + "x" + std::to_string(q->norm->d.H) + "x" + std::to_string(q->norm->d.W) + "x" + std::to_string(q->norm->d.C) +
-              " act=" + std::to_string(q->norm->d.act) + " (fold of tile stats + 1 sweep) +add act=" + std::to_string(q->addAct) + (q->resFirst ? " (residual first)" : "");
+              " act=" + std::to_string(q->norm->d.act) + (tiles.folded ? " (statistics from the convolution, 1 sweep) +add act=" : " (fold of tile stats + 1 sweep) +add act=") + std::to_string(q->addAct) + (q->resFirst ? " (residual first)" : "");
     return q->norm;
 }
 

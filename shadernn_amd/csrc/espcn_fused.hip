@@ -866,10 +866,9 @@ struct ConvInstanceNormPlan : snnhip_plan {
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         int rc = conv->run(in, nIn, out);
         if (rc != SNNHIP_OK) return rc;
-        TileStatsRef t;
-        t.part = conv->statPart; t.tilesX = conv->statTilesX; t.tilesY = conv->statTilesY; t.TH = conv->statTH; t.TW = conv->statTW;
-        return instancenorm_apply_tile_stats(norm, t, out);
+        return instancenorm_apply_tile_stats(norm, tiles, out);
     }
+    TileStatsRef tiles;
 };
 
 // Graph rule I: InstanceNorm -> [UpSampling] -> [Pad] -> Conv2D.  The norm runs its statistics sweep and fold only; the convolution (a copy
@@ -1384,6 +1383,14 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         auto* cv = dynamic_cast<ConvPlanBase*>(a.plain);
         if (!cv || cv->depthwise || cv->numInputs != 1) continue;
         if (normFusionMode < 0 && cv->desc.rfind("conv2d_mfma_wide_f16", 0) != 0) continue;
+        {
+            // small tensors (one 720p image: 17 MB per layer) are swept out of the L2 / MALL in less time than the two fold launches take
+            // (Candy batch 1: 1.12 ms without the rule, 1.24 ms with it); from a few images per batch on the sweep is an HBM pass
+            const char* mb = snnhip::option("SNNHIP_NORM_FUSION_MIN_MB");
+            const double minBytes = (mb ? atof(mb) : 128.0) * 1048576.0;
+            const double outBytes = static_cast<double>(cv->outDims[0]) * cv->outDims[1] * cv->outDims[2] * cv->outDims[3] * (cv->dtype == SNNHIP_F16 ? 2.0 : 4.0);
+            if (normFusionMode < 0 && outBytes < minBytes) continue;
+        }
         auto* inConv = dynamic_cast<InstanceNormConvPlan*>(b.plain);
         snnhip_plan* normPlan = inConv ? inConv->norm : b.plain;
         snnhip_instancenorm_desc nd;
@@ -1415,6 +1422,9 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         if (instancenorm_reserve_tile_stats(normPlan, cv->statTilesX, cv->statTilesY) != SNNHIP_OK) continue;
         TileStatsRef tiles;
         tiles.part = cv->statPart; tiles.tilesX = cv->statTilesX; tiles.tilesY = cv->statTilesY; tiles.TH = cv->statTH; tiles.TW = cv->statTW;
+        // a kernel that folds the records itself (the last block of an image: norm_fold.h) leaves nothing to launch between it and the consumer
+        NormFoldTarget target;
+        if (!snnhip::option("SNNHIP_NO_KERNEL_FOLD") && instancenorm_fold_target(normPlan, &target)) tiles.folded = cv->enableNormFold(target);
         a.plain = cv;
         a.desc = cv->desc;
         ++fusedCount;
@@ -1426,7 +1436,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         }
         if (inConv) { // rules F + I
             inConv->tiles = tiles;
-            inConv->desc = "instancenorm(fold of tile stats) -> " + inConv->conv->desc;
+            inConv->desc = (tiles.folded ? "instancenorm(statistics from the convolution in front) -> " : "instancenorm(fold of tile stats) -> ") + inConv->conv->desc;
             b.desc = inConv->desc;
             b.bytes -= static_cast<double>(nd.N) * nd.H * nd.W * nd.C * (cv->dtype == SNNHIP_F16 ? 2.0 : 4.0);
             continue;
@@ -1435,12 +1445,13 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         both->ctx = ctx;
         both->conv = cv;
         both->norm = b.plain;
+        both->tiles = tiles;
         both->dtype = cv->dtype;
         memcpy(both->inDims, cv->inDims, sizeof(both->inDims));
         memcpy(both->outDims, cv->outDims, sizeof(both->outDims));
         both->flops = a.flops + b.flops;
         both->bytes = a.bytes + b.bytes * 2.0 / 3.0;
-        both->desc = cv->desc + " -> instancenorm(fold of tile stats + 1 sweep) act=" + std::to_string(nd.act);
+        both->desc = cv->desc + (tiles.folded ? " -> instancenorm(1 sweep) act=" : " -> instancenorm(fold of tile stats + 1 sweep) act=") + std::to_string(nd.act);
         chain->owned.push_back(both);
         a.plain = both;
         a.desc = both->desc;

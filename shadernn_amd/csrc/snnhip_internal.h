@@ -203,7 +203,19 @@ struct ConvPlanBase : snnhip_plan {
     float* statPart = nullptr;
     int statTilesX = 0, statTilesY = 0, statTH = 0, statTW = 0;
     virtual bool enableTileStats() { return false; }
+    // ... and a kernel that can also FOLD the records itself (the last block of an image to finish merges that image's records and writes the
+    // norm's shift / mul: no fold launches behind the convolution) is given the norm's parameters here; false = not supported
+    virtual bool enableNormFold(const struct NormFoldTarget&) { return false; }
 };
+// the InstanceNorm a convolution folds its tile statistics for: y = x * mul[n][c] + shift[n][c], mul = gamma / sqrt(var + eps), shift = beta - mean * mul
+struct NormFoldTarget {
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float* shift = nullptr;
+    float* mul = nullptr;
+    float eps = 0.0f;
+};
+bool instancenorm_fold_target(snnhip_plan* normPlan, NormFoldTarget* t);
 // eltwise_pool.hip: identify an InstanceNorm plan / run its fold + normalise passes in place from a convolution's tile statistics
 bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d);
 // chain rule H: InstanceNorm -> Add(., residual) folded into the norm's normalise sweep (two-input plan; borrows normPlan)
@@ -215,6 +227,7 @@ bool instancenorm_stat_pointers(const snnhip_plan* plan, const float** shift, co
 struct TileStatsRef {
     const float* part = nullptr;
     int tilesX = 0, tilesY = 0, TH = 0, TW = 0;
+    bool folded = false; // the convolution folded the records itself (ConvPlanBase::enableNormFold): shift / mul are ready when it has run
 };
 // the norm's shift / mul from a statistics sweep over x, or (tiles && tiles->part) from a fold over the producing convolution's tile records
 int instancenorm_run_stats(snnhip_plan* plan, const snnhip_tensor* x, const TileStatsRef* tiles = nullptr);

@@ -242,15 +242,21 @@ def test_stem32_matches_oracle_and_tap_pair_kernel(ctx, monkeypatch, shape):
         np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("n,h,w,ic,oc,offset", [(2, 19, 45, 32, 128, 0.0), (1, 37, 70, 64, 64, 6.0), (3, 9, 33, 16, 32, 0.0), (1, 16, 64, 128, 128, 40.0)])
-def test_wide_tile_stats_feed_instancenorm(ctx, monkeypatch, n, h, w, ic, oc, offset):
+@pytest.mark.parametrize("kernel_fold", [True, False], ids=["kernel-fold", "fold-launches"])
+@pytest.mark.parametrize("n,h,w,ic,oc,offset", [(2, 19, 45, 32, 128, 0.0), (1, 37, 70, 64, 64, 6.0), (3, 9, 33, 16, 32, 0.0), (1, 16, 64, 128, 128, 40.0), (2, 70, 300, 16, 32, 0.0)])
+def test_wide_tile_stats_feed_instancenorm(ctx, monkeypatch, n, h, w, ic, oc, offset, kernel_fold):
     """Chain rule F on the wide kernel (the default there): reflect Pad -> Conv2D -> InstanceNorm as ONE step -- the convolution's epilogue leaves
     {mean, M2} of every output tile and channel, a fold over those records replaces the norm's statistics sweep.  Ragged tile edges in both
     directions, several images, and a layer whose mean is far from zero compared with its deviation (the tile records are merged with the
-    parallel-variance update, not as raw sums).  Against the separate launches and the oracle."""
+    parallel-variance update, not as raw sums).  The records are folded by the convolution kernel itself (the last block of an image to finish:
+    norm_fold.h; default) or by two fold launches (SNNHIP_NO_KERNEL_FOLD).  Against the separate launches and the oracle; run twice (the
+    kernel's block counters must be back at zero)."""
     import shadernn_amd as snn
 
     monkeypatch.setenv("SNNHIP_CONV", "wide")
+    monkeypatch.setenv("SNNHIP_NORM_FUSION_MIN_MB", "0")
+    if not kernel_fold:
+        monkeypatch.setenv("SNNHIP_NO_KERNEL_FOLD", "1")
     x, wt = _rand((n, h, w, ic), 1), _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9))
     b = _rand((oc,), 3, 0.5) + offset
     beta, gamma = _rand((oc,), 4, 0.3), 1.0 + _rand((oc,), 5, 0.2)
@@ -260,9 +266,11 @@ def test_wide_tile_stats_feed_instancenorm(ctx, monkeypatch, n, h, w, ic, oc, of
     norm = snn.instancenorm_plan(ctx, n, oh, ow, oc, beta, gamma, act="relu")
     fused = snn.chain_plan(ctx, [pad, conv, norm])
     d = fused.describe()
-    assert fused.num_steps() == 1 and "wide" in d and "+tile-stats" in d and "fold of tile stats + 1 sweep" in d, d
+    assert fused.num_steps() == 1 and "wide" in d and "+tile-stats" in d, d
+    assert ("+tile-stats+fold" in d and "instancenorm(1 sweep)" in d) if kernel_fold else "fold of tile stats + 1 sweep" in d, d
     xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
     y = fused(xt).numpy()
+    np.testing.assert_array_equal(fused(xt).numpy(), y)
     two = norm(conv(pad(xt))).numpy()
     c = O._h(O.conv2d(O.pad(O._h(x), (1, 1, 1, 1), "reflect"), O._h(wt), b, 1, (0, 0, 0, 0), "constant", "", 0.0, None))
     want = O._h(O.instancenorm(c, beta, gamma, "relu"))
@@ -285,6 +293,7 @@ def test_wide_tile_stats_feed_instancenorm_add_at_the_end_of_a_graph_run(ctx, mo
     import shadernn_amd as snn
 
     monkeypatch.setenv("SNNHIP_CONV", "wide")
+    monkeypatch.setenv("SNNHIP_NORM_FUSION_MIN_MB", "0")
     n, h, w, c = 2, 21, 37, 64
     x, wt, b = _rand((n, h, w, c), 1), _rand((c, c, 3, 3), 2, 1.0 / np.sqrt(c * 9)), _rand((c,), 3, 0.5)
     beta, gamma = _rand((c,), 4, 0.3), 1.0 + _rand((c,), 5, 0.2)
@@ -300,10 +309,11 @@ def test_wide_tile_stats_feed_instancenorm_add_at_the_end_of_a_graph_run(ctx, mo
     assert [p is None for p, _ in fused] == [False, True, True, True, False], [p.describe() if p else None for p, _ in fused]
     tail, ins = fused[4]
     d = tail.describe()
-    assert ins == [0, 0] and "chain{" in d and "+tile-stats" in d and "(fold of tile stats + 1 sweep) +add" in d, (ins, d)
+    assert ins == [0, 0] and "chain{" in d and "+tile-stats+fold" in d and "(statistics from the convolution, 1 sweep) +add" in d, (ins, d)
     xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
     t0 = pre(xt)
     y = tail([t0, t0]).numpy()
+    np.testing.assert_array_equal(tail([t0, t0]).numpy(), y)
     nrm = norm(conv(pad(t0)))
     two = add([nrm, t0] if order[0] == 3 else [t0, nrm]).numpy()
     np.testing.assert_allclose(y, two, rtol=2e-3, atol=2e-3, err_msg=d)
@@ -317,9 +327,10 @@ def test_wide_tile_stats_feed_instancenorm_add_at_the_end_of_a_graph_run(ctx, mo
 
 def test_wide_tile_stats_feed_a_normalising_convolution(ctx, monkeypatch):
     """Rules F + I: Conv2D (wide) -> InstanceNorm -> reflect Pad -> Conv2D 9x9 32 -> 3 (the tail of the style networks).  The second convolution
-    normalises while it stages (I) and the norm's statistics come from the first one's tile records (F): the norm is two tiny fold launches."""
+    normalises while it stages (I) and the norm's statistics come from the first one's tile records (F), folded by that kernel: the norm is no launch at all."""
     import shadernn_amd as snn
 
+    monkeypatch.setenv("SNNHIP_NORM_FUSION_MIN_MB", "0")
     n, h, w, ic, c = 2, 150, 340, 64, 32  # 220 blocks of 512 pixels: large enough for the wide kernel to be the default choice
     x, w1, b1 = _rand((n, h, w, ic), 1), _rand((c, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9)), _rand((c,), 3, 0.5)
     w2, b2 = _rand((3, c, 9, 9), 6, 1.0 / np.sqrt(c * 81)), _rand((3,), 7, 0.5)
@@ -331,7 +342,7 @@ def test_wide_tile_stats_feed_a_normalising_convolution(ctx, monkeypatch):
     plans = [conv1, norm, pad, conv2]
     fused = snn.chain_plan(ctx, plans)
     d = fused.describe()
-    assert fused.num_steps() == 2 and "+tile-stats" in d and "instancenorm(fold of tile stats) -> " in d and "rowfold" in d, d
+    assert fused.num_steps() == 2 and "+tile-stats+fold" in d and "instancenorm(statistics from the convolution in front) -> " in d and "rowfold" in d, d
     xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
     y = fused(xt).numpy()
     t = xt

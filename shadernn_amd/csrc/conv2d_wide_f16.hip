@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     constexpr int BN = 32 * NT * WN;
     constexpr int Q = 2 * C8;  // 16-byte slots per staged pixel
     constexpr int S = 9 * C8;  // K steps (16 channels each) per chunk
-    constexpr int D = 3;       // weight ring depth in K steps (divides S)
+    // weight ring depth in K steps (divides S).  One step is MT * NT MFMAs: 256 cycles with NT = 2 -- three steps of lead cover an L2 round trip --
+    // but only 128 with NT = 1, where a whole chunk's 9 steps are kept in flight (64 -> 32 @816x1376 b16: 1500 -> 1277 us; no change for NT = 2)
+    constexpr int D = NT == 1 ? 9 : 3;
     constexpr int kTileW = 34; // staged tile width: the 32-pixel tile row + the 3x3 halo
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -80,7 +82,37 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     // addresses in registers and spilled).  Pixels outside the image (zero padding), the padding slots and the slots past the tile read a
     // block of zeros behind the packed weights.  No staging registers, no ds_write; the copy for chunk c+1 is issued at the top of chunk c
     // and waited for with a COUNTED vmcnt before the closing barrier (the weight ring's youngest loads stay in flight).
+    // The source pixel of a staged pixel is separable -- its row depends on the tile row only, its column on the tile column only -- so the padding
+    // / fused Pad / fused UpSampling resolution runs ONCE per tile row and column (52 threads, one coordinate each) into two small LDS tables, and
+    // a thread's R elements are two look-ups each (resolved per element it was ~110 VALU instructions x R: as long as a quarter of the wave's MFMAs)
     constexpr int QP = Q + 1;
+    float* const epiTab = smem + p.epiOfs; // (behind the staging buffers AND the epilogue's output tile) this block's BN rows of the epilogue table {bias, bnScale, bnMean, bnBeta}
+    float* const biasTab = epiTab + 4 * BN; // the biases alone, contiguous: the four of a lane's channel run are one ds_read_b128
+    int* const syTab = reinterpret_cast<int*>(biasTab + BN); // [tileH <= 32] pixel index of the source row's first pixel, -1 = outside (zeros)
+    int* const sxTab = syTab + 32;                          // [kTileW] source column, -1 = outside
+    if (tid < BN) {
+        const float4 e4 = epi[blockIdx.y * BN + tid];
+        reinterpret_cast<float4*>(epiTab)[tid] = e4;
+        biasTab[tid] = e4.x;
+    }
+    if (tid >= 192 && tid < 192 + kTileW) {
+        const int c = tid - 192;
+        int sx = resolve_nobranch(ix0 + c, p.W, p.padMode);
+        if (p.preMode) { // a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied (-1 stays -1: size <= 2^30)
+            const int px = resolve_nobranch(sx - p.preX, p.srcW << p.preShift, p.preMode);
+            sx = sx < 0 ? -1 : (px < 0 ? -1 : px >> p.preShift);
+        }
+        sxTab[c] = sx;
+    } else if (tid >= 128 && tid < 128 + p.tileH) {
+        const int rr = tid - 128;
+        int sy = resolve_nobranch(iy0 + rr, p.H, p.padMode);
+        if (p.preMode) {
+            const int py = resolve_nobranch(sy - p.preY, p.srcH << p.preShift, p.preMode);
+            sy = sy < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
+        }
+        syTab[rr] = sy < 0 ? -1 : (n * p.srcH + sy) * p.srcW;
+    }
+    __syncthreads();
     int gofs[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -91,14 +123,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
             const int ql = e - pix * QP;
             const int rr = static_cast<int>(__umulhi(static_cast<unsigned>(pix), p.magicW));
             const int c = pix - rr * p.tileW;
-            int sy = resolve_nobranch(iy0 + rr, p.H, p.padMode);
-            int sx = resolve_nobranch(ix0 + c, p.W, p.padMode);
-            if (p.preMode) { // a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied (-1 stays -1: size <= 2^30)
-                const int py = resolve_nobranch(sy - p.preY, p.srcH << p.preShift, p.preMode), px = resolve_nobranch(sx - p.preX, p.srcW << p.preShift, p.preMode);
-                sy = sy < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
-                sx = sx < 0 ? -1 : (px < 0 ? -1 : px >> p.preShift);
-            }
-            if (sy >= 0 && sx >= 0 && ql < Q) gofs[r] = ((n * p.srcH + sy) * p.srcW + sx) * p.IC + ql * 8;
+            const int rowPix = syTab[rr], sx = sxTab[c];
+            if (rowPix >= 0 && sx >= 0 && ql < Q) gofs[r] = (rowPix + sx) * p.IC + ql * 8;
         }
     }
     const _Float16* const zeros = reinterpret_cast<const _Float16*>(wp + p.zeroOfs);
@@ -134,13 +160,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         bptr += bstep;
     }
 
-    float* const epiTab = smem + p.epiOfs; // (behind the staging buffers AND the epilogue's output tile) this block's BN rows of the epilogue table {bias, bnScale, bnMean, bnBeta}
-    float* const biasTab = epiTab + 4 * BN; // the biases alone, contiguous: the four of a lane's channel run are one ds_read_b128
-    if (tid < BN) {
-        const float4 e4 = epi[blockIdx.y * BN + tid];
-        reinterpret_cast<float4*>(epiTab)[tid] = e4;
-        biasTab[tid] = e4.x;
-    }
     stage_dma(smem, 0);
     lds_dma_wait();
     __syncthreads();
@@ -177,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         }
         // the DMA of this chunk is older than every weight refill of the chunk; the ring keeps D * NT loads in flight
         if (D * NT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (D * NT == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         __syncthreads();
     }
@@ -203,6 +223,25 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias4[u][g] = btab[u * 8 + 2 * g];
     }
+    // layers without batch norm whose activation is none or relu (every 3x3 layer of the style graphs): bias and clamp, two instructions per value --
+    // the general form below (run-time batch-norm select, mul / max / med3 activation) is seven, and with 128 values per lane the epilogue's
+    // VALU work was a third of the wave's MFMA time
+    const bool fastEpi = SIMPLE && !p.useBN && ac.alpha == 1.0f && ac.hi == __builtin_huge_valf();
+    if (fastEpi) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float bk[4] = {bias4[u][g].x, bias4[u][g].y, bias4[u][g].z, bias4[u][g].w};
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    h4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(fmaxf(acc[t][u][4 * g + k] + bk[k], ac.lo));
+                    *reinterpret_cast<h4*>(otile + ((wm * MT + t) * 32 + l32) * EPITCH + wn * (NT * 32) + u * 32 + 8 * g + 4 * h) = o;
+                }
+            }
+    } else
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -474,7 +513,7 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (!fn) return SNNHIP_E_UNSUPPORTED;
     const int PIX = 128 * WM;
     p.epiOfs = static_cast<int>(std::max(static_cast<size_t>(2) * p.bufFloats * 4, static_cast<size_t>(PIX) * (BN + 8) * 2) / 4);
-    const size_t lds = static_cast<size_t>(p.epiOfs) * 4 + static_cast<size_t>(BN) * 20;
+    const size_t lds = static_cast<size_t>(p.epiOfs) * 4 + static_cast<size_t>(BN) * 20 + (32 + 40) * sizeof(int); // + the row / column tables of the staging
     if (lds > 80 * 1024) return SNNHIP_E_UNSUPPORTED;
 
     auto* plan = new WideConvPlan();
@@ -495,9 +534,9 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         return SNNHIP_E_HIP;
     }
 
-    // weights: Wp[chunk][tap][c8][h][OC] x 8 halfs, ic = chunk*16*C8 + (c8*2 + h)*8 + j  (+ D zero steps for the ring's read-ahead)
+    // weights: Wp[chunk][tap][c8][h][OC] x 8 halfs, ic = chunk*16*C8 + (c8*2 + h)*8 + j  (+ 10 zero steps: the ring's read-ahead, D <= 9, and the DMA's block of zeros)
     const size_t steps = static_cast<size_t>(p.nChunks) * 9 * C8;
-    std::vector<float> wpk((steps + 4) * 2 * g.OC * 4, 0.0f);
+    std::vector<float> wpk((steps + 10) * 2 * g.OC * 4, 0.0f); // the ring reads up to D = 9 steps past the last one
     _Float16* wph = reinterpret_cast<_Float16*>(wpk.data());
     for (int chunk = 0; chunk < p.nChunks; ++chunk)
         for (int t = 0; t < 9; ++t)

@@ -58,63 +58,78 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_kernel(RowfoldParams p,
 #pragma unroll
     for (int s = 0; s < NK; ++s) b[s] = wp[s * 64 + lane];
 
-    // ---- stage the input tile: element e -> (row, column, slot); zero outside the (padded) image, the Pad layer resolved on the fly
+    // ---- stage the input tile; zero outside the (padded) image, the Pad layer resolved on the fly.  Element e = tid + 256 r of the tile
+    // [ROWS][64 columns][Q slots] is column (tid / Q) % 64, slot tid % Q of row r * RPI + tid / (64 Q): a thread's elements share their column and
+    // channel slot, and a round's row is wave-uniform -- the column is resolved once per thread, the row on the scalar unit, an element costs an
+    // address add, its load, and the LDS store at an immediate offset.  (Resolving row AND column per element, with a bounds branch each, made this
+    // prologue 1300 VALU + 1300 SALU instructions for the wave's 72 MFMAs: the kernel was issue-bound on address arithmetic.)
     {
-        constexpr int TOTAL = ROWS * kCols * Q;
+        constexpr int CPR = kCols * Q;     // elements per staged row (256 or 128)
+        constexpr int RPI = 256 / CPR;     // staged rows per round of 256 elements (1 or 2)
+        constexpr int NRND = (ROWS + RPI - 1) / RPI;
         const _Float16* xn = x + static_cast<size_t>(n) * p.srcH * p.srcW * p.IC;
-        // all of a thread's loads (16 for a 16 x 64 x 32-channel tile) are requested before the first LDS store: one HBM round trip per block
-        // graph rule I: a thread's elements all sit in channel slot tid % Q (256 % Q == 0), i.e. share their 8 channels and, within a block, the image
+        const int sl = tid % Q, c = (tid / Q) % kCols;
+        const int rsub = __builtin_amdgcn_readfirstlane(tid / CPR); // wave-uniform (a wave's 64 elements sit in one row)
+        int sx = resolve_nobranch(ix0 + c, p.W, p.padMode);
+        if (p.preMode) { // (uniform) a pixel of the padded image -> the source pixel the Pad layer would have copied; -1 stays -1
+            const int px = resolve_nobranch(sx - p.preX, p.srcW << p.preShift, p.preMode);
+            sx = sx < 0 ? -1 : (px < 0 ? -1 : px >> p.preShift);
+        }
+        const bool colOk = sx >= 0;
+        const int colOfs = (colOk ? sx : 0) * p.IC + 8 * sl;
+        float* const ldsp = smem + ((rsub * kCols + c) * Q + (sl ^ ((c >> (Q == 4 ? 2 : 3)) & (Q - 1)))) * 4;
+        // graph rule I: a thread's elements share their 8 channels and, within a block, the image
         float nShift[8], nMul[8];
         if (p.normShift) {
-            const int cb = 8 * (tid % Q);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                nShift[k] = p.normShift[static_cast<size_t>(n) * p.IC + cb + k];
-                nMul[k] = p.normMul[static_cast<size_t>(n) * p.IC + cb + k];
+                nShift[k] = p.normShift[static_cast<size_t>(n) * p.IC + 8 * sl + k];
+                nMul[k] = p.normMul[static_cast<size_t>(n) * p.IC + 8 * sl + k];
             }
         }
         const bool nRelu = p.normAc.act == SNNHIP_ACT_RELU; // (uniform) one instruction instead of the general mul / max / med3
-        for (int base = tid; base < TOTAL; base += 16 * 256) {
-            float4 v[16];
-            int lo[16];
-            unsigned live = 0; // elements that were read from the tensor (the others are padding zeros and stay zero)
+        float4 v[NRND];
+        bool rowOk[NRND];
+        // all of a thread's loads (16 for a 16 x 64 x 32-channel tile) are requested before the first LDS store: one HBM round trip per block
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int e = base + r * 256;
-                v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                lo[r] = -1;
-                if (e < TOTAL) {
-                    const int s = e % Q, pc = e / Q;
-                    const int c = pc % kCols, rr = pc / kCols;
-                    int sy = resolve_nobranch(iy0 + rr, p.H, p.padMode), sx = resolve_nobranch(ix0 + c, p.W, p.padMode);
-                    if (p.preMode) { // (uniform) a pixel of the padded image -> the source pixel the Pad layer would have copied; -1 stays -1
-                        const int py = resolve_nobranch(sy - p.preY, p.srcH << p.preShift, p.preMode), px = resolve_nobranch(sx - p.preX, p.srcW << p.preShift, p.preMode);
-                        sy = sy < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
-                        sx = sx < 0 ? -1 : (px < 0 ? -1 : px >> p.preShift);
+        for (int r = 0; r < NRND; ++r) {
+            const int rr = r * RPI + rsub;
+            int sy = resolve_nobranch(iy0 + rr, p.H, p.padMode);
+            if (p.preMode) {
+                const int py = resolve_nobranch(sy - p.preY, p.srcH << p.preShift, p.preMode);
+                sy = sy < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
+            }
+            rowOk[r] = sy >= 0 && rr < ROWS; // (uniform)
+            v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowOk[r]) v[r] = *reinterpret_cast<const float4*>(xn + static_cast<size_t>(sy) * p.srcW * p.IC + colOfs); // (a column outside reads column 0: masked below)
+        }
+        if (p.normShift) { // (the activation test sits OUTSIDE the element loops: inside, the compiler kept both forms behind a branch per element)
+            if (nRelu) {
+#pragma unroll
+                for (int r = 0; r < NRND; ++r) {
+                    h8 hv = *reinterpret_cast<const h8*>(&v[r]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) hv[k] = static_cast<_Float16>(fmaxf(fmaf(static_cast<float>(hv[k]), nMul[k], nShift[k]), 0.0f));
+                    v[r] = *reinterpret_cast<const float4*>(&hv);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NRND; ++r) {
+                    h8 hv = *reinterpret_cast<const h8*>(&v[r]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float f = fmaf(static_cast<float>(hv[k]), nMul[k], nShift[k]);
+                        hv[k] = static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
                     }
-                    if (sy >= 0 && sx >= 0) {
-                        v[r] = *reinterpret_cast<const float4*>(xn + (static_cast<size_t>(sy) * p.srcW + sx) * p.IC + 8 * s);
-                        live |= 1u << r;
-                    }
-                    lo[r] = ((rr * kCols + c) * Q + (s ^ ((c >> (Q == 4 ? 2 : 3)) & (Q - 1)))) * 4;
+                    v[r] = *reinterpret_cast<const float4*>(&hv);
                 }
             }
-            if (p.normShift) {
+        }
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (live & (1u << r)) {
-                        h8 hv = *reinterpret_cast<const h8*>(&v[r]);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const float f = fmaf(static_cast<float>(hv[k]), nMul[k], nShift[k]);
-                            hv[k] = static_cast<_Float16>(nRelu ? fmaxf(f, 0.0f) : __builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
-                        }
-                        v[r] = *reinterpret_cast<const float4*>(&hv);
-                    }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (lo[r] >= 0) *reinterpret_cast<float4*>(smem + lo[r]) = v[r];
+        for (int r = 0; r < NRND; ++r) {
+            const bool live = rowOk[r] && colOk; // padding stays zero (the norm is not applied to it)
+            const float4 o = make_float4(live ? v[r].x : 0.f, live ? v[r].y : 0.f, live ? v[r].z : 0.f, live ? v[r].w : 0.f);
+            if (r * RPI + rsub < ROWS) *reinterpret_cast<float4*>(ldsp + r * RPI * CPR * 4) = o;
         }
     }
     __syncthreads();

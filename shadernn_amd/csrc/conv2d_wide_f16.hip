@@ -14,8 +14,8 @@
 //       WM=2 WN=2 NT=2: 256 px x 128 oc     WM=4 WN=1 NT=2: 512 px x 64 oc     WM=4 WN=1 NT=1: 512 px x 32 oc
 //   * halo tile staged through registers into LDS in channel chunks of 16 C8 (double-buffered, one barrier per chunk), XOR-swizzled 16-byte
 //     slots as in conv2d_mfma_kernel (lds_off); the fused Pad / UpSampling address path (ConvGeom::preMode / preShift) resolves here;
-//   * (graph rule I, the InstanceNorm in front applied while staging, is NOT in this kernel: DMA staging has no registers to apply it in, and an
-//     in-LDS fix-up pass costs more than the norm's own normalise sweep on these layers -- conv2d_mfma / conv2d_rowfold have it)
+//   * graph rule I (the InstanceNorm in front folded into this layer): the DMA carries the raw values, every thread then normalises the slots
+//     its own lanes copied, in LDS, before the barrier that publishes the chunk (norm_fixup below);
 //   * weights packed exactly as for conv2d_mfma_kernel ([chunk][tap][c8][h][OCp] x 8 halfs), streamed per lane with a 3-step ring;
 //   * the weights are the MFMA's A operand, the pixels its B operand: a lane ends up with runs of 4 consecutive output channels of its own
 //     pixel and the epilogue (bias / BN / activation / fused residual Add) stores them directly, 8 bytes per lane, without an LDS transpose.
@@ -48,6 +48,10 @@ struct WideParams {
     ActCfg ac2;
     float* statPart; // chain rule F: per (image, tile, channel) {mean, M2} of the stored values, [n][ty][tx][2][OC]; null = off
     NormFoldArgs fold; // ... and the last block of an image folds them into the norm's shift / mul (norm_fold.h); fold.counter == null = off
+    // graph rule I: the InstanceNorm in front, normAc(x * mul[n][c] + shift[n][c]), applied to the staged values IN LDS (below); null = none
+    const float* normShift;
+    const float* normMul;
+    ActCfg normAc;
 };
 
 template <int WM, int WN, int NT, int C8, int R, bool SIMPLE, bool RES>
@@ -90,6 +94,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     float* const biasTab = epiTab + 4 * BN; // the biases alone, contiguous: the four of a lane's channel run are one ds_read_b128
     int* const syTab = reinterpret_cast<int*>(biasTab + BN); // [tileH <= 32] pixel index of the source row's first pixel, -1 = outside (zeros)
     int* const sxTab = syTab + 32;                          // [kTileW] source column, -1 = outside
+    float* const normTab = reinterpret_cast<float*>(sxTab + 40); // [2][IC] graph rule I: shift, mul of this block's image
+    if (p.normShift)
+        for (int i = tid; i < p.IC; i += 256) {
+            normTab[i] = p.normShift[n * p.IC + i];
+            normTab[p.IC + i] = p.normMul[n * p.IC + i];
+        }
     if (tid < BN) {
         const float4 e4 = epi[blockIdx.y * BN + tid];
         reinterpret_cast<float4*>(epiTab)[tid] = e4;
@@ -114,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     }
     __syncthreads();
     int gofs[R];
+    unsigned qlPack = 0; // channel slot of element r in bits 4r .. 4r+2 (the norm fix-up below)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int e = tid + 256 * r;
@@ -121,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         if (e < p.total) {
             const int pix = e / QP;
             const int ql = e - pix * QP;
+            qlPack |= static_cast<unsigned>(ql) << (4 * r);
             const int rr = static_cast<int>(__umulhi(static_cast<unsigned>(pix), p.magicW));
             const int c = pix - rr * p.tileW;
             const int rowPix = syTab[rr], sx = sxTab[c];
@@ -133,6 +145,34 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         for (int r = 0; r < R; ++r) {
             const _Float16* src = gofs[r] >= 0 ? x + gofs[r] + ic0 : zeros;
             lds_dma16(src, buf + (wave * 64 + 256 * r) * 4);
+        }
+    };
+
+    // graph rule I: the DMA cannot touch the values it carries, so the InstanceNorm in front of this layer is applied to the chunk IN LDS: every
+    // thread normalises exactly the 16-byte slots ITS lanes of the DMA wrote (no other thread has seen them: the pass sits between the DMA's
+    // vmcnt wait and the barrier that publishes the chunk), x -> half(act(x * mul[c] + shift[c])) in fp32 -- the arithmetic and rounding point of
+    // the norm's own normalise sweep, so the result is bit-identical to the separate launches.  Padding (zeros block) stays zero.  Costs ~180
+    // instructions per thread and chunk next to the chunk's 144 MFMAs (+10 %); the normalise sweep it replaces is a read + write of the tensor.
+    auto norm_fixup = [&](float* buf, int ic0) {
+        typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+        const bool nRelu = p.normAc.act == SNNHIP_ACT_RELU;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (gofs[r] < 0) continue;
+            float* slot = buf + (tid + 256 * r) * 4;
+            const float* tb = normTab + ic0 + 8 * static_cast<int>((qlPack >> (4 * r)) & 7u);
+            h8v hv = *reinterpret_cast<const h8v*>(slot);
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const float4 sh = *reinterpret_cast<const float4*>(tb + 4 * q4), mu = *reinterpret_cast<const float4*>(tb + p.IC + 4 * q4);
+                const float shv[4] = {sh.x, sh.y, sh.z, sh.w}, muv[4] = {mu.x, mu.y, mu.z, mu.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float f = fmaf(static_cast<float>(hv[4 * q4 + k]), muv[k], shv[k]);
+                    hv[4 * q4 + k] = static_cast<_Float16>(nRelu ? fmaxf(f, 0.0f) : __builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                }
+            }
+            *reinterpret_cast<h8v*>(slot) = hv;
         }
     };
 
@@ -162,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
 
     stage_dma(smem, 0);
     lds_dma_wait();
+    if (p.normShift) norm_fixup(smem, 0);
     __syncthreads();
 
     float4 a[MT];
@@ -198,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         if (D * NT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (D * NT == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (p.normShift && more) norm_fixup(smem + ((chunk + 1) & 1) * p.bufFloats, (chunk + 1) * 16 * C8);
         __syncthreads();
     }
 
@@ -459,7 +501,7 @@ WideFn pick_wide(bool simple, bool res) {
 int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
     if (g.IC % 16 != 0 || g.OC % 32 != 0 || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED;
-    if (g.normShift) return SNNHIP_E_UNSUPPORTED; // graph rule I: not in this kernel
+    if (g.normShift && !act_is_simple(g.normAct)) return SNNHIP_E_UNSUPPORTED; // graph rule I: the branch-free activations only
     const double inCount = static_cast<double>(g.N) * (g.preMode ? g.srcH : g.H) * (g.preMode ? g.srcW : g.W) * g.IC;
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
@@ -513,7 +555,11 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (!fn) return SNNHIP_E_UNSUPPORTED;
     const int PIX = 128 * WM;
     p.epiOfs = static_cast<int>(std::max(static_cast<size_t>(2) * p.bufFloats * 4, static_cast<size_t>(PIX) * (BN + 8) * 2) / 4);
-    const size_t lds = static_cast<size_t>(p.epiOfs) * 4 + static_cast<size_t>(BN) * 20 + (32 + 40) * sizeof(int); // + the row / column tables of the staging
+    const size_t lds = static_cast<size_t>(p.epiOfs) * 4 + static_cast<size_t>(BN) * 20 + (32 + 40) * sizeof(int) + // + the row / column tables of the staging
+                       (g.normShift ? static_cast<size_t>(2) * g.IC * sizeof(float) : 0);                                  // + the norm's shift / mul (rule I)
+    p.normShift = g.normShift;
+    p.normMul = g.normMul;
+    p.normAc = make_act_cfg(g.normShift ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
     if (lds > 80 * 1024) return SNNHIP_E_UNSUPPORTED;
 
     auto* plan = new WideConvPlan();
@@ -566,6 +612,7 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->desc = buf;
     if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
     if (g.preMode && g.preShift) plan->desc += " +upsample(x2)";
+    if (g.normShift) plan->desc = "instancenorm(act=" + std::to_string(g.normAct) + ", in LDS behind the DMA) -> " + plan->desc;
     if (plan->fusedAdd) {
         plan->desc += " +add";
         plan->bytes += 2.0 * static_cast<double>(g.N) * g.OH * g.OW * g.OC;

@@ -861,7 +861,7 @@ constexpr int B_TW = 32, B_TH = 8;
 // next to its output; the InstanceNorm's statistics sweep -- one of its three passes over the tensor -- is replaced by a fold over those
 // tile records, and its normalise pass runs in place on the convolution's output.  Both plans are borrowed (the chain or the caller owns them).
 struct ConvInstanceNormPlan : snnhip_plan {
-    ConvPlanBase* conv = nullptr;
+    snnhip_plan* conv = nullptr; // the convolution, or the InstanceNorm -> convolution of rule I that wraps it
     snnhip_plan* norm = nullptr;
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         int rc = conv->run(in, nIn, out);
@@ -1337,9 +1337,13 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         auto* cv = dynamic_cast<ConvPlanBase*>(b.plain);
         if (!cv || cv->depthwise || cv->numInputs != 1 || cv->g.normShift || !instancenorm_plan_desc(a.plain, &nd) || !act_is_simple(nd.act)) continue;
         if (nd.N != cv->inDims[0] || nd.H != cv->inDims[1] || nd.W != cv->inDims[2] || nd.C != cv->inDims[3]) continue;
-        // only where the convolution already runs on a kernel that can normalise: trading the 4 x 2-tile kernel (conv2d_wide_f16) for the
-        // 128-pixel one costs more than the normalise sweep saves (measured on Candy's residual blocks: 160 + 290 us apart, 600 us folded)
-        if (cv->desc.rfind("conv2d_mfma_f16_", 0) != 0 && cv->desc.rfind("conv2d_rowfold", 0) != 0) continue;
+        // only where the convolution already runs on a kernel that can normalise (trading conv2d_wide_f16 for the 128-pixel kernel cost more than
+        // the normalise sweep saves, measured on Candy's residual blocks: 160 + 290 us apart, 600 us folded -- the wide kernel has its own form now)
+        // conv2d_wide_f16 normalises in LDS behind its DMA: worth it on the 64 / 128-channel blocks (body layers 310 + 130 us apart -> 370 us), not
+        // behind a fused UpSampling (the pass runs on the 4x replicated pixels) nor on the VALU-bound 32-channel blocks (64 -> 32 up-conv: 1.07 ms
+        // + 0.17 ms sweep apart, 1.70 ms folded)
+        const bool onWide = cv->desc.rfind("conv2d_mfma_wide_f16", 0) == 0 && !cv->g.preShift && cv->g.OC % 64 == 0;
+        if (cv->desc.rfind("conv2d_mfma_f16_", 0) != 0 && cv->desc.rfind("conv2d_rowfold", 0) != 0 && !(onWide && !snnhip::option("SNNHIP_NO_WIDE_NORM"))) continue;
         ConvGeom g2 = cv->g;
         if (!instancenorm_stat_pointers(a.plain, &g2.normShift, &g2.normMul)) continue;
         g2.normAct = nd.act;
@@ -1348,6 +1352,10 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         const int frc = cv->desc.rfind("conv2d_rowfold", 0) == 0 ? make_conv2d_rowfold_plan(ctx, g2, cv->w_oihw.data(), cv->epi4, &fused)
                                                                  : make_conv2d_mfma_plan(ctx, g2, cv->w_oihw.data(), cv->epi4, &fused);
         if (frc != SNNHIP_OK) continue;
+        if (onWide && fused->desc.find("conv2d_mfma_wide_f16") == std::string::npos) { // (routed elsewhere with the norm attached: keep the separate launches)
+            delete fused;
+            continue;
+        }
         chain->owned.push_back(fused);
         auto* both = new InstanceNormConvPlan();
         both->ctx = ctx;
@@ -1380,9 +1388,10 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
     for (size_t k = 0; rc == SNNHIP_OK && k + 1 < chain->steps.size() && normFusionMode != 0; ++k) {
         ChainPlan::Step &a = chain->steps[k], &b = chain->steps[k + 1];
         if (a.kind != ChainPlan::PLAIN || b.kind != ChainPlan::PLAIN) continue;
-        auto* cv = dynamic_cast<ConvPlanBase*>(a.plain);
+        auto* aIn = dynamic_cast<InstanceNormConvPlan*>(a.plain); // the producer may itself be a normalising convolution (rule I): its inner plan is the chain's
+        auto* cv = dynamic_cast<ConvPlanBase*>(aIn ? aIn->conv : a.plain);
         if (!cv || cv->depthwise || cv->numInputs != 1) continue;
-        if (normFusionMode < 0 && cv->desc.rfind("conv2d_mfma_wide_f16", 0) != 0) continue;
+        if (normFusionMode < 0 && cv->desc.find("conv2d_mfma_wide_f16") == std::string::npos) continue;
         {
             // small tensors (one 720p image: 17 MB per layer) are swept out of the L2 / MALL in less time than the two fold launches take
             // (Candy batch 1: 1.12 ms without the rule, 1.24 ms with it); from a few images per batch on the sweep is an HBM pass
@@ -1405,7 +1414,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         // caller owns -- a borrowed per-layer plan stays what it was; the chain works on its own copy (rule D's product already is chain-owned).
         bool borrowed = false;
         for (int i = 0; i < n; ++i) borrowed = borrowed || plans[i] == a.plain;
-        if (borrowed) {
+        if (borrowed && !aIn) {
             snnhip_plan* copy = nullptr;
             if (make_conv2d_mfma_plan(ctx, cv->g, cv->w_oihw.data(), cv->epi4, &copy) != SNNHIP_OK) continue;
             auto* cc = dynamic_cast<ConvPlanBase*>(copy);
@@ -1425,8 +1434,14 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         // a kernel that folds the records itself (the last block of an image: norm_fold.h) leaves nothing to launch between it and the consumer
         NormFoldTarget target;
         if (!snnhip::option("SNNHIP_NO_KERNEL_FOLD") && instancenorm_fold_target(normPlan, &target)) tiles.folded = cv->enableNormFold(target);
-        a.plain = cv;
-        a.desc = cv->desc;
+        if (aIn) {
+            const size_t arrow = aIn->desc.find(" -> ");
+            aIn->desc = (arrow == std::string::npos ? std::string("instancenorm") : aIn->desc.substr(0, arrow)) + " -> " + cv->desc;
+            a.desc = aIn->desc;
+        } else {
+            a.plain = cv;
+            a.desc = cv->desc;
+        }
         ++fusedCount;
         if (normAdd) { // rules F + H: the plan was built by the graph walk for this chain (it is the chain's to change)
             instancenorm_add_use_tile_stats(b.plain, tiles);
@@ -1443,7 +1458,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         }
         auto* both = new ConvInstanceNormPlan();
         both->ctx = ctx;
-        both->conv = cv;
+        both->conv = aIn ? static_cast<snnhip_plan*>(aIn) : cv;
         both->norm = b.plain;
         both->tiles = tiles;
         both->dtype = cv->dtype;
@@ -1451,7 +1466,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         memcpy(both->outDims, cv->outDims, sizeof(both->outDims));
         both->flops = a.flops + b.flops;
         both->bytes = a.bytes + b.bytes * 2.0 / 3.0;
-        both->desc = cv->desc + (tiles.folded ? " -> instancenorm(1 sweep) act=" : " -> instancenorm(fold of tile stats + 1 sweep) act=") + std::to_string(nd.act);
+        both->desc = a.desc + (tiles.folded ? " -> instancenorm(1 sweep) act=" : " -> instancenorm(fold of tile stats + 1 sweep) act=") + std::to_string(nd.act);
         chain->owned.push_back(both);
         a.plain = both;
         a.desc = both->desc;

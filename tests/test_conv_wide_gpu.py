@@ -353,3 +353,87 @@ def test_wide_tile_stats_feed_a_normalising_convolution(ctx, monkeypatch):
     r = O.pad(O._h(O.instancenorm(cc, beta, gamma, "relu")), (4, 4, 4, 4), "reflect")
     want = O._h(O.conv2d(r, O._h(w2), b2, 1, (0, 0, 0, 0), "constant", "tanh", 0.0, None))
     np.testing.assert_allclose(y, want, rtol=6e-3, atol=6e-3, err_msg=d)
+
+
+@pytest.mark.parametrize("with_pad", [False, True])
+@pytest.mark.parametrize("n,h,w,ic,oc,act", [(2, 19, 45, 32, 128, "relu"), (1, 37, 70, 64, 64, "leakyRelu"), (3, 9, 33, 16, 64, "relu"), (1, 16, 40, 128, 128, "")])
+def test_wide_normalises_in_lds_behind_the_dma(ctx, monkeypatch, n, h, w, ic, oc, act, with_pad, with_up=False):
+    """Graph rule I on the wide kernel: InstanceNorm -> [UpSampling] -> [Pad] -> Conv2D 3x3 as the norm's statistics + ONE convolution launch.  The
+    DMA staging cannot transform what it copies: every thread normalises the LDS slots its own lanes wrote, before the barrier that publishes the
+    chunk.  Same arithmetic and rounding point as the norm's normalise sweep: bit-identical to the separate launches; zero padding of a 'same'
+    convolution stays zero; 128- and 64-channel blocks, 16- and 32-channel chunks (the planner keeps the separate launches behind a fused
+    UpSampling and on 32-channel blocks, where the pass costs more than the sweep it replaces)."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_CONV", "wide")
+    x = 1.5 * _rand((n, h, w, ic), 1) + 0.2
+    wt, b = _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9)), _rand((oc,), 3, 0.5)
+    beta, gamma = _rand((ic,), 4, 0.3), 1.0 + _rand((ic,), 5, 0.2)
+    norm = snn.instancenorm_plan(ctx, n, h, w, ic, beta, gamma, act=act, leaky=0.1)
+    plans, hh, ww = [norm], h, w
+    if with_up:
+        plans.append(snn.upsample_plan(ctx, n, h, w, ic, 2.0, "nearest"))
+        hh, ww = 2 * h, 2 * w
+    cp = (1, 1, 1, 1)
+    if with_pad:
+        plans.append(snn.pad_plan(ctx, n, hh, ww, ic, (1, 1, 1, 1), "reflect"))
+        hh, ww, cp = hh + 2, ww + 2, (0, 0, 0, 0)
+    plans.append(snn.conv2d_plan(ctx, n, hh, ww, wt, b, stride=1, pads=cp, act="relu", dtype=snn.F16))
+    fused = snn.chain_plan(ctx, plans)
+    d = fused.describe()
+    assert fused.num_steps() == 1 and "in LDS behind the DMA) -> conv2d_mfma_wide_f16" in d, d
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    y = fused(xt).numpy()
+    t = xt
+    for pl in plans:
+        t = pl(t)
+    np.testing.assert_array_equal(y, t.numpy(), err_msg=d)
+    ref = O._h(O.instancenorm(O._h(x), beta, gamma, act, 0.1))
+    if with_up:
+        ref = O.upsample(ref, 2.0, "nearest")
+    if with_pad:
+        ref = O.pad(ref, (1, 1, 1, 1), "reflect")
+    want = O._h(O.conv2d(ref, O._h(wt), b, 1, cp, "constant", "relu", 0.0, None))
+    np.testing.assert_allclose(y, want, err_msg=d, rtol=6e-3, atol=6e-3)
+    monkeypatch.setenv("SNNHIP_NO_WIDE_NORM", "1")
+    assert "in LDS behind the DMA" not in snn.chain_plan(ctx, plans).describe() if (with_pad or with_up) else True
+
+
+def test_wide_residual_block_is_two_convolutions_and_one_sweep(ctx, monkeypatch):
+    """Rules D + I + F + H together on a residual block of the style networks, X -> Pad -> Conv -> InstanceNorm(relu) -> Pad -> Conv -> InstanceNorm
+    -> Add(., X): conv 1 leaves tile statistics (F), conv 2 normalises conv 1's output in its staging (I) and leaves tile statistics of its own
+    (F), the Add is folded into the second norm's single sweep (H) -- three launches, and of the block's seven tensor passes between the
+    convolutions only the last norm's read + residual read + write remain."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_CONV", "wide")
+    monkeypatch.setenv("SNNHIP_NORM_FUSION_MIN_MB", "0")
+    n, h, w, c = 2, 21, 37, 64
+    x = _rand((n, h, w, c), 1)
+    w1, b1, w2, b2 = _rand((c, c, 3, 3), 2, 1.0 / np.sqrt(c * 9)), _rand((c,), 3, 0.5), _rand((c, c, 3, 3), 6, 1.0 / np.sqrt(c * 9)), _rand((c,), 7, 0.5)
+    be1, ga1, be2, ga2 = _rand((c,), 4, 0.3), 1.0 + _rand((c,), 5, 0.2), _rand((c,), 8, 0.3), 1.0 + _rand((c,), 9, 0.2)
+    pre = snn.activation_plan(ctx, n, h, w, c, "relu")
+    pad1 = snn.pad_plan(ctx, n, h, w, c, (1, 1, 1, 1), "reflect")
+    conv1 = snn.conv2d_plan(ctx, n, h + 2, w + 2, w1, b1, stride=1, pads=(0, 0, 0, 0), act="", dtype=snn.F16)
+    h1, w1_ = conv1.out_shape()[1:3]
+    norm1 = snn.instancenorm_plan(ctx, n, h1, w1_, c, be1, ga1, act="relu")
+    pad2 = snn.pad_plan(ctx, n, h1, w1_, c, (1, 1, 1, 1), "reflect")
+    conv2 = snn.conv2d_plan(ctx, n, h1 + 2, w1_ + 2, w2, b2, stride=1, pads=(0, 0, 0, 0), act="", dtype=snn.F16)
+    h2, w2_ = conv2.out_shape()[1:3]
+    norm2 = snn.instancenorm_plan(ctx, n, h2, w2_, c, be2, ga2, act="")
+    add = snn.add_plan(ctx, n, h2, w2_, c, act="")
+    nodes = [(pre, [-1], False), (pad1, [0], False), (conv1, [1], False), (norm1, [2], False), (pad2, [3], False), (conv2, [4], False), (norm2, [5], False),
+             (add, [6, 0], True)]
+    fused = snn.graph_fuse(ctx, nodes)
+    assert [p is None for p, _ in fused] == [False] + [True] * 6 + [False], [p.describe() if p else None for p, _ in fused]
+    tail, ins = fused[7]
+    d = tail.describe()
+    assert ins == [0, 0] and tail.num_steps() == 3, (ins, d)
+    assert d.count("+tile-stats+fold") == 2 and "instancenorm(statistics from the convolution in front) -> instancenorm(act=1, in LDS behind the DMA)" in d, d
+    assert "(statistics from the convolution, 1 sweep) +add" in d, d
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    t0 = pre(xt)
+    y = tail([t0, t0]).numpy()
+    np.testing.assert_array_equal(tail([t0, t0]).numpy(), y)
+    two = add([norm2(conv2(pad2(norm1(conv1(pad1(t0)))))), t0]).numpy()
+    np.testing.assert_allclose(y, two, rtol=4e-3, atol=4e-3, err_msg=d)

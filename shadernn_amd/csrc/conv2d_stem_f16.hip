@@ -60,6 +60,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
         for (int s = 0; s < kSteps; ++s) wa[s] = wsrc[s * 64];
     }
     if (tid < 32) etab[tid] = epi[blockIdx.y * 32 + tid];
+    // layers without batch norm whose activation is none or relu (Candy's stem): the lane's 16 biases stay in registers for the life of the
+    // (persistent) wave and a value's epilogue is add + max -- the general form (table row from LDS, run-time batch-norm select, mul / max / med3)
+    // is eight instructions a value, 512 per wave and tile next to its 84 MFMAs
+    const bool fastEpi = SIMPLE && !p.useBN && ac.alpha == 1.0f && ac.hi == __builtin_huge_valf();
+    float bias16[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bias16[i] = epi[blockIdx.y * 32 + 8 * (i >> 2) + 4 * h + (i & 3)].x;
 
     // staging: pixel -> 4 halfs (channels past IC are 0).  The loads of tile i+1 are issued before the MFMAs of tile i and written to LDS after
     // them: no global-load latency on the critical path (a rolled load-store loop waited out 7 round trips per tile)
@@ -151,16 +158,26 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
 #pragma unroll
         for (int yy = 0; yy < kNR; ++yy) {
             const int oy = oy0 + wave * kNR + yy;
+            if (fastEpi) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                h4 o;
+                for (int g = 0; g < 4; ++g) {
+                    h4 o;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v = epi_affine(acc[yy][4 * g + k], etab[8 * g + 4 * h + k], p.useBN);
-                    v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
-                    o[k] = static_cast<_Float16>(v);
+                    for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(fmaxf(acc[yy][4 * g + k] + bias16[4 * g + k], ac.lo));
+                    *reinterpret_cast<h4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = o;
                 }
-                *reinterpret_cast<h4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = o;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    h4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float v = epi_affine(acc[yy][4 * g + k], etab[8 * g + 4 * h + k], p.useBN);
+                        v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+                        o[k] = static_cast<_Float16>(v);
+                    }
+                    *reinterpret_cast<h4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = o;
+                }
             }
             // (wave-private scratch: the LDS queue of a wave is in order, no barrier)
 #pragma unroll

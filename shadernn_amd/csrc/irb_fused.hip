@@ -58,6 +58,7 @@ struct IrbParams {
     int offH, offWe, offWp, offMask; // LDS map in floats: x planes at 0 (wave kernel: per wave; offWe = its mask, offMask = floats per wave)
     int hasRes;
     int noExpand;      // DepthwiseConv2D -> Conv2D 1x1 without an expand layer in front (MobileNetV2's first block): the 'hidden' slice is the x tile itself
+    unsigned magicQuads, magicHWd; // ceil(2^32 / d) for d = 4 Cj and HWd: the staging's two divisions as mul-hi (operands < 2^16: exact)
     ActCfg ac1, ac2, ac3, ac4;
 };
 
@@ -115,8 +116,9 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                 v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
                 lo[r] = -1;
                 if (e < total) {
-                    const int hp = e / quads, q = e - hp * quads;
-                    const int hy = hp / p.HWd, hx = hp - hy * p.HWd;
+                    // (divisions by run-time values are ~25 instructions each: two per element made this staging a quarter of the wave's VALU work)
+                    const int hp = static_cast<int>(__umulhi(static_cast<unsigned>(e), p.magicQuads)), q = e - hp * quads;
+                    const int hy = static_cast<int>(__umulhi(static_cast<unsigned>(hp), p.magicHWd)), hx = hp - hy * p.HWd;
                     const int iy = hy0 + hy, ix = hx0 + hx;
                     const bool in = hp < p.HP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                     if (in && q < cq) v[r] = *reinterpret_cast<const float4*>(x + ((static_cast<size_t>(img) * p.H + iy) * p.W + ix) * p.C + 4 * q);
@@ -360,6 +362,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     IrbParams p = {};
     p.N = ge.N; p.H = ge.H; p.W = ge.W; p.C = C; p.Ch = Ch; p.Co = Co; p.OH = gd.OH; p.OW = gd.OW; p.s = s; p.padx = gd.padx; p.pady = gd.pady;
     p.Cj = up_div(C, 16);
+    p.magicQuads = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(4 * p.Cj) - 1) / static_cast<unsigned>(4 * p.Cj));
     p.NCB = up_div(Co, 16);
     // tile per wave: 2 pixel groups (4x8) for stride 1, 1 (2x8) for stride 2 -- measured (tools/gpu_irb.sh): the small tiles' occupancy beats their extra
     // halo work; a smaller tile when the per-wave LDS would leave fewer than 4 waves on a CU.  SNNHIP_IRB_WAVE_G=1|2|4 pins it (tests).
@@ -372,6 +375,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         p.TWs = 3;
         p.HH = (TH - 1) * s + 3;
         p.HWd = (TWv - 1) * s + 3;
+        p.magicHWd = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(p.HWd) - 1) / static_cast<unsigned>(p.HWd));
         p.HP = p.HH * p.HWd;
         p.MT = up_div(p.HP, 16);
         p.tilesX = up_div(p.OW, TWv);

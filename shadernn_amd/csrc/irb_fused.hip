@@ -173,21 +173,27 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0.w, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1.w, acc1, 0, 0, 0);
                     }
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f sc01 = {sc.x, sc.y}, sc23 = {sc.z, sc.w}, sh01 = {sh.x, sh.y}, sh23 = {sh.z, sh.w};
                 float4 h;
-                h.x = irb_act<R6>(p.ac1, fmaf(sc.x, acc0[0], sh.x));
-                h.y = irb_act<R6>(p.ac1, fmaf(sc.y, acc0[1], sh.y));
-                h.z = irb_act<R6>(p.ac1, fmaf(sc.z, acc0[2], sh.z));
-                h.w = irb_act<R6>(p.ac1, fmaf(sc.w, acc0[3], sh.w));
+                {
+                    const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
+                    h.x = irb_act<R6>(p.ac1, u01[0]);
+                    h.y = irb_act<R6>(p.ac1, u01[1]);
+                    h.z = irb_act<R6>(p.ac1, u23[0]);
+                    h.w = irb_act<R6>(p.ac1, u23[1]);
+                }
                 if (border) {
                     const float m0 = msk[px0];
                     h.x *= m0; h.y *= m0; h.z *= m0; h.w *= m0;
                 }
                 *reinterpret_cast<float4*>(hs + k * p.hPlane + px0 * 4) = h;
                 if (two) {
-                    h.x = irb_act<R6>(p.ac1, fmaf(sc.x, acc1[0], sh.x));
-                    h.y = irb_act<R6>(p.ac1, fmaf(sc.y, acc1[1], sh.y));
-                    h.z = irb_act<R6>(p.ac1, fmaf(sc.z, acc1[2], sh.z));
-                    h.w = irb_act<R6>(p.ac1, fmaf(sc.w, acc1[3], sh.w));
+                    const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);
+                    h.x = irb_act<R6>(p.ac1, u01[0]);
+                    h.y = irb_act<R6>(p.ac1, u01[1]);
+                    h.z = irb_act<R6>(p.ac1, u23[0]);
+                    h.w = irb_act<R6>(p.ac1, u23[1]);
                     if (border) {
                         const float m1 = msk[px1];
                         h.x *= m1; h.y *= m1; h.z *= m1; h.w *= m1;
@@ -207,22 +213,24 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
             float4 dv[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                // the 36 tap FMAs as 18 v_pk_fma_f32 (two channels per instruction: the kernel is bound by VALU issue, and the packed form retires two
+                // FMAs per lane in one slot); same products and the same per-channel summation order as the scalar form
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
                 for (int fy = 0; fy < 3; ++fy)
 #pragma unroll
                     for (int fx = 0; fx < 3; ++fx) {
                         const float4 h = *reinterpret_cast<const float4*>(hb + (hp0[g] + fy * p.HWd + fx) * 4);
                         const float4 w = wd[fy * 3 + fx];
-                        s4.x = fmaf(h.x, w.x, s4.x);
-                        s4.y = fmaf(h.y, w.y, s4.y);
-                        s4.z = fmaf(h.z, w.z, s4.z);
-                        s4.w = fmaf(h.w, w.w, s4.w);
+                        s01 = __builtin_elementwise_fma(v2f{h.x, h.y}, v2f{w.x, w.y}, s01);
+                        s23 = __builtin_elementwise_fma(v2f{h.z, h.w}, v2f{w.z, w.w}, s23);
                     }
-                dv[g].x = irb_act<R6>(p.ac2, fmaf(sc.x, s4.x, sh.x));
-                dv[g].y = irb_act<R6>(p.ac2, fmaf(sc.y, s4.y, sh.y));
-                dv[g].z = irb_act<R6>(p.ac2, fmaf(sc.z, s4.z, sh.z));
-                dv[g].w = irb_act<R6>(p.ac2, fmaf(sc.w, s4.w, sh.w));
+                const v2f t01 = __builtin_elementwise_fma(v2f{sc.x, sc.y}, s01, v2f{sh.x, sh.y}), t23 = __builtin_elementwise_fma(v2f{sc.z, sc.w}, s23, v2f{sh.z, sh.w});
+                dv[g].x = irb_act<R6>(p.ac2, t01[0]);
+                dv[g].y = irb_act<R6>(p.ac2, t01[1]);
+                dv[g].z = irb_act<R6>(p.ac2, t23[0]);
+                dv[g].w = irb_act<R6>(p.ac2, t23[1]);
             }
 #pragma unroll
             for (int cb = 0; cb < NCBT; ++cb)

@@ -289,6 +289,52 @@ def csrc_fingerprint():
     return fingerprint.csrc_sha16()
 
 
+def _template_ints(name):
+    """integer template arguments of a kernel symbol, mangled (`...ILi4ELi1E...`) or demangled (`...<4, 1, ...>`)"""
+    import re
+
+    if name.startswith("_Z"):
+        return [int(v) for v in re.findall(r"Li(\d+)E", name)]
+    m = re.search(r"<([^>]*)>", name)
+    return [int(v) for v in re.findall(r"\b\d+\b", m.group(1))] if m else []
+
+
+def pmc_entry(pmc, desc, tags):
+    """The PMC record (profiles/pmc_latest.json, keyed by kernel function) of the launch a plan description stands for: the `kernel=` tag of the
+    description, its first word, or -- for the convolution kernels whose symbols differ from their description -- the function name plus the
+    template arguments the description implies."""
+    import re
+
+    key = tags.get("kernel", desc.split(" ")[0])
+    if key in pmc:
+        return pmc[key]
+    core = desc.split(" -> ")[-1] if "instancenorm(" in desc.split(" ")[0] else desc  # (a norm folded in front of a convolution: the convolution's launch)
+    m = re.search(r"k=(\d+)x\d+ s=(\d+) ic=(\d+) oc=(\d+)", core)
+    want = None
+    if "conv2d_mfma_wide_f16" in core and m:
+        wm = 2 if "tile=8x32px" in core else 4
+        nt = int(re.search(r"\(4x(\d) MFMA tiles", core).group(1))
+        c8 = int(re.search(r"chunk=(\d+)", core).group(1)) // 16
+        want = ("conv2d_wide_kernel", [wm, 4 // wm, nt, c8])
+    elif "conv2d_mfma_stem_f16" in core:
+        want = ("conv2d_stem_kernel", [])
+    elif "conv2d_mfma_stem_f32" in core and m:
+        want = ("conv2d_stem32_kernel", [int(m.group(1)), int(m.group(2))])
+    elif "conv2d_rowfold" in core and m:
+        want = ("conv2d_rowfold_kernel", [int(m.group(1)), int(m.group(3)) // 16])
+    elif "conv2d_mfma_wino" in core:
+        want = ("conv2d_wino_kernel", [])
+    if not want:
+        return None
+    for k, v in pmc.items():
+        if want[0] in k and (k.startswith("_Z") or "<" in k) and _template_ints(k)[: len(want[1])] == want[1]:
+            return v
+    for k, v in pmc.items():  # (a key without template arguments: every instantiation of the function in one record)
+        if k == want[0]:
+            return v
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -464,7 +510,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")  # written by tools/profile_gpu.sh -> summarize_prof.py, keyed by kernel function
             if os.path.exists(pmc):
                 try:
-                    ent = json.load(open(pmc)).get(tags.get("kernel", dom["kernel"].split(" ")[0]), None)
+                    ent = pmc_entry(json.load(open(pmc)), dom["kernel"], tags)
                     if ent is not None:
                         if ent.get("csrc_sha16") == csrc_fingerprint():
                             traffic = ent.get("hbm_bytes_per_launch")

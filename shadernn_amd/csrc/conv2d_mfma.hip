@@ -323,6 +323,8 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     p.normAc = make_act_cfg(preNorm ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
     p.normTabOfs = static_cast<int>(ldsNeed / 4);
     if (preNorm) ldsNeed += static_cast<size_t>(2) * g.IC * sizeof(float); // [shift | mul] behind the staging buffers
+    p.coordTabOfs = static_cast<int>(ldsNeed / 4);
+    ldsNeed += static_cast<size_t>(p.tileH + p.tileW) * sizeof(int); // the staging's row / column tables
     if (p.ldsEpi) ldsNeed = std::max(ldsNeed, static_cast<size_t>(128) * (BN + 8) * 2);
     const bool simple = act_is_simple(g.act);
     KernelFn fn = nullptr;

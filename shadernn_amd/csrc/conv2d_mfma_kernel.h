@@ -49,6 +49,7 @@ struct MfmaParams { // (declared after ActCfg: epilogue.h)
     const float* normMul;
     ActCfg normAc;
     int normTabOfs; // float offset in LDS of [shift | mul] x IC of the tile's image
+    int coordTabOfs; // float offset in LDS of the staging's row / column tables (tileH + tileW ints)
 };
 
 // LDS layout of the staged activations.  A pixel owns ICc floats = ICc/4 16-byte slots; the slot is XOR-swizzled with
@@ -109,6 +110,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
     const int taps = p.kh * p.kw;
     const bool vec4 = (p.IC % CH) == 0;
 
+    // ---- the source pixel of a staged pixel is separable (its row depends on the tile row only, its column on the tile column only): padding /
+    // fused Pad / fused UpSampling are resolved once per tile row and column into two LDS tables, an element below is two look-ups (resolved per
+    // element it was ~60 of the ~100 instructions an element costs, x R elements, in blocks whose waves run 36-72 MFMAs)
+    int* const syTab = reinterpret_cast<int*>(smem + p.coordTabOfs); // [tileH] first pixel of the source row (row * srcW), -1 = outside (zeros)
+    int* const sxTab = syTab + p.tileH;                               // [tileW] source column, -1 = outside
+    for (int i = tid; i < p.tileH + p.tileW; i += 256) {
+        const bool isRow = i < p.tileH;
+        int s1 = resolve_nobranch(isRow ? iy0 + i : ix0 + (i - p.tileH), isRow ? p.H : p.W, p.padMode);
+        if (p.preMode) { // (uniform) a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied; -1 stays -1
+            const int pp = resolve_nobranch(s1 - (isRow ? p.preY : p.preX), (isRow ? p.srcH : p.srcW) << p.preShift, p.preMode);
+            s1 = s1 < 0 ? -1 : (pp < 0 ? -1 : pp >> p.preShift); // nearest x2: upsampled pixel (y, x) is source pixel (y / 2, x / 2) (vk_upsampling2d_nearest.comp:50-65)
+        }
+        syTab[i] = (isRow && s1 >= 0) ? s1 * p.srcW : s1;
+    }
+    __syncthreads();
+
     // ---- staging descriptors: element e = tid + 256 r -> (pixel of the halo tile, channel quad q); q is the same for all r
     const int q = tid & (Q - 1);
     int gofs[R], lofs[R];
@@ -124,17 +141,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(MfmaParams p, ActCf
             const int c = pix - t2 * p.tileW;
             const int b = p.tileH == 1 ? t2 : static_cast<int>(__umulhi(static_cast<unsigned>(t2), p.magicH));
             const int rr = t2 - b * p.tileH;
-            int sy = resolve_nobranch(iy0 + rr, p.H, p.padMode);
-            int sx = resolve_nobranch(ix0 + c, p.W, p.padMode);
-            if (p.preMode) { // (uniform) a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied; -1 stays -1
-                const int py = resolve_nobranch(sy - p.preY, p.srcH << p.preShift, p.preMode), px = resolve_nobranch(sx - p.preX, p.srcW << p.preShift, p.preMode);
-                sy = sy < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift); // nearest x2: upsampled pixel (y, x) is source pixel (y / 2, x / 2) (vk_upsampling2d_nearest.comp:50-65)
-                sx = sx < 0 ? -1 : (px < 0 ? -1 : px >> p.preShift);
-            }
+            const int rowPix = syTab[rr], sx = sxTab[c];
             const int n = b0 + b;
             const int cm = p.evenCols ? (c & 1) * p.evenCols + (c >> 1) : c;
             lofs[r] = lds_off<C8>(b * p.imgPitch + rr * p.rowPitch + cm, q);
-            if (sy >= 0 && sx >= 0 && n < p.N) gofs[r] = ((n * p.srcH + sy) * p.srcW + sx) * p.IC + q * CH;
+            if (rowPix >= 0 && sx >= 0 && n < p.N) gofs[r] = (n * p.srcH * p.srcW + rowPix + sx) * p.IC + q * CH;
         }
     }
     float4 stage[R];

@@ -243,7 +243,8 @@ def test_stem32_matches_oracle_and_tap_pair_kernel(ctx, monkeypatch, shape):
 
 
 @pytest.mark.parametrize("kernel_fold", [True, False], ids=["kernel-fold", "fold-launches"])
-@pytest.mark.parametrize("n,h,w,ic,oc,offset", [(2, 19, 45, 32, 128, 0.0), (1, 37, 70, 64, 64, 6.0), (3, 9, 33, 16, 32, 0.0), (1, 16, 64, 128, 128, 40.0), (2, 70, 300, 16, 32, 0.0)])
+@pytest.mark.parametrize("n,h,w,ic,oc,offset", [(2, 19, 45, 32, 128, 0.0), (1, 37, 70, 64, 64, 6.0), (3, 9, 33, 16, 32, 0.0), (1, 16, 64, 128, 128, 40.0), (2, 70, 300, 16, 32, 0.0),
+                                                (2, 12, 40, 32, 256, 0.0), (2, 21, 37, 16, 96, 0.0)])  # (the last two: several output-channel blocks per pixel tile)
 def test_wide_tile_stats_feed_instancenorm(ctx, monkeypatch, n, h, w, ic, oc, offset, kernel_fold):
     """Chain rule F on the wide kernel (the default there): reflect Pad -> Conv2D -> InstanceNorm as ONE step -- the convolution's epilogue leaves
     {mean, M2} of every output tile and channel, a fold over those records replaces the norm's statistics sweep.  Ragged tile edges in both

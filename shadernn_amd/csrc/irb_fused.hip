@@ -491,8 +491,19 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     char head[64];
     if (noExpand) snprintf(head, sizeof(head), "depthwise3x3 %d s%d", Ch, s);
     else snprintf(head, sizeof(head), "conv1x1 %d->%d + depthwise3x3 s%d", C, Ch, s);
-    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [%s + conv1x1 %d->%d%s] tile=%dx8px per wave, halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_wave_kernel",
-             head, Ch, Co, addPlan ? " + add" : "", 2 * G, p.HH, p.HWd, p.nChunks, plan->threads, lds, fusedBytes);
+    // the instantiation pick_irb_wave chose, for the profile look-up (bench.py matches the PMC record of exactly this kernel)
+    int vNcb = 0, vCj = 0;
+    {
+        static const int kVariants[][2] = {{2, 1}, {2, 2}, {4, 2}, {4, 4}, {6, 4}, {6, 6}, {10, 6}, {10, 10}, {20, 10}};
+        for (const auto& v : kVariants)
+            if (p.NCB <= v[0] && p.Cj <= v[1]) {
+                vNcb = v[0];
+                vCj = v[1];
+                break;
+            }
+    }
+    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [%s + conv1x1 %d->%d%s] tile=%dx8px per wave, halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_wave_kernel<%d,%d,%d,%s>",
+             head, Ch, Co, addPlan ? " + add" : "", 2 * G, p.HH, p.HWd, p.nChunks, plan->threads, lds, fusedBytes, G, vNcb, vCj, r6 ? "true" : "false");
     plan->desc = buf;
     if (r6) plan->desc += " relu6-epilogues";
     *out = plan;

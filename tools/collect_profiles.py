@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Copies what a tools/gpu_final.sh run left under gpurun_out/ into profiles/ (tracked): the rocprofv3 summaries of the c2 / c3 / c5 bench commands, the
+"""Copies what a tools/gpu_final.sh run left under gpurun_out/ into profiles/ (tracked): the rocprofv3 summaries of the c2 / c3 / c4 / c5 bench commands, the
 merged per-kernel PMC traffic file bench.py reads (profiles/pmc_latest.json, keyed to the kernel-source fingerprint) and one bench line per config.
 
     python tools/collect_profiles.py r02z [--round r02]
@@ -18,7 +18,8 @@ def main():
     ap.add_argument("--round", default="r02")
     a = ap.parse_args()
     out, prof = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-    names = {"c2": "%s_c2_rocprofv3_summary.md", "c3": "%s_c3_resnet18_rocprofv3_summary.md", "c5": "%s_c5_candy_fp16_rocprofv3_summary.md"}
+    names = {"c2": "%s_c2_rocprofv3_summary.md", "c3": "%s_c3_resnet18_rocprofv3_summary.md", "c4": "%s_c4_mobilenetv2_rocprofv3_summary.md",
+             "c5": "%s_c5_candy_fp16_rocprofv3_summary.md"}
     pmc = {}
     for c, fmt in names.items():
         d = os.path.join(out, "%s_%s" % (a.tag, c))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# End-of-round run on the GPU box: the whole -m gpu suite, rocprofv3 kernel trace + PMC passes of the c2 / c3 / c5 bench commands (profiles/),
+# End-of-round run on the GPU box: the whole -m gpu suite, rocprofv3 kernel trace + PMC passes of the c2 / c3 / c4 / c5 bench commands (profiles/),
 # and one bench line per BASELINE config.   usage (via gpurun): tools/gpu_final.sh <tag>
 cd $GRAFT_REPO_ROOT
 TAG=${1:-final}
@@ -11,6 +11,7 @@ tail -4 $O/pytest.txt
 timeout 900 tools/profile_gpu.sh ${TAG}_c2 > $O/profile_c2.log 2>&1
 grep "derived" -A6 $O/profile_c2.log | cut -c1-260
 PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --config c3 --no-cpu-baseline --steps 10 --warmup 2 --preheat-ms 20" timeout 900 tools/profile_gpu.sh ${TAG}_c3 > $O/profile_c3.log 2>&1
+PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --config c4 --no-cpu-baseline --steps 4 --warmup 1 --preheat-ms 20" timeout 900 tools/profile_gpu.sh ${TAG}_c4 > $O/profile_c4.log 2>&1
 PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --config c5 --no-cpu-baseline --steps 2 --warmup 1 --preheat-ms 20" timeout 1200 tools/profile_gpu.sh ${TAG}_c5 > $O/profile_c5.log 2>&1
 grep "derived" -A40 $O/profile_c5.log | cut -c1-220 | head -24
 timeout 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err

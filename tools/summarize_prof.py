@@ -92,11 +92,15 @@ def main():
     for k, d in res["kernels"].items():
         if "hbm_read_bytes_corrected_x2" in d and "hbm_write_bytes" in d:
             base = k.split("<")[0].strip()
-            pmc[base] = {"hbm_bytes_per_launch": d["hbm_read_bytes_corrected_x2"] + d["hbm_write_bytes"],
+            rec = {"hbm_bytes_per_launch": d["hbm_read_bytes_corrected_x2"] + d["hbm_write_bytes"],
                          "read_bytes_x2_corrected": d["hbm_read_bytes_corrected_x2"], "write_bytes": d["hbm_write_bytes"],
                          "csrc_sha16": sha, "git_head": head, "avg_us_kernel_trace": d.get("avg_us"), "mfma_pipe_util": d.get("mfma_pipe_util"), "eff_clock_ghz": d.get("eff_clock_ghz"),
                          "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_gpu.sh); FETCH_SIZE KiB x2 "
                                    "per MI355X_MICROARCH.md HBM section"}
+            # one record per INSTANTIATION (`name<args>`, blanks removed: the key a plan description's `kernel=` tag can name exactly), and the bare
+            # function name for the first one seen (kernels with a single instantiation in the profiled command)
+            pmc[k.replace(" ", "")] = rec
+            pmc.setdefault(base, rec)
     json.dump(pmc, open(os.path.join(out, "pmc_by_kernel.json"), "w"), indent=1)
 
 

@@ -329,10 +329,9 @@ def pmc_entry(pmc, desc, tags):
     for k, v in pmc.items():
         if want[0] in k and (k.startswith("_Z") or "<" in k) and _template_ints(k)[: len(want[1])] == want[1]:
             return v
-    for k, v in pmc.items():  # (a key without template arguments: every instantiation of the function in one record)
-        if k == want[0]:
-            return v
-    return None
+    if any(want[0] in k and (k.startswith("_Z") or "<" in k) for k in pmc):
+        return None  # the profile holds other instantiations of this function only: their traffic is not this launch's
+    return pmc.get(want[0])  # (a file keyed by bare function names)
 
 
 def main():

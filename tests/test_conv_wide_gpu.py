@@ -438,3 +438,60 @@ def test_wide_residual_block_is_two_convolutions_and_one_sweep(ctx, monkeypatch)
     np.testing.assert_array_equal(tail([t0, t0]).numpy(), y)
     two = add([norm2(conv2(pad2(norm1(conv1(pad1(t0)))))), t0]).numpy()
     np.testing.assert_allclose(y, two, rtol=4e-3, atol=4e-3, err_msg=d)
+
+
+def _style_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        c = int(rng.choice([32, 64, 96, 128]))  # (both layers on the wide kernel: IC % 16 == 0, OC % 32 == 0)
+        c2 = int(rng.choice([32, 64, 96, 128]))
+        out.append((int(rng.choice([1, 2, 3])), int(rng.integers(6, 40)), int(rng.integers(6, 75)), c, c2, str(rng.choice(["relu", "", "leakyRelu", "relu6"])),
+                    str(rng.choice(["reflect", "replicate", "constant"])), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("case", _style_cases(16, 20260928), ids=lambda c: "n%d_%dx%d_%d-%d_%s_%s_add%d_fold%d" % c[:9])
+def test_wide_random_style_runs_match_the_separate_launches(ctx, monkeypatch, case):
+    """Randomised (fixed seed) runs of the style networks' building block on the wide kernel, X -> Pad -> Conv 3x3 -> InstanceNorm(act) -> Pad -> Conv
+    3x3 -> InstanceNorm [-> Add(., X)], offered to the graph walk: whatever mix of rules D / F / H / I the planner applies to the shape (tile
+    statistics with the kernel's own fold or with fold launches, the norm fixed up in LDS, the Add in the norm's sweep), the result is the separate
+    launches' -- bit-identical where only D / H / I apply, within fp16 rounding of the statistics where rule F supplies them."""
+    import shadernn_amd as snn
+
+    n, h, w, c, c2, act, pad_mode, with_add, kernel_fold, seed = case
+    monkeypatch.setenv("SNNHIP_CONV", "wide")
+    monkeypatch.setenv("SNNHIP_NORM_FUSION_MIN_MB", "0")
+    if not kernel_fold:
+        monkeypatch.setenv("SNNHIP_NO_KERNEL_FOLD", "1")
+    x = _rand((n, h, w, c), seed)
+    w1, b1 = _rand((c2, c, 3, 3), seed + 1, 1.0 / np.sqrt(c * 9)), _rand((c2,), seed + 2, 0.5)
+    w2, b2 = _rand((c, c2, 3, 3), seed + 3, 1.0 / np.sqrt(c2 * 9)), _rand((c,), seed + 4, 0.5)
+    be1, ga1, be2, ga2 = _rand((c2,), seed + 5, 0.3), 1.0 + _rand((c2,), seed + 6, 0.2), _rand((c,), seed + 7, 0.3), 1.0 + _rand((c,), seed + 8, 0.2)
+    pre = snn.activation_plan(ctx, n, h, w, c, "tanh")
+    pad1 = snn.pad_plan(ctx, n, h, w, c, (1, 1, 1, 1), pad_mode)
+    conv1 = snn.conv2d_plan(ctx, n, h + 2, w + 2, w1, b1, stride=1, pads=(0, 0, 0, 0), act="", dtype=snn.F16)
+    h1, w1_ = conv1.out_shape()[1:3]
+    norm1 = snn.instancenorm_plan(ctx, n, h1, w1_, c2, be1, ga1, act=act, leaky=0.1)
+    pad2 = snn.pad_plan(ctx, n, h1, w1_, c2, (1, 1, 1, 1), pad_mode)
+    conv2 = snn.conv2d_plan(ctx, n, h1 + 2, w1_ + 2, w2, b2, stride=1, pads=(0, 0, 0, 0), act="", dtype=snn.F16)
+    h2, w2_ = conv2.out_shape()[1:3]
+    norm2 = snn.instancenorm_plan(ctx, n, h2, w2_, c, be2, ga2, act="")
+    nodes = [(pre, [-1], False), (pad1, [0], False), (conv1, [1], False), (norm1, [2], False), (pad2, [3], False), (conv2, [4], False), (norm2, [5], not with_add)]
+    if with_add:
+        add = snn.add_plan(ctx, n, h2, w2_, c, act="")
+        nodes.append((add, [6, 0], True))
+    fused = snn.graph_fuse(ctx, nodes)
+    last = len(nodes) - 1
+    tail, ins = fused[last]
+    d = tail.describe()
+    assert all(p is None for p, _ in fused[1:last]) and "conv2d_mfma_wide_f16" in d and "tile-stats" in d, d
+    assert (fused[0][0] is None) == (not with_add)  # without the Add nobody else reads the block input: its producer joins the run
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    t0 = pre(xt)
+    y = (tail([t0, t0]) if with_add else tail(xt)).numpy()
+    ref = norm2(conv2(pad2(norm1(conv1(pad1(t0))))))
+    if with_add:
+        ref = add([ref, t0])
+    np.testing.assert_allclose(y, ref.numpy(), rtol=6e-3, atol=6e-3, err_msg=d)
+    assert np.isfinite(y).all()

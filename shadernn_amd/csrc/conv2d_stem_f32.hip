@@ -26,14 +26,14 @@ struct Stem32Params {
     int tilesX, tilesY;
 };
 
-constexpr int kNR = 4;                  // output rows per wave
-constexpr int kTH = 4 * kNR, kTW = 32;  // block tile: 4 waves stacked in y
+constexpr int kTW = 32;                 // block tile: 4 waves stacked in y, NR output rows per wave (4; 2 on grids that leave CUs idle: half the latency)
 constexpr int kOutPitch = 36;           // floats per pixel row of a wave's output scratch (32 + 4: 16-byte aligned, the runs of 8 lanes on distinct banks)
 
 
-template <int K, int S, bool SIMPLE>
+template <int K, int S, int kNR, bool SIMPLE>
 __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem32Params p, ActCfg ac, const float* __restrict__ x, const float* __restrict__ wp,
                                                             const float4* __restrict__ epi, float* __restrict__ y) {
+    constexpr int kTH = 4 * kNR;
     constexpr int IN_H = (kTH - 1) * S + K, IN_W = (kTW - 1) * S + K; // staged halo tile
     constexpr int ROWS = (kNR - 1) * S + K;                           // input rows a wave touches
     constexpr int NW = 2 * K * K;                                     // weight registers per lane
@@ -155,8 +155,9 @@ struct Stem32Plan : ConvPlanBase {
 };
 
 template <int K, int S>
-Stem32Fn pick_stem32(bool simple) {
-    return simple ? conv2d_stem32_kernel<K, S, true> : conv2d_stem32_kernel<K, S, false>;
+Stem32Fn pick_stem32(bool simple, int nr) {
+    if (nr == 2) return simple ? conv2d_stem32_kernel<K, S, 2, true> : conv2d_stem32_kernel<K, S, 2, false>;
+    return simple ? conv2d_stem32_kernel<K, S, 4, true> : conv2d_stem32_kernel<K, S, 4, false>;
 }
 
 } // namespace
@@ -173,9 +174,16 @@ int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     const bool simple = act_is_simple(g.act);
     Stem32Fn fn = nullptr;
     int K = g.kh, S = g.sh;
-    if (K == 3 && S == 1) fn = pick_stem32<3, 1>(simple);
-    if (K == 3 && S == 2) fn = pick_stem32<3, 2>(simple);
-    if (K == 7 && S == 2) fn = pick_stem32<7, 2>(simple);
+    // 16-row tiles (4 rows per wave) unless they leave the chip under-filled: a single 224x224 image is 196 blocks on 256 CUs and the launch takes one
+    // block's latency -- with 8-row tiles it is 392 blocks of half the work (BASELINE configs[0]: 8.5 -> 6 us)
+    const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+    const long blocks16 = static_cast<long>(g.N) * up_div(g.OH, 16) * up_div(g.OW, kTW) * (g.OC / 32);
+    int NR = blocks16 < 2L * cus ? 2 : 4;
+    if (const char* e = snnhip::option("SNNHIP_STEM_ROWS")) NR = atoi(e) == 2 ? 2 : 4;
+    const int kTH = 4 * NR;
+    if (K == 3 && S == 1) fn = pick_stem32<3, 1>(simple, NR);
+    if (K == 3 && S == 2) fn = pick_stem32<3, 2>(simple, NR);
+    if (K == 7 && S == 2) fn = pick_stem32<7, 2>(simple, NR);
     if (!fn) return SNNHIP_E_UNSUPPORTED;
     if (static_cast<double>(g.N) * g.OH * g.OW * g.OC >= 2147483647.0 * 2) return SNNHIP_E_UNSUPPORTED;
 

@@ -209,10 +209,12 @@ STEM32 = [(1, 224, 224, 3, 64, 3, 1), (2, 64, 64, 3, 32, 3, 2), (2, 75, 61, 3, 6
           (1, 17, 130, 2, 64, 3, 1)]
 
 
+@pytest.mark.parametrize("rows", [4, 2], ids=["16-row-tiles", "8-row-tiles"])
 @pytest.mark.parametrize("shape", STEM32, ids=lambda c: "x".join(map(str, c)))
-def test_stem32_matches_oracle_and_tap_pair_kernel(ctx, monkeypatch, shape):
+def test_stem32_matches_oracle_and_tap_pair_kernel(ctx, monkeypatch, shape, rows):
     import shadernn_amd as snn
 
+    monkeypatch.setenv("SNNHIP_STEM_ROWS", str(rows))  # (default: 8-row tiles on grids below two blocks per CU, 16-row tiles otherwise)
     N, H, W, IC, OC, k, s = shape
     x = _rand((N, H, W, IC), 41)
     w = _rand((OC, IC, k, k), 42, 1.0 / np.sqrt(IC * k * k))
@@ -232,7 +234,7 @@ def test_stem32_matches_oracle_and_tap_pair_kernel(ctx, monkeypatch, shape):
             continue
         monkeypatch.delenv("SNNHIP_CONV_STEM", raising=False)
         y, desc = run(pad_mode, act, bn if use_bn else None)
-        assert "conv2d_mfma_stem_f32" in desc, desc
+        assert "conv2d_mfma_stem_f32" in desc and "tile=%dx32px" % (4 * rows) in desc, desc
         want = O.conv2d(x, w, b, s, pads, pad_mode, act, 0.0, bn if use_bn else None)
         assert y.shape == want.shape
         np.testing.assert_allclose(y, want, err_msg=desc, **tol)

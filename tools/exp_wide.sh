@@ -1,6 +1,6 @@
 #!/bin/bash
 # Experiment builds of conv2d_wide_f16.hip into build/abl/libsnnhip_<tag>.so for same-box A/B runs (SNNHIP_LIB_PATH=...).
-#   usage: tools/exp_wide.sh tag1:-DSNNHIP_WIDE_EXP=1 tag2:-DSNNHIP_WIDE_ABL=4 ...
+#   usage: tools/exp_wide.sh a4:-DSNNHIP_WIDE_ABL=4 a15:-DSNNHIP_WIDE_ABL=15 mine:-DMY_EXPERIMENT=1 ...   (one library per tag:flags pair)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/abl

@@ -163,3 +163,41 @@ def test_bench_self_spawns_ranks_from_a_plain_shell():
     elif not torch.cuda.is_available():
         assert r.returncode != 0
         assert r.stderr.count("no GPU visible") >= 2, r.stderr[-2000:]
+
+
+def test_bench_pmc_lookup_names_the_exact_instantiation():
+    """bench.py's `roofline.traffic` comes from profiles/pmc_latest.json: the record must be the one of the kernel INSTANTIATION a plan description stands
+    for -- never another instantiation of the same function (its traffic is another layer's)."""
+    import json
+
+    import bench
+    from shadernn_amd import fingerprint
+
+    pmc = {
+        "_ZN6snnhip12_GLOBAL__N_118conv2d_wide_kernelILi2ELi2ELi2ELi2ELi7ELb1ELb0EEEvNS0_10WideParamsE": {"hbm_bytes_per_launch": 1.0},
+        "_ZN6snnhip12_GLOBAL__N_118conv2d_wide_kernelILi4ELi1ELi1ELi1ELi8ELb1ELb0EEEvNS0_10WideParamsE": {"hbm_bytes_per_launch": 2.0},
+        "conv2d_stem32_kernel<7,2,4,true>": {"hbm_bytes_per_launch": 3.0},
+        "irb_wave_kernel<1,2,1,true>": {"hbm_bytes_per_launch": 4.0},
+        "irb_wave_kernel": {"hbm_bytes_per_launch": 4.0},
+        "conv_kxk_c1o16_wino3x3_c16o16_kernel": {"hbm_bytes_per_launch": 5.0},
+    }
+
+    def look(desc):
+        tags = dict(tk.split("=", 1) for tk in desc.split(" ") if "=" in tk and not tk.startswith("tile"))
+        e = bench.pmc_entry(pmc, desc, tags)
+        return None if e is None else e["hbm_bytes_per_launch"]
+
+    wide = "conv2d_mfma_wide_f16_32x32x16 k=3x3 s=1 ic=%d oc=%d tile=%s x %doc (4x%d MFMA tiles per wave) chunk=%d lds=1B"
+    assert look(wide % (128, 128, "8x32px", 128, 2, 32)) == 1.0
+    assert look(wide % (64, 32, "16x32px", 32, 1, 16)) == 2.0
+    assert look("instancenorm(statistics from the convolution in front) -> instancenorm(act=1, in LDS behind the DMA) -> " + wide % (128, 128, "8x32px", 128, 2, 32)) == 1.0
+    assert look(wide % (128, 64, "16x32px", 64, 2, 16)) is None          # 4 x 1 x 2: not in this profile
+    assert look("conv2d_mfma_stem_f32_32x32x2 k=7x7 s=2 ic=3 oc=64 tile=16x32px x 32oc") == 3.0
+    assert look("conv2d_mfma_stem_f32_32x32x2 k=3x3 s=1 ic=3 oc=64 tile=8x32px x 32oc") is None  # another instantiation of the same function
+    assert look("irb_fused_mfma_f32_16x16x4 [...] tile=2x8px per wave, hbm_bytes=1 kernel=irb_wave_kernel<1,2,1,true>") == 4.0
+    assert look("fused[conv5x5(1->16)+conv3x3(16->16)] mfma_f32_16x16x4 tile=32x16 kernel=conv_kxk_c1o16_wino3x3_c16o16_kernel mfma_flops=1") == 5.0
+    # the committed file: one source fingerprint per record (bench.py reports `traffic` only when it equals the fingerprint of the sources it runs,
+    # and says "stale" otherwise -- a kernel edit does not turn this test red, it turns the bench field to null until the profile is re-taken)
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    assert committed and all(len(v.get("csrc_sha16", "")) == 16 and v["hbm_bytes_per_launch"] >= 0 for v in committed.values())
+    assert len(fingerprint.csrc_sha16()) == 16

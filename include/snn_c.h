@@ -38,6 +38,10 @@ int snn_model_batch(snn_model* m);
 int snn_model_destroy(snn_model* m);
 int snn_model_upload_input(snn_model* m, const float* nhwc);      /* [batch x] H x W x C floats */
 int snn_model_run(snn_model* m);                                   /* MixedInferenceCore::run (enqueue + one sync) */
+/* RunParameters::deferSync: enqueue the inference and return; several inferences stay in flight on the model's stream until
+ * snn_model_sync (throughput mode; the reference waits once per inference, core.cpp:203) */
+int snn_model_run_async(snn_model* m);
+int snn_model_sync(snn_model* m);
 int snn_model_output_dims(snn_model* m, int hwc[3]);
 int snn_model_download_output(snn_model* m, float* nhwc);
 /* SNNModelOutput of the next runs (snn.h ModelType: 0 CLASSIFICATION, 1 DETECTION, 2 SEGMENTATION, 3 OTHER; MixedInferenceCore::run, core.cpp:228-237) */
@@ -77,6 +81,10 @@ int snn_graph_summary(const char* json_path, int in_w, int in_h, int in_c, char*
 
 /* Host-only: YOLOLayer's decode + NMS (yololayer.cpp:114-226) on two NHWC heads of net/32 and net/16 cells x 18 channels */
 int snn_yolo_decode(const float* head_coarse, const float* head_fine, int net_size, float* rows6, int max_rows);
+
+/* Host-only: parse `text` as ONE JSON number with the model loader's own parser (ic2/json.h); returns 0 and the value, -1 if it is not a number.
+ * Test hook for the loader's number grammar (overflow saturates to +-HUGE_VAL, underflow gives +-0 / a denormal, like the reference's strtod). */
+int snn_json_number(const char* text, double* out);
 
 /* ".dump" reader (image.cpp:300-311): returns W,H,D,C and, if out != NULL, the RGBA32F pixels ([D][H][W][4] floats). */
 int snn_dump_read(const char* path, int whdc[4], float* out, long out_floats);

@@ -5,8 +5,10 @@
 
 #include "snnhip_internal.h"
 
+#include <chrono>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 
 namespace snnhip {
@@ -21,7 +23,12 @@ const char* option(const char* name) {
     {
         std::lock_guard<std::mutex> lock(g_optMutex);
         auto it = opt_map().find(name);
-        if (it != opt_map().end()) return it->second.c_str(); // (stable until the same name is set again)
+        if (it != opt_map().end()) {
+            // the pointer crosses the C ABI (snnhip_get_option) and outlives the lock: hand out an interned, never-freed copy so a concurrent
+            // snnhip_set_option of the same name cannot leave the caller with a dangling pointer
+            static std::set<std::string> interned;
+            return interned.insert(it->second).first->c_str();
+        }
     }
     return getenv(name);
 }
@@ -209,6 +216,19 @@ void* snnhip_ctx_stream(snnhip_ctx* ctx) { return ctx ? ctx->stream : nullptr; }
 
 int snnhip_sync(snnhip_ctx* ctx) {
     SNNHIP_REQUIRE(ctx, "sync: null ctx");
+    // An inference of the headline config is ~0.1 ms of stream time: a blocking wait (interrupt + wake-up of the host thread) costs a
+    // tenth of that.  Poll the stream for up to SNNHIP_SYNC_SPIN_US microseconds (default 2000, 0 = block at once) before blocking.
+    const char* spinOpt = snnhip::option("SNNHIP_SYNC_SPIN_US"); // read per call (a map lookup): harnesses switch it between runs
+    const long spinUs = spinOpt ? atol(spinOpt) : 2000L;
+    if (spinUs > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) return SNNHIP_OK;
+            if (q != hipErrorNotReady) SNNHIP_CHECK_HIP(q);
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spinUs) break;
+        }
+    }
     SNNHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return SNNHIP_OK;
 }

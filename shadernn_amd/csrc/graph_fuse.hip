@@ -166,7 +166,7 @@ extern "C" int snnhip_graph_fuse(snnhip_ctx* ctx, const snnhip_graph_node* nodes
             const int rc = make_chain_plan(ctx, run.data(), static_cast<int>(run.size()), &chain);
             if (rc == SNNHIP_OK && chain_adopt_plan(chain, out[tail].plan)) {
                 out[tail].plan = chain;
-                out[tail].inputs[0] = nodes[i].inputs[0];
+                out[tail].inputs[0] = out[i].n_inputs > 0 ? out[i].inputs[0] : nodes[i].inputs[0]; // the CURRENT wiring (rule 0b re-wires a Dense past its Flatten)
                 for (int t = i; t <= j; ++t) {
                     out[t].plan = nullptr;
                     out[t].n_inputs = 0;
@@ -184,10 +184,11 @@ extern "C" int snnhip_graph_fuse(snnhip_ctx* ctx, const snnhip_graph_node* nodes
             snnhip_plan* chain = nullptr;
             const int rc = make_chain_plan(ctx, run.data(), static_cast<int>(run.size()), &chain);
             if (rc == SNNHIP_OK) {
+                const int firstInput = out[i].n_inputs > 0 ? out[i].inputs[0] : nodes[i].inputs[0]; // the CURRENT wiring, read before out[i] is cleared
                 out[j].plan = chain;
                 out[j].owned = 1;
                 out[j].n_inputs = 1;
-                out[j].inputs[0] = nodes[i].inputs[0];
+                out[j].inputs[0] = firstInput;
                 for (int t = i; t < j; ++t) {
                     out[t].plan = nullptr;
                     out[t].n_inputs = 0;

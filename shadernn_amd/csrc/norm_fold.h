@@ -59,6 +59,11 @@ __device__ __forceinline__ void tile_stats_finish(const NormFoldArgs& f, const f
     }
     __syncthreads();
     if (scratch[3 * 512] == 0.0f) return;
+    // The hand-off above is relaxed on purpose (a release in EVERY block would be the L2 write-back described at the top).  What makes the records
+    // visible is that they are written through (sc1 stores, acknowledged before the block is counted) and read with sc1 loads; formally that still
+    // leaves the last block without an acquire.  It gets one here -- ONE agent-scope acquire per image (an invalidate, no write-back): nothing this
+    // block has cached from an earlier launch of the same plan (the records live in the same buffer launch after launch) can satisfy the loads below.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     constexpr int HP = BN / 2, PARTS = 256 / HP, B = 16;
     const int cp = tid % HP, q = tid / HP;
     const float* pn = part + static_cast<size_t>(n) * tiles * 2 * OC + ocb + 2 * cp;

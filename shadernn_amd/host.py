@@ -25,6 +25,8 @@ SIGNATURES = {
     "snn_model_destroy": (C.c_int, [_P]),
     "snn_model_upload_input": (C.c_int, [_P, _FP]),
     "snn_model_run": (C.c_int, [_P]),
+    "snn_model_run_async": (C.c_int, [_P]),
+    "snn_model_sync": (C.c_int, [_P]),
     "snn_model_output_dims": (C.c_int, [_P, C.POINTER(C.c_int * 3)]),
     "snn_model_download_output": (C.c_int, [_P, _FP]),
     "snn_model_set_type": (C.c_int, [_P, C.c_int]),
@@ -40,6 +42,7 @@ SIGNATURES = {
     "snn_conv_test_with_layer": (C.c_int, [C.c_int, _FP, _FP, _FP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _FP, _FP, _FP, _FP,
                                            C.c_char_p, C.c_int]),
     "snn_graph_summary": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "snn_json_number": (C.c_int, [C.c_char_p, C.POINTER(C.c_double)]),
     "snn_dump_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int * 4), _FP, C.c_long]),
 }
 
@@ -72,6 +75,12 @@ def graph_summary(json_path, w, h, c):
                      "inputs": [int(v) for v in ins.split(",") if v]})
     assert len(rows) == n
     return rows
+
+
+def json_number(text):
+    """The model loader's JSON parser on one number literal (None if it refuses it)."""
+    d = C.c_double()
+    return d.value if lib().snn_json_number(text.encode(), C.byref(d)) == 0 else None
 
 
 def read_dump(path):
@@ -137,6 +146,13 @@ class Model:
 
     def run(self):
         assert lib().snn_model_run(self.h) == 0
+
+    def run_async(self):
+        """RunParameters::deferSync: enqueue one inference, no wait (pair with sync())."""
+        assert lib().snn_model_run_async(self.h) == 0
+
+    def sync(self):
+        assert lib().snn_model_sync(self.h) == 0
 
     def output(self):
         d = (C.c_int * 3)()

@@ -150,11 +150,18 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
         if (!backend->endRecord() || !backend->replay()) SNN_RIP("hipGraph capture of the inference failed: %s", snnhip_last_error());
     }
     if (gpuRunTime) gpuRunTime->stop();
-    backend->sync(); // the only GPU wait of an inference (core.cpp:203)
-    backend->postRun(stages, cp.dumpOutputs, outputDir());
+    bool hostStage = false;
     for (auto& s : stages)
-        if (s.timer && !s.layer->isInputLayer) s.timer->getTime();
-    if (gpuRunTime) gpuRunTime->getTime();
+        if (!s.layer->isInputLayer && s.backend != Backend::Backend_GPU) hostStage = true;
+    const bool defer = rp.deferSync && !cp.profiling && !cp.dumpOutputs && !hostStage && rp.modelOutput.modelType != ModelType::CLASSIFICATION &&
+                       rp.modelOutput.modelType != ModelType::DETECTION;
+    if (!defer) backend->sync(); // the only GPU wait of an inference (core.cpp:203)
+    backend->postRun(stages, cp.dumpOutputs, outputDir());
+    if (!defer) {
+        for (auto& s : stages)
+            if (s.timer && !s.layer->isInputLayer) s.timer->getTime();
+        if (gpuRunTime) gpuRunTime->getTime();
+    }
     cpuRunTime.stop();
     if (rp.outputImages && rp.outputImages->size() > 0 && bindOutput) {
         // the reference binds the last stage's texture to the caller's output image (Android path); here the caller's
@@ -173,6 +180,8 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
     }
     backend->cleanupRun();
 }
+
+bool MixedInferenceCore::sync() { return backend->sync(); }
 
 void MixedInferenceCore::writeTimeStat(std::map<std::string, std::vector<double>>& timeArray) { // core.cpp:437-442
     if (gpuRunTime) timeArray[gpuRunTime->getName()].push_back(gpuRunTime->duration() / 1000000.0);

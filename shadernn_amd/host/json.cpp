@@ -163,7 +163,11 @@ struct P {
         }
         double d = 0.0;
         const auto res = std::from_chars(s.data() + i, s.data() + j, d);
-        if (res.ec == std::errc::result_out_of_range) d = (s[i] == '-') ? -HUGE_VAL : HUGE_VAL; // like strtod: overflow saturates (underflow gives 0 / denormal)
+        if (res.ec == std::errc::result_out_of_range) {
+            // from_chars reports overflow AND underflow this way and leaves d untouched: let strtod (whose span was validated above: JSON's number
+            // grammar, '.' as the radix character) tell them apart -- +-HUGE_VAL on overflow, +-0 / a denormal on underflow
+            d = strtod(std::string(s.data() + i, j - i).c_str(), nullptr);
+        }
         else if (res.ec != std::errc() || res.ptr != s.data() + j) return fail("malformed number");
         v.type = Value::Number;
         v.num = d;

@@ -41,8 +41,13 @@ public:
         std::vector<std::vector<std::vector<float>>> inputMatrix;
         std::vector<std::vector<std::vector<float>>> output;
         SNNModelOutput modelOutput;
+        // HIP extension: return right after the inference is enqueued instead of waiting for it (the reference waits once per inference,
+        // core.cpp:203).  The caller keeps several inferences in flight on the backend's stream and calls sync() when it needs a result;
+        // ignored with profiling / dumps / CPU stages / a classifier or detection output (those read results on the host inside run()).
+        bool deferSync = false;
     };
     void run(RunParameters& rp);
+    bool sync(); // HIP extension: wait for every inference enqueued with deferSync
     struct CreationParameters : InferenceGraph {
         uint32_t outputWidth = 0, outputHeight = 0, outputDepth = 0;
         bool dumpOutputs = false;

@@ -5,6 +5,7 @@
 #include "../../include/snnhip.h"
 #include "ic2/backend.h"
 #include "ic2/dp.h"
+#include "ic2/json.h"
 #include "ic2/layerFactory.h"
 #include "snn/contextFactory.h"
 #include "snn/core.h"
@@ -111,12 +112,13 @@ int snn_model_upload_input(snn_model* m, const float* nhwc) {
     return 0;
 }
 
-int snn_model_run(snn_model* m) {
+static int runModel(snn_model* m, bool deferSync) {
     try {
         MixedInferenceCore::RunParameters rp;
         rp.inputImages = &m->inputs;
         rp.outputImages = &m->outputs;
         rp.modelOutput.modelType = m->modelOutput.modelType;
+        rp.deferSync = deferSync;
         m->core->run(rp);
         m->modelOutput = rp.modelOutput;
     } catch (const std::exception& e) {
@@ -125,6 +127,20 @@ int snn_model_run(snn_model* m) {
     } catch (...) {
         return -2;
     }
+    return 0;
+}
+
+int snn_model_run(snn_model* m) { return runModel(m, false); }
+
+int snn_model_run_async(snn_model* m) { return runModel(m, true); }
+
+int snn_model_sync(snn_model* m) { return m->core->sync() ? 0 : -1; }
+
+int snn_json_number(const char* text, double* out) {
+    if (!text || !out) return -1;
+    json::Value v;
+    if (!json::parse(v, text).empty() || !v.isNumber()) return -1;
+    *out = v.num;
     return 0;
 }
 

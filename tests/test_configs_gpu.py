@@ -220,3 +220,96 @@ def test_c5_candy_720p_fp32_crop_free_layers(ctx):
     y = r(x)
     want = O.forward(net, x, threads=THREADS)
     np.testing.assert_allclose(y, want, **TOL)
+
+
+# ------------------------------------------------------------------------------------------------ what bench.py times, through the path it times
+# bench.py runs every config through the C++ host mirror (JSON + .bin model -> ModelParser -> MixedInferenceCore::create / run, fusion by
+# HipBackend::finalizeStages, recorded hipGraph replay) at the batch / micro-batch sizes below.  These tests run exactly that.
+
+def _bench_model(tmp_path, config, batch, **kw):
+    import bench
+    from shadernn_amd import host, models
+
+    cfg = bench.CONFIGS[config]
+    net = bench.make_net(config)
+    H, W = cfg["hw"]
+    path = models.write_json(net, W, H, str(tmp_path / (config + ".json")), bin_weights=True)
+    m = host.Model(path, W, H, cfg["cin"], fuse_chains=True, prefer_half=cfg["dtype"] == "f16", capture_graph=True, batch=batch, **kw)
+    return net, m, (H, W, cfg["cin"])
+
+
+def test_c2_espcn_1080p_whole_frame_through_host_graph_replay(ctx, tmp_path):
+    """BASELINE configs[1] as bench.py times it: the whole 1080p frame (every one of the 2160 x 3840 output pixels, no crops) against the
+    oracle at the north-star tolerance; first run = record + launch, second / third run = hipGraph replay, deferred-sync runs in flight."""
+    import bench
+
+    net, m, (H, W, C) = _bench_model(tmp_path, "c2", 1)
+    x = bench.oracle_input("c2")
+    want = O.forward(net, x, threads=THREADS)
+    assert want.shape == (1, 2 * H, 2 * W, 1)
+    y0 = m(x)
+    np.testing.assert_allclose(y0[None], want, **TOL)
+    kinds = " ".join(d for _, _, d, _, _ in m.plan_steps())
+    assert "wino3x3" in kinds and "d2s" in kinds and len(m.plan_steps()) == 2, kinds  # rule A + rule B: the two kernels of the bench line
+    m.run()                                  # replay
+    np.testing.assert_array_equal(m.output(), y0)
+    x2 = np.random.default_rng(11).random((1, H, W, 1), dtype=np.float32)
+    m.upload(x2)                             # same device buffer, new contents: the recording stays valid
+    for _ in range(3):
+        m.run_async()                        # three inferences in flight, one wait
+    m.sync()
+    np.testing.assert_allclose(m.output()[None], O.forward(net, x2, threads=THREADS), **TOL)
+    m.close()
+
+
+def test_c4_mobilenetv2_batch256_through_host_graph_replay(ctx, tmp_path):
+    """BASELINE configs[3] as bench.py times it on one GPU: all 256 images in ONE pass through the host mirror + hipGraph.  Images 0 / 127 /
+    255 against the oracle (final softmax output, 1e-4), then the batch-index property at this batch size."""
+    net, m, (H, W, C) = _bench_model(tmp_path, "c4", 256)
+    x = np.random.default_rng(7767517).random((256, H, W, C), dtype=np.float32)
+    y = m(x).reshape(256, -1)
+    assert y.shape == (256, 1000) and np.isfinite(y).all()
+    np.testing.assert_allclose(y.sum(axis=1), 1.0, atol=1e-4)
+    for n in (0, 127, 255):
+        want = O.forward(net, x[n : n + 1], threads=THREADS).reshape(-1)
+        np.testing.assert_allclose(y[n], want, err_msg="image %d" % n, **TOL)
+    kinds = " ".join(d for _, _, d, _, _ in m.plan_steps())
+    assert "irb_" in kinds, kinds            # the fused inverted-residual kernels the bench line lists
+    m.run()                                  # replay of the recording
+    np.testing.assert_array_equal(m.output().reshape(256, -1), y)
+    xb = np.repeat(x[127:128], 256, axis=0)
+    yb = m(xb).reshape(256, -1)
+    for i in range(256):
+        np.testing.assert_allclose(yb[i], y[127], rtol=1e-6, atol=1e-7, err_msg="batch position %d" % i)
+    m.close()
+
+
+def test_c5_candy_720p_fp16_microbatch16_default_switches_through_host(ctx, tmp_path):
+    """BASELINE configs[4] as bench.py times it: micro-batch 16 through the host mirror with the DEFAULT switches, so the 128 -> 128 body layers
+    take rule F (tile statistics + in-kernel fold, on from 128 MB per tensor) and rule I (normalisation applied in LDS behind the DMA) -- the
+    kernels of the bench line, which the batch-2 test above does not reach.  Image 0 and image 15 (different inputs) against the half-quantised
+    oracle with the acceptance of the batch-2 test; then a second, different batch through the same plans (stale tile records of the previous
+    launch must not leak into the fold: the relaxed-atomic hand-off of norm_fold.h)."""
+    net, m, (H, W, C) = _bench_model(tmp_path, "c5", 16)
+    kinds = " ".join(d for _, _, d, _, _ in m.plan_steps())
+    assert "+tile-stats+fold" in kinds and "in LDS behind the DMA" in kinds, kinds
+    rng = np.random.default_rng(7767517)
+    x = rng.random((16, H, W, C), dtype=np.float32)
+
+    def check(y, xs, positions):
+        for n in positions:
+            want = O.forward(net, xs[n : n + 1], fp16=True, threads=THREADS)
+            assert y[n : n + 1].shape == want.shape
+            scale = max(1.0, float(np.abs(want).max()))
+            err = np.abs(y[n : n + 1] - want) / scale
+            assert np.isfinite(y[n]).all()
+            assert np.quantile(err, 0.999) < 6e-3 and err.max() < 6e-2, (n, float(np.quantile(err, 0.999)), float(err.max()))
+
+    y = m(x)
+    assert y.shape[0] == 16
+    check(y, x, (0, 15))
+    # a different batch right behind it (brighter, other statistics) through the same plans and the same record buffers
+    x2 = (0.25 + 0.5 * rng.random((16, H, W, C), dtype=np.float32)).astype(np.float32)
+    y2 = m(x2)
+    check(y2, x2, (7,))
+    m.close()

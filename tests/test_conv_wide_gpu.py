@@ -282,6 +282,15 @@ def test_wide_tile_stats_feed_instancenorm(ctx, monkeypatch, n, h, w, ic, oc, of
     np.testing.assert_allclose(y, two, rtol=2e-3, atol=2e-3, err_msg=d)
     if offset == 0:
         np.testing.assert_allclose(y, want, err_msg=d, rtol=6e-3, atol=6e-3)
+    # a DIFFERENT input right behind it through the same plan (same record / counter / mul / shift buffers): a replay of identical data cannot tell
+    # fresh tile records from the previous launch's -- this one can (other scale, other mean)
+    x2 = (0.5 * _rand((n, h, w, ic), 11) + 0.75).astype(np.float32)
+    xt2 = snn.Tensor.from_numpy(ctx, x2, dtype=snn.F16)
+    y2 = fused(xt2).numpy()
+    two2 = norm(conv(pad(xt2))).numpy()
+    assert np.abs(two2 - two).max() > 0.05  # (the two inputs really normalise differently)
+    np.testing.assert_allclose(y2, two2, rtol=2e-3, atol=2e-3, err_msg="second input through the same plan: " + d)
+    np.testing.assert_allclose(fused(xt).numpy(), y, rtol=0, atol=0, err_msg="and back to the first input")
     # the caller's convolution plan is not changed by the fusion, and the rule can be switched off
     assert "tile-stats" not in conv.describe()
     monkeypatch.setenv("SNNHIP_NORM_FUSION", "0")

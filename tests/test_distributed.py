@@ -162,7 +162,8 @@ def test_bench_self_spawns_ranks_from_a_plain_shell():
         assert r.returncode == 0 and '"n_gpus": 2' in r.stdout
     elif not torch.cuda.is_available():
         assert r.returncode != 0
-        assert r.stderr.count("no GPU visible") >= 2, r.stderr[-2000:]
+        # (torchrun tears the other rank down as soon as the first one exits: both lines usually arrive, one always does)
+        assert r.stderr.count("no GPU visible") >= 1, r.stderr[-2000:]
 
 
 def test_bench_pmc_lookup_names_the_exact_instantiation():

@@ -31,6 +31,21 @@ def test_core_library_exports_declared_symbols(built):
     assert l is not None
 
 
+def test_json_number_grammar_overflow_and_underflow(built):
+    """The loader's number parser (std::from_chars reports overflow AND underflow as out-of-range): overflow saturates, underflow goes to +-0 / a
+    denormal -- what the reference's picojson (strtod) yields -- and never to +-inf."""
+    import math
+
+    from shadernn_amd import host
+
+    assert host.json_number("1.5e3") == 1500.0 and host.json_number("-0.25") == -0.25 and host.json_number("0") == 0.0
+    assert host.json_number("1e400") == math.inf and host.json_number("-1e400") == -math.inf
+    assert host.json_number("1e-400") == 0.0 and host.json_number("-1e-400") == 0.0 and math.copysign(1.0, host.json_number("-1e-400")) == -1.0
+    assert host.json_number("4.9e-324") == 5e-324 and 0.0 < host.json_number("2e-310") < 1e-300  # denormals survive
+    for bad in ("1.", ".5", "+1", "01", "1e", "nan", "0x10", ""):
+        assert host.json_number(bad) is None, bad
+
+
 def test_parser_and_graph_on_cpu(built, tmp_path):
     """No GPU needed: plan creation is deferred to the backend, like pipeline creation in the reference."""
     from shadernn_amd import host, models

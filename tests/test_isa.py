@@ -1,0 +1,36 @@
+"""Build-time checks on the generated gfx950 ISA (no GPU needed: hipcc cross-compiles)."""
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "shadernn_amd", "csrc")
+
+
+def _device_asm(src, tmp_path):
+    out = str(tmp_path / (os.path.basename(src) + ".s"))
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "--cuda-device-only", "-S", src, "-o", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    return open(out).read()
+
+
+def test_lds_dma_is_the_only_m0_user(tmp_path):
+    """epilogue.h::lds_dma16 writes m0 inside inline assembly the compiler cannot see through.  That is only safe while nothing else
+    in those kernels keeps a value in m0 (movrel indexing, s_sendmsg, LDS-direct reads, ds ops that consume m0): every m0 mention in the
+    generated code of the translation units that use the DMA must be the `s_mov_b32 m0, sN` of lds_dma16 itself, and each of those must be
+    followed by its global_load_lds."""
+    users = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and "lds_dma16" in open(os.path.join(CSRC, f)).read()]
+    assert users, "no translation unit uses lds_dma16 any more: drop this test"
+    with ThreadPoolExecutor(max_workers=len(users)) as ex:
+        asms = list(ex.map(lambda s: _device_asm(s, tmp_path), users))
+    for src, asm in zip(users, asms):
+        lines = [l.strip() for l in asm.split("\n")]
+        code = [l for l in lines if l and not l.startswith((";", ".", "//")) and not l.endswith(":")]
+        m0 = [(i, l) for i, l in enumerate(code) if re.search(r"\bm0\b", l.split(";")[0])]
+        assert m0, "%s: lds_dma16 used but no m0 write in the ISA?" % src
+        for i, l in m0:
+            assert re.fullmatch(r"s_mov_b32 m0, s\d+", l.split(";")[0].strip()), "%s: m0 used outside lds_dma16: %r" % (os.path.basename(src), l)
+            assert code[i + 1].startswith("global_load_lds_dwordx4"), "%s: %r is not followed by its DMA but by %r" % (os.path.basename(src), l, code[i + 1])
+        assert sum(1 for l in code if l.startswith("global_load_lds")) == len(m0)

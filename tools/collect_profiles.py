@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Copies what a tools/gpu_final.sh run left under gpurun_out/ into profiles/ (tracked): the rocprofv3 summaries of the c2 / c3 / c4 / c5 bench commands, the
+"""Copies what a tools/gpu.sh <tag> tests prof:c2 prof:c3 prof:c4 prof:c5 bench run left under gpurun_out/ into profiles/ (tracked): the rocprofv3 summaries of the c2 / c3 / c4 / c5 bench commands, the
 merged per-kernel PMC traffic file bench.py reads (profiles/pmc_latest.json, keyed to the kernel-source fingerprint) and one bench line per config.
 
     python tools/collect_profiles.py r02z [--round r02]

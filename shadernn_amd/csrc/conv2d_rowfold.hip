@@ -228,6 +228,13 @@ RowfoldFn pick_rowfold(int ics, bool simple) {
 } // namespace
 
 int make_conv2d_rowfold_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
+    {   // the row-marching form first (conv2d_rowmarch.hip: OC <= 4); this file's tile kernel takes what it declines (and SNNHIP_ROWFOLD=tile)
+        const char* force = snnhip::option("SNNHIP_CONV");
+        if (!force || strcmp(force, "rowfold") == 0) {
+            const int rc = make_conv2d_rowmarch_plan(ctx, g, w_oihw, epi4, out);
+            if (rc != SNNHIP_E_UNSUPPORTED) return rc;
+        }
+    }
     // eligibility: half tensors, square odd kernel 5 / 7 / 9, stride 1, k * OC <= 32, IC = 16 or 32 (the weights of a lane stay in registers)
     const char* force = snnhip::option("SNNHIP_CONV");
     if (force && strcmp(force, "rowfold") != 0) return SNNHIP_E_UNSUPPORTED;

@@ -7,6 +7,7 @@
 #include "../../include/snnhip.h"
 #include "ic2/backend.h"
 #include "ic2/dp.h"
+#include "ic2/genericlayer.h"
 #include "snn/core.h"
 
 using namespace snn;
@@ -95,6 +96,21 @@ bool MixedInferenceCore::init(const CreationParameters& cp_) {
     graphUsable = cp.captureGraph && !cp.dumpOutputs && !cp.profiling;
     for (auto& s : stages)
         if (!s.layer->isInputLayer && s.backend != Backend::Backend_GPU) graphUsable = false;
+    if (graphUsable) {
+        // A recorded graph pays off when an inference is MANY launches (ResNet-18 23, MobileNetV2 41, Candy 88 after fusion).  For a handful it costs:
+        // consecutive hipGraphLaunch calls leave ~5 us between graphs on the stream where plain kernel launches queue back to back (measured on the
+        // fused ESPCN, 2 launches of 86 + 34 us: 125.0 us per inference replayed, 120 launched directly) -- below the threshold run() just launches.
+        int launches = 0;
+        for (auto& s : stages) {
+            auto* ml = static_cast<dp::GenericModelLayer*>(s.layer->modelLayer);
+            if (!ml || s.layer->isInputLayer) continue;
+            for (auto& rp : ml->getRenderPasses())
+                if (auto* hp = dynamic_cast<dp::HipRenderPass*>(rp.get()))
+                    if (!hp->skip && hp->plan) launches += snnhip_plan_num_steps(hp->plan);
+        }
+        const char* minL = getenv("SNN_GRAPH_MIN_LAUNCHES");
+        if (launches < (minL ? atoi(minL) : 6)) graphUsable = false;
+    }
     return true;
 }
 

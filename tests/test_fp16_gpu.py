@@ -239,6 +239,33 @@ def test_fp16_rowfold_conv_matches_quantised_oracle_and_thin_kernel(ctx, monkeyp
     np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=4e-3, atol=4e-3)
 
 
+MARCH = [(1, 100, 131, 32, 3, 9, "reflect", "", "3"), (2, 61, 200, 32, 3, 9, "constant", "tanh", ""), (1, 75, 57, 16, 4, 7, "replicate", "relu", "2"),
+         (1, 9, 64, 32, 2, 5, "constant", "", ""), (2, 130, 113, 32, 1, 9, "constant", "sigmoid", "4")]
+
+
+@pytest.mark.parametrize("case", MARCH, ids=lambda c: "x".join(map(str, c[:6])) + "_" + c[6] + "_segs" + (c[8] or "auto"))
+def test_fp16_rowfold_marching_strips_match_the_tile_kernel_and_the_oracle(ctx, monkeypatch, case):
+    """conv2d_rowmarch.hip: several iterations of the LDS row ring per block, several row segments per strip (forced and chosen), ragged last iteration and
+    last strip, odd widths (rows that start on a 2-byte boundary take the 2-byte store path) -- against the quantised oracle and conv2d_rowfold.hip's tile
+    kernel (SNNHIP_ROWFOLD=tile) on the same inputs."""
+    N, H, W, IC, OC, k, pad_mode, act, segs = case
+    x = _rand((N, H, W, IC), 301)
+    w = _rand((OC, IC, k, k), 302, 1.0 / np.sqrt(IC * k * k))
+    b = _rand((OC,), 303, 0.1)
+    bn = _bn(OC, 304) if act else None
+    pads = O.padding_offsets("same", k)
+    if segs:
+        monkeypatch.setenv("SNNHIP_ROWFOLD_SEGS", segs)
+    y, desc = _conv16(ctx, x, w, b, 1, pads, pad_mode, act, bn)
+    assert "conv2d_rowfold" in desc and "row-marching" in desc and (not segs or "segments=%s x" % segs in desc), desc
+    want = O._h(O.conv2d(O._h(x), O._h(w), b, 1, pads, pad_mode, act, 0.0, bn))
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOLH)
+    monkeypatch.setenv("SNNHIP_ROWFOLD", "tile")
+    y2, desc2 = _conv16(ctx, x, w, b, 1, pads, pad_mode, act, bn)
+    assert "conv2d_rowfold" in desc2 and "row-marching" not in desc2, desc2
+    np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-3, atol=2e-3)
+
+
 def test_fp16_rowfold_with_fused_reflect_pad(ctx):
     """Chain rule D on the row-fold kernel: Pad(reflect 4) -> Conv2D 9x9 "valid" 32 -> 3 (Candy's output layer) as one launch."""
     import shadernn_amd as snn

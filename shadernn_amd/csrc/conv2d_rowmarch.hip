@@ -228,9 +228,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                 for (int i = 0; i < 16; ++i) {
                     const int n0 = 8 * (i >> 2) + (i & 3), n1 = n0 + 4;
                     if (n0 >= K * OC) continue; // (compile-time) neither half holds a real column in this register
-                    float pv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pa[i], __builtin_bit_cast(int, acc[j][t][i])));
+                    // (element copies first: __builtin_bit_cast applied to the vector-element expression itself pulled element 0 whatever i was)
+                    const float own = acc[j][t][i];
+                    float pv = __int_as_float(__builtin_amdgcn_ds_bpermute(pa[i], __float_as_int(own)));
                     if (t == 0) {
-                        const float pn = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pa[i], __builtin_bit_cast(int, acc[j][1][i])));
+                        const float nxt = acc[j][1][i];
+                        const float pn = __int_as_float(__builtin_amdgcn_ds_bpermute(pa[i], __float_as_int(nxt)));
                         pv = ((crossMask >> i) & 1u) ? pn : pv;
                     }
                     // half 0 adds it to channel n0 % OC, half 1 to channel n1 % OC (nothing if n1 is a padding column)

@@ -97,21 +97,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
 
     float4 v[NRND];
     unsigned rowOkMask = 0;
-    auto load_group = [&](int g) { // issue the loads of group g (rows outside the padded image / the source are zeros and never loaded)
+    // The source row of a staged row is wave-uniform, but resolving it on the scalar unit (padding mode, fused Pad, fused UpSampling: ~60 SALU
+    // instructions and two branches per row) made the row loop 1000 SALU instructions + 16 pipeline drains per iteration next to the wave's 72 MFMAs.
+    // Lane r resolves row r of the group ONCE on the vector unit; a round reads its row back with v_readlane.
+    auto load_group = [&](int g) { // issue the loads of group g (rows outside the padded image / the source read row 0 and are zeroed when stored)
+        int syv = resolve_nobranch(iyS + g * kTH + (lane & 7), p.H, p.padMode);
+        {
+            const int py = resolve_nobranch(syv - p.preY, p.srcH << p.preShift, p.preMode);
+            const int pre = syv < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
+            syv = p.preMode ? pre : syv;
+        }
         rowOkMask = 0;
 #pragma unroll
         for (int r = 0; r < NRND; ++r) {
-            const int rr = r * RPI + rsub;
-            int sy = resolve_nobranch(iyS + g * kTH + rr, p.H, p.padMode);
-            if (p.preMode) {
-                const int py = resolve_nobranch(sy - p.preY, p.srcH << p.preShift, p.preMode);
-                sy = sy < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
-            }
-            v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sy >= 0) { // (uniform)
-                rowOkMask |= 1u << r;
-                v[r] = *reinterpret_cast<const float4*>(xn + static_cast<size_t>(sy) * p.srcW * p.IC + colOfs); // (a column outside reads column 0: masked below)
-            }
+            const int sy = __builtin_amdgcn_readlane(syv, r * RPI + rsub); // (r * RPI + rsub is wave-uniform)
+            rowOkMask |= static_cast<unsigned>(sy >= 0) << r;
+            v[r] = *reinterpret_cast<const float4*>(xn + static_cast<size_t>(max(sy, 0)) * p.srcW * p.IC + colOfs); // (a column outside reads column 0: masked when stored)
         }
     };
     auto store_group = [&](int g) { // normalise (rule I) and write the group into ring rows 8 (g & 1) ..
@@ -170,6 +171,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
         crossMask |= static_cast<unsigned>(src >= 32) << i;
     }
     const bool h1 = h != 0;
+    // (uniform) none / relu / relu6 / leakyRelu go through the branch-free med3 form; the run-time switch of epi_act (tanh, sigmoid, ...) pulled
+    // ~700 VALU instructions and ~200 branches into the iteration loop
+    const bool actSimple = act_is_simple_dev(ac.act);
 
     // prologue: groups 0 and 1
     load_group(0);
@@ -221,6 +225,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
             _Float16* const line = scratch + (wave * 2 + j) * (kCols * 4);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
+                // Register i holds column n0 = 8 (i / 4) + i % 4 in lane half 0 and n0 + 4 in half 1: channel n0 % OC resp. (n0 + 4) % OC.  Both halves add
+                // their pull to accumulator n0 % OC -- ONE add, no select: in half 1 accumulator r therefore stands for channel (r + 4) % OC, undone
+                // when the halves are combined.
                 float o[OC];
 #pragma unroll
                 for (int k = 0; k < OC; ++k) o[k] = 0.0f;
@@ -236,18 +243,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                         const float pn = __int_as_float(__builtin_amdgcn_ds_bpermute(pa[i], __float_as_int(nxt)));
                         pv = ((crossMask >> i) & 1u) ? pn : pv;
                     }
-                    // half 0 adds it to channel n0 % OC, half 1 to channel n1 % OC (nothing if n1 is a padding column)
-                    const float v0 = h1 ? 0.0f : pv, v1 = h1 ? pv : 0.0f;
-                    o[n0 % OC] += v0;
-                    if (n1 < K * OC) o[n1 % OC] += v1;
+                    // half 1's column n1 may be one of the zero-weight padding columns: its pull reaches past the receptive field (fx >= K), where
+                    // 0 * inf would be NaN -- dropped
+                    if (n1 >= K * OC) pv = h1 ? 0.0f : pv;
+                    o[n0 % OC] += pv;
                 }
+                float tot[OC]; // (the exchange runs with every lane active: a pull from a disabled lane returns 0)
 #pragma unroll
-                for (int k = 0; k < OC; ++k) o[k] += __shfl_xor(o[k], 32); // the other half's columns
+                for (int k = 0; k < OC; ++k) tot[k] = o[k] + __shfl_xor(o[((k - 4) % OC + OC) % OC], 32); // half 0: channel k of the other half sits in ITS accumulator (k - 4) mod OC
                 if (!h1) {
 #pragma unroll
                     for (int k = 0; k < OC; ++k) {
-                        float r = epi_affine(o[k], epi[k], p.useBN);
-                        r = epi_act(ac.act, ac.leaky, r, 0.0f);
+                        float r = epi_affine(tot[k], epi[k], p.useBN);
+                        r = actSimple ? __builtin_amdgcn_fmed3f(fmaxf(r, r * ac.alpha), ac.lo, ac.hi) : epi_act(ac.act, ac.leaky, r, 0.0f);
                         line[(t * 32 + l32) * OC + k] = static_cast<_Float16>(r);
                     }
                 }

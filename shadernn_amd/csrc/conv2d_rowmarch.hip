@@ -197,23 +197,33 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[j][t][i] = 0.0f;
         const int rbase = __builtin_amdgcn_readfirstlane(kTH * (it & 1) + 2 * wave);
-#pragma unroll
-        for (int rr = 0; rr < K + 1; ++rr) { // relative input row 8 it + 2 w + rr feeds output row j at tap fy = rr - j
+        // operand reads one input row ahead of the MFMAs that consume them (left to the scheduler they sat right in front of their MFMAs behind an
+        // lgkmcnt(0): sixteen exposed LDS round trips per iteration)
+        float4 a[2][ICS][2];
+        auto read_row = [&](int rr, float4 (&dst)[ICS][2]) {
             const float* rowp = smem + ((rbase + rr) & 15) * ROWF;
 #pragma unroll
-            for (int cc = 0; cc < ICS; ++cc) {
-                float4 a[2];
+            for (int cc = 0; cc < ICS; ++cc)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const float4*>(rowp + bofs[t][cc]);
+                for (int t = 0; t < 2; ++t) dst[cc][t] = *reinterpret_cast<const float4*>(rowp + bofs[t][cc]);
+        };
+        read_row(0, a[0]);
+#pragma unroll
+        for (int rr = 0; rr < K + 1; ++rr) { // relative input row 8 it + 2 w + rr feeds output row j at tap fy = rr - j
+            if (rr < K) read_row(rr + 1, a[(rr + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cc = 0; cc < ICS; ++cc) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int fy = rr - j;
                     if (fy < 0 || fy >= K) continue; // compile-time after unrolling
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
-                        acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b[fy * ICS + cc]), *reinterpret_cast<const h8*>(&a[t]), acc[j][t], 0, 0, 0);
+                        acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b[fy * ICS + cc]), *reinterpret_cast<const h8*>(&a[rr & 1][cc][t]), acc[j][t], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads(); // every wave is done with the older group: its ring rows may be overwritten (below, after the epilogue)
 
@@ -231,22 +241,31 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                 float o[OC];
 #pragma unroll
                 for (int k = 0; k < OC; ++k) o[k] = 0.0f;
+                // all pulls of the row tile are issued before the first is used (one at a time each waited out its LDS round trip: ~50 exposed waits
+                // per iteration)
+                float pv[16], pn[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (8 * (i >> 2) + (i & 3) >= K * OC) continue; // (compile-time) neither half holds a real column in this register
+                    // (element copies first: __builtin_bit_cast applied to the vector-element expression itself pulled element 0 whatever i was)
+                    const float own = acc[j][t][i];
+                    pv[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(pa[i], __float_as_int(own)));
+                    if (t == 0) {
+                        const float nxt = acc[j][1][i];
+                        pn[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(pa[i], __float_as_int(nxt)));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int n0 = 8 * (i >> 2) + (i & 3), n1 = n0 + 4;
-                    if (n0 >= K * OC) continue; // (compile-time) neither half holds a real column in this register
-                    // (element copies first: __builtin_bit_cast applied to the vector-element expression itself pulled element 0 whatever i was)
-                    const float own = acc[j][t][i];
-                    float pv = __int_as_float(__builtin_amdgcn_ds_bpermute(pa[i], __float_as_int(own)));
-                    if (t == 0) {
-                        const float nxt = acc[j][1][i];
-                        const float pn = __int_as_float(__builtin_amdgcn_ds_bpermute(pa[i], __float_as_int(nxt)));
-                        pv = ((crossMask >> i) & 1u) ? pn : pv;
-                    }
+                    if (n0 >= K * OC) continue;
+                    float q = pv[i];
+                    if (t == 0) q = ((crossMask >> i) & 1u) ? pn[i] : q;
                     // half 1's column n1 may be one of the zero-weight padding columns: its pull reaches past the receptive field (fx >= K), where
                     // 0 * inf would be NaN -- dropped
-                    if (n1 >= K * OC) pv = h1 ? 0.0f : pv;
-                    o[n0 % OC] += pv;
+                    if (n1 >= K * OC) q = h1 ? 0.0f : q;
+                    o[n0 % OC] += q;
                 }
                 float tot[OC]; // (the exchange runs with every lane active: a pull from a disabled lane returns 0)
 #pragma unroll

@@ -6,6 +6,7 @@
 #     bench[:c1,c2,...]                one bench.py line per config (default: all five)                   -> bench_<c>.json / .err
 #     benchx:<c>:<extra bench args>    one bench line with extra arguments ('+' stands for a blank)        -> benchx_<n>.json
 #     prof:<c>                         rocprofv3 kernel trace + PMC passes of that config's bench command -> <tag>_<c>/summary.md
+#     profx:<name>:<command>           the same passes around an arbitrary command ('+' stands for a blank)   -> <tag>_<name>/summary.md
 #     layers[:fp16]                    tools/bench_layers.py                                               -> layers[_fp16].txt
 #     py:<script>[:args]               python tools/<script> args ('+' stands for a blank)                 -> py_<n>.txt
 #     env:NAME=VALUE                   export for the following actions
@@ -37,6 +38,10 @@ for act in "$@"; do
       PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --config $arg --no-cpu-baseline --no-parity --layer-table 0 --event-launches 0 --preheat-ms 20 $steps" \
         timeout 1500 tools/profile_gpu.sh "${TAG}_$arg" > "$O/profile_$arg.log" 2>&1
       grep "derived" -A30 "$O/profile_$arg.log" | cut -c1-240 | head -34 ;;
+    profx) # profx:<name>:<command, '+' for blanks>: kernel trace + PMC passes of an arbitrary command (e.g. one layer through tools/bench_layers.py)
+      nm=${arg%%:*}; cmd=${arg#*:}
+      PROF_CMD="${cmd//+/ }" timeout 1500 tools/profile_gpu.sh "${TAG}_$nm" > "$O/profile_$nm.log" 2>&1
+      grep "derived" -A12 "$O/profile_$nm.log" | cut -c1-600 | head -16 ;;
     layers)
       timeout 600 python tools/bench_layers.py ${arg:+--$arg} > "$O/layers${arg:+_$arg}.txt" 2>/dev/null; tail -40 "$O/layers${arg:+_$arg}.txt" ;;
     py)

@@ -466,6 +466,18 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
             if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
         }
     }
+    // fp16 3x3 stride-2 layers with 32 / 64 input channels on large maps: the row-marching strips of conv2d_s2march.hip (SNNHIP_CONV=s2march forces it
+    // for every eligible shape, SNNHIP_CONV=mfma / SNNHIP_CONV_S2MARCH=0 keep the 128-pixel kernel)
+    {
+        const char* force = snnhip::option("SNNHIP_CONV");
+        const char* w = snnhip::option("SNNHIP_CONV_S2MARCH");
+        const bool forced = force && strcmp(force, "s2march") == 0;
+        const bool allowed = !force && !(w && atoi(w) == 0) && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_SPLITK") && !snnhip::option("SNNHIP_CONV_C8");
+        if (forced || allowed) {
+            const int rc = make_conv2d_s2march_plan(ctx, g, w_oihw, epi4, out);
+            if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
+        }
+    }
     // pointwise layers (fp32, and fp16 with OC % 8 == 0) stream through conv1x1_stream.hip (no halo tile to stage); forcing a kernel or a
     // configuration skips it
     if (!snnhip::option("SNNHIP_CONV") && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_SPLITK") && !snnhip::option("SNNHIP_CONV_C8")) {

@@ -1,0 +1,347 @@
+// conv2d_s2march.hip -- fp16 3x3 STRIDE-2 convolution for large feature maps with 32 or 64 input channels (the two down-sampling layers of the
+// fast-neural-style networks, BASELINE configs[4]: 32 -> 64 @ 728 x 1288 and 64 -> 128 @ 364 x 644 per image), row-marching like conv2d_rowmarch.hip.
+//
+// Round 2 ran these layers on conv2d_mfma_kernel's 128-pixel blocks: 590 + 584 us per 16 images with the matrix pipe 10 % busy and 2x the input
+// fetched (profiles/r02_c5_*) -- 36 MFMAs per wave behind a block's whole prologue / staging / epilogue, 29 000 blocks per launch.  A stride-2 layer
+// has almost no halo to share (3 input rows per output row, 2 of them its own), so what a kernel can win here is not re-use but (a) weights that
+// stay in registers for a whole strip instead of being streamed per 128 pixels, (b) the next rows in flight while the current ones are
+// multiplied, (c) no per-tile prologue: one block = one 32-column strip of one image, marching down a segment of its rows.
+//
+//   * block = 512 threads = 8 waves = WR output rows x WN 32-channel column tiles (32 -> 64: 4 rows x 2 tiles, 64 -> 128: 2 rows x 4 tiles); per
+//     iteration TH = WR output rows, i.e. 2 TH NEW input rows (+ 1 kept from the previous iteration) in an LDS ring of 2 TH + 1 rows;
+//   * a wave = ONE output row x ONE 32-channel tile: all 9 x IC/16 weight operands of its tile in registers (the MFMA's A operand, 72 / 144
+//     VGPRs), the 32 pixels of the row are the B operand (LDS: pixel pitch Q + 1 sixteen-byte slots -- odd, so the stride-2 operand reads are
+//     conflict-free and every tap / channel-slot displacement is an immediate offset), 9 x IC/16 MFMAs per wave and iteration;
+//   * the rows of iteration it + 1 are requested before the MFMAs of iteration it (registers), normalised (graph rule I) and written over the
+//     rows that have just retired; the fused Pad in front (rule D) resolves in the row / column look-ups;
+//   * the output tile (TH x 32 pixels x 32 WN channels) leaves through LDS as 16-byte channel-contiguous vectors.
+// Operator contract as the other convolution kernels (shadertemplate_vk_conv2d.comp:148-347: padding modes, bias -> BN -> activation).
+#include <cstring>
+#include <vector>
+
+#include "epilogue.h"
+#include "snnhip_internal.h"
+
+namespace snnhip {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+struct S2Params {
+    int N, H, W, IC, OC, OH, OW, padx, pady, padMode, useBN;
+    int preMode, preX, preY, srcH, srcW, preShift; // fused Pad / nearest x2 upsampling in front (ConvGeom)
+    int tilesX, segs, segRows;                     // column strips, row segments per strip, output rows per segment (multiple of TH)
+    const float* normShift;                        // InstanceNorm in front (graph rule I); null = none
+    const float* normMul;
+    ActCfg normAc;
+};
+
+constexpr int kCW = 65; // staged input columns of a 32-column output strip: 2 * 31 + 3
+
+template <int ICS /* IC / 16: 2 | 4 */, int WN /* 32-channel tiles per block: 2 | 4 */>
+__global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
+                                                                const float4* __restrict__ epi, _Float16* __restrict__ y) {
+    constexpr int Q = 2 * ICS;          // 16-byte slots per pixel
+    constexpr int QP = Q + 1;           // ... and its pitch in LDS
+    constexpr int WR = 8 / WN;          // output rows per iteration (one per wave row)
+    constexpr int TH = WR;
+    constexpr int GR = 2 * TH;          // new input rows per iteration
+    constexpr int RING = GR + 1;        // ring rows
+    constexpr int ROWF = kCW * QP * 4;  // floats per ring row
+    constexpr int EPR = 64 * Q;         // main staging elements per row (256 | 512)
+    constexpr int RPR = 512 / EPR;      // rows per staging round (2 | 1)
+    constexpr int NRND = GR / RPR;      // rounds per batch of GR rows (4)
+    constexpr int BN = 32 * WN;         // output channels per block
+    constexpr int EP = BN + 8;          // halfs per pixel of the output tile in LDS
+    static_assert(NRND * RPR == GR && GR * Q == 32, "staging map");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* const otile = reinterpret_cast<_Float16*>(smem + RING * ROWF);                         // [TH][32][EP] halfs
+    float* const normTab = smem + RING * ROWF + (TH * 32 * EP) / 2;                                  // [2][IC] shift, mul of this block's image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int wr = wave / WN, wn = wave % WN;
+    const int bx = blockIdx.x;
+    const int seg = bx % p.segs, tx = (bx / p.segs) % p.tilesX, n = bx / (p.segs * p.tilesX);
+    const int ox0 = tx * 32, oyS = seg * p.segRows, oyE = min(p.OH, oyS + p.segRows);
+    const int ix0 = 2 * ox0 - p.padx, iyS = 2 * oyS - p.pady;
+    const int nIter = (oyE - oyS + TH - 1) / TH;
+    const int ocb = blockIdx.y * BN;
+
+    // ---- this wave's weights (the MFMA's A operand): wq[tap][cc] = 8 halfs {W[ocb + 32 wn + l32][16 cc + 8 h + j][fy][fx]}
+    float4 wq[9][ICS];
+    {
+        const float4* wt = wp + (static_cast<size_t>(blockIdx.y * WN + wn) * 9 * ICS) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int cc = 0; cc < ICS; ++cc) wq[t][cc] = wt[(t * ICS + cc) * 64];
+    }
+    if (p.normShift)
+        for (int i = tid; i < p.IC; i += 512) {
+            normTab[i] = p.normShift[n * p.IC + i];
+            normTab[p.IC + i] = p.normMul[n * p.IC + i];
+        }
+
+    // ---- staging map: thread -> column c (0..63) and slot sl of row r * RPR + rsub of a batch; threads 0..31 also carry column 64 (row tid / Q)
+    const _Float16* xn = x + static_cast<size_t>(n) * p.srcH * p.srcW * p.IC;
+    const int sl = tid % Q, c = (tid / Q) % 64;
+    const int rsub = __builtin_amdgcn_readfirstlane(tid / EPR);
+    auto resolve_col = [&](int cc) {
+        int sx = resolve_nobranch(ix0 + cc, p.W, p.padMode);
+        const int px = resolve_nobranch(sx - p.preX, p.srcW << p.preShift, p.preMode);
+        const int pre = sx < 0 ? -1 : (px < 0 ? -1 : px >> p.preShift);
+        return p.preMode ? pre : sx;
+    };
+    const int sxMain = resolve_col(c), sxLast = resolve_col(64);
+    const int colOfs = max(sxMain, 0) * p.IC + 8 * sl, colOfsLast = max(sxLast, 0) * p.IC + 8 * sl;
+    const int ldsMain = (c * QP + sl) * 4, ldsLast = (64 * QP + sl) * 4; // + ring row * ROWF
+    const int rowLast = tid / Q;                                          // (threads 0..31) row of the batch their column-64 element sits in
+    const bool nRelu = p.normAc.act == SNNHIP_ACT_RELU;
+
+    float4 v[NRND], vLast;
+    unsigned rowOkMask = 0;
+    bool lastOk = false;
+    int ringOf[NRND], ringLast = 0; // ring rows the batch in flight goes to
+    // batch b = relative input rows GR b + 1 .. GR b + GR of the segment (b = -1: the rows up to row 0)
+    auto load_batch = [&](int b) {
+        const int r0 = GR * b + 1;
+        int syv = resolve_nobranch(iyS + r0 + (lane & 7), p.H, p.padMode); // lane l resolves row l of the batch once, on the vector unit
+        {
+            const int py = resolve_nobranch(syv - p.preY, p.srcH << p.preShift, p.preMode);
+            const int pre = syv < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
+            syv = p.preMode ? pre : syv;
+        }
+        rowOkMask = 0;
+#pragma unroll
+        for (int r = 0; r < NRND; ++r) {
+            const int rr = r * RPR + rsub; // (wave-uniform)
+            const int sy = __builtin_amdgcn_readlane(syv, rr);
+            rowOkMask |= static_cast<unsigned>(sy >= 0) << r;
+            ringOf[r] = ((r0 + rr) % RING + RING) % RING;
+            v[r] = *reinterpret_cast<const float4*>(xn + static_cast<size_t>(max(sy, 0)) * p.srcW * p.IC + colOfs);
+        }
+        if (tid < 32) {
+            const int sy = __shfl(syv, rowLast); // (lanes 0..31 of wave 0)
+            lastOk = sy >= 0;
+            ringLast = ((r0 + rowLast) % RING + RING) % RING;
+            vLast = *reinterpret_cast<const float4*>(xn + static_cast<size_t>(max(sy, 0)) * p.srcW * p.IC + colOfsLast);
+        }
+    };
+    auto normalise = [&](float4& q) { // graph rule I on 8 staged channels 8 sl ..: half(act(x * mul + shift)) in fp32, the norm sweep's own arithmetic
+        h8 hv = *reinterpret_cast<const h8*>(&q);
+        const float* tb = normTab + 8 * sl;
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4) {
+            const float4 sh = *reinterpret_cast<const float4*>(tb + 4 * q4), mu = *reinterpret_cast<const float4*>(tb + p.IC + 4 * q4);
+            const float shv[4] = {sh.x, sh.y, sh.z, sh.w}, muv[4] = {mu.x, mu.y, mu.z, mu.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float f = fmaf(static_cast<float>(hv[4 * q4 + k]), muv[k], shv[k]);
+                hv[4 * q4 + k] = static_cast<_Float16>(nRelu ? fmaxf(f, 0.0f) : __builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+            }
+        }
+        q = *reinterpret_cast<const float4*>(&hv);
+    };
+    auto store_batch = [&]() { // normalise and write the batch in flight into its ring rows; padding stays zero
+#pragma unroll
+        for (int r = 0; r < NRND; ++r) {
+            if (p.normShift) normalise(v[r]);
+            const bool live = ((rowOkMask >> r) & 1u) && sxMain >= 0;
+            const float4 o = make_float4(live ? v[r].x : 0.f, live ? v[r].y : 0.f, live ? v[r].z : 0.f, live ? v[r].w : 0.f);
+            *reinterpret_cast<float4*>(smem + ringOf[r] * ROWF + ldsMain) = o;
+        }
+        if (tid < 32) {
+            if (p.normShift) normalise(vLast);
+            const bool live = lastOk && sxLast >= 0;
+            const float4 o = make_float4(live ? vLast.x : 0.f, live ? vLast.y : 0.f, live ? vLast.z : 0.f, live ? vLast.w : 0.f);
+            *reinterpret_cast<float4*>(smem + ringLast * ROWF + ldsLast) = o;
+        }
+    };
+
+    // ---- MFMA B operand (pixels): lane (l32, h) reads pixel 2 l32 + fx, slot 2 cc + h of a ring row: the lane part of the float offset
+    const int bofs = (2 * l32 * QP + h) * 4;
+
+    __syncthreads(); // the norm table
+    load_batch(-1);
+    store_batch();
+    __syncthreads(); // (batch 0 overwrites the ring rows batch -1 used for the rows in front of the segment, from other threads)
+    load_batch(0);
+    store_batch();
+    __syncthreads();
+
+    const float4* const et = epi + ocb + 32 * wn; // this wave's rows of the epilogue table {bias, bnScale, bnMean, bnBeta}
+    const bool actSimple = act_is_simple_dev(ac.act);
+    for (int it = 0; it < nIter; ++it) {
+        const bool more = it + 1 < nIter;
+        if (more) load_batch(it + 1);
+
+        // ---- wave = output row TH it + wr: input rows GR it + 2 wr + fy
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        const int r0 = __builtin_amdgcn_readfirstlane(GR * it + 2 * wr);
+        // operand registers: a[cc] is dead once its MFMA has issued and is refilled for the next tap at once (the other MFMAs of the tap cover the
+        // LDS round trip) -- one set of ICS operands, not two
+        float4 a[ICS];
+        auto tap_ptr = [&](int t) { return smem + ((r0 + t / 3) % RING) * ROWF + bofs + (t % 3) * QP * 4; }; // tap t = 3 fy + fx
+        {
+            const float* rowp = tap_ptr(0);
+#pragma unroll
+            for (int cc = 0; cc < ICS; ++cc) a[cc] = *reinterpret_cast<const float4*>(rowp + 2 * cc * 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float* nextp = tap_ptr(t + 1 < 9 ? t + 1 : t);
+#pragma unroll
+            for (int cc = 0; cc < ICS; ++cc) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&wq[t][cc]), *reinterpret_cast<const h8*>(&a[cc]), acc, 0, 0, 0);
+                if (t + 1 < 9) a[cc] = *reinterpret_cast<const float4*>(nextp + 2 * cc * 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- epilogue into the LDS tile: acc[4 g + k] = channel ocb + 32 wn + 8 g + 4 h + k of pixel l32 of row wr
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            h4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float r = epi_affine(acc[4 * g + k], et[8 * g + 4 * h + k], p.useBN);
+                r = actSimple ? __builtin_amdgcn_fmed3f(fmaxf(r, r * ac.alpha), ac.lo, ac.hi) : epi_act(ac.act, ac.leaky, r, 0.0f);
+                o[k] = static_cast<_Float16>(r);
+            }
+            *reinterpret_cast<h4*>(otile + (wr * 32 + l32) * EP + 32 * wn + 8 * g + 4 * h) = o;
+        }
+        __syncthreads(); // the tile is complete, and every wave is done with the ring rows that retire
+
+        // ---- the tile leaves as 16-byte vectors, a pixel's BN channels contiguous
+#pragma unroll
+        for (int q = 0; q < (TH * 32 * (BN / 8)) / 512; ++q) {
+            const int vi = tid + 512 * q;
+            const int pix = vi / (BN / 8), c8 = vi % (BN / 8);
+            const int oy = oyS + it * TH + (pix >> 5), ox = ox0 + (pix & 31);
+            if (oy < oyE && ox < p.OW)
+                *reinterpret_cast<float4*>(y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox) * p.OC + ocb + 8 * c8) = *reinterpret_cast<const float4*>(otile + pix * EP + 8 * c8);
+        }
+        if (more) store_batch();
+        __syncthreads();
+    }
+}
+
+struct S2marchPlan : ConvPlanBase {
+    S2Params p;
+    ActCfg ac;
+    float* d_w = nullptr;
+    float* d_epi = nullptr;
+    size_t ldsBytes = 0;
+    dim3 grid;
+    void (*kernel)(S2Params, ActCfg, const _Float16*, const float4*, const float4*, _Float16*) = nullptr;
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == p.IC, "conv2d: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h,
+                       x->w, x->c, p.N, p.srcH, p.srcW, p.IC);
+        SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n,
+                       out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
+        hipLaunchKernelGGL(kernel, grid, dim3(512), ldsBytes, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
+                           reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+} // namespace
+
+// Tried by make_conv2d_mfma_plan (conv2d_mfma.hip) in front of the 128-pixel kernel; SNNHIP_E_UNSUPPORTED hands the layer on.
+int make_conv2d_s2march_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
+    const char* force = snnhip::option("SNNHIP_CONV");
+    const bool forced = force && strcmp(force, "s2march") == 0;
+    if (g.normShift && !act_is_simple(g.normAct)) return SNNHIP_E_UNSUPPORTED;
+    if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 2 || g.sw != 2 || (g.IC != 32 && g.IC != 64)) return SNNHIP_E_UNSUPPORTED;
+    const int ICS = g.IC / 16, WN = g.IC == 32 ? 2 : 4, BN = 32 * WN, TH = 8 / WN;
+    if (g.OC % BN != 0 || g.act == SNNHIP_ACT_SILU_QUIRK || g.addAct >= 0) return SNNHIP_E_UNSUPPORTED;
+    if (static_cast<double>(g.N) * std::max(g.H, g.srcH) * std::max(g.W, g.srcW) * g.IC >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
+    const int tilesX = up_div(g.OW, 32);
+    // a strip is worth its prologue (2 batches of rows, the weights) from a few dozen output rows on, and the chip wants every CU busy
+    if (!forced && (g.OH < 48 || static_cast<long>(g.N) * tilesX * up_div(g.OH, 48) < ctx->props.multiProcessorCount)) return SNNHIP_E_UNSUPPORTED;
+    S2Params p = {};
+    p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.OH = g.OH; p.OW = g.OW; p.padx = g.padx; p.pady = g.pady; p.padMode = g.padMode; p.useBN = g.useBN;
+    p.preMode = g.preMode; p.preX = g.preX; p.preY = g.preY; p.preShift = g.preShift;
+    p.srcH = g.preMode ? g.srcH : g.H;
+    p.srcW = g.preMode ? g.srcW : g.W;
+    p.tilesX = tilesX;
+    {   // row segments: whole rounds of one block per CU, the segment's prologue (GR rows re-read + the weights) weighed against the tail round
+        const int slots = std::max(1, ctx->props.multiProcessorCount), strips = g.N * tilesX * (g.OC / BN);
+        const char* fs = snnhip::option("SNNHIP_S2MARCH_SEGS");
+        int bestSegs = 1;
+        double bestEff = -1.0;
+        for (int s = 1; s <= 64; ++s) {
+            const int rows = round_up(up_div(g.OH, s), TH);
+            const int segs = up_div(g.OH, rows);
+            if (segs != s) continue;
+            if (s > 1 && rows < 24) break;
+            const double blocks = static_cast<double>(strips) * segs;
+            const double eff = blocks / (std::ceil(blocks / slots) * slots) * rows / (rows + 2 * TH + 2);
+            if ((fs && atoi(fs) == s) || (!fs && eff > bestEff + 1e-9)) {
+                bestEff = eff;
+                bestSegs = segs;
+                if (fs) break;
+            }
+        }
+        p.segRows = round_up(up_div(g.OH, bestSegs), TH);
+        p.segs = up_div(g.OH, p.segRows);
+    }
+    p.normShift = g.normShift; p.normMul = g.normMul;
+    p.normAc = make_act_cfg(g.normShift ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
+    const int QP = 2 * ICS + 1, RING = 2 * TH + 1;
+    const size_t lds = static_cast<size_t>(RING) * kCW * QP * 16 + static_cast<size_t>(TH) * 32 * (BN + 8) * 2 + 2 * static_cast<size_t>(g.IC) * 4;
+    auto fn = g.IC == 32 ? conv2d_s2march_kernel<2, 2> : conv2d_s2march_kernel<4, 4>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+        set_error("conv2d_s2march: hipFuncSetAttribute(%zu) failed", lds);
+        return SNNHIP_E_HIP;
+    }
+    auto* plan = new S2marchPlan();
+    plan->ctx = ctx;
+    plan->g = g;
+    plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC * 9);
+    plan->epi4 = epi4;
+    plan->p = p;
+    plan->ac = make_act_cfg(g.act, g.leaky);
+    plan->kernel = fn;
+    plan->ldsBytes = lds;
+    plan->grid = dim3(static_cast<unsigned>(p.tilesX) * p.segs * g.N, static_cast<unsigned>(g.OC / BN));
+    plan->dtype = SNNHIP_F16;
+    // weights: Wp[32-channel tile nt][tap][cc][lane = 32 hh + m] x 8 halfs {W[32 nt + m][16 cc + 8 hh + j][fy][fx]}
+    const int NT = g.OC / 32;
+    std::vector<float> wpk(static_cast<size_t>(NT) * 9 * ICS * 64 * 4, 0.0f);
+    _Float16* wph = reinterpret_cast<_Float16*>(wpk.data());
+    for (int oc = 0; oc < g.OC; ++oc)
+        for (int ic = 0; ic < g.IC; ++ic)
+            for (int t = 0; t < 9; ++t) {
+                const int nt = oc / 32, m = oc % 32, cc = ic / 16, hh = (ic % 16) / 8, j = ic % 8;
+                wph[(((static_cast<size_t>(nt) * 9 + t) * ICS + cc) * 64 + hh * 32 + m) * 8 + j] = static_cast<_Float16>(w_oihw[(static_cast<size_t>(oc) * g.IC + ic) * 9 + t]);
+            }
+    int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
+    if (rc == SNNHIP_OK) rc = plan->upload(epi4.data(), epi4.size(), &plan->d_epi);
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    plan->inDims[0] = g.N; plan->inDims[1] = p.srcH; plan->inDims[2] = p.srcW; plan->inDims[3] = g.IC;
+    plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
+    plan->flops = 2.0 * 9 * g.IC * g.OC * static_cast<double>(g.OH) * g.OW * g.N;
+    plan->bytes = 2.0 * (static_cast<double>(g.N) * p.srcH * p.srcW * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * 9);
+    char buf[320];
+    snprintf(buf, sizeof(buf), "conv2d_mfma_f16_32x32x16 k=3x3 s=2 ic=%d oc=%d row-marching strips=%dx32px x %doc (wave = 1 row x 32 oc, weights in registers) segments=%d x %d rows lds=%zuB",
+             g.IC, g.OC, TH, BN, p.segs, p.segRows, lds);
+    plan->desc = buf;
+    if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
+    if (g.preMode && g.preShift) plan->desc += " +upsample(x2)";
+    if (g.normShift) plan->desc = "instancenorm(act=" + std::to_string(g.normAct) + ", in the staging) -> " + plan->desc;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip

@@ -266,6 +266,63 @@ def test_fp16_rowfold_marching_strips_match_the_tile_kernel_and_the_oracle(ctx, 
     np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-3, atol=2e-3)
 
 
+S2M = [(1, 40, 70, 32, 64, "constant", "relu", ""), (2, 33, 61, 64, 128, "reflect", "", "2"), (1, 21, 130, 32, 128, "replicate", "leakyRelu", ""),
+       (1, 50, 37, 64, 256, "constant", "tanh", "3"), (2, 9, 9, 32, 64, "constant", "", ""), (1, 64, 64, 64, 128, "constant", "relu6", "")]
+
+
+@pytest.mark.parametrize("case", S2M, ids=lambda c: "x".join(map(str, c[:5])) + "_" + c[5] + "_segs" + (c[7] or "auto"))
+def test_fp16_stride2_marching_strips_match_the_oracle_and_the_tile_kernel(ctx, monkeypatch, case):
+    """conv2d_s2march.hip (forced: the default takes it on large maps only): ragged strips and last iterations, several row segments, several
+    output-channel blocks per strip (OC > 64 / 128), every padding mode, BN + activations -- against the quantised oracle and the 128-pixel kernel."""
+    N, H, W, IC, OC, pad_mode, act, segs = case
+    x = _rand((N, H, W, IC), 401)
+    w = _rand((OC, IC, 3, 3), 402, 1.0 / np.sqrt(IC * 9))
+    b = _rand((OC,), 403, 0.1)
+    bn = _bn(OC, 404) if act else None
+    pads = O.padding_offsets("same", 3)
+    monkeypatch.setenv("SNNHIP_CONV", "s2march")
+    if segs:
+        monkeypatch.setenv("SNNHIP_S2MARCH_SEGS", segs)
+    y, desc = _conv16(ctx, x, w, b, 2, pads, pad_mode, act, bn)
+    assert "s=2" in desc and "row-marching" in desc and (not segs or "segments=%s x" % segs in desc), desc
+    want = O._h(O.conv2d(O._h(x), O._h(w), b, 2, pads, pad_mode, act, 0.0, bn))
+    assert y.shape == want.shape
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOLH)
+    monkeypatch.setenv("SNNHIP_CONV", "mfma")
+    y2, desc2 = _conv16(ctx, x, w, b, 2, pads, pad_mode, act, bn)
+    assert "row-marching" not in desc2, desc2
+    np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("n,h,w,ic,oc,act", [(1, 40, 56, 32, 64, "relu"), (2, 37, 45, 64, 128, "relu"), (1, 25, 80, 32, 64, "leakyRelu")])
+def test_fp16_stride2_marching_with_fused_pad_and_instancenorm(ctx, monkeypatch, n, h, w, ic, oc, act):
+    """Graph rules D + I on the stride-2 strips: InstanceNorm -> reflect Pad -> Conv2D 3x3 stride 2 as the norm's statistics sweep + ONE convolution
+    launch that resolves the pad in its row / column look-ups and normalises what it stages: bit-identical to the separate launches."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_CONV", "s2march")
+    x = 1.5 * _rand((n, h, w, ic), 1) + 0.2
+    wt, b = _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9)), _rand((oc,), 3, 0.5)
+    beta, gamma = _rand((ic,), 4, 0.3), 1.0 + _rand((ic,), 5, 0.2)
+    norm = snn.instancenorm_plan(ctx, n, h, w, ic, beta, gamma, act=act, leaky=0.1)
+    pad = snn.pad_plan(ctx, n, h, w, ic, (1, 1, 1, 1), "reflect")
+    conv = snn.conv2d_plan(ctx, n, h + 2, w + 2, wt, b, stride=2, pads=(0, 0, 0, 0), act="relu", dtype=snn.F16)
+    assert "row-marching" in conv.describe(), conv.describe()
+    plans = [norm, pad, conv]
+    fused = snn.chain_plan(ctx, plans)
+    d = fused.describe()
+    assert fused.num_steps() == 1 and "in the staging" in d and "row-marching" in d and "+pad(reflect)" in d, d
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    y = fused(xt).numpy()
+    t = xt
+    for pl in plans:
+        t = pl(t)
+    np.testing.assert_array_equal(y, t.numpy())
+    ref = O.pad(O._h(O.instancenorm(O._h(x), beta, gamma, act, 0.1)), (1, 1, 1, 1), "reflect")
+    want = O._h(O.conv2d(ref, O._h(wt), b, 2, (0, 0, 0, 0), "constant", "relu", 0.0, None))
+    np.testing.assert_allclose(y, want, err_msg=d, rtol=6e-3, atol=6e-3)
+
+
 def test_fp16_rowfold_with_fused_reflect_pad(ctx):
     """Chain rule D on the row-fold kernel: Pad(reflect 4) -> Conv2D 9x9 "valid" 32 -> 3 (Candy's output layer) as one launch."""
     import shadernn_amd as snn

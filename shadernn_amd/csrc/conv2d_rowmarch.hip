@@ -376,7 +376,7 @@ int make_conv2d_rowmarch_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w
             const int rows = round_up(up_div(g.OH, s), kTH);
             const int segs = up_div(g.OH, rows);
             if (segs != s) continue; // (this s rounds to a segment count already tried)
-            if (s > 1 && rows < 3 * kTH) break;
+            if (s > 1 && rows < 3 * kTH && !forced) break;
             const double blocks = static_cast<double>(strips) * segs;
             const double eff = blocks / (std::ceil(blocks / slots) * slots) * rows / (rows + kTH);
             if ((forced && atoi(forced) == s) || (!forced && eff > bestEff + 1e-9)) {

@@ -281,7 +281,7 @@ int make_conv2d_s2march_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
             const int rows = round_up(up_div(g.OH, s), TH);
             const int segs = up_div(g.OH, rows);
             if (segs != s) continue;
-            if (s > 1 && rows < 24) break;
+            if (s > 1 && rows < 24 && !fs) break;
             const double blocks = static_cast<double>(strips) * segs;
             const double eff = blocks / (std::ceil(blocks / slots) * slots) * rows / (rows + 2 * TH + 2);
             if ((fs && atoi(fs) == s) || (!fs && eff > bestEff + 1e-9)) {

@@ -38,9 +38,17 @@ struct S2Params {
     ActCfg normAc;
 };
 
-constexpr int kCW = 65; // staged input columns of a 32-column output strip: 2 * 31 + 3
+// (a 32-column output strip stages input columns 0 .. 64: 2 * 31 + 3 of them)
+// The pixels of a ring row are DE-INTERLEAVED BY COLUMN PARITY: even columns 0, 2, .. 64 at pixel slots 0 .. 32, odd columns 1, 3, .. 63 at kOdd ..
+// kOdd + 31.  A stride-2 operand read (lane l32 -> column 2 l32 + fx) then walks CONSECUTIVE pixel slots of one plane: with the odd pixel pitch of
+// Q + 1 sixteen-byte slots the 16 lanes of a ds_read_b128 lane group hit 16 different bank slots.  (Interleaved, lane l32 sat at slot 2 (Q + 1) l32:
+// even slots only -- PMC of the first version: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE.)  kOdd * (Q + 1) = 4 (mod 8) keeps the eight
+// lanes of a staging ds_write_b128 group (two pixels x 4 slots for IC = 32) on distinct slots too.
+constexpr int kOdd = 36;
+constexpr int kRowPix = kOdd + 32; // pixel slots per ring row
+__host__ __device__ constexpr int pix_slot(int c) { return (c & 1) ? kOdd + (c >> 1) : (c >> 1); }
 
-template <int ICS /* IC / 16: 2 | 4 */, int WN /* 32-channel tiles per block: 2 | 4 */>
+template <int ICS /* IC / 16: 2 | 4 */, int WN /* 32-channel tiles per block: 2 | 4 */, int PF /* batches of rows in flight: 1 | 2 */>
 __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
                                                                 const float4* __restrict__ epi, _Float16* __restrict__ y) {
     constexpr int Q = 2 * ICS;          // 16-byte slots per pixel
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
     constexpr int TH = WR;
     constexpr int GR = 2 * TH;          // new input rows per iteration
     constexpr int RING = GR + 1;        // ring rows
-    constexpr int ROWF = kCW * QP * 4;  // floats per ring row
+    constexpr int ROWF = kRowPix * QP * 4;  // floats per ring row
     constexpr int EPR = 64 * Q;         // main staging elements per row (256 | 512)
     constexpr int RPR = 512 / EPR;      // rows per staging round (2 | 1)
     constexpr int NRND = GR / RPR;      // rounds per batch of GR rows (4)
@@ -95,16 +103,19 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
     };
     const int sxMain = resolve_col(c), sxLast = resolve_col(64);
     const int colOfs = max(sxMain, 0) * p.IC + 8 * sl, colOfsLast = max(sxLast, 0) * p.IC + 8 * sl;
-    const int ldsMain = (c * QP + sl) * 4, ldsLast = (64 * QP + sl) * 4; // + ring row * ROWF
+    const int ldsMain = (pix_slot(c) * QP + sl) * 4, ldsLast = (pix_slot(64) * QP + sl) * 4; // + ring row * ROWF
     const int rowLast = tid / Q;                                          // (threads 0..31) row of the batch their column-64 element sits in
     const bool nRelu = p.normAc.act == SNNHIP_ACT_RELU;
 
-    float4 v[NRND], vLast;
-    unsigned rowOkMask = 0;
-    bool lastOk = false;
-    int ringOf[NRND], ringLast = 0; // ring rows the batch in flight goes to
+    // a batch of GR rows in flight: the thread's NRND elements (+ its column-64 element), which of their rows exist, the ring rows they go to
+    struct Batch {
+        float4 v[NRND], vLast;
+        unsigned rowOkMask;
+        bool lastOk;
+        int ringOf[NRND], ringLast;
+    };
     // batch b = relative input rows GR b + 1 .. GR b + GR of the segment (b = -1: the rows up to row 0)
-    auto load_batch = [&](int b) {
+    auto load_batch = [&](int b, Batch& B) {
         const int r0 = GR * b + 1;
         int syv = resolve_nobranch(iyS + r0 + (lane & 7), p.H, p.padMode); // lane l resolves row l of the batch once, on the vector unit
         {
@@ -112,20 +123,20 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
             const int pre = syv < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
             syv = p.preMode ? pre : syv;
         }
-        rowOkMask = 0;
+        B.rowOkMask = 0;
 #pragma unroll
         for (int r = 0; r < NRND; ++r) {
             const int rr = r * RPR + rsub; // (wave-uniform)
             const int sy = __builtin_amdgcn_readlane(syv, rr);
-            rowOkMask |= static_cast<unsigned>(sy >= 0) << r;
-            ringOf[r] = ((r0 + rr) % RING + RING) % RING;
-            v[r] = *reinterpret_cast<const float4*>(xn + static_cast<size_t>(max(sy, 0)) * p.srcW * p.IC + colOfs);
+            B.rowOkMask |= static_cast<unsigned>(sy >= 0) << r;
+            B.ringOf[r] = ((r0 + rr) % RING + RING) % RING;
+            B.v[r] = *reinterpret_cast<const float4*>(xn + static_cast<size_t>(max(sy, 0)) * p.srcW * p.IC + colOfs);
         }
         if (tid < 32) {
             const int sy = __shfl(syv, rowLast); // (lanes 0..31 of wave 0)
-            lastOk = sy >= 0;
-            ringLast = ((r0 + rowLast) % RING + RING) % RING;
-            vLast = *reinterpret_cast<const float4*>(xn + static_cast<size_t>(max(sy, 0)) * p.srcW * p.IC + colOfsLast);
+            B.lastOk = sy >= 0;
+            B.ringLast = ((r0 + rowLast) % RING + RING) % RING;
+            B.vLast = *reinterpret_cast<const float4*>(xn + static_cast<size_t>(max(sy, 0)) * p.srcW * p.IC + colOfsLast);
         }
     };
     auto normalise = [&](float4& q) { // graph rule I on 8 staged channels 8 sl ..: half(act(x * mul + shift)) in fp32, the norm sweep's own arithmetic
@@ -143,38 +154,48 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
         }
         q = *reinterpret_cast<const float4*>(&hv);
     };
-    auto store_batch = [&]() { // normalise and write the batch in flight into its ring rows; padding stays zero
+    auto store_batch = [&](Batch& B) { // normalise and write a landed batch into its ring rows; padding stays zero
 #pragma unroll
         for (int r = 0; r < NRND; ++r) {
-            if (p.normShift) normalise(v[r]);
-            const bool live = ((rowOkMask >> r) & 1u) && sxMain >= 0;
-            const float4 o = make_float4(live ? v[r].x : 0.f, live ? v[r].y : 0.f, live ? v[r].z : 0.f, live ? v[r].w : 0.f);
-            *reinterpret_cast<float4*>(smem + ringOf[r] * ROWF + ldsMain) = o;
+            if (p.normShift) normalise(B.v[r]);
+            const bool live = ((B.rowOkMask >> r) & 1u) && sxMain >= 0;
+            const float4 o = make_float4(live ? B.v[r].x : 0.f, live ? B.v[r].y : 0.f, live ? B.v[r].z : 0.f, live ? B.v[r].w : 0.f);
+            *reinterpret_cast<float4*>(smem + B.ringOf[r] * ROWF + ldsMain) = o;
         }
         if (tid < 32) {
-            if (p.normShift) normalise(vLast);
-            const bool live = lastOk && sxLast >= 0;
-            const float4 o = make_float4(live ? vLast.x : 0.f, live ? vLast.y : 0.f, live ? vLast.z : 0.f, live ? vLast.w : 0.f);
-            *reinterpret_cast<float4*>(smem + ringLast * ROWF + ldsLast) = o;
+            if (p.normShift) normalise(B.vLast);
+            const bool live = B.lastOk && sxLast >= 0;
+            const float4 o = make_float4(live ? B.vLast.x : 0.f, live ? B.vLast.y : 0.f, live ? B.vLast.z : 0.f, live ? B.vLast.w : 0.f);
+            *reinterpret_cast<float4*>(smem + B.ringLast * ROWF + ldsLast) = o;
         }
     };
 
-    // ---- MFMA B operand (pixels): lane (l32, h) reads pixel 2 l32 + fx, slot 2 cc + h of a ring row: the lane part of the float offset
-    const int bofs = (2 * l32 * QP + h) * 4;
+    // ---- MFMA B operand (pixels): lane (l32, h) reads column 2 l32 + fx = pixel slot l32 (fx = 0), kOdd + l32 (fx = 1), l32 + 1 (fx = 2), channel
+    // slot 2 cc + h of a ring row: the lane part of the float offset (the tap part is an immediate)
+    const int bofs = (l32 * QP + h) * 4;
 
+    Batch b0, b1;
     __syncthreads(); // the norm table
-    load_batch(-1);
-    store_batch();
+    load_batch(-1, b0);
+    store_batch(b0);
     __syncthreads(); // (batch 0 overwrites the ring rows batch -1 used for the rows in front of the segment, from other threads)
-    load_batch(0);
-    store_batch();
+    load_batch(0, b0);
+    store_batch(b0);
+    // PF = 2: TWO batches stay in flight (the first version, one batch = 33 KB per CU, ran at the latency of its loads: ~5 us per iteration whatever
+    // the iteration computed); batch it + 1 was requested an iteration ago and is written to the ring now, batch it + 2 is requested first thing
+    if (PF == 2 && nIter > 1) load_batch(1, b1);
     __syncthreads();
 
     const float4* const et = epi + ocb + 32 * wn; // this wave's rows of the epilogue table {bias, bnScale, bnMean, bnBeta}
     const bool actSimple = act_is_simple_dev(ac.act);
-    for (int it = 0; it < nIter; ++it) {
+    // X: the batch written to the ring at the end of this iteration (rows of iteration it + 1); Y (PF = 2): the buffer the request for it + 2 goes to
+    auto iteration = [&](int it, Batch& X, Batch& Y) {
         const bool more = it + 1 < nIter;
-        if (more) load_batch(it + 1);
+        if (PF == 2) {
+            if (it + 2 < nIter) load_batch(it + 2, Y);
+        } else if (more) {
+            load_batch(it + 1, X);
+        }
 
         // ---- wave = output row TH it + wr: input rows GR it + 2 wr + fy
         f32x16 acc;
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
         // operand registers: a[cc] is dead once its MFMA has issued and is refilled for the next tap at once (the other MFMAs of the tap cover the
         // LDS round trip) -- one set of ICS operands, not two
         float4 a[ICS];
-        auto tap_ptr = [&](int t) { return smem + ((r0 + t / 3) % RING) * ROWF + bofs + (t % 3) * QP * 4; }; // tap t = 3 fy + fx
+        auto tap_ptr = [&](int t) { return smem + ((r0 + t / 3) % RING) * ROWF + bofs + pix_slot(t % 3) * QP * 4; }; // tap t = 3 fy + fx
         {
             const float* rowp = tap_ptr(0);
 #pragma unroll
@@ -224,8 +245,16 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
             if (oy < oyE && ox < p.OW)
                 *reinterpret_cast<float4*>(y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox) * p.OC + ocb + 8 * c8) = *reinterpret_cast<const float4*>(otile + pix * EP + 8 * c8);
         }
-        if (more) store_batch();
+        if (more) store_batch(X);
         __syncthreads();
+    };
+    if (PF == 2) {
+        for (int it = 0; it < nIter; it += 2) { // (two iterations per trip: the batch buffers alternate without run-time register indexing)
+            iteration(it, b1, b0);
+            if (it + 1 < nIter) iteration(it + 1, b0, b1);
+        }
+    } else {
+        for (int it = 0; it < nIter; ++it) iteration(it, b0, b0);
     }
 }
 
@@ -296,8 +325,8 @@ int make_conv2d_s2march_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     p.normShift = g.normShift; p.normMul = g.normMul;
     p.normAc = make_act_cfg(g.normShift ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
     const int QP = 2 * ICS + 1, RING = 2 * TH + 1;
-    const size_t lds = static_cast<size_t>(RING) * kCW * QP * 16 + static_cast<size_t>(TH) * 32 * (BN + 8) * 2 + 2 * static_cast<size_t>(g.IC) * 4;
-    auto fn = g.IC == 32 ? conv2d_s2march_kernel<2, 2> : conv2d_s2march_kernel<4, 4>;
+    const size_t lds = static_cast<size_t>(RING) * kRowPix * QP * 16 + static_cast<size_t>(TH) * 32 * (BN + 8) * 2 + 2 * static_cast<size_t>(g.IC) * 4;
+    auto fn = g.IC == 32 ? conv2d_s2march_kernel<2, 2, 2> : conv2d_s2march_kernel<4, 4, 1>; // (64 input channels: 144 weight registers leave no room for a second batch)
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("conv2d_s2march: hipFuncSetAttribute(%zu) failed", lds);
         return SNNHIP_E_HIP;

@@ -182,6 +182,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
     store_group(1);
     __syncthreads();
 
+    // the epilogue rows {bias, bnScale, bnMean, bnBeta} of the OC channels, read once (wave-uniform: they live in SGPRs); indexed inside the loop they
+    // were re-loaded every iteration, twelve scalar loads each waited out
+    float4 eR[OC];
+#pragma unroll
+    for (int k = 0; k < OC; ++k) eR[k] = epi[k];
     const size_t rowHalfs = static_cast<size_t>(p.OW) * OC;
     const int validCols = min(TW, p.OW - ox0);
     for (int it = 0; it < nIter; ++it) {
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                 if (!h1) {
 #pragma unroll
                     for (int k = 0; k < OC; ++k) {
-                        float r = epi_affine(tot[k], epi[k], p.useBN);
+                        float r = epi_affine(tot[k], eR[k], p.useBN);
                         r = actSimple ? __builtin_amdgcn_fmed3f(fmaxf(r, r * ac.alpha), ac.lo, ac.hi) : epi_act(ac.act, ac.leaky, r, 0.0f);
                         line[(t * 32 + l32) * OC + k] = static_cast<_Float16>(r);
                     }

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* const otile = reinterpret_cast<_Float16*>(smem + RING * ROWF);                         // [TH][32][EP] halfs
     float* const normTab = smem + RING * ROWF + (TH * 32 * EP) / 2;                                  // [2][IC] shift, mul of this block's image
+    float* const epiTab = normTab + 2 * 64;                                                          // [2][BN] scale, shift of this block's channels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
     const int wr = wave / WN, wn = wave % WN;
     const int bx = blockIdx.x;
@@ -84,6 +85,14 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int cc = 0; cc < ICS; ++cc) wq[t][cc] = wt[(t * ICS + cc) * 64];
+    }
+    // epilogue folded to one fma per value, act(acc * scale + shift): scale = bnScale (1 without BN), shift = bnScale * (bias - bnMean) + bnBeta (bias).
+    // The table sits in LDS: read per channel from global memory inside the loop (16 dependent loads per iteration, each behind an s_waitcnt vmcnt(0)
+    // that also drained the row prefetch) the first version spent ~4 us per iteration on it -- its whole run time.
+    if (tid < BN) {
+        const float4 e4 = epi[ocb + tid];
+        epiTab[tid] = p.useBN ? e4.y : 1.0f;
+        epiTab[BN + tid] = p.useBN ? fmaf(e4.y, e4.x - e4.z, e4.w) : e4.x;
     }
     if (p.normShift)
         for (int i = tid; i < p.IC; i += 512) {
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
     if (PF == 2 && nIter > 1) load_batch(1, b1);
     __syncthreads();
 
-    const float4* const et = epi + ocb + 32 * wn; // this wave's rows of the epilogue table {bias, bnScale, bnMean, bnBeta}
+    const float* const et = epiTab + 32 * wn + 4 * h; // this lane's channel runs: 8 g + 4 h + k of the wave's 32-channel tile
     const bool actSimple = act_is_simple_dev(ac.act);
     // X: the batch written to the ring at the end of this iteration (rows of iteration it + 1); Y (PF = 2): the buffer the request for it + 2 goes to
     auto iteration = [&](int it, Batch& X, Batch& Y) {
@@ -225,10 +234,12 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
         // ---- epilogue into the LDS tile: acc[4 g + k] = channel ocb + 32 wn + 8 g + 4 h + k of pixel l32 of row wr
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            const float4 sc = *reinterpret_cast<const float4*>(et + 8 * g), sh = *reinterpret_cast<const float4*>(et + BN + 8 * g);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
             h4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float r = epi_affine(acc[4 * g + k], et[8 * g + 4 * h + k], p.useBN);
+                float r = fmaf(acc[4 * g + k], scv[k], shv[k]);
                 r = actSimple ? __builtin_amdgcn_fmed3f(fmaxf(r, r * ac.alpha), ac.lo, ac.hi) : epi_act(ac.act, ac.leaky, r, 0.0f);
                 o[k] = static_cast<_Float16>(r);
             }
@@ -325,7 +336,7 @@ int make_conv2d_s2march_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     p.normShift = g.normShift; p.normMul = g.normMul;
     p.normAc = make_act_cfg(g.normShift ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
     const int QP = 2 * ICS + 1, RING = 2 * TH + 1;
-    const size_t lds = static_cast<size_t>(RING) * kRowPix * QP * 16 + static_cast<size_t>(TH) * 32 * (BN + 8) * 2 + 2 * static_cast<size_t>(g.IC) * 4;
+    const size_t lds = static_cast<size_t>(RING) * kRowPix * QP * 16 + static_cast<size_t>(TH) * 32 * (BN + 8) * 2 + 2 * 64 * 4 + 2 * static_cast<size_t>(BN) * 4;
     auto fn = g.IC == 32 ? conv2d_s2march_kernel<2, 2, 2> : conv2d_s2march_kernel<4, 4, 1>; // (64 input channels: 144 weight registers leave no room for a second batch)
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("conv2d_s2march: hipFuncSetAttribute(%zu) failed", lds);

@@ -44,6 +44,11 @@ struct S2Params {
 // Q + 1 sixteen-byte slots the 16 lanes of a ds_read_b128 lane group hit 16 different bank slots.  (Interleaved, lane l32 sat at slot 2 (Q + 1) l32:
 // even slots only -- PMC of the first version: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE.)  kOdd * (Q + 1) = 4 (mod 8) keeps the eight
 // lanes of a staging ds_write_b128 group (two pixels x 4 slots for IC = 32) on distinct slots too.
+#ifdef SNNHIP_S2_TRACE // experiment builds (tools/exp_one.sh): block 0 prints the s_memtime stamps of its phases for a few iterations
+#define S2_MARK(i) do { if (trace) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define S2_MARK(i) do { } while (0)
+#endif
 constexpr int kOdd = 36;
 constexpr int kRowPix = kOdd + 32; // pixel slots per ring row
 __host__ __device__ constexpr int pix_slot(int c) { return (c & 1) ? kOdd + (c >> 1) : (c >> 1); }
@@ -198,14 +203,20 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
     const float* const et = epiTab + 32 * wn + 4 * h; // this lane's channel runs: 8 g + 4 h + k of the wave's 32-channel tile
     const bool actSimple = act_is_simple_dev(ac.act);
     // X: the batch written to the ring at the end of this iteration (rows of iteration it + 1); Y (PF = 2): the buffer the request for it + 2 goes to
+#ifdef SNNHIP_S2_TRACE
+    const bool trace = blockIdx.x == 3 && blockIdx.y == 0 && (tid == 0 || tid == 448);
+    unsigned long long tstamp[8] = {};
+#endif
     auto iteration = [&](int it, Batch& X, Batch& Y) {
         const bool more = it + 1 < nIter;
+        S2_MARK(0);
         if (PF == 2) {
             if (it + 2 < nIter) load_batch(it + 2, Y);
         } else if (more) {
             load_batch(it + 1, X);
         }
 
+        S2_MARK(1);
         // ---- wave = output row TH it + wr: input rows GR it + 2 wr + fy
         f32x16 acc;
 #pragma unroll
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
             }
         }
 
+        S2_MARK(2);
         // ---- epilogue into the LDS tile: acc[4 g + k] = channel ocb + 32 wn + 8 g + 4 h + k of pixel l32 of row wr
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -245,7 +257,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
             }
             *reinterpret_cast<h4*>(otile + (wr * 32 + l32) * EP + 32 * wn + 8 * g + 4 * h) = o;
         }
+        S2_MARK(3);
         __syncthreads(); // the tile is complete, and every wave is done with the ring rows that retire
+        S2_MARK(4);
 
         // ---- the tile leaves as 16-byte vectors, a pixel's BN channels contiguous
 #pragma unroll
@@ -256,8 +270,16 @@ __global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActC
             if (oy < oyE && ox < p.OW)
                 *reinterpret_cast<float4*>(y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox) * p.OC + ocb + 8 * c8) = *reinterpret_cast<const float4*>(otile + pix * EP + 8 * c8);
         }
+        S2_MARK(5);
         if (more) store_batch(X);
+        S2_MARK(6);
         __syncthreads();
+        S2_MARK(7);
+#ifdef SNNHIP_S2_TRACE
+        if (trace && it >= 4 && it < 8)
+            printf("s2trace tid %d it %d: loads %llu mfma %llu epi %llu bar1 %llu stores %llu batch %llu bar2 %llu total %llu\n", tid, it, tstamp[1] - tstamp[0],
+                   tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4], tstamp[6] - tstamp[5], tstamp[7] - tstamp[6], tstamp[7] - tstamp[0]);
+#endif
     };
     if (PF == 2) {
         for (int it = 0; it < nIter; it += 2) { // (two iterations per trip: the batch buffers alternate without run-time register indexing)

@@ -9,6 +9,7 @@
 #     profx:<name>:<command>           the same passes around an arbitrary command ('+' stands for a blank)   -> <tag>_<name>/summary.md
 #     layers[:fp16]                    tools/bench_layers.py                                               -> layers[_fp16].txt
 #     py:<script>[:args]               python tools/<script> args ('+' stands for a blank)                 -> py_<n>.txt
+#     lib:<tag>                        load build/abl/libsnnhip_<tag>.so in the following actions ('lib:' = the product library again)
 #     env:NAME=VALUE                   export for the following actions
 cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${1:-run}; shift
@@ -44,6 +45,7 @@ for act in "$@"; do
       grep "derived" -A12 "$O/profile_$nm.log" | cut -c1-600 | head -16 ;;
     layers)
       timeout 600 python tools/bench_layers.py ${arg:+--$arg} > "$O/layers${arg:+_$arg}.txt" 2>/dev/null; tail -40 "$O/layers${arg:+_$arg}.txt" ;;
+    lib) export SNNHIP_LIB_PATH="$GRAFT_REPO_ROOT/build/abl/libsnnhip_$arg.so"; [ -z "$arg" ] && unset SNNHIP_LIB_PATH ;;   # lib:<tag> = an experiment build (tools/exp_one.sh), lib: = back to the product library
     py)
       s=${arg%%:*}; a=""; [ "$s" != "$arg" ] && a=${arg#*:}
       timeout 1200 python "tools/$s" ${a//+/ } > "$O/py_$n.txt" 2>&1; tail -60 "$O/py_$n.txt" ;;

@@ -278,9 +278,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                 if (!h1) {
 #pragma unroll
                     for (int k = 0; k < OC; ++k) {
-                        float r = epi_affine(tot[k], eR[k], p.useBN);
-                        r = actSimple ? __builtin_amdgcn_fmed3f(fmaxf(r, r * ac.alpha), ac.lo, ac.hi) : epi_act(ac.act, ac.leaky, r, 0.0f);
-                        line[(t * 32 + l32) * OC + k] = static_cast<_Float16>(r);
+                        tot[k] = epi_affine(tot[k], eR[k], p.useBN);
+                    }
+                    if (actSimple) { // (tested once per row tile, not per value: a branch is a pipeline drain)
+#pragma unroll
+                        for (int k = 0; k < OC; ++k) tot[k] = __builtin_amdgcn_fmed3f(fmaxf(tot[k], tot[k] * ac.alpha), ac.lo, ac.hi);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < OC; ++k) tot[k] = epi_act(ac.act, ac.leaky, tot[k], 0.0f);
+                    }
+#pragma unroll
+                    for (int k = 0; k < OC; ++k) {
+                        line[(t * 32 + l32) * OC + k] = static_cast<_Float16>(tot[k]);
                     }
                 }
             }

@@ -436,6 +436,8 @@ def pmc_entry(pmc, desc, tags):
         want = ("conv2d_stem_kernel", [])
     elif "conv2d_mfma_stem_f32" in core and m:
         want = ("conv2d_stem32_kernel", [int(m.group(1)), int(m.group(2))])
+    elif "conv2d_mfma_upconv" in core and m:
+        want = ("conv2d_upconv_kernel", [int(m.group(3)) // 16])
     elif "s=2" in core and "row-marching" in core and m:
         want = ("conv2d_s2march_kernel", [int(m.group(3)) // 16])
     elif "conv2d_rowfold" in core and "row-marching" in core and m:

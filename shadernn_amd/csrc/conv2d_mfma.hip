@@ -454,6 +454,18 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_stem32_plan(ctx, g, w_oihw, epi4, out);
         if (rc != SNNHIP_E_UNSUPPORTED) return rc;
     }
+    // fp16 nearest x2 UpSampling -> reflect Pad(1) -> 3x3 (rule D's fused geometry): 4 phases x 2x2 taps on the low-resolution tensor (conv2d_upconv.hip;
+    // SNNHIP_CONV=upconv forces it for every eligible shape, SNNHIP_CONV_UPCONV=0 keeps the 9-tap kernels)
+    if (g.preShift == 1) {
+        const char* force = snnhip::option("SNNHIP_CONV");
+        const char* w = snnhip::option("SNNHIP_CONV_UPCONV");
+        const bool forced = force && strcmp(force, "upconv") == 0;
+        const bool allowed = !force && !(w && atoi(w) == 0) && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_SPLITK") && !snnhip::option("SNNHIP_CONV_C8");
+        if (forced || allowed) {
+            const int rc = make_conv2d_upconv_plan(ctx, g, w_oihw, epi4, out);
+            if (rc != SNNHIP_E_UNSUPPORTED) return rc;
+        }
+    }
     // fp16 3x3 stride-1 layers on large maps: the 4 x 2 register-block kernel of conv2d_wide_f16.hip (SNNHIP_CONV=wide forces it for every
     // eligible shape, SNNHIP_CONV=mfma / SNNHIP_CONV_WIDE=0 keep the 128-pixel kernel)
     {

@@ -54,7 +54,7 @@ constexpr int kRowPix = kOdd + 32; // pixel slots per ring row
 __host__ __device__ constexpr int pix_slot(int c) { return (c & 1) ? kOdd + (c >> 1) : (c >> 1); }
 
 template <int ICS /* IC / 16: 2 | 4 */, int WN /* 32-channel tiles per block: 2 | 4 */, int PF /* batches of rows in flight: 1 | 2 */>
-__global__ __launch_bounds__(512, 1) void conv2d_s2march_kernel(S2Params p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
+__global__ __launch_bounds__(512, 2) void conv2d_s2march_kernel(S2Params p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
                                                                 const float4* __restrict__ epi, _Float16* __restrict__ y) {
     constexpr int Q = 2 * ICS;          // 16-byte slots per pixel
     constexpr int QP = Q + 1;           // ... and its pitch in LDS

@@ -1,0 +1,352 @@
+// conv2d_upconv.hip -- fp16 "up-convolution" of the fast-neural-style networks (BASELINE configs[4]): nearest x2 UpSampling2D -> reflect Pad(1) ->
+// Conv2D 3x3 stride 1 (64 -> 32 and 128 -> 64 channels in the zoo graph), evaluated on the LOW-RESOLUTION tensor.
+//
+// Round 2 ran these layers on conv2d_wide_f16 with the upsampling and the pad resolved in its staging addresses (rule D): 1103 + 870 us per 16
+// images at 0.24 / 0.33 of the fp16 matrix peak, the two most expensive kernels of the graph.  That form multiplies every low-resolution pixel 9 x 4
+// times.  But a 3x3 window over a x2-replicated image only ever sees a 2x2 block of DIFFERENT low-resolution pixels: for output pixel
+// (2m + py, 2q + px) -- phase (py, px) of low-resolution position (m, q) -- the three rows of the window are rows {m-1, m, m} (py = 0) or
+// {m, m, m+1} (py = 1) of the low-resolution tensor L, and the same for the columns.  So
+//     out[2m + py][2q + px][oc] = sum_{a, b in {0,1}} sum_ic  Wp[py][px][a][b][oc][ic] * L[clamp(m - 1 + py + a)][clamp(q - 1 + px + b)][ic]
+// with Wp the kernel taps that fall on the same low-resolution pixel ADDED UP (in fp32, then rounded to half once): 4 taps instead of 9 -- 2.25x
+// fewer MFMAs and operand reads -- and the staged tile is the low-resolution halo tile (read once, not 4x replicated).  The reflect pad of 1 around
+// the upsampled image is exactly a clamp of the low-resolution coordinate.  The reference's size rule keeps the PADDED extent as the output extent
+// (2H + 2) with zeros beyond it: the last two output rows / columns see fewer taps.  They are the phases of ONE extra low-resolution row
+// m = H (column q = W) with their own pre-summed weights (the taps that fall outside dropped) -- four weight classes (bulk / last row x bulk /
+// last column), chosen per block.  Same operator contract otherwise (vk_upsampling2d_nearest.comp:43, padlayer.cpp:27-67,
+// shadertemplate_vk_conv2d.comp:148-347: bias -> BN -> activation).
+//
+//   * block = one 32-column strip of the low-resolution grid of one image, marching down a segment of its rows 2 per iteration (= a 4 x 64 output
+//     tile); LDS ring of 4 low-resolution rows (34 pixels x IC halfs, pixel pitch odd in 16-byte slots: conflict-free operand reads); the rows of
+//     iteration it + 1 are requested while iteration it computes;
+//   * wave = one phase (x one 32-channel tile): its 4 taps x IC/16 weight operands stay in registers for the whole strip (64 / 128 VGPRs), the 32
+//     low-resolution pixels of a row are the MFMA's B operand; 8 IC/16 MFMAs per wave and iteration on two independent accumulators;
+//   * the 4 x 64 x OC output tile leaves through LDS as 16-byte channel-contiguous vectors.
+#include <cstring>
+#include <vector>
+
+#include "epilogue.h"
+#include "snnhip_internal.h"
+
+namespace snnhip {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+struct UpParams {
+    int N, srcH, srcW, IC, OC, OH, OW, useBN;
+    int tilesX, segs, segRows; // strips of 32 low-resolution columns (+ 1 for column W), row segments per strip (+ 1 for row H), rows per segment (even)
+};
+
+constexpr int kTP = 34; // staged pixels per low-resolution row: the strip's 32 + one on either side
+
+template <int ICS /* IC / 16: 4 | 8 */, int WNT /* 32-channel tiles per block: 1 | 2 */>
+__global__ __launch_bounds__(256 * WNT, WNT == 1 ? 3 : 2) void conv2d_upconv_kernel(UpParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
+                                                                                  const float4* __restrict__ epi, _Float16* __restrict__ y) {
+    constexpr int Q = 2 * ICS, QP = Q + 1;   // 16-byte slots per pixel, and its (odd) pitch in LDS
+    constexpr int MT = 2;                     // low-resolution rows per iteration
+    constexpr int ROWF = kTP * QP * 4;        // floats per ring row
+    constexpr int T = 256 * WNT;              // threads
+    constexpr int BN = 32 * WNT, EP = BN + 8; // output channels per block; halfs per pixel of the output tile in LDS
+    constexpr int EB = MT * kTP * Q;          // 16-byte elements per batch of MT rows
+    constexpr int NR = (EB + T - 1) / T;      // staging rounds per batch (3)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* const otile = reinterpret_cast<_Float16*>(smem + 4 * ROWF); // [2 MT][64][EP] halfs
+    float* const epiTab = smem + 4 * ROWF + (2 * MT * 64 * EP) / 2;       // [2][BN] scale, shift of this block's channels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int phase = wave & 3, py = phase >> 1, px = phase & 1, nt = wave >> 2;
+    const int bx = blockIdx.x;
+    const int nseg = p.segs + 1;
+    const int sg = bx % nseg, tx = (bx / nseg) % p.tilesX, n = bx / (nseg * p.tilesX);
+    const bool lastRow = sg == p.segs, lastCol = tx == p.tilesX - 1;
+    const int m0 = lastRow ? p.srcH : sg * p.segRows, mEnd = lastRow ? p.srcH + 1 : min(p.srcH, m0 + p.segRows);
+    const int q0 = lastCol ? p.srcW : 32 * tx, qEnd = lastCol ? p.srcW + 1 : min(p.srcW, q0 + 32);
+    const int nIter = (mEnd - m0 + MT - 1) / MT;
+    const int ocb = blockIdx.y * BN;
+    const int wclass = (lastRow ? 2 : 0) + (lastCol ? 1 : 0);
+
+    // ---- this wave's weights (the MFMA's A operand): wq[a][b][cc] = 8 halfs {Wp[class][py][px][a][b][ocb + 32 nt + l32][16 cc + 8 h + j]}
+    float4 wq[2][2][ICS];
+    {
+        const int ntg = blockIdx.y * WNT + nt, NT = p.OC / 32;
+        const float4* wt = wp + ((static_cast<size_t>(wclass) * NT + ntg) * 4 + phase) * (4 * ICS * 64) + lane;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int cc = 0; cc < ICS; ++cc) wq[a][b][cc] = wt[((a * 2 + b) * ICS + cc) * 64];
+    }
+    // epilogue folded to one fma per value, act(acc * scale + shift) (conv2d_s2march.hip)
+    if (tid < BN) {
+        const float4 e4 = epi[ocb + tid];
+        epiTab[tid] = p.useBN ? e4.y : 1.0f;
+        epiTab[BN + tid] = p.useBN ? fmaf(e4.y, e4.x - e4.z, e4.w) : e4.x;
+    }
+
+    // ---- staging map of a batch of MT rows: element e = tid + T r -> row e / (34 Q), pixel, slot; the same for every batch
+    const _Float16* xn = x + static_cast<size_t>(n) * p.srcH * p.srcW * p.IC;
+    int colOfs[NR], ldsOfs[NR];
+    unsigned rowBits = 0, liveBits = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = min(tid + T * r, EB - 1); // (elements past the batch re-read its last one and are not stored)
+        const int row = e / (kTP * Q), rem = e - row * (kTP * Q);
+        const int pxl = rem / Q, sl = rem - pxl * Q;
+        const int sx = min(max(q0 - 1 + pxl, 0), p.srcW - 1); // the reflect pad of the upsampled image = a clamp down here
+        colOfs[r] = sx * p.IC + 8 * sl;
+        ldsOfs[r] = (row & 1) * ROWF + (pxl * QP + sl) * 4;
+        rowBits |= static_cast<unsigned>(row & 1) << r;
+        liveBits |= static_cast<unsigned>(tid + T * r < EB) << r;
+    }
+    static_assert(NR == 3, "three staging rounds per batch");
+    float4 v0, v1, v2; // (named registers: as an array captured by the two lambdas below the rows in flight ended up in scratch memory)
+    v0 = v1 = v2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_one = [&](int r, int sy0, int sy1) {
+        const int sy = ((rowBits >> r) & 1u) ? sy1 : sy0;
+        return *reinterpret_cast<const float4*>(xn + static_cast<size_t>(sy) * p.srcW * p.IC + colOfs[r]);
+    };
+    auto load_batch = [&](int b) { // batch b = relative rows 2 b, 2 b + 1 (relative row r = low-resolution row m0 - 1 + r, clamped)
+        const int sy0 = min(max(m0 - 1 + 2 * b, 0), p.srcH - 1), sy1 = min(max(m0 + 2 * b, 0), p.srcH - 1);
+        v0 = load_one(0, sy0, sy1);
+        v1 = load_one(1, sy0, sy1);
+        v2 = load_one(2, sy0, sy1);
+    };
+    auto store_batch = [&](int b) { // into ring rows 2 (b & 1), 2 (b & 1) + 1
+        float* const dst = smem + (b & 1) * 2 * ROWF;
+        if (liveBits & 1u) *reinterpret_cast<float4*>(dst + ldsOfs[0]) = v0;
+        if (liveBits & 2u) *reinterpret_cast<float4*>(dst + ldsOfs[1]) = v1;
+        if (liveBits & 4u) *reinterpret_cast<float4*>(dst + ldsOfs[2]) = v2;
+    };
+
+    // ---- MFMA B operand (low-resolution pixels): lane (l32, h), phase column px: pixel l32 + px + b, slot 2 cc + h of a ring row
+    const int bofs = ((l32 + px) * QP + h) * 4;
+
+    load_batch(0);
+    store_batch(0);
+    load_batch(1);
+    store_batch(1);
+    __syncthreads();
+
+    const float* const et = epiTab + 32 * nt + 4 * h; // this lane's channel runs: 8 g + 4 h + k of the wave's 32-channel tile
+    const bool actSimple = act_is_simple_dev(ac.act);
+    for (int it = 0; it < nIter; ++it) {
+        const bool more = it + 1 < nIter;
+        if (more) load_batch(it + 2);
+
+        // ---- wave = phase (py, px) of low-resolution rows MT it, MT it + 1: row j takes taps a = 0, 1 from relative rows MT it + j + py + a
+        f32x16 acc[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+        const int rb = __builtin_amdgcn_readfirstlane(MT * it + py);
+        // steps s = (ri, b, cc): operand of relative row rb + ri, pixel column px + b, channel step cc; it feeds row j = ri with tap a = 0 and row
+        // j = ri - 1 with tap a = 1.  The operand of step s + 1 is requested before the MFMAs of step s.
+        constexpr int NS = 3 * 2 * ICS;
+        float4 bop[2];
+        auto read_step = [&](int s, float4& dst) {
+            const int ri = s / (2 * ICS), b = (s / ICS) % 2, cc = s % ICS;
+            dst = *reinterpret_cast<const float4*>(smem + ((rb + ri) & 3) * ROWF + bofs + (b * QP + 2 * cc) * 4);
+        };
+        read_step(0, bop[0]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + 1 < NS) read_step(s + 1, bop[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ri = s / (2 * ICS), b = (s / ICS) % 2, cc = s % ICS;
+            if (ri < MT) acc[ri] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&wq[0][b][cc]), *reinterpret_cast<const h8*>(&bop[s & 1]), acc[ri], 0, 0, 0);
+            if (ri >= 1) acc[ri - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&wq[1][b][cc]), *reinterpret_cast<const h8*>(&bop[s & 1]), acc[ri - 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue into the LDS tile: acc[j][4 g + k] = channel ocb + 32 nt + 8 g + 4 h + k of output pixel (2 j + py, 2 l32 + px) of the tile
+        // (one channel run of 4 at a time: holding all 32 table values of the lane next to the weights, both accumulators and the rows in flight made the
+        // compiler park the prefetched rows in scratch memory -- behind an s_waitcnt vmcnt(0) right after their loads)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 sh = *reinterpret_cast<const float4*>(et + BN + 8 * g);
+            float4 sc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            if (p.useBN) sc = *reinterpret_cast<const float4*>(et + 8 * g);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+            float rv[MT][4];
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rv[j][k] = fmaf(acc[j][4 * g + k], scv[k], shv[k]);
+            if (actSimple) { // (tested per channel run, not per value: a branch is a pipeline drain)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rv[j][k] = __builtin_amdgcn_fmed3f(fmaxf(rv[j][k], rv[j][k] * ac.alpha), ac.lo, ac.hi);
+            } else {
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rv[j][k] = epi_act(ac.act, ac.leaky, rv[j][k], 0.0f);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                h4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(rv[j][k]);
+                *reinterpret_cast<h4*>(otile + ((2 * j + py) * 64 + 2 * l32 + px) * EP + 32 * nt + 8 * g + 4 * h) = o;
+            }
+        }
+        __syncthreads(); // the tile is complete, and every wave is done with the ring rows that retire
+
+        // ---- the 4 x 64 tile leaves as 16-byte vectors, a pixel's BN channels contiguous
+        const int mIt = m0 + MT * it;
+#pragma unroll
+        for (int q = 0; q < (2 * MT * 64 * (BN / 8)) / T; ++q) {
+            const int vi = tid + T * q;
+            const int pix = vi / (BN / 8), c8 = vi % (BN / 8);
+            const int orow = pix >> 6, ocol = pix & 63;
+            if (mIt + (orow >> 1) < mEnd && q0 + (ocol >> 1) < qEnd)
+                *reinterpret_cast<float4*>(y + ((static_cast<size_t>(n) * p.OH + 2 * mIt + orow) * p.OW + 2 * q0 + ocol) * p.OC + ocb + 8 * c8) =
+                    *reinterpret_cast<const float4*>(otile + pix * EP + 8 * c8);
+        }
+        if (more) store_batch(it + 2);
+        __syncthreads();
+    }
+}
+
+struct UpconvPlan : ConvPlanBase {
+    UpParams p;
+    ActCfg ac;
+    float* d_w = nullptr;
+    float* d_epi = nullptr;
+    size_t ldsBytes = 0;
+    dim3 grid, block;
+    void (*kernel)(UpParams, ActCfg, const _Float16*, const float4*, const float4*, _Float16*) = nullptr;
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == p.IC, "conv2d: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h,
+                       x->w, x->c, p.N, p.srcH, p.srcW, p.IC);
+        SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n,
+                       out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
+        hipLaunchKernelGGL(kernel, grid, block, ldsBytes, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
+                           reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+// kernel rows (columns) of the 3-tap window that fall on low-resolution row m - 1 + py + a, for the bulk and for the extra last row m = H (whose
+// window reaches past the padded extent: those taps are dropped)
+void tap_set(int py, int a, bool last, int out[3], int* n) {
+    *n = 0;
+    if (!last) {
+        if (py == 0 && a == 0) out[(*n)++] = 0;
+        if (py == 0 && a == 1) { out[(*n)++] = 1; out[(*n)++] = 2; }
+        if (py == 1 && a == 0) { out[(*n)++] = 0; out[(*n)++] = 1; }
+        if (py == 1 && a == 1) out[(*n)++] = 2;
+    } else { // output rows 2H (py = 0: window rows 2H, 2H + 1 exist) and 2H + 1 (py = 1: only row 2H + 1)
+        if (py == 0 && a == 0) out[(*n)++] = 0;
+        if (py == 0 && a == 1) out[(*n)++] = 1;
+        if (py == 1 && a == 0) out[(*n)++] = 0;
+    }
+}
+
+} // namespace
+
+// Tried by make_conv2d_mfma_plan (conv2d_mfma.hip) in front of conv2d_wide_f16; SNNHIP_E_UNSUPPORTED hands the layer on.
+int make_conv2d_upconv_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
+    const char* force = snnhip::option("SNNHIP_CONV");
+    const bool forced = force && strcmp(force, "upconv") == 0;
+    // exactly: nearest x2 upsampling -> reflect pad 1 -> 3x3 stride 1, no padding of its own, output extent = the padded extent (size rule Q20)
+    if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 1 || g.sw != 1 || g.preShift != 1 || g.preMode != SNNHIP_PAD_REFLECT || g.preX != 1 || g.preY != 1)
+        return SNNHIP_E_UNSUPPORTED;
+    if (g.padx != 0 || g.pady != 0 || g.H != 2 * g.srcH + 2 || g.W != 2 * g.srcW + 2 || g.OH != g.H || g.OW != g.W || g.normShift || g.addAct >= 0) return SNNHIP_E_UNSUPPORTED;
+    if ((g.IC != 64 && g.IC != 128) || g.srcH < 2 || g.srcW < 2 || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED;
+    const int ICS = g.IC / 16, WNT = g.IC == 64 ? 1 : 2, BN = 32 * WNT;
+    if (g.OC % BN != 0) return SNNHIP_E_UNSUPPORTED;
+    if (static_cast<double>(g.N) * g.OH * g.OW * g.OC >= 2147483647.0 * 4 || static_cast<double>(g.N) * g.srcH * g.srcW * g.IC >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
+    UpParams p = {};
+    p.N = g.N; p.srcH = g.srcH; p.srcW = g.srcW; p.IC = g.IC; p.OC = g.OC; p.OH = g.OH; p.OW = g.OW; p.useBN = g.useBN;
+    p.tilesX = up_div(g.srcW, 32) + 1;
+    const int slots = std::max(1, ctx->props.multiProcessorCount) * (WNT == 1 ? 3 : 1), strips = g.N * p.tilesX * (g.OC / BN);
+    if (!forced && (g.srcH < 24 || static_cast<long>(strips) * up_div(g.srcH, 48) < ctx->props.multiProcessorCount)) return SNNHIP_E_UNSUPPORTED;
+    {
+        const char* fs = snnhip::option("SNNHIP_UPCONV_SEGS");
+        int bestSegs = 1;
+        double bestEff = -1.0;
+        for (int s = 1; s <= 64; ++s) {
+            const int rows = round_up(up_div(g.srcH, s), 2);
+            const int segs = up_div(g.srcH, rows);
+            if (segs != s) continue;
+            if (s > 1 && rows < 16 && !fs) break;
+            const double blocks = static_cast<double>(strips) * (segs + 1);
+            const double eff = blocks / (std::ceil(blocks / slots) * slots) * rows / (rows + 4);
+            if ((fs && atoi(fs) == s) || (!fs && eff > bestEff + 1e-9)) {
+                bestEff = eff;
+                bestSegs = segs;
+                if (fs) break;
+            }
+        }
+        p.segRows = round_up(up_div(g.srcH, bestSegs), 2);
+        p.segs = up_div(g.srcH, p.segRows);
+    }
+    const int QP = 2 * ICS + 1;
+    const size_t lds = static_cast<size_t>(4) * kTP * QP * 16 + static_cast<size_t>(4) * 64 * (BN + 8) * 2 + 2 * static_cast<size_t>(BN) * 4;
+    auto fn = g.IC == 64 ? conv2d_upconv_kernel<4, 1> : conv2d_upconv_kernel<8, 2>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+        set_error("conv2d_upconv: hipFuncSetAttribute(%zu) failed", lds);
+        return SNNHIP_E_HIP;
+    }
+    auto* plan = new UpconvPlan();
+    plan->ctx = ctx;
+    plan->g = g;
+    plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC * 9);
+    plan->epi4 = epi4;
+    plan->p = p;
+    plan->ac = make_act_cfg(g.act, g.leaky);
+    plan->kernel = fn;
+    plan->ldsBytes = lds;
+    plan->grid = dim3(static_cast<unsigned>(p.tilesX) * (p.segs + 1) * g.N, static_cast<unsigned>(g.OC / BN));
+    plan->block = dim3(256 * WNT);
+    plan->dtype = SNNHIP_F16;
+    // weights: Wp[class][32-channel tile][phase][tap a * 2 + b][cc][lane = 32 hh + m] x 8 halfs: the kernel taps that fall on low-resolution pixel (a, b)
+    // of the phase's 2x2 block, summed in fp32 and rounded to half once
+    const int NT = g.OC / 32;
+    std::vector<float> wpk(static_cast<size_t>(4) * NT * 4 * 4 * ICS * 64 * 4, 0.0f);
+    _Float16* wph = reinterpret_cast<_Float16*>(wpk.data());
+    for (int cls = 0; cls < 4; ++cls)
+        for (int ph = 0; ph < 4; ++ph)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    int fys[3], fxs[3], ny = 0, nx = 0;
+                    tap_set(ph >> 1, a, (cls & 2) != 0, fys, &ny);
+                    tap_set(ph & 1, b, (cls & 1) != 0, fxs, &nx);
+                    for (int oc = 0; oc < g.OC; ++oc)
+                        for (int ic = 0; ic < g.IC; ++ic) {
+                            float sum = 0.0f;
+                            for (int i = 0; i < ny; ++i)
+                                for (int j = 0; j < nx; ++j) sum += static_cast<float>(static_cast<_Float16>(w_oihw[((static_cast<size_t>(oc) * g.IC + ic) * 3 + fys[i]) * 3 + fxs[j]]));
+                            const int ntile = oc / 32, m = oc % 32, cc = ic / 16, hh = (ic % 16) / 8, jj = ic % 8;
+                            wph[((((static_cast<size_t>(cls) * NT + ntile) * 4 + ph) * 4 + (a * 2 + b)) * ICS + cc) * 64 * 8 + (hh * 32 + m) * 8 + jj] = static_cast<_Float16>(sum);
+                        }
+                }
+    int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
+    if (rc == SNNHIP_OK) rc = plan->upload(epi4.data(), epi4.size(), &plan->d_epi);
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    plan->inDims[0] = g.N; plan->inDims[1] = g.srcH; plan->inDims[2] = g.srcW; plan->inDims[3] = g.IC;
+    plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
+    plan->flops = 2.0 * 9 * g.IC * g.OC * static_cast<double>(g.OH) * g.OW * g.N; // the ALGORITHMIC count of the 3x3 layer; executed: 4 / 9 of it
+    plan->bytes = 2.0 * (static_cast<double>(g.N) * g.srcH * g.srcW * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * 9);
+    char buf[360];
+    snprintf(buf, sizeof(buf), "conv2d_mfma_upconv_f16_32x32x16 k=3x3 s=1 ic=%d oc=%d as 4 phases x 2x2 taps on the low-resolution tensor (pre-summed weights), row-marching strips=2x32 low-res px "
+                               "(4x64 out) x %doc segments=%d x %d rows lds=%zuB mfma_flops=%.6g +pad(reflect) +upsample(x2)",
+             g.IC, g.OC, BN, p.segs, p.segRows, lds, plan->flops * 4.0 / 9.0);
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip

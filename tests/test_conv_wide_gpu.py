@@ -506,3 +506,46 @@ def test_wide_random_style_runs_match_the_separate_launches(ctx, monkeypatch, ca
         ref = add([ref, t0])
     np.testing.assert_allclose(y, ref.numpy(), rtol=6e-3, atol=6e-3, err_msg=d)
     assert np.isfinite(y).all()
+
+
+UPCONV = [(2, 13, 21, 64, 32, "relu", ""), (1, 30, 45, 128, 64, "", "2"), (1, 9, 70, 64, 64, "leakyRelu", ""), (2, 17, 33, 128, 128, "relu", "3"), (1, 2, 2, 64, 32, "", ""),
+          (1, 25, 32, 64, 32, "tanh", "")]
+
+
+@pytest.mark.parametrize("case", UPCONV, ids=lambda c: "x".join(map(str, c[:5])) + "_segs" + (c[6] or "auto"))
+def test_upconv_low_resolution_phases_match_the_oracle_and_the_nine_tap_kernel(ctx, monkeypatch, case):
+    """conv2d_upconv.hip: UpSampling2D x2 -> reflect Pad(1) -> Conv2D 3x3 as 4 phases x 2x2 pre-summed taps on the LOW-RESOLUTION tensor (forced: the
+    default takes it on large maps only).  Whole output incl. the last two rows / columns, where the reference's size rule (the padded extent is the
+    output extent, zeros beyond it) drops taps -- the extra low-resolution row / column with their own weight classes; ragged strips, odd extents,
+    several segments and channel tiles.  Against the quantised oracle on the upsampled + padded tensor and against the 9-tap kernel on the same inputs
+    (the pre-summed weights are rounded once more: compared at the fp16 tolerance, not bit for bit)."""
+    import shadernn_amd as snn
+
+    n, h, w_, ic, oc, act, segs = case
+    x, wt, b = _rand((n, h, w_, ic), 1), _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9)), _rand((oc,), 3, 0.2)
+    bn = _bn(oc, 9) if act == "tanh" else None
+
+    def chain():
+        plans = [snn.upsample_plan(ctx, n, h, w_, ic, 2.0, "nearest"), snn.pad_plan(ctx, n, 2 * h, 2 * w_, ic, (1, 1, 1, 1), "reflect"),
+                 snn.conv2d_plan(ctx, n, 2 * h + 2, 2 * w_ + 2, wt, b, stride=1, pads=(0, 0, 0, 0), act=act, leaky=0.1, bn=bn, dtype=snn.F16)]
+        return snn.chain_plan(ctx, plans)
+
+    monkeypatch.setenv("SNNHIP_CONV", "upconv")
+    if segs:
+        monkeypatch.setenv("SNNHIP_UPCONV_SEGS", segs)
+    up = chain()
+    d = up.describe()
+    assert up.num_steps() == 1 and "upconv" in d and "+upsample(x2)" in d and (not segs or "segments=%s x" % segs in d), d
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    y = up(xt).numpy()
+    t = O.pad(O.upsample(O._h(x), 2.0, "nearest"), (1, 1, 1, 1), "reflect")
+    want = O._h(O.conv2d(t, O._h(wt), b, 1, (0, 0, 0, 0), "constant", act, 0.1, bn))
+    assert y.shape == want.shape == (n, 2 * h + 2, 2 * w_ + 2, oc)  # the padded extent (Q20)
+    np.testing.assert_allclose(y, want, err_msg=d, **TOLH)
+    np.testing.assert_allclose(y[:, -2:], want[:, -2:], err_msg="last two rows " + d, **TOLH)
+    np.testing.assert_allclose(y[:, :, -2:], want[:, :, -2:], err_msg="last two columns " + d, **TOLH)
+    monkeypatch.delenv("SNNHIP_CONV")
+    monkeypatch.setenv("SNNHIP_CONV_UPCONV", "0")
+    nine = chain()
+    assert "upconv" not in nine.describe(), nine.describe()
+    np.testing.assert_allclose(y, nine(xt).numpy(), err_msg=d + " vs " + nine.describe(), rtol=3e-3, atol=3e-3)

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "epilogue.h"
+#include "norm_fold.h"
 #include "snnhip_internal.h"
 
 namespace snnhip {
@@ -37,12 +38,20 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 struct UpParams {
     int N, srcH, srcW, IC, OC, OH, OW, useBN;
     int tilesX, segs, segRows; // strips of 32 low-resolution columns (+ 1 for column W), row segments per strip (+ 1 for row H), rows per segment (even)
+    // chain rule F (Conv2D -> InstanceNorm): every block leaves ONE record {pixels, sum (v - bias), sum (v - bias)^2} per channel of the values it stored,
+    // statRec[((n * gridDim.y + by) * blocksPerImage + block)][1 + 2 BN]; the last block of an image to finish adds the image's records up and writes the
+    // norm's shift / mul (fold; the hand-off of norm_fold.h).  null = off
+    float* statRec;
+    NormFoldArgs fold;
 };
 
 constexpr int kTP = 34; // staged pixels per low-resolution row: the strip's 32 + one on either side
+#ifndef SNNHIP_UPCONV_OCC
+#define SNNHIP_UPCONV_OCC 2 // waves per SIMD the 256-thread form is compiled for (3 = 168 VGPRs: the statistics accumulators then spill to scratch)
+#endif
 
 template <int ICS /* IC / 16: 4 | 8 */, int WNT /* 32-channel tiles per block: 1 | 2 */>
-__global__ __launch_bounds__(256 * WNT, WNT == 1 ? 3 : 2) void conv2d_upconv_kernel(UpParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
+__global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void conv2d_upconv_kernel(UpParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
                                                                                   const float4* __restrict__ epi, _Float16* __restrict__ y) {
     constexpr int Q = 2 * ICS, QP = Q + 1;   // 16-byte slots per pixel, and its (odd) pitch in LDS
     constexpr int MT = 2;                     // low-resolution rows per iteration
@@ -131,6 +140,11 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? 3 : 2) void conv2d_upconv_ker
 
     const float* const et = epiTab + 32 * nt + 4 * h; // this lane's channel runs: 8 g + 4 h + k of the wave's 32-channel tile
     const bool actSimple = act_is_simple_dev(ac.act);
+    // rule F: a thread's vectors of the store loop are pixels of ONE 8-channel column (T % (BN / 8) == 0): sums of (v - pivot) and (v - pivot)^2 of the
+    // stored (rounded) values accumulate while they pass; pivot = the channel's bias (shift), the same in every block, so records simply add up
+    float st1[8], st2[8], stN = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.0f;
     for (int it = 0; it < nIter; ++it) {
         const bool more = it + 1 < nIter;
         if (more) load_batch(it + 2);
@@ -203,12 +217,81 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? 3 : 2) void conv2d_upconv_ker
             const int vi = tid + T * q;
             const int pix = vi / (BN / 8), c8 = vi % (BN / 8);
             const int orow = pix >> 6, ocol = pix & 63;
-            if (mIt + (orow >> 1) < mEnd && q0 + (ocol >> 1) < qEnd)
-                *reinterpret_cast<float4*>(y + ((static_cast<size_t>(n) * p.OH + 2 * mIt + orow) * p.OW + 2 * q0 + ocol) * p.OC + ocb + 8 * c8) =
-                    *reinterpret_cast<const float4*>(otile + pix * EP + 8 * c8);
+            if (mIt + (orow >> 1) < mEnd && q0 + (ocol >> 1) < qEnd) {
+                const float4 ov = *reinterpret_cast<const float4*>(otile + pix * EP + 8 * c8);
+                *reinterpret_cast<float4*>(y + ((static_cast<size_t>(n) * p.OH + 2 * mIt + orow) * p.OW + 2 * q0 + ocol) * p.OC + ocb + 8 * c8) = ov;
+                if (p.statRec) { // (uniform)
+                    const h8 hv = *reinterpret_cast<const h8*>(&ov);
+                    const float4 pa = *reinterpret_cast<const float4*>(epiTab + BN + 8 * c8), pb = *reinterpret_cast<const float4*>(epiTab + BN + 8 * c8 + 4);
+                    const float pv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float d = static_cast<float>(hv[k]) - pv[k];
+                        st1[k] += d;
+                        st2[k] = fmaf(d, d, st2[k]);
+                    }
+                    stN += 1.0f;
+                }
+            }
         }
         if (more) store_batch(it + 2);
         __syncthreads();
+    }
+
+    if (!p.statRec) return; // (uniform)
+    // ---- the block's record: the T / (BN / 8) threads of a channel column are added in a fixed order through LDS (ring and tile are dead)
+    {
+        constexpr int CPT = BN / 8, TPC = T / CPT; // channel columns, threads per column
+        float* const red = smem;                   // [17][T]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[k * T + tid] = st1[k];
+            red[(8 + k) * T + tid] = st2[k];
+        }
+        red[16 * T + tid] = stN;
+        __syncthreads();
+        const int BPI = (p.segs + 1) * p.tilesX;
+        float* const rec = p.statRec + (static_cast<size_t>(n * gridDim.y + blockIdx.y) * BPI + (bx - n * BPI)) * (1 + 2 * BN);
+        if (tid < BN) {
+            const int col = tid >> 3, kk = tid & 7;
+            float a1 = 0.0f, a2 = 0.0f, an = 0.0f;
+            for (int j = 0; j < TPC; ++j) {
+                a1 += red[kk * T + col + j * CPT];
+                a2 += red[(8 + kk) * T + col + j * CPT];
+                an += red[16 * T + col + j * CPT];
+            }
+            st_agent(rec + 1 + tid, a1);
+            st_agent(rec + 1 + BN + tid, a2);
+            if (tid == 0) st_agent(rec, an); // (every column of the block saw the same pixels)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record is acknowledged before the block is counted (norm_fold.h)
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* cnt = p.fold.counter + n * gridDim.y + blockIdx.y;
+            const unsigned prev = atomicAdd(cnt, 1u);
+            const bool last = prev + 1u == static_cast<unsigned>(BPI);
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch (a replayed hipGraph)
+            red[0] = last ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        if (red[0] == 0.0f) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // one acquire per image, in its last block only
+        if (tid < BN) { // the image's records in block order: deterministic whichever block is last
+            const float* r0 = p.statRec + static_cast<size_t>(n * gridDim.y + blockIdx.y) * BPI * (1 + 2 * BN);
+            float a1 = 0.0f, a2 = 0.0f, an = 0.0f;
+            for (int b = 0; b < BPI; ++b) {
+                const float* rb2 = r0 + static_cast<size_t>(b) * (1 + 2 * BN);
+                an += ld_agent(rb2);
+                a1 += ld_agent(rb2 + 1 + tid);
+                a2 += ld_agent(rb2 + 1 + BN + tid);
+            }
+            const float pivot = epiTab[BN + tid];
+            const float dm = a1 / an, mean = pivot + dm;
+            const float var = fmaxf(a2 / an - dm * dm, 0.0f);
+            const float mu = p.fold.gamma[ocb + tid] / sqrtf(var + p.fold.eps);
+            p.fold.mul[n * p.OC + ocb + tid] = mu;
+            p.fold.shift[n * p.OC + ocb + tid] = p.fold.beta[ocb + tid] - mean * mu;
+        }
     }
 }
 
@@ -221,8 +304,36 @@ struct UpconvPlan : ConvPlanBase {
     dim3 grid, block;
     void (*kernel)(UpParams, ActCfg, const _Float16*, const float4*, const float4*, _Float16*) = nullptr;
 
+    // chain rule F.  The records of this kernel are per BLOCK (a strip segment of any height, border strips of 2 pixels): not the regular tile grid
+    // the norm's fold launches expect -- the statistics are only offered together with the in-kernel fold.
+    bool enableTileStats() override {
+        if (statPart) return true;
+        if (snnhip::option("SNNHIP_NO_KERNEL_FOLD")) return false;
+        const int BPI = (p.segs + 1) * p.tilesX, BN = static_cast<int>(p.OC / grid.y);
+        void* buf = nullptr;
+        if (hipMalloc(&buf, static_cast<size_t>(p.N) * grid.y * BPI * (1 + 2 * BN) * sizeof(float)) != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        statPart = p.statRec = static_cast<float*>(buf);
+        statTilesX = BPI; statTilesY = 1; statTH = 0; statTW = 0;
+        desc += " +tile-stats";
+        return true;
+    }
+    bool enableNormFold(const NormFoldTarget& t) override {
+        if (!statPart || p.fold.counter) return false;
+        void* buf = nullptr;
+        const size_t bytes = static_cast<size_t>(p.N) * grid.y * sizeof(unsigned);
+        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        if (hipMemset(buf, 0, bytes) != hipSuccess) return false;
+        p.fold.counter = static_cast<unsigned*>(buf);
+        p.fold.gamma = t.gamma; p.fold.beta = t.beta; p.fold.shift = t.shift; p.fold.mul = t.mul; p.fold.eps = t.eps;
+        desc += "+fold";
+        return true;
+    }
+
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
+        SNNHIP_REQUIRE(!p.statRec || p.fold.counter, "conv2d_upconv: block statistics were switched on without the in-kernel fold (no fold launch reads its records)");
         const snnhip_tensor* x = in[0];
         SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == p.IC, "conv2d: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h,
                        x->w, x->c, p.N, p.srcH, p.srcW, p.IC);
@@ -268,7 +379,7 @@ int make_conv2d_upconv_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     UpParams p = {};
     p.N = g.N; p.srcH = g.srcH; p.srcW = g.srcW; p.IC = g.IC; p.OC = g.OC; p.OH = g.OH; p.OW = g.OW; p.useBN = g.useBN;
     p.tilesX = up_div(g.srcW, 32) + 1;
-    const int slots = std::max(1, ctx->props.multiProcessorCount) * (WNT == 1 ? 3 : 1), strips = g.N * p.tilesX * (g.OC / BN);
+    const int slots = std::max(1, ctx->props.multiProcessorCount) * (WNT == 1 ? SNNHIP_UPCONV_OCC : 1), strips = g.N * p.tilesX * (g.OC / BN);
     if (!forced && (g.srcH < 24 || static_cast<long>(strips) * up_div(g.srcH, 48) < ctx->props.multiProcessorCount)) return SNNHIP_E_UNSUPPORTED;
     {
         const char* fs = snnhip::option("SNNHIP_UPCONV_SEGS");

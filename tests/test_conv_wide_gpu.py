@@ -549,3 +549,36 @@ def test_upconv_low_resolution_phases_match_the_oracle_and_the_nine_tap_kernel(c
     nine = chain()
     assert "upconv" not in nine.describe(), nine.describe()
     np.testing.assert_allclose(y, nine(xt).numpy(), err_msg=d + " vs " + nine.describe(), rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("n,h,w_,ic,oc,offset", [(2, 30, 45, 64, 32, 0.0), (1, 25, 70, 128, 64, 3.0), (3, 9, 33, 64, 64, 0.0)])
+def test_upconv_block_statistics_feed_the_instancenorm_behind_it(ctx, monkeypatch, n, h, w_, ic, oc, offset):
+    """Rule F on conv2d_upconv.hip: UpSampling -> Pad -> Conv2D -> InstanceNorm as the convolution (whose blocks leave {pixels, sum, sum of squares} records
+    around the channel's bias and whose last block per image folds them into the norm's shift / mul) + ONE normalise sweep.  Several images, a mean far
+    from zero, several row segments per strip; against the separate launches and the oracle; a second, different input through the same plan."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_CONV", "upconv")
+    monkeypatch.setenv("SNNHIP_NORM_FUSION_MIN_MB", "0")
+    monkeypatch.setenv("SNNHIP_UPCONV_SEGS", "2")
+    x, wt = _rand((n, h, w_, ic), 1), _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9))
+    b = _rand((oc,), 3, 0.5) + offset
+    beta, gamma = _rand((oc,), 4, 0.3), 1.0 + _rand((oc,), 5, 0.2)
+    up = snn.upsample_plan(ctx, n, h, w_, ic, 2.0, "nearest")
+    pad = snn.pad_plan(ctx, n, 2 * h, 2 * w_, ic, (1, 1, 1, 1), "reflect")
+    conv = snn.conv2d_plan(ctx, n, 2 * h + 2, 2 * w_ + 2, wt, b, stride=1, pads=(0, 0, 0, 0), act="", dtype=snn.F16)
+    norm = snn.instancenorm_plan(ctx, n, 2 * h + 2, 2 * w_ + 2, oc, beta, gamma, act="relu")
+    fused = snn.chain_plan(ctx, [up, pad, conv, norm])
+    d = fused.describe()
+    assert fused.num_steps() == 1 and "upconv" in d and "+tile-stats+fold" in d and "instancenorm(1 sweep)" in d, d
+    for seed in (1, 11):
+        xs = x if seed == 1 else (0.5 * _rand((n, h, w_, ic), seed) + 0.75).astype(np.float32)
+        xt = snn.Tensor.from_numpy(ctx, xs, dtype=snn.F16)
+        y = fused(xt).numpy()
+        np.testing.assert_array_equal(fused(xt).numpy(), y)
+        two = norm(snn.chain_plan(ctx, [up, pad, conv])(xt)).numpy()
+        np.testing.assert_allclose(y, two, rtol=2e-3, atol=2e-3, err_msg="seed %d: %s" % (seed, d))
+        if offset == 0:
+            t = O.pad(O.upsample(O._h(xs), 2.0, "nearest"), (1, 1, 1, 1), "reflect")
+            c = O._h(O.conv2d(t, O._h(wt), b, 1, (0, 0, 0, 0), "constant", "", 0.0, None))
+            np.testing.assert_allclose(y, O._h(O.instancenorm(c, beta, gamma, "relu")), err_msg=d, rtol=6e-3, atol=6e-3)

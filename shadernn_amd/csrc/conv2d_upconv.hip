@@ -276,21 +276,54 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
         __syncthreads();
         if (red[0] == 0.0f) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // one acquire per image, in its last block only
-        if (tid < BN) { // the image's records in block order: deterministic whichever block is last
+        // The fold is the tail of the launch (the last image's last block runs it when every other block is done), so it is built for latency:
+        // thread = (channel, 1 of T / BN parts), four records (12 loads) in flight per thread -- one record per round trip to the coherence point
+        // (the first version: a loop over ~110 records in BN threads) cost ~110 us per launch.  Fixed order: deterministic whichever block is last.
+        {
+            constexpr int PARTS = T / BN;
+            const int ch = tid % BN, part = tid / BN;
             const float* r0 = p.statRec + static_cast<size_t>(n * gridDim.y + blockIdx.y) * BPI * (1 + 2 * BN);
             float a1 = 0.0f, a2 = 0.0f, an = 0.0f;
-            for (int b = 0; b < BPI; ++b) {
-                const float* rb2 = r0 + static_cast<size_t>(b) * (1 + 2 * BN);
-                an += ld_agent(rb2);
-                a1 += ld_agent(rb2 + 1 + tid);
-                a2 += ld_agent(rb2 + 1 + BN + tid);
+            for (int b0 = part; b0 < BPI; b0 += 4 * PARTS) {
+                float t1[4], t2[4], tn[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int b = b0 + j * PARTS;
+                    t1[j] = t2[j] = tn[j] = 0.0f;
+                    if (b < BPI) {
+                        const float* rb2 = r0 + static_cast<size_t>(b) * (1 + 2 * BN);
+                        tn[j] = ld_agent(rb2);
+                        t1[j] = ld_agent(rb2 + 1 + ch);
+                        t2[j] = ld_agent(rb2 + 1 + BN + ch);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    an += tn[j];
+                    a1 += t1[j];
+                    a2 += t2[j];
+                }
             }
-            const float pivot = epiTab[BN + tid];
-            const float dm = a1 / an, mean = pivot + dm;
-            const float var = fmaxf(a2 / an - dm * dm, 0.0f);
-            const float mu = p.fold.gamma[ocb + tid] / sqrtf(var + p.fold.eps);
-            p.fold.mul[n * p.OC + ocb + tid] = mu;
-            p.fold.shift[n * p.OC + ocb + tid] = p.fold.beta[ocb + tid] - mean * mu;
+            __syncthreads(); // (red[0] has been read by everyone)
+            red[tid] = an;
+            red[T + tid] = a1;
+            red[2 * T + tid] = a2;
+            __syncthreads();
+            if (tid < BN) {
+                an = a1 = a2 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < PARTS; ++j) {
+                    an += red[j * BN + tid];
+                    a1 += red[T + j * BN + tid];
+                    a2 += red[2 * T + j * BN + tid];
+                }
+                const float pivot = epiTab[BN + tid];
+                const float dm = a1 / an, mean = pivot + dm;
+                const float var = fmaxf(a2 / an - dm * dm, 0.0f);
+                const float mu = p.fold.gamma[ocb + tid] / sqrtf(var + p.fold.eps);
+                p.fold.mul[n * p.OC + ocb + tid] = mu;
+                p.fold.shift[n * p.OC + ocb + tid] = p.fold.beta[ocb + tid] - mean * mu;
+            }
         }
     }
 }

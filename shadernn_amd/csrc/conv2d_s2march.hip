@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "epilogue.h"
+#include "norm_fold.h"
 #include "snnhip_internal.h"
 
 namespace snnhip {
@@ -36,6 +37,10 @@ struct S2Params {
     const float* normShift;                        // InstanceNorm in front (graph rule I); null = none
     const float* normMul;
     ActCfg normAc;
+    // chain rule F (Conv2D -> InstanceNorm), as in conv2d_upconv.hip: one record {pixels, sum (v - bias), sum (v - bias)^2} per block and channel,
+    // statRec[((n * gridDim.y + by) * blocksPerImage + block)][1 + 2 BN]; the last block of an image folds them into the norm's shift / mul.  null = off
+    float* statRec;
+    NormFoldArgs fold;
 };
 
 // (a 32-column output strip stages input columns 0 .. 64: 2 * 31 + 3 of them)
@@ -202,6 +207,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2march_kernel(S2Params p, ActC
 
     const float* const et = epiTab + 32 * wn + 4 * h; // this lane's channel runs: 8 g + 4 h + k of the wave's 32-channel tile
     const bool actSimple = act_is_simple_dev(ac.act);
+    // rule F: a thread's vectors of the store loop are pixels of ONE 8-channel column: sums around the channel's bias of the stored (rounded) values
+    float st1[8], st2[8], stN = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.0f;
     // X: the batch written to the ring at the end of this iteration (rows of iteration it + 1); Y (PF = 2): the buffer the request for it + 2 goes to
 #ifdef SNNHIP_S2_TRACE
     const bool trace = blockIdx.x == 3 && blockIdx.y == 0 && (tid == 0 || tid == 448);
@@ -287,8 +296,22 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2march_kernel(S2Params p, ActC
             const int vi = tid + 512 * q;
             const int pix = vi / (BN / 8), c8 = vi % (BN / 8);
             const int oy = oyS + it * TH + (pix >> 5), ox = ox0 + (pix & 31);
-            if (oy < oyE && ox < p.OW)
-                *reinterpret_cast<float4*>(y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox) * p.OC + ocb + 8 * c8) = *reinterpret_cast<const float4*>(otile + pix * EP + 8 * c8);
+            if (oy < oyE && ox < p.OW) {
+                const float4 ov = *reinterpret_cast<const float4*>(otile + pix * EP + 8 * c8);
+                *reinterpret_cast<float4*>(y + ((static_cast<size_t>(n) * p.OH + oy) * p.OW + ox) * p.OC + ocb + 8 * c8) = ov;
+                if (ICS == 2 && p.statRec) { // (uniform; the 64-channel form has no registers left for the accumulators and is never asked)
+                    const h8 hv = *reinterpret_cast<const h8*>(&ov);
+                    const float4 pa = *reinterpret_cast<const float4*>(epiTab + BN + 8 * c8), pb = *reinterpret_cast<const float4*>(epiTab + BN + 8 * c8 + 4);
+                    const float pv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float d = static_cast<float>(hv[k]) - pv[k];
+                        st1[k] += d;
+                        st2[k] = fmaf(d, d, st2[k]);
+                    }
+                    stN += 1.0f;
+                }
+            }
         }
         S2_MARK(5);
         if (more) store_batch(X);
@@ -309,6 +332,89 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2march_kernel(S2Params p, ActC
     } else {
         for (int it = 0; it < nIter; ++it) iteration(it, b0, b0);
     }
+
+    if (ICS != 2 || !p.statRec) return; // (uniform)
+    // ---- the block's record, the count of finished blocks, and in the image's last block the fold (conv2d_upconv.hip)
+    {
+        constexpr int T = 512, CPT = BN / 8, TPC = T / CPT, PARTS = T / BN;
+        float* const red = smem; // [17][T]: the ring and the tile are dead
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[k * T + tid] = st1[k];
+            red[(8 + k) * T + tid] = st2[k];
+        }
+        red[16 * T + tid] = stN;
+        __syncthreads();
+        const int BPI = p.segs * p.tilesX;
+        float* const rec = p.statRec + (static_cast<size_t>(n * gridDim.y + blockIdx.y) * BPI + (bx - n * BPI)) * (1 + 2 * BN);
+        if (tid < BN) {
+            const int col = tid >> 3, kk = tid & 7;
+            float a1 = 0.0f, a2 = 0.0f, an = 0.0f;
+            for (int j = 0; j < TPC; ++j) {
+                a1 += red[kk * T + col + j * CPT];
+                a2 += red[(8 + kk) * T + col + j * CPT];
+                an += red[16 * T + col + j * CPT];
+            }
+            st_agent(rec + 1 + tid, a1);
+            st_agent(rec + 1 + BN + tid, a2);
+            if (tid == 0) st_agent(rec, an);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* cnt = p.fold.counter + n * gridDim.y + blockIdx.y;
+            const unsigned prev = atomicAdd(cnt, 1u);
+            const bool last = prev + 1u == static_cast<unsigned>(BPI);
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            red[0] = last ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        if (red[0] == 0.0f) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int ch = tid % BN, part = tid / BN;
+        const float* r0 = p.statRec + static_cast<size_t>(n * gridDim.y + blockIdx.y) * BPI * (1 + 2 * BN);
+        float a1 = 0.0f, a2 = 0.0f, an = 0.0f;
+        for (int b0i = part; b0i < BPI; b0i += 4 * PARTS) {
+            float t1[4], t2[4], tn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = b0i + j * PARTS;
+                t1[j] = t2[j] = tn[j] = 0.0f;
+                if (b < BPI) {
+                    const float* rb2 = r0 + static_cast<size_t>(b) * (1 + 2 * BN);
+                    tn[j] = ld_agent(rb2);
+                    t1[j] = ld_agent(rb2 + 1 + ch);
+                    t2[j] = ld_agent(rb2 + 1 + BN + ch);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                an += tn[j];
+                a1 += t1[j];
+                a2 += t2[j];
+            }
+        }
+        __syncthreads();
+        red[tid] = an;
+        red[T + tid] = a1;
+        red[2 * T + tid] = a2;
+        __syncthreads();
+        if (tid < BN) {
+            an = a1 = a2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PARTS; ++j) {
+                an += red[j * BN + tid];
+                a1 += red[T + j * BN + tid];
+                a2 += red[2 * T + j * BN + tid];
+            }
+            const float pivot = epiTab[BN + tid];
+            const float dm = a1 / an, mean = pivot + dm;
+            const float var = fmaxf(a2 / an - dm * dm, 0.0f);
+            const float mu = p.fold.gamma[ocb + tid] / sqrtf(var + p.fold.eps);
+            p.fold.mul[n * p.OC + ocb + tid] = mu;
+            p.fold.shift[n * p.OC + ocb + tid] = p.fold.beta[ocb + tid] - mean * mu;
+        }
+    }
 }
 
 struct S2marchPlan : ConvPlanBase {
@@ -320,8 +426,35 @@ struct S2marchPlan : ConvPlanBase {
     dim3 grid;
     void (*kernel)(S2Params, ActCfg, const _Float16*, const float4*, const float4*, _Float16*) = nullptr;
 
+    // chain rule F: per-block records, offered only together with the in-kernel fold (conv2d_upconv.hip)
+    bool enableTileStats() override {
+        if (statPart) return true;
+        if (snnhip::option("SNNHIP_NO_KERNEL_FOLD") || p.IC != 32) return false;
+        const int BPI = p.segs * p.tilesX, BN = static_cast<int>(p.OC / grid.y);
+        void* buf = nullptr;
+        if (hipMalloc(&buf, static_cast<size_t>(p.N) * grid.y * BPI * (1 + 2 * BN) * sizeof(float)) != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        statPart = p.statRec = static_cast<float*>(buf);
+        statTilesX = BPI; statTilesY = 1; statTH = 0; statTW = 0;
+        desc += " +tile-stats";
+        return true;
+    }
+    bool enableNormFold(const NormFoldTarget& t) override {
+        if (!statPart || p.fold.counter) return false;
+        void* buf = nullptr;
+        const size_t bytes = static_cast<size_t>(p.N) * grid.y * sizeof(unsigned);
+        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        if (hipMemset(buf, 0, bytes) != hipSuccess) return false;
+        p.fold.counter = static_cast<unsigned*>(buf);
+        p.fold.gamma = t.gamma; p.fold.beta = t.beta; p.fold.shift = t.shift; p.fold.mul = t.mul; p.fold.eps = t.eps;
+        desc += "+fold";
+        return true;
+    }
+
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
+        SNNHIP_REQUIRE(!p.statRec || p.fold.counter, "conv2d_s2march: block statistics were switched on without the in-kernel fold (no fold launch reads its records)");
         const snnhip_tensor* x = in[0];
         SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == p.IC, "conv2d: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h,
                        x->w, x->c, p.N, p.srcH, p.srcW, p.IC);

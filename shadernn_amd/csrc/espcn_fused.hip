@@ -1380,7 +1380,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
     // ---- rule F: a convolution step (as given, or one a rule above built) whose kernel can reduce its output tiles to {mean, M2} records, followed by
     // a step that starts with an InstanceNorm: the norm's statistics sweep becomes a fold over those records.  The consumer is the norm itself (the
     // two steps become one: conv, fold, normalise in place), the norm + Add of rule H (last step of a two-input chain), or the norm -> convolution of
-    // rule I.  Default: conv2d_wide_f16 and conv2d_upconv only -- their 256 / 512-pixel tiles pass through registers on their way out anyway (+3 % on the kernel, one
+    // rule I.  Default: conv2d_wide_f16, conv2d_upconv and conv2d_s2march only -- their 256 / 512-pixel tiles pass through registers on their way out anyway (+3 % on the kernel, one
     // tensor read saved).  SNNHIP_NORM_FUSION=1 also takes conv2d_mfma's fp16 kernel (measured a loss: its short blocks pay 45-125 us per layer
     // for the statistics where the sweep costs 40), =0 switches the rule off.
     const char* normFusion = snnhip::option("SNNHIP_NORM_FUSION");
@@ -1391,7 +1391,9 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         auto* aIn = dynamic_cast<InstanceNormConvPlan*>(a.plain); // the producer may itself be a normalising convolution (rule I): its inner plan is the chain's
         auto* cv = dynamic_cast<ConvPlanBase*>(aIn ? aIn->conv : a.plain);
         if (!cv || cv->depthwise || cv->numInputs != 1) continue;
-        if (normFusionMode < 0 && cv->desc.find("conv2d_mfma_wide_f16") == std::string::npos && cv->desc.find("conv2d_mfma_upconv_f16") == std::string::npos) continue;
+        if (normFusionMode < 0 && cv->desc.find("conv2d_mfma_wide_f16") == std::string::npos && cv->desc.find("conv2d_mfma_upconv_f16") == std::string::npos &&
+            !(cv->desc.find("row-marching") != std::string::npos && cv->desc.find(" s=2 ") != std::string::npos))
+            continue;
         {
             // small tensors (one 720p image: 17 MB per layer) are swept out of the L2 / MALL in less time than the two fold launches take
             // (Candy batch 1: 1.12 ms without the rule, 1.24 ms with it); from a few images per batch on the sweep is an HBM pass

@@ -342,3 +342,28 @@ def test_fp16_rowfold_with_fused_reflect_pad(ctx):
     assert got.shape == want.shape  # "valid" keeps the padded extent (Q20)
     np.testing.assert_allclose(got, want, **TOLH)
     np.testing.assert_array_equal(got, sep)
+
+
+def test_fp16_stride2_marching_block_statistics_feed_the_instancenorm_behind_it(ctx, monkeypatch):
+    """Rule F on conv2d_s2march.hip (32 input channels): Conv2D 3x3 stride 2 -> InstanceNorm as the convolution (block records + in-kernel fold) + ONE
+    normalise sweep; against the separate launches and the oracle, two different inputs through the same plan."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_CONV", "s2march")
+    monkeypatch.setenv("SNNHIP_NORM_FUSION_MIN_MB", "0")
+    monkeypatch.setenv("SNNHIP_S2MARCH_SEGS", "2")
+    n, h, w, ic, oc = 2, 61, 90, 32, 64
+    wt, b = _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9)), _rand((oc,), 3, 0.5) + 2.0
+    beta, gamma = _rand((oc,), 4, 0.3), 1.0 + _rand((oc,), 5, 0.2)
+    conv = snn.conv2d_plan(ctx, n, h, w, wt, b, stride=2, pads=O.padding_offsets("same", 3), act="", dtype=snn.F16)
+    oh, ow = conv.out_shape()[1:3]
+    norm = snn.instancenorm_plan(ctx, n, oh, ow, oc, beta, gamma, act="relu")
+    fused = snn.chain_plan(ctx, [conv, norm])
+    d = fused.describe()
+    assert fused.num_steps() == 1 and "row-marching" in d and "+tile-stats+fold" in d and "instancenorm(1 sweep)" in d, d
+    for seed in (1, 11):
+        x = _rand((n, h, w, ic), seed) if seed == 1 else (0.5 * _rand((n, h, w, ic), seed) + 0.75).astype(np.float32)
+        xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+        y = fused(xt).numpy()
+        np.testing.assert_array_equal(fused(xt).numpy(), y)
+        np.testing.assert_allclose(y, norm(conv(xt)).numpy(), rtol=2e-3, atol=2e-3, err_msg="seed %d: %s" % (seed, d))

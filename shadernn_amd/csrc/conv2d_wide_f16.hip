@@ -28,6 +28,12 @@
 #define SNNHIP_WIDE_ABL 0 // ablation builds only (tools/ablate_wide.sh): 1 no weight refills, 2 no LDS operand reads, 4 no activation DMA, 8 no output stores
 #endif
 
+#ifdef SNNHIP_WIDE_TRACE // experiment builds (tools/exp_one.sh): one block prints the s_memtime stamps of its phases
+#define WIDE_MARK(i) do { if (wtrace) wstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WIDE_MARK(i) do { } while (0)
+#endif
+
 namespace snnhip {
 
 namespace {
@@ -75,6 +81,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     const int l32 = lane & 31, h = lane >> 5;
 
     const int mt = blockIdx.x;
+#ifdef SNNHIP_WIDE_TRACE
+    const bool wtrace = (blockIdx.x == 777 || blockIdx.x == 5000) && blockIdx.y == 0 && (tid == 0 || tid == 192);
+    unsigned long long wstamp[8] = {};
+#endif
+    WIDE_MARK(0);
     const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, n = mt / (p.tilesX * p.tilesY);
     const int ox0 = tx << 5, oy0 = ty << p.THs;
     const int ix0 = ox0 - p.padx, iy0 = oy0 - p.pady;
@@ -200,10 +211,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         bptr += bstep;
     }
 
+    WIDE_MARK(1);
     stage_dma(smem, 0);
     lds_dma_wait();
     if (p.normShift) norm_fixup(smem, 0);
     __syncthreads();
+    WIDE_MARK(2);
 
     float4 a[MT];
     for (int chunk = 0; chunk < p.nChunks; ++chunk) {
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         __syncthreads();
     }
 
+    WIDE_MARK(3);
     // ---- epilogue.  The MFMAs ran with the WEIGHTS as the A operand (M = output channels) and the pixels as B (N = 32 pixels of a tile row), so
     // a lane holds, for ITS pixel, runs of four consecutive output channels: acc[t][u][4g + k] = channel n0 + 32u + 8g + 4h + k of pixel
     // (row wm*MT + t, column l32).  bias -> BN -> activation, each run goes to the LDS tile [pixel][BN halfs] as ONE ds_write_b64 (with the
@@ -317,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         const int oy = oy0 + (i >> 5), ox = ox0 + (i & 31);
         oofs[j] = (oy < p.OH && ox < p.OW) ? ((n * p.OH + oy) * p.OW + ox) * p.OC + blockIdx.y * BN + c8 * 8 : -1;
     }
+    WIDE_MARK(4);
     float4 rpack[RES ? NV : 1];
     if (RES) {
 #pragma unroll
@@ -326,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     // chain rule F (p.statPart, uniform): the InstanceNorm behind this layer needs mean and variance per (image, channel).  A thread's NV vectors are
     // NV pixels of ONE 8-channel column (256 % VPR == 0): sums of (v - pivot) and (v - pivot)^2 of the stored (rounded) values accumulate in
     // registers while the vectors pass through, pivot = the thread's first pixel (the differences stay small: no cancellation in S2 - S1^2 / n)
+    WIDE_MARK(5);
     float sPiv[8], sA[8], sB[8];
     int sCnt = 0;
 #pragma unroll
@@ -359,6 +375,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         }
         if (oofs[j] >= 0 && !((SNNHIP_WIDE_ABL & 8) && p.OC != 12345)) *reinterpret_cast<float4*>(y + oofs[j]) = pack;
     }
+    WIDE_MARK(6);
+#ifdef SNNHIP_WIDE_TRACE
+    if (wtrace && !(!RES && p.statPart))
+        printf("widetrace blk %d tid %d: prologue %llu stage0 %llu kloop %llu epi %llu bar %llu stores %llu total %llu\n", blockIdx.x, tid, wstamp[1] - wstamp[0], wstamp[2] - wstamp[1],
+               wstamp[3] - wstamp[2], wstamp[4] - wstamp[3], wstamp[5] - wstamp[4], wstamp[6] - wstamp[5], wstamp[6] - wstamp[0]);
+#endif
     if (!RES && p.statPart) {
         // thread record (count, mean, M2) per channel -> LDS (the output tile is dead); thread c < BN then merges the PG pixel groups of its channel in a
         // fixed order with the parallel-variance update (n = na + nb, d = mb - ma, m = ma + d nb / n, M2 = M2a + M2b + d^2 na nb / n): deterministic,
@@ -424,6 +446,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
             st_agent(po + tid, ma); // (read by another block of this launch when the kernel folds: norm_fold.h)
             st_agent(po + p.OC + tid, M2);
         }
+        WIDE_MARK(7);
+#ifdef SNNHIP_WIDE_TRACE
+        if (wtrace)
+            printf("widetrace blk %d tid %d: prologue %llu stage0 %llu kloop %llu epi %llu bar %llu stores %llu stats %llu total %llu\n", blockIdx.x, tid, wstamp[1] - wstamp[0],
+                   wstamp[2] - wstamp[1], wstamp[3] - wstamp[2], wstamp[4] - wstamp[3], wstamp[5] - wstamp[4], wstamp[6] - wstamp[5], wstamp[7] - wstamp[6], wstamp[7] - wstamp[0]);
+#endif
         if (p.fold.counter) tile_stats_finish<BN>(p.fold, p.statPart, sred2 + 3 * 256, n, p.tilesX, p.tilesY, 1 << p.THs, 32, p.OH, p.OW, p.OC, blockIdx.y * BN);
     }
 }

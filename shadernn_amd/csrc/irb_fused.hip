@@ -91,6 +91,11 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, k = lane >> 4;
     const int NWv = blockDim.x >> 6;
+#ifdef SNNHIP_IRB_TRACE // experiment builds (tools/exp_one.sh)
+    const bool itrace = blockIdx.x == 1000 && lane == 0 && (wave == 0 || wave == 2);
+    unsigned long long istamp[4] = {};
+    if (itrace) istamp[0] = __builtin_readcyclecounter();
+#endif
     constexpr int TW = 8, TH = G * 2; // 16 G pixels
     const int mt = blockIdx.x * NWv + wave;
     if (mt >= p.tilesX * p.tilesY * p.N) return; // (no barrier in this kernel)
@@ -132,6 +137,9 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
         }
     }
 
+#ifdef SNNHIP_IRB_TRACE
+    if (itrace) istamp[1] = __builtin_readcyclecounter();
+#endif
     int hp0[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -247,6 +255,9 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
         }
     }
 
+#ifdef SNNHIP_IRB_TRACE
+    if (itrace) istamp[2] = __builtin_readcyclecounter();
+#endif
     // ---- epilogue: lane holds output channels 16 cb + 4k .. + 3 of its pixels
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -277,6 +288,11 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
             }
         }
     }
+#ifdef SNNHIP_IRB_TRACE
+    if (itrace)
+        printf("irbtrace G%d NCB%d Cj%d chunks %d noexp %d wave %d: stage %llu slices %llu (%llu each) epi %llu\n", G, p.NCB, p.Cj, p.nChunks, p.noExpand, wave, istamp[1] - istamp[0],
+               istamp[2] - istamp[1], (istamp[2] - istamp[1]) / p.nChunks, __builtin_readcyclecounter() - istamp[2]);
+#endif
 }
 
 struct IrbPlan : snnhip_plan {

@@ -38,6 +38,11 @@ struct RowmarchParams {
 };
 
 constexpr int kTH = 8, kCols = 64;
+#ifdef SNNHIP_RM_TRACE // experiment builds (tools/exp_one.sh): one block prints the s_memtime stamps of its phases
+#define RM_MARK(i) do { if (rtrace) rstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RM_MARK(i) do { } while (0)
+#endif
 
 // orders a wave's LDS writes before its later LDS reads of the same (wave-private) bytes through other lanes and pointer types
 __device__ __forceinline__ void wave_lds_sync() {
@@ -189,9 +194,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
     for (int k = 0; k < OC; ++k) eR[k] = epi[k];
     const size_t rowHalfs = static_cast<size_t>(p.OW) * OC;
     const int validCols = min(TW, p.OW - ox0);
+#ifdef SNNHIP_RM_TRACE
+    const bool rtrace = blockIdx.x == 700 && (tid == 0 || tid == 192);
+    unsigned long long rstamp[6] = {};
+#endif
     for (int it = 0; it < nIter; ++it) {
         const bool more = it + 1 < nIter;
+        RM_MARK(0);
         if (more) load_group(it + 2); // consumed after this iteration's MFMAs and epilogue
+        RM_MARK(1);
 
         // ---- wave = output rows 2w, 2w + 1 of the iteration x both 32-column tiles
         f32x16 acc[2][2];
@@ -230,7 +241,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        RM_MARK(2);
         __syncthreads(); // every wave is done with the older group: its ring rows may be overwritten (below, after the epilogue)
+        RM_MARK(3);
 
         // ---- epilogue, per wave: shift-add by lane pulls, bias -> BN -> activation, row packed in the wave's LDS line, 4-byte stores
 #pragma unroll
@@ -317,8 +330,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
             wave_lds_sync();
         }
 
+        RM_MARK(4);
         if (more) store_group(it + 2);
+        RM_MARK(5);
         __syncthreads();
+#ifdef SNNHIP_RM_TRACE
+        if (rtrace && it >= 4 && it < 7)
+            printf("rmtrace tid %d it %d: loads %llu mfma %llu bar1 %llu epi %llu batch %llu bar2 %llu total %llu\n", tid, it, rstamp[1] - rstamp[0], rstamp[2] - rstamp[1], rstamp[3] - rstamp[2],
+                   rstamp[4] - rstamp[3], rstamp[5] - rstamp[4], __builtin_readcyclecounter() - rstamp[5], __builtin_readcyclecounter() - rstamp[0]);
+#endif
     }
 }
 

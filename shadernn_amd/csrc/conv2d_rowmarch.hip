@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
     const int validCols = min(TW, p.OW - ox0);
 #ifdef SNNHIP_RM_TRACE
     const bool rtrace = blockIdx.x == 700 && (tid == 0 || tid == 192);
-    unsigned long long rstamp[6] = {};
+    unsigned long long rstamp[6] = {}, estamp[8] = {};
 #endif
     for (int it = 0; it < nIter; ++it) {
         const bool more = it + 1 < nIter;
@@ -264,6 +264,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                 for (int k = 0; k < OC; ++k) o[k] = 0.0f;
                 // all pulls of the row tile are issued before the first is used (one at a time each waited out its LDS round trip: ~50 exposed waits
                 // per iteration)
+#ifdef SNNHIP_RM_TRACE
+                if (rtrace && j == 0 && t == 0) estamp[0] = __builtin_readcyclecounter();
+#endif
                 float pv[16], pn[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -288,9 +291,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                     if (n1 >= K * OC) q = h1 ? 0.0f : q;
                     o[n0 % OC] += q;
                 }
+#ifdef SNNHIP_RM_TRACE
+                if (rtrace && j == 0 && t == 0) estamp[1] = __builtin_readcyclecounter();
+#endif
                 float tot[OC]; // (the exchange runs with every lane active: a pull from a disabled lane returns 0)
 #pragma unroll
                 for (int k = 0; k < OC; ++k) tot[k] = o[k] + __shfl_xor(o[((k - 4) % OC + OC) % OC], 32); // half 0: channel k of the other half sits in ITS accumulator (k - 4) mod OC
+#ifdef SNNHIP_RM_TRACE
+                if (rtrace && j == 0 && t == 0) estamp[2] = __builtin_readcyclecounter();
+#endif
                 if (!h1) {
 #pragma unroll
                     for (int k = 0; k < OC; ++k) {
@@ -309,7 +318,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                     }
                 }
             }
+#ifdef SNNHIP_RM_TRACE
+            if (rtrace && j == 0) estamp[3] = __builtin_readcyclecounter();
+#endif
             wave_lds_sync();
+#ifdef SNNHIP_RM_TRACE
+            if (rtrace && j == 0) estamp[4] = __builtin_readcyclecounter();
+#endif
             // the row: validCols * OC halfs, contiguous in the output
             const size_t base = (static_cast<size_t>(n) * p.OH + oy) * rowHalfs + static_cast<size_t>(ox0) * OC;
             _Float16* const yr = y + base;
@@ -331,6 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                 }
             }
             wave_lds_sync();
+#ifdef SNNHIP_RM_TRACE
+            if (rtrace && j == 0) estamp[5] = __builtin_readcyclecounter();
+#endif
         }
 
         RM_MARK(4);
@@ -338,6 +356,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
         RM_MARK(5);
         __syncthreads();
 #ifdef SNNHIP_RM_TRACE
+        if (rtrace && it >= 4 && it < 7)
+            printf("rmepi tid %d it %d: j0t0 pulls+acc %llu shfl %llu | row0 to-line %llu sync %llu stores %llu\n", tid, it, estamp[1] - estamp[0], estamp[2] - estamp[1], estamp[3] - estamp[0],
+                   estamp[4] - estamp[3], estamp[5] - estamp[4]);
         if (rtrace && it >= 4 && it < 7)
             printf("rmtrace tid %d it %d: loads %llu mfma %llu bar1 %llu epi %llu batch %llu bar2 %llu total %llu\n", tid, it, rstamp[1] - rstamp[0], rstamp[2] - rstamp[1], rstamp[3] - rstamp[2],
                    rstamp[4] - rstamp[3], rstamp[5] - rstamp[4], __builtin_readcyclecounter() - rstamp[5], __builtin_readcyclecounter() - rstamp[0]);

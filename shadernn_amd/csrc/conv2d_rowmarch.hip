@@ -332,10 +332,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
             if ((base & 1) == 0) { // (uniform) 4-byte aligned row start: consecutive lanes store consecutive dwords
                 const unsigned* const lw = reinterpret_cast<const unsigned*>(line);
                 unsigned* const yw = reinterpret_cast<unsigned*>(yr);
+                constexpr int NQ = (TW * OC / 2 + 63) / 64;
+                unsigned dw[NQ];
 #pragma unroll
-                for (int q = 0; q < (TW * OC / 2 + 63) / 64; ++q) {
+                for (int q = 0; q < NQ; ++q) dw[q] = lw[lane + 64 * q]; // (both reads first: one LDS round trip per row, not one per store)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
                     const int d = lane + 64 * q;
-                    if (2 * d + 1 < nh) yw[d] = lw[d];
+                    if (2 * d + 1 < nh) yw[d] = dw[q];
                 }
                 if ((nh & 1) && lane == 0) yr[nh - 1] = line[nh - 1];
             } else {
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                     if (e < nh) yr[e] = line[e];
                 }
             }
-            wave_lds_sync();
+            asm volatile("" ::: "memory"); // (the line of row j is not written again before the next iteration: LDS order does the rest)
 #ifdef SNNHIP_RM_TRACE
             if (rtrace && j == 0) estamp[5] = __builtin_readcyclecounter();
 #endif

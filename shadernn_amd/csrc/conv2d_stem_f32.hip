@@ -3,8 +3,11 @@
 //
 // conv2d_mfma_kernel's tap-pair mode walks the taps with a rolled loop and one LDS operand read per MFMA: the 7x7 stem of ResNet-18 (batch 32) ran
 // at 58 TF/s, 130 us, bound by instruction issue.  The structure of conv2d_stem_f16.hip, for fp32:
-//   * a pixel = 4 floats in LDS, stored {c0, c2, c1, c3}: lane half h reads the 8 bytes {c_h, c_(2+h)} of a tap with ONE ds_read_b64 and feeds
-//     two MFMAs with them (K = 2 per MFMA: channel pair (0,1), then (2,3)); 2 MFMAs per tap, 3 of 4 operand slots carry data;
+//   * lane half h reads the 8 bytes {c_h, c_(2+h)} of a tap's pixel with ONE ds_read_b64 and feeds two MFMAs with them (K = 2 per MFMA: channel
+//     pair (0,1), then (2,3)); 2 MFMAs per tap, 3 of 4 operand slots carry data.  The tile sits in LDS as PLANES [row][h][column parity][column / 2]
+//     of those 8-byte pairs (stride 1: no parity split): the 32 lanes of an operand read walk 32 CONSECUTIVE pairs = all 64 banks once.  (Round 2
+//     stored a pixel as 16 bytes {c0, c2, c1, c3}: at stride 2 the lanes sat 32 bytes apart, 8 bank pairs for 32 lanes -- PMC: SQ_LDS_BANK_CONFLICT
+//     65 % of SQ_LDS_IDX_ACTIVE on the ResNet-18 stem, 51 % on MobileNetV2's.)
 //   * ALL weights of a 32-channel output block in registers (2 k^2 floats per lane: the MFMA's A operand is one VGPR), loaded once per wave;
 //   * a wave owns NR = 4 output rows x 32 columns: the operand of (input row r, tap column fx) is read ONCE and feeds the MFMAs of every output
 //     row y with r - s y a valid kernel row; straight-line code;
@@ -27,6 +30,7 @@ struct Stem32Params {
 };
 
 constexpr int kTW = 32;                 // block tile: 4 waves stacked in y, NR output rows per wave (4; 2 on grids that leave CUs idle: half the latency)
+constexpr int kPlaneW = 40;             // 8-byte pairs per plane row (>= 32 + K / 2 + 1; = 8 mod 16: the two parity planes of a staging write group land on distinct banks)
 constexpr int kOutPitch = 36;           // floats per pixel row of a wave's output scratch (32 + 4: 16-byte aligned, the runs of 8 lanes on distinct banks)
 
 
@@ -38,8 +42,10 @@ __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem
     constexpr int ROWS = (kNR - 1) * S + K;                           // input rows a wave touches
     constexpr int NW = 2 * K * K;                                     // weight registers per lane
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const tile = smem;                                         // [IN_H][IN_W][4]
-    float* const oscr = smem + IN_H * IN_W * 4;                       // [4 waves][32][kOutPitch]
+    constexpr int NP = S == 2 ? 2 : 1;                                // column-parity planes
+    constexpr int ROWFL = 2 * NP * kPlaneW * 2;                       // floats per tile row: [h][parity][kPlaneW] pairs
+    float* const tile = smem;                                         // [IN_H][2][NP][kPlaneW][2]
+    float* const oscr = smem + IN_H * ROWFL;                          // [4 waves][32][kOutPitch]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, h = lane >> 5;
     const int mt = blockIdx.x;
@@ -54,7 +60,15 @@ __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem
         for (int s = 0; s < NW; ++s) wa[s] = wsrc[s * 64];
     }
 
-    // ---- stage the halo tile: pixel -> {c0, c2, c1, c3}; every load of the thread is issued before its first LDS write
+    // the lane's 16 rows of the epilogue table, requested up front (at the top of the epilogue they were 16 loads the wave sat out: an L2 round trip
+    // in a block that lives for a few microseconds)
+    float4 e[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[4 * g + k] = epi[blockIdx.y * 32 + 8 * g + 4 * h + k];
+
+    // ---- stage the halo tile into the pair planes; every load of the thread is issued before its first LDS write
     constexpr int kR = (IN_H * IN_W + 255) / 256;
     {
         float sv[kR][4];
@@ -72,7 +86,12 @@ __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
             const int e = tid + 256 * r;
-            if (e < IN_H * IN_W) *reinterpret_cast<float4*>(tile + e * 4) = make_float4(sv[r][0], sv[r][2], sv[r][1], sv[r][3]);
+            const int rr = e / IN_W, c = e - rr * IN_W;
+            if (e < IN_H * IN_W) {
+                float* const d0 = tile + rr * ROWFL + ((S == 2 ? (c & 1) * kPlaneW + (c >> 1) : c)) * 2; // plane h = 0: {c0, c2}
+                *reinterpret_cast<float2*>(d0) = make_float2(sv[r][0], sv[r][2]);
+                *reinterpret_cast<float2*>(d0 + NP * kPlaneW * 2) = make_float2(sv[r][1], sv[r][3]); // plane h = 1: {c1, c3}
+            }
         }
     }
     __syncthreads();
@@ -83,13 +102,13 @@ __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    // operand base of this lane: pixel (row wave*kNR*S, column l32*S) of the tile, floats {c_h, c_(2+h)}
-    const float* const tb = tile + ((wave * kNR * S) * IN_W + l32 * S) * 4 + 2 * h;
+    // operand base of this lane: row wave*kNR*S, plane h, pair l32 (tap column fx adds parity plane fx & 1 and fx / 2 pairs: immediates)
+    const float* const tb = tile + (wave * kNR * S) * ROWFL + (h * NP * kPlaneW + l32) * 2;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
         for (int fx = 0; fx < K; ++fx) {
-            const float2 b = *reinterpret_cast<const float2*>(tb + (r * IN_W + fx) * 4);
+            const float2 b = *reinterpret_cast<const float2*>(tb + r * ROWFL + (S == 2 ? (fx & 1) * kPlaneW + (fx >> 1) : fx) * 2);
 #pragma unroll
             for (int yy = 0; yy < kNR; ++yy) {
                 const int fy = r - yy * S;
@@ -100,11 +119,6 @@ __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem
         }
 
     // ---- epilogue: acc[yy][4g + k] = channel 8g + 4h + k of pixel (row yy, column l32)
-    float4 e[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) e[4 * g + k] = epi[blockIdx.y * 32 + 8 * g + 4 * h + k];
     float* const sc = oscr + wave * (32 * kOutPitch);
 #pragma unroll
     for (int yy = 0; yy < kNR; ++yy) {
@@ -192,7 +206,8 @@ int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     p.OH = g.OH; p.OW = g.OW;
     p.tilesX = up_div(g.OW, kTW); p.tilesY = up_div(g.OH, kTH);
     const int IN_H = (kTH - 1) * S + K, IN_W = (kTW - 1) * S + K;
-    const size_t lds = (static_cast<size_t>(IN_H) * IN_W * 4 + 4 * 32 * kOutPitch) * sizeof(float);
+    (void) IN_W;
+    const size_t lds = (static_cast<size_t>(IN_H) * (2 * (S == 2 ? 2 : 1) * kPlaneW * 2) + 4 * 32 * kOutPitch) * sizeof(float); // [IN_H][2][parity planes][kPlaneW] pairs
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("conv2d_stem32: hipFuncSetAttribute(%zu) failed", lds);
         return SNNHIP_E_HIP;

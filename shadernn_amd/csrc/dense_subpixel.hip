@@ -84,6 +84,65 @@ __global__ __launch_bounds__(256) void dense_kernel(int In, int Out, int batch, 
     }
 }
 
+// Batched classifier heads (batch >= 32, fp32, In % 8 == 0: MobileNetV2's 1280 -> 1000 at batch 256, BASELINE configs[3]) are a small GEMM
+// y[b][o] = sum_i x[b][i] W[o][i], and dense_kernel above -- one wave per output unit, the batch rows re-read per group -- took 85 us for what is 0.66
+// GFLOP and 6.3 MB of operands.  Here: v_mfma_f32_32x32x2_f32 (an exact fp32 fma chain) with the weight rows as the A operand (M = 32 output units) and
+// the batch rows as B (N = 32 images): both operands are row-major with K contiguous, so lane (r = l % 32, kh = l / 32) loads the 16 bytes
+// [r][8 j + 4 kh ..] of each and the four MFMAs of a K block consume the four components (the K permutation is the same on both sides).  A block =
+// one 32 x 32 tile, its four waves split K and add their tiles up through LDS; bias and the CPU path's activation in the epilogue.
+typedef float f32x16d __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void dense_mfma_kernel(int In, int Out, int batch, int act, float leaky, const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y) {
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, kh = lane >> 5;
+    const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int kw = ((In / 4 + 7) / 8) * 8; // K range of a wave (multiple of 8)
+    const int kBeg = wave * kw, kEnd = min(In, kBeg + kw);
+    const bool aOk = o0 + r < Out, bOk = b0 + r < batch;
+    const float4* ap = reinterpret_cast<const float4*>(w + static_cast<size_t>(min(o0 + r, Out - 1)) * In + 4 * kh);
+    const float4* bp = reinterpret_cast<const float4*>(x + static_cast<size_t>(min(b0 + r, batch - 1)) * In + 4 * kh);
+    f32x16d acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = kBeg; k0 < kEnd; k0 += 32) { // four K blocks (eight loads) in flight per lane
+        float4 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = k0 + 8 * j < kEnd;
+            a[j] = (in && aOk) ? ap[(k0 + 8 * j) / 4] : zero4;
+            b[j] = (in && bOk) ? bp[(k0 + 8 * j) / 4] : zero4;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b[j].w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    // D layout: lane (column = image b0 + l % 32, half h) holds rows (output units) 8 (i / 4) + 4 h + i % 4
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, i = e >> 6, ln = e & 63;
+        const int b = b0 + (ln & 31), o = o0 + 8 * (i >> 2) + 4 * (ln >> 5) + (i & 3);
+        if (b < batch && o < Out) {
+            float v = ((red[0][i][ln] + red[1][i][ln]) + (red[2][i][ln] + red[3][i][ln])) + bias[o];
+            switch (act) {
+            case SNNHIP_DENSE_RELU: v = v > 0 ? v : 0.0f * v; break;
+            case SNNHIP_DENSE_LEAKY: v = v > 0 ? v : leaky * v; break;
+            case SNNHIP_DENSE_SIGMOID: v = 1.0f / (1.0f + expf(-v)); break;
+            case SNNHIP_DENSE_TANH: v = (expf(2 * v) - 1) / (expf(2 * v) + 1); break;
+            default: break;
+            }
+            y[static_cast<size_t>(b) * Out + o] = v;
+        }
+    }
+}
+
 // softmax over one output row per block (cpulayer.h:173-189): max, exp(x-max), sum, divide
 __global__ __launch_bounds__(256) void softmax_rows_kernel(int Out, float* __restrict__ y) {
     __shared__ float red[4];
@@ -118,6 +177,7 @@ struct DensePlan : snnhip_plan {
     float* d_w = nullptr;
     float* d_b = nullptr;
     float* d_row = nullptr; // fp32 result rows when the output tensor holds halfs
+    bool mfma = false;      // batch >= 32, In % 8 == 0 (fp32 tensors): dense_mfma_kernel
 
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "dense: expects 1 input, got %d", nIn);
@@ -132,6 +192,7 @@ struct DensePlan : snnhip_plan {
         const bool vec = (d.in_units % 4) == 0;
         const bool half = out->dtype == SNNHIP_F16;
         float* rows = half ? d_row : out->data;
+        const bool useMfma = !half && mfma; // batched fp32 heads: the 32 x 32-tile MFMA GEMM
         if (half) {
             const _Float16* xh = reinterpret_cast<const _Float16*>(x->data);
 #define SNNHIP_DENSE(V, TXX, XP)                                                                                                                          \
@@ -141,11 +202,14 @@ struct DensePlan : snnhip_plan {
     } while (0)
             if (vec) SNNHIP_DENSE(true, _Float16, xh);
             else SNNHIP_DENSE(false, _Float16, xh);
+        } else if (useMfma) {
+            hipLaunchKernelGGL(dense_mfma_kernel, dim3(up_div(d.out_units, 32), up_div(d.batch, 32)), dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky,
+                               x->data, d_w, d_b, rows);
         } else {
             if (vec) SNNHIP_DENSE(true, float, x->data);
             else SNNHIP_DENSE(false, float, x->data);
-#undef SNNHIP_DENSE
         }
+#undef SNNHIP_DENSE
         SNNHIP_CHECK_HIP(hipGetLastError());
         if (d.act == SNNHIP_DENSE_SOFTMAX) {
             hipLaunchKernelGGL(softmax_rows_kernel, dim3(d.batch), dim3(256), 0, ctx->stream, d.out_units, rows);
@@ -224,8 +288,11 @@ int make_dense_plan(snnhip_ctx* ctx, const snnhip_dense_desc& d, const float* w_
     plan->outDims[0] = d.batch; plan->outDims[1] = 1; plan->outDims[2] = 1; plan->outDims[3] = d.out_units;
     plan->flops = 2.0 * d.batch * static_cast<double>(d.in_units) * d.out_units;
     plan->bytes = 4.0 * (static_cast<double>(d.in_units) * d.out_units + static_cast<double>(d.batch) * (d.in_units + d.out_units) + d.out_units);
-    char buf[160];
-    snprintf(buf, sizeof(buf), "dense_f32 wave-per-row in=%d out=%d batch=%d act=%d", d.in_units, d.out_units, d.batch, d.act);
+    const char* dm = snnhip::option("SNNHIP_DENSE_MFMA");
+    plan->mfma = d.batch >= 32 && d.in_units % 8 == 0 && !(dm && atoi(dm) == 0);
+    char buf[200];
+    snprintf(buf, sizeof(buf), "dense_f32 %s in=%d out=%d batch=%d act=%d", plan->mfma ? "mfma_f32_32x32x2 GEMM (32x32 tiles, K over 4 waves; half tensors: wave-per-row)" : "wave-per-row",
+             d.in_units, d.out_units, d.batch, d.act);
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

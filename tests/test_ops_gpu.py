@@ -117,6 +117,28 @@ def test_dense_matches_oracle(ctx, act, batch, inu, outu):
     np.testing.assert_allclose(y, want, **TOL)
 
 
+@pytest.mark.parametrize("act", ["relu", "", "softmax", "tanh"])
+@pytest.mark.parametrize("batch,inu,outu", [(256, 1280, 1000), (32, 512, 1000), (33, 72, 37), (100, 40, 5)])
+def test_dense_batched_mfma_gemm_matches_oracle_and_the_wave_per_row_kernel(ctx, monkeypatch, act, batch, inu, outu):
+    """dense_mfma_kernel (batch >= 32, fp32, In % 8 == 0): the classifier heads of BASELINE configs[2] / [3] at their batch sizes, ragged tiles in both
+    directions, a K range that does not split evenly over the four waves; against the oracle and the wave-per-row kernel (SNNHIP_DENSE_MFMA=0)."""
+    import shadernn_amd as snn
+
+    x = _rand((batch, 1, 1, inu), 31)
+    w = _rand((outu * inu,), 32, 1.0 / np.sqrt(inu))
+    b = _rand((outu,), 33, 0.1)
+    plan = snn.dense_plan(ctx, batch, w, outu, b, act=act, leaky=0.3)
+    assert "GEMM" in plan.describe(), plan.describe()
+    xt = snn.Tensor.from_numpy(ctx, x)
+    y = plan(xt).numpy().reshape(batch, outu)
+    want = O.dense(x.reshape(batch, inu), w, outu, b, act, 0.3)
+    np.testing.assert_allclose(y, want, err_msg=plan.describe(), **TOL)
+    monkeypatch.setenv("SNNHIP_DENSE_MFMA", "0")
+    old = snn.dense_plan(ctx, batch, w, outu, b, act=act, leaky=0.3)
+    assert "GEMM" not in old.describe()
+    np.testing.assert_allclose(y, old(xt).numpy().reshape(batch, outu), rtol=2e-5, atol=2e-6)
+
+
 def test_dense_flattens_hwc(ctx):
     """Dense consumes a [N,H,W,C] activation in HWC order (reference CPU flatten, cpulayer.h:94-113)."""
     import shadernn_amd as snn

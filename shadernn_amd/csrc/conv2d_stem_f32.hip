@@ -30,7 +30,9 @@ struct Stem32Params {
 };
 
 constexpr int kTW = 32;                 // block tile: 4 waves stacked in y, NR output rows per wave (4; 2 on grids that leave CUs idle: half the latency)
-constexpr int kPlaneW = 40;             // 8-byte pairs per plane row (>= 32 + K / 2 + 1; = 8 mod 16: the two parity planes of a staging write group land on distinct banks)
+// 8-byte pairs per plane row: the 32 pairs of an operand read + the taps' reach, as tight as the kernel allows (the 3x3 stride-2 tile must leave room for
+// three blocks per CU: 40 pairs per row cost MobileNetV2's stem 161 -> 175 us)
+__host__ __device__ constexpr int plane_w(int K, int S) { return S == 2 ? (K == 7 ? 36 : 33) : 32 + K - 1; }
 constexpr int kOutPitch = 36;           // floats per pixel row of a wave's output scratch (32 + 4: 16-byte aligned, the runs of 8 lanes on distinct banks)
 
 
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem
     constexpr int NW = 2 * K * K;                                     // weight registers per lane
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NP = S == 2 ? 2 : 1;                                // column-parity planes
+    constexpr int kPlaneW = plane_w(K, S);
     constexpr int ROWFL = 2 * NP * kPlaneW * 2;                       // floats per tile row: [h][parity][kPlaneW] pairs
     float* const tile = smem;                                         // [IN_H][2][NP][kPlaneW][2]
     float* const oscr = smem + IN_H * ROWFL;                          // [4 waves][32][kOutPitch]
@@ -207,7 +210,7 @@ int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     p.tilesX = up_div(g.OW, kTW); p.tilesY = up_div(g.OH, kTH);
     const int IN_H = (kTH - 1) * S + K, IN_W = (kTW - 1) * S + K;
     (void) IN_W;
-    const size_t lds = (static_cast<size_t>(IN_H) * (2 * (S == 2 ? 2 : 1) * kPlaneW * 2) + 4 * 32 * kOutPitch) * sizeof(float); // [IN_H][2][parity planes][kPlaneW] pairs
+    const size_t lds = (static_cast<size_t>(IN_H) * (2 * (S == 2 ? 2 : 1) * plane_w(K, S) * 2) + 4 * 32 * kOutPitch) * sizeof(float); // [IN_H][2][parity planes][kPlaneW] pairs
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("conv2d_stem32: hipFuncSetAttribute(%zu) failed", lds);
         return SNNHIP_E_HIP;

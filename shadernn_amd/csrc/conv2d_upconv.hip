@@ -45,6 +45,11 @@ struct UpParams {
     NormFoldArgs fold;
 };
 
+#ifdef SNNHIP_UP_TRACE // experiment builds (tools/exp_one.sh)
+#define UP_MARK(i) do { if (utrace) ustamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define UP_MARK(i) do { } while (0)
+#endif
 constexpr int kTP = 34; // staged pixels per low-resolution row: the strip's 32 + one on either side
 #ifndef SNNHIP_UPCONV_OCC
 #define SNNHIP_UPCONV_OCC 2 // waves per SIMD the 256-thread form is compiled for (3 = 168 VGPRs: the statistics accumulators then spill to scratch)
@@ -145,9 +150,15 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
     float st1[8], st2[8], stN = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.0f;
+#ifdef SNNHIP_UP_TRACE
+    const bool utrace = blockIdx.x == 900 && blockIdx.y == 0 && (tid == 0 || tid == 192);
+    unsigned long long ustamp[8] = {};
+#endif
     for (int it = 0; it < nIter; ++it) {
         const bool more = it + 1 < nIter;
+        UP_MARK(0);
         if (more) load_batch(it + 2);
+        UP_MARK(1);
 
         // ---- wave = phase (py, px) of low-resolution rows MT it, MT it + 1: row j takes taps a = 0, 1 from relative rows MT it + j + py + a
         f32x16 acc[MT];
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
         }
 
         // ---- epilogue into the LDS tile: acc[j][4 g + k] = channel ocb + 32 nt + 8 g + 4 h + k of output pixel (2 j + py, 2 l32 + px) of the tile
+        UP_MARK(2);
         // (one channel run of 4 at a time: holding all 32 table values of the lane next to the weights, both accumulators and the rows in flight made the
         // compiler park the prefetched rows in scratch memory -- behind an s_waitcnt vmcnt(0) right after their loads)
 #pragma unroll
@@ -208,7 +220,9 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
                 *reinterpret_cast<h4*>(otile + ((2 * j + py) * 64 + 2 * l32 + px) * EP + 32 * nt + 8 * g + 4 * h) = o;
             }
         }
+        UP_MARK(3);
         __syncthreads(); // the tile is complete, and every wave is done with the ring rows that retire
+        UP_MARK(4);
 
         // ---- the 4 x 64 tile leaves as 16-byte vectors, a pixel's BN channels contiguous
         const int mIt = m0 + MT * it;
@@ -234,8 +248,15 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
                 }
             }
         }
+        UP_MARK(5);
         if (more) store_batch(it + 2);
+        UP_MARK(6);
         __syncthreads();
+#ifdef SNNHIP_UP_TRACE
+        if (utrace && it >= 4 && it < 7)
+            printf("uptrace tid %d it %d: loads %llu mfma %llu epi %llu bar1 %llu stores %llu batch %llu bar2 %llu total %llu\n", tid, it, ustamp[1] - ustamp[0], ustamp[2] - ustamp[1],
+                   ustamp[3] - ustamp[2], ustamp[4] - ustamp[3], ustamp[5] - ustamp[4], ustamp[6] - ustamp[5], __builtin_readcyclecounter() - ustamp[6], __builtin_readcyclecounter() - ustamp[0]);
+#endif
     }
 
     if (!p.statRec) return; // (uniform)

@@ -145,6 +145,12 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
 
     const float* const et = epiTab + 32 * nt + 4 * h; // this lane's channel runs: 8 g + 4 h + k of the wave's 32-channel tile
     const bool actSimple = act_is_simple_dev(ac.act);
+    float shReg[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 sh = *reinterpret_cast<const float4*>(et + BN + 8 * g);
+        shReg[4 * g] = sh.x; shReg[4 * g + 1] = sh.y; shReg[4 * g + 2] = sh.z; shReg[4 * g + 3] = sh.w;
+    }
     // rule F: a thread's vectors of the store loop are pixels of ONE 8-channel column (T % (BN / 8) == 0): sums of (v - pivot) and (v - pivot)^2 of the
     // stored (rounded) values accumulate while they pass; pivot = the channel's bias (shift), the same in every block, so records simply add up
     float st1[8], st2[8], stN = 0.0f;
@@ -188,19 +194,19 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
 
         // ---- epilogue into the LDS tile: acc[j][4 g + k] = channel ocb + 32 nt + 8 g + 4 h + k of output pixel (2 j + py, 2 l32 + px) of the tile
         UP_MARK(2);
-        // (one channel run of 4 at a time: holding all 32 table values of the lane next to the weights, both accumulators and the rows in flight made the
-        // compiler park the prefetched rows in scratch memory -- behind an s_waitcnt vmcnt(0) right after their loads)
+        // The lane's 16 shift values live in registers for the whole strip (shReg); only batch-norm layers read their scale per channel run from LDS.
+        // (Read per run inside the loop -- four dependent LDS round trips -- the epilogue was 1 844 of an iteration's 4 600 cycles; holding all 32
+        // table values of a BN layer next to the weights made the compiler park the prefetched rows in scratch memory.)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 sh = *reinterpret_cast<const float4*>(et + BN + 8 * g);
             float4 sc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
             if (p.useBN) sc = *reinterpret_cast<const float4*>(et + 8 * g);
-            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
             float rv[MT][4];
 #pragma unroll
             for (int j = 0; j < MT; ++j)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) rv[j][k] = fmaf(acc[j][4 * g + k], scv[k], shv[k]);
+                for (int k = 0; k < 4; ++k) rv[j][k] = fmaf(acc[j][4 * g + k], scv[k], shReg[4 * g + k]);
             if (actSimple) { // (tested per channel run, not per value: a branch is a pipeline drain)
 #pragma unroll
                 for (int j = 0; j < MT; ++j)

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--round", default="r02")
     a = ap.parse_args()
     out, prof = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-    names = {"c2": "%s_c2_rocprofv3_summary.md", "c3": "%s_c3_resnet18_rocprofv3_summary.md", "c4": "%s_c4_mobilenetv2_rocprofv3_summary.md",
+    names = {"c1": "%s_c1_conv3x3_rocprofv3_summary.md", "c2": "%s_c2_rocprofv3_summary.md", "c3": "%s_c3_resnet18_rocprofv3_summary.md", "c4": "%s_c4_mobilenetv2_rocprofv3_summary.md",
              "c5": "%s_c5_candy_fp16_rocprofv3_summary.md"}
     pmc = {}
     for c, fmt in names.items():

@@ -47,6 +47,11 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
     constexpr int kDepth = NT == 1 ? 8 : 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
+#ifdef SNNHIP_STREAM_TRACE // experiment builds (tools/exp_one.sh)
+    const bool strace = blockIdx.x == 40 && blockIdx.y == 1 && lane == 0 && (wave == 0 || wave == 3);
+    unsigned long long sstamp[5] = {};
+    if (strace) sstamp[0] = __builtin_readcyclecounter();
+#endif
     {
         const int cnt = p.nChunks * 2 * BN;
         const float4* src = wp + static_cast<size_t>(blockIdx.y) * cnt;
@@ -56,6 +61,9 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
 #pragma unroll
     for (int u = 0; u < NT; ++u) e[u] = epi[n0 + u * 32 + l32]; // table padded to the block grid's channel count
     __syncthreads();
+#ifdef SNNHIP_STREAM_TRACE
+    if (strace) sstamp[1] = __builtin_readcyclecounter();
+#endif
 
     // one 32-pixel tile per wave.  (A persistent walk over several tiles per wave, with the next tile's first chunks requested before the
     // epilogue, measured 10-100 % SLOWER the more tiles a wave owned: these layers live on memory-level parallelism, and a wave that is busy
@@ -111,6 +119,9 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
             }
         }
     }
+#ifdef SNNHIP_STREAM_TRACE
+    if (strace) sstamp[2] = __builtin_readcyclecounter();
+#endif
     // epilogue: bias -> BN -> activation [-> + residual -> activation of the Add layer], 128-byte channel-contiguous stores
     const int row0 = tile * 32 + 4 * h;
     const bool addSimple = act_is_simple_dev(p.ac2.act);
@@ -132,6 +143,11 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
                 }
             }
         }
+#ifdef SNNHIP_STREAM_TRACE
+    if (strace)
+        printf("streamtrace ic %d oc %d NT %d M %d res %d wave %d: weights+barrier %llu kloop %llu epilogue %llu\n", p.IC, p.OC, NT, p.M, p.res != nullptr, wave, sstamp[1] - sstamp[0],
+               sstamp[2] - sstamp[1], __builtin_readcyclecounter() - sstamp[2]);
+#endif
 }
 
 // fp16 tensors (half storage, fp32 accumulation on v_mfma_f32_32x32x16_f16): a chunk is 16 channels, lane (row, h) loads the 16 bytes

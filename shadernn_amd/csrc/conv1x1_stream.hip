@@ -52,10 +52,18 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
     unsigned long long sstamp[5] = {};
     if (strace) sstamp[0] = __builtin_readcyclecounter();
 #endif
-    {
+    {   // the block's weight slice -> LDS, eight loads in flight per thread (one at a time -- load, wait, store -- the staging of a 320 x 64 slice took
+        // 21 000 cycles of a 90 000-cycle block: an L2 round trip per 16 bytes)
         const int cnt = p.nChunks * 2 * BN;
         const float4* src = wp + static_cast<size_t>(blockIdx.y) * cnt;
-        for (int i = tid; i < cnt; i += 256) s_w[i] = src[i];
+        for (int i0 = tid; i0 < cnt; i0 += 256 * 8) {
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = src[min(i0 + 256 * j, cnt - 1)]; // (unconditional: a partly written register array goes to scratch)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (i0 + 256 * j < cnt) s_w[i0 + 256 * j] = t[j];
+        }
     }
     float4 e[NT];
 #pragma unroll
@@ -122,27 +130,82 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
 #ifdef SNNHIP_STREAM_TRACE
     if (strace) sstamp[2] = __builtin_readcyclecounter();
 #endif
-    // epilogue: bias -> BN -> activation [-> + residual -> activation of the Add layer], 128-byte channel-contiguous stores
+    // epilogue: bias -> BN -> activation [-> + residual -> activation of the Add layer]
     const int row0 = tile * 32 + 4 * h;
     const bool addSimple = act_is_simple_dev(p.ac2.act);
+    if ((p.OC & 3) == 0) {
+        // A lane holds ONE channel (column l32) of 16 pixels; written as it stands that is 16 NT scalar stores per lane (48 for a 96-channel tile: the
+        // phase trace of MobileNetV2's expand layers had the epilogue as long as the K loop).  The four values of a channel run (pixels R .. R + 3) are
+        // transposed across the four lanes of a quad (channels 4m .. 4m + 3) with two DPP exchange steps: lane q then holds pixel R + q, channels
+        // 4m .. 4m + 3 -- ONE 16-byte store, the quads of a row side by side (whole 128-byte lines), a quarter of the store instructions; the residual
+        // of a fused Add arrives the same way, as 16-byte loads that are all requested before the first store.
+        const int q = l32 & 3, m4 = l32 & ~3;
+        const bool qb0 = (q & 1) != 0, qb1 = (q & 2) != 0;
+        float4 rv[NT][4];
+        if (p.res) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+            for (int u = 0; u < NT; ++u)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int row = row0 + 8 * g + k;
-            if (row < p.M) {
-                const size_t o = static_cast<size_t>(row) * p.OC + n0 + l32;
+                for (int g = 0; g < 4; ++g) {
+                    const int row = row0 + 8 * g + q, c0 = n0 + u * 32 + m4;
+                    rv[u][g] = (row < p.M && c0 < p.OC) ? *reinterpret_cast<const float4*>(p.res + static_cast<size_t>(row) * p.OC + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
 #pragma unroll
-                for (int u = 0; u < NT; ++u) {
-                    if (n0 + u * 32 + l32 < p.OC) {
-                        float v = epi_affine(acc[u][4 * g + k], e[u], p.useBN);
-                        v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
-                        if (p.res) v = add_act(p.ac2, addSimple, v + p.res[o + u * 32]);
-                        y[o + u * 32] = v;
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = epi_affine(acc[u][4 * g + k], e[u], p.useBN);
+                    v[k] = SIMPLE ? apply_act<true>(ac, t, 0.0f) : epi_act(ac.act, ac.leaky, t, 0.0f);
+                }
+                // 4 x 4 transpose (register index k <-> lane index q of the quad): swap bit 0 with the lane one over, then bit 1 with the lane two over
+                float x[4], t1[4], o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[k]), 0xB1, 0xF, 0xF, true)); // quad_perm [1, 0, 3, 2]
+                t1[0] = qb0 ? x[1] : v[0];
+                t1[1] = qb0 ? v[1] : x[0];
+                t1[2] = qb0 ? x[3] : v[2];
+                t1[3] = qb0 ? v[3] : x[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t1[k]), 0x4E, 0xF, 0xF, true)); // quad_perm [2, 3, 0, 1]
+                o[0] = qb1 ? x[2] : t1[0];
+                o[1] = qb1 ? x[3] : t1[1];
+                o[2] = qb1 ? t1[2] : x[0];
+                o[3] = qb1 ? t1[3] : x[1];
+                const int row = row0 + 8 * g + q, c0 = n0 + u * 32 + m4;
+                if (row < p.M && c0 < p.OC) {
+                    if (p.res) {
+                        o[0] = add_act(p.ac2, addSimple, o[0] + rv[u][g].x);
+                        o[1] = add_act(p.ac2, addSimple, o[1] + rv[u][g].y);
+                        o[2] = add_act(p.ac2, addSimple, o[2] + rv[u][g].z);
+                        o[3] = add_act(p.ac2, addSimple, o[3] + rv[u][g].w);
+                    }
+                    *reinterpret_cast<float4*>(y + static_cast<size_t>(row) * p.OC + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = row0 + 8 * g + k;
+                if (row < p.M) {
+                    const size_t o = static_cast<size_t>(row) * p.OC + n0 + l32;
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) {
+                        if (n0 + u * 32 + l32 < p.OC) {
+                            float v = epi_affine(acc[u][4 * g + k], e[u], p.useBN);
+                            v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+                            if (p.res) v = add_act(p.ac2, addSimple, v + p.res[o + u * 32]);
+                            y[o + u * 32] = v;
+                        }
                     }
                 }
             }
-        }
+    }
 #ifdef SNNHIP_STREAM_TRACE
     if (strace)
         printf("streamtrace ic %d oc %d NT %d M %d res %d wave %d: weights+barrier %llu kloop %llu epilogue %llu\n", p.IC, p.OC, NT, p.M, p.res != nullptr, wave, sstamp[1] - sstamp[0],
@@ -166,10 +229,18 @@ __global__ __launch_bounds__(256) void conv1x1_stream_f16_kernel(StreamParams p,
     _Float16* __restrict__ y = reinterpret_cast<_Float16*>(yv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
-    {
+    {   // the block's weight slice -> LDS, eight loads in flight per thread (one at a time -- load, wait, store -- the staging of a 320 x 64 slice took
+        // 21 000 cycles of a 90 000-cycle block: an L2 round trip per 16 bytes)
         const int cnt = p.nChunks * 2 * BN;
         const float4* src = wp + static_cast<size_t>(blockIdx.y) * cnt;
-        for (int i = tid; i < cnt; i += 256) s_w[i] = src[i];
+        for (int i0 = tid; i0 < cnt; i0 += 256 * 8) {
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = src[min(i0 + 256 * j, cnt - 1)]; // (unconditional: a partly written register array goes to scratch)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (i0 + 256 * j < cnt) s_w[i0 + 256 * j] = t[j];
+        }
     }
     float4 e[NT];
 #pragma unroll

@@ -30,6 +30,7 @@ struct StreamParams {
     int M;       // pixels = N*H*W
     int IC, OC;
     int nChunks; // IC / 8
+    int phaseChunks; // chunks of the weight slice resident in LDS at a time (= nChunks unless the slice is staged in several K phases; multiple of 8)
     int nTiles;  // ceil(M / 32)
     int useBN;
     int stride, W, HW, OW, OHW; // stride > 1 (ResNet's 1x1 s2 downsample convolutions): output row -> input pixel (n, s*oy, s*ox); HW = H*W, OHW = OH*OW
@@ -52,26 +53,9 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
     unsigned long long sstamp[5] = {};
     if (strace) sstamp[0] = __builtin_readcyclecounter();
 #endif
-    {   // the block's weight slice -> LDS, eight loads in flight per thread (one at a time -- load, wait, store -- the staging of a 320 x 64 slice took
-        // 21 000 cycles of a 90 000-cycle block: an L2 round trip per 16 bytes)
-        const int cnt = p.nChunks * 2 * BN;
-        const float4* src = wp + static_cast<size_t>(blockIdx.y) * cnt;
-        for (int i0 = tid; i0 < cnt; i0 += 256 * 8) {
-            float4 t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = src[min(i0 + 256 * j, cnt - 1)]; // (unconditional: a partly written register array goes to scratch)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (i0 + 256 * j < cnt) s_w[i0 + 256 * j] = t[j];
-        }
-    }
     float4 e[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) e[u] = epi[n0 + u * 32 + l32]; // table padded to the block grid's channel count
-    __syncthreads();
-#ifdef SNNHIP_STREAM_TRACE
-    if (strace) sstamp[1] = __builtin_readcyclecounter();
-#endif
 
     // one 32-pixel tile per wave.  (A persistent walk over several tiles per wave, with the next tile's first chunks requested before the
     // epilogue, measured 10-100 % SLOWER the more tiles a wave owned: these layers live on memory-level parallelism, and a wave that is busy
@@ -80,7 +64,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
     // requesting the first activation chunks BEFORE the weight staging above: vmcnt retires in order, so the L2-resident weights then wait for
     // the HBM loads in front of them and the barrier moves out (16->96 @112x112 36.4 -> 42.2 us).)
     const int tile = blockIdx.x * 4 + wave;
-    if (tile >= p.nTiles) return;
+    const bool active = tile < p.nTiles; // (wave-uniform; an idle wave of the last block still takes part in the barriers of the weight phases)
     // chunk c of the tile's row l32 for this lane's K half; rows past M and chunks past IC read as zero (their products vanish / are not stored)
     const int arow = tile * 32 + l32;
     int irow = arow < p.M ? arow : 0;
@@ -102,31 +86,56 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
     for (int u = 0; u < NT; ++u)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[u][i] = 0.0f;
-    for (int c0 = 0; c0 < p.nChunks; c0 += kDepth) {
-        float4 cur[kDepth];
+    // The weight slice [IC][BN] sits in LDS in K PHASES of p.phaseChunks chunks (one phase for the slices that fit: every MobileNetV2 layer up to 576
+    // input channels; the 960-channel layers of the 7x7 stage take two -- they used to fall to the 128-pixel tile kernel at 0.22-0.34 of the roofline).
+    for (int pb = 0; pb < p.nChunks; pb += p.phaseChunks) {
+        const int pe = min(p.nChunks, pb + p.phaseChunks);
+        if (pb) __syncthreads(); // every wave is done with the previous phase's weights
+        {   // this phase's weights -> LDS, eight loads in flight per thread (one at a time -- load, wait, store -- the staging of a 320 x 64 slice took
+            // 21 000 cycles of a 90 000-cycle block: an L2 round trip per 16 bytes)
+            const int cnt = (pe - pb) * 2 * BN;
+            const float4* src = wp + (static_cast<size_t>(blockIdx.y) * p.nChunks + pb) * 2 * BN;
+            for (int i0 = tid; i0 < cnt; i0 += 256 * 8) {
+                float4 t[8];
 #pragma unroll
-        for (int d = 0; d < kDepth; ++d) cur[d] = nxt[d];
-        if (c0 + kDepth < p.nChunks) {
+                for (int j = 0; j < 8; ++j) t[j] = src[min(i0 + 256 * j, cnt - 1)]; // (unconditional: a partly written register array goes to scratch)
 #pragma unroll
-            for (int d = 0; d < kDepth; ++d) nxt[d] = loadA(c0 + kDepth + d);
+                for (int j = 0; j < 8; ++j)
+                    if (i0 + 256 * j < cnt) s_w[i0 + 256 * j] = t[j];
+            }
         }
+        __syncthreads();
+#ifdef SNNHIP_STREAM_TRACE
+        if (strace && pb == 0) sstamp[1] = __builtin_readcyclecounter();
+#endif
+        if (!active) continue;
+        for (int c0 = pb; c0 < pe; c0 += kDepth) {
+            float4 cur[kDepth];
 #pragma unroll
-        for (int d = 0; d < kDepth; ++d) {
-            if (c0 + d < p.nChunks) { // wave-uniform
-                float4 b[NT];
+            for (int d = 0; d < kDepth; ++d) cur[d] = nxt[d];
+            if (c0 + kDepth < p.nChunks) {
 #pragma unroll
-                for (int u = 0; u < NT; ++u) b[u] = s_w[((c0 + d) * 2 + h) * BN + u * 32 + l32];
+                for (int d = 0; d < kDepth; ++d) nxt[d] = loadA(c0 + kDepth + d);
+            }
 #pragma unroll
-                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].x, b[u].x, acc[u], 0, 0, 0);
+            for (int d = 0; d < kDepth; ++d) {
+                if (c0 + d < pe) { // wave-uniform
+                    float4 b[NT];
 #pragma unroll
-                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].y, b[u].y, acc[u], 0, 0, 0);
+                    for (int u = 0; u < NT; ++u) b[u] = s_w[((c0 + d - pb) * 2 + h) * BN + u * 32 + l32];
 #pragma unroll
-                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].z, b[u].z, acc[u], 0, 0, 0);
+                    for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].x, b[u].x, acc[u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].w, b[u].w, acc[u], 0, 0, 0);
+                    for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].y, b[u].y, acc[u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].z, b[u].z, acc[u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[d].w, b[u].w, acc[u], 0, 0, 0);
+                }
             }
         }
     }
+    if (!active) return;
 #ifdef SNNHIP_STREAM_TRACE
     if (strace) sstamp[2] = __builtin_readcyclecounter();
 #endif
@@ -396,28 +405,41 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     // columns per block: the widest of 96 / 64 / 32 that pads the channel count by at most a third and whose weight slice fits the LDS budget
     size_t ldsCap = 80 * 1024;
     if (const char* e = snnhip::option("SNNHIP_CONV_1X1_LDS_KB")) ldsCap = static_cast<size_t>(atoi(e)) * 1024; // experiments
-    int NT = 0;
+    int NT = 0, KP = 1;
     for (int c = 3; c >= 1 && !NT; --c) {
         const int ocp = (g.OC + 32 * c - 1) / (32 * c) * (32 * c);
         const size_t wBytes = f16 ? static_cast<size_t>((g.IC + 15) / 16) * 2 * 32 * c * 16 + static_cast<size_t>(4) * 32 * (32 * c + 8) * 2
                                   : static_cast<size_t>(g.IC) * 32 * c * 4;
         if ((c == 1 || (ocp - g.OC) * 3 <= g.OC) && wBytes <= ldsCap) NT = c;
     }
+    // fp32 slices that do not fit (MobileNetV2's 960 -> 160 / 320 at 7x7): staged in two K phases of <= 64 KB (two blocks per CU), from a few thousand
+    // pixel rows on (the few-tile layers of a small batch stay with the general kernel's split-K); SNNHIP_CONV_1X1_PHASES=0 switches it off
+    if (!NT && !f16 && M >= 8192.0 && !(snnhip::option("SNNHIP_CONV_1X1_PHASES") && atoi(snnhip::option("SNNHIP_CONV_1X1_PHASES")) == 0)) {
+        for (int c = 2; c >= 1 && !NT; --c) {
+            const int ocp = (g.OC + 32 * c - 1) / (32 * c) * (32 * c);
+            const size_t wBytes = static_cast<size_t>(g.IC) * 32 * c * 4;
+            if ((c == 1 || (ocp - g.OC) * 3 <= g.OC) && wBytes <= 2 * 64 * 1024) {
+                NT = c;
+                KP = 2;
+            }
+        }
+    }
     if (!NT) return SNNHIP_E_UNSUPPORTED;
     if (g.IC >= 128 && static_cast<long long>((nTiles + 3) / 4) * ((g.OC + 32 * NT - 1) / (32 * NT)) < cus / 4 && !(sw && atoi(sw) == 2)) return SNNHIP_E_UNSUPPORTED;
     const int BN = 32 * NT, ocBlocks = (g.OC + BN - 1) / BN, OCp = ocBlocks * BN, nChunks = f16 ? (g.IC + 15) / 16 : g.IC / 8;
+    const int phaseChunks = KP == 1 ? nChunks : ((nChunks + KP - 1) / KP + 7) / 8 * 8; // a multiple of the deepest prefetch (8 chunks)
 
     auto* plan = new Conv1x1StreamPlan();
     plan->ctx = ctx;
     plan->g = g;
     plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC);
     plan->epi4 = epi4;
-    plan->p = StreamParams{static_cast<int>(M), g.IC, g.OC, nChunks, nTiles, g.useBN, g.sh, g.W, g.H * g.W, g.OW, g.OH * g.OW, nullptr,
+    plan->p = StreamParams{static_cast<int>(M), g.IC, g.OC, nChunks, phaseChunks, nTiles, g.useBN, g.sh, g.W, g.H * g.W, g.OW, g.OH * g.OW, nullptr,
                            make_act_cfg(g.addAct >= 0 ? g.addAct : SNNHIP_ACT_NONE, g.addLeaky)};
     plan->ac = make_act_cfg(g.act, g.leaky);
     plan->fusedAdd = g.addAct >= 0;
     if (plan->fusedAdd) plan->numInputs = 2;
-    plan->ldsBytes = static_cast<size_t>(nChunks) * 2 * BN * 16 + (f16 ? static_cast<size_t>(4) * 32 * (BN + 8) * 2 : 0);
+    plan->ldsBytes = static_cast<size_t>(std::min(nChunks, phaseChunks)) * 2 * BN * 16 + (f16 ? static_cast<size_t>(4) * 32 * (BN + 8) * 2 : 0);
     const bool simple = act_is_simple(g.act);
     if (f16) plan->kernel = NT == 3 ? pick16<3>(simple) : NT == 2 ? pick16<2>(simple) : pick16<1>(simple);
     else plan->kernel = NT == 3 ? pick<3>(simple) : NT == 2 ? pick<2>(simple) : pick<1>(simple);
@@ -466,6 +488,7 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     snprintf(buf, sizeof(buf), "conv2d_mfma_%s k=1x1 s=%d ic=%d oc=%d stream: wave = 32px x %doc, grid %dx%d, lds=%zuB", f16 ? "f16_32x32x16" : "f32_32x32x2", g.sh, g.IC, g.OC, BN, gx, ocBlocks,
              plan->ldsBytes);
     plan->desc = buf;
+    if (KP > 1) plan->desc += " (weight slice in " + std::to_string((nChunks + phaseChunks - 1) / phaseChunks) + " K phases)";
     if (plan->fusedAdd) {
         plan->desc += " +add";
         plan->bytes += esz * M * g.OC;

@@ -278,3 +278,34 @@ def test_pointwise_stream_full_size_and_fused_add(ctx):
     want = O.add_act(O.conv2d(x, wt, b, 1, (0, 0, 0, 0), "constant", "", 0.0, bn), skip, "relu", 0.0)
     np.testing.assert_allclose(y, want, err_msg=fused.describe(), **TOL)
     np.testing.assert_allclose(y, add([conv(xt), st]).numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("oc,with_add", [(160, True), (320, False), (36, False)])
+def test_pointwise_stream_weight_slice_in_k_phases(ctx, monkeypatch, oc, with_add):
+    """MobileNetV2's 960-channel pointwise layers of the 7x7 stage at batch 256 (12 544 pixel rows): the [960][32] weight slice does not fit the LDS
+    budget and is staged in two K phases (barriers between them, an idle wave in the last block, the activation prefetch running across the phase
+    boundary); ragged last pixel tile, ragged last column block, fused residual Add.  Against the oracle and the general kernel."""
+    import shadernn_amd as snn
+
+    n, h, w, ic = 8, 32, 32 + 1, 960  # 8448 pixel rows (>= 8192), not a multiple of 128
+    x, wt, b = _rand((n, h, w, ic), 71), _rand((oc, ic, 1, 1), 72, 1.0 / np.sqrt(ic)), _rand((oc,), 73, 0.1)
+    bn = _bn(oc, 74)
+    conv = snn.conv2d_plan(ctx, n, h, w, wt, b, stride=1, pads=(0, 0, 0, 0), act="relu6" if not with_add else "", bn=bn)
+    assert "stream" in conv.describe() and "2 K phases" in conv.describe(), conv.describe()
+    xt = snn.Tensor.from_numpy(ctx, x)
+    want = O.conv2d(x, wt, b, 1, (0, 0, 0, 0), "constant", "relu6" if not with_add else "", 0.0, bn, threads=8)
+    if with_add:
+        skip = _rand((n, h, w, oc), 75)
+        add = snn.add_plan(ctx, n, h, w, oc, act="")
+        fused = snn.chain_plan(ctx, [conv, add])
+        assert fused.num_steps() == 1 and "K phases" in fused.describe() and "+add" in fused.describe(), fused.describe()
+        y = fused([xt, snn.Tensor.from_numpy(ctx, skip)]).numpy()
+        want = O.add_act(want, skip, "", 0.0)
+    else:
+        y = conv(xt).numpy()
+    np.testing.assert_allclose(y, want, err_msg=conv.describe(), **TOL)
+    monkeypatch.setenv("SNNHIP_CONV_1X1_PHASES", "0")
+    gen = snn.conv2d_plan(ctx, n, h, w, wt, b, stride=1, pads=(0, 0, 0, 0), act="relu6" if not with_add else "", bn=bn)
+    assert "K phases" not in gen.describe(), gen.describe()
+    if not with_add:
+        np.testing.assert_allclose(y, gen(xt).numpy(), rtol=2e-5, atol=2e-5)

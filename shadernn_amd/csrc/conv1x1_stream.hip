@@ -426,12 +426,12 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     }
     if (!NT) return SNNHIP_E_UNSUPPORTED;
     // a slice that fits but leaves one or two blocks per CU (320 -> 1280: 80 KB, 576 -> 96: 72 KB) is staged in phases as well: the blocks' weight
-    // staging, K loops and epilogues overlap across more resident blocks (SNNHIP_CONV_1X1_PHASE_KB: the phase budget, 0 = off)
-    if (KP == 1 && !f16 && M >= 8192.0) {
+    // staging, K loops and epilogues overlap across more resident blocks (SNNHIP_CONV_1X1_PHASE_KB: the phase budget, default 26, 0 = off)
+    if (!f16 && M >= 8192.0) {
         const char* pk = snnhip::option("SNNHIP_CONV_1X1_PHASE_KB");
-        const size_t budget = static_cast<size_t>(pk ? atoi(pk) : 0) * 1024;
+        const size_t budget = static_cast<size_t>(pk ? atoi(pk) : 26) * 1024; // (c4 at batch 256: off 3.42 ms, 53 KB 3.37, 40 KB 3.36, 26 / 16 / 12 KB 3.34)
         const size_t wBytes = static_cast<size_t>(g.IC) * 32 * NT * 4;
-        if (budget && wBytes > budget) KP = static_cast<int>(std::min<size_t>(4, (wBytes + budget - 1) / budget));
+        if (budget && wBytes > budget) KP = std::max(KP, static_cast<int>(std::min<size_t>(8, (wBytes + budget - 1) / budget)));
     }
     if (g.IC >= 128 && static_cast<long long>((nTiles + 3) / 4) * ((g.OC + 32 * NT - 1) / (32 * NT)) < cus / 4 && !(sw && atoi(sw) == 2)) return SNNHIP_E_UNSUPPORTED;
     const int BN = 32 * NT, ocBlocks = (g.OC + BN - 1) / BN, OCp = ocBlocks * BN, nChunks = f16 ? (g.IC + 15) / 16 : g.IC / 8;

@@ -242,6 +242,24 @@ __global__ __launch_bounds__(256 * OPB, 3 - OPB) void conv2d_wino_kernel(WinoPar
     for (int o = 0; o < 2; ++o) {
         const int oc = blockIdx.y * (32 * OPB) + (2 * op + o) * 16 + 4 * k;
         if (oc >= p.OC) continue;
+        // the epilogue rows of the lane's four channels and the residual of its 2 x 2 output pixels are requested FIRST, the inverse transform runs in
+        // the shadow of those loads (requested where they are used -- a table load, then per pixel a residual load, each waited out -- they were eight
+        // exposed L2 round trips per wave: conv1x1_stream's phase trace, DESIGN.md 5.1-8, found the same pattern)
+        float4 e4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) e4[c] = epi[oc + c];
+        size_t idx4[2][2];
+        bool ok4[2][2];
+        float4 rv4[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                ok4[r][cx] = !(n >= p.N || oy + r >= p.OH || ox + cx >= p.OW);
+                idx4[r][cx] = ((static_cast<size_t>(n) * p.OH + oy + r) * p.OW + ox + cx) * p.OC + oc;
+                rv4[r][cx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.res && p.splitK == 1 && ok4[r][cx]) rv4[r][cx] = *reinterpret_cast<const float4*>(p.res + idx4[r][cx]);
+            }
         f32x4 yv[2][2];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -256,15 +274,12 @@ __global__ __launch_bounds__(256 * OPB, 3 - OPB) void conv2d_wino_kernel(WinoPar
             yv[1][0][c] = t1[0] + t1[1] + t1[2];
             yv[1][1][c] = t1[1] - t1[2] - t1[3];
         }
-        float4 e4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) e4[c] = epi[oc + c];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int cx = 0; cx < 2; ++cx) {
-                if (n >= p.N || oy + r >= p.OH || ox + cx >= p.OW) continue;
-                const size_t idx = ((static_cast<size_t>(n) * p.OH + oy + r) * p.OW + ox + cx) * p.OC + oc;
+                if (!ok4[r][cx]) continue;
+                const size_t idx = idx4[r][cx];
                 float o4[4];
                 if (p.splitK > 1) {
 #pragma unroll
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(256 * OPB, 3 - OPB) void conv2d_wino_kernel(WinoPar
                     o4[c] = apply_act<SIMPLE>(ac, vv, 0.0f);
                 }
                 if (p.res) {
-                    const float4 rv = *reinterpret_cast<const float4*>(p.res + idx);
+                    const float4 rv = rv4[r][cx];
                     o4[0] = add_act(p.ac2, addSimple, o4[0] + rv.x);
                     o4[1] = add_act(p.ac2, addSimple, o4[1] + rv.y);
                     o4[2] = add_act(p.ac2, addSimple, o4[2] + rv.z);

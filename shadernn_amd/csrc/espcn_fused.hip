@@ -1224,6 +1224,19 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);
             i += 2;
             ++fusedCount;
+        } else if (snnhip_plan* sirb = nullptr; i + 2 < n && c0 && c1 && c2 && !c0->depthwise && c0->g.kh == 3 && c0->g.IC == 3 && c1->depthwise && !c2->depthwise &&
+                                         make_irb_plan(ctx, nullptr, plans[i + 1], plans[i + 2], nullptr, &sirb, plans[i]) == SNNHIP_OK) {
+            // ---- rule G with the network's stem as the 'expand' layer: Conv2D 3x3 (3 -> C channels) -> DepthwiseConv2D 3x3 -> Conv2D 1x1 (the head of
+            // MobileNetV2) -> the same kernel, its staging gathers the 27 image values per pixel; the stem's output never reaches memory
+            chain->owned.push_back(sirb);
+            st.kind = ChainPlan::PLAIN;
+            st.plain = sirb;
+            memcpy(st.outDims, sirb->outDims, sizeof(st.outDims));
+            st.desc = sirb->desc;
+            st.flops = sirb->flops;
+            st.bytes = sirb->bytes;
+            i += 3;
+            ++fusedCount;
         } else if (snnhip_plan* irb = nullptr; i + 2 < n && c0 && c1 && c2 && !c0->depthwise && c1->depthwise && !c2->depthwise &&
                                         make_irb_plan(ctx, plans[i], plans[i + 1], plans[i + 2], nullptr, &irb) == SNNHIP_OK) {
             // ---- rule G: Conv2D 1x1 -> DepthwiseConv2D 3x3 -> Conv2D 1x1 (an inverted-residual block without skip connection) -> one kernel

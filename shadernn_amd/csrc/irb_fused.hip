@@ -59,6 +59,13 @@ struct IrbParams {
     int hasRes;
     int noExpand;      // DepthwiseConv2D -> Conv2D 1x1 without an expand layer in front (MobileNetV2's first block): the 'hidden' slice is the x tile itself
     unsigned magicQuads, magicHWd; // ceil(2^32 / d) for d = 4 Cj and HWd: the staging's two divisions as mul-hi (operands < 2^16: exact)
+    // stem mode (stemK > 0): the 'expand' layer is a 3x3 convolution of a 3-channel image (MobileNetV2's Conv2D 3x3 s2 3->32 in front of its first,
+    // expansion-less block).  x is the image; the x tile holds, per halo pixel (= stem output pixel), the stemK = 27 image values under the 3x3
+    // window as 'channels' tap*3 + c (im2col while staging), and the expand MFMAs are the stem convolution.  (H, W) stay the dims of the tensor the
+    // depthwise layer reads = the stem's output.
+    int stemK, stemS, stemPadX, stemPadY, IH, IW;
+    int rawH, rawW3;     // the image patch under the halo tile: rows, floats per row (3 per pixel)
+    unsigned magicRawW3; // ceil(2^32 / rawW3)
     ActCfg ac1, ac2, ac3, ac4;
 };
 
@@ -85,7 +92,7 @@ __device__ __forceinline__ float irb_act(const ActCfg& a, float v) {
 // One lane = (pixel n16 of a 16-pixel group, channel quad k); weights pre-packed on the host in the MFMA operand order (K permuted so that one
 // float4 per operand feeds four v_mfma_f32_16x16x4_f32).
 template <int G /* 16-pixel output groups per wave: 4 = 8x8 tile, 2 = 4x8, 1 = 2x8 */, int NCBT /* compile-time bound on the output blocks */, int CJT /* ... on Cj */,
-          bool R6 /* expand and depthwise activations are ReLU6 */>
+          bool R6 /* expand and depthwise activations are ReLU6 */, bool STEM = false /* IrbParams::stemK: the expand layer is a 3x3 convolution of an RGB image */>
 __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const float* __restrict__ x, const float4* __restrict__ weg, const float4* __restrict__ wpg,
                                                        const float4* __restrict__ epi3, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -109,7 +116,75 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
     float* const msk = xs + p.offWe;
 
     // ---- x tile of this wave: HP pixels x 4*Cj quads (channels past C and pixels outside the image are zero) + the inside-the-image mask
-    {
+    if constexpr (STEM) {
+        // stem mode, two steps.  (a) The raw image patch under the halo tile -- rawH rows of rawW3 = 3 x pixels consecutive floats (interleaved RGB), zero
+        // outside the image = the stem's zero padding -- is copied into the (still unused) hidden-slice region: row segments are contiguous in memory,
+        // a wave instruction covers a whole segment.  (b) The x tile is built from it by LDS reads: 'channel' ch = 3 tap + c of halo pixel (hy, hx) is
+        // raw[(hy stemS + fy) rawW3 + 3 hx stemS + (ch - 9 fy)], fy = ch / 9: the nine values of one window row are adjacent in the patch.
+        // (Gathering the 27 values per pixel straight from global memory -- 32 predicated scalar loads per lane -- took 14.8k of the wave's 27k cycles.)
+        // The kernel is bound by instruction issue (irb_act's note), so both steps walk their index spaces incrementally -- a lane's elements are 64
+        // apart: (row, col) and (hy, hx) advance by an add and a wrap -- instead of dividing per element, and (b) uses that the tile has 8 quads:
+        // a lane's quad, hence its four tap offsets, never change.
+        const int ry0 = hy0 * p.stemS - p.stemPadY, rx0 = (hx0 * p.stemS - p.stemPadX) * 3, rowF = p.IW * 3;
+        const int rawTotal = p.rawH * p.rawW3;
+        const float* const ximg = x + static_cast<size_t>(img) * p.IH * rowF;
+        {
+            int row = static_cast<int>(__umulhi(static_cast<unsigned>(lane), p.magicRawW3)), col = lane - row * p.rawW3; // (rawW3 >= 33: host)
+            for (int base = lane; base < rawTotal; base += 16 * 64) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int iy = ry0 + row, fx = rx0 + col;
+                    const bool in = base + r * 64 < rawTotal && iy >= 0 && iy < p.IH && fx >= 0 && fx < rowF;
+                    const float t = ximg[in ? iy * rowF + fx : 0];
+                    v[r] = in ? t : 0.0f;
+                    col += 64;
+                    if (col >= p.rawW3) { col -= p.rawW3; ++row; }
+                    if (col >= p.rawW3) { col -= p.rawW3; ++row; }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (base + r * 64 < rawTotal) hs[base + r * 64] = v[r];
+            }
+        }
+#ifdef SNNHIP_IRB_TRACE
+        if (itrace) {
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            istamp[3] = __builtin_readcyclecounter();
+        }
+#endif
+        {
+            const int q = lane & 7, rowStep = p.rawW3 - 9;
+            int tapOff[4];
+#pragma unroll
+            for (int cm = 0; cm < 4; ++cm) {
+                const int ch = min(4 * q + cm, 26);
+                tapOff[cm] = ((ch * 57) >> 9) * rowStep + ch; // fy (rawW3 - 9) + ch, fy = ch / 9 for ch < 32
+            }
+            const bool k3 = 4 * q + 3 < p.stemK; // only 'channel' 27 (quad 6, component 3) and quads 7 are padding
+            const bool kq = 4 * q < p.stemK;
+            const int iters = p.MT * 2; // MT 16 pixels x 8 quads / 64 lanes
+            int hp = lane >> 3;
+            int hy = static_cast<int>(__umulhi(static_cast<unsigned>(hp), p.magicHWd)), hx = hp - hy * p.HWd; // (HWd >= 8: one wrap per step)
+            float* xq = xs + q * p.xPlane + hp * 4;
+#pragma unroll 4 // (iters is even: MT 16 pixels; four iterations' LDS reads in flight)
+            for (int it = 0; it < iters; ++it) {
+                const bool real = hp < p.HP; // the padding pixels of the last MFMA tile: zeros
+                const float* rp = hs + (real ? hy * p.stemS * p.rawW3 + hx * p.stemS * 3 : 0);
+                const float t0 = rp[tapOff[0]], t1 = rp[tapOff[1]], t2 = rp[tapOff[2]], t3 = rp[tapOff[3]];
+                const bool on = real && kq;
+                *reinterpret_cast<float4*>(xq) = make_float4(on ? t0 : 0.0f, on ? t1 : 0.0f, on ? t2 : 0.0f, (on && k3) ? t3 : 0.0f);
+                if (q == 0) {
+                    const int sy = hy0 + hy, sx = hx0 + hx;
+                    msk[hp] = (real && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) ? 1.0f : 0.0f;
+                }
+                hp += 8;
+                xq += 32;
+                hx += 8;
+                if (hx >= p.HWd) { hx -= p.HWd; ++hy; }
+            }
+        }
+    } else {
         const int quads = 4 * p.Cj, cq = p.C >> 2;
         const int total = p.MT * 16 * quads;
         for (int base = lane; base < total; base += 8 * 64) {
@@ -290,8 +365,8 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
     }
 #ifdef SNNHIP_IRB_TRACE
     if (itrace)
-        printf("irbtrace G%d NCB%d Cj%d chunks %d noexp %d wave %d: stage %llu slices %llu (%llu each) epi %llu\n", G, p.NCB, p.Cj, p.nChunks, p.noExpand, wave, istamp[1] - istamp[0],
-               istamp[2] - istamp[1], (istamp[2] - istamp[1]) / p.nChunks, __builtin_readcyclecounter() - istamp[2]);
+        printf("irbtrace G%d NCB%d Cj%d chunks %d noexp %d wave %d: stage %llu slices %llu (%llu each) epi %llu (stem patch %llu)\n", G, p.NCB, p.Cj, p.nChunks, p.noExpand, wave,
+               istamp[1] - istamp[0], istamp[2] - istamp[1], (istamp[2] - istamp[1]) / p.nChunks, __builtin_readcyclecounter() - istamp[2], STEM ? istamp[3] - istamp[0] : 0ull);
 #endif
 }
 
@@ -308,8 +383,10 @@ struct IrbPlan : snnhip_plan {
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "inverted-residual block: expects 1 input (the block input is also the residual), got %d", nIn);
         const snnhip_tensor* x = in[0];
-        SNNHIP_REQUIRE(x->n == p.N && x->h == p.H && x->w == p.W && x->c == p.C, "irb: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h, x->w, x->c,
-                       p.N, p.H, p.W, p.C);
+        if (p.stemK) SNNHIP_REQUIRE(x->n == p.N && x->h == p.IH && x->w == p.IW && x->c == 3, "irb (stem): input dims %dx%dx%dx%d != plan %dx%dx%dx3", x->n, x->h, x->w, x->c, p.N, p.IH, p.IW);
+        else
+            SNNHIP_REQUIRE(x->n == p.N && x->h == p.H && x->w == p.W && x->c == p.C, "irb: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h, x->w, x->c,
+                           p.N, p.H, p.W, p.C);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.Co, "irb: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n,
                        out->h, out->w, out->c, p.N, p.OH, p.OW, p.Co);
         hipLaunchKernelGGL(kernel, grid, dim3(static_cast<unsigned>(threads)), ldsBytes, ctx->stream, p, x->data, reinterpret_cast<const float4*>(d_we),
@@ -342,15 +419,29 @@ IrbFn pick_irb_wave(int ncb, int cj) {
 
 // expand / dw / project: the three per-layer plans (borrowed; only read here; expand may be null: DepthwiseConv2D -> Conv2D 1x1, the expansion-factor-1
 // block at the head of MobileNetV2); add: the residual Add plan or nullptr.
-int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan, snnhip_plan* projectPlan, snnhip_plan* addPlan, snnhip_plan** out) {
+// stem (with expand == null, add == null): the 3x3 convolution of a 3-channel image in front of the depthwise layer (MobileNetV2: Conv2D 3x3 s2 3->32 ->
+// DepthwiseConv2D -> Conv2D 1x1) takes the expand layer's place: K = 27 image values per output pixel, gathered by the staging (IrbParams::stemK).
+int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan, snnhip_plan* projectPlan, snnhip_plan* addPlan, snnhip_plan** out,
+                  snnhip_plan* stemPlan) {
     if (snnhip::option("SNNHIP_NO_IRB_FUSION")) return SNNHIP_E_UNSUPPORTED;
+    auto* cs = stemPlan ? dynamic_cast<ConvPlanBase*>(stemPlan) : nullptr;
+    if (stemPlan) {
+        // Opt-in (SNNHIP_STEM_IRB_FUSION=1): MobileNetV2's head at batch 256 takes 403 us fused, 157 + 237 us as stem + two-layer kernel -- the 0.82 GB
+        // of traffic it removes buy no time, the kernel is bound by instruction issue and the halo tile makes the stem do 1.9x its work
+        const char* on = snnhip::option("SNNHIP_STEM_IRB_FUSION");
+        if (!cs || expandPlan || addPlan || !on || atoi(on) == 0) return SNNHIP_E_UNSUPPORTED;
+        const ConvGeom& gs = cs->g;
+        if (cs->depthwise || gs.kh != 3 || gs.kw != 3 || gs.IC != 3 || gs.sh != gs.sw || gs.sh < 1 || gs.sh > 2 || gs.preMode != 0 || gs.addAct >= 0 ||
+            gs.dtype != SNNHIP_F32 || (gs.padMode != SNNHIP_PAD_CONSTANT && gs.padMode != SNNHIP_PAD_NONE) || gs.OC % 16 != 0)
+            return SNNHIP_E_UNSUPPORTED;
+    }
     const char* irbMode = snnhip::option("SNNHIP_IRB_FUSION"); // "all": also the 14x14 / 7x7 blocks, where the separate layers are faster (tools/bench_irb.py)
     auto* ce = dynamic_cast<ConvPlanBase*>(expandPlan);
     auto* cd = dynamic_cast<ConvPlanBase*>(dwPlan);
     auto* cp = dynamic_cast<ConvPlanBase*>(projectPlan);
     auto* ad = addPlan ? dynamic_cast<EltwisePlanBase*>(addPlan) : nullptr;
-    const bool noExpand = expandPlan == nullptr; // DepthwiseConv2D -> Conv2D 1x1 (MobileNetV2's first block, expansion factor 1)
-    if ((!noExpand && !ce) || !cd || !cp || (ce && ce->depthwise) || !cd->depthwise || cp->depthwise || (addPlan && (!ad || ad->mode != 0))) return SNNHIP_E_UNSUPPORTED;
+    const bool noExpand = expandPlan == nullptr && !cs; // DepthwiseConv2D -> Conv2D 1x1 (MobileNetV2's first block, expansion factor 1)
+    if ((!noExpand && !ce && !cs) || !cd || !cp || (ce && ce->depthwise) || !cd->depthwise || cp->depthwise || (addPlan && (!ad || ad->mode != 0))) return SNNHIP_E_UNSUPPORTED;
     ConvGeom geId = cd->g; // stand-in geometry of the missing expand layer: identity on the depthwise layer's input
     geId.kh = geId.kw = geId.sh = geId.sw = 1;
     geId.OC = geId.IC;
@@ -360,7 +451,15 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     geId.useBN = 0;
     geId.preMode = 0;
     geId.addAct = -1;
-    const ConvGeom &ge = noExpand ? geId : ce->g, &gd = cd->g, &gp = cp->g;
+    if (cs) { // the stem as a pointwise layer over its im2col'd input: 27 (+1 zero) 'channels' -> OC, on the depthwise layer's grid
+        geId.IC = 28;
+        geId.OC = cs->g.OC;
+        geId.act = cs->g.act;
+        geId.leaky = cs->g.leaky;
+        geId.useBN = cs->g.useBN;
+        if (cs->g.N != cd->g.N || cs->g.OH != cd->g.H || cs->g.OW != cd->g.W) return SNNHIP_E_UNSUPPORTED;
+    }
+    const ConvGeom &ge = (noExpand || cs) ? geId : ce->g, &gd = cd->g, &gp = cp->g;
     if (noExpand && gd.IC % 16 != 0) return SNNHIP_E_UNSUPPORTED; // whole 16-channel slices of the x tile
     auto pointwise = [](const ConvGeom& g) { return g.kh == 1 && g.kw == 1 && g.sh == 1 && g.sw == 1 && g.preMode == 0 && g.addAct < 0 && g.dtype == SNNHIP_F32; };
     if (!pointwise(ge) || !pointwise(gp) || gd.dtype != SNNHIP_F32 || gd.kh != 3 || gd.kw != 3 || gd.sh != gd.sw || gd.sh < 1 || gd.sh > 2 || gd.preMode != 0)
@@ -430,6 +529,19 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     p.offWp = 0;
     p.hasRes = ad ? 1 : 0;
     p.noExpand = noExpand ? 1 : 0;
+    if (cs) {
+        p.stemK = 27;
+        p.stemS = cs->g.sh;
+        p.stemPadX = cs->g.padx;
+        p.stemPadY = cs->g.pady;
+        p.IH = cs->g.H;
+        p.IW = cs->g.W;
+        if (static_cast<double>(cs->g.N) * cs->g.H * cs->g.W * 3 >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
+        p.rawH = (p.HH - 1) * p.stemS + 3;
+        p.rawW3 = ((p.HWd - 1) * p.stemS + 3) * 3;
+        p.magicRawW3 = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(p.rawW3) - 1) / static_cast<unsigned>(p.rawW3));
+        if (p.rawH * p.rawW3 > 4 * p.hPlane || p.rawW3 < 33 || p.HWd < 8) return SNNHIP_E_UNSUPPORTED; // the patch is parked in the hidden-slice region until the x tile is built
+    }
     p.ac1 = make_act_cfg(ge.act, ge.leaky);
     p.ac2 = make_act_cfg(gd.act, gd.leaky);
     p.ac3 = make_act_cfg(gp.act, gp.leaky);
@@ -437,9 +549,14 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     const size_t lds = static_cast<size_t>(NWv) * perWave * sizeof(float);
     const bool r6 = ge.act == SNNHIP_ACT_RELU6 && gd.act == SNNHIP_ACT_RELU6;
     IrbFn fn = nullptr;
-    if (G == 4) fn = r6 ? pick_irb_wave<4, true>(p.NCB, p.Cj) : pick_irb_wave<4, false>(p.NCB, p.Cj);
-    if (G == 2) fn = r6 ? pick_irb_wave<2, true>(p.NCB, p.Cj) : pick_irb_wave<2, false>(p.NCB, p.Cj);
-    if (G == 1) fn = r6 ? pick_irb_wave<1, true>(p.NCB, p.Cj) : pick_irb_wave<1, false>(p.NCB, p.Cj);
+    if (cs) { // stem mode: its own instantiations (Cj = 2: the 27 image values; up to 32 output channels)
+        if (p.NCB > 2) return SNNHIP_E_UNSUPPORTED;
+        if (G == 4) fn = r6 ? irb_wave_kernel<4, 2, 2, true, true> : irb_wave_kernel<4, 2, 2, false, true>;
+        if (G == 2) fn = r6 ? irb_wave_kernel<2, 2, 2, true, true> : irb_wave_kernel<2, 2, 2, false, true>;
+        if (G == 1) fn = r6 ? irb_wave_kernel<1, 2, 2, true, true> : irb_wave_kernel<1, 2, 2, false, true>;
+    } else if (G == 4) fn = r6 ? pick_irb_wave<4, true>(p.NCB, p.Cj) : pick_irb_wave<4, false>(p.NCB, p.Cj);
+    else if (G == 2) fn = r6 ? pick_irb_wave<2, true>(p.NCB, p.Cj) : pick_irb_wave<2, false>(p.NCB, p.Cj);
+    else if (G == 1) fn = r6 ? pick_irb_wave<1, true>(p.NCB, p.Cj) : pick_irb_wave<1, false>(p.NCB, p.Cj);
     if (!fn) return SNNHIP_E_UNSUPPORTED;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("irb_fused: hipFuncSetAttribute(%zu) failed", lds);
@@ -447,7 +564,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     }
 
     // ---- slice blobs (the kernel's LDS images)
-    const std::vector<float> e1 = noExpand ? std::vector<float>(static_cast<size_t>(Ch) * 2, 0.0f) : fold_epilogue(ce->epi4, Ch, ge.useBN);
+    const std::vector<float> e1 = noExpand ? std::vector<float>(static_cast<size_t>(Ch) * 2, 0.0f) : fold_epilogue(cs ? cs->epi4 : ce->epi4, Ch, ge.useBN);
     const std::vector<float> e2 = fold_epilogue(cd->epi4, Ch, gd.useBN), e3 = fold_epilogue(cp->epi4, Co, gp.useBN);
     std::vector<float> we(static_cast<size_t>(p.nChunks) * p.wePieces * 256, 0.0f), wp(static_cast<size_t>(p.nChunks) * p.wpPieces * 256, 0.0f);
     for (int c = 0; c < p.nChunks; ++c) {
@@ -459,6 +576,10 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
             // expand: [j][lane = 16 kk + m] float4 {We[hc][16 j + 4 kk + jj]}
             for (int ic = 0; ic < C && !noExpand; ++ic) {
                 const int j = ic / 16, kk = (ic % 16) / 4, jj = ic % 4;
+                if (cs) { // 'channel' ic = 3 tap + c of the im2col'd image (the staging's order); the stem's weights are [oc][c][tap]
+                    if (ic < 27) wb[j * 256 + (kk * 16 + m) * 4 + jj] = cs->w_oihw[(static_cast<size_t>(hc) * 3 + ic % 3) * 9 + ic / 3];
+                    continue;
+                }
                 wb[j * 256 + (kk * 16 + m) * 4 + jj] = ce->w_oihw[static_cast<size_t>(hc) * C + ic];
             }
             wb[p.Cj * 256 + m] = e1[2 * hc];
@@ -498,14 +619,16 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         delete plan;
         return rc;
     }
-    memcpy(plan->inDims, noExpand ? dwPlan->inDims : expandPlan->inDims, sizeof(plan->inDims));
+    memcpy(plan->inDims, cs ? stemPlan->inDims : noExpand ? dwPlan->inDims : expandPlan->inDims, sizeof(plan->inDims));
     memcpy(plan->outDims, projectPlan->outDims, sizeof(plan->outDims));
-    plan->flops = (ce ? ce->flops : 0.0) + cd->flops + cp->flops;
-    plan->bytes = (ce ? ce->bytes : 0.0) + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
-    const double fusedBytes = 4.0 * (static_cast<double>(p.N) * p.H * p.W * C + static_cast<double>(p.N) * p.OH * p.OW * Co + static_cast<double>(Ch) * (C + Co + 9));
+    plan->flops = (ce ? ce->flops : 0.0) + (cs ? cs->flops : 0.0) + cd->flops + cp->flops;
+    plan->bytes = (ce ? ce->bytes : 0.0) + (cs ? cs->bytes : 0.0) + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
+    const double inElems = cs ? static_cast<double>(p.N) * p.IH * p.IW * 3 : static_cast<double>(p.N) * p.H * p.W * C;
+    const double fusedBytes = 4.0 * (inElems + static_cast<double>(p.N) * p.OH * p.OW * Co + static_cast<double>(Ch) * (C + Co + 9));
     char buf[320];
     char head[64];
-    if (noExpand) snprintf(head, sizeof(head), "depthwise3x3 %d s%d", Ch, s);
+    if (cs) snprintf(head, sizeof(head), "stem conv3x3 s%d 3->%d + depthwise3x3 s%d", p.stemS, Ch, s);
+    else if (noExpand) snprintf(head, sizeof(head), "depthwise3x3 %d s%d", Ch, s);
     else snprintf(head, sizeof(head), "conv1x1 %d->%d + depthwise3x3 s%d", C, Ch, s);
     // the instantiation pick_irb_wave chose, for the profile look-up (bench.py matches the PMC record of exactly this kernel)
     int vNcb = 0, vCj = 0;
@@ -518,8 +641,9 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
                 break;
             }
     }
-    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [%s + conv1x1 %d->%d%s] tile=%dx8px per wave, halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_wave_kernel<%d,%d,%d,%s>",
-             head, Ch, Co, addPlan ? " + add" : "", 2 * G, p.HH, p.HWd, p.nChunks, plan->threads, lds, fusedBytes, G, vNcb, vCj, r6 ? "true" : "false");
+    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [%s + conv1x1 %d->%d%s] tile=%dx8px per wave, halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_wave_kernel<%d,%d,%d,%s,%s>",
+             head, Ch, Co, addPlan ? " + add" : "", 2 * G, p.HH, p.HWd, p.nChunks, plan->threads, lds, fusedBytes, G, cs ? 2 : vNcb, cs ? 2 : vCj, r6 ? "true" : "false",
+             cs ? "true" : "false");
     plan->desc = buf;
     if (r6) plan->desc += " relu6-epilogues";
     *out = plan;

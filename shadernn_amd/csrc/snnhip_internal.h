@@ -184,7 +184,8 @@ int make_subpixel_plan(snnhip_ctx* ctx, const snnhip_subpixel_desc& d, snnhip_pl
 int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_plan** out);
 bool chain_adopt_plan(snnhip_plan* chain, snnhip_plan* p); // the chain deletes p with itself; false if `chain` is not a ChainPlan
 // irb_fused.hip (chain rule G): Conv2D 1x1 -> DepthwiseConv2D 3x3 -> Conv2D 1x1 [-> Add with the block input] as one kernel; the plans are only read
-int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan, snnhip_plan* projectPlan, snnhip_plan* addPlan, snnhip_plan** out);
+int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan, snnhip_plan* projectPlan, snnhip_plan* addPlan, snnhip_plan** out,
+                  snnhip_plan* stemPlan = nullptr);
 
 // espcn_stream.hip: the whole ESPCN pattern in one launch (rule C of the chain planner); cfg is an opaque blob
 constexpr size_t kStreamCfgBytes = 160;

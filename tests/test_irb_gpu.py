@@ -178,3 +178,50 @@ def test_depthwise_pointwise_pair_runs_as_one_kernel(ctx, case):
     want = O.conv2d(d, wp, bp, 1, (0, 0, 0, 0), "constant", a2, 0.0, bnp, threads=8)
     np.testing.assert_allclose(got, want, err_msg=plan.describe(), **TOL)
     np.testing.assert_allclose(got, pp(pd(xt)).numpy(), err_msg=plan.describe(), rtol=2e-5, atol=2e-5)
+
+
+# N, IH, IW, stem stride, stem pads ("same" | "none"), C (stem channels), Co, depthwise stride, (stem act, dw act, pw act), wave tile G
+STEM_CASES = [(2, 224, 224, 2, "same", 32, 16, 1, ("relu6", "relu6", ""), None),     # MobileNetV2's head
+              (1, 75, 61, 2, "same", 32, 16, 1, ("relu6", "relu6", ""), "4"),        # ragged, odd image, 8x8 wave tiles
+              (2, 63, 70, 1, "same", 16, 24, 2, ("relu", "leakyRelu", "relu"), None),  # stride-1 stem, stride-2 depthwise
+              (1, 64, 64, 2, "none", 48, 8, 1, ("", "relu6", ""), "1")]              # no padding at all in the stem, 3 slices
+
+
+@pytest.mark.parametrize("case", STEM_CASES, ids=["mbv2_head", "ragged_G4", "s1_stem_s2_dw", "nopad_48"])
+def test_stem_depthwise_pointwise_runs_as_one_kernel(ctx, case, monkeypatch):
+    """Rule G with the network's stem as the 'expand' layer: Conv2D 3x3 (3 -> C) -> DepthwiseConv2D 3x3 -> Conv2D 1x1 as one launch (the staging gathers the
+    27 image values per pixel, the stem's output never reaches memory).  Against the oracle layer by layer and the three separate layers; the switch
+    rule is opt-in (SNNHIP_STEM_IRB_FUSION=1: no faster than the stem + two-layer kernel at the benchmark size)."""
+    import shadernn_amd as snn
+
+    N, IH, IW, ss, spad, C, Co, s, acts, G = case
+    monkeypatch.setenv("SNNHIP_STEM_IRB_FUSION", "1")
+    if G:
+        monkeypatch.setenv("SNNHIP_IRB_WAVE_G", G)
+    x = _rand((N, IH, IW, 3), 21)
+    ws, bs, bns = _rand((C, 3, 3, 3), 22, 1.0 / np.sqrt(27)), _rand((C,), 23, 0.1), _bn(C, 24)
+    wd, bd, bnd = _rand((C, 3, 3), 25, 1.0 / 3.0), _rand((C,), 26, 0.1), _bn(C, 27)
+    wp, bp, bnp = _rand((Co, C, 1, 1), 28, 1.0 / np.sqrt(C)), _rand((Co,), 29, 0.1), _bn(Co, 30)
+    spads = O.padding_offsets("same", 3) if spad == "same" else (0, 0, 0, 0)
+    smode = "constant" if spad == "same" else "none"
+    ps = snn.conv2d_plan(ctx, N, IH, IW, ws, bs, stride=ss, pads=spads, pad_mode=smode, act=acts[0], leaky=0.1, bn=bns)
+    _, H, W, _ = ps.out_shape()
+    pd = snn.conv2d_plan(ctx, N, H, W, wd, bd, stride=s, pads=O.padding_offsets("same", 3), act=acts[1], leaky=0.1, bn=bnd, depthwise=True)
+    _, OH, OW, _ = pd.out_shape()
+    pp = snn.conv2d_plan(ctx, N, OH, OW, wp, bp, act=acts[2], leaky=0.1, bn=bnp)
+    plan = snn.chain_plan(ctx, [ps, pd, pp])
+    assert plan.num_steps() == 1 and "irb_fused" in plan.describe() and "[stem conv3x3 s%d 3->%d + depthwise3x3 s%d + conv1x1" % (ss, C, s) in plan.describe(), plan.describe()
+    xt = snn.Tensor.from_numpy(ctx, x)
+    got = plan(xt).numpy()
+    h = O.conv2d(x, ws, bs, ss, spads, smode, acts[0], 0.1, bns, threads=8)
+    d = O.depthwise(h, wd, bd, s, O.padding_offsets("same", 3), acts[1], 0.1, bnd)
+    want = O.conv2d(d, wp, bp, 1, (0, 0, 0, 0), "constant", acts[2], 0.1, bnp, threads=8)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, err_msg=plan.describe(), **TOL)
+    np.testing.assert_allclose(got, pp(pd(ps(xt))).numpy(), err_msg=plan.describe(), rtol=2e-5, atol=2e-5)
+    f, b = plan.cost()
+    assert f > 0 and b > 0
+    monkeypatch.delenv("SNNHIP_STEM_IRB_FUSION")
+    two = snn.chain_plan(ctx, [ps, pd, pp])
+    assert two.num_steps() == 2 and "stem conv3x3" not in two.describe(), two.describe()
+    np.testing.assert_allclose(two(xt).numpy(), got, rtol=2e-5, atol=2e-5)

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
         }
 #endif
         {
-            const int q = lane & 7, rowStep = p.rawW3 - 9;
+            const int q = lane >> 3, rowStep = p.rawW3 - 9; // (eight consecutive lanes = eight consecutive pixels of one quad: conflict-free ds_write_b128, see below)
             int tapOff[4];
 #pragma unroll
             for (int cm = 0; cm < 4; ++cm) {
@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
             const bool k3 = 4 * q + 3 < p.stemK; // only 'channel' 27 (quad 6, component 3) and quads 7 are padding
             const bool kq = 4 * q < p.stemK;
             const int iters = p.MT * 2; // MT 16 pixels x 8 quads / 64 lanes
-            int hp = lane >> 3;
-            int hy = static_cast<int>(__umulhi(static_cast<unsigned>(hp), p.magicHWd)), hx = hp - hy * p.HWd; // (HWd >= 8: one wrap per step)
+            int hp = lane & 7;
+            int hy = 0, hx = hp; // (HWd >= 8: the first eight pixels are in row 0, one wrap per step)
             float* xq = xs + q * p.xPlane + hp * 4;
 #pragma unroll 4 // (iters is even: MT 16 pixels; four iterations' LDS reads in flight)
             for (int it = 0; it < iters; ++it) {
@@ -197,7 +197,12 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                 lo[r] = -1;
                 if (e < total) {
                     // (divisions by run-time values are ~25 instructions each: two per element made this staging a quarter of the wave's VALU work)
-                    const int hp = static_cast<int>(__umulhi(static_cast<unsigned>(e), p.magicQuads)), q = e - hp * quads;
+                    // element -> (pixel, quad): EIGHT CONSECUTIVE LANES = eight consecutive pixels of one quad, the next eight lanes the next quad of the same
+                    // pixels.  A ds_write_b128 is serviced eight lanes at a time and the planes are 0 mod 256 bytes apart: with the quad running fastest
+                    // (lanes 0-7 = the 8 quads of ONE pixel) every store was an 8-way bank conflict -- 72 % of the LDS cycles of MobileNetV2's head block
+                    // (PMC), half of its LDS time.  The global side is unchanged: a wave instruction still covers whole pixels.
+                    const int blk = static_cast<int>(__umulhi(static_cast<unsigned>(e >> 3), p.magicQuads)), q = (e >> 3) - blk * quads;
+                    const int hp = blk * 8 + (e & 7);
                     const int hy = static_cast<int>(__umulhi(static_cast<unsigned>(hp), p.magicHWd)), hx = hp - hy * p.HWd;
                     const int iy = hy0 + hy, ix = hx0 + hx;
                     const bool in = hp < p.HP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;

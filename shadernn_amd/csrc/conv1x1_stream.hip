@@ -40,11 +40,17 @@ struct StreamParams {
 
 // kDepth = activation chunks (8 channels = 16 bytes per lane each) in flight per lane: 4 next to 48 accumulators, 8 for the one-column
 // project layers (deep K, everything they move is the activation read)
-template <int NT, bool SIMPLE>
-__global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, ActCfg ac, const float* __restrict__ x, const float4* __restrict__ wp,
+// kStreamWaves = 32-pixel tiles (waves) per block = pixels per staged weight slice / 32.  4 for the layers that narrow (project: OC < 3 IC), 8 for the
+// ones that widen (MobileNetV2's expand layers and head): their slices are the big ones (96 output channels x IC per block, re-staged for every
+// 128 pixels: 86 MB of L2 -> LDS traffic next to 115 MB of output on 96 -> 576 at 14x14), and a block of eight waves stages a slice for 256
+// pixels with half the work per thread.  Per layer at batch 256, 4 / 8 waves, us: 160 -> 960 60 / 50, 320 -> 1280 120 / 113, 96 -> 576 88 / 86,
+// 64 -> 384 51 / 49; the project layers lose (384 -> 96 55 / 62, 576 -> 160 36 / 38) and keep four.
+template <int NT, bool SIMPLE, int kStreamWaves>
+__global__ __launch_bounds__(64 * kStreamWaves) void conv1x1_stream_kernel(StreamParams p, ActCfg ac, const float* __restrict__ x, const float4* __restrict__ wp,
                                                           const float4* __restrict__ epi, float* __restrict__ y) {
     extern __shared__ float4 s_w[]; // [nChunks][2][BN]
     constexpr int BN = 32 * NT;
+    constexpr int kStreamThreads = 64 * kStreamWaves;
     constexpr int kDepth = NT == 1 ? 8 : 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
     // side by side, sharing the LDS weight reads, also lost: 144->24 @56x56 b32 22.0 -> 23.6 us, 192->32 @28x28 9.2 -> 16.6 us.  So did
     // requesting the first activation chunks BEFORE the weight staging above: vmcnt retires in order, so the L2-resident weights then wait for
     // the HBM loads in front of them and the barrier moves out (16->96 @112x112 36.4 -> 42.2 us).)
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x * kStreamWaves + wave;
     const bool active = tile < p.nTiles; // (wave-uniform; an idle wave of the last block still takes part in the barriers of the weight phases)
     // chunk c of the tile's row l32 for this lane's K half; rows past M and chunks past IC read as zero (their products vanish / are not stored)
     const int arow = tile * 32 + l32;
@@ -95,13 +101,13 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamParams p, Act
             // 21 000 cycles of a 90 000-cycle block: an L2 round trip per 16 bytes)
             const int cnt = (pe - pb) * 2 * BN;
             const float4* src = wp + (static_cast<size_t>(blockIdx.y) * p.nChunks + pb) * 2 * BN;
-            for (int i0 = tid; i0 < cnt; i0 += 256 * 8) {
+            for (int i0 = tid; i0 < cnt; i0 += kStreamThreads * 8) {
                 float4 t[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = src[min(i0 + 256 * j, cnt - 1)]; // (unconditional: a partly written register array goes to scratch)
+                for (int j = 0; j < 8; ++j) t[j] = src[min(i0 + kStreamThreads * j, cnt - 1)]; // (unconditional: a partly written register array goes to scratch)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (i0 + 256 * j < cnt) s_w[i0 + 256 * j] = t[j];
+                    if (i0 + kStreamThreads * j < cnt) s_w[i0 + kStreamThreads * j] = t[j];
             }
         }
         __syncthreads();
@@ -348,6 +354,7 @@ struct Conv1x1StreamPlan : ConvPlanBase {
     dim3 grid;
     void (*kernel)(StreamParams, ActCfg, const float*, const float4*, const float4*, float*) = nullptr;
     bool fusedAdd = false;
+    int waves = 4; // 32-pixel tiles per block
 
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == (fusedAdd ? 2 : 1), "conv2d: expects %d input(s), got %d", fusedAdd ? 2 : 1, nIn);
@@ -365,7 +372,7 @@ struct Conv1x1StreamPlan : ConvPlanBase {
                            g.OC);
             q.res = r->data;
         }
-        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, q, ac, static_cast<const float*>(x->data), reinterpret_cast<const float4*>(d_w),
+        hipLaunchKernelGGL(kernel, grid, dim3(64 * waves), ldsBytes, ctx->stream, q, ac, static_cast<const float*>(x->data), reinterpret_cast<const float4*>(d_w),
                            reinterpret_cast<const float4*>(d_epi), out->data);
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
@@ -373,8 +380,9 @@ struct Conv1x1StreamPlan : ConvPlanBase {
 };
 
 template <int NT>
-decltype(Conv1x1StreamPlan::kernel) pick(bool simple) {
-    return simple ? conv1x1_stream_kernel<NT, true> : conv1x1_stream_kernel<NT, false>;
+decltype(Conv1x1StreamPlan::kernel) pick(bool simple, int waves) {
+    if (waves == 8) return simple ? conv1x1_stream_kernel<NT, true, 8> : conv1x1_stream_kernel<NT, false, 8>;
+    return simple ? conv1x1_stream_kernel<NT, true, 4> : conv1x1_stream_kernel<NT, false, 4>;
 }
 template <int NT>
 decltype(Conv1x1StreamPlan::kernel) pick16(bool simple) {
@@ -450,8 +458,13 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     plan->ldsBytes = static_cast<size_t>(std::min(nChunks, phaseChunks)) * 2 * BN * 16 + (f16 ? static_cast<size_t>(4) * 32 * (BN + 8) * 2 : 0);
     const bool simple = act_is_simple(g.act);
     if (f16) plan->kernel = NT == 3 ? pick16<3>(simple) : NT == 2 ? pick16<2>(simple) : pick16<1>(simple);
-    else plan->kernel = NT == 3 ? pick<3>(simple) : NT == 2 ? pick<2>(simple) : pick<1>(simple);
-    const int gx = (nTiles + 3) / 4; // 4 waves = 4 tiles per block
+    // eight tiles per block for the fp32 layers that widen at least threefold (see the kernel), SNNHIP_CONV_1X1_WAVES=4|8 pins it
+    int waves = (!f16 && g.OC >= 3 * g.IC) ? 8 : 4;
+    if (const char* wv = snnhip::option("SNNHIP_CONV_1X1_WAVES"))
+        if (!f16 && (atoi(wv) == 4 || atoi(wv) == 8)) waves = atoi(wv);
+    plan->waves = waves;
+    if (!f16) plan->kernel = NT == 3 ? pick<3>(simple, waves) : NT == 2 ? pick<2>(simple, waves) : pick<1>(simple, waves);
+    const int gx = (nTiles + waves - 1) / waves; // one 32-pixel tile per wave
     plan->grid = dim3(gx, ocBlocks);
     if (plan->ldsBytes > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(plan->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan->ldsBytes)) != hipSuccess) {
@@ -493,8 +506,8 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     const double esz = f16 ? 2.0 : 4.0;
     plan->bytes = esz * (static_cast<double>(g.N) * g.H * g.W * g.IC + M * g.OC + static_cast<double>(g.OC) * g.IC); // same accounting as the general kernel
     char buf[256];
-    snprintf(buf, sizeof(buf), "conv2d_mfma_%s k=1x1 s=%d ic=%d oc=%d stream: wave = 32px x %doc, grid %dx%d, lds=%zuB", f16 ? "f16_32x32x16" : "f32_32x32x2", g.sh, g.IC, g.OC, BN, gx, ocBlocks,
-             plan->ldsBytes);
+    snprintf(buf, sizeof(buf), "conv2d_mfma_%s k=1x1 s=%d ic=%d oc=%d stream: wave = 32px x %doc, %d waves per block, grid %dx%d, lds=%zuB", f16 ? "f16_32x32x16" : "f32_32x32x2", g.sh, g.IC, g.OC,
+             BN, waves, gx, ocBlocks, plan->ldsBytes);
     plan->desc = buf;
     if (KP > 1) plan->desc += " (weight slice in " + std::to_string((nChunks + phaseChunks - 1) / phaseChunks) + " K phases)";
     if (plan->fusedAdd) {

@@ -434,6 +434,8 @@ def pmc_entry(pmc, desc, tags):
         want = ("conv2d_wide_kernel", [wm, 4 // wm, nt, c8])
     elif "conv2d_mfma_stem_f16" in core:
         want = ("conv2d_stem_kernel", [])
+    elif "conv2d_mfma_stem_f32" in core and "dense (tap, channel) K" in core:
+        want = ("conv2d_stem32_dense_kernel", [])
     elif "conv2d_mfma_stem_f32" in core and m:
         want = ("conv2d_stem32_kernel", [int(m.group(1)), int(m.group(2))])
     elif "conv2d_mfma_upconv" in core and m:

@@ -33,8 +33,40 @@ constexpr int kTW = 32;                 // block tile: 4 waves stacked in y, NR 
 // 8-byte pairs per plane row: the 32 pairs of an operand read + the taps' reach, as tight as the kernel allows (the 3x3 stride-2 tile must leave room for
 // three blocks per CU: 40 pairs per row cost MobileNetV2's stem 161 -> 175 us)
 __host__ __device__ constexpr int plane_w(int K, int S) { return S == 2 ? (K == 7 ? 36 : 33) : 32 + K - 1; }
+constexpr int kDensePW = 36;            // dense 7x7 stride-2 kernel: floats per column-parity row of a channel plane (35 even columns of the 69-column halo tile)
+constexpr int kDenseSteps = 74;         // ... K steps (= weight registers) per output row: ceil(7 * 7 * 3 / 2)
 constexpr int kOutPitch = 36;           // floats per pixel row of a wave's output scratch (32 + 4: 16-byte aligned, the runs of 8 lanes on distinct banks)
 
+
+// epilogue of a wave's kNR output rows x 32 columns: acc[yy][4g + k] = channel 8g + 4h + k of pixel (row yy, column l32); e = the lane's 16 rows of the
+// epilogue table; sc = the wave's LDS scratch
+template <int kNR, bool SIMPLE>
+__device__ __forceinline__ void stem32_epilogue(const Stem32Params& p, const ActCfg& ac, const f32x16 (&acc)[kNR], const float4 (&e)[16], float* const sc, float* __restrict__ y, int n,
+                                                int oyW, int ox0, int lane) {
+    const int l32 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int yy = 0; yy < kNR; ++yy) {
+        const int oy = oyW + yy;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = epi_affine(acc[yy][4 * g + k], e[4 * g + k], p.useBN);
+                o[k] = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+            }
+            *reinterpret_cast<float4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        // (wave-private scratch: a wave's LDS operations complete in order).  Out: 16-byte pieces, lane L = piece L % 8 of pixel L / 8 (+ 8 i)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int opix = 8 * i + (lane >> 3), piece = lane & 7;
+            const float4 v = *reinterpret_cast<const float4*>(sc + opix * kOutPitch + 4 * piece);
+            const int ox = ox0 + opix;
+            if (oy < p.OH && ox < p.OW) *reinterpret_cast<float4*>(y + (static_cast<size_t>(n * p.OH + oy) * p.OW + ox) * p.OC + blockIdx.y * 32 + 4 * piece) = v;
+        }
+    }
+}
 
 template <int K, int S, int kNR, bool SIMPLE>
 __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem32Params p, ActCfg ac, const float* __restrict__ x, const float* __restrict__ wp,
@@ -121,30 +153,107 @@ __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem
             }
         }
 
-    // ---- epilogue: acc[yy][4g + k] = channel 8g + 4h + k of pixel (row yy, column l32)
-    float* const sc = oscr + wave * (32 * kOutPitch);
+    stem32_epilogue<kNR, SIMPLE>(p, ac, acc, e, oscr + wave * (32 * kOutPitch), y, n, oy0 + wave * kNR, ox0, lane);
+}
+
+// The 7x7 stride-2 RGB stem (ResNet-18) with the reduction packed DENSELY: K = 7 x 7 taps x 3 channels = 147 -> 74 K steps of 2 per output row instead of the 98
+// of the kernel above (which spends a K slot on the absent fourth channel of every tap); the stem is bound by the matrix pipe, so the MFMA count is its time.
+//   * K order: e = (fy 7 + fx) 3 + ch; the lane halves of an MFMA take e = 2k and 2k + 1.  Seen from the input, the elements of the wave's ROWS input rows
+//     are g = r 21 + fx 3 + ch and an output row yy reads them at e = g - 42 yy: an EVEN shift, so the pairing (2s, 2s + 1) of the input elements is the
+//     same for every output row -- the operand of step s is read ONCE and feeds the MFMAs of up to four output rows, with weight register s - 21 yy.
+//   * tile in LDS as channel planes [ch][row][column parity][column / 2] of floats: the 32 lanes of a half read 32 consecutive floats; the two halves read
+//     different (tap, channel) elements, i.e. different compile-time offsets: one v_cndmask + one ds_read_b32 per step.
+//   * 74 weight registers per lane (flat order, zero behind e = 146); epilogue = the kernel above.
+template <int kNR, bool SIMPLE>
+__global__ __launch_bounds__(256, 3) void conv2d_stem32_dense_kernel(Stem32Params p, ActCfg ac, const float* __restrict__ x, const float* __restrict__ wp,
+                                                                  const float4* __restrict__ epi, float* __restrict__ y) {
+    constexpr int K = 7, S = 2;
+    constexpr int kTH = 4 * kNR;
+    constexpr int IN_H = (kTH - 1) * S + K, IN_W = (kTW - 1) * S + K; // staged halo tile
+    constexpr int ROWS = (kNR - 1) * S + K;                           // input rows a wave touches
+    constexpr int PW = kDensePW, ROWFL = 2 * PW, CHFL = IN_H * ROWFL; // floats per parity row / per (channel, row) / per channel plane
+    constexpr int NE = ROWS * 21, NS = (NE + 1) / 2;                  // input elements (row, fx, ch) of a wave, K steps
+    constexpr int NWD = kDenseSteps;                                  // weight registers: pairs of the flat 147 (+1 zero)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const tile = smem;                 // [3][IN_H][2][PW]
+    float* const oscr = smem + 3 * CHFL;      // [4 waves][32][kOutPitch]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, h = lane >> 5;
+    const int mt = blockIdx.x;
+    const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, n = mt / (p.tilesX * p.tilesY);
+    const int ox0 = tx * kTW, oy0 = ty * kTH;
+
+    float wa[NWD];
+    {
+        const float* wsrc = wp + static_cast<size_t>(blockIdx.y) * NWD * 64 + lane;
 #pragma unroll
-    for (int yy = 0; yy < kNR; ++yy) {
-        const int oy = oy0 + wave * kNR + yy;
+        for (int s = 0; s < NWD; ++s) wa[s] = wsrc[s * 64];
+    }
+    // the block's 32 rows of the epilogue table go through LDS (requested here, read back after the MFMA loop): held in registers across the loop -- 64 of
+    // them per lane, as in the kernel above -- they were the difference between two and three resident blocks per CU
+    float4* const etab = reinterpret_cast<float4*>(smem + 3 * CHFL + 4 * 32 * kOutPitch); // [32]
+    if (tid < 32) etab[tid] = epi[blockIdx.y * 32 + tid];
+
+    // ---- stage the halo tile into the channel planes; every load of the thread is issued before its first LDS write
+    constexpr int kR = (IN_H * IN_W + 255) / 256;
+    {
+        float sv[kR][3];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float o[4];
+        for (int r = 0; r < kR; ++r) {
+            const int el = tid + 256 * r;
+            const int rr = el / IN_W, c = el - rr * IN_W;
+            const int sy = resolve_nobranch(oy0 * S - p.pady + rr, p.H, p.padMode);
+            const int sx = resolve_nobranch(ox0 * S - p.padx + c, p.W, p.padMode);
+            const bool ok = el < IN_H * IN_W && sy >= 0 && sx >= 0;
+            const float* src = x + (static_cast<size_t>(n * p.H + (ok ? sy : 0)) * p.W + (ok ? sx : 0)) * 3;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v = epi_affine(acc[yy][4 * g + k], e[4 * g + k], p.useBN);
-                o[k] = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+            for (int k = 0; k < 3; ++k) {
+                const float t = src[k];
+                sv[r][k] = ok ? t : 0.0f;
             }
-            *reinterpret_cast<float4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        // (wave-private scratch: a wave's LDS operations complete in order).  Out: 16-byte pieces, lane L = piece L % 8 of pixel L / 8 (+ 8 i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int opix = 8 * i + (lane >> 3), piece = lane & 7;
-            const float4 v = *reinterpret_cast<const float4*>(sc + opix * kOutPitch + 4 * piece);
-            const int ox = ox0 + opix;
-            if (oy < p.OH && ox < p.OW) *reinterpret_cast<float4*>(y + (static_cast<size_t>(n * p.OH + oy) * p.OW + ox) * p.OC + blockIdx.y * 32 + 4 * piece) = v;
+        for (int r = 0; r < kR; ++r) {
+            const int el = tid + 256 * r;
+            const int rr = el / IN_W, c = el - rr * IN_W;
+            if (el < IN_H * IN_W) {
+                float* const d0 = tile + rr * ROWFL + (c & 1) * PW + (c >> 1);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) d0[k * CHFL] = sv[r][k];
+            }
         }
     }
+    __syncthreads();
+
+    f32x16 acc[kNR];
+#pragma unroll
+    for (int i = 0; i < kNR; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const float* const tb = tile + (wave * kNR * S) * ROWFL + l32;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        // input elements 2s (lane half 0) and 2s + 1 (half 1; the one past the end repeats the last: its weight is zero): (row, fx, ch) -> plane offset
+        const int g0 = 2 * s, g1 = 2 * s + 1 < NE ? 2 * s + 1 : NE - 1;
+        const int r0 = g0 / 21, fx0 = (g0 % 21) / 3, c0 = g0 % 3;
+        const int r1 = g1 / 21, fx1 = (g1 % 21) / 3, c1 = g1 % 3;
+        const int o0 = c0 * CHFL + r0 * ROWFL + (fx0 & 1) * PW + (fx0 >> 1);
+        const int o1 = c1 * CHFL + r1 * ROWFL + (fx1 & 1) * PW + (fx1 >> 1);
+        const float b = tb[h ? o1 : o0];
+#pragma unroll
+        for (int yy = 0; yy < kNR; ++yy) {
+            const int k = s - 21 * yy; // weight pair of output row yy
+            if (k < 0 || k >= NWD) continue; // compile-time after unrolling
+            acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[k], b, acc[yy], 0, 0, 0);
+        }
+    }
+    float4 e[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) e[4 * g + kk] = etab[8 * g + 4 * h + kk];
+    stem32_epilogue<kNR, SIMPLE>(p, ac, acc, e, oscr + wave * (32 * kOutPitch), y, n, oy0 + wave * kNR, ox0, lane);
 }
 
 typedef void (*Stem32Fn)(Stem32Params, ActCfg, const float*, const float*, const float4*, float*);
@@ -201,6 +310,11 @@ int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     if (K == 3 && S == 1) fn = pick_stem32<3, 1>(simple, NR);
     if (K == 3 && S == 2) fn = pick_stem32<3, 2>(simple, NR);
     if (K == 7 && S == 2) fn = pick_stem32<7, 2>(simple, NR);
+    // the 7x7 stride-2 RGB stem: dense (tap, channel) packing of the reduction, 74 instead of 98 MFMAs per row tile (SNNHIP_STEM_DENSE=0: the general form)
+    bool dense = K == 7 && S == 2 && g.IC == 3;
+    if (const char* e = snnhip::option("SNNHIP_STEM_DENSE")) dense = dense && atoi(e) != 0;
+    if (dense) fn = NR == 2 ? (simple ? conv2d_stem32_dense_kernel<2, true> : conv2d_stem32_dense_kernel<2, false>)
+                            : (simple ? conv2d_stem32_dense_kernel<4, true> : conv2d_stem32_dense_kernel<4, false>);
     if (!fn) return SNNHIP_E_UNSUPPORTED;
     if (static_cast<double>(g.N) * g.OH * g.OW * g.OC >= 2147483647.0 * 2) return SNNHIP_E_UNSUPPORTED;
 
@@ -210,7 +324,8 @@ int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     p.tilesX = up_div(g.OW, kTW); p.tilesY = up_div(g.OH, kTH);
     const int IN_H = (kTH - 1) * S + K, IN_W = (kTW - 1) * S + K;
     (void) IN_W;
-    const size_t lds = (static_cast<size_t>(IN_H) * (2 * (S == 2 ? 2 : 1) * plane_w(K, S) * 2) + 4 * 32 * kOutPitch) * sizeof(float); // [IN_H][2][parity planes][kPlaneW] pairs
+    const size_t lds = dense ? (static_cast<size_t>(3) * IN_H * 2 * kDensePW + 4 * 32 * kOutPitch + 32 * 4) * sizeof(float) // [3][IN_H][2][kDensePW] floats, scratch, epilogue table
+                             : (static_cast<size_t>(IN_H) * (2 * (S == 2 ? 2 : 1) * plane_w(K, S) * 2) + 4 * 32 * kOutPitch) * sizeof(float); // [IN_H][2][parity planes][kPlaneW] pairs
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("conv2d_stem32: hipFuncSetAttribute(%zu) failed", lds);
         return SNNHIP_E_HIP;
@@ -239,6 +354,17 @@ int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
                     for (int o = 0; o < 32; ++o)
                         wpk[(static_cast<size_t>(b) * NW + 2 * t + m) * 64 + 32 * hh + o] = w_oihw[(static_cast<size_t>(b * 32 + o) * g.IC + ic) * K * K + t];
                 }
+    if (dense) { // Wp[oc block][k][lane = 32 hh + o] = W_flat[32 b + o][e = 2k + hh], e = (fy 7 + fx) 3 + ch, zero behind e = 146
+        wpk.assign(static_cast<size_t>(ocb) * kDenseSteps * 64, 0.0f);
+        for (int b = 0; b < ocb; ++b)
+            for (int k = 0; k < kDenseSteps; ++k)
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int e = 2 * k + hh;
+                    if (e >= 147) continue;
+                    const int ch = e % 3, t = e / 3;
+                    for (int o = 0; o < 32; ++o) wpk[(static_cast<size_t>(b) * kDenseSteps + k) * 64 + 32 * hh + o] = w_oihw[(static_cast<size_t>(b * 32 + o) * 3 + ch) * 49 + t];
+                }
+    }
     int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
     if (rc == SNNHIP_OK) rc = plan->upload(epi4.data(), epi4.size(), &plan->d_epi);
     if (rc != SNNHIP_OK) {
@@ -251,8 +377,8 @@ int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     plan->flops = 2.0 * K * K * g.IC * g.OC * static_cast<double>(g.OH) * g.OW * g.N;
     plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * K * K);
     char buf[256];
-    snprintf(buf, sizeof(buf), "conv2d_mfma_stem_f32_32x32x2 k=%dx%d s=%d ic=%d oc=%d tile=%dx%dpx x 32oc (2 MFMAs per tap, weights in registers) lds=%zuB", K, K, S, g.IC, g.OC,
-             kTH, kTW, lds);
+    snprintf(buf, sizeof(buf), "conv2d_mfma_stem_f32_32x32x2 k=%dx%d s=%d ic=%d oc=%d tile=%dx%dpx x 32oc (%s, weights in registers) lds=%zuB", K, K, S, g.IC, g.OC, kTH, kTW,
+             dense ? "dense (tap, channel) K: 74 MFMAs per row tile" : "2 MFMAs per tap", lds);
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

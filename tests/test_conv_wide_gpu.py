@@ -205,7 +205,7 @@ def test_stem_with_fused_reflect_pad_and_non_finite_neighbours(ctx):
 
 
 # ---- conv2d_stem_f32.hip: the fp32 RGB stems (IC <= 4; 3x3 stride 1 / 2, 7x7 stride 2), 2 MFMAs per tap, weights in registers
-STEM32 = [(1, 224, 224, 3, 64, 3, 1), (2, 64, 64, 3, 32, 3, 2), (2, 75, 61, 3, 64, 7, 2), (1, 33, 47, 1, 32, 3, 1), (1, 40, 40, 4, 96, 7, 2), (3, 9, 11, 3, 32, 3, 2),
+STEM32 = [(1, 224, 224, 3, 64, 3, 1), (2, 64, 64, 3, 32, 3, 2), (2, 75, 61, 3, 64, 7, 2), (2, 224, 224, 3, 64, 7, 2), (1, 33, 47, 1, 32, 3, 1), (1, 40, 40, 4, 96, 7, 2), (3, 9, 11, 3, 32, 3, 2),
           (1, 17, 130, 2, 64, 3, 1)]
 
 
@@ -238,6 +238,15 @@ def test_stem32_matches_oracle_and_tap_pair_kernel(ctx, monkeypatch, shape, rows
         want = O.conv2d(x, w, b, s, pads, pad_mode, act, 0.0, bn if use_bn else None)
         assert y.shape == want.shape
         np.testing.assert_allclose(y, want, err_msg=desc, **tol)
+        if k == 7 and IC == 3:  # the RGB 7x7 stride-2 stem packs its reduction densely (74 K steps); SNNHIP_STEM_DENSE=0 gives the general form back
+            assert "dense (tap, channel) K" in desc, desc
+            monkeypatch.setenv("SNNHIP_STEM_DENSE", "0")
+            y3, desc3 = run(pad_mode, act, bn if use_bn else None)
+            monkeypatch.delenv("SNNHIP_STEM_DENSE")
+            assert "2 MFMAs per tap" in desc3, desc3
+            np.testing.assert_allclose(y, y3, err_msg=desc + " vs " + desc3, rtol=2e-5, atol=2e-5)
+        else:
+            assert "2 MFMAs per tap" in desc, desc
         monkeypatch.setenv("SNNHIP_CONV_STEM", "0")
         y2, desc2 = run(pad_mode, act, bn if use_bn else None)
         assert "stem" not in desc2, desc2

@@ -89,36 +89,62 @@ __global__ __launch_bounds__(256) void dense_kernel(int In, int Out, int batch, 
 // GFLOP and 6.3 MB of operands.  Here: v_mfma_f32_32x32x2_f32 (an exact fp32 fma chain) with the weight rows as the A operand (M = 32 output units) and
 // the batch rows as B (N = 32 images): both operands are row-major with K contiguous, so lane (r = l % 32, kh = l / 32) loads the 16 bytes
 // [r][8 j + 4 kh ..] of each and the four MFMAs of a K block consume the four components (the K permutation is the same on both sides).  A block =
-// one 32 x 32 tile, its four waves split K and add their tiles up through LDS; bias and the CPU path's activation in the epilogue.
+// one 32 x 32 tile, its four waves split K and add their tiles up through LDS; bias and the CPU path's activation in the epilogue.  (That first form is
+// described here for the record; what runs is the LDS-staged form below.)
 typedef float f32x16d __attribute__((ext_vector_type(16)));
+// Operands through LDS (round 3, second form).  Loaded straight into the operand layout a lane's 16 bytes are 1/8 of a 128-byte line and the other
+// seven eighths belong to three more instructions and the other lane half: the four-wave form took 41 us (MobileNetV2) / 19.8 us (ResNet-18) at 0.09 /
+// 0.008 of the matrix pipe with 16 MB of HBM traffic, and neither more waves nor more loads in flight moved it -- the lines were
+// fetched from L2 over and over.  Here a K chunk of 64 of both 32-row tiles is copied with whole-line loads (16 lanes x 16 bytes = one 256-byte row
+// segment; chunk c + 1 is in registers while chunk c is multiplied), rows 68 floats apart in LDS (a multiple of 16 bytes that is odd in 16-byte units:
+// the ds_read_b128 of 32 rows at one K offset is conflict-free), and wave w multiplies K sixteenth-pairs [16w, 16w + 16) of every chunk.
+constexpr int kDenseKC = 64, kDensePitch = kDenseKC + 4;
 __global__ __launch_bounds__(256) void dense_mfma_kernel(int In, int Out, int batch, int act, float leaky, const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float tileW[32 * kDensePitch], tileX[32 * kDensePitch];
     __shared__ float red[4][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, kh = lane >> 5;
     const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-    const int kw = ((In / 4 + 7) / 8) * 8; // K range of a wave (multiple of 8)
-    const int kBeg = wave * kw, kEnd = min(In, kBeg + kw);
-    const bool aOk = o0 + r < Out, bOk = b0 + r < batch;
-    const float4* ap = reinterpret_cast<const float4*>(w + static_cast<size_t>(min(o0 + r, Out - 1)) * In + 4 * kh);
-    const float4* bp = reinterpret_cast<const float4*>(x + static_cast<size_t>(min(b0 + r, batch - 1)) * In + 4 * kh);
+    // staging: thread t copies float4 (row t / 16, column 4 (t % 16)) and the same column of row 16 + t / 16, of both tiles
+    const int srow = tid >> 4, scol = (tid & 15) * 4;
+    const float* wsrc0 = w + static_cast<size_t>(min(o0 + srow, Out - 1)) * In + scol;
+    const float* wsrc1 = w + static_cast<size_t>(min(o0 + srow + 16, Out - 1)) * In + scol;
+    const float* xsrc0 = x + static_cast<size_t>(min(b0 + srow, batch - 1)) * In + scol;
+    const float* xsrc1 = x + static_cast<size_t>(min(b0 + srow + 16, batch - 1)) * In + scol;
+    float4 pw0, pw1, px0, px1;
+    // (In % 8 == 0, scol % 4 == 0: a float4 is inside the row or past it; rows past Out / batch repeat the last one and are not stored.  A macro: a lambda
+    // that captures the four registers by reference puts them in scratch)
+#define DENSE_FETCH(k0_)                                                                   \
+    do {                                                                                   \
+        const bool in_ = (k0_) + scol < In;                                                \
+        const int kk_ = in_ ? (k0_) : 0; /* unconditional loads: a select between a load and a constant took the constant's ADDRESS (scratch) */ \
+        pw0 = *reinterpret_cast<const float4*>(wsrc0 + kk_);                               \
+        pw1 = *reinterpret_cast<const float4*>(wsrc1 + kk_);                               \
+        px0 = *reinterpret_cast<const float4*>(xsrc0 + kk_);                               \
+        px1 = *reinterpret_cast<const float4*>(xsrc1 + kk_);                               \
+        if (!in_) pw0 = pw1 = px0 = px1 = make_float4(0.f, 0.f, 0.f, 0.f);                 \
+    } while (0)
     f32x16d acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = kBeg; k0 < kEnd; k0 += 32) { // four K blocks (eight loads) in flight per lane
-        float4 a[4], b[4];
+    DENSE_FETCH(0);
+    const float* const aop = tileW + r * kDensePitch + 16 * wave + 4 * kh; // this wave's K sixteenth, the lane's half of each 8
+    const float* const bop = tileX + r * kDensePitch + 16 * wave + 4 * kh;
+    for (int k0 = 0; k0 < In; k0 += kDenseKC) {
+        if (k0) __syncthreads(); // every wave is done with the previous chunk
+        *reinterpret_cast<float4*>(tileW + srow * kDensePitch + scol) = pw0;
+        *reinterpret_cast<float4*>(tileW + (srow + 16) * kDensePitch + scol) = pw1;
+        *reinterpret_cast<float4*>(tileX + srow * kDensePitch + scol) = px0;
+        *reinterpret_cast<float4*>(tileX + (srow + 16) * kDensePitch + scol) = px1;
+        __syncthreads();
+        if (k0 + kDenseKC < In) DENSE_FETCH(k0 + kDenseKC);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool in = k0 + 8 * j < kEnd;
-            a[j] = (in && aOk) ? ap[(k0 + 8 * j) / 4] : zero4;
-            b[j] = (in && bOk) ? bp[(k0 + 8 * j) / 4] : zero4;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b[j].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b[j].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b[j].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b[j].w, acc, 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+            const float4 a = *reinterpret_cast<const float4*>(aop + 8 * j), b = *reinterpret_cast<const float4*>(bop + 8 * j);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
     }
 #pragma unroll
@@ -141,6 +167,7 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(int In, int Out, int ba
             y[static_cast<size_t>(b) * Out + o] = v;
         }
     }
+#undef DENSE_FETCH
 }
 
 // softmax over one output row per block (cpulayer.h:173-189): max, exp(x-max), sum, divide

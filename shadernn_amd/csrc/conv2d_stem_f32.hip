@@ -27,6 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct Stem32Params {
     int N, H, W, IC, OC, padx, pady, padMode, useBN, OH, OW;
     int tilesX, tilesY;
+    int poolOH, poolOW; // dense kernel, POOL form: dims of the MaxPooling2D 3x3 stride 2 output written instead of the convolution's (0 otherwise)
 };
 
 constexpr int kTW = 32;                 // block tile: 4 waves stacked in y, NR output rows per wave (4; 2 on grids that leave CUs idle: half the latency)
@@ -164,7 +165,13 @@ __global__ __launch_bounds__(256, K <= 3 ? 3 : 2) void conv2d_stem32_kernel(Stem
 //   * tile in LDS as channel planes [ch][row][column parity][column / 2] of floats: the 32 lanes of a half read 32 consecutive floats; the two halves read
 //     different (tap, channel) elements, i.e. different compile-time offsets: one v_cndmask + one ds_read_b32 per step.
 //   * 74 weight registers per lane (flat order, zero behind e = 146); epilogue = the kernel above.
-template <int kNR, bool SIMPLE>
+//   * POOL (chain rule J): the MaxPooling2D 3x3 stride 2 behind the stem (no padding on top / left: maxpool2dVulkan.cpp:62-64; window clipped at the
+//     bottom / right, the maximum starts at -100000.0) runs in the epilogue and the 112x112 tensor never reaches memory.  A block then owns 7 x 15
+//     POOLED pixels = rows [14 ty, 14 ty + 15) x columns [30 tx, 30 tx + 31) of the convolution (one row / column of its 16 x 32 tile is spare, 8
+//     instead of 7 row tiles: +14 % stem work against the pool launch's 29 us and 183 MB).  Wave w holds rows 4w .. 4w + 3: pooled row 2w is the
+//     maximum of its rows 0-2, pooled row 2w + 1 needs row 0 of wave w + 1, handed over through the (by then dead) input tile; the column maximum is
+//     taken while a pooled row passes through the wave's output scratch.
+template <int kNR, bool SIMPLE, bool POOL = false>
 __global__ __launch_bounds__(256, 3) void conv2d_stem32_dense_kernel(Stem32Params p, ActCfg ac, const float* __restrict__ x, const float* __restrict__ wp,
                                                                   const float4* __restrict__ epi, float* __restrict__ y) {
     constexpr int K = 7, S = 2;
@@ -181,7 +188,8 @@ __global__ __launch_bounds__(256, 3) void conv2d_stem32_dense_kernel(Stem32Param
     const int l32 = lane & 31, h = lane >> 5;
     const int mt = blockIdx.x;
     const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, n = mt / (p.tilesX * p.tilesY);
-    const int ox0 = tx * kTW, oy0 = ty * kTH;
+    const int ox0 = POOL ? tx * 30 : tx * kTW, oy0 = POOL ? ty * 14 : ty * kTH;
+    static_assert(!POOL || kNR == 4, "the pooling epilogue is written for 16-row tiles");
 
     float wa[NWD];
     {
@@ -248,12 +256,79 @@ __global__ __launch_bounds__(256, 3) void conv2d_stem32_dense_kernel(Stem32Param
             acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[k], b, acc[yy], 0, 0, 0);
         }
     }
-    float4 e[16];
+    __builtin_amdgcn_sched_barrier(0); // (nothing of the epilogue is scheduled into the K loop: its registers are spoken for)
+    if constexpr (!POOL) {
+        float4 e[16];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) e[4 * g + kk] = etab[8 * g + 4 * h + kk];
-    stem32_epilogue<kNR, SIMPLE>(p, ac, acc, e, oscr + wave * (32 * kOutPitch), y, n, oy0 + wave * kNR, ox0, lane);
+            for (int kk = 0; kk < 4; ++kk) e[4 * g + kk] = etab[8 * g + 4 * h + kk];
+        stem32_epilogue<kNR, SIMPLE>(p, ac, acc, e, oscr + wave * (32 * kOutPitch), y, n, oy0 + wave * kNR, ox0, lane);
+    } else {
+        constexpr float kPoolFloor = -100000.0f; // the reference's initial maximum; also the value of a pixel outside the convolution's output
+        const bool colOk = ox0 + l32 < p.OW;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { // four table rows at a time (all sixteen next to the 64 accumulators and the hand-over row spilled)
+            float4 e[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) e[kk] = etab[8 * g + 4 * h + kk];
+#pragma unroll
+            for (int yy = 0; yy < kNR; ++yy) {
+                const bool ok = colOk && oy0 + wave * kNR + yy < p.OH;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float v = epi_affine(acc[yy][4 * g + kk], e[kk], p.useBN);
+                    const float a = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
+                    acc[yy][4 * g + kk] = ok ? a : kPoolFloor;
+                }
+            }
+        }
+        __syncthreads(); // every wave is done with the input tile: its space carries the hand-over rows
+        float* const xrow = tile + wave * (32 * kOutPitch);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(xrow + l32 * kOutPitch + 8 * g + 4 * h) = make_float4(acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]);
+        __syncthreads();
+        const float* const nrow = tile + ((wave + 1) & 3) * (32 * kOutPitch) + l32 * kOutPitch + 4 * h; // row 0 of the wave below (wave 3: unused)
+        float* const sc = oscr + wave * (32 * kOutPitch);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            if (jj == 1 && wave == 3) break; // pooled row 7 of the tile belongs to the next one (wave-uniform)
+            const int py = ty * 7 + 2 * wave + jj;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float m[4];
+                const float4 nx4 = jj == 1 ? *reinterpret_cast<const float4*>(nrow + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float nx[4] = {nx4.x, nx4.y, nx4.z, nx4.w};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int i = 4 * g + kk;
+                    const float t = jj == 0 ? fmaxf(fmaxf(acc[0][i], acc[1][i]), acc[2][i]) : fmaxf(fmaxf(acc[2][i], acc[3][i]), nx[kk]);
+                    m[kk] = fmaxf(t, kPoolFloor);
+                }
+                *reinterpret_cast<float4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = make_float4(m[0], m[1], m[2], m[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (wave-private scratch: LDS operations of a wave complete in order; keep the compiler's order)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) { // 15 pooled pixels x 8 16-byte pieces = 120 items over two passes of the wave
+                const int item = lane + 64 * pass, opix = item >> 3, piece = item & 7;
+                if (item < 120) {
+                    const float4 a = *reinterpret_cast<const float4*>(sc + (2 * opix) * kOutPitch + 4 * piece);
+                    const float4 b = *reinterpret_cast<const float4*>(sc + (2 * opix + 1) * kOutPitch + 4 * piece);
+                    const float4 c = *reinterpret_cast<const float4*>(sc + (2 * opix + 2) * kOutPitch + 4 * piece);
+                    const int px = tx * 15 + opix;
+                    if (py < p.poolOH && px < p.poolOW)
+                        *reinterpret_cast<float4*>(y + (static_cast<size_t>(n * p.poolOH + py) * p.poolOW + px) * p.OC + blockIdx.y * 32 + 4 * piece) =
+                            make_float4(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z), fmaxf(fmaxf(a.w, b.w), c.w));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
 }
 
 typedef void (*Stem32Fn)(Stem32Params, ActCfg, const float*, const float*, const float4*, float*);
@@ -272,8 +347,9 @@ struct Stem32Plan : ConvPlanBase {
         const snnhip_tensor* x = in[0];
         SNNHIP_REQUIRE(x->n == p.N && x->h == p.H && x->w == p.W && x->c == p.IC && x->dtype == SNNHIP_F32, "conv2d: input dims %dx%dx%dx%d (dtype %d) != plan %dx%dx%dx%d fp32",
                        x->n, x->h, x->w, x->c, x->dtype, p.N, p.H, p.W, p.IC);
-        SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC && out->dtype == SNNHIP_F32, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
-                       out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
+        const int eoh = p.poolOH ? p.poolOH : p.OH, eow = p.poolOH ? p.poolOW : p.OW;
+        SNNHIP_REQUIRE(out->n == p.N && out->h == eoh && out->w == eow && out->c == p.OC && out->dtype == SNNHIP_F32, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
+                       out->n, out->h, out->w, out->c, p.N, eoh, eow, p.OC);
         hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, x->data, d_w, reinterpret_cast<const float4*>(d_epi), out->data);
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
@@ -379,6 +455,71 @@ int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     char buf[256];
     snprintf(buf, sizeof(buf), "conv2d_mfma_stem_f32_32x32x2 k=%dx%d s=%d ic=%d oc=%d tile=%dx%dpx x 32oc (%s, weights in registers) lds=%zuB", K, K, S, g.IC, g.OC, kTH, kTW,
              dense ? "dense (tap, channel) K: 74 MFMAs per row tile" : "2 MFMAs per tap", lds);
+    plan->desc = buf;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+// Chain rule J: the 7x7 stride-2 RGB stem -> MaxPooling2D 3x3 stride 2 as one launch (conv2d_stem32_dense_kernel<4, ., true>)
+int make_conv2d_stem32_pool_plan(snnhip_ctx* ctx, snnhip_plan* stemPlan, snnhip_plan* poolPlan, snnhip_plan** out) {
+    if (snnhip::option("SNNHIP_NO_STEM_POOL_FUSION")) return SNNHIP_E_UNSUPPORTED;
+    auto* cs = dynamic_cast<Stem32Plan*>(stemPlan);
+    snnhip_pool2d_desc pd;
+    if (!cs || !pool2d_plan_desc(poolPlan, &pd)) return SNNHIP_E_UNSUPPORTED;
+    const ConvGeom& g = cs->g;
+    if (cs->desc.find("dense (tap, channel) K") == std::string::npos) return SNNHIP_E_UNSUPPORTED; // the dense 7x7 stride-2 RGB form only
+    if (pd.type != SNNHIP_POOL_MAX || pd.kh != 3 || pd.kw != 3 || pd.sh != 2 || pd.sw != 2 || pd.padT != 0 || pd.padL != 0) return SNNHIP_E_UNSUPPORTED;
+    if (pd.N != g.N || pd.H != g.OH || pd.W != g.OW || pd.C != g.OC) return SNNHIP_E_UNSUPPORTED;
+    // every pooled pixel's window must start inside the convolution's output (rows 2 py, columns 2 px): true for the reference's output-size rule
+    if (2 * (pd.OH - 1) >= g.OH || 2 * (pd.OW - 1) >= g.OW) return SNNHIP_E_UNSUPPORTED;
+    const bool simple = act_is_simple(g.act);
+    Stem32Fn fn = simple ? conv2d_stem32_dense_kernel<4, true, true> : conv2d_stem32_dense_kernel<4, false, true>;
+    Stem32Params p = cs->p;
+    p.poolOH = pd.OH;
+    p.poolOW = pd.OW;
+    p.tilesX = up_div(pd.OW, 15);
+    p.tilesY = up_div(pd.OH, 7);
+    constexpr int IN_H = 15 * 2 + 7;
+    const size_t lds = (static_cast<size_t>(3) * IN_H * 2 * kDensePW + 4 * 32 * kOutPitch + 32 * 4) * sizeof(float);
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+        set_error("conv2d_stem32+pool: hipFuncSetAttribute(%zu) failed", lds);
+        return SNNHIP_E_HIP;
+    }
+    auto* plan = new Stem32Plan();
+    plan->ctx = ctx;
+    plan->g = g;
+    plan->w_oihw = cs->w_oihw;
+    plan->epi4 = cs->epi4;
+    plan->p = p;
+    plan->ac = cs->ac;
+    plan->kernel = fn;
+    plan->ldsBytes = lds;
+    plan->grid = dim3(static_cast<unsigned>(p.tilesX) * p.tilesY * g.N, g.OC / 32, 1);
+    // the packed weights and the epilogue table of the 16-row-tile dense form are what this kernel reads: re-packed here (the borrowed plan may use 8-row tiles)
+    const int ocb = g.OC / 32;
+    std::vector<float> wpk(static_cast<size_t>(ocb) * kDenseSteps * 64, 0.0f);
+    for (int b = 0; b < ocb; ++b)
+        for (int k = 0; k < kDenseSteps; ++k)
+            for (int hh = 0; hh < 2; ++hh) {
+                const int e = 2 * k + hh;
+                if (e >= 147) continue;
+                const int ch = e % 3, t = e / 3;
+                for (int o = 0; o < 32; ++o) wpk[(static_cast<size_t>(b) * kDenseSteps + k) * 64 + 32 * hh + o] = cs->w_oihw[(static_cast<size_t>(b * 32 + o) * 3 + ch) * 49 + t];
+            }
+    int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
+    if (rc == SNNHIP_OK) rc = plan->upload(cs->epi4.data(), cs->epi4.size(), &plan->d_epi);
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    memcpy(plan->inDims, stemPlan->inDims, sizeof(plan->inDims));
+    memcpy(plan->outDims, poolPlan->outDims, sizeof(plan->outDims));
+    plan->dtype = SNNHIP_F32;
+    plan->flops = stemPlan->flops + poolPlan->flops;
+    plan->bytes = stemPlan->bytes + poolPlan->bytes; // unfused accounting of the two layers it replaces
+    char buf[320];
+    snprintf(buf, sizeof(buf), "conv2d_mfma_stem_f32_32x32x2 k=7x7 s=2 ic=3 oc=%d tile=16x32px x 32oc (dense (tap, channel) K: 74 MFMAs per row tile, weights in registers) "
+             "+maxpool3x3/2 in the epilogue (7x15 pooled px per block) lds=%zuB", g.OC, lds);
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

@@ -792,6 +792,13 @@ snnhip_plan* instancenorm_add_use_tile_stats(snnhip_plan* plan, const TileStatsR
     return q->norm;
 }
 
+bool pool2d_plan_desc(const snnhip_plan* plan, snnhip_pool2d_desc* d) {
+    const auto* pp = dynamic_cast<const PoolPlan*>(plan);
+    if (!pp) return false;
+    if (d) *d = pp->d;
+    return true;
+}
+
 bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d) {
     const auto* q = dynamic_cast<const InstanceNormPlan*>(plan);
     if (!q) return false;

@@ -1224,6 +1224,18 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             st.bytes = 4.0 * (static_cast<double>(g0.N) * g0.H * g0.W * (16 + 4) + 4.0 * 16 * 9);
             i += 2;
             ++fusedCount;
+        } else if (snnhip_plan* spool = nullptr; i + 1 < n && c0 && !c0->depthwise && c0->g.kh == 7 && pool2d_plan_desc(plans[i + 1], nullptr) &&
+                                          make_conv2d_stem32_pool_plan(ctx, plans[i], plans[i + 1], &spool) == SNNHIP_OK) {
+            // ---- rule J: Conv2D 7x7 stride 2 (RGB) -> MaxPooling2D 3x3 stride 2 (the head of ResNet-18) -> the pooling runs in the stem's epilogue
+            chain->owned.push_back(spool);
+            st.kind = ChainPlan::PLAIN;
+            st.plain = spool;
+            memcpy(st.outDims, spool->outDims, sizeof(st.outDims));
+            st.desc = spool->desc;
+            st.flops = spool->flops;
+            st.bytes = spool->bytes;
+            i += 2;
+            ++fusedCount;
         } else if (snnhip_plan* sirb = nullptr; i + 2 < n && c0 && c1 && c2 && !c0->depthwise && c0->g.kh == 3 && c0->g.IC == 3 && c1->depthwise && !c2->depthwise &&
                                          make_irb_plan(ctx, nullptr, plans[i + 1], plans[i + 2], nullptr, &sirb, plans[i]) == SNNHIP_OK) {
             // ---- rule G with the network's stem as the 'expand' layer: Conv2D 3x3 (3 -> C channels) -> DepthwiseConv2D 3x3 -> Conv2D 1x1 (the head of

@@ -222,6 +222,11 @@ struct NormFoldTarget {
 bool instancenorm_fold_target(snnhip_plan* normPlan, NormFoldTarget* t);
 // eltwise_pool.hip: identify an InstanceNorm plan / run its fold + normalise passes in place from a convolution's tile statistics
 bool instancenorm_plan_desc(const snnhip_plan* plan, snnhip_instancenorm_desc* d);
+// eltwise_pool.hip: identify a Pooling plan (resolved output dims included)
+bool pool2d_plan_desc(const snnhip_plan* plan, snnhip_pool2d_desc* d);
+// conv2d_stem_f32.hip, chain rule J: Conv2D 7x7 stride 2 of an RGB image -> MaxPooling2D 3x3 stride 2 (the head of ResNet-18) as one launch: the pooling
+// runs in the stem's epilogue (borrows both plans; SNNHIP_E_UNSUPPORTED for anything else)
+int make_conv2d_stem32_pool_plan(snnhip_ctx* ctx, snnhip_plan* stemPlan, snnhip_plan* poolPlan, snnhip_plan** out);
 // chain rule H: InstanceNorm -> Add(., residual) folded into the norm's normalise sweep (two-input plan; borrows normPlan)
 // the Add's output must have the norm's extent (a smaller residual is added top-left aligned, the reference's ragged-Add rule)
 int make_instancenorm_add_plan(snnhip_ctx* ctx, snnhip_plan* normPlan, snnhip_plan* addPlan, bool normIsFirstInput, snnhip_plan** out);

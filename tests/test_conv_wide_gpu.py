@@ -253,6 +253,40 @@ def test_stem32_matches_oracle_and_tap_pair_kernel(ctx, monkeypatch, shape, rows
         np.testing.assert_allclose(y, y2, err_msg=desc + " vs " + desc2, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 224, 224, 64, "relu", True), (1, 75, 61, 32, "tanh", False), (3, 131, 58, 96, "leakyRelu", True), (1, 33, 230, 64, "", True)],
+                         ids=["resnet_head", "ragged_tanh", "three_oc_blocks", "wide_short"])
+def test_stem_maxpool_runs_as_one_launch(ctx, monkeypatch, shape):
+    """Chain rule J: Conv2D 7x7 stride 2 of an RGB image -> MaxPooling2D 3x3 stride 2 (the head of ResNet-18) as one launch: the pooling runs in the dense
+    stem kernel's epilogue (windows clipped at the bottom / right, no padding on top / left, maximum floored at -100000.0 like the separate layer).
+    Bit-identical to the two separate launches (the same convolution arithmetic, then exact maxima), within 1e-4 of the oracle; the switch turns
+    the rule off."""
+    import shadernn_amd as snn
+
+    N, H, W, OC, act, use_bn = shape
+    x = _rand((N, H, W, 3), 91)
+    w = _rand((OC, 3, 7, 7), 92, 1.0 / np.sqrt(147))
+    b = _rand((OC,), 93, 0.1)
+    bn = _bn(OC, 94) if use_bn else None
+    pads = O.padding_offsets("same", 7)
+    conv = snn.conv2d_plan(ctx, N, H, W, w, b, stride=2, pads=pads, pad_mode="constant", act=act, leaky=0.1, bn=bn)
+    _, CH, CW, _ = conv.out_shape()
+    pool = snn.pool2d_plan(ctx, N, CH, CW, OC, 3, 2, kind="max", same=True)
+    fused = snn.chain_plan(ctx, [conv, pool])
+    assert fused.num_steps() == 1 and "+maxpool3x3/2 in the epilogue" in fused.describe(), fused.describe()
+    xt = snn.Tensor.from_numpy(ctx, x)
+    got = fused(xt).numpy()
+    two = pool(conv(xt)).numpy()
+    want = O.pool2d(O.conv2d(x, w, b, 2, pads, "constant", act, 0.1, bn, threads=8), 3, 2, kind="max", same=True)
+    assert got.shape == want.shape == two.shape
+    np.testing.assert_array_equal(got, two, err_msg=fused.describe())
+    np.testing.assert_allclose(got, want, err_msg=fused.describe(), rtol=1e-4, atol=1e-4)
+    f, bts = fused.cost()
+    assert f > 0 and bts > 0
+    monkeypatch.setenv("SNNHIP_NO_STEM_POOL_FUSION", "1")
+    with pytest.raises(snn.capi.SnnHipError, match="no rule matches"):  # (the chain planner reports a chain it cannot shorten; the caller keeps the two plans)
+        snn.chain_plan(ctx, [conv, pool])
+
+
 @pytest.mark.parametrize("kernel_fold", [True, False], ids=["kernel-fold", "fold-launches"])
 @pytest.mark.parametrize("n,h,w,ic,oc,offset", [(2, 19, 45, 32, 128, 0.0), (1, 37, 70, 64, 64, 6.0), (3, 9, 33, 16, 32, 0.0), (1, 16, 64, 128, 128, 40.0), (2, 70, 300, 16, 32, 0.0),
                                                 (2, 12, 40, 32, 256, 0.0), (2, 21, 37, 16, 96, 0.0)])  # (the last two: several output-channel blocks per pixel tile)

@@ -28,13 +28,23 @@ Rank 0 prints ONE JSON line.
 Before the driver's `--warmup` steps a fixed time-based pre-heat (>= --preheat-ms of the workload, default 150 ms, reported as
 `preheat_ms`) brings the clocks up, so a 20-step run does not time the ramp.
 
+Timing: the timed region (K steps between two barriers + synchronisations, MAX over ranks) is repeated R times (--repeats; default 7 when K steps
+take less than 50 ms, else 3) and `value` / `ms_per_step` are the MEDIAN; `timing` carries min / max / every repeat.
+
 Extra objects on the line (prompt section 4):
-  roofline     -- dominant kernel of the step (largest average launch duration): algorithmic flops (or bytes) per launch / average
-                  launch duration measured live with HIP events on the launch stream over a FIXED number of event-bracketed inferences
-                  (--event-launches, default 32) run right after the timed region on the same plans and buffers, against the dense
-                  MFMA peak of the dtype (fp32 157.3 TFLOP/s, fp16 2500 TFLOP/s) or 8 TB/s HBM, whichever bounds that kernel.
+  roofline     -- the kernel FUNCTION the step spends most of its GPU time in (summed over all its launches and template instantiations;
+                  a step that launches a convolution and a statistics sweep is two entries, never one): the algorithmic flops (or HBM
+                  bytes) of those launches / their summed duration, against the dense MFMA peak of the dtype (fp32 157.3 TFLOP/s, fp16
+                  2500 TFLOP/s) or 8 TB/s HBM, whichever bounds that kernel.  Durations are measured live: a launch trace
+                  (snnhip_trace_begin, include/snnhip.h) over a fixed number of inferences (--event-launches) run launch by launch right
+                  after the timed region, every kernel stamped with its own dispatch start / end (what rocprofv3 --kernel-trace reports).
+                  A fused plan is priced on what the fused launch itself has to move (its `hbm_bytes`), never on the per-layer sum.
                   `traffic` = HBM bytes per launch from the committed PMC passes (profiles/pmc_latest.json), only when that file was
                   taken with the kernel sources of this build (fingerprint match), else null.
+  kernels      -- every kernel function of the step by share of GPU time, each with its own bound and fraction.
+  configs      -- (default run: --config c2 on one GPU) compact records of the OTHER BASELINE configs c1, c3, c4, c5 measured the same way
+                  in the same process: ms_per_step / images/s (median of R), in-run parity against the oracle, whole-step fraction,
+                  dominant kernel with fraction and PMC traffic ratio (--also none switches them off).
   cpu_baseline -- the CPU oracle (kind "port": this repo's C restatement of the reference shaders; the reference has no CPU conv
                   path) timed on this host on a bounded sample of the same workload; for the configs with a Dense head also the
                   reference's own Eigen dense path (oracle/_ref/ref_dense, kind "reference") timed beside it.
@@ -42,6 +52,7 @@ Extra objects on the line (prompt section 4):
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -70,15 +81,6 @@ CONFIGS = {
 
 # ------------------------------------------------------------------------------------------------ workloads
 
-def zoo_net(name, shape):
-    from shadernn_amd import param_import
-
-    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "zoo_topologies.json")))[name]
-    ops = [{"type": o["type"], "name": o["name"], "inputs": o["inputs"], "outputs": o["outputs"], "params": {int(k): v for k, v in o["params"].items()}}
-           for o in fx["ops"]]
-    return param_import.from_ops(ops, name=name, seed=1, input_shape=shape)
-
-
 def make_net(config):
     from shadernn_amd import models
 
@@ -90,7 +92,7 @@ def make_net(config):
         return models.resnet18(seed=1)
     if config == "c4":
         return models.mobilenetv2(seed=1)
-    return zoo_net("candy-9_simplified-opt", (720, 1280, 3))
+    return models.zoo("candy-9_simplified-opt", (720, 1280, 3), seed=1)
 
 
 def shard_plan(config, world, rank, micro=0):
@@ -141,7 +143,7 @@ class Workload:
             r.x.upload(rng.random(r.in_shape, dtype=np.float32))
 
     def first_input_output(self):
-        """(input, output) of the first micro-batch after one synchronous pass (parity leg)."""
+        """output of the first micro-batch after one synchronous pass (parity leg)."""
         r = self.runners[0][0]
         r.run_device()
         self.ctx.sync()
@@ -161,12 +163,8 @@ class Workload:
     def sync(self):
         self.ctx.sync()
 
-    def profile(self, on):
-        for p in self.all_plans():
-            p.profile(on)
-
-    def all_plans(self):
-        return [p for _, plans in self.runners for p in plans]
+    def launch_by_launch(self, on):
+        pass  # the ctypes runners never replay a graph
 
     def cost(self):
         f = b = 0.0
@@ -179,27 +177,8 @@ class Workload:
     def launches(self):
         return sum(n * sum(p.num_steps() for p in plans) for (_, plans), n in zip(self.runners, self.counts))
 
-
-class HostPlanView:
-    """One kernel-launching plan of a host.Model stage, with the Plan methods the timing loop uses."""
-
-    def __init__(self, model, stage, nsteps):
-        self.m, self.stage, self.n = model, stage, nsteps
-
-    def num_steps(self):
-        return self.n
-
-    def profile(self, on):
-        pass  # switched per model (HostWorkload.profile)
-
-    def profile_read(self, i):
-        return self.m.profile_read(self.stage, i)
-
-    def step_describe(self, i):
-        return [d for st, k, d, _, _ in self.m.plan_steps() if st == self.stage and k == i][0]
-
-    def step_cost(self, i):
-        return [(f, b) for st, k, _, f, b in self.m.plan_steps() if st == self.stage and k == i][0]
+    def close(self):
+        pass
 
 
 class HostWorkload:
@@ -220,7 +199,6 @@ class HostWorkload:
             self.models.append(m)
             self.counts.append(sizes.count(mb))
         self.micro_sizes = sizes
-        self.runners = [(m, None) for m in self.models]
         self.json_path = path
         self.model_args = dict(w=W, h=H, c=cfg["cin"], device=device, fuse_chains=not unfused, prefer_half=cfg["dtype"] == "f16")
 
@@ -275,18 +253,10 @@ class HostWorkload:
         for m in self.models:
             m.sync()
 
-    def profile(self, on):
+    def launch_by_launch(self, on):
+        """a replayed hipGraph never calls the plans: traced inferences run launch by launch"""
         for m in self.models:
-            m.profile(on)
-
-    def all_plans(self):
-        out = []
-        for m in self.models:
-            stages = {}
-            for st, k, _, _, _ in m.plan_steps():
-                stages[st] = max(stages.get(st, 0), k + 1)
-            out += [HostPlanView(m, st, n) for st, n in sorted(stages.items())]
-        return out
+            m.suspend_replay(on)
 
     def cost(self):
         f = b = 0.0
@@ -298,6 +268,11 @@ class HostWorkload:
 
     def launches(self):
         return sum(n * len(m.plan_steps()) for m, n in zip(self.models, self.counts))
+
+    def close(self):
+        for m in self.models:
+            m.close()
+        self.models = []
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -405,57 +380,311 @@ def csrc_fingerprint():
     return fingerprint.csrc_sha16()
 
 
-def _template_ints(name):
-    """integer template arguments of a kernel symbol, mangled (`...ILi4ELi1E...`) or demangled (`...<4, 1, ...>`)"""
-    import re
-
-    if name.startswith("_Z"):
-        return [int(v) for v in re.findall(r"Li(\d+)E", name)]
-    m = re.search(r"<([^>]*)>", name)
-    return [int(v) for v in re.findall(r"\b\d+\b", m.group(1))] if m else []
+def _short_kernel_name(full):
+    """`void snnhip::(anonymous namespace)::conv2d_wide_kernel<4, 1, 4, 8>(Params, ...)` -> `conv2d_wide_kernel<4,1,4,8>`: the key tools/summarize_prof.py
+    writes a PMC record under"""
+    n = full.replace("void snnhip::(anonymous namespace)::", "").replace("snnhip::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    return n.split("(")[0].replace(" ", "")
 
 
-def pmc_entry(pmc, desc, tags):
-    """The PMC record (profiles/pmc_latest.json, keyed by kernel function) of the launch a plan description stands for: the `kernel=` tag of the
-    description, its first word, or -- for the convolution kernels whose symbols differ from their description -- the function name plus the
-    template arguments the description implies."""
-    import re
+def pmc_traffic(kernel):
+    """HBM bytes per launch of a kernel function from the committed PMC passes (profiles/pmc_latest.json, written by tools/profile_gpu.sh ->
+    summarize_prof.py, one record per template instantiation): the launch-weighted mean over the instantiations this run launched, only from
+    records taken with the kernel sources of this build.  (traffic or None, where it came from)"""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None, "profiles/pmc_latest.json is missing"
+    try:
+        pmc = json.load(open(path))
+    except Exception as e:
+        return None, "profiles/pmc_latest.json unreadable: %r" % (e,)
+    sha = csrc_fingerprint()
+    tot = n = 0.0
+    stale = missing = 0
+    head = None
+    for inst in kernel["instances"]:
+        ent = pmc.get(_short_kernel_name(inst["name"]))
+        if ent is None:
+            missing += inst["launches"]
+        elif ent.get("csrc_sha16") != sha:
+            stale += inst["launches"]
+            head = ent.get("csrc_sha16")
+        else:
+            tot += ent["hbm_bytes_per_launch"] * inst["launches"]
+            n += inst["launches"]
+            head = ent.get("git_head")
+    if n and not missing and not stale:
+        return tot / n, "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s, commit %s), launch-weighted over %d instantiation(s)" % (
+            sha, head, len(kernel["instances"]))
+    if stale:
+        return None, "stale: profiles/pmc_latest.json was taken with kernel sources %s, this build is %s" % (head, sha)
+    return None, "no PMC record for this kernel's instantiations in profiles/pmc_latest.json"
 
-    key = tags.get("kernel", desc.split(" ")[0])
-    if key in pmc:
-        return pmc[key]
-    core = desc.split(" -> ")[-1] if "instancenorm(" in desc.split(" ")[0] else desc  # (a norm folded in front of a convolution: the convolution's launch)
-    m = re.search(r"k=(\d+)x\d+ s=(\d+) ic=(\d+) oc=(\d+)", core)
-    want = None
-    if "conv2d_mfma_wide_f16" in core and m:
-        wm = 2 if "tile=8x32px" in core else 4
-        nt = int(re.search(r"\(4x(\d) MFMA tiles", core).group(1))
-        c8 = int(re.search(r"chunk=(\d+)", core).group(1)) // 16
-        want = ("conv2d_wide_kernel", [wm, 4 // wm, nt, c8])
-    elif "conv2d_mfma_stem_f16" in core:
-        want = ("conv2d_stem_kernel", [])
-    elif "conv2d_mfma_stem_f32" in core and "dense (tap, channel) K" in core:
-        want = ("conv2d_stem32_dense_kernel", [])
-    elif "conv2d_mfma_stem_f32" in core and m:
-        want = ("conv2d_stem32_kernel", [int(m.group(1)), int(m.group(2))])
-    elif "conv2d_mfma_upconv" in core and m:
-        want = ("conv2d_upconv_kernel", [int(m.group(3)) // 16])
-    elif "s=2" in core and "row-marching" in core and m:
-        want = ("conv2d_s2march_kernel", [int(m.group(3)) // 16])
-    elif "conv2d_rowfold" in core and "row-marching" in core and m:
-        want = ("conv2d_rowfold_march_kernel", [int(m.group(1)), int(m.group(3)) // 16, int(m.group(4))])
-    elif "conv2d_rowfold" in core and m:
-        want = ("conv2d_rowfold_kernel", [int(m.group(1)), int(m.group(3)) // 16])
-    elif "conv2d_mfma_wino" in core:
-        want = ("conv2d_wino_kernel", [])
-    if not want:
-        return None
-    for k, v in pmc.items():
-        if want[0] in k and (k.startswith("_Z") or "<" in k) and _template_ints(k)[: len(want[1])] == want[1]:
-            return v
-    if any(want[0] in k and (k.startswith("_Z") or "<" in k) for k in pmc):
-        return None  # the profile holds other instantiations of this function only: their traffic is not this launch's
-    return pmc.get(want[0])  # (a file keyed by bare function names)
+
+def kernel_table(trace, inferences, peak_tf):
+    """The launch trace (capi.trace_end) as one row per kernel FUNCTION, most GPU time first.  `flops` / `bytes` are the algorithmic work of the plan
+    invocations whose main launch the function was (a fused plan: what the fused launch moves), per traced step; a function that only ever runs
+    beside another plan's main kernel (split-K reduce, statistics fold, softmax) has none and no fraction."""
+    total_ms = sum(k["total_ms"] for k in trace["kernels"]) or 1.0
+    rows = []
+    for k in trace["kernels"]:
+        t = k["total_ms"] * 1e-3
+        tf, tb = k["flops"] / (peak_tf * 1e12), k["bytes"] / (PEAK_HBM_GBPS * 1e9)
+        row = {"function": k["function"], "launches_per_step": k["launches"] / inferences, "us_per_step": 1e3 * k["total_ms"] / inferences,
+               "avg_launch_us": 1e3 * k["total_ms"] / max(1, k["launches"]), "share_of_gpu_time": k["total_ms"] / total_ms,
+               "algorithmic_flops_per_step": k["flops"] / inferences, "algorithmic_bytes_per_step": k["bytes"] / inferences,
+               "instances": [{"name": i["name"], "launches": i["launches"], "total_ms": i["total_ms"], "flops": i["flops"], "bytes": i["bytes"],
+                              "plans": i["plans"][:4]} for i in sorted(k["instances"], key=lambda i: -i["total_ms"])]}
+        if k["main_launches"] and t > 0 and (tf > 0 or tb > 0):
+            row["bound"] = "mfma" if tf >= tb else "hbm"
+            row["frac"] = max(tf, tb) / t
+            row["achieved_tflops"] = k["flops"] / t / 1e12
+            row["achieved_hbm_gbps"] = k["bytes"] / t / 1e9
+        else:
+            row["bound"], row["frac"] = "aux", None
+        rows.append(row)
+    rows.sort(key=lambda r: -r["us_per_step"])
+    return rows
+
+
+def roofline_record(rows, peak_tf, single_launch_step):
+    dom = rows[0]
+    launches = sum(i["launches"] for i in dom["instances"]) or 1
+    t = sum(i["total_ms"] for i in dom["instances"]) * 1e-3
+    flops, nbytes = sum(i["flops"] for i in dom["instances"]), sum(i["bytes"] for i in dom["instances"])
+    mfma = dom.get("bound") == "mfma"
+    ach = (flops / t / 1e12) if mfma else (nbytes / t / 1e9)
+    peak = peak_tf if mfma else PEAK_HBM_GBPS
+    traffic, src = pmc_traffic(dom)
+    rec = {"bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s", "frac": ach / peak,
+           "traffic": traffic, "traffic_source": src, "kernel": dom["function"],
+           "kernel_instances": [_short_kernel_name(i["name"]) for i in dom["instances"]],
+           "dominant_by": "total GPU time over all launches of the function in the traced steps", "share_of_gpu_time": dom["share_of_gpu_time"],
+           "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
+           "algorithmic_flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": nbytes / launches,
+           "traffic_over_algorithmic_bytes": (traffic / (nbytes / launches)) if (traffic and nbytes) else None,
+           "hbm_gbps_of_this_kernel": nbytes / t / 1e9, "plans": dom["instances"][0]["plans"][:3]}
+    if single_launch_step and dom["avg_launch_us"] < 25.0:
+        # a step that is ONE kernel of a few microseconds (c1: 196 blocks on 256 CUs, 8-11 us): what bounds it is the launch itself (dispatch,
+        # wave start-up, the tail of a single round of blocks), not the memory system; the fraction stays quoted against HBM
+        rec["bound"] = "launch"
+        rec["bound_note"] = "single %.1f us kernel per step: launch / ramp bound; achieved and peak are the HBM figures" % dom["avg_launch_us"]
+    m = re.search(r"mfma_flops=([0-9.e+]+)", " ".join(rec["plans"]))
+    if m and mfma:
+        # `achieved` uses the ALGORITHMIC flops of the direct convolutions (2*k*k*IC*OC per output pixel, SURVEY 8d).  The ESPCN kernel evaluates its
+        # 3x3 layer as Winograd F(2x2,3x3) (2.25x fewer multiplies) but recomputes conv1 on the tile halo: what the matrix pipe really executes
+        ex = float(m.group(1))
+        rec["executed_mfma_flops_per_launch"] = ex
+        rec["executed_mfma_tflops"] = ex * launches / t / 1e12
+        rec["frac_executed"] = ex * launches / t / 1e12 / peak_tf
+    return rec
+
+
+def run_config(config, args, env, primary):
+    """Builds `config`'s workload on this rank, checks image 0 against the oracle, times it (median of R timed regions of K steps) and traces its
+    kernels.  Returns the record of the JSON line (primary) or a compact one (the `configs` block)."""
+    import numpy as np
+    import tempfile
+
+    import shadernn_amd as snn
+    import shadernn_amd.capi as capi_mod
+
+    cfg = CONFIGS[config]
+    rank, world, group, ctx, dev, info = env["rank"], env["world"], env["group"], env["ctx"], env["dev"], env["info"]
+    steps = args.steps if (primary and args.steps is not None) else {"c1": 500, "c2": 200, "c3": 50, "c4": 20, "c5": 10}[config]
+    warmup = args.warmup if (primary and args.warmup is not None) else {"c1": 50, "c2": 20, "c3": 5, "c4": 3, "c5": 2}[config]
+    if not primary:
+        steps = {"c1": 200, "c2": 100, "c3": 20, "c4": 8, "c5": 3}[config]
+        warmup = {"c1": 20, "c2": 10, "c3": 3, "c4": 2, "c5": 1}[config]
+    net = make_net(config)
+    shard = shard_plan(config, world, rank, args.micro if primary else 0)
+    images, global_batch = shard["images"], shard["global_batch"]
+    if images == 0:
+        sys.stderr.write("bench.py: rank %d has no images (global batch %d over %d ranks)\n" % (rank, global_batch, world))
+        sys.exit(2)
+    through = args.through if args.through != "auto" else "host"
+    rng = np.random.default_rng(7767517 + rank)
+    tmpdir = tempfile.mkdtemp(prefix="snn_bench_")
+    if through == "host":
+        os.environ.setdefault("SNN_LOG_LEVEL", "2")
+        wl = HostWorkload(config, net, shard["micro_sizes"], dev, tmpdir, unfused=args.unfused, capture=not args.no_capture)
+    else:
+        wl = Workload(ctx, config, net, shard["micro_sizes"], unfused=args.unfused)
+    # synthetic input (U(0,1), seed echoing the reference's SRAND(7767517), a different stream per rank), uploaded once: resident in HBM
+    wl.upload(rng)
+    ctx.sync()
+    env["torch"].cuda.synchronize()
+
+    # ---- parity leg (rank 0): the GPU result of image 0 against the oracle's, before anything is timed
+    parity, cpu_rec = None, None
+    if rank == 0 and not args.no_parity:
+        cpu_rec, want = cpu_baseline(config, net, timed_legs=(primary and world == 1 and not args.no_cpu_baseline))
+        got = wl.first_input_output()
+        got = np.asarray(got).reshape((-1,) + tuple(want.shape[1:]))[:1]
+        parity = parity_record(config, got, want)
+        if not parity["ok"]:
+            sys.stderr.write("bench.py: PARITY FAILURE (%s) against the CPU oracle: %s\n" % (config, json.dumps(parity)))
+    elif rank == 0 and primary and world == 1 and not args.no_cpu_baseline:
+        cpu_rec, _ = cpu_baseline(config, net)
+
+    barrier = group.barrier  # dist.barrier + torch.cuda.synchronize()
+    barrier()
+
+    def timed_region(step_fn, n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step_fn()
+        wl.sync()
+        barrier()
+        return group.max_over_ranks(time.perf_counter() - t0)
+
+    # time-based pre-heat, then the driver's warmup steps
+    t0 = time.perf_counter()
+    pre_steps = 0
+    preheat_target = args.preheat_ms if primary else min(args.preheat_ms, 100.0)
+    while True:
+        for _ in range(4):
+            wl.run_inflight()
+        pre_steps += 4
+        wl.sync()
+        if 1e3 * (time.perf_counter() - t0) >= preheat_target:
+            break
+    preheat_ms = 1e3 * (time.perf_counter() - t0)
+    value_fn = wl.run_sync if (args.value_mode == "sync" and through == "host") else wl.run_inflight
+    for _ in range(warmup):
+        value_fn()
+    # R timed regions of exactly `steps` steps each; the line quotes the median (a 20-step ESPCN region is 2.5 ms: one sample cannot be told from noise)
+    first = timed_region(value_fn, steps)
+    repeats = args.repeats if args.repeats > 0 else (7 if first < 0.05 else 3)
+    if not primary:
+        repeats = min(repeats, 5)
+    samples = [first] + [timed_region(value_fn, steps) for _ in range(repeats - 1)]
+    elapsed = float(np.median(samples))
+
+    # the other wait semantics on the same models, same step count (host path; outside `value`)
+    modes = {}
+    if through == "host" and primary:
+        other = wl.run_inflight if value_fn == wl.run_sync else wl.run_sync
+        med = lambda fn: float(np.median([timed_region(fn, steps) for _ in range(min(repeats, 3))]))
+        if value_fn == wl.run_sync:
+            modes["sync_per_inference_blocking_wait"] = elapsed
+            modes["inflight"] = med(other)
+        else:
+            modes["inflight"] = elapsed
+            modes["sync_per_inference_blocking_wait"] = med(other)
+        capi_mod.set_option("SNNHIP_SYNC_SPIN_US", "2000")  # opt in to the polling wait (the library's default blocks at once)
+        modes["sync_per_inference"] = med(wl.run_sync)
+        capi_mod.set_option("SNNHIP_SYNC_SPIN_US", None)
+
+    # per-kernel durations: a launch trace over a fixed number of steps run launch by launch on the same plans and buffers, right after the timed
+    # region (clocks still up); every kernel is stamped with its own dispatch start / end
+    rows, trace_steps = [], 0
+    if not args.no_kernel_events and args.event_launches > 0:
+        trace_steps = max(1, min(args.event_launches, {"c1": 64, "c2": 32, "c3": 8, "c4": 4, "c5": 2}[config]))
+        wl.launch_by_launch(True)
+        wl.run_sync() if through == "host" else (wl.run_device(), wl.sync())  # first launch-by-launch pass untraced
+        capi_mod.trace_begin()
+        for _ in range(trace_steps):
+            wl.run_sync() if through == "host" else wl.run_device()
+        wl.sync()
+        trace = capi_mod.trace_end()
+        wl.launch_by_launch(False)
+        peak_tf = PEAK_F16_MFMA_TFLOPS if cfg["dtype"] == "f16" else PEAK_F32_MFMA_TFLOPS
+        rows = kernel_table(trace, trace_steps, peak_tf)
+
+    layer_table = None
+    table_loops = args.layer_table if args.layer_table is not None else (20 if world == 1 else 0)
+    if rank == 0 and through == "host" and primary and table_loops > 0:
+        layer_table = wl.layer_table(table_loops)
+
+    out = None
+    if rank == 0:
+        flops, bytes_unfused = wl.cost()
+        flops_img, bytes_img = flops / images, bytes_unfused / images
+        step_s = elapsed / steps
+        value = global_batch * steps / elapsed
+        peak_tf = PEAK_F16_MFMA_TFLOPS if cfg["dtype"] == "f16" else PEAK_F32_MFMA_TFLOPS
+        H, W = cfg["hw"]
+        value_mode = ("sync per inference" if value_fn == wl.run_sync else "inferences in flight") if through == "host" else "kernels enqueued from Python, one wait at the end"
+        launches = wl.launches()
+        out = {
+            "metric": "images/sec (1080p ESPCN 2x) at 1/2/4/8 MI355X; achieved HBM GB/s" if config == "c2" else "images/sec (%s)" % cfg["workload"],
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * step_s, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
+            "dtype": cfg["dtype"], "data": "synthetic", "preheat_ms": preheat_ms, "preheat_steps": pre_steps,
+            "value_mode": value_mode,
+            "timing": {"repeats": len(samples), "what": "each repeat = exactly %d steps between two barriers + synchronisations, MAX over ranks; value and ms_per_step are the median" % steps,
+                       "median_ms_per_step": 1e3 * step_s, "min_ms_per_step": 1e3 * min(samples) / steps, "max_ms_per_step": 1e3 * max(samples) / steps,
+                       "ms_per_step_of_each_repeat": [1e3 * t / steps for t in samples]},
+            "config": {"workload": cfg["workload"], "config_id": config, "global_batch": global_batch, "images_per_rank_per_step": images,
+                       "micro_batches_per_rank": wl.micro_sizes, "input": [images, H, W, cfg["cin"]],
+                       "parallelism": "dp%d (batch split, weights replicated, no data-path collective)" % world,
+                       "path": ("C++ host mirror (libsnn_core.so, JSON + .bin model -> ModelParser -> MixedInferenceCore::create / run%s)" % ("" if args.no_capture else ", recorded hipGraph replay")
+                                if through == "host" else "per-layer plans through the C-ABI") +
+                               (", graph fusion (snnhip_graph_fuse)" if not args.unfused else ", one kernel per layer") + ", %d kernel launches per step" % launches,
+                       "device": info["name"], "compute_units": info["compute_units"]},
+            "parity": parity,
+            "max_abs_err": parity["max_abs_err"] if parity else None, "max_rel_err": parity["max_rel_err"] if parity else None,
+            "flops_per_image": flops_img, "bytes_per_image_unfused_accounting": bytes_img,
+            "achieved_tflops_per_gpu": flops / step_s / 1e12,
+            "achieved_hbm_gbps_unfused_accounting_per_gpu": bytes_unfused / step_s / 1e9,
+            "frac_hbm_roofline_unfused_accounting": bytes_unfused / step_s / 1e9 / PEAK_HBM_GBPS,
+            "frac_compute_roofline": flops / step_s / 1e12 / peak_tf,
+            "whole_step_roofline_ms": 1e3 * max(flops / peak_tf / 1e12, bytes_unfused / PEAK_HBM_GBPS / 1e9),
+        }
+        out["frac_of_whole_step_roofline"] = out["whole_step_roofline_ms"] / out["ms_per_step"]
+        if modes:
+            out["wait_semantics"] = {
+                "value_is": value_mode,
+                "inflight": {"images_per_s": global_batch * steps / modes["inflight"], "ms_per_step": 1e3 * modes["inflight"] / steps,
+                             "what": "RunParameters::deferSync: %d steps enqueued back to back, one wait at the end" % steps},
+                "sync_per_inference": {"images_per_s": global_batch * steps / modes["sync_per_inference"], "ms_per_step": 1e3 * modes["sync_per_inference"] / steps,
+                                       "what": "reference semantics: MixedInferenceCore::run waits once per inference (core.cpp:203); snnhip_sync polls the stream "
+                                               "for up to SNNHIP_SYNC_SPIN_US=2000 us before it blocks (opt-in)"},
+                "sync_per_inference_blocking_wait": {"images_per_s": global_batch * steps / modes["sync_per_inference_blocking_wait"],
+                                                     "ms_per_step": 1e3 * modes["sync_per_inference_blocking_wait"] / steps,
+                                                     "what": "the same with the library default SNNHIP_SYNC_SPIN_US=0: hipStreamSynchronize at once"},
+            }
+            out["frac_of_whole_step_roofline_sync_per_inference"] = out["whole_step_roofline_ms"] / out["wait_semantics"]["sync_per_inference"]["ms_per_step"]
+        if layer_table is not None:
+            out["layer_table"] = {"method": "reference benchmark table (inferenceProcessor.cpp:84-86,143-199): %d inferences, first 5 dropped, per-stage device timers "
+                                            "(MixedInferenceCore::writeTimeStat), mean and population sigma in ms; launch by launch (timers need the host between stages)" % (table_loops + 5),
+                                  "rows": layer_table}
+        if rows:
+            # the same bound kernel by kernel, on the FUSED graph's own accounting (a fused launch counts its inputs and outputs once): fusion cannot
+            # beat this one, and a compute-bound layer is not hidden behind the graph's HBM total
+            per_step = sum(max(r["algorithmic_flops_per_step"] / peak_tf / 1e12, r["algorithmic_bytes_per_step"] / PEAK_HBM_GBPS / 1e9) for r in rows)
+            out["sum_of_launch_rooflines_ms"] = 1e3 * per_step
+            out["frac_of_sum_of_launch_rooflines"] = 1e3 * per_step / out["ms_per_step"]
+            out["sum_of_kernel_durations_ms"] = sum(r["us_per_step"] for r in rows) / 1e3
+            out["traced_steps"] = trace_steps
+            out["kernels"] = rows if args.all_kernels else [dict(r, instances=r["instances"][:3]) for r in rows[:10]]
+            out["roofline"] = roofline_record(rows, peak_tf, single_launch_step=(launches == 1))
+        if cpu_rec is not None:
+            out["cpu_baseline"] = cpu_rec
+        if not primary:
+            # the compact form of the `configs` block
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "scaling", "value_mode", "frac_of_whole_step_roofline", "whole_step_roofline_ms",
+                    "sum_of_launch_rooflines_ms", "frac_of_sum_of_launch_rooflines", "sum_of_kernel_durations_ms", "flops_per_image", "bytes_per_image_unfused_accounting")
+            comp = {k: out[k] for k in keep if k in out}
+            comp["workload"] = cfg["workload"]
+            comp["images_per_step"] = global_batch
+            comp["micro_batches"] = wl.micro_sizes
+            comp["launches_per_step"] = launches
+            comp["timing"] = {k: out["timing"][k] for k in ("repeats", "median_ms_per_step", "min_ms_per_step", "max_ms_per_step")}
+            comp["parity"] = {k: parity[k] for k in ("ok", "max_abs_err", "max_rel_err", "tolerance") if k in parity} if parity else None
+            if parity and "q999_err_over_range" in parity:
+                comp["parity"]["q999_err_over_range"] = parity["q999_err_over_range"]
+            if rows:
+                r = out["roofline"]
+                comp["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic_bytes", "kernel", "share_of_gpu_time",
+                                                      "launches_per_step", "avg_launch_us", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch") if k in r}
+                comp["kernels"] = [{"function": k["function"], "share_of_gpu_time": k["share_of_gpu_time"], "us_per_step": k["us_per_step"], "launches_per_step": k["launches_per_step"],
+                                    "bound": k["bound"], "frac": k["frac"]} for k in rows[:6]]
+            out = comp
+    wl.close()
+    return out, parity
 
 
 def main():
@@ -464,6 +693,10 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--also", default=None,
+                    help="comma-separated configs measured in the same run and reported compactly under `configs` (default: the other four when --config c2 "
+                         "runs on one GPU; `none` = off)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions per config (value = median); 0 = 7 when a region is shorter than 50 ms, else 3")
     ap.add_argument("--preheat-ms", type=float, default=150.0, help="run the workload untimed for at least this long before --warmup (clock ramp)")
     ap.add_argument("--unfused", action="store_true", help="one kernel per layer, no chain fusion (debug / comparison)")
     ap.add_argument("--through", choices=["auto", "host", "capi"], default="auto",
@@ -472,20 +705,15 @@ def main():
     ap.add_argument("--value-mode", choices=["inflight", "sync"], default="inflight",
                     help="what `value` is quoted on (host path): inflight = the K inferences of the timed region enqueued back to back, one wait at the end; "
                          "sync = MixedInferenceCore::run's one wait per inference (the other mode is reported beside it)")
-    ap.add_argument("--all-kernels", action="store_true", help="list every kernel of the step in `kernels` (default: the 12 most expensive)")
+    ap.add_argument("--all-kernels", action="store_true", help="list every kernel function and instantiation of the step in `kernels` (default: the 10 most expensive)")
     ap.add_argument("--micro", type=int, default=0, help="micro-batch size of the rank's share (default: the config's)")
     ap.add_argument("--no-capture", action="store_true", help="host path: launch kernel by kernel instead of replaying the recorded hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU legs (the parity check still runs the oracle once)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle check (debug only: the line then says parity: null)")
-    ap.add_argument("--no-kernel-events", action="store_true", help="skip the event-bracketed per-kernel leg (no `roofline` / `kernels`)")
-    ap.add_argument("--event-launches", type=int, default=32, help="inferences run launch by launch with HIP event pairs around every kernel, after the timed region")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the launch-trace leg (no `roofline` / `kernels`)")
+    ap.add_argument("--event-launches", type=int, default=64, help="upper bound on the steps run under the launch trace after the timed region (per config: 64 / 32 / 8 / 4 / 2)")
     ap.add_argument("--layer-table", type=int, default=None, help="loops of the reference-style per-layer table (first 5 dropped); default 20 at N=1, 0 = off")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-    if args.steps is None:
-        args.steps = {"c1": 500, "c2": 200, "c3": 50, "c4": 20, "c5": 10}[args.config]
-    if args.warmup is None:
-        args.warmup = {"c1": 50, "c2": 20, "c3": 5, "c4": 3, "c5": 2}[args.config]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started from a plain shell: become N ranks (one process per GPU) under torch.distributed.run
@@ -516,215 +744,33 @@ def main():
     dev = torch.cuda.current_device()
     stream = torch.cuda.Stream(device=dev)
     ctx = snn.Context(dev, stream=stream.cuda_stream)
-    info = ctx.info()
-    net = make_net(args.config)
-    shard = shard_plan(args.config, world, rank, args.micro)
-    images, global_batch = shard["images"], shard["global_batch"]
-    if images == 0:
-        sys.stderr.write("bench.py: rank %d has no images (global batch %d over %d ranks)\n" % (rank, global_batch, world))
-        sys.exit(2)
-    through = args.through if args.through != "auto" else "host"
-    import numpy as np
-    import tempfile
+    env = {"rank": rank, "world": world, "group": group, "ctx": ctx, "dev": dev, "info": ctx.info(), "torch": torch}
 
-    rng = np.random.default_rng(7767517 + rank)
-    tmpdir = tempfile.mkdtemp(prefix="snn_bench_")
-    if through == "host":
-        os.environ.setdefault("SNN_LOG_LEVEL", "2")
-        wl = HostWorkload(args.config, net, shard["micro_sizes"], dev, tmpdir, unfused=args.unfused, capture=not args.no_capture)
-    else:
-        wl = Workload(ctx, args.config, net, shard["micro_sizes"], unfused=args.unfused)
-    # synthetic input (U(0,1), seed echoing the reference's SRAND(7767517), a different stream per rank), uploaded once: resident in HBM
-    wl.upload(rng)
-    ctx.sync()
-    torch.cuda.synchronize()
-
-    # ---- parity leg (rank 0): the GPU result of image 0 against the oracle's, before anything is timed
-    parity, cpu_rec = None, None
-    if rank == 0 and not args.no_parity:
-        cpu_rec, want = cpu_baseline(args.config, net, timed_legs=(world == 1 and not args.no_cpu_baseline))
-        got = wl.first_input_output()
-        got = np.asarray(got).reshape((-1,) + tuple(want.shape[1:]))[:1]
-        parity = parity_record(args.config, got, want)
-        if not parity["ok"]:
-            sys.stderr.write("bench.py: PARITY FAILURE against the CPU oracle: %s\n" % json.dumps(parity))
-    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_rec, _ = cpu_baseline(args.config, net)
-
-    barrier = group.barrier  # dist.barrier + torch.cuda.synchronize()
-    barrier()
-
-    def timed_region(step_fn, steps):
-        barrier()
+    out, parity = run_config(args.config, args, env, primary=True)
+    failed = parity is not None and not parity["ok"]
+    also = args.also if args.also is not None else ("c1,c3,c4,c5" if (args.config == "c2" and world == 1 and not args.unfused and args.through != "capi") else "none")
+    extra = [c for c in also.split(",") if c in CONFIGS and c != args.config] if also != "none" else []
+    if extra:
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step_fn()
-        wl.sync()
-        barrier()
-        return group.max_over_ranks(time.perf_counter() - t0)
-
-    # time-based pre-heat, then the driver's warmup steps
-    t0 = time.perf_counter()
-    pre_steps = 0
-    while True:
-        for _ in range(4):
-            wl.run_inflight()
-        pre_steps += 4
-        wl.sync()
-        if 1e3 * (time.perf_counter() - t0) >= args.preheat_ms:
-            break
-    preheat_ms = 1e3 * (time.perf_counter() - t0)
-    value_fn = wl.run_sync if (args.value_mode == "sync" and through == "host") else wl.run_inflight
-    for _ in range(args.warmup):
-        value_fn()
-    elapsed = timed_region(value_fn, args.steps)
-
-    # the other wait semantics on the same models, same step count (host path; outside `value`)
-    modes = {}
-    if through == "host":
-        other = wl.run_inflight if value_fn == wl.run_sync else wl.run_sync
-        import shadernn_amd.capi as capi_mod
-
-        if value_fn == wl.run_sync:
-            modes["sync_per_inference"] = elapsed
-            modes["inflight"] = timed_region(other, args.steps)
-        else:
-            modes["inflight"] = elapsed
-            modes["sync_per_inference"] = timed_region(other, args.steps)
-        capi_mod.set_option("SNNHIP_SYNC_SPIN_US", "0")
-        modes["sync_per_inference_blocking_wait"] = timed_region(wl.run_sync, args.steps)
-        capi_mod.set_option("SNNHIP_SYNC_SPIN_US", None)
-
-    # per-kernel launch durations: a fixed number of inferences run launch by launch with an event pair around every kernel, on the same stream,
-    # plans and buffers, right after the timed region (clocks still up)
-    kernels = []
-    profile = not args.no_kernel_events and args.event_launches > 0
-    plans = wl.all_plans()
-    if profile:
-        wl.profile(True)
-        for _ in range(args.event_launches):
-            wl.run_sync() if through == "host" else wl.run_device()
-        wl.sync()
-        wl.profile(False)
-        for p in plans:
-            for i in range(p.num_steps()):
-                ms, n = p.profile_read(i)
-                fl, by = p.step_cost(i)
-                if n:
-                    desc = p.step_describe(i)
-                    # a fused plan's cost() keeps the SURVEY 8(d) accounting of the layers it replaces (the whole-step roofline is quoted on that); the
-                    # kernel-level roofline uses what the fused kernel itself has to move, which such plans publish as hbm_bytes=... in their description
-                    fused_bytes = [tk.split("=", 1)[1] for tk in desc.split(" ") if tk.startswith("hbm_bytes=")]
-                    kernels.append({"kernel": desc, "launches": n, "avg_us": 1e3 * ms / n, "flops": fl, "bytes": float(fused_bytes[0]) if fused_bytes else by,
-                                    "bytes_unfused_accounting": by})
-
-    layer_table = None
-    table_loops = args.layer_table if args.layer_table is not None else (20 if world == 1 else 0)
-    if rank == 0 and through == "host" and table_loops > 0:
-        layer_table = wl.layer_table(table_loops)
-
+        recs = {}
+        for c in extra:
+            try:
+                rec, par = run_config(c, args, env, primary=False)
+                failed = failed or (par is not None and not par["ok"])
+            except Exception as e:  # one config's failure must not cost the headline line; it is reported, and the run exits non-zero
+                rec, failed = {"error": repr(e)}, True
+            if rank == 0:
+                recs[c] = rec
+        if rank == 0:
+            out["configs"] = recs
+            out["configs_note"] = ("the other BASELINE configs, same process, same method (host mirror + hipGraph replay, in-run oracle parity on image 0, median of R "
+                                   "timed regions, launch trace for the per-kernel roofline); CPU legs: the parity pass only; %.0f s in total" % (time.perf_counter() - t0))
     if rank == 0:
-        flops, bytes_unfused = wl.cost()
-        flops_img, bytes_img = flops / images, bytes_unfused / images
-        step_s = elapsed / args.steps
-        value = global_batch * args.steps / elapsed
-        peak_tf = PEAK_F16_MFMA_TFLOPS if cfg["dtype"] == "f16" else PEAK_F32_MFMA_TFLOPS
-        H, W = cfg["hw"]
-        value_mode = ("sync per inference" if value_fn == wl.run_sync else "inferences in flight") if through == "host" else "kernels enqueued from Python, one wait at the end"
-        out = {
-            "metric": "images/sec (1080p ESPCN 2x) at 1/2/4/8 MI355X; achieved HBM GB/s" if args.config == "c2" else "images/sec (%s)" % cfg["workload"],
-            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * step_s, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
-            "dtype": cfg["dtype"], "data": "synthetic", "preheat_ms": preheat_ms, "preheat_steps": pre_steps,
-            "value_mode": value_mode,
-            "config": {"workload": cfg["workload"], "config_id": args.config, "global_batch": global_batch, "images_per_rank_per_step": images,
-                       "micro_batches_per_rank": wl.micro_sizes, "input": [images, H, W, cfg["cin"]],
-                       "parallelism": "dp%d (batch split, weights replicated, no data-path collective)" % world,
-                       "path": ("C++ host mirror (libsnn_core.so, JSON + .bin model -> ModelParser -> MixedInferenceCore::create / run%s)" % ("" if args.no_capture else ", recorded hipGraph replay")
-                                if through == "host" else "per-layer plans through the C-ABI") +
-                               (", graph fusion (snnhip_graph_fuse)" if not args.unfused else ", one kernel per layer") + ", %d kernel launches per step" % wl.launches(),
-                       "device": info["name"], "compute_units": info["compute_units"]},
-            "parity": parity,
-            "max_abs_err": parity["max_abs_err"] if parity else None, "max_rel_err": parity["max_rel_err"] if parity else None,
-            "flops_per_image": flops_img, "bytes_per_image_unfused_accounting": bytes_img,
-            "achieved_tflops_per_gpu": flops / step_s / 1e12,
-            "achieved_hbm_gbps_unfused_accounting_per_gpu": bytes_unfused / step_s / 1e9,
-            "frac_hbm_roofline_unfused_accounting": bytes_unfused / step_s / 1e9 / PEAK_HBM_GBPS,
-            "frac_compute_roofline": flops / step_s / 1e12 / peak_tf,
-            "whole_step_roofline_ms": 1e3 * max(flops / peak_tf / 1e12, bytes_unfused / PEAK_HBM_GBPS / 1e9),
-            "kernels": sorted(kernels, key=lambda k: -k["avg_us"] * k["launches"])[: (None if args.all_kernels else 12)],
-        }
-        if modes:
-            out["wait_semantics"] = {
-                "value_is": value_mode,
-                "inflight": {"images_per_s": global_batch * args.steps / modes["inflight"], "ms_per_step": 1e3 * modes["inflight"] / args.steps,
-                             "what": "RunParameters::deferSync: %d steps enqueued back to back, one wait at the end" % args.steps},
-                "sync_per_inference": {"images_per_s": global_batch * args.steps / modes["sync_per_inference"], "ms_per_step": 1e3 * modes["sync_per_inference"] / args.steps,
-                                       "what": "reference semantics: MixedInferenceCore::run waits once per inference (core.cpp:203); snnhip_sync polls the stream "
-                                               "(SNNHIP_SYNC_SPIN_US, default 2000) before it blocks"},
-                "sync_per_inference_blocking_wait": {"images_per_s": global_batch * args.steps / modes["sync_per_inference_blocking_wait"],
-                                                     "ms_per_step": 1e3 * modes["sync_per_inference_blocking_wait"] / args.steps,
-                                                     "what": "the same with SNNHIP_SYNC_SPIN_US=0: hipStreamSynchronize at once"},
-            }
-        if layer_table is not None:
-            out["layer_table"] = {"method": "reference benchmark table (inferenceProcessor.cpp:84-86,143-199): %d inferences, first 5 dropped, per-stage device timers "
-                                            "(MixedInferenceCore::writeTimeStat), mean and population sigma in ms; launch by launch (timers need the host between stages)" % (table_loops + 5),
-                                  "rows": layer_table}
-        out["frac_of_whole_step_roofline"] = out["whole_step_roofline_ms"] / out["ms_per_step"]
-        if kernels:
-            # the same bound launch by launch, on the FUSED graph's own accounting (a fused step counts its inputs and outputs once): fusion cannot
-            # beat this one, and a compute-bound layer is not hidden behind the graph's HBM total
-            per_step = sum(k["launches"] * max(k["flops"] / peak_tf / 1e12, k["bytes"] / PEAK_HBM_GBPS / 1e9) for k in kernels) / args.event_launches
-            out["sum_of_launch_rooflines_ms"] = 1e3 * per_step
-            out["frac_of_sum_of_launch_rooflines"] = 1e3 * per_step / out["ms_per_step"]
-            out["sum_of_kernel_durations_ms"] = sum(k["launches"] * k["avg_us"] for k in kernels) / args.event_launches / 1e3
-        if kernels:
-            dom = max(kernels, key=lambda k: k["avg_us"])
-            t = dom["avg_us"] * 1e-6
-            mfma_bound = dom["flops"] / (peak_tf * 1e12) >= dom["bytes"] / (PEAK_HBM_GBPS * 1e9)
-            tags = dict(tk.split("=", 1) for tk in dom["kernel"].split(" ") if "=" in tk and not tk.startswith("tile"))
-            traffic, traffic_source = None, "no PMC entry for this kernel in profiles/pmc_latest.json"
-            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")  # written by tools/profile_gpu.sh -> summarize_prof.py, keyed by kernel function
-            if os.path.exists(pmc):
-                try:
-                    ent = pmc_entry(json.load(open(pmc)), dom["kernel"], tags)
-                    if ent is not None:
-                        if ent.get("csrc_sha16") == csrc_fingerprint():
-                            traffic = ent.get("hbm_bytes_per_launch")
-                            traffic_source = "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s, commit %s)" % (
-                                ent.get("csrc_sha16"), ent.get("git_head"))
-                        else:
-                            traffic_source = "stale: profiles/pmc_latest.json was taken with kernel sources %s, this build is %s" % (ent.get("csrc_sha16"), csrc_fingerprint())
-                except Exception as e:
-                    traffic_source = "unreadable: %r" % (e,)
-            if mfma_bound:
-                ach = dom["flops"] / t / 1e12
-                out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
-            else:
-                ach = dom["bytes"] / t / 1e9
-                out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBPS}
-            if len(kernels) == 1 and dom["avg_us"] < 25.0:
-                # a step that is ONE kernel of a few microseconds (c1: 196 blocks on 256 CUs, 8-11 us): what bounds it is the launch itself (dispatch,
-                # wave start-up, the tail of a single round of blocks), not the memory system; the fraction stays quoted against HBM
-                out["roofline"]["bound"] = "launch"
-                out["roofline"]["bound_note"] = "single %.1f us kernel per step: launch / ramp bound; achieved and peak are the HBM figures" % dom["avg_us"]
-            out["roofline"].update({"traffic": traffic, "traffic_source": traffic_source, "kernel": dom["kernel"], "avg_launch_us": dom["avg_us"],
-                                    "algorithmic_flops_per_launch": dom["flops"], "algorithmic_bytes_per_launch": dom["bytes"],
-                                    "hbm_gbps_of_this_kernel": dom["bytes"] / t / 1e9})
-            if "mfma_flops" in tags:
-                # `achieved` uses the ALGORITHMIC flops of the direct convolutions (2*k*k*IC*OC per output pixel).  The kernel
-                # evaluates its 3x3 layer as Winograd F(2x2,3x3) (2.25x fewer multiplies) but recomputes conv1 on the tile halo: the
-                # flops the matrix pipe really executes, and its utilisation, are reported next to it.
-                ex = float(tags["mfma_flops"])
-                out["roofline"]["executed_mfma_flops_per_launch"] = ex
-                out["roofline"]["executed_mfma_tflops"] = ex / t / 1e12
-                out["roofline"]["frac_executed"] = ex / t / 1e12 / peak_tf
-        if cpu_rec is not None:
-            out["cpu_baseline"] = cpu_rec
         print(json.dumps(out))
+        sys.stdout.flush()
     group.barrier()
     group.close()
-    if parity is not None and not parity["ok"]:
+    if failed:
         sys.exit(4)
 
 

@@ -63,6 +63,9 @@ int snn_model_stage_plan_steps(snn_model* m, int stage);
 int snn_model_stage_plan_step(snn_model* m, int stage, int step, char* desc, int desc_len, double* flops, double* bytes);
 int snn_model_profile_enable(snn_model* m, int enable);
 int snn_model_profile_read(snn_model* m, int stage, int step, double* total_ms, int* launches);
+/* run launch by launch instead of replaying the recorded hipGraph (1) / replay again (0): what a launch trace (snnhip_trace_begin) needs --
+ * a replayed graph never calls the plans */
+int snn_model_suspend_replay(snn_model* m, int suspend);
 int snn_model_cost(snn_model* m, double* flops, double* bytes);
 /* per-stage device timers of the last run, milliseconds (MixedInferenceCore::writeTimeStat); returns count written */
 int snn_model_time_stats(snn_model* m, char* names, int names_len, double* ms, int max_entries);

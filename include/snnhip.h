@@ -358,6 +358,19 @@ int snnhip_plan_step_cost(const snnhip_plan* plan, int step, double* flops, doub
 int snnhip_plan_profile_enable(snnhip_plan* plan, int enable);
 int snnhip_plan_profile_read(snnhip_plan* plan, int step, double* total_ms, int* launches);
 
+/* ---- launch trace: per-KERNEL-FUNCTION timing of everything the library launches (measurement only) -------------------------
+ * The reference times per STAGE (DeviceTimer around a render pass, core/src/ic2/core.cpp:140-153,392-404); a fused plan or a split-K
+ * convolution is several launches per stage, and a roofline is a statement about ONE kernel.  Between snnhip_trace_begin and
+ * snnhip_trace_end every kernel launch of the process's plans is issued with its own event pair (the dispatch packet's start / end
+ * stamps: the durations rocprofv3 --kernel-trace reports) and booked on the plan that launched it; plans must be RUN, not replayed
+ * from a captured graph, while a trace is on.  snnhip_trace_report writes JSON: launches grouped by kernel function (template
+ * instantiations listed inside), each with launch count, summed duration, and the algorithmic flops / HBM bytes of the plan
+ * invocations whose longest launch it was (a plan's cost = snnhip_plan_cost's flops and, for a fused plan, what the fused launch
+ * itself has to move instead of the per-layer sum).  *needed = bytes the full report takes (call with buf == NULL to size it). */
+int snnhip_trace_begin(void);
+int snnhip_trace_end(void);
+int snnhip_trace_report(char* buf, size_t buflen, size_t* needed);
+
 /* ---- device timers (hipEvent pairs on the context stream) ---------------------------------------- */
 
 int snnhip_timer_create(snnhip_ctx* ctx, snnhip_timer** out);

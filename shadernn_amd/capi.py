@@ -162,6 +162,9 @@ SIGNATURES = {
     "snnhip_timer_stop": (C.c_int, [_P]),
     "snnhip_timer_elapsed_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "snnhip_timer_destroy": (C.c_int, [_P]),
+    "snnhip_trace_begin": (C.c_int, []),
+    "snnhip_trace_end": (C.c_int, []),
+    "snnhip_trace_report": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
 
@@ -199,6 +202,23 @@ def set_option(name, value):
 def get_option(name):
     v = lib().snnhip_get_option(name.encode())
     return None if v is None else v.decode()
+
+
+def trace_begin():
+    """snnhip_trace_begin: from now on every kernel the library launches is stamped with its own dispatch start / end and booked on its plan."""
+    check(lib().snnhip_trace_begin())
+
+
+def trace_end():
+    """snnhip_trace_end + snnhip_trace_report: the launches since trace_begin grouped by kernel function (parsed JSON)."""
+    import json
+
+    check(lib().snnhip_trace_end())
+    need = C.c_size_t(0)
+    check(lib().snnhip_trace_report(None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value + 16)
+    check(lib().snnhip_trace_report(buf, len(buf), C.byref(need)))
+    return json.loads(buf.value.decode("utf-8", "replace"))
 
 
 def check(rc):

@@ -5,7 +5,9 @@
 
 #include "snnhip_internal.h"
 
+#include <atomic>
 #include <chrono>
+#include <cxxabi.h>
 #include <map>
 #include <mutex>
 #include <set>
@@ -93,6 +95,113 @@ int resolve_conv_geom(const snnhip_conv2d_desc* d, bool depthwise, ConvGeom* g) 
 
 } // namespace snnhip
 
+// ---- launch trace --------------------------------------------------------------------------------------------------------------------------
+namespace snnhip {
+namespace {
+struct TraceRec {
+    const void* fn;
+    hipStream_t stream;
+    hipEvent_t start, stop;
+    int scope;
+};
+struct TraceScopeRec {
+    std::string desc;
+    double flops, bytes;
+};
+struct Tracer {
+    std::mutex m;
+    std::vector<TraceRec> recs;
+    std::vector<TraceScopeRec> scopes;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t used = 0;
+};
+Tracer& tracer() {
+    static Tracer* t = new Tracer(); // leaked on purpose: events must not be destroyed after the HIP runtime has shut down
+    return *t;
+}
+std::atomic<bool> g_traceOn{false};
+thread_local int t_scope = -1;
+
+std::string json_escape(const std::string& in) {
+    std::string o;
+    for (char c : in) {
+        if (c == '"' || c == '\\') o += '\\';
+        if (static_cast<unsigned char>(c) < 0x20) o += ' ';
+        else o += c;
+    }
+    return o;
+}
+std::string demangle(const char* mangled) {
+    if (!mangled) return "?";
+    int st = 0;
+    char* d = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+    std::string out = (st == 0 && d) ? d : mangled;
+    free(d);
+    return out;
+}
+// "void snnhip::(anonymous namespace)::conv2d_wide_kernel<4, 1, 4, 8>(Params, ...)" -> "conv2d_wide_kernel"
+std::string base_name(const std::string& full) {
+    size_t end = full.size();
+    int depth = 0;
+    // cut the parameter list: the last top-level '(' that is not "(anonymous namespace)"
+    for (size_t i = 0; i < full.size(); ++i) {
+        if (full[i] == '<') ++depth;
+        else if (full[i] == '>') --depth;
+        else if (full[i] == '(' && depth == 0 && full.compare(i, 21, "(anonymous namespace)") != 0) {
+            end = i;
+            break;
+        }
+    }
+    std::string head = full.substr(0, end);
+    const size_t lt = head.find('<');
+    if (lt != std::string::npos) head = head.substr(0, lt);
+    const size_t sp = head.rfind(' ');
+    if (sp != std::string::npos) head = head.substr(sp + 1);
+    const size_t cc = head.rfind("::");
+    if (cc != std::string::npos) head = head.substr(cc + 2);
+    return head;
+}
+} // namespace
+
+bool trace_active() { return g_traceOn.load(std::memory_order_relaxed); }
+
+int trace_events(const void* fn, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop) {
+    Tracer& t = tracer();
+    std::lock_guard<std::mutex> lock(t.m);
+    if (t.used == t.pool.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            *start = *stop = nullptr; // the launch still happens, untimed
+            return SNNHIP_E_HIP;
+        }
+        t.pool.emplace_back(a, b);
+    }
+    *start = t.pool[t.used].first;
+    *stop = t.pool[t.used].second;
+    ++t.used;
+    t.recs.push_back(TraceRec{fn, stream, *start, *stop, t_scope});
+    return SNNHIP_OK;
+}
+
+TraceScope::TraceScope(const std::string& desc, double flops, double bytes) {
+    if (!trace_active()) return;
+    Tracer& t = tracer();
+    std::lock_guard<std::mutex> lock(t.m);
+    t.scopes.push_back(TraceScopeRec{desc, flops, bytes});
+    prev = t_scope;
+    t_scope = static_cast<int>(t.scopes.size()) - 1;
+}
+TraceScope::TraceScope(const ::snnhip_plan* plan) : TraceScope(plan->desc, plan->flops, plan->ownBytes()) {}
+TraceScope::~TraceScope() {
+    if (prev != -2) t_scope = prev;
+}
+} // namespace snnhip
+
+int snnhip_plan::invoke(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) {
+    snnhip::TraceScope scope(this);
+    return run(in, nIn, out);
+}
+
 int snnhip_plan::upload(const float* host, size_t count, float** dev) {
     void* p = nullptr;
     SNNHIP_CHECK_HIP(hipMalloc(&p, count ? count * sizeof(float) : 4));
@@ -144,6 +253,8 @@ int snnhip_plan::profEnd(int step) {
 
 using namespace snnhip;
 
+static std::atomic<long> g_syncSpinUs{-1}; // SNNHIP_SYNC_SPIN_US, cached: -1 = not read yet
+
 extern "C" {
 
 const char* snnhip_last_error(void) { return g_err; }
@@ -154,6 +265,7 @@ int snnhip_set_option(const char* name, const char* value) {
     std::lock_guard<std::mutex> lock(g_optMutex);
     if (value) opt_map()[name] = value;
     else opt_map().erase(name);
+    if (strcmp(name, "SNNHIP_SYNC_SPIN_US") == 0) g_syncSpinUs.store(value ? (atol(value) > 0 ? atol(value) : 0L) : -1L); // -1: re-read the environment at the next sync
     return SNNHIP_OK;
 }
 const char* snnhip_get_option(const char* name) { return name ? snnhip::option(name) : nullptr; }
@@ -216,10 +328,17 @@ void* snnhip_ctx_stream(snnhip_ctx* ctx) { return ctx ? ctx->stream : nullptr; }
 
 int snnhip_sync(snnhip_ctx* ctx) {
     SNNHIP_REQUIRE(ctx, "sync: null ctx");
-    // An inference of the headline config is ~0.1 ms of stream time: a blocking wait (interrupt + wake-up of the host thread) costs a
-    // tenth of that.  Poll the stream for up to SNNHIP_SYNC_SPIN_US microseconds (default 2000, 0 = block at once) before blocking.
-    const char* spinOpt = snnhip::option("SNNHIP_SYNC_SPIN_US"); // read per call (a map lookup): harnesses switch it between runs
-    const long spinUs = spinOpt ? atol(spinOpt) : 2000L;
+    // An inference of the headline config is ~0.1 ms of stream time: a blocking wait (interrupt + wake-up of the host thread) can cost a tenth of
+    // that.  SNNHIP_SYNC_SPIN_US > 0 polls the stream for up to that many microseconds before blocking.  Default 0 (block at once): a library must
+    // not burn a host core per waiting thread unasked -- harnesses that want the polling wait opt in (bench.py times both).  The value is cached
+    // (set_option / first use), not looked up per call.
+    long spinUs = g_syncSpinUs.load(std::memory_order_relaxed);
+    if (spinUs < 0) {
+        const char* e = getenv("SNNHIP_SYNC_SPIN_US");
+        spinUs = e ? atol(e) : 0L;
+        if (spinUs < 0) spinUs = 0;
+        g_syncSpinUs.store(spinUs, std::memory_order_relaxed);
+    }
     if (spinUs > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
@@ -417,9 +536,9 @@ int snnhip_tensor_fill(snnhip_tensor* t, float value) {
     size_t n = t->count();
     unsigned blocks = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 4096));
     if (t->dtype == SNNHIP_F16)
-        hipLaunchKernelGGL(fill_half_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, reinterpret_cast<_Float16*>(t->data), n, value);
+        SNNHIP_LAUNCH(fill_half_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, reinterpret_cast<_Float16*>(t->data), n, value);
     else
-        hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, t->data, n, value);
+        SNNHIP_LAUNCH(fill_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, t->data, n, value);
     SNNHIP_CHECK_HIP(hipGetLastError());
     return SNNHIP_OK;
 }
@@ -508,11 +627,11 @@ int snnhip_plan_run_n(snnhip_plan* plan, const snnhip_tensor* const* inputs, int
     if (plan->profiling && !plan->profilesItself()) {
         int rc = plan->profBegin(0);
         if (rc != SNNHIP_OK) return rc;
-        rc = plan->run(inputs, n_in, out);
+        rc = plan->invoke(inputs, n_in, out);
         if (rc != SNNHIP_OK) return rc;
         return plan->profEnd(0);
     }
-    return plan->run(inputs, n_in, out);
+    return plan->invoke(inputs, n_in, out);
 }
 
 int snnhip_plan_num_steps(const snnhip_plan* plan) { return plan ? plan->numSteps() : 0; }
@@ -578,6 +697,102 @@ int snnhip_plan_cost(const snnhip_plan* plan, double* flops, double* bytes) {
 
 int snnhip_plan_destroy(snnhip_plan* plan) {
     delete plan;
+    return SNNHIP_OK;
+}
+
+/* ---- launch trace ---- */
+
+int snnhip_trace_begin(void) {
+    Tracer& t = tracer();
+    std::lock_guard<std::mutex> lock(t.m);
+    t.recs.clear();
+    t.scopes.clear();
+    t.used = 0;
+    g_traceOn.store(true);
+    return SNNHIP_OK;
+}
+
+int snnhip_trace_end(void) {
+    g_traceOn.store(false);
+    return SNNHIP_OK;
+}
+
+int snnhip_trace_report(char* buf, size_t buflen, size_t* needed) {
+    SNNHIP_REQUIRE(!g_traceOn.load(), "trace_report: call snnhip_trace_end first");
+    Tracer& t = tracer();
+    std::lock_guard<std::mutex> lock(t.m);
+    struct Inst {
+        std::string name;
+        long launches = 0;
+        double ms = 0, flops = 0, bytes = 0;
+        long mainLaunches = 0;
+        std::vector<std::string> plans;
+    };
+    std::map<const void*, Inst> insts;
+    std::vector<float> dur(t.recs.size(), 0.0f);
+    for (size_t i = 0; i < t.recs.size(); ++i) {
+        const TraceRec& r = t.recs[i];
+        if (!r.start) continue;
+        SNNHIP_CHECK_HIP(hipEventSynchronize(r.stop));
+        SNNHIP_CHECK_HIP(hipEventElapsedTime(&dur[i], r.start, r.stop));
+        Inst& in = insts[r.fn];
+        if (in.name.empty()) in.name = demangle(hipKernelNameRefByPtr(r.fn, r.stream));
+        ++in.launches;
+        in.ms += dur[i];
+    }
+    // a scope's algorithmic cost is booked on its longest launch (a convolution next to its split-K reduce pass, a dense layer next to its softmax)
+    std::vector<int> mainOf(t.scopes.size(), -1);
+    for (size_t i = 0; i < t.recs.size(); ++i) {
+        const int sc = t.recs[i].scope;
+        if (sc < 0 || !t.recs[i].start) continue;
+        if (mainOf[sc] < 0 || dur[i] > dur[mainOf[sc]]) mainOf[sc] = static_cast<int>(i);
+    }
+    for (size_t sc = 0; sc < t.scopes.size(); ++sc) {
+        if (mainOf[sc] < 0) continue;
+        Inst& in = insts[t.recs[mainOf[sc]].fn];
+        in.flops += t.scopes[sc].flops;
+        in.bytes += t.scopes[sc].bytes;
+        ++in.mainLaunches;
+        bool seen = false;
+        for (const auto& d : in.plans) seen = seen || d == t.scopes[sc].desc;
+        if (!seen && in.plans.size() < 64) in.plans.push_back(t.scopes[sc].desc);
+    }
+    std::map<std::string, std::vector<const Inst*>> byBase;
+    for (const auto& kv : insts) byBase[base_name(kv.second.name)].push_back(&kv.second);
+    std::string js = "{\"launches\": " + std::to_string(t.recs.size()) + ", \"kernels\": [";
+    bool firstK = true;
+    char num[256];
+    for (const auto& kv : byBase) {
+        long launches = 0, mainLaunches = 0;
+        double ms = 0, flops = 0, bytes = 0;
+        for (const Inst* in : kv.second) {
+            launches += in->launches;
+            mainLaunches += in->mainLaunches;
+            ms += in->ms;
+            flops += in->flops;
+            bytes += in->bytes;
+        }
+        snprintf(num, sizeof(num), "\"launches\": %ld, \"main_launches\": %ld, \"total_ms\": %.9g, \"flops\": %.9g, \"bytes\": %.9g", launches, mainLaunches, ms, flops, bytes);
+        js += std::string(firstK ? "" : ", ") + "{\"function\": \"" + json_escape(kv.first) + "\", " + num + ", \"instances\": [";
+        firstK = false;
+        bool firstI = true;
+        for (const Inst* in : kv.second) {
+            snprintf(num, sizeof(num), "\"launches\": %ld, \"main_launches\": %ld, \"total_ms\": %.9g, \"flops\": %.9g, \"bytes\": %.9g", in->launches, in->mainLaunches, in->ms,
+                     in->flops, in->bytes);
+            js += std::string(firstI ? "" : ", ") + "{\"name\": \"" + json_escape(in->name) + "\", " + num + ", \"plans\": [";
+            firstI = false;
+            for (size_t k = 0; k < in->plans.size(); ++k) js += std::string(k ? ", " : "") + "\"" + json_escape(in->plans[k]) + "\"";
+            js += "]}";
+        }
+        js += "]}";
+    }
+    js += "]}";
+    if (needed) *needed = js.size() + 1;
+    if (buf && buflen > 0) {
+        const size_t n = js.size() < buflen - 1 ? js.size() : buflen - 1;
+        memcpy(buf, js.data(), n);
+        buf[n] = 0;
+    }
     return SNNHIP_OK;
 }
 

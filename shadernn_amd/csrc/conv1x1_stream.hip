@@ -372,7 +372,7 @@ struct Conv1x1StreamPlan : ConvPlanBase {
                            g.OC);
             q.res = r->data;
         }
-        hipLaunchKernelGGL(kernel, grid, dim3(64 * waves), ldsBytes, ctx->stream, q, ac, static_cast<const float*>(x->data), reinterpret_cast<const float4*>(d_w),
+        SNNHIP_LAUNCH(kernel, grid, dim3(64 * waves), ldsBytes, ctx->stream, q, ac, static_cast<const float*>(x->data), reinterpret_cast<const float4*>(d_w),
                            reinterpret_cast<const float4*>(d_epi), out->data);
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;

@@ -160,7 +160,7 @@ struct GenericConvPlan : ConvPlanBase {
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
                        out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
         dim3 grid(p.tilesX * up_div(p.OH, TILE_H), p.ocBlocks, p.N);
-        hipLaunchKernelGGL(conv2d_generic_kernel, grid, dim3(256), ldsBytes, ctx->stream, p, x->data, d_w, reinterpret_cast<const float4*>(d_epi),
+        SNNHIP_LAUNCH(conv2d_generic_kernel, grid, dim3(256), ldsBytes, ctx->stream, p, x->data, d_w, reinterpret_cast<const float4*>(d_epi),
                            out->data);
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;

@@ -67,12 +67,12 @@ int launch_splitk_reduce(snnhip_ctx* ctx, int OC, int splitK, int useBN, const A
     if (out->dtype == SNNHIP_F16) {
         _Float16* yo = reinterpret_cast<_Float16*>(out->data);
         const _Float16* rr = res ? reinterpret_cast<const _Float16*>(res->data) : nullptr;
-        if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, _Float16>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, yo, rr, ac2);
-        else hipLaunchKernelGGL((splitk_reduce_kernel<false, _Float16>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, yo, rr, ac2);
+        if (simple) SNNHIP_LAUNCH((splitk_reduce_kernel<true, _Float16>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, yo, rr, ac2);
+        else SNNHIP_LAUNCH((splitk_reduce_kernel<false, _Float16>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, yo, rr, ac2);
     } else {
         const float* rr = res ? res->data : nullptr;
-        if (simple) hipLaunchKernelGGL((splitk_reduce_kernel<true, float>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, out->data, rr, ac2);
-        else hipLaunchKernelGGL((splitk_reduce_kernel<false, float>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, out->data, rr, ac2);
+        if (simple) SNNHIP_LAUNCH((splitk_reduce_kernel<true, float>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, out->data, rr, ac2);
+        else SNNHIP_LAUNCH((splitk_reduce_kernel<false, float>), gr, dim3(256), 0, ctx->stream, MN, OC, splitK, useBN, ac, ws, e4, out->data, rr, ac2);
     }
     SNNHIP_CHECK_HIP(hipGetLastError());
     return SNNHIP_OK;
@@ -127,7 +127,7 @@ struct MfmaConvPlan : ConvPlanBase {
                        x->n, x->h, x->w, x->c, p.N, p.srcH, p.srcW, p.IC);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
                        out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
-        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, static_cast<const void*>(x->data), static_cast<const void*>(d_w),
+        SNNHIP_LAUNCH(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, static_cast<const void*>(x->data), static_cast<const void*>(d_w),
                            reinterpret_cast<const float4*>(d_epi), static_cast<void*>(out->data), d_ws);
         if (p.splitK > 1)
             return launch_splitk_reduce(ctx, p.OC, p.splitK, p.useBN, ac, d_ws, reinterpret_cast<const float4*>(d_epi), out, fusedAdd ? in[1] : nullptr, p.ac2);

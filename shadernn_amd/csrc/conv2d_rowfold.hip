@@ -211,7 +211,7 @@ struct RowfoldPlan : ConvPlanBase {
                        x->w, x->c, p.N, p.srcH, p.srcW, p.IC);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n,
                        out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
-        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
+        SNNHIP_LAUNCH(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
                            reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;

@@ -439,6 +439,12 @@ struct S2marchPlan : ConvPlanBase {
         desc += " +tile-stats";
         return true;
     }
+    bool tileStatsNeedKernelFold() const override { return true; }
+    void disableTileStats() override {
+        statPart = p.statRec = nullptr; // (the buffer stays with the plan's allocations)
+        const size_t at = desc.rfind(" +tile-stats");
+        if (at != std::string::npos) desc.erase(at);
+    }
     bool enableNormFold(const NormFoldTarget& t) override {
         if (!statPart || p.fold.counter) return false;
         void* buf = nullptr;
@@ -460,7 +466,7 @@ struct S2marchPlan : ConvPlanBase {
                        x->w, x->c, p.N, p.srcH, p.srcW, p.IC);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n,
                        out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
-        hipLaunchKernelGGL(kernel, grid, dim3(512), ldsBytes, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
+        SNNHIP_LAUNCH(kernel, grid, dim3(512), ldsBytes, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
                            reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;

@@ -210,10 +210,10 @@ struct StemConvPlan : ConvPlanBase {
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC && out->dtype == SNNHIP_F16,
                        "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
         if (simple)
-            hipLaunchKernelGGL(conv2d_stem_kernel<true>, grid, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data),
+            SNNHIP_LAUNCH(conv2d_stem_kernel<true>, grid, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data),
                                reinterpret_cast<const float4*>(d_w), reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
         else
-            hipLaunchKernelGGL(conv2d_stem_kernel<false>, grid, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data),
+            SNNHIP_LAUNCH(conv2d_stem_kernel<false>, grid, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data),
                                reinterpret_cast<const float4*>(d_w), reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;

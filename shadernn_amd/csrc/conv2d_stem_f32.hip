@@ -350,7 +350,7 @@ struct Stem32Plan : ConvPlanBase {
         const int eoh = p.poolOH ? p.poolOH : p.OH, eow = p.poolOH ? p.poolOW : p.OW;
         SNNHIP_REQUIRE(out->n == p.N && out->h == eoh && out->w == eow && out->c == p.OC && out->dtype == SNNHIP_F32, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d",
                        out->n, out->h, out->w, out->c, p.N, eoh, eow, p.OC);
-        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, x->data, d_w, reinterpret_cast<const float4*>(d_epi), out->data);
+        SNNHIP_LAUNCH(kernel, grid, dim3(256), ldsBytes, ctx->stream, p, ac, x->data, d_w, reinterpret_cast<const float4*>(d_epi), out->data);
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -517,9 +517,12 @@ int make_conv2d_stem32_pool_plan(snnhip_ctx* ctx, snnhip_plan* stemPlan, snnhip_
     plan->dtype = SNNHIP_F32;
     plan->flops = stemPlan->flops + poolPlan->flops;
     plan->bytes = stemPlan->bytes + poolPlan->bytes; // unfused accounting of the two layers it replaces
-    char buf[320];
+    // what the one launch moves: the image, the pooled tensor, the weights (the stem's output never reaches memory)
+    plan->kernelBytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(plan->outDims[0]) * plan->outDims[1] * plan->outDims[2] * plan->outDims[3] +
+                               static_cast<double>(g.OC) * g.IC * 49);
+    char buf[384];
     snprintf(buf, sizeof(buf), "conv2d_mfma_stem_f32_32x32x2 k=7x7 s=2 ic=3 oc=%d tile=16x32px x 32oc (dense (tap, channel) K: 74 MFMAs per row tile, weights in registers) "
-             "+maxpool3x3/2 in the epilogue (7x15 pooled px per block) lds=%zuB", g.OC, lds);
+             "+maxpool3x3/2 in the epilogue (7x15 pooled px per block) lds=%zuB hbm_bytes=%.6g", g.OC, lds, plan->kernelBytes);
     plan->desc = buf;
     *out = plan;
     return SNNHIP_OK;

@@ -209,11 +209,11 @@ struct ThinConvPlan : ConvPlanBase {
         const float4* e4 = reinterpret_cast<const float4*>(d_epi);
         const bool simple = act_is_simple(ac.act);
         if (dtype == SNNHIP_F16) {
-            if (simple) hipLaunchKernelGGL((conv2d_thin_kernel<true, true>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
-            else hipLaunchKernelGGL((conv2d_thin_kernel<false, true>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
+            if (simple) SNNHIP_LAUNCH((conv2d_thin_kernel<true, true>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
+            else SNNHIP_LAUNCH((conv2d_thin_kernel<false, true>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
         } else {
-            if (simple) hipLaunchKernelGGL((conv2d_thin_kernel<true, false>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
-            else hipLaunchKernelGGL((conv2d_thin_kernel<false, false>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
+            if (simple) SNNHIP_LAUNCH((conv2d_thin_kernel<true, false>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
+            else SNNHIP_LAUNCH((conv2d_thin_kernel<false, false>), grid, dim3(64 * waves), ldsBytes, ctx->stream, p, ac, xv, wv, e4, yv);
         }
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;

@@ -509,7 +509,7 @@ struct WideConvPlan : ConvPlanBase {
                        "conv2d: input dims %dx%dx%dx%d (dtype %d) != plan %dx%dx%dx%d fp16", x->n, x->h, x->w, x->c, x->dtype, p.N, p.srcH, p.srcW, p.IC);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC && out->dtype == SNNHIP_F16,
                        "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
-        hipLaunchKernelGGL(kernel, grid, dim3(256), ldsBytes, ctx->stream, q, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
+        SNNHIP_LAUNCH(kernel, grid, dim3(256), ldsBytes, ctx->stream, q, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
                            reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;

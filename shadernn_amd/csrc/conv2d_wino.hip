@@ -336,11 +336,11 @@ struct WinoConvPlan : ConvPlanBase {
         const float4* u4 = reinterpret_cast<const float4*>(d_u);
         const float4* e4 = reinterpret_cast<const float4*>(d_epi);
         if (opb == 2) {
-            if (simple) hipLaunchKernelGGL((conv2d_wino_kernel<true, 2>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
-            else hipLaunchKernelGGL((conv2d_wino_kernel<false, 2>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+            if (simple) SNNHIP_LAUNCH((conv2d_wino_kernel<true, 2>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+            else SNNHIP_LAUNCH((conv2d_wino_kernel<false, 2>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
         } else {
-            if (simple) hipLaunchKernelGGL((conv2d_wino_kernel<true, 1>), grid, dim3(256), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
-            else hipLaunchKernelGGL((conv2d_wino_kernel<false, 1>), grid, dim3(256), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+            if (simple) SNNHIP_LAUNCH((conv2d_wino_kernel<true, 1>), grid, dim3(256), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+            else SNNHIP_LAUNCH((conv2d_wino_kernel<false, 1>), grid, dim3(256), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
         }
         SNNHIP_CHECK_HIP(hipGetLastError());
         if (p.splitK > 1) return launch_splitk_reduce(ctx, p.OC, p.splitK, p.useBN, ac, d_ws, e4, out, fusedAdd ? in[1] : nullptr, p.ac2);

@@ -107,17 +107,19 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(int In, int Out, int ba
     const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
     // staging: thread t copies float4 (row t / 16, column 4 (t % 16)) and the same column of row 16 + t / 16, of both tiles
     const int srow = tid >> 4, scol = (tid & 15) * 4;
-    const float* wsrc0 = w + static_cast<size_t>(min(o0 + srow, Out - 1)) * In + scol;
-    const float* wsrc1 = w + static_cast<size_t>(min(o0 + srow + 16, Out - 1)) * In + scol;
-    const float* xsrc0 = x + static_cast<size_t>(min(b0 + srow, batch - 1)) * In + scol;
-    const float* xsrc1 = x + static_cast<size_t>(min(b0 + srow + 16, batch - 1)) * In + scol;
+    // row starts WITHOUT the column: a thread whose column lies past the row (In < 64, or the last chunk) falls back to column 0 of its row, an
+    // address inside the allocation whatever In is (with the column in the pointer the fallback read up to 220 bytes past the last row)
+    const float* wsrc0 = w + static_cast<size_t>(min(o0 + srow, Out - 1)) * In;
+    const float* wsrc1 = w + static_cast<size_t>(min(o0 + srow + 16, Out - 1)) * In;
+    const float* xsrc0 = x + static_cast<size_t>(min(b0 + srow, batch - 1)) * In;
+    const float* xsrc1 = x + static_cast<size_t>(min(b0 + srow + 16, batch - 1)) * In;
     float4 pw0, pw1, px0, px1;
     // (In % 8 == 0, scol % 4 == 0: a float4 is inside the row or past it; rows past Out / batch repeat the last one and are not stored.  A macro: a lambda
     // that captures the four registers by reference puts them in scratch)
 #define DENSE_FETCH(k0_)                                                                   \
     do {                                                                                   \
         const bool in_ = (k0_) + scol < In;                                                \
-        const int kk_ = in_ ? (k0_) : 0; /* unconditional loads: a select between a load and a constant took the constant's ADDRESS (scratch) */ \
+        const int kk_ = in_ ? (k0_) + scol : 0; /* unconditional loads: a select between a load and a constant took the constant's ADDRESS (scratch) */ \
         pw0 = *reinterpret_cast<const float4*>(wsrc0 + kk_);                               \
         pw1 = *reinterpret_cast<const float4*>(wsrc1 + kk_);                               \
         px0 = *reinterpret_cast<const float4*>(xsrc0 + kk_);                               \
@@ -224,13 +226,13 @@ struct DensePlan : snnhip_plan {
             const _Float16* xh = reinterpret_cast<const _Float16*>(x->data);
 #define SNNHIP_DENSE(V, TXX, XP)                                                                                                                          \
     do {                                                                                                                                             \
-        if (gb == 16) hipLaunchKernelGGL((dense_kernel<V, TXX, 16>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky, XP, d_w, d_b, rows); \
-        else hipLaunchKernelGGL((dense_kernel<V, TXX, 4>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky, XP, d_w, d_b, rows);           \
+        if (gb == 16) SNNHIP_LAUNCH((dense_kernel<V, TXX, 16>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky, XP, d_w, d_b, rows); \
+        else SNNHIP_LAUNCH((dense_kernel<V, TXX, 4>), grid, dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky, XP, d_w, d_b, rows);           \
     } while (0)
             if (vec) SNNHIP_DENSE(true, _Float16, xh);
             else SNNHIP_DENSE(false, _Float16, xh);
         } else if (useMfma) {
-            hipLaunchKernelGGL(dense_mfma_kernel, dim3(up_div(d.out_units, 32), up_div(d.batch, 32)), dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky,
+            SNNHIP_LAUNCH(dense_mfma_kernel, dim3(up_div(d.out_units, 32), up_div(d.batch, 32)), dim3(256), 0, ctx->stream, d.in_units, d.out_units, d.batch, d.act, d.leaky,
                                x->data, d_w, d_b, rows);
         } else {
             if (vec) SNNHIP_DENSE(true, float, x->data);
@@ -239,12 +241,12 @@ struct DensePlan : snnhip_plan {
 #undef SNNHIP_DENSE
         SNNHIP_CHECK_HIP(hipGetLastError());
         if (d.act == SNNHIP_DENSE_SOFTMAX) {
-            hipLaunchKernelGGL(softmax_rows_kernel, dim3(d.batch), dim3(256), 0, ctx->stream, d.out_units, rows);
+            SNNHIP_LAUNCH(softmax_rows_kernel, dim3(d.batch), dim3(256), 0, ctx->stream, d.out_units, rows);
             SNNHIP_CHECK_HIP(hipGetLastError());
         }
         if (half) {
             const size_t n = static_cast<size_t>(d.batch) * d.out_units;
-            hipLaunchKernelGGL(convert_rows_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, n, rows,
+            SNNHIP_LAUNCH(convert_rows_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, n, rows,
                                reinterpret_cast<_Float16*>(out->data));
             SNNHIP_CHECK_HIP(hipGetLastError());
         }
@@ -285,7 +287,7 @@ struct SubpixelPlan : SubpixelPlanBase {
         const size_t cap = static_cast<size_t>(ctx->props.multiProcessorCount) * 16;
         if (blocks > cap) blocks = cap;
         if (blocks == 0) return SNNHIP_OK;
-        SNNHIP_WITH_T(out->dtype, hipLaunchKernelGGL((subpixel_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d.N, d.H, d.W,
+        SNNHIP_WITH_T(out->dtype, SNNHIP_LAUNCH((subpixel_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, ctx->stream, d.N, d.H, d.W,
                                                      d.C, d.factor, d.mode, cptr<T>(x), mptr<T>(out)););
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;

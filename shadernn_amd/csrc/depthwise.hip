@@ -192,7 +192,7 @@ struct DepthwisePlan : ConvPlanBase {
             const bool simple = act_is_simple(p.act);
             const bool small = total4 + static_cast<size_t>(blocks4) * 256 < 0x7fffffffull; // idx + stride never wraps 32 bits
 #define SNNHIP_DW_(ST, SI, TT, IX, RW)                                                                                                             \
-    hipLaunchKernelGGL((depthwise3x3_strip_kernel<ST, SI, TT, IX, RW>), g4, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const TT*>(x->data), d_w, e4, \
+    SNNHIP_LAUNCH((depthwise3x3_strip_kernel<ST, SI, TT, IX, RW>), g4, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const TT*>(x->data), d_w, e4, \
                        reinterpret_cast<TT*>(out->data))
 #define SNNHIP_DW(ST, SI, TT)                                \
     do {                                                     \
@@ -222,7 +222,7 @@ struct DepthwisePlan : ConvPlanBase {
         if (blocks == 0) return SNNHIP_OK;
         const dim3 gg(static_cast<unsigned>(blocks));
         const float4* e4 = reinterpret_cast<const float4*>(d_epi);
-#define SNNHIP_DWG(V, TT) hipLaunchKernelGGL((depthwise_kernel<V, TT>), gg, dim3(256), 0, ctx->stream, p, reinterpret_cast<const TT*>(x->data), d_w, e4, reinterpret_cast<TT*>(out->data))
+#define SNNHIP_DWG(V, TT) SNNHIP_LAUNCH((depthwise_kernel<V, TT>), gg, dim3(256), 0, ctx->stream, p, reinterpret_cast<const TT*>(x->data), d_w, e4, reinterpret_cast<TT*>(out->data))
         if (dtype == SNNHIP_F16) {
             if (vec) SNNHIP_DWG(true, _Float16); else SNNHIP_DWG(false, _Float16);
         } else {

@@ -523,9 +523,9 @@ struct EltwisePlan : EltwisePlanBase {
             SNNHIP_REQUIRE(dims_match(out, d.N, d.H, d.W, d.C), "%s: output dims mismatch", desc.c_str());
             const unsigned gg = grid_for(ctx, out->count() / (v4 ? 4 : 1));
             SNNHIP_WITH_T(out->dtype,
-                if (v4) hipLaunchKernelGGL((add_ragged_kernel<4, T>), dim3(gg), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, in[0]->h, in[0]->w, in[1]->h,
+                if (v4) SNNHIP_LAUNCH((add_ragged_kernel<4, T>), dim3(gg), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, in[0]->h, in[0]->w, in[1]->h,
                                            in[1]->w, d.act, d.leaky, cptr<T>(in[0]), cptr<T>(in[1]), mptr<T>(out));
-                else hipLaunchKernelGGL((add_ragged_kernel<1, T>), dim3(gg), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, in[0]->h, in[0]->w, in[1]->h,
+                else SNNHIP_LAUNCH((add_ragged_kernel<1, T>), dim3(gg), dim3(256), 0, ctx->stream, d.N, d.H, d.W, d.C, in[0]->h, in[0]->w, in[1]->h,
                                         in[1]->w, d.act, d.leaky, cptr<T>(in[0]), cptr<T>(in[1]), mptr<T>(out)););
             SNNHIP_CHECK_HIP(hipGetLastError());
             return SNNHIP_OK;
@@ -541,9 +541,9 @@ struct EltwisePlan : EltwisePlanBase {
         const float4* tab = reinterpret_cast<const float4*>(d_tab);
 #define SNNHIP_ELT(M)                                                                                                                            \
     SNNHIP_WITH_T(out->dtype, const T* bb = M == 0 ? cptr<T>(in[1]) : nullptr;                                                                   \
-                  if (v4) hipLaunchKernelGGL((eltwise_kernel<M, 4, T>), dim3(g), dim3(256), 0, ctx->stream, count, d.C, d.act, d.leaky, cptr<T>(in[0]), bb, \
+                  if (v4) SNNHIP_LAUNCH((eltwise_kernel<M, 4, T>), dim3(g), dim3(256), 0, ctx->stream, count, d.C, d.act, d.leaky, cptr<T>(in[0]), bb, \
                                              tab, mptr<T>(out));                                                                                 \
-                  else hipLaunchKernelGGL((eltwise_kernel<M, 1, T>), dim3(g), dim3(256), 0, ctx->stream, count, d.C, d.act, d.leaky, cptr<T>(in[0]), bb, tab, \
+                  else SNNHIP_LAUNCH((eltwise_kernel<M, 1, T>), dim3(g), dim3(256), 0, ctx->stream, count, d.C, d.act, d.leaky, cptr<T>(in[0]), bb, tab, \
                                           mptr<T>(out));)
         if (mode == 0) {
             SNNHIP_ELT(0);
@@ -596,15 +596,15 @@ struct PoolPlan : snnhip_plan {
         const bool vec = (d.C & 3) == 0;
         if (vec && d.type == SNNHIP_POOL_AVG && d.OH == 1 && d.OW == 1 && d.padT == 0 && d.padL == 0 && d.kh >= d.H && d.kw >= d.W && d.H * d.W >= 16) {
             const size_t outs = static_cast<size_t>(d.N) * (d.C >> 2);
-            SNNHIP_WITH_T(out->dtype, hipLaunchKernelGGL((global_avgpool_kernel<T>), dim3(static_cast<unsigned>((outs + 15) / 16)), dim3(256), 0, ctx->stream, d.N,
+            SNNHIP_WITH_T(out->dtype, SNNHIP_LAUNCH((global_avgpool_kernel<T>), dim3(static_cast<unsigned>((outs + 15) / 16)), dim3(256), 0, ctx->stream, d.N,
                                                          d.H * d.W, d.C, cptr<T>(in[0]), mptr<T>(out)););
             SNNHIP_CHECK_HIP(hipGetLastError());
             return SNNHIP_OK;
         }
         const unsigned g = grid_for(ctx, out->count() / (vec ? 4 : 1));
 #define SNNHIP_POOL(TY)                                                                                                                   \
-    SNNHIP_WITH_T(out->dtype, if (vec) hipLaunchKernelGGL((pool2d_kernel<TY, 4, T>), dim3(g), dim3(256), 0, ctx->stream, d, cptr<T>(in[0]), mptr<T>(out)); \
-                  else hipLaunchKernelGGL((pool2d_kernel<TY, 1, T>), dim3(g), dim3(256), 0, ctx->stream, d, cptr<T>(in[0]), mptr<T>(out));)
+    SNNHIP_WITH_T(out->dtype, if (vec) SNNHIP_LAUNCH((pool2d_kernel<TY, 4, T>), dim3(g), dim3(256), 0, ctx->stream, d, cptr<T>(in[0]), mptr<T>(out)); \
+                  else SNNHIP_LAUNCH((pool2d_kernel<TY, 1, T>), dim3(g), dim3(256), 0, ctx->stream, d, cptr<T>(in[0]), mptr<T>(out));)
         if (d.type == SNNHIP_POOL_MAX) {
             SNNHIP_POOL(SNNHIP_POOL_MAX);
         } else {
@@ -623,8 +623,8 @@ struct PadPlan : PadPlanBase {
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, OH, OW, d.C), "pad: tensor dims do not match the plan");
         const bool vec = (d.C & 3) == 0;
         const unsigned g = grid_for(ctx, out->count() / (vec ? 4 : 1));
-        SNNHIP_WITH_T(out->dtype, if (vec) hipLaunchKernelGGL((pad_kernel<4, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, cptr<T>(in[0]), mptr<T>(out));
-                      else hipLaunchKernelGGL((pad_kernel<1, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, cptr<T>(in[0]), mptr<T>(out)););
+        SNNHIP_WITH_T(out->dtype, if (vec) SNNHIP_LAUNCH((pad_kernel<4, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, cptr<T>(in[0]), mptr<T>(out));
+                      else SNNHIP_LAUNCH((pad_kernel<1, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, cptr<T>(in[0]), mptr<T>(out)););
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -640,8 +640,8 @@ struct UpsamplePlan : UpsamplePlanBase {
         const float inv = 1.0f / d.scale; // upsampling2dVulkan.cpp:101
 #define SNNHIP_UP(M)                                                                                                                          \
     SNNHIP_WITH_T(out->dtype,                                                                                                                 \
-                  if (vec) hipLaunchKernelGGL((upsample_kernel<M, 4, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, inv, cptr<T>(in[0]), mptr<T>(out)); \
-                  else hipLaunchKernelGGL((upsample_kernel<M, 1, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, inv, cptr<T>(in[0]), mptr<T>(out));)
+                  if (vec) SNNHIP_LAUNCH((upsample_kernel<M, 4, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, inv, cptr<T>(in[0]), mptr<T>(out)); \
+                  else SNNHIP_LAUNCH((upsample_kernel<M, 1, T>), dim3(g), dim3(256), 0, ctx->stream, d, OH, OW, inv, cptr<T>(in[0]), mptr<T>(out));)
         if (d.mode == SNNHIP_UPSAMPLE_NEAREST) {
             SNNHIP_UP(SNNHIP_UPSAMPLE_NEAREST);
         } else {
@@ -687,27 +687,46 @@ struct InstanceNormPlan : snnhip_plan {
         const dim3 gf(static_cast<unsigned>(NC)); // one block per (image, channel)
         const float invHW = 1.0f / (static_cast<float>(d.H) * static_cast<float>(d.W));
 #define SNNHIP_IN(ST, CVV)                                                                                                                                     \
-    hipLaunchKernelGGL((instancenorm_kernel<ST, CVV, T>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta, d_part, \
+    SNNHIP_LAUNCH((instancenorm_kernel<ST, CVV, T>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta, d_part, \
                        mptr<T>(out), ST == 2 ? ra : InResidual())
 #define SNNHIP_FOLD() \
-    hipLaunchKernelGGL(instancenorm_fold_kernel<T>, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, cptr<T>(in[0]), d_part, d_gamma, d_beta, d_mean, d_mul)
+    SNNHIP_LAUNCH(instancenorm_fold_kernel<T>, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, cptr<T>(in[0]), d_part, d_gamma, d_beta, d_mean, d_mul)
         const bool sweep = !(tiles && tiles->part);
+        // launch trace: each pass under its own scope with the bytes that pass has to move (the statistics sweep reads the tensor once, the
+        // normalise sweep reads it [and the residual] once and writes it once; the folds move a few KB)
+        const double tensorBytes = static_cast<double>(d.N) * d.H * d.W * d.C * (out->dtype == SNNHIP_F16 ? 2.0 : 4.0);
+        const double resBytes = res ? static_cast<double>(res->n) * res->h * res->w * res->c * (out->dtype == SNNHIP_F16 ? 2.0 : 4.0) : 0.0;
         if (!sweep && !tiles->folded) {
+            TraceScope ts(desc + " [fold of tile statistics]", 0.0, 0.0);
             const int rc = foldTiles(*tiles);
             if (rc != SNNHIP_OK) return rc;
         }
         SNNHIP_WITH_T(out->dtype, if ((d.C & 3) == 0) {
             if (sweep) {
-                SNNHIP_IN(0, 4);
+                {
+                    TraceScope ts(desc + " [statistics sweep]", 2.0 * tensorBytes / (out->dtype == SNNHIP_F16 ? 2.0 : 4.0), tensorBytes);
+                    SNNHIP_IN(0, 4);
+                }
+                TraceScope ts(desc + " [fold]", 0.0, 0.0);
                 SNNHIP_FOLD();
             }
-            if (!statsOnly) SNNHIP_IN(2, 4);
+            if (!statsOnly) {
+                TraceScope ts(desc + " [normalise sweep]", 2.0 * tensorBytes / (out->dtype == SNNHIP_F16 ? 2.0 : 4.0), 2.0 * tensorBytes + resBytes);
+                SNNHIP_IN(2, 4);
+            }
         } else {
             if (sweep) {
-                SNNHIP_IN(0, 1);
+                {
+                    TraceScope ts(desc + " [statistics sweep]", 2.0 * tensorBytes / (out->dtype == SNNHIP_F16 ? 2.0 : 4.0), tensorBytes);
+                    SNNHIP_IN(0, 1);
+                }
+                TraceScope ts(desc + " [fold]", 0.0, 0.0);
                 SNNHIP_FOLD();
             }
-            if (!statsOnly) SNNHIP_IN(2, 1);
+            if (!statsOnly) {
+                TraceScope ts(desc + " [normalise sweep]", 2.0 * tensorBytes / (out->dtype == SNNHIP_F16 ? 2.0 : 4.0), 2.0 * tensorBytes + resBytes);
+                SNNHIP_IN(2, 1);
+            }
         });
 #undef SNNHIP_IN
 #undef SNNHIP_FOLD
@@ -826,9 +845,9 @@ int InstanceNormPlan::foldTiles(const TileStatsRef& t) {
     const int tiles = t.tilesX * t.tilesY, chunks = (tiles + kFoldChunk - 1) / kFoldChunk;
     const size_t need = static_cast<size_t>(d.N) * chunks * 3 * d.C;
     SNNHIP_REQUIRE(foldScratchCount >= need, "instancenorm: fold scratch not reserved for a %d x %d tile grid (instancenorm_reserve_tile_stats)", t.tilesX, t.tilesY);
-    hipLaunchKernelGGL(instancenorm_fold_tiles1_kernel, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, d.H, d.W,
+    SNNHIP_LAUNCH(instancenorm_fold_tiles1_kernel, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, d.H, d.W,
                        t.tilesX, t.tilesY, t.TH, t.TW, t.part, d_foldScratch);
-    hipLaunchKernelGGL(instancenorm_fold_tiles2_kernel, dim3(static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, chunks, d.eps, d_foldScratch, d_gamma, d_beta,
+    SNNHIP_LAUNCH(instancenorm_fold_tiles2_kernel, dim3(static_cast<unsigned>(d.N)), dim3(256), 0, ctx->stream, d.C, chunks, d.eps, d_foldScratch, d_gamma, d_beta,
                        d_mean, d_mul);
     SNNHIP_CHECK_HIP(hipGetLastError());
     return SNNHIP_OK;

@@ -343,7 +343,7 @@ int espcn_stream_launch(hipStream_t stream, const void* step, const float* x, co
                         const float* w3r, const float* ep3, float* y) {
     const StreamStep& s = *static_cast<const StreamStep*>(step);
     dim3 grid(up_div(s.sp.numStrips * s.sp.numSegs * s.sp.N, WPB));
-#define SNNHIP_LAUNCH_S(K, S) hipLaunchKernelGGL((espcn_stream_kernel<K, S>), grid, dim3(64 * WPB), 0, stream, s.sp, x, wA1, ep1, wA2, ep2, w3r, ep3, y)
+#define SNNHIP_LAUNCH_S(K, S) SNNHIP_LAUNCH((espcn_stream_kernel<K, S>), grid, dim3(64 * WPB), 0, stream, s.sp, x, wA1, ep1, wA2, ep2, w3r, ep3, y)
     if (s.k1 == 5) {
         if (s.simple) SNNHIP_LAUNCH_S(5, true); else SNNHIP_LAUNCH_S(5, false);
     } else {

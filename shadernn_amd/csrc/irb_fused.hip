@@ -394,7 +394,7 @@ struct IrbPlan : snnhip_plan {
                            p.N, p.H, p.W, p.C);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.Co, "irb: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n,
                        out->h, out->w, out->c, p.N, p.OH, p.OW, p.Co);
-        hipLaunchKernelGGL(kernel, grid, dim3(static_cast<unsigned>(threads)), ldsBytes, ctx->stream, p, x->data, reinterpret_cast<const float4*>(d_we),
+        SNNHIP_LAUNCH(kernel, grid, dim3(static_cast<unsigned>(threads)), ldsBytes, ctx->stream, p, x->data, reinterpret_cast<const float4*>(d_we),
                            reinterpret_cast<const float4*>(d_wp), reinterpret_cast<const float4*>(d_e3), out->data);
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
@@ -630,6 +630,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     plan->bytes = (ce ? ce->bytes : 0.0) + (cs ? cs->bytes : 0.0) + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
     const double inElems = cs ? static_cast<double>(p.N) * p.IH * p.IW * 3 : static_cast<double>(p.N) * p.H * p.W * C;
     const double fusedBytes = 4.0 * (inElems + static_cast<double>(p.N) * p.OH * p.OW * Co + static_cast<double>(Ch) * (C + Co + 9));
+    plan->kernelBytes = fusedBytes;
     char buf[320];
     char head[64];
     if (cs) snprintf(head, sizeof(head), "stem conv3x3 s%d 3->%d + depthwise3x3 s%d", p.stemS, Ch, s);

@@ -252,8 +252,8 @@ struct ConcatPlan : snnhip_plan {
         const bool vec = ((d.C0 | d.C1 | d.OC) & 3) == 0 && d.OC <= d.C0 + d.C1;
         const unsigned g = grid_for(ctx, pixels * ((d.OC + 3) / 4));
         SNNHIP_WITH_T(out->dtype,
-                      if (vec) hipLaunchKernelGGL((concat_kernel<true, T>), dim3(g), dim3(256), 0, ctx->stream, pixels, d.C0, d.C1, d.OC, cptr<T>(in[0]), cptr<T>(in[1]), mptr<T>(out));
-                      else hipLaunchKernelGGL((concat_kernel<false, T>), dim3(g), dim3(256), 0, ctx->stream, pixels, d.C0, d.C1, d.OC, cptr<T>(in[0]), cptr<T>(in[1]), mptr<T>(out)););
+                      if (vec) SNNHIP_LAUNCH((concat_kernel<true, T>), dim3(g), dim3(256), 0, ctx->stream, pixels, d.C0, d.C1, d.OC, cptr<T>(in[0]), cptr<T>(in[1]), mptr<T>(out));
+                      else SNNHIP_LAUNCH((concat_kernel<false, T>), dim3(g), dim3(256), 0, ctx->stream, pixels, d.C0, d.C1, d.OC, cptr<T>(in[0]), cptr<T>(in[1]), mptr<T>(out)););
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -268,8 +268,8 @@ struct UnaryPlan : snnhip_plan {
         const size_t count = out->count();
         const bool vec = (d.C & 3) == 0;
         const unsigned g = grid_for(ctx, vec ? count / 4 : count);
-        SNNHIP_WITH_T(out->dtype, if (vec) hipLaunchKernelGGL((unary_kernel<4, T>), dim3(g), dim3(256), 0, ctx->stream, count, d.op, d.value, cptr<T>(in[0]), mptr<T>(out));
-                      else hipLaunchKernelGGL((unary_kernel<1, T>), dim3(g), dim3(256), 0, ctx->stream, count, d.op, d.value, cptr<T>(in[0]), mptr<T>(out)););
+        SNNHIP_WITH_T(out->dtype, if (vec) SNNHIP_LAUNCH((unary_kernel<4, T>), dim3(g), dim3(256), 0, ctx->stream, count, d.op, d.value, cptr<T>(in[0]), mptr<T>(out));
+                      else SNNHIP_LAUNCH((unary_kernel<1, T>), dim3(g), dim3(256), 0, ctx->stream, count, d.op, d.value, cptr<T>(in[0]), mptr<T>(out)););
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -283,7 +283,7 @@ struct CalculatePlan : snnhip_plan {
         SNNHIP_REQUIRE(dims_match(in[0], d.N, d.H, d.W, d.C) && dims_match(out, d.N, d.H, d.W, d.OC), "calculate: tensor dims do not match the plan");
         const size_t pixels = static_cast<size_t>(d.N) * d.H * d.W;
         const unsigned g = grid_for(ctx, pixels * d.OC);
-        SNNHIP_WITH_T(out->dtype, hipLaunchKernelGGL((calculate_kernel<T>), dim3(g), dim3(256), 0, ctx->stream, pixels, d.C, d.OC, cptr<T>(in[0]), mptr<T>(out)););
+        SNNHIP_WITH_T(out->dtype, SNNHIP_LAUNCH((calculate_kernel<T>), dim3(g), dim3(256), 0, ctx->stream, pixels, d.C, d.OC, cptr<T>(in[0]), mptr<T>(out)););
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -297,8 +297,8 @@ struct ResizePlan : snnhip_plan {
         SNNHIP_REQUIRE(dims_match(in[0], a.N, a.H, a.W, a.C) && dims_match(out, a.N, a.OH, a.OW, a.C), "resize: tensor dims do not match the plan");
         const bool vec = (a.C & 3) == 0;
         const unsigned g = grid_for(ctx, out->count() / (vec ? 4 : 1));
-        SNNHIP_WITH_T(out->dtype, if (vec) hipLaunchKernelGGL((resize_kernel<4, T>), dim3(g), dim3(256), 0, ctx->stream, a, cptr<T>(in[0]), mptr<T>(out));
-                      else hipLaunchKernelGGL((resize_kernel<1, T>), dim3(g), dim3(256), 0, ctx->stream, a, cptr<T>(in[0]), mptr<T>(out)););
+        SNNHIP_WITH_T(out->dtype, if (vec) SNNHIP_LAUNCH((resize_kernel<4, T>), dim3(g), dim3(256), 0, ctx->stream, a, cptr<T>(in[0]), mptr<T>(out));
+                      else SNNHIP_LAUNCH((resize_kernel<1, T>), dim3(g), dim3(256), 0, ctx->stream, a, cptr<T>(in[0]), mptr<T>(out)););
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -315,7 +315,7 @@ struct ImageU8Plan : snnhip_plan {
         const float4 m = make_float4(d.means[0], d.means[1], d.means[2], d.means[3]), s = make_float4(d.norms[0], d.norms[1], d.norms[2], d.norms[3]);
         const unsigned g = grid_for(ctx, pixels);
         const unsigned char* src = reinterpret_cast<const unsigned char*>(in[0]->data);
-        SNNHIP_WITH_T(out->dtype, hipLaunchKernelGGL((image_u8_kernel<T>), dim3(g), dim3(256), 0, ctx->stream, pixels, d.src_channels, m, s, src, mptr<T>(out)););
+        SNNHIP_WITH_T(out->dtype, SNNHIP_LAUNCH((image_u8_kernel<T>), dim3(g), dim3(256), 0, ctx->stream, pixels, d.src_channels, m, s, src, mptr<T>(out)););
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }
@@ -331,7 +331,7 @@ struct DeconvPlan : snnhip_plan {
         SNNHIP_REQUIRE(dims_match(in[0], a.N, a.H, a.W, a.IC) && dims_match(out, a.N, a.OH, a.OW, a.OC), "deconv2d: tensor dims do not match the plan (%s)",
                        desc.c_str());
         const unsigned g = grid_for(ctx, static_cast<size_t>(a.N) * a.OH * a.OW * ((a.OC + 3) / 4));
-        SNNHIP_WITH_T(out->dtype, hipLaunchKernelGGL((deconv2d_kernel<T>), dim3(g), dim3(256), 0, ctx->stream, a, cptr<T>(in[0]), reinterpret_cast<const float4*>(d_w),
+        SNNHIP_WITH_T(out->dtype, SNNHIP_LAUNCH((deconv2d_kernel<T>), dim3(g), dim3(256), 0, ctx->stream, a, cptr<T>(in[0]), reinterpret_cast<const float4*>(d_w),
                                                      reinterpret_cast<const float4*>(d_epi), mptr<T>(out)););
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
@@ -488,9 +488,9 @@ int snnhip_tensor_argmax(const snnhip_tensor* t, int n, int* out_index) {
     SNNHIP_CHECK_HIP(hipMalloc(&d, sizeof(int)));
     const size_t per = t->count() / t->n;
     if (t->dtype == SNNHIP_F16)
-        hipLaunchKernelGGL((argmax_kernel<_Float16>), dim3(1), dim3(256), 0, t->ctx->stream, per, reinterpret_cast<const _Float16*>(t->data) + per * n, d);
+        SNNHIP_LAUNCH((argmax_kernel<_Float16>), dim3(1), dim3(256), 0, t->ctx->stream, per, reinterpret_cast<const _Float16*>(t->data) + per * n, d);
     else
-        hipLaunchKernelGGL((argmax_kernel<float>), dim3(1), dim3(256), 0, t->ctx->stream, per, t->data + per * n, d);
+        SNNHIP_LAUNCH((argmax_kernel<float>), dim3(1), dim3(256), 0, t->ctx->stream, per, t->data + per * n, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out_index, d, sizeof(int), hipMemcpyDeviceToHost, t->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->ctx->stream);

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -31,6 +32,39 @@ void set_error(const char* fmt, ...);
             ::snnhip::set_error(__VA_ARGS__);  \
             return SNNHIP_E_INVALID;           \
         }                                      \
+    } while (0)
+
+// ---- launch trace (snnhip_trace_begin / _end / _report, include/snnhip.h): every kernel launch of the library goes through SNNHIP_LAUNCH; while a
+// trace is on it is issued with hipExtLaunchKernelGGL and a fresh event pair -- the dispatch packet's own start / end stamps, what rocprofv3's
+// kernel trace reports -- and recorded under the innermost open scope (the plan that launched it and that plan's algorithmic cost).
+bool trace_active();
+int trace_events(const void* fn, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop);
+struct TraceScope {
+    int prev = -2; // -2 = inactive
+    TraceScope(const std::string& desc, double flops, double bytes);
+    explicit TraceScope(const ::snnhip_plan* plan);
+    ~TraceScope();
+    TraceScope(const TraceScope&) = delete;
+    TraceScope& operator=(const TraceScope&) = delete;
+};
+
+#define SNNHIP_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                  \
+    do {                                                                                                                      \
+        if (::snnhip::trace_active()) {                                                                                       \
+            hipEvent_t trS_ = nullptr, trE_ = nullptr;                                                                        \
+            (void) ::snnhip::trace_events(reinterpret_cast<const void*>(kernel), stream, &trS_, &trE_);                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, trS_, trE_, 0, __VA_ARGS__);                              \
+        } else {                                                                                                              \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                \
+        }                                                                                                                     \
+    } while (0)
+
+// the same for a launch site that may already hold a plan-profile event pair (evS / evE null = none)
+#define SNNHIP_LAUNCH_EV(kernel, grid, block, lds, stream, evS, evE, ...)                                                     \
+    do {                                                                                                                      \
+        hipEvent_t trS_ = evS, trE_ = evE;                                                                                    \
+        if (!trS_ && ::snnhip::trace_active()) (void) ::snnhip::trace_events(reinterpret_cast<const void*>(kernel), stream, &trS_, &trE_); \
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, trS_, trE_, 0, __VA_ARGS__);                                  \
     } while (0)
 
 inline int up_div(int x, int y) { return (x + y - 1) / y; }
@@ -92,7 +126,11 @@ struct snnhip_plan {
     bool anyDtype = false;    // ... unless it adapts to the tensors of each call (element-wise / pooling / shape operators)
     bool u8Input = false;     // snnhip_image_u8_plan_create: the only plan that reads SNNHIP_U8 tensors
     std::string desc;
-    double flops = 0, bytes = 0;
+    double flops = 0, bytes = 0; // algorithmic cost in SURVEY 8(d)'s accounting (a fused plan: the sum over the layers it replaces)
+    // what THIS plan's own launches have to move through HBM (inputs once + outputs once + weights): differs from `bytes` only for fused plans,
+    // which must set it (the launch trace and bench.py's per-kernel roofline use it); < 0 = same as `bytes`
+    double kernelBytes = -1.0;
+    double ownBytes() const { return kernelBytes >= 0.0 ? kernelBytes : bytes; }
     std::vector<void*> deviceAllocs; // freed in the destructor
 
     // per-launch profiling (hipEvent pairs on ctx->stream), see snnhip_plan_profile_enable
@@ -112,6 +150,8 @@ struct snnhip_plan {
             }
     }
     virtual int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) = 0;
+    // run() under a launch-trace scope of this plan (snnhip_trace_begin): what the C-ABI and every composite plan call
+    int invoke(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out);
     virtual int numSteps() const { return 1; }
     virtual std::string stepDesc(int) const { return desc; }
     virtual void stepCost(int, double* f, double* b) const {
@@ -210,6 +250,10 @@ struct ConvPlanBase : snnhip_plan {
     // ... and a kernel that can also FOLD the records itself (the last block of an image to finish merges that image's records and writes the
     // norm's shift / mul: no fold launches behind the convolution) is given the norm's parameters here; false = not supported
     virtual bool enableNormFold(const struct NormFoldTarget&) { return false; }
+    // a kernel whose records are per BLOCK (conv2d_upconv, conv2d_s2march) can only be read by its own in-kernel fold: when enableNormFold fails the
+    // chain planner switches the statistics off again and the norm keeps its sweep
+    virtual bool tileStatsNeedKernelFold() const { return false; }
+    virtual void disableTileStats() {}
 };
 // the InstanceNorm a convolution folds its tile statistics for: y = x * mul[n][c] + shift[n][c], mul = gamma / sqrt(var + eps), shift = beta - mean * mul
 struct NormFoldTarget {

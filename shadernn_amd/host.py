@@ -21,6 +21,7 @@ SIGNATURES = {
     "snn_model_stage_plan_step": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "snn_model_profile_enable": (C.c_int, [_P, C.c_int]),
     "snn_model_profile_read": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "snn_model_suspend_replay": (C.c_int, [_P, C.c_int]),
     "snn_model_cost": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "snn_model_destroy": (C.c_int, [_P]),
     "snn_model_upload_input": (C.c_int, [_P, _FP]),
@@ -196,6 +197,10 @@ class Model:
 
     def profile(self, enable=True):
         assert lib().snn_model_profile_enable(self.h, int(enable)) == 0
+
+    def suspend_replay(self, suspend=True):
+        """launch by launch instead of replaying the recorded hipGraph (a launch trace needs the plans to run)"""
+        assert lib().snn_model_suspend_replay(self.h, int(suspend)) == 0
 
     def profile_read(self, stage, step):
         ms, n = C.c_double(), C.c_int()

@@ -6,6 +6,8 @@
 
 #include "ic2/json.h"
 
+#include <locale.h>
+
 namespace snn {
 namespace json {
 namespace {
@@ -165,8 +167,11 @@ struct P {
         const auto res = std::from_chars(s.data() + i, s.data() + j, d);
         if (res.ec == std::errc::result_out_of_range) {
             // from_chars reports overflow AND underflow this way and leaves d untouched: let strtod (whose span was validated above: JSON's number
-            // grammar, '.' as the radix character) tell them apart -- +-HUGE_VAL on overflow, +-0 / a denormal on underflow
-            d = strtod(std::string(s.data() + i, j - i).c_str(), nullptr);
+            // grammar) tell them apart -- +-HUGE_VAL on overflow, +-0 / a denormal on underflow
+            // ... in the "C" locale explicitly (strtod_l): under a process locale whose radix character is ',' plain strtod would stop at the '.'
+            static const locale_t cLocale = newlocale(LC_ALL_MASK, "C", static_cast<locale_t>(0));
+            const std::string span(s.data() + i, j - i);
+            d = cLocale ? strtod_l(span.c_str(), nullptr, cLocale) : strtod(span.c_str(), nullptr);
         }
         else if (res.ec != std::errc() || res.ptr != s.data() + j) return fail("malformed number");
         v.type = Value::Number;

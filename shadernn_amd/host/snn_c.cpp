@@ -249,6 +249,11 @@ int snn_model_profile_enable(snn_model* m, int enable) {
     return 0;
 }
 
+int snn_model_suspend_replay(snn_model* m, int suspend) {
+    m->core->suspendReplay(suspend != 0);
+    return 0;
+}
+
 int snn_model_profile_read(snn_model* m, int stage, int step, double* total_ms, int* launches) {
     snnhip_plan* p = stagePlan(m, stage);
     if (!p) return -1;

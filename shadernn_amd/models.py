@@ -294,3 +294,17 @@ def write_json(net, width, height, path, bin_weights=False):
     with open(path, "w") as f:
         json.dump(d, f)
     return path
+
+
+def zoo(name, input_shape, seed=1):
+    """A graph of the reference's model zoo (modelzoo/*.param, topologies parsed once into shadernn_amd/data/zoo_topologies.json by
+    tests/golden/make_zoo_topologies.py) with synthetic weights: e.g. zoo("candy-9_simplified-opt", (720, 1280, 3)) = BASELINE configs[4]."""
+    import json
+    import os
+
+    from . import param_import
+
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "zoo_topologies.json")))[name]
+    ops = [{"type": o["type"], "name": o["name"], "inputs": o["inputs"], "outputs": o["outputs"], "params": {int(k): v for k, v in o["params"].items()}}
+           for o in fx["ops"]]
+    return param_import.from_ops(ops, name=name, seed=seed, input_shape=input_shape)

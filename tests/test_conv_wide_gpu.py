@@ -594,6 +594,46 @@ def test_upconv_low_resolution_phases_match_the_oracle_and_the_nine_tap_kernel(c
     np.testing.assert_allclose(y, nine(xt).numpy(), err_msg=d + " vs " + nine.describe(), rtol=3e-3, atol=3e-3)
 
 
+def test_upconv_presummed_weights_stay_within_their_rounding_bound_when_taps_cancel(ctx, monkeypatch):
+    """conv2d_upconv.hip sums the (up to four) half-rounded taps that fall on one low-resolution pixel in fp32 and rounds the SUM to half once more;
+    the 9-tap path (and the reference) multiply each half-rounded tap on its own.  The extra error per pre-summed weight is <= 2^-11 of the summed
+    magnitude, so per output |upconv - nine| <= 2^-11 * sum |w_presummed| * |x| (+ the output rounding of either path).  Worst case: neighbouring
+    taps that cancel, leaving a remainder much smaller than the taps -- checked here against that bound, not against a loose tolerance."""
+    import shadernn_amd as snn
+
+    n, h, w_, ic, oc = 1, 21, 27, 64, 32
+    rng = np.random.default_rng(77)
+    wt = rng.standard_normal((oc, ic, 3, 3)).astype(np.float32) / np.sqrt(ic * 9)
+    wt[:, :, :, 1] = -wt[:, :, :, 0] + 1e-3 * rng.standard_normal((oc, ic, 3)).astype(np.float32)   # columns 0 and 1 cancel to ~1e-3 of a tap
+    wt[:, :, 1, :] = -wt[:, :, 2, :] + 1e-3 * rng.standard_normal((oc, ic, 3)).astype(np.float32)   # and rows 1 and 2
+    x, b = _rand((n, h, w_, ic), 5), _rand((oc,), 6, 0.2)
+
+    def chain():
+        plans = [snn.upsample_plan(ctx, n, h, w_, ic, 2.0, "nearest"), snn.pad_plan(ctx, n, 2 * h, 2 * w_, ic, (1, 1, 1, 1), "reflect"),
+                 snn.conv2d_plan(ctx, n, 2 * h + 2, 2 * w_ + 2, wt, b, stride=1, pads=(0, 0, 0, 0), act="", dtype=snn.F16)]
+        return snn.chain_plan(ctx, plans)
+
+    monkeypatch.setenv("SNNHIP_CONV", "upconv")
+    up = chain()
+    assert "upconv" in up.describe(), up.describe()
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    y = up(xt).numpy()
+    monkeypatch.delenv("SNNHIP_CONV")
+    monkeypatch.setenv("SNNHIP_CONV_UPCONV", "0")
+    nine = chain()
+    assert "upconv" not in nine.describe(), nine.describe()
+    y9 = nine(xt).numpy()
+    # bound: every pre-summed weight is off by at most half an fp16 ulp of its magnitude (<= 2^-11 |w_sum|, |w_sum| <= sum of the |taps| it holds),
+    # times the inputs it multiplies; plus one fp16 output rounding on each side
+    t = O.pad(O.upsample(O._h(x), 2.0, "nearest"), (1, 1, 1, 1), "reflect")
+    mag = O.conv2d(np.abs(t), np.abs(O._h(wt)), None, 1, (0, 0, 0, 0), "constant", "", 0.0, None)   # sum |w| |x| per output (an upper bound of sum |w_sum| |x|)
+    bound = 2.0 ** -11 * mag + 2.0 ** -10 * np.maximum(np.abs(y9), 2.0 ** -14) + 1e-6
+    d = np.abs(y.astype(np.float64) - y9.astype(np.float64))
+    assert (d <= bound).all(), "max excess %.3e at %s" % (float((d - bound).max()), np.unravel_index(int((d - bound).argmax()), d.shape))
+    want = O._h(O.conv2d(t, O._h(wt), b, 1, (0, 0, 0, 0), "constant", "", 0.0, None))
+    np.testing.assert_allclose(y, want, **TOLH)
+
+
 @pytest.mark.parametrize("n,h,w_,ic,oc,offset", [(2, 30, 45, 64, 32, 0.0), (1, 25, 70, 128, 64, 3.0), (3, 9, 33, 64, 64, 0.0)])
 def test_upconv_block_statistics_feed_the_instancenorm_behind_it(ctx, monkeypatch, n, h, w_, ic, oc, offset):
     """Rule F on conv2d_upconv.hip: UpSampling -> Pad -> Conv2D -> InstanceNorm as the convolution (whose blocks leave {pixels, sum, sum of squares} records

@@ -166,39 +166,52 @@ def test_bench_self_spawns_ranks_from_a_plain_shell():
         assert r.stderr.count("no GPU visible") >= 1, r.stderr[-2000:]
 
 
-def test_bench_pmc_lookup_names_the_exact_instantiation():
-    """bench.py's `roofline.traffic` comes from profiles/pmc_latest.json: the record must be the one of the kernel INSTANTIATION a plan description stands
-    for -- never another instantiation of the same function (its traffic is another layer's)."""
+def test_bench_kernel_table_groups_by_function_and_prices_the_dominant_one(monkeypatch, tmp_path):
+    """bench.py's `roofline` names the kernel FUNCTION with the most GPU time over all its launches (never a multi-launch step, never the longest
+    single launch), prices it on the algorithmic work booked on it, and takes `traffic` from profiles/pmc_latest.json only for the INSTANTIATIONS
+    the run launched and only from records taken with the kernel sources of this build."""
     import json
 
     import bench
     from shadernn_amd import fingerprint
 
-    pmc = {
-        "_ZN6snnhip12_GLOBAL__N_118conv2d_wide_kernelILi2ELi2ELi2ELi2ELi7ELb1ELb0EEEvNS0_10WideParamsE": {"hbm_bytes_per_launch": 1.0},
-        "_ZN6snnhip12_GLOBAL__N_118conv2d_wide_kernelILi4ELi1ELi1ELi1ELi8ELb1ELb0EEEvNS0_10WideParamsE": {"hbm_bytes_per_launch": 2.0},
-        "conv2d_stem32_kernel<7,2,4,true>": {"hbm_bytes_per_launch": 3.0},
-        "irb_wave_kernel<1,2,1,true>": {"hbm_bytes_per_launch": 4.0},
-        "irb_wave_kernel": {"hbm_bytes_per_launch": 4.0},
-        "conv_kxk_c1o16_wino3x3_c16o16_kernel": {"hbm_bytes_per_launch": 5.0},
-    }
+    trace = {"launches": 14, "kernels": [
+        {"function": "conv2d_wide_kernel", "launches": 8, "main_launches": 8, "total_ms": 4.0, "flops": 8e12, "bytes": 4e9, "instances": [
+            {"name": "void snnhip::(anonymous namespace)::conv2d_wide_kernel<2, 2, 2, 2>(snnhip::(anonymous namespace)::WideParams)", "launches": 6, "main_launches": 6,
+             "total_ms": 3.0, "flops": 6e12, "bytes": 3e9, "plans": ["conv2d_mfma_wide_f16 a"]},
+            {"name": "void snnhip::(anonymous namespace)::conv2d_wide_kernel<4, 1, 1, 1>(snnhip::(anonymous namespace)::WideParams)", "launches": 2, "main_launches": 2,
+             "total_ms": 1.0, "flops": 2e12, "bytes": 1e9, "plans": ["conv2d_mfma_wide_f16 b"]}]},
+        {"function": "conv2d_upconv_kernel", "launches": 2, "main_launches": 2, "total_ms": 1.4, "flops": 1e12, "bytes": 3.5e9, "instances": [
+            {"name": "void snnhip::(anonymous namespace)::conv2d_upconv_kernel<8, 2>(P)", "launches": 2, "main_launches": 2, "total_ms": 1.4, "flops": 1e12, "bytes": 3.5e9, "plans": ["up"]}]},
+        {"function": "splitk_reduce_kernel", "launches": 4, "main_launches": 0, "total_ms": 0.1, "flops": 0.0, "bytes": 0.0, "instances": [
+            {"name": "void snnhip::(anonymous namespace)::splitk_reduce_kernel<true, float>(int)", "launches": 4, "main_launches": 0, "total_ms": 0.1, "flops": 0, "bytes": 0, "plans": []}]},
+    ]}
+    rows = bench.kernel_table(trace, 2, bench.PEAK_F16_MFMA_TFLOPS)
+    assert [r["function"] for r in rows] == ["conv2d_wide_kernel", "conv2d_upconv_kernel", "splitk_reduce_kernel"]  # by total time: the longest LAUNCH (0.7 ms, upconv) is not first
+    assert rows[0]["bound"] == "mfma" and abs(rows[0]["frac"] - 8e12 / 4e-3 / 2500e12) < 1e-12
+    assert rows[1]["bound"] == "hbm" and abs(rows[1]["frac"] - 3.5e9 / 1.4e-3 / 8e12) < 1e-12
+    assert rows[2]["bound"] == "aux" and rows[2]["frac"] is None
+    assert abs(sum(r["share_of_gpu_time"] for r in rows) - 1.0) < 1e-12 and rows[0]["launches_per_step"] == 4
 
-    def look(desc):
-        tags = dict(tk.split("=", 1) for tk in desc.split(" ") if "=" in tk and not tk.startswith("tile"))
-        e = bench.pmc_entry(pmc, desc, tags)
-        return None if e is None else e["hbm_bytes_per_launch"]
-
-    wide = "conv2d_mfma_wide_f16_32x32x16 k=3x3 s=1 ic=%d oc=%d tile=%s x %doc (4x%d MFMA tiles per wave) chunk=%d lds=1B"
-    assert look(wide % (128, 128, "8x32px", 128, 2, 32)) == 1.0
-    assert look(wide % (64, 32, "16x32px", 32, 1, 16)) == 2.0
-    assert look("instancenorm(statistics from the convolution in front) -> instancenorm(act=1, in LDS behind the DMA) -> " + wide % (128, 128, "8x32px", 128, 2, 32)) == 1.0
-    assert look(wide % (128, 64, "16x32px", 64, 2, 16)) is None          # 4 x 1 x 2: not in this profile
-    assert look("conv2d_mfma_stem_f32_32x32x2 k=7x7 s=2 ic=3 oc=64 tile=16x32px x 32oc") == 3.0
-    assert look("conv2d_mfma_stem_f32_32x32x2 k=3x3 s=1 ic=3 oc=64 tile=8x32px x 32oc") is None  # another instantiation of the same function
-    assert look("irb_fused_mfma_f32_16x16x4 [...] tile=2x8px per wave, hbm_bytes=1 kernel=irb_wave_kernel<1,2,1,true>") == 4.0
-    assert look("fused[conv5x5(1->16)+conv3x3(16->16)] mfma_f32_16x16x4 tile=32x16 kernel=conv_kxk_c1o16_wino3x3_c16o16_kernel mfma_flops=1") == 5.0
-    # the committed file: one source fingerprint per record (bench.py reports `traffic` only when it equals the fingerprint of the sources it runs,
-    # and says "stale" otherwise -- a kernel edit does not turn this test red, it turns the bench field to null until the profile is re-taken)
+    sha = fingerprint.csrc_sha16()
+    pmc = {"conv2d_wide_kernel<2,2,2,2>": {"hbm_bytes_per_launch": 6e8, "csrc_sha16": sha, "git_head": "x"},
+           "conv2d_wide_kernel<4,1,1,1>": {"hbm_bytes_per_launch": 2e8, "csrc_sha16": sha, "git_head": "x"},
+           "conv2d_wide_kernel": {"hbm_bytes_per_launch": 1.0, "csrc_sha16": sha},  # the bare key is never used: it is one instantiation's record
+           "conv2d_upconv_kernel<8,2>": {"hbm_bytes_per_launch": 9e8, "csrc_sha16": "0" * 16}}
+    os.makedirs(tmp_path / "profiles")
+    json.dump(pmc, open(tmp_path / "profiles" / "pmc_latest.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t, src = bench.pmc_traffic(rows[0])
+    assert abs(t - (6 * 6e8 + 2 * 2e8) / 8) < 1e-3 and "launch-weighted" in src
+    t, src = bench.pmc_traffic(rows[1])
+    assert t is None and src.startswith("stale")   # a kernel edit turns the field to null until the profile is re-taken, it does not lie
+    t, src = bench.pmc_traffic(rows[2])
+    assert t is None and "no PMC record" in src
+    rec = bench.roofline_record(rows, bench.PEAK_F16_MFMA_TFLOPS, single_launch_step=False)
+    assert rec["kernel"] == "conv2d_wide_kernel" and rec["bound"] == "mfma" and abs(rec["frac"] - rows[0]["frac"]) < 1e-12
+    assert abs(rec["algorithmic_bytes_per_launch"] - 0.5e9) < 1 and abs(rec["traffic_over_algorithmic_bytes"] - 5e8 / 0.5e9) < 1e-9
+    monkeypatch.undo()
+    # the committed file: one source fingerprint per record
     committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
     assert committed and all(len(v.get("csrc_sha16", "")) == 16 and v["hbm_bytes_per_launch"] >= 0 for v in committed.values())
     assert len(fingerprint.csrc_sha16()) == 16

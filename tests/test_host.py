@@ -41,6 +41,7 @@ def test_json_number_grammar_overflow_and_underflow(built):
     assert host.json_number("1.5e3") == 1500.0 and host.json_number("-0.25") == -0.25 and host.json_number("0") == 0.0
     assert host.json_number("1e400") == math.inf and host.json_number("-1e400") == -math.inf
     assert host.json_number("1e-400") == 0.0 and host.json_number("-1e-400") == 0.0 and math.copysign(1.0, host.json_number("-1e-400")) == -1.0
+    assert host.json_number("1.5e400") == math.inf and host.json_number("1.5e-400") == 0.0  # the out-of-range fallback parses the '.' in the "C" locale (strtod_l)
     assert host.json_number("4.9e-324") == 5e-324 and 0.0 < host.json_number("2e-310") < 1e-300  # denormals survive
     for bad in ("1.", ".5", "+1", "01", "1e", "nan", "0x10", ""):
         assert host.json_number(bad) is None, bad

@@ -118,10 +118,11 @@ def test_dense_matches_oracle(ctx, act, batch, inu, outu):
 
 
 @pytest.mark.parametrize("act", ["relu", "", "softmax", "tanh"])
-@pytest.mark.parametrize("batch,inu,outu", [(256, 1280, 1000), (32, 512, 1000), (33, 72, 37), (100, 40, 5)])
+@pytest.mark.parametrize("batch,inu,outu", [(256, 1280, 1000), (32, 512, 1000), (33, 72, 37), (100, 40, 5), (32, 8, 32), (64, 32, 33), (32, 56, 7)])
 def test_dense_batched_mfma_gemm_matches_oracle_and_the_wave_per_row_kernel(ctx, monkeypatch, act, batch, inu, outu):
     """dense_mfma_kernel (batch >= 32, fp32, In % 8 == 0): the classifier heads of BASELINE configs[2] / [3] at their batch sizes, ragged tiles in both
-    directions, a K range that does not split evenly over the four waves; against the oracle and the wave-per-row kernel (SNNHIP_DENSE_MFMA=0)."""
+    directions, a K range that does not split evenly over the four waves, rows shorter than one 64-column staging chunk (in_units 8 / 32 / 56: the
+    staging threads past the row must fall back to an address inside it); against the oracle and the wave-per-row kernel (SNNHIP_DENSE_MFMA=0)."""
     import shadernn_amd as snn
 
     x = _rand((batch, 1, 1, inu), 31)

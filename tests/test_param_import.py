@@ -1,4 +1,4 @@
-"""ncnn .param importer: the reference's model-zoo graphs (fixture tests/golden/zoo_topologies.json, generated from
+"""ncnn .param importer: the reference's model-zoo graphs (fixture shadernn_amd/data/zoo_topologies.json, generated from
 modelzoo/*.param by tests/golden/make_zoo_topologies.py) -> graph nets with the converter's folding rules -> oracle / HIP."""
 import json
 import os
@@ -16,7 +16,7 @@ TOL = dict(rtol=1e-4, atol=1e-4)
 def _zoo(name, input_shape=None, seed=1):
     from shadernn_amd import param_import
 
-    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "zoo_topologies.json")))[name]
+    fx = json.load(open(os.path.join(ROOT, "shadernn_amd", "data", "zoo_topologies.json")))[name]
     ops = [{"type": o["type"], "name": o["name"], "inputs": o["inputs"], "outputs": o["outputs"], "params": {int(k): v for k, v in o["params"].items()}}
            for o in fx["ops"]]
     return param_import.from_ops(ops, name=name, seed=seed, input_shape=input_shape)

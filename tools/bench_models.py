@@ -37,7 +37,7 @@ def main():
     def zoo(name, shape):
         from shadernn_amd import param_import
 
-        fx = json.load(open(os.path.join(ROOT, "tests", "golden", "zoo_topologies.json")))[name]
+        fx = json.load(open(os.path.join(ROOT, "shadernn_amd", "data", "zoo_topologies.json")))[name]
         ops = [{"type": o["type"], "name": o["name"], "inputs": o["inputs"], "outputs": o["outputs"], "params": {int(k): v for k, v in o["params"].items()}}
                for o in fx["ops"]]
         return param_import.from_ops(ops, name=name, seed=1, input_shape=shape)

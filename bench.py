@@ -384,7 +384,7 @@ def _short_kernel_name(full):
     """`void snnhip::(anonymous namespace)::conv2d_wide_kernel<4, 1, 4, 8>(Params, ...)` -> `conv2d_wide_kernel<4,1,4,8>`: the key tools/summarize_prof.py
     writes a PMC record under"""
     n = full.replace("void snnhip::(anonymous namespace)::", "").replace("snnhip::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")
-    return n.split("(")[0].replace(" ", "")
+    return n.split("(")[0][:110].replace(" ", "")  # ([:110]: summarize_prof.py's cut -- mangled names of the fp16 kernels, which no demangler here resolves, are long)
 
 
 def pmc_traffic(kernel):

@@ -16,6 +16,8 @@ extern "C" {
 #endif
 
 typedef struct snn_model snn_model;
+struct snnhip_ctx;    /* include/snnhip.h */
+struct snnhip_tensor;
 
 /* Loads a JSON model, builds the graph for one W x H x C input image and initialises every stage on `device`.
  * dump_outputs: write "<SNN_OUTPUT_DIR>/<layer name> pass[0].dump" for every layer on each run (disables fusion).
@@ -35,6 +37,9 @@ int snn_model_create3(const char* json_path, int device, int in_w, int in_h, int
 int snn_model_create4(const char* json_path, int device, int in_w, int in_h, int in_c, int dump_outputs, int fuse_chains, int profiling,
                       int prefer_half, int capture_graph, int batch, snn_model** out);
 int snn_model_batch(snn_model* m);
+/* the C-ABI handles behind a model: its context (device + stream) and the device tensor of its last stage's output (borrowed) */
+struct snnhip_ctx* snn_model_hip_ctx(snn_model* m);
+struct snnhip_tensor* snn_model_output_tensor(snn_model* m);
 int snn_model_destroy(snn_model* m);
 int snn_model_upload_input(snn_model* m, const float* nhwc);      /* [batch x] H x W x C floats */
 int snn_model_run(snn_model* m);                                   /* MixedInferenceCore::run (enqueue + one sync) */
@@ -69,6 +74,26 @@ int snn_model_suspend_replay(snn_model* m, int suspend);
 int snn_model_cost(snn_model* m, double* flops, double* bytes);
 /* per-stage device timers of the last run, milliseconds (MixedInferenceCore::writeTimeStat); returns count written */
 int snn_model_time_stats(snn_model* m, char* names, int names_len, double* ms, int max_entries);
+
+/* ---- multi-device pool (shadernn_amd/host/pool.cpp; SURVEY 8b "Threading" + 8e): one replica = one host thread + HipContext + stream per entry of
+ * devices[] (an entry may repeat), each owning one MixedInferenceCore per micro-batch slot of its share [g*B/G, (g+1)*B/G) of the global batch.
+ * Weights are loaded per replica, nothing crosses devices on the data path.  micro_batch 0 = a replica's share in one pass.
+ * The reference is single-device (vulkanBackend.cpp:30-31); its benchmark loop (inferenceProcessor.cpp:84-86) is what one replica runs. */
+typedef struct snn_pool snn_pool;
+int snn_pool_create(const char* json_path, const int* devices, int n_devices, int in_w, int in_h, int in_c, int prefer_half, int capture_graph,
+                    int global_batch, int micro_batch, snn_pool** out);
+int snn_pool_destroy(snn_pool* p);
+int snn_pool_replicas(snn_pool* p);
+int snn_pool_shard(snn_pool* p, int replica, int* first_image, int* images, int* slots);
+int snn_pool_output_dims(snn_pool* p, int hwc[3]);
+int snn_pool_upload_input(snn_pool* p, const float* nhwc);              /* global_batch x H x W x C floats; every replica takes its images */
+/* all replicas released together; each enqueues `steps` passes over its slots (deferSync) and waits once; returns when the slowest is done
+ * (seconds = that wall time: the in-process form of bench.py's barrier + MAX over ranks) */
+int snn_pool_run(snn_pool* p, int steps, double* seconds);
+int snn_pool_download_output(snn_pool* p, float* nhwc);                 /* gather through host memory: global_batch x outH x outW x outC floats */
+/* the edge collective of SURVEY 8e: one ncclAllGather per slot over the replicas' streams (librccl.so loaded at run time), rank 0's copy handed to
+ * the host.  -3: the replicas do not have equal shares or two of them share a device (RCCL needs one rank per device); -4: RCCL unavailable / failed */
+int snn_pool_allgather_output_rccl(snn_pool* p, float* nhwc_rank0);
 
 /* Restatement of ShaderUnitTest::snnConvTestWithLayer (shaderUnitTest.cpp:174-280): input HWC floats, weights as OC*IC
  * matrices of k x k (flat OIHW), bias[OC], optional BN (4 arrays of OC or NULL), pad: 0 constant 1 replicate 2 reflect.

@@ -141,6 +141,19 @@ std::string demangle(const char* mangled) {
 }
 // "void snnhip::(anonymous namespace)::conv2d_wide_kernel<4, 1, 4, 8>(Params, ...)" -> "conv2d_wide_kernel"
 std::string base_name(const std::string& full) {
+    if (full.compare(0, 3, "_ZN") == 0) {
+        // libstdc++'s demangler does not know _Float16 (DF16_): walk the nested name ourselves -- <len><identifier>... up to the template arguments
+        size_t i = 3;
+        std::string last;
+        while (i < full.size() && full[i] >= '0' && full[i] <= '9') {
+            size_t n = 0;
+            while (i < full.size() && full[i] >= '0' && full[i] <= '9') n = n * 10 + static_cast<size_t>(full[i++] - '0');
+            if (i + n > full.size()) break;
+            last = full.substr(i, n);
+            i += n;
+        }
+        if (!last.empty()) return last;
+    }
     size_t end = full.size();
     int depth = 0;
     // cut the parameter list: the last top-level '(' that is not "(anonymous namespace)"

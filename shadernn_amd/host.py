@@ -6,7 +6,8 @@ import numpy as np
 
 from . import capi
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsnn_core.so")
+# SNN_CORE_LIB_PATH: another build of the host library (tools/sanitize.sh points it at lib/libsnn_core_asan.so)
+LIB_PATH = os.environ.get("SNN_CORE_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsnn_core.so")
 _lib = None
 _P = C.c_void_p
 _FP = C.POINTER(C.c_float)
@@ -17,6 +18,17 @@ SIGNATURES = {
     "snn_model_create3": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "snn_model_create4": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "snn_model_batch": (C.c_int, [_P]),
+    "snn_model_hip_ctx": (_P, [_P]),
+    "snn_model_output_tensor": (_P, [_P]),
+    "snn_pool_create": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "snn_pool_destroy": (C.c_int, [_P]),
+    "snn_pool_replicas": (C.c_int, [_P]),
+    "snn_pool_shard": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "snn_pool_output_dims": (C.c_int, [_P, C.POINTER(C.c_int * 3)]),
+    "snn_pool_upload_input": (C.c_int, [_P, _FP]),
+    "snn_pool_run": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
+    "snn_pool_download_output": (C.c_int, [_P, _FP]),
+    "snn_pool_allgather_output_rccl": (C.c_int, [_P, _FP]),
     "snn_model_stage_plan_steps": (C.c_int, [_P, C.c_int]),
     "snn_model_stage_plan_step": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "snn_model_profile_enable": (C.c_int, [_P, C.c_int]),
@@ -244,3 +256,50 @@ def conv_test_with_layer(x_hwc, w_oihw, bias, stride=1, pad=0, bn=None, device=0
                                         _fp(arrs[2]), _fp(arrs[3]), path, 1024)
     assert rc == 0
     return path.value.decode()
+
+
+class Pool:
+    """snn_pool (include/snn_c.h): one replica (host thread + HipContext + stream) per entry of `devices`, a global batch split [g*B/G, (g+1)*B/G)."""
+
+    def __init__(self, json_path, w, h, c, devices, global_batch, micro_batch=0, prefer_half=False, capture_graph=True):
+        self.h = _P()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = lib().snn_pool_create(json_path.encode(), devs, len(devices), w, h, c, int(prefer_half), int(capture_graph), global_batch, micro_batch, C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("snn_pool_create failed: %d" % rc)
+        self.global_batch, self.in_shape = global_batch, (global_batch, h, w, c)
+        hwc = (C.c_int * 3)()
+        lib().snn_pool_output_dims(self.h, C.byref(hwc))
+        self.out_shape = (global_batch,) + tuple(hwc)
+
+    def replicas(self):
+        return lib().snn_pool_replicas(self.h)
+
+    def shard(self, g):
+        a, b, s = C.c_int(), C.c_int(), C.c_int()
+        assert lib().snn_pool_shard(self.h, g, C.byref(a), C.byref(b), C.byref(s)) == 0
+        return a.value, b.value, s.value
+
+    def upload(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.shape == self.in_shape, (x.shape, self.in_shape)
+        assert lib().snn_pool_upload_input(self.h, _fp(x)) == 0
+
+    def run(self, steps=1):
+        sec = C.c_double()
+        rc = lib().snn_pool_run(self.h, steps, C.byref(sec))
+        if rc != 0:
+            raise RuntimeError("snn_pool_run failed: %d" % rc)
+        return sec.value
+
+    def output(self, rccl=False):
+        out = np.empty(self.out_shape, dtype=np.float32)
+        rc = (lib().snn_pool_allgather_output_rccl if rccl else lib().snn_pool_download_output)(self.h, _fp(out))
+        if rc != 0:
+            raise RuntimeError("snn_pool output gather failed: %d" % rc)
+        return out
+
+    def close(self):
+        if self.h:
+            lib().snn_pool_destroy(self.h)
+            self.h = None

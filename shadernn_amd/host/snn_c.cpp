@@ -190,6 +190,13 @@ int snn_model_output_dims(snn_model* m, int hwc[3]) {
 
 int snn_model_batch(snn_model* m) { return m->batch; }
 
+snnhip_ctx* snn_model_hip_ctx(snn_model* m) {
+    auto* hc = dynamic_cast<HipContext*>(m->context);
+    return hc ? hc->ctx : nullptr;
+}
+
+snnhip_tensor* snn_model_output_tensor(snn_model* m) { return lastOutput(m).tensor(); }
+
 int snn_model_download_output(snn_model* m, float* nhwc) {
     lastOutput(m).downloadNHWC(nhwc);
     return 0;

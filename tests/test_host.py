@@ -575,3 +575,26 @@ def test_calculate_layer_json_end_to_end(ctx, tmp_path):
     m.close()
     r = snn.GraphRunner(ctx, net, 1, 20, 28)
     np.testing.assert_allclose(r(x).reshape(-1), want.reshape(-1), rtol=1e-4, atol=1e-4)
+
+
+def test_pool_and_cli_fail_loudly_without_a_gpu(built, tmp_path):
+    """snn_pool_create / lib/snn_run on a box without a GPU: an error code, never a silent CPU path; the CLI rejects a malformed command line (rc 2)."""
+    import subprocess
+
+    import torch
+
+    from shadernn_amd import host, models
+
+    cli = os.path.join(ROOT, "shadernn_amd", "lib", "snn_run")
+    assert os.path.exists(cli), "build_host() did not produce lib/snn_run"
+    r = subprocess.run([cli, "--w", "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert r.returncode == 2 and "usage: snn_run" in r.stderr
+    if torch.cuda.is_available():
+        return
+    path = models.write_json(models.espcn_weights(seed=1), 16, 12, str(tmp_path / "m.json"), bin_weights=True)
+    try:
+        host.Pool(path, 16, 12, 1, devices=[0, 0], global_batch=4)
+    except (RuntimeError, SystemExit):
+        pass
+    else:
+        raise AssertionError("snn_pool_create succeeded without a GPU")

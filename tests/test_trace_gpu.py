@@ -47,7 +47,7 @@ def test_trace_splits_a_multi_launch_plan_by_kernel(ctx):
     x = np.random.default_rng(4).standard_normal((N, H, W, C)).astype(np.float32)
     tx, ty = snn.Tensor(ctx, N, H, W, C), snn.Tensor(ctx, N, H, W, C)
     tx.upload(x)
-    p = snn.instancenorm_plan(ctx, N, H, W, C, np.zeros(C, np.float32), np.ones(C, np.float32), act=0)
+    p = snn.instancenorm_plan(ctx, N, H, W, C, np.zeros(C, np.float32), np.ones(C, np.float32), act="")
     p.run(tx, ty)
     ctx.sync()
     capi.trace_begin()

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Host-side checker target (SURVEY section 5 "Race detection / sanitizers": the reference has none, core/CMakeLists.txt:235).
+#   tools/sanitize.sh            builds lib/libsnn_core_asan.so (-fsanitize=address,undefined) and runs the CPU suite's host tests against it
+#   tools/sanitize.sh gpu        on a GPU box: the smoke test + the host-mirror GPU tests under the same library, plus the kernels under
+#                                AMD_LOG_LEVEL=1 HSA_ENABLE_DEBUG=1 (out-of-bounds accesses of a kernel show up as a memory-access fault that aborts the run)
+set -eu
+cd "$(dirname "$0")/.."
+python -c "import __graft_entry__ as g; g.build_hip(); g.build_host(); print(g.build_host(sanitize='address,undefined'))"
+ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.so)
+export LD_PRELOAD="$ASAN:$UBSAN" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:protect_shadow_gap=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
+export SNN_CORE_LIB_PATH="$PWD/shadernn_amd/lib/libsnn_core_asan.so"
+if [ "${1:-cpu}" = "gpu" ]; then
+  AMD_LOG_LEVEL=1 HSA_ENABLE_DEBUG=1 python -m pytest tests/test_host.py tests/test_configs_gpu.py -q -m gpu -x -k "not c5"
+else
+  python -m pytest tests/test_host.py tests/test_param_import.py -q -m "not gpu" -x
+fi

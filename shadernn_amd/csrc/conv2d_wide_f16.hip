@@ -58,7 +58,20 @@ struct WideParams {
     const float* normShift;
     const float* normMul;
     ActCfg normAc;
+    // K-loop token (round 4): the two blocks a CU holds lock-step -- both in their K loops (the matrix pipe shared), then both in prologue / epilogue
+    // / stores (the pipe idle): 0.45 busy over the launch.  kTok[physical CU] is a mutual exclusion around the K loop: a block takes it before its
+    // first chunk and returns it after its last, so a CU's blocks ALTERNATE (one multiplies at the full pipe rate while the other stages / stores).
+    // Purely a performance device: a token shared by blocks of different CUs (an aliased id) only serialises them.  null = off.
+    unsigned* kTok;
 };
+
+// physical CU of the calling wave, hashed to [0, 2048): XCC id (8) x the SE / SH / CU fields of HW_ID (bits 8..15)
+__device__ __forceinline__ unsigned physical_cu_slot() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (8 << 6) | (7 << 11));   // HW_REG_HW_ID, 8 bits from bit 8: cu_id, sh_id, se_id (bit 16 up: the workgroup slot)
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)); // HW_REG_XCC_ID, 4 bits
+    return ((xcc & 7u) << 8) | (hw & 255u);
+}
+constexpr int kTokSlots = 2048;
 
 template <int WM, int WN, int NT, int C8, int R, bool SIMPLE, bool RES>
 __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
@@ -215,6 +228,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     stage_dma(smem, 0);
     lds_dma_wait();
     if (p.normShift) norm_fixup(smem, 0);
+    unsigned* const tok = p.kTok ? p.kTok + physical_cu_slot() : nullptr;
+    if (tok && tid == 0) { // chunk 0 is in LDS: wait for the CU's other block to leave its K loop
+        while (__hip_atomic_exchange(tok, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) __builtin_amdgcn_s_sleep(16);
+    }
     __syncthreads();
     WIDE_MARK(2);
 
@@ -256,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
         __syncthreads();
     }
 
+    if (tok && tid == 0) __hip_atomic_store(tok, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     WIDE_MARK(3);
     // ---- epilogue.  The MFMAs ran with the WEIGHTS as the A operand (M = output channels) and the pixels as B (N = 32 pixels of a tile row), so
     // a lane holds, for ITS pixel, runs of four consecutive output channels: acc[t][u][4g + k] = channel n0 + 32u + 8g + 4h + k of pixel
@@ -629,6 +647,19 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         delete plan;
         return rc;
     }
+    // K-loop token: where a CU holds exactly two of these blocks and the grid is several rounds of them (SNNHIP_WIDE_TOKEN=0 / 1 forces it off / on)
+    {
+        const char* tk = snnhip::option("SNNHIP_WIDE_TOKEN");
+        const bool twoPerCu = lds > 53 * 1024;
+        const bool want = tk ? atoi(tk) != 0 : false;
+        if (want && twoPerCu) {
+            void* buf = nullptr;
+            if (hipMalloc(&buf, kTokSlots * sizeof(unsigned)) == hipSuccess) {
+                plan->deviceAllocs.push_back(buf);
+                if (hipMemset(buf, 0, kTokSlots * sizeof(unsigned)) == hipSuccess) plan->p.kTok = static_cast<unsigned*>(buf);
+            }
+        }
+    }
     plan->inDims[0] = g.N; plan->inDims[1] = p.srcH; plan->inDims[2] = p.srcW; plan->inDims[3] = g.IC;
     plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
     plan->dtype = SNNHIP_F16;
@@ -645,6 +676,7 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         plan->desc += " +add";
         plan->bytes += 2.0 * static_cast<double>(g.N) * g.OH * g.OW * g.OC;
     }
+    if (plan->p.kTok) plan->desc += " +ktoken";
     *out = plan;
     return SNNHIP_OK;
 }

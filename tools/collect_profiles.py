@@ -31,7 +31,7 @@ def main():
                 pmc.setdefault(k, v)
     if pmc:
         json.dump(pmc, open(os.path.join(prof, "pmc_latest.json"), "w"), indent=1)
-    for c in ("c1", "c2", "c3", "c4", "c5"):
+    for c in ("c1", "c2", "c3", "c4", "c5", "all"):
         src = os.path.join(out, a.tag, "bench_%s.json" % c)
         if os.path.exists(src) and os.path.getsize(src):
             shutil.copy(src, os.path.join(prof, "%s_bench_%s.json" % (a.round, c)))

@@ -3,7 +3,8 @@
 #   usage: gpurun --timeout S -- 'tools/gpu.sh <tag> <action> [<action> ...]'
 #   actions:
 #     tests[:<pytest -k expression>]   the -m gpu suite (or the tests matching the expression)            -> pytest[_N].txt
-#     bench[:c1,c2,...]                one bench.py line per config (default: all five)                   -> bench_<c>.json / .err
+#     bench[:c1,c2,...]                one bench.py line per config (default: all five), each with --also none -> bench_<c>.json / .err
+#     benchall                         the driver's command: python bench.py (c2 + the other four configs in `configs`) -> bench_all.json
 #     benchx:<c>:<extra bench args>    one bench line with extra arguments ('+' stands for a blank)        -> benchx_<n>.json
 #     prof:<c>                         rocprofv3 kernel trace + PMC passes of that config's bench command -> <tag>_<c>/summary.md
 #     profx:<name>:<command>           the same passes around an arbitrary command ('+' stands for a blank)   -> <tag>_<name>/summary.md
@@ -27,16 +28,19 @@ for act in "$@"; do
       else timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > "$O/pytest.txt" 2>&1; tail -6 "$O/pytest.txt"; fi ;;
     bench)
       for c in $(echo "${arg:-c2,c1,c3,c4,c5}" | tr ',' ' '); do
-        timeout 900 python bench.py --config "$c" > "$O/bench_$c.json" 2> "$O/bench_$c.err" || { echo "bench $c rc=$?"; tail -3 "$O/bench_$c.err"; }
+        timeout 900 python bench.py --config "$c" --also none > "$O/bench_$c.json" 2> "$O/bench_$c.err" || { echo "bench $c rc=$?"; tail -3 "$O/bench_$c.err"; }
       done
       python tools/bench_digest.py "$O" ;;
+    benchall)
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_all.json" 2> "$O/bench_all.err" || { echo "benchall rc=$?"; tail -3 "$O/bench_all.err"; }
+      python tools/bench_digest.py "$O/bench_all.json" ;;
     benchx)
       c=${arg%%:*}; extra=${arg#*:}
       timeout 900 python bench.py --config "$c" ${extra//+/ } > "$O/benchx_$n.json" 2> "$O/benchx_$n.err" || { echo "benchx $arg rc=$?"; tail -3 "$O/benchx_$n.err"; }
       python tools/bench_digest.py "$O/benchx_$n.json" ;;
     prof)
       steps=$(python -c "print({'c1':'--steps 200 --warmup 20','c2':'--steps 100 --warmup 10','c3':'--steps 10 --warmup 2','c4':'--steps 4 --warmup 1','c5':'--steps 2 --warmup 1'}['$arg'])")
-      PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --config $arg --no-cpu-baseline --no-parity --layer-table 0 --event-launches 0 --preheat-ms 20 $steps" \
+      PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --config $arg --also none --no-cpu-baseline --no-parity --layer-table 0 --event-launches 0 --preheat-ms 20 --repeats 1 $steps" \
         timeout 1500 tools/profile_gpu.sh "${TAG}_$arg" > "$O/profile_$arg.log" 2>&1
       grep "derived" -A30 "$O/profile_$arg.log" | cut -c1-240 | head -34 ;;
     profx) # profx:<name>:<command, '+' for blanks>: kernel trace + PMC passes of an arbitrary command (e.g. one layer through tools/bench_layers.py)

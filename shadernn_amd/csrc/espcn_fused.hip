@@ -330,16 +330,25 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
     }
     store_input();
 
-    float a1[KS1];
+    // 5x5: the 7th K step would carry ONE tap (row 4, column 4) in a 4-deep MFMA -- 32 pipe cycles for 64 useful FMAs per lane group.  That tap goes
+    // to the VALU instead: every lane reads the input value under its own pixel and adds w[oc][24] * x to its four accumulators (4 FMAs, ~10 cycles)
+    #ifdef SNNHIP_ESPCN_TAP25_MFMA // experiment builds (tools/exp_one.sh): the round-3 form, all 7 steps on the matrix pipe
+    constexpr bool kValuTap = false;
+#else
+    constexpr bool kValuTap = K1 == 5;
+#endif
+    constexpr int KSM = kValuTap ? KS1 - 1 : KS1; // K steps on the matrix pipe
+    float a1[KSM];
 #pragma unroll
-    for (int s = 0; s < KS1; ++s) a1[s] = wA1[s * 64 + lane];
-    float sc1[4], sh1[4], sc2[4], sh2[4];
+    for (int s = 0; s < KSM; ++s) a1[s] = wA1[s * 64 + lane];
+    float sc1[4], sh1[4], sc2[4], sh2[4], w24[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         sc1[r] = ep1[(4 * g + r) * 2];
         sh1[r] = ep1[(4 * g + r) * 2 + 1];
         sc2[r] = ep2[(4 * g + r) * 2];
         sh2[r] = ep2[(4 * g + r) * 2 + 1];
+        w24[r] = kValuTap ? wA1[(KS1 - 1) * 64 + 4 * g + r] : 0.0f; // step 6 holds w[oc][24] at lane oc (its lane group 0)
     }
     const int rowTap = (g < K1 ? g : 0) * INP; // K-steps s < K1: tap row g (invalid g: zero weight, any initialised row)
     const int lastTap = 4 * INP + g;           // K-steps s >= K1 (K1 == 5): tap row 4, col g (+4)
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
     // [wv*GPW, wv*GPW+GPW), two per iteration (two independent MFMA chains).  The LDS operands of iteration it+1 are
     // fetched before the MFMAs of iteration it (the loop is fully unrolled, so this is register renaming, not copies).
     {
-        float bv[2][U][KS1];
+        float bv[2][U][KS1]; // (5x5: slot KS1 - 1 holds the input value of the VALU tap)
         int rr[2][U], cc[2][U];
         bool valid[2][U];
         auto fetch = [&](int it, int buf) {
@@ -374,7 +383,8 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
                 const float* src = s_in + rr[buf][u] * INP + cc[buf][u];
                 const float* srcRow = src + rowTap;
 #pragma unroll
-                for (int s = 0; s < KS1; ++s) bv[buf][u][s] = s < K1 ? srcRow[s] : src[lastTap + 4 * (s - K1)];
+                for (int s = 0; s < KSM; ++s) bv[buf][u][s] = s < K1 ? srcRow[s] : src[lastTap + 4 * (s - K1)];
+                if (kValuTap) bv[buf][u][KS1 - 1] = src[4 * INP + 4]; // tap (4, 4) under this lane's pixel, whatever its lane group
             }
         };
         fetch(0, 0);
@@ -386,9 +396,15 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
 #pragma unroll
             for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], bv[cur][u][0], f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
 #pragma unroll
-            for (int s = 1; s < KS1; ++s)
+            for (int s = 1; s < KSM; ++s)
 #pragma unroll
                 for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bv[cur][u][s], acc[u], 0, 0, 0);
+            if (kValuTap) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[u][k] = fmaf(w24[k], bv[cur][u][KS1 - 1], acc[u][k]);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 float4 o;
@@ -1164,7 +1180,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             {
                 const double tiles = static_cast<double>(st.a.tilesX) * st.a.tilesY * g0.N;
                 const int c1px = (aTW + 2) * (aTH + 2);
-                const double conv1 = st.wino ? 4.0 * (((((c1px + 15) / 16) + 3) / 4 + 1) / 2 * 2) * wino_conv1_ksteps(K1) : ((c1px + 15) / 16) * ks1;
+                const double conv1 = st.wino ? 4.0 * (((((c1px + 15) / 16) + 3) / 4 + 1) / 2 * 2) * (wino_conv1_ksteps(K1) - (K1 == 5 ? 1 : 0)) : ((c1px + 15) / 16) * ks1; // (5x5: the 25th tap runs on the VALU)
                 const double conv2 = st.wino ? (aTW / 2) * (aTH / 2) / 16 * 64.0 : aTW * aTH / 16 * 36.0;
                 mfmaFlops = tiles * (conv1 + conv2) * 2048.0;
             }

@@ -59,6 +59,8 @@ int snn_model_detections(snn_model* m, float* rows6, int max_rows);         /* Y
 int snn_model_upload_input_u8(snn_model* m, const unsigned char* pixels, int w, int h, int channels, const float means[4], const float norms[4],
                               const float resize_means[4], const float resize_norms[4]);
 int snn_model_num_stages(snn_model* m);
+/* *fused_away: bit 0 = the stage's work moved into a later stage's fused plan; bit 1 = the stage is issued on the side stream beside the
+ * previous launching stage (SNN_BRANCH_OVERLAP=1) */
 int snn_model_stage_info(snn_model* m, int stage, char* name, int name_len, int hwc[3], int* fused_away);
 int snn_model_download_stage(snn_model* m, int stage, float* nhwc);
 int snn_model_describe(snn_model* m, char* buf, int buflen);

@@ -88,6 +88,15 @@ int snnhip_ctx_create_on_stream(int device, void* hip_stream, snnhip_ctx** out);
 int snnhip_ctx_destroy(snnhip_ctx* ctx);
 int snnhip_ctx_info(snnhip_ctx* ctx, snnhip_device_info* info);
 void* snnhip_ctx_stream(snnhip_ctx* ctx);
+/* Two independent operators side by side (MI355X-side design; the reference records one command buffer on one queue,
+ * vulkanBackend.cpp:80-95).  snnhip_ctx_fork: the context's SIDE stream (created on first use) waits for everything enqueued on the main stream
+ * so far, and every plan run on this context goes to the side stream until snnhip_ctx_main switches back (the side work keeps running);
+ * snnhip_ctx_join makes the main stream wait for the side stream's work.  Valid inside a graph capture (the side stream joins the
+ * capture through the fork event and must be joined before the capture ends).  Used by the host mirror for residual-block pairs such as
+ * ResNet's 3x3 stride-2 convolution and the 1x1 stride-2 downsample that read the same tensor. */
+int snnhip_ctx_fork(snnhip_ctx* ctx);
+int snnhip_ctx_main(snnhip_ctx* ctx);
+int snnhip_ctx_join(snnhip_ctx* ctx);
 int snnhip_sync(snnhip_ctx* ctx);
 const char* snnhip_last_error(void);
 const char* snnhip_version(void);

@@ -103,6 +103,9 @@ SIGNATURES = {
     "snnhip_ctx_destroy": (C.c_int, [_P]),
     "snnhip_ctx_info": (C.c_int, [_P, C.POINTER(DeviceInfo)]),
     "snnhip_ctx_stream": (_P, [_P]),
+    "snnhip_ctx_fork": (C.c_int, [_P]),
+    "snnhip_ctx_main": (C.c_int, [_P]),
+    "snnhip_ctx_join": (C.c_int, [_P]),
     "snnhip_sync": (C.c_int, [_P]),
     "snnhip_last_error": (C.c_char_p, []),
     "snnhip_version": (C.c_char_p, []),
@@ -256,6 +259,17 @@ class Context:
 
     def stream(self):
         return lib().snnhip_ctx_stream(self.h)
+
+    def fork(self):
+        """plans run from now on go to the context's side stream (it first waits for the main stream's work so far)"""
+        check(lib().snnhip_ctx_fork(self.h))
+
+    def main(self):
+        check(lib().snnhip_ctx_main(self.h))
+
+    def join(self):
+        """back on the main stream, which waits for the side stream's work"""
+        check(lib().snnhip_ctx_join(self.h))
 
     def close(self):
         if self.h:

@@ -309,6 +309,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool own, snnhip_ct
     } else {
         ctx->stream = stream;
     }
+    ctx->mainStream = ctx->stream;
     *out = ctx;
     return SNNHIP_OK;
 }
@@ -319,8 +320,43 @@ int snnhip_ctx_create_on_stream(int device, void* hip_stream, snnhip_ctx** out) 
     return ctx_create_common(device, static_cast<hipStream_t>(hip_stream), false, out);
 }
 
+int snnhip_ctx_fork(snnhip_ctx* ctx) {
+    SNNHIP_REQUIRE(ctx, "ctx_fork: null ctx");
+    SNNHIP_REQUIRE(ctx->stream == ctx->mainStream, "ctx_fork: already on the side stream");
+    if (!ctx->sideStream) {
+        SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));
+        SNNHIP_CHECK_HIP(hipStreamCreateWithFlags(&ctx->sideStream, hipStreamNonBlocking));
+        SNNHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->forkEvent, hipEventDisableTiming));
+        SNNHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->joinEvent, hipEventDisableTiming));
+    }
+    SNNHIP_CHECK_HIP(hipEventRecord(ctx->forkEvent, ctx->mainStream));
+    SNNHIP_CHECK_HIP(hipStreamWaitEvent(ctx->sideStream, ctx->forkEvent, 0));
+    ctx->stream = ctx->sideStream;
+    return SNNHIP_OK;
+}
+
+int snnhip_ctx_main(snnhip_ctx* ctx) {
+    SNNHIP_REQUIRE(ctx, "ctx_main: null ctx");
+    ctx->stream = ctx->mainStream;
+    return SNNHIP_OK;
+}
+
+int snnhip_ctx_join(snnhip_ctx* ctx) {
+    SNNHIP_REQUIRE(ctx && ctx->sideStream, "ctx_join: nothing was forked");
+    ctx->stream = ctx->mainStream;
+    SNNHIP_CHECK_HIP(hipEventRecord(ctx->joinEvent, ctx->sideStream));
+    SNNHIP_CHECK_HIP(hipStreamWaitEvent(ctx->mainStream, ctx->joinEvent, 0));
+    return SNNHIP_OK;
+}
+
 int snnhip_ctx_destroy(snnhip_ctx* ctx) {
     if (!ctx) return SNNHIP_OK;
+    ctx->stream = ctx->mainStream;
+    if (ctx->sideStream) {
+        (void) hipStreamDestroy(ctx->sideStream);
+        (void) hipEventDestroy(ctx->forkEvent);
+        (void) hipEventDestroy(ctx->joinEvent);
+    }
     if (ctx->ownsStream && ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
     return SNNHIP_OK;
@@ -355,13 +391,13 @@ int snnhip_sync(snnhip_ctx* ctx) {
     if (spinUs > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
-            const hipError_t q = hipStreamQuery(ctx->stream);
+            const hipError_t q = hipStreamQuery(ctx->mainStream);
             if (q == hipSuccess) return SNNHIP_OK;
             if (q != hipErrorNotReady) SNNHIP_CHECK_HIP(q);
             if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spinUs) break;
         }
     }
-    SNNHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    SNNHIP_CHECK_HIP(hipStreamSynchronize(ctx->mainStream)); // (side-stream work is joined into the main stream by snnhip_ctx_join)
     return SNNHIP_OK;
 }
 
@@ -369,14 +405,14 @@ int snnhip_sync(snnhip_ctx* ctx) {
 
 int snnhip_graph_begin_capture(snnhip_ctx* ctx) {
     SNNHIP_REQUIRE(ctx, "graph_begin_capture: null ctx");
-    SNNHIP_CHECK_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    SNNHIP_CHECK_HIP(hipStreamBeginCapture(ctx->mainStream, hipStreamCaptureModeThreadLocal));
     return SNNHIP_OK;
 }
 
 int snnhip_graph_end_capture(snnhip_ctx* ctx, snnhip_graph** out) {
     SNNHIP_REQUIRE(ctx && out, "graph_end_capture: null argument");
     hipGraph_t graph = nullptr;
-    SNNHIP_CHECK_HIP(hipStreamEndCapture(ctx->stream, &graph));
+    SNNHIP_CHECK_HIP(hipStreamEndCapture(ctx->mainStream, &graph));
     SNNHIP_REQUIRE(graph != nullptr, "graph_end_capture: the capture was invalidated (a synchronising call or profiling events inside it)");
     auto* g = new snnhip_graph();
     g->ctx = ctx;
@@ -397,7 +433,7 @@ int snnhip_graph_end_capture(snnhip_ctx* ctx, snnhip_graph** out) {
 
 int snnhip_graph_launch(snnhip_graph* g) {
     SNNHIP_REQUIRE(g && g->exec, "graph_launch: null graph");
-    SNNHIP_CHECK_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
+    SNNHIP_CHECK_HIP(hipGraphLaunch(g->exec, g->ctx->mainStream));
     return SNNHIP_OK;
 }
 

@@ -87,9 +87,11 @@ inline int conv_out_dim(int in, int kernel, int stride, int padA, int padB) {
 
 struct snnhip_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; // where plans launch: the main stream, or the side stream between snnhip_ctx_fork and snnhip_ctx_main
     bool ownsStream = false;
     hipDeviceProp_t props;
+    hipStream_t mainStream = nullptr, sideStream = nullptr;
+    hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
 };
 
 struct snnhip_tensor {

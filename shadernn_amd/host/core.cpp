@@ -146,9 +146,7 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
             recordingNow = backend->beginRecord();
         }
     }
-    for (size_t i = 0; i < stages.size() && !replayed; i++) {
-        auto& s = stages[i];
-        if (s.layer->isInputLayer) continue;
+    auto runStage = [&](RenderStage& s) {
         for (size_t n = 0; n < s.delayBindMask.size(); ++n) {
             if (s.delayBindMask[n] > 0) s.stageInputs[n].attach(&(*rp.inputImages)[static_cast<size_t>(s.inputIds[n])]); // core.cpp:127-133
         }
@@ -161,6 +159,30 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
             s.layer->imageTextureFunPtr(s.stageInputs, s.stageOutputs);
         }
         if (s.timer) s.timer->stop();
+    };
+    const bool sideBySide = !cp.profiling && !cp.dumpOutputs; // per-stage timers and dumps want one stream and the reference's order
+    for (size_t i = 0; i < stages.size() && !replayed; i++) {
+        auto& s = stages[i];
+        if (s.layer->isInputLayer) continue;
+        if (s.fusedAway) { // its pass is skipped, but a model input may be bound through it (the fused plan of a later stage reads that slot)
+            runStage(s);
+            continue;
+        }
+        // HIP extension: the next launching stage is independent of this one (HipBackend::finalizeStages) -> it goes to the side stream first, this one
+        // runs on the main stream beside it, and the main stream waits for both before the stage that consumes them
+        size_t j = i + 1;
+        while (j < stages.size() && (stages[j].layer->isInputLayer || stages[j].fusedAway)) ++j;
+        if (sideBySide && j < stages.size() && stages[j].sideOfPrevious && backend->forkSide()) {
+            for (size_t m = i + 1; m < j; ++m)
+                if (!stages[m].layer->isInputLayer) runStage(stages[m]); // (fused-away stages in between: input binding only, nothing is launched)
+            runStage(stages[j]);
+            backend->backToMain();
+            runStage(s);
+            backend->joinSide();
+            i = j;
+            continue;
+        }
+        runStage(s);
     }
     if (recordingNow) { // the loop above only recorded: submit it now
         if (!backend->endRecord() || !backend->replay()) SNN_RIP("hipGraph capture of the inference failed: %s", snnhip_last_error());

@@ -64,6 +64,11 @@ public:
     virtual bool endRecord() { return false; }
     virtual bool replay() { return false; }
     virtual void dropRecording() {}
+    // HIP extension: two independent stages side by side.  forkSide: what runs next goes to a second stream that starts behind the work enqueued
+    // so far; backToMain: what runs next goes to the main stream again; joinSide: the main stream waits for the side stream.
+    virtual bool forkSide() { return false; }
+    virtual void backToMain() {}
+    virtual void joinSide() {}
 };
 
 class HipRenderPass : public RenderPass {
@@ -94,6 +99,9 @@ public:
     bool endRecord() override;
     bool replay() override;
     void dropRecording() override;
+    bool forkSide() override;
+    void backToMain() override;
+    void joinSide() override;
 
 private:
     snnhip_ctx* ctx;

@@ -28,6 +28,10 @@ struct RenderStage {
     std::vector<int> inputIds;
     std::vector<int> delayBindMask;
     bool fusedAway = false; // HIP extension: this stage's work is done by the fused plan of a later stage (HipBackend::finalizeStages)
+    // HIP extension (HipBackend::finalizeStages): this stage and the previous launching stage read only tensors produced earlier -- two
+    // branches of a residual block (ResNet: the 3x3 stride-2 convolution and the 1x1 stride-2 downsample of the same input).  run() issues this
+    // one on the backend's side stream next to the previous one instead of behind it (DeviceBackend::forkSide / joinSide).
+    bool sideOfPrevious = false;
 };
 typedef std::vector<RenderStage> RenderStagesArray;
 

@@ -313,3 +313,31 @@ def test_c5_candy_720p_fp16_microbatch16_default_switches_through_host(ctx, tmp_
     y2 = m(x2)
     check(y2, x2, (7,))
     m.close()
+
+
+def test_c3_residual_branches_side_by_side_give_the_same_result(ctx, tmp_path, monkeypatch):
+    """SNN_BRANCH_OVERLAP=1 (host mirror, opt-in): the 1x1 stride-2 downsample of a ResNet stage entry is issued on the context's side stream
+    (snnhip_ctx_fork / _main / _join) beside the 3x3 stride-2 convolution that reads the same tensor -- in the recorded hipGraph as well.  Same
+    bits as the one-stream order, on a batch of 4 at 224x224, first run (record), replay and launch-by-launch."""
+    from shadernn_amd import host, models
+
+    net = models.resnet18(seed=1)
+    H = W = 224
+    path = models.write_json(net, W, H, str(tmp_path / "resnet18.json"), bin_weights=True)
+    x = np.random.default_rng(31).random((4, H, W, 3), dtype=np.float32)
+    plain = host.Model(path, W, H, 3, device=0, capture_graph=True, batch=4)
+    want = np.asarray(plain(x)).copy()
+    plain.close()
+    monkeypatch.setenv("SNN_BRANCH_OVERLAP", "1")
+    monkeypatch.setenv("SNN_LOG_LEVEL", "3")
+    m = host.Model(path, W, H, 3, device=0, capture_graph=True, batch=4)
+    got = np.asarray(m(x)).copy()                   # record + launch
+    np.testing.assert_array_equal(got, want)
+    m.run()                                          # replay of the two-stream graph
+    np.testing.assert_array_equal(np.asarray(m.output()), want)
+    m.suspend_replay(True)
+    m.run()                                          # launch by launch, events between the streams
+    np.testing.assert_array_equal(np.asarray(m.output()), want)
+    sides = [s for s in m.stages() if s.get("side")]
+    assert len(sides) == 3, [s["name"] for s in m.stages()]   # l2_b0_down, l3_b0_down, l4_b0_down
+    m.close()

@@ -1279,7 +1279,8 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             i += 3;
             ++fusedCount;
         } else if (snnhip_plan* dwpw = nullptr; i + 1 < n && c0 && c1 && c0->depthwise && !c1->depthwise &&
-                                         make_irb_plan(ctx, nullptr, plans[i], plans[i + 1], nullptr, &dwpw) == SNNHIP_OK) {
+                                         (make_dwpw_march_plan(ctx, plans[i], plans[i + 1], &dwpw) == SNNHIP_OK || // (large stride-1 maps: the row-marching streaming form)
+                                          make_irb_plan(ctx, nullptr, plans[i], plans[i + 1], nullptr, &dwpw) == SNNHIP_OK)) {
             // ---- rule G without an expand layer: DepthwiseConv2D 3x3 -> Conv2D 1x1 (MobileNetV2's first block) -> the same kernel, its hidden slice is the x tile
             chain->owned.push_back(dwpw);
             st.kind = ChainPlan::PLAIN;

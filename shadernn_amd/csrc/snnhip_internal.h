@@ -228,6 +228,8 @@ bool chain_adopt_plan(snnhip_plan* chain, snnhip_plan* p); // the chain deletes 
 // irb_fused.hip (chain rule G): Conv2D 1x1 -> DepthwiseConv2D 3x3 -> Conv2D 1x1 [-> Add with the block input] as one kernel; the plans are only read
 int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan, snnhip_plan* projectPlan, snnhip_plan* addPlan, snnhip_plan** out,
                   snnhip_plan* stemPlan = nullptr);
+// dwpw_march.hip (chain rule G without an expand layer, large maps): DepthwiseConv2D 3x3 stride 1 -> Conv2D 1x1 as one row-marching streaming kernel; the plans are only read
+int make_dwpw_march_plan(snnhip_ctx* ctx, snnhip_plan* dwPlan, snnhip_plan* pwPlan, snnhip_plan** out);
 
 // espcn_stream.hip: the whole ESPCN pattern in one launch (rule C of the chain planner); cfg is an opaque blob
 constexpr size_t kStreamCfgBytes = 160;

@@ -225,3 +225,63 @@ def test_stem_depthwise_pointwise_runs_as_one_kernel(ctx, case, monkeypatch):
     two = snn.chain_plan(ctx, [ps, pd, pp])
     assert two.num_steps() == 2 and "stem conv3x3" not in two.describe(), two.describe()
     np.testing.assert_allclose(two(xt).numpy(), got, rtol=2e-5, atol=2e-5)
+
+
+# N, H, W, C, Co, depthwise activation, pointwise activation
+MARCH_CASES = [(2, 112, 112, 32, 16, "relu6", ""),       # MobileNetV2's first block (one 16-pixel group per compute wave)
+               (1, 112, 112, 32, 16, "relu6", ""),       # one image: 14 row runs of 8 rows, the runs' halo rows come from the neighbouring runs' rows
+               (1, 45, 37, 16, 24, "relu6", "relu"),     # ragged width (3 groups, the last one 5 pixels), two output blocks with 8 live channels in the second
+               (3, 30, 70, 32, 8, "", "leakyRelu"),      # half an output block
+               (1, 9, 128, 32, 32, "relu", ""),          # 8 groups on 7 compute waves, 20 DMA pieces per row
+               (2, 2, 19, 16, 4, "relu6", ""),           # fewer rows than the loader keeps in flight
+               (1, 1, 16, 32, 16, "", "")]               # a single row
+
+
+@pytest.mark.parametrize("case", MARCH_CASES, ids=lambda c: "%dx%dx%dx%d-%d" % c[:5])
+def test_depthwise_pointwise_row_marching_kernel(ctx, case, monkeypatch):
+    """dwpw_march.hip (forced; the default takes it on large maps only): DepthwiseConv2D 3x3 stride 1 -> Conv2D 1x1 as a loader wave + seven compute
+    waves marching down the rows.  Whole output against the oracle, against the two separate layers, and against the tile kernel it replaces
+    (SNNHIP_DWPW_MARCH=0: irb_fused's no-expand mode, same inputs)."""
+    import shadernn_amd as snn
+
+    N, H, W, C, Co, a1, a2 = case
+    x = _rand((N, H, W, C), 13)
+    wd, bd, bnd = _rand((C, 3, 3), 14, 1.0 / 3.0), _rand((C,), 15, 0.1), _bn(C, 16)
+    wp, bp, bnp = _rand((Co, C, 1, 1), 17, 1.0 / np.sqrt(C)), _rand((Co,), 18, 0.1), (_bn(Co, 19) if a2 != "leakyRelu" else None)
+    pd = snn.conv2d_plan(ctx, N, H, W, wd, bd, stride=1, pads=O.padding_offsets("same", 3), act=a1, leaky=0.1, bn=bnd, depthwise=True)
+    pp = snn.conv2d_plan(ctx, N, H, W, wp, bp, act=a2, leaky=0.1, bn=bnp)
+    monkeypatch.setenv("SNNHIP_DWPW_MARCH", "1")
+    plan = snn.chain_plan(ctx, [pd, pp])
+    d = plan.describe()
+    assert plan.num_steps() == 1 and "dwpw_march_f32 [depthwise3x3 %d s1 + conv1x1 %d->%d]" % (C, C, Co) in d, d
+    xt = snn.Tensor.from_numpy(ctx, x)
+    got = plan(xt).numpy()
+    h = O.depthwise(x, wd, bd, 1, O.padding_offsets("same", 3), a1, 0.1, bnd)
+    want = O.conv2d(h, wp, bp, 1, (0, 0, 0, 0), "constant", a2, 0.1, bnp, threads=8)
+    assert got.shape == want.shape == (N, H, W, Co)
+    np.testing.assert_allclose(got, want, err_msg=d, **TOL)
+    np.testing.assert_allclose(got, pp(pd(xt)).numpy(), err_msg=d, rtol=2e-5, atol=2e-5)
+    np.testing.assert_array_equal(plan(xt).numpy(), got)   # a second run through the same ring: bit-identical
+    monkeypatch.setenv("SNNHIP_DWPW_MARCH", "0")
+    if H * W >= 28 * 28:  # (the tile kernel declines smaller maps: there the pair stays two launches)
+        tile = snn.chain_plan(ctx, [pd, pp])
+        assert "irb_fused" in tile.describe(), tile.describe()
+        np.testing.assert_allclose(got, tile(xt).numpy(), err_msg=d + " vs " + tile.describe(), rtol=2e-5, atol=2e-5)
+
+
+def test_depthwise_pointwise_default_rule_takes_the_marching_kernel_on_large_maps_only(ctx, monkeypatch):
+    import shadernn_amd as snn
+
+    monkeypatch.delenv("SNNHIP_DWPW_MARCH", raising=False)
+
+    def kind(N, H, W, C, Co, s=1):
+        wd, wp = _rand((C, 3, 3), 1), _rand((Co, C, 1, 1), 2)
+        pd = snn.conv2d_plan(ctx, N, H, W, wd, None, stride=s, pads=O.padding_offsets("same", 3), act="relu6", depthwise=True)
+        _, OH, OW, _ = pd.out_shape()
+        return snn.chain_plan(ctx, [pd, snn.conv2d_plan(ctx, N, OH, OW, wp, None)]).describe()
+
+    assert "dwpw_march" in kind(64, 112, 112, 32, 16)       # 103 MB of input: a stream
+    assert "irb_fused" in kind(2, 112, 112, 32, 16)          # 3 MB: the tile kernel
+    assert "irb_fused" in kind(64, 112, 112, 32, 16, s=2)    # stride 2 is not the marching kernel's
+    assert "irb_fused" in kind(64, 112, 112, 48, 16)         # nor are 48 channels
+    assert "irb_fused" in kind(32, 112, 112, 64, 16)         # ... or 64 (the operands of a lane would not fit its registers)

@@ -1254,7 +1254,8 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
             i += 2;
             ++fusedCount;
         } else if (snnhip_plan* sirb = nullptr; i + 2 < n && c0 && c1 && c2 && !c0->depthwise && c0->g.kh == 3 && c0->g.IC == 3 && c1->depthwise && !c2->depthwise &&
-                                         make_irb_plan(ctx, nullptr, plans[i + 1], plans[i + 2], nullptr, &sirb, plans[i]) == SNNHIP_OK) {
+                                         (make_stem_dwpw_march_plan(ctx, plans[i], plans[i + 1], plans[i + 2], &sirb) == SNNHIP_OK || // (large maps: the row-marching form)
+                                          make_irb_plan(ctx, nullptr, plans[i + 1], plans[i + 2], nullptr, &sirb, plans[i]) == SNNHIP_OK)) {
             // ---- rule G with the network's stem as the 'expand' layer: Conv2D 3x3 (3 -> C channels) -> DepthwiseConv2D 3x3 -> Conv2D 1x1 (the head of
             // MobileNetV2) -> the same kernel, its staging gathers the 27 image values per pixel; the stem's output never reaches memory
             chain->owned.push_back(sirb);

@@ -230,6 +230,8 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
                   snnhip_plan* stemPlan = nullptr);
 // dwpw_march.hip (chain rule G without an expand layer, large maps): DepthwiseConv2D 3x3 stride 1 -> Conv2D 1x1 as one row-marching streaming kernel; the plans are only read
 int make_dwpw_march_plan(snnhip_ctx* ctx, snnhip_plan* dwPlan, snnhip_plan* pwPlan, snnhip_plan** out);
+// ... with the network's stem in front: Conv2D 3x3 stride 2 (3 -> 32 channels) -> DepthwiseConv2D 3x3 -> Conv2D 1x1 as one launch, the stem's output only ever in LDS
+int make_stem_dwpw_march_plan(snnhip_ctx* ctx, snnhip_plan* stemPlan, snnhip_plan* dwPlan, snnhip_plan* pwPlan, snnhip_plan** out);
 
 // espcn_stream.hip: the whole ESPCN pattern in one launch (rule C of the chain planner); cfg is an opaque blob
 constexpr size_t kStreamCfgBytes = 160;

@@ -285,3 +285,49 @@ def test_depthwise_pointwise_default_rule_takes_the_marching_kernel_on_large_map
     assert "irb_fused" in kind(64, 112, 112, 32, 16, s=2)    # stride 2 is not the marching kernel's
     assert "irb_fused" in kind(64, 112, 112, 48, 16)         # nor are 48 channels
     assert "irb_fused" in kind(32, 112, 112, 64, 16)         # ... or 64 (the operands of a lane would not fit its registers)
+
+
+# N, IH, IW, Co, (stem act, dw act, pw act)
+STEM_MARCH_CASES = [(2, 224, 224, 16, ("relu6", "relu6", "")),      # MobileNetV2's head (3 DMA pieces per image row, one 16-pixel group per compute wave)
+                    (1, 224, 224, 16, ("relu6", "relu6", "")),      # one image: 14 row runs, every run recomputes its two halo stem rows
+                    (1, 64, 96, 8, ("relu", "leakyRelu", "relu")),  # 2 pieces per image row, 3 groups, half an output block
+                    (3, 36, 40, 12, ("", "relu6", "")),             # ragged: 20 output columns (2 groups, the second one 4 pixels), 18 rows
+                    (1, 4, 256, 16, ("relu6", "", "")),             # 128 columns = 8 groups on 7 waves, two output rows
+                    (2, 2, 16, 4, ("relu6", "relu6", ""))]          # a single output row
+
+
+@pytest.mark.parametrize("case", STEM_MARCH_CASES, ids=lambda c: "%dx%dx%d-%d" % c[:4])
+def test_stem_depthwise_pointwise_row_marching_kernel(ctx, case, monkeypatch):
+    """stem_dwpw_march_kernel (forced; default on large maps): Conv2D 3x3 stride 2 (RGB -> 32) -> DepthwiseConv2D 3x3 -> Conv2D 1x1 as one launch, the stem's
+    output only ever in the LDS ring of stem rows.  Whole output against the oracle layer by layer, the three separate layers, and the two-launch form."""
+    import shadernn_amd as snn
+
+    N, IH, IW, Co, acts = case
+    C = 32
+    x = _rand((N, IH, IW, 3), 41)
+    ws, bs, bns = _rand((C, 3, 3, 3), 42, 1.0 / np.sqrt(27)), _rand((C,), 43, 0.1), _bn(C, 44)
+    wd, bd, bnd = _rand((C, 3, 3), 45, 1.0 / 3.0), _rand((C,), 46, 0.1), _bn(C, 47)
+    wp, bp, bnp = _rand((Co, C, 1, 1), 48, 1.0 / np.sqrt(C)), _rand((Co,), 49, 0.1), _bn(Co, 50)
+    same = O.padding_offsets("same", 3)
+    ps = snn.conv2d_plan(ctx, N, IH, IW, ws, bs, stride=2, pads=same, act=acts[0], leaky=0.1, bn=bns)
+    _, H, W, _ = ps.out_shape()
+    assert (H, W) == (IH // 2, IW // 2)
+    pd = snn.conv2d_plan(ctx, N, H, W, wd, bd, stride=1, pads=same, act=acts[1], leaky=0.1, bn=bnd, depthwise=True)
+    pp = snn.conv2d_plan(ctx, N, H, W, wp, bp, act=acts[2], leaky=0.1, bn=bnp)
+    monkeypatch.setenv("SNNHIP_DWPW_MARCH", "1")
+    plan = snn.chain_plan(ctx, [ps, pd, pp])
+    d = plan.describe()
+    assert plan.num_steps() == 1 and "stem_dwpw_march_f32 [stem conv3x3 s2 3->32 + depthwise3x3 32 s1 + conv1x1 32->%d]" % Co in d, d
+    xt = snn.Tensor.from_numpy(ctx, x)
+    got = plan(xt).numpy()
+    h = O.conv2d(x, ws, bs, 2, same, "constant", acts[0], 0.1, bns, threads=8)
+    dd = O.depthwise(h, wd, bd, 1, same, acts[1], 0.1, bnd)
+    want = O.conv2d(dd, wp, bp, 1, (0, 0, 0, 0), "constant", acts[2], 0.1, bnp, threads=8)
+    assert got.shape == want.shape == (N, H, W, Co)
+    np.testing.assert_allclose(got, want, err_msg=d, **TOL)
+    np.testing.assert_allclose(got, pp(pd(ps(xt))).numpy(), err_msg=d, rtol=2e-5, atol=2e-5)
+    np.testing.assert_array_equal(plan(xt).numpy(), got)
+    monkeypatch.setenv("SNNHIP_STEM_MARCH", "0")   # the stem as its own launch, the pair still marching
+    two = snn.chain_plan(ctx, [ps, pd, pp])
+    assert two.num_steps() == 2 and "dwpw_march_f32" in two.describe() and "stem_dwpw" not in two.describe(), two.describe()
+    np.testing.assert_allclose(two(xt).numpy(), got, err_msg=d, rtol=2e-5, atol=2e-5)

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace snnhip {
 namespace {
@@ -36,6 +37,7 @@ struct StreamParams {
     int stride, W, HW, OW, OHW; // stride > 1 (ResNet's 1x1 s2 downsample convolutions): output row -> input pixel (n, s*oy, s*ox); HW = H*W, OHW = OH*OW
     const float* res; // fused residual Add (chain rule E), set per launch
     ActCfg ac2;
+    int segTiles; // conv1x1_march_kernel (round 4): 32-pixel tiles per block segment
 };
 
 // kDepth = activation chunks (8 channels = 16 bytes per lane each) in flight per lane: 4 next to 48 accumulators, 8 for the one-column
@@ -228,6 +230,175 @@ __global__ __launch_bounds__(64 * kStreamWaves) void conv1x1_stream_kernel(Strea
 #endif
 }
 
+// s_waitcnt vmcnt(n) for a compile-time n (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+#ifdef SNNHIP_M1_TRACE // experiment builds (tools/exp_one.sh): one block prints the s_memtime stamps of its phases
+#define M1_MARK(i) do { if (mtrace || ((i) == 4 && mtotal_pre)) mstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define M1_MARK(i) do { } while (0)
+#endif
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_n() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+// conv1x1_march_kernel (round 4) -- the WIDENING pointwise layers (MobileNetV2's expand convolutions 64 -> 384, 96 -> 576, 160 -> 960 at batch 256: 0.44 of
+// their roofline on the kernel above, whose waves each load their own activations, wait for them, multiply, and then spend as long again in a 48-store
+// epilogue during which they request nothing).  Same arithmetic, same packed weights, other roles:
+//   * a block is PERSISTENT on one 96-channel output block and a run of 32-pixel tiles: its weight slice [IC][96] goes to LDS ONCE (the kernel above
+//     re-stages it for every 128 / 256 pixels: 86 MB of L2 -> LDS traffic next to 115 MB of output on 96 -> 576);
+//   * ONE LOADER wave copies the activation tiles of the NEXT step into an LDS ring with global_load_lds_dwordx4 while the compute waves work on this
+//     step's (rows IC / 4 + 1 16-byte slots apart -- odd -- so the 32 rows of an operand read fall into different bank groups); it never stores, so its
+//     vmcnt counts loads only;
+//   * 3 TS COMPUTE waves: wave (tile ts, column tile u) multiplies tile ts by the 32 output channels u of the slice -- 16 accumulators, both operands
+//     one ds_read_b128 per 8-channel chunk -- and stores its 32 x 32 result, one 128-byte pixel run per half wave and accumulator; three waves per SIMD
+//     interleave K loops and epilogues;
+//   * one s_barrier per step (TS tiles).
+template <int TS, int PI, int EPI /* 0: any activation; 1: none / relu / relu6 / leakyRelu; 2: those without the leaky slope */>
+__global__ __launch_bounds__(64 * (3 * TS + 1), (3 * TS + 4) / 4) void conv1x1_march_kernel(StreamParams p, ActCfg ac, const float* __restrict__ x, const float4* __restrict__ wp,
+                                                                                             const float4* __restrict__ epi, float* __restrict__ y) {
+    extern __shared__ float4 s_w[]; // [nChunks][2][96] weights, then the ring: 2 halves x TS tiles x (PI * 64) slots
+    constexpr int BN = 96, NCW = 3 * TS, kTileSlots = PI * 64;
+    static_assert(TS * PI <= 63, "one step of tiles in flight: vmcnt is a 6-bit counter");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5; // (wave: a scalar for the compiler)
+    const int n0 = blockIdx.y * BN;
+    const int SP = p.IC / 4 + 1; // 16-byte slots per pixel row of a tile (the last one padding: IC / 4 is even, the row pitch odd)
+    float4* const ringp = s_w + p.nChunks * 2 * BN;
+    const int t0 = blockIdx.x * p.segTiles, t1 = min(p.nTiles, t0 + p.segTiles);
+    const int steps = (t1 - t0 + TS - 1) / TS;
+    if (steps <= 0) return; // (block-uniform)
+#ifdef SNNHIP_M1_TRACE
+    const bool mtrace = blockIdx.x == 10 && blockIdx.y == 1 && lane == 0 && (wave == 0 || wave == 5 || wave == NCW);
+    unsigned long long mstamp[5] = {};
+    const bool mtotal_pre = true;
+    M1_MARK(4);
+    const unsigned long long mwall0 = wall_clock64();
+    const bool mtotal = (blockIdx.x % 20 == 3) && lane == 0 && wave == 0; // un-perturbed blocks: whole-block cycles and the 100 MHz wall clock beside them
+#endif
+
+    if (wave == NCW) { // ---- loader
+        // per lane and copy: the byte offset of its 16 bytes inside a tile's 32 x IC block.  The lanes of the padding slot of a row (and those past the 32 rows in
+        // the last copy) re-read the tile's first 16 bytes: no compute wave reads what they write, and the copy then needs neither an exec mask nor a
+        // select -- the loader's steady state is SALU + the copies themselves.
+        unsigned voff[PI];
+#pragma unroll
+        for (int k = 0; k < PI; ++k) {
+            const int e = 64 * k + lane, row = e / SP, sl = e - row * SP;
+            voff[k] = (row < 32 && sl < SP - 1) ? static_cast<unsigned>(row * p.IC + sl * 4) * 4u : 0u;
+        }
+        const unsigned ringLds = lds_byte_addr(ringp);
+        auto issue_step = [&](int st) {
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                const int tile = t0 + st * TS + ts; // (wave-uniform)
+                if (tile >= t1) break;
+                const float* xt = x + static_cast<size_t>(tile) * 32 * p.IC;
+                const unsigned dst = ringLds + static_cast<unsigned>(((st & 1) * TS + ts) * kTileSlots) * 16u;
+                if (tile * 32 + 32 <= p.M) {
+#pragma unroll
+                    for (int k = 0; k < PI; ++k) lds_dma16_sbase(xt, voff[k], dst + 1024u * k);
+                } else { // the tensor's last, partial tile: rows past the end re-read the tile's first bytes (their results are not stored)
+                    const int lastRow = p.M - 1 - tile * 32;
+#pragma unroll
+                    for (int k = 0; k < PI; ++k) lds_dma16_sbase(xt, (64 * k + lane) / SP <= lastRow ? voff[k] : 0u, dst + 1024u * k);
+                }
+            }
+        };
+        issue_step(0);
+        for (int st = 0; st < steps; ++st) {
+            M1_MARK(0);
+            wait_vmcnt_n<0>();
+            M1_MARK(1);
+            __syncthreads(); // step st is published; every compute wave has left step st - 1 (whose half of the ring step st + 1 overwrites)
+            M1_MARK(2);
+            if (st + 1 < steps) issue_step(st + 1);
+            M1_MARK(3);
+#ifdef SNNHIP_M1_TRACE
+            if (mtrace && st >= 2 && st < 5)
+                printf("m1 loader st %d: wait-loads %llu barrier %llu issue %llu\n", st, mstamp[1] - mstamp[0], mstamp[2] - mstamp[1], mstamp[3] - mstamp[2]);
+#endif
+        }
+        wait_vmcnt_n<0>();
+        return;
+    }
+
+    // ---- compute waves: the weight slice once, then one tile x 32 channels per step
+    {
+        const int cnt = p.nChunks * 2 * BN;
+        const float4* src = wp + static_cast<size_t>(blockIdx.y) * cnt;
+        for (int i0 = tid; i0 < cnt; i0 += 64 * NCW * 4) {
+            float4 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = src[min(i0 + 64 * NCW * j, cnt - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + 64 * NCW * j < cnt) s_w[i0 + 64 * NCW * j] = t[j];
+        }
+    }
+    const int ts = wave / 3, u = wave - 3 * ts;
+    const float4 e = epi[n0 + u * 32 + l32];
+    const float4* const bop = s_w + h * BN + u * 32 + l32; // + chunk * 2 * BN
+    for (int st = 0; st < steps; ++st) {
+        M1_MARK(0);
+        __syncthreads();
+        M1_MARK(1);
+        const int tile = t0 + st * TS + ts;
+        if (tile >= t1) continue; // (wave-uniform; the barrier of the next step is at the loop top)
+        const float4* const aop = ringp + ((st & 1) * TS + ts) * kTileSlots + l32 * SP + h; // + 2 * chunk
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        float4 a = aop[0], b = bop[0];
+        for (int c = 0; c < p.nChunks; ++c) { // the next chunk's operands are on their way while this chunk's four MFMAs issue
+            const int cn = min(c + 1, p.nChunks - 1);
+            const float4 an = aop[2 * cn], bn = bop[cn * 2 * BN];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            a = an;
+            b = bn;
+        }
+        M1_MARK(2);
+        // epilogue: bias -> BN -> activation, ONE 4-byte store per accumulator: a half wave's lanes are 32 channels of one pixel (128 contiguous bytes, a whole
+        // line), the row base is scalar and the lane offset a constant, so a store costs no VALU instruction.  (The quad-transposed 16-byte stores of
+        // conv1x1_stream_kernel cost 4 VALU per value here: 64 of a wave's 176 epilogue instructions, on the pipe the MFMAs need.  36.0 vs 37.9 us on 64 -> 384.)
+        {
+            const unsigned vo = static_cast<unsigned>(4 * h * p.OC + u * 32 + l32) * 4u;
+            float* const yt = y + static_cast<size_t>(tile) * 32 * p.OC + n0;
+            auto value = [&](int i, auto bnTag) -> float {
+                float t = acc[i] + e.x;
+                if (decltype(bnTag)::value) t = (e.y * (t - e.z)) + e.w; // (epi_affine)
+                if (EPI == 2) return __builtin_amdgcn_fmed3f(t, ac.lo, ac.hi); // alpha == 1: apply_act<true>'s fmaxf(t, t * 1) is t
+                return EPI == 1 ? apply_act<true>(ac, t, 0.0f) : epi_act(ac.act, ac.leaky, t, 0.0f);
+            };
+            auto emit = [&](auto bnTag) {
+                if (tile * 32 + 32 <= p.M) { // (wave-uniform)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) store_dword_sbase(yt + static_cast<size_t>(8 * (i >> 2) + (i & 3)) * p.OC, vo, value(i, bnTag));
+                } else { // the tensor's last, partial tile
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int r = 8 * (i >> 2) + (i & 3);
+                        if (tile * 32 + r + 4 * h < p.M) yt[static_cast<size_t>(r) * p.OC + (vo >> 2)] = value(i, bnTag);
+                    }
+                }
+            };
+            if (p.useBN) emit(std::true_type{});
+            else emit(std::false_type{});
+        }
+        M1_MARK(3);
+#ifdef SNNHIP_M1_TRACE
+        if (mtotal && st == steps - 1)
+            printf("m1 block (%d,%d) total: %llu cycles, %llu wall ticks (100 MHz), steps %d\n", blockIdx.x, blockIdx.y, __builtin_readcyclecounter() - mstamp[4],
+                   wall_clock64() - mwall0, steps);
+        if (mtrace && st >= 2 && st < 5)
+            printf("m1 wave %d st %d: barrier %llu k-loop %llu epilogue %llu (steps %d, block start->now %llu)\n", wave, st, mstamp[1] - mstamp[0], mstamp[2] - mstamp[1], mstamp[3] - mstamp[2], steps,
+                   mstamp[3] - mstamp[4]);
+#endif
+    }
+}
+
 // fp16 tensors (half storage, fp32 accumulation on v_mfma_f32_32x32x16_f16): a chunk is 16 channels, lane (row, h) loads the 16 bytes
 // x[row][16c + 8h .. +7] and ONE MFMA consumes them.  A lane's results are single halfs of 16 different pixels; written directly they would
 // leave as 2-byte stores in 64-byte runs, so every wave transposes its 32 x BN tile through its own LDS region (no block barrier: the wave
@@ -384,6 +555,17 @@ decltype(Conv1x1StreamPlan::kernel) pick(bool simple, int waves) {
     if (waves == 8) return simple ? conv1x1_stream_kernel<NT, true, 8> : conv1x1_stream_kernel<NT, false, 8>;
     return simple ? conv1x1_stream_kernel<NT, true, 4> : conv1x1_stream_kernel<NT, false, 4>;
 }
+// conv1x1_march_kernel instantiation for `pieces` 1 KB DMA pieces per 32-pixel tile: four tiles per step where that is at most 63 pieces and the ring fits, else two
+decltype(Conv1x1StreamPlan::kernel) pick_march(int pieces, int epi, int* TS, int* PI) {
+#define SNNHIP_MARCH(T, P) (*TS = T, *PI = P, epi == 2 ? conv1x1_march_kernel<T, P, 2> : epi == 1 ? conv1x1_march_kernel<T, P, 1> : conv1x1_march_kernel<T, P, 0>)
+    if (pieces <= 5) return SNNHIP_MARCH(4, 5);
+    if (pieces <= 9) return SNNHIP_MARCH(4, 9);
+    if (pieces <= 13) return SNNHIP_MARCH(4, 13);
+    if (pieces <= 17) return SNNHIP_MARCH(2, 17);
+    if (pieces <= 21) return SNNHIP_MARCH(2, 21);
+#undef SNNHIP_MARCH
+    return nullptr;
+}
 template <int NT>
 decltype(Conv1x1StreamPlan::kernel) pick16(bool simple) {
     return simple ? conv1x1_stream_f16_kernel<NT, true> : conv1x1_stream_f16_kernel<NT, false>;
@@ -464,8 +646,35 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
         if (!f16 && (atoi(wv) == 4 || atoi(wv) == 8)) waves = atoi(wv);
     plan->waves = waves;
     if (!f16) plan->kernel = NT == 3 ? pick<3>(simple, waves) : NT == 2 ? pick<2>(simple, waves) : pick<1>(simple, waves);
-    const int gx = (nTiles + waves - 1) / waves; // one 32-pixel tile per wave
+    int gx = (nTiles + waves - 1) / waves; // one 32-pixel tile per wave
     plan->grid = dim3(gx, ocBlocks);
+    // ---- the widening fp32 layers as persistent blocks with a loader wave (conv1x1_march_kernel): whole 96-channel blocks, stride 1, no fused Add, a weight
+    // slice of at most 64 KB, and enough tiles that every CU's block runs several steps.  SNNHIP_CONV_1X1_MARCH=0 keeps the kernel above, =1 forces it on small layers
+    bool march = false;
+    int mTS = 0, mPI = 0;
+    {
+        const char* mo = snnhip::option("SNNHIP_CONV_1X1_MARCH");
+        const int mode = mo ? atoi(mo) : -1;
+        const int pieces = (32 * (g.IC / 4 + 1) + 63) / 64;
+        const bool shape = !f16 && NT == 3 && g.sh == 1 && !plan->fusedAdd && g.OC % 96 == 0 && static_cast<size_t>(g.IC) * 96 * 4 <= 64 * 1024 && pieces <= 21;
+        const bool worth = g.OC >= 3 * g.IC && static_cast<long long>(nTiles) * ocBlocks >= 8LL * cus;
+        if (shape && mode != 0 && (worth || mode == 1)) {
+            auto fn = pick_march(pieces, !simple ? 0 : g.act == SNNHIP_ACT_LEAKY ? 1 : 2, &mTS, &mPI);
+            const size_t lds = static_cast<size_t>(nChunks) * 2 * BN * 16 + static_cast<size_t>(2) * mTS * mPI * 64 * 16;
+            if (fn && lds <= 160 * 1024) {
+                march = true;
+                plan->kernel = fn;
+                plan->ldsBytes = lds;
+                plan->waves = 3 * mTS + 1;
+                int segs = std::max(1, cus / ocBlocks);
+                plan->p.segTiles = (nTiles + segs - 1) / segs;
+                segs = (nTiles + plan->p.segTiles - 1) / plan->p.segTiles;
+                plan->p.phaseChunks = nChunks; // the whole slice is resident
+                gx = segs;
+                plan->grid = dim3(segs, ocBlocks);
+            }
+        }
+    }
     if (plan->ldsBytes > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(plan->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan->ldsBytes)) != hipSuccess) {
         delete plan;
@@ -509,7 +718,13 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     snprintf(buf, sizeof(buf), "conv2d_mfma_%s k=1x1 s=%d ic=%d oc=%d stream: wave = 32px x %doc, %d waves per block, grid %dx%d, lds=%zuB", f16 ? "f16_32x32x16" : "f32_32x32x2", g.sh, g.IC, g.OC,
              BN, waves, gx, ocBlocks, plan->ldsBytes);
     plan->desc = buf;
-    if (KP > 1) plan->desc += " (weight slice in " + std::to_string((nChunks + phaseChunks - 1) / phaseChunks) + " K phases)";
+    if (march) {
+        snprintf(buf, sizeof(buf), "conv2d_mfma_f32_32x32x2 k=1x1 s=1 ic=%d oc=%d march: persistent blocks (grid %dx%d, %d tiles each, weights resident), loader wave "
+                 "(LDS-DMA %d KB/tile) + %d compute waves, %d tiles/step, lds=%zuB kernel=conv1x1_march_kernel<%d,%d>",
+                 g.IC, g.OC, gx, ocBlocks, plan->p.segTiles, mPI, 3 * mTS, mTS, plan->ldsBytes, mTS, mPI);
+        plan->desc = buf;
+    }
+    if (KP > 1 && !march) plan->desc += " (weight slice in " + std::to_string((nChunks + phaseChunks - 1) / phaseChunks) + " K phases)";
     if (plan->fusedAdd) {
         plan->desc += " +add";
         plan->bytes += esz * M * g.OC;

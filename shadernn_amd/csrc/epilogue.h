@@ -132,6 +132,18 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const void* ldsWaveB
     const unsigned base = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)(ldsWaveBase))));
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(base) : "memory");
 }
+// The same copy with a wave-uniform base pointer in SGPRs and a 32-bit byte offset per lane: no 64-bit address arithmetic on the VALU (a loader wave's
+// VALU instructions queue behind the MFMAs of the compute waves it shares a SIMD with: phase trace of conv1x1_march_kernel, 300 cycles per copy).
+__device__ __forceinline__ void lds_dma16_sbase(const void* uniformBase, unsigned laneByteOffset, unsigned ldsByteAddr) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(laneByteOffset), "s"(uniformBase), "s"(ldsByteAddr) : "memory");
+}
+// 4-byte store to (wave-uniform base in SGPRs) + a 32-bit byte offset per lane
+__device__ __forceinline__ void store_dword_sbase(void* uniformBase, unsigned laneByteOffset, float v) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(laneByteOffset), "v"(v), "s"(uniformBase) : "memory");
+}
+__device__ __forceinline__ unsigned lds_byte_addr(const void* ldsPtr) { // wave-uniform LDS address as a scalar
+    return __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)(ldsPtr))));
+}
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // coordinate resolution of vk_conv2d.comp:168-218; returns -1 when the fetch yields 0

@@ -309,3 +309,55 @@ def test_pointwise_stream_weight_slice_in_k_phases(ctx, monkeypatch, oc, with_ad
     assert "K phases" not in gen.describe(), gen.describe()
     if not with_add:
         np.testing.assert_allclose(y, gen(xt).numpy(), rtol=2e-5, atol=2e-5)
+
+
+MARCH_CASES = [
+    # (N, H, W, IC, OC, act, bn)   widening pointwise layers through conv1x1_march_kernel (SNNHIP_CONV_1X1_MARCH=1 forces it on layers this small)
+    (4, 14, 14, 64, 384, "relu6", True),     # MobileNetV2 64 -> 384: 9 DMA pieces per tile, four tiles per step, four output blocks
+    (2, 14, 14, 96, 576, "relu6", True),     # 96 -> 576: 13 pieces, six output blocks, 13 tiles = ragged steps (392 px: the last tile 8 rows)
+    (8, 7, 7, 160, 960, "relu6", True),      # 160 -> 960: 21 pieces, two tiles per step, ten output blocks
+    (1, 33, 47, 32, 96, "relu", False),      # 5 pieces; 1551 pixels = 48 tiles + 15 rows
+    (2, 9, 11, 128, 384, "SiLU", True),      # 17 pieces, non-simple activation
+    (1, 5, 5, 16, 96, "", False),            # one tile, one step
+    (3, 20, 20, 24, 96, "leakyRelu", True),  # IC not a multiple of 16: 7 slots per row
+]
+
+
+@pytest.mark.parametrize("case", MARCH_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_pointwise_march_matches_oracle_and_the_stream_kernel(ctx, monkeypatch, case):
+    """conv1x1_march_kernel: persistent blocks (weight slice resident in LDS), one loader wave filling an LDS ring of activation tiles by LDS-DMA, 3 x TS compute
+    waves (tile x 32 channels each).  Whole output against the oracle and, bit for bit, against conv1x1_stream_kernel on the same layer (same MFMA order)."""
+    N, H, W, IC, OC, act, use_bn = case
+    x = _rand((N, H, W, IC), 61)
+    w = _rand((OC, IC, 1, 1), 62, 1.0 / np.sqrt(IC))
+    b = _rand((OC,), 63, 0.1)
+    bn = _bn(OC, 64) if use_bn else None
+    monkeypatch.setenv("SNNHIP_CONV_1X1", "2")
+    monkeypatch.setenv("SNNHIP_CONV_1X1_MARCH", "1")
+    y, desc = run_conv(ctx, x, w, b, 1, (0, 0, 0, 0), "constant", act, 0.1, bn)
+    assert "march: persistent blocks" in desc and "conv1x1_march_kernel" in desc, desc
+    want = O.conv2d(x, w, b, 1, (0, 0, 0, 0), "constant", act, 0.1, bn)
+    np.testing.assert_allclose(y, want, err_msg=desc, **TOL)
+    y_again, _ = run_conv(ctx, x, w, b, 1, (0, 0, 0, 0), "constant", act, 0.1, bn)
+    np.testing.assert_array_equal(y, y_again)
+    monkeypatch.setenv("SNNHIP_CONV_1X1_MARCH", "0")
+    y2, desc2 = run_conv(ctx, x, w, b, 1, (0, 0, 0, 0), "constant", act, 0.1, bn)
+    assert "stream: wave" in desc2 and "march" not in desc2, desc2
+    np.testing.assert_array_equal(y, y2, err_msg=desc + " vs " + desc2)
+
+
+def test_pointwise_march_is_the_default_on_large_widening_layers_only(ctx, monkeypatch):
+    import shadernn_amd as snn
+
+    monkeypatch.delenv("SNNHIP_CONV_1X1_MARCH", raising=False)
+    monkeypatch.delenv("SNNHIP_CONV_1X1", raising=False)
+
+    def kind(N, H, W, IC, OC, stride=1):
+        wgt = _rand((OC, IC, 1, 1), 1)
+        return snn.conv2d_plan(ctx, N, H, W, wgt, None, stride=stride, pads=(0, 0, 0, 0), act="relu6").describe()
+
+    assert "march" in kind(256, 14, 14, 96, 576)         # MobileNetV2 b11 at batch 256
+    assert "march" in kind(256, 14, 14, 64, 384)
+    assert "march" not in kind(4, 14, 14, 96, 576)       # a few tiles per CU: the one-tile-per-wave kernel
+    assert "march" not in kind(256, 14, 14, 576, 96)     # a project layer (narrowing)
+    assert "march" not in kind(256, 14, 14, 96, 160)     # not whole 96-channel blocks

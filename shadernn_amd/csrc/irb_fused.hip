@@ -401,6 +401,234 @@ struct IrbPlan : snnhip_plan {
     }
 };
 
+// ---- whole-image form (round 4): the 14x14 / 7x7 blocks of MobileNetV2 (b07-b16).  On these maps the tile-per-wave kernel above loses to the three
+// separate layers (a 4x8 tile of a 14x14 image is mostly halo, and every wave walks all 24-60 weight slices), and the separate layers run at 0.22-0.27
+// of the MFMA roofline: expand 32 us + depthwise 41 us + project/add 46 us for 64 -> 384 -> 64 at batch 256, 31 us of matrix work.  Here a BLOCK owns
+// one whole IMAGE -- no halo at all -- and each of its four waves (one per SIMD) a QUARTER OF THE HIDDEN CHANNELS (slices c = wave, wave + 4, ...):
+//   x tile     the image, [pixel][C / 4 + 1] 16-byte slots (odd pitch: conflict-free operand reads), copied once by LDS-DMA; also the residual
+//   E(c)       expand MFMAs over the image's ceil(HW / 16) pixel tiles (B operand straight from the x tile) -> act -> the wave's PRIVATE hidden slice,
+//              a zero-bordered (H + pad) x (W + pad) tile of 4 quad planes: the depthwise layer's zero padding is the border, written once
+//   D(c), P(c) depthwise taps per output pixel tile -> act -> the B operand of the project MFMAs, accumulated in the wave's own acc[Co / 16][tiles]
+//              (a wave's hidden channels are read by no other wave: NO barrier in the loop; every weight is read once per image)
+//   reduce     the four waves' partial sums over their hidden quarters meet in LDS, one 16-channel output block at a time (fixed order), then
+//              scale / shift / act [+ x -> act] and 16-byte stores.
+// One wave per SIMD with up to 320 accumulator registers: latency is hidden inside the wave (next slice's weights requested a phase ahead, independent
+// MFMA chains), not by occupancy.  Weight blobs: the slice format of irb_wave_kernel.
+struct IrbImgParams {
+    int N, H, W, C, Ch, Co, OH, OW, s;
+    int HW, OHW;
+    int MT;            // ceil(HW / 16) expand MFMA tiles
+    int SP;            // 16-byte slots per pixel of the x tile: C / 4 + 1
+    int HWd, hPlane4;  // hidden tile: row pitch in pixels, float4 per quad plane (>= rows * HWd + 1: the last slot takes the results of padding pixels)
+    int offH4;         // float4 offset of the hidden region (4 waves x 4 planes); the pixel tables follow it
+    int slicesPerWave; // Ch / 64
+    int wePieces, wpPieces;
+    int hasRes;
+    unsigned magicSP;
+    ActCfg ac1, ac2, ac3, ac4;
+};
+
+template <int NCB /* Co / 16 */, int CJ /* C / 16 */, int G /* output pixel tiles */, bool R6>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void irb_image_kernel(IrbImgParams p, const float* __restrict__ x, const float4* __restrict__ weg,
+                                                                                                 const float4* __restrict__ wpg, const float4* __restrict__ epi3,
+                                                                                                 const int* __restrict__ tabs, float* __restrict__ y) {
+    extern __shared__ float4 sm4[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n16 = lane & 15, k = lane >> 4;
+    const int img = blockIdx.x;
+    float4* const xs4 = sm4;
+    float4* const hs4 = sm4 + p.offH4 + wave * 4 * p.hPlane4;
+    int* const tabE = reinterpret_cast<int*>(sm4 + p.offH4 + 16 * p.hPlane4); // [MT * 16]: hidden position of x-tile pixel i
+    int* const tabD = tabE + p.MT * 16;                                        // [G * 16]: hidden position of output pixel o's first tap
+    {
+        const float* xi = x + static_cast<size_t>(img) * p.HW * p.C;
+        const int totalSlots = p.HW * p.SP;
+        const unsigned xsLds = lds_byte_addr(xs4);
+        for (int e0 = wave * 64; e0 < totalSlots; e0 += 256) { // (wave-uniform)
+            const int e = e0 + lane;
+            const int px = static_cast<int>(__umulhi(static_cast<unsigned>(e), p.magicSP)), sl = e - px * p.SP;
+            // the pad slot of a pixel and the slots past the image re-read the image's first bytes: nothing reads what they write
+            lds_dma16_sbase(xi, (e < totalSlots && sl < p.SP - 1) ? static_cast<unsigned>(px * p.C + sl * 4) * 4u : 0u, xsLds + static_cast<unsigned>(e0) * 16u);
+        }
+        for (int i = lane; i < 4 * p.hPlane4; i += 64) hs4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < (p.MT + G) * 16; i += 256) tabE[i] = tabs[i];
+        lds_dma_wait();
+    }
+    __syncthreads();
+
+    f32x4 acc[NCB][G];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[cb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const size_t weStep = static_cast<size_t>(4) * p.wePieces * 64, wpStep = static_cast<size_t>(4) * p.wpPieces * 64;
+    const float4* web = weg + static_cast<size_t>(wave) * p.wePieces * 64; // slices wave, wave + 4, ...
+    const float4* wpb = wpg + static_cast<size_t>(wave) * p.wpPieces * 64;
+    float4 a[CJ], ap[NCB], wd[9];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) a[j] = web[j * 64 + lane];
+    float4 sc1 = web[CJ * 64 + k], sh1 = web[CJ * 64 + 4 + k];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[cb * 64 + lane];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
+    float4 sc2 = wpb[NCB * 64 + 36 + k], sh2 = wpb[NCB * 64 + 40 + k];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+
+    for (int i = 0; i < p.slicesPerWave; ++i) {
+        const bool more = i + 1 < p.slicesPerWave; // (wave-uniform)
+        // ---- E: the wave's hidden slice over the whole image, two pixel tiles in flight
+        for (int t = 0; t < p.MT; t += 2) {
+            const int px0 = t * 16 + n16;
+            const bool two = t + 1 < p.MT;
+            const int px1 = two ? px0 + 16 : px0;
+            const float4* const b0p = xs4 + px0 * p.SP + k;
+            const float4* const b1p = xs4 + px1 * p.SP + k;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                const float4 b0 = b0p[4 * j], b1 = b1p[4 * j];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1.w, acc1, 0, 0, 0);
+            }
+            const v2f sc01 = {sc1.x, sc1.y}, sc23 = {sc1.z, sc1.w}, sh01 = {sh1.x, sh1.y}, sh23 = {sh1.z, sh1.w};
+            {
+                const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
+                hs4[k * p.hPlane4 + tabE[px0]] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
+            }
+            if (two) {
+                const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);
+                hs4[k * p.hPlane4 + tabE[px1]] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
+            }
+        }
+        // the next slice's expand weights are requested now and arrive under D / P (one wave per SIMD: nobody else hides the L2 round trip)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) web += weStep;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) a[j] = web[j * 64 + lane];
+        sc1 = web[CJ * 64 + k];
+        sh1 = web[CJ * 64 + 4 + k];
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- D + P: depthwise taps of output tile g -> the B operand of the project MFMAs (kk outer, cb inner: consecutive MFMAs are independent).
+        // The order is pinned (sched_barrier): tile g's tap FMAs, then the 9 tap reads of tile g + 1 INTO THE SAME REGISTERS, then tile g's MFMAs, under
+        // which they arrive.  Left alone the scheduler hoists the tap reads of all 13 tiles to the top (468 registers next to 208-312 accumulators: scratch).
+        const float4* const hb = hs4 + k * p.hPlane4;
+        float4 h[9];
+        {
+            const int hp0 = tabD[n16];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) h[tp] = hb[hp0 + (tp / 3) * p.HWd + tp % 3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                s01 = __builtin_elementwise_fma(v2f{h[tp].x, h[tp].y}, v2f{wd[tp].x, wd[tp].y}, s01);
+                s23 = __builtin_elementwise_fma(v2f{h[tp].z, h[tp].w}, v2f{wd[tp].z, wd[tp].w}, s23);
+            }
+            const v2f t01 = __builtin_elementwise_fma(v2f{sc2.x, sc2.y}, s01, v2f{sh2.x, sh2.y}), t23 = __builtin_elementwise_fma(v2f{sc2.z, sc2.w}, s23, v2f{sh2.z, sh2.w});
+            const float d0 = irb_act<R6>(p.ac2, t01[0]), d1 = irb_act<R6>(p.ac2, t01[1]), d2 = irb_act<R6>(p.ac2, t23[0]), d3 = irb_act<R6>(p.ac2, t23[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < G) {
+                const int hp0 = tabD[(g + 1) * 16 + n16];
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) h[tp] = hb[hp0 + (tp / 3) * p.HWd + tp % 3];
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].x, d0, acc[cb][g], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].y, d1, acc[cb][g], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].z, d2, acc[cb][g], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].w, d3, acc[cb][g], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) wpb += wpStep;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[cb * 64 + lane];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
+        sc2 = wpb[NCB * 64 + 36 + k];
+        sh2 = wpb[NCB * 64 + 40 + k];
+    }
+
+    // ---- the four hidden quarters meet, one 16-channel output block at a time: [wave][tile][lane] partial sums in the (now free) hidden region
+    __syncthreads();
+    float4* const red4 = sm4 + p.offH4;
+    float* const yi = y + static_cast<size_t>(img) * p.OHW * p.Co;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) red4[(wave * G + g) * 64 + lane] = make_float4(acc[cb][g][0], acc[cb][g][1], acc[cb][g][2], acc[cb][g][3]);
+        __syncthreads();
+        const float4 sc = epi3[2 * (cb * 4 + k)], sh = epi3[2 * (cb * 4 + k) + 1];
+        for (int g = wave; g < G; g += 4) {
+            const float4 q0 = red4[(0 * G + g) * 64 + lane], q1 = red4[(1 * G + g) * 64 + lane], q2 = red4[(2 * G + g) * 64 + lane], q3 = red4[(3 * G + g) * 64 + lane];
+            const int o = g * 16 + n16;
+            if (o < p.OHW) {
+                float4 r;
+                r.x = apply_act<true>(p.ac3, fmaf(sc.x, ((q0.x + q1.x) + q2.x) + q3.x, sh.x), 0.f);
+                r.y = apply_act<true>(p.ac3, fmaf(sc.y, ((q0.y + q1.y) + q2.y) + q3.y, sh.y), 0.f);
+                r.z = apply_act<true>(p.ac3, fmaf(sc.z, ((q0.z + q1.z) + q2.z) + q3.z, sh.z), 0.f);
+                r.w = apply_act<true>(p.ac3, fmaf(sc.w, ((q0.w + q1.w) + q2.w) + q3.w, sh.w), 0.f);
+                if (p.hasRes) { // (stride 1, C == Co: output pixel o is x-tile pixel o)
+                    const float4 xr = xs4[o * p.SP + cb * 4 + k];
+                    r.x = apply_act<true>(p.ac4, r.x + xr.x, 0.f);
+                    r.y = apply_act<true>(p.ac4, r.y + xr.y, 0.f);
+                    r.z = apply_act<true>(p.ac4, r.z + xr.z, 0.f);
+                    r.w = apply_act<true>(p.ac4, r.w + xr.w, 0.f);
+                }
+                *reinterpret_cast<float4*>(yi + static_cast<size_t>(o) * p.Co + cb * 16 + 4 * k) = r;
+            }
+        }
+        if (cb + 1 < NCB) __syncthreads();
+    }
+}
+
+struct IrbImagePlan : snnhip_plan {
+    IrbImgParams p;
+    float* d_we = nullptr;
+    float* d_wp = nullptr;
+    float* d_e3 = nullptr;
+    float* d_tabs = nullptr;
+    size_t ldsBytes = 0;
+    void (*kernel)(IrbImgParams, const float*, const float4*, const float4*, const float4*, const int*, float*) = nullptr;
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "inverted-residual block: expects 1 input (the block input is also the residual), got %d", nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == p.N && x->h == p.H && x->w == p.W && x->c == p.C, "irb: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h, x->w, x->c, p.N, p.H, p.W, p.C);
+        SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.Co, "irb: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w,
+                       out->c, p.N, p.OH, p.OW, p.Co);
+        SNNHIP_LAUNCH(kernel, dim3(static_cast<unsigned>(p.N)), dim3(256), ldsBytes, ctx->stream, p, x->data, reinterpret_cast<const float4*>(d_we),
+                      reinterpret_cast<const float4*>(d_wp), reinterpret_cast<const float4*>(d_e3), reinterpret_cast<const int*>(d_tabs), out->data);
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+typedef void (*IrbImgFn)(IrbImgParams, const float*, const float4*, const float4*, const float4*, const int*, float*);
+IrbImgFn pick_irb_image(int ncb, int cj, int g, int* gt) {
+#define SNNHIP_IRBI(NCB_, CJ_, G_) \
+    if (ncb == NCB_ && cj == CJ_ && g <= G_) return *gt = G_, irb_image_kernel<NCB_, CJ_, G_, true>;
+    SNNHIP_IRBI(4, 4, 13)   // 64 -> 384 -> 64 at 14x14 (MobileNetV2 b07-b09)
+    SNNHIP_IRBI(6, 4, 13)   // 64 -> 384 -> 96 (b10)
+    SNNHIP_IRBI(6, 6, 13)   // 96 -> 576 -> 96 (b11, b12)
+    SNNHIP_IRBI(10, 6, 4)   // 96 -> 576 -> 160, 14x14 -> 7x7 (b13)
+    SNNHIP_IRBI(10, 10, 4)  // 160 -> 960 -> 160 at 7x7 (b14, b15)
+#undef SNNHIP_IRBI
+    return nullptr;
+}
+
 typedef void (*IrbFn)(IrbParams, const float*, const float4*, const float4*, const float4*, float*);
 template <int G, bool R6>
 IrbFn pick_irb_wave(int ncb, int cj) {
@@ -479,13 +707,63 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     // this kernel: b01 (112x112, stride 2) 787 / 364, b02 (56x56) 615 / 334, b03 (56x56 s2) 368 / 237, b04 (28x28) 201 / 129, b06 (28x28 s2) 124 / 99;
     // from 14x14 down the separate layers win (b07 143 / 148, b10 149 / 170, b11 258 / 332): few tiles per image and 24-60 slices of weights.
     const bool fuseAll = irbMode && strcmp(irbMode, "all") == 0;
-    if (!fuseAll && ge.H * ge.W < 28 * 28) return SNNHIP_E_UNSUPPORTED;
     if (C % 4 || Ch % 4 || Co % 4 || C > 16 * kMaxCj || Co > 16 * kMaxNCB) return SNNHIP_E_UNSUPPORTED;
     const int acts[4] = {ge.act, gd.act, gp.act, ad ? ad->d.act : 0};
     for (int a : acts)
         if (!act_is_simple(a)) return SNNHIP_E_UNSUPPORTED;
     if (ad && (s != 1 || C != Co || ad->d.N != gp.N || ad->d.H != gp.OH || ad->d.W != gp.OW || ad->d.C != Co)) return SNNHIP_E_UNSUPPORTED;
     if (static_cast<double>(ge.N) * ge.H * ge.W * std::max(C, Ch) >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
+    // The whole-image kernel (irb_image_kernel): maps of at most 13 pixel tiles (14x14), whole 16-channel blocks in and out, hidden channels in four equal
+    // quarters of whole slices, ReLU6 after expand and depthwise, and at least one image per two CUs (a block is an image).  SNNHIP_IRB_IMAGE=0 switches it
+    // off, =1 takes it at any batch size (tests).
+    IrbImgFn imgFn = nullptr;
+    IrbImgParams ip = {};
+    size_t imgLds = 0;
+    std::vector<int> imgTabs;
+    {
+        const char* io = snnhip::option("SNNHIP_IRB_IMAGE");
+        const int mode = io ? atoi(io) : -1;
+        const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+        const int HW = ge.H * ge.W, OHW = gd.OH * gd.OW;
+        int GT = 0;
+        if (mode != 0 && !cs && !noExpand && !fuseAll && C % 16 == 0 && Co % 16 == 0 && Ch % 64 == 0 && HW <= 16 * 13 && ge.act == SNNHIP_ACT_RELU6 &&
+            gd.act == SNNHIP_ACT_RELU6 && (ge.N * 2 >= cus || mode == 1))
+            imgFn = pick_irb_image(Co / 16, C / 16, up_div(OHW, 16), &GT);
+        if (imgFn) {
+            ip.N = ge.N; ip.H = ge.H; ip.W = ge.W; ip.C = C; ip.Ch = Ch; ip.Co = Co; ip.OH = gd.OH; ip.OW = gd.OW; ip.s = s;
+            ip.HW = HW;
+            ip.OHW = OHW;
+            ip.MT = up_div(HW, 16);
+            ip.SP = C / 4 + 1;
+            ip.magicSP = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(ip.SP) - 1) / static_cast<unsigned>(ip.SP));
+            const int rows = std::max(gd.pady + ge.H, (gd.OH - 1) * s + 3);
+            ip.HWd = std::max(gd.padx + ge.W, (gd.OW - 1) * s + 3);
+            ip.hPlane4 = round_up(std::max(rows * ip.HWd + 1, GT * 16), 16); // (... and room for the reduction: 4 waves x GT tiles x 64 float4 in 16 planes)
+            ip.offH4 = std::max(ip.MT * 16 * ip.SP, round_up(HW * ip.SP, 64));
+            ip.slicesPerWave = Ch / 64;
+            ip.hasRes = ad ? 1 : 0;
+            imgLds = (static_cast<size_t>(ip.offH4) + 16 * ip.hPlane4) * 16 + static_cast<size_t>(ip.MT + GT) * 16 * 4;
+            if (imgLds > 160 * 1024 || HW * ip.SP >= 65536 ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(imgFn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(imgLds)) != hipSuccess)
+                imgFn = nullptr;
+            ip.wePieces = C / 16 + 1;
+            ip.wpPieces = Co / 16 + 1;
+            if (imgFn) {
+                ip.ac1 = make_act_cfg(ge.act, ge.leaky);
+                ip.ac2 = make_act_cfg(gd.act, gd.leaky);
+                ip.ac3 = make_act_cfg(gp.act, gp.leaky);
+                ip.ac4 = make_act_cfg(ad ? ad->d.act : 0, ad ? ad->d.leaky : 0.0f);
+            }
+            // pixel tables: hidden position of x-tile pixel i (padding pixels: the plane's last slot), of output pixel o's first tap (padding pixels: 0)
+            if (imgFn) {
+                std::vector<int>& tb = imgTabs;
+                tb.assign(static_cast<size_t>(ip.MT + GT) * 16, 0);
+                for (int i = 0; i < ip.MT * 16; ++i) tb[i] = i < HW ? (i / ge.W + gd.pady) * ip.HWd + i % ge.W + gd.padx : ip.hPlane4 - 1;
+                for (int o = 0; o < GT * 16; ++o) tb[ip.MT * 16 + o] = o < OHW ? (o / gd.OW) * s * ip.HWd + (o % gd.OW) * s : 0;
+            }
+        }
+    }
+    if (!imgFn && !fuseAll && ge.H * ge.W < 28 * 28) return SNNHIP_E_UNSUPPORTED;
 
     IrbParams p = {};
     p.N = ge.N; p.H = ge.H; p.W = ge.W; p.C = C; p.Ch = Ch; p.Co = Co; p.OH = gd.OH; p.OW = gd.OW; p.s = s; p.padx = gd.padx; p.pady = gd.pady;
@@ -498,7 +776,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     int G = gopt ? atoi(gopt) : (s == 2 ? 1 : 2);
     if (G != 1 && G != 2 && G != 4) G = s == 2 ? 1 : 2;
     int NWv = 0, perWave = 0;
-    for (;; G >>= 1) {
+    for (; !imgFn; G >>= 1) {
         const int TH = 2 * G, TWv = 8;
         p.TWs = 3;
         p.HH = (TH - 1) * s + 3;
@@ -554,7 +832,8 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     const size_t lds = static_cast<size_t>(NWv) * perWave * sizeof(float);
     const bool r6 = ge.act == SNNHIP_ACT_RELU6 && gd.act == SNNHIP_ACT_RELU6;
     IrbFn fn = nullptr;
-    if (cs) { // stem mode: its own instantiations (Cj = 2: the 27 image values; up to 32 output channels)
+    if (imgFn) {
+    } else if (cs) { // stem mode: its own instantiations (Cj = 2: the 27 image values; up to 32 output channels)
         if (p.NCB > 2) return SNNHIP_E_UNSUPPORTED;
         if (G == 4) fn = r6 ? irb_wave_kernel<4, 2, 2, true, true> : irb_wave_kernel<4, 2, 2, false, true>;
         if (G == 2) fn = r6 ? irb_wave_kernel<2, 2, 2, true, true> : irb_wave_kernel<2, 2, 2, false, true>;
@@ -562,8 +841,8 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     } else if (G == 4) fn = r6 ? pick_irb_wave<4, true>(p.NCB, p.Cj) : pick_irb_wave<4, false>(p.NCB, p.Cj);
     else if (G == 2) fn = r6 ? pick_irb_wave<2, true>(p.NCB, p.Cj) : pick_irb_wave<2, false>(p.NCB, p.Cj);
     else if (G == 1) fn = r6 ? pick_irb_wave<1, true>(p.NCB, p.Cj) : pick_irb_wave<1, false>(p.NCB, p.Cj);
-    if (!fn) return SNNHIP_E_UNSUPPORTED;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+    if (!fn && !imgFn) return SNNHIP_E_UNSUPPORTED;
+    if (fn && lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("irb_fused: hipFuncSetAttribute(%zu) failed", lds);
         return SNNHIP_E_HIP;
     }
@@ -609,6 +888,36 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         e3p[(co / 4) * 8 + 4 + co % 4] = e3[2 * co + 1];
     }
 
+    const double inElems = cs ? static_cast<double>(p.N) * p.IH * p.IW * 3 : static_cast<double>(p.N) * p.H * p.W * C;
+    const double fusedBytes = 4.0 * (inElems + static_cast<double>(p.N) * p.OH * p.OW * Co + static_cast<double>(Ch) * (C + Co + 9));
+    if (imgFn) {
+        auto* ipl = new IrbImagePlan();
+        ipl->ctx = ctx;
+        ipl->p = ip;
+        ipl->kernel = imgFn;
+        ipl->ldsBytes = imgLds;
+        ipl->dtype = SNNHIP_F32;
+        int rc = ipl->upload(we.data(), we.size(), &ipl->d_we);
+        if (rc == SNNHIP_OK) rc = ipl->upload(wp.data(), wp.size(), &ipl->d_wp);
+        if (rc == SNNHIP_OK) rc = ipl->upload(e3p.data(), e3p.size(), &ipl->d_e3);
+        if (rc == SNNHIP_OK) rc = ipl->upload(reinterpret_cast<const float*>(imgTabs.data()), imgTabs.size(), &ipl->d_tabs);
+        if (rc != SNNHIP_OK) {
+            delete ipl;
+            return rc;
+        }
+        memcpy(ipl->inDims, expandPlan->inDims, sizeof(ipl->inDims));
+        memcpy(ipl->outDims, projectPlan->outDims, sizeof(ipl->outDims));
+        ipl->flops = ce->flops + cd->flops + cp->flops;
+        ipl->bytes = ce->bytes + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
+        ipl->kernelBytes = fusedBytes;
+        char ib[320];
+        snprintf(ib, sizeof(ib), "irb_fused_mfma_f32_16x16x4 [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] image per block (%dx%d, %d px tiles), hidden quarter per wave, "
+                 "slices=%d lds=%zuB hbm_bytes=%.6g kernel=irb_image_kernel<%d,%d,%d,true> relu6-epilogues",
+                 C, Ch, s, Ch, Co, addPlan ? " + add" : "", ip.H, ip.W, ip.MT, Ch / 16, imgLds, fusedBytes, Co / 16, C / 16, static_cast<int>(imgTabs.size() / 16) - ip.MT);
+        ipl->desc = ib;
+        *out = ipl;
+        return SNNHIP_OK;
+    }
     auto* plan = new IrbPlan();
     plan->ctx = ctx;
     plan->p = p;
@@ -628,8 +937,6 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     memcpy(plan->outDims, projectPlan->outDims, sizeof(plan->outDims));
     plan->flops = (ce ? ce->flops : 0.0) + (cs ? cs->flops : 0.0) + cd->flops + cp->flops;
     plan->bytes = (ce ? ce->bytes : 0.0) + (cs ? cs->bytes : 0.0) + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
-    const double inElems = cs ? static_cast<double>(p.N) * p.IH * p.IW * 3 : static_cast<double>(p.N) * p.H * p.W * C;
-    const double fusedBytes = 4.0 * (inElems + static_cast<double>(p.N) * p.OH * p.OW * Co + static_cast<double>(Ch) * (C + Co + 9));
     plan->kernelBytes = fusedBytes;
     char buf[320];
     char head[64];

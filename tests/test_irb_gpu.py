@@ -331,3 +331,87 @@ def test_stem_depthwise_pointwise_row_marching_kernel(ctx, case, monkeypatch):
     two = snn.chain_plan(ctx, [ps, pd, pp])
     assert two.num_steps() == 2 and "dwpw_march_f32" in two.describe() and "stem_dwpw" not in two.describe(), two.describe()
     np.testing.assert_allclose(two(xt).numpy(), got, err_msg=d, rtol=2e-5, atol=2e-5)
+
+
+# N, H, W, C, Ch, Co, stride, residual, (act1, act2, act3): the whole-image kernel (irb_image_kernel; SNNHIP_IRB_IMAGE=1 takes it at any batch size)
+IMAGE_CASES = [(2, 14, 14, 64, 384, 64, 1, True, ("relu6", "relu6", "")),      # MobileNetV2 b07-b09: 13 pixel tiles, 4 output blocks
+               (2, 14, 14, 64, 384, 96, 1, False, ("relu6", "relu6", "")),     # b10
+               (3, 14, 14, 96, 576, 96, 1, True, ("relu6", "relu6", "")),      # b11 / b12: 312 accumulator registers per lane
+               (2, 14, 14, 96, 576, 160, 2, False, ("relu6", "relu6", "")),    # b13: 14x14 -> 7x7
+               (3, 7, 7, 160, 960, 160, 1, True, ("relu6", "relu6", "")),      # b14 / b15
+               (2, 10, 13, 64, 128, 64, 1, True, ("relu6", "relu6", "relu")),  # 130 pixels = 8 tiles + 2 pixels, two slices per wave, activations after project and add
+               (1, 13, 11, 96, 192, 160, 2, False, ("relu6", "relu6", "leakyRelu")),  # odd extents at stride 2 (7x6 outputs = 3 tiles of the 4 the kernel walks)
+               (2, 5, 9, 160, 64, 160, 1, False, ("relu6", "relu6", ""))]      # one slice per wave
+
+
+@pytest.mark.parametrize("case", IMAGE_CASES, ids=lambda c: "%dx%dx%d_%d-%d-%d_s%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], "_res" if c[7] else ""))
+def test_irb_whole_image_kernel_matches_oracle_and_separate_layers(ctx, case, monkeypatch):
+    """irb_image_kernel: block = one image, wave = a quarter of the hidden channels, partial sums reduced through LDS.  Against the CPU oracle layer by
+    layer and against the separate HIP layers."""
+    import shadernn_amd as snn
+
+    monkeypatch.delenv("SNNHIP_IRB_FUSION", raising=False)
+    monkeypatch.setenv("SNNHIP_IRB_IMAGE", "1")
+    N, H, W, C, Ch, Co, s, res, acts = case
+    x = _rand((N, H, W, C), 171)
+    L = _layers(case, 180)
+    (we, be, bne), (wd, bd, bnd), (wp, bp, bnp) = L
+    pe = snn.conv2d_plan(ctx, N, H, W, we, be, act=acts[0], leaky=0.1, bn=bne)
+    pd = snn.conv2d_plan(ctx, N, H, W, wd, bd, stride=s, pads=O.padding_offsets("same", 3), act=acts[1], leaky=0.1, bn=bnd, depthwise=True)
+    _, OH, OW, _ = pd.out_shape()
+    pp = snn.conv2d_plan(ctx, N, OH, OW, wp, bp, act=acts[2], leaky=0.1, bn=bnp)
+    xt = snn.Tensor.from_numpy(ctx, x)
+    sep = pp(pd(pe(xt)))
+    want = _oracle(case, x, L)
+    if res:
+        act4 = "relu" if acts[2] == "relu" else ""
+        want = O.add_act(O.conv2d(O.depthwise(O.conv2d(x, we, be, 1, (0, 0, 0, 0), "constant", acts[0], 0.1, bne, threads=8), wd, bd, s, O.padding_offsets("same", 3),
+                                              acts[1], 0.1, bnd), wp, bp, 1, (0, 0, 0, 0), "constant", acts[2], 0.1, bnp, threads=8), x, act4)
+        pa = snn.add_plan(ctx, N, OH, OW, Co, act=act4)
+        sep = pa([sep, xt])
+        fused = snn.graph_fuse(ctx, [(pe, [-1], False), (pd, [0], False), (pp, [1], False), (pa, [2, -1], True)])
+        assert [f[0] is None for f in fused] == [True, True, True, False], [f[0] and f[0].describe() for f in fused]
+        plan, ins = fused[3]
+        assert ins == [-1]
+    else:
+        plan = snn.chain_plan(ctx, [pe, pd, pp])
+        assert plan.num_steps() == 1
+    d = plan.describe()
+    assert "irb_fused" in d and "image per block" in d and "irb_image_kernel" in d and ("+ add" in d) == res, d
+    got = plan(xt).numpy()
+    assert got.shape == want.shape == (N, OH, OW, Co)
+    np.testing.assert_allclose(got, want, err_msg=d, **TOL)
+    np.testing.assert_allclose(got, sep.numpy(), err_msg=d, rtol=2e-5, atol=2e-5)
+    np.testing.assert_array_equal(got, plan(xt).numpy())  # fixed reduction order
+    f, b = plan.cost()
+    assert f > 0 and b > 0
+
+
+def test_irb_whole_image_kernel_is_the_default_on_small_maps_at_large_batch_only(ctx, monkeypatch):
+    import shadernn_amd as snn
+
+    monkeypatch.delenv("SNNHIP_IRB_FUSION", raising=False)
+    monkeypatch.delenv("SNNHIP_IRB_IMAGE", raising=False)
+
+    def steps(N, H, W, C, Ch, Co, s):
+        case = (N, H, W, C, Ch, Co, s, False, ("relu6", "relu6", ""))
+        (we, be, bne), (wd, bd, bnd), (wp, bp, bnp) = _layers(case, 5)
+        pe = snn.conv2d_plan(ctx, N, H, W, we, be, act="relu6", bn=bne)
+        pd = snn.conv2d_plan(ctx, N, H, W, wd, bd, stride=s, pads=O.padding_offsets("same", 3), act="relu6", bn=bnd, depthwise=True)
+        _, OH, OW, _ = pd.out_shape()
+        pp = snn.conv2d_plan(ctx, N, OH, OW, wp, bp, bn=bnp)
+        try:
+            plan = snn.chain_plan(ctx, [pe, pd, pp])
+        except snn.SnnHipError as e:  # no rule takes the three layers: they stay three launches
+            return 3, str(e)
+        return plan.num_steps(), plan.describe()
+
+    n, d = steps(256, 14, 14, 64, 384, 64, 1)
+    assert n == 1 and "image per block" in d, d
+    n, d = steps(8, 14, 14, 64, 384, 64, 1)      # eight images would leave 248 CUs idle: the three layers
+    assert n == 3, d
+    n, d = steps(256, 14, 14, 64, 384, 72, 1)    # not whole 16-channel output blocks
+    assert n == 3, d
+    monkeypatch.setenv("SNNHIP_IRB_IMAGE", "0")
+    n, d = steps(256, 14, 14, 64, 384, 64, 1)
+    assert n == 3, d

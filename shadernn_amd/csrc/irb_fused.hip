@@ -435,6 +435,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ float4 sm4[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n16 = lane & 15, k = lane >> 4;
     const int img = blockIdx.x;
+#ifdef SNNHIP_IRBI_TRACE // experiment builds (tools/exp_one.sh): one block prints the s_memtime stamps of its phases
+    const bool itr = blockIdx.x == 100 && lane == 0 && (wave == 0 || wave == 3);
+    unsigned long long ist[8] = {};
+    if (itr) ist[0] = __builtin_readcyclecounter();
+#define IRBI_MARK(i) do { if (itr) ist[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define IRBI_MARK(i) do { } while (0)
+#endif
     float4* const xs4 = sm4;
     float4* const hs4 = sm4 + p.offH4 + wave * 4 * p.hPlane4;
     int* const tabE = reinterpret_cast<int*>(sm4 + p.offH4 + 16 * p.hPlane4); // [MT * 16]: hidden position of x-tile pixel i
@@ -454,6 +462,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         lds_dma_wait();
     }
     __syncthreads();
+    IRBI_MARK(1);
 
     f32x4 acc[NCB][G];
 #pragma unroll
@@ -467,16 +476,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float4 a[CJ], ap[NCB], wd[9];
 #pragma unroll
     for (int j = 0; j < CJ; ++j) a[j] = web[j * 64 + lane];
-    float4 sc1 = web[CJ * 64 + k], sh1 = web[CJ * 64 + 4 + k];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[cb * 64 + lane];
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
-    float4 sc2 = wpb[NCB * 64 + 36 + k], sh2 = wpb[NCB * 64 + 40 + k];
     typedef float v2f __attribute__((ext_vector_type(2)));
 
     for (int i = 0; i < p.slicesPerWave; ++i) {
         const bool more = i + 1 < p.slicesPerWave; // (wave-uniform)
+        if (i == 1) IRBI_MARK(2);
+        if (i == 2) IRBI_MARK(4);
+        // (the epilogue constants of a phase are requested at its start -- their first use is a tile's worth of MFMAs / tap FMAs away -- instead of with the
+        // weights a phase earlier: 16 registers the 96 -> 576 -> 96 instantiation does not have)
+        const float4 sc1 = web[CJ * 64 + k], sh1 = web[CJ * 64 + 4 + k];
         // ---- E: the wave's hidden slice over the whole image, two pixel tiles in flight
         for (int t = 0; t < p.MT; t += 2) {
             const int px0 = t * 16 + n16;
@@ -507,13 +519,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 hs4[k * p.hPlane4 + tabE[px1]] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
         }
+        if (i == 1) IRBI_MARK(3);
         // the next slice's expand weights are requested now and arrive under D / P (one wave per SIMD: nobody else hides the L2 round trip)
         __builtin_amdgcn_sched_barrier(0);
         if (more) web += weStep;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) a[j] = web[j * 64 + lane];
-        sc1 = web[CJ * 64 + k];
-        sh1 = web[CJ * 64 + 4 + k];
+        const float4 sc2 = wpb[NCB * 64 + 36 + k], sh2 = wpb[NCB * 64 + 40 + k];
         __builtin_amdgcn_sched_barrier(0);
         // ---- D + P: depthwise taps of output tile g -> the B operand of the project MFMAs (kk outer, cb inner: consecutive MFMAs are independent).
         // The order is pinned (sched_barrier): tile g's tap FMAs, then the 9 tap reads of tile g + 1 INTO THE SAME REGISTERS, then tile g's MFMAs, under
@@ -557,12 +569,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[cb * 64 + lane];
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
-        sc2 = wpb[NCB * 64 + 36 + k];
-        sh2 = wpb[NCB * 64 + 40 + k];
     }
 
     // ---- the four hidden quarters meet, one 16-channel output block at a time: [wave][tile][lane] partial sums in the (now free) hidden region
+    IRBI_MARK(5);
     __syncthreads();
+    IRBI_MARK(6);
     float4* const red4 = sm4 + p.offH4;
     float* const yi = y + static_cast<size_t>(img) * p.OHW * p.Co;
 #pragma unroll
@@ -592,6 +604,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (cb + 1 < NCB) __syncthreads();
     }
+#ifdef SNNHIP_IRBI_TRACE
+    if (itr)
+        printf("irbi NCB%d CJ%d G%d wave %d: stage %llu | slice 1: E %llu D+P %llu | loop %llu (%d slices) | wait-others %llu reduce+store %llu | total %llu\n", NCB, CJ, G, wave, ist[1] - ist[0],
+               ist[3] - ist[2], ist[4] - ist[3], ist[5] - ist[1], p.slicesPerWave, ist[6] - ist[5], __builtin_readcyclecounter() - ist[6], __builtin_readcyclecounter() - ist[0]);
+#endif
+#undef IRBI_MARK
 }
 
 struct IrbImagePlan : snnhip_plan {

@@ -20,6 +20,7 @@
 //   weights: pre-packed on the host in operand order (one 1 KiB piece per MFMA operand set, epilogue constants and depthwise taps riding in the same
 //   blobs), read by every wave straight from L1 / L2
 //   epilogue: act3(scale*acc + shift) [+ x from the tile -> act4], 16-byte channel-contiguous stores.
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -57,6 +58,8 @@ struct IrbParams {
     int xPlane, hPlane;      // floats between quad planes of the x tile / a hidden buffer (multiples of 64)
     int offH, offWe, offWp, offMask; // LDS map in floats: x planes at 0 (wave kernel: per wave; offWe = its mask, offMask = floats per wave)
     int hasRes;
+    int tail8;         // C % 16 == 8: the expand layer's last 8 channels are TWO MFMAs (k lane kk = channel 16 j + kk, then 16 j + 4 + kk) with 4-byte operand reads
+                       // from quad planes 4 j and 4 j + 1, instead of four MFMAs half of whose k lanes multiply zeros (MobileNetV2 b02 / b03: 24 channels, 6 instead of 8)
     int noExpand;      // DepthwiseConv2D -> Conv2D 1x1 without an expand layer in front (MobileNetV2's first block): the 'hidden' slice is the x tile itself
     unsigned magicQuads, magicHWd; // ceil(2^32 / d) for d = 4 Cj and HWd: the staging's two divisions as mul-hi (operands < 2^16: exact)
     // stem mode (stemK > 0): the 'expand' layer is a 3x3 convolution of a 3-channel image (MobileNetV2's Conv2D 3x3 s2 3->32 in front of its first,
@@ -249,7 +252,15 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < CJT; ++j)
-                    if (j < p.Cj) {
+                    if (j == p.Cj - 1 && p.tail8) { // (wave-uniform)
+                        const float* const q0 = xs + 4 * j * p.xPlane + px0 * 4 + k;
+                        const float* const q1 = xs + 4 * j * p.xPlane + px1 * 4 + k;
+                        const float b00 = q0[0], b01 = q0[p.xPlane], b10 = q1[0], b11 = q1[p.xPlane];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b00, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b10, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b01, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b11, acc1, 0, 0, 0);
+                    } else if (j < p.Cj) {
                         const float4 b0 = *reinterpret_cast<const float4*>(xs + (4 * j + k) * p.xPlane + px0 * 4);
                         const float4 b1 = *reinterpret_cast<const float4*>(xs + (4 * j + k) * p.xPlane + px1 * 4);
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0.x, acc0, 0, 0, 0);
@@ -647,6 +658,284 @@ IrbImgFn pick_irb_image(int ncb, int cj, int g, int* gt) {
     return nullptr;
 }
 
+// ---- band form (round 4): the blocks on 28x28 .. 112x112 maps (MobileNetV2 b01-b06), where irb_wave_kernel's 2x8 / 4x8 tiles per wave pay 1.5-2x the
+// expand layer in halo pixels, pad 24 input channels to 32, and every wave walks every weight slice for 16-32 output pixels.  A BLOCK owns a band of R
+// output rows x SW columns of one image:
+//   x tile     the band's input pixels (halo rows / columns included, clipped to the image), [pixel][C / 4 + 1] slots, one LDS-DMA pass
+//   per slice  E: the block's NW waves share the x tile's pixel tiles (tile t -> wave t mod NW), results into one of TWO hidden buffers (zero-bordered
+//              band tile, 4 quad planes) -- one barrier -- D + P: every wave its own output pixel tiles, all output channels: acc[Co / 16][GW].
+//              E(c + 1) writes the other buffer, so ONE barrier per slice orders everything.
+//   C % 16 == 8 (24 channels): the last 8 channels are TWO MFMAs with 4-byte operand reads (channel 16 j + kk, 16 j + 4 + kk) instead of four half-empty ones.
+// Halo work of the expand layer: 1.14-1.5x (rows only, or rows and a strip's two columns) instead of 1.5-2x; the accumulators are small (8-32 registers),
+// so 7-8 waves per block (2 per SIMD) hide each other's latencies.
+struct IrbBandParams {
+    int N, H, W, C, Ch, Co, OH, OW, s, padx, pady;
+    int R, SW, nBy, nBx;
+    int HWd, hPlane4, SP;
+    int offH4, offTab4; // float4 offsets: the two hidden buffers (2 x 4 planes), the tables
+    int MTmax;          // pixel tiles of the largest x tile
+    int NW, nSlices, wePieces, wpPieces;
+    int hasRes, tail8;
+    unsigned magicSP;
+    ActCfg ac1, ac2, ac3, ac4;
+};
+
+template <int NCB, int CJ, int GW, bool R6>
+__global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const float* __restrict__ x, const float4* __restrict__ weg, const float4* __restrict__ wpg,
+                                                      const float4* __restrict__ epi3, float* __restrict__ y) {
+    extern __shared__ float4 sm4[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n16 = lane & 15, k = lane >> 4;
+    const int NT = p.NW * 64, OT16 = p.NW * GW * 16;
+    const int bx = blockIdx.x % p.nBx, by = (blockIdx.x / p.nBx) % p.nBy, img = blockIdx.x / (p.nBx * p.nBy);
+    // band geometry (block-uniform)
+    const int oy0 = by * p.R, ox0 = bx * p.SW;
+    const int Rb = min(p.R, p.OH - oy0), OWb = min(p.SW, p.OW - ox0);
+    const int hy0 = oy0 * p.s - p.pady, hx0 = ox0 * p.s - p.padx;
+    const int iyA = max(hy0, 0), iyB = min(hy0 + (Rb - 1) * p.s + 3, p.H), ixA = max(hx0, 0), ixB = min(hx0 + (OWb - 1) * p.s + 3, p.W);
+    const int Wx = ixB - ixA, nPx = (iyB - iyA) * Wx, MT = (nPx + 15) >> 4;
+    const unsigned magicWx = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(Wx) - 1) / static_cast<unsigned>(Wx));
+    float4* const xs4 = sm4;
+    float4* const hsb = sm4 + p.offH4;
+    int* const tabE = reinterpret_cast<int*>(sm4 + p.offTab4); // [MTmax * 16] hidden position of x-tile pixel i (padding pixels: the plane's last slot)
+    int* const tabD = tabE + p.MTmax * 16;                     // [OT16] hidden position of output pixel o's first tap
+    int* const tabO = tabD + OT16;                             // [OT16] float offset of output pixel o in the image's output, -1 outside the band
+    int* const tabR = tabO + OT16;                             // [OT16] x-tile pixel of output pixel o (the residual)
+    {
+        for (int i = tid; i < p.MTmax * 16; i += NT) {
+            const int row = static_cast<int>(__umulhi(static_cast<unsigned>(i), magicWx));
+            tabE[i] = i < nPx ? (iyA - hy0 + row) * p.HWd + (ixA - hx0) + (i - row * Wx) : p.hPlane4 - 1;
+        }
+        const unsigned magicOWb = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(OWb) - 1) / static_cast<unsigned>(OWb));
+        for (int o = tid; o < OT16; o += NT) {
+            const int orow = static_cast<int>(__umulhi(static_cast<unsigned>(o), magicOWb)), ocol = o - orow * OWb;
+            const bool ok = orow < Rb;
+            tabD[o] = ok ? orow * p.s * p.HWd + ocol * p.s : 0;
+            tabO[o] = ok ? ((oy0 + orow) * p.OW + ox0 + ocol) * p.Co : -1;
+            tabR[o] = ok ? (oy0 + orow - iyA) * Wx + (ox0 + ocol - ixA) : 0;
+        }
+        for (int i = tid; i < 8 * p.hPlane4; i += NT) hsb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* xi = x + static_cast<size_t>(img) * p.H * p.W * p.C;
+        const int totalSlots = nPx * p.SP;
+        const unsigned xsLds = lds_byte_addr(xs4);
+        const unsigned firstOff = static_cast<unsigned>((iyA * p.W + ixA) * p.C) * 4u; // (pad slots and slots past the tile re-read the tile's first bytes)
+        for (int e0 = wave * 64; e0 < totalSlots; e0 += NT) {
+            const int e = e0 + lane;
+            const int px = static_cast<int>(__umulhi(static_cast<unsigned>(e), p.magicSP)), sl = e - px * p.SP;
+            const int row = static_cast<int>(__umulhi(static_cast<unsigned>(px), magicWx)), col = px - row * Wx;
+            const unsigned off = static_cast<unsigned>(((iyA + row) * p.W + ixA + col) * p.C + sl * 4) * 4u;
+            lds_dma16_sbase(xi, (e < totalSlots && sl < p.SP - 1) ? off : firstOff, xsLds + static_cast<unsigned>(e0) * 16u);
+        }
+        lds_dma_wait();
+    }
+    __syncthreads();
+
+    f32x4 acc[NCB][GW];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int g = 0; g < GW; ++g) acc[cb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float4* web = weg;
+    const float4* wpb = wpg;
+    float4 a[CJ], ap[NCB], wd[9];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) a[j] = web[j * 64 + lane];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[cb * 64 + lane];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const float* const xsf = reinterpret_cast<const float*>(xs4);
+
+    for (int c = 0; c < p.nSlices; ++c) {
+        const bool more = c + 1 < p.nSlices;
+        float4* const hs4 = hsb + (c & 1) * 4 * p.hPlane4;
+        const float4 sc1 = web[CJ * 64 + k], sh1 = web[CJ * 64 + 4 + k];
+        const float4 sc2 = wpb[NCB * 64 + 36 + k], sh2 = wpb[NCB * 64 + 40 + k];
+        // ---- E: this wave's share of the x tile's pixel tiles, two in flight
+        for (int t = wave; t < MT; t += 2 * p.NW) {
+            const int px0 = t * 16 + n16;
+            const bool two = t + p.NW < MT;
+            const int px1 = two ? px0 + 16 * p.NW : px0;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                if (j == CJ - 1 && p.tail8) { // (wave-uniform) the last 8 channels: k lane kk multiplies channel 16 j + kk, then 16 j + 4 + kk
+                    const float* const q0 = xsf + (px0 * p.SP + 4 * j) * 4 + k;
+                    const float* const q1 = xsf + (px1 * p.SP + 4 * j) * 4 + k;
+                    const float b00 = q0[0], b01 = q0[4], b10 = q1[0], b11 = q1[4];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b00, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b10, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b01, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b11, acc1, 0, 0, 0);
+                } else {
+                    const float4 b0 = xs4[px0 * p.SP + 4 * j + k], b1 = xs4[px1 * p.SP + 4 * j + k];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1.w, acc1, 0, 0, 0);
+                }
+            }
+            const v2f sc01 = {sc1.x, sc1.y}, sc23 = {sc1.z, sc1.w}, sh01 = {sh1.x, sh1.y}, sh23 = {sh1.z, sh1.w};
+            {
+                const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
+                hs4[k * p.hPlane4 + tabE[px0]] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
+            }
+            if (two) {
+                const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);
+                hs4[k * p.hPlane4 + tabE[px1]] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
+            }
+        }
+        if (more) web += p.wePieces * 64;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) a[j] = web[j * 64 + lane]; // the next slice's expand weights, under D / P
+        __syncthreads(); // slice c of the hidden tensor is complete; every wave has left D / P (c - 1), whose buffer E (c + 1) will overwrite
+        // ---- D + P: this wave's output pixel tiles
+        const float4* const hb = hs4 + k * p.hPlane4;
+#pragma unroll
+        for (int g = 0; g < GW; ++g) {
+            const int hp0 = tabD[(wave + p.NW * g) * 16 + n16];
+            v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+#pragma unroll
+            for (int fy = 0; fy < 3; ++fy)
+#pragma unroll
+                for (int fx = 0; fx < 3; ++fx) {
+                    const float4 h = hb[hp0 + fy * p.HWd + fx];
+                    const float4 w = wd[fy * 3 + fx];
+                    s01 = __builtin_elementwise_fma(v2f{h.x, h.y}, v2f{w.x, w.y}, s01);
+                    s23 = __builtin_elementwise_fma(v2f{h.z, h.w}, v2f{w.z, w.w}, s23);
+                }
+            const v2f t01 = __builtin_elementwise_fma(v2f{sc2.x, sc2.y}, s01, v2f{sh2.x, sh2.y}), t23 = __builtin_elementwise_fma(v2f{sc2.z, sc2.w}, s23, v2f{sh2.z, sh2.w});
+            const float d0 = irb_act<R6>(p.ac2, t01[0]), d1 = irb_act<R6>(p.ac2, t01[1]), d2 = irb_act<R6>(p.ac2, t23[0]), d3 = irb_act<R6>(p.ac2, t23[1]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].x, d0, acc[cb][g], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].y, d1, acc[cb][g], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].z, d2, acc[cb][g], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].w, d3, acc[cb][g], 0, 0, 0);
+        }
+        if (more) wpb += p.wpPieces * 64;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[cb * 64 + lane];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
+    }
+
+    // ---- epilogue: lane holds output channels 16 cb + 4 k .. + 3 of its pixels
+    float* const yi = y + static_cast<size_t>(img) * p.OH * p.OW * p.Co;
+#pragma unroll
+    for (int g = 0; g < GW; ++g) {
+        const int o = (wave + p.NW * g) * 16 + n16;
+        const int oo = tabO[o];
+        if (oo < 0) continue;
+        const int xr = tabR[o];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int co = cb * 16 + 4 * k;
+            if (co >= p.Co) continue;
+            const float4 sc = epi3[2 * (cb * 4 + k)], sh = epi3[2 * (cb * 4 + k) + 1];
+            float4 r;
+            r.x = apply_act<true>(p.ac3, fmaf(sc.x, acc[cb][g][0], sh.x), 0.f);
+            r.y = apply_act<true>(p.ac3, fmaf(sc.y, acc[cb][g][1], sh.y), 0.f);
+            r.z = apply_act<true>(p.ac3, fmaf(sc.z, acc[cb][g][2], sh.z), 0.f);
+            r.w = apply_act<true>(p.ac3, fmaf(sc.w, acc[cb][g][3], sh.w), 0.f);
+            if (p.hasRes) {
+                const float4 xv = xs4[xr * p.SP + cb * 4 + k];
+                r.x = apply_act<true>(p.ac4, r.x + xv.x, 0.f);
+                r.y = apply_act<true>(p.ac4, r.y + xv.y, 0.f);
+                r.z = apply_act<true>(p.ac4, r.z + xv.z, 0.f);
+                r.w = apply_act<true>(p.ac4, r.w + xv.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(yi + oo + co) = r;
+        }
+    }
+}
+
+struct IrbBandPlan : snnhip_plan {
+    IrbBandParams p;
+    float* d_we = nullptr;
+    float* d_wp = nullptr;
+    float* d_e3 = nullptr;
+    size_t ldsBytes = 0;
+    void (*kernel)(IrbBandParams, const float*, const float4*, const float4*, const float4*, float*) = nullptr;
+
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "inverted-residual block: expects 1 input (the block input is also the residual), got %d", nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == p.N && x->h == p.H && x->w == p.W && x->c == p.C, "irb: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h, x->w, x->c, p.N, p.H, p.W, p.C);
+        SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.Co, "irb: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w,
+                       out->c, p.N, p.OH, p.OW, p.Co);
+        SNNHIP_LAUNCH(kernel, dim3(static_cast<unsigned>(p.N * p.nBy * p.nBx)), dim3(static_cast<unsigned>(64 * p.NW)), ldsBytes, ctx->stream, p, x->data,
+                      reinterpret_cast<const float4*>(d_we), reinterpret_cast<const float4*>(d_wp), reinterpret_cast<const float4*>(d_e3), out->data);
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+typedef void (*IrbBandFn)(IrbBandParams, const float*, const float4*, const float4*, const float4*, float*);
+IrbBandFn pick_irb_band(int ncb, int cj, int gw) {
+#define SNNHIP_IRBB(NCB_, CJ_) \
+    if (ncb == NCB_ && cj == CJ_) return gw == 1 ? irb_band_kernel<NCB_, CJ_, 1, true> : irb_band_kernel<NCB_, CJ_, 2, true>;
+    SNNHIP_IRBB(2, 1)  // 16 -> 96 -> 24 (MobileNetV2 b01)
+    SNNHIP_IRBB(2, 2)  // 24 -> 144 -> 24 / 32 (b02, b03), 32 -> 192 -> 32 (b04, b05)
+    SNNHIP_IRBB(4, 2)  // 32 -> 192 -> 64 (b06)
+#undef SNNHIP_IRBB
+    return nullptr;
+}
+
+// Band geometry: output rows R x columns SW per block and waves NW, by a small cost model -- MFMA issue slots of the busiest SIMD per round of blocks
+// (ceil(tiles / NW) per wave and slice, ceil(NW x blocks per CU / 4) waves on a SIMD) plus a fixed cost per block and per slice -- over the candidates
+// that fit 160 KB of LDS.  Returns false if none does.
+struct BandChoice {
+    int R = 0, SW = 0, NW = 0, GW = 0, MTmax = 0, hPlane4 = 0, wavesPerCU = 0;
+    size_t lds = 0;
+};
+bool choose_band(int N, int H, int W, int C, int Ch, int Co, int OH, int OW, int s, int cus, BandChoice* out) {
+    const int SP = C / 4 + 1, nSl = up_div(Ch, 16), NCB = up_div(Co, 16);
+    const int eSteps = (C / 16) * 4 + ((C % 16) ? 2 : 0);
+    double best = 0.0;
+    int pinR = 0, pinSW = 0, pinNW = 0; // SNNHIP_IRB_BAND_GEOM=R,SW,NW pins the geometry (tuning runs, tests of odd shapes)
+    if (const char* ge = snnhip::option("SNNHIP_IRB_BAND_GEOM")) sscanf(ge, "%d,%d,%d", &pinR, &pinSW, &pinNW);
+    for (int div = 1; div <= 4; div *= 2) {
+        const int SW = pinSW ? std::min(pinSW, OW) : up_div(OW, div);
+        if (div > 1 && (SW < 14 || pinSW)) break;
+        for (int R = 1; R <= std::min(OH, 16); ++R) {
+            if (pinR && R != std::min(pinR, OH)) continue;
+            const int HH = (R - 1) * s + 3, HWd = (SW - 1) * s + 3;
+            const int xPx = std::min(HH, H) * std::min(HWd, W), MT = up_div(xPx, 16), OT = up_div(R * SW, 16);
+            const int hPlane4 = round_up(HH * HWd + 1, 16);
+            for (int NW = 4; NW <= 8; ++NW) {
+                if (pinNW ? NW != pinNW : (NW == 5 || NW == 6)) continue;
+                if (!pinNW && !pinR && s == 2 && (NW != 4 || R > 4)) continue; // stride 2 (measured, b03 / b06): four waves and at most four rows, e.g. b03 181 us vs 196-229 with 5-7 rows
+                const int GW = up_div(OT, NW);
+                if (GW > 2) continue;
+                const size_t lds = (static_cast<size_t>(std::max(MT * 16 * SP, round_up(xPx * SP, 64))) + 8 * hPlane4) * 16 + (static_cast<size_t>(MT) * 16 + 3 * NW * GW * 16) * 4;
+                if (lds > 160 * 1024) continue;
+                const int bpc = std::max(1, std::min(std::min(4, 16 / NW), static_cast<int>((160 * 1024) / lds)));
+                const long blocks = static_cast<long>(N) * up_div(OH, R) * up_div(OW, SW);
+                // Fitted to 31 measured geometries of MobileNetV2 b01-b06 at batch 256 (tools/sweep_band.sh; within ~15 %): a wave's matrix work and its VALU
+                // work add (they share the issue port), a SIMD runs its ceil(waves / 4) waves one after the other and pays ~150 cycles per slice and
+                // wave on the CU (barrier, LDS and issue contention), and a round of blocks cannot be shorter than one wave's work plus its exposed
+                // latencies (staging 8 000 cycles, 3 000 per slice).  Only the measured wave counts (4, 7, 8) are candidates: 6 waves ran 25 % slower than predicted.
+                const double work = nSl * (32.0 * (up_div(MT, NW) * eSteps + GW * NCB * 4) + 100.0 * up_div(MT, NW) + 150.0 * GW);
+                const double lat = 8000.0 + nSl * 3000.0;
+                const double rounds = static_cast<double>(blocks) / (static_cast<double>(cus) * bpc);
+                const double cost = rounds * std::max(work * up_div(NW * bpc, 4) + nSl * 150.0 * NW * bpc, work + lat);
+                if (best == 0.0 || cost < best) {
+                    best = cost;
+                    *out = BandChoice{R, SW, NW, GW, MT, hPlane4, NW * bpc, lds};
+                }
+            }
+        }
+    }
+    return best > 0.0;
+}
+
 typedef void (*IrbFn)(IrbParams, const float*, const float4*, const float4*, const float4*, float*);
 template <int G, bool R6>
 IrbFn pick_irb_wave(int ncb, int cj) {
@@ -782,6 +1071,24 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         }
     }
     if (!imgFn && !fuseAll && ge.H * ge.W < 28 * 28) return SNNHIP_E_UNSUPPORTED;
+    // The band kernel (irb_band_kernel) on the larger maps: 16 k or 16 k + 8 input channels, at most 64 output channels, ReLU6 after expand and depthwise,
+    // at least two blocks per CU, and nine or more slices: measured at batch 256 (tools/sweep_band.sh, us, irb_wave_kernel / this kernel at its best geometry):
+    // b02 311 / 301, b03 218 / 182, b04 126 / 103, b06 96 / 79; b01 (six slices, 16 channels in) 351 / 446 -- its blocks are too short for their fixed cost.
+    // SNNHIP_IRB_BAND=0 keeps irb_wave_kernel, =1 takes the band kernel wherever it runs (tests).
+    IrbBandFn bandFn = nullptr;
+    BandChoice bc;
+    if (!imgFn && !cs && !noExpand && !fuseAll) {
+        const char* bo = snnhip::option("SNNHIP_IRB_BAND");
+        const int mode = bo ? atoi(bo) : -1;
+        const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+        if (mode != 0 && (C % 16 == 0 || C % 16 == 8) && ge.act == SNNHIP_ACT_RELU6 && gd.act == SNNHIP_ACT_RELU6 &&
+            choose_band(ge.N, ge.H, ge.W, C, Ch, Co, gd.OH, gd.OW, s, cus, &bc) &&
+            ((static_cast<long>(ge.N) * up_div(gd.OH, bc.R) * up_div(gd.OW, bc.SW) >= 2L * cus && Ch >= 144) || mode == 1) &&
+            bc.MTmax * 16 * (C / 4 + 1) < 65536)
+            bandFn = pick_irb_band(up_div(Co, 16), up_div(C, 16), bc.GW);
+        if (bandFn && hipFuncSetAttribute(reinterpret_cast<const void*>(bandFn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bc.lds)) != hipSuccess) bandFn = nullptr;
+    }
+    const bool tail8 = !imgFn && !cs && !noExpand && C % 16 == 8 && !snnhip::option("SNNHIP_IRB_NO_TAIL8"); // (the switch: A/B runs of irb_wave_kernel)
 
     IrbParams p = {};
     p.N = ge.N; p.H = ge.H; p.W = ge.W; p.C = C; p.Ch = Ch; p.Co = Co; p.OH = gd.OH; p.OW = gd.OW; p.s = s; p.padx = gd.padx; p.pady = gd.pady;
@@ -794,7 +1101,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     int G = gopt ? atoi(gopt) : (s == 2 ? 1 : 2);
     if (G != 1 && G != 2 && G != 4) G = s == 2 ? 1 : 2;
     int NWv = 0, perWave = 0;
-    for (; !imgFn; G >>= 1) {
+    for (; !imgFn && !bandFn; G >>= 1) {
         const int TH = 2 * G, TWv = 8;
         p.TWs = 3;
         p.HH = (TH - 1) * s + 3;
@@ -829,6 +1136,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     p.wpPieces = p.NCB + 1;
     p.offWp = 0;
     p.hasRes = ad ? 1 : 0;
+    p.tail8 = tail8 ? 1 : 0;
     p.noExpand = noExpand ? 1 : 0;
     if (cs) {
         p.stemK = 27;
@@ -850,7 +1158,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     const size_t lds = static_cast<size_t>(NWv) * perWave * sizeof(float);
     const bool r6 = ge.act == SNNHIP_ACT_RELU6 && gd.act == SNNHIP_ACT_RELU6;
     IrbFn fn = nullptr;
-    if (imgFn) {
+    if (imgFn || bandFn) {
     } else if (cs) { // stem mode: its own instantiations (Cj = 2: the 27 image values; up to 32 output channels)
         if (p.NCB > 2) return SNNHIP_E_UNSUPPORTED;
         if (G == 4) fn = r6 ? irb_wave_kernel<4, 2, 2, true, true> : irb_wave_kernel<4, 2, 2, false, true>;
@@ -859,7 +1167,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     } else if (G == 4) fn = r6 ? pick_irb_wave<4, true>(p.NCB, p.Cj) : pick_irb_wave<4, false>(p.NCB, p.Cj);
     else if (G == 2) fn = r6 ? pick_irb_wave<2, true>(p.NCB, p.Cj) : pick_irb_wave<2, false>(p.NCB, p.Cj);
     else if (G == 1) fn = r6 ? pick_irb_wave<1, true>(p.NCB, p.Cj) : pick_irb_wave<1, false>(p.NCB, p.Cj);
-    if (!fn && !imgFn) return SNNHIP_E_UNSUPPORTED;
+    if (!fn && !imgFn && !bandFn) return SNNHIP_E_UNSUPPORTED;
     if (fn && lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("irb_fused: hipFuncSetAttribute(%zu) failed", lds);
         return SNNHIP_E_HIP;
@@ -878,6 +1186,10 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
             // expand: [j][lane = 16 kk + m] float4 {We[hc][16 j + 4 kk + jj]}
             for (int ic = 0; ic < C && !noExpand; ++ic) {
                 const int j = ic / 16, kk = (ic % 16) / 4, jj = ic % 4;
+                if (tail8 && j == p.Cj - 1) { // irb_band_kernel's last 8 channels: component 0 = channel 16 j + kk, component 1 = channel 16 j + 4 + kk
+                    wb[j * 256 + ((ic % 4) * 16 + m) * 4 + (ic % 16) / 4] = ce->w_oihw[static_cast<size_t>(hc) * C + ic];
+                    continue;
+                }
                 if (cs) { // 'channel' ic = 3 tap + c of the im2col'd image (the staging's order); the stem's weights are [oc][c][tap]
                     if (ic < 27) wb[j * 256 + (kk * 16 + m) * 4 + jj] = cs->w_oihw[(static_cast<size_t>(hc) * 3 + ic % 3) * 9 + ic / 3];
                     continue;
@@ -908,6 +1220,51 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
 
     const double inElems = cs ? static_cast<double>(p.N) * p.IH * p.IW * 3 : static_cast<double>(p.N) * p.H * p.W * C;
     const double fusedBytes = 4.0 * (inElems + static_cast<double>(p.N) * p.OH * p.OW * Co + static_cast<double>(Ch) * (C + Co + 9));
+    if (bandFn) {
+        auto* bpl = new IrbBandPlan();
+        IrbBandParams& b = bpl->p;
+        b = IrbBandParams{};
+        b.N = ge.N; b.H = ge.H; b.W = ge.W; b.C = C; b.Ch = Ch; b.Co = Co; b.OH = gd.OH; b.OW = gd.OW; b.s = s; b.padx = gd.padx; b.pady = gd.pady;
+        b.R = bc.R; b.SW = bc.SW; b.nBy = up_div(gd.OH, bc.R); b.nBx = up_div(gd.OW, bc.SW);
+        b.HWd = (bc.SW - 1) * s + 3;
+        b.hPlane4 = bc.hPlane4;
+        b.SP = C / 4 + 1;
+        b.magicSP = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(b.SP) - 1) / static_cast<unsigned>(b.SP));
+        b.MTmax = bc.MTmax;
+        b.offH4 = std::max(bc.MTmax * 16 * b.SP, round_up(std::min((bc.R - 1) * s + 3, ge.H) * std::min(b.HWd, ge.W) * b.SP, 64));
+        b.offTab4 = b.offH4 + 8 * b.hPlane4;
+        b.NW = bc.NW;
+        b.nSlices = p.nChunks; b.wePieces = p.wePieces; b.wpPieces = p.wpPieces;
+        b.hasRes = ad ? 1 : 0;
+        b.tail8 = tail8 ? 1 : 0;
+        b.ac1 = make_act_cfg(ge.act, ge.leaky);
+        b.ac2 = make_act_cfg(gd.act, gd.leaky);
+        b.ac3 = make_act_cfg(gp.act, gp.leaky);
+        b.ac4 = make_act_cfg(ad ? ad->d.act : 0, ad ? ad->d.leaky : 0.0f);
+        bpl->ctx = ctx;
+        bpl->kernel = bandFn;
+        bpl->ldsBytes = bc.lds;
+        bpl->dtype = SNNHIP_F32;
+        int rc = bpl->upload(we.data(), we.size(), &bpl->d_we);
+        if (rc == SNNHIP_OK) rc = bpl->upload(wp.data(), wp.size(), &bpl->d_wp);
+        if (rc == SNNHIP_OK) rc = bpl->upload(e3p.data(), e3p.size(), &bpl->d_e3);
+        if (rc != SNNHIP_OK) {
+            delete bpl;
+            return rc;
+        }
+        memcpy(bpl->inDims, expandPlan->inDims, sizeof(bpl->inDims));
+        memcpy(bpl->outDims, projectPlan->outDims, sizeof(bpl->outDims));
+        bpl->flops = ce->flops + cd->flops + cp->flops;
+        bpl->bytes = ce->bytes + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
+        bpl->kernelBytes = fusedBytes;
+        char bb[352];
+        snprintf(bb, sizeof(bb), "irb_fused_mfma_f32_16x16x4 [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] band per block (%d rows x %d cols, %d waves, %d px tiles in), "
+                 "slices=%d lds=%zuB hbm_bytes=%.6g kernel=irb_band_kernel<%d,%d,%d,true> relu6-epilogues%s",
+                 C, Ch, s, Ch, Co, addPlan ? " + add" : "", bc.R, bc.SW, bc.NW, bc.MTmax, p.nChunks, bc.lds, fusedBytes, up_div(Co, 16), up_div(C, 16), bc.GW, tail8 ? " tail8" : "");
+        bpl->desc = bb;
+        *out = bpl;
+        return SNNHIP_OK;
+    }
     if (imgFn) {
         auto* ipl = new IrbImagePlan();
         ipl->ctx = ctx;
@@ -977,6 +1334,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
              cs ? "true" : "false");
     plan->desc = buf;
     if (r6) plan->desc += " relu6-epilogues";
+    if (tail8) plan->desc += " tail8";
     *out = plan;
     return SNNHIP_OK;
 }

@@ -415,3 +415,58 @@ def test_irb_whole_image_kernel_is_the_default_on_small_maps_at_large_batch_only
     monkeypatch.setenv("SNNHIP_IRB_IMAGE", "0")
     n, d = steps(256, 14, 14, 64, 384, 64, 1)
     assert n == 3, d
+
+
+# N, H, W, C, Ch, Co, stride, residual, (act1, act2, act3): the band kernel (irb_band_kernel; SNNHIP_IRB_BAND=1 takes it at any batch size)
+BAND_CASES = [((2, 112, 112, 16, 96, 24, 2, False, ("relu6", "relu6", "")), None),       # MobileNetV2 b01: column strips, stride 2
+              ((2, 56, 56, 24, 144, 24, 1, True, ("relu6", "relu6", "")), None),        # b02: 24 channels = one full 16-channel step + the 8-channel tail
+              ((2, 56, 56, 24, 144, 32, 2, False, ("relu6", "relu6", "")), None),       # b03
+              ((3, 28, 28, 32, 192, 32, 1, True, ("relu6", "relu6", "")), None),        # b04 / b05
+              ((2, 28, 28, 32, 192, 64, 2, False, ("relu6", "relu6", "")), None),       # b06: four output blocks
+              ((1, 45, 37, 32, 80, 32, 1, True, ("relu6", "relu6", "relu")), "4,20,5"),  # ragged: last band 1 row, last strip 17 columns, 5 waves
+              ((2, 33, 50, 8, 48, 24, 2, False, ("relu6", "relu6", "leakyRelu")), "3,13,4"),  # C = 8: only the tail step; 17x25 outputs in bands of 3 x 13
+              ((1, 30, 30, 32, 64, 64, 1, False, ("relu6", "relu6", "")), "7,30,8")]     # four output blocks, 8 waves
+
+
+@pytest.mark.parametrize("case,geom", BAND_CASES, ids=lambda c: ("%dx%dx%d_%d-%d-%d_s%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], "_res" if c[7] else "")) if isinstance(c, tuple) else str(c))
+def test_irb_band_kernel_matches_oracle_and_separate_layers(ctx, case, geom, monkeypatch):
+    """irb_band_kernel: block = a band of output rows x a column strip of one image, the waves share the expand layer's pixel tiles and own their output
+    tiles, two hidden buffers and one barrier per slice.  Against the CPU oracle layer by layer and against the separate HIP layers."""
+    import shadernn_amd as snn
+
+    monkeypatch.delenv("SNNHIP_IRB_FUSION", raising=False)
+    monkeypatch.setenv("SNNHIP_IRB_BAND", "1")
+    if geom:
+        monkeypatch.setenv("SNNHIP_IRB_BAND_GEOM", geom)
+    N, H, W, C, Ch, Co, s, res, acts = case
+    x = _rand((N, H, W, C), 271)
+    L = _layers(case, 280)
+    (we, be, bne), (wd, bd, bnd), (wp, bp, bnp) = L
+    pe = snn.conv2d_plan(ctx, N, H, W, we, be, act=acts[0], leaky=0.1, bn=bne)
+    pd = snn.conv2d_plan(ctx, N, H, W, wd, bd, stride=s, pads=O.padding_offsets("same", 3), act=acts[1], leaky=0.1, bn=bnd, depthwise=True)
+    _, OH, OW, _ = pd.out_shape()
+    pp = snn.conv2d_plan(ctx, N, OH, OW, wp, bp, act=acts[2], leaky=0.1, bn=bnp)
+    xt = snn.Tensor.from_numpy(ctx, x)
+    sep = pp(pd(pe(xt)))
+    h = O.conv2d(x, we, be, 1, (0, 0, 0, 0), "constant", acts[0], 0.1, bne, threads=8)
+    dd = O.depthwise(h, wd, bd, s, O.padding_offsets("same", 3), acts[1], 0.1, bnd)
+    want = O.conv2d(dd, wp, bp, 1, (0, 0, 0, 0), "constant", acts[2], 0.1, bnp, threads=8)
+    if res:
+        act4 = "relu" if acts[2] == "relu" else ""
+        want = O.add_act(want, x, act4)
+        pa = snn.add_plan(ctx, N, OH, OW, Co, act=act4)
+        sep = pa([sep, xt])
+        fused = snn.graph_fuse(ctx, [(pe, [-1], False), (pd, [0], False), (pp, [1], False), (pa, [2, -1], True)])
+        assert [f[0] is None for f in fused] == [True, True, True, False], [f[0] and f[0].describe() for f in fused]
+        plan, ins = fused[3]
+        assert ins == [-1]
+    else:
+        plan = snn.chain_plan(ctx, [pe, pd, pp])
+        assert plan.num_steps() == 1
+    d = plan.describe()
+    assert "irb_fused" in d and "band per block" in d and "irb_band_kernel" in d and ("+ add" in d) == res and ("tail8" in d) == (C % 16 == 8), d
+    got = plan(xt).numpy()
+    assert got.shape == want.shape == (N, OH, OW, Co)
+    np.testing.assert_allclose(got, want, err_msg=d, **TOL)
+    np.testing.assert_allclose(got, sep.numpy(), err_msg=d, rtol=2e-5, atol=2e-5)
+    np.testing.assert_array_equal(got, plan(xt).numpy())

@@ -75,7 +75,8 @@ def main():
         fl = pe.cost()[0] + pd.cost()[0] + pp.cost()[0]
         t_sep = None if args.fused_only else timeit(separate)
         t_f = timeit(lambda: fused.run(x, ty)) if fused is not None and "irb_fused" in fused.describe() else None
-        tile = fused.describe().split("tile=")[1].split(" ")[0] if t_f else "-"
+        d = fused.describe() if t_f else ""
+        tile = d.split("tile=")[1].split(" ")[0] if "tile=" in d else ("band " + d.split("band per block (")[1].split(")")[0]) if "band per block" in d else "image" if "image per block" in d else "-"
         print("%s %dx%d %d->%d->%d s%d%s b%d: separate %s us, fused[%s per wave] %s us (%.1f TF/s)" % (
             name, H, H, C, Ch, Co, s, " +add" if res else "", N, "%.1f" % t_sep if t_sep else "-", tile, "%.1f" % t_f if t_f else "n/a",
             fl / t_f / 1e6 if t_f else 0.0), flush=True)

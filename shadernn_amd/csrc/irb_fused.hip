@@ -541,6 +541,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- D + P: depthwise taps of output tile g -> the B operand of the project MFMAs (kk outer, cb inner: consecutive MFMAs are independent).
         // The order is pinned (sched_barrier): tile g's tap FMAs, then the 9 tap reads of tile g + 1 INTO THE SAME REGISTERS, then tile g's MFMAs, under
         // which they arrive.  Left alone the scheduler hoists the tap reads of all 13 tiles to the top (468 registers next to 208-312 accumulators: scratch).
+        // (Software-pipelined by one tile -- tile g's MFMAs interleaved by sched_group_barrier with tile g + 1's packed tap FMAs and the refills of the tap
+        // registers -- it ran 2-6 % SLOWER on every block (b07 69.3 -> 73.7 us): fp32 VALU work beside fp32 MFMAs is not hidden, it shares their issue port.)
         const float4* const hb = hs4 + k * p.hPlane4;
         float4 h[9];
         {

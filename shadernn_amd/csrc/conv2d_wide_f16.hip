@@ -616,7 +616,12 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->p = p;
     plan->ac = make_act_cfg(g.act, g.leaky);
     plan->kernel = fn;
+#ifdef SNNHIP_WIDE_LDS_PAD_KB // experiment builds (tools/exp_one.sh): extra LDS per block = fewer blocks per CU (what does a block do when it has the CU to itself?)
+    plan->ldsBytes = lds + static_cast<size_t>(SNNHIP_WIDE_LDS_PAD_KB) * 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(plan->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan->ldsBytes));
+#else
     plan->ldsBytes = lds;
+#endif
     plan->fusedAdd = g.addAct >= 0;
     if (plan->fusedAdd) plan->numInputs = 2;
     plan->grid = dim3(static_cast<unsigned>(tiles), g.OC / BN, 1);

@@ -15,6 +15,7 @@
 //     contiguous per row.
 // The fused Pad in front (ConvGeom::preMode, reflect in the style graphs) resolves in the staging loop.  Bias / BN / activation as everywhere.
 #include "epilogue.h"
+#include "norm_fold.h"
 #include "snnhip_internal.h"
 
 #include <cstring>
@@ -31,6 +32,11 @@ struct StemParams {
     int N, H, W, IC, OC, padx, pady, padMode, useBN, OH, OW;
     int tilesX, tilesY;
     int preMode, preX, preY, srcH, srcW;
+    // chain rule F (Conv2D -> InstanceNorm): per (image, block) records {pixels, sum[32], sum of squares[32]} of the STORED values, and in the image's last
+    // block the fold into the norm's shift / mul (norm_fold.h); null = off
+    float* statRec;
+    int statSlots; // records per image: the most blocks whose tile runs can meet one image
+    NormFoldArgs fold;
 };
 
 constexpr int kK = 9;                 // kernel extent
@@ -41,12 +47,14 @@ constexpr int kSteps = 2 * kK + 3;    // 18 full steps + 3 left-over steps
 constexpr int kOutPitch = 40;         // halfs per pixel row of the wave's output scratch (80 bytes: 16-byte aligned rows, the 8-byte runs of 16 lanes on distinct banks)
 
 
-template <bool SIMPLE>
+template <bool SIMPLE, bool STATS /* chain rule F: StemParams::statRec */>
 __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
                                                           const float4* __restrict__ epi, _Float16* __restrict__ y) {
     __shared__ __attribute__((aligned(16))) _Float16 tile[kInH * kInW * 4];
     __shared__ __attribute__((aligned(16))) _Float16 oscr[4][32 * kOutPitch];
     __shared__ float4 etab[32]; // this block's rows of the epilogue table {bias, bnScale, bnMean, bnBeta}
+    __shared__ float red[STATS ? 17 * 256 : 1]; // rule F: the block's partial sums on their way into a record, then the fold's
+    __shared__ __attribute__((aligned(16))) float btab[32]; // (STATS) the biases alone: the statistics accumulators take the registers bias16 has otherwise
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, h = lane >> 5;
 
@@ -59,14 +67,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
 #pragma unroll
         for (int s = 0; s < kSteps; ++s) wa[s] = wsrc[s * 64];
     }
-    if (tid < 32) etab[tid] = epi[blockIdx.y * 32 + tid];
+    if (tid < 32) {
+        etab[tid] = epi[blockIdx.y * 32 + tid];
+        btab[tid] = etab[tid].x;
+    }
     // layers without batch norm whose activation is none or relu (Candy's stem): the lane's 16 biases stay in registers for the life of the
     // (persistent) wave and a value's epilogue is add + max -- the general form (table row from LDS, run-time batch-norm select, mul / max / med3)
     // is eight instructions a value, 512 per wave and tile next to its 84 MFMAs
     const bool fastEpi = SIMPLE && !p.useBN && ac.alpha == 1.0f && ac.hi == __builtin_huge_valf();
-    float bias16[16];
+    float bias16[STATS ? 1 : 16];
+    if (!STATS) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bias16[i] = epi[blockIdx.y * 32 + 8 * (i >> 2) + 4 * h + (i & 3)].x;
+        for (int i = 0; i < 16; ++i) bias16[i] = epi[blockIdx.y * 32 + 8 * (i >> 2) + 4 * h + (i & 3)].x;
+    }
 
     // staging: pixel -> 4 halfs (channels past IC are 0).  The loads of tile i+1 are issued before the MFMAs of tile i and written to LDS after
     // them: no global-load latency on the critical path (a rolled load-store loop waited out 7 round trips per tile)
@@ -91,10 +104,117 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
             for (int k = 0; k < 4; ++k) sv[r][k] = (ok && k < p.IC) ? src[k] : static_cast<_Float16>(0.0f);
         }
     };
-    const int total = p.tilesX * p.tilesY * p.N;
-    int mt = blockIdx.x;
+    // ---- rule F.  A lane of the store loop below always carries the same 8 channels (8 (lane & 3) ..): sums and sums of squares of the values it
+    // stores (the rounded halfs: what a statistics sweep over the tensor would read) accumulate in 17 registers across the block's tiles of one image.
+    // The block's tiles are a contiguous run (below) that ascends through one or two images: flush_image writes the block's record of image `img` when
+    // the run leaves it (and at the end) and, in the block that counts in last of those whose runs meet the image, folds the image's records into the
+    // norm's shift / mul.  No pivot: the values are
+    // post-activation halfs of modest range and a record covers ~2 k pixels; var = E[x^2] - mean^2 in fp32 keeps five digits.
+    float st1[8], st2[8], stN = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.0f;
+    auto flush_image = [&](int img) {
+        constexpr int T = 256, BN = 32, RECF = 1 + 2 * BN;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[k * T + tid] = st1[k];
+            red[(8 + k) * T + tid] = st2[k];
+            st1[k] = st2[k] = 0.0f;
+        }
+        red[16 * T + tid] = stN;
+        stN = 0.0f;
+        __syncthreads();
+        // the blocks whose runs meet image img: first .. last; this block's record is slot blockIdx.x - first of the image's p.statSlots
+        const int tpiF = p.tilesX * p.tilesY, chunkF = (tpiF * p.N + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+        const int firstB = (img * tpiF) / chunkF, lastB = ((img + 1) * tpiF - 1) / chunkF;
+        const int BPI = lastB - firstB + 1;
+        float* const rec = p.statRec + (static_cast<size_t>(img * gridDim.y + blockIdx.y) * p.statSlots + (blockIdx.x - firstB)) * RECF;
+        if (tid < BN) { // channel tid = 8 piece + k: the 64 threads with (t & 3) == piece
+            const int piece = tid >> 3, kk = tid & 7;
+            float a1 = 0.0f, a2 = 0.0f, an = 0.0f;
+            for (int j = 0; j < 64; ++j) {
+                a1 += red[kk * T + piece + 4 * j];
+                a2 += red[(8 + kk) * T + piece + 4 * j];
+                an += red[16 * T + 4 * j]; // (pixels: counted by the lanes of piece 0)
+            }
+            st_agent(rec + 1 + tid, a1);
+            st_agent(rec + 1 + BN + tid, a2);
+            if (tid == 0) st_agent(rec, an);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* cnt = p.fold.counter + img * gridDim.y + blockIdx.y;
+            const unsigned prev = atomicAdd(cnt, 1u);
+            const bool last = prev + 1u == static_cast<unsigned>(BPI);
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            red[0] = last ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        const bool last = red[0] != 0.0f;
+        __syncthreads();
+        if (!last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int ch = tid % BN, part = tid / BN; // 8 parts x 4 records in flight
+        const float* const r0 = p.statRec + static_cast<size_t>(img * gridDim.y + blockIdx.y) * p.statSlots * RECF;
+        float a1 = 0.0f, a2 = 0.0f, an = 0.0f;
+        for (int b0 = part; b0 < BPI; b0 += 4 * 8) {
+            float t1[4], t2[4], tn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = b0 + 8 * j;
+                t1[j] = t2[j] = tn[j] = 0.0f;
+                if (b < BPI) {
+                    const float* rb = r0 + static_cast<size_t>(b) * RECF;
+                    tn[j] = ld_agent(rb);
+                    t1[j] = ld_agent(rb + 1 + ch);
+                    t2[j] = ld_agent(rb + 1 + BN + ch);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                an += tn[j];
+                a1 += t1[j];
+                a2 += t2[j];
+            }
+        }
+        red[tid] = an;
+        red[T + tid] = a1;
+        red[2 * T + tid] = a2;
+        __syncthreads();
+        if (tid < BN) {
+            an = a1 = a2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                an += red[j * BN + tid];
+                a1 += red[T + j * BN + tid];
+                a2 += red[2 * T + j * BN + tid];
+            }
+            const float mean = a1 / an;
+            const float var = fmaxf(a2 / an - mean * mean, 0.0f);
+            const int oc = blockIdx.y * BN + tid;
+            const float mu = p.fold.gamma[oc] / sqrtf(var + p.fold.eps);
+            p.fold.mul[img * p.OC + oc] = mu;
+            p.fold.shift[img * p.OC + oc] = p.fold.beta[oc] - mean * mu;
+        }
+        __syncthreads();
+    };
+
+    // Tile order.  Without the statistics: tiles blockIdx.x, + gridDim.x, ... (the blocks resident at any moment work on neighbouring tiles).  With them:
+    // a CONTIGUOUS run of tiles per block, so that a block meets one or two images, not all of them -- a flush is a round trip to the coherence point
+    // (record stores acknowledged, a counter fetched), ~10 us: striding through all 16 images of a Candy micro-batch cost every block 16 of them
+    // (the kernel 360 -> 610 us); with runs it is one or two, and an image's fold reads ~33 records instead of 512.
+    const int tpi = p.tilesX * p.tilesY, totalAll = tpi * p.N;
+    const int chunk = (totalAll + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+    const int tstep = STATS ? 1 : static_cast<int>(gridDim.x);
+    const int total = STATS ? min(totalAll, (static_cast<int>(blockIdx.x) + 1) * chunk) : totalAll;
+    int mt = STATS ? static_cast<int>(blockIdx.x) * chunk : static_cast<int>(blockIdx.x);
+    if (mt >= total) return; // (STATS, block-uniform: the last blocks of a grid that does not divide the tiles)
+    int statImg = mt / tpi; // the image whose values the accumulators hold
     stage_load(mt);
     for (;;) {
+        if (STATS) // this tile opens the next image: close the one before it
+            for (const int nNow = mt / tpi; statImg < nNow; ++statImg) flush_image(statImg);
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
             const int e = tid + 256 * r;
@@ -103,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
         __syncthreads();
         const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, n = mt / (p.tilesX * p.tilesY);
         const int ox0 = tx * kTW, oy0 = ty * kTH;
-        const int next = mt + gridDim.x;
+        const int next = mt + tstep;
         if (next < total) stage_load(next);
 
         f32x16 acc[kNR];
@@ -162,8 +282,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     h4 o;
+                    if (STATS) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(btab + 8 * g + 4 * h);
+                        o[0] = static_cast<_Float16>(fmaxf(acc[yy][4 * g + 0] + b4.x, ac.lo));
+                        o[1] = static_cast<_Float16>(fmaxf(acc[yy][4 * g + 1] + b4.y, ac.lo));
+                        o[2] = static_cast<_Float16>(fmaxf(acc[yy][4 * g + 2] + b4.z, ac.lo));
+                        o[3] = static_cast<_Float16>(fmaxf(acc[yy][4 * g + 3] + b4.w, ac.lo));
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(fmaxf(acc[yy][4 * g + k] + bias16[4 * g + k], ac.lo));
+                        for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(fmaxf(acc[yy][4 * g + k] + bias16[4 * g + k], ac.lo));
+                    }
                     *reinterpret_cast<h4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = o;
                 }
             } else {
@@ -185,12 +313,28 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
                 const int opix = 16 * i + (lane >> 2), piece = lane & 3;
                 const float4 v = *reinterpret_cast<const float4*>(sc + opix * kOutPitch + 8 * piece);
                 const int ox = ox0 + opix;
-                if (oy < p.OH && ox < p.OW) *reinterpret_cast<float4*>(y + (static_cast<size_t>(n * p.OH + oy) * p.OW + ox) * p.OC + blockIdx.y * 32 + 8 * piece) = v;
+                if (oy < p.OH && ox < p.OW) {
+                    *reinterpret_cast<float4*>(y + (static_cast<size_t>(n * p.OH + oy) * p.OW + ox) * p.OC + blockIdx.y * 32 + 8 * piece) = v;
+                    if (STATS) {
+                        const h8 hv = *reinterpret_cast<const h8*>(&v);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float xv = static_cast<float>(hv[k]);
+                            st1[k] += xv;
+                            st2[k] = fmaf(xv, xv, st2[k]);
+                        }
+                        stN += piece == 0 ? 1.0f : 0.0f;
+                    }
+                }
             }
         }
         if (next >= total) break;
         mt = next;
         __syncthreads(); // every wave is done with the tile before the next one is written
+    }
+    if (STATS) {
+        __syncthreads();
+        flush_image(statImg);
     }
 }
 
@@ -202,19 +346,50 @@ struct StemConvPlan : ConvPlanBase {
     dim3 grid;
     bool simple = true;
 
+    // chain rule F: per (image, block) records, offered only together with the in-kernel fold (conv2d_upconv.hip / conv2d_s2march.hip)
+    bool enableTileStats() override {
+        if (statPart) return true;
+        if (snnhip::option("SNNHIP_NO_KERNEL_FOLD")) return false;
+        const int tpi = p.tilesX * p.tilesY, chunk = up_div(tpi * p.N, static_cast<int>(grid.x));
+        p.statSlots = up_div(tpi, chunk) + 1;
+        void* buf = nullptr;
+        if (hipMalloc(&buf, static_cast<size_t>(p.N) * grid.y * p.statSlots * (1 + 2 * 32) * sizeof(float)) != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        statPart = p.statRec = static_cast<float*>(buf);
+        statTilesX = p.statSlots; statTilesY = 1; statTH = 0; statTW = 0;
+        desc += " +tile-stats";
+        return true;
+    }
+    bool tileStatsNeedKernelFold() const override { return true; }
+    void disableTileStats() override {
+        statPart = p.statRec = nullptr; // (the buffer stays with the plan's allocations)
+        const size_t at = desc.rfind(" +tile-stats");
+        if (at != std::string::npos) desc.erase(at);
+    }
+    bool enableNormFold(const NormFoldTarget& t) override {
+        if (!statPart || p.fold.counter) return false;
+        void* buf = nullptr;
+        const size_t bytes = static_cast<size_t>(p.N) * grid.y * sizeof(unsigned);
+        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        if (hipMemset(buf, 0, bytes) != hipSuccess) return false;
+        p.fold.counter = static_cast<unsigned*>(buf);
+        p.fold.gamma = t.gamma; p.fold.beta = t.beta; p.fold.shift = t.shift; p.fold.mul = t.mul; p.fold.eps = t.eps;
+        desc += "+fold";
+        return true;
+    }
+
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
+        SNNHIP_REQUIRE(!p.statRec || p.fold.counter, "conv2d_stem: block statistics were switched on without the in-kernel fold (no fold launch reads its records)");
         const snnhip_tensor* x = in[0];
         SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == p.IC && x->dtype == SNNHIP_F16,
                        "conv2d: input dims %dx%dx%dx%d (dtype %d) != plan %dx%dx%dx%d fp16", x->n, x->h, x->w, x->c, x->dtype, p.N, p.srcH, p.srcW, p.IC);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC && out->dtype == SNNHIP_F16,
                        "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
-        if (simple)
-            SNNHIP_LAUNCH(conv2d_stem_kernel<true>, grid, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data),
-                               reinterpret_cast<const float4*>(d_w), reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
-        else
-            SNNHIP_LAUNCH(conv2d_stem_kernel<false>, grid, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data),
-                               reinterpret_cast<const float4*>(d_w), reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
+        auto fn = p.statRec ? (simple ? conv2d_stem_kernel<true, true> : conv2d_stem_kernel<false, true>) : (simple ? conv2d_stem_kernel<true, false> : conv2d_stem_kernel<false, false>);
+        SNNHIP_LAUNCH(fn, grid, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
+                      reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
     }

@@ -1436,6 +1436,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         auto* cv = dynamic_cast<ConvPlanBase*>(aIn ? aIn->conv : a.plain);
         if (!cv || cv->depthwise || cv->numInputs != 1) continue;
         if (normFusionMode < 0 && cv->desc.find("conv2d_mfma_wide_f16") == std::string::npos && cv->desc.find("conv2d_mfma_upconv_f16") == std::string::npos &&
+            !(cv->desc.find("conv2d_mfma_stem_f16") != std::string::npos && !snnhip::option("SNNHIP_STEM_NO_STATS")) &&
             !(cv->desc.find("row-marching") != std::string::npos && cv->desc.find(" s=2 ") != std::string::npos))
             continue;
         {

@@ -367,3 +367,32 @@ def test_fp16_stride2_marching_block_statistics_feed_the_instancenorm_behind_it(
         y = fused(xt).numpy()
         np.testing.assert_array_equal(fused(xt).numpy(), y)
         np.testing.assert_allclose(y, norm(conv(xt)).numpy(), rtol=2e-3, atol=2e-3, err_msg="seed %d: %s" % (seed, d))
+
+
+@pytest.mark.parametrize("shape", [(2, 50, 70), (3, 33, 100), (1, 16, 32)], ids=["2x50x70", "3x33x100_many_blocks_per_image", "one_tile"])
+def test_fp16_rgb_stem_block_statistics_feed_the_instancenorm_behind_it(ctx, monkeypatch, shape):
+    """Rule F on conv2d_stem_f16.hip: [Pad ->] Conv2D 9x9 (3 -> 32) -> InstanceNorm as the convolution (one record per persistent block and image, folded by
+    the block that counts in last) + ONE normalise sweep; against the separate launches, two different inputs through the same plan (the counters re-arm)."""
+    import shadernn_amd as snn
+
+    monkeypatch.setenv("SNNHIP_NORM_FUSION_MIN_MB", "0")
+    n, h, w = shape
+    wt, b = _rand((32, 3, 9, 9), 2, 1.0 / np.sqrt(3 * 81)), _rand((32,), 3, 0.3) + 0.5
+    beta, gamma = _rand((32,), 4, 0.3), 1.0 + _rand((32,), 5, 0.2)
+    pad = snn.pad_plan(ctx, n, h, w, 3, (4, 4, 4, 4), "reflect")
+    conv = snn.conv2d_plan(ctx, n, h + 8, w + 8, wt, b, pads=(0, 0, 0, 0), act="relu", dtype=snn.F16)
+    assert "conv2d_mfma_stem_f16" in conv.describe(), conv.describe()
+    oh, ow = conv.out_shape()[1:3]
+    norm = snn.instancenorm_plan(ctx, n, oh, ow, 32, beta, gamma, act="relu")
+    fused = snn.chain_plan(ctx, [pad, conv, norm])
+    d = fused.describe()
+    assert fused.num_steps() == 1 and "stem_f16" in d and "+tile-stats+fold" in d and "instancenorm(1 sweep)" in d and "+pad(reflect)" in d, d
+    for seed in (1, 11):
+        x = _rand((n, h, w, 3), seed) if seed == 1 else (0.5 * _rand((n, h, w, 3), seed) + 0.75).astype(np.float32)
+        xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+        y = fused(xt).numpy()
+        np.testing.assert_array_equal(fused(xt).numpy(), y)
+        np.testing.assert_allclose(y, norm(conv(pad(xt))).numpy(), rtol=2e-3, atol=2e-3, err_msg="seed %d: %s" % (seed, d))
+    monkeypatch.setenv("SNNHIP_STEM_NO_STATS", "1")
+    d2 = snn.chain_plan(ctx, [pad, conv, norm]).describe()
+    assert "tile-stats" not in d2, d2

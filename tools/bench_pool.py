@@ -18,6 +18,7 @@ def main():
     ap.add_argument("config")
     ap.add_argument("replicas", type=int, nargs="+")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0, help="global batch (default: the config's); e.g. c2 with --batch 2: two frames per step, one per replica")
     a = ap.parse_args()
     import bench
     from shadernn_amd import host, models
@@ -27,7 +28,7 @@ def main():
     H, W = cfg["hw"]
     tmp = tempfile.mkdtemp(prefix="snn_pool_")
     path = models.write_json(net, W, H, os.path.join(tmp, "m.json"), bin_weights=True)
-    B = cfg.get("global", cfg.get("per_rank"))
+    B = a.batch or cfg.get("global", cfg.get("per_rank"))
     x = np.random.default_rng(7767517).random((B, H, W, cfg["cin"]), dtype=np.float32)
     ref = None
     for r in a.replicas:

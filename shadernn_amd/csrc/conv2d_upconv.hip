@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
 
     const float* const et = epiTab + 32 * nt + 4 * h; // this lane's channel runs: 8 g + 4 h + k of the wave's 32-channel tile
     const bool actSimple = act_is_simple_dev(ac.act);
+    const bool actNone = actSimple && ac.alpha == 1.0f && ac.lo == -__builtin_huge_valf() && ac.hi == __builtin_huge_valf();
     float shReg[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -207,7 +208,14 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
             for (int j = 0; j < MT; ++j)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) rv[j][k] = fmaf(acc[j][4 * g + k], scv[k], shReg[4 * g + k]);
-            if (actSimple) { // (tested per channel run, not per value: a branch is a pipeline drain)
+            if (actNone) { // (the style graphs: an InstanceNorm follows, the convolution itself has no activation -- three instructions a value saved
+                           // in an epilogue that is 1 740 of an iteration's 4 970 cycles, phase trace of round 4)
+            } else if (actSimple && ac.alpha == 1.0f) { // none / relu / relu6 with bounds: fmaxf(v, v * 1) is v
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rv[j][k] = __builtin_amdgcn_fmed3f(rv[j][k], ac.lo, ac.hi);
+            } else if (actSimple) { // (tested per channel run, not per value: a branch is a pipeline drain)
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -232,6 +240,14 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
 
         // ---- the 4 x 64 tile leaves as 16-byte vectors, a pixel's BN channels contiguous
         const int mIt = m0 + MT * it;
+        // the thread's 8 channels are the same for every vector it stores (T % (BN / 8) == 0): their pivots once per iteration, not once per vector -- where
+        // the registers allow (the 128 -> 64 instantiation sits at 252 and re-reads them per vector)
+        constexpr bool kHoistPivots = ICS <= 4;
+        float pv[8];
+        if (kHoistPivots && p.statRec) {
+            const float4 pa = *reinterpret_cast<const float4*>(epiTab + BN + 8 * (tid % (BN / 8))), pb = *reinterpret_cast<const float4*>(epiTab + BN + 8 * (tid % (BN / 8)) + 4);
+            pv[0] = pa.x; pv[1] = pa.y; pv[2] = pa.z; pv[3] = pa.w; pv[4] = pb.x; pv[5] = pb.y; pv[6] = pb.z; pv[7] = pb.w;
+        }
 #pragma unroll
         for (int q = 0; q < (2 * MT * 64 * (BN / 8)) / T; ++q) {
             const int vi = tid + T * q;
@@ -242,8 +258,10 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
                 *reinterpret_cast<float4*>(y + ((static_cast<size_t>(n) * p.OH + 2 * mIt + orow) * p.OW + 2 * q0 + ocol) * p.OC + ocb + 8 * c8) = ov;
                 if (p.statRec) { // (uniform)
                     const h8 hv = *reinterpret_cast<const h8*>(&ov);
-                    const float4 pa = *reinterpret_cast<const float4*>(epiTab + BN + 8 * c8), pb = *reinterpret_cast<const float4*>(epiTab + BN + 8 * c8 + 4);
-                    const float pv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+                    if (!kHoistPivots) {
+                        const float4 pa = *reinterpret_cast<const float4*>(epiTab + BN + 8 * c8), pb = *reinterpret_cast<const float4*>(epiTab + BN + 8 * c8 + 4);
+                        pv[0] = pa.x; pv[1] = pa.y; pv[2] = pa.z; pv[3] = pa.w; pv[4] = pb.x; pv[5] = pb.y; pv[6] = pb.z; pv[7] = pb.w;
+                    }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const float d = static_cast<float>(hv[k]) - pv[k];

@@ -23,6 +23,8 @@
 #include "norm_fold.h"
 #include "snnhip_internal.h"
 
+#include <type_traits>
+
 namespace snnhip {
 namespace {
 
@@ -158,31 +160,63 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2march_kernel(S2Params p, ActC
             B.vLast = *reinterpret_cast<const float4*>(xn + static_cast<size_t>(max(sy, 0)) * p.srcW * p.IC + colOfsLast);
         }
     };
-    auto normalise = [&](float4& q) { // graph rule I on 8 staged channels 8 sl ..: half(act(x * mul + shift)) in fp32, the norm sweep's own arithmetic
+    // graph rule I on 8 staged channels 8 sl ..: half(act(x * mul + shift)) in fp32, the norm sweep's own arithmetic.  The thread's channel slot never
+    // changes: with 32 input channels its 8 shifts and 8 multipliers stay in registers (the 64-channel instantiation has none to spare and reads them
+    // from the LDS table per element, four ds_read_b128); and the activation kind is tested once per batch, not selected per value (the select
+    // computed both forms: five instructions a value where ReLU needs one).  Phase trace, round 4: this pass was 3 200-3 900 of an iteration's 7 000 cycles.
+    constexpr bool kNormRegs = ICS == 2;
+    float nSh[8], nMu[8];
+    if (kNormRegs && p.normShift) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            nSh[k] = p.normShift[n * p.IC + 8 * sl + k];
+            nMu[k] = p.normMul[n * p.IC + 8 * sl + k];
+        }
+    }
+    auto normalise = [&](float4& q, auto reluTag) {
         h8 hv = *reinterpret_cast<const h8*>(&q);
         const float* tb = normTab + 8 * sl;
 #pragma unroll
         for (int q4 = 0; q4 < 2; ++q4) {
-            const float4 sh = *reinterpret_cast<const float4*>(tb + 4 * q4), mu = *reinterpret_cast<const float4*>(tb + p.IC + 4 * q4);
-            const float shv[4] = {sh.x, sh.y, sh.z, sh.w}, muv[4] = {mu.x, mu.y, mu.z, mu.w};
+            float shv[4], muv[4];
+            if (kNormRegs) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    shv[k] = nSh[4 * q4 + k];
+                    muv[k] = nMu[4 * q4 + k];
+                }
+            } else {
+                const float4 sh = *reinterpret_cast<const float4*>(tb + 4 * q4), mu = *reinterpret_cast<const float4*>(tb + p.IC + 4 * q4);
+                shv[0] = sh.x; shv[1] = sh.y; shv[2] = sh.z; shv[3] = sh.w;
+                muv[0] = mu.x; muv[1] = mu.y; muv[2] = mu.z; muv[3] = mu.w;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float f = fmaf(static_cast<float>(hv[4 * q4 + k]), muv[k], shv[k]);
-                hv[4 * q4 + k] = static_cast<_Float16>(nRelu ? fmaxf(f, 0.0f) : __builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                hv[4 * q4 + k] = static_cast<_Float16>(decltype(reluTag)::value ? fmaxf(f, 0.0f) : __builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
             }
         }
         q = *reinterpret_cast<const float4*>(&hv);
     };
     auto store_batch = [&](Batch& B) { // normalise and write a landed batch into its ring rows; padding stays zero
+        if (p.normShift) { // (uniform)
+            if (nRelu) {
+#pragma unroll
+                for (int r = 0; r < NRND; ++r) normalise(B.v[r], std::true_type{});
+                if (tid < 32) normalise(B.vLast, std::true_type{});
+            } else {
+#pragma unroll
+                for (int r = 0; r < NRND; ++r) normalise(B.v[r], std::false_type{});
+                if (tid < 32) normalise(B.vLast, std::false_type{});
+            }
+        }
 #pragma unroll
         for (int r = 0; r < NRND; ++r) {
-            if (p.normShift) normalise(B.v[r]);
             const bool live = ((B.rowOkMask >> r) & 1u) && sxMain >= 0;
             const float4 o = make_float4(live ? B.v[r].x : 0.f, live ? B.v[r].y : 0.f, live ? B.v[r].z : 0.f, live ? B.v[r].w : 0.f);
             *reinterpret_cast<float4*>(smem + B.ringOf[r] * ROWF + ldsMain) = o;
         }
         if (tid < 32) {
-            if (p.normShift) normalise(B.vLast);
             const bool live = B.lastOk && sxLast >= 0;
             const float4 o = make_float4(live ? B.vLast.x : 0.f, live ? B.vLast.y : 0.f, live ? B.vLast.z : 0.f, live ? B.vLast.w : 0.f);
             *reinterpret_cast<float4*>(smem + B.ringLast * ROWF + ldsLast) = o;

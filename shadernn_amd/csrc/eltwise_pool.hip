@@ -250,7 +250,7 @@ struct InResidual { // graph rule H: the Add behind an InstanceNorm, applied in 
     float leaky = 0.0f;
 };
 
-template <int STAGE, int CV, typename T>
+template <int STAGE, int CV, typename T, bool FAST = false /* STAGE 2: the norm's activation is none or ReLU and the Add's is none: max(x, lo), no run-time switch per value */>
 __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int pixelsPerSlab, int CLs, const T* __restrict__ x,
                                                           const float* __restrict__ statMean, const float* __restrict__ statMul,
                                                           const float* __restrict__ beta, float* __restrict__ partOut, T* __restrict__ y,
@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
     // the norm (top-left aligned, add_ragged_kernel's rule): outside it the sum is the norm alone, or 0 when the residual is the Add's FIRST input.
     const T* __restrict__ res = static_cast<const T*>(ra.p);
     const bool ragged = ra.p && (ra.H != d.H || ra.W != d.W);
+    const float fastLo = d.act == SNNHIP_ACT_RELU ? 0.0f : -__builtin_huge_valf(); // (FAST)
     __shared__ float red[2 * 256 * CV];
     const int n = blockIdx.x / S, s = blockIdx.x % S;
     const int tid = threadIdx.x;
@@ -301,6 +302,19 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
                 }
             } else {
                 float o[CV];
+                if (FAST) { // (epi_act's switch per value -- 16 values in flight per thread, each behind its own branches -- is what the generic form below costs)
+#pragma unroll
+                    for (int k = 0; k < CV; ++k) o[k] = fmaxf(fmaf(v[k], mul[k], piv[k]), fastLo);
+                    if (res) {
+                        if (rp >= 0) {
+#pragma unroll
+                            for (int k = 0; k < CV; ++k) o[k] = static_cast<float>(static_cast<T>(o[k])) + rv[k];
+                        } else if (ra.zeroOutside) {
+#pragma unroll
+                            for (int k = 0; k < CV; ++k) o[k] = 0.0f;
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int k = 0; k < CV; ++k) o[k] = act1(d.act, d.leaky, fmaf(v[k], mul[k], piv[k])); // x * mul + shift (shift = beta - mean * mul, from the fold)
                 if (res) {
@@ -311,6 +325,7 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
 #pragma unroll
                         for (int k = 0; k < CV; ++k) o[k] = ra.zeroOutside ? 0.0f : act1(ra.act, ra.leaky, static_cast<float>(static_cast<T>(o[k])));
                     }
+                }
                 }
                 stv<T, CV>(yn + p * d.C + c, o);
             }
@@ -686,9 +701,16 @@ struct InstanceNormPlan : snnhip_plan {
         const int NC = d.N * d.C, HW = d.H * d.W;
         const dim3 gf(static_cast<unsigned>(NC)); // one block per (image, channel)
         const float invHW = 1.0f / (static_cast<float>(d.H) * static_cast<float>(d.W));
+        const bool fastNorm = (d.act == SNNHIP_ACT_NONE || d.act == SNNHIP_ACT_RELU) && (!res || addAct == SNNHIP_ACT_NONE) && !snnhip::option("SNNHIP_NORM_GENERIC_ACT");
 #define SNNHIP_IN(ST, CVV)                                                                                                                                     \
-    SNNHIP_LAUNCH((instancenorm_kernel<ST, CVV, T>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta, d_part, \
-                       mptr<T>(out), ST == 2 ? ra : InResidual())
+    do {                                                                                                                                                       \
+        if (ST == 2 && fastNorm)                                                                                                                               \
+            SNNHIP_LAUNCH((instancenorm_kernel<ST, CVV, T, ST == 2>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul,  \
+                          d_beta, d_part, mptr<T>(out), ST == 2 ? ra : InResidual());                                                                          \
+        else                                                                                                                                                   \
+            SNNHIP_LAUNCH((instancenorm_kernel<ST, CVV, T, false>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul,    \
+                          d_beta, d_part, mptr<T>(out), ST == 2 ? ra : InResidual());                                                                          \
+    } while (0)
 #define SNNHIP_FOLD() \
     SNNHIP_LAUNCH(instancenorm_fold_kernel<T>, gf, dim3(256), 0, ctx->stream, NC, d.C, S, HW, invHW, d.eps, cptr<T>(in[0]), d_part, d_gamma, d_beta, d_mean, d_mul)
         const bool sweep = !(tiles && tiles->part);

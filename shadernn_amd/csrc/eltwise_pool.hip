@@ -734,7 +734,19 @@ struct InstanceNormPlan : snnhip_plan {
             }
             if (!statsOnly) {
                 TraceScope ts(desc + " [normalise sweep]", 2.0 * tensorBytes / (out->dtype == SNNHIP_F16 ? 2.0 : 4.0), 2.0 * tensorBytes + resBytes);
-                SNNHIP_IN(2, 4);
+                // half tensors with whole 8-channel groups, branch-free form: 16 bytes per access (SNNHIP_NORM_CV8=0: 8).  With the per-value activation
+                // switch in the loop the wider access measured 0.73x (round 3); without it the sweep is a plain stream.
+                const char* cv8 = snnhip::option("SNNHIP_NORM_CV8");
+                if (sizeof(T) == 2 && fastNorm && (d.C & 7) == 0 && CLs >= 1 && !(cv8 && atoi(cv8) == 0)) {
+                    const int CLs4 = CLs;
+                    {
+                        const int CLs = CLs4 - 1; // half as many channel lanes, each twice as wide
+                        SNNHIP_LAUNCH((instancenorm_kernel<2, 8, T, true>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta,
+                                      d_part, mptr<T>(out), ra);
+                    }
+                } else {
+                    SNNHIP_IN(2, 4);
+                }
             }
         } else {
             if (sweep) {

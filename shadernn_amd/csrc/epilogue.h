@@ -84,7 +84,12 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // round-to-nearest-even on store) and for CV = 4 (C % 4 == 0: one 16- or 8-byte access) or CV = 1.
 template <typename T, int CV>
 __device__ __forceinline__ void ldv(const T* __restrict__ p, float (&v)[CV]) {
-    if (CV == 4) {
+    if (CV == 8 && sizeof(T) == 2) { // eight halfs: one 16-byte access
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const h8 t = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k % CV] = static_cast<float>(t[k]);
+    } else if (CV == 4) {
         if (sizeof(T) == 4) {
             const float4 t = *reinterpret_cast<const float4*>(p);
             v[0] = t.x;
@@ -105,7 +110,13 @@ __device__ __forceinline__ void ldv(const T* __restrict__ p, float (&v)[CV]) {
 }
 template <typename T, int CV>
 __device__ __forceinline__ void stv(T* __restrict__ p, const float (&v)[CV]) {
-    if (CV == 4) {
+    if (CV == 8 && sizeof(T) == 2) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = static_cast<_Float16>(v[k % CV]);
+        *reinterpret_cast<h8*>(p) = t;
+    } else if (CV == 4) {
         if (sizeof(T) == 4) {
             *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % CV], v[2 % CV], v[3 % CV]);
         } else {

@@ -179,7 +179,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
     // instructions per thread and chunk next to the chunk's 144 MFMAs (+10 %); the normalise sweep it replaces is a read + write of the tensor.
     auto norm_fixup = [&](float* buf, int ic0) {
         typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-        const bool nRelu = p.normAc.act == SNNHIP_ACT_RELU;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (gofs[r] < 0) continue;
@@ -193,7 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wide_kernel(WideParams p, ActCf
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float f = fmaf(static_cast<float>(hv[4 * q4 + k]), muv[k], shv[k]);
-                    hv[4 * q4 + k] = static_cast<_Float16>(nRelu ? fmaxf(f, 0.0f) : __builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                    // (one branch-free form for every simple activation -- ReLU is alpha 1, lo 0 --: a per-value select between this and fmaxf(f, 0) computed both)
+                    hv[4 * q4 + k] = static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
                 }
             }
             *reinterpret_cast<h8v*>(slot) = hv;

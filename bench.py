@@ -286,9 +286,11 @@ def oracle_input(config):
     return np.random.default_rng(7767517).random((1, H, W, cfg["cin"]), dtype=np.float32)
 
 
-def cpu_baseline(config, net, timed_legs=True):
+def cpu_baseline(config, net, timed_legs=True, compact=False):
     """The oracle ("port") on a bounded sample of the workload, single thread and all host threads; dense heads also on the reference's
-    own Eigen path (oracle/_ref/ref_dense).  Returns (record or None, the oracle's result for image 0 of rank 0 -- the parity leg's expectation)."""
+    own Eigen path (oracle/_ref/ref_dense).  Returns (record or None, the oracle's result for image 0 of rank 0 -- the parity leg's expectation).
+    compact = the `configs` block's leg: the parity pass itself is the all-thread sample (plus a short single-thread one where that is under a
+    few seconds), the better of the two is `value`, labelled with the threads that gave it (inferenceProcessor.cpp:84-86: a mean over whole inferences)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
 
@@ -310,6 +312,9 @@ def cpu_baseline(config, net, timed_legs=True):
     # sample sizes chosen so the whole leg stays around 10-30 s of CPU work
     n_multi = {"c1": 20, "c2": 2, "c3": 4, "c4": 8, "c5": 1}[config] if timed_legs else 1
     n_single = {"c1": 5, "c2": 2, "c3": 1, "c4": 2, "c5": 0}[config] if timed_legs else 0
+    if timed_legs and compact:
+        n_multi = {"c1": 5, "c2": 1, "c3": 2, "c4": 2, "c5": 1}[config]
+        n_single = {"c1": 2, "c2": 1, "c3": 1, "c4": 2, "c5": 0}[config]
     tn = timed(cores, n_multi)
     if not timed_legs:
         return None, keep["y"]
@@ -319,6 +324,9 @@ def cpu_baseline(config, net, timed_legs=True):
            "sample": "%d full-size image(s) of the workload (%s) through oracle/liboracle.so, the C restatement of the reference shaders, "
                      "batch 1, all %d host threads%s" % (n_multi, cfg["workload"], cores, (" and %d single-threaded" % n_single) if n_single else ""),
            "all_threads_images_per_s": 1.0 / tn, "single_thread_images_per_s": (1.0 / t1) if t1 else None, "host_threads": cores}
+    if compact:
+        out["sample"] = "%d image(s), all %d host threads%s; oracle/liboracle.so" % (n_multi, cores, (", %d single-threaded" % n_single) if n_single else "")
+        return out, keep["y"]
     dense = [l for l in net["layers"] if l["type"] == "Dense"]
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_dense")
     if dense and os.path.exists(ref):
@@ -421,6 +429,25 @@ def pmc_traffic(kernel):
     return None, "no PMC record for this kernel's instantiations in profiles/pmc_latest.json"
 
 
+def pmc_field(kernel, field):
+    """launch-weighted mean of one field of the committed PMC records (profiles/pmc_latest.json) over a kernel function's instantiations; None when a
+    record is missing or was taken with other kernel sources"""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return None
+    sha = csrc_fingerprint()
+    tot = n = 0.0
+    for inst in kernel["instances"]:
+        ent = pmc.get(_short_kernel_name(inst["name"]))
+        if ent is None or ent.get("csrc_sha16") != sha or ent.get(field) is None:
+            return None
+        tot += ent[field] * inst["launches"]
+        n += inst["launches"]
+    return (tot / n) if n else None
+
+
 def kernel_table(trace, inferences, peak_tf):
     """The launch trace (capi.trace_end) as one row per kernel FUNCTION, most GPU time first.  `flops` / `bytes` are the algorithmic work of the plan
     invocations whose main launch the function was (a fused plan: what the fused launch moves), per traced step; a function that only ever runs
@@ -434,12 +461,20 @@ def kernel_table(trace, inferences, peak_tf):
                "avg_launch_us": 1e3 * k["total_ms"] / max(1, k["launches"]), "share_of_gpu_time": k["total_ms"] / total_ms,
                "algorithmic_flops_per_step": k["flops"] / inferences, "algorithmic_bytes_per_step": k["bytes"] / inferences,
                "instances": [{"name": i["name"], "launches": i["launches"], "total_ms": i["total_ms"], "flops": i["flops"], "bytes": i["bytes"],
-                              "plans": i["plans"][:4]} for i in sorted(k["instances"], key=lambda i: -i["total_ms"])]}
+                              "mfma_flops": i.get("mfma_flops", 0.0), "plans": i["plans"][:4]} for i in sorted(k["instances"], key=lambda i: -i["total_ms"])]}
         if k["main_launches"] and t > 0 and (tf > 0 or tb > 0):
             row["bound"] = "mfma" if tf >= tb else "hbm"
             row["frac"] = max(tf, tb) / t
             row["achieved_tflops"] = k["flops"] / t / 1e12
             row["achieved_hbm_gbps"] = k["bytes"] / t / 1e9
+            if k.get("mfma_flops", 0) > 0 and row["bound"] == "mfma":
+                # Winograd / pre-summed-tap kernels execute fewer multiplies than the algorithmic count: `frac` is throughput on the reference's work,
+                # `frac_executed` what the matrix pipe really does -- read headroom from this one
+                done = k["mfma_flops"] + sum(i["flops"] for i in k["instances"] if not i.get("mfma_flops"))
+                row["frac_executed"] = done / t / 1e12 / peak_tf
+            util = pmc_field(k, "mfma_pipe_util")
+            if util is not None:
+                row["mfma_pipe_util_pmc"] = util
         else:
             row["bound"], row["frac"] = "aux", None
         rows.append(row)
@@ -469,14 +504,15 @@ def roofline_record(rows, peak_tf, single_launch_step):
         # wave start-up, the tail of a single round of blocks), not the memory system; the fraction stays quoted against HBM
         rec["bound"] = "launch"
         rec["bound_note"] = "single %.1f us kernel per step: launch / ramp bound; achieved and peak are the HBM figures" % dom["avg_launch_us"]
-    m = re.search(r"mfma_flops=([0-9.e+]+)", " ".join(rec["plans"]))
-    if m and mfma:
-        # `achieved` uses the ALGORITHMIC flops of the direct convolutions (2*k*k*IC*OC per output pixel).  The ESPCN kernel evaluates its
-        # 3x3 layer as Winograd F(2x2,3x3) (2.25x fewer multiplies) but recomputes conv1 on the tile halo: what the matrix pipe really executes
-        ex = float(m.group(1))
-        rec["executed_mfma_flops_per_launch"] = ex
-        rec["executed_mfma_tflops"] = ex * launches / t / 1e12
-        rec["frac_executed"] = ex * launches / t / 1e12 / peak_tf
+    if mfma and dom.get("frac_executed") is not None:
+        # `achieved` uses the ALGORITHMIC flops of the direct convolutions (2*k*k*IC*OC per output pixel).  A Winograd F(2x2,3x3) kernel
+        # multiplies 2.25x less (the ESPCN kernel also recomputes conv1 on the tile halo): `frac_executed` is what the matrix pipe really executes
+        ex = sum((i.get("mfma_flops") or i["flops"]) for i in dom["instances"])
+        rec["executed_mfma_flops_per_launch"] = ex / launches
+        rec["executed_mfma_tflops"] = ex / t / 1e12
+        rec["frac_executed"] = ex / t / 1e12 / peak_tf
+    if dom.get("mfma_pipe_util_pmc") is not None:
+        rec["mfma_pipe_util_pmc"] = dom["mfma_pipe_util_pmc"]
     return rec
 
 
@@ -518,7 +554,7 @@ def run_config(config, args, env, primary):
     # ---- parity leg (rank 0): the GPU result of image 0 against the oracle's, before anything is timed
     parity, cpu_rec = None, None
     if rank == 0 and not args.no_parity:
-        cpu_rec, want = cpu_baseline(config, net, timed_legs=(primary and world == 1 and not args.no_cpu_baseline))
+        cpu_rec, want = cpu_baseline(config, net, timed_legs=(world == 1 and not args.no_cpu_baseline), compact=not primary)
         got = wl.first_input_output()
         got = np.asarray(got).reshape((-1,) + tuple(want.shape[1:]))[:1]
         parity = parity_record(config, got, want)
@@ -531,13 +567,16 @@ def run_config(config, args, env, primary):
     barrier()
 
     def timed_region(step_fn, n):
+        """exactly n steps between two barriers + synchronisations; a rank's interval ends on its own clock right after its own wait (the
+        trailing barrier sits OUTSIDE it: an RCCL barrier inside a 2.4 ms region would read as 2-4 % of lost scaling), MAX over ranks"""
         barrier()
         t0 = time.perf_counter()
         for _ in range(n):
             step_fn()
         wl.sync()
+        dt = time.perf_counter() - t0
         barrier()
-        return group.max_over_ranks(time.perf_counter() - t0)
+        return group.max_over_ranks(dt)
 
     # time-based pre-heat, then the driver's warmup steps
     t0 = time.perf_counter()
@@ -620,6 +659,7 @@ def run_config(config, args, env, primary):
             "config": {"workload": cfg["workload"], "config_id": config, "global_batch": global_batch, "images_per_rank_per_step": images,
                        "micro_batches_per_rank": wl.micro_sizes, "input": [images, H, W, cfg["cin"]],
                        "parallelism": "dp%d (batch split, weights replicated, no data-path collective)" % world,
+                       "backend": group.backend or "none (one rank)", "ranks_per_device": max(1, -(-world // max(1, env["torch"].cuda.device_count()))),
                        "path": ("C++ host mirror (libsnn_core.so, JSON + .bin model -> ModelParser -> MixedInferenceCore::create / run%s)" % ("" if args.no_capture else ", recorded hipGraph replay")
                                 if through == "host" else "per-layer plans through the C-ABI") +
                                (", graph fusion (snnhip_graph_fuse)" if not args.unfused else ", one kernel per layer") + ", %d kernel launches per step" % launches,
@@ -631,9 +671,12 @@ def run_config(config, args, env, primary):
             "achieved_hbm_gbps_unfused_accounting_per_gpu": bytes_unfused / step_s / 1e9,
             "frac_hbm_roofline_unfused_accounting": bytes_unfused / step_s / 1e9 / PEAK_HBM_GBPS,
             "frac_compute_roofline": flops / step_s / 1e12 / peak_tf,
-            "whole_step_roofline_ms": 1e3 * max(flops / peak_tf / 1e12, bytes_unfused / PEAK_HBM_GBPS / 1e9),
         }
-        out["frac_of_whole_step_roofline"] = out["whole_step_roofline_ms"] / out["ms_per_step"]
+        # per-LAYER accounting (every layer reads its input and writes its output once): what the unfused graph would have to move.  Where fusion
+        # removes tensors the step beats this figure (c5: 1.5x), so it is reported as a ratio, never as a roofline fraction
+        unfused_ms = 1e3 * max(flops / peak_tf / 1e12, bytes_unfused / PEAK_HBM_GBPS / 1e9)
+        out["unfused_accounting"] = {"roofline_ms": unfused_ms, "ratio_to_measured": unfused_ms / out["ms_per_step"],
+                                     "note": "per-layer byte count of the unfused graph; not a bound on the fused step (a ratio above 1 = traffic the fusion removed)"}
         if modes:
             out["wait_semantics"] = {
                 "value_is": value_mode,
@@ -646,7 +689,6 @@ def run_config(config, args, env, primary):
                                                      "ms_per_step": 1e3 * modes["sync_per_inference_blocking_wait"] / steps,
                                                      "what": "the same with the library default SNNHIP_SYNC_SPIN_US=0: hipStreamSynchronize at once"},
             }
-            out["frac_of_whole_step_roofline_sync_per_inference"] = out["whole_step_roofline_ms"] / out["wait_semantics"]["sync_per_inference"]["ms_per_step"]
         if layer_table is not None:
             out["layer_table"] = {"method": "reference benchmark table (inferenceProcessor.cpp:84-86,143-199): %d inferences, first 5 dropped, per-stage device timers "
                                             "(MixedInferenceCore::writeTimeStat), mean and population sigma in ms; launch by launch (timers need the host between stages)" % (table_loops + 5),
@@ -657,15 +699,27 @@ def run_config(config, args, env, primary):
             per_step = sum(max(r["algorithmic_flops_per_step"] / peak_tf / 1e12, r["algorithmic_bytes_per_step"] / PEAK_HBM_GBPS / 1e9) for r in rows)
             out["sum_of_launch_rooflines_ms"] = 1e3 * per_step
             out["frac_of_sum_of_launch_rooflines"] = 1e3 * per_step / out["ms_per_step"]
+            # THE whole-step fraction: the step against the sum of its launches' own rooflines (fused accounting) -- always <= 1 for a correct count
+            out["whole_step_roofline_ms"] = 1e3 * per_step
+            out["frac_of_whole_step_roofline"] = out["frac_of_sum_of_launch_rooflines"]
+            if modes:
+                out["frac_of_whole_step_roofline_sync_per_inference"] = 1e3 * per_step / (1e3 * modes["sync_per_inference"] / steps)
             out["sum_of_kernel_durations_ms"] = sum(r["us_per_step"] for r in rows) / 1e3
             out["traced_steps"] = trace_steps
             out["kernels"] = rows if args.all_kernels else [dict(r, instances=r["instances"][:3]) for r in rows[:10]]
             out["roofline"] = roofline_record(rows, peak_tf, single_launch_step=(launches == 1))
+            out["roofline"]["whole_step_frac"] = out["frac_of_whole_step_roofline"]
+            if modes:
+                # `value` keeps the timed region's inferences in flight (RunParameters::deferSync); under the reference's one wait per inference
+                # (core.cpp:203) the same models give:
+                out["roofline"]["sync_per_inference_images_per_s"] = global_batch * steps / modes["sync_per_inference"]
+                out["roofline"]["sync_per_inference_blocking_wait_images_per_s"] = global_batch * steps / modes["sync_per_inference_blocking_wait"]
+                out["roofline"]["whole_step_frac_sync_per_inference"] = out["frac_of_whole_step_roofline_sync_per_inference"]
         if cpu_rec is not None:
             out["cpu_baseline"] = cpu_rec
         if not primary:
             # the compact form of the `configs` block
-            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "scaling", "value_mode", "frac_of_whole_step_roofline", "whole_step_roofline_ms",
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "scaling", "value_mode", "frac_of_whole_step_roofline", "whole_step_roofline_ms", "unfused_accounting", "unfused_accounting",
                     "sum_of_launch_rooflines_ms", "frac_of_sum_of_launch_rooflines", "sum_of_kernel_durations_ms", "flops_per_image", "bytes_per_image_unfused_accounting")
             comp = {k: out[k] for k in keep if k in out}
             comp["workload"] = cfg["workload"]
@@ -679,9 +733,12 @@ def run_config(config, args, env, primary):
             if rows:
                 r = out["roofline"]
                 comp["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic_bytes", "kernel", "share_of_gpu_time",
-                                                      "launches_per_step", "avg_launch_us", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch") if k in r}
+                                                      "launches_per_step", "avg_launch_us", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "frac_executed",
+                                                      "mfma_pipe_util_pmc", "whole_step_frac") if k in r}
                 comp["kernels"] = [{"function": k["function"], "share_of_gpu_time": k["share_of_gpu_time"], "us_per_step": k["us_per_step"], "launches_per_step": k["launches_per_step"],
-                                    "bound": k["bound"], "frac": k["frac"]} for k in rows[:6]]
+                                    "bound": k["bound"], "frac": k["frac"], "frac_executed": k.get("frac_executed")} for k in rows[:6]]
+            if cpu_rec is not None:
+                comp["cpu_baseline"] = cpu_rec
             out = comp
     wl.close()
     return out, parity
@@ -712,6 +769,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle check (debug only: the line then says parity: null)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the launch-trace leg (no `roofline` / `kernels`)")
     ap.add_argument("--event-launches", type=int, default=64, help="upper bound on the steps run under the launch trace after the timed region (per config: 64 / 32 / 8 / 4 / 2)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the barrier / MAX-reduction (nccl = RCCL, the driver's; gloo: several ranks may share one GPU -- rank r "
+                         "runs on device r %% device_count -- which is how the N > 1 path is exercised on a one-GPU box)")
     ap.add_argument("--layer-table", type=int, default=None, help="loops of the reference-style per-layer table (first 5 dropped); default 20 at N=1, 0 = off")
     args = ap.parse_args()
 
@@ -734,9 +794,10 @@ def main():
         sys.stderr.write("bench.py: no GPU visible; the HIP path has no CPU fallback\n")
         sys.exit(3)
     if torch.cuda.device_count() < world and rank == 0:
-        sys.stderr.write("bench.py: %d ranks on %d visible GPU(s)\n" % (world, torch.cuda.device_count()))
+        sys.stderr.write("bench.py: %d ranks on %d visible GPU(s)%s\n" % (world, torch.cuda.device_count(),
+                                                                          "" if args.backend == "gloo" else " -- RCCL refuses two ranks on one device: use --backend gloo"))
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-    group = sdist.Group(backend="nccl")  # nccl == RCCL on ROCm; only barrier + MAX-reduction of the time use it
+    group = sdist.Group(backend=args.backend, local_device=local_rank % max(1, torch.cuda.device_count()))  # nccl == RCCL on ROCm; only barrier + MAX-reduction of the time use it
 
     import shadernn_amd as snn
 
@@ -764,7 +825,18 @@ def main():
         if rank == 0:
             out["configs"] = recs
             out["configs_note"] = ("the other BASELINE configs, same process, same method (host mirror + hipGraph replay, in-run oracle parity on image 0, median of R "
-                                   "timed regions, launch trace for the per-kernel roofline); CPU legs: the parity pass only; %.0f s in total" % (time.perf_counter() - t0))
+                                   "timed regions, launch trace for the per-kernel roofline); CPU legs: the oracle timed on 1-5 whole images per config (the parity pass "
+                                   "is one of them), better of all-threads / single-thread, labelled; %.0f s in total" % (time.perf_counter() - t0))
+            if "roofline" in out:
+                def brief(c, r):
+                    if "error" in r:
+                        return {"id": c, "error": r["error"]}
+                    rf, cb, par = r.get("roofline") or {}, r.get("cpu_baseline") or {}, r.get("parity") or {}
+                    return {"id": c, "ms_per_step": r.get("ms_per_step"), "images_per_s": r.get("value"), "whole_step_frac": r.get("frac_of_whole_step_roofline"),
+                            "dominant_kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": rf.get("frac"), "frac_executed": rf.get("frac_executed"),
+                            "share_of_gpu_time": rf.get("share_of_gpu_time"), "parity_ok": par.get("ok"), "max_abs_err": par.get("max_abs_err"),
+                            "cpu_images_per_s": cb.get("value"), "cpu_cores": cb.get("cores")}
+                out["roofline"]["other_configs"] = [brief(c, recs[c]) for c in extra]
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

@@ -48,6 +48,7 @@ extern "C" {
 #define SNNHIP_E_HIP (-2)         /* a HIP runtime call failed (message has the hipError)   */
 #define SNNHIP_E_UNSUPPORTED (-3) /* valid request that no kernel variant implements        */
 #define SNNHIP_E_NOMEM (-4)
+#define SNNHIP_E_GUARD (-5)       /* SNNHIP_GUARD=1: a kernel wrote outside one of the library's device allocations */
 
 typedef struct snnhip_ctx snnhip_ctx;
 typedef struct snnhip_tensor snnhip_tensor;
@@ -105,6 +106,16 @@ const char* snnhip_version(void);
  * counterpart: its shader variants are picked by MixedInferenceCore's options struct (core/inc/snn/core.h: dumpOutputs, mrtMode, weightMode ...). */
 int snnhip_set_option(const char* name, const char* value);
 const char* snnhip_get_option(const char* name); /* the effective value (override, else environment), or NULL */
+/* Device-side guard mode (SURVEY section 5's "compute-sanitizer equivalent"; the reference has none, core/CMakeLists.txt:235).  With SNNHIP_GUARD=1 in the
+ * environment when the library makes its first allocation, every device allocation of the library -- tensors, packed weights, split-K / statistics
+ * scratch -- sits between two 64 KiB red zones filled with 0xFF bytes (a NaN in fp32 and in fp16: an out-of-bounds READ that reaches a result
+ * poisons it, and fresh tensors / scratch are poisoned the same way, so a read of something never written shows too), the tensor flush against the
+ * zone behind it.  snnhip_sync (and snnhip_guard_check) then verifies every red zone of the context's device and returns SNNHIP_E_GUARD naming
+ * the allocation a kernel wrote outside of.  snnhip_guard_selftest writes one byte `offset` bytes past the END of a tensor (offset < 0: in front
+ * of it) from a kernel -- the deliberate fault the checker's own test uses.  tools/sanitize.sh runs the fuzz and bench-size tests under it. */
+int snnhip_guard_active(void);
+int snnhip_guard_check(snnhip_ctx* ctx);
+int snnhip_guard_selftest(snnhip_ctx* ctx, snnhip_tensor* t, long offset);
 
 /* ---- tensors: NHWC fp32 in HBM ------------------------------------------------------------------- */
 

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNNHIP_LIB_PATH") or os.path.join(_HERE, "lib", "libsnnhip.so")  # the override serves ablation builds (tools/)
 
-OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4
+OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM, E_GUARD = 0, -1, -2, -3, -4, -5
 
 ACT = {"": 0, "linear": 0, "none": 0, "relu": 1, "relu6": 2, "tanh": 3, "sigmoid": 4, "leakyRelu": 5, "SiLU": 6, "SiLU_quirk": 7}
 PAD_MODE = {"none": 0, "constant": 1, "replicate": 2, "reflect": 3}
@@ -110,6 +110,9 @@ SIGNATURES = {
     "snnhip_last_error": (C.c_char_p, []),
     "snnhip_version": (C.c_char_p, []),
     "snnhip_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "snnhip_guard_active": (C.c_int, []),
+    "snnhip_guard_check": (C.c_int, [_P]),
+    "snnhip_guard_selftest": (C.c_int, [_P, _P, C.c_long]),
     "snnhip_get_option": (C.c_char_p, [C.c_char_p]),
     "snnhip_tensor_alloc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "snnhip_tensor_wrap": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),

@@ -38,6 +38,10 @@ const char* option(const char* name) {
 
 
 namespace snnhip {
+namespace {
+bool guard_on(); // SNNHIP_GUARD=1 (below: device allocations + the guard mode)
+}
+static int guard_check_device(snnhip_ctx* ctx);
 
 static thread_local char g_err[1024] = "";
 
@@ -179,6 +183,13 @@ std::string base_name(const std::string& full) {
 bool trace_active() { return g_traceOn.load(std::memory_order_relaxed); }
 
 int trace_events(const void* fn, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop) {
+    // a stream that is being captured into a graph cannot carry timing events (they would invalidate the capture and the recording run of a
+    // capture_graph model would abort): such a launch goes out untimed and unrecorded -- a trace measures plans that are RUN, never the recording
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        *start = *stop = nullptr;
+        return SNNHIP_OK;
+    }
     Tracer& t = tracer();
     std::lock_guard<std::mutex> lock(t.m);
     if (t.used == t.pool.size()) {
@@ -217,7 +228,7 @@ int snnhip_plan::invoke(const snnhip_tensor* const* in, int nIn, snnhip_tensor* 
 
 int snnhip_plan::upload(const float* host, size_t count, float** dev) {
     void* p = nullptr;
-    SNNHIP_CHECK_HIP(hipMalloc(&p, count ? count * sizeof(float) : 4));
+    SNNHIP_CHECK_HIP(snnhip::dev_malloc(&p, count ? count * sizeof(float) : 4, "packed weights / table of a plan"));
     deviceAllocs.push_back(p);
     if (count) SNNHIP_CHECK_HIP(hipMemcpy(p, host, count * sizeof(float), hipMemcpyHostToDevice));
     *dev = static_cast<float*>(p);
@@ -398,6 +409,7 @@ int snnhip_sync(snnhip_ctx* ctx) {
         }
     }
     SNNHIP_CHECK_HIP(hipStreamSynchronize(ctx->mainStream)); // (side-stream work is joined into the main stream by snnhip_ctx_join)
+    if (snnhip::guard_on()) return snnhip::guard_check_device(ctx); // SNNHIP_GUARD=1: every red zone of this device, SNNHIP_E_GUARD names the allocation
     return SNNHIP_OK;
 }
 
@@ -447,6 +459,164 @@ int snnhip_graph_destroy(snnhip_graph* g) {
     return SNNHIP_OK;
 }
 
+/* ---- device allocations + the guard mode (SNNHIP_GUARD=1) ---- */
+
+extern "C++" {
+namespace snnhip {
+namespace {
+constexpr size_t kGuardZone = 64 * 1024; // bytes of 0xFF in front of and behind every allocation (a multiple of 256: the user pointer keeps hipMalloc's alignment)
+struct GuardRec {
+    char* base;       // what hipMalloc returned: [front zone][user bytes][slack to 16 + back zone]
+    size_t bytes;     // user bytes
+    size_t backBytes; // bytes of the zone behind the user region (kGuardZone + the slack that rounds the region up to 16)
+    int device;
+    std::string what;
+};
+struct GuardZoneDesc {
+    const unsigned char* p;
+    unsigned long long bytes;
+};
+std::mutex g_guardMutex;
+std::map<void*, GuardRec>& guard_map() {
+    static std::map<void*, GuardRec> m;
+    return m;
+}
+std::atomic<int> g_guardOn{-1};
+
+bool guard_on() {
+    int v = g_guardOn.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("SNNHIP_GUARD"); // (the environment only, read once at the first allocation: a process is guarded or it is not)
+        v = (e && atoi(e) != 0) ? 1 : 0;
+        g_guardOn.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+
+// one block per red zone: the lowest offset whose byte is not 0xFF, as (zone index << 40 | offset), minimum over everything
+__global__ void guard_check_kernel(const GuardZoneDesc* zones, unsigned long long* first) {
+    const GuardZoneDesc z = zones[blockIdx.x];
+    for (unsigned long long i = threadIdx.x; i < z.bytes; i += blockDim.x)
+        if (z.p[i] != 0xFFu) {
+            atomicMin(first, (static_cast<unsigned long long>(blockIdx.x) << 40) | i);
+            break;
+        }
+}
+__global__ void guard_poke_kernel(unsigned char* p) { *p = 0x5A; }
+} // namespace
+
+hipError_t dev_malloc_bytes(void** p, size_t bytes, const char* what) {
+    if (!guard_on()) return hipMalloc(p, bytes);
+    const size_t user = (bytes + 15) & ~static_cast<size_t>(15);
+    void* base = nullptr;
+    const hipError_t e = hipMalloc(&base, kGuardZone + user + kGuardZone);
+    if (e != hipSuccess) return e;
+    const hipError_t m = hipMemset(base, 0xFF, kGuardZone + user + kGuardZone); // zones AND contents: nothing reads as a plausible number before it is written
+    if (m != hipSuccess) {
+        (void) hipFree(base);
+        return m;
+    }
+    GuardRec r;
+    r.base = static_cast<char*>(base);
+    r.bytes = bytes;
+    r.backBytes = (user - bytes) + kGuardZone;
+    r.what = what ? what : "";
+    r.device = 0;
+    (void) hipGetDevice(&r.device);
+    *p = r.base + kGuardZone;
+    std::lock_guard<std::mutex> lock(g_guardMutex);
+    guard_map()[*p] = r;
+    return hipSuccess;
+}
+
+hipError_t dev_free(void* p) {
+    if (!p) return hipSuccess;
+    if (guard_on()) {
+        std::lock_guard<std::mutex> lock(g_guardMutex);
+        auto it = guard_map().find(p);
+        if (it != guard_map().end()) {
+            void* base = it->second.base;
+            guard_map().erase(it);
+            return hipFree(base);
+        }
+    }
+    return hipFree(p);
+}
+
+// every red zone of the allocations on ctx's device; SNNHIP_E_GUARD + a message naming the first damaged allocation (its zone is re-poisoned so that the
+// next check reports new damage only).  The stream is drained first: called from snnhip_sync, never inside a capture.
+static int guard_check_device(snnhip_ctx* ctx) {
+    std::vector<GuardZoneDesc> zones;
+    std::vector<void*> owner;
+    {
+        std::lock_guard<std::mutex> lock(g_guardMutex);
+        for (const auto& kv : guard_map()) {
+            const GuardRec& r = kv.second;
+            if (r.device != ctx->device) continue;
+            zones.push_back({reinterpret_cast<const unsigned char*>(r.base), static_cast<unsigned long long>(kGuardZone)});
+            owner.push_back(kv.first);
+            zones.push_back({reinterpret_cast<const unsigned char*>(r.base) + kGuardZone + r.bytes, static_cast<unsigned long long>(r.backBytes)});
+            owner.push_back(kv.first);
+        }
+    }
+    if (zones.empty()) return SNNHIP_OK;
+    SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    void* dz = nullptr;
+    SNNHIP_CHECK_HIP(hipMalloc(&dz, zones.size() * sizeof(GuardZoneDesc) + 8));
+    unsigned long long* dfirst = reinterpret_cast<unsigned long long*>(static_cast<char*>(dz) + zones.size() * sizeof(GuardZoneDesc));
+    unsigned long long first = ~0ull;
+    hipError_t e = hipMemcpy(dz, zones.data(), zones.size() * sizeof(GuardZoneDesc), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dfirst, &first, 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(guard_check_kernel, dim3(static_cast<unsigned>(zones.size())), dim3(256), 0, ctx->mainStream, static_cast<const GuardZoneDesc*>(dz), dfirst);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->mainStream);
+    if (e == hipSuccess) e = hipMemcpy(&first, dfirst, 8, hipMemcpyDeviceToHost);
+    (void) hipFree(dz);
+    SNNHIP_CHECK_HIP(e);
+    if (first == ~0ull) return SNNHIP_OK;
+    const size_t zi = static_cast<size_t>(first >> 40), off = static_cast<size_t>(first & ((1ull << 40) - 1));
+    std::string what;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_guardMutex);
+        auto it = guard_map().find(owner[zi]);
+        if (it != guard_map().end()) {
+            what = it->second.what;
+            bytes = it->second.bytes;
+        }
+    }
+    (void) hipMemset(const_cast<unsigned char*>(zones[zi].p), 0xFF, zones[zi].bytes);
+    if (zi & 1)
+        set_error("SNNHIP_GUARD: a kernel wrote %zu byte(s) past the END of a device allocation (%s, %zu bytes, device %d)", off + 1, what.c_str(), bytes, ctx->device);
+    else
+        set_error("SNNHIP_GUARD: a kernel wrote %zu byte(s) in FRONT of a device allocation (%s, %zu bytes, device %d)", kGuardZone - off, what.c_str(), bytes, ctx->device);
+    return SNNHIP_E_GUARD;
+}
+} // namespace snnhip
+} // extern "C++"
+
+int snnhip_guard_active(void) { return snnhip::guard_on() ? 1 : 0; }
+
+int snnhip_guard_check(snnhip_ctx* ctx) {
+    SNNHIP_REQUIRE(ctx, "guard_check: null ctx");
+    if (!snnhip::guard_on()) return SNNHIP_OK;
+    SNNHIP_CHECK_HIP(hipStreamSynchronize(ctx->mainStream));
+    return snnhip::guard_check_device(ctx);
+}
+
+int snnhip_guard_selftest(snnhip_ctx* ctx, snnhip_tensor* t, long offset) {
+    SNNHIP_REQUIRE(ctx && t && t->data, "guard_selftest: null argument");
+    SNNHIP_REQUIRE(snnhip::guard_on() && t->owns, "guard_selftest: needs SNNHIP_GUARD=1 and a tensor of snnhip_tensor_alloc");
+    SNNHIP_REQUIRE(offset >= -static_cast<long>(snnhip::kGuardZone) && offset < static_cast<long>(snnhip::kGuardZone) && offset != -0x7fffffffL,
+                   "guard_selftest: offset %ld outside the red zones", offset);
+    unsigned char* p = reinterpret_cast<unsigned char*>(t->data) + (offset >= 0 ? static_cast<long>(t->bytes()) + offset : offset);
+    hipLaunchKernelGGL(snnhip::guard_poke_kernel, dim3(1), dim3(1), 0, ctx->stream, p);
+    SNNHIP_CHECK_HIP(hipGetLastError());
+    return SNNHIP_OK;
+}
+
 /* ---- tensors ---- */
 
 int snnhip_tensor_alloc(snnhip_ctx* ctx, int n, int h, int w, int c, int dtype, snnhip_tensor** out) {
@@ -458,7 +628,9 @@ int snnhip_tensor_alloc(snnhip_ctx* ctx, int n, int h, int w, int c, int dtype, 
     t->ctx = ctx; t->n = n; t->h = h; t->w = w; t->c = c; t->owns = true; t->dtype = dtype;
     void* p = nullptr;
     const size_t nbytes = (t->bytes() + 15) & ~static_cast<size_t>(15);
-    hipError_t e = hipMalloc(&p, nbytes);
+    char what[96];
+    snprintf(what, sizeof(what), "tensor %dx%dx%dx%d dtype %d", n, h, w, c, dtype);
+    hipError_t e = snnhip::dev_malloc(&p, nbytes, what);
     if (e != hipSuccess) {
         delete t;
         set_error("hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e));
@@ -484,7 +656,7 @@ int snnhip_tensor_wrap(snnhip_ctx* ctx, void* device_ptr, int n, int h, int w, i
 
 int snnhip_tensor_free(snnhip_tensor* t) {
     if (!t) return SNNHIP_OK;
-    if (t->owns && t->data) (void) hipFree(t->data);
+    if (t->owns && t->data) (void) snnhip::dev_free(t->data);
     delete t;
     return SNNHIP_OK;
 }
@@ -523,11 +695,11 @@ int snnhip_tensor_download(const snnhip_tensor* t, float* host) {
         SNNHIP_CHECK_HIP(hipMemcpyAsync(tmp.data(), t->data, t->bytes(), hipMemcpyDeviceToHost, t->ctx->stream));
         SNNHIP_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
         for (size_t i = 0; i < tmp.size(); ++i) host[i] = static_cast<float>(tmp[i]);
-        return SNNHIP_OK;
+        return (snnhip::guard_on() && t->ctx->stream == t->ctx->mainStream) ? snnhip::guard_check_device(t->ctx) : SNNHIP_OK;
     }
     SNNHIP_CHECK_HIP(hipMemcpyAsync(host, t->data, t->bytes(), hipMemcpyDeviceToHost, t->ctx->stream));
     SNNHIP_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
-    return SNNHIP_OK;
+    return (snnhip::guard_on() && t->ctx->stream == t->ctx->mainStream) ? snnhip::guard_check_device(t->ctx) : SNNHIP_OK; // (a download ends most tests: SNNHIP_GUARD checks here too)
 }
 
 int snnhip_tensor_upload_raw(snnhip_tensor* t, const void* host, size_t nbytes) {
@@ -774,6 +946,7 @@ int snnhip_trace_report(char* buf, size_t buflen, size_t* needed) {
         std::string name;
         long launches = 0;
         double ms = 0, flops = 0, bytes = 0;
+        double mfmaFlops = 0; // what the matrix pipe executes where that differs from the algorithmic count ("mfma_flops=" in the plan's description: Winograd, pre-summed taps)
         long mainLaunches = 0;
         std::vector<std::string> plans;
     };
@@ -801,6 +974,10 @@ int snnhip_trace_report(char* buf, size_t buflen, size_t* needed) {
         Inst& in = insts[t.recs[mainOf[sc]].fn];
         in.flops += t.scopes[sc].flops;
         in.bytes += t.scopes[sc].bytes;
+        {
+            const size_t at = t.scopes[sc].desc.find("mfma_flops=");
+            if (at != std::string::npos) in.mfmaFlops += strtod(t.scopes[sc].desc.c_str() + at + 11, nullptr);
+        }
         ++in.mainLaunches;
         bool seen = false;
         for (const auto& d : in.plans) seen = seen || d == t.scopes[sc].desc;
@@ -813,21 +990,23 @@ int snnhip_trace_report(char* buf, size_t buflen, size_t* needed) {
     char num[256];
     for (const auto& kv : byBase) {
         long launches = 0, mainLaunches = 0;
-        double ms = 0, flops = 0, bytes = 0;
+        double ms = 0, flops = 0, bytes = 0, mfmaFlops = 0;
         for (const Inst* in : kv.second) {
             launches += in->launches;
             mainLaunches += in->mainLaunches;
             ms += in->ms;
             flops += in->flops;
             bytes += in->bytes;
+            mfmaFlops += in->mfmaFlops;
         }
-        snprintf(num, sizeof(num), "\"launches\": %ld, \"main_launches\": %ld, \"total_ms\": %.9g, \"flops\": %.9g, \"bytes\": %.9g", launches, mainLaunches, ms, flops, bytes);
+        snprintf(num, sizeof(num), "\"launches\": %ld, \"main_launches\": %ld, \"total_ms\": %.9g, \"flops\": %.9g, \"bytes\": %.9g, \"mfma_flops\": %.9g", launches, mainLaunches, ms,
+                 flops, bytes, mfmaFlops);
         js += std::string(firstK ? "" : ", ") + "{\"function\": \"" + json_escape(kv.first) + "\", " + num + ", \"instances\": [";
         firstK = false;
         bool firstI = true;
         for (const Inst* in : kv.second) {
-            snprintf(num, sizeof(num), "\"launches\": %ld, \"main_launches\": %ld, \"total_ms\": %.9g, \"flops\": %.9g, \"bytes\": %.9g", in->launches, in->mainLaunches, in->ms,
-                     in->flops, in->bytes);
+            snprintf(num, sizeof(num), "\"launches\": %ld, \"main_launches\": %ld, \"total_ms\": %.9g, \"flops\": %.9g, \"bytes\": %.9g, \"mfma_flops\": %.9g", in->launches,
+                     in->mainLaunches, in->ms, in->flops, in->bytes, in->mfmaFlops);
             js += std::string(firstI ? "" : ", ") + "{\"name\": \"" + json_escape(in->name) + "\", " + num + ", \"plans\": [";
             firstI = false;
             for (size_t k = 0; k < in->plans.size(); ++k) js += std::string(k ? ", " : "") + "\"" + json_escape(in->plans[k]) + "\"";

@@ -113,7 +113,11 @@ __global__ __launch_bounds__(256) void conv2d_generic_kernel(GenericParams p, co
 
     // ---- epilogue + store
     const int oy = oy0 + qy;
+#ifdef SNNHIP_GUARD_BREAK // the deliberately broken build tools/sanitize.sh guard must catch: an off-by-one row bound, i.e. one output row stored past the end of the last image
+    if (oy > p.OH) return;
+#else
     if (oy >= p.OH) return;
+#endif
     const int oc0 = ocb * OCB + ocq * 4;
     float4 e[4];
 #pragma unroll

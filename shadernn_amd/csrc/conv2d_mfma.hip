@@ -150,7 +150,7 @@ struct MfmaConvPlan : ConvPlanBase {
         }
         void* buf = nullptr;
         const size_t bytes = static_cast<size_t>(p.N) * p.tilesY * p.tilesX * 2 * p.OC * sizeof(float);
-        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        if (snnhip::dev_malloc(&buf, bytes) != hipSuccess) return false;
         deviceAllocs.push_back(buf);
         statPart = p.statPart = static_cast<float*>(buf);
         statTilesX = p.tilesX; statTilesY = p.tilesY; statTH = 1 << p.THs; statTW = 1 << p.TWs;
@@ -394,7 +394,7 @@ static int make_conv2d_mfma_plan_ex(snnhip_ctx* ctx, const ConvGeom& g, const fl
     if (p.splitK > 1) {
         void* ws = nullptr;
         const size_t wsBytes = static_cast<size_t>(p.splitK) * g.N * g.OH * g.OW * g.OC * sizeof(float);
-        if (hipMalloc(&ws, wsBytes) != hipSuccess) {
+        if (snnhip::dev_malloc(&ws, wsBytes) != hipSuccess) {
             set_error("conv2d_mfma: split-K workspace of %zu bytes", wsBytes);
             delete plan;
             return SNNHIP_E_HIP;
@@ -564,9 +564,9 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     const size_t inBytes = static_cast<size_t>(g.N) * (g.preMode ? g.srcH : g.H) * (g.preMode ? g.srcW : g.W) * g.IC * esz;
     const size_t outBytes = static_cast<size_t>(g.N) * g.OH * g.OW * g.OC * esz;
     void *dx = nullptr, *dy = nullptr, *dr = nullptr;
-    if (hipMalloc(&dx, inBytes) != hipSuccess || hipMalloc(&dy, outBytes) != hipSuccess || (g.addAct >= 0 && hipMalloc(&dr, outBytes) != hipSuccess)) {
-        if (dx) (void) hipFree(dx);
-        if (dy) (void) hipFree(dy);
+    if (snnhip::dev_malloc(&dx, inBytes) != hipSuccess || snnhip::dev_malloc(&dy, outBytes) != hipSuccess || (g.addAct >= 0 && snnhip::dev_malloc(&dr, outBytes) != hipSuccess)) {
+        if (dx) (void) snnhip::dev_free(dx);
+        if (dy) (void) snnhip::dev_free(dy);
         return make_conv2d_mfma_plan_ex(ctx, g, w_oihw, epi4, MfmaOverride(), out);
     }
     bool hipOk = hipMemsetAsync(dx, 0, inBytes, ctx->stream) == hipSuccess;
@@ -582,9 +582,9 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (!hipOk) { // the tuner is an optimisation: any HIP failure here falls back to the heuristic configuration
         if (e0) (void) hipEventDestroy(e0);
         if (e1) (void) hipEventDestroy(e1);
-        (void) hipFree(dx);
-        (void) hipFree(dy);
-        if (dr) (void) hipFree(dr);
+        (void) snnhip::dev_free(dx);
+        (void) snnhip::dev_free(dy);
+        if (dr) (void) snnhip::dev_free(dr);
         return make_conv2d_mfma_plan_ex(ctx, g, w_oihw, epi4, MfmaOverride(), out);
     }
     MfmaOverride best;
@@ -629,9 +629,9 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     (void) hipEventDestroy(e0);
     (void) hipEventDestroy(e1);
     (void) hipStreamSynchronize(ctx->stream);
-    (void) hipFree(dx);
-    (void) hipFree(dy);
-    if (dr) (void) hipFree(dr);
+    (void) snnhip::dev_free(dx);
+    (void) snnhip::dev_free(dy);
+    if (dr) (void) snnhip::dev_free(dr);
     {
         std::lock_guard<std::mutex> lock(cacheMutex);
         cache[key] = best;

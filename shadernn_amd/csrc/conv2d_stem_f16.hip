@@ -353,7 +353,7 @@ struct StemConvPlan : ConvPlanBase {
         const int tpi = p.tilesX * p.tilesY, chunk = up_div(tpi * p.N, static_cast<int>(grid.x));
         p.statSlots = up_div(tpi, chunk) + 1;
         void* buf = nullptr;
-        if (hipMalloc(&buf, static_cast<size_t>(p.N) * grid.y * p.statSlots * (1 + 2 * 32) * sizeof(float)) != hipSuccess) return false;
+        if (snnhip::dev_malloc(&buf, static_cast<size_t>(p.N) * grid.y * p.statSlots * (1 + 2 * 32) * sizeof(float)) != hipSuccess) return false;
         deviceAllocs.push_back(buf);
         statPart = p.statRec = static_cast<float*>(buf);
         statTilesX = p.statSlots; statTilesY = 1; statTH = 0; statTW = 0;
@@ -370,7 +370,7 @@ struct StemConvPlan : ConvPlanBase {
         if (!statPart || p.fold.counter) return false;
         void* buf = nullptr;
         const size_t bytes = static_cast<size_t>(p.N) * grid.y * sizeof(unsigned);
-        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        if (snnhip::dev_malloc(&buf, bytes) != hipSuccess) return false;
         deviceAllocs.push_back(buf);
         if (hipMemset(buf, 0, bytes) != hipSuccess) return false;
         p.fold.counter = static_cast<unsigned*>(buf);

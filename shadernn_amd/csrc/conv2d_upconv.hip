@@ -389,7 +389,7 @@ struct UpconvPlan : ConvPlanBase {
         if (snnhip::option("SNNHIP_NO_KERNEL_FOLD")) return false;
         const int BPI = (p.segs + 1) * p.tilesX, BN = static_cast<int>(p.OC / grid.y);
         void* buf = nullptr;
-        if (hipMalloc(&buf, static_cast<size_t>(p.N) * grid.y * BPI * (1 + 2 * BN) * sizeof(float)) != hipSuccess) return false;
+        if (snnhip::dev_malloc(&buf, static_cast<size_t>(p.N) * grid.y * BPI * (1 + 2 * BN) * sizeof(float)) != hipSuccess) return false;
         deviceAllocs.push_back(buf);
         statPart = p.statRec = static_cast<float*>(buf);
         statTilesX = BPI; statTilesY = 1; statTH = 0; statTW = 0;
@@ -406,7 +406,7 @@ struct UpconvPlan : ConvPlanBase {
         if (!statPart || p.fold.counter) return false;
         void* buf = nullptr;
         const size_t bytes = static_cast<size_t>(p.N) * grid.y * sizeof(unsigned);
-        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        if (snnhip::dev_malloc(&buf, bytes) != hipSuccess) return false;
         deviceAllocs.push_back(buf);
         if (hipMemset(buf, 0, bytes) != hipSuccess) return false;
         p.fold.counter = static_cast<unsigned*>(buf);

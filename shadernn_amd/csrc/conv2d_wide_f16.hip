@@ -492,7 +492,7 @@ struct WideConvPlan : ConvPlanBase {
         if (fusedAdd) return false; // (rule E: the kernel instantiation with the residual carries no statistics code)
         void* buf = nullptr;
         const size_t bytes = static_cast<size_t>(p.N) * p.tilesY * p.tilesX * 2 * p.OC * sizeof(float);
-        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        if (snnhip::dev_malloc(&buf, bytes) != hipSuccess) return false;
         deviceAllocs.push_back(buf);
         statPart = p.statPart = static_cast<float*>(buf);
         statTilesX = p.tilesX; statTilesY = p.tilesY; statTH = 1 << p.THs; statTW = 32;
@@ -503,7 +503,7 @@ struct WideConvPlan : ConvPlanBase {
         if (!statPart || p.fold.counter) return false;
         void* buf = nullptr;
         const size_t bytes = static_cast<size_t>(p.N) * grid.y * sizeof(unsigned);
-        if (hipMalloc(&buf, bytes) != hipSuccess) return false;
+        if (snnhip::dev_malloc(&buf, bytes) != hipSuccess) return false;
         deviceAllocs.push_back(buf);
         if (hipMemset(buf, 0, bytes) != hipSuccess) return false;
         p.fold.counter = static_cast<unsigned*>(buf);
@@ -659,7 +659,7 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         const bool want = tk ? atoi(tk) != 0 : false;
         if (want && twoPerCu) {
             void* buf = nullptr;
-            if (hipMalloc(&buf, kTokSlots * sizeof(unsigned)) == hipSuccess) {
+            if (snnhip::dev_malloc(&buf, kTokSlots * sizeof(unsigned)) == hipSuccess) {
                 plan->deviceAllocs.push_back(buf);
                 if (hipMemset(buf, 0, kTokSlots * sizeof(unsigned)) == hipSuccess) plan->p.kTok = static_cast<unsigned*>(buf);
             }

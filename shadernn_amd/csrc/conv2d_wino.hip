@@ -442,7 +442,7 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (p.splitK > 1) {
         void* wsp = nullptr;
         const size_t wsBytes = static_cast<size_t>(p.splitK) * g.N * g.OH * g.OW * g.OC * sizeof(float);
-        if (hipMalloc(&wsp, wsBytes) != hipSuccess) {
+        if (snnhip::dev_malloc(&wsp, wsBytes) != hipSuccess) {
             set_error("conv2d_wino: split-K workspace of %zu bytes", wsBytes);
             delete plan;
             return SNNHIP_E_HIP;

@@ -250,7 +250,7 @@ struct InResidual { // graph rule H: the Add behind an InstanceNorm, applied in 
     float leaky = 0.0f;
 };
 
-template <int STAGE, int CV, typename T, bool FAST = false /* STAGE 2: the norm's activation is none or ReLU and the Add's is none: max(x, lo), no run-time switch per value */>
+template <int STAGE, int CV, typename T, int FAST = 0 /* STAGE 2, the Add's activation none: 1 = the norm's activation is ReLU (max(x, 0)), 2 = none (no max at all: a NaN stays a NaN) -- no run-time switch per value */>
 __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_desc d, int S, int pixelsPerSlab, int CLs, const T* __restrict__ x,
                                                           const float* __restrict__ statMean, const float* __restrict__ statMul,
                                                           const float* __restrict__ beta, float* __restrict__ partOut, T* __restrict__ y,
@@ -260,7 +260,6 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
     // the norm (top-left aligned, add_ragged_kernel's rule): outside it the sum is the norm alone, or 0 when the residual is the Add's FIRST input.
     const T* __restrict__ res = static_cast<const T*>(ra.p);
     const bool ragged = ra.p && (ra.H != d.H || ra.W != d.W);
-    const float fastLo = d.act == SNNHIP_ACT_RELU ? 0.0f : -__builtin_huge_valf(); // (FAST)
     __shared__ float red[2 * 256 * CV];
     const int n = blockIdx.x / S, s = blockIdx.x % S;
     const int tid = threadIdx.x;
@@ -304,7 +303,10 @@ __global__ __launch_bounds__(256) void instancenorm_kernel(snnhip_instancenorm_d
                 float o[CV];
                 if (FAST) { // (epi_act's switch per value -- 16 values in flight per thread, each behind its own branches -- is what the generic form below costs)
 #pragma unroll
-                    for (int k = 0; k < CV; ++k) o[k] = fmaxf(fmaf(v[k], mul[k], piv[k]), fastLo);
+                    for (int k = 0; k < CV; ++k) {
+                        const float f = fmaf(v[k], mul[k], piv[k]);
+                        o[k] = FAST == 1 ? fmaxf(f, 0.0f) : f;
+                    }
                     if (res) {
                         if (rp >= 0) {
 #pragma unroll
@@ -704,11 +706,14 @@ struct InstanceNormPlan : snnhip_plan {
         const bool fastNorm = (d.act == SNNHIP_ACT_NONE || d.act == SNNHIP_ACT_RELU) && (!res || addAct == SNNHIP_ACT_NONE) && !snnhip::option("SNNHIP_NORM_GENERIC_ACT");
 #define SNNHIP_IN(ST, CVV)                                                                                                                                     \
     do {                                                                                                                                                       \
-        if (ST == 2 && fastNorm)                                                                                                                               \
-            SNNHIP_LAUNCH((instancenorm_kernel<ST, CVV, T, ST == 2>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul,  \
+        if (ST == 2 && fastNorm && d.act == SNNHIP_ACT_RELU)                                                                                                   \
+            SNNHIP_LAUNCH((instancenorm_kernel<ST, CVV, T, ST == 2 ? 1 : 0>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, \
+                          d_beta, d_part, mptr<T>(out), ST == 2 ? ra : InResidual());                                                                          \
+        else if (ST == 2 && fastNorm)                                                                                                                          \
+            SNNHIP_LAUNCH((instancenorm_kernel<ST, CVV, T, ST == 2 ? 2 : 0>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, \
                           d_beta, d_part, mptr<T>(out), ST == 2 ? ra : InResidual());                                                                          \
         else                                                                                                                                                   \
-            SNNHIP_LAUNCH((instancenorm_kernel<ST, CVV, T, false>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul,    \
+            SNNHIP_LAUNCH((instancenorm_kernel<ST, CVV, T, 0>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul,    \
                           d_beta, d_part, mptr<T>(out), ST == 2 ? ra : InResidual());                                                                          \
     } while (0)
 #define SNNHIP_FOLD() \
@@ -741,8 +746,12 @@ struct InstanceNormPlan : snnhip_plan {
                     const int CLs4 = CLs;
                     {
                         const int CLs = CLs4 - 1; // half as many channel lanes, each twice as wide
-                        SNNHIP_LAUNCH((instancenorm_kernel<2, 8, T, true>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta,
-                                      d_part, mptr<T>(out), ra);
+                        if (d.act == SNNHIP_ACT_RELU)
+                            SNNHIP_LAUNCH((instancenorm_kernel<2, 8, T, 1>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta,
+                                          d_part, mptr<T>(out), ra);
+                        else
+                            SNNHIP_LAUNCH((instancenorm_kernel<2, 8, T, 2>), g, dim3(256), 0, ctx->stream, d, S, pixelsPerSlab, CLs, cptr<T>(in[0]), d_mean, d_mul, d_beta,
+                                          d_part, mptr<T>(out), ra);
                     }
                 } else {
                     SNNHIP_IN(2, 4);
@@ -867,7 +876,7 @@ int instancenorm_reserve_tile_stats(snnhip_plan* inPlan, int tilesX, int tilesY)
     const size_t need = static_cast<size_t>(q->d.N) * chunks * 3 * q->d.C;
     if (q->foldScratchCount < need) {
         void* buf = nullptr;
-        SNNHIP_CHECK_HIP(hipMalloc(&buf, need * sizeof(float)));
+        SNNHIP_CHECK_HIP(snnhip::dev_malloc(&buf, need * sizeof(float)));
         q->deviceAllocs.push_back(buf);
         q->d_foldScratch = static_cast<float*>(buf);
         q->foldScratchCount = need;

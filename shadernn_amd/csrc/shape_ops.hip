@@ -485,7 +485,7 @@ int snnhip_tensor_argmax(const snnhip_tensor* t, int n, int* out_index) {
     SNNHIP_REQUIRE(n >= 0 && n < t->n, "tensor_argmax: image %d of %d", n, t->n);
     SNNHIP_REQUIRE(t->dtype == SNNHIP_F32 || t->dtype == SNNHIP_F16, "tensor_argmax: dtype %d", t->dtype);
     int* d = nullptr;
-    SNNHIP_CHECK_HIP(hipMalloc(&d, sizeof(int)));
+    SNNHIP_CHECK_HIP(snnhip::dev_malloc(&d, sizeof(int)));
     const size_t per = t->count() / t->n;
     if (t->dtype == SNNHIP_F16)
         SNNHIP_LAUNCH((argmax_kernel<_Float16>), dim3(1), dim3(256), 0, t->ctx->stream, per, reinterpret_cast<const _Float16*>(t->data) + per * n, d);
@@ -494,7 +494,7 @@ int snnhip_tensor_argmax(const snnhip_tensor* t, int n, int* out_index) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out_index, d, sizeof(int), hipMemcpyDeviceToHost, t->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->ctx->stream);
-    (void) hipFree(d);
+    (void) snnhip::dev_free(d);
     SNNHIP_CHECK_HIP(e);
     return SNNHIP_OK;
 }

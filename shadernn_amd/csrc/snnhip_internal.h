@@ -67,6 +67,18 @@ struct TraceScope {
         hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, trS_, trE_, 0, __VA_ARGS__);                                  \
     } while (0)
 
+// ---- device allocations of the library (tensors, packed weights, scratch).  Plain hipMalloc / hipFree, or -- SNNHIP_GUARD=1 -- the guarded form
+// of include/snnhip.h (red zones around every allocation, everything poisoned with 0xFF); capi.hip.
+hipError_t dev_malloc_bytes(void** p, size_t bytes, const char* what);
+hipError_t dev_free(void* p);
+template <class T>
+inline hipError_t dev_malloc(T** p, size_t bytes, const char* what = "plan buffer") {
+    void* v = nullptr;
+    const hipError_t e = dev_malloc_bytes(&v, bytes, what);
+    *p = static_cast<T*>(v);
+    return e;
+}
+
 inline int up_div(int x, int y) { return (x + y - 1) / y; }
 inline int round_up(int x, int y) { return up_div(x, y) * y; }
 
@@ -144,7 +156,7 @@ struct snnhip_plan {
     std::vector<size_t> stepUsed;                   // pairs recorded since the last read
 
     virtual ~snnhip_plan() {
-        for (void* p : deviceAllocs) (void) hipFree(p);
+        for (void* p : deviceAllocs) (void) ::snnhip::dev_free(p);
         for (auto& v : stepEvents)
             for (auto& e : v) {
                 (void) hipEventDestroy(e.start);

@@ -16,13 +16,15 @@ def shard_range(n_items, world, rank):
 
 
 class Group:
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, local_device=None):
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist = torch, dist
         self.rank, self.local_rank, self.world = env_rank_world()
         self.device = device
+        # the GPU this rank runs on: LOCAL_RANK under the driver's launch (one rank per GPU); several gloo ranks may share a device
+        self.local_device = self.local_rank if local_device is None else local_device
         self.active = self.world > 1
         if self.active and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -31,19 +33,19 @@ class Group:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             kw = {}
             if backend == "nccl":
-                kw["device_id"] = torch.device("cuda", self.local_rank)
+                kw["device_id"] = torch.device("cuda", self.local_device)
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
         self.backend = dist.get_backend() if self.active else None
 
     def _dev(self):
         if self.backend == "nccl":
-            return self.torch.device("cuda", self.local_rank)
+            return self.torch.device("cuda", self.local_device)
         return self.torch.device("cpu")
 
     def barrier(self):
         if self.active:
             if self.backend == "nccl":
-                self.dist.barrier(device_ids=[self.local_rank])
+                self.dist.barrier(device_ids=[self.local_device])
             else:
                 self.dist.barrier()
         if self.torch.cuda.is_available():

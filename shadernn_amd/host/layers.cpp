@@ -1,6 +1,7 @@
 // layers.cpp -- layer definitions of the hot path + the layer factory
 // (reference core/src/ic2/genericlayer.cpp, conv2d.cpp, conv2dVulkan.cpp, separableconvolution*.cpp, denselayer*.cpp,
 //  subpixelmergeVulkan.cpp, layerFactory.cpp).  createCS() packs a host-side recipe; the backend turns it into a HIP plan.
+#include <mutex>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -760,9 +761,22 @@ static GenericModelLayer* YOLOCreator(ModelParser& parser, int i, bool) {
     return new YOLOLayer(std::move(desc));
 }
 
-void snn::dp::registerLayer(const std::string& layerName, LayerCreator creator) { LayerRegistryDict.emplace(layerName, creator); }
+// The registry is shared by every model of the process and the replica threads of snn_pool_create build their models at the same time: all
+// writes happen under registryMutex, the built-in table is filled exactly once (std::call_once), and createLayerInstance copies the creator out
+// under the lock before it calls it.  (The reference is single-threaded here, layerFactory.cpp:102-129.)
+static std::mutex registryMutex;
+static std::once_flag registryOnce;
 
-void snn::dp::initLayerRegisty() { // layerFactory.cpp:109-129 (the hot-path operators + the element-wise / pooling / shape operators around them)
+void snn::dp::registerLayer(const std::string& layerName, LayerCreator creator) {
+    std::lock_guard<std::mutex> lock(registryMutex);
+    LayerRegistryDict.emplace(layerName, creator);
+}
+
+static void fillLayerRegistry();
+void snn::dp::initLayerRegisty() { std::call_once(registryOnce, fillLayerRegistry); }
+
+static void fillLayerRegistry() { // layerFactory.cpp:109-129 (the hot-path operators + the element-wise / pooling / shape operators around them)
+    using snn::dp::registerLayer;
     registerLayer("InputLayer", InputLayerCreator);
     registerLayer("Conv2D", Conv2DCreator);
     registerLayer("SeparableConv2D", SeparableConv2DCreator);
@@ -790,7 +804,12 @@ GenericModelLayer* snn::dp::createLayerInstance(std::string layerName, ModelPars
     if (layerName == "subpixel" || layerName == "depth_to_space") layerName = "Subpixel";
     if (layerName == "InstanceNormalization") layerName = "InstanceNorm";
     if (layerName == "ZeroPadding2D") layerName = "Pad";
-    auto it = LayerRegistryDict.find(layerName);
-    if (it == LayerRegistryDict.end()) SNN_RIP("Not found layer: %s", layerName.c_str());
-    return it->second(parser, i, useVulkan);
+    LayerCreator creator = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(registryMutex);
+        auto it = LayerRegistryDict.find(layerName);
+        if (it != LayerRegistryDict.end()) creator = it->second;
+    }
+    if (!creator) SNN_RIP("Not found layer: %s", layerName.c_str());
+    return creator(parser, i, useVulkan);
 }

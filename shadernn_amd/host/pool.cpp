@@ -120,14 +120,20 @@ int snn_pool_create(const char* json_path, const int* devices, int n_devices, in
     if (!json_path || !devices || !out || n_devices < 1 || global_batch < 1 || in_w < 1 || in_h < 1 || in_c < 1) return -1;
     // every device must exist BEFORE a replica thread is started: a context failure inside MixedInferenceCore is fatal (SNN_RIP aborts the process,
     // the reference's convention), a bad device list is an error code
-    for (int g = 0; g < n_devices; ++g) {
-        snnhip_ctx* probe = nullptr;
-        if (snnhip_ctx_create(devices[g], &probe) != SNNHIP_OK) {
-            SNN_LOGE("snn_pool_create: device %d: %s", devices[g], snnhip_last_error());
-            return -2;
+    // (probed on a thread of its own: the current HIP device is per thread, and the caller's must be what it was when this call returns)
+    int probeRc = 0;
+    std::thread([&] {
+        for (int g = 0; g < n_devices && probeRc == 0; ++g) {
+            snnhip_ctx* probe = nullptr;
+            if (snnhip_ctx_create(devices[g], &probe) != SNNHIP_OK) {
+                SNN_LOGE("snn_pool_create: device %d: %s", devices[g], snnhip_last_error());
+                probeRc = -2;
+            } else {
+                snnhip_ctx_destroy(probe);
+            }
         }
-        snnhip_ctx_destroy(probe);
-    }
+    }).join();
+    if (probeRc != 0) return probeRc;
     auto* p = new snn_pool();
     p->globalBatch = global_batch;
     p->inW = in_w;
@@ -267,19 +273,26 @@ int snn_pool_allgather_output_rccl(snn_pool* p, float* nhwc_rank0) {
     using GroupFn = int (*)();
     using AllGatherFn = int (*)(const void*, void*, size_t, int, void*, void*);
     if (!p->rccl) {
-        p->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!p->rccl) p->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (!p->rccl) p->rccl = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (!p->rccl) {
+        // the handle and the communicators are published only once ncclCommInitAll has succeeded: a failed attempt leaves the pool as it was and
+        // the next call starts over
+        void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) {
             SNN_LOGE("snn_pool_allgather_output_rccl: librccl.so not found (%s)", dlerror());
             return -4;
         }
-        auto initAll = reinterpret_cast<InitAllFn>(dlsym(p->rccl, "ncclCommInitAll"));
-        if (!initAll) return -4;
+        auto initAll = reinterpret_cast<InitAllFn>(dlsym(lib, "ncclCommInitAll"));
         std::vector<int> devs;
         for (Replica* r : p->reps) devs.push_back(r->device);
-        p->comms.assign(static_cast<size_t>(G), nullptr);
-        if (initAll(p->comms.data(), G, devs.data()) != 0) return -4;
+        std::vector<void*> comms(static_cast<size_t>(G), nullptr);
+        if (!initAll || initAll(comms.data(), G, devs.data()) != 0) {
+            SNN_LOGE("snn_pool_allgather_output_rccl: ncclCommInitAll over %d device(s) failed", G);
+            dlclose(lib);
+            return -4;
+        }
+        p->comms = comms;
+        p->rccl = lib;
     }
     auto groupStart = reinterpret_cast<GroupFn>(dlsym(p->rccl, "ncclGroupStart"));
     auto groupEnd = reinterpret_cast<GroupFn>(dlsym(p->rccl, "ncclGroupEnd"));
@@ -296,7 +309,9 @@ int snn_pool_allgather_output_rccl(snn_pool* p, float* nhwc_rank0) {
         const int rc = onAll(p, [=](Replica* r) {
             snnhip_ctx* ctx = snn_model_hip_ctx(r->models[0]);
             p->ctxs[r->index] = ctx;
-            return snnhip_tensor_alloc(ctx, G * maxSlot, p->outHWC[0], p->outHWC[1], p->outHWC[2], p->half ? SNNHIP_F16 : SNNHIP_F32, &p->gatherBufs[r->index]);
+            // (the output tensor's own type: a model asked for half precision may still end in an fp32 layer)
+            return snnhip_tensor_alloc(ctx, G * maxSlot, p->outHWC[0], p->outHWC[1], p->outHWC[2], snnhip_tensor_dtype(snn_model_output_tensor(r->models[0])),
+                                       &p->gatherBufs[r->index]);
         });
         if (rc != 0) return -2;
     }
@@ -306,12 +321,15 @@ int snn_pool_allgather_output_rccl(snn_pool* p, float* nhwc_rank0) {
         const size_t count = static_cast<size_t>(mb) * per; // elements per rank
         if (onAll(p, [=](Replica* r) { return snn_model_sync(r->models[s]); }) != 0) return -2;
         if (groupStart() != 0) return -4;
-        for (int g = 0; g < G; ++g) {
+        bool sent = true;
+        for (int g = 0; g < G && sent; ++g) {
             Replica* r = p->reps[g];
-            const void* send = snnhip_tensor_data(snn_model_output_tensor(r->models[s]));
-            if (allGather(send, snnhip_tensor_data(p->gatherBufs[g]), count, p->half ? 6 : 7, p->comms[g], snnhip_ctx_stream(p->ctxs[g])) != 0) return -4;
+            const snnhip_tensor* o = snn_model_output_tensor(r->models[s]);
+            const int ncclType = snnhip_tensor_dtype(o) == SNNHIP_F16 ? 6 : 7;
+            sent = allGather(snnhip_tensor_data(o), snnhip_tensor_data(p->gatherBufs[g]), count, ncclType, p->comms[g], snnhip_ctx_stream(p->ctxs[g])) == 0;
         }
-        if (groupEnd() != 0) return -4;
+        const bool closed = groupEnd() == 0; // (always: an error between the two calls must not leave the group open)
+        if (!sent || !closed) return -4;
         // rank 0's copy to the host (its stream orders the download behind the collective); rank g's block is images [slotFirst_g[s], +mb)
         if (onAll(p, [&](Replica* r) {
                 if (r->index != 0) return snnhip_sync(p->ctxs[r->index]) == SNNHIP_OK ? 0 : -2;

@@ -308,6 +308,35 @@ def test_c5_candy_720p_fp16_microbatch16_default_switches_through_host(ctx, tmp_
     y = m(x)
     assert y.shape[0] == 16
     check(y, x, (0, 15))
+    # per layer at THIS micro-batch (the reference checks layer by layer: demo/common/testutil.h:1194-1195, fp16 bound 0.1; styleTransferTest.cpp):
+    # image 15's tensor right behind the first InstanceNorm that the fused graph materialises, and the output of the last residual block -- an error
+    # in the statistics fold (rule F) or in the normalisation applied behind the DMA (rule I) shows here before fifteen norms have amplified it
+    import re
+
+    _, named = O.forward(net, x[15:16], fp16=True, threads=THREADS, return_named=True)
+    stages = m.stages()
+
+    def layer_of(st):
+        k = re.search(r"layer \[(\d+)\]", st["name"])
+        return net["layers"][int(k.group(1)) - 1] if k and int(k.group(1)) >= 1 else None
+
+    first_norm = next(i for i, st in enumerate(stages) if (layer_of(st) or {}).get("type") == "InstanceNorm")
+    last_add = max(i for i, st in enumerate(stages) if (layer_of(st) or {}).get("type") == "Add")
+    picks, checked = [next((i for i in range(first_norm, len(stages)) if not stages[i]["fused_away"] and layer_of(stages[i])), None), last_add], 0
+    for i in picks:
+        if i is None or stages[i]["fused_away"]:
+            continue
+        lay = layer_of(stages[i])
+        got = m.stage_output(i)
+        if got is None or lay["name"] not in named:
+            continue
+        want = named[lay["name"]]
+        assert got[15:16].shape == want.shape, (stages[i]["name"], got.shape, want.shape)
+        e = np.abs(got[15:16] - want) / max(1.0, float(np.abs(want).max()))
+        assert np.isfinite(got[15]).all() and np.quantile(e, 0.999) < 6e-3 and e.max() < 6e-2, (stages[i]["name"], float(np.quantile(e, 0.999)), float(e.max()))
+        del got
+        checked += 1
+    assert checked >= 1, [st["name"] for st in stages if not st["fused_away"]]
     # a different batch right behind it (brighter, other statistics) through the same plans and the same record buffers
     x2 = (0.25 + 0.5 * rng.random((16, H, W, C), dtype=np.float32)).astype(np.float32)
     y2 = m(x2)

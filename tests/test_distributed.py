@@ -211,6 +211,16 @@ def test_bench_kernel_table_groups_by_function_and_prices_the_dominant_one(monke
     assert rec["kernel"] == "conv2d_wide_kernel" and rec["bound"] == "mfma" and abs(rec["frac"] - rows[0]["frac"]) < 1e-12
     assert abs(rec["algorithmic_bytes_per_launch"] - 0.5e9) < 1 and abs(rec["traffic_over_algorithmic_bytes"] - 5e8 / 0.5e9) < 1e-9
     monkeypatch.undo()
+    # a Winograd kernel: `frac` on the algorithmic count, `frac_executed` on what the matrix pipe multiplies ("mfma_flops=" of the plans, summed by the
+    # trace), and the PMC pipe utilisation beside them when the committed record matches the build
+    wino = {"launches": 2, "kernels": [{"function": "conv2d_wino_kernel", "launches": 2, "main_launches": 2, "total_ms": 0.1, "flops": 14.8e9, "bytes": 1e8, "mfma_flops": 6.6e9,
+                                        "instances": [{"name": "void snnhip::(anonymous namespace)::conv2d_wino_kernel<2>(P)", "launches": 2, "main_launches": 2, "total_ms": 0.1,
+                                                       "flops": 14.8e9, "bytes": 1e8, "mfma_flops": 6.6e9, "plans": ["conv2d_mfma_wino mfma_flops=3.3e9"]}]}]}
+    wrows = bench.kernel_table(wino, 1, bench.PEAK_F32_MFMA_TFLOPS)
+    assert abs(wrows[0]["frac"] - 14.8e9 / 1e-4 / 157.3e12) < 1e-9 and abs(wrows[0]["frac_executed"] - 6.6e9 / 1e-4 / 157.3e12) < 1e-9
+    wrec = bench.roofline_record(wrows, bench.PEAK_F32_MFMA_TFLOPS, single_launch_step=False)
+    assert abs(wrec["frac_executed"] - wrows[0]["frac_executed"]) < 1e-12 and abs(wrec["executed_mfma_flops_per_launch"] - 3.3e9) < 1
+    assert "frac_executed" not in rows[0]  # a direct kernel executes what it is priced on
     # the committed file: one source fingerprint per record
     committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
     assert committed and all(len(v.get("csrc_sha16", "")) == 16 and v["hbm_bytes_per_launch"] >= 0 for v in committed.values())

@@ -10,6 +10,7 @@
 #     profx:<name>:<command>           the same passes around an arbitrary command ('+' stands for a blank)   -> <tag>_<name>/summary.md
 #     layers[:fp16]                    tools/bench_layers.py                                               -> layers[_fp16].txt
 #     py:<script>[:args]               python tools/<script> args ('+' stands for a blank)                 -> py_<n>.txt
+#     sh:<script>[:args]               bash tools/<script> args ('+' stands for a blank)                   -> sh_<n>.txt
 #     lib:<tag>                        load build/abl/libsnnhip_<tag>.so in the following actions ('lib:' = the product library again)
 #     env:NAME=VALUE                   export for the following actions
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -53,6 +54,9 @@ for act in "$@"; do
     py)
       s=${arg%%:*}; a=""; [ "$s" != "$arg" ] && a=${arg#*:}
       timeout 1200 python "tools/$s" ${a//+/ } > "$O/py_$n.txt" 2>&1; tail -60 "$O/py_$n.txt" ;;
+    sh)
+      s=${arg%%:*}; a=""; [ "$s" != "$arg" ] && a=${arg#*:}
+      timeout 1800 bash "tools/$s" ${a//+/ } > "$O/sh_$n.txt" 2>&1; echo "sh $s rc=$?"; tail -25 "$O/sh_$n.txt" ;;
     *) echo "unknown action $act" ;;
   esac
 done

@@ -506,7 +506,7 @@ __global__ void guard_poke_kernel(unsigned char* p) { *p = 0x5A; }
 } // namespace
 
 hipError_t dev_malloc_bytes(void** p, size_t bytes, const char* what) {
-    if (!guard_on()) return hipMalloc(p, bytes);
+    if (!guard_on()) return hipMalloc(p, (bytes + 15) & ~static_cast<size_t>(15));
     const size_t user = (bytes + 15) & ~static_cast<size_t>(15);
     void* base = nullptr;
     const hipError_t e = hipMalloc(&base, kGuardZone + user + kGuardZone);
@@ -627,7 +627,7 @@ int snnhip_tensor_alloc(snnhip_ctx* ctx, int n, int h, int w, int c, int dtype, 
     if (!t) return SNNHIP_E_NOMEM;
     t->ctx = ctx; t->n = n; t->h = h; t->w = w; t->c = c; t->owns = true; t->dtype = dtype;
     void* p = nullptr;
-    const size_t nbytes = (t->bytes() + 15) & ~static_cast<size_t>(15);
+    const size_t nbytes = t->bytes(); // (rounded up to whole 16-byte vectors by the allocator; under SNNHIP_GUARD the red zone starts right behind the last element)
     char what[96];
     snprintf(what, sizeof(what), "tensor %dx%dx%dx%d dtype %d", n, h, w, c, dtype);
     hipError_t e = snnhip::dev_malloc(&p, nbytes, what);

@@ -553,6 +553,8 @@ int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (inCount >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED;
     const char* force = snnhip::option("SNNHIP_CONV");
     const bool forced = force && strcmp(force, "wide") == 0;
+    // the 128 -> 128 body layers of the style graphs: the persistent form (conv2d_widep_f16.hip), unless it declines or SNNHIP_WIDE_PERSIST=0
+    if (make_conv2d_widep_plan(ctx, g, w_oihw, epi4, out) == SNNHIP_OK) return SNNHIP_OK;
 
     // block shape: 256 px x 128 oc when the channels fill it, else 512 px x 64 / 32 oc
     int WM = 4, NT = 2, BN = 64;

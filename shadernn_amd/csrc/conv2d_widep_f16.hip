@@ -1,0 +1,607 @@
+// conv2d_widep_f16.hip -- conv2d_wide_f16's 256-pixel x 128-channel block as a PERSISTENT kernel (round 5): fp16 Conv2D 3x3 stride 1, IC = 128, OC = 128 on
+// large maps -- the ten body layers of the style-transfer graphs (Candy: 47 % of a step at 0.36 of the fp16 MFMA peak with one block per tile).
+//
+// What the one-block-per-tile kernel paid per tile besides its 576 MFMAs per wave (phase trace + ablations): a prologue of
+// tables and staging maps (4 500 cycles), the first chunk's DMA in the open (4 300), an epilogue through a block-wide 68 KB LDS tile with three
+// barriers (8 800), a statistics merge with three more, the image counter's atomic round trip in every block, and -- found while this kernel was
+// written -- a drained prefetch at the head of every chunk: the compiler counts only ITS loads in s_waitcnt vmcnt(N), so with inline-asm LDS-DMA
+// copies in the queue its counted wait for a weight operand also waited for the copies issued just before.
+//
+//   * grid = two blocks per CU, each walks tiles b, b + G, b + 2G, ... (image-major: images finish in order and their statistics fold while later
+//     images are still being multiplied); 4 waves = 2 x 2 (pixel rows x 64-channel halves), a wave = 4 x 2 v_mfma_f32_32x32x16_f16 tiles as before;
+//   * EVERY vector-memory instruction is inline assembly and every s_waitcnt vmcnt is counted by hand (the table at KSTEP below): weight operands
+//     (a ring of D K-steps per lane, scalar base + 32-bit lane offset), LDS-DMA copies of the next chunk's halo tile, output stores.  The four
+//     chunks of a tile are unrolled (no loop back-edge carries a register that a load is still writing), the ring wraps from a tile's last
+//     steps into the next tile's first (the weights do not depend on the tile) and is waited for once, under the epilogue's stores, before the
+//     tile loop's back-edge;
+//   * the next tile's row / column tables are resolved during chunk 1, its staging map and its first chunk's copies are issued at the top of
+//     chunk 3: a tile never starts with an exposed copy;
+//   * the epilogue is WAVE-PRIVATE: a wave converts one 32-pixel row of its accumulators (bias [-> BN] -> activation -> half), passes it through
+//     its own 4.5 KB of LDS as 8-byte runs and reads it back as 16-byte vectors -- 8 lanes = the 128 contiguous bytes of a pixel's channel half --
+//     no block barrier, no 68 KB tile (so the block still fits twice on a CU beside its two 28 KB staging buffers); stores are unconditional
+//     (pixels outside the map go to a dump buffer) so that their number is known to the counted waits;
+//   * chain rule F: sums and squares around the channel's bias of the values a lane carries to memory (8 channels x 16 pixels), summed over a
+//     wave through its LDS scratch: one {mean, M2} record per WAVE (4 rows x 32 columns x 64 channels, written through to the coherence point);
+//     the image counter is bumped one tile LATER, by an atomic whose return rides the next tile's chunk-1 wait: no round trip in the open, and
+//     the block that draws an image's last ticket folds it right there (norm_fold.h);
+//   * graph rule I (the InstanceNorm in front, applied in LDS behind the DMA) as before, with a two-instruction form for none / ReLU.
+// Semantics: shadertemplate_vk_conv2d.comp:148-347 (padding redirects :180-185,213-218), bit-identical to conv2d_wide_kernel's convolution (same
+// K order); the statistics differ from its per-thread mean / M2 records only in how the same sums are grouped.
+#include "conv2d_mfma_kernel.h"
+#include "norm_fold.h"
+
+#include <cstring>
+
+namespace snnhip {
+
+namespace {
+
+using mfma_detail::f32x16;
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTileW = 34;                        // staged tile: 32 + 2 columns
+constexpr int kTileH = 10;                        // 8 + 2 rows
+constexpr int kQP = 5;                            // 16-byte slots per staged pixel: 4 of data (32 channels) + 1 of padding (odd pitch: conflict-free ds_read_b128)
+constexpr int kTotal = kTileH * kTileW * kQP;     // 1700 slots
+constexpr int kR = 7;                             // DMA instructions per thread and chunk (7 x 256 >= 1700)
+constexpr int kBufBytes = kR * 256 * 16;          // 28 672
+constexpr int kScrPitch = 144;                    // bytes per pixel of a wave's epilogue scratch (64 halfs + 16: rows rotate by four banks)
+constexpr int kScrBytes = 32 * kScrPitch;         // 4 608 per wave
+constexpr int kLdsBuf0 = 0, kLdsBuf1 = kBufBytes, kLdsScr = 2 * kBufBytes, kLdsEpi = kLdsScr + 4 * kScrBytes /* float4[128] */, kLdsBias = kLdsEpi + 2048 /* float[128] */,
+              kLdsSy = kLdsBias + 512 /* int[32] */, kLdsSx = kLdsSy + 128 /* int[40] */, kLdsNorm = kLdsSx + 160 /* [2 slots][2][IC] floats */;
+constexpr int kStepBytes = 2 * 128 * 16;          // packed weights per K step: [h][oc] x 16 bytes
+constexpr int kEpiStores = 16;                    // output stores per thread and tile (4 rows x 4 vectors)
+
+struct WidePParams {
+    int N, H, W, OH, OW, padx, pady, padMode, useBN;
+    unsigned tilesX, tilesY, tilesPerImage, numTiles;
+    int preMode, preX, preY, srcH, srcW, preShift;
+    const _Float16* zeros;  // 16 bytes of zeros per lane (behind the packed weights): source of the padding pixels' DMA
+    _Float16* dump;         // 64 KB nobody reads: where the stores of pixels outside the map go (their NUMBER must not depend on the tile)
+    float* statPart;        // chain rule F: [n][2 tilesY][tilesX][2][128] per-wave {mean, M2} records; null = off
+    unsigned* counter;      // ... [N] tiles of the image counted so far; the block that draws an image's last ticket folds it; null = no in-kernel fold
+    const NormFoldArgs* fold; // (device copy: read by the folding block only -- eleven scalar registers the tile loop does not have to carry)
+    const float* normShift; // graph rule I
+    const float* normMul;
+    ActCfg normAc;
+};
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// the wait for a weight operand: the registers go through the statement, so nothing that reads them can be scheduled in front of it
+template <int N>
+__device__ __forceinline__ void vm_wait_tie(f4& a, f4& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+__device__ __forceinline__ void gload16x2(const char* sbase, unsigned voff, f4& r0, f4& r1) { // [oc tile 0, oc tile 1] of one K step (512 bytes apart)
+    asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:512" : "=&v"(r0), "=&v"(r1) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void lds_dma16_at(const void* gsrc, unsigned ldsWaveByteAddr) { // epilogue.h's lds_dma16 with the wave's LDS address already a scalar
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(ldsWaveByteAddr) : "memory");
+}
+__device__ __forceinline__ void lds_barrier() { // LDS traffic of this wave done, then the block barrier; vector memory stays in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// NORM: 0 = no InstanceNorm in front, 1 = its activation is none / ReLU (max(f, lo)), 2 = any branch-free activation (med3 form)
+// STATS: chain rule F records (+ the in-kernel fold when p.fold.counter)
+// D: K steps of weight operands in flight per lane (divides 18)
+template <int NORM, bool STATS, int D>
+__global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, ActCfg ac, const _Float16* __restrict__ x, const char* __restrict__ wp, const float4* __restrict__ epi,
+                                                           _Float16* __restrict__ y) {
+    constexpr int NCH = 4, IC = 32 * NCH, OC = 128, S = 18, L = 2 * (D - 1); // L: weight loads younger than the one a step waits for
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l32 = lane & 31, h = lane >> 5;
+
+    int* const syTab = reinterpret_cast<int*>(smem + kLdsSy);
+    int* const sxTab = reinterpret_cast<int*>(smem + kLdsSx);
+    float* const normTab = reinterpret_cast<float*>(smem + kLdsNorm);
+    float* const biasTab = reinterpret_cast<float*>(smem + kLdsBias);
+
+    // ---- once per block
+    if (tid < OC) {
+        const float4 e4 = epi[tid];
+        reinterpret_cast<float4*>(smem + kLdsEpi)[tid] = e4;
+        biasTab[tid] = e4.x;
+    }
+    const unsigned aoff0 = static_cast<unsigned>(((wm * 4 * kTileW + l32) * kQP + h) * 16);   // operand reads: pixel (row 4 wm + t, column l32), slot 2 c8 + h
+    const unsigned wlane0 = static_cast<unsigned>(h * 2048 + (wn * 64 + l32) * 16);          // weight operand: [h][oc = 64 wn + 32 u + l32]
+    const unsigned G = gridDim.x;
+    // Per-lane / per-wave bases the tile loop re-derives from values the compiler cannot see through (an empty asm per iteration): hoisted out of the
+    // loop as invariants, the 72 weight-step addresses, the 14 DMA destinations and the epilogue's address arithmetic were 164 spilled scalar and 23-150
+    // spilled vector registers (ROCm 7.2; the naive persistent loop of round 4 failed the same way)
+    unsigned wlane = wlane0, waveLds = static_cast<unsigned>(wave * 1024);
+    unsigned tq = static_cast<unsigned>(tid); // the thread index as the tile loop sees it
+
+    // row / column tables of a tile (52 threads, one coordinate each): the source pixel of a staged pixel is separable
+    auto resolve_tables = [&](unsigned tile) {
+        const unsigned n = tile / p.tilesPerImage, rem = tile - n * p.tilesPerImage, ty = rem / p.tilesX, tx = rem - ty * p.tilesX;
+        if (tq >= 192u && tq < 192u + kTileW) {
+            const int c = static_cast<int>(tq) - 192;
+            int sx = resolve_nobranch(static_cast<int>(tx << 5) - p.padx + c, p.W, p.padMode);
+            if (p.preMode) { // a pixel of the (virtual) padded image -> the source pixel the Pad layer would have copied
+                const int px = resolve_nobranch(sx - p.preX, p.srcW << p.preShift, p.preMode);
+                sx = sx < 0 ? -1 : (px < 0 ? -1 : px >> p.preShift);
+            }
+            sxTab[c] = sx;
+        } else if (tq >= 128u && tq < 128u + kTileH) {
+            const int rr = static_cast<int>(tq) - 128;
+            int sy = resolve_nobranch(static_cast<int>(ty << 3) - p.pady + rr, p.H, p.padMode);
+            if (p.preMode) {
+                const int py = resolve_nobranch(sy - p.preY, p.srcH << p.preShift, p.preMode);
+                sy = sy < 0 ? -1 : (py < 0 ? -1 : py >> p.preShift);
+            }
+            syTab[rr] = sy < 0 ? -1 : (static_cast<int>(n) * p.srcH + sy) * p.srcW;
+        }
+    };
+    // staging map of the tile whose tables are published: byte offset of element r's 16 bytes in x (chunk 0), ~0u = zeros (padding, pad slot, past the tile)
+    unsigned gofs[kR];
+    auto build_map = [&]() {
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const unsigned e = tq + 256u * r;
+            const unsigned pix = e / kQP, ql = e - pix * kQP, rr = pix / kTileW, c = pix - rr * kTileW;
+            gofs[r] = ~0u;
+            if (e < static_cast<unsigned>(kTotal)) {
+                const int rowPix = syTab[rr], sx = sxTab[c];
+                if (rowPix >= 0 && sx >= 0 && ql < 4u) gofs[r] = static_cast<unsigned>(rowPix + sx) * (IC * 2) + ql * 16;
+            }
+        }
+    };
+    auto stage_dma = [&](int bufOfs, int ic0) {
+        const char* const xb = reinterpret_cast<const char*>(x) + ic0 * 2;
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const char* src = gofs[r] != ~0u ? xb + gofs[r] : reinterpret_cast<const char*>(p.zeros);
+            lds_dma16_at(src, static_cast<unsigned>(bufOfs + 4096 * r) + waveLds);
+        }
+    };
+    // graph rule I: every thread normalises the 16-byte slots ITS lanes copied, between the copies' wait and the barrier that publishes the chunk
+    auto norm_fixup = [&](int bufOfs, int ic0, int slot) {
+        if (NORM == 0) return;
+        const float* const tb0 = normTab + slot * 2 * IC + ic0;
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            if (gofs[r] == ~0u) continue;
+            char* const sp = smem + bufOfs + (tq + 256u * r) * 16;
+            const float* const tb = tb0 + 8 * ((gofs[r] >> 4) & 3u);
+            h8 hv = *reinterpret_cast<const h8*>(sp);
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const f4 sh = *reinterpret_cast<const f4*>(tb + 4 * q4), mu = *reinterpret_cast<const f4*>(tb + IC + 4 * q4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float f = fmaf(static_cast<float>(hv[4 * q4 + k]), mu[k], sh[k]);
+                    hv[4 * q4 + k] = static_cast<_Float16>(NORM == 1 ? fmaxf(f, p.normAc.lo) : __builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                }
+            }
+            *reinterpret_cast<h8*>(sp) = hv;
+        }
+    };
+    auto load_norm_tab = [&](unsigned n, int slot, float& v) { // thread t < IC: shift[n][t]; t >= IC: mul[n][t - IC]  (IC = 128: one value per thread)
+        if (NORM == 0) return;
+        const float* src = tq < static_cast<unsigned>(IC) ? p.normShift + n * IC + tq : p.normMul + n * IC + (tq - IC);
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(src));
+        (void) slot;
+    };
+
+    // ---- first tile: tables, map, chunk 0, weight ring
+    unsigned tile = blockIdx.x;
+    waveLds = __builtin_amdgcn_readfirstlane(waveLds);
+    resolve_tables(tile);
+    {
+        float nv = 0.0f;
+        load_norm_tab(tile / p.tilesPerImage, 0, nv);
+        if (NORM != 0) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nv));
+            normTab[tid] = nv; // slot 0: [shift[IC] | mul[IC]]
+        }
+    }
+    lds_barrier();
+    build_map();
+    stage_dma(kLdsBuf0, 0);
+    f4 bq[D][2];
+#pragma unroll
+    for (int d = 0; d < D; ++d) gload16x2(wp, wlane + d * kStepBytes, bq[d][0], bq[d][1]);
+    vm_wait<0>();
+#pragma unroll
+    for (int d = 0; d < D; ++d) vm_wait_tie<0>(bq[d][0], bq[d][1]);
+    norm_fixup(kLdsBuf0, 0, 0);
+    lds_barrier();
+
+    f32x16 acc[4][2];
+    f4 a[4];
+    int it = 0;            // tiles done by this block (parity = the norm table slot of the current tile)
+    int pendN = -1;        // STATS + fold: image of the tile whose records are written but not yet counted
+    int foldN = -1;        // ... image whose last ticket this block may have drawn (the flag published by chunk 1's barrier says)
+    unsigned ticket = 0;   // (thread 0) the counter value the pending tile's atomic returned
+
+    for (;;) {
+        asm volatile("" : "+v"(wlane), "+v"(tq), "+s"(waveLds)); // (see above: nothing derived from these is a loop invariant)
+        const unsigned n = tile / p.tilesPerImage, rem = tile - n * p.tilesPerImage, ty = rem / p.tilesX, tx = rem - ty * p.tilesX;
+        const unsigned next = tile + G;
+        const bool hasNext = next < p.numTiles;
+        const unsigned ntile = hasNext ? next : tile; // (the last tile prefetches itself: the number of copies in the queue must not depend on the tile)
+        const int slot = it & 1;
+        float nv = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int curOfs = (c & 1) ? kLdsBuf1 : kLdsBuf0, nxtOfs = (c & 1) ? kLdsBuf0 : kLdsBuf1;
+            // ---- top of the chunk: the next chunk's copies (chunk 3: the NEXT TILE's first chunk, with its own map)
+            if (c == NCH - 1) build_map();                       // (tables of ntile: published by chunk 1's barrier)
+            stage_dma(nxtOfs, c == NCH - 1 ? 0 : (c + 1) * 32);
+            if (c == 1) {
+                resolve_tables(ntile);                            // (read again in chunk 3; the previous tile's were last read in ITS chunk 3)
+                load_norm_tab(ntile / p.tilesPerImage, slot ^ 1, nv); // one more vector-memory load in the queue when NORM (counted below)
+                if (STATS && pendN >= 0 && tid == 0) {            // the previous tile's records were acknowledged before chunk 0's barrier: count it
+                    unsigned* cnt = p.counter + pendN;
+                    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(ticket) : "v"(cnt), "v"(1u) : "memory");
+                }
+                foldN = pendN;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const f4*>(smem + curOfs + aoff0 + t * (kTileW * kQP * 16));
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                // KSTEP.  The operand of this step was requested D steps ago; younger than it in the queue: the L = 2 (D - 1) weight loads of the
+                // steps between, and -- when a chunk top lies between (s < D) -- that top's 7 copies (+ 1 table load in chunk 1 when NORM; thread
+                // 0's atomic there is left out: a count that is too SMALL only waits for one load more).  Chunk 0, s < D: waited for before the
+                // tile loop's back-edge (first tile: by the prologue).
+                f4 b0 = bq[s % D][0], b1 = bq[s % D][1];
+                if (s >= D) vm_wait_tie<L>(b0, b1);
+                else if (c == 1 && NORM != 0) vm_wait_tie<L + kR + 1>(b0, b1);
+                else if (c >= 1) vm_wait_tie<L + kR>(b0, b1);
+                {
+                    const int g2 = (c * S + s + D) % (NCH * S); // the ring wraps into the next tile's first steps: same weights
+                    gload16x2(wp, wlane + g2 * kStepBytes, bq[s % D][0], bq[s % D][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int tap = (s + 1) / 2;
+                const int dl = (((tap / 3) * kTileW + (tap % 3)) * kQP + ((s + 1) % 2) * 2) * 16; // compile-time: an immediate offset of the ds_read
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b0), *reinterpret_cast<const h8*>(&a[t]), acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b1), *reinterpret_cast<const h8*>(&a[t]), acc[t][1], 0, 0, 0);
+                    if (s + 1 < S) a[t] = *reinterpret_cast<const f4*>(smem + curOfs + aoff0 + t * (kTileW * kQP * 16) + dl);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- end of the chunk: everything older than the ring's 2 D youngest loads has landed (the copies, the table load, the ticket)
+            vm_wait<2 * D>();
+            if (c == 1) {
+                if (NORM != 0) {
+                    asm volatile("" : "+v"(nv));
+                    normTab[(slot ^ 1) * 2 * IC + tq] = nv;
+                }
+                if (STATS && tid == 0) {
+                    int last = 0;
+                    if (pendN >= 0) {
+                        asm volatile("" : "+v"(ticket));
+                        last = ticket + 1u == static_cast<unsigned>(p.tilesPerImage);
+                        if (last) __hip_atomic_store(p.counter + pendN, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch (a replayed hipGraph)
+                    }
+                    *reinterpret_cast<volatile int*>(smem + kLdsScr + 4 * kScrBytes - 16) = last; // (the scratch's last 16 bytes: pad columns of wave 3's last pixel row, never read as data)
+                }
+            }
+            norm_fixup(nxtOfs, c == NCH - 1 ? 0 : (c + 1) * 32, c == NCH - 1 ? (slot ^ 1) : slot);
+            lds_barrier();
+        }
+
+        // ---- epilogue (wave-private): accumulator layout acc[t][u][4 g + k] = channel 64 wn + 32 u + 8 g + 4 h + k of pixel (row 4 wm + t, column l32)
+        {
+            const unsigned lane = tq & 63u, l32 = tq & 31u, h = (tq >> 5) & 1u, wm = (tq >> 6) & 1u, wn = tq >> 7; // (shadow the kernel's: re-derived per tile)
+            const unsigned oy0 = (ty << 3) + wm * 4, ox0 = tx << 5;
+            char* const scr = smem + kLdsScr + waveLds / 1024 * kScrBytes;
+            const unsigned scrW = l32 * kScrPitch + h * 8;                    // + (32 u + 8 g) * 2
+            const unsigned scrR = (lane >> 3) * kScrPitch + (lane & 7) * 16;  // + 8 j * pitch
+            const float* const biasW = biasTab + wn * 64 + 4 * h;             // + 32 u + 8 g: the 4 biases of an accumulator run
+            const bool fastEpi = !p.useBN && ac.alpha == 1.0f && ac.hi == __builtin_huge_valf();
+            float sA[8], sB[8]; // rule F: sums and squares of (value - bias) of the 8 channels this lane carries to memory (channel 64 wn + 8 (lane & 7) + e)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sA[e] = sB[e] = 0.0f;
+            const unsigned pxl = lane >> 3;                              // + 8 j: the pixel (column) of this lane's vector j
+            const unsigned chanB = (wn * 64 + (lane & 7) * 8) * 2;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (fastEpi) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f4 b4 = *reinterpret_cast<const f4*>(biasW + 32 * u + 8 * g);
+                            h4 o;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(fmaxf(acc[t][u][4 * g + k] + b4[k], ac.lo));
+                            *reinterpret_cast<h4*>(scr + scrW + (32 * u + 8 * g) * 2) = o;
+                        }
+                } else {
+                    const float4* const etab = reinterpret_cast<const float4*>(smem + kLdsEpi) + wn * 64 + 4 * h;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            h4 o;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float4 e4 = etab[u * 32 + 8 * g + k]; // {bias, bnScale, bnMean, bnBeta}
+                                const float v = epi_affine(acc[t][u][4 * g + k], e4, p.useBN);
+                                o[k] = static_cast<_Float16>(apply_act<true>(ac, v, 0.0f));
+                            }
+                            *reinterpret_cast<h4*>(scr + scrW + (32 * u + 8 * g) * 2) = o;
+                        }
+                }
+                // (one wave's LDS instructions execute in order: the reads below see the writes above, and the next row's writes follow these reads)
+                f4 pk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[j] = *reinterpret_cast<const f4*>(scr + scrR + j * 8 * kScrPitch);
+                const unsigned oy = oy0 + t;
+                const bool rowIn = oy < static_cast<unsigned>(p.OH);
+                const unsigned rowB = ((n * p.OH + oy) * p.OW + ox0) * (OC * 2);
+                f4 piv0, piv1;
+                if (STATS) {
+                    piv0 = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 8 * (lane & 7));
+                    piv1 = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 8 * (lane & 7) + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned ox = ox0 + pxl + 8 * j;
+                    const bool in = rowIn && ox < static_cast<unsigned>(p.OW);
+                    if (STATS && in) {
+                        const _Float16* ch = reinterpret_cast<const _Float16*>(&pk[j]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = static_cast<float>(ch[e]) - (e < 4 ? piv0[e & 3] : piv1[e & 3]);
+                            sA[e] += f;
+                            sB[e] = fmaf(f, f, sB[e]);
+                        }
+                    }
+                    // unconditional: a pixel outside the map stores to the dump buffer (lane-private 16 bytes of it)
+                    char* const dst = in ? reinterpret_cast<char*>(y) + (rowB + (pxl + 8 * j) * (OC * 2) + chanB) : reinterpret_cast<char*>(p.dump) + tq * 16;
+                    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(pk[j]) : "memory");
+                }
+            }
+            if (STATS) {
+                // the wave's record: lanes (pixel group pg = lane >> 3, column c8 = lane & 7) -> LDS [pg][2][64], then lane c sums its channel's 8 groups
+                float* const red = reinterpret_cast<float*>(scr); // 8 x 128 floats = 4 096 bytes of the wave's 4 608
+                {
+                    float* const w = red + (lane >> 3) * 128 + (lane & 7) * 8;
+                    *reinterpret_cast<f4*>(w) = f4{sA[0], sA[1], sA[2], sA[3]};
+                    *reinterpret_cast<f4*>(w + 4) = f4{sA[4], sA[5], sA[6], sA[7]};
+                    *reinterpret_cast<f4*>(w + 64) = f4{sB[0], sB[1], sB[2], sB[3]};
+                    *reinterpret_cast<f4*>(w + 68) = f4{sB[4], sB[5], sB[6], sB[7]};
+                }
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) {
+                    s1 += red[g8 * 128 + lane];
+                    s2 += red[g8 * 128 + 64 + lane];
+                }
+                const int rows = max(0, min(4, p.OH - static_cast<int>(oy0))), cols = max(0, min(32, p.OW - static_cast<int>(ox0)));
+                const float cnt = static_cast<float>(rows * cols), inv = cnt > 0.0f ? 1.0f / cnt : 0.0f;
+                const float m1 = s1 * inv;
+                const float mean = biasTab[wn * 64 + lane] + m1, M2 = fmaxf(s2 - s1 * m1, 0.0f);
+                float* const po = p.statPart + (static_cast<size_t>((n * 2 * p.tilesY + 2 * ty + wm) * p.tilesX + tx) * 2 * OC + wn * 64 + lane);
+                asm volatile("global_store_dword %0, %1, off sc1\n\tglobal_store_dword %0, %2, off offset:512 sc1" ::"v"(po), "v"(mean), "v"(M2) : "memory");
+                pendN = p.counter ? static_cast<int>(n) : -1;
+            }
+        }
+        if (STATS && foldN >= 0) {
+            // the ticket of the tile BEFORE this one came back under chunk 1's wait and its verdict was published by chunk 1's barrier; the fold runs
+            // here, where no accumulator is live (its 16 records in flight per thread are 80 registers).  Other waves may still be inside their
+            // epilogues, whose scratch the fold re-uses: one barrier first (this path runs N times per launch, not once per tile)
+            if (*reinterpret_cast<volatile int*>(smem + kLdsScr + 4 * kScrBytes - 16) != 0) {
+                lds_barrier();
+                tile_stats_fold<128>(*p.fold, p.statPart, reinterpret_cast<float*>(smem + kLdsScr), foldN, p.tilesX, 2 * p.tilesY, 4, 32, p.OH, p.OW, OC, 0);
+                lds_barrier();
+            }
+            foldN = -1;
+        }
+        if (!hasNext) break;
+        // the ring (steps 0 .. D-1 of the next tile, requested in chunk 3's last D steps) has landed long ago; formally: everything older than the
+        // epilogue's stores.  After this statement no register of the loop's back-edge is the target of a load in flight.
+#pragma unroll
+        for (int d = 0; d < D; ++d) vm_wait_tie<kEpiStores + (STATS ? 2 : 0)>(bq[d][0], bq[d][1]);
+        tile = next;
+        ++it;
+    }
+
+    if (STATS && p.counter) { // the last tile's ticket: nothing to hide it behind
+        if (pendN >= 0) {
+            vm_wait<0>();
+            lds_barrier();
+            int* const flag = reinterpret_cast<int*>(smem + kLdsScr + 4 * kScrBytes - 16);
+            if (tid == 0) {
+                unsigned* cnt = p.counter + pendN;
+                const unsigned prev = atomicAdd(cnt, 1u);
+                const bool last = prev + 1u == static_cast<unsigned>(p.tilesPerImage);
+                if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = last;
+            }
+            __syncthreads();
+            const bool last = *flag != 0;
+            __syncthreads();
+            if (last) tile_stats_fold<128>(*p.fold, p.statPart, reinterpret_cast<float*>(smem + kLdsScr), pendN, p.tilesX, 2 * p.tilesY, 4, 32, p.OH, p.OW, OC, 0);
+        }
+    }
+}
+
+typedef void (*WidePFn)(WidePParams, ActCfg, const _Float16*, const char*, const float4*, _Float16*);
+
+struct WidePConvPlan : ConvPlanBase {
+    WidePParams p;
+    ActCfg ac;
+    float* d_w = nullptr;
+    float* d_epi = nullptr;
+    size_t ldsBytes = 0;
+    int gridBlocks = 0;
+    int normKind = 0;
+    int ringD = 3;
+
+    WidePFn pick() const {
+#define SNNHIP_WP_D(NK, ST) (ringD == 6 ? conv2d_widep_kernel<NK, ST, 6> : conv2d_widep_kernel<NK, ST, 3>)
+        const bool st = p.statPart != nullptr;
+        if (normKind == 0) return st ? SNNHIP_WP_D(0, true) : SNNHIP_WP_D(0, false);
+        if (normKind == 1) return st ? SNNHIP_WP_D(1, true) : SNNHIP_WP_D(1, false);
+        return st ? SNNHIP_WP_D(2, true) : SNNHIP_WP_D(2, false);
+#undef SNNHIP_WP_D
+    }
+
+    // chain rule F: per-WAVE records (4 rows x 32 columns x 64 channels), i.e. a record grid of tilesX x 2 tilesY tiles of 4 x 32 pixels
+    bool enableTileStats() override {
+        if (statPart) return true;
+        void* buf = nullptr;
+        const size_t bytes = static_cast<size_t>(p.N) * 2 * p.tilesY * p.tilesX * 2 * 128 * sizeof(float);
+        if (snnhip::dev_malloc(&buf, bytes, "conv2d_widep tile statistics") != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        statPart = p.statPart = static_cast<float*>(buf);
+        statTilesX = p.tilesX; statTilesY = 2 * p.tilesY; statTH = 4; statTW = 32;
+        desc += " +tile-stats";
+        return true;
+    }
+    bool enableNormFold(const NormFoldTarget& t) override {
+        if (!statPart || p.counter) return false;
+        void* buf = nullptr;
+        const size_t bytes = static_cast<size_t>(p.N) * sizeof(unsigned);
+        if (snnhip::dev_malloc(&buf, bytes, "conv2d_widep image counters") != hipSuccess) return false;
+        deviceAllocs.push_back(buf);
+        if (hipMemset(buf, 0, bytes) != hipSuccess) return false;
+        NormFoldArgs f{};
+        f.counter = static_cast<unsigned*>(buf);
+        f.gamma = t.gamma; f.beta = t.beta; f.shift = t.shift; f.mul = t.mul; f.eps = t.eps;
+        void* fbuf = nullptr;
+        if (snnhip::dev_malloc(&fbuf, sizeof(f), "conv2d_widep fold arguments") != hipSuccess) return false;
+        deviceAllocs.push_back(fbuf);
+        if (hipMemcpy(fbuf, &f, sizeof(f), hipMemcpyHostToDevice) != hipSuccess) return false;
+        p.fold = static_cast<const NormFoldArgs*>(fbuf);
+        p.counter = f.counter;
+        desc += "+fold";
+        return true;
+    }
+    int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
+        SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
+        const snnhip_tensor* x = in[0];
+        SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == 128 && x->dtype == SNNHIP_F16,
+                       "conv2d: input dims %dx%dx%dx%d (dtype %d) != plan %dx%dx%dx%d fp16", x->n, x->h, x->w, x->c, x->dtype, p.N, p.srcH, p.srcW, 128);
+        SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == 128 && out->dtype == SNNHIP_F16,
+                       "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, 128);
+        const WidePFn fn = pick();
+        SNNHIP_LAUNCH(fn, dim3(static_cast<unsigned>(gridBlocks)), dim3(256), ldsBytes, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data),
+                      reinterpret_cast<const char*>(d_w), reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
+        SNNHIP_CHECK_HIP(hipGetLastError());
+        return SNNHIP_OK;
+    }
+};
+
+} // namespace
+
+// fp16 3x3 stride-1 layers with IC = OC = 128, no fused residual, at least one tile per resident block slot; SNNHIP_WIDE_PERSIST=0 keeps conv2d_wide_kernel
+// (A/B runs), SNNHIP_WIDE_RING=3|6 pins the weight ring's depth
+int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
+    if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
+    if (g.IC != 128 || g.OC != 128 || !act_is_simple(g.act) || g.addAct >= 0) return SNNHIP_E_UNSUPPORTED; // (other activations / a fused residual: conv2d_wide_kernel)
+    if (g.normShift && !act_is_simple(g.normAct)) return SNNHIP_E_UNSUPPORTED;
+    if (const char* e = snnhip::option("SNNHIP_WIDE_PERSIST"))
+        if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
+    const int srcH = g.preMode ? g.srcH : g.H, srcW = g.preMode ? g.srcW : g.W;
+    const double inBytes = 2.0 * g.N * srcH * srcW * g.IC, outBytes = 2.0 * g.N * g.OH * g.OW * g.OC;
+    if (inBytes >= 4294967295.0 || outBytes >= 4294967295.0) return SNNHIP_E_UNSUPPORTED; // 32-bit byte offsets from a scalar base
+    const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+    const int tilesX = up_div(g.OW, 32), tilesY = up_div(g.OH, 8);
+    const long tiles = static_cast<long>(g.N) * tilesX * tilesY;
+    const char* force = snnhip::option("SNNHIP_CONV");
+    const bool forced = force && strcmp(force, "wide") == 0;
+    if (!forced && tiles < 3L * cus / 4) return SNNHIP_E_UNSUPPORTED; // (conv2d_wide's own bound: below it the 128-pixel blocks and their split-K fill the chip better)
+    if (tiles >= 2147483647L / 4) return SNNHIP_E_UNSUPPORTED;
+
+    WidePParams p{};
+    p.N = g.N; p.H = g.H; p.W = g.W; p.OH = g.OH; p.OW = g.OW; p.padx = g.padx; p.pady = g.pady; p.padMode = g.padMode; p.useBN = g.useBN;
+    p.tilesX = tilesX; p.tilesY = tilesY; p.tilesPerImage = tilesX * tilesY; p.numTiles = static_cast<unsigned>(tiles);
+    p.preMode = g.preMode; p.preX = g.preX; p.preY = g.preY; p.preShift = g.preMode ? g.preShift : 0;
+    p.srcH = srcH; p.srcW = srcW;
+    p.normShift = g.normShift; p.normMul = g.normMul;
+    p.normAc = make_act_cfg(g.normShift ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
+
+    auto* plan = new WidePConvPlan();
+    plan->ctx = ctx;
+    plan->g = g;
+    plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC * 9);
+    plan->epi4 = epi4;
+    plan->ac = make_act_cfg(g.act, g.leaky);
+    plan->normKind = !g.normShift ? 0 : ((p.normAc.alpha == 1.0f && p.normAc.hi == __builtin_huge_valf()) ? 1 : 2);
+    plan->ringD = 3;
+    if (const char* e = snnhip::option("SNNHIP_WIDE_RING"))
+        if (atoi(e) == 6) plan->ringD = 6;
+    plan->ldsBytes = static_cast<size_t>(kLdsNorm) + 2 * 2 * 128 * sizeof(float);
+    {   // 80 KB of dynamic LDS: every instantiation this plan may pick later (statistics / fold are switched on after creation)
+        const bool keepStat = plan->p.statPart != nullptr;
+        bool ok = true;
+        for (int st = 0; st < 2 && ok; ++st) {
+            plan->p.statPart = st ? reinterpret_cast<float*>(plan) : nullptr; // (only pick()'s test of it)
+            ok = hipFuncSetAttribute(reinterpret_cast<const void*>(plan->pick()), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan->ldsBytes)) == hipSuccess;
+        }
+        plan->p.statPart = keepStat ? plan->p.statPart : nullptr;
+        if (!ok) {
+            set_error("conv2d_widep: hipFuncSetAttribute(%zu) failed", plan->ldsBytes);
+            delete plan;
+            return SNNHIP_E_HIP;
+        }
+    }
+    plan->gridBlocks = static_cast<int>(std::min<long>(tiles, 2L * cus));
+
+    // weights: Wp[step = (chunk, tap, c8)][h][oc] x 8 halfs, ic = chunk*32 + (c8*2 + h)*8 + j -- conv2d_wide_f16's packing (C8 = 2) -- + one step of zeros (the padding pixels' DMA source)
+    const size_t steps = 72;
+    std::vector<float> wpk((steps + 1) * 2 * 128 * 4, 0.0f);
+    _Float16* wph = reinterpret_cast<_Float16*>(wpk.data());
+    for (int chunk = 0; chunk < 4; ++chunk)
+        for (int t = 0; t < 9; ++t)
+            for (int c8 = 0; c8 < 2; ++c8)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int j = 0; j < 8; ++j) {
+                        const int ic = chunk * 32 + (c8 * 2 + hh) * 8 + j;
+                        const size_t base = (((static_cast<size_t>(chunk) * 9 + t) * 2 + c8) * 2 + hh) * 128;
+                        for (int o = 0; o < 128; ++o) wph[(base + o) * 8 + j] = static_cast<_Float16>(w_oihw[(static_cast<size_t>(o) * 128 + ic) * 9 + t]);
+                    }
+    std::vector<float> epiP(static_cast<size_t>(128) * 4, 0.0f);
+    std::memcpy(epiP.data(), epi4.data(), sizeof(float) * 4 * 128);
+    int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
+    if (rc == SNNHIP_OK) rc = plan->upload(epiP.data(), epiP.size(), &plan->d_epi);
+    void* dump = nullptr;
+    if (rc == SNNHIP_OK && snnhip::dev_malloc(&dump, 256 * 16, "conv2d_widep dump buffer") != hipSuccess) rc = SNNHIP_E_NOMEM;
+    if (rc != SNNHIP_OK) {
+        delete plan;
+        return rc;
+    }
+    plan->deviceAllocs.push_back(dump);
+    p.zeros = reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(plan->d_w) + steps * kStepBytes);
+    p.dump = static_cast<_Float16*>(dump);
+    plan->p = p;
+    plan->inDims[0] = g.N; plan->inDims[1] = srcH; plan->inDims[2] = srcW; plan->inDims[3] = g.IC;
+    plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
+    plan->dtype = SNNHIP_F16;
+    plan->flops = 2.0 * 9 * g.IC * g.OC * static_cast<double>(g.OH) * g.OW * g.N;
+    plan->bytes = 2.0 * (static_cast<double>(g.N) * srcH * srcW * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * 9);
+    char buf[320];
+    snprintf(buf, sizeof(buf), "conv2d_mfma_wide_f16_32x32x16 persistent k=3x3 s=1 ic=128 oc=128 tile=8x32px x 128oc (4x2 MFMA tiles per wave) chunk=32 ring=%d blocks=%d lds=%zuB",
+             plan->ringD, plan->gridBlocks, plan->ldsBytes);
+    plan->desc = buf;
+    if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
+    if (g.preMode && g.preShift) plan->desc += " +upsample(x2)";
+    if (g.normShift) plan->desc = "instancenorm(act=" + std::to_string(g.normAct) + ", in LDS behind the DMA) -> " + plan->desc;
+    *out = plan;
+    return SNNHIP_OK;
+}
+
+} // namespace snnhip

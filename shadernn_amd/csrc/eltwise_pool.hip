@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void instancenorm_fold_tiles1_kernel(int C, in
                 const int t = t0 + j;
                 if (t < tiles) {
                     const int ty = t / tilesX, tx = t - ty * tilesX;
-                    const float cnt = static_cast<float>(min(TH, H - ty * TH) * min(TW, W - tx * TW));
+                    const float cnt = static_cast<float>(max(0, min(TH, H - ty * TH)) * max(0, min(TW, W - tx * TW)));
                     stat_merge(a, cnt, pn[static_cast<size_t>(t) * 2 * C + c], pn[static_cast<size_t>(t) * 2 * C + C + c]);
                 }
             }

@@ -44,6 +44,12 @@ constexpr int kFoldScratchFloats = 3 * 512 + 1; // LDS the fold needs
 // first channel (even: the 8-byte loads).  The fold is the tail of the launch (the last image's last block runs it when everything else is
 // done), so it is built for latency: thread = (channel pair, 1 of 512 / BN parts), 16 records (64 floats) in flight per thread -- a 720p map of
 // 286 tiles x 128 channels takes 5 round trips to the coherence point instead of the 143 of a one-record-at-a-time walk.
+// The fold proper: called by all 256 threads of the block that saw an image's last record counted (after ONE agent-scope acquire, below).
+// counterBlocks / counterIndex stand for gridDim.y / blockIdx.y of the tile kernels (a persistent kernel has neither).
+template <int BN>
+__device__ __forceinline__ void tile_stats_fold(const NormFoldArgs& f, const float* part, float* scratch, int n, int tilesX, int tilesY, int TH, int TW, int OH, int OW, int OC,
+                                                int ocb);
+
 template <int BN>
 __device__ __forceinline__ void tile_stats_finish(const NormFoldArgs& f, const float* part, float* scratch, int n, int tilesX, int tilesY, int TH, int TW, int OH, int OW,
                                                   int OC, int ocb) {
@@ -59,7 +65,14 @@ __device__ __forceinline__ void tile_stats_finish(const NormFoldArgs& f, const f
     }
     __syncthreads();
     if (scratch[3 * 512] == 0.0f) return;
-    // The hand-off above is relaxed on purpose (a release in EVERY block would be the L2 write-back described at the top).  What makes the records
+    tile_stats_fold<BN>(f, part, scratch, n, tilesX, tilesY, TH, TW, OH, OW, OC, ocb);
+}
+
+template <int BN>
+__device__ __forceinline__ void tile_stats_fold(const NormFoldArgs& f, const float* part, float* scratch, int n, int tilesX, int tilesY, int TH, int TW, int OH, int OW, int OC,
+                                                int ocb) {
+    const int tid = threadIdx.x, tiles = tilesX * tilesY;
+    // The hand-off is relaxed on purpose (a release in EVERY block would be the L2 write-back described at the top).  What makes the records
     // visible is that they are written through (sc1 stores, acknowledged before the block is counted) and read with sc1 loads; formally that still
     // leaves the last block without an acquire.  It gets one here -- ONE agent-scope acquire per image (an invalidate, no write-back): nothing this
     // block has cached from an earlier launch of the same plan (the records live in the same buffer launch after launch) can satisfy the loads below.
@@ -78,7 +91,7 @@ __device__ __forceinline__ void tile_stats_finish(const NormFoldArgs& f, const f
             mb[j] = qb[j] = make_float2(0.0f, 0.0f);
             if (t < tiles) {
                 const int ty = t / tilesX, tx = t - ty * tilesX;
-                nb[j] = static_cast<float>(min(TH, OH - ty * TH) * min(TW, OW - tx * TW));
+                nb[j] = static_cast<float>(max(0, min(TH, OH - ty * TH)) * max(0, min(TW, OW - tx * TW))); // (a record row / column entirely outside the image counts nothing)
                 mb[j] = ld_agent2(pn + static_cast<size_t>(t) * 2 * OC);
                 qb[j] = ld_agent2(pn + static_cast<size_t>(t) * 2 * OC + OC);
             }

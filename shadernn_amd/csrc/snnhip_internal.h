@@ -227,6 +227,7 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
 int make_conv2d_stem_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp16 9x9 s1, IC <= 4; tried first by make_conv2d_mfma_plan
 int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp32 stems (IC <= 4), tried first by make_conv2d_mfma_plan
 int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp16 3x3 s1, large maps; tried first by make_conv2d_mfma_plan
+int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // ... IC = OC = 128: persistent blocks; tried first by make_conv2d_wide_plan
 int make_conv2d_upconv_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp16 upsample x2 -> reflect pad 1 -> 3x3 on the low-resolution tensor; tried by make_conv2d_mfma_plan
 int make_conv2d_s2march_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp16 3x3 s2, IC 32 / 64, large maps; tried by make_conv2d_mfma_plan
 int make_conv2d_rowmarch_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // ... OC <= 4: row-marching strips

@@ -261,9 +261,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                 // 0's atomic there is left out: a count that is too SMALL only waits for one load more).  Chunk 0, s < D: waited for before the
                 // tile loop's back-edge (first tile: by the prologue).
                 f4 b0 = bq[s % D][0], b1 = bq[s % D][1];
+#ifdef SNNHIP_WIDEP_STRICT // experiment build: every operand wait as if nothing but weight loads were in the queue (drains the copies early; correctness probe)
+                if (c >= 1 || s >= D) vm_wait_tie<L>(b0, b1);
+#else
                 if (s >= D) vm_wait_tie<L>(b0, b1);
                 else if (c == 1 && NORM != 0) vm_wait_tie<L + kR + 1>(b0, b1);
                 else if (c >= 1) vm_wait_tie<L + kR>(b0, b1);
+#endif
                 {
                     const int g2 = (c * S + s + D) % (NCH * S); // the ring wraps into the next tile's first steps: same weights
                     gload16x2(wp, wlane + g2 * kStepBytes, bq[s % D][0], bq[s % D][1]);
@@ -344,6 +348,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                         }
                 }
                 // (one wave's LDS instructions execute in order: the reads below see the writes above, and the next row's writes follow these reads)
+#ifdef SNNHIP_WIDEP_SYNCEPI
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
                 f4 pk[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pk[j] = *reinterpret_cast<const f4*>(scr + scrR + j * 8 * kScrPitch);
@@ -370,7 +377,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                     }
                     // unconditional: a pixel outside the map stores to the dump buffer (lane-private 16 bytes of it)
                     char* const dst = in ? reinterpret_cast<char*>(y) + (rowB + (pxl + 8 * j) * (OC * 2) + chanB) : reinterpret_cast<char*>(p.dump) + tq * 16;
-                    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(pk[j]) : "memory");
+                    // (s_nop 1: a store of more than 8 bytes reads its data registers over the following cycles; the compiler's hazard recognizer puts the wait
+                    // states behind ITS stores, not behind an inline-asm one -- without them the address arithmetic of the next vector, allocated into pk[j]'s
+                    // first register, reached memory in lanes 12-15 of every row of 16: found as wrong values at odd pixels, channels 32 u + 8 g + {0, 1})
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(pk[j]) : "memory");
                 }
             }
             if (STATS) {

@@ -32,6 +32,14 @@
 
 #include <cstring>
 
+#ifdef SNNHIP_WIDEP_TRACE // experiment builds (tools/exp_one.sh): one block sums the s_memtime spans of its phases over its tiles and prints them
+#define WP_T0() unsigned long long wpT = __builtin_readcyclecounter()
+#define WP_ADD(i) do { const unsigned long long wpN = __builtin_readcyclecounter(); wpAcc[i] += wpN - wpT; wpT = wpN; } while (0)
+#else
+#define WP_T0() do { } while (0)
+#define WP_ADD(i) do { } while (0)
+#endif
+
 namespace snnhip {
 
 namespace {
@@ -58,8 +66,7 @@ struct WidePParams {
     int N, H, W, OH, OW, padx, pady, padMode, useBN;
     unsigned tilesX, tilesY, tilesPerImage, numTiles;
     int preMode, preX, preY, srcH, srcW, preShift;
-    const _Float16* zeros;  // 16 bytes of zeros per lane (behind the packed weights): source of the padding pixels' DMA
-    _Float16* dump;         // 64 KB nobody reads: where the stores of pixels outside the map go (their NUMBER must not depend on the tile)
+    unsigned xBytes, yBytes; // sizes of the input / output tensors (the raw buffer descriptors' bounds)
     float* statPart;        // chain rule F: [n][2 tilesY][tilesX][2][128] per-wave {mean, M2} records; null = off
     unsigned* counter;      // ... [N] tiles of the image counted so far; the block that draws an image's last ticket folds it; null = no in-kernel fold
     const NormFoldArgs* fold; // (device copy: read by the folding block only -- eleven scalar registers the tile loop does not have to carry)
@@ -80,17 +87,39 @@ __device__ __forceinline__ void vm_wait_tie(f4& a, f4& b) {
 __device__ __forceinline__ void gload16x2(const char* sbase, unsigned voff, f4& r0, f4& r1) { // [oc tile 0, oc tile 1] of one K step (512 bytes apart)
     asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:512" : "=&v"(r0), "=&v"(r1) : "v"(voff), "s"(sbase));
 }
-__device__ __forceinline__ void lds_dma16_at(const void* gsrc, unsigned ldsWaveByteAddr) { // epilogue.h's lds_dma16 with the wave's LDS address already a scalar
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(ldsWaveByteAddr) : "memory");
+// Tensors are addressed through raw buffer descriptors (base, 0 stride, size in bytes): a lane offset at or beyond the size is out of range -- a load
+// returns zeros (the padding pixels of the staging map: no select against a block of zeros, no 64-bit address arithmetic per copy) and a store is
+// dropped (pixels of a ragged tile outside the map: every thread still issues the same NUMBER of stores, which the counted waits rely on).
+typedef int i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i4 make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    i4 r;
+    r[0] = __builtin_amdgcn_readfirstlane(static_cast<int>(a));
+    r[1] = __builtin_amdgcn_readfirstlane(static_cast<int>((a >> 32) & 0xffffu)); // stride 0, no swizzle
+    r[2] = __builtin_amdgcn_readfirstlane(static_cast<int>(bytes));
+    r[3] = 0x00020000; // gfx9 raw buffer: DATA_FORMAT 32
+    return r;
+}
+constexpr unsigned kOutOfRange = 0xfffffff0u;
+__device__ __forceinline__ void lds_dma16_buf(const i4& rsrc, unsigned laneByteOffset, unsigned uniformByteOffset, unsigned ldsWaveByteAddr) {
+    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(laneByteOffset), "s"(rsrc), "s"(ldsWaveByteAddr), "s"(uniformByteOffset) : "memory");
+}
+// (s_nop 1: a store of more than 8 bytes reads its data registers over the following cycles; the compiler's hazard recognizer puts the wait states
+// behind ITS stores, not behind an inline-asm one -- without them the address arithmetic of the next vector, allocated into the data's first register,
+// reached memory in lanes 12-15 of every row of 16: found as wrong values at odd pixels, channels 32 u + 8 g + {0, 1})
+__device__ __forceinline__ void store16_buf(const i4& rsrc, unsigned laneByteOffset, const f4& v) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(laneByteOffset), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void lds_barrier() { // LDS traffic of this wave done, then the block barrier; vector memory stays in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// NORM: 0 = no InstanceNorm in front, 1 = its activation is none / ReLU (max(f, lo)), 2 = any branch-free activation (med3 form)
+// NORM: 0 = no InstanceNorm in front, 1 = its activation is ReLU (max on the packed halfs), 2 = any branch-free activation (med3 form), 3 = none
+// FAST: the layer has no batch norm and its activation is none (FAST = 2) or ReLU (FAST = 1): the bias is the C operand of a tile's first MFMAs and the
+//       epilogue is a conversion [+ a packed max]; 0 = the general bias [-> BN] -> med3 epilogue
 // STATS: chain rule F records (+ the in-kernel fold when p.fold.counter)
 // D: K steps of weight operands in flight per lane (divides 18)
-template <int NORM, bool STATS, int D>
+template <int NORM, bool STATS, int D, int FAST>
 __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, ActCfg ac, const _Float16* __restrict__ x, const char* __restrict__ wp, const float4* __restrict__ epi,
                                                            _Float16* __restrict__ y) {
     constexpr int NCH = 4, IC = 32 * NCH, OC = 128, S = 18, L = 2 * (D - 1); // L: weight loads younger than the one a step waits for
@@ -118,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     // spilled vector registers (ROCm 7.2; the naive persistent loop of round 4 failed the same way)
     unsigned wlane = wlane0, waveLds = static_cast<unsigned>(wave * 1024);
     unsigned tq = static_cast<unsigned>(tid); // the thread index as the tile loop sees it
+    const i4 xRsrc = make_rsrc(x, p.xBytes), yRsrc = make_rsrc(y, p.yBytes);
 
     // row / column tables of a tile (52 threads, one coordinate each): the source pixel of a staged pixel is separable
     auto resolve_tables = [&](unsigned tile) {
@@ -147,41 +177,53 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
         for (int r = 0; r < kR; ++r) {
             const unsigned e = tq + 256u * r;
             const unsigned pix = e / kQP, ql = e - pix * kQP, rr = pix / kTileW, c = pix - rr * kTileW;
-            gofs[r] = ~0u;
-            if (e < static_cast<unsigned>(kTotal)) {
-                const int rowPix = syTab[rr], sx = sxTab[c];
-                if (rowPix >= 0 && sx >= 0 && ql < 4u) gofs[r] = static_cast<unsigned>(rowPix + sx) * (IC * 2) + ql * 16;
-            }
+            // (rr <= 10 < 32 and c < 34 < 40 for every e < 1792: the look-ups stay inside the tables, no branch around them)
+            const int rowPix = syTab[rr], sx = sxTab[c];
+            const bool ok = e < static_cast<unsigned>(kTotal) && rowPix >= 0 && sx >= 0 && ql < 4u;
+            gofs[r] = ok ? static_cast<unsigned>(rowPix + sx) * (IC * 2) + ql * 16 : kOutOfRange;
         }
     };
     auto stage_dma = [&](int bufOfs, int ic0) {
-        const char* const xb = reinterpret_cast<const char*>(x) + ic0 * 2;
 #pragma unroll
-        for (int r = 0; r < kR; ++r) {
-            const char* src = gofs[r] != ~0u ? xb + gofs[r] : reinterpret_cast<const char*>(p.zeros);
-            lds_dma16_at(src, static_cast<unsigned>(bufOfs + 4096 * r) + waveLds);
-        }
+        for (int r = 0; r < kR; ++r) lds_dma16_buf(xRsrc, gofs[r], static_cast<unsigned>(ic0 * 2), static_cast<unsigned>(bufOfs + 4096 * r) + waveLds);
     };
     // graph rule I: every thread normalises the 16-byte slots ITS lanes copied, between the copies' wait and the barrier that publishes the chunk
     auto norm_fixup = [&](int bufOfs, int ic0, int slot) {
         if (NORM == 0) return;
         const float* const tb0 = normTab + slot * 2 * IC + ic0;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
-            if (gofs[r] == ~0u) continue;
+            // (no branch around a slot of padding: its zeros are normalised like everything else and written back as zeros by the select below -- seven
+            // short branches per chunk cost more than the 20 instructions they skip on the few border tiles)
             char* const sp = smem + bufOfs + (tq + 256u * r) * 16;
             const float* const tb = tb0 + 8 * ((gofs[r] >> 4) & 3u);
-            h8 hv = *reinterpret_cast<const h8*>(sp);
+            const h8 hv = *reinterpret_cast<const h8*>(sp);
+            h8 ov;
 #pragma unroll
             for (int q4 = 0; q4 < 2; ++q4) {
                 const f4 sh = *reinterpret_cast<const f4*>(tb + 4 * q4), mu = *reinterpret_cast<const f4*>(tb + IC + 4 * q4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float f = fmaf(static_cast<float>(hv[4 * q4 + k]), mu[k], sh[k]);
-                    hv[4 * q4 + k] = static_cast<_Float16>(NORM == 1 ? fmaxf(f, p.normAc.lo) : __builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                    const float f = fmaf(static_cast<float>(hv[4 * q4 + k]), mu[k], sh[k]); // (v_fma_mix: the conversions ride the fma)
+                    if (NORM == 2) ov[4 * q4 + k] = static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                    else ov[4 * q4 + k] = static_cast<_Float16>(f);
                 }
             }
-            *reinterpret_cast<h8*>(sp) = hv;
+            if (NORM == 1) { // ReLU on the rounded halfs, two per instruction (rounding is monotonic and keeps zero: the same bits as max-then-round)
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    h2 v2 = {ov[2 * k2], ov[2 * k2 + 1]};
+                    v2 = __builtin_elementwise_max(v2, h2{static_cast<_Float16>(0.0f), static_cast<_Float16>(0.0f)});
+                    ov[2 * k2] = v2[0];
+                    ov[2 * k2 + 1] = v2[1];
+                }
+            }
+            const bool pad = gofs[r] == kOutOfRange;
+            f4 res = *reinterpret_cast<const f4*>(&ov);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) res[k] = pad ? 0.0f : res[k];
+            *reinterpret_cast<f4*>(sp) = res;
         }
     };
     auto load_norm_tab = [&](unsigned n, int slot, float& v) { // thread t < IC: shift[n][t]; t >= IC: mul[n][t - IC]  (IC = 128: one value per thread)
@@ -222,6 +264,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     int foldN = -1;        // ... image whose last ticket this block may have drawn (the flag published by chunk 1's barrier says)
     unsigned ticket = 0;   // (thread 0) the counter value the pending tile's atomic returned
 
+#ifdef SNNHIP_WIDEP_TRACE
+    unsigned long long wpAcc[8] = {};
+    int wpTiles = 0;
+    const unsigned long long wpStart = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+#endif
+    WP_T0();
     for (;;) {
         asm volatile("" : "+v"(wlane), "+v"(tq), "+s"(waveLds)); // (see above: nothing derived from these is a loop invariant)
         const unsigned n = tile / p.tilesPerImage, rem = tile - n * p.tilesPerImage, ty = rem / p.tilesX, tx = rem - ty * p.tilesX;
@@ -230,12 +278,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
         const unsigned ntile = hasNext ? next : tile; // (the last tile prefetches itself: the number of copies in the queue must not depend on the tile)
         const int slot = it & 1;
         float nv = 0.0f;
+        // FAST: acc = bias + sum (the bias rides the first MFMA's C operand: 128 additions per tile less); else acc = sum, bias in the epilogue
+        f32x16 cinit[2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int g = 0; g < 4; ++g) {
+                const f4 b4 = FAST ? *reinterpret_cast<const f4*>(biasTab + (tq >> 7) * 64 + 4 * ((tq >> 5) & 1u) + 32 * u + 8 * g) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+                for (int k = 0; k < 4; ++k) cinit[u][4 * g + k] = b4[k];
+            }
 
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -252,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                 }
                 foldN = pendN;
             }
+            WP_ADD(0); // chunk top: map, copies issued, tables
 #pragma unroll
             for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const f4*>(smem + curOfs + aoff0 + t * (kTileW * kQP * 16));
 #pragma unroll
@@ -277,14 +330,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                 const int dl = (((tap / 3) * kTileW + (tap % 3)) * kQP + ((s + 1) % 2) * 2) * 16; // compile-time: an immediate offset of the ds_read
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b0), *reinterpret_cast<const h8*>(&a[t]), acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b1), *reinterpret_cast<const h8*>(&a[t]), acc[t][1], 0, 0, 0);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b0), *reinterpret_cast<const h8*>(&a[t]), (c == 0 && s == 0) ? cinit[0] : acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b1), *reinterpret_cast<const h8*>(&a[t]), (c == 0 && s == 0) ? cinit[1] : acc[t][1], 0, 0, 0);
                     if (s + 1 < S) a[t] = *reinterpret_cast<const f4*>(smem + curOfs + aoff0 + t * (kTileW * kQP * 16) + dl);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // ---- end of the chunk: everything older than the ring's 2 D youngest loads has landed (the copies, the table load, the ticket)
+            WP_ADD(1); // K steps
             vm_wait<2 * D>();
+            WP_ADD(2); // wait for the copies
             if (c == 1) {
                 if (NORM != 0) {
                     asm volatile("" : "+v"(nv));
@@ -301,7 +356,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                 }
             }
             norm_fixup(nxtOfs, c == NCH - 1 ? 0 : (c + 1) * 32, c == NCH - 1 ? (slot ^ 1) : slot);
+            WP_ADD(3); // norm fix-up, ticket
             lds_barrier();
+            WP_ADD(4); // barrier
         }
 
         // ---- epilogue (wave-private): accumulator layout acc[t][u][4 g + k] = channel 64 wn + 32 u + 8 g + 4 h + k of pixel (row 4 wm + t, column l32)
@@ -311,24 +368,29 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
             char* const scr = smem + kLdsScr + waveLds / 1024 * kScrBytes;
             const unsigned scrW = l32 * kScrPitch + h * 8;                    // + (32 u + 8 g) * 2
             const unsigned scrR = (lane >> 3) * kScrPitch + (lane & 7) * 16;  // + 8 j * pitch
-            const float* const biasW = biasTab + wn * 64 + 4 * h;             // + 32 u + 8 g: the 4 biases of an accumulator run
-            const bool fastEpi = !p.useBN && ac.alpha == 1.0f && ac.hi == __builtin_huge_valf();
             float sA[8], sB[8]; // rule F: sums and squares of (value - bias) of the 8 channels this lane carries to memory (channel 64 wn + 8 (lane & 7) + e)
 #pragma unroll
             for (int e = 0; e < 8; ++e) sA[e] = sB[e] = 0.0f;
             const unsigned pxl = lane >> 3;                              // + 8 j: the pixel (column) of this lane's vector j
             const unsigned chanB = (wn * 64 + (lane & 7) * 8) * 2;
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (fastEpi) {
+                if (FAST) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const f4 b4 = *reinterpret_cast<const f4*>(biasW + 32 * u + 8 * g);
                             h4 o;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(fmaxf(acc[t][u][4 * g + k] + b4[k], ac.lo));
+                            for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(acc[t][u][4 * g + k]);
+                            if (FAST == 1) { // ReLU on the rounded halfs (same bits as max-then-round)
+                                h2 lo2 = {o[0], o[1]}, hi2 = {o[2], o[3]};
+                                const h2 z2 = {static_cast<_Float16>(0.0f), static_cast<_Float16>(0.0f)};
+                                lo2 = __builtin_elementwise_max(lo2, z2);
+                                hi2 = __builtin_elementwise_max(hi2, z2);
+                                o = h4{lo2[0], lo2[1], hi2[0], hi2[1]};
+                            }
                             *reinterpret_cast<h4*>(scr + scrW + (32 * u + 8 * g) * 2) = o;
                         }
                 } else {
@@ -375,12 +437,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                             sB[e] = fmaf(f, f, sB[e]);
                         }
                     }
-                    // unconditional: a pixel outside the map stores to the dump buffer (lane-private 16 bytes of it)
-                    char* const dst = in ? reinterpret_cast<char*>(y) + (rowB + (pxl + 8 * j) * (OC * 2) + chanB) : reinterpret_cast<char*>(p.dump) + tq * 16;
-                    // (s_nop 1: a store of more than 8 bytes reads its data registers over the following cycles; the compiler's hazard recognizer puts the wait
-                    // states behind ITS stores, not behind an inline-asm one -- without them the address arithmetic of the next vector, allocated into pk[j]'s
-                    // first register, reached memory in lanes 12-15 of every row of 16: found as wrong values at odd pixels, channels 32 u + 8 g + {0, 1})
-                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(pk[j]) : "memory");
+                    // unconditional: a pixel outside the map gets an offset the buffer descriptor drops
+                    store16_buf(yRsrc, in ? rowB + (pxl + 8 * j) * (OC * 2) + chanB : kOutOfRange, pk[j]);
+
                 }
             }
             if (STATS) {
@@ -419,14 +478,28 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
             }
             foldN = -1;
         }
+        WP_ADD(5); // epilogue
+#ifdef SNNHIP_WIDEP_TRACE
+        ++wpTiles;
+#endif
         if (!hasNext) break;
         // the ring (steps 0 .. D-1 of the next tile, requested in chunk 3's last D steps) has landed long ago; formally: everything older than the
         // epilogue's stores.  After this statement no register of the loop's back-edge is the target of a load in flight.
 #pragma unroll
         for (int d = 0; d < D; ++d) vm_wait_tie<kEpiStores + (STATS ? 2 : 0)>(bq[d][0], bq[d][1]);
+        WP_ADD(6); // ring wait before the back-edge
         tile = next;
         ++it;
     }
+#ifdef SNNHIP_WIDEP_TRACE
+    if (tid == 0 && p.N == 15) { // census (a 15-image layer is the experiment's marker): which CU, from when to when
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (8 << 6) | (15 << 11)), xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
+        printf("wpblk %d xcc %u hw %x t0 %llu t1 %llu tiles %d\n", blockIdx.x, xcc & 7u, hw & 0xffffu, wpStart, (unsigned long long) __builtin_amdgcn_s_memrealtime(), wpTiles);
+    }
+    if ((blockIdx.x == 7 || blockIdx.x == 300) && (tid == 0 || tid == 192))
+        printf("wptrace blk %d tid %d tiles %d (cycles per tile): top %llu ksteps %llu copywait %llu fixup %llu barrier %llu epilogue %llu ringwait %llu\n", blockIdx.x, tid, wpTiles,
+               wpAcc[0] / wpTiles, wpAcc[1] / wpTiles, wpAcc[2] / wpTiles, wpAcc[3] / wpTiles, wpAcc[4] / wpTiles, wpAcc[5] / wpTiles, wpAcc[6] / wpTiles);
+#endif
 
     if (STATS && p.counter) { // the last tile's ticket: nothing to hide it behind
         if (pendN >= 0) {
@@ -459,14 +532,18 @@ struct WidePConvPlan : ConvPlanBase {
     int gridBlocks = 0;
     int normKind = 0;
     int ringD = 3;
+    int fastKind = 0; // 2: no batch norm, activation none; 1: ... ReLU; 0: the general epilogue
 
     WidePFn pick() const {
-#define SNNHIP_WP_D(NK, ST) (ringD == 6 ? conv2d_widep_kernel<NK, ST, 6> : conv2d_widep_kernel<NK, ST, 3>)
+#define SNNHIP_WP_F(NK, ST) (fastKind == 2 ? conv2d_widep_kernel<NK, ST, 3, 2> : fastKind == 1 ? conv2d_widep_kernel<NK, ST, 3, 1> : conv2d_widep_kernel<NK, ST, 3, 0>)
         const bool st = p.statPart != nullptr;
-        if (normKind == 0) return st ? SNNHIP_WP_D(0, true) : SNNHIP_WP_D(0, false);
-        if (normKind == 1) return st ? SNNHIP_WP_D(1, true) : SNNHIP_WP_D(1, false);
-        return st ? SNNHIP_WP_D(2, true) : SNNHIP_WP_D(2, false);
-#undef SNNHIP_WP_D
+        switch (normKind) {
+        case 0: return st ? SNNHIP_WP_F(0, true) : SNNHIP_WP_F(0, false);
+        case 1: return st ? SNNHIP_WP_F(1, true) : SNNHIP_WP_F(1, false);
+        case 3: return st ? SNNHIP_WP_F(3, true) : SNNHIP_WP_F(3, false);
+        default: return st ? SNNHIP_WP_F(2, true) : SNNHIP_WP_F(2, false);
+        }
+#undef SNNHIP_WP_F
     }
 
     // chain rule F: per-WAVE records (4 rows x 32 columns x 64 channels), i.e. a record grid of tilesX x 2 tilesY tiles of 4 x 32 pixels
@@ -518,7 +595,7 @@ struct WidePConvPlan : ConvPlanBase {
 } // namespace
 
 // fp16 3x3 stride-1 layers with IC = OC = 128, no fused residual, at least one tile per resident block slot; SNNHIP_WIDE_PERSIST=0 keeps conv2d_wide_kernel
-// (A/B runs), SNNHIP_WIDE_RING=3|6 pins the weight ring's depth
+// (A/B runs)
 int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
     if (g.IC != 128 || g.OC != 128 || !act_is_simple(g.act) || g.addAct >= 0) return SNNHIP_E_UNSUPPORTED; // (other activations / a fused residual: conv2d_wide_kernel)
@@ -527,7 +604,7 @@ int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oi
         if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
     const int srcH = g.preMode ? g.srcH : g.H, srcW = g.preMode ? g.srcW : g.W;
     const double inBytes = 2.0 * g.N * srcH * srcW * g.IC, outBytes = 2.0 * g.N * g.OH * g.OW * g.OC;
-    if (inBytes >= 4294967295.0 || outBytes >= 4294967295.0) return SNNHIP_E_UNSUPPORTED; // 32-bit byte offsets from a scalar base
+    if (inBytes >= 4026531840.0 || outBytes >= 4026531840.0) return SNNHIP_E_UNSUPPORTED; // 32-bit byte offsets below the out-of-range marker (raw buffer descriptors)
     const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
     const int tilesX = up_div(g.OW, 32), tilesY = up_div(g.OH, 8);
     const long tiles = static_cast<long>(g.N) * tilesX * tilesY;
@@ -550,10 +627,9 @@ int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oi
     plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC * 9);
     plan->epi4 = epi4;
     plan->ac = make_act_cfg(g.act, g.leaky);
-    plan->normKind = !g.normShift ? 0 : ((p.normAc.alpha == 1.0f && p.normAc.hi == __builtin_huge_valf()) ? 1 : 2);
+    plan->normKind = !g.normShift ? 0 : (g.normAct == SNNHIP_ACT_RELU ? 1 : g.normAct == SNNHIP_ACT_NONE ? 3 : 2);
+    plan->fastKind = g.useBN ? 0 : (g.act == SNNHIP_ACT_NONE ? 2 : g.act == SNNHIP_ACT_RELU ? 1 : 0);
     plan->ringD = 3;
-    if (const char* e = snnhip::option("SNNHIP_WIDE_RING"))
-        if (atoi(e) == 6) plan->ringD = 6;
     plan->ldsBytes = static_cast<size_t>(kLdsNorm) + 2 * 2 * 128 * sizeof(float);
     {   // 80 KB of dynamic LDS: every instantiation this plan may pick later (statistics / fold are switched on after creation)
         const bool keepStat = plan->p.statPart != nullptr;
@@ -588,15 +664,12 @@ int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oi
     std::memcpy(epiP.data(), epi4.data(), sizeof(float) * 4 * 128);
     int rc = plan->upload(wpk.data(), wpk.size(), &plan->d_w);
     if (rc == SNNHIP_OK) rc = plan->upload(epiP.data(), epiP.size(), &plan->d_epi);
-    void* dump = nullptr;
-    if (rc == SNNHIP_OK && snnhip::dev_malloc(&dump, 256 * 16, "conv2d_widep dump buffer") != hipSuccess) rc = SNNHIP_E_NOMEM;
     if (rc != SNNHIP_OK) {
         delete plan;
         return rc;
     }
-    plan->deviceAllocs.push_back(dump);
-    p.zeros = reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(plan->d_w) + steps * kStepBytes);
-    p.dump = static_cast<_Float16*>(dump);
+    p.xBytes = static_cast<unsigned>(inBytes);
+    p.yBytes = static_cast<unsigned>(outBytes);
     plan->p = p;
     plan->inDims[0] = g.N; plan->inDims[1] = srcH; plan->inDims[2] = srcW; plan->inDims[3] = g.IC;
     plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
@@ -606,6 +679,10 @@ int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oi
     char buf[320];
     snprintf(buf, sizeof(buf), "conv2d_mfma_wide_f16_32x32x16 persistent k=3x3 s=1 ic=128 oc=128 tile=8x32px x 128oc (4x2 MFMA tiles per wave) chunk=32 ring=%d blocks=%d lds=%zuB",
              plan->ringD, plan->gridBlocks, plan->ldsBytes);
+    if (const char* e = snnhip::option("SNNHIP_WIDEP_GRID")) { // experiments: resident blocks
+        const int v = atoi(e);
+        if (v > 0) plan->gridBlocks = static_cast<int>(std::min<long>(tiles, v));
+    }
     plan->desc = buf;
     if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
     if (g.preMode && g.preShift) plan->desc += " +upsample(x2)";

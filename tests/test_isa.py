@@ -32,5 +32,7 @@ def test_lds_dma_is_the_only_m0_user(tmp_path):
         assert m0, "%s: lds_dma16 used but no m0 write in the ISA?" % src
         for i, l in m0:
             assert re.fullmatch(r"s_mov_b32 m0, s\d+", l.split(";")[0].strip()), "%s: m0 used outside lds_dma16: %r" % (os.path.basename(src), l)
-            assert code[i + 1].startswith("global_load_lds_dwordx4"), "%s: %r is not followed by its DMA but by %r" % (os.path.basename(src), l, code[i + 1])
-        assert sum(1 for l in code if l.startswith("global_load_lds")) == len(m0)
+            nxt = code[i + 1]
+            assert nxt.startswith("global_load_lds_dwordx4") or (nxt.startswith("buffer_load_dwordx4") and nxt.split(";")[0].rstrip().endswith(" lds")), \
+                "%s: %r is not followed by its DMA but by %r" % (os.path.basename(src), l, nxt)
+        assert sum(1 for l in code if l.startswith("global_load_lds") or (l.startswith("buffer_load_dword") and l.split(";")[0].rstrip().endswith(" lds"))) == len(m0)

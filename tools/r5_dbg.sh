@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/${1:-r5_dbg}; mkdir -p "$O"
-timeout 200 python tools/debug_widep.py > "$O/dbg.txt" 2>&1; tail -60 "$O/dbg.txt" | cut -c1-230
-for t in strict syncepi; do echo "#### $t"; SNNHIP_LIB_PATH=$GRAFT_REPO_ROOT/build/abl/libsnnhip_$t.so timeout 200 python tools/debug_widep.py 2>&1 | grep "==" | cut -c1-200; done
+timeout 200 python tools/debug_widep.py > "$O/dbg.txt" 2>&1; grep "==" "$O/dbg.txt" | cut -c1-200
+DBG_N=3 DBG_H=90 DBG_W=200 timeout 200 python tools/debug_widep.py > "$O/dbg2.txt" 2>&1; grep "==" -A6 "$O/dbg2.txt" | cut -c1-200 | head -40

@@ -115,8 +115,8 @@ __device__ __forceinline__ void lds_barrier() { // LDS traffic of this wave done
 }
 
 // NORM: 0 = no InstanceNorm in front, 1 = its activation is ReLU (max on the packed halfs), 2 = any branch-free activation (med3 form), 3 = none
-// FAST: the layer has no batch norm and its activation is none (FAST = 2) or ReLU (FAST = 1): the bias is the C operand of a tile's first MFMAs and the
-//       epilogue is a conversion [+ a packed max]; 0 = the general bias [-> BN] -> med3 epilogue
+// FAST: the layer has no batch norm and its activation is none (FAST = 2) or ReLU (FAST = 1): the epilogue is bias + conversion [+ a max on the packed
+//       halfs]; 0 = the general bias [-> BN] -> med3 epilogue
 // STATS: chain rule F records (+ the in-kernel fold when p.fold.counter)
 // D: K steps of weight operands in flight per lane (divides 18)
 template <int NORM, bool STATS, int D, int FAST>
@@ -278,16 +278,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
         const unsigned ntile = hasNext ? next : tile; // (the last tile prefetches itself: the number of copies in the queue must not depend on the tile)
         const int slot = it & 1;
         float nv = 0.0f;
-        // FAST: acc = bias + sum (the bias rides the first MFMA's C operand: 128 additions per tile less); else acc = sum, bias in the epilogue
-        f32x16 cinit[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f4 b4 = FAST ? *reinterpret_cast<const f4*>(biasTab + (tq >> 7) * 64 + 4 * ((tq >> 5) & 1u) + 32 * u + 8 * g) : f4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) cinit[u][4 * g + k] = b4[k];
-            }
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -330,8 +326,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                 const int dl = (((tap / 3) * kTileW + (tap % 3)) * kQP + ((s + 1) % 2) * 2) * 16; // compile-time: an immediate offset of the ds_read
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b0), *reinterpret_cast<const h8*>(&a[t]), (c == 0 && s == 0) ? cinit[0] : acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b1), *reinterpret_cast<const h8*>(&a[t]), (c == 0 && s == 0) ? cinit[1] : acc[t][1], 0, 0, 0);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b0), *reinterpret_cast<const h8*>(&a[t]), acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b1), *reinterpret_cast<const h8*>(&a[t]), acc[t][1], 0, 0, 0);
                     if (s + 1 < S) a[t] = *reinterpret_cast<const f4*>(smem + curOfs + aoff0 + t * (kTileW * kQP * 16) + dl);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -381,9 +377,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
+                            // (sum first, bias second: the order of conv2d_wide_kernel, whose fused-Add form must give the bits of this layer + an Add launch)
+                            const f4 b4 = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 4 * h + 32 * u + 8 * g);
                             h4 o;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(acc[t][u][4 * g + k]);
+                            for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(acc[t][u][4 * g + k] + b4[k]);
                             if (FAST == 1) { // ReLU on the rounded halfs (same bits as max-then-round)
                                 h2 lo2 = {o[0], o[1]}, hi2 = {o[2], o[3]};
                                 const h2 z2 = {static_cast<_Float16>(0.0f), static_cast<_Float16>(0.0f)};

@@ -101,14 +101,21 @@ __device__ __forceinline__ i4 make_rsrc(const void* base, unsigned bytes) {
     return r;
 }
 constexpr unsigned kOutOfRange = 0xfffffff0u;
+__device__ __forceinline__ unsigned in_sgpr(unsigned v) { // a scalar-register operand for inline assembly, also when the value is a compile-time constant
+    v = __builtin_amdgcn_readfirstlane(v);                // (wave-uniform values the compiler sees as per-lane: a wave's row of the tile)
+    asm volatile("s_nop 4" : "+s"(v));                    // (the MUBUF soffset field takes a register or an inline constant, not a literal; the wait states: a
+                                                          // vector instruction's scalar result may not feed a vector-memory instruction for five cycles, and
+                                                          // the hazard recognizer does not look inside inline assembly)
+    return v;
+}
 __device__ __forceinline__ void lds_dma16_buf(const i4& rsrc, unsigned laneByteOffset, unsigned uniformByteOffset, unsigned ldsWaveByteAddr) {
-    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(laneByteOffset), "s"(rsrc), "s"(ldsWaveByteAddr), "s"(uniformByteOffset) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(laneByteOffset), "s"(rsrc), "s"(in_sgpr(ldsWaveByteAddr)), "s"(in_sgpr(uniformByteOffset)) : "memory");
 }
 // (s_nop 1: a store of more than 8 bytes reads its data registers over the following cycles; the compiler's hazard recognizer puts the wait states
 // behind ITS stores, not behind an inline-asm one -- without them the address arithmetic of the next vector, allocated into the data's first register,
 // reached memory in lanes 12-15 of every row of 16: found as wrong values at odd pixels, channels 32 u + 8 g + {0, 1})
-__device__ __forceinline__ void store16_buf(const i4& rsrc, unsigned laneByteOffset, const f4& v) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(laneByteOffset), "s"(rsrc) : "memory");
+__device__ __forceinline__ void store16_buf(const i4& rsrc, unsigned laneByteOffset, unsigned uniformByteOffset, const f4& v) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(laneByteOffset), "s"(rsrc), "s"(in_sgpr(uniformByteOffset)) : "memory");
 }
 __device__ __forceinline__ void lds_barrier() { // LDS traffic of this wave done, then the block barrier; vector memory stays in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
         }
     };
     // staging map of the tile whose tables are published: byte offset of element r's 16 bytes in x (chunk 0), ~0u = zeros (padding, pad slot, past the tile)
-    unsigned gofs[kR];
+    unsigned gofs[kR], gofsN[kR]; // this tile's map / the next tile's (built during chunk 2, used by chunk 3's copies; moved over at the tile's end)
     auto build_map = [&]() {
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
@@ -182,6 +189,47 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
             const bool ok = e < static_cast<unsigned>(kTotal) && rowPix >= 0 && sx >= 0 && ql < 4u;
             gofs[r] = ok ? static_cast<unsigned>(rowPix + sx) * (IC * 2) + ql * 16 : kOutOfRange;
         }
+    };
+    auto map_elem = [&](int r) -> unsigned {
+        const unsigned e = tq + 256u * r;
+        const unsigned pix = e / kQP, ql = e - pix * kQP, rr = pix / kTileW, c = pix - rr * kTileW;
+        const int rowPix = syTab[rr], sx = sxTab[c];
+        const bool ok = e < static_cast<unsigned>(kTotal) && rowPix >= 0 && sx >= 0 && ql < 4u;
+        return ok ? static_cast<unsigned>(rowPix + sx) * (IC * 2) + ql * 16 : kOutOfRange;
+    };
+    // one slot of the fix-up in two halves (a K step apart: the LDS round trip hides under that step's MFMAs): read the slot and its table rows ...
+    f4 fxv, fxs0, fxs1, fxm0, fxm1;
+    auto fix_read = [&](int bufOfs, int ic0, int slot, int r, unsigned g) {
+        const float* const tb = normTab + slot * 2 * IC + ic0 + 8 * ((g >> 4) & 3u);
+        fxv = *reinterpret_cast<const f4*>(smem + bufOfs + (tq + 256u * r) * 16);
+        fxs0 = *reinterpret_cast<const f4*>(tb);
+        fxs1 = *reinterpret_cast<const f4*>(tb + 4);
+        fxm0 = *reinterpret_cast<const f4*>(tb + IC);
+        fxm1 = *reinterpret_cast<const f4*>(tb + IC + 4);
+    };
+    // ... normalise (two halves, one per pair of MFMAs: the ~12 vector instructions of a half fit the issue slots two MFMAs leave), activate, write back
+    // (padding stays zero)
+    typedef _Float16 h2x __attribute__((ext_vector_type(2)));
+    h2x fxo[4];
+    auto fix_half = [&](int half) {
+        const h8 hv = *reinterpret_cast<const h8*>(&fxv);
+#pragma unroll
+        for (int k = 4 * half; k < 4 * half + 4; ++k) {
+            const float f = fmaf(static_cast<float>(hv[k]), half == 0 ? fxm0[k & 3] : fxm1[k & 3], half == 0 ? fxs0[k & 3] : fxs1[k & 3]);
+            const _Float16 o = NORM == 2 ? static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi)) : static_cast<_Float16>(f);
+            fxo[k >> 1][k & 1] = o;
+        }
+        if (NORM == 1) { // ReLU on the rounded halfs, two per instruction (rounding is monotonic and keeps zero: the same bits as max-then-round)
+#pragma unroll
+            for (int k2 = 2 * half; k2 < 2 * half + 2; ++k2) fxo[k2] = __builtin_elementwise_max(fxo[k2], h2x{static_cast<_Float16>(0.0f), static_cast<_Float16>(0.0f)});
+        }
+    };
+    auto fix_write = [&](int bufOfs, int r, unsigned g) {
+        const bool pad = g == kOutOfRange;
+        f4 res;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) res[k] = pad ? 0.0f : __builtin_bit_cast(float, fxo[k]);
+        *reinterpret_cast<f4*>(smem + bufOfs + (tq + 256u * r) * 16) = res;
     };
     auto stage_dma = [&](int bufOfs, int ic0) {
 #pragma unroll
@@ -247,6 +295,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     }
     lds_barrier();
     build_map();
+#pragma unroll
+    for (int r = 0; r < kR; ++r) gofsN[r] = gofs[r];
     stage_dma(kLdsBuf0, 0);
     f4 bq[D][2];
 #pragma unroll
@@ -288,47 +338,60 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int curOfs = (c & 1) ? kLdsBuf1 : kLdsBuf0, nxtOfs = (c & 1) ? kLdsBuf0 : kLdsBuf1;
-            // ---- top of the chunk: the next chunk's copies (chunk 3: the NEXT TILE's first chunk, with its own map)
-            if (c == NCH - 1) build_map();                       // (tables of ntile: published by chunk 1's barrier)
-            stage_dma(nxtOfs, c == NCH - 1 ? 0 : (c + 1) * 32);
-            if (c == 1) {
-                resolve_tables(ntile);                            // (read again in chunk 3; the previous tile's were last read in ITS chunk 3)
-                load_norm_tab(ntile / p.tilesPerImage, slot ^ 1, nv); // one more vector-memory load in the queue when NORM (counted below)
-                if (STATS && pendN >= 0 && tid == 0) {            // the previous tile's records were acknowledged before chunk 0's barrier: count it
-                    unsigned* cnt = p.counter + pendN;
-                    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(ticket) : "v"(cnt), "v"(1u) : "memory");
-                }
-                foldN = pendN;
-            }
-            WP_ADD(0); // chunk top: map, copies issued, tables
+            const int nIc0 = c == NCH - 1 ? 0 : (c + 1) * 32, nSlot = c == NCH - 1 ? (slot ^ 1) : slot; // the chunk being staged: the next one (chunk 3: the next tile's first)
 #pragma unroll
             for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const f4*>(smem + curOfs + aoff0 + t * (kTileW * kQP * 16));
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                // KSTEP.  The operand of this step was requested D steps ago; younger than it in the queue: the L = 2 (D - 1) weight loads of the
-                // steps between, and -- when a chunk top lies between (s < D) -- that top's 7 copies (+ 1 table load in chunk 1 when NORM; thread
-                // 0's atomic there is left out: a count that is too SMALL only waits for one load more).  Chunk 0, s < D: waited for before the
-                // tile loop's back-edge (first tile: by the prologue).
+                // KSTEP.  Everything that is not a multiplication rides INSIDE the steps, under the wave's own MFMAs (beside the partner wave's MFMA stream a
+                // vector instruction of a non-multiplying phase got an issue slot every ~17 cycles: phase trace): the staged chunk's copy r at
+                // step r, the fix-up of its slot r at steps 8 + r / 9 + r, the next tile's tables at chunk 1 step 0 and its map element r at chunk 2 step r.
+                // Vector-memory queue at step s: [operand wait] [2 weight loads for step s + D] [copy s, s < 7] [chunk 1, step 0: table load, ticket].
+                // The operand of step s was requested at step s - D; younger than it: L = 2 (D - 1) weight loads, the copies of steps s - D .. s - 1 that
+                // exist (0 .. 6), the table load when it lies between (thread 0's atomic is left out: a count that is too SMALL only waits for one load
+                // more).  Chunk 0, s < D: waited for before the tile loop's back-edge (first tile: by the prologue).
                 f4 b0 = bq[s % D][0], b1 = bq[s % D][1];
-#ifdef SNNHIP_WIDEP_STRICT // experiment build: every operand wait as if nothing but weight loads were in the queue (drains the copies early; correctness probe)
-                if (c >= 1 || s >= D) vm_wait_tie<L>(b0, b1);
-#else
-                if (s >= D) vm_wait_tie<L>(b0, b1);
-                else if (c == 1 && NORM != 0) vm_wait_tie<L + kR + 1>(b0, b1);
-                else if (c >= 1) vm_wait_tie<L + kR>(b0, b1);
-#endif
+                if (c >= 1 || s >= D) {
+                    const int lo = s - D > 0 ? s - D : 0, hi = s - 1 < kR - 1 ? s - 1 : kR - 1;
+                    const int n = L + (hi >= lo ? hi - lo + 1 : 0) + ((c == 1 && NORM != 0 && s >= 1 && s <= D) ? 1 : 0);
+                    if (n == L) vm_wait_tie<L>(b0, b1);
+                    else if (n == L + 1) vm_wait_tie<L + 1>(b0, b1);
+                    else if (n == L + 2) vm_wait_tie<L + 2>(b0, b1);
+                    else if (n == L + 3) vm_wait_tie<L + 3>(b0, b1);
+                    else vm_wait_tie<L + 4>(b0, b1);
+                    static_assert(D == 3, "the chain above covers D = 3 (at most 3 copies + 1 table load between)");
+                }
                 {
                     const int g2 = (c * S + s + D) % (NCH * S); // the ring wraps into the next tile's first steps: same weights
                     gload16x2(wp, wlane + g2 * kStepBytes, bq[s % D][0], bq[s % D][1]);
                 }
+                if (s < kR) lds_dma16_buf(xRsrc, c == NCH - 1 ? gofsN[s] : gofs[s], static_cast<unsigned>(nIc0 * 2), static_cast<unsigned>(nxtOfs + 4096 * s) + waveLds);
+                if (c == 1 && s == 0) {
+                    resolve_tables(ntile);                            // (read by chunk 2's map elements; the previous tile's were last read in ITS chunk 2)
+                    load_norm_tab(ntile / p.tilesPerImage, slot ^ 1, nv);
+                    if (STATS && pendN >= 0 && tid == 0) {            // the previous tile's records were acknowledged before chunk 0's barrier: count it
+                        unsigned* cnt = p.counter + pendN;
+                        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(ticket) : "v"(cnt), "v"(1u) : "memory");
+                    }
+                    foldN = pendN;
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const int tap = (s + 1) / 2;
                 const int dl = (((tap / 3) * kTileW + (tap % 3)) * kQP + ((s + 1) % 2) * 2) * 16; // compile-time: an immediate offset of the ds_read
+                const int fr = s - 8;                                  // fix-up slot read in this step (its copy was issued 8 steps ago and is older than every
+                                                                       // weight load the operand wait above left in flight: it has landed)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b0), *reinterpret_cast<const h8*>(&a[t]), acc[t][0], 0, 0, 0);
                     acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b1), *reinterpret_cast<const h8*>(&a[t]), acc[t][1], 0, 0, 0);
                     if (s + 1 < S) a[t] = *reinterpret_cast<const f4*>(smem + curOfs + aoff0 + t * (kTileW * kQP * 16) + dl);
+                    if (NORM != 0 && t == 0 && fr >= 0 && fr < kR) fix_read(nxtOfs, nIc0, nSlot, fr, c == NCH - 1 ? gofsN[fr] : gofs[fr]);
+                    if (NORM != 0 && t == 2 && fr >= 0 && fr < kR) fix_half(0);
+                    if (NORM != 0 && t == 3 && fr >= 0 && fr < kR) {
+                        fix_half(1);
+                        fix_write(nxtOfs, fr, c == NCH - 1 ? gofsN[fr] : gofs[fr]);
+                    }
+                    if (c == 2 && t == 1 && s < kR) gofsN[s] = map_elem(s); // (tables of ntile: published by chunk 1's barrier)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -351,11 +414,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                     *reinterpret_cast<volatile int*>(smem + kLdsScr + 4 * kScrBytes - 16) = last; // (the scratch's last 16 bytes: pad columns of wave 3's last pixel row, never read as data)
                 }
             }
-            norm_fixup(nxtOfs, c == NCH - 1 ? 0 : (c + 1) * 32, c == NCH - 1 ? (slot ^ 1) : slot);
-            WP_ADD(3); // norm fix-up, ticket
+            WP_ADD(3); // table / ticket bookkeeping
             lds_barrier();
             WP_ADD(4); // barrier
         }
+#pragma unroll
+        for (int r = 0; r < kR; ++r) gofs[r] = gofsN[r];
 
         // ---- epilogue (wave-private): accumulator layout acc[t][u][4 g + k] = channel 64 wn + 32 u + 8 g + 4 h + k of pixel (row 4 wm + t, column l32)
         {
@@ -368,8 +432,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #pragma unroll
             for (int e = 0; e < 8; ++e) sA[e] = sB[e] = 0.0f;
             const unsigned pxl = lane >> 3;                              // + 8 j: the pixel (column) of this lane's vector j
-            const unsigned chanB = (wn * 64 + (lane & 7) * 8) * 2;
+            const unsigned laneOut = pxl * (OC * 2) + (wn * 64 + (lane & 7) * 8) * 2; // byte offset of the lane's vector inside a tile row's first 8 pixels
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            f4 bias4[2][4];
+            if (FAST) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bias4[u][g] = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 4 * h + 32 * u + 8 * g);
+            }
+            f4 piv0, piv1;
+            if (STATS) {
+                piv0 = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 8 * (lane & 7));
+                piv1 = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 8 * (lane & 7) + 4);
+            }
+            // a tile inside the map (all but the last tile row / column): no per-lane tests, the stores' addresses are one constant lane offset + a scalar
+            const bool full = oy0 + 4 <= static_cast<unsigned>(p.OH) && ox0 + 32 <= static_cast<unsigned>(p.OW);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (FAST) {
@@ -378,10 +456,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             // (sum first, bias second: the order of conv2d_wide_kernel, whose fused-Add form must give the bits of this layer + an Add launch)
-                            const f4 b4 = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 4 * h + 32 * u + 8 * g);
                             h4 o;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(acc[t][u][4 * g + k] + b4[k]);
+                            for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(acc[t][u][4 * g + k] + bias4[u][g][k]);
                             if (FAST == 1) { // ReLU on the rounded halfs (same bits as max-then-round)
                                 h2 lo2 = {o[0], o[1]}, hi2 = {o[2], o[3]};
                                 const h2 z2 = {static_cast<_Float16>(0.0f), static_cast<_Float16>(0.0f)};
@@ -408,36 +485,35 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                         }
                 }
                 // (one wave's LDS instructions execute in order: the reads below see the writes above, and the next row's writes follow these reads)
-#ifdef SNNHIP_WIDEP_SYNCEPI
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
                 f4 pk[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pk[j] = *reinterpret_cast<const f4*>(scr + scrR + j * 8 * kScrPitch);
                 const unsigned oy = oy0 + t;
-                const bool rowIn = oy < static_cast<unsigned>(p.OH);
-                const unsigned rowB = ((n * p.OH + oy) * p.OW + ox0) * (OC * 2);
-                f4 piv0, piv1;
-                if (STATS) {
-                    piv0 = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 8 * (lane & 7));
-                    piv1 = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 8 * (lane & 7) + 4);
-                }
+                const unsigned rowB = ((n * p.OH + oy) * p.OW + ox0) * (OC * 2); // (uniform)
+                auto stat_add = [&](const f4& v) {
+                    const _Float16* ch = reinterpret_cast<const _Float16*>(&v);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned ox = ox0 + pxl + 8 * j;
-                    const bool in = rowIn && ox < static_cast<unsigned>(p.OW);
-                    if (STATS && in) {
-                        const _Float16* ch = reinterpret_cast<const _Float16*>(&pk[j]);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float f = static_cast<float>(ch[e]) - (e < 4 ? piv0[e & 3] : piv1[e & 3]);
-                            sA[e] += f;
-                            sB[e] = fmaf(f, f, sB[e]);
-                        }
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = static_cast<float>(ch[e]) - (e < 4 ? piv0[e & 3] : piv1[e & 3]);
+                        sA[e] += f;
+                        sB[e] = fmaf(f, f, sB[e]);
                     }
-                    // unconditional: a pixel outside the map gets an offset the buffer descriptor drops
-                    store16_buf(yRsrc, in ? rowB + (pxl + 8 * j) * (OC * 2) + chanB : kOutOfRange, pk[j]);
-
+                };
+                if (full) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (STATS) stat_add(pk[j]);
+                        store16_buf(yRsrc, laneOut, rowB + j * 8 * (OC * 2), pk[j]);
+                    }
+                } else {
+                    const bool rowIn = oy < static_cast<unsigned>(p.OH);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool in = rowIn && ox0 + pxl + 8 * j < static_cast<unsigned>(p.OW);
+                        if (STATS && in) stat_add(pk[j]);
+                        // unconditional: a pixel outside the map gets an offset the buffer descriptor drops
+                        store16_buf(yRsrc, in ? laneOut : kOutOfRange, rowIn ? rowB + j * 8 * (OC * 2) : 0u, pk[j]);
+                    }
                 }
             }
             if (STATS) {

@@ -61,15 +61,19 @@ constexpr int kLdsBuf0 = 0, kLdsBuf1 = kBufBytes, kLdsScr = 2 * kBufBytes, kLdsE
               kLdsSy = kLdsBias + 512 /* int[32] */, kLdsSx = kLdsSy + 128 /* int[40] */, kLdsNorm = kLdsSx + 160 /* [2 slots][2][IC] floats */;
 constexpr int kStepBytes = 2 * 128 * 16;          // packed weights per K step: [h][oc] x 16 bytes
 constexpr int kEpiStores = 16;                    // output stores per thread and tile (4 rows x 4 vectors)
+constexpr int kRecFloats = 4 + 2 * 256;           // a statistics record: {pixels of wave row 0, of wave row 1, -, -}, then per wave row [S1[128] | S2[128]]
 
 struct WidePParams {
     int N, H, W, OH, OW, padx, pady, padMode, useBN;
     unsigned tilesX, tilesY, tilesPerImage, numTiles;
     int preMode, preX, preY, srcH, srcW, preShift;
     unsigned xBytes, yBytes; // sizes of the input / output tensors (the raw buffer descriptors' bounds)
-    float* statPart;        // chain rule F: [n][2 tilesY][tilesX][2][128] per-wave {mean, M2} records; null = off
-    unsigned* counter;      // ... [N] tiles of the image counted so far; the block that draws an image's last ticket folds it; null = no in-kernel fold
+    // chain rule F: one record per (image, block that worked on it): [n][recsMax][kRecFloats] sums around the channels' biases; null = off.  A block's
+    // tiles are a contiguous run, so it leaves one record per image it touched (rarely more than one) when its run leaves the image
+    float* statRec;
+    unsigned* counter;        // [N] records of the image written so far; the block that writes an image's last record folds it (norm_fold.h's hand-off)
     const NormFoldArgs* fold; // (device copy: read by the folding block only -- eleven scalar registers the tile loop does not have to carry)
+    unsigned tilesBase, tilesRem, recsMax; // block b works on tiles [b base + min(b, rem), + base + (b < rem))
     const float* normShift; // graph rule I
     const float* normMul;
     ActCfg normAc;
@@ -119,6 +123,55 @@ __device__ __forceinline__ void store16_buf(const i4& rsrc, unsigned laneByteOff
 }
 __device__ __forceinline__ void lds_barrier() { // LDS traffic of this wave done, then the block barrier; vector memory stays in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The fold of an image's records (all 256 threads of the block that wrote the last one; scratch: 3 x 256 floats of LDS nobody uses).  Every record holds
+// sums around the SAME pivots (the channels' biases), so adding them up in record order is the whole merge: deterministic whichever block folds.
+// thread = (channel, 1 of 2 parts), four records (24 loads) in flight per thread; ~33 records per 720p image.
+__device__ __forceinline__ void widep_stats_fold(const NormFoldArgs& f, const float* recs, int nRecs, const float* biasTab, float* scratch, int n) {
+    const int tid = threadIdx.x, ch = tid & 127, part = tid >> 7;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // one acquire per image, in the folding block only (norm_fold.h)
+    float an = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int b0 = part; b0 < nRecs; b0 += 8) {
+        float tn[4][2], t1[4][2], t2[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = b0 + 2 * j;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) tn[j][w] = t1[j][w] = t2[j][w] = 0.0f;
+            if (b < nRecs) {
+                const float* rb = recs + static_cast<size_t>(b) * kRecFloats;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    tn[j][w] = ld_agent(rb + w);
+                    t1[j][w] = ld_agent(rb + 4 + w * 256 + ch);
+                    t2[j][w] = ld_agent(rb + 4 + w * 256 + 128 + ch);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                an += tn[j][w];
+                a1 += t1[j][w];
+                a2 += t2[j][w];
+            }
+    }
+    scratch[tid] = an;
+    scratch[256 + tid] = a1;
+    scratch[512 + tid] = a2;
+    __syncthreads();
+    if (tid < 128) {
+        an = scratch[tid] + scratch[128 + tid];
+        a1 = scratch[256 + tid] + scratch[256 + 128 + tid];
+        a2 = scratch[512 + tid] + scratch[512 + 128 + tid];
+        const float dm = a1 / an, mean = biasTab[tid] + dm;
+        const float var = fmaxf(a2 / an - dm * dm, 0.0f);
+        const float mu = f.gamma[tid] / sqrtf(var + f.eps);
+        f.mul[n * 128 + tid] = mu;
+        f.shift[n * 128 + tid] = f.beta[tid] - mean * mu; // y = x * mul + shift (instancenorm_fold_kernel's form)
+    }
 }
 
 // NORM: 0 = no InstanceNorm in front, 1 = its activation is ReLU (max on the packed halfs), 2 = any branch-free activation (med3 form), 3 = none
@@ -282,7 +335,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     };
 
     // ---- first tile: tables, map, chunk 0, weight ring
-    unsigned tile = blockIdx.x;
+    const unsigned runLen = p.tilesBase + (blockIdx.x < p.tilesRem ? 1u : 0u);
+    unsigned tile = blockIdx.x * p.tilesBase + (blockIdx.x < p.tilesRem ? blockIdx.x : p.tilesRem);
+    const unsigned tileEnd = tile + runLen;
     waveLds = __builtin_amdgcn_readfirstlane(waveLds);
     resolve_tables(tile);
     {
@@ -310,9 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     f32x16 acc[4][2];
     f4 a[4];
     int it = 0;            // tiles done by this block (parity = the norm table slot of the current tile)
-    int pendN = -1;        // STATS + fold: image of the tile whose records are written but not yet counted
-    int foldN = -1;        // ... image whose last ticket this block may have drawn (the flag published by chunk 1's barrier says)
-    unsigned ticket = 0;   // (thread 0) the counter value the pending tile's atomic returned
+    float stS1 = 0.0f, stS2 = 0.0f, stCnt = 0.0f; // rule F: this wave's sums for channel 64 wn + lane over the block's tiles of the current image, and their pixel count
 
 #ifdef SNNHIP_WIDEP_TRACE
     unsigned long long wpAcc[8] = {};
@@ -323,8 +376,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     for (;;) {
         asm volatile("" : "+v"(wlane), "+v"(tq), "+s"(waveLds)); // (see above: nothing derived from these is a loop invariant)
         const unsigned n = tile / p.tilesPerImage, rem = tile - n * p.tilesPerImage, ty = rem / p.tilesX, tx = rem - ty * p.tilesX;
-        const unsigned next = tile + G;
-        const bool hasNext = next < p.numTiles;
+        const unsigned next = tile + 1;
+        const bool hasNext = next < tileEnd;
         const unsigned ntile = hasNext ? next : tile; // (the last tile prefetches itself: the number of copies in the queue must not depend on the tile)
         const int slot = it & 1;
         float nv = 0.0f;
@@ -369,11 +422,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                 if (c == 1 && s == 0) {
                     resolve_tables(ntile);                            // (read by chunk 2's map elements; the previous tile's were last read in ITS chunk 2)
                     load_norm_tab(ntile / p.tilesPerImage, slot ^ 1, nv);
-                    if (STATS && pendN >= 0 && tid == 0) {            // the previous tile's records were acknowledged before chunk 0's barrier: count it
-                        unsigned* cnt = p.counter + pendN;
-                        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(ticket) : "v"(cnt), "v"(1u) : "memory");
-                    }
-                    foldN = pendN;
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int tap = (s + 1) / 2;
@@ -403,15 +451,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                 if (NORM != 0) {
                     asm volatile("" : "+v"(nv));
                     normTab[(slot ^ 1) * 2 * IC + tq] = nv;
-                }
-                if (STATS && tid == 0) {
-                    int last = 0;
-                    if (pendN >= 0) {
-                        asm volatile("" : "+v"(ticket));
-                        last = ticket + 1u == static_cast<unsigned>(p.tilesPerImage);
-                        if (last) __hip_atomic_store(p.counter + pendN, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch (a replayed hipGraph)
-                    }
-                    *reinterpret_cast<volatile int*>(smem + kLdsScr + 4 * kScrBytes - 16) = last; // (the scratch's last 16 bytes: pad columns of wave 3's last pixel row, never read as data)
                 }
             }
             WP_ADD(3); // table / ticket bookkeeping
@@ -533,34 +572,52 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                     s2 += red[g8 * 128 + 64 + lane];
                 }
                 const int rows = max(0, min(4, p.OH - static_cast<int>(oy0))), cols = max(0, min(32, p.OW - static_cast<int>(ox0)));
-                const float cnt = static_cast<float>(rows * cols), inv = cnt > 0.0f ? 1.0f / cnt : 0.0f;
-                const float m1 = s1 * inv;
-                const float mean = biasTab[wn * 64 + lane] + m1, M2 = fmaxf(s2 - s1 * m1, 0.0f);
-                float* const po = p.statPart + (static_cast<size_t>((n * 2 * p.tilesY + 2 * ty + wm) * p.tilesX + tx) * 2 * OC + wn * 64 + lane);
-                asm volatile("global_store_dword %0, %1, off sc1\n\tglobal_store_dword %0, %2, off offset:512 sc1" ::"v"(po), "v"(mean), "v"(M2) : "memory");
-                pendN = p.counter ? static_cast<int>(n) : -1;
+                stS1 += s1;
+                stS2 += s2;
+                stCnt += static_cast<float>(rows * cols);
             }
-        }
-        if (STATS && foldN >= 0) {
-            // the ticket of the tile BEFORE this one came back under chunk 1's wait and its verdict was published by chunk 1's barrier; the fold runs
-            // here, where no accumulator is live (its 16 records in flight per thread are 80 registers).  Other waves may still be inside their
-            // epilogues, whose scratch the fold re-uses: one barrier first (this path runs N times per launch, not once per tile)
-            if (*reinterpret_cast<volatile int*>(smem + kLdsScr + 4 * kScrBytes - 16) != 0) {
-                lds_barrier();
-                tile_stats_fold<128>(*p.fold, p.statPart, reinterpret_cast<float*>(smem + kLdsScr), foldN, p.tilesX, 2 * p.tilesY, 4, 32, p.OH, p.OW, OC, 0);
-                lds_barrier();
-            }
-            foldN = -1;
         }
         WP_ADD(5); // epilogue
 #ifdef SNNHIP_WIDEP_TRACE
         ++wpTiles;
 #endif
+        if (STATS) {
+            // the run leaves the image (or ends): the block's record for image n, then the hand-off of norm_fold.h -- records written through (sc1), acknowledged,
+            // the image's counter bumped; whoever writes an image's last record adds them all up.  Once or twice per block and launch (a per-TILE record was
+            // two written-through stores in front of every tile's weight loads -- vector memory retires in order -- and an atomic round trip per tile)
+            const unsigned nNext = hasNext ? next / p.tilesPerImage : ~0u;
+            if (nNext != n) {
+                const unsigned lane = tq & 63u, wm = (tq >> 6) & 1u, wn = tq >> 7;
+                const unsigned bT = p.tilesBase + 1, cut = p.tilesRem * bT, t0 = n * p.tilesPerImage, t1 = t0 + p.tilesPerImage - 1; // first / last tile of the image
+                const unsigned bFirst = t0 < cut ? t0 / bT : p.tilesRem + (t0 - cut) / p.tilesBase, bLast = t1 < cut ? t1 / bT : p.tilesRem + (t1 - cut) / p.tilesBase;
+                float* const rec = p.statRec + (static_cast<size_t>(n) * p.recsMax + (blockIdx.x - bFirst)) * kRecFloats;
+                float* const po = rec + 4 + wm * 256 + wn * 64 + lane;
+                asm volatile("global_store_dword %0, %1, off sc1\n\tglobal_store_dword %0, %2, off offset:512 sc1" ::"v"(po), "v"(stS1), "v"(stS2) : "memory");
+                if (wn == 0 && lane == 0) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(rec + wm), "v"(stCnt) : "memory");
+                stS1 = stS2 = stCnt = 0.0f;
+                vm_wait<0>();
+                lds_barrier();
+                int* const flag = reinterpret_cast<int*>(smem + kLdsScr + 4 * kScrBytes - 16); // (the scratch's last 16 bytes: pad columns, never data)
+                if (tid == 0) {
+                    unsigned* cnt = p.counter + n;
+                    const unsigned prev = atomicAdd(cnt, 1u);
+                    const bool last = prev == bLast - bFirst;
+                    if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch (a replayed hipGraph)
+                    *flag = last;
+                }
+                __syncthreads();
+                const bool last = *flag != 0;
+                __syncthreads();
+                if (last) widep_stats_fold(*p.fold, p.statRec + static_cast<size_t>(n) * p.recsMax * kRecFloats, static_cast<int>(bLast - bFirst + 1), biasTab,
+                                           reinterpret_cast<float*>(smem + kLdsScr), static_cast<int>(n));
+                lds_barrier();
+            }
+        }
         if (!hasNext) break;
         // the ring (steps 0 .. D-1 of the next tile, requested in chunk 3's last D steps) has landed long ago; formally: everything older than the
         // epilogue's stores.  After this statement no register of the loop's back-edge is the target of a load in flight.
 #pragma unroll
-        for (int d = 0; d < D; ++d) vm_wait_tie<kEpiStores + (STATS ? 2 : 0)>(bq[d][0], bq[d][1]);
+        for (int d = 0; d < D; ++d) vm_wait_tie<kEpiStores>(bq[d][0], bq[d][1]);
         WP_ADD(6); // ring wait before the back-edge
         tile = next;
         ++it;
@@ -575,24 +632,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                wpAcc[0] / wpTiles, wpAcc[1] / wpTiles, wpAcc[2] / wpTiles, wpAcc[3] / wpTiles, wpAcc[4] / wpTiles, wpAcc[5] / wpTiles, wpAcc[6] / wpTiles);
 #endif
 
-    if (STATS && p.counter) { // the last tile's ticket: nothing to hide it behind
-        if (pendN >= 0) {
-            vm_wait<0>();
-            lds_barrier();
-            int* const flag = reinterpret_cast<int*>(smem + kLdsScr + 4 * kScrBytes - 16);
-            if (tid == 0) {
-                unsigned* cnt = p.counter + pendN;
-                const unsigned prev = atomicAdd(cnt, 1u);
-                const bool last = prev + 1u == static_cast<unsigned>(p.tilesPerImage);
-                if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *flag = last;
-            }
-            __syncthreads();
-            const bool last = *flag != 0;
-            __syncthreads();
-            if (last) tile_stats_fold<128>(*p.fold, p.statPart, reinterpret_cast<float*>(smem + kLdsScr), pendN, p.tilesX, 2 * p.tilesY, 4, 32, p.OH, p.OW, OC, 0);
-        }
-    }
 }
 
 typedef void (*WidePFn)(WidePParams, ActCfg, const _Float16*, const char*, const float4*, _Float16*);
@@ -610,7 +649,7 @@ struct WidePConvPlan : ConvPlanBase {
 
     WidePFn pick() const {
 #define SNNHIP_WP_F(NK, ST) (fastKind == 2 ? conv2d_widep_kernel<NK, ST, 3, 2> : fastKind == 1 ? conv2d_widep_kernel<NK, ST, 3, 1> : conv2d_widep_kernel<NK, ST, 3, 0>)
-        const bool st = p.statPart != nullptr;
+        const bool st = p.statRec != nullptr;
         switch (normKind) {
         case 0: return st ? SNNHIP_WP_F(0, true) : SNNHIP_WP_F(0, false);
         case 1: return st ? SNNHIP_WP_F(1, true) : SNNHIP_WP_F(1, false);
@@ -620,17 +659,24 @@ struct WidePConvPlan : ConvPlanBase {
 #undef SNNHIP_WP_F
     }
 
-    // chain rule F: per-WAVE records (4 rows x 32 columns x 64 channels), i.e. a record grid of tilesX x 2 tilesY tiles of 4 x 32 pixels
+    // chain rule F.  The records are per (image, block): nothing the norm's fold launches could read -- statistics only together with the in-kernel fold
     bool enableTileStats() override {
         if (statPart) return true;
+        if (snnhip::option("SNNHIP_NO_KERNEL_FOLD")) return false;
         void* buf = nullptr;
-        const size_t bytes = static_cast<size_t>(p.N) * 2 * p.tilesY * p.tilesX * 2 * 128 * sizeof(float);
-        if (snnhip::dev_malloc(&buf, bytes, "conv2d_widep tile statistics") != hipSuccess) return false;
+        const size_t bytes = static_cast<size_t>(p.N) * p.recsMax * kRecFloats * sizeof(float);
+        if (snnhip::dev_malloc(&buf, bytes, "conv2d_widep block statistics") != hipSuccess) return false;
         deviceAllocs.push_back(buf);
-        statPart = p.statPart = static_cast<float*>(buf);
-        statTilesX = p.tilesX; statTilesY = 2 * p.tilesY; statTH = 4; statTW = 32;
+        statPart = p.statRec = static_cast<float*>(buf);
+        statTilesX = static_cast<int>(p.recsMax); statTilesY = 1; statTH = 0; statTW = 0;
         desc += " +tile-stats";
         return true;
+    }
+    bool tileStatsNeedKernelFold() const override { return true; }
+    void disableTileStats() override {
+        statPart = p.statRec = nullptr; // (the buffer stays with the plan's allocations)
+        const size_t at = desc.rfind(" +tile-stats");
+        if (at != std::string::npos) desc.erase(at);
     }
     bool enableNormFold(const NormFoldTarget& t) override {
         if (!statPart || p.counter) return false;
@@ -653,6 +699,7 @@ struct WidePConvPlan : ConvPlanBase {
     }
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == 1, "conv2d: expects 1 input, got %d", nIn);
+        SNNHIP_REQUIRE(!p.statRec || p.counter, "conv2d_widep: block statistics were switched on without the in-kernel fold (no fold launch reads its records)");
         const snnhip_tensor* x = in[0];
         SNNHIP_REQUIRE(x->n == p.N && x->h == p.srcH && x->w == p.srcW && x->c == 128 && x->dtype == SNNHIP_F16,
                        "conv2d: input dims %dx%dx%dx%d (dtype %d) != plan %dx%dx%dx%d fp16", x->n, x->h, x->w, x->c, x->dtype, p.N, p.srcH, p.srcW, 128);
@@ -676,6 +723,7 @@ int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oi
     if (g.normShift && !act_is_simple(g.normAct)) return SNNHIP_E_UNSUPPORTED;
     if (const char* e = snnhip::option("SNNHIP_WIDE_PERSIST"))
         if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
+    if (snnhip::option("SNNHIP_NO_KERNEL_FOLD")) return SNNHIP_E_UNSUPPORTED; // (this kernel's statistics records are per block: only its own fold reads them)
     const int srcH = g.preMode ? g.srcH : g.H, srcW = g.preMode ? g.srcW : g.W;
     const double inBytes = 2.0 * g.N * srcH * srcW * g.IC, outBytes = 2.0 * g.N * g.OH * g.OW * g.OC;
     if (inBytes >= 4026531840.0 || outBytes >= 4026531840.0) return SNNHIP_E_UNSUPPORTED; // 32-bit byte offsets below the out-of-range marker (raw buffer descriptors)
@@ -706,13 +754,12 @@ int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oi
     plan->ringD = 3;
     plan->ldsBytes = static_cast<size_t>(kLdsNorm) + 2 * 2 * 128 * sizeof(float);
     {   // 80 KB of dynamic LDS: every instantiation this plan may pick later (statistics / fold are switched on after creation)
-        const bool keepStat = plan->p.statPart != nullptr;
         bool ok = true;
         for (int st = 0; st < 2 && ok; ++st) {
-            plan->p.statPart = st ? reinterpret_cast<float*>(plan) : nullptr; // (only pick()'s test of it)
+            plan->p.statRec = st ? reinterpret_cast<float*>(plan) : nullptr; // (only pick()'s test of it)
             ok = hipFuncSetAttribute(reinterpret_cast<const void*>(plan->pick()), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan->ldsBytes)) == hipSuccess;
         }
-        plan->p.statPart = keepStat ? plan->p.statPart : nullptr;
+        plan->p.statRec = nullptr;
         if (!ok) {
             set_error("conv2d_widep: hipFuncSetAttribute(%zu) failed", plan->ldsBytes);
             delete plan;
@@ -720,6 +767,13 @@ int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oi
         }
     }
     plan->gridBlocks = static_cast<int>(std::min<long>(tiles, 2L * cus));
+    if (const char* e = snnhip::option("SNNHIP_WIDEP_GRID")) { // experiments: resident blocks
+        const int v = atoi(e);
+        if (v > 0) plan->gridBlocks = static_cast<int>(std::min<long>(tiles, v));
+    }
+    p.tilesBase = static_cast<unsigned>(tiles / plan->gridBlocks);
+    p.tilesRem = static_cast<unsigned>(tiles % plan->gridBlocks);
+    p.recsMax = static_cast<unsigned>(p.tilesPerImage / p.tilesBase + 2); // blocks whose run can touch one image
 
     // weights: Wp[step = (chunk, tap, c8)][h][oc] x 8 halfs, ic = chunk*32 + (c8*2 + h)*8 + j -- conv2d_wide_f16's packing (C8 = 2) -- + one step of zeros (the padding pixels' DMA source)
     const size_t steps = 72;
@@ -753,10 +807,6 @@ int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oi
     char buf[320];
     snprintf(buf, sizeof(buf), "conv2d_mfma_wide_f16_32x32x16 persistent k=3x3 s=1 ic=128 oc=128 tile=8x32px x 128oc (4x2 MFMA tiles per wave) chunk=32 ring=%d blocks=%d lds=%zuB",
              plan->ringD, plan->gridBlocks, plan->ldsBytes);
-    if (const char* e = snnhip::option("SNNHIP_WIDEP_GRID")) { // experiments: resident blocks
-        const int v = atoi(e);
-        if (v > 0) plan->gridBlocks = static_cast<int>(std::min<long>(tiles, v));
-    }
     plan->desc = buf;
     if (g.preMode) plan->desc += " +pad(" + std::string(g.preMode == SNNHIP_PAD_REFLECT ? "reflect" : g.preMode == SNNHIP_PAD_REPLICATE ? "replicate" : "constant") + ")";
     if (g.preMode && g.preShift) plan->desc += " +upsample(x2)";

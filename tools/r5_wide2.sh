@@ -3,7 +3,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/${1:-r5_wide2}; mkdir -p "$O"
 timeout 420 python -m pytest tests/test_conv_wide_gpu.py -m gpu -q -x --timeout 120 -k "wide" > "$O/t_wide.txt" 2>&1; rc=$?; echo "wide tests rc=$rc"; tail -5 "$O/t_wide.txt" | cut -c1-220
 if [ $rc -ne 0 ]; then tail -40 "$O/t_wide.txt" | cut -c1-200; exit 0; fi
-tools/ab_wide.sh SNNHIP_WIDE_PERSIST=0 SNNHIP_WIDE_PERSIST=1 SNNHIP_WIDEP_GRID=256 SNNHIP_WIDEP_GRID=384 2>&1 | grep -v "128->64" | tee "$O/ab.txt"
+tools/ab_wide.sh SNNHIP_WIDE_PERSIST=0 SNNHIP_WIDE_PERSIST=1  2>&1 | grep -v "128->64" | tee "$O/ab.txt"
 for spec in SNNHIP_WIDE_PERSIST=0 SNNHIP_WIDE_PERSIST=1; do
   env $spec timeout 600 python bench.py --config c5 --also none --no-cpu-baseline --layer-table 0 > "$O/bench_c5_$spec.json" 2> "$O/bench_c5_$spec.err" || tail -3 "$O/bench_c5_$spec.err"
   python tools/bench_digest.py "$O/bench_c5_$spec.json" | head -4

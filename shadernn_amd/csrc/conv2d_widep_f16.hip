@@ -174,7 +174,7 @@ __device__ __forceinline__ void widep_stats_fold(const NormFoldArgs& f, const fl
     }
 }
 
-// NORM: 0 = no InstanceNorm in front, 1 = its activation is ReLU (max on the packed halfs), 2 = any branch-free activation (med3 form), 3 = none
+// NORM: 0 = no InstanceNorm in front, 1 = its activation is ReLU or none (max(x, lo) on the packed halfs), 2 = any branch-free activation (med3 form)
 // FAST: the layer has no batch norm and its activation is none (FAST = 2) or ReLU (FAST = 1): the epilogue is bias + conversion [+ a max on the packed
 //       halfs]; 0 = the general bias [-> BN] -> med3 epilogue
 // STATS: chain rule F records (+ the in-kernel fold when p.fold.counter)
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     float* const biasTab = reinterpret_cast<float*>(smem + kLdsBias);
 
     // ---- once per block
+    if (NORM != 0 && tid < 16) normTab[4 * IC + (tid & 7) + (tid >> 3) * IC] = 0.0f; // the zero rows (shift at 4 IC, mul IC floats behind it)
     if (tid < OC) {
         const float4 e4 = epi[tid];
         reinterpret_cast<float4*>(smem + kLdsEpi)[tid] = e4;
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     // one slot of the fix-up in two halves (a K step apart: the LDS round trip hides under that step's MFMAs): read the slot and its table rows ...
     f4 fxv, fxs0, fxs1, fxm0, fxm1;
     auto fix_read = [&](int bufOfs, int ic0, int slot, int r, unsigned g) {
-        const float* const tb = normTab + slot * 2 * IC + ic0 + 8 * ((g >> 4) & 3u);
+        // (a padding slot -- zeros from the copy -- looks up the zero rows behind the two table slots: 0 * 0 + 0 stays zero through every activation of the family)
+        const float* const tb = g == kOutOfRange ? normTab + 4 * IC : normTab + slot * 2 * IC + ic0 + 8 * ((g >> 4) & 3u);
         fxv = *reinterpret_cast<const f4*>(smem + bufOfs + (tq + 256u * r) * 16);
         fxs0 = *reinterpret_cast<const f4*>(tb);
         fxs1 = *reinterpret_cast<const f4*>(tb + 4);
@@ -263,26 +265,39 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     // ... normalise (two halves, one per pair of MFMAs: the ~12 vector instructions of a half fit the issue slots two MFMAs leave), activate, write back
     // (padding stays zero)
     typedef _Float16 h2x __attribute__((ext_vector_type(2)));
-    h2x fxo[4];
     auto fix_half = [&](int half) {
         const h8 hv = *reinterpret_cast<const h8*>(&fxv);
+        if (NORM != 2) {
+            // half(fma(float(x), mul, shift)) as ONE instruction per value: v_fma_mixlo_f16 / v_fma_mixhi_f16 read the half operand in place (op_sel picks the
+            // word) and write the rounded result into the low / high word of the destination -- the compiler's form was cvt + packed fp32 fma + cvt_pk
 #pragma unroll
-        for (int k = 4 * half; k < 4 * half + 4; ++k) {
-            const float f = fmaf(static_cast<float>(hv[k]), half == 0 ? fxm0[k & 3] : fxm1[k & 3], half == 0 ? fxs0[k & 3] : fxs1[k & 3]);
-            const _Float16 o = NORM == 2 ? static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi)) : static_cast<_Float16>(f);
-            fxo[k >> 1][k & 1] = o;
+            for (int k2 = 2 * half; k2 < 2 * half + 2; ++k2) {
+                const unsigned src = __builtin_bit_cast(unsigned, fxv[k2]);
+                const float m0 = half == 0 ? fxm0[(2 * k2) & 3] : fxm1[(2 * k2) & 3], m1 = half == 0 ? fxm0[(2 * k2 + 1) & 3] : fxm1[(2 * k2 + 1) & 3];
+                const float s0 = half == 0 ? fxs0[(2 * k2) & 3] : fxs1[(2 * k2) & 3], s1 = half == 0 ? fxs0[(2 * k2 + 1) & 3] : fxs1[(2 * k2 + 1) & 3];
+                unsigned d;
+                asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                    : "=&v"(d) : "v"(src), "v"(m0), "v"(s0), "v"(m1), "v"(s1));
+                fxv[k2] = __builtin_bit_cast(float, d); // (in place: the source word pair is dead)
+            }
+        } else {
+#pragma unroll
+            for (int k = 4 * half; k < 4 * half + 4; ++k) {
+                const float f = fmaf(static_cast<float>(hv[k]), half == 0 ? fxm0[k & 3] : fxm1[k & 3], half == 0 ? fxs0[k & 3] : fxs1[k & 3]);
+                h2x w = __builtin_bit_cast(h2x, fxv[k >> 1]);
+                w[k & 1] = static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+                fxv[k >> 1] = __builtin_bit_cast(float, w);
+            }
         }
         if (NORM == 1) { // ReLU on the rounded halfs, two per instruction (rounding is monotonic and keeps zero: the same bits as max-then-round)
 #pragma unroll
-            for (int k2 = 2 * half; k2 < 2 * half + 2; ++k2) fxo[k2] = __builtin_elementwise_max(fxo[k2], h2x{static_cast<_Float16>(0.0f), static_cast<_Float16>(0.0f)});
+            const _Float16 lo = static_cast<_Float16>(p.normAc.lo); // 0 (ReLU) or -inf (none: the max is the identity)
+            for (int k2 = 2 * half; k2 < 2 * half + 2; ++k2) fxv[k2] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(h2x, fxv[k2]), h2x{lo, lo}));
         }
     };
     auto fix_write = [&](int bufOfs, int r, unsigned g) {
-        const bool pad = g == kOutOfRange;
-        f4 res;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) res[k] = pad ? 0.0f : __builtin_bit_cast(float, fxo[k]);
-        *reinterpret_cast<f4*>(smem + bufOfs + (tq + 256u * r) * 16) = res;
+        (void) g;
+        *reinterpret_cast<f4*>(smem + bufOfs + (tq + 256u * r) * 16) = fxv;
     };
     auto stage_dma = [&](int bufOfs, int ic0) {
 #pragma unroll
@@ -388,6 +403,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
+#ifdef SNNHIP_WIDEP_PRIO
+        __builtin_amdgcn_s_setprio(SNNHIP_WIDEP_PRIO);
+#endif
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int curOfs = (c & 1) ? kLdsBuf1 : kLdsBuf0, nxtOfs = (c & 1) ? kLdsBuf0 : kLdsBuf1;
@@ -460,6 +478,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #pragma unroll
         for (int r = 0; r < kR; ++r) gofs[r] = gofsN[r];
 
+#ifdef SNNHIP_WIDEP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- epilogue (wave-private): accumulator layout acc[t][u][4 g + k] = channel 64 wn + 32 u + 8 g + 4 h + k of pixel (row 4 wm + t, column l32)
         {
             const unsigned lane = tq & 63u, l32 = tq & 31u, h = (tq >> 5) & 1u, wm = (tq >> 6) & 1u, wn = tq >> 7; // (shadow the kernel's: re-derived per tile)
@@ -653,8 +674,7 @@ struct WidePConvPlan : ConvPlanBase {
         switch (normKind) {
         case 0: return st ? SNNHIP_WP_F(0, true) : SNNHIP_WP_F(0, false);
         case 1: return st ? SNNHIP_WP_F(1, true) : SNNHIP_WP_F(1, false);
-        case 3: return st ? SNNHIP_WP_F(3, true) : SNNHIP_WP_F(3, false);
-        default: return st ? SNNHIP_WP_F(2, true) : SNNHIP_WP_F(2, false);
+        default: return SNNHIP_WP_F(2, false); // (no statistics instantiation: 256 registers do not hold both -- enableTileStats declines)
         }
 #undef SNNHIP_WP_F
     }
@@ -662,7 +682,7 @@ struct WidePConvPlan : ConvPlanBase {
     // chain rule F.  The records are per (image, block): nothing the norm's fold launches could read -- statistics only together with the in-kernel fold
     bool enableTileStats() override {
         if (statPart) return true;
-        if (snnhip::option("SNNHIP_NO_KERNEL_FOLD")) return false;
+        if (snnhip::option("SNNHIP_NO_KERNEL_FOLD") || normKind == 2) return false;
         void* buf = nullptr;
         const size_t bytes = static_cast<size_t>(p.N) * p.recsMax * kRecFloats * sizeof(float);
         if (snnhip::dev_malloc(&buf, bytes, "conv2d_widep block statistics") != hipSuccess) return false;
@@ -749,10 +769,10 @@ int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oi
     plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC * 9);
     plan->epi4 = epi4;
     plan->ac = make_act_cfg(g.act, g.leaky);
-    plan->normKind = !g.normShift ? 0 : (g.normAct == SNNHIP_ACT_RELU ? 1 : g.normAct == SNNHIP_ACT_NONE ? 3 : 2);
+    plan->normKind = !g.normShift ? 0 : ((g.normAct == SNNHIP_ACT_RELU || g.normAct == SNNHIP_ACT_NONE) ? 1 : 2);
     plan->fastKind = g.useBN ? 0 : (g.act == SNNHIP_ACT_NONE ? 2 : g.act == SNNHIP_ACT_RELU ? 1 : 0);
     plan->ringD = 3;
-    plan->ldsBytes = static_cast<size_t>(kLdsNorm) + 2 * 2 * 128 * sizeof(float);
+    plan->ldsBytes = static_cast<size_t>(kLdsNorm) + (2 * 2 * 128 + 128 + 8) * sizeof(float); // two table slots + the zero rows a padding slot looks up
     {   // 80 KB of dynamic LDS: every instantiation this plan may pick later (statistics / fold are switched on after creation)
         bool ok = true;
         for (int st = 0; st < 2 && ok; ++st) {

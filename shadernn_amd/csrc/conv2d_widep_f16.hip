@@ -290,8 +290,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
             }
         }
         if (NORM == 1) { // ReLU on the rounded halfs, two per instruction (rounding is monotonic and keeps zero: the same bits as max-then-round)
-#pragma unroll
             const _Float16 lo = static_cast<_Float16>(p.normAc.lo); // 0 (ReLU) or -inf (none: the max is the identity)
+#pragma unroll
             for (int k2 = 2 * half; k2 < 2 * half + 2; ++k2) fxv[k2] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(h2x, fxv[k2]), h2x{lo, lo}));
         }
     };

@@ -267,27 +267,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     typedef _Float16 h2x __attribute__((ext_vector_type(2)));
     auto fix_half = [&](int half) {
         const h8 hv = *reinterpret_cast<const h8*>(&fxv);
-        if (NORM != 2) {
-            // half(fma(float(x), mul, shift)) as ONE instruction per value: v_fma_mixlo_f16 / v_fma_mixhi_f16 read the half operand in place (op_sel picks the
-            // word) and write the rounded result into the low / high word of the destination -- the compiler's form was cvt + packed fp32 fma + cvt_pk
 #pragma unroll
-            for (int k2 = 2 * half; k2 < 2 * half + 2; ++k2) {
-                const unsigned src = __builtin_bit_cast(unsigned, fxv[k2]);
-                const float m0 = half == 0 ? fxm0[(2 * k2) & 3] : fxm1[(2 * k2) & 3], m1 = half == 0 ? fxm0[(2 * k2 + 1) & 3] : fxm1[(2 * k2 + 1) & 3];
-                const float s0 = half == 0 ? fxs0[(2 * k2) & 3] : fxs1[(2 * k2) & 3], s1 = half == 0 ? fxs0[(2 * k2 + 1) & 3] : fxs1[(2 * k2 + 1) & 3];
-                unsigned d;
-                asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                    : "=&v"(d) : "v"(src), "v"(m0), "v"(s0), "v"(m1), "v"(s1));
-                fxv[k2] = __builtin_bit_cast(float, d); // (in place: the source word pair is dead)
-            }
-        } else {
-#pragma unroll
-            for (int k = 4 * half; k < 4 * half + 4; ++k) {
-                const float f = fmaf(static_cast<float>(hv[k]), half == 0 ? fxm0[k & 3] : fxm1[k & 3], half == 0 ? fxs0[k & 3] : fxs1[k & 3]);
-                h2x w = __builtin_bit_cast(h2x, fxv[k >> 1]);
-                w[k & 1] = static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
-                fxv[k >> 1] = __builtin_bit_cast(float, w);
-            }
+        for (int k = 4 * half; k < 4 * half + 4; ++k) {
+            const float f = fmaf(static_cast<float>(hv[k]), half == 0 ? fxm0[k & 3] : fxm1[k & 3], half == 0 ? fxs0[k & 3] : fxs1[k & 3]);
+            h2x w = __builtin_bit_cast(h2x, fxv[k >> 1]);
+            w[k & 1] = NORM == 2 ? static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi)) : static_cast<_Float16>(f);
+            fxv[k >> 1] = __builtin_bit_cast(float, w);
         }
         if (NORM == 1) { // ReLU on the rounded halfs, two per instruction (rounding is monotonic and keeps zero: the same bits as max-then-round)
             const _Float16 lo = static_cast<_Float16>(p.normAc.lo); // 0 (ReLU) or -inf (none: the max is the identity)
@@ -330,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #pragma unroll
                 for (int k2 = 0; k2 < 4; ++k2) {
                     h2 v2 = {ov[2 * k2], ov[2 * k2 + 1]};
-                    v2 = __builtin_elementwise_max(v2, h2{static_cast<_Float16>(0.0f), static_cast<_Float16>(0.0f)});
+                    v2 = __builtin_elementwise_max(v2, h2{static_cast<_Float16>(p.normAc.lo), static_cast<_Float16>(p.normAc.lo)}); // lo: 0 (ReLU) or -inf (none)
                     ov[2 * k2] = v2[0];
                     ov[2 * k2 + 1] = v2[1];
                 }

@@ -252,37 +252,42 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
         return ok ? static_cast<unsigned>(rowPix + sx) * (IC * 2) + ql * 16 : kOutOfRange;
     };
     // one slot of the fix-up in two halves (a K step apart: the LDS round trip hides under that step's MFMAs): read the slot and its table rows ...
-    f4 fxv, fxs0, fxs1, fxm0, fxm1;
+    f4 fxv, fxs, fxm;
+    const float* fxtb;
     auto fix_read = [&](int bufOfs, int ic0, int slot, int r, unsigned g) {
         // (a padding slot -- zeros from the copy -- looks up the zero rows behind the two table slots: 0 * 0 + 0 stays zero through every activation of the family)
         const float* const tb = g == kOutOfRange ? normTab + 4 * IC : normTab + slot * 2 * IC + ic0 + 8 * ((g >> 4) & 3u);
         fxv = *reinterpret_cast<const f4*>(smem + bufOfs + (tq + 256u * r) * 16);
-        fxs0 = *reinterpret_cast<const f4*>(tb);
-        fxs1 = *reinterpret_cast<const f4*>(tb + 4);
-        fxm0 = *reinterpret_cast<const f4*>(tb + IC);
-        fxm1 = *reinterpret_cast<const f4*>(tb + IC + 4);
+        fxs = *reinterpret_cast<const f4*>(tb);
+        fxm = *reinterpret_cast<const f4*>(tb + IC);
+        fxtb = tb;
+    };
+    auto fix_rows1 = [&]() { // the table rows of the slot's second half, into the registers the first half has just used
+        fxs = *reinterpret_cast<const f4*>(fxtb + 4);
+        fxm = *reinterpret_cast<const f4*>(fxtb + IC + 4);
     };
     // ... normalise (two halves, one per pair of MFMAs: the ~12 vector instructions of a half fit the issue slots two MFMAs leave), activate, write back
     // (padding stays zero)
     typedef _Float16 h2x __attribute__((ext_vector_type(2)));
+    h2x fxo[4];
     auto fix_half = [&](int half) {
         const h8 hv = *reinterpret_cast<const h8*>(&fxv);
 #pragma unroll
         for (int k = 4 * half; k < 4 * half + 4; ++k) {
-            const float f = fmaf(static_cast<float>(hv[k]), half == 0 ? fxm0[k & 3] : fxm1[k & 3], half == 0 ? fxs0[k & 3] : fxs1[k & 3]);
-            h2x w = __builtin_bit_cast(h2x, fxv[k >> 1]);
-            w[k & 1] = NORM == 2 ? static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi)) : static_cast<_Float16>(f);
-            fxv[k >> 1] = __builtin_bit_cast(float, w);
+            const float f = fmaf(static_cast<float>(hv[k]), fxm[k & 3], fxs[k & 3]);
+            fxo[k >> 1][k & 1] = NORM == 2 ? static_cast<_Float16>(__builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi)) : static_cast<_Float16>(f);
         }
-        if (NORM == 1) { // ReLU on the rounded halfs, two per instruction (rounding is monotonic and keeps zero: the same bits as max-then-round)
+        if (NORM == 1) { // max(x, lo) on the rounded halfs, two per instruction (rounding is monotonic and keeps zero: the same bits as max-then-round)
             const _Float16 lo = static_cast<_Float16>(p.normAc.lo); // 0 (ReLU) or -inf (none: the max is the identity)
 #pragma unroll
-            for (int k2 = 2 * half; k2 < 2 * half + 2; ++k2) fxv[k2] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(h2x, fxv[k2]), h2x{lo, lo}));
+            for (int k2 = 2 * half; k2 < 2 * half + 2; ++k2) fxo[k2] = __builtin_elementwise_max(fxo[k2], h2x{lo, lo});
         }
     };
-    auto fix_write = [&](int bufOfs, int r, unsigned g) {
-        (void) g;
-        *reinterpret_cast<f4*>(smem + bufOfs + (tq + 256u * r) * 16) = fxv;
+    auto fix_write = [&](int bufOfs, int r) {
+        f4 res;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) res[k] = __builtin_bit_cast(float, fxo[k]);
+        *reinterpret_cast<f4*>(smem + bufOfs + (tq + 256u * r) * 16) = res;
     };
     auto stage_dma = [&](int bufOfs, int ic0) {
 #pragma unroll
@@ -436,11 +441,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                     acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b0), *reinterpret_cast<const h8*>(&a[t]), acc[t][0], 0, 0, 0);
                     acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&b1), *reinterpret_cast<const h8*>(&a[t]), acc[t][1], 0, 0, 0);
                     if (s + 1 < S) a[t] = *reinterpret_cast<const f4*>(smem + curOfs + aoff0 + t * (kTileW * kQP * 16) + dl);
-                    if (NORM != 0 && t == 0 && fr >= 0 && fr < kR) fix_read(nxtOfs, nIc0, nSlot, fr, c == NCH - 1 ? gofsN[fr] : gofs[fr]);
-                    if (NORM != 0 && t == 2 && fr >= 0 && fr < kR) fix_half(0);
-                    if (NORM != 0 && t == 3 && fr >= 0 && fr < kR) {
+                    // fix-up, slot fr: read at t = 1, first half + the second half's table rows at t = 3; second half + write-back at t = 0 of the NEXT step
+                    if (NORM != 0 && t == 0 && fr - 1 >= 0 && fr - 1 < kR) {
                         fix_half(1);
-                        fix_write(nxtOfs, fr, c == NCH - 1 ? gofsN[fr] : gofs[fr]);
+                        fix_write(nxtOfs, fr - 1);
+                    }
+                    if (NORM != 0 && t == 1 && fr >= 0 && fr < kR) fix_read(nxtOfs, nIc0, nSlot, fr, c == NCH - 1 ? gofsN[fr] : gofs[fr]);
+                    if (NORM != 0 && t == 3 && fr >= 0 && fr < kR) {
+                        fix_half(0);
+                        fix_rows1();
                     }
                     if (c == 2 && t == 1 && s < kR) gofsN[s] = map_elem(s); // (tables of ntile: published by chunk 1's barrier)
                     __builtin_amdgcn_sched_barrier(0);
@@ -659,7 +668,7 @@ struct WidePConvPlan : ConvPlanBase {
         switch (normKind) {
         case 0: return st ? SNNHIP_WP_F(0, true) : SNNHIP_WP_F(0, false);
         case 1: return st ? SNNHIP_WP_F(1, true) : SNNHIP_WP_F(1, false);
-        default: return SNNHIP_WP_F(2, false); // (no statistics instantiation: 256 registers do not hold both -- enableTileStats declines)
+        default: return nullptr;
         }
 #undef SNNHIP_WP_F
     }
@@ -667,7 +676,7 @@ struct WidePConvPlan : ConvPlanBase {
     // chain rule F.  The records are per (image, block): nothing the norm's fold launches could read -- statistics only together with the in-kernel fold
     bool enableTileStats() override {
         if (statPart) return true;
-        if (snnhip::option("SNNHIP_NO_KERNEL_FOLD") || normKind == 2) return false;
+        if (snnhip::option("SNNHIP_NO_KERNEL_FOLD")) return false;
         void* buf = nullptr;
         const size_t bytes = static_cast<size_t>(p.N) * p.recsMax * kRecFloats * sizeof(float);
         if (snnhip::dev_malloc(&buf, bytes, "conv2d_widep block statistics") != hipSuccess) return false;
@@ -725,7 +734,7 @@ struct WidePConvPlan : ConvPlanBase {
 int make_conv2d_widep_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 1 || g.sw != 1) return SNNHIP_E_UNSUPPORTED;
     if (g.IC != 128 || g.OC != 128 || !act_is_simple(g.act) || g.addAct >= 0) return SNNHIP_E_UNSUPPORTED; // (other activations / a fused residual: conv2d_wide_kernel)
-    if (g.normShift && !act_is_simple(g.normAct)) return SNNHIP_E_UNSUPPORTED;
+    if (g.normShift && g.normAct != SNNHIP_ACT_RELU && g.normAct != SNNHIP_ACT_NONE) return SNNHIP_E_UNSUPPORTED; // (other norm activations: conv2d_wide_kernel; the med3 form does not fit 256 registers here)
     if (const char* e = snnhip::option("SNNHIP_WIDE_PERSIST"))
         if (atoi(e) == 0) return SNNHIP_E_UNSUPPORTED;
     if (snnhip::option("SNNHIP_NO_KERNEL_FOLD")) return SNNHIP_E_UNSUPPORTED; // (this kernel's statistics records are per block: only its own fold reads them)

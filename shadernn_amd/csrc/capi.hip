@@ -511,7 +511,10 @@ hipError_t dev_malloc_bytes(void** p, size_t bytes, const char* what) {
     void* base = nullptr;
     const hipError_t e = hipMalloc(&base, kGuardZone + user + kGuardZone);
     if (e != hipSuccess) return e;
-    const hipError_t m = hipMemset(base, 0xFF, kGuardZone + user + kGuardZone); // zones AND contents: nothing reads as a plausible number before it is written
+    hipError_t m = hipMemset(base, 0xFF, kGuardZone + user + kGuardZone); // zones AND contents: nothing reads as a plausible number before it is written
+    // (the fill runs on the null stream, which a context's non-blocking stream does not wait for: without this wait a kernel launched right behind
+    // the allocation raced the fill and its output came back poisoned -- the guard leg's first finding was its own)
+    if (m == hipSuccess) m = hipStreamSynchronize(nullptr);
     if (m != hipSuccess) {
         (void) hipFree(base);
         return m;

@@ -70,9 +70,14 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
     float* const epiTab = smem + 4 * ROWF + (2 * MT * 64 * EP) / 2;       // [2][BN] scale, shift of this block's channels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
     const int phase = wave & 3, py = phase >> 1, px = phase & 1, nt = wave >> 2;
+    // block order: all marching blocks first (segment fastest within a strip), the one-row blocks of row H behind them.  Workgroups go to the eight
+    // XCDs round-robin by index: with the one-row block as every (segs + 1)'th index and segs + 1 even, whole XCDs received nothing else (3
+    // segments: XCDs 3 and 7 idle; round 5, odd segment counts measured 5-8 % slower than their even neighbours) -- and short jobs belong last
     const int bx = blockIdx.x;
     const int nseg = p.segs + 1;
-    const int sg = bx % nseg, tx = (bx / nseg) % p.tilesX, n = bx / (nseg * p.tilesX);
+    const int marching = p.N * p.tilesX * p.segs;
+    const int strip = bx < marching ? bx / p.segs : bx - marching;
+    const int sg = bx < marching ? bx - strip * p.segs : p.segs, tx = strip % p.tilesX, n = strip / p.tilesX;
     const bool lastRow = sg == p.segs, lastCol = tx == p.tilesX - 1;
     const int m0 = lastRow ? p.srcH : sg * p.segRows, mEnd = lastRow ? p.srcH + 1 : min(p.srcH, m0 + p.segRows);
     const int q0 = lastCol ? p.srcW : 32 * tx, qEnd = lastCol ? p.srcW + 1 : min(p.srcW, q0 + 32);
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
         red[16 * T + tid] = stN;
         __syncthreads();
         const int BPI = (p.segs + 1) * p.tilesX;
-        float* const rec = p.statRec + (static_cast<size_t>(n * gridDim.y + blockIdx.y) * BPI + (bx - n * BPI)) * (1 + 2 * BN);
+        float* const rec = p.statRec + (static_cast<size_t>(n * gridDim.y + blockIdx.y) * BPI + (tx * nseg + sg)) * (1 + 2 * BN);
         if (tid < BN) {
             const int col = tid >> 3, kk = tid & 7;
             float a1 = 0.0f, a2 = 0.0f, an = 0.0f;
@@ -474,8 +479,11 @@ int make_conv2d_upconv_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
             const int segs = up_div(g.srcH, rows);
             if (segs != s) continue;
             if (s > 1 && rows < 16 && !fs) break;
-            const double blocks = static_cast<double>(strips) * (segs + 1);
-            const double eff = blocks / (std::ceil(blocks / slots) * slots) * rows / (rows + 4);
+            // blocks are handed out dynamically and do not finish together: what a launch loses is about half a block time at its end, not the
+            // unfilled part of a last "round" (round 5, tools/bench_upconv.py --segs at Candy's micro-batch 16: the round model picked 3 segments
+            // for both up-convolutions, 973 / 642 us; 6 segments 885 / 599 us, flat from 4 to 12).  The segs + 1'th block of a strip is one row.
+            const double perSlot = static_cast<double>(strips) * segs / slots;
+            const double eff = perSlot / (perSlot + 0.5) * rows / (rows + 4);
             if ((fs && atoi(fs) == s) || (!fs && eff > bestEff + 1e-9)) {
                 bestEff = eff;
                 bestSegs = segs;

@@ -1,5 +1,6 @@
 // conv2d_widep_f16.hip -- conv2d_wide_f16's 256-pixel x 128-channel block as a PERSISTENT kernel (round 5): fp16 Conv2D 3x3 stride 1, IC = 128, OC = 128 on
-// large maps -- the ten body layers of the style-transfer graphs (Candy: 47 % of a step at 0.36 of the fp16 MFMA peak with one block per tile).
+// large maps -- the ten body layers of the style-transfer graphs (Candy: 47 % of a step at 0.36 of the fp16 MFMA peak with one block per tile; 43 % at
+// 0.415 with this kernel, 333 -> 292 us per launch inside the graph).
 //
 // What the one-block-per-tile kernel paid per tile besides its 576 MFMAs per wave (phase trace + ablations): a prologue of
 // tables and staging maps (4 500 cycles), the first chunk's DMA in the open (4 300), an epilogue through a block-wide 68 KB LDS tile with three
@@ -7,24 +8,29 @@
 // written -- a drained prefetch at the head of every chunk: the compiler counts only ITS loads in s_waitcnt vmcnt(N), so with inline-asm LDS-DMA
 // copies in the queue its counted wait for a weight operand also waited for the copies issued just before.
 //
-//   * grid = two blocks per CU, each walks tiles b, b + G, b + 2G, ... (image-major: images finish in order and their statistics fold while later
-//     images are still being multiplied); 4 waves = 2 x 2 (pixel rows x 64-channel halves), a wave = 4 x 2 v_mfma_f32_32x32x16_f16 tiles as before;
+//   * grid = two blocks per CU; block b walks a CONTIGUOUS run of tiles (image-major, tilesBase / tilesRem), so it leaves an image once and its
+//     statistics need one record per (block, image); 4 waves = 2 x 2 (pixel rows x 64-channel halves), a wave = 4 x 2 v_mfma_f32_32x32x16_f16 tiles;
 //   * EVERY vector-memory instruction is inline assembly and every s_waitcnt vmcnt is counted by hand (the table at KSTEP below): weight operands
-//     (a ring of D K-steps per lane, scalar base + 32-bit lane offset), LDS-DMA copies of the next chunk's halo tile, output stores.  The four
-//     chunks of a tile are unrolled (no loop back-edge carries a register that a load is still writing), the ring wraps from a tile's last
-//     steps into the next tile's first (the weights do not depend on the tile) and is waited for once, under the epilogue's stores, before the
-//     tile loop's back-edge;
-//   * the next tile's row / column tables are resolved during chunk 1, its staging map and its first chunk's copies are issued at the top of
-//     chunk 3: a tile never starts with an exposed copy;
-//   * the epilogue is WAVE-PRIVATE: a wave converts one 32-pixel row of its accumulators (bias [-> BN] -> activation -> half), passes it through
-//     its own 4.5 KB of LDS as 8-byte runs and reads it back as 16-byte vectors -- 8 lanes = the 128 contiguous bytes of a pixel's channel half --
-//     no block barrier, no 68 KB tile (so the block still fits twice on a CU beside its two 28 KB staging buffers); stores are unconditional
-//     (pixels outside the map go to a dump buffer) so that their number is known to the counted waits;
-//   * chain rule F: sums and squares around the channel's bias of the values a lane carries to memory (8 channels x 16 pixels), summed over a
-//     wave through its LDS scratch: one {mean, M2} record per WAVE (4 rows x 32 columns x 64 channels, written through to the coherence point);
-//     the image counter is bumped one tile LATER, by an atomic whose return rides the next tile's chunk-1 wait: no round trip in the open, and
-//     the block that draws an image's last ticket folds it right there (norm_fold.h);
-//   * graph rule I (the InstanceNorm in front, applied in LDS behind the DMA) as before, with a two-instruction form for none / ReLU.
+//     (a ring of D K-steps per lane, scalar base + 32-bit lane offset), LDS-DMA copies of the next chunk's halo tile and output stores through raw
+//     buffer descriptors (a lane offset beyond the tensor = the copy writes zeros / the store is dropped: ragged tiles and zero padding cost no
+//     branch and keep the instruction count the waits rely on).  The four chunks of a tile are unrolled (no loop back-edge carries a register a
+//     load is still writing), the ring wraps from a tile's last steps into the next tile's first (the weights do not depend on the tile) and is
+//     waited for once, under the epilogue's stores, before the tile loop's back-edge.  Two hazards the compiler's recogniser does not see in
+//     inline assembly are padded by hand: a 16-byte store's data registers rewritten by the next VALU instruction (s_nop 1), and an SGPR written
+//     by v_readfirstlane used as a buffer instruction's soffset (s_nop 4);
+//   * everything that is not an MFMA is spread over the K-steps of the wave's OWN MFMA stream -- one copy per step in steps 0..6 of a chunk, the
+//     next tile's tables at chunk 1 step 0, one element of its staging map per step of chunk 2, rule I's fix-up of the rows just copied in the
+//     slots behind step 8.  Measured (phase traces, profiles/r05_widep_phase_trace_*.txt): the same VALU / LDS work as a phase of its own, beside
+//     the partner wave's MFMAs, costs ~17 cycles per instruction; inside the wave's own K-steps it is almost free;
+//   * the epilogue is WAVE-PRIVATE: a wave converts one 32-pixel row of its accumulators (sum + bias [-> BN] -> activation -> half), passes it
+//     through its own 4.5 KB of LDS as 8-byte runs and reads it back as 16-byte vectors -- 8 lanes = the 128 contiguous bytes of a pixel's channel
+//     half -- no block barrier, no 68 KB tile (so the block still fits twice on a CU beside its two 28 KB staging buffers);
+//   * chain rule F: sums and squares around the channel's bias of the values a lane carries to memory, kept in registers across the tiles of
+//     the run that lie in one image; when the run leaves the image the block writes ONE record (through to the coherence point), bumps the
+//     image's counter, and the block that writes an image's last record folds it right there (norm_fold.h's hand-off).  Per-tile records with
+//     a per-tile atomic were the first form: their acknowledgements sat in front of the weight loads in the in-order vmcnt queue;
+//   * graph rule I (the InstanceNorm in front, applied in LDS behind the DMA) for none / ReLU in a two-instruction form; the other activations
+//     of the norm stay on conv2d_wide_kernel.
 // Semantics: shadertemplate_vk_conv2d.comp:148-347 (padding redirects :180-185,213-218), bit-identical to conv2d_wide_kernel's convolution (same
 // K order); the statistics differ from its per-thread mean / M2 records only in how the same sums are grouped.
 #include "conv2d_mfma_kernel.h"

@@ -36,3 +36,23 @@ def test_lds_dma_is_the_only_m0_user(tmp_path):
             assert nxt.startswith("global_load_lds_dwordx4") or (nxt.startswith("buffer_load_dwordx4") and nxt.split(";")[0].rstrip().endswith(" lds")), \
                 "%s: %r is not followed by its DMA but by %r" % (os.path.basename(src), l, nxt)
         assert sum(1 for l in code if l.startswith("global_load_lds") or (l.startswith("buffer_load_dword") and l.split(";")[0].rstrip().endswith(" lds"))) == len(m0)
+
+
+def test_persistent_wide_kernel_waits_cover_every_load(tmp_path):
+    """conv2d_widep_f16.hip counts its s_waitcnt vmcnt(N) by hand (every vector-memory instruction is inline assembly the compiler does not count:
+    DESIGN 5.1-12).  tools/audit_vmcnt.py replays the in-order counter over the generated code: no instruction may touch a register an outstanding
+    load still writes; the same walk must report hazards once every wait is loosened by one (the check has teeth); and the kernel must not use
+    scratch memory (a compiler scratch reload is a vmcnt(0): the prefetch pipeline would run synchronously)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_vmcnt
+    asm = _device_asm(os.path.join(CSRC, "conv2d_widep_f16.hip"), tmp_path)
+    res = audit_vmcnt.audit(asm, "conv2d_widep_kernel")
+    assert len(res) >= 12, "expected the NORM x STATS x FAST instantiations, got %d" % len(res)
+    for kernel, loads, depth, hazards, _ in res:
+        assert loads >= 150 and depth >= 16, (kernel, loads, depth)
+        assert not hazards, "%s:\n%s" % (kernel, "\n".join(hazards[:5]))
+    loose = re.sub(r"vmcnt\((\d+)\)", lambda m: "vmcnt(%d)" % (int(m.group(1)) + 1), asm)
+    assert all(h for _, _, _, h, _ in audit_vmcnt.audit(loose, "conv2d_widep_kernel"))
+    sizes = re.findall(r"conv2d_widep_kernel\S*\.private_seg_size, (\d+)", asm)
+    assert sizes and all(int(x) == 0 for x in sizes), sizes

@@ -37,6 +37,7 @@
 #include "norm_fold.h"
 
 #include <cstring>
+#include <type_traits>
 
 #ifdef SNNHIP_WIDEP_TRACE // experiment builds (tools/exp_one.sh): one block sums the s_memtime spans of its phases over its tiles and prints them
 #define WP_T0() unsigned long long wpT = __builtin_readcyclecounter()
@@ -172,7 +173,7 @@ __device__ __forceinline__ void widep_stats_fold(const NormFoldArgs& f, const fl
         an = scratch[tid] + scratch[128 + tid];
         a1 = scratch[256 + tid] + scratch[256 + 128 + tid];
         a2 = scratch[512 + tid] + scratch[512 + 128 + tid];
-        const float dm = a1 / an, mean = biasTab[tid] + dm;
+        const float dm = a1 / an, mean = static_cast<float>(static_cast<_Float16>(biasTab[tid])) + dm; // (the pivot the records were taken around: the bias as a half)
         const float var = fmaxf(a2 / an - dm * dm, 0.0f);
         const float mu = f.gamma[tid] / sqrtf(var + f.eps);
         f.mul[n * 128 + tid] = mu;
@@ -402,8 +403,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #ifdef SNNHIP_WIDEP_PRIO
         __builtin_amdgcn_s_setprio(SNNHIP_WIDEP_PRIO);
 #endif
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
+        // (the four chunks as four calls of one body with a compile-time c instead of a `#pragma unroll` loop: the same code with 20-30 fewer scalar
+        // registers spilled to vector lanes -- v_readlane / v_writelane are vector instructions inside the K-steps)
+        auto chunk = [&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
             const int curOfs = (c & 1) ? kLdsBuf1 : kLdsBuf0, nxtOfs = (c & 1) ? kLdsBuf0 : kLdsBuf1;
             const int nIc0 = c == NCH - 1 ? 0 : (c + 1) * 32, nSlot = c == NCH - 1 ? (slot ^ 1) : slot; // the chunk being staged: the next one (chunk 3: the next tile's first)
 #pragma unroll
@@ -474,7 +477,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
             WP_ADD(3); // table / ticket bookkeeping
             lds_barrier();
             WP_ADD(4); // barrier
-        }
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+        static_assert(NCH == 4, "four chunk calls");
 #pragma unroll
         for (int r = 0; r < kR; ++r) gofs[r] = gofsN[r];
 
@@ -501,10 +509,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #pragma unroll
                     for (int g = 0; g < 4; ++g) bias4[u][g] = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 4 * h + 32 * u + 8 * g);
             }
+            // rule F pivots: the channel's bias ROUNDED TO HALF (any pivot serves as long as the fold adds the same one back; a half pivot lets the
+            // full-tile path subtract on the packed halfs): as floats for the ragged path, as (p, p) pairs for the packed one
             f4 piv0, piv1;
+            h2 pivh[8];
             if (STATS) {
                 piv0 = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 8 * (lane & 7));
                 piv1 = *reinterpret_cast<const f4*>(biasTab + wn * 64 + 8 * (lane & 7) + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 q0 = static_cast<_Float16>(piv0[e]), q1 = static_cast<_Float16>(piv1[e]);
+                    pivh[e] = h2{q0, q0};
+                    pivh[4 + e] = h2{q1, q1};
+                    piv0[e] = static_cast<float>(q0);
+                    piv1[e] = static_cast<float>(q1);
+                }
             }
             // a tile inside the map (all but the last tile row / column): no per-lane tests, the stores' addresses are one constant lane offset + a scalar
             const bool full = oy0 + 4 <= static_cast<unsigned>(p.OH) && ox0 + 32 <= static_cast<unsigned>(p.OW);
@@ -559,12 +578,36 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
                         sB[e] = fmaf(f, f, sB[e]);
                     }
                 };
-                if (full) {
+                // full tiles: two pixels at a time -- v_perm pairs the two pixels' values of a channel, the pivot comes off both with one packed
+                // subtraction, v_dot2c adds (d0 + d1) and (d0 d0 + d1 d1) to the fp32 sums: 2 vector instructions per value instead of 4 (convert,
+                // subtract, add, fma).  The subtraction rounds to half: exact whenever value and pivot lie within a factor of two of each other
+                // (the offset layers), 2^-11 relative to the DEVIATION otherwise
+                auto stat_pair = [&](const f4& va, const f4& vb) {
+                    const h2 one2 = {static_cast<_Float16>(1.0f), static_cast<_Float16>(1.0f)};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (STATS) stat_add(pk[j]);
-                        store16_buf(yRsrc, laneOut, rowB + j * 8 * (OC * 2), pk[j]);
+                    for (int k = 0; k < 4; ++k) {
+                        const float fa = va[k], fb = vb[k]; // (element copies first: __builtin_bit_cast on a vector ELEMENT expression reads element 0)
+                        const unsigned xa = __builtin_bit_cast(unsigned, fa), xb = __builtin_bit_cast(unsigned, fb);
+                        const h2 dl = __builtin_bit_cast(h2, __builtin_amdgcn_perm(xb, xa, 0x05040100u)) - pivh[2 * k];     // channel 2k of both pixels
+                        const h2 dh = __builtin_bit_cast(h2, __builtin_amdgcn_perm(xb, xa, 0x07060302u)) - pivh[2 * k + 1]; // channel 2k + 1
+                        sA[2 * k] = __builtin_amdgcn_fdot2(dl, one2, sA[2 * k], false);
+                        sB[2 * k] = __builtin_amdgcn_fdot2(dl, dl, sB[2 * k], false);
+                        sA[2 * k + 1] = __builtin_amdgcn_fdot2(dh, one2, sA[2 * k + 1], false);
+                        sB[2 * k + 1] = __builtin_amdgcn_fdot2(dh, dh, sB[2 * k + 1], false);
                     }
+                };
+                if (full) {
+                    if (STATS) {
+#ifdef SNNHIP_WIDEP_STATS_SCALAR // experiment build: the per-value form (A/B of the packed one)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) stat_add(pk[j]);
+#else
+                        stat_pair(pk[0], pk[1]);
+                        stat_pair(pk[2], pk[3]);
+#endif
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) store16_buf(yRsrc, laneOut, rowB + j * 8 * (OC * 2), pk[j]);
                 } else {
                     const bool rowIn = oy < static_cast<unsigned>(p.OH);
 #pragma unroll

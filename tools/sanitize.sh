@@ -12,7 +12,7 @@ if [ "${1:-cpu}" = "guard" ]; then
   python -c "import __graft_entry__ as g; g.build_hip(); g.build_host()"
   [ -f build/abl/libsnnhip_guardbreak.so ] || tools/exp_one.sh conv2d_generic.hip guardbreak:-DSNNHIP_GUARD_BREAK=1 > /dev/null
   python -m pytest tests/test_guard_gpu.py -q -m gpu -x
-  SNNHIP_GUARD=1 python -m pytest tests/test_conv_fuzz_gpu.py tests/test_ops_fuzz_gpu.py tests/test_irb_gpu.py tests/test_conv_wide_gpu.py tests/test_espcn_gpu.py -q -m gpu -x
+  SNNHIP_GUARD=1 python -m pytest tests/test_conv_fuzz_gpu.py tests/test_ops_fuzz_gpu.py tests/test_irb_gpu.py tests/test_conv_wide_gpu.py tests/test_conv_widep_gpu.py tests/test_espcn_gpu.py -q -m gpu -x
   SNNHIP_GUARD=1 python -m pytest tests/test_configs_gpu.py tests/test_golden.py -q -m gpu -x -k "not c5"
   exit 0
 fi

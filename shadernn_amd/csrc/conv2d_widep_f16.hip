@@ -400,8 +400,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
-#ifdef SNNHIP_WIDEP_PRIO
-        __builtin_amdgcn_s_setprio(SNNHIP_WIDEP_PRIO);
+        // The two blocks of a CU (b and b + G / 2: workgroups fill every CU's first slot before any second one) take turns at the higher wave priority,
+        // tile by tile.  Measured, not derived: -1.2 ... -1.6 % on the layer in ABAB runs on two boxes (round 5); the same priority for the whole K loop,
+        // for the block dispatched second, or for the wave in its epilogue changed nothing
+#ifndef SNNHIP_WIDEP_NO_PRIO_ALT // (experiment builds switch it off)
+        if ((it + (blockIdx.x >= (G >> 1) ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
 #endif
         // (the four chunks as four calls of one body with a compile-time c instead of a `#pragma unroll` loop: the same code with 20-30 fewer scalar
         // registers spilled to vector lanes -- v_readlane / v_writelane are vector instructions inside the K-steps)
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #pragma unroll
         for (int r = 0; r < kR; ++r) gofs[r] = gofsN[r];
 
-#ifdef SNNHIP_WIDEP_PRIO
+#ifndef SNNHIP_WIDEP_NO_PRIO_ALT
         __builtin_amdgcn_s_setprio(0);
 #endif
         // ---- epilogue (wave-private): accumulator layout acc[t][u][4 g + k] = channel 64 wn + 32 u + 8 g + 4 h + k of pixel (row 4 wm + t, column l32)
@@ -535,16 +539,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             // (sum first, bias second: the order of conv2d_wide_kernel, whose fused-Add form must give the bits of this layer + an Add launch)
-                            h4 o;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(acc[t][u][4 * g + k] + bias4[u][g][k]);
+                            // as two aligned pairs: v_pk_add_f32 + v_cvt_pk_f16_f32 each.  Written element by element the vectoriser paired elements
+                            // (1, 2) and moved them, and their bias, into fresh register pairs: 13 instructions per four values instead of 4
+                            typedef float f2 __attribute__((ext_vector_type(2)));
+                            const f2 s01 = f2{acc[t][u][4 * g], acc[t][u][4 * g + 1]} + f2{bias4[u][g][0], bias4[u][g][1]};
+                            const f2 s23 = f2{acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]} + f2{bias4[u][g][2], bias4[u][g][3]};
+                            h2 lo2 = __builtin_convertvector(s01, h2), hi2 = __builtin_convertvector(s23, h2);
                             if (FAST == 1) { // ReLU on the rounded halfs (same bits as max-then-round)
-                                h2 lo2 = {o[0], o[1]}, hi2 = {o[2], o[3]};
                                 const h2 z2 = {static_cast<_Float16>(0.0f), static_cast<_Float16>(0.0f)};
                                 lo2 = __builtin_elementwise_max(lo2, z2);
                                 hi2 = __builtin_elementwise_max(hi2, z2);
-                                o = h4{lo2[0], lo2[1], hi2[0], hi2[1]};
                             }
+                            const h4 o = h4{lo2[0], lo2[1], hi2[0], hi2[1]};
                             *reinterpret_cast<h4*>(scr + scrW + (32 * u + 8 * g) * 2) = o;
                         }
                 } else {

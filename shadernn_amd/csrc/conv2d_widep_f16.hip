@@ -347,8 +347,36 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
     };
 
     // ---- first tile: tables, map, chunk 0, weight ring
-    const unsigned runLen = p.tilesBase + (blockIdx.x < p.tilesRem ? 1u : 0u);
-    unsigned tile = blockIdx.x * p.tilesBase + (blockIdx.x < p.tilesRem ? blockIdx.x : p.tilesRem);
+    // Which run of tiles.  Workgroups go to the eight XCDs round-robin by index: runs handed out by blockIdx.x put vertically neighbouring tiles -- one run
+    // apart or two -- into different L2s, and every halo row was fetched from the memory side twice (PMC: 1.5x the algorithmic bytes).  So: segment x of
+    // the tile order (one contiguous eighth: two images of a 16-image batch) belongs to XCD x, physical block x + 8 j takes run j of it.  The tiles / G
+    // remainder stays with the first-dispatched blocks (physical index < tilesRem), i.e. spread over all XCDs: the first ex(x) runs of segment x are one
+    // tile longer.  With G not a multiple of 8 there is one segment and this is the plain scheme (runs by blockIdx.x).
+#ifdef SNNHIP_WIDEP_NO_XCD_RUNS // (experiment builds)
+    const unsigned nSeg = 1u;
+#else
+    const unsigned nSeg = (G & 7u) == 0 ? 8u : 1u;
+#endif
+    const unsigned segRuns = G / nSeg;
+    auto seg_extras = [&](unsigned x) -> unsigned { // runs of segment x with tilesBase + 1 tiles
+        if (nSeg == 1u) return p.tilesRem;
+        return p.tilesRem > x ? min(segRuns, (p.tilesRem - x + 7u) >> 3) : 0u;
+    };
+    auto run_of_tile = [&](unsigned t) -> unsigned { // the (logical) run that holds tile t
+        unsigned x = 0, S = 0;
+        for (; x + 1 < nSeg; ++x) {
+            const unsigned nextS = S + segRuns * p.tilesBase + seg_extras(x);
+            if (t < nextS) break;
+            S = nextS;
+        }
+        const unsigned ex = seg_extras(x), tt = t - S, cut = ex * (p.tilesBase + 1);
+        return x * segRuns + (tt < cut ? tt / (p.tilesBase + 1) : ex + (tt - cut) / p.tilesBase);
+    };
+    const unsigned segX = nSeg == 1u ? 0u : blockIdx.x & 7u, segJ = nSeg == 1u ? blockIdx.x : blockIdx.x >> 3;
+    const unsigned bid = segX * segRuns + segJ; // logical run index: the order of the runs in the tile sequence
+    unsigned tile = segX * segRuns * p.tilesBase + segJ * p.tilesBase + min(segJ, seg_extras(segX));
+    for (unsigned x = 0; x < segX; ++x) tile += seg_extras(x);
+    const unsigned runLen = p.tilesBase + (segJ < seg_extras(segX) ? 1u : 0u);
     const unsigned tileEnd = tile + runLen;
     waveLds = __builtin_amdgcn_readfirstlane(waveLds);
     resolve_tables(tile);
@@ -658,9 +686,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
             const unsigned nNext = hasNext ? next / p.tilesPerImage : ~0u;
             if (nNext != n) {
                 const unsigned lane = tq & 63u, wm = (tq >> 6) & 1u, wn = tq >> 7;
-                const unsigned bT = p.tilesBase + 1, cut = p.tilesRem * bT, t0 = n * p.tilesPerImage, t1 = t0 + p.tilesPerImage - 1; // first / last tile of the image
-                const unsigned bFirst = t0 < cut ? t0 / bT : p.tilesRem + (t0 - cut) / p.tilesBase, bLast = t1 < cut ? t1 / bT : p.tilesRem + (t1 - cut) / p.tilesBase;
-                float* const rec = p.statRec + (static_cast<size_t>(n) * p.recsMax + (blockIdx.x - bFirst)) * kRecFloats;
+                const unsigned t0 = n * p.tilesPerImage, t1 = t0 + p.tilesPerImage - 1; // first / last tile of the image
+                const unsigned bFirst = run_of_tile(t0), bLast = run_of_tile(t1);
+                float* const rec = p.statRec + (static_cast<size_t>(n) * p.recsMax + (bid - bFirst)) * kRecFloats;
                 float* const po = rec + 4 + wm * 256 + wn * 64 + lane;
                 asm volatile("global_store_dword %0, %1, off sc1\n\tglobal_store_dword %0, %2, off offset:512 sc1" ::"v"(po), "v"(stS1), "v"(stS2) : "memory");
                 if (wn == 0 && lane == 0) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(rec + wm), "v"(stCnt) : "memory");

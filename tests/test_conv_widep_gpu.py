@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 MAPS = [(1, 8, 32), (2, 19, 45), (1, 37, 70), (3, 9, 33), (4, 5, 7), (1, 8, 300), (5, 17, 65)]
 
 
-@pytest.mark.parametrize("grid", ["", "1", "3", "7"], ids=lambda g: "grid" + (g or "auto"))
+@pytest.mark.parametrize("grid", ["", "1", "3", "7", "8", "16"], ids=lambda g: "grid" + (g or "auto"))  # (8, 16: the XCD-segment run layout)
 @pytest.mark.parametrize("nhw", MAPS, ids=lambda c: "x".join(map(str, c)))
 def test_widep_is_bit_identical_to_the_block_per_tile_kernel(ctx, monkeypatch, nhw, grid):
     N, H, W = nhw
@@ -47,7 +47,7 @@ def test_widep_is_bit_identical_to_the_block_per_tile_kernel(ctx, monkeypatch, n
             np.testing.assert_allclose(y, want, err_msg=desc, **TOLH)
 
 
-@pytest.mark.parametrize("grid", ["", "1", "3", "7"], ids=lambda g: "grid" + (g or "auto"))
+@pytest.mark.parametrize("grid", ["", "1", "3", "7", "8", "16"], ids=lambda g: "grid" + (g or "auto"))  # (8, 16: the XCD-segment run layout)
 @pytest.mark.parametrize("n,h,w,offset", [(3, 19, 45, 0.0), (5, 9, 70, 6.0), (2, 30, 33, 0.0)])
 def test_widep_block_records_feed_the_instancenorm_for_any_grid(ctx, monkeypatch, n, h, w, offset, grid):
     """Chain rule F on the persistent kernel: ONE record per (block, image), written when a block's run of tiles leaves the image; the block that

@@ -361,6 +361,13 @@ __global__ __launch_bounds__(256, WPS) void conv_kxk_c1o16_wino3x3_c16o16_kernel
     tile_origin(tile, n, x0, y0);
     const int next = tile + gridDim.x;
     const bool more = next < ntiles;
+    // The two blocks of a CU (b and b + grid / 2: workgroups fill every CU's first slot before any second one) take turns at the higher wave priority,
+    // tile by tile -- conv2d_widep_f16.hip's rule, measured here as well: kernel A 75.4 -> 73.5 us in six of six ABAB pairs on one box (round 5), the
+    // headline 9.26 k -> 9.41 k images/s there.  Recorded as measured, not derived
+#ifndef SNNHIP_ESPCN_NO_PRIO_ALT // (experiment builds switch it off)
+    if (((tile / static_cast<int>(gridDim.x)) + (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
     if (more) issue_loads(next);
     const bool border = x0 == 0 || y0 == 0 || x0 + TW >= p.W || y0 + TH >= p.H; // wave-uniform
 

@@ -1,8 +1,11 @@
-// dp.cpp -- JSON model -> layer DAG -> InferenceGraph (reference core/src/ic2/dp.cpp:115-167, 389-640).
-#include <map>
-#include <queue>
-#include <sstream>
+// dp.cpp -- JSON model -> layer DAG -> InferenceGraph.  The interface (ic2/dp.h) and the observable results -- stage order, names, descriptors, the layer
+// table in the log -- are the reference's (core/src/ic2/dp.cpp:115-167 model loading, :389-429 ordering, :432-640 graph generation); the construction is
+// this repository's: layers are numbered once, the order is computed over index arrays, and a small builder owns the per-stage bookkeeping.
+#include <algorithm>
+#include <cstdio>
+#include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "ic2/dp.h"
 #include "ic2/layerFactory.h"
@@ -10,194 +13,244 @@
 using namespace snn;
 using namespace snn::dp;
 
+namespace {
+
+typedef std::shared_ptr<GenericModelLayer> LayerPtr;
+
+std::string baseName(const std::string& path) {
+    const size_t cut = path.find_last_of('/');
+    return cut == std::string::npos ? path : path.substr(cut + 1);
+}
+
+// Stage order: breadth-first by resolved dependencies, ties in the order the layers were handed in (the order the reference's queue-based pass produces,
+// dp.cpp:389-429 -- stage indices name dump files and timers, so the order is part of the contract).  Index arrays instead of pointer-keyed maps.
+std::vector<LayerPtr> stageOrder(const std::vector<LayerPtr>& layers) {
+    const size_t count = layers.size();
+    std::unordered_map<const GenericModelLayer*, size_t> slot;
+    slot.reserve(count);
+    for (size_t i = 0; i < count; ++i) slot.emplace(layers[i].get(), i);
+    std::vector<size_t> pending(count, 0); // unresolved producers per layer
+    for (const LayerPtr& layer : layers)
+        for (const LayerPtr& consumer : layer->nextLayers) {
+            auto it = slot.find(consumer.get());
+            if (it != slot.end()) pending[it->second]++;
+        }
+    std::vector<size_t> ready; // a FIFO that is never popped: `head` walks it
+    ready.reserve(count);
+    for (size_t i = 0; i < count; ++i)
+        if (pending[i] == 0) ready.push_back(i);
+    for (size_t head = 0; head < ready.size(); ++head)
+        for (const LayerPtr& consumer : layers[ready[head]]->nextLayers) {
+            auto it = slot.find(consumer.get());
+            if (it != slot.end() && --pending[it->second] == 0) ready.push_back(it->second);
+        }
+    if (ready.size() != count) SNN_LOGW("the layer graph has a cycle: %zu of %zu layers can be ordered", ready.size(), count);
+    std::vector<LayerPtr> ordered;
+    ordered.reserve(ready.size());
+    for (size_t i : ready) ordered.push_back(layers[i]);
+    return ordered;
+}
+
+// The layer table of the log (same columns as the reference prints, dp.cpp:482-636)
+class LayerTable {
+public:
+    LayerTable() {
+        rule('=');
+        text += "|  Layer ID  |              Name                 | Output Dims |\n";
+        rule('=');
+    }
+    void row(size_t id, const std::string& fullName, uint32_t w, uint32_t h, uint32_t d) {
+        const size_t bracket = fullName.find('[');
+        std::string name = bracket == std::string::npos ? fullName : fullName.substr(bracket);
+        if (name.size() > 34) name = name.substr(0, 31) + "...";
+        char dims[64];
+        snprintf(dims, sizeof(dims), "%u x %u x %u", w, h, d);
+        char line[160];
+        snprintf(line, sizeof(line), "| %-*zu| %-34s| %-12s|\n", 11, id, name.c_str(), dims);
+        text += line;
+        rule('-');
+    }
+    const std::string& finish() {
+        rule('=');
+        return text;
+    }
+
+private:
+    void rule(char c) { text += std::string(64, c) + "\n"; }
+    std::string text;
+};
+
+// One pass over the ordered layers: stage records, input wiring, output descriptors, inference passes
+class GraphBuilder {
+public:
+    GraphBuilder(const ShaderGenOptions& o) : options(o), format(o.preferrHalfPrecision ? ColorFormat::RGBA16F : ColorFormat::RGBA32F) {
+        graph.mrtMode = o.mrtMode;
+        graph.weightMode = o.weightMode;
+    }
+
+    InferenceGraph build(const std::vector<LayerPtr>& ordered) {
+        for (const LayerPtr& layer : ordered) addStage(layer);
+        LayerTable table;
+        for (size_t i = 0; i < ordered.size(); ++i) {
+            uint32_t w = 0, h = 0, d = 0;
+            describeStage(i, ordered[i], w, h, d);
+            table.row(i, ordered[i]->getName(), w, h, d);
+        }
+        graph.inputsDesc = options.desiredInput;
+        SNN_LOGI("\n%s", table.finish().c_str());
+        return std::move(graph);
+    }
+
+private:
+    const ShaderGenOptions& options;
+    const ColorFormat format;
+    InferenceGraph graph;
+    std::unordered_map<const GenericModelLayer*, int> stageOf;
+    uint32_t inputStages = 0;
+
+    // the descriptor of model input `idx`.  The reference passes channels = 4 * depth (dp.cpp:506-508); the true count, when the caller gives one, lets
+    // the NHWC tensors carry exactly C channels
+    InferenceGraph::IODesc modelInput(uint32_t idx) const {
+        SNN_CHK(idx < options.desiredInput.size());
+        const auto& want = options.desiredInput[idx];
+        return InferenceGraph::IODesc{format, want.width, want.height, want.depth, want.channels ? want.channels : 4 * want.depth, options.batch};
+    }
+
+    void addStage(const LayerPtr& layer) {
+        graph.layers.emplace_back(new InferenceGraph::Layer);
+        InferenceGraph::Layer& stage = *graph.layers.back();
+        stage.modelLayer = layer.get();
+        stage.name = layer->getName();
+        stage.layerLoc = layer->getLayerExecutionType();
+        stage.isInputLayer = layer->isInputLayer();
+        if (stage.isInputLayer) {
+            stage.inputIndex = layer->getInputIndex();
+            ++inputStages;
+        }
+        stage.imageTextureFunPtr = [layer](ImageTextureArray& in, ImageTextureArray& out) { layer->computeImageTexture(in, out); };
+        stage.initFunPtr = [layer](DeviceBackend* backend, ImageTextureArray& in, ImageTextureArray& out) { layer->init(backend, in, out); };
+        stage.runFunPtr = [layer](DeviceBackend* backend, bool dumpOutputs) { layer->run(backend, dumpOutputs); };
+    }
+
+    // what stage `producer` hands to a consumer: a model input's descriptor (with the InputLayer's "outputPlanes" as the true channel count) or the
+    // producing stage's output
+    InferenceGraph::IODesc feed(const LayerPtr& producer, InferenceGraph::LayerRef& ref) const {
+        ref.index = stageOf.at(producer.get());
+        ref.isStageOutput = !producer->isInputLayer();
+        if (ref.isStageOutput) return graph.layers[static_cast<size_t>(ref.index)]->outputDesc;
+        InferenceGraph::IODesc desc = modelInput(producer->getInputIndex());
+        if (producer->getDesc().numOutputPlanes) desc.channels = producer->getDesc().numOutputPlanes;
+        return desc;
+    }
+
+    void describeStage(size_t i, const LayerPtr& layer, uint32_t& width, uint32_t& height, uint32_t& depth) {
+        InferenceGraph::Layer& stage = *graph.layers[i];
+        layer->setMRTMode(options.mrtMode);
+        layer->setWeightAccessMode(options.weightMode);
+        stageOf[layer.get()] = static_cast<int>(i);
+
+        uint32_t inW = 0, inH = 0; // the largest input extent: what a GPU stage is generated for
+        if (layer->prevLayers.empty()) { // a model input
+            InferenceGraph::LayerRef ref;
+            ref.index = -1;
+            ref.isStageOutput = false;
+            const InferenceGraph::IODesc desc = modelInput(layer->getInputIndex());
+            layer->addInputDim(desc);
+            inW = desc.width;
+            inH = desc.height;
+            stage.inputRefs.push_back(ref);
+        } else {
+            for (const LayerPtr& producer : layer->prevLayers) {
+                InferenceGraph::LayerRef ref;
+                const InferenceGraph::IODesc desc = feed(producer, ref);
+                layer->addInputDim(desc);
+                inW = std::max(inW, desc.width);
+                inH = std::max(inH, desc.height);
+                stage.inputRefs.push_back(ref);
+            }
+        }
+        layer->getOutputDims(width, height, depth);
+
+        if (stage.layerLoc == InferenceGraph::LayerExecutionType::CPU) {
+            if (i == 0) SNN_RIP("CPU layer currently cannot cannot be the 1-st layer in the graph !");
+            if (options.batch != 1)
+                SNN_RIP("CPU layer %s: CPU stages (the YOLO head) take one image per inference, batch = %u", layer->getName().c_str(), options.batch);
+            stage.outputDesc = {format, width, height, depth, layer->getDesc().numOutputPlanes};
+            return;
+        }
+        describeGpuStage(i, layer, stage, inW, inH, width, height);
+    }
+
+    void describeGpuStage(size_t i, const LayerPtr& layer, InferenceGraph::Layer& stage, uint32_t inW, uint32_t inH, uint32_t width, uint32_t height) {
+        if (layer->isInputLayer()) {
+            layer->setLayerExecutionType(InferenceGraph::LayerExecutionType::GPU_HIP);
+        } else {
+            GenericModelLayer::LayerGenOptions gen;
+            static_cast<ShaderGenOptions&>(gen) = options;
+            if (!gen.desiredInput.empty()) {
+                gen.desiredInput[0].width = inW;
+                gen.desiredInput[0].height = inH;
+            }
+            gen.desiredOutputWidth = width;
+            gen.desiredOutputHeight = height;
+            gen.isFirstLayer = i == inputStages;
+            gen.isLastLayer = i + 1 == graph.layers.size();
+            layer->createInferencePasses(gen);
+        }
+        stage.layerLoc = layer->getLayerExecutionType();
+        const uint32_t planes = layer->getDesc().numOutputPlanes;
+        if (layer->isInputLayer()) {
+            stage.outputDesc = modelInput(layer->getInputIndex());
+        } else if (dynamic_cast<DenseLayer*>(layer.get()) || dynamic_cast<FlattenLayer*>(layer.get())) {
+            // Dense: a units x 1 x 1 single-channel image in the reference (denselayer.cpp:40-55, CPU-stage descriptor dp.cpp:365-367) -- it runs on the
+            // GPU here but keeps that shape; Flatten: W*H*C x 1 x 1, one channel (flattenlayer.cpp:48-62)
+            stage.outputDesc = {format, width, 1, 1, 1, options.batch};
+            stage.flattenLayer = true;
+        } else {
+            stage.outputDesc = {format, width, height, static_cast<uint32_t>(DIV_4_ROUND_UP(planes)), planes, options.batch}; // (dp.cpp:328-332)
+        }
+        SNN_ASSERT(stage.outputDesc.width > 0 && stage.outputDesc.height > 0);
+    }
+};
+
+} // namespace
+
 InferenceModel snn::dp::loadFromJsonModel(const std::string& fileName, bool useVulkan, const MRTMode& mrtMode, const WeightAccessMethod& weightMode,
                                           bool preferHp) {
-    InferenceModel layers;
     ModelParser parser({fileName, preferHp, mrtMode, weightMode});
-    const int32_t layerCount = parser.getLayerCount();
     initLayerRegisty();
-    const size_t slash = fileName.find_last_of('/');
-    const std::string shortName = slash == std::string::npos ? fileName : fileName.substr(slash + 1);
-    for (int i = 0; i < layerCount; i++) {
+    const std::string file = baseName(fileName);
+    const int32_t count = parser.getLayerCount();
+    InferenceModel model;
+    model.reserve(static_cast<size_t>(std::max(count, 0)));
+    for (int32_t i = 0; i < count; ++i) {
         SNN_ASSERT(parser.getNumInbound(i) == static_cast<int>(parser.getInboundLayerId(i).size()));
-        const std::string layerName = parser.getLayerName(i);
-        layers.emplace_back(std::shared_ptr<GenericModelLayer>(createLayerInstance(layerName, parser, i, useVulkan)));
-        layers.back()->setName(formatString("%s layer [%02d] %s", shortName.c_str(), i, layerName.c_str())); // dp.cpp:134
+        const std::string kind = parser.getLayerName(i);
+        model.emplace_back(createLayerInstance(kind, parser, i, useVulkan));
+        model.back()->setName(formatString("%s layer [%02d] %s", file.c_str(), i, kind.c_str())); // (the reference's stage names, dp.cpp:134)
     }
-    if (layers.empty()) {
+    if (model.empty()) {
         SNN_LOGE("head layer not found.");
         return {};
     }
-    for (int i = 0; i < layerCount; i++) { // build layer connections (dp.cpp:144-156)
-        for (int ii : parser.getInboundLayerId(i)) {
-            layers[static_cast<size_t>(i)]->prevLayers.push_back(layers[static_cast<size_t>(ii)]);
-            layers[static_cast<size_t>(ii)]->nextLayers.push_back(layers[static_cast<size_t>(i)]);
+    for (int32_t i = 0; i < count; ++i) // edges, both directions
+        for (int producer : parser.getInboundLayerId(i)) {
+            model[static_cast<size_t>(i)]->prevLayers.push_back(model[static_cast<size_t>(producer)]);
+            model[static_cast<size_t>(producer)]->nextLayers.push_back(model[static_cast<size_t>(i)]);
         }
-    }
-    return layers;
-}
-
-// Kahn's algorithm over all layers (dp.cpp:389-429)
-static std::vector<std::shared_ptr<GenericModelLayer>> topologicalSort2(const std::vector<std::shared_ptr<GenericModelLayer>>& layers) {
-    std::vector<std::shared_ptr<GenericModelLayer>> sorted;
-    std::unordered_map<GenericModelLayer*, size_t> inDegree;
-    for (auto& n : layers)
-        for (auto& nx : n->nextLayers) inDegree[nx.get()]++;
-    std::queue<std::shared_ptr<GenericModelLayer>> processing;
-    for (auto& n : layers)
-        if (inDegree[n.get()] == 0) processing.push(n);
-    while (!processing.empty()) {
-        auto n = processing.front();
-        processing.pop();
-        sorted.push_back(n);
-        for (auto& nx : n->nextLayers)
-            if (--inDegree[nx.get()] == 0) processing.push(nx);
-    }
-    if (sorted.size() != layers.size()) SNN_LOGW("There exists a cycle in the graph !");
-    return sorted;
+    return model;
 }
 
 InferenceGraph snn::dp::generateInferenceGraph(std::vector<std::shared_ptr<GenericModelLayer>>& layers, const ShaderGenOptions& options) {
-    auto modelLayers = topologicalSort2(layers);
-    InferenceGraph graph;
-    graph.mrtMode = options.mrtMode;
-    graph.weightMode = options.weightMode;
-    std::map<GenericModelLayer*, size_t> s2i;
-    uint32_t inputLayers = 0;
-    const ColorFormat fmt = options.preferrHalfPrecision ? ColorFormat::RGBA16F : ColorFormat::RGBA32F;
-
-    for (auto& modelLayer : modelLayers) { // dp.cpp:446-478
-        graph.layers.emplace_back(new InferenceGraph::Layer);
-        auto* igLayer = graph.layers.back().get();
-        igLayer->imageTextureFunPtr = [modelLayer](ImageTextureArray& in, ImageTextureArray& out) { modelLayer->computeImageTexture(in, out); };
-        igLayer->initFunPtr = [modelLayer](DeviceBackend* backend, ImageTextureArray& in, ImageTextureArray& out) { modelLayer->init(backend, in, out); };
-        igLayer->runFunPtr = [modelLayer](DeviceBackend* backend, bool dumpOutputs) { modelLayer->run(backend, dumpOutputs); };
-        igLayer->modelLayer = modelLayer.get();
-        igLayer->layerLoc = modelLayer->getLayerExecutionType();
-        igLayer->name = modelLayer->getName();
-        igLayer->isInputLayer = modelLayer->isInputLayer();
-        if (modelLayer->isInputLayer()) {
-            inputLayers++;
-            igLayer->inputIndex = modelLayer->getInputIndex();
-        }
-    }
-
-    std::ostringstream modelFormat;
-    modelFormat << "================================================================\n";
-    modelFormat << "|  Layer ID  |              Name                 | Output Dims |\n";
-    modelFormat << "================================================================\n";
-    for (size_t i = 0; i < graph.layers.size(); ++i) { // dp.cpp:491-632
-        auto* igLayer = graph.layers[i].get();
-        auto& modelLayer = modelLayers[i];
-        modelLayer->setMRTMode(options.mrtMode);
-        modelLayer->setWeightAccessMode(options.weightMode);
-        s2i[modelLayer.get()] = i;
-        uint32_t inputWidth = 0, inputHeight = 0, width = 0, height = 0, depth = 0;
-        auto inputDesc = [&](uint32_t idx) {
-            SNN_CHK(idx < options.desiredInput.size());
-            const auto& di = options.desiredInput[idx];
-            // the reference passes channels = 4*depth for model inputs (dp.cpp:506-508); the true count, when the caller
-            // gives one, lets the NHWC tensors carry exactly C channels
-            return InferenceGraph::IODesc{fmt, di.width, di.height, di.depth, di.channels ? di.channels : 4 * di.depth, options.batch};
-        };
-        if (!modelLayer->prevLayers.empty()) {
-            for (auto& prev : modelLayer->prevLayers) {
-                InferenceGraph::LayerRef ref;
-                ref.index = static_cast<int>(s2i[prev.get()]);
-                InferenceGraph::IODesc imageInput;
-                if (prev->isInputLayer()) {
-                    ref.isStageOutput = false;
-                    imageInput = inputDesc(prev->getInputIndex());
-                    if (prev->getDesc().numOutputPlanes) imageInput.channels = prev->getDesc().numOutputPlanes; // InputLayer "outputPlanes" = true channels
-                } else {
-                    ref.isStageOutput = true;
-                    imageInput = graph.layers[static_cast<size_t>(ref.index)]->outputDesc;
-                }
-                modelLayer->addInputDim(imageInput);
-                inputWidth = std::max(inputWidth, imageInput.width);
-                inputHeight = std::max(inputHeight, imageInput.height);
-                igLayer->inputRefs.push_back(ref);
-            }
-            modelLayer->getOutputDims(width, height, depth);
-        } else { // input layers
-            InferenceGraph::LayerRef ref;
-            ref.isStageOutput = false;
-            ref.index = -1;
-            auto imageInput = inputDesc(modelLayer->getInputIndex());
-            modelLayer->addInputDim(imageInput);
-            inputWidth = imageInput.width;
-            inputHeight = imageInput.height;
-            modelLayer->getOutputDims(width, height, depth);
-            igLayer->inputRefs.push_back(ref);
-        }
-        const std::string& nm = modelLayer->getName();
-        const size_t br = nm.find('[');
-        std::string layerName = br == std::string::npos ? nm : nm.substr(br);
-        if (layerName.size() > 34) layerName = layerName.substr(0, 31) + "...";
-        const std::string dims = std::to_string(width) + " x " + std::to_string(height) + " x " + std::to_string(depth);
-        modelFormat << "| " << i << std::string(i > 9 ? 9 : 10, ' ') << "| " << layerName << std::string(34 - layerName.size(), ' ') << "| " << dims
-                    << std::string(dims.size() < 12 ? 12 - dims.size() : 0, ' ') << "|\n";
-
-        if (igLayer->layerLoc != InferenceGraph::LayerExecutionType::CPU) {
-            GenericModelLayer::LayerGenOptions opt;
-            static_cast<ShaderGenOptions&>(opt) = options;
-            if (!opt.desiredInput.empty()) {
-                opt.desiredInput[0].width = inputWidth;
-                opt.desiredInput[0].height = inputHeight;
-            }
-            opt.desiredOutputWidth = width;
-            opt.desiredOutputHeight = height;
-            opt.isFirstLayer = (i == inputLayers);
-            opt.isLastLayer = (i == graph.layers.size() - 1);
-            if (modelLayer->isInputLayer()) {
-                modelLayer->setLayerExecutionType(InferenceGraph::LayerExecutionType::GPU_HIP);
-            } else {
-                modelLayer->createInferencePasses(opt);
-            }
-            igLayer->layerLoc = modelLayer->getLayerExecutionType();
-            igLayer->outputDesc = {fmt, width, height, static_cast<uint32_t>(DIV_4_ROUND_UP(modelLayer->getDesc().numOutputPlanes)),
-                                   modelLayer->getDesc().numOutputPlanes, options.batch}; // dp.cpp:328-332
-            if (modelLayer->isInputLayer()) igLayer->outputDesc = inputDesc(modelLayer->getInputIndex());
-            if (dynamic_cast<DenseLayer*>(modelLayer.get())) {
-                // Dense output is a units x 1 x 1 single-channel image in the reference (denselayer.cpp:40-55, CPU-stage
-                // descriptor dp.cpp:365-367); it runs on the GPU here but keeps that shape
-                igLayer->outputDesc = {fmt, width, 1, 1, 1, options.batch};
-                igLayer->flattenLayer = true;
-            }
-            if (dynamic_cast<FlattenLayer*>(modelLayer.get())) { // W*H*C x 1 x 1, one channel (flattenlayer.cpp:48-62)
-                igLayer->outputDesc = {fmt, width, 1, 1, 1, options.batch};
-                igLayer->flattenLayer = true;
-            }
-            SNN_ASSERT(igLayer->outputDesc.width > 0 && igLayer->outputDesc.height > 0);
-        } else {
-            if (i == 0) SNN_RIP("CPU layer currently cannot cannot be the 1-st layer in the graph !");
-            if (options.batch != 1) SNN_RIP("CPU layer %s: CPU stages (the YOLO head) take one image per inference, batch = %u", modelLayer->getName().c_str(), options.batch);
-            igLayer->outputDesc = {fmt, width, height, depth, modelLayer->getDesc().numOutputPlanes};
-        }
-        modelFormat << "----------------------------------------------------------------\n";
-    }
-    graph.inputsDesc = options.desiredInput;
-    modelFormat << "================================================================\n";
-    SNN_LOGI("\n%s", modelFormat.str().c_str());
-    return graph;
+    return GraphBuilder(options).build(stageOrder(layers));
 }
 
 InferenceGraph snn::dp::generateInferenceGraph(const std::shared_ptr<GenericModelLayer> firstLayer, const ShaderGenOptions& options) {
-    // collect everything reachable from the head (the reference walks nextLayers with a BFS, dp.cpp:33-55)
-    std::vector<std::shared_ptr<GenericModelLayer>> all;
-    std::queue<std::shared_ptr<GenericModelLayer>> q;
-    std::map<GenericModelLayer*, bool> seen;
-    q.push(firstLayer);
-    seen[firstLayer.get()] = true;
-    while (!q.empty()) {
-        auto n = q.front();
-        q.pop();
-        all.push_back(n);
-        for (auto& nx : n->nextLayers)
-            if (!seen[nx.get()]) {
-                seen[nx.get()] = true;
-                q.push(nx);
-            }
-    }
-    return generateInferenceGraph(all, options);
+    // everything reachable from the head, breadth first (the single-input form of the reference walks nextLayers the same way, dp.cpp:33-55)
+    std::vector<LayerPtr> reach{firstLayer};
+    std::unordered_map<const GenericModelLayer*, bool> seen{{firstLayer.get(), true}};
+    for (size_t head = 0; head < reach.size(); ++head)
+        for (const LayerPtr& next : reach[head]->nextLayers)
+            if (seen.emplace(next.get(), true).second) reach.push_back(next);
+    return generateInferenceGraph(reach, options);
 }

@@ -598,3 +598,22 @@ def test_pool_and_cli_fail_loudly_without_a_gpu(built, tmp_path):
         pass
     else:
         raise AssertionError("snn_pool_create succeeded without a GPU")
+
+
+def test_stage_graphs_of_the_bench_configs_match_the_stored_ones():
+    """dp::loadFromJsonModel + dp::generateInferenceGraph (host/dp.cpp; reference core/src/ic2/dp.cpp:115-167, 389-640): stage order, stage names,
+    execution types, output dims and input references of the five BASELINE configs against tests/golden/graph_stages.json, which was written with the
+    round-4 implementation (tests/golden/make_graph_stages.py) -- the stage order names dump files and timers, so a rewrite of the file must not move it."""
+    import json
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_graph_stages
+
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph_stages.json")))
+    got = make_graph_stages.stage_graphs()
+    assert sorted(got) == sorted(want)
+    for cfg in want:
+        assert len(got[cfg]) == len(want[cfg]), cfg
+        for g, w in zip(got[cfg], want[cfg]):
+            assert g == w, (cfg, g, w)

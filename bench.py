@@ -321,8 +321,8 @@ def cpu_baseline(config, net, timed_legs=True, compact=False):
     t1 = timed(1, n_single) if n_single else None
     best_t, best_c = (tn, cores) if (t1 is None or tn <= t1) else (t1, 1)
     out = {"value": 1.0 / best_t, "unit": "images/s", "cores": best_c, "kind": "port",
-           "sample": "%d full-size image(s) of the workload (%s) through oracle/liboracle.so, the C restatement of the reference shaders, "
-                     "batch 1, all %d host threads%s" % (n_multi, cfg["workload"], cores, (" and %d single-threaded" % n_single) if n_single else ""),
+           "sample": "%d full-size image(s) of %s (batch 1) through oracle/liboracle.so (C restatement of the reference shaders), all %d host threads%s"
+                     % (n_multi, config, cores, (" + %d single-threaded" % n_single) if n_single else ""),
            "all_threads_images_per_s": 1.0 / tn, "single_thread_images_per_s": (1.0 / t1) if t1 else None, "host_threads": cores}
     if compact:
         out["sample"] = "%d image(s), all %d host threads%s; oracle/liboracle.so" % (n_multi, cores, (", %d single-threaded" % n_single) if n_single else "")
@@ -370,6 +370,93 @@ def parity_record(config, got, want):
         rec["tolerance"] = "fp16 storage vs the half-quantised oracle: q99.9(|d|) < 6e-3 * range and max |d| < 6e-2 * range"
         rec["ok"] = bool(rec["finite"] and rec["q999_err_over_range"] < 6e-3 and float(e.max()) < 6e-2)
     return rec
+
+
+# ------------------------------------------------------------------------------------------------ the printed line
+
+LINE_BUDGET = 6000  # bytes; the driver keeps a bounded tail of stdout (8 081 characters in BENCH_r05.json, whose 22.7 KB line came back parsed: null)
+
+
+def _r(v, sig=5):
+    """floats to `sig` significant digits (the line is a summary: the full-precision record is bench_detail.json)"""
+    if isinstance(v, float):
+        return float("%.*g" % (sig, v))
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def compact_line(detail, detail_path="bench_detail.json"):
+    """The ONE line rank 0 prints: the driver's standard keys, `roofline` (dominant kernel of the headline config + one short row per other config),
+    `cpu_baseline` and the in-run parity verdict -- nothing else.  In the spirit of the reference's own benchmark output, a compact table
+    (demo/common/inferenceProcessor.cpp:143-199).  Everything else (kernels, layer_table, wait_semantics, the full `configs` block) stays in `detail`,
+    which main() writes to bench_detail.json.  Pure function of the detail record (tests/test_bench_line.py builds it from a stored one)."""
+    d = detail
+    cfg = d.get("config") or {}
+    line = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value_mode"] = d.get("value_mode")
+    line["config"] = {k: cfg[k] for k in ("workload", "config_id", "global_batch", "images_per_rank_per_step", "parallelism", "backend", "ranks_per_device",
+                                          "launches_per_step", "device", "compute_units", "rccl_ranks", "collective_ranks_seen", "ranks") if k in cfg}
+    t = d.get("timing") or {}
+    line["timing"] = {k: t[k] for k in ("repeats", "min_ms_per_step", "max_ms_per_step") if k in t}
+    if d.get("ms_per_step_of_each_rank"):
+        line["ms_per_step_of_each_rank"] = d["ms_per_step_of_each_rank"]
+    par = d.get("parity")
+    line["parity"] = {k: par[k] for k in ("ok", "max_abs_err", "max_rel_err", "q999_err_over_range") if k in par} if par else None
+    if par:
+        line["parity"]["vs"] = "oracle/liboracle.so, image 0 (parity unpinned by reference fixtures)"
+    rf = d.get("roofline")
+    if rf:
+        line["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic_bytes", "kernel", "share_of_gpu_time",
+                                               "launches_per_step", "avg_launch_us", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "frac_executed",
+                                               "mfma_pipe_util_pmc", "bound_note", "whole_step_frac", "sync_per_inference_images_per_s",
+                                               "sync_per_inference_blocking_wait_images_per_s", "whole_step_frac_sync_per_inference") if rf.get(k) is not None or k == "traffic"}
+        for k in ("sum_of_kernel_durations_ms", "sum_of_launch_rooflines_ms"):
+            if k in d:
+                line["roofline"][k] = d[k]
+        if rf.get("other_configs"):
+            line["roofline"]["other_configs"] = rf["other_configs"]
+    cb = d.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "single_thread_images_per_s") if cb.get(k) is not None}
+        if len(line["cpu_baseline"].get("sample", "")) > 200:
+            line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:197] + "..."
+    if d.get("errors"):
+        line["errors"] = d["errors"]
+    line["detail"] = detail_path
+    line = _r(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_BUDGET:  # never lose the headline to a long list: drop the per-config rows first, then the optional objects
+        for victim in (("roofline", "other_configs"), ("timing",), ("config", "ranks"), ("ms_per_step_of_each_rank",)):
+            node = line
+            for k in victim[:-1]:
+                node = node.get(k) or {}
+            if victim[-1] in node:
+                node.pop(victim[-1])
+                line["truncated"] = line.get("truncated", []) + [".".join(victim)]
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= LINE_BUDGET:
+                break
+    return text
+
+
+def write_detail(detail, path=None):
+    """the full record of the run (what the line used to carry): bench_detail.json beside bench.py, and a copy under gpurun_out/ when that exists
+    (the directory gpurun merges back)"""
+    paths = [path or os.path.join(ROOT, "bench_detail.json")]
+    if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    done = []
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(detail, f, indent=1)
+            done.append(p)
+        except OSError as e:  # a read-only tree must not cost the line
+            sys.stderr.write("bench.py: could not write %s: %r\n" % (p, e))
+    return done
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -600,6 +687,16 @@ def run_config(config, args, env, primary):
         repeats = min(repeats, 5)
     samples = [first] + [timed_region(value_fn, steps) for _ in range(repeats - 1)]
     elapsed = float(np.median(samples))
+    # each rank's OWN clock over one more region of the same steps (the samples above are already the MAX over ranks): a slow GPU shows up by rank
+    own_ms = None
+    if world > 1:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            value_fn()
+        wl.sync()
+        own_ms = group.gather_values(1e3 * (time.perf_counter() - t0) / steps)
+        barrier()
 
     # the other wait semantics on the same models, same step count (host path; outside `value`)
     modes = {}
@@ -659,11 +756,16 @@ def run_config(config, args, env, primary):
             "config": {"workload": cfg["workload"], "config_id": config, "global_batch": global_batch, "images_per_rank_per_step": images,
                        "micro_batches_per_rank": wl.micro_sizes, "input": [images, H, W, cfg["cin"]],
                        "parallelism": "dp%d (batch split, weights replicated, no data-path collective)" % world,
-                       "backend": group.backend or "none (one rank)", "ranks_per_device": max(1, -(-world // max(1, env["torch"].cuda.device_count()))),
+                       "backend": group.backend or "none (one rank)", "launches_per_step": launches,
+                       "rccl_ranks": (group.collective_ranks if group.backend == "nccl" else None),
+                       "collective_ranks_seen": group.collective_ranks,
+                       "ranks": [{"rank": c["rank"], "device": c["device"].get("ordinal"), "pci": c["device"].get("pci_bus_id")} for c in group.census],
+                       "ranks_per_device": max(1, -(-world // max(1, env["torch"].cuda.device_count()))),
                        "path": ("C++ host mirror (libsnn_core.so, JSON + .bin model -> ModelParser -> MixedInferenceCore::create / run%s)" % ("" if args.no_capture else ", recorded hipGraph replay")
                                 if through == "host" else "per-layer plans through the C-ABI") +
                                (", graph fusion (snnhip_graph_fuse)" if not args.unfused else ", one kernel per layer") + ", %d kernel launches per step" % launches,
                        "device": info["name"], "compute_units": info["compute_units"]},
+            "ms_per_step_of_each_rank": own_ms,
             "parity": parity,
             "max_abs_err": parity["max_abs_err"] if parity else None, "max_rel_err": parity["max_rel_err"] if parity else None,
             "flops_per_image": flops_img, "bytes_per_image_unfused_accounting": bytes_img,
@@ -693,6 +795,10 @@ def run_config(config, args, env, primary):
             out["layer_table"] = {"method": "reference benchmark table (inferenceProcessor.cpp:84-86,143-199): %d inferences, first 5 dropped, per-stage device timers "
                                             "(MixedInferenceCore::writeTimeStat), mean and population sigma in ms; launch by launch (timers need the host between stages)" % (table_loops + 5),
                                   "rows": layer_table}
+        # always on the record (null without a launch trace, --no-kernel-events); since round 5 the whole-step fraction is the step against the SUM of
+        # its launches' own rooflines (fused accounting), not rounds 1-4's max(flops, unfused bytes) bound
+        out.update({"sum_of_launch_rooflines_ms": None, "frac_of_sum_of_launch_rooflines": None, "whole_step_roofline_ms": None, "frac_of_whole_step_roofline": None,
+                    "frac_of_whole_step_roofline_definition": "v2 (round 5+): sum over the step's launches of max(flops / MFMA peak, fused-launch bytes / 8 TB/s) / ms_per_step"})
         if rows:
             # the same bound kernel by kernel, on the FUSED graph's own accounting (a fused launch counts its inputs and outputs once): fusion cannot
             # beat this one, and a compute-bound layer is not hidden behind the graph's HBM total
@@ -719,7 +825,7 @@ def run_config(config, args, env, primary):
             out["cpu_baseline"] = cpu_rec
         if not primary:
             # the compact form of the `configs` block
-            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "scaling", "value_mode", "frac_of_whole_step_roofline", "whole_step_roofline_ms", "unfused_accounting", "unfused_accounting",
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "scaling", "value_mode", "frac_of_whole_step_roofline", "whole_step_roofline_ms", "unfused_accounting",
                     "sum_of_launch_rooflines_ms", "frac_of_sum_of_launch_rooflines", "sum_of_kernel_durations_ms", "flops_per_image", "bytes_per_image_unfused_accounting")
             comp = {k: out[k] for k in keep if k in out}
             comp["workload"] = cfg["workload"]
@@ -773,6 +879,7 @@ def main():
                     help="torch.distributed backend of the barrier / MAX-reduction (nccl = RCCL, the driver's; gloo: several ranks may share one GPU -- rank r "
                          "runs on device r %% device_count -- which is how the N > 1 path is exercised on a one-GPU box)")
     ap.add_argument("--layer-table", type=int, default=None, help="loops of the reference-style per-layer table (first 5 dropped); default 20 at N=1, 0 = off")
+    ap.add_argument("--detail-out", default=None, help="where the full record goes (default: bench_detail.json beside bench.py, plus gpurun_out/ when present)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -797,7 +904,13 @@ def main():
         sys.stderr.write("bench.py: %d ranks on %d visible GPU(s)%s\n" % (world, torch.cuda.device_count(),
                                                                           "" if args.backend == "gloo" else " -- RCCL refuses two ranks on one device: use --backend gloo"))
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-    group = sdist.Group(backend=args.backend, local_device=local_rank % max(1, torch.cuda.device_count()))  # nccl == RCCL on ROCm; only barrier + MAX-reduction of the time use it
+    try:
+        # nccl == RCCL on ROCm; only barrier + MAX-reduction of the time use it.  Group() publishes every rank's GPU (ordinal, PCI address) through the
+        # rendezvous store and refuses two RCCL ranks on one device before the first collective
+        group = sdist.Group(backend=args.backend, local_device=local_rank % max(1, torch.cuda.device_count()))
+    except sdist.SharedDeviceError as e:
+        sys.stderr.write("bench.py: REFUSED: %s\n" % (e,))
+        sys.exit(5)
 
     import shadernn_amd as snn
 
@@ -832,13 +945,14 @@ def main():
                     if "error" in r:
                         return {"id": c, "error": r["error"]}
                     rf, cb, par = r.get("roofline") or {}, r.get("cpu_baseline") or {}, r.get("parity") or {}
-                    return {"id": c, "ms_per_step": r.get("ms_per_step"), "images_per_s": r.get("value"), "whole_step_frac": r.get("frac_of_whole_step_roofline"),
+                    return {"id": c, "dtype": r.get("dtype"), "launches": r.get("launches_per_step"), "ms_per_step": r.get("ms_per_step"), "images_per_s": r.get("value"), "whole_step_frac": r.get("frac_of_whole_step_roofline"),
                             "dominant_kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": rf.get("frac"), "frac_executed": rf.get("frac_executed"),
                             "share_of_gpu_time": rf.get("share_of_gpu_time"), "parity_ok": par.get("ok"), "max_abs_err": par.get("max_abs_err"),
                             "cpu_images_per_s": cb.get("value"), "cpu_cores": cb.get("cores")}
                 out["roofline"]["other_configs"] = [brief(c, recs[c]) for c in extra]
     if rank == 0:
-        print(json.dumps(out))
+        write_detail(out, args.detail_out)
+        print(compact_line(out, os.path.relpath(args.detail_out or os.path.join(ROOT, "bench_detail.json"), ROOT)))
         sys.stdout.flush()
     group.barrier()
     group.close()

@@ -225,3 +225,73 @@ def test_bench_kernel_table_groups_by_function_and_prices_the_dominant_one(monke
     committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
     assert committed and all(len(v.get("csrc_sha16", "")) == 16 and v["hbm_bytes_per_launch"] >= 0 for v in committed.values())
     assert len(fingerprint.csrc_sha16()) == 16
+
+
+# ---- the N > 1 line is self-verifying: a census of (rank, device, PCI address) through the rendezvous store, RCCL refused on a shared device ----
+
+def _census_worker(rank, world, port, q, backend, same_device):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    sys.path.insert(0, ROOT)
+    from shadernn_amd import dist
+
+    ident = {"ordinal": 0 if same_device else rank, "pci_bus_id": "0000:05:00" if same_device else "0000:%02x:00" % (5 + rank), "uuid": None, "name": "test"}
+    try:
+        g = dist.Group(backend=backend, identity=ident)
+    except dist.SharedDeviceError as e:
+        q.put((rank, "refused", str(e)))
+        return
+    vals = g.gather_values(10.0 + rank)
+    q.put((rank, "ok", {"census": g.census, "seen": g.collective_ranks, "vals": vals, "backend": g.backend}))
+    g.barrier()
+    g.close()
+
+
+def _run_census(backend, same_device):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_census_worker, args=(r, 2, port, q, backend, same_device)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_census_reports_every_rank_and_the_collective_sees_them_all():
+    got = _run_census("gloo", same_device=False)
+    for rank, status, rec in got:
+        assert status == "ok" and rec["backend"] == "gloo" and rec["seen"] == 2
+        assert [c["rank"] for c in rec["census"]] == [0, 1]
+        assert [c["device"]["pci_bus_id"] for c in rec["census"]] == ["0000:05:00", "0000:06:00"]
+        assert rec["vals"] == [10.0, 11.0]  # every rank's own figure, in rank order
+
+
+def test_two_gloo_ranks_may_share_a_device():
+    got = _run_census("gloo", same_device=True)
+    assert all(status == "ok" for _, status, _ in got)
+
+
+def test_two_rccl_ranks_on_one_device_are_refused_before_rccl_is_touched():
+    # backend "nccl" cannot even initialise on this CPU box: the refusal must come first, on both ranks, naming the colliding ranks
+    got = _run_census("nccl", same_device=True)
+    for rank, status, msg in got:
+        assert status == "refused"
+        assert "ranks 0 and 1" in msg and "0000:05:00" in msg and "one rank per device" in msg
+
+
+def test_check_one_rank_per_device_rules():
+    import pytest
+
+    from shadernn_amd import dist
+
+    mk = lambda r, host, pci, ordinal=0: {"rank": r, "host": host, "device": {"ordinal": ordinal, "pci_bus_id": pci, "uuid": None}}
+    dist.check_one_rank_per_device([mk(0, "a", "0000:05:00"), mk(1, "a", "0000:06:00", 1)], "nccl")
+    dist.check_one_rank_per_device([mk(0, "a", "0000:05:00"), mk(1, "b", "0000:05:00")], "nccl")  # same address on another host is another GPU
+    dist.check_one_rank_per_device([mk(0, "a", "0000:05:00"), mk(1, "a", "0000:05:00")], "gloo")
+    with pytest.raises(dist.SharedDeviceError):
+        dist.check_one_rank_per_device([mk(0, "a", "0000:05:00"), mk(1, "a", "0000:06:00", 1), mk(2, "a", "0000:05:00")], "nccl")
+    with pytest.raises(dist.SharedDeviceError):  # no PCI address known: fall back on the ordinal
+        dist.check_one_rank_per_device([mk(0, "a", None, 3), mk(1, "a", None, 3)], "nccl")

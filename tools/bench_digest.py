@@ -21,12 +21,15 @@ def _one(tag, d):
 
 def digest(path):
     try:
-        d = json.loads(open(path).read().strip().split("\n")[-1])
+        line = open(path).read().strip().split("\n")[-1]
+        full = path[:-5] + ".detail.json"  # since round 6 the printed line is a summary (< 8 KB); the full record sits beside it
+        d = json.load(open(full)) if os.path.exists(full) else json.loads(line)
+        d["_line_bytes"] = len(line)
     except Exception as e:
         return "%s: unreadable (%s)" % (path, e)
     cb, w = d.get("cpu_baseline") or {}, d.get("wait_semantics") or {}
     s = _one("%s %s [%s]" % (os.path.basename(path), d["config"].get("config_id"), d.get("value_mode")), d)
-    s += "\n    cpu %.2f img/s @%s threads" % (cb.get("value", 0), cb.get("cores"))
+    s += "\n    cpu %.2f img/s @%s threads | printed line %d bytes" % (cb.get("value", 0), cb.get("cores"), d["_line_bytes"])
     if w:
         s += "\n    wait: in flight %.4f ms, sync/inference %.4f ms (polling) %.4f ms (blocking)" % (
             w["inflight"]["ms_per_step"], w["sync_per_inference"]["ms_per_step"], w["sync_per_inference_blocking_wait"]["ms_per_step"])
@@ -39,7 +42,7 @@ def digest(path):
 
 def main():
     for a in sys.argv[1:]:
-        files = sorted(glob.glob(os.path.join(a, "bench*.json"))) if os.path.isdir(a) else [a]
+        files = sorted(f for f in glob.glob(os.path.join(a, "bench*.json")) if not f.endswith(".detail.json")) if os.path.isdir(a) else [a]
         for f in files:
             if os.path.getsize(f):
                 print(digest(f))

@@ -29,15 +29,15 @@ for act in "$@"; do
       else timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > "$O/pytest.txt" 2>&1; tail -6 "$O/pytest.txt"; fi ;;
     bench)
       for c in $(echo "${arg:-c2,c1,c3,c4,c5}" | tr ',' ' '); do
-        timeout 900 python bench.py --config "$c" --also none > "$O/bench_$c.json" 2> "$O/bench_$c.err" || { echo "bench $c rc=$?"; tail -3 "$O/bench_$c.err"; }
+        timeout 900 python bench.py --config "$c" --also none --detail-out "$O/bench_$c.detail.json" > "$O/bench_$c.json" 2> "$O/bench_$c.err" || { echo "bench $c rc=$?"; tail -3 "$O/bench_$c.err"; }
       done
       python tools/bench_digest.py "$O" ;;
     benchall)
-      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_all.json" 2> "$O/bench_all.err" || { echo "benchall rc=$?"; tail -3 "$O/bench_all.err"; }
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --detail-out "$O/bench_all.detail.json" > "$O/bench_all.json" 2> "$O/bench_all.err" || { echo "benchall rc=$?"; tail -3 "$O/bench_all.err"; }
       python tools/bench_digest.py "$O/bench_all.json" ;;
     benchx)
       c=${arg%%:*}; extra=${arg#*:}
-      timeout 900 python bench.py --config "$c" ${extra//+/ } > "$O/benchx_$n.json" 2> "$O/benchx_$n.err" || { echo "benchx $arg rc=$?"; tail -3 "$O/benchx_$n.err"; }
+      timeout 900 python bench.py --config "$c" ${extra//+/ } --detail-out "$O/benchx_$n.detail.json" > "$O/benchx_$n.json" 2> "$O/benchx_$n.err" || { echo "benchx $arg rc=$?"; tail -3 "$O/benchx_$n.err"; }
       python tools/bench_digest.py "$O/benchx_$n.json" ;;
     prof)
       steps=$(python -c "print({'c1':'--steps 200 --warmup 20','c2':'--steps 100 --warmup 10','c3':'--steps 10 --warmup 2','c4':'--steps 4 --warmup 1','c5':'--steps 2 --warmup 1'}['$arg'])")

@@ -47,7 +47,7 @@ def test_two_ranks_on_one_device_c2_weak_scaling_line(built):
     assert d["config"]["global_batch"] == 2 and d["config"]["images_per_rank_per_step"] == 1 and d["config"]["backend"] == "gloo"
     assert d["parity"]["ok"] and d["parity"]["max_abs_err"] <= 1e-4
     # whole-job value: both ranks' images over the slowest rank's time; two ranks share one GPU here, so it is about the one-rank figure, not twice it
-    assert abs(d["value"] - 2 * 20 / (d["ms_per_step"] * 1e-3 * 20)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 2 * 20 / (d["ms_per_step"] * 1e-3 * 20)) < 2e-4 * d["value"]
     assert d["roofline"]["frac"] > 0 and d["roofline"]["whole_step_frac"] <= 1.0
     # the self-verifying part of the N > 1 line: who ran where, what the collective backend saw, every rank's own step time beside the MAX
     assert d["config"]["collective_ranks_seen"] == 2 and d["config"]["rccl_ranks"] is None  # gloo here; under the driver's nccl launch rccl_ranks == N
@@ -68,7 +68,7 @@ def test_two_ranks_on_one_device_c4_shards_the_global_batch(built):
     detail = json.load(open(os.path.join(ROOT, d["detail"])))
     assert detail["config"]["micro_batches_per_rank"] == [128]
     assert d["parity"]["ok"]
-    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # every image of the global batch counted once
+    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 2e-4 * d["value"]  # every image of the global batch counted once
 
 
 def test_one_rank_under_torch_distributed_run_matches_the_plain_run(built):

@@ -22,6 +22,7 @@
 //     low-resolution pixels of a row are the MFMA's B operand; 8 IC/16 MFMAs per wave and iteration on two independent accumulators;
 //   * the 4 x 64 x OC output tile leaves through LDS as 16-byte channel-contiguous vectors.
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "epilogue.h"
@@ -43,6 +44,11 @@ struct UpParams {
     // norm's shift / mul (fold; the hand-off of norm_fold.h).  null = off
     float* statRec;
     NormFoldArgs fold;
+    // graph rule I: the InstanceNorm in front, normAc(x * mul[n][c] + shift[n][c]), applied to the staged LOW-RESOLUTION values (once per pixel, not to the 4x
+    // replicated ones); null = none.  Only the NORM instantiation reads these.
+    const float* normShift;
+    const float* normMul;
+    ActCfg normAc;
 };
 
 #ifdef SNNHIP_UP_TRACE // experiment builds (tools/exp_one.sh)
@@ -55,7 +61,7 @@ constexpr int kTP = 34; // staged pixels per low-resolution row: the strip's 32 
 #define SNNHIP_UPCONV_OCC 2 // waves per SIMD the 256-thread form is compiled for (3 = 168 VGPRs: the statistics accumulators then spill to scratch)
 #endif
 
-template <int ICS /* IC / 16: 4 | 8 */, int WNT /* 32-channel tiles per block: 1 | 2 */>
+template <int ICS /* IC / 16: 4 | 8 */, int WNT /* 32-channel tiles per block: 1 | 2 */, bool NORM = false /* graph rule I (the 64-channel form: its thread keeps 8 shifts + 8 multipliers) */>
 __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void conv2d_upconv_kernel(UpParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
                                                                                   const float4* __restrict__ epi, _Float16* __restrict__ y) {
     constexpr int Q = 2 * ICS, QP = Q + 1;   // 16-byte slots per pixel, and its (odd) pitch in LDS
@@ -132,7 +138,37 @@ __global__ __launch_bounds__(256 * WNT, WNT == 1 ? SNNHIP_UPCONV_OCC : 2) void c
         v1 = load_one(1, sy0, sy1);
         v2 = load_one(2, sy0, sy1);
     };
+    // graph rule I: half(act(x * mul + shift)) in fp32 on the 8 staged channels of an element -- the norm sweep's own arithmetic and rounding point.  T % Q == 0:
+    // a thread's channel slot is the same for every element it ever stages, so its 8 shifts and 8 multipliers stay in registers; every staged pixel is a
+    // real (clamped) pixel of the image, so every element is normalised; the activation kind is tested once per batch (conv2d_s2march.hip).
+    static_assert(T % Q == 0, "a thread's staged elements share their channel slot");
+    float nSh[8], nMu[8];
+    const bool nRelu = NORM && p.normAc.act == SNNHIP_ACT_RELU;
+    if constexpr (NORM) {
+        const int slT = tid % Q;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            nSh[k] = p.normShift[n * p.IC + 8 * slT + k];
+            nMu[k] = p.normMul[n * p.IC + 8 * slT + k];
+        }
+    }
+    auto normalise = [&](float4& q, auto reluTag) {
+        h8 hv = *reinterpret_cast<const h8*>(&q);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float f = fmaf(static_cast<float>(hv[k]), nMu[k], nSh[k]);
+            hv[k] = static_cast<_Float16>(decltype(reluTag)::value ? fmaxf(f, 0.0f) : __builtin_amdgcn_fmed3f(fmaxf(f, f * p.normAc.alpha), p.normAc.lo, p.normAc.hi));
+        }
+        q = *reinterpret_cast<const float4*>(&hv);
+    };
     auto store_batch = [&](int b) { // into ring rows 2 (b & 1), 2 (b & 1) + 1
+        if constexpr (NORM) {
+            if (nRelu) {
+                normalise(v0, std::true_type{}); normalise(v1, std::true_type{}); normalise(v2, std::true_type{});
+            } else {
+                normalise(v0, std::false_type{}); normalise(v1, std::false_type{}); normalise(v2, std::false_type{});
+            }
+        }
         float* const dst = smem + (b & 1) * 2 * ROWF;
         if (liveBits & 1u) *reinterpret_cast<float4*>(dst + ldsOfs[0]) = v0;
         if (liveBits & 2u) *reinterpret_cast<float4*>(dst + ldsOfs[1]) = v1;
@@ -460,7 +496,9 @@ int make_conv2d_upconv_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     // exactly: nearest x2 upsampling -> reflect pad 1 -> 3x3 stride 1, no padding of its own, output extent = the padded extent (size rule Q20)
     if (g.dtype != SNNHIP_F16 || g.kh != 3 || g.kw != 3 || g.sh != 1 || g.sw != 1 || g.preShift != 1 || g.preMode != SNNHIP_PAD_REFLECT || g.preX != 1 || g.preY != 1)
         return SNNHIP_E_UNSUPPORTED;
-    if (g.padx != 0 || g.pady != 0 || g.H != 2 * g.srcH + 2 || g.W != 2 * g.srcW + 2 || g.OH != g.H || g.OW != g.W || g.normShift || g.addAct >= 0) return SNNHIP_E_UNSUPPORTED;
+    if (g.padx != 0 || g.pady != 0 || g.H != 2 * g.srcH + 2 || g.W != 2 * g.srcW + 2 || g.OH != g.H || g.OW != g.W || g.addAct >= 0) return SNNHIP_E_UNSUPPORTED;
+    // graph rule I: the 64-channel form only (the 128-channel one sits at 252 VGPRs), branch-free activations
+    if (g.normShift && (g.IC != 64 || !act_is_simple(g.normAct) || snnhip::option("SNNHIP_NO_UPCONV_NORM"))) return SNNHIP_E_UNSUPPORTED;
     if ((g.IC != 64 && g.IC != 128) || g.srcH < 2 || g.srcW < 2 || g.act == SNNHIP_ACT_SILU_QUIRK) return SNNHIP_E_UNSUPPORTED;
     const int ICS = g.IC / 16, WNT = g.IC == 64 ? 1 : 2, BN = 32 * WNT;
     if (g.OC % BN != 0) return SNNHIP_E_UNSUPPORTED;
@@ -495,7 +533,9 @@ int make_conv2d_upconv_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     }
     const int QP = 2 * ICS + 1;
     const size_t lds = static_cast<size_t>(4) * kTP * QP * 16 + static_cast<size_t>(4) * 64 * (BN + 8) * 2 + 2 * static_cast<size_t>(BN) * 4;
-    auto fn = g.IC == 64 ? conv2d_upconv_kernel<4, 1> : conv2d_upconv_kernel<8, 2>;
+    p.normShift = g.normShift; p.normMul = g.normMul;
+    p.normAc = make_act_cfg(g.normShift ? g.normAct : SNNHIP_ACT_NONE, g.normLeaky);
+    auto fn = g.IC == 64 ? (g.normShift ? conv2d_upconv_kernel<4, 1, true> : conv2d_upconv_kernel<4, 1, false>) : conv2d_upconv_kernel<8, 2, false>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("conv2d_upconv: hipFuncSetAttribute(%zu) failed", lds);
         return SNNHIP_E_HIP;
@@ -548,6 +588,7 @@ int make_conv2d_upconv_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
                                "(4x64 out) x %doc segments=%d x %d rows lds=%zuB mfma_flops=%.6g +pad(reflect) +upsample(x2)",
              g.IC, g.OC, BN, p.segs, p.segRows, lds, plan->flops * 4.0 / 9.0);
     plan->desc = buf;
+    if (g.normShift) plan->desc = "instancenorm(act=" + std::to_string(g.normAct) + ", in the staging) -> " + plan->desc;
     *out = plan;
     return SNNHIP_OK;
 }

@@ -1394,7 +1394,10 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         // behind a fused UpSampling (the pass runs on the 4x replicated pixels) nor on the VALU-bound 32-channel blocks (64 -> 32 up-conv: 1.07 ms
         // + 0.17 ms sweep apart, 1.70 ms folded)
         const bool onWide = cv->desc.rfind("conv2d_mfma_wide_f16", 0) == 0 && !cv->g.preShift && cv->g.OC % 64 == 0;
-        if (cv->desc.rfind("conv2d_mfma_f16_", 0) != 0 && cv->desc.rfind("conv2d_rowfold", 0) != 0 && !(onWide && !snnhip::option("SNNHIP_NO_WIDE_NORM"))) continue;
+        // conv2d_upconv (round 6) stages the LOW-RESOLUTION tensor, so its pass runs once per pixel: the 64 -> 32 up-convolution of the style graphs reads the
+        // norm's input and the 944 MB normalise sweep in front of it disappears
+        const bool onUpconv = cv->desc.rfind("conv2d_mfma_upconv_f16", 0) == 0 && cv->g.IC == 64;
+        if (cv->desc.rfind("conv2d_mfma_f16_", 0) != 0 && cv->desc.rfind("conv2d_rowfold", 0) != 0 && !(onWide && !snnhip::option("SNNHIP_NO_WIDE_NORM")) && !onUpconv) continue;
         ConvGeom g2 = cv->g;
         if (!instancenorm_stat_pointers(a.plain, &g2.normShift, &g2.normMul)) continue;
         g2.normAct = nd.act;
@@ -1403,7 +1406,7 @@ int make_chain_plan(snnhip_ctx* ctx, snnhip_plan* const* plans, int n, snnhip_pl
         const int frc = cv->desc.rfind("conv2d_rowfold", 0) == 0 ? make_conv2d_rowfold_plan(ctx, g2, cv->w_oihw.data(), cv->epi4, &fused)
                                                                  : make_conv2d_mfma_plan(ctx, g2, cv->w_oihw.data(), cv->epi4, &fused);
         if (frc != SNNHIP_OK) continue;
-        if (onWide && fused->desc.find("conv2d_mfma_wide_f16") == std::string::npos) { // (routed elsewhere with the norm attached: keep the separate launches)
+        if ((onWide && fused->desc.find("conv2d_mfma_wide_f16") == std::string::npos) || (onUpconv && fused->desc.find("conv2d_mfma_upconv_f16") == std::string::npos)) { // (routed elsewhere with the norm attached: keep the separate launches)
             delete fused;
             continue;
         }

@@ -262,6 +262,38 @@ def test_c2_espcn_1080p_whole_frame_through_host_graph_replay(ctx, tmp_path):
     m.close()
 
 
+def test_c3_resnet18_batch32_through_host_graph_replay(ctx, tmp_path):
+    """BASELINE configs[2] as bench.py times it: the 32-image batch in one pass through the host mirror (JSON + .bin model -> ModelParser ->
+    MixedInferenceCore::create / run) + hipGraph.  Images 0 / 13 / 31 against the oracle (softmax output, 1e-4), the replay of the recording
+    bit-identical, a second batch through the same recording, the batch-index property.  Reference style: demo/test/unittest/resnet18Test.cpp:84-140
+    (the whole network against a second implementation on the same input)."""
+    net, m, (H, W, C) = _bench_model(tmp_path, "c3", 32)
+    x = np.random.default_rng(7767517).random((32, H, W, C), dtype=np.float32)
+    y = m(x).reshape(32, -1).copy()                 # record + launch
+    assert y.shape == (32, 1000) and np.isfinite(y).all()
+    np.testing.assert_allclose(y.sum(axis=1), 1.0, atol=1e-4)
+    for n in (0, 13, 31):
+        want = O.forward(net, x[n : n + 1], threads=THREADS).reshape(-1)
+        np.testing.assert_allclose(y[n], want, err_msg="image %d" % n, **TOL)
+    steps = m.plan_steps()
+    kinds = " ".join(d for _, _, d, _, _ in steps)
+    assert "wino" in kinds and "splitK=" in kinds and "stream" in kinds, kinds   # the kernels of the bench line: Winograd body, split-K stage entries, 1x1 s2 stream
+    assert len(steps) <= 24, len(steps)              # rule E folded the eight Adds, rule J the max pool, rule 0b the Flatten
+    m.run()                                          # replay
+    np.testing.assert_array_equal(m.output().reshape(32, -1), y)
+    x2 = (0.5 * np.random.default_rng(12).random((32, H, W, C), dtype=np.float32)).astype(np.float32)
+    m.upload(x2)                                     # same device buffer, new contents: the recording stays valid
+    for _ in range(3):
+        m.run_async()                                # three inferences in flight, one wait
+    m.sync()
+    y2 = m.output().reshape(32, -1).copy()
+    np.testing.assert_allclose(y2[31], O.forward(net, x2[31:32], threads=THREADS).reshape(-1), err_msg="second batch, image 31", **TOL)
+    yb = m(np.repeat(x[13:14], 32, axis=0)).reshape(32, -1)
+    for i in range(32):
+        np.testing.assert_allclose(yb[i], y[13], rtol=1e-6, atol=1e-7, err_msg="batch position %d" % i)
+    m.close()
+
+
 def test_c4_mobilenetv2_batch256_through_host_graph_replay(ctx, tmp_path):
     """BASELINE configs[3] as bench.py times it on one GPU: all 256 images in ONE pass through the host mirror + hipGraph.  Images 0 / 127 /
     255 against the oracle (final softmax output, 1e-4), then the batch-index property at this batch size."""

@@ -665,3 +665,48 @@ def test_upconv_block_statistics_feed_the_instancenorm_behind_it(ctx, monkeypatc
             t = O.pad(O.upsample(O._h(xs), 2.0, "nearest"), (1, 1, 1, 1), "reflect")
             c = O._h(O.conv2d(t, O._h(wt), b, 1, (0, 0, 0, 0), "constant", "", 0.0, None))
             np.testing.assert_allclose(y, O._h(O.instancenorm(c, beta, gamma, "relu")), err_msg=d, rtol=6e-3, atol=6e-3)
+
+
+@pytest.mark.parametrize("n,h,w_,oc,act,segs", [(2, 30, 45, 32, "relu", "2"), (1, 26, 70, 64, "", "1"), (3, 24, 33, 32, "leakyRelu", "3")])
+def test_upconv_normalises_the_low_resolution_tensor_while_it_stages(ctx, monkeypatch, n, h, w_, oc, act, segs):
+    """Graph rule I on conv2d_upconv.hip (round 6): InstanceNorm [-> ReLU] -> UpSampling x2 -> reflect Pad(1) -> Conv2D 3x3 (64 channels in) as the norm's
+    statistics sweep + fold and ONE up-convolution launch that applies half(act(x * mul + shift)) to the LOW-RESOLUTION pixels it stages.  Same arithmetic
+    and rounding point as the norm's own normalise sweep: bit-identical to the separate launches; within tolerance of the oracle; several images (the
+    shift / mul of the block's own image), several row segments, border strips; with the norm of rule F behind it as well (Candy's 64 -> 32 layer)."""
+    import shadernn_amd as snn
+
+    ic = 64
+    monkeypatch.setenv("SNNHIP_CONV", "upconv")
+    monkeypatch.setenv("SNNHIP_UPCONV_SEGS", segs)
+    monkeypatch.setenv("SNNHIP_NORM_FUSION_MIN_MB", "0")
+    x = 1.5 * _rand((n, h, w_, ic), 1) + 0.2
+    x[1:] *= 0.5  # (other statistics per image)
+    wt, b = _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9)), _rand((oc,), 3, 0.5)
+    beta, gamma = _rand((ic,), 4, 0.3), 1.0 + _rand((ic,), 5, 0.2)
+    norm = snn.instancenorm_plan(ctx, n, h, w_, ic, beta, gamma, act=act, leaky=0.1)
+    up = snn.upsample_plan(ctx, n, h, w_, ic, 2.0, "nearest")
+    pad = snn.pad_plan(ctx, n, 2 * h, 2 * w_, ic, (1, 1, 1, 1), "reflect")
+    conv = snn.conv2d_plan(ctx, n, 2 * h + 2, 2 * w_ + 2, wt, b, stride=1, pads=(0, 0, 0, 0), act="", dtype=snn.F16)
+    fused = snn.chain_plan(ctx, [norm, up, pad, conv])
+    d = fused.describe()
+    assert fused.num_steps() == 1 and "instancenorm(statistics sweep + fold) -> instancenorm(act=" in d and "in the staging" in d and "upconv" in d, d
+    xt = snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)
+    y = fused(xt).numpy()
+    np.testing.assert_array_equal(fused(xt).numpy(), y)
+    apart = snn.chain_plan(ctx, [up, pad, conv])
+    assert "upconv" in apart.describe() and "in the staging" not in apart.describe()
+    np.testing.assert_array_equal(y, apart(norm(xt)).numpy())
+    ref = O.pad(O.upsample(O._h(O.instancenorm(O._h(x), beta, gamma, act, 0.1)), 2.0, "nearest"), (1, 1, 1, 1), "reflect")
+    want = O._h(O.conv2d(ref, O._h(wt), b, 1, (0, 0, 0, 0), "constant", "", 0.0, None))
+    np.testing.assert_allclose(y, want, err_msg=d, rtol=6e-3, atol=6e-3)
+    # ... and with rule F behind it: the same launch also leaves the statistics records of the norm that follows
+    beta2, gamma2 = _rand((oc,), 6, 0.3), 1.0 + _rand((oc,), 7, 0.2)
+    norm2 = snn.instancenorm_plan(ctx, n, 2 * h + 2, 2 * w_ + 2, oc, beta2, gamma2, act="relu")
+    both = snn.chain_plan(ctx, [norm, up, pad, conv, norm2])
+    d2 = both.describe()
+    assert "in the staging" in d2 and "+tile-stats+fold" in d2, d2
+    y2 = both(xt).numpy()
+    np.testing.assert_allclose(y2, norm2(apart(norm(xt))).numpy(), rtol=2e-3, atol=2e-3, err_msg=d2)
+    # the switch: SNNHIP_NO_UPCONV_NORM keeps the norm's own normalise sweep in front of the up-convolution
+    monkeypatch.setenv("SNNHIP_NO_UPCONV_NORM", "1")
+    assert "in the staging" not in snn.chain_plan(ctx, [norm, up, pad, conv]).describe()

@@ -228,6 +228,9 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
     for (int g = 0; g < G; ++g) {
         const int pl = g * 16 + n16; // 16 consecutive pixels of the tile in row-major order (two rows of 8)
         hp0[g] = (pl >> 3) * p.s * p.HWd + (pl & 7) * p.s;
+#ifdef SNNHIP_IRB_ABL_NOCONF // ablation build (wrong results): 16 consecutive slots per tap read = no bank conflict
+        hp0[g] = g * 16 + n16;
+#endif
     }
     f32x4 acc[NCBT][G];
 #pragma unroll
@@ -546,7 +549,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float4* const hb = hs4 + k * p.hPlane4;
         float4 h[9];
         {
+#ifdef SNNHIP_IRB_ABL_NOCONF
+            const int hp0 = n16;
+#else
             const int hp0 = tabD[n16];
+#endif
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) h[tp] = hb[hp0 + (tp / 3) * p.HWd + tp % 3];
         }
@@ -563,7 +570,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float d0 = irb_act<R6>(p.ac2, t01[0]), d1 = irb_act<R6>(p.ac2, t01[1]), d2 = irb_act<R6>(p.ac2, t23[0]), d3 = irb_act<R6>(p.ac2, t23[1]);
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < G) {
+#ifdef SNNHIP_IRB_ABL_NOCONF
+                const int hp0 = ((g + 1) & 7) * 16 + n16;
+#else
                 const int hp0 = tabD[(g + 1) * 16 + n16];
+#endif
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) h[tp] = hb[hp0 + (tp / 3) * p.HWd + tp % 3];
             }
@@ -799,7 +810,11 @@ __global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const fl
         const float4* const hb = hs4 + k * p.hPlane4;
 #pragma unroll
         for (int g = 0; g < GW; ++g) {
+#ifdef SNNHIP_IRB_ABL_NOCONF
+            const int hp0 = ((wave + p.NW * g) & 3) * 16 + n16;
+#else
             const int hp0 = tabD[(wave + p.NW * g) * 16 + n16];
+#endif
             v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
             for (int fy = 0; fy < 3; ++fy)

@@ -511,12 +511,26 @@ hipError_t dev_malloc_bytes(void** p, size_t bytes, const char* what) {
     void* base = nullptr;
     const hipError_t e = hipMalloc(&base, kGuardZone + user + kGuardZone);
     if (e != hipSuccess) return e;
-    hipError_t m = hipMemset(base, 0xFF, kGuardZone + user + kGuardZone); // zones AND contents: nothing reads as a plausible number before it is written
-    // (the fill runs on the null stream, which a context's non-blocking stream does not wait for: without this wait a kernel launched right behind
-    // the allocation raced the fill and its output came back poisoned -- the guard leg's first finding was its own)
-    if (m == hipSuccess) m = hipStreamSynchronize(nullptr);
+    // zones AND contents are filled with 0xFF: nothing reads as a plausible number before it is written.  The fill runs on a helper stream of its own and is
+    // waited for here (a kernel launched right behind the allocation on a context's non-blocking stream raced a null-stream fill: the guard leg's first
+    // finding was its own).  Not the null stream: a legacy-stream memset + synchronise is illegal while another stream of the thread records a hipGraph;
+    // if the runtime refuses the helper stream's wait for that reason the allocation fails with a message that says so (allocate before the capture).
+    hipError_t m = hipSuccess;
+    {
+        static std::mutex fillMutex;
+        static std::map<int, hipStream_t> fillStreams;
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(fillMutex);
+        hipStream_t& fs = fillStreams[dev];
+        if (!fs) m = hipStreamCreateWithFlags(&fs, hipStreamNonBlocking);
+        if (m == hipSuccess) m = hipMemsetAsync(base, 0xFF, kGuardZone + user + kGuardZone, fs);
+        if (m == hipSuccess) m = hipStreamSynchronize(fs);
+    }
     if (m != hipSuccess) {
         (void) hipFree(base);
+        set_error("SNNHIP_GUARD: the poison fill of a new allocation (%s, %zu bytes) failed: %s%s", what ? what : "", bytes, hipGetErrorString(m),
+                  (m == hipErrorStreamCaptureUnsupported || m == hipErrorStreamCaptureImplicit) ? " -- guarded allocations cannot be made while a stream capture is in progress" : "");
         return m;
     }
     GuardRec r;
@@ -551,8 +565,15 @@ hipError_t dev_free(void* p) {
 static int guard_check_device(snnhip_ctx* ctx) {
     std::vector<GuardZoneDesc> zones;
     std::vector<void*> owner;
+    // The registry stays locked for the WHOLE check: a dev_free of a same-device allocation from another thread (a pool replica, a plan being destroyed)
+    // would otherwise let the check kernel read freed memory.  dev_free / dev_malloc_bytes wait; nothing in here calls them.
+    std::lock_guard<std::mutex> lock(g_guardMutex);
+    struct DeviceRestore { // the caller's current device is put back on every path out
+        int prev = -1;
+        DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+        ~DeviceRestore() { if (prev >= 0) (void) hipSetDevice(prev); }
+    } restoreDevice;
     {
-        std::lock_guard<std::mutex> lock(g_guardMutex);
         for (const auto& kv : guard_map()) {
             const GuardRec& r = kv.second;
             if (r.device != ctx->device) continue;
@@ -583,14 +604,13 @@ static int guard_check_device(snnhip_ctx* ctx) {
     std::string what;
     size_t bytes = 0;
     {
-        std::lock_guard<std::mutex> lock(g_guardMutex);
         auto it = guard_map().find(owner[zi]);
         if (it != guard_map().end()) {
             what = it->second.what;
             bytes = it->second.bytes;
         }
     }
-    (void) hipMemset(const_cast<unsigned char*>(zones[zi].p), 0xFF, zones[zi].bytes);
+    if (hipMemsetAsync(const_cast<unsigned char*>(zones[zi].p), 0xFF, zones[zi].bytes, ctx->mainStream) == hipSuccess) (void) hipStreamSynchronize(ctx->mainStream);
     if (zi & 1)
         set_error("SNNHIP_GUARD: a kernel wrote %zu byte(s) past the END of a device allocation (%s, %zu bytes, device %d)", off + 1, what.c_str(), bytes, ctx->device);
     else

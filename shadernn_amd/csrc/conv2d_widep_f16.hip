@@ -498,11 +498,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_widep_kernel(WidePParams p, Act
             }
             // ---- end of the chunk: everything older than the ring's 2 D youngest loads has landed (the copies, the table load, the ticket)
             WP_ADD(1); // K steps
-            vm_wait<2 * D>();
+            // (chunk 1: the norm-table value requested at its step 0 goes THROUGH the wait statement, as the weight ring's registers do in vm_wait_tie -- no
+            // use of it can be scheduled in front of the wait; tools/audit_vmcnt.py additionally reports any instruction, a copy or a spill included, that
+            // touches the register of an outstanding load)
+            if (c == 1 && NORM != 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(nv) : "n"(2 * D) : "memory");
+            else vm_wait<2 * D>();
             WP_ADD(2); // wait for the copies
             if (c == 1) {
                 if (NORM != 0) {
-                    asm volatile("" : "+v"(nv));
                     normTab[(slot ^ 1) * 2 * IC + tq] = nv;
                 }
             }

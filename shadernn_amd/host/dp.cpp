@@ -44,7 +44,12 @@ std::vector<LayerPtr> stageOrder(const std::vector<LayerPtr>& layers) {
             auto it = slot.find(consumer.get());
             if (it != slot.end() && --pending[it->second] == 0) ready.push_back(it->second);
         }
-    if (ready.size() != count) SNN_LOGW("the layer graph has a cycle: %zu of %zu layers can be ordered", ready.size(), count);
+    if (ready.size() != count) { // a malformed model: fail here, by name, not later inside the builder (the C ABI has no way to carry an exception out)
+        std::string stuck;
+        for (size_t i = 0; i < count && stuck.size() < 200; ++i)
+            if (pending[i] != 0) stuck += (stuck.empty() ? "" : ", ") + layers[i]->getName();
+        SNN_RIP("the layer graph has a cycle: %zu of %zu layers can be ordered; waiting for a producer that never runs: %s", ready.size(), count, stuck.c_str());
+    }
     std::vector<LayerPtr> ordered;
     ordered.reserve(ready.size());
     for (size_t i : ready) ordered.push_back(layers[i]);
@@ -135,7 +140,10 @@ private:
     // what stage `producer` hands to a consumer: a model input's descriptor (with the InputLayer's "outputPlanes" as the true channel count) or the
     // producing stage's output
     InferenceGraph::IODesc feed(const LayerPtr& producer, InferenceGraph::LayerRef& ref) const {
-        ref.index = stageOf.at(producer.get());
+        const auto at = stageOf.find(producer.get());
+        if (at == stageOf.end()) // (an edge into a layer that was not handed in, or that is ordered behind its consumer: stageOrder() rules out the second)
+            SNN_RIP("layer %s is read before it has a stage: it is not part of the layer set the graph is generated from", producer->getName().c_str());
+        ref.index = at->second;
         ref.isStageOutput = !producer->isInputLayer();
         if (ref.isStageOutput) return graph.layers[static_cast<size_t>(ref.index)]->outputDesc;
         InferenceGraph::IODesc desc = modelInput(producer->getInputIndex());
@@ -235,6 +243,7 @@ InferenceModel snn::dp::loadFromJsonModel(const std::string& fileName, bool useV
     }
     for (int32_t i = 0; i < count; ++i) // edges, both directions
         for (int producer : parser.getInboundLayerId(i)) {
+            if (producer < 0 || producer >= count) SNN_RIP("%s: layer %d names inbound layer %d, the model has layers 0..%d", file.c_str(), i, producer, count - 1);
             model[static_cast<size_t>(i)]->prevLayers.push_back(model[static_cast<size_t>(producer)]);
             model[static_cast<size_t>(producer)]->nextLayers.push_back(model[static_cast<size_t>(i)]);
         }

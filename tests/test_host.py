@@ -617,3 +617,36 @@ def test_stage_graphs_of_the_bench_configs_match_the_stored_ones():
         assert len(got[cfg]) == len(want[cfg]), cfg
         for g, w in zip(got[cfg], want[cfg]):
             assert g == w, (cfg, g, w)
+
+
+def test_malformed_layer_graphs_stop_with_a_message_that_names_the_layer(built, tmp_path):
+    """A model whose layers form a cycle, or that names an inbound layer it does not have, must end in SNN_RIP with a readable reason -- the reference's
+    own error style (a FATAL log line, then abort), not an exception escaping through the C ABI (round-5 review: stageOf.at() threw std::out_of_range).
+    Each case in a child process: the abort is the expected outcome."""
+    import json
+    import subprocess
+    import sys
+
+    from shadernn_amd import models
+
+    good = models.write_json(models.espcn_weights(seed=1), 16, 12, str(tmp_path / "good.json"), bin_weights=True)
+    cases = {}
+    d = json.load(open(good))
+    d["Layer_1"]["inputId"] = [2]          # conv2d reads conv2d_1, which reads conv2d: a cycle
+    cases["cycle"] = (d, "the layer graph has a cycle", "[01] Conv2D")
+    d = json.load(open(good))
+    d["Layer_3"]["inputId"] = [7]          # no such layer
+    cases["dangling"] = (d, "names inbound layer 7", "layers 0..4")
+    child = ("import sys; sys.path.insert(0, %r); from shadernn_amd import host; print(len(host.graph_summary(sys.argv[1], 16, 12, 1)))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", child, good], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "5", r.stderr[-1000:]
+    for name, (model, reason, detail) in cases.items():
+        path = str(tmp_path / (name + ".json"))
+        model["numLayers"]["bin_file_name"] = "good.bin"  # (the weights of the untouched model, beside it)
+        json.dump(model, open(path, "w"))
+        r = subprocess.run([sys.executable, "-c", child, path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        assert r.returncode != 0, name
+        assert r.returncode < 0 or r.returncode == 134, (name, r.returncode)   # SIGABRT: SNN_RIP
+        text = r.stderr + r.stdout
+        assert reason in text and detail in text, (name, text[-1500:])
+        assert "out_of_range" not in text and "terminate called" not in text, text[-1500:]

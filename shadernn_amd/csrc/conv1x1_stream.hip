@@ -618,7 +618,8 @@ int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
     // few-tile layers (ResNet-18's 1x1 stride-2 downsample convolutions at batch 32: 196 / 49 row tiles): a wave's K loop is a serial chain of IC / 8 x 4 NT
     // MFMAs, so the widest column leaves a few hundred long waves on 1024 SIMDs.  Narrower columns until the grid has three waves per CU (the activations are
     // re-read from L2, which these layers do not notice).  tools/r6_ds.sh, batch 32, NT 3 / 2 / 1: 128->256 @28x28 13.0 / 11.8 / 11.6 us, 256->512 @14x14 - / 18.2 / 10.7 us
-    if (!f16)
+    const char* marchPin = snnhip::option("SNNHIP_CONV_1X1_MARCH"); // (=1 forces the 96-channel persistent form on small layers: tests; it needs the full width)
+    if (!f16 && !(marchPin && atoi(marchPin) == 1))
         while (NT > 1 && static_cast<long long>(nTiles) * ((g.OC + 32 * NT - 1) / (32 * NT)) < 3LL * cus) --NT;
     if (const char* pin = snnhip::option("SNNHIP_CONV_1X1_NT")) // experiments: pin the column width (1-3 x 32 channels)
         if (atoi(pin) >= 1 && atoi(pin) <= 3) NT = atoi(pin);

@@ -548,6 +548,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // registers -- it ran 2-6 % SLOWER on every block (b07 69.3 -> 73.7 us): fp32 VALU work beside fp32 MFMAs is not hidden, it shares their issue port.)
         const float4* const hb = hs4 + k * p.hPlane4;
         float4 h[9];
+        // (round 6) the table entry of tile g + 1 is read a tile ahead, behind the tap reads of tile g: the nine reads of a tile used to start with an LDS
+        // round trip for their own base address (the ablation that replaced the look-up by n16 ran b07 68.6 -> 65.0 us: profiles/r06_irb_*)
+        int hpNext = 0;
         {
 #ifdef SNNHIP_IRB_ABL_NOCONF
             const int hp0 = n16;
@@ -556,6 +559,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) h[tp] = hb[hp0 + (tp / 3) * p.HWd + tp % 3];
+            if (G > 1) hpNext = tabD[16 + n16];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -573,10 +577,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef SNNHIP_IRB_ABL_NOCONF
                 const int hp0 = ((g + 1) & 7) * 16 + n16;
 #else
-                const int hp0 = tabD[(g + 1) * 16 + n16];
+                const int hp0 = hpNext;
 #endif
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) h[tp] = hb[hp0 + (tp / 3) * p.HWd + tp % 3];
+                if (g + 2 < G) hpNext = tabD[(g + 2) * 16 + n16];
             }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].x, d0, acc[cb][g], 0, 0, 0);

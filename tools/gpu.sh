@@ -7,6 +7,7 @@
 #     benchall                         the driver's command: python bench.py (c2 + the other four configs in `configs`) -> bench_all.json
 #     benchx:<c>:<extra bench args>    one bench line with extra arguments ('+' stands for a blank)        -> benchx_<n>.json
 #     prof:<c>                         rocprofv3 kernel trace + PMC passes of that config's bench command -> <tag>_<c>/summary.md
+#     livecheck:<c>                    bench.py with its live launch trace under rocprofv3 --kernel-trace, same process -> live_vs_rocprof_<c>.json
 #     profx:<name>:<command>           the same passes around an arbitrary command ('+' stands for a blank)   -> <tag>_<name>/summary.md
 #     layers[:fp16]                    tools/bench_layers.py                                               -> layers[_fp16].txt
 #     py:<script>[:args]               python tools/<script> args ('+' stands for a blank)                 -> py_<n>.txt
@@ -44,6 +45,10 @@ for act in "$@"; do
       PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --config $arg --also none --no-cpu-baseline --no-parity --layer-table 0 --event-launches 0 --preheat-ms 20 --repeats 1 $steps" \
         timeout 1500 tools/profile_gpu.sh "${TAG}_$arg" > "$O/profile_$arg.log" 2>&1
       grep "derived" -A30 "$O/profile_$arg.log" | cut -c1-240 | head -34 ;;
+    livecheck) # livecheck:<c>: bench.py (its own launch trace ON) under rocprofv3 --kernel-trace in one process; tools/live_vs_rocprof.py compares the two on the same launches
+      mkdir -p "$O/live_$arg"
+      ( cd /tmp && TMPDIR=/tmp timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/live_$arg" -- python "$GRAFT_REPO_ROOT/bench.py" --config "$arg" --also none --no-cpu-baseline --layer-table 0 --detail-out "$GRAFT_REPO_ROOT/$O/live_$arg/detail.json" > "$GRAFT_REPO_ROOT/$O/live_$arg/line.json" 2> "$GRAFT_REPO_ROOT/$O/live_$arg/err.txt" )
+      python tools/live_vs_rocprof.py "$O/live_$arg" | tee "$O/live_vs_rocprof_$arg.json" ;;
     profx) # profx:<name>:<command, '+' for blanks>: kernel trace + PMC passes of an arbitrary command (e.g. one layer through tools/bench_layers.py)
       nm=${arg%%:*}; cmd=${arg#*:}
       PROF_CMD="${cmd//+/ }" timeout 1500 tools/profile_gpu.sh "${TAG}_$nm" > "$O/profile_$nm.log" 2>&1

@@ -36,6 +36,25 @@ def main():
                                                             float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
         res["kernels"].setdefault(name, {})["avg_us"] = avg
         res["kernels"][name]["calls"] = int(r["Calls"])
+    # per-dispatch durations of the same trace: the --stats average above includes the pre-heat and warm-up launches (clocks still ramping: the max column);
+    # the timed region of bench.py is the tail of the run, so the median and the mean of the second half of a kernel's launches are what its `roofline` leg
+    # (measured after the timed region, clocks up) has to agree with
+    per = defaultdict(list)
+    for r in rows(out + "/trace/**/*kernel_trace.csv"):
+        per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    if per:
+        print("\n## steady state (same trace, per-dispatch durations in launch order)\n")
+        print("| kernel | calls | median us | mean of the 2nd half us | mean of the 1st half us |")
+        print("|---|---|---|---|---|")
+        for name, lst in sorted(per.items(), key=lambda kv: -sum(d for _, d in kv[1])):
+            lst.sort()
+            d = [x for _, x in lst]
+            h = len(d) // 2
+            med = sorted(d)[len(d) // 2]
+            second = sum(d[h:]) / max(1, len(d) - h)
+            first = sum(d[:h]) / max(1, h) if h else second
+            print("| %s | %d | %.2f | %.2f | %.2f |" % (name, len(d), med, second, first))
+            res["kernels"].setdefault(name, {}).update({"median_us": med, "steady_mean_us": second})
     # PMC: average per dispatch per kernel
     for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
         acc = defaultdict(lambda: defaultdict(float))

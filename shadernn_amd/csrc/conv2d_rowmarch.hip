@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
     // ---- shift-add tables.  D layout of the 32x32 MFMA with A = weights: lane (l32, h) holds, for pixel l32, rows (fx, oc) index
     // n_i = 8 (i / 4) + 4 h + i % 4 in register i.  For register i this lane pulls from the lane of pixel l32 + fx(n_i) (same half): the value is
     // P[x + fx][fx][oc], its term of out[x][oc(n_i)].  fx / oc of a register differ between the two lane halves only.
+#ifdef SNNHIP_RM_PULLS // (the form of rounds 2-5; round 6's epilogue below needs no tables)
     int pa[16];            // ds_bpermute byte address
     unsigned crossMask = 0; // bit i: the pulled pixel sits in the NEXT 32-column tile
 #pragma unroll
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
         crossMask |= static_cast<unsigned>(src >= 32) << i;
     }
     const bool h1 = h != 0;
+#endif
     // (uniform) none / relu / relu6 / leakyRelu go through the branch-free med3 form; the run-time switch of epi_act (tanh, sigmoid, ...) pulled
     // ~700 VALU instructions and ~200 branches into the iteration loop
     const bool actSimple = act_is_simple_dev(ac.act);
@@ -254,6 +256,60 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
             const int oy = oyS + it * kTH + 2 * wave + j;
             if (oy >= oyE) continue; // (uniform)
             _Float16* const line = scratch + (wave * 2 + j) * (kCols * 4);
+#ifndef SNNHIP_RM_PULLS // (round 6; -DSNNHIP_RM_PULLS builds the ds_bpermute form of rounds 2-5 for A/B runs)
+            {
+                // The shift-add over fx as a Horner walk over the 64 pixels of the strip at once.  Register i of a tile holds (fx, oc) column n0 = 8 (i / 4) + i % 4
+                // in lane half 0 and n0 + 4 in half 1, for pixel l32 of ITS tile.  ONE v_permlane32_swap of the two tiles' register i (swap the upper half of
+                // the first with the lower half of the second) leaves  X_i = column n0 of pixel `lane` (0..63)  and  Y_i = column n0 + 4 of pixel `lane`:
+                // every (fx, oc) column as a 64-lane vector in pixel order.  Then  out[x][oc] = sum_fx P[x + fx][fx][oc]  is
+                //     T = P[.][K-1][oc];  T = shl1(T) + P[.][fx][oc]  for fx = K-2 .. 0          (shl1: lane x takes lane x + 1 = DPP wave_shl:1, one VALU slot)
+                // -- K - 1 shifted adds per channel for BOTH tiles, no ds_bpermute, no exchange between the lane halves, no pull across the tile boundary (the strip
+                // is exactly the wave: lanes beyond TW - 1 compute sums that reach past it and are never stored).  Rounds 2-5: 45 ds_bpermute + 3 cross-half
+                // shuffles per output row (phase trace: pulls + adds 630, exchange 335 of a row tile's ~1 800 cycles).
+#ifdef SNNHIP_RM_TRACE
+                if (rtrace && j == 0) estamp[0] = __builtin_readcyclecounter();
+#endif
+                float X[16], Y[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (8 * (i >> 2) + (i & 3) >= K * OC) continue; // (compile-time) neither half holds a real column in this register
+                    const float lo = acc[j][0][i], hi = acc[j][1][i];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                    X[i] = __uint_as_float(sw[0]);
+                    Y[i] = __uint_as_float(sw[1]);
+                }
+#ifdef SNNHIP_RM_TRACE
+                if (rtrace && j == 0) estamp[1] = __builtin_readcyclecounter();
+#endif
+                float tot[OC];
+#pragma unroll
+                for (int k = 0; k < OC; ++k) {
+                    float T = 0.0f;
+#pragma unroll
+                    for (int fx = K - 1; fx >= 0; --fx) {
+                        const int m = fx * OC + k, i = 4 * (m >> 3) + (m & 3); // (compile-time) column m sits in register i, lane half (m >> 2) & 1
+                        const float col = ((m >> 2) & 1) ? Y[i] : X[i];
+                        if (fx == K - 1) T = col;
+                        else T = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(T), 0x130 /* wave_shl:1 */, 0xf, 0xf, false)) + col;
+                    }
+                    tot[k] = T;
+                }
+#ifdef SNNHIP_RM_TRACE
+                if (rtrace && j == 0) estamp[2] = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+                for (int k = 0; k < OC; ++k) tot[k] = epi_affine(tot[k], eR[k], p.useBN);
+                if (actSimple) { // (tested once per row, not per value: a branch is a pipeline drain)
+#pragma unroll
+                    for (int k = 0; k < OC; ++k) tot[k] = __builtin_amdgcn_fmed3f(fmaxf(tot[k], tot[k] * ac.alpha), ac.lo, ac.hi);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < OC; ++k) tot[k] = epi_act(ac.act, ac.leaky, tot[k], 0.0f);
+                }
+#pragma unroll
+                for (int k = 0; k < OC; ++k) line[lane * OC + k] = static_cast<_Float16>(tot[k]);
+            }
+#else
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 // Register i holds column n0 = 8 (i / 4) + i % 4 in lane half 0 and n0 + 4 in half 1: channel n0 % OC resp. (n0 + 4) % OC.  Both halves add
@@ -318,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_rowfold_march_kernel(RowmarchPa
                     }
                 }
             }
+#endif
 #ifdef SNNHIP_RM_TRACE
             if (rtrace && j == 0) estamp[3] = __builtin_readcyclecounter();
 #endif

@@ -18,6 +18,7 @@
 #include "norm_fold.h"
 #include "snnhip_internal.h"
 
+#include <cstdio>
 #include <cstring>
 
 namespace snnhip {
@@ -32,6 +33,8 @@ struct StemParams {
     int N, H, W, IC, OC, padx, pady, padMode, useBN, OH, OW;
     int tilesX, tilesY;
     int preMode, preX, preY, srcH, srcW;
+    unsigned xBytes; // size of the input tensor (RGB instantiation: its loads go through a raw buffer descriptor, a read past the end returns zeros)
+    unsigned yBytes; // size of the output tensor: the bound of the raw buffer descriptor its stores go through (round 6)
     // chain rule F (Conv2D -> InstanceNorm): per (image, block) records {pixels, sum[32], sum of squares[32]} of the STORED values, and in the image's last
     // block the fold into the norm's shift / mul (norm_fold.h); null = off
     float* statRec;
@@ -47,7 +50,12 @@ constexpr int kSteps = 2 * kK + 3;    // 18 full steps + 3 left-over steps
 constexpr int kOutPitch = 40;         // halfs per pixel row of the wave's output scratch (80 bytes: 16-byte aligned rows, the 8-byte runs of 16 lanes on distinct banks)
 
 
-template <bool SIMPLE, bool STATS /* chain rule F: StemParams::statRec */>
+#ifdef SNNHIP_STEM_TRACE // experiment builds (tools/exp_one.sh): one block prints the s_memtime spans of a tile's phases
+#define STEM_MARK(i) do { if (strace) sst[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STEM_MARK(i) do { } while (0)
+#endif
+template <bool SIMPLE, bool STATS /* chain rule F: StemParams::statRec */, bool RGB = false /* IC == 3 (round 6): a pixel is ONE 8-byte load, see stage_load */>
 __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCfg ac, const _Float16* __restrict__ x, const float4* __restrict__ wp,
                                                           const float4* __restrict__ epi, _Float16* __restrict__ y) {
     __shared__ __attribute__((aligned(16))) _Float16 tile[kInH * kInW * 4];
@@ -71,6 +79,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
         etab[tid] = epi[blockIdx.y * 32 + tid];
         btab[tid] = etab[tid].x;
     }
+    // (round 6) output stores go through a raw buffer descriptor (base, stride 0, size in bytes): a lane whose pixel lies outside the map hands in an offset beyond
+    // the size and the hardware drops its store -- every lane issues every store, no branch around them, so the compiler can COUNT them in front of the next
+    // tile's prefetched loads (s_waitcnt vmcnt(8) instead of vmcnt(0): the loads' wait no longer includes the stores' round trip to memory)
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    typedef int i2v __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t xRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(x), 0, static_cast<int>(p.xBytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yRsrc = __builtin_amdgcn_make_buffer_rsrc(y, 0, static_cast<int>(p.yBytes), 0x00020000 /* gfx9 raw buffer: DATA_FORMAT 32 */);
     // layers without batch norm whose activation is none or relu (Candy's stem): the lane's 16 biases stay in registers for the life of the
     // (persistent) wave and a value's epilogue is add + max -- the general form (table row from LDS, run-time batch-norm select, mul / max / med3)
     // is eight instructions a value, 512 per wave and tile next to its 84 MFMAs
@@ -85,23 +100,58 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
     // them: no global-load latency on the critical path (a rolled load-store loop waited out 7 round trips per tile)
     constexpr int kR = (kInH * kInW + 255) / 256;
     _Float16 sv[kR][4];
+    i2v svd[kR];      // (RGB) the two dwords around the pixel's 6 bytes
+    unsigned svOdd = 0; // (RGB) bit r: the pixel starts in the upper half of its first dword
+    unsigned svOk = 0; // bit r: staged element r lies inside the (padded) image; the others are written as zeros
     auto stage_load = [&](int mt) {
         const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, n = mt / (p.tilesX * p.tilesY);
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
             const int e = tid + 256 * r;
             const int rr = e / kInW, c = e - rr * kInW;
+#if defined(SNNHIP_STEM_ABL) && (SNNHIP_STEM_ABL & 1) // ablation builds (tools/exp_one.sh; wrong at the borders): no padding / Pad resolution in the staging
+            int sy = min(max(ty * kTH - p.pady + rr, 0), p.srcH - 1), sx = min(max(tx * kTW - p.padx + c, 0), p.srcW - 1);
+            if (false) {
+#else
             int sy = resolve_nobranch(ty * kTH - p.pady + rr, p.H, p.padMode);
             int sx = resolve_nobranch(tx * kTW - p.padx + c, p.W, p.padMode);
             if (p.preMode) {
+#endif
                 const int py = resolve_nobranch(sy - p.preY, p.srcH, p.preMode), px = resolve_nobranch(sx - p.preX, p.srcW, p.preMode);
                 sy = sy < 0 ? -1 : py;
                 sx = sx < 0 ? -1 : px;
             }
             const bool ok = e < kInH * kInW && sy >= 0 && sx >= 0;
             const _Float16* src = x + (static_cast<size_t>(n * p.srcH + (ok ? sy : 0)) * p.srcW + (ok ? sx : 0)) * p.IC;
+#if !defined(SNNHIP_STEM_ABL) || !(SNNHIP_STEM_ABL & 16)
+#ifndef SNNHIP_STEM_BRANCHY_IO
+            // (round 6) EVERY lane loads (a pixel outside the image reads pixel (0, 0) and is zeroed by a select): the loads used to sit behind one exec branch
+            // each -- 16 per thread and tile -- and with a load that may or may not have been issued the compiler can only wait with vmcnt(0), which at the
+            // next tile's head also waited for this tile's output stores to be acknowledged
+            if constexpr (RGB) {
+                // an RGB pixel is 6 bytes at byte offset 6 * pixel: the dword pair that starts at the 4-byte boundary below it holds all three halfs -- ONE 8-byte load per
+                // pixel instead of three 2-byte ones (ablation: the image loads were 80 of the kernel's 423 us, all of it issue: 16 two-byte loads per thread and tile)
+                const unsigned byteOfs = static_cast<unsigned>((n * p.srcH + (ok ? sy : 0)) * p.srcW + (ok ? sx : 0)) * 6u;
+                svd[r] = __builtin_amdgcn_raw_buffer_load_b64(xRsrc, static_cast<int>(byteOfs & ~3u), 0, 0);
+                svOdd = r == 0 ? ((byteOfs >> 1) & 1u) : (svOdd | (((byteOfs >> 1) & 1u) << r));
+                svOk = r == 0 ? (ok ? 1u : 0u) : (svOk | (ok ? 1u << r : 0u));
+            } else {
+                const int c1 = min(1, p.IC - 1), c2 = min(2, p.IC - 1), c3 = min(3, p.IC - 1); // (uniform; channels past IC re-read the last one and are zeroed)
+                // (the raw values stay untouched until the LDS write of the next tile's head: a select here would put the loads' wait right behind them)
+                sv[r][0] = src[0]; sv[r][1] = src[c1]; sv[r][2] = src[c2]; sv[r][3] = src[c3];
+                svOk = r == 0 ? (ok ? 1u : 0u) : (svOk | (ok ? 1u << r : 0u));
+            }
+            continue;
+#endif
+#endif
+#if defined(SNNHIP_STEM_ABL) && (SNNHIP_STEM_ABL & 16) // ablation: no image loads
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[r][k] = static_cast<_Float16>(ok ? 1.0f : 0.0f);
+            asm volatile("" ::"v"(src));
+#else
 #pragma unroll
             for (int k = 0; k < 4; ++k) sv[r][k] = (ok && k < p.IC) ? src[k] : static_cast<_Float16>(0.0f);
+#endif
         }
     };
     // ---- rule F.  A lane of the store loop below always carries the same 8 channels (8 (lane & 3) ..): sums and sums of squares of the values it
@@ -211,20 +261,55 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
     int mt = STATS ? static_cast<int>(blockIdx.x) * chunk : static_cast<int>(blockIdx.x);
     if (mt >= total) return; // (STATS, block-uniform: the last blocks of a grid that does not divide the tiles)
     int statImg = mt / tpi; // the image whose values the accumulators hold
+#ifndef SNNHIP_STEM_BRANCHY_IO
+    // (round 6) everything requested so far -- the weights, the epilogue table -- has landed before the tile loop is entered: left pending, the compiler's merged
+    // wait for them sat in front of the first MFMA of EVERY tile as s_waitcnt vmcnt(18), which on the back-edge path means "all but two of the previous tile's
+    // stores acknowledged"
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+#endif
     stage_load(mt);
+#ifndef SNNHIP_STEM_BRANCHY_IO
+    // (round 6) eight stores that the hardware drops (offset beyond the descriptor), so that the vector-memory queue at the loop head looks the same on the way in as
+    // on the back-edge -- [16 loads of the tile][8 stores] -- and the compiler waits for the loads with vmcnt(8 + ...) on BOTH paths; without them the entry path has
+    // no younger stores and the merged wait is vmcnt(0)
+#pragma unroll
+    for (int i = 0; i < 2 * kNR; ++i) __builtin_amdgcn_raw_buffer_store_b128(i4v{0, 0, 0, 0}, yRsrc, static_cast<int>(0xffffff00u + 16u * i), 0, 0); // (distinct offsets: identical ones are merged into one store)
+#endif
+#ifdef SNNHIP_STEM_TRACE
+    const bool strace = blockIdx.x == 300 && blockIdx.y == 0 && (tid == 0 || tid == 192);
+    unsigned long long sst[8] = {};
+    int stile = 0;
+#endif
     for (;;) {
+        STEM_MARK(0);
         if (STATS) // this tile opens the next image: close the one before it
             for (const int nNow = mt / tpi; statImg < nNow; ++statImg) flush_image(statImg);
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
             const int e = tid + 256 * r;
+#ifndef SNNHIP_STEM_BRANCHY_IO
+            if constexpr (RGB) {
+                const bool ok = (svOk >> r) & 1u, odd = (svOdd >> r) & 1u;
+                const unsigned d0 = static_cast<unsigned>(svd[r][0]), d1 = static_cast<unsigned>(svd[r][1]);
+                const unsigned rg = odd ? __builtin_amdgcn_alignbit(d1, d0, 16) : d0, b0 = odd ? (d1 >> 16) : (d1 & 0xffffu); // {R, G}, {B, 0}
+                if (e < kInH * kInW) *reinterpret_cast<i2v*>(tile + e * 4) = i2v{static_cast<int>(ok ? rg : 0u), static_cast<int>(ok ? b0 : 0u)};
+            } else {
+                const _Float16 z = static_cast<_Float16>(0.0f);
+                const bool ok = (svOk >> r) & 1u;
+                if (e < kInH * kInW) *reinterpret_cast<h4*>(tile + e * 4) = h4{ok ? sv[r][0] : z, (ok && 1 < p.IC) ? sv[r][1] : z, (ok && 2 < p.IC) ? sv[r][2] : z, (ok && 3 < p.IC) ? sv[r][3] : z};
+            }
+#else
             if (e < kInH * kInW) *reinterpret_cast<h4*>(tile + e * 4) = h4{sv[r][0], sv[r][1], sv[r][2], sv[r][3]};
+#endif
         }
+        STEM_MARK(1);
         __syncthreads();
+        STEM_MARK(2);
         const int tx = mt % p.tilesX, ty = (mt / p.tilesX) % p.tilesY, n = mt / (p.tilesX * p.tilesY);
         const int ox0 = tx * kTW, oy0 = ty * kTH;
         const int next = mt + tstep;
         if (next < total) stage_load(next);
+        STEM_MARK(3);
 
         f32x16 acc[kNR];
 #pragma unroll
@@ -271,6 +356,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
             acc[yy] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&wa[2 * kK + 2]), b, acc[yy], 0, 0, 0);
         }
 
+        STEM_MARK(4);
         // ---- epilogue: acc[yy][4g + k] = channel 8g + 4h + k of pixel (row yy, column l32).  Per row: 8-byte runs -> wave scratch -> 16-byte
         // pieces, lane L = piece L % 4 of pixel L / 4 (+ 16): each store instruction of the wave writes 1 KB contiguous (OC == 32: the row's
         // pixels are adjacent in memory)
@@ -292,7 +378,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = static_cast<_Float16>(fmaxf(acc[yy][4 * g + k] + bias16[4 * g + k], ac.lo));
                     }
+#if defined(SNNHIP_STEM_ABL) && (SNNHIP_STEM_ABL & 2)
+                    asm volatile("" ::"v"(o)); // (ablation: the converted row is kept alive, not written to the scratch)
+#else
                     *reinterpret_cast<h4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = o;
+#endif
                 }
             } else {
 #pragma unroll
@@ -304,17 +394,27 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
                         v = SIMPLE ? apply_act<true>(ac, v, 0.0f) : epi_act(ac.act, ac.leaky, v, 0.0f);
                         o[k] = static_cast<_Float16>(v);
                     }
+#if defined(SNNHIP_STEM_ABL) && (SNNHIP_STEM_ABL & 2)
+                    asm volatile("" ::"v"(o)); // (ablation: the converted row is kept alive, not written to the scratch)
+#else
                     *reinterpret_cast<h4*>(sc + l32 * kOutPitch + 8 * g + 4 * h) = o;
+#endif
                 }
             }
             // (wave-private scratch: the LDS queue of a wave is in order, no barrier)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int opix = 16 * i + (lane >> 2), piece = lane & 3;
+#if defined(SNNHIP_STEM_ABL) && (SNNHIP_STEM_ABL & 2) // ablation: no read-back of the row from the scratch (wrong values, same stores)
+                const float4 v = make_float4(acc[yy][4 * i], acc[yy][4 * i + 1], acc[yy][4 * i + 2], acc[yy][4 * i + 3]);
+#else
                 const float4 v = *reinterpret_cast<const float4*>(sc + opix * kOutPitch + 8 * piece);
+#endif
                 const int ox = ox0 + opix;
                 if (oy < p.OH && ox < p.OW) {
+#ifdef SNNHIP_STEM_BRANCHY_IO // the form of rounds 2-5 (A/B builds)
                     *reinterpret_cast<float4*>(y + (static_cast<size_t>(n * p.OH + oy) * p.OW + ox) * p.OC + blockIdx.y * 32 + 8 * piece) = v;
+#endif
                     if (STATS) {
                         const h8 hv = *reinterpret_cast<const h8*>(&v);
 #pragma unroll
@@ -326,11 +426,32 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
                         stN += piece == 0 ? 1.0f : 0.0f;
                     }
                 }
+                // (the store BEHIND the statistics' branch: in front of it the compiler sank a copy into either arm, and a store that may or may not have been issued
+                // cannot be counted)
+#ifndef SNNHIP_STEM_BRANCHY_IO
+                {
+                    const bool inside = oy < p.OH && ox < p.OW;
+                    const unsigned off = inside ? static_cast<unsigned>(((n * p.OH + oy) * p.OW + ox) * p.OC + blockIdx.y * 32 + 8 * piece) * 2u : 0xfffffff0u; // (yBytes <= 0xfffffaf0: beyond the descriptor's size, the store is dropped)
+#if defined(SNNHIP_STEM_ABL) && (SNNHIP_STEM_ABL & 4) // ablation: no output stores
+                    asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(off));
+#else
+                    i4v vi;
+                    vi[0] = __float_as_int(v.x); vi[1] = __float_as_int(v.y); vi[2] = __float_as_int(v.z); vi[3] = __float_as_int(v.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(vi, yRsrc, static_cast<int>(off), 0, 0);
+#endif
+                }
+#endif
             }
         }
+        STEM_MARK(5);
         if (next >= total) break;
         mt = next;
         __syncthreads(); // every wave is done with the tile before the next one is written
+#ifdef SNNHIP_STEM_TRACE
+        if (strace && ++stile >= 3 && stile < 6)
+            printf("stemtrace tid %d tile %d: wait+ldswrite %llu bar %llu stage_issue %llu mfma %llu epilogue %llu bar2 %llu total %llu\n", tid, stile, sst[1] - sst[0], sst[2] - sst[1],
+                   sst[3] - sst[2], sst[4] - sst[3], sst[5] - sst[4], __builtin_readcyclecounter() - sst[5], __builtin_readcyclecounter() - sst[0]);
+#endif
     }
     if (STATS) {
         __syncthreads();
@@ -388,6 +509,10 @@ struct StemConvPlan : ConvPlanBase {
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC && out->dtype == SNNHIP_F16,
                        "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
         auto fn = p.statRec ? (simple ? conv2d_stem_kernel<true, true> : conv2d_stem_kernel<false, true>) : (simple ? conv2d_stem_kernel<true, false> : conv2d_stem_kernel<false, false>);
+#ifndef SNNHIP_STEM_BRANCHY_IO
+        if (p.IC == 3 && p.xBytes) // (the style graphs' RGB stems)
+            fn = p.statRec ? (simple ? conv2d_stem_kernel<true, true, true> : conv2d_stem_kernel<false, true, true>) : (simple ? conv2d_stem_kernel<true, false, true> : conv2d_stem_kernel<false, false, true>);
+#endif
         SNNHIP_LAUNCH(fn, grid, dim3(256), 0, ctx->stream, p, ac, reinterpret_cast<const _Float16*>(x->data), reinterpret_cast<const float4*>(d_w),
                       reinterpret_cast<const float4*>(d_epi), reinterpret_cast<_Float16*>(out->data));
         SNNHIP_CHECK_HIP(hipGetLastError());
@@ -408,7 +533,7 @@ int make_conv2d_stem_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     if (const char* f = snnhip::option("SNNHIP_CONV"))
         if (strcmp(f, "stem") != 0) return SNNHIP_E_UNSUPPORTED; // another kernel is being forced
     const double outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
-    if (outCount >= 2147483647.0 * 4) return SNNHIP_E_UNSUPPORTED;
+    if (outCount >= 2147483000.0) return SNNHIP_E_UNSUPPORTED; // (32-bit element index; the stores' byte offset through the buffer descriptor stays below 2^32 - 16)
 
     StemParams p{};
     p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.padx = g.padx; p.pady = g.pady; p.padMode = g.padMode; p.useBN = g.useBN;
@@ -417,6 +542,13 @@ int make_conv2d_stem_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.preMode = g.preMode; p.preX = g.preX; p.preY = g.preY;
     p.srcH = g.preMode ? g.srcH : g.H;
     p.srcW = g.preMode ? g.srcW : g.W;
+    p.yBytes = static_cast<unsigned>(outCount * 2.0);
+    {
+        const double inBytes = 2.0 * g.N * p.srcH * p.srcW * g.IC;
+        // (0: the two-byte loads.  Rounded up to whole dwords: the last pixel's second dword ends two bytes past the tensor -- inside its allocation, which is
+        // rounded to 16 bytes -- and a dword that crosses the descriptor's size would read as zero)
+        p.xBytes = inBytes < 4294966000.0 ? (static_cast<unsigned>(inBytes) + 3u) & ~3u : 0u;
+    }
 
     auto* plan = new StemConvPlan();
     plan->ctx = ctx;

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 for r in 1 2; do
   for lib in "" "$PWD/build/abl/libsnnhip_pulls.so"; do
-    echo "== ${lib:-product (DPP Horner)}"
+    echo "== ${lib:-product}"
     SNNHIP_LIB_PATH=$lib python tools/bench_layers.py --fp16 --only=adhoc --shape 16,728,1288,32,3,9,1 --reps 30 2>&1 | grep adhoc | cut -c1-200
   done
 done

@@ -704,6 +704,13 @@ __global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const fl
     extern __shared__ float4 sm4[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n16 = lane & 15, k = lane >> 4;
     const int NT = p.NW * 64, OT16 = p.NW * GW * 16;
+#ifdef SNNHIP_IRBB_TRACE // experiment builds (tools/exp_one.sh): one block sums the s_memtime spans of its phases over the slices and prints them
+    const bool btr = blockIdx.x == 1500 && lane == 0 && (wave == 0 || wave == p.NW - 1);
+    unsigned long long bT = __builtin_readcyclecounter(), bAcc[6] = {};
+#define IRBB_ADD(i) do { if (btr) { const unsigned long long n_ = __builtin_readcyclecounter(); bAcc[i] += n_ - bT; bT = n_; } } while (0)
+#else
+#define IRBB_ADD(i) do { } while (0)
+#endif
     const int bx = blockIdx.x % p.nBx, by = (blockIdx.x / p.nBx) % p.nBy, img = blockIdx.x / (p.nBx * p.nBy);
     // band geometry (block-uniform)
     const int oy0 = by * p.R, ox0 = bx * p.SW;
@@ -746,6 +753,7 @@ __global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const fl
         lds_dma_wait();
     }
     __syncthreads();
+    IRBB_ADD(0); // setup: tables, zero fill, x tile DMA, barrier
 
     f32x4 acc[NCB][GW];
 #pragma unroll
@@ -810,7 +818,9 @@ __global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const fl
         if (more) web += p.wePieces * 64;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) a[j] = web[j * 64 + lane]; // the next slice's expand weights, under D / P
+        IRBB_ADD(1); // E
         __syncthreads(); // slice c of the hidden tensor is complete; every wave has left D / P (c - 1), whose buffer E (c + 1) will overwrite
+        IRBB_ADD(2); // barrier
         // ---- D + P: this wave's output pixel tiles
         const float4* const hb = hs4 + k * p.hPlane4;
 #pragma unroll
@@ -846,6 +856,7 @@ __global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const fl
         for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[cb * 64 + lane];
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
+        IRBB_ADD(3); // D + P
     }
 
     // ---- epilogue: lane holds output channels 16 cb + 4 k .. + 3 of its pixels
@@ -876,6 +887,13 @@ __global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const fl
             *reinterpret_cast<float4*>(yi + oo + co) = r;
         }
     }
+#ifdef SNNHIP_IRBB_TRACE
+    IRBB_ADD(4);
+    if (btr)
+        printf("irbb NCB%d CJ%d GW%d NW%d slices %d MT %d wave %d: setup %llu | E %llu barrier %llu D+P %llu (sums over the slices) | epilogue %llu | total %llu\n", NCB, CJ, GW, p.NW, p.nSlices, MT, wave,
+               bAcc[0], bAcc[1], bAcc[2], bAcc[3], bAcc[4], bAcc[0] + bAcc[1] + bAcc[2] + bAcc[3] + bAcc[4]);
+#endif
+#undef IRBB_ADD
 }
 
 struct IrbBandPlan : snnhip_plan {

@@ -50,7 +50,9 @@ constexpr int kSteps = 2 * kK + 3;    // 18 full steps + 3 left-over steps
 constexpr int kOutPitch = 40;         // halfs per pixel row of the wave's output scratch (80 bytes: 16-byte aligned rows, the 8-byte runs of 16 lanes on distinct banks)
 
 
-#ifdef SNNHIP_STEM_TRACE // experiment builds (tools/exp_one.sh): one block prints the s_memtime spans of a tile's phases
+#ifdef SNNHIP_STEM_TRACE // experiment builds (tools/exp_one.sh): one block prints the s_memtime spans of a tile's phases; the launch's span from its blocks' own clocks
+__device__ unsigned long long g_stemFirstEntry = ~0ull, g_stemFirstStart = ~0ull, g_stemLastEnd = 0, g_stemSumLife = 0, g_stemLastStart = 0;
+__device__ unsigned g_stemDone = 0;
 #define STEM_MARK(i) do { if (strace) sst[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STEM_MARK(i) do { } while (0)
@@ -65,6 +67,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
     __shared__ __attribute__((aligned(16))) float btab[32]; // (STATS) the biases alone: the statistics accumulators take the registers bias16 has otherwise
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, h = lane >> 5;
+#ifdef SNNHIP_STEM_TRACE
+    if (tid == 0) atomicMin(&g_stemFirstEntry, wall_clock64());
+#endif
 
     // ---- weights of this block's 32 output channels: 21 x 16 bytes per lane, in registers for the life of the wave -- the block is persistent
     // (grid = the resident block count) and walks the pixel tiles with stride gridDim.x, so the 21 KB per wave are fetched once per kernel, not
@@ -279,6 +284,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
     const bool strace = blockIdx.x == 300 && blockIdx.y == 0 && (tid == 0 || tid == 192);
     unsigned long long sst[8] = {};
     int stile = 0;
+    const unsigned long long sstWall0 = wall_clock64();
+    if (tid == 0) atomicMax(&g_stemLastStart, sstWall0);
+    int stilesDone = 0;
 #endif
     for (;;) {
         STEM_MARK(0);
@@ -444,11 +452,25 @@ __global__ __launch_bounds__(256, 2) void conv2d_stem_kernel(StemParams p, ActCf
             }
         }
         STEM_MARK(5);
+#ifdef SNNHIP_STEM_TRACE
+        ++stilesDone;
+        if ((next >= total) && tid == 0 && blockIdx.y == 0) { // the launch's span from its blocks' own clocks: first start .. last end, one line from the block that ends last
+            const unsigned long long wEnd = wall_clock64();
+            atomicMin(&g_stemFirstStart, sstWall0);
+            atomicMax(&g_stemLastEnd, wEnd);
+            atomicAdd(&g_stemSumLife, wEnd - sstWall0);
+            if (atomicAdd(&g_stemDone, 1u) + 1u == gridDim.x) {
+                printf("stemlaunch: %u blocks, first kernel entry .. first loop start %.1f us, first loop start .. last end %.1f us, mean block life %.1f us, last block started %.1f us after the first\n", gridDim.x,
+                       (g_stemFirstStart - g_stemFirstEntry) * 0.01, (g_stemLastEnd - g_stemFirstStart) * 0.01, g_stemSumLife * 0.01 / gridDim.x, (g_stemLastStart - g_stemFirstStart) * 0.01);
+                g_stemFirstEntry = ~0ull; g_stemDone = 0; g_stemFirstStart = ~0ull; g_stemLastEnd = 0; g_stemSumLife = 0; g_stemLastStart = 0;
+            }
+        }
+#endif
         if (next >= total) break;
         mt = next;
         __syncthreads(); // every wave is done with the tile before the next one is written
 #ifdef SNNHIP_STEM_TRACE
-        if (strace && ++stile >= 3 && stile < 6)
+        if (strace && ++stile >= SNNHIP_STEM_TRACE && stile < SNNHIP_STEM_TRACE + 3)
             printf("stemtrace tid %d tile %d: wait+ldswrite %llu bar %llu stage_issue %llu mfma %llu epilogue %llu bar2 %llu total %llu\n", tid, stile, sst[1] - sst[0], sst[2] - sst[1],
                    sst[3] - sst[2], sst[4] - sst[3], sst[5] - sst[4], __builtin_readcyclecounter() - sst[5], __builtin_readcyclecounter() - sst[0]);
 #endif

@@ -35,3 +35,27 @@ def test_readme_layout_paths_exist():
             assert glob.glob(os.path.join(ROOT, path)), path
         else:
             assert os.path.exists(os.path.join(ROOT, path)), path
+
+
+def test_committed_pmc_passes_were_taken_with_these_kernel_sources():
+    """bench.py fills `roofline.traffic` from profiles/pmc_latest.json only when the file's kernel-source fingerprint is the build's (shadernn_amd/fingerprint.py);
+    a kernel edit without a fresh `tools/gpurun.sh <t> <tag> prof:c1 ... prof:c5` + `tools/collect_profiles.py` would put `traffic: null` on the driver's line."""
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from shadernn_amd import fingerprint
+
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    assert pmc, "profiles/pmc_latest.json is empty"
+    shas = {v.get("csrc_sha16") for v in pmc.values()}
+    assert shas == {fingerprint.csrc_sha16()}, "profiles/pmc_latest.json was taken with kernel sources %s, the tree is %s: re-run the profile pass" % (sorted(shas), fingerprint.csrc_sha16())
+    # the dominant kernels of the five bench configs have a traffic record
+    for name in ("conv_kxk_c1o16_wino3x3_c16o16_kernel<5,16,2,2>", "conv2d_wino_kernel<true,1>", "irb_image_kernel<6,6,13,true>", "conv2d_stem32_kernel<3,1,2,true>"):
+        assert name in pmc and pmc[name].get("hbm_bytes_per_launch", 0) > 0, name
+
+
+def test_rocprof_summaries_of_this_round_carry_the_steady_state_table():
+    for c in ("c1_conv3x3", "c2", "c3_resnet18", "c4_mobilenetv2", "c5_candy_fp16"):
+        text = _read("profiles/r06_%s_rocprofv3_summary.md" % c)
+        assert "## kernel stats (--kernel-trace --stats)" in text and "## steady state (same trace, per-dispatch durations in launch order)" in text, c

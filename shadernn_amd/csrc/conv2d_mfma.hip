@@ -494,6 +494,19 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
             if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
         }
     }
+    // fp32 3x3 stride-2 layers with GEMM-sized channel counts: the K axis split over the waves of a block, operands straight from the L2, partial
+    // tiles summed through LDS (conv2d_ksplit.hip) -- one launch where the kernel below needs split-K over blockIdx.z + a reduce pass.
+    // SNNHIP_CONV=ksplit forces it for every eligible shape (any kernel size / stride), SNNHIP_CONV=mfma / SNNHIP_CONV_KSPLIT=0 keep the split-K kernel.
+    {
+        const char* force = snnhip::option("SNNHIP_CONV");
+        const char* w = snnhip::option("SNNHIP_CONV_KSPLIT");
+        const bool forced = force && strcmp(force, "ksplit") == 0;
+        const bool allowed = !force && !(w && atoi(w) == 0) && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_SPLITK") && !snnhip::option("SNNHIP_CONV_C8");
+        if (forced || allowed) {
+            const int rc = make_conv2d_ksplit_plan(ctx, g, w_oihw, epi4, out);
+            if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;
+        }
+    }
     // the RGB stems (IC <= 4): conv2d_stem_f16.hip (fp16 9x9 stride 1) and conv2d_stem_f32.hip (fp32 3x3 stride 1 / 2, 7x7 stride 2)
     {
         int rc = make_conv2d_stem_plan(ctx, g, w_oihw, epi4, out);

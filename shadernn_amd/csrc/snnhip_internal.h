@@ -224,6 +224,7 @@ int make_conv2d_generic_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_
 int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out);
 int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // tried first by make_conv2d_mfma_plan
 int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // tried first by make_conv2d_mfma_plan for fp32 3x3 s1
+int make_conv2d_ksplit_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp32 3x3 s2 (K split over the waves of a block, no reduce launch); tried by make_conv2d_mfma_plan
 int make_conv2d_stem_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp16 9x9 s1, IC <= 4; tried first by make_conv2d_mfma_plan
 int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp32 stems (IC <= 4), tried first by make_conv2d_mfma_plan
 int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp16 3x3 s1, large maps; tried first by make_conv2d_mfma_plan

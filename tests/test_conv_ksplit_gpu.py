@@ -1,0 +1,132 @@
+"""conv2d_ksplit.hip: fp32 convolutions as an implicit GEMM whose K axis is split over the waves of a block (operands straight from memory, partial
+tiles summed through LDS; the 3x3 stride-2 layers of ResNet-18) -- against the CPU oracle (north-star tolerance), against the split-K + reduce
+kernel it replaces on the same inputs, over every (tile, K-split, look-ahead) instantiation, ragged extents and last tiles, every epilogue, and at
+the benchmark batch."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_ops_gpu import _bn, _rand
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def _plan(ctx, family, *a, geom=None, **kw):
+    import shadernn_amd as snn
+
+    if family:
+        os.environ["SNNHIP_CONV"] = family
+    if geom:
+        os.environ["SNNHIP_KSPLIT"] = geom
+    try:
+        return snn.conv2d_plan(ctx, *a, **kw)
+    finally:
+        os.environ.pop("SNNHIP_CONV", None)
+        os.environ.pop("SNNHIP_KSPLIT", None)
+
+
+# N, H, W, IC, OC, k, stride, act, bn, pads
+CASES = [(2, 56, 56, 64, 128, 3, 2, "relu", True, (1, 1, 1, 1)),       # ResNet-18 layer2 entry
+         (3, 28, 28, 128, 256, 3, 2, "relu", True, (1, 1, 1, 1)),      # layer3 entry: tiles straddle images (196 pixels per image)
+         (5, 14, 14, 256, 512, 3, 2, "", True, (1, 1, 1, 1)),          # layer4 entry: 49 pixels per image, a ragged last tile
+         (2, 17, 23, 32, 64, 3, 2, "leakyRelu", True, (1, 1, 1, 1)),   # odd extents: the bottom / right taps leave the image too
+         (1, 9, 9, 48, 64, 3, 2, "tanh", False, (1, 1, 1, 1)),         # three 16-channel chunks per tap, non-simple activation, M = 25 < one tile
+         (2, 12, 20, 64, 128, 3, 2, "sigmoid", True, (0, 0, 0, 0)),    # "valid": pads 0 and the reference's size rule (Q20)
+         (1, 33, 65, 16, 64, 3, 2, "relu6", False, (1, 1, 1, 1)),      # a single chunk per tap
+         (2, 12, 20, 64, 64, 3, 1, "relu", True, (1, 1, 1, 1)),        # forced: stride 1
+         (1, 15, 15, 16, 64, 5, 2, "SiLU", False, (2, 2, 2, 2)),       # forced: 5x5 stride 2
+         (2, 10, 14, 32, 192, 1, 1, "", False, (0, 0, 0, 0))]          # forced: 1x1 (T = 2 iterations: fewer than some K splits have waves)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c[:7]) + "_" + (c[7] or "linear"))
+def test_ksplit_matches_oracle_and_the_split_k_kernel(ctx, case):
+    import shadernn_amd as snn
+
+    N, H, W, IC, OC, k, s, act, use_bn, pads = case
+    x = _rand((N, H, W, IC), 61)
+    w = _rand((OC, IC, k, k), 62, 1.0 / np.sqrt(k * k * IC))
+    b = _rand((OC,), 63, 0.1)
+    bn = _bn(OC, 64) if use_bn else None
+    pk = _plan(ctx, "ksplit", N, H, W, w, b, stride=s, pads=pads, act=act, leaky=0.1, bn=bn)
+    assert "ksplit" in pk.describe(), pk.describe()
+    xt = snn.Tensor.from_numpy(ctx, x)
+    got = pk(xt).numpy()
+    want = O.conv2d(x, w, b, s, pads, "constant", act, 0.1, bn, threads=8)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, err_msg=pk.describe(), **TOL)
+    np.testing.assert_array_equal(got, pk(xt).numpy(), err_msg="second run differs: " + pk.describe())  # fixed summation order
+    pd = _plan(ctx, "mfma", N, H, W, w, b, stride=s, pads=pads, act=act, leaky=0.1, bn=bn)
+    assert "ksplit" not in pd.describe()
+    np.testing.assert_allclose(got, pd(xt).numpy(), err_msg=pk.describe() + " vs " + pd.describe(), rtol=2e-5, atol=2e-5)
+
+
+GEOMS = ["1,1,2", "1,2,2", "1,3,2", "1,4,2", "1,6,2", "1,8,2", "2,1,2", "2,2,2", "2,3,2", "2,4,2", "2,6,2", "2,8,2", "1,4,3", "2,4,3"]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_every_instantiation_on_a_ragged_layer(ctx, geom):
+    """(pixel tiles per wave, K split, look-ahead depth): each on a layer whose last pixel tile is partial and whose K iterations (27) divide into
+    none of the splits evenly."""
+    import shadernn_amd as snn
+
+    N, H, W, IC, OC = 3, 13, 19, 48, 128
+    x, w, b, bn = _rand((N, H, W, IC), 71), _rand((OC, IC, 3, 3), 72, 1.0 / np.sqrt(9 * IC)), _rand((OC,), 73, 0.1), _bn(OC, 74)
+    p = _plan(ctx, "ksplit", N, H, W, w, b, stride=2, pads=(1, 1, 1, 1), act="relu", bn=bn, geom=geom)
+    mi, ks, depth = (int(t) for t in geom.split(","))
+    d = p.describe()
+    assert "tile=%dpx" % (32 * mi) in d and "K over %d waves" % ks in d and "depth %d" % depth in d, d
+    got = p(snn.Tensor.from_numpy(ctx, x)).numpy()
+    np.testing.assert_allclose(got, O.conv2d(x, w, b, 2, (1, 1, 1, 1), "constant", "relu", 0.0, bn, threads=8), err_msg=d, **TOL)
+
+
+def test_ksplit_is_the_default_for_fp32_3x3_stride_2_layers(ctx):
+    import shadernn_amd as snn
+
+    w = _rand((128, 64, 3, 3), 1, 0.05)
+    assert "ksplit" in snn.conv2d_plan(ctx, 2, 20, 20, w, stride=2, act="relu").describe()
+    assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, w, stride=1, act="relu").describe()                        # stride 1: Winograd
+    assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, w, stride=2, pad_mode="reflect").describe()               # reflect padding
+    assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, _rand((64, 24, 3, 3), 2, 0.05), stride=2).describe()      # IC % 16 != 0
+    assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, _rand((96, 64, 3, 3), 3, 0.05), stride=2).describe()      # OC % 64 != 0
+    assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, _rand((64, 64, 5, 5), 4, 0.05), stride=2).describe()      # 5x5: only when forced
+    assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, w, stride=2, act="relu", dtype=snn.F16).describe()        # fp16 keeps its own kernels
+    os.environ["SNNHIP_CONV_KSPLIT"] = "0"
+    try:
+        d = snn.conv2d_plan(ctx, 2, 20, 20, w, stride=2, act="relu").describe()
+        assert "ksplit" not in d and "conv2d_mfma" in d, d
+    finally:
+        os.environ.pop("SNNHIP_CONV_KSPLIT")
+
+
+def test_a_fused_add_behind_it_keeps_the_split_k_kernel(ctx):
+    """Chain rule E is not offered by this kernel: the planner must fall back to conv2d_mfma's fused form, same result as the two launches."""
+    import shadernn_amd as snn
+
+    N, H, W, IC, OC = 2, 16, 16, 64, 128
+    x, res = _rand((N, H, W, IC), 81), _rand((N, 8, 8, OC), 82)
+    w, b = _rand((OC, IC, 3, 3), 83, 1.0 / np.sqrt(9 * IC)), _rand((OC,), 84, 0.1)
+    conv = snn.conv2d_plan(ctx, N, H, W, w, b, stride=2, act="")
+    assert "ksplit" in conv.describe()
+    fused = snn.chain_plan(ctx, [conv, snn.add_plan(ctx, N, 8, 8, OC, act="relu")])
+    got = fused([snn.Tensor.from_numpy(ctx, x), snn.Tensor.from_numpy(ctx, res)]).numpy()
+    want = O.add_act(O.conv2d(x, w, b, 2, (1, 1, 1, 1), "constant", "", 0.0, None, threads=8), res, "relu")
+    np.testing.assert_allclose(got, want, err_msg=fused.describe(), **TOL)
+
+
+def test_ksplit_resnet_shapes_batch32_properties(ctx):
+    """The three ResNet-18 stage entries at the benchmark batch through the default plan: every batch position of a replicated image returns the same
+    tensor, bit for bit (a pixel's K order does not depend on where its tile sits), and image 0 matches the oracle."""
+    import shadernn_amd as snn
+
+    for H, C in ((56, 64), (28, 128), (14, 256)):
+        x1 = _rand((1, H, H, C), 90 + H)
+        w, b, bn = _rand((2 * C, C, 3, 3), 91, 1.0 / np.sqrt(9 * C)), _rand((2 * C,), 92, 0.1), _bn(2 * C, 93)
+        p = snn.conv2d_plan(ctx, 32, H, H, w, b, stride=2, act="relu", bn=bn)
+        assert "ksplit" in p.describe(), p.describe()
+        got = p(snn.Tensor.from_numpy(ctx, np.repeat(x1, 32, axis=0))).numpy()
+        for i in (1, 13, 31):
+            np.testing.assert_array_equal(got[i], got[0], err_msg="%s image %d" % (p.describe(), i))
+        np.testing.assert_allclose(got[:1], O.conv2d(x1, w, b, 2, (1, 1, 1, 1), "constant", "relu", 0.0, bn, threads=8), err_msg=p.describe(), **TOL)

@@ -31,6 +31,10 @@
 #include "epilogue.h"
 #include "snnhip_internal.h"
 
+#ifndef SNNHIP_KS_ABL
+#define SNNHIP_KS_ABL 0 // ablation builds only (tools/exp_one.sh; results are wrong by construction): 1 no weight loads, 2 no activation loads, 4 no reduction / epilogue
+#endif
+
 namespace snnhip {
 
 namespace {
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(64 * KS) void conv2d_ksplit_kernel(KsParams p, ActC
         const int tapOfs = ((dyp * p.W + dxp) * p.IC + 16 * cp) * 4;
         const int wOfs = (wTile + itp) * 4096;
         auto wload = [&](int piece) {
+            if (SNNHIP_KS_ABL & 1) return f32x4{1.0f, 2.0f, 3.0f, static_cast<float>(piece)};
             const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wRsrc, wLane + piece * 1024, wOfs, 0);
             f32x4 f;
             __builtin_memcpy(&f, &v, 16);
@@ -116,6 +121,11 @@ __global__ __launch_bounds__(64 * KS) void conv2d_ksplit_kernel(KsParams p, ActC
         for (int i = 0; i < MI; ++i) {
             const bool ok = static_cast<unsigned>(iy0[i] + dyp) < static_cast<unsigned>(p.H) && static_cast<unsigned>(ix0[i] + dxp) < static_cast<unsigned>(p.W);
             const unsigned ofs = ok ? static_cast<unsigned>(base[i] + tapOfs) : kOutOfRange;
+            if (SNNHIP_KS_ABL & 2) {
+                a[i][0] = f32x4{1.0f, 2.0f, static_cast<float>(ofs), 4.0f};
+                a[i][1] = a[i][0];
+                continue;
+            }
             const i32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(xRsrc, static_cast<int>(ofs), 0, 0);
             const i32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(xRsrc, static_cast<int>(ofs + 16u), 0, 0);
             __builtin_memcpy(&a[i][0], &v0, 16); // (a bit_cast of a vector ELEMENT expression reads element 0 whatever the index: DESIGN.md 5.1)
@@ -163,6 +173,13 @@ __global__ __launch_bounds__(64 * KS) void conv2d_ksplit_kernel(KsParams p, ActC
         }
     }
 
+    if (SNNHIP_KS_ABL & 4) {
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) t += acc[i][0][0] + acc[i][1][5];
+        if (t == 12345.678f) y[0] = t;
+        return;
+    }
     // ---- reduction over the block's waves through LDS (the two epilogue rows a lane can need are requested first)
     const float4 e4a = epi[ocTile * 64 + r], e4b = epi[ocTile * 64 + 32 + r];
 #pragma unroll

@@ -62,15 +62,24 @@ struct WinoParams {
 
 // OPB = output-channel pairs (2 x 16 channels) per block: 2 -> 512 threads, 64 channels, one block per CU; 1 -> 256 threads, 32 channels,
 // two independent blocks per CU (their barriers and LDS-read bursts drift apart, the pair of waves on a SIMD is no longer in lock step)
-template <bool SIMPLE, int OPB>
-__global__ __launch_bounds__(256 * OPB, 3 - OPB) void conv2d_wino_kernel(WinoParams p, ActCfg ac, const float* __restrict__ x, const float4* __restrict__ ug,
+// KS = 2 (round 6; OPB = 1 only): the block's channel chunks are split over TWO groups of four waves -- each group stages its own chunks into its own
+// pair of LDS buffers and runs the K loop below on them, barrier for barrier --, then the groups exchange half of their sums through LDS (group g keeps
+// output-channel block g: it hands the partner the other block's sixteen positions and adds the partner's to its own -- p0 + p1 in both groups, the order
+// of the reduce pass), and every wave runs the epilogue of ONE channel block.  What a 14x14 stage needed split-K over blockIdx.z + a reduce launch for
+// (partial sums through HBM, 6 us per launch) stays inside the block.
+template <bool SIMPLE, int OPB, int KS = 1>
+__global__ __launch_bounds__(256 * OPB * KS, KS > 1 ? 1 : 3 - OPB) void conv2d_wino_kernel(WinoParams p, ActCfg ac, const float* __restrict__ x, const float4* __restrict__ ug,
                                                                         const float4* __restrict__ epi, float* __restrict__ y, float* __restrict__ ws) {
-    constexpr int NT = 256 * OPB;            // threads
+    static_assert(KS == 1 || (KS == 2 && OPB == 1), "in-block K split: two groups of four waves");
+    constexpr int NT = 256 * OPB;            // threads of a group
     constexpr int kUFloats = 4096 * OPB;     // U slab of one chunk: 16 positions x OPB pairs x 64 lanes x float4 (16 / 32 KB)
     constexpr int UQ = 1024 * OPB;           // ... in float4
     constexpr int R = 4 / OPB;               // staged activation quads per thread (halo tile of up to 1024 quads)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) float smemAll[];
+    const int lane = threadIdx.x & 63;
+    const int ks = KS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0; // K group of this wave
+    const int tid = KS > 1 ? (threadIdx.x & 255) : threadIdx.x, wave = tid >> 6;     // thread / wave within the group
+    float* const smem = smemAll + ks * 2 * p.bufFloats;                              // the group's two buffers
     const int tg = wave & 3, op = wave >> 2;
     const int n16 = lane & 15, k = lane >> 4;
 
@@ -99,7 +108,12 @@ __global__ __launch_bounds__(256 * OPB, 3 - OPB) void conv2d_wino_kernel(WinoPar
             if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W && n < p.N) gofs[r] = ((n * p.H + sy) * p.W + sx) * p.IC + q * 4;
         }
     }
-    const int chunk0 = blockIdx.z * p.chunksPerSplit, chunk1 = min(p.nChunks, chunk0 + p.chunksPerSplit);
+    int chunk0 = blockIdx.z * p.chunksPerSplit, chunk1 = min(p.nChunks, chunk0 + p.chunksPerSplit);
+    if (KS > 1) { // (the planner only splits even chunk counts: both groups run the same number of iterations, their barriers pair up)
+        const int half = (chunk1 - chunk0) >> 1;
+        chunk0 += ks * half;
+        chunk1 = chunk0 + half;
+    }
     // U slab of (oc block, chunk): UQ float4, thread t copies float4 t + NT j, j < 4
     const float4* uptr = ug + (static_cast<size_t>(blockIdx.y) * p.nChunks + chunk0) * UQ + tid;
 
@@ -235,11 +249,35 @@ __global__ __launch_bounds__(256 * OPB, 3 - OPB) void conv2d_wino_kernel(WinoPar
         if (!(SNNHIP_WINO_ABL & 1)) __syncthreads();
     }
 
+    // ---- KS = 2: the two K groups exchange one channel block's sums (region of wave w: [pos][lane] float4 = 16 KB, 128 KB in all; the staging buffers are
+    // free: every wave is past the loop's last barrier)
+    if (KS > 1) {
+        f32x4* const xb = reinterpret_cast<f32x4*>(smemAll);
+        f32x4* const mine = xb + ((ks * 4 + wave) * 16) * 64 + lane;
+        const f32x4* const theirs = xb + (((1 - ks) * 4 + wave) * 16) * 64 + lane;
+        if (ks == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mine[i * 64] = acc[i][1];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mine[i * 64] = acc[i][0];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i][0] += theirs[i * 64]; // p0 + p1
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i][1] = theirs[i * 64] + acc[i][1]; // p0 + p1 as well
+        }
+    }
+
     // ---- Y = At M A, At = [1 1 1 0; 0 1 -1 -1]; lane holds output channels 4k..4k+3 of each 16-channel block for its tile
     const int oy = oy0 + 2 * tty, ox = ox0 + 2 * ttx, n = b0 + tbi;
     const bool addSimple = act_is_simple_dev(p.ac2.act);
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
+        if (KS > 1 && o != ks) continue; // (wave-uniform: group g finishes channel block g)
         const int oc = blockIdx.y * (32 * OPB) + (2 * op + o) * 16 + 4 * k;
         if (oc >= p.OC) continue;
         // the epilogue rows of the lane's four channels and the residual of its 2 x 2 output pixels are requested FIRST, the inverse transform runs in
@@ -316,6 +354,7 @@ struct WinoConvPlan : ConvPlanBase {
     bool fusedAdd = false;
     bool simple = true;
     int opb = 1;
+    int ks = 1; // K groups per block (2: eight waves, the channel chunks split inside the block)
 
     int run(const snnhip_tensor* const* in, int nIn, snnhip_tensor* out) override {
         SNNHIP_REQUIRE(nIn == (fusedAdd ? 2 : 1), "conv2d: expects %d input(s), got %d", fusedAdd ? 2 : 1, nIn);
@@ -335,7 +374,10 @@ struct WinoConvPlan : ConvPlanBase {
                        out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
         const float4* u4 = reinterpret_cast<const float4*>(d_u);
         const float4* e4 = reinterpret_cast<const float4*>(d_epi);
-        if (opb == 2) {
+        if (ks == 2) {
+            if (simple) SNNHIP_LAUNCH((conv2d_wino_kernel<true, 1, 2>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+            else SNNHIP_LAUNCH((conv2d_wino_kernel<false, 1, 2>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
+        } else if (opb == 2) {
             if (simple) SNNHIP_LAUNCH((conv2d_wino_kernel<true, 2>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
             else SNNHIP_LAUNCH((conv2d_wino_kernel<false, 2>), grid, dim3(512), ldsBytes, ctx->stream, q, ac, x->data, u4, e4, out->data, d_ws);
         } else {
@@ -413,8 +455,24 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     else
         while (blocks * splitK * 2 <= cus && splitK * 2 <= p.nChunks / 2) splitK *= 2; // doubling must still fit one round of blocks
     splitK = std::min(splitK, p.nChunks);
+    // round 6: the first factor of two of the split stays INSIDE the block (two K groups of four waves, kernel template KS = 2): 256 -> 256 @14x14 needs no
+    // reduce launch at all, 512 -> 512 @7x7 reduces two partial tensors instead of four.  SNNHIP_WINO_KGROUPS=1 keeps the split over blockIdx.z only.
+    int ks = 1;
+    {
+        const char* e = snnhip::option("SNNHIP_WINO_KGROUPS");
+        const bool wanted = e ? atoi(e) == 2 : (splitK == 2 && !snnhip::option("SNNHIP_CONV_SPLITK")); // (where the reduce launch disappears; a deeper split keeps it)
+        if (wanted && opb == 1 && splitK % 2 == 0 && p.nChunks % splitK == 0) {
+            ks = 2;
+            splitK /= 2;
+        } else if (e && atoi(e) == 2 && opb == 1 && splitK == 1 && p.nChunks % 2 == 0) {
+            ks = 2; // forced on a layer that would not split at all (tests)
+        }
+    }
     p.chunksPerSplit = up_div(p.nChunks, splitK);
     p.splitK = up_div(p.nChunks, p.chunksPerSplit);
+    if (ks == 2 && (p.nChunks % p.splitK != 0 || p.chunksPerSplit % 2 != 0)) return SNNHIP_E_UNSUPPORTED; // (cannot happen with the conditions above)
+    const size_t ldsAll = ks == 2 ? std::max<size_t>(2 * lds, 128 * 1024) : lds; // two groups' buffers; the exchange of the sums needs 8 x 16 KB
+    if (ldsAll > 160 * 1024) return SNNHIP_E_UNSUPPORTED;
 
     auto* plan = new WinoConvPlan();
     plan->ctx = ctx;
@@ -424,17 +482,19 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->p = p;
     plan->ac = make_act_cfg(g.act, g.leaky);
     plan->simple = act_is_simple(g.act);
-    plan->ldsBytes = lds;
+    plan->ldsBytes = ldsAll;
+    plan->ks = ks;
     plan->fusedAdd = g.addAct >= 0;
     if (plan->fusedAdd) plan->numInputs = 2;
     plan->opb = opb;
     plan->grid = dim3(p.tilesX * p.tilesY * up_div(g.N, TB), p.OCblocks, p.splitK);
     plan->dtype = SNNHIP_F32;
     for (int s = 0; s < 2; ++s) {
-        const void* fn = opb == 2 ? (s ? reinterpret_cast<const void*>(conv2d_wino_kernel<true, 2>) : reinterpret_cast<const void*>(conv2d_wino_kernel<false, 2>))
+        const void* fn = ks == 2 ? (s ? reinterpret_cast<const void*>(conv2d_wino_kernel<true, 1, 2>) : reinterpret_cast<const void*>(conv2d_wino_kernel<false, 1, 2>))
+                         : opb == 2 ? (s ? reinterpret_cast<const void*>(conv2d_wino_kernel<true, 2>) : reinterpret_cast<const void*>(conv2d_wino_kernel<false, 2>))
                                   : (s ? reinterpret_cast<const void*>(conv2d_wino_kernel<true, 1>) : reinterpret_cast<const void*>(conv2d_wino_kernel<false, 1>));
-        if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
-            set_error("conv2d_wino: hipFuncSetAttribute(%zu) failed", lds);
+        if (ldsAll > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsAll)) != hipSuccess) {
+            set_error("conv2d_wino: hipFuncSetAttribute(%zu) failed", ldsAll);
             delete plan;
             return SNNHIP_E_HIP;
         }
@@ -483,8 +543,8 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     plan->bytes = 4.0 * (static_cast<double>(g.N) * g.H * g.W * g.IC + static_cast<double>(g.N) * g.OH * g.OW * g.OC + static_cast<double>(g.OC) * g.IC * 9);
     const double mfmaFlops = 2.0 * 16 * 64 * 8 * ocPerBlock * static_cast<double>(plan->grid.x) * p.OCblocks * p.nChunks; // executed on the matrix pipe (padded tiles included)
     char buf[320];
-    snprintf(buf, sizeof(buf), "conv2d_mfma_wino_f32_16x16x4 F(2x2,3x3) k=3x3 s=1 ic=%d oc=%d tile=%dx%dx%dpx x %doc chunk=8 lds=%zuB splitK=%d mfma_flops=%.6g",
-             g.IC, g.OC, TB, 2 * TTH, 2 * TTW, ocPerBlock, lds, p.splitK, mfmaFlops);
+    snprintf(buf, sizeof(buf), "conv2d_mfma_wino_f32_16x16x4 F(2x2,3x3) k=3x3 s=1 ic=%d oc=%d tile=%dx%dx%dpx x %doc chunk=8 lds=%zuB kgroups=%d splitK=%d mfma_flops=%.6g",
+             g.IC, g.OC, TB, 2 * TTH, 2 * TTW, ocPerBlock, ldsAll, ks, p.splitK, mfmaFlops);
     plan->desc = buf;
     if (plan->fusedAdd) {
         plan->desc += " +add";

@@ -105,3 +105,77 @@ def test_wino_resnet_shapes_batch32_properties(ctx):
         for i in (1, 13, 31):
             np.testing.assert_array_equal(got[i], got[0], err_msg="%s image %d" % (p.describe(), i))
         np.testing.assert_allclose(got[:1], O.conv2d(x1, w, b, 1, (1, 1, 1, 1), "constant", "relu", threads=8), err_msg=p.describe(), **TOL)
+
+
+def _plan_kgroups(ctx, kgroups, *a, **kw):
+    import shadernn_amd as snn
+
+    os.environ["SNNHIP_WINO_KGROUPS"] = str(kgroups)
+    try:
+        return snn.conv2d_plan(ctx, *a, **kw)
+    finally:
+        os.environ.pop("SNNHIP_WINO_KGROUPS")
+
+
+# N, H, W, C_in, C_out, act, bn
+KGROUP_CASES = [(32, 14, 14, 256, 256, "relu", True),    # ResNet-18 stage 3 at the benchmark batch: split-K 2 + reduce launch -> one launch
+                (32, 7, 7, 512, 512, "relu", True),      # stage 4: split-K 4 -> two K groups x split-K 2
+                (5, 7, 7, 512, 512, "", False),          # a ragged image group
+                (3, 28, 28, 128, 128, "relu", True),     # forced on a layer the planner does not split
+                (2, 17, 23, 32, 48, "leakyRelu", True),  # four chunks: two per group; odd extents, a half-empty channel block
+                (1, 9, 9, 16, 16, "tanh", False)]        # two chunks: ONE per group; a single 16-channel output block (group 1's block is beyond OC)
+
+
+@pytest.mark.parametrize("case", KGROUP_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]) + "_" + (c[5] or "linear"))
+def test_wino_k_groups_inside_the_block_match_the_split_over_blocks(ctx, case):
+    """The channel chunks split over two groups of four waves INSIDE a block (sums exchanged through LDS, no reduce launch for the first factor of two)
+    against the split over blockIdx.z + reduce pass on the same inputs, and against the oracle."""
+    import shadernn_amd as snn
+
+    N, H, W, IC, OC, act, use_bn = case
+    x = _rand((N, H, W, IC), 131)
+    w, b = _rand((OC, IC, 3, 3), 132, 1.0 / np.sqrt(9 * IC)), _rand((OC,), 133, 0.1)
+    bn = _bn(OC, 134) if use_bn else None
+    xt = snn.Tensor.from_numpy(ctx, x)
+    os.environ["SNNHIP_CONV"] = "wino"
+    try:
+        p2 = _plan_kgroups(ctx, 2, N, H, W, w, b, act=act, leaky=0.1, bn=bn)
+        p1 = _plan_kgroups(ctx, 1, N, H, W, w, b, act=act, leaky=0.1, bn=bn)
+    finally:
+        os.environ.pop("SNNHIP_CONV")
+    assert "kgroups=2" in p2.describe() and "kgroups=1" in p1.describe(), (p2.describe(), p1.describe())
+    got = p2(xt).numpy()
+    np.testing.assert_array_equal(got, p2(xt).numpy(), err_msg="second run differs: " + p2.describe())
+    np.testing.assert_allclose(got, p1(xt).numpy(), err_msg=p2.describe() + " vs " + p1.describe(), rtol=2e-5, atol=2e-5)
+    n = min(N, 2)
+    np.testing.assert_allclose(got[:n], O.conv2d(x[:n], w, b, 1, (1, 1, 1, 1), "constant", act, 0.1, bn, threads=8), err_msg=p2.describe(), **TOL)
+    if N > 2:
+        np.testing.assert_allclose(got[-1:], O.conv2d(x[-1:], w, b, 1, (1, 1, 1, 1), "constant", act, 0.1, bn, threads=8), err_msg=p2.describe(), **TOL)
+
+
+def test_wino_k_groups_are_the_default_where_the_planner_splits(ctx):
+    import shadernn_amd as snn
+
+    d3 = snn.conv2d_plan(ctx, 32, 14, 14, _rand((256, 256, 3, 3), 1, 0.02), act="relu").describe()
+    assert "kgroups=2 splitK=1" in d3, d3                                # no reduce launch left
+    d4 = snn.conv2d_plan(ctx, 32, 7, 7, _rand((512, 512, 3, 3), 2, 0.02), act="relu").describe()
+    assert "kgroups=2 splitK=2" in d4, d4
+    d1 = snn.conv2d_plan(ctx, 32, 56, 56, _rand((64, 64, 3, 3), 3, 0.05), act="relu").describe()
+    assert "kgroups=1 splitK=1" in d1, d1                                # enough block tiles: nothing to split
+
+
+@pytest.mark.parametrize("shape", [(32, 14, 14, 256), (6, 7, 7, 512)], ids=["14x14x256_b32", "7x7x512_b6"])
+def test_wino_k_groups_with_the_fused_residual_add(ctx, shape):
+    """Chain rule E with two K groups: at 14x14 the residual is added in the kernel's own epilogue (no reduce pass any more), at 7x7 in the reduce pass."""
+    import shadernn_amd as snn
+
+    N, H, W, C = shape
+    x, res = _rand((N, H, W, C), 141), _rand((N, H, W, C), 142)
+    w, b, bn = _rand((C, C, 3, 3), 143, 1.0 / np.sqrt(9 * C)), _rand((C,), 144, 0.1), _bn(C, 145)
+    conv = snn.conv2d_plan(ctx, N, H, W, w, b, act="", bn=bn)
+    fused = snn.chain_plan(ctx, [conv, snn.add_plan(ctx, N, H, W, C, act="relu")])
+    assert "kgroups=2" in fused.describe() and "+add" in fused.describe() and fused.num_steps() == 1, fused.describe()
+    got = fused([snn.Tensor.from_numpy(ctx, x), snn.Tensor.from_numpy(ctx, res)]).numpy()
+    for i in (0, N - 1):
+        want = O.add_act(O.conv2d(x[i:i + 1], w, b, 1, (1, 1, 1, 1), "constant", "", 0.0, bn, threads=8), res[i:i + 1], "relu")
+        np.testing.assert_allclose(got[i:i + 1], want, err_msg="%s image %d" % (fused.describe(), i), **TOL)

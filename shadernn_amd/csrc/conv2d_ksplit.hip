@@ -276,8 +276,11 @@ int make_conv2d_ksplit_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     if (inBytes >= 2147483647.0 || outCount >= 2147483647.0) return SNNHIP_E_UNSUPPORTED; // 31-bit byte offsets into the input (kOutOfRange), 32-bit pixel index
     const char* force = snnhip::option("SNNHIP_CONV");
     const bool forced = force && strcmp(force, "ksplit") == 0;
-    // default: the 3x3 stride-2 layers (the shapes conv2d_mfma_kernel runs split-K + a reduce launch on); anything else only when forced
-    if (!forced && !(g.kh == 3 && g.kw == 3 && g.sh == 2 && g.sw == 2 && g.IC >= 32)) return SNNHIP_E_UNSUPPORTED;
+    // default: the 3x3 stride-2 layers (the shapes conv2d_mfma_kernel runs split-K + a reduce launch on) and their 1x1 stride-2 siblings (ResNet's
+    // downsample branch: few short waves, where conv1x1_stream_kernel's weight staging + barrier in front of the first MFMA is a third of a wave's life:
+    // 34.9 -> 27.0 us for the three layers at batch 32, tools/r6_ds2.sh); anything else only when forced
+    const bool s2 = g.sh == 2 && g.sw == 2 && g.IC >= 32;
+    if (!forced && !(s2 && ((g.kh == 3 && g.kw == 3) || (g.kh == 1 && g.kw == 1)))) return SNNHIP_E_UNSUPPORTED;
 
     KsParams p = {};
     p.N = g.N; p.H = g.H; p.W = g.W; p.IC = g.IC; p.OC = g.OC; p.OH = g.OH; p.OW = g.OW;
@@ -294,8 +297,13 @@ int make_conv2d_ksplit_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_o
     // launch should have at least 1.5 waves per SIMD: 32-pixel tiles when 64-pixel tiles give fewer.
     const int simds = (ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256) * 4;
     int mi = 2, ks = 1, depth = 2;
-    while (ks < 8 && p.T / (2 * ks) >= 14) ks *= 2; // 36 iterations -> 2 waves, 72 -> 4, 144 -> 8
-    if (static_cast<double>(up_div(p.M, 64)) * (g.OC / 64) * ks < 1.5 * simds) mi = 1;
+    if (g.kh * g.kw == 1) { // pointwise: four iterations per wave (4 / 8 / 16 iterations -> 1 / 2 / 4 waves), 32-pixel tiles
+        mi = 1;
+        while (ks < 8 && p.T / (2 * ks) >= 4) ks *= 2;
+    } else {
+        while (ks < 8 && p.T / (2 * ks) >= 14) ks *= 2; // 36 iterations -> 2 waves, 72 -> 4, 144 -> 8
+        if (static_cast<double>(up_div(p.M, 64)) * (g.OC / 64) * ks < 1.5 * simds) mi = 1;
+    }
     if (const char* e = snnhip::option("SNNHIP_KSPLIT")) { // experiments: MI,KS[,DEPTH]
         int a = 0, b = 0, c = 0;
         const int n = sscanf(e, "%d,%d,%d", &a, &b, &c);

@@ -501,7 +501,8 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
         const char* force = snnhip::option("SNNHIP_CONV");
         const char* w = snnhip::option("SNNHIP_CONV_KSPLIT");
         const bool forced = force && strcmp(force, "ksplit") == 0;
-        const bool allowed = !force && !(w && atoi(w) == 0) && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_SPLITK") && !snnhip::option("SNNHIP_CONV_C8");
+        const bool allowed = !force && !(w && atoi(w) == 0) && !snnhip::option("SNNHIP_CONV_BN") && !snnhip::option("SNNHIP_CONV_SPLITK") && !snnhip::option("SNNHIP_CONV_C8") &&
+                             !snnhip::option("SNNHIP_CONV_1X1"); // (a pinned pointwise kernel stays pinned)
         if (forced || allowed) {
             const int rc = make_conv2d_ksplit_plan(ctx, g, w_oihw, epi4, out);
             if (rc != SNNHIP_E_UNSUPPORTED || forced) return rc;

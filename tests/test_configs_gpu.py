@@ -277,7 +277,7 @@ def test_c3_resnet18_batch32_through_host_graph_replay(ctx, tmp_path):
         np.testing.assert_allclose(y[n], want, err_msg="image %d" % n, **TOL)
     steps = m.plan_steps()
     kinds = " ".join(d for _, _, d, _, _ in steps)
-    assert "wino" in kinds and "splitK=" in kinds and "stream" in kinds, kinds   # the kernels of the bench line: Winograd body, split-K stage entries, 1x1 s2 stream
+    assert "wino" in kinds and "kgroups=2" in kinds and kinds.count("ksplit") == 6, kinds   # the kernels of the bench line: Winograd body (two K groups at 14x14), the stage entries' 3x3 and 1x1 stride-2 pairs on the K-split kernel
     assert len(steps) <= 24, len(steps)              # rule E folded the eight Adds, rule J the max pool, rule 0b the Flatten
     m.run()                                          # replay
     np.testing.assert_array_equal(m.output().reshape(32, -1), y)

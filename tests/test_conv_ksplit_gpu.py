@@ -38,7 +38,11 @@ CASES = [(2, 56, 56, 64, 128, 3, 2, "relu", True, (1, 1, 1, 1)),       # ResNet-
          (1, 33, 65, 16, 64, 3, 2, "relu6", False, (1, 1, 1, 1)),      # a single chunk per tap
          (2, 12, 20, 64, 64, 3, 1, "relu", True, (1, 1, 1, 1)),        # forced: stride 1
          (1, 15, 15, 16, 64, 5, 2, "SiLU", False, (2, 2, 2, 2)),       # forced: 5x5 stride 2
-         (2, 10, 14, 32, 192, 1, 1, "", False, (0, 0, 0, 0))]          # forced: 1x1 (T = 2 iterations: fewer than some K splits have waves)
+         (2, 10, 14, 32, 192, 1, 1, "", False, (0, 0, 0, 0)),          # forced: 1x1 (T = 2 iterations: fewer than some K splits have waves)
+         (3, 56, 56, 64, 128, 1, 2, "", True, (0, 0, 0, 0)),           # ResNet-18's downsample branches (default plan): 1 / 2 / 4 waves per tile
+         (3, 28, 28, 128, 256, 1, 2, "", True, (0, 0, 0, 0)),
+         (5, 14, 14, 256, 512, 1, 2, "relu", True, (0, 0, 0, 0)),
+         (2, 15, 17, 64, 64, 1, 2, "leakyRelu", False, (0, 0, 0, 0))]  # odd extents
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c[:7]) + "_" + (c[7] or "linear"))
@@ -88,6 +92,9 @@ def test_ksplit_is_the_default_for_fp32_3x3_stride_2_layers(ctx):
     w = _rand((128, 64, 3, 3), 1, 0.05)
     assert "ksplit" in snn.conv2d_plan(ctx, 2, 20, 20, w, stride=2, act="relu").describe()
     assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, w, stride=1, act="relu").describe()                        # stride 1: Winograd
+    w1 = _rand((128, 64, 1, 1), 5, 0.1)
+    assert "ksplit" in snn.conv2d_plan(ctx, 2, 20, 20, w1, stride=2, pads=(0, 0, 0, 0)).describe()                    # the 1x1 stride-2 sibling (downsample branch)
+    assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, w1, stride=1, pads=(0, 0, 0, 0)).describe()                # 1x1 stride 1: the stream kernel
     assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, w, stride=2, pad_mode="reflect").describe()               # reflect padding
     assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, _rand((64, 24, 3, 3), 2, 0.05), stride=2).describe()      # IC % 16 != 0
     assert "ksplit" not in snn.conv2d_plan(ctx, 2, 20, 20, _rand((96, 64, 3, 3), 3, 0.05), stride=2).describe()      # OC % 64 != 0

@@ -159,7 +159,7 @@ def test_wino_k_groups_are_the_default_where_the_planner_splits(ctx):
     d3 = snn.conv2d_plan(ctx, 32, 14, 14, _rand((256, 256, 3, 3), 1, 0.02), act="relu").describe()
     assert "kgroups=2 splitK=1" in d3, d3                                # no reduce launch left
     d4 = snn.conv2d_plan(ctx, 32, 7, 7, _rand((512, 512, 3, 3), 2, 0.02), act="relu").describe()
-    assert "kgroups=2 splitK=2" in d4, d4
+    assert "kgroups=1 splitK=4" in d4, d4                                # a deeper split keeps its reduce launch: the groups would not pay
     d1 = snn.conv2d_plan(ctx, 32, 56, 56, _rand((64, 64, 3, 3), 3, 0.05), act="relu").describe()
     assert "kgroups=1 splitK=1" in d1, d1                                # enough block tiles: nothing to split
 
@@ -172,8 +172,12 @@ def test_wino_k_groups_with_the_fused_residual_add(ctx, shape):
     N, H, W, C = shape
     x, res = _rand((N, H, W, C), 141), _rand((N, H, W, C), 142)
     w, b, bn = _rand((C, C, 3, 3), 143, 1.0 / np.sqrt(9 * C)), _rand((C,), 144, 0.1), _bn(C, 145)
-    conv = snn.conv2d_plan(ctx, N, H, W, w, b, act="", bn=bn)
-    fused = snn.chain_plan(ctx, [conv, snn.add_plan(ctx, N, H, W, C, act="relu")])
+    os.environ["SNNHIP_WINO_KGROUPS"] = "2"   # (the planner's own choice at 14x14; forced at 7x7)
+    try:
+        conv = snn.conv2d_plan(ctx, N, H, W, w, b, act="", bn=bn)
+        fused = snn.chain_plan(ctx, [conv, snn.add_plan(ctx, N, H, W, C, act="relu")])
+    finally:
+        os.environ.pop("SNNHIP_WINO_KGROUPS")
     assert "kgroups=2" in fused.describe() and "+add" in fused.describe() and fused.num_steps() == 1, fused.describe()
     got = fused([snn.Tensor.from_numpy(ctx, x), snn.Tensor.from_numpy(ctx, res)]).numpy()
     for i in (0, N - 1):

@@ -137,3 +137,41 @@ def test_ksplit_resnet_shapes_batch32_properties(ctx):
         for i in (1, 13, 31):
             np.testing.assert_array_equal(got[i], got[0], err_msg="%s image %d" % (p.describe(), i))
         np.testing.assert_allclose(got[:1], O.conv2d(x1, w, b, 2, (1, 1, 1, 1), "constant", "relu", 0.0, bn, threads=8), err_msg=p.describe(), **TOL)
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        k = int(rng.choice([1, 2, 3, 3, 4, 5, 7]))
+        s = int(rng.choice([1, 2, 2]))
+        ic = int(rng.choice([16, 32, 48, 64, 96, 144]))
+        oc = int(rng.choice([64, 128, 192]))
+        h, w = int(rng.integers(max(k, 5), 36)), int(rng.integers(max(k, 5), 40))
+        b = int(rng.choice([1, 2, 3, 5]))
+        if b * h * w * ic * k * k * oc > 3e8:  # keep the oracle fast
+            continue
+        padding = "same" if k % 2 == 0 else str(rng.choice(["same", "valid"]))
+        out.append((b, h, w, ic, oc, k, s, str(rng.choice(["", "relu", "relu6", "tanh", "sigmoid", "leakyRelu", "SiLU"])), bool(rng.integers(0, 2)), padding,
+                    str(rng.choice(GEOMS)), int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(40, 20261001), ids=lambda c: "n%d_%dx%d_%d-%d_k%ds%d_%s_bn%d_%s_g%s" % c[:11])
+def test_ksplit_random_shapes_and_geometries_match_oracle(ctx, case):
+    """Randomised sweep (fixed seed) of the kernel forced on shapes it is not the default for: kernel sizes 1 .. 7 (even ones with their asymmetric "same"
+    padding), both strides, ragged maps and batches, every activation, a random (tile, K split, look-ahead) instantiation per case."""
+    import shadernn_amd as snn
+
+    n, h, w, ic, oc, k, s, act, use_bn, padding, geom, seed = case
+    x = _rand((n, h, w, ic), seed)
+    wt = _rand((oc, ic, k, k), seed + 1, 1.0 / np.sqrt(ic * k * k))
+    b = _rand((oc,), seed + 2, 0.2)
+    bn = _bn(oc, seed + 3) if use_bn else None
+    pads = O.padding_offsets(padding, k)
+    plan = _plan(ctx, "ksplit", n, h, w, wt, b, stride=s, pads=pads, act=act, leaky=0.15, bn=bn, geom=geom)
+    assert "ksplit" in plan.describe(), plan.describe()
+    got = plan(snn.Tensor.from_numpy(ctx, x)).numpy()
+    want = O.conv2d(x, wt, b, s, pads, "constant", act, 0.15, bn)
+    assert got.shape == want.shape, plan.describe()
+    np.testing.assert_allclose(got, want, err_msg=plan.describe(), **TOL)

@@ -811,6 +811,33 @@ int snnhip_conv2d_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, c
     if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_thin_plan(ctx, g, w_oihw, epi, out);
     if (rc == SNNHIP_E_UNSUPPORTED) rc = make_conv2d_mfma_plan(ctx, g, w_oihw, epi, out);
     if (rc == SNNHIP_E_UNSUPPORTED && g.dtype != SNNHIP_F32) {
+        // A half-precision layer whose OWN input or output tensor has 2^31 or more elements (Candy's 64 -> 32 up-convolution at 32 images: the x2-upsampled,
+        // padded 64-channel tensor it nominally reads has 2.3e9 -- a tensor that never exists, graph rule D evaluates the layer on the low-resolution one):
+        // the layer gets a description-only plan the chain planner can fuse from (geometry, weights, epilogue table); running it alone fails with a message.
+        const double inCount = static_cast<double>(g.N) * g.H * g.W * g.IC, outCount = static_cast<double>(g.N) * g.OH * g.OW * g.OC;
+        if (inCount >= 2147483647.0 || outCount >= 2147483647.0) {
+            struct OversizeConvPlan : ConvPlanBase {
+                int run(const snnhip_tensor* const*, int, snnhip_tensor*) override {
+                    set_error("conv2d: %s -- a tensor of 2^31 or more elements: this layer only runs fused behind its UpSampling2D / Pad (graph rule D)", desc.c_str());
+                    return SNNHIP_E_UNSUPPORTED;
+                }
+            };
+            auto* plan = new OversizeConvPlan();
+            plan->ctx = ctx;
+            plan->g = g;
+            plan->w_oihw.assign(w_oihw, w_oihw + static_cast<size_t>(g.OC) * g.IC * g.kh * g.kw);
+            plan->epi4 = epi;
+            plan->dtype = g.dtype;
+            plan->inDims[0] = g.N; plan->inDims[1] = g.H; plan->inDims[2] = g.W; plan->inDims[3] = g.IC;
+            plan->outDims[0] = g.N; plan->outDims[1] = g.OH; plan->outDims[2] = g.OW; plan->outDims[3] = g.OC;
+            plan->flops = 2.0 * g.kh * g.kw * g.IC * g.OC * static_cast<double>(g.OH) * g.OW * g.N;
+            plan->bytes = 2.0 * (inCount + outCount + static_cast<double>(g.OC) * g.IC * g.kh * g.kw);
+            char buf[200];
+            snprintf(buf, sizeof(buf), "conv2d_mfma_f16 k=%dx%d s=%d ic=%d oc=%d OVERSIZE (%.3g input elements): description only, runs fused (rule D)", g.kh, g.kw, g.sh, g.IC, g.OC, inCount);
+            plan->desc = buf;
+            *out = plan;
+            return SNNHIP_OK;
+        }
         set_error("conv2d: no fp16 kernel takes this shape (k=%dx%d stride %d, %d->%d)", g.kh, g.kw, g.sh, g.IC, g.OC);
         return rc;
     }

@@ -710,3 +710,36 @@ def test_upconv_normalises_the_low_resolution_tensor_while_it_stages(ctx, monkey
     # the switch: SNNHIP_NO_UPCONV_NORM keeps the norm's own normalise sweep in front of the up-convolution
     monkeypatch.setenv("SNNHIP_NO_UPCONV_NORM", "1")
     assert "in the staging" not in snn.chain_plan(ctx, [norm, up, pad, conv]).describe()
+
+
+def test_an_oversize_up_convolution_is_a_description_only_plan_that_runs_fused(ctx):
+    """Candy's 64 -> 32 up-convolution at bench.py's c5 micro-batch of 32: the tensor the layer nominally reads -- the x2-upsampled, padded 64-channel map --
+    has 32 x 818 x 1378 x 64 = 2.3e9 elements, beyond the 32-bit element offsets of every fp16 convolution kernel, and it never exists: graph rule D
+    evaluates the layer on the low-resolution tensor (conv2d_upconv).  The per-layer plan the host creates first is therefore description-only (geometry +
+    weights for the chain planner): running it fails with a message, the fused chain runs and gives every image what a two-image batch gives."""
+    import shadernn_amd as snn
+
+    n, h, w_, ic, oc = 32, 408, 688, 64, 32
+    wt, b = _rand((oc, ic, 3, 3), 2, 1.0 / np.sqrt(ic * 9)), _rand((oc,), 3, 0.2)
+
+    def plans(nn):
+        return [snn.upsample_plan(ctx, nn, h, w_, ic, 2.0, "nearest"), snn.pad_plan(ctx, nn, 2 * h, 2 * w_, ic, (1, 1, 1, 1), "reflect"),
+                snn.conv2d_plan(ctx, nn, 2 * h + 2, 2 * w_ + 2, wt, b, stride=1, pads=(0, 0, 0, 0), act="", dtype=snn.F16)]
+
+    big = plans(n)
+    assert "OVERSIZE" in big[2].describe(), big[2].describe()
+    pair = _rand((2, h, w_, ic), 1)
+    with pytest.raises(snn.SnnHipError, match="only runs fused"):
+        big[2](snn.Tensor(ctx, 1, 4, 4, ic, dtype=snn.F16), snn.Tensor(ctx, 1, 4, 4, oc, dtype=snn.F16))  # (the plan refuses before it looks at a tensor)
+    fused = snn.chain_plan(ctx, big)
+    assert fused.num_steps() == 1 and "upconv" in fused.describe() and "+upsample(x2)" in fused.describe(), fused.describe()
+    x = np.empty((n, h, w_, ic), np.float32)
+    x[0::2], x[1::2] = pair[0], pair[1]
+    y = fused(snn.Tensor.from_numpy(ctx, x, dtype=snn.F16)).numpy()
+    del x
+    small = snn.chain_plan(ctx, plans(2))
+    assert "OVERSIZE" not in small.describe()
+    want = small(snn.Tensor.from_numpy(ctx, pair, dtype=snn.F16)).numpy()
+    assert y.shape == (n, 2 * h + 2, 2 * w_ + 2, oc) and np.isfinite(want).all()
+    for i in (0, 1, 16, 31):
+        np.testing.assert_array_equal(y[i], want[i % 2], err_msg="image %d" % i)

@@ -15,7 +15,7 @@ Configs (BASELINE.json `configs`, SURVEY 8d shapes; default c2 = the configurati
       (--micro N overrides; measured on one MI355X: c4 as 8 x 32 images 9.4 ms, 4 x 64 6.6 ms, 2 x 128 5.6 ms, 1 x 256 5.0 ms per step --
       the 14x14 / 7x7 layers of a 32-image batch do not fill 256 CUs; c5 as 4 x 16 images 24.8 ms, 2 x 32 23.6 ms -- half the launches, and the
       persistent 128 -> 128 kernel's 512 blocks walk 16.5 tiles each instead of 8.25, i.e. 17 / 16.5 rounds instead of 9 / 8.25; 64 images in one
-      pass would put 2^31 elements into single tensors, beyond the 32-bit element offsets of the fp16 kernels)
+      pass would put 2^31 elements into single tensors, beyond the 32-bit element offsets of the fp16 kernels: refused)
 One "step" = one pass of the path over that batch, inputs already resident in HBM.  Every config runs through the C++ host mirror by
 default (libsnn_core.so: the net written as the reference's .json + .bin model -> ModelParser -> MixedInferenceCore::create / run, fusion by
 HipBackend::finalizeStages, the inference replayed as one recorded hipGraph); `--through capi` drives per-layer plans from Python instead.
@@ -77,7 +77,7 @@ CONFIGS = {
     "c4": {"workload": "MobileNetV2 224x224 fp32, global batch 256 sharded over the GPUs (BASELINE configs[3])", "dtype": "f32", "scaling": "strong",
            "global": 256, "micro": 256, "hw": (224, 224), "cin": 3},
     "c5": {"workload": "Candy fast-neural-style (zoo graph) 720p fp16, global batch 64 sharded over the GPUs (BASELINE configs[4])", "dtype": "f16",
-           "scaling": "strong", "global": 64, "micro": 32, "hw": (720, 1280), "cin": 3},
+           "scaling": "strong", "global": 64, "micro": 32, "micro_max": 32, "hw": (720, 1280), "cin": 3},
 }
 
 
@@ -108,6 +108,9 @@ def shard_plan(config, world, rank, micro=0):
         images, global_batch, first = hi - lo, cfg["global"], lo
     else:
         images, global_batch, first = cfg["per_rank"], cfg["per_rank"] * world, rank * cfg["per_rank"]
+    if micro and micro > cfg.get("micro_max", 1 << 30):
+        raise SystemExit("bench.py: REFUSED: --micro %d for %s: more than %d images per pass put 2^31 or more elements into single tensors (beyond the fp16 "
+                         "kernels' 32-bit element offsets; a 64-image pass took a GPU box down)" % (micro, config, cfg["micro_max"]))
     sizes, left = [], images
     while left > 0:
         sizes.append(min(micro or cfg["micro"], left))

@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -146,6 +147,9 @@ def test_shard_plan_every_config_and_world():
                 assert plans[0]["global_batch"] == world * cfg["per_rank"]
     assert bench.shard_plan("c4", 8, 3) == {"images": 32, "global_batch": 256, "first_image": 96, "micro_sizes": [32]}
     assert bench.shard_plan("c5", 8, 7) == {"images": 8, "global_batch": 64, "first_image": 56, "micro_sizes": [8]}
+    assert bench.shard_plan("c5", 1, 0)["micro_sizes"] == [32, 32] and bench.shard_plan("c5", 1, 0, micro=16)["micro_sizes"] == [16] * 4
+    with pytest.raises(SystemExit, match="REFUSED"):  # 64 images per pass: single tensors of 2^31 elements
+        bench.shard_plan("c5", 1, 0, micro=64)
 
 
 def test_bench_self_spawns_ranks_from_a_plain_shell():

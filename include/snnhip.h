@@ -150,7 +150,10 @@ typedef struct {
     int OH, OW;                 /* 0 => derived with the reference's float rule (conv2d.cpp:102-113) */
 } snnhip_conv2d_desc;
 
-/* w_oihw [OC][IC][kh][kw]; bias [OC] or NULL; BN arrays [OC] or NULL (required when useBN). Host pointers. */
+/* w_oihw [OC][IC][kh][kw]; bias [OC] or NULL; BN arrays [OC] or NULL (required when useBN). Host pointers.
+ * A half-precision layer whose own input or output tensor would have 2^31 or more elements (a layer behind a fused UpSampling2D / Pad, whose nominal
+ * input never exists) gets a DESCRIPTION-ONLY plan: snnhip_chain_plan_create fuses from it (graph rule D), snnhip_plan_run on it alone returns
+ * SNNHIP_E_UNSUPPORTED with a message. */
 int snnhip_conv2d_plan_create(snnhip_ctx* ctx, const snnhip_conv2d_desc* desc, const float* w_oihw, const float* bias,
                               const float* bn_beta, const float* bn_gamma, const float* bn_mean, const float* bn_var,
                               snnhip_plan** out);

@@ -5,14 +5,14 @@
 #                                AMD_LOG_LEVEL=1 HSA_ENABLE_DEBUG=1 (out-of-bounds accesses of a kernel show up as a memory-access fault that aborts the run)
 #   tools/sanitize.sh guard      on a GPU box: the device-side guard mode (SNNHIP_GUARD=1, include/snnhip.h: red zones of 0xFF around every device allocation,
 #                                checked at every snnhip_sync / download) over the randomised convolution / operator sweeps, the inverted-residual kernels,
-#                                the fp16 wide / marching kernels and the bench-size configs c1-c4, plus the deliberately broken build the checker must catch
+#                                the fp16 wide / marching kernels, the K-split and Winograd kernels and the bench-size configs c1-c4, plus the deliberately broken build the checker must catch
 set -eu
 cd "$(dirname "$0")/.."
 if [ "${1:-cpu}" = "guard" ]; then
   python -c "import __graft_entry__ as g; g.build_hip(); g.build_host()"
   [ -f build/abl/libsnnhip_guardbreak.so ] || tools/exp_one.sh conv2d_generic.hip guardbreak:-DSNNHIP_GUARD_BREAK=1 > /dev/null
   python -m pytest tests/test_guard_gpu.py -q -m gpu -x
-  SNNHIP_GUARD=1 python -m pytest tests/test_conv_fuzz_gpu.py tests/test_ops_fuzz_gpu.py tests/test_irb_gpu.py tests/test_conv_wide_gpu.py tests/test_conv_widep_gpu.py tests/test_espcn_gpu.py -q -m gpu -x
+  SNNHIP_GUARD=1 python -m pytest tests/test_conv_fuzz_gpu.py tests/test_ops_fuzz_gpu.py tests/test_irb_gpu.py tests/test_conv_wide_gpu.py tests/test_conv_widep_gpu.py tests/test_conv_ksplit_gpu.py tests/test_conv_wino_gpu.py tests/test_espcn_gpu.py -q -m gpu -x
   SNNHIP_GUARD=1 python -m pytest tests/test_configs_gpu.py tests/test_golden.py -q -m gpu -x -k "not c5"
   exit 0
 fi

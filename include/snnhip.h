@@ -98,6 +98,14 @@ void* snnhip_ctx_stream(snnhip_ctx* ctx);
 int snnhip_ctx_fork(snnhip_ctx* ctx);
 int snnhip_ctx_main(snnhip_ctx* ctx);
 int snnhip_ctx_join(snnhip_ctx* ctx);
+/* Launch groups (HIP extension, round 6): plans that report snnhip_plan_groupable (today: the K-split convolutions of conv2d_ksplit.hip) and are run
+ * between _group_begin and _group_end are launched by _group_end -- two independent ones that fit one grid as ONE kernel launch (a ResNet stage entry's
+ * 3x3 stride-2 convolution and the 1x1 stride-2 downsample beside it: the short blocks of the second fill the CUs the first leaves idle), anything
+ * else one by one.  The caller guarantees that the grouped plans do not consume each other's outputs; every other plan run inside a group is launched
+ * at once, as usual.  Valid inside a graph capture. */
+int snnhip_ctx_group_begin(snnhip_ctx* ctx);
+int snnhip_ctx_group_end(snnhip_ctx* ctx);
+int snnhip_plan_groupable(const snnhip_plan* plan);
 int snnhip_sync(snnhip_ctx* ctx);
 const char* snnhip_last_error(void);
 const char* snnhip_version(void);

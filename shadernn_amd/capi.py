@@ -106,6 +106,9 @@ SIGNATURES = {
     "snnhip_ctx_fork": (C.c_int, [_P]),
     "snnhip_ctx_main": (C.c_int, [_P]),
     "snnhip_ctx_join": (C.c_int, [_P]),
+    "snnhip_ctx_group_begin": (C.c_int, [_P]),
+    "snnhip_ctx_group_end": (C.c_int, [_P]),
+    "snnhip_plan_groupable": (C.c_int, [_P]),
     "snnhip_sync": (C.c_int, [_P]),
     "snnhip_last_error": (C.c_char_p, []),
     "snnhip_version": (C.c_char_p, []),
@@ -274,6 +277,13 @@ class Context:
         """back on the main stream, which waits for the side stream's work"""
         check(lib().snnhip_ctx_join(self.h))
 
+    def group_begin(self):
+        """groupable plans (Plan.groupable()) run from now on are launched by group_end -- two that fit one grid as ONE kernel launch"""
+        check(lib().snnhip_ctx_group_begin(self.h))
+
+    def group_end(self):
+        check(lib().snnhip_ctx_group_end(self.h))
+
     def close(self):
         if self.h:
             lib().snnhip_ctx_destroy(self.h)
@@ -391,6 +401,9 @@ class Plan:
             y = Tensor(self.ctx, *self.out_shape(), dtype=first.dtype)
         self.run(x, y)
         return y
+
+    def groupable(self):
+        return bool(lib().snnhip_plan_groupable(self.h))
 
     def num_steps(self):
         return lib().snnhip_plan_num_steps(self.h)

@@ -352,6 +352,19 @@ int snnhip_ctx_main(snnhip_ctx* ctx) {
     return SNNHIP_OK;
 }
 
+int snnhip_ctx_group_begin(snnhip_ctx* ctx) {
+    SNNHIP_REQUIRE(ctx, "ctx_group_begin: null context");
+    return snnhip::ksplit_group_begin(ctx);
+}
+
+int snnhip_ctx_group_end(snnhip_ctx* ctx) {
+    SNNHIP_REQUIRE(ctx, "ctx_group_end: null context");
+    SNNHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    return snnhip::ksplit_group_end(ctx);
+}
+
+int snnhip_plan_groupable(const snnhip_plan* plan) { return plan && snnhip::ksplit_plan(plan) ? 1 : 0; }
+
 int snnhip_ctx_join(snnhip_ctx* ctx) {
     SNNHIP_REQUIRE(ctx && ctx->sideStream, "ctx_join: nothing was forked");
     ctx->stream = ctx->mainStream;

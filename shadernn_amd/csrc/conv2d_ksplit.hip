@@ -55,16 +55,16 @@ struct KsParams {
 
 constexpr unsigned kOutOfRange = 0x80000000u; // a byte offset no descriptor of this kernel covers (tensors < 2 GiB): the load returns zeros
 
+// one block's work: output tile `blk` of the problem (p, x, wpk, epi, y); red = the block's LDS, [KS][G][64] float4
 template <bool SIMPLE, int MI, int KS, int DEPTH>
-__global__ __launch_bounds__(64 * KS) void conv2d_ksplit_kernel(KsParams p, ActCfg ac, const float* __restrict__ x, const float4* __restrict__ wpk,
-                                                               const float4* __restrict__ epi, float* __restrict__ y) {
+__device__ __forceinline__ void ksplit_tile(const KsParams& p, const ActCfg& ac, const float* __restrict__ x, const float4* __restrict__ wpk,
+                                            const float4* __restrict__ epi, float* __restrict__ y, const int blk, f32x4* const red) {
     constexpr int G = 8 * MI;               // accumulator quads (float4) per lane
     constexpr int GW = (G + KS - 1) / KS;   // quads a wave owns in the reduction (quad g belongs to wave g % KS)
     static_assert(KS >= 1 && KS <= G, "at most one wave per accumulator quad");
-    extern __shared__ __attribute__((aligned(16))) f32x4 red[]; // [KS][G][64]
     const int lane = threadIdx.x & 63, k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (k in a scalar register: the K range, the tap walk and the loop are wave-uniform)
     const int r = lane & 31, h = lane >> 5;
-    const int mTile = blockIdx.x % p.mTiles, ocTile = blockIdx.x / p.mTiles;
+    const int mTile = blk % p.mTiles, ocTile = blk / p.mTiles;
 
     const __amdgpu_buffer_rsrc_t xRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, static_cast<int>(p.xBytes), 0x00020000);
 
@@ -219,6 +219,41 @@ __global__ __launch_bounds__(64 * KS) void conv2d_ksplit_kernel(KsParams p, ActC
     }
 }
 
+template <bool SIMPLE, int MI, int KS, int DEPTH>
+__global__ __launch_bounds__(64 * KS) void conv2d_ksplit_kernel(KsParams p, ActCfg ac, const float* __restrict__ x, const float4* __restrict__ wpk,
+                                                               const float4* __restrict__ epi, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 red[];
+    ksplit_tile<SIMPLE, MI, KS, DEPTH>(p, ac, x, wpk, epi, y, blockIdx.x, red);
+}
+
+// Two problems in ONE launch (snnhip_ctx_group_begin / _end around two independent plans: the 3x3 stride-2 convolution of a ResNet stage entry and the
+// 1x1 stride-2 downsample beside it, both reading the same tensor): blocks [0, nA) are tiles of A (64 pixels), the rest tiles of B (32 pixels) -- the
+// short ones last, where they fill the CUs the first problem's 1.53 or 3.06 blocks per CU leave idle, instead of a launch of their own behind it.
+struct KsPair {
+    KsParams a, b;
+    ActCfg aca, acb;
+    const float *xa, *xb;
+    const float4 *wa, *wb, *ea, *eb;
+    float *ya, *yb;
+    int nA;
+};
+template <int KS>
+__global__ __launch_bounds__(64 * KS) void conv2d_ksplit_pair_kernel(KsPair q) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 red[];
+    if (static_cast<int>(blockIdx.x) < q.nA) ksplit_tile<true, 2, KS, 2>(q.a, q.aca, q.xa, q.wa, q.ea, q.ya, blockIdx.x, red);
+    else ksplit_tile<true, 1, KS, 2>(q.b, q.acb, q.xb, q.wb, q.eb, q.yb, static_cast<int>(blockIdx.x) - q.nA, red);
+}
+
+struct KsplitConvPlan;
+struct KsDeferred {
+    KsplitConvPlan* plan;
+    const float* x;
+    float* y;
+};
+struct KsGroup {
+    std::vector<KsDeferred> items;
+};
+
 struct KsplitConvPlan : ConvPlanBase {
     KsParams p;
     ActCfg ac;
@@ -248,10 +283,15 @@ struct KsplitConvPlan : ConvPlanBase {
                        x->c, p.N, p.H, p.W, p.IC);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.OC, "conv2d: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n,
                        out->h, out->w, out->c, p.N, p.OH, p.OW, p.OC);
-        const float* xd = x->data;
+        if (ctx->ksGroup) { // inside snnhip_ctx_group_begin / _end: launched (alone or with its partner) by the group's end
+            static_cast<KsGroup*>(ctx->ksGroup)->items.push_back({this, x->data, out->data});
+            return SNNHIP_OK;
+        }
+        return launch(x->data, out->data);
+    }
+    int launch(const float* xd, float* yd) {
         const float4* w4 = reinterpret_cast<const float4*>(d_w);
         const float4* e4 = reinterpret_cast<const float4*>(d_epi);
-        float* yd = out->data;
         void* args[] = {&p, &ac, &xd, &w4, &e4, &yd};
         if (::snnhip::trace_active()) { // (SNNHIP_LAUNCH for a kernel picked at run time)
             hipEvent_t evS = nullptr, evE = nullptr;
@@ -264,7 +304,71 @@ struct KsplitConvPlan : ConvPlanBase {
     }
 };
 
+int launch_pair(snnhip_ctx* ctx, const KsDeferred& A, const KsDeferred& B) {
+    KsPair q;
+    q.a = A.plan->p; q.b = B.plan->p;
+    q.aca = A.plan->ac; q.acb = B.plan->ac;
+    q.xa = A.x; q.xb = B.x;
+    q.wa = reinterpret_cast<const float4*>(A.plan->d_w); q.wb = reinterpret_cast<const float4*>(B.plan->d_w);
+    q.ea = reinterpret_cast<const float4*>(A.plan->d_epi); q.eb = reinterpret_cast<const float4*>(B.plan->d_epi);
+    q.ya = A.y; q.yb = B.y;
+    q.nA = static_cast<int>(A.plan->grid.x);
+    const int ks = A.plan->ks;
+    const void* fn = ks == 2 ? reinterpret_cast<const void*>(conv2d_ksplit_pair_kernel<2>) : ks == 4 ? reinterpret_cast<const void*>(conv2d_ksplit_pair_kernel<4>)
+                                                                                                 : reinterpret_cast<const void*>(conv2d_ksplit_pair_kernel<8>);
+    const size_t lds = static_cast<size_t>(ks) * 16 * 64 * sizeof(float4); // A's (two pixel tiles per wave) covers B's
+    static bool ldsSet[3] = {false, false, false}; // (once per kernel: not inside every recorded launch)
+    bool& set = ldsSet[ks == 2 ? 0 : ks == 4 ? 1 : 2];
+    if (lds > 64 * 1024 && !set) {
+        SNNHIP_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        set = true;
+    }
+    const dim3 grid(A.plan->grid.x + B.plan->grid.x);
+    void* args[] = {&q};
+    const double sharedIn = A.x == B.x ? 4.0 * A.plan->p.N * A.plan->p.H * A.plan->p.W * A.plan->p.IC : 0.0; // the tensor both read: once
+    TraceScope ts("conv2d_ksplit pair [" + A.plan->desc + "] + [" + B.plan->desc + "]", A.plan->flops + B.plan->flops, A.plan->bytes + B.plan->bytes - sharedIn);
+    if (::snnhip::trace_active()) {
+        hipEvent_t evS = nullptr, evE = nullptr;
+        (void) ::snnhip::trace_events(fn, ctx->stream, &evS, &evE);
+        SNNHIP_CHECK_HIP(hipExtLaunchKernel(fn, grid, dim3(64 * ks), args, lds, ctx->stream, evS, evE, 0));
+    } else {
+        SNNHIP_CHECK_HIP(hipLaunchKernel(fn, grid, dim3(64 * ks), args, lds, ctx->stream));
+    }
+    return SNNHIP_OK;
+}
+
 } // namespace
+
+// ---- launch groups (include/snnhip.h: snnhip_ctx_group_begin / _end): K-split plans run between the two calls are launched by the group's end -- two
+// that fit one grid (a 64-pixel-tile problem split over 2 / 4 / 8 waves and a 32-pixel-tile one, simple activations) as ONE launch, anything else one by one
+bool ksplit_plan(const snnhip_plan* plan) { return dynamic_cast<const KsplitConvPlan*>(plan) != nullptr; }
+int ksplit_group_begin(snnhip_ctx* ctx) {
+    SNNHIP_REQUIRE(!ctx->ksGroup, "ctx_group_begin: a group is already open on this context");
+    ctx->ksGroup = new KsGroup();
+    return SNNHIP_OK;
+}
+int ksplit_group_end(snnhip_ctx* ctx) {
+    SNNHIP_REQUIRE(ctx->ksGroup, "ctx_group_end: no group is open on this context");
+    KsGroup* g = static_cast<KsGroup*>(ctx->ksGroup);
+    ctx->ksGroup = nullptr;
+    int rc = SNNHIP_OK;
+    auto fits = [](const KsDeferred& a, const KsDeferred& b) {
+        return a.plan->mi == 2 && b.plan->mi == 1 && a.plan->simple && b.plan->simple && a.plan->depth == 2 && (a.plan->ks == 2 || a.plan->ks == 4 || a.plan->ks == 8) &&
+               a.plan->ks <= 8 && !SNNHIP_KS_ABL;
+    };
+    if (g->items.size() == 2 && !snnhip::option("SNNHIP_KSPLIT_NO_PAIRS") && (fits(g->items[0], g->items[1]) || fits(g->items[1], g->items[0]))) {
+        const bool first = fits(g->items[0], g->items[1]);
+        rc = launch_pair(ctx, g->items[first ? 0 : 1], g->items[first ? 1 : 0]);
+    } else {
+        for (const KsDeferred& d : g->items) {
+            TraceScope ts(d.plan);
+            const int r1 = d.plan->launch(d.x, d.y);
+            if (r1 != SNNHIP_OK) rc = r1;
+        }
+    }
+    delete g;
+    return rc;
+}
 
 int make_conv2d_ksplit_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out) {
     // eligibility: fp32, zero padding by clipped taps, no fused neighbours, whole 16-channel iterations and 64-channel output tiles

@@ -104,6 +104,7 @@ struct snnhip_ctx {
     hipDeviceProp_t props;
     hipStream_t mainStream = nullptr, sideStream = nullptr;
     hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
+    void* ksGroup = nullptr; // an open launch group (snnhip_ctx_group_begin; conv2d_ksplit.hip owns the object)
 };
 
 struct snnhip_tensor {
@@ -225,6 +226,10 @@ int make_conv2d_mfma_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
 int make_conv1x1_stream_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // tried first by make_conv2d_mfma_plan
 int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // tried first by make_conv2d_mfma_plan for fp32 3x3 s1
 int make_conv2d_ksplit_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp32 3x3 s2 (K split over the waves of a block, no reduce launch); tried by make_conv2d_mfma_plan
+// conv2d_ksplit.hip: launch groups -- K-split plans run inside a group are launched by its end, two compatible ones as ONE grid
+bool ksplit_plan(const snnhip_plan* plan);
+int ksplit_group_begin(snnhip_ctx* ctx);
+int ksplit_group_end(snnhip_ctx* ctx);
 int make_conv2d_stem_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp16 9x9 s1, IC <= 4; tried first by make_conv2d_mfma_plan
 int make_conv2d_stem32_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp32 stems (IC <= 4), tried first by make_conv2d_mfma_plan
 int make_conv2d_wide_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oihw, const std::vector<float>& epi4, snnhip_plan** out); // fp16 3x3 s1, large maps; tried first by make_conv2d_mfma_plan

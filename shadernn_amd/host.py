@@ -186,7 +186,7 @@ class Model:
             d = (C.c_int * 3)()
             fused = C.c_int()
             lib().snn_model_stage_info(self.h, i, name, 512, C.byref(d), C.byref(fused))
-            out.append({"name": name.value.decode(), "hwc": tuple(d), "fused_away": bool(fused.value & 1), "side": bool(fused.value & 2)})
+            out.append({"name": name.value.decode(), "hwc": tuple(d), "fused_away": bool(fused.value & 1), "side": bool(fused.value & 2), "group": bool(fused.value & 4)})
         return out
 
     def stage_output(self, i):

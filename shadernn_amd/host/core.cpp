@@ -172,6 +172,15 @@ void MixedInferenceCore::run(RunParameters& rp) { // core.cpp:97-245
         // runs on the main stream beside it, and the main stream waits for both before the stage that consumes them
         size_t j = i + 1;
         while (j < stages.size() && (stages[j].layer->isInputLayer || stages[j].fusedAway)) ++j;
+        if (sideBySide && j < stages.size() && stages[j].groupWithPrevious && backend->groupBegin()) { // one launch for both (HipBackend::finalizeStages)
+            runStage(s);
+            for (size_t m = i + 1; m < j; ++m)
+                if (!stages[m].layer->isInputLayer) runStage(stages[m]); // (fused-away stages in between: input binding only, nothing is launched)
+            runStage(stages[j]);
+            backend->groupEnd();
+            i = j;
+            continue;
+        }
         if (sideBySide && j < stages.size() && stages[j].sideOfPrevious && backend->forkSide()) {
             for (size_t m = i + 1; m < j; ++m)
                 if (!stages[m].layer->isInputLayer) runStage(stages[m]); // (fused-away stages in between: input binding only, nothing is launched)

@@ -108,6 +108,8 @@ void HipBackend::dropRecording() {
 bool HipBackend::forkSide() { return snnhip_ctx_fork(ctx) == SNNHIP_OK; }
 void HipBackend::backToMain() { hipChk(snnhip_ctx_main(ctx), "snnhip_ctx_main"); }
 void HipBackend::joinSide() { hipChk(snnhip_ctx_join(ctx), "snnhip_ctx_join"); }
+bool HipBackend::groupBegin() { return snnhip_ctx_group_begin(ctx) == SNNHIP_OK; }
+void HipBackend::groupEnd() { hipChk(snnhip_ctx_group_end(ctx), "snnhip_ctx_group_end"); }
 
 DeviceTimer* HipBackend::createDeviceTimer(const std::string& name) { return new HipDeviceTimer(ctx, name); }
 
@@ -183,8 +185,13 @@ void HipBackend::finalizeStages(RenderStagesArray& stages, bool dumpOutputs, boo
     // time (k itself must not be the side stage of another pair).  Opt-in (SNN_BRANCH_OVERLAP=1): measured on ResNet-18 b32 the 1x1 stride-2
     // downsample (19 us alone) and the split-K 3x3 stride-2 convolution (53 us alone) do run concurrently (137 / 181 us summed over the three pairs
     // instead of 56 / 160) but each already fills the chip: 1.104 ms per step with the overlap, 1.101 ms without.
+    // Round 6: when BOTH stages of such a pair run plans the library can put into one grid (snnhip_plan_groupable: conv2d_ksplit's 3x3 stride-2 convolution
+    // and the 1x1 stride-2 downsample beside it), run() brackets them with a launch group instead -- one launch, the short blocks of the second behind the
+    // first's; the default (SNN_STAGE_GROUPS=0: off).
     const char* overlap = getenv("SNN_BRANCH_OVERLAP");
-    if (!overlap || atoi(overlap) == 0) return;
+    const char* groupsEnv = getenv("SNN_STAGE_GROUPS");
+    const bool wantOverlap = overlap && atoi(overlap) != 0, wantGroups = !(groupsEnv && atoi(groupsEnv) == 0);
+    if (!wantOverlap && !wantGroups) return;
     int prev = -1;
     for (size_t i = 0; i < stages.size(); ++i) {
         HipRenderPass* rp = passOf(i);
@@ -194,14 +201,21 @@ void HipBackend::finalizeStages(RenderStagesArray& stages, bool dumpOutputs, boo
         }
         const int nIn = fused[i].plan ? fused[i].n_inputs : nodes[i].n_inputs;
         const int* ins = fused[i].plan ? fused[i].inputs : nodes[i].inputs;
-        bool independent = prev >= 0 && !stages[static_cast<size_t>(prev)].sideOfPrevious;
+        bool independent = prev >= 0 && !stages[static_cast<size_t>(prev)].sideOfPrevious && !stages[static_cast<size_t>(prev)].groupWithPrevious;
         for (int k = 0; k < nIn && independent; ++k) independent = ins[k] != prev;
         // the previous stage's fused group must not contain a producer of i either (a fused plan sits at the LAST stage of its group)
         for (int k = 0; k < nIn && independent; ++k)
             if (ins[k] >= 0 && ins[k] < prev && stages[static_cast<size_t>(ins[k])].fusedAway) independent = false;
         if (independent && i + 1 < stages.size()) { // (never the model's last stage: its output is bound to the caller)
-            stages[i].sideOfPrevious = true;
-            SNN_LOGI("stage %zu (%s) runs beside stage %d (%s) on the side stream", i, stages[i].layer->name.c_str(), prev, stages[static_cast<size_t>(prev)].layer->name.c_str());
+            const snnhip_plan* pi = fused[i].plan ? fused[i].plan : nodes[i].plan;
+            const snnhip_plan* pk = fused[static_cast<size_t>(prev)].plan ? fused[static_cast<size_t>(prev)].plan : nodes[static_cast<size_t>(prev)].plan;
+            if (wantGroups && snnhip_plan_groupable(pi) && snnhip_plan_groupable(pk)) {
+                stages[i].groupWithPrevious = true;
+                SNN_LOGI("stage %zu (%s) and stage %d (%s) run in one launch group", i, stages[i].layer->name.c_str(), prev, stages[static_cast<size_t>(prev)].layer->name.c_str());
+            } else if (wantOverlap) {
+                stages[i].sideOfPrevious = true;
+                SNN_LOGI("stage %zu (%s) runs beside stage %d (%s) on the side stream", i, stages[i].layer->name.c_str(), prev, stages[static_cast<size_t>(prev)].layer->name.c_str());
+            }
         }
         prev = static_cast<int>(i);
     }

@@ -69,6 +69,9 @@ public:
     virtual bool forkSide() { return false; }
     virtual void backToMain() {}
     virtual void joinSide() {}
+    // HIP extension: a launch group -- groupable plans run between the two calls are launched by groupEnd, two compatible ones as one kernel launch
+    virtual bool groupBegin() { return false; }
+    virtual void groupEnd() {}
 };
 
 class HipRenderPass : public RenderPass {
@@ -102,6 +105,8 @@ public:
     bool forkSide() override;
     void backToMain() override;
     void joinSide() override;
+    bool groupBegin() override;
+    void groupEnd() override;
 
 private:
     snnhip_ctx* ctx;

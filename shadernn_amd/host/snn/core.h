@@ -32,6 +32,9 @@ struct RenderStage {
     // branches of a residual block (ResNet: the 3x3 stride-2 convolution and the 1x1 stride-2 downsample of the same input).  run() issues this
     // one on the backend's side stream next to the previous one instead of behind it (DeviceBackend::forkSide / joinSide).
     bool sideOfPrevious = false;
+    // ... or, when both stages run plans the library can launch as ONE grid (snnhip_plan_groupable: the K-split convolutions), inside a launch group
+    // (DeviceBackend::groupBegin / groupEnd): the default for such pairs; SNN_STAGE_GROUPS=0 switches it off
+    bool groupWithPrevious = false;
 };
 typedef std::vector<RenderStage> RenderStagesArray;
 

@@ -210,7 +210,7 @@ int snn_model_stage_info(snn_model* m, int stage, char* name, int name_len, int 
     hwc[0] = static_cast<int>(s.layer->outputDesc.height);
     hwc[1] = static_cast<int>(s.layer->outputDesc.width);
     hwc[2] = static_cast<int>(s.layer->outputDesc.channels);
-    *fused_away = (s.fusedAway ? 1 : 0) | (s.sideOfPrevious ? 2 : 0);
+    *fused_away = (s.fusedAway ? 1 : 0) | (s.sideOfPrevious ? 2 : 0) | (s.groupWithPrevious ? 4 : 0);
     return 0;
 }
 

@@ -378,6 +378,35 @@ def test_c5_candy_720p_fp16_microbatch_default_switches_through_host(ctx, tmp_pa
     m.close()
 
 
+def test_c3_stage_entries_run_their_two_branches_as_one_launch(ctx, tmp_path, monkeypatch):
+    """Round 6, the default: the 3x3 stride-2 convolution of a ResNet stage entry and the 1x1 stride-2 downsample beside it (same input, both on
+    conv2d_ksplit) are bracketed by a launch group (snnhip_ctx_group_begin / _end) and leave as ONE kernel launch -- in the recorded hipGraph as well.
+    Same bits as the two launches (SNN_STAGE_GROUPS=0), on a batch of 4 at 224x224: first run (record), replay and launch-by-launch."""
+    from shadernn_amd import host, models
+
+    net = models.resnet18(seed=1)
+    H = W = 224
+    path = models.write_json(net, W, H, str(tmp_path / "resnet18.json"), bin_weights=True)
+    x = np.random.default_rng(33).random((4, H, W, 3), dtype=np.float32)
+    monkeypatch.setenv("SNN_STAGE_GROUPS", "0")
+    plain = host.Model(path, W, H, 3, device=0, capture_graph=True, batch=4)
+    want = np.asarray(plain(x)).copy()
+    assert not any(s.get("group") for s in plain.stages())
+    plain.close()
+    monkeypatch.delenv("SNN_STAGE_GROUPS")
+    m = host.Model(path, W, H, 3, device=0, capture_graph=True, batch=4)
+    groups = [s for s in m.stages() if s.get("group")]
+    assert len(groups) == 3 and not any(s.get("side") for s in m.stages()), [s["name"] for s in m.stages()]   # l2_b0_down, l3_b0_down, l4_b0_down
+    got = np.asarray(m(x)).copy()                   # record + launch
+    np.testing.assert_array_equal(got, want)
+    m.run()                                          # replay
+    np.testing.assert_array_equal(np.asarray(m.output()), want)
+    m.suspend_replay(True)
+    m.run()                                          # launch by launch
+    np.testing.assert_array_equal(np.asarray(m.output()), want)
+    m.close()
+
+
 def test_c3_residual_branches_side_by_side_give_the_same_result(ctx, tmp_path, monkeypatch):
     """SNN_BRANCH_OVERLAP=1 (host mirror, opt-in): the 1x1 stride-2 downsample of a ResNet stage entry is issued on the context's side stream
     (snnhip_ctx_fork / _main / _join) beside the 3x3 stride-2 convolution that reads the same tensor -- in the recorded hipGraph as well.  Same
@@ -392,6 +421,7 @@ def test_c3_residual_branches_side_by_side_give_the_same_result(ctx, tmp_path, m
     want = np.asarray(plain(x)).copy()
     plain.close()
     monkeypatch.setenv("SNN_BRANCH_OVERLAP", "1")
+    monkeypatch.setenv("SNN_STAGE_GROUPS", "0")     # (since round 6 such a pair is ONE launch by default: the side stream only when that is off)
     monkeypatch.setenv("SNN_LOG_LEVEL", "3")
     m = host.Model(path, W, H, 3, device=0, capture_graph=True, batch=4)
     got = np.asarray(m(x)).copy()                   # record + launch

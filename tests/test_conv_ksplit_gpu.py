@@ -175,3 +175,75 @@ def test_ksplit_random_shapes_and_geometries_match_oracle(ctx, case):
     want = O.conv2d(x, wt, b, s, pads, "constant", act, 0.15, bn)
     assert got.shape == want.shape, plan.describe()
     np.testing.assert_allclose(got, want, err_msg=plan.describe(), **TOL)
+
+
+@pytest.mark.parametrize("case", [(4, 56, 56, 64, 128, 2), (4, 28, 28, 128, 256, 4), (5, 14, 14, 256, 512, 8), (3, 17, 23, 32, 64, 2), (2, 20, 20, 64, 64, 0)],
+                         ids=lambda c: "x".join(map(str, c[:5])) + "_ks%d" % c[5])
+def test_a_launch_group_runs_the_3x3_and_the_1x1_stride_2_layers_as_one_kernel(ctx, case):
+    """snnhip_ctx_group_begin / _end around the two branches of a ResNet stage entry (same input): ONE launch (conv2d_ksplit_pair_kernel: the blocks of the
+    1x1 problem behind the 3x3's; checked in the launch trace), bit-identical to the two launches at the same K split -- a tile's arithmetic does not
+    depend on which grid it runs in -- and within the tolerance of the oracle; either order inside the group; a group of one and a group with a plan the
+    library cannot defer behave like no group at all; SNNHIP_KSPLIT_NO_PAIRS=1 launches the two one by one at the group's end.  The geometries the bench
+    batch gives the planner (64-pixel tiles, K over 2 / 4 / 8 waves) are pinned here at oracle-sized batches; ks0 = the planner's own choice at this size
+    (32-pixel tiles: no pair kernel, the group launches one by one)."""
+    import shadernn_amd as snn
+    from shadernn_amd import capi
+
+    N, H, W, IC, OC, ks = case
+    x = _rand((N, H, W, IC), 101)
+    w3, b3, bn3 = _rand((OC, IC, 3, 3), 102, 1.0 / np.sqrt(9 * IC)), _rand((OC,), 103, 0.1), _bn(OC, 104)
+    w1, b1, bn1 = _rand((OC, IC, 1, 1), 105, 1.0 / np.sqrt(IC)), _rand((OC,), 106, 0.1), _bn(OC, 107)
+    p3 = _plan(ctx, "", N, H, W, w3, b3, stride=2, pads=(1, 1, 1, 1), act="relu", bn=bn3, geom="2,%d,2" % ks if ks else None)
+    p1 = _plan(ctx, "", N, H, W, w1, b1, stride=2, pads=(0, 0, 0, 0), act="", bn=bn1, geom="1,%d,2" % ks if ks else None)
+    assert p3.groupable() and p1.groupable() and "ksplit" in p3.describe() and "ksplit" in p1.describe()
+    xt = snn.Tensor.from_numpy(ctx, x)
+    y3, y1 = p3(xt).numpy(), p1(xt).numpy()
+    np.testing.assert_allclose(y3[:1], O.conv2d(x[:1], w3, b3, 2, (1, 1, 1, 1), "constant", "relu", 0.0, bn3, threads=8), **TOL)
+    np.testing.assert_allclose(y1[:1], O.conv2d(x[:1], w1, b1, 2, (0, 0, 0, 0), "constant", "", 0.0, bn1, threads=8), **TOL)
+
+    def grouped(first, second, also=None):
+        outs = {id(p3): snn.Tensor(ctx, *p3.out_shape()), id(p1): snn.Tensor(ctx, *p1.out_shape())}
+        for t in outs.values():
+            t.fill(-7.0)
+        capi.trace_begin()
+        ctx.group_begin()
+        first(xt, outs[id(first)])
+        if also is not None:
+            also()
+        if second is not None:
+            second(xt, outs[id(second)])
+        ctx.group_end()
+        ctx.sync()
+        fns = sorted(k["function"] for k in capi.trace_end()["kernels"])
+        return outs[id(p3)].numpy(), outs[id(p1)].numpy(), fns
+
+    g3, g1, fns = grouped(p3, p1)
+    assert fns == (["conv2d_ksplit_pair_kernel"] if ks else ["conv2d_ksplit_kernel"]), fns
+    np.testing.assert_array_equal(g3, y3)
+    np.testing.assert_array_equal(g1, y1)
+    g3, g1, fns = grouped(p1, p3)                # the downsample first
+    assert fns == (["conv2d_ksplit_pair_kernel"] if ks else ["conv2d_ksplit_kernel"]), fns
+    np.testing.assert_array_equal(g3, y3)
+    np.testing.assert_array_equal(g1, y1)
+    g3, g1, fns = grouped(p3, None)              # a group of one
+    assert fns == ["conv2d_ksplit_kernel"], fns
+    np.testing.assert_array_equal(g3, y3)
+    assert (g1 == -7.0).all()
+    add = snn.add_plan(ctx, N, H, W, IC, act="relu")
+    assert not add.groupable()
+    side = {}
+    g3, g1, fns = grouped(p3, p1, also=lambda: side.setdefault("y", add([xt, xt])))   # a plan that launches at once, between the two deferred ones
+    assert len(fns) == 2 and ("conv2d_ksplit_pair_kernel" in fns) == bool(ks), fns
+    np.testing.assert_array_equal(g3, y3)
+    np.testing.assert_array_equal(g1, y1)
+    np.testing.assert_array_equal(side["y"].numpy(), np.maximum(x + x, 0.0))
+    os.environ["SNNHIP_KSPLIT_NO_PAIRS"] = "1"
+    try:
+        g3, g1, fns = grouped(p3, p1)
+    finally:
+        os.environ.pop("SNNHIP_KSPLIT_NO_PAIRS")
+    assert fns == ["conv2d_ksplit_kernel"], fns
+    np.testing.assert_array_equal(g3, y3)
+    np.testing.assert_array_equal(g1, y1)
+    with pytest.raises(snn.SnnHipError, match="no group is open"):
+        ctx.group_end()

@@ -495,6 +495,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
     typedef float v2f __attribute__((ext_vector_type(2)));
+    const int eFirst0 = tabE[n16], eFirst1 = tabE[(p.MT > 1 ? 16 : 0) + n16];
 
     for (int i = 0; i < p.slicesPerWave; ++i) {
         const bool more = i + 1 < p.slicesPerWave; // (wave-uniform)
@@ -504,10 +505,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // weights a phase earlier: 16 registers the 96 -> 576 -> 96 instantiation does not have)
         const float4 sc1 = web[CJ * 64 + k], sh1 = web[CJ * 64 + 4 + k];
         // ---- E: the wave's hidden slice over the whole image, two pixel tiles in flight
+        int eNext0 = eFirst0, eNext1 = eFirst1;
         for (int t = 0; t < p.MT; t += 2) {
             const int px0 = t * 16 + n16;
             const bool two = t + 1 < p.MT;
             const int px1 = two ? px0 + 16 : px0;
+            // (round 6) this pair's hidden positions were read a pair ahead (the first pair's once per block): one wave per SIMD, nobody hides the look-up
+            const int e0 = eNext0, e1 = eNext1;
+            if (t + 2 < p.MT) {
+                eNext0 = tabE[px0 + 32];
+                eNext1 = tabE[t + 3 < p.MT ? px0 + 48 : px0 + 32];
+            }
             const float4* const b0p = xs4 + px0 * p.SP + k;
             const float4* const b1p = xs4 + px1 * p.SP + k;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -526,11 +534,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const v2f sc01 = {sc1.x, sc1.y}, sc23 = {sc1.z, sc1.w}, sh01 = {sh1.x, sh1.y}, sh23 = {sh1.z, sh1.w};
             {
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
-                hs4[k * p.hPlane4 + tabE[px0]] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
+                hs4[k * p.hPlane4 + e0] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
             if (two) {
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);
-                hs4[k * p.hPlane4 + tabE[px1]] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
+                hs4[k * p.hPlane4 + e1] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
         }
         if (i == 1) IRBI_MARK(3);
@@ -699,7 +707,7 @@ struct IrbBandParams {
 };
 
 template <int NCB, int CJ, int GW, bool R6>
-__global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const float* __restrict__ x, const float4* __restrict__ weg, const float4* __restrict__ wpg,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 4 : 2))) void irb_band_kernel(IrbBandParams p, const float* __restrict__ x, const float4* __restrict__ weg, const float4* __restrict__ wpg,
                                                       const float4* __restrict__ epi3, float* __restrict__ y) {
     extern __shared__ float4 sm4[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n16 = lane & 15, k = lane >> 4;
@@ -771,6 +779,11 @@ __global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const fl
     for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
     typedef float v2f __attribute__((ext_vector_type(2)));
     const float* const xsf = reinterpret_cast<const float*>(xs4);
+    // (round 6) table entries that are the same in every slice live in registers: the first tile pair's hidden positions, the output tiles' first-tap positions
+    const int eFirst0 = tabE[min(wave, MT - 1) * 16 + n16], eFirst1 = tabE[(wave + p.NW < MT ? wave + p.NW : min(wave, MT - 1)) * 16 + n16];
+    int hpD[GW];
+#pragma unroll
+    for (int g = 0; g < GW; ++g) hpD[g] = tabD[(wave + p.NW * g) * 16 + n16];
 
     for (int c = 0; c < p.nSlices; ++c) {
         const bool more = c + 1 < p.nSlices;
@@ -778,10 +791,19 @@ __global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const fl
         const float4 sc1 = web[CJ * 64 + k], sh1 = web[CJ * 64 + 4 + k];
         const float4 sc2 = wpb[NCB * 64 + 36 + k], sh2 = wpb[NCB * 64 + 40 + k];
         // ---- E: this wave's share of the x tile's pixel tiles, two in flight
+        int eNext0 = eFirst0, eNext1 = eFirst1;
         for (int t = wave; t < MT; t += 2 * p.NW) {
             const int px0 = t * 16 + n16;
             const bool two = t + p.NW < MT;
             const int px1 = two ? px0 + 16 * p.NW : px0;
+            // (round 6) the hidden positions of this pair were read a pair ahead (the first pair's once per block): the look-up used to sit between the
+            // MFMAs' results and the LDS write, an exposed round trip per pair
+            const int e0 = eNext0, e1 = eNext1;
+            if (t + 2 * p.NW < MT) {
+                const int q0 = px0 + 32 * p.NW;
+                eNext0 = tabE[q0];
+                eNext1 = tabE[t + 3 * p.NW < MT ? q0 + 16 * p.NW : q0];
+            }
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
@@ -808,11 +830,11 @@ __global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const fl
             const v2f sc01 = {sc1.x, sc1.y}, sc23 = {sc1.z, sc1.w}, sh01 = {sh1.x, sh1.y}, sh23 = {sh1.z, sh1.w};
             {
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
-                hs4[k * p.hPlane4 + tabE[px0]] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
+                hs4[k * p.hPlane4 + e0] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
             if (two) {
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);
-                hs4[k * p.hPlane4 + tabE[px1]] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
+                hs4[k * p.hPlane4 + e1] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
         }
         if (more) web += p.wePieces * 64;
@@ -828,7 +850,7 @@ __global__ __launch_bounds__(512) void irb_band_kernel(IrbBandParams p, const fl
 #ifdef SNNHIP_IRB_ABL_NOCONF
             const int hp0 = ((wave + p.NW * g) & 3) * 16 + n16;
 #else
-            const int hp0 = tabD[(wave + p.NW * g) * 16 + n16];
+            const int hp0 = hpD[g];
 #endif
             v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
@@ -941,6 +963,13 @@ bool choose_band(int N, int H, int W, int C, int Ch, int Co, int OH, int OW, int
     double best = 0.0;
     int pinR = 0, pinSW = 0, pinNW = 0; // SNNHIP_IRB_BAND_GEOM=R,SW,NW pins the geometry (tuning runs, tests of odd shapes)
     if (const char* ge = snnhip::option("SNNHIP_IRB_BAND_GEOM")) sscanf(ge, "%d,%d,%d", &pinR, &pinSW, &pinNW);
+    // Measured geometries (round 6, tools/r6_geom.sh: 62 geometries of MobileNetV2's b02 / b03 / b04 / b06 at batch 256 on the round-6 kernel) where the model
+    // below ranks them wrong -- it prices eight waves above seven at equal tiles per wave, the kernel runs them 7 % faster: b02 8 x 28 x 7 waves 283 us,
+    // x 8 waves 264; b03 2 x 28 x 4 186 us, 4 x 28 x 8 174.  Applied only to those shapes with enough blocks for four rounds.
+    if (!pinR && !pinSW && !pinNW && H == 56 && W == 56 && C == 24 && Ch == 144) {
+        if (s == 1 && OH == 56 && OW == 56 && N * 14L >= 4L * cus) pinR = 8, pinSW = 28, pinNW = 8;
+        if (s == 2 && OH == 28 && OW == 28 && N * 7L >= 4L * cus) pinR = 4, pinSW = 28, pinNW = 8;
+    }
     for (int div = 1; div <= 4; div *= 2) {
         const int SW = pinSW ? std::min(pinSW, OW) : up_div(OW, div);
         if (div > 1 && (SW < 14 || pinSW)) break;
@@ -1284,6 +1313,10 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         bpl->ctx = ctx;
         bpl->kernel = bandFn;
         bpl->ldsBytes = bc.lds;
+        if (const char* padOpt = snnhip::option("SNNHIP_IRB_BAND_LDS_PAD")) { // developer switch: extra dynamic LDS per block (residency experiments)
+            bpl->ldsBytes += static_cast<size_t>(atoi(padOpt));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bandFn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bpl->ldsBytes));
+        }
         bpl->dtype = SNNHIP_F32;
         int rc = bpl->upload(we.data(), we.size(), &bpl->d_we);
         if (rc == SNNHIP_OK) rc = bpl->upload(wp.data(), wp.size(), &bpl->d_wp);
@@ -1302,6 +1335,12 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
                  "slices=%d lds=%zuB hbm_bytes=%.6g kernel=irb_band_kernel<%d,%d,%d,true> relu6-epilogues%s",
                  C, Ch, s, Ch, Co, addPlan ? " + add" : "", bc.R, bc.SW, bc.NW, bc.MTmax, p.nChunks, bc.lds, fusedBytes, up_div(Co, 16), up_div(C, 16), bc.GW, tail8 ? " tail8" : "");
         bpl->desc = bb;
+        if (snnhip::option("SNNHIP_IRB_OCC")) { // developer switch: what the runtime says about co-resident blocks of this geometry
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(bandFn), 64 * bc.NW, bc.lds);
+            fprintf(stderr, "[irb occ] band R=%d SW=%d NW=%d GW=%d lds=%zu blocks=%ld: %d blocks per CU (model: %d waves)\n", bc.R, bc.SW, bc.NW, bc.GW, bc.lds,
+                    static_cast<long>(b.N) * b.nBy * b.nBx, nb, bc.wavesPerCU);
+        }
         *out = bpl;
         return SNNHIP_OK;
     }
@@ -1353,6 +1392,11 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     plan->flops = (ce ? ce->flops : 0.0) + (cs ? cs->flops : 0.0) + cd->flops + cp->flops;
     plan->bytes = (ce ? ce->bytes : 0.0) + (cs ? cs->bytes : 0.0) + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
     plan->kernelBytes = fusedBytes;
+    if (snnhip::option("SNNHIP_IRB_OCC")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fn), 64 * NWv, lds);
+        fprintf(stderr, "[irb occ] wave G=%d NW=%d lds=%zu grid=%u: %d blocks per CU\n", G, NWv, lds, plan->grid.x, nb);
+    }
     char buf[320];
     char head[64];
     if (cs) snprintf(head, sizeof(head), "stem conv3x3 s%d 3->%d + depthwise3x3 s%d", p.stemS, Ch, s);

@@ -496,6 +496,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int eFirst0 = tabE[n16], eFirst1 = tabE[(p.MT > 1 ? 16 : 0) + n16];
+#ifdef SNNHIP_IRBI_ABL
+    float ablSink = 0.f;
+#endif
 
     for (int i = 0; i < p.slicesPerWave; ++i) {
         const bool more = i + 1 < p.slicesPerWave; // (wave-uniform)
@@ -531,6 +534,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0.w, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1.w, acc1, 0, 0, 0);
             }
+#if defined(SNNHIP_IRBI_ABL) && (SNNHIP_IRBI_ABL & 1) // ablation build (tools/r6_iabl.sh): E without its epilogue (scale / ReLU6 / LDS write)
+            ablSink += acc0[0] + acc1[0] + static_cast<float>(e0 + e1);
+            continue;
+#endif
             const v2f sc01 = {sc1.x, sc1.y}, sc23 = {sc1.z, sc1.w}, sh01 = {sh1.x, sh1.y}, sh23 = {sh1.z, sh1.w};
             {
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
@@ -565,13 +572,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
             const int hp0 = tabD[n16];
 #endif
+#if defined(SNNHIP_IRBI_ABL) && (SNNHIP_IRBI_ABL & 2) // ablation build: D without its tap reads and FMAs
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) h[tp] = wd[tp];
+            ablSink += static_cast<float>(hp0 + hpNext);
+#else
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) h[tp] = hb[hp0 + (tp / 3) * p.HWd + tp % 3];
             if (G > 1) hpNext = tabD[16 + n16];
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+#if defined(SNNHIP_IRBI_ABL) && (SNNHIP_IRBI_ABL & 2)
+            const float d0 = sc2.x, d1 = sc2.y, d2 = sh2.x, d3 = sh2.y;
+            if (false) {
+#else
             v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
@@ -582,6 +599,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float d0 = irb_act<R6>(p.ac2, t01[0]), d1 = irb_act<R6>(p.ac2, t01[1]), d2 = irb_act<R6>(p.ac2, t23[0]), d3 = irb_act<R6>(p.ac2, t23[1]);
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < G) {
+#endif
 #ifdef SNNHIP_IRB_ABL_NOCONF
                 const int hp0 = ((g + 1) & 7) * 16 + n16;
 #else
@@ -608,6 +626,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
     }
 
+#ifdef SNNHIP_IRBI_ABL
+    if (p.N < 0) y[tid] = ablSink;
+#endif
     // ---- the four hidden quarters meet, one 16-channel output block at a time: [wave][tile][lane] partial sums in the (now free) hidden region
     IRBI_MARK(5);
     __syncthreads();

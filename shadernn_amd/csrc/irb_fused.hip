@@ -457,6 +457,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
 #define IRBI_MARK(i) do { } while (0)
 #endif
+#if defined(SNNHIP_IRBI_TRACE) && SNNHIP_IRBI_TRACE >= 2
+    const unsigned long long censusT0 = wall_clock64();
+    unsigned long long censusT1 = 0;
+#endif
     float4* const xs4 = sm4;
     float4* const hs4 = sm4 + p.offH4 + wave * 4 * p.hPlane4;
     int* const tabE = reinterpret_cast<int*>(sm4 + p.offH4 + 16 * p.hPlane4); // [MT * 16]: hidden position of x-tile pixel i
@@ -477,6 +481,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
     IRBI_MARK(1);
+#if defined(SNNHIP_IRBI_TRACE) && SNNHIP_IRBI_TRACE >= 2
+    censusT1 = wall_clock64(); // staging done
+#endif
 
     f32x4 acc[NCB][G];
 #pragma unroll
@@ -662,6 +669,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (cb + 1 < NCB) __syncthreads();
     }
+#if defined(SNNHIP_IRBI_TRACE) && SNNHIP_IRBI_TRACE >= 2 // census build: every block's wall-clock span (100 MHz ticks) and its XCC / CU
+    if (tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        printf("irbc %d xcc %u se %u cu %u : %llu %llu %llu\n", blockIdx.x, xcc & 15, (hw >> 13) & 7, (hw >> 8) & 15, censusT0, censusT1, static_cast<unsigned long long>(wall_clock64()));
+    }
+#endif
 #ifdef SNNHIP_IRBI_TRACE
     if (itr)
         printf("irbi NCB%d CJ%d G%d wave %d: stage %llu | slice 1: E %llu D+P %llu | loop %llu (%d slices) | wait-others %llu reduce+store %llu | total %llu\n", NCB, CJ, G, wave, ist[1] - ist[0],

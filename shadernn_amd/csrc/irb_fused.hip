@@ -27,6 +27,13 @@
 #include "epilogue.h"
 #include "snnhip_internal.h"
 
+#ifndef SNNHIP_IRB_FOLD_BN
+#define SNNHIP_IRB_FOLD_BN 1 // (round 6) the expand / depthwise layers' folded BN scale is multiplied into their weights at plan creation and the accumulators start from the shift
+#endif                      // (the MFMA's C operand, the tap sum's first addend): two packed FMAs fewer per pixel tile and slice in E and in D.  0: the round-5 form (A/B builds)
+#ifndef SNNHIP_IRBI_FOLD_BN
+#define SNNHIP_IRBI_FOLD_BN 0 // ... but not in irb_image_kernel: same-box A/B with the fold b14 108.3 vs 104.4 us, c4's nine image launches 839 vs 798 us (one wave per SIMD at 350 - 500
+#endif                       // registers: the allocation the compiler finds for the shorter epilogue is the slower one); its plans keep unscaled weights
+
 namespace snnhip {
 
 namespace {
@@ -252,7 +259,11 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                 const int px0 = t * 16 + n16;
                 const bool two = t + 1 < p.MT; // wave-uniform
                 const int px1 = two ? px0 + 16 : px0;
+#if SNNHIP_IRB_FOLD_BN
+                f32x4 acc0 = {sh.x, sh.y, sh.z, sh.w}, acc1 = acc0;
+#else
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
                 for (int j = 0; j < CJT; ++j)
                     if (j == p.Cj - 1 && p.tail8) { // (wave-uniform)
@@ -276,10 +287,14 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1.w, acc1, 0, 0, 0);
                     }
                 typedef float v2f __attribute__((ext_vector_type(2)));
-                const v2f sc01 = {sc.x, sc.y}, sc23 = {sc.z, sc.w}, sh01 = {sh.x, sh.y}, sh23 = {sh.z, sh.w};
+                [[maybe_unused]] const v2f sc01 = {sc.x, sc.y}, sc23 = {sc.z, sc.w}, sh01 = {sh.x, sh.y}, sh23 = {sh.z, sh.w};
                 float4 h;
                 {
+#if SNNHIP_IRB_FOLD_BN
+                    const v2f u01 = {acc0[0], acc0[1]}, u23 = {acc0[2], acc0[3]};
+#else
                     const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
+#endif
                     h.x = irb_act<R6>(p.ac1, u01[0]);
                     h.y = irb_act<R6>(p.ac1, u01[1]);
                     h.z = irb_act<R6>(p.ac1, u23[0]);
@@ -291,7 +306,11 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                 }
                 *reinterpret_cast<float4*>(hs + k * p.hPlane + px0 * 4) = h;
                 if (two) {
+#if SNNHIP_IRB_FOLD_BN
+                    const v2f u01 = {acc1[0], acc1[1]}, u23 = {acc1[2], acc1[3]};
+#else
                     const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);
+#endif
                     h.x = irb_act<R6>(p.ac1, u01[0]);
                     h.y = irb_act<R6>(p.ac1, u01[1]);
                     h.z = irb_act<R6>(p.ac1, u23[0]);
@@ -311,14 +330,19 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
             float4 wd[9];
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) wd[tp] = dwb[tp * 4 + k];
-            const float4 sc = dwb[36 + k], sh = dwb[40 + k];
+            [[maybe_unused]] const float4 sc = dwb[36 + k];
+            const float4 sh = dwb[40 + k];
             float4 dv[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 // the 36 tap FMAs as 18 v_pk_fma_f32 (two channels per instruction: the kernel is bound by VALU issue, and the packed form retires two
                 // FMAs per lane in one slot); same products and the same per-channel summation order as the scalar form
                 typedef float v2f __attribute__((ext_vector_type(2)));
+#if SNNHIP_IRB_FOLD_BN
+                v2f s01 = {sh.x, sh.y}, s23 = {sh.z, sh.w};
+#else
                 v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+#endif
 #pragma unroll
                 for (int fy = 0; fy < 3; ++fy)
 #pragma unroll
@@ -328,7 +352,11 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                         s01 = __builtin_elementwise_fma(v2f{h.x, h.y}, v2f{w.x, w.y}, s01);
                         s23 = __builtin_elementwise_fma(v2f{h.z, h.w}, v2f{w.z, w.w}, s23);
                     }
+#if SNNHIP_IRB_FOLD_BN
+                const v2f t01 = s01, t23 = s23;
+#else
                 const v2f t01 = __builtin_elementwise_fma(v2f{sc.x, sc.y}, s01, v2f{sh.x, sh.y}), t23 = __builtin_elementwise_fma(v2f{sc.z, sc.w}, s23, v2f{sh.z, sh.w});
+#endif
                 dv[g].x = irb_act<R6>(p.ac2, t01[0]);
                 dv[g].y = irb_act<R6>(p.ac2, t01[1]);
                 dv[g].z = irb_act<R6>(p.ac2, t23[0]);
@@ -528,7 +556,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             const float4* const b0p = xs4 + px0 * p.SP + k;
             const float4* const b1p = xs4 + px1 * p.SP + k;
+#if SNNHIP_IRBI_FOLD_BN
+            f32x4 acc0 = {sh1.x, sh1.y, sh1.z, sh1.w}, acc1 = acc0;
+#else
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
                 const float4 b0 = b0p[4 * j], b1 = b1p[4 * j];
@@ -545,13 +577,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ablSink += acc0[0] + acc1[0] + static_cast<float>(e0 + e1);
             continue;
 #endif
-            const v2f sc01 = {sc1.x, sc1.y}, sc23 = {sc1.z, sc1.w}, sh01 = {sh1.x, sh1.y}, sh23 = {sh1.z, sh1.w};
+            [[maybe_unused]] const v2f sc01 = {sc1.x, sc1.y}, sc23 = {sc1.z, sc1.w}, sh01 = {sh1.x, sh1.y}, sh23 = {sh1.z, sh1.w};
             {
+#if SNNHIP_IRBI_FOLD_BN
+                const v2f u01 = {acc0[0], acc0[1]}, u23 = {acc0[2], acc0[3]};
+#else
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
+#endif
                 hs4[k * p.hPlane4 + e0] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
             if (two) {
+#if SNNHIP_IRBI_FOLD_BN
+                const v2f u01 = {acc1[0], acc1[1]}, u23 = {acc1[2], acc1[3]};
+#else
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);
+#endif
                 hs4[k * p.hPlane4 + e1] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
         }
@@ -561,7 +601,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (more) web += weStep;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) a[j] = web[j * 64 + lane];
-        const float4 sc2 = wpb[NCB * 64 + 36 + k], sh2 = wpb[NCB * 64 + 40 + k];
+        [[maybe_unused]] const float4 sc2 = wpb[NCB * 64 + 36 + k];
+        const float4 sh2 = wpb[NCB * 64 + 40 + k];
         __builtin_amdgcn_sched_barrier(0);
         // ---- D + P: depthwise taps of output tile g -> the B operand of the project MFMAs (kk outer, cb inner: consecutive MFMAs are independent).
         // The order is pinned (sched_barrier): tile g's tap FMAs, then the 9 tap reads of tile g + 1 INTO THE SAME REGISTERS, then tile g's MFMAs, under
@@ -596,13 +637,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float d0 = sc2.x, d1 = sc2.y, d2 = sh2.x, d3 = sh2.y;
             if (false) {
 #else
+#if SNNHIP_IRBI_FOLD_BN
+            v2f s01 = {sh2.x, sh2.y}, s23 = {sh2.z, sh2.w};
+#else
             v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+#endif
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
                 s01 = __builtin_elementwise_fma(v2f{h[tp].x, h[tp].y}, v2f{wd[tp].x, wd[tp].y}, s01);
                 s23 = __builtin_elementwise_fma(v2f{h[tp].z, h[tp].w}, v2f{wd[tp].z, wd[tp].w}, s23);
             }
+#if SNNHIP_IRBI_FOLD_BN
+            const v2f t01 = s01, t23 = s23;
+#else
             const v2f t01 = __builtin_elementwise_fma(v2f{sc2.x, sc2.y}, s01, v2f{sh2.x, sh2.y}), t23 = __builtin_elementwise_fma(v2f{sc2.z, sc2.w}, s23, v2f{sh2.z, sh2.w});
+#endif
             const float d0 = irb_act<R6>(p.ac2, t01[0]), d1 = irb_act<R6>(p.ac2, t01[1]), d2 = irb_act<R6>(p.ac2, t23[0]), d3 = irb_act<R6>(p.ac2, t23[1]);
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < G) {
@@ -825,7 +874,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
         const bool more = c + 1 < p.nSlices;
         float4* const hs4 = hsb + (c & 1) * 4 * p.hPlane4;
         const float4 sc1 = web[CJ * 64 + k], sh1 = web[CJ * 64 + 4 + k];
-        const float4 sc2 = wpb[NCB * 64 + 36 + k], sh2 = wpb[NCB * 64 + 40 + k];
+        [[maybe_unused]] const float4 sc2 = wpb[NCB * 64 + 36 + k];
+        const float4 sh2 = wpb[NCB * 64 + 40 + k];
         // ---- E: this wave's share of the x tile's pixel tiles, two in flight
         int eNext0 = eFirst0, eNext1 = eFirst1;
         for (int t = wave; t < MT; t += 2 * p.NW) {
@@ -840,7 +890,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
                 eNext0 = tabE[q0];
                 eNext1 = tabE[t + 3 * p.NW < MT ? q0 + 16 * p.NW : q0];
             }
+#if SNNHIP_IRB_FOLD_BN
+            f32x4 acc0 = {sh1.x, sh1.y, sh1.z, sh1.w}, acc1 = acc0;
+#else
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
                 if (j == CJ - 1 && p.tail8) { // (wave-uniform) the last 8 channels: k lane kk multiplies channel 16 j + kk, then 16 j + 4 + kk
@@ -863,13 +917,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1.w, acc1, 0, 0, 0);
                 }
             }
-            const v2f sc01 = {sc1.x, sc1.y}, sc23 = {sc1.z, sc1.w}, sh01 = {sh1.x, sh1.y}, sh23 = {sh1.z, sh1.w};
+            [[maybe_unused]] const v2f sc01 = {sc1.x, sc1.y}, sc23 = {sc1.z, sc1.w}, sh01 = {sh1.x, sh1.y}, sh23 = {sh1.z, sh1.w};
             {
+#if SNNHIP_IRB_FOLD_BN
+                const v2f u01 = {acc0[0], acc0[1]}, u23 = {acc0[2], acc0[3]};
+#else
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
+#endif
                 hs4[k * p.hPlane4 + e0] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
             if (two) {
+#if SNNHIP_IRB_FOLD_BN
+                const v2f u01 = {acc1[0], acc1[1]}, u23 = {acc1[2], acc1[3]};
+#else
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);
+#endif
                 hs4[k * p.hPlane4 + e1] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
         }
@@ -888,7 +950,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
 #else
             const int hp0 = hpD[g];
 #endif
+#if SNNHIP_IRB_FOLD_BN
+            v2f s01 = {sh2.x, sh2.y}, s23 = {sh2.z, sh2.w};
+#else
             v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+#endif
 #pragma unroll
             for (int fy = 0; fy < 3; ++fy)
 #pragma unroll
@@ -898,7 +964,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
                     s01 = __builtin_elementwise_fma(v2f{h.x, h.y}, v2f{w.x, w.y}, s01);
                     s23 = __builtin_elementwise_fma(v2f{h.z, h.w}, v2f{w.z, w.w}, s23);
                 }
+#if SNNHIP_IRB_FOLD_BN
+            const v2f t01 = s01, t23 = s23;
+#else
             const v2f t01 = __builtin_elementwise_fma(v2f{sc2.x, sc2.y}, s01, v2f{sh2.x, sh2.y}), t23 = __builtin_elementwise_fma(v2f{sc2.z, sc2.w}, s23, v2f{sh2.z, sh2.w});
+#endif
             const float d0 = irb_act<R6>(p.ac2, t01[0]), d1 = irb_act<R6>(p.ac2, t01[1]), d2 = irb_act<R6>(p.ac2, t23[0]), d3 = irb_act<R6>(p.ac2, t23[1]);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].x, d0, acc[cb][g], 0, 0, 0);
@@ -1288,23 +1358,26 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         for (int m = 0; m < 16; ++m) {
             const int hc = 16 * c + m;
             if (hc >= Ch) continue;
+            // the layers' folded scales go into their weights where the kernel starts its sums from the shift (irb_wave / irb_band; irb_image: SNNHIP_IRBI_FOLD_BN)
+            const bool foldBN = imgFn ? SNNHIP_IRBI_FOLD_BN != 0 : SNNHIP_IRB_FOLD_BN != 0;
+            const float s1 = (foldBN && !noExpand) ? e1[2 * hc] : 1.0f, s2 = foldBN ? e2[2 * hc] : 1.0f;
             // expand: [j][lane = 16 kk + m] float4 {We[hc][16 j + 4 kk + jj]}
             for (int ic = 0; ic < C && !noExpand; ++ic) {
                 const int j = ic / 16, kk = (ic % 16) / 4, jj = ic % 4;
                 if (tail8 && j == p.Cj - 1) { // irb_band_kernel's last 8 channels: component 0 = channel 16 j + kk, component 1 = channel 16 j + 4 + kk
-                    wb[j * 256 + ((ic % 4) * 16 + m) * 4 + (ic % 16) / 4] = ce->w_oihw[static_cast<size_t>(hc) * C + ic];
+                    wb[j * 256 + ((ic % 4) * 16 + m) * 4 + (ic % 16) / 4] = s1 * ce->w_oihw[static_cast<size_t>(hc) * C + ic];
                     continue;
                 }
                 if (cs) { // 'channel' ic = 3 tap + c of the im2col'd image (the staging's order); the stem's weights are [oc][c][tap]
-                    if (ic < 27) wb[j * 256 + (kk * 16 + m) * 4 + jj] = cs->w_oihw[(static_cast<size_t>(hc) * 3 + ic % 3) * 9 + ic / 3];
+                    if (ic < 27) wb[j * 256 + (kk * 16 + m) * 4 + jj] = s1 * cs->w_oihw[(static_cast<size_t>(hc) * 3 + ic % 3) * 9 + ic / 3];
                     continue;
                 }
-                wb[j * 256 + (kk * 16 + m) * 4 + jj] = ce->w_oihw[static_cast<size_t>(hc) * C + ic];
+                wb[j * 256 + (kk * 16 + m) * 4 + jj] = s1 * ce->w_oihw[static_cast<size_t>(hc) * C + ic];
             }
             wb[p.Cj * 256 + m] = e1[2 * hc];
             wb[p.Cj * 256 + 16 + m] = e1[2 * hc + 1];
             // depthwise taps [tap][16], scale[16], shift[16]
-            for (int tp = 0; tp < 9; ++tp) pb[p.NCB * 256 + tp * 16 + m] = cd->w_oihw[static_cast<size_t>(hc) * 9 + tp];
+            for (int tp = 0; tp < 9; ++tp) pb[p.NCB * 256 + tp * 16 + m] = s2 * cd->w_oihw[static_cast<size_t>(hc) * 9 + tp];
             pb[p.NCB * 256 + 144 + m] = e2[2 * hc];
             pb[p.NCB * 256 + 160 + m] = e2[2 * hc + 1];
         }

@@ -425,7 +425,9 @@ BAND_CASES = [((2, 112, 112, 16, 96, 24, 2, False, ("relu6", "relu6", "")), None
               ((2, 28, 28, 32, 192, 64, 2, False, ("relu6", "relu6", "")), None),       # b06: four output blocks
               ((1, 45, 37, 32, 80, 32, 1, True, ("relu6", "relu6", "relu")), "4,20,5"),  # ragged: last band 1 row, last strip 17 columns, 5 waves
               ((2, 33, 50, 8, 48, 24, 2, False, ("relu6", "relu6", "leakyRelu")), "3,13,4"),  # C = 8: only the tail step; 17x25 outputs in bands of 3 x 13
-              ((1, 30, 30, 32, 64, 64, 1, False, ("relu6", "relu6", "")), "7,30,8")]     # four output blocks, 8 waves
+              ((1, 30, 30, 32, 64, 64, 1, False, ("relu6", "relu6", "")), "7,30,8"),     # four output blocks, 8 waves
+              ((2, 56, 56, 24, 144, 24, 1, True, ("relu6", "relu6", "")), "8,28,8"),     # b02 at the geometry batch 256 pins (round 6: eight waves, tools/r6_geom.sh)
+              ((2, 56, 56, 24, 144, 32, 2, False, ("relu6", "relu6", "")), "4,28,8")]    # b03 at its pinned geometry: stride 2 with eight waves
 
 
 @pytest.mark.parametrize("case,geom", BAND_CASES, ids=lambda c: ("%dx%dx%d_%d-%d-%d_s%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], "_res" if c[7] else "")) if isinstance(c, tuple) else str(c))

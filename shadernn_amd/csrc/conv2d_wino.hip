@@ -471,7 +471,8 @@ int make_conv2d_wino_plan(snnhip_ctx* ctx, const ConvGeom& g, const float* w_oih
     p.chunksPerSplit = up_div(p.nChunks, splitK);
     p.splitK = up_div(p.nChunks, p.chunksPerSplit);
     if (ks == 2 && (p.nChunks % p.splitK != 0 || p.chunksPerSplit % 2 != 0)) return SNNHIP_E_UNSUPPORTED; // (cannot happen with the conditions above)
-    const size_t ldsAll = ks == 2 ? std::max<size_t>(2 * lds, 128 * 1024) : lds; // two groups' buffers; the exchange of the sums needs 8 x 16 KB
+    size_t ldsAll = ks == 2 ? std::max<size_t>(2 * lds, 128 * 1024) : lds; // two groups' buffers; the exchange of the sums needs 8 x 16 KB
+    if (const char* padOpt = snnhip::option("SNNHIP_WINO_LDS_PAD")) ldsAll = std::min<size_t>(160 * 1024, ldsAll + static_cast<size_t>(atoi(padOpt))); // developer switch: residency experiments
     if (ldsAll > 160 * 1024) return SNNHIP_E_UNSUPPORTED;
 
     auto* plan = new WinoConvPlan();

@@ -90,6 +90,28 @@ template <bool R6>
 __device__ __forceinline__ float irb_act(const ActCfg& a, float v) {
     return R6 ? __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f) : apply_act<true>(a, v, 0.f);
 }
+// ReLU6 of a hidden channel the split-precision form keeps scaled by a power of two: the bound is 6 x that power (same instruction, a register instead of the constant)
+__device__ __forceinline__ float irb_relu_to(float v, float bound) { return __builtin_amdgcn_fmed3f(v, 0.0f, bound); }
+
+// ---- split-precision form of the two pointwise stages (round 6, S16): every fp32 operand x is carried as two halves, x = hi + lo (hi = fp16(x), lo = fp16(x - hi),
+// |x - hi - lo| <= 2^-22 |x|), and a product w x is the three f16 MFMA products wh xh + wh xl + wl xh accumulated in fp32 (the dropped wl xl is 2^-22 of the product):
+// ONE v_mfma_f32_16x16x32_f16 whose K axis carries (channel, hi | lo) -- A = [wh | wh], B = [xh | xl]: the 16-byte slot a lane read as four fp32 channels is now the
+// same four channels as [hi x 4 | lo x 4] -- plus ONE v_mfma_f32_16x16x16_f16 (A = wl, B = xh = the slot's lower half) replace FOUR v_mfma_f32_16x16x4_f32:
+// 2 x ~18 cycles of the matrix pipe instead of 4 x 32 (tools/ubench_mfma_f16.hip), same accumulator layout.  Ranges: the block input is scaled per image by a power of
+// two when its largest magnitude reaches 2^15 (undone in the expand epilogue's scale), the depthwise output is ReLU6's [0, 6]; weight rows are normalised by powers of
+// two on the host (undone in the same scales); lo parts below fp16's normal range lose bits that are 2^-25 of the row's largest magnitude.  The depthwise stage, all
+// epilogues, the reduction and the residual (re-read from global memory: the LDS tile holds the split form) are fp32 as before.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f16x8 split_f16x3(float d0, float d1, float d2, float d3) {
+    const f16x2 h01 = __builtin_convertvector(f32x2v{d0, d1}, f16x2), h23 = __builtin_convertvector(f32x2v{d2, d3}, f16x2); // (round to nearest even; the residuals are exact)
+    const float r0 = d0 - static_cast<float>(h01[0]), r1 = d1 - static_cast<float>(h01[1]), r2 = d2 - static_cast<float>(h23[0]), r3 = d3 - static_cast<float>(h23[1]);
+    const f16x2 l01 = __builtin_convertvector(f32x2v{r0, r1}, f16x2), l23 = __builtin_convertvector(f32x2v{r2, r3}, f16x2);
+    return f16x8{h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
+}
 
 // Wave-autonomous: every WAVE owns one small output tile (4x8 pixels for stride 1, 2x8 for stride 2) from the x tile to the store, in its own
 // slice of LDS, and the kernel has NO barrier at all.  Its predecessor gave a 256-thread block one 8x16 / 8x8 tile and synchronised the four
@@ -196,7 +218,11 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
         }
     } else {
         const int quads = 4 * p.Cj, cq = p.C >> 2;
+#ifdef SNNHIP_IRBW_ABL_NOSTAGE // ablation build (wrong results): no staging of the x tile
+        const int total = 0;
+#else
         const int total = p.MT * 16 * quads;
+#endif
         for (int base = lane; base < total; base += 8 * 64) {
             float4 v[8];
             int lo[8];
@@ -470,7 +496,7 @@ struct IrbImgParams {
     ActCfg ac1, ac2, ac3, ac4;
 };
 
-template <int NCB /* Co / 16 */, int CJ /* C / 16 */, int G /* output pixel tiles */, bool R6>
+template <int NCB /* Co / 16 */, int CJ /* C / 16 */, int G /* output pixel tiles */, bool R6, bool S16 = false /* split-precision pointwise stages */>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void irb_image_kernel(IrbImgParams p, const float* __restrict__ x, const float4* __restrict__ weg,
                                                                                                  const float4* __restrict__ wpg, const float4* __restrict__ epi3,
                                                                                                  const int* __restrict__ tabs, float* __restrict__ y) {
@@ -505,9 +531,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         for (int i = lane; i < 4 * p.hPlane4; i += 64) hs4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = tid; i < (p.MT + G) * 16; i += 256) tabE[i] = tabs[i];
+        if (S16 && tid == 0) tabD[G * 16] = 0; // the image's largest magnitude (bit pattern of a non-negative float)
         lds_dma_wait();
     }
     __syncthreads();
+    [[maybe_unused]] float sxInv = 1.0f;
+    if constexpr (S16) { // the x tile in place: fp32 x 4 -> [hi x 4 | lo x 4] per 16-byte slot, scaled by a power of two if the image reaches 2^15
+        const int totalSlots = p.HW * p.SP;
+        float m = 0.f;
+        for (int e = tid; e < totalSlots; e += 256) {
+            const float4 v = xs4[e];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) atomicMax(&tabD[G * 16], __float_as_int(m));
+        __syncthreads();
+        const int mb = tabD[G * 16];
+        float sx = 1.0f;
+        if (mb >= 0x47000000) { // >= 2^15: bring the largest magnitude into [2^14, 2^15)
+            const int ex = (mb >> 23) & 255;
+            sx = __int_as_float((127 + 14 + 127 - ex) << 23);
+            sxInv = __int_as_float((ex - 14) << 23);
+        }
+        for (int e = tid; e < totalSlots; e += 256) {
+            const float4 v = xs4[e];
+            xs4[e] = __builtin_bit_cast(float4, split_f16x3(v.x * sx, v.y * sx, v.z * sx, v.w * sx));
+        }
+        __syncthreads();
+    }
     IRBI_MARK(1);
 #if defined(SNNHIP_IRBI_TRACE) && SNNHIP_IRBI_TRACE >= 2
     censusT1 = wall_clock64(); // staging done
@@ -541,7 +593,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (i == 2) IRBI_MARK(4);
         // (the epilogue constants of a phase are requested at its start -- their first use is a tile's worth of MFMAs / tap FMAs away -- instead of with the
         // weights a phase earlier: 16 registers the 96 -> 576 -> 96 instantiation does not have)
-        const float4 sc1 = web[CJ * 64 + k], sh1 = web[CJ * 64 + 4 + k];
+        float4 sc1 = web[CJ * 64 + k];
+        const float4 sh1 = web[CJ * 64 + 4 + k];
+        if constexpr (S16) { // (the power of two the image was scaled by)
+            static_assert(!S16 || !SNNHIP_IRBI_FOLD_BN, "the split form undoes the input scale in the expand epilogue's multiplier");
+            sc1.x *= sxInv; sc1.y *= sxInv; sc1.z *= sxInv; sc1.w *= sxInv;
+        }
         // ---- E: the wave's hidden slice over the whole image, two pixel tiles in flight
         int eNext0 = eFirst0, eNext1 = eFirst1;
         for (int t = 0; t < p.MT; t += 2) {
@@ -561,9 +618,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #endif
+            [[maybe_unused]] f32x4 lo0 = {0.f, 0.f, 0.f, 0.f}, lo1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
                 const float4 b0 = b0p[4 * j], b1 = b1p[4 * j];
+                if constexpr (S16) { // (the two MFMA shapes keep their own accumulator chains -- an x16 never reads what an x32 has just written --, summed in the epilogue)
+                    const f16x8 aj = __builtin_bit_cast(f16x8, a[j]), c0 = __builtin_bit_cast(f16x8, b0), c1 = __builtin_bit_cast(f16x8, b1);
+                    const f16x8 ahh = __builtin_shufflevector(aj, aj, 0, 1, 2, 3, 0, 1, 2, 3);
+                    const f16x4 al = __builtin_shufflevector(aj, aj, 4, 5, 6, 7);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahh, c0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahh, c1, acc1, 0, 0, 0);
+                    lo0 = __builtin_amdgcn_mfma_f32_16x16x16f16(al, __builtin_shufflevector(c0, c0, 0, 1, 2, 3), lo0, 0, 0, 0);
+                    lo1 = __builtin_amdgcn_mfma_f32_16x16x16f16(al, __builtin_shufflevector(c1, c1, 0, 1, 2, 3), lo1, 0, 0, 0);
+                    continue;
+                }
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0.x, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b1.x, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b0.y, acc0, 0, 0, 0);
@@ -572,6 +640,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b1.z, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0.w, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1.w, acc1, 0, 0, 0);
+            }
+            if constexpr (S16) {
+                acc0 += lo0;
+                acc1 += lo1;
             }
 #if defined(SNNHIP_IRBI_ABL) && (SNNHIP_IRBI_ABL & 1) // ablation build (tools/r6_iabl.sh): E without its epilogue (scale / ReLU6 / LDS write)
             ablSink += acc0[0] + acc1[0] + static_cast<float>(e0 + e1);
@@ -665,14 +737,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int tp = 0; tp < 9; ++tp) h[tp] = hb[hp0 + (tp / 3) * p.HWd + tp % 3];
                 if (g + 2 < G) hpNext = tabD[(g + 2) * 16 + n16];
             }
+            if constexpr (S16) {
+                // ONE MFMA shape on the output accumulators (an x16 reading what an x32 has just written is a hazard the compiler does not pad): the weight slot
+                // [wh | wl] is the A operand of both products as it is, B = [dh | dh] gives wh dh + wl dh, B = [dl | 0] gives wh dl; both built once per tile
+                const f16x8 db = split_f16x3(d0, d1, d2, d3);
+                const f16x8 dhh = __builtin_shufflevector(db, db, 0, 1, 2, 3, 0, 1, 2, 3);
+                const f16x8 dl0 = __builtin_shufflevector(db, f16x8{0, 0, 0, 0, 0, 0, 0, 0}, 4, 5, 6, 7, 8, 9, 10, 11);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].x, d0, acc[cb][g], 0, 0, 0);
+                for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ap[cb]), dhh, acc[cb][g], 0, 0, 0);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].y, d1, acc[cb][g], 0, 0, 0);
+                for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ap[cb]), dl0, acc[cb][g], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].z, d2, acc[cb][g], 0, 0, 0);
+                for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].x, d0, acc[cb][g], 0, 0, 0);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].w, d3, acc[cb][g], 0, 0, 0);
+                for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].y, d1, acc[cb][g], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].z, d2, acc[cb][g], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].w, d3, acc[cb][g], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more) wpb += wpStep;
@@ -706,8 +790,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 r.y = apply_act<true>(p.ac3, fmaf(sc.y, ((q0.y + q1.y) + q2.y) + q3.y, sh.y), 0.f);
                 r.z = apply_act<true>(p.ac3, fmaf(sc.z, ((q0.z + q1.z) + q2.z) + q3.z, sh.z), 0.f);
                 r.w = apply_act<true>(p.ac3, fmaf(sc.w, ((q0.w + q1.w) + q2.w) + q3.w, sh.w), 0.f);
-                if (p.hasRes) { // (stride 1, C == Co: output pixel o is x-tile pixel o)
-                    const float4 xr = xs4[o * p.SP + cb * 4 + k];
+                if (p.hasRes) { // (stride 1, C == Co: output pixel o is x-tile pixel o; the split form's tile is no longer the fp32 input: L2 has it)
+                    const float4 xr = S16 ? *reinterpret_cast<const float4*>(x + (static_cast<size_t>(img) * p.HW + o) * p.C + cb * 16 + 4 * k) : xs4[o * p.SP + cb * 4 + k];
                     r.x = apply_act<true>(p.ac4, r.x + xr.x, 0.f);
                     r.y = apply_act<true>(p.ac4, r.y + xr.y, 0.f);
                     r.z = apply_act<true>(p.ac4, r.z + xr.z, 0.f);
@@ -757,9 +841,9 @@ struct IrbImagePlan : snnhip_plan {
 };
 
 typedef void (*IrbImgFn)(IrbImgParams, const float*, const float4*, const float4*, const float4*, const int*, float*);
-IrbImgFn pick_irb_image(int ncb, int cj, int g, int* gt) {
+IrbImgFn pick_irb_image(int ncb, int cj, int g, bool s16, int* gt) {
 #define SNNHIP_IRBI(NCB_, CJ_, G_) \
-    if (ncb == NCB_ && cj == CJ_ && g <= G_) return *gt = G_, irb_image_kernel<NCB_, CJ_, G_, true>;
+    if (ncb == NCB_ && cj == CJ_ && g <= G_) return *gt = G_, s16 ? irb_image_kernel<NCB_, CJ_, G_, true, true> : irb_image_kernel<NCB_, CJ_, G_, true, false>;
     SNNHIP_IRBI(4, 4, 13)   // 64 -> 384 -> 64 at 14x14 (MobileNetV2 b07-b09)
     SNNHIP_IRBI(6, 4, 13)   // 64 -> 384 -> 96 (b10)
     SNNHIP_IRBI(6, 6, 13)   // 96 -> 576 -> 96 (b11, b12)
@@ -791,7 +875,7 @@ struct IrbBandParams {
     ActCfg ac1, ac2, ac3, ac4;
 };
 
-template <int NCB, int CJ, int GW, bool R6>
+template <int NCB, int CJ, int GW, bool R6, bool S16 = false /* split-precision pointwise stages: irb_image_kernel's note */>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 4 : 2))) void irb_band_kernel(IrbBandParams p, const float* __restrict__ x, const float4* __restrict__ weg, const float4* __restrict__ wpg,
                                                       const float4* __restrict__ epi3, float* __restrict__ y) {
     extern __shared__ float4 sm4[];
@@ -843,9 +927,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
             const unsigned off = static_cast<unsigned>(((iyA + row) * p.W + ixA + col) * p.C + sl * 4) * 4u;
             lds_dma16_sbase(xi, (e < totalSlots && sl < p.SP - 1) ? off : firstOff, xsLds + static_cast<unsigned>(e0) * 16u);
         }
+        if (S16 && tid == 0) tabR[OT16] = 0; // the tile's largest magnitude (bit pattern of a non-negative float)
         lds_dma_wait();
     }
     __syncthreads();
+    [[maybe_unused]] float sxS = 1.0f, sxInv = 1.0f;
+    [[maybe_unused]] bool scaled = false;
+    if constexpr (S16) { // the x tile in place: fp32 x 4 -> [hi x 4 | lo x 4] per 16-byte slot (pad slots too: a 24-channel tile's last K group reads them against zero weights)
+        static_assert(!S16 || SNNHIP_IRB_FOLD_BN, "the split form of the band kernel keeps the hidden slice scaled per channel: folded expand epilogue only");
+        const int totalSlots = nPx * p.SP;
+        float m = 0.f;
+        for (int e = tid; e < totalSlots; e += NT) {
+            const float4 v = xs4[e];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) atomicMax(&tabR[OT16], __float_as_int(m));
+        __syncthreads();
+        const int mb = __builtin_amdgcn_readfirstlane(tabR[OT16]); // (block-uniform: the rare scaled path is a scalar branch)
+        if (mb >= 0x47000000) { // >= 2^15 (rare): the tile times a power of two that brings it into [2^14, 2^15), undone after the expand MFMAs
+            const int ex = (mb >> 23) & 255;
+            sxS = __int_as_float((127 + 14 + 127 - ex) << 23);
+            sxInv = __int_as_float((ex - 14) << 23);
+            scaled = true;
+        }
+        for (int e = tid; e < totalSlots; e += NT) {
+            const float4 v = xs4[e];
+            xs4[e] = __builtin_bit_cast(float4, split_f16x3(v.x * sxS, v.y * sxS, v.z * sxS, v.w * sxS));
+        }
+        __syncthreads();
+    }
     IRBB_ADD(0); // setup: tables, zero fill, x tile DMA, barrier
 
     f32x4 acc[NCB][GW];
@@ -873,7 +985,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
     for (int c = 0; c < p.nSlices; ++c) {
         const bool more = c + 1 < p.nSlices;
         float4* const hs4 = hsb + (c & 1) * 4 * p.hPlane4;
-        const float4 sc1 = web[CJ * 64 + k], sh1 = web[CJ * 64 + 4 + k];
+        [[maybe_unused]] const float4 sc1 = web[CJ * 64 + k]; // (split form: 6 x the power of two the slice's channels are kept at)
+        const float4 sh1 = web[CJ * 64 + 4 + k];
         [[maybe_unused]] const float4 sc2 = wpb[NCB * 64 + 36 + k];
         const float4 sh2 = wpb[NCB * 64 + 40 + k];
         // ---- E: this wave's share of the x tile's pixel tiles, two in flight
@@ -892,11 +1005,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
             }
 #if SNNHIP_IRB_FOLD_BN
             f32x4 acc0 = {sh1.x, sh1.y, sh1.z, sh1.w}, acc1 = acc0;
+            if (S16 && scaled) acc0 = acc1 = f32x4{sh1.x * sxS, sh1.y * sxS, sh1.z * sxS, sh1.w * sxS};
+            [[maybe_unused]] f32x4 lo0 = {0.f, 0.f, 0.f, 0.f}, lo1 = {0.f, 0.f, 0.f, 0.f}; // (split form: the x16 products' own chains, irb_image_kernel's note)
 #else
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #endif
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
+                if constexpr (S16) {
+                    // (a 24-channel tile's last K group: lanes k = 2, 3 re-read quads 4, 5 against zero weights -- quads 6, 7 are the pad slot and the next pixel)
+                    const int kq = (j == CJ - 1 && p.tail8) ? (k & 1) : k;
+                    const f16x8 c0 = __builtin_bit_cast(f16x8, xs4[px0 * p.SP + 4 * j + kq]), c1 = __builtin_bit_cast(f16x8, xs4[px1 * p.SP + 4 * j + kq]);
+                    const f16x8 aj = __builtin_bit_cast(f16x8, a[j]);
+                    const f16x8 ahh = __builtin_shufflevector(aj, aj, 0, 1, 2, 3, 0, 1, 2, 3);
+                    const f16x4 al = __builtin_shufflevector(aj, aj, 4, 5, 6, 7);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahh, c0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahh, c1, acc1, 0, 0, 0);
+                    lo0 = __builtin_amdgcn_mfma_f32_16x16x16f16(al, __builtin_shufflevector(c0, c0, 0, 1, 2, 3), lo0, 0, 0, 0);
+                    lo1 = __builtin_amdgcn_mfma_f32_16x16x16f16(al, __builtin_shufflevector(c1, c1, 0, 1, 2, 3), lo1, 0, 0, 0);
+                    continue;
+                }
                 if (j == CJ - 1 && p.tail8) { // (wave-uniform) the last 8 channels: k lane kk multiplies channel 16 j + kk, then 16 j + 4 + kk
                     const float* const q0 = xsf + (px0 * p.SP + 4 * j) * 4 + k;
                     const float* const q1 = xsf + (px1 * p.SP + 4 * j) * 4 + k;
@@ -920,19 +1048,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
             [[maybe_unused]] const v2f sc01 = {sc1.x, sc1.y}, sc23 = {sc1.z, sc1.w}, sh01 = {sh1.x, sh1.y}, sh23 = {sh1.z, sh1.w};
             {
 #if SNNHIP_IRB_FOLD_BN
-                const v2f u01 = {acc0[0], acc0[1]}, u23 = {acc0[2], acc0[3]};
+                v2f u01 = {acc0[0], acc0[1]}, u23 = {acc0[2], acc0[3]};
+                if constexpr (S16) { u01 += v2f{lo0[0], lo0[1]}; u23 += v2f{lo0[2], lo0[3]}; }
+                if (S16 && scaled) { u01 *= sxInv; u23 *= sxInv; }
 #else
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
 #endif
-                hs4[k * p.hPlane4 + e0] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
+                if constexpr (S16) // (the slice's channels are kept times their weight rows' powers of two: sc1 holds 6 x that power, the depthwise taps its inverse)
+                    hs4[k * p.hPlane4 + e0] = make_float4(irb_relu_to(u01[0], sc1.x), irb_relu_to(u01[1], sc1.y), irb_relu_to(u23[0], sc1.z), irb_relu_to(u23[1], sc1.w));
+                else
+                    hs4[k * p.hPlane4 + e0] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
             if (two) {
 #if SNNHIP_IRB_FOLD_BN
-                const v2f u01 = {acc1[0], acc1[1]}, u23 = {acc1[2], acc1[3]};
+                v2f u01 = {acc1[0], acc1[1]}, u23 = {acc1[2], acc1[3]};
+                if constexpr (S16) { u01 += v2f{lo1[0], lo1[1]}; u23 += v2f{lo1[2], lo1[3]}; }
+                if (S16 && scaled) { u01 *= sxInv; u23 *= sxInv; }
 #else
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);
 #endif
-                hs4[k * p.hPlane4 + e1] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
+                if constexpr (S16)
+                    hs4[k * p.hPlane4 + e1] = make_float4(irb_relu_to(u01[0], sc1.x), irb_relu_to(u01[1], sc1.y), irb_relu_to(u23[0], sc1.z), irb_relu_to(u23[1], sc1.w));
+                else
+                    hs4[k * p.hPlane4 + e1] = make_float4(irb_act<R6>(p.ac1, u01[0]), irb_act<R6>(p.ac1, u01[1]), irb_act<R6>(p.ac1, u23[0]), irb_act<R6>(p.ac1, u23[1]));
             }
         }
         if (more) web += p.wePieces * 64;
@@ -970,6 +1108,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
             const v2f t01 = __builtin_elementwise_fma(v2f{sc2.x, sc2.y}, s01, v2f{sh2.x, sh2.y}), t23 = __builtin_elementwise_fma(v2f{sc2.z, sc2.w}, s23, v2f{sh2.z, sh2.w});
 #endif
             const float d0 = irb_act<R6>(p.ac2, t01[0]), d1 = irb_act<R6>(p.ac2, t01[1]), d2 = irb_act<R6>(p.ac2, t23[0]), d3 = irb_act<R6>(p.ac2, t23[1]);
+            if constexpr (S16) {
+                // (ONE MFMA shape on the output accumulators, irb_image_kernel's note: A = the weight slot [wh | wl], B = [dh | dh], then B = [dl | 0])
+                const f16x8 db = split_f16x3(d0, d1, d2, d3);
+                const f16x8 dhh = __builtin_shufflevector(db, db, 0, 1, 2, 3, 0, 1, 2, 3);
+                const f16x8 dl0 = __builtin_shufflevector(db, f16x8{0, 0, 0, 0, 0, 0, 0, 0}, 4, 5, 6, 7, 8, 9, 10, 11);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ap[cb]), dhh, acc[cb][g], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ap[cb]), dl0, acc[cb][g], 0, 0, 0);
+                continue;
+            }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cb].x, d0, acc[cb][g], 0, 0, 0);
 #pragma unroll
@@ -1005,8 +1154,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
             r.y = apply_act<true>(p.ac3, fmaf(sc.y, acc[cb][g][1], sh.y), 0.f);
             r.z = apply_act<true>(p.ac3, fmaf(sc.z, acc[cb][g][2], sh.z), 0.f);
             r.w = apply_act<true>(p.ac3, fmaf(sc.w, acc[cb][g][3], sh.w), 0.f);
-            if (p.hasRes) {
-                const float4 xv = xs4[xr * p.SP + cb * 4 + k];
+            if (p.hasRes) { // (the split form's tile is no longer the fp32 input; stride 1 and C == Co: the input pixel sits at the output pixel's offset, in L2)
+                const float4 xv = S16 ? *reinterpret_cast<const float4*>(x + static_cast<size_t>(img) * p.H * p.W * p.C + oo + co) : xs4[xr * p.SP + cb * 4 + k];
                 r.x = apply_act<true>(p.ac4, r.x + xv.x, 0.f);
                 r.y = apply_act<true>(p.ac4, r.y + xv.y, 0.f);
                 r.z = apply_act<true>(p.ac4, r.z + xv.z, 0.f);
@@ -1046,9 +1195,11 @@ struct IrbBandPlan : snnhip_plan {
 };
 
 typedef void (*IrbBandFn)(IrbBandParams, const float*, const float4*, const float4*, const float4*, float*);
-IrbBandFn pick_irb_band(int ncb, int cj, int gw) {
+IrbBandFn pick_irb_band(int ncb, int cj, int gw, bool s16) {
 #define SNNHIP_IRBB(NCB_, CJ_) \
-    if (ncb == NCB_ && cj == CJ_) return gw == 1 ? irb_band_kernel<NCB_, CJ_, 1, true> : irb_band_kernel<NCB_, CJ_, 2, true>;
+    if (ncb == NCB_ && cj == CJ_)  \
+        return s16 ? (gw == 1 ? irb_band_kernel<NCB_, CJ_, 1, true, true> : irb_band_kernel<NCB_, CJ_, 2, true, true>) \
+                   : (gw == 1 ? irb_band_kernel<NCB_, CJ_, 1, true, false> : irb_band_kernel<NCB_, CJ_, 2, true, false>);
     SNNHIP_IRBB(2, 1)  // 16 -> 96 -> 24 (MobileNetV2 b01)
     SNNHIP_IRBB(2, 2)  // 24 -> 144 -> 24 / 32 (b02, b03), 32 -> 192 -> 32 (b04, b05)
     SNNHIP_IRBB(4, 2)  // 32 -> 192 -> 64 (b06)
@@ -1199,6 +1350,10 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     // quarters of whole slices, ReLU6 after expand and depthwise, and at least one image per two CUs (a block is an image).  SNNHIP_IRB_IMAGE=0 switches it
     // off, =1 takes it at any batch size (tests).
     IrbImgFn imgFn = nullptr;
+    // SNNHIP_IRB_SPLIT=0: the whole-image kernel's pointwise stages as fp32 MFMAs (round 5's form); default: the split-precision form (three f16 products per fp32 product)
+    const char* splitOpt = snnhip::option("SNNHIP_IRB_SPLIT");
+    const bool imgS16 = !(splitOpt && atoi(splitOpt) == 0) && !SNNHIP_IRBI_FOLD_BN;
+    const bool bandS16 = !(splitOpt && atoi(splitOpt) == 0) && SNNHIP_IRB_FOLD_BN; // (band / wave kernels: the hidden slice stays scaled per channel, which needs the folded epilogue)
     IrbImgParams ip = {};
     size_t imgLds = 0;
     std::vector<int> imgTabs;
@@ -1210,7 +1365,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         int GT = 0;
         if (mode != 0 && !cs && !noExpand && !fuseAll && C % 16 == 0 && Co % 16 == 0 && Ch % 64 == 0 && HW <= 16 * 13 && ge.act == SNNHIP_ACT_RELU6 &&
             gd.act == SNNHIP_ACT_RELU6 && (ge.N * 2 >= cus || mode == 1))
-            imgFn = pick_irb_image(Co / 16, C / 16, up_div(OHW, 16), &GT);
+            imgFn = pick_irb_image(Co / 16, C / 16, up_div(OHW, 16), imgS16, &GT);
         if (imgFn) {
             ip.N = ge.N; ip.H = ge.H; ip.W = ge.W; ip.C = C; ip.Ch = Ch; ip.Co = Co; ip.OH = gd.OH; ip.OW = gd.OW; ip.s = s;
             ip.HW = HW;
@@ -1224,7 +1379,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
             ip.offH4 = std::max(ip.MT * 16 * ip.SP, round_up(HW * ip.SP, 64));
             ip.slicesPerWave = Ch / 64;
             ip.hasRes = ad ? 1 : 0;
-            imgLds = (static_cast<size_t>(ip.offH4) + 16 * ip.hPlane4) * 16 + static_cast<size_t>(ip.MT + GT) * 16 * 4;
+            imgLds = (static_cast<size_t>(ip.offH4) + 16 * ip.hPlane4) * 16 + static_cast<size_t>(ip.MT + GT) * 16 * 4 + (imgS16 ? 16 : 0); // (+ the split form's magnitude slot)
             if (imgLds > 160 * 1024 || HW * ip.SP >= 65536 ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(imgFn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(imgLds)) != hipSuccess)
                 imgFn = nullptr;
@@ -1260,10 +1415,12 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
             choose_band(ge.N, ge.H, ge.W, C, Ch, Co, gd.OH, gd.OW, s, cus, &bc) &&
             ((static_cast<long>(ge.N) * up_div(gd.OH, bc.R) * up_div(gd.OW, bc.SW) >= 2L * cus && Ch >= 144) || mode == 1) &&
             bc.MTmax * 16 * (C / 4 + 1) < 65536)
-            bandFn = pick_irb_band(up_div(Co, 16), up_div(C, 16), bc.GW);
+            bandFn = pick_irb_band(up_div(Co, 16), up_div(C, 16), bc.GW, bandS16);
+        if (bandFn && bandS16) bc.lds += 16; // (the split form's magnitude slot behind the tables)
         if (bandFn && hipFuncSetAttribute(reinterpret_cast<const void*>(bandFn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bc.lds)) != hipSuccess) bandFn = nullptr;
     }
     const bool tail8 = !imgFn && !cs && !noExpand && C % 16 == 8 && !snnhip::option("SNNHIP_IRB_NO_TAIL8"); // (the switch: A/B runs of irb_wave_kernel)
+    const bool s16 = (imgFn && imgS16) || (bandFn && bandS16);
 
     IrbParams p = {};
     p.N = ge.N; p.H = ge.H; p.W = ge.W; p.C = C; p.Ch = Ch; p.Co = Co; p.OH = gd.OH; p.OW = gd.OW; p.s = s; p.padx = gd.padx; p.pady = gd.pady;
@@ -1352,6 +1509,35 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     const std::vector<float> e1 = noExpand ? std::vector<float>(static_cast<size_t>(Ch) * 2, 0.0f) : fold_epilogue(cs ? cs->epi4 : ce->epi4, Ch, ge.useBN);
     const std::vector<float> e2 = fold_epilogue(cd->epi4, Ch, gd.useBN), e3 = fold_epilogue(cp->epi4, Co, gp.useBN);
     std::vector<float> we(static_cast<size_t>(p.nChunks) * p.wePieces * 256, 0.0f), wp(static_cast<size_t>(p.nChunks) * p.wpPieces * 256, 0.0f);
+    // split-precision form (irb_image_kernel<.., S16>): every weight row times the power of two that puts its largest magnitude into [2^13, 2^14) -- undone in the
+    // row's epilogue scale --, each weight as [hi | lo] halves: a lane's 16-byte operand slot holds {hi of its four K values, lo of the same four}
+    std::vector<int> rowExpE(static_cast<size_t>(Ch), 0), rowExpP(static_cast<size_t>(Co), 0);
+    if (s16) {
+        auto row_exp = [](const float* w, int n, int stride) {
+            float m = 0.0f;
+            for (int i = 0; i < n; ++i) m = std::max(m, std::fabs(w[static_cast<size_t>(i) * stride]));
+            if (!(m > 0.0f) || !std::isfinite(m)) return 0;
+            int ex = 0;
+            (void)std::frexp(m, &ex); // m = f 2^ex, f in [0.5, 1)
+            return std::min(100, std::max(-100, 14 - ex));
+        };
+        const bool fold = imgFn ? SNNHIP_IRBI_FOLD_BN != 0 : SNNHIP_IRB_FOLD_BN != 0;
+        for (int hc = 0; hc < Ch; ++hc) {
+            rowExpE[hc] = row_exp(ce->w_oihw.data() + static_cast<size_t>(hc) * C, C, 1);
+            if (fold && e1[2 * hc] != 0.0f && std::isfinite(e1[2 * hc])) { // (the row the kernel multiplies is scale x weights)
+                int ex = 0;
+                (void)std::frexp(std::fabs(e1[2 * hc]), &ex);
+                rowExpE[hc] = std::min(100, std::max(-100, rowExpE[hc] - (ex - 1)));
+            }
+        }
+        for (int co = 0; co < Co; ++co) rowExpP[co] = row_exp(cp->w_oihw.data() + static_cast<size_t>(co) * Ch, Ch, 1);
+    }
+    auto put_split = [](float* slot, int jj, float w) { // slot: 4 floats = 8 halves
+        _Float16* const h = reinterpret_cast<_Float16*>(slot);
+        const _Float16 hi = static_cast<_Float16>(w);
+        h[jj] = hi;
+        h[4 + jj] = static_cast<_Float16>(w - static_cast<float>(hi));
+    };
     for (int c = 0; c < p.nChunks; ++c) {
         float* wb = we.data() + static_cast<size_t>(c) * p.wePieces * 256;
         float* pb = wp.data() + static_cast<size_t>(c) * p.wpPieces * 256;
@@ -1364,7 +1550,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
             // expand: [j][lane = 16 kk + m] float4 {We[hc][16 j + 4 kk + jj]}
             for (int ic = 0; ic < C && !noExpand; ++ic) {
                 const int j = ic / 16, kk = (ic % 16) / 4, jj = ic % 4;
-                if (tail8 && j == p.Cj - 1) { // irb_band_kernel's last 8 channels: component 0 = channel 16 j + kk, component 1 = channel 16 j + 4 + kk
+                if (!s16 && tail8 && j == p.Cj - 1) { // irb_band_kernel's last 8 channels: component 0 = channel 16 j + kk, component 1 = channel 16 j + 4 + kk
                     wb[j * 256 + ((ic % 4) * 16 + m) * 4 + (ic % 16) / 4] = s1 * ce->w_oihw[static_cast<size_t>(hc) * C + ic];
                     continue;
                 }
@@ -1372,12 +1558,19 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
                     if (ic < 27) wb[j * 256 + (kk * 16 + m) * 4 + jj] = s1 * cs->w_oihw[(static_cast<size_t>(hc) * 3 + ic % 3) * 9 + ic / 3];
                     continue;
                 }
+                if (s16) { // (the band kernel's tail8 component order does not apply: its split form reads whole K groups)
+                    put_split(wb + j * 256 + (kk * 16 + m) * 4, jj, std::ldexp(s1 * ce->w_oihw[static_cast<size_t>(hc) * C + ic], rowExpE[hc]));
+                    continue;
+                }
                 wb[j * 256 + (kk * 16 + m) * 4 + jj] = s1 * ce->w_oihw[static_cast<size_t>(hc) * C + ic];
             }
-            wb[p.Cj * 256 + m] = e1[2 * hc];
-            wb[p.Cj * 256 + 16 + m] = e1[2 * hc + 1];
+            // split form, unfolded epilogue (image kernel): the row's power of two is undone in the multiplier; folded (band kernel): the slice stays scaled -- the sums
+            // start from the scaled shift, ReLU6 clamps to the scaled 6 (kept in the multiplier's slot), the depthwise taps carry the inverse power
+            const bool keepScaled = s16 && foldBN;
+            wb[p.Cj * 256 + m] = keepScaled ? std::ldexp(6.0f, rowExpE[hc]) : s16 ? std::ldexp(e1[2 * hc], -rowExpE[hc]) : e1[2 * hc];
+            wb[p.Cj * 256 + 16 + m] = keepScaled ? std::ldexp(e1[2 * hc + 1], rowExpE[hc]) : e1[2 * hc + 1];
             // depthwise taps [tap][16], scale[16], shift[16]
-            for (int tp = 0; tp < 9; ++tp) pb[p.NCB * 256 + tp * 16 + m] = s2 * cd->w_oihw[static_cast<size_t>(hc) * 9 + tp];
+            for (int tp = 0; tp < 9; ++tp) pb[p.NCB * 256 + tp * 16 + m] = keepScaled ? std::ldexp(s2 * cd->w_oihw[static_cast<size_t>(hc) * 9 + tp], -rowExpE[hc]) : s2 * cd->w_oihw[static_cast<size_t>(hc) * 9 + tp];
             pb[p.NCB * 256 + 144 + m] = e2[2 * hc];
             pb[p.NCB * 256 + 160 + m] = e2[2 * hc + 1];
         }
@@ -1386,13 +1579,17 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
             for (int q = 0; q < 16; ++q) {
                 const int hc = 16 * c + q;
                 if (hc >= Ch) continue;
+                if (s16) {
+                    put_split(pb + (co / 16) * 256 + ((q / 4) * 16 + co % 16) * 4, q % 4, std::ldexp(cp->w_oihw[static_cast<size_t>(co) * Ch + hc], rowExpP[co]));
+                    continue;
+                }
                 pb[(co / 16) * 256 + ((q / 4) * 16 + co % 16) * 4 + q % 4] = cp->w_oihw[static_cast<size_t>(co) * Ch + hc];
             }
     }
     // final epilogue: per (cb, k) {scale float4, shift float4}
     std::vector<float> e3p(static_cast<size_t>(p.NCB) * 4 * 8, 0.0f);
     for (int co = 0; co < Co; ++co) {
-        e3p[(co / 4) * 8 + co % 4] = e3[2 * co];
+        e3p[(co / 4) * 8 + co % 4] = s16 ? std::ldexp(e3[2 * co], -rowExpP[co]) : e3[2 * co];
         e3p[(co / 4) * 8 + 4 + co % 4] = e3[2 * co + 1];
     }
 
@@ -1440,9 +1637,10 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         bpl->bytes = ce->bytes + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
         bpl->kernelBytes = fusedBytes;
         char bb[352];
-        snprintf(bb, sizeof(bb), "irb_fused_mfma_f32_16x16x4 [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] band per block (%d rows x %d cols, %d waves, %d px tiles in), "
-                 "slices=%d lds=%zuB hbm_bytes=%.6g kernel=irb_band_kernel<%d,%d,%d,true> relu6-epilogues%s",
-                 C, Ch, s, Ch, Co, addPlan ? " + add" : "", bc.R, bc.SW, bc.NW, bc.MTmax, p.nChunks, bc.lds, fusedBytes, up_div(Co, 16), up_div(C, 16), bc.GW, tail8 ? " tail8" : "");
+        snprintf(bb, sizeof(bb), "irb_fused_mfma_%s [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] band per block (%d rows x %d cols, %d waves, %d px tiles in), "
+                 "slices=%d lds=%zuB hbm_bytes=%.6g kernel=irb_band_kernel<%d,%d,%d,true,%s> relu6-epilogues%s",
+                 bandS16 ? "f16x3split_16x16x32" : "f32_16x16x4", C, Ch, s, Ch, Co, addPlan ? " + add" : "", bc.R, bc.SW, bc.NW, bc.MTmax, p.nChunks, bc.lds, fusedBytes, up_div(Co, 16),
+                 up_div(C, 16), bc.GW, bandS16 ? "true" : "false", tail8 ? " tail8" : "");
         bpl->desc = bb;
         if (snnhip::option("SNNHIP_IRB_OCC")) { // developer switch: what the runtime says about co-resident blocks of this geometry
             int nb = -1;
@@ -1474,9 +1672,10 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         ipl->bytes = ce->bytes + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
         ipl->kernelBytes = fusedBytes;
         char ib[320];
-        snprintf(ib, sizeof(ib), "irb_fused_mfma_f32_16x16x4 [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] image per block (%dx%d, %d px tiles), hidden quarter per wave, "
-                 "slices=%d lds=%zuB hbm_bytes=%.6g kernel=irb_image_kernel<%d,%d,%d,true> relu6-epilogues",
-                 C, Ch, s, Ch, Co, addPlan ? " + add" : "", ip.H, ip.W, ip.MT, Ch / 16, imgLds, fusedBytes, Co / 16, C / 16, static_cast<int>(imgTabs.size() / 16) - ip.MT);
+        snprintf(ib, sizeof(ib), "irb_fused_mfma_%s [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] image per block (%dx%d, %d px tiles), hidden quarter per wave, "
+                 "slices=%d lds=%zuB hbm_bytes=%.6g kernel=irb_image_kernel<%d,%d,%d,true,%s> relu6-epilogues",
+                 imgS16 ? "f16x3split_16x16x32" : "f32_16x16x4", C, Ch, s, Ch, Co, addPlan ? " + add" : "", ip.H, ip.W, ip.MT, Ch / 16, imgLds, fusedBytes, Co / 16, C / 16,
+                 static_cast<int>(imgTabs.size() / 16) - ip.MT, imgS16 ? "true" : "false");
         ipl->desc = ib;
         *out = ipl;
         return SNNHIP_OK;

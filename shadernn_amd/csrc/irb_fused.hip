@@ -124,7 +124,8 @@ __device__ __forceinline__ f16x8 split_f16x3(float d0, float d1, float d2, float
 // One lane = (pixel n16 of a 16-pixel group, channel quad k); weights pre-packed on the host in the MFMA operand order (K permuted so that one
 // float4 per operand feeds four v_mfma_f32_16x16x4_f32).
 template <int G /* 16-pixel output groups per wave: 4 = 8x8 tile, 2 = 4x8, 1 = 2x8 */, int NCBT /* compile-time bound on the output blocks */, int CJT /* ... on Cj */,
-          bool R6 /* expand and depthwise activations are ReLU6 */, bool STEM = false /* IrbParams::stemK: the expand layer is a 3x3 convolution of an RGB image */>
+          bool R6 /* expand and depthwise activations are ReLU6 */, bool STEM = false /* IrbParams::stemK: the expand layer is a 3x3 convolution of an RGB image */,
+          bool S16 = false /* split-precision pointwise stages (irb_image_kernel's note); the wave's x tile is split in place behind the staging */>
 __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const float* __restrict__ x, const float4* __restrict__ weg, const float4* __restrict__ wpg,
                                                        const float4* __restrict__ epi3, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -253,6 +254,33 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
         }
     }
 
+    [[maybe_unused]] float sxS = 1.0f, sxInv = 1.0f;
+    [[maybe_unused]] bool scaled = false;
+    if constexpr (S16) { // the wave's x tile in place (its LDS operations complete in order): fp32 x 4 -> [hi x 4 | lo x 4] per 16-byte slot; zeros stay zeros
+        static_assert(!S16 || (SNNHIP_IRB_FOLD_BN && R6 && !STEM), "the split form keeps the hidden slice scaled per channel: folded ReLU6 expand epilogue only");
+        const int quads = 4 * p.Cj, npx = p.MT * 16;
+        float m = 0.f;
+        for (int q = 0; q < quads; ++q)
+            for (int hp = lane; hp < npx; hp += 64) {
+                const float4 v = *reinterpret_cast<const float4*>(xs + q * p.xPlane + hp * 4);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const int mb = __builtin_amdgcn_readfirstlane(__float_as_int(m));
+        if (mb >= 0x47000000) { // >= 2^15 (rare): the tile times a power of two that brings it into [2^14, 2^15), undone after the expand MFMAs
+            const int ex = (mb >> 23) & 255;
+            sxS = __int_as_float((127 + 14 + 127 - ex) << 23);
+            sxInv = __int_as_float((ex - 14) << 23);
+            scaled = true;
+        }
+        for (int q = 0; q < quads; ++q)
+            for (int hp = lane; hp < npx; hp += 64) {
+                float4* const sp = reinterpret_cast<float4*>(xs + q * p.xPlane + hp * 4);
+                const float4 v = *sp;
+                *sp = __builtin_bit_cast(float4, split_f16x3(v.x * sxS, v.y * sxS, v.z * sxS, v.w * sxS));
+            }
+    }
 #ifdef SNNHIP_IRB_TRACE
     if (itrace) istamp[1] = __builtin_readcyclecounter();
 #endif
@@ -287,12 +315,25 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                 const int px1 = two ? px0 + 16 : px0;
 #if SNNHIP_IRB_FOLD_BN
                 f32x4 acc0 = {sh.x, sh.y, sh.z, sh.w}, acc1 = acc0;
+                if (S16 && scaled) acc0 = acc1 = f32x4{sh.x * sxS, sh.y * sxS, sh.z * sxS, sh.w * sxS};
 #else
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #endif
 #pragma unroll
                 for (int j = 0; j < CJT; ++j)
-                    if (j == p.Cj - 1 && p.tail8) { // (wave-uniform)
+                    if constexpr (S16) { // (planes past C hold zeros: a 24-channel tile needs no tail form; one MFMA shape per chain, irb_band_kernel's note)
+                        if (j < p.Cj) {
+                            const f16x8 c0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const float4*>(xs + (4 * j + k) * p.xPlane + px0 * 4));
+                            const f16x8 c1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const float4*>(xs + (4 * j + k) * p.xPlane + px1 * 4));
+                            const f16x8 aj = __builtin_bit_cast(f16x8, a[j]);
+                            const f16x8 ahh = __builtin_shufflevector(aj, aj, 0, 1, 2, 3, 0, 1, 2, 3);
+                            const f16x8 al0 = __builtin_shufflevector(aj, f16x8{0, 0, 0, 0, 0, 0, 0, 0}, 4, 5, 6, 7, 8, 9, 10, 11);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahh, c0, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahh, c1, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, c0, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, c1, acc1, 0, 0, 0);
+                        }
+                    } else if (j == p.Cj - 1 && p.tail8) { // (wave-uniform)
                         const float* const q0 = xs + 4 * j * p.xPlane + px0 * 4 + k;
                         const float* const q1 = xs + 4 * j * p.xPlane + px1 * 4 + k;
                         const float b00 = q0[0], b01 = q0[p.xPlane], b10 = q1[0], b11 = q1[p.xPlane];
@@ -317,14 +358,22 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                 float4 h;
                 {
 #if SNNHIP_IRB_FOLD_BN
-                    const v2f u01 = {acc0[0], acc0[1]}, u23 = {acc0[2], acc0[3]};
+                    v2f u01 = {acc0[0], acc0[1]}, u23 = {acc0[2], acc0[3]};
+                    if (S16 && scaled) { u01 *= sxInv; u23 *= sxInv; }
 #else
                     const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
 #endif
-                    h.x = irb_act<R6>(p.ac1, u01[0]);
-                    h.y = irb_act<R6>(p.ac1, u01[1]);
-                    h.z = irb_act<R6>(p.ac1, u23[0]);
-                    h.w = irb_act<R6>(p.ac1, u23[1]);
+                    if constexpr (S16) { // (the slice's channels stay times their weight rows' powers of two: sc holds 6 x that power, the depthwise taps its inverse)
+                        h.x = irb_relu_to(u01[0], sc.x);
+                        h.y = irb_relu_to(u01[1], sc.y);
+                        h.z = irb_relu_to(u23[0], sc.z);
+                        h.w = irb_relu_to(u23[1], sc.w);
+                    } else {
+                        h.x = irb_act<R6>(p.ac1, u01[0]);
+                        h.y = irb_act<R6>(p.ac1, u01[1]);
+                        h.z = irb_act<R6>(p.ac1, u23[0]);
+                        h.w = irb_act<R6>(p.ac1, u23[1]);
+                    }
                 }
                 if (border) {
                     const float m0 = msk[px0];
@@ -333,14 +382,22 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                 *reinterpret_cast<float4*>(hs + k * p.hPlane + px0 * 4) = h;
                 if (two) {
 #if SNNHIP_IRB_FOLD_BN
-                    const v2f u01 = {acc1[0], acc1[1]}, u23 = {acc1[2], acc1[3]};
+                    v2f u01 = {acc1[0], acc1[1]}, u23 = {acc1[2], acc1[3]};
+                    if (S16 && scaled) { u01 *= sxInv; u23 *= sxInv; }
 #else
                     const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);
 #endif
-                    h.x = irb_act<R6>(p.ac1, u01[0]);
-                    h.y = irb_act<R6>(p.ac1, u01[1]);
-                    h.z = irb_act<R6>(p.ac1, u23[0]);
-                    h.w = irb_act<R6>(p.ac1, u23[1]);
+                    if constexpr (S16) {
+                        h.x = irb_relu_to(u01[0], sc.x);
+                        h.y = irb_relu_to(u01[1], sc.y);
+                        h.z = irb_relu_to(u23[0], sc.z);
+                        h.w = irb_relu_to(u23[1], sc.w);
+                    } else {
+                        h.x = irb_act<R6>(p.ac1, u01[0]);
+                        h.y = irb_act<R6>(p.ac1, u01[1]);
+                        h.z = irb_act<R6>(p.ac1, u23[0]);
+                        h.w = irb_act<R6>(p.ac1, u23[1]);
+                    }
                     if (border) {
                         const float m1 = msk[px1];
                         h.x *= m1; h.y *= m1; h.z *= m1; h.w *= m1;
@@ -388,10 +445,26 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                 dv[g].z = irb_act<R6>(p.ac2, t23[0]);
                 dv[g].w = irb_act<R6>(p.ac2, t23[1]);
             }
+            [[maybe_unused]] f16x8 dhh[G], dl0[G];
+            if constexpr (S16) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const f16x8 db = split_f16x3(dv[g].x, dv[g].y, dv[g].z, dv[g].w);
+                    dhh[g] = __builtin_shufflevector(db, db, 0, 1, 2, 3, 0, 1, 2, 3);
+                    dl0[g] = __builtin_shufflevector(db, f16x8{0, 0, 0, 0, 0, 0, 0, 0}, 4, 5, 6, 7, 8, 9, 10, 11);
+                }
+            }
 #pragma unroll
             for (int cb = 0; cb < NCBT; ++cb)
                 if (cb < p.NCB) {
                     const float4 a = wpb[cb * 64 + lane];
+                    if constexpr (S16) { // (A = the weight slot [wh | wl]; B = [dh | dh], then [dl | 0]: irb_image_kernel's note)
+#pragma unroll
+                        for (int g = 0; g < G; ++g) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), dhh[g], acc[cb][g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < G; ++g) acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), dl0[g], acc[cb][g], 0, 0, 0);
+                        continue;
+                    }
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         acc[cb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, dv[g].x, acc[cb][g], 0, 0, 0);
@@ -425,8 +498,9 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
                 o.y = apply_act<true>(p.ac3, fmaf(sc.y, acc[cb][g][1], sh.y), 0.f);
                 o.z = apply_act<true>(p.ac3, fmaf(sc.z, acc[cb][g][2], sh.z), 0.f);
                 o.w = apply_act<true>(p.ac3, fmaf(sc.w, acc[cb][g][3], sh.w), 0.f);
-                if (p.hasRes) {
-                    const float4 r = *reinterpret_cast<const float4*>(xs + (co >> 2) * p.xPlane + hpc * 4);
+                if (p.hasRes) { // (the split form's tile is no longer the fp32 input; stride 1, C == Co: the input pixel sits where the output pixel does, in L2)
+                    const float4 r = S16 ? *reinterpret_cast<const float4*>(x + ((static_cast<size_t>(img) * p.H + oy) * p.W + ox) * p.C + co)
+                                         : *reinterpret_cast<const float4*>(xs + (co >> 2) * p.xPlane + hpc * 4);
                     o.x = apply_act<true>(p.ac4, o.x + r.x, 0.f);
                     o.y = apply_act<true>(p.ac4, o.y + r.y, 0.f);
                     o.z = apply_act<true>(p.ac4, o.z + r.z, 0.f);
@@ -622,8 +696,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
                 const float4 b0 = b0p[4 * j], b1 = b1p[4 * j];
-                if constexpr (S16) { // (the two MFMA shapes keep their own accumulator chains -- an x16 never reads what an x32 has just written --, summed in the epilogue)
+                if constexpr (S16) {
                     const f16x8 aj = __builtin_bit_cast(f16x8, a[j]), c0 = __builtin_bit_cast(f16x8, b0), c1 = __builtin_bit_cast(f16x8, b1);
+                    // the two MFMA shapes keep their OWN accumulator chains (an x16 reading what an x32 has just written is a hazard the compiler does not pad), summed
+                    // in the epilogue: A = [wh | wh] against the slot [xh | xl], A = wl against its lower half (the all-x32 form of irb_band_kernel spills here)
                     const f16x8 ahh = __builtin_shufflevector(aj, aj, 0, 1, 2, 3, 0, 1, 2, 3);
                     const f16x4 al = __builtin_shufflevector(aj, aj, 4, 5, 6, 7);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahh, c0, acc0, 0, 0, 0);
@@ -1006,7 +1082,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
 #if SNNHIP_IRB_FOLD_BN
             f32x4 acc0 = {sh1.x, sh1.y, sh1.z, sh1.w}, acc1 = acc0;
             if (S16 && scaled) acc0 = acc1 = f32x4{sh1.x * sxS, sh1.y * sxS, sh1.z * sxS, sh1.w * sxS};
-            [[maybe_unused]] f32x4 lo0 = {0.f, 0.f, 0.f, 0.f}, lo1 = {0.f, 0.f, 0.f, 0.f}; // (split form: the x16 products' own chains, irb_image_kernel's note)
 #else
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #endif
@@ -1017,12 +1092,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
                     const int kq = (j == CJ - 1 && p.tail8) ? (k & 1) : k;
                     const f16x8 c0 = __builtin_bit_cast(f16x8, xs4[px0 * p.SP + 4 * j + kq]), c1 = __builtin_bit_cast(f16x8, xs4[px1 * p.SP + 4 * j + kq]);
                     const f16x8 aj = __builtin_bit_cast(f16x8, a[j]);
+                    // ONE MFMA shape per accumulator chain (an x16 reading what an x32 has just written is a hazard the compiler does not pad): the slot [xh | xl] is the
+                    // B operand of both products, A = [wh | wh] gives wh xh + wh xl, A = [wl | 0] gives wl xh (both tuples are per slice, not per tile)
                     const f16x8 ahh = __builtin_shufflevector(aj, aj, 0, 1, 2, 3, 0, 1, 2, 3);
-                    const f16x4 al = __builtin_shufflevector(aj, aj, 4, 5, 6, 7);
+                    const f16x8 al0 = __builtin_shufflevector(aj, f16x8{0, 0, 0, 0, 0, 0, 0, 0}, 4, 5, 6, 7, 8, 9, 10, 11);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahh, c0, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahh, c1, acc1, 0, 0, 0);
-                    lo0 = __builtin_amdgcn_mfma_f32_16x16x16f16(al, __builtin_shufflevector(c0, c0, 0, 1, 2, 3), lo0, 0, 0, 0);
-                    lo1 = __builtin_amdgcn_mfma_f32_16x16x16f16(al, __builtin_shufflevector(c1, c1, 0, 1, 2, 3), lo1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, c0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, c1, acc1, 0, 0, 0);
                     continue;
                 }
                 if (j == CJ - 1 && p.tail8) { // (wave-uniform) the last 8 channels: k lane kk multiplies channel 16 j + kk, then 16 j + 4 + kk
@@ -1049,7 +1126,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
             {
 #if SNNHIP_IRB_FOLD_BN
                 v2f u01 = {acc0[0], acc0[1]}, u23 = {acc0[2], acc0[3]};
-                if constexpr (S16) { u01 += v2f{lo0[0], lo0[1]}; u23 += v2f{lo0[2], lo0[3]}; }
                 if (S16 && scaled) { u01 *= sxInv; u23 *= sxInv; }
 #else
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc0[0], acc0[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc0[2], acc0[3]}, sh23);
@@ -1062,7 +1138,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
             if (two) {
 #if SNNHIP_IRB_FOLD_BN
                 v2f u01 = {acc1[0], acc1[1]}, u23 = {acc1[2], acc1[3]};
-                if constexpr (S16) { u01 += v2f{lo1[0], lo1[1]}; u23 += v2f{lo1[2], lo1[3]}; }
                 if (S16 && scaled) { u01 *= sxInv; u23 *= sxInv; }
 #else
                 const v2f u01 = __builtin_elementwise_fma(sc01, v2f{acc1[0], acc1[1]}, sh01), u23 = __builtin_elementwise_fma(sc23, v2f{acc1[2], acc1[3]}, sh23);

@@ -416,7 +416,7 @@ def compact_line(detail, detail_path="bench_detail.json"):
     if rf:
         line["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic_bytes", "kernel", "share_of_gpu_time",
                                                "launches_per_step", "avg_launch_us", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "frac_executed",
-                                               "mfma_pipe_util_pmc", "bound_note", "whole_step_frac", "sync_per_inference_images_per_s",
+                                               "mfma_pipe_util_pmc", "bound_note", "arithmetic", "frac_of_split_peak", "whole_step_frac", "sync_per_inference_images_per_s",
                                                "sync_per_inference_blocking_wait_images_per_s", "whole_step_frac_sync_per_inference") if rf.get(k) is not None or k == "traffic"}
         for k in ("sum_of_kernel_durations_ms", "sum_of_launch_rooflines_ms"):
             if k in d:
@@ -540,6 +540,15 @@ def pmc_field(kernel, field):
     return (tot / n) if n else None
 
 
+SPLIT_TAG = "f16x3split"  # plan descriptions of the split-precision kernels (irb_fused.hip): fp32 operands as fp16 hi + lo, three f16 MFMA products per fp32 product
+SPLIT_NOTE = ("pointwise stages with fp32 operands carried as fp16 hi + lo halves: three f16 MFMA products per fp32 product, fp32 accumulate (|error| <= 2^-21 per "
+              "product); `frac` stays algorithmic fp32 flops against the fp32 MFMA peak, `frac_of_split_peak` is the same flops against the f16 pipe's 2500 / 3 TFLOP/s")
+
+
+def _is_split(inst):
+    return any(SPLIT_TAG in (pl or "") for pl in inst.get("plans", []))
+
+
 def kernel_table(trace, inferences, peak_tf):
     """The launch trace (capi.trace_end) as one row per kernel FUNCTION, most GPU time first.  `flops` / `bytes` are the algorithmic work of the plan
     invocations whose main launch the function was (a fused plan: what the fused launch moves), per traced step; a function that only ever runs
@@ -567,6 +576,10 @@ def kernel_table(trace, inferences, peak_tf):
             util = pmc_field(k, "mfma_pipe_util")
             if util is not None:
                 row["mfma_pipe_util_pmc"] = util
+            split_flops = sum(i["flops"] for i in k["instances"] if _is_split(i))
+            if split_flops > 0:
+                row["arithmetic"] = "f16x3 split products, fp32 accumulate" + ("" if split_flops >= 0.999 * k["flops"] else " (%.0f %% of this function's flops)" % (100.0 * split_flops / k["flops"]))
+                row["frac_of_split_peak"] = split_flops / t / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0)
         else:
             row["bound"], row["frac"] = "aux", None
         rows.append(row)
@@ -605,6 +618,8 @@ def roofline_record(rows, peak_tf, single_launch_step):
         rec["frac_executed"] = ex / t / 1e12 / peak_tf
     if dom.get("mfma_pipe_util_pmc") is not None:
         rec["mfma_pipe_util_pmc"] = dom["mfma_pipe_util_pmc"]
+    if dom.get("arithmetic"):
+        rec["arithmetic"], rec["frac_of_split_peak"], rec["split_peak"], rec["arithmetic_note"] = dom["arithmetic"], dom["frac_of_split_peak"], PEAK_F16_MFMA_TFLOPS / 3.0, SPLIT_NOTE
     return rec
 
 
@@ -952,6 +967,7 @@ def main():
                     rf, cb, par = r.get("roofline") or {}, r.get("cpu_baseline") or {}, r.get("parity") or {}
                     return {"id": c, "dtype": r.get("dtype"), "launches": r.get("launches_per_step"), "ms_per_step": r.get("ms_per_step"), "images_per_s": r.get("value"), "whole_step_frac": r.get("frac_of_whole_step_roofline"),
                             "dominant_kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": rf.get("frac"), "frac_executed": rf.get("frac_executed"),
+                            "arithmetic": rf.get("arithmetic"), "frac_of_split_peak": rf.get("frac_of_split_peak"),
                             "share_of_gpu_time": rf.get("share_of_gpu_time"), "parity_ok": par.get("ok"), "max_abs_err": par.get("max_abs_err"),
                             "cpu_images_per_s": cb.get("value"), "cpu_cores": cb.get("cores")}
                 out["roofline"]["other_configs"] = [brief(c, recs[c]) for c in extra]

@@ -1338,10 +1338,10 @@ bool choose_band(int N, int H, int W, int C, int Ch, int Co, int OH, int OW, int
 }
 
 typedef void (*IrbFn)(IrbParams, const float*, const float4*, const float4*, const float4*, float*);
-template <int G, bool R6>
+template <int G, bool R6, bool S16 = false>
 IrbFn pick_irb_wave(int ncb, int cj) {
 #define SNNHIP_IRBW(NCBT_, CJT_) \
-    if (ncb <= NCBT_ && cj <= CJT_) return irb_wave_kernel<G, NCBT_, CJT_, R6>;
+    if (ncb <= NCBT_ && cj <= CJT_) return irb_wave_kernel<G, NCBT_, CJT_, R6, false, S16>;
     SNNHIP_IRBW(2, 1)
     SNNHIP_IRBW(2, 2)
     SNNHIP_IRBW(4, 2)
@@ -1495,7 +1495,9 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         if (bandFn && hipFuncSetAttribute(reinterpret_cast<const void*>(bandFn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bc.lds)) != hipSuccess) bandFn = nullptr;
     }
     const bool tail8 = !imgFn && !cs && !noExpand && C % 16 == 8 && !snnhip::option("SNNHIP_IRB_NO_TAIL8"); // (the switch: A/B runs of irb_wave_kernel)
-    const bool s16 = (imgFn && imgS16) || (bandFn && bandS16);
+    const bool r6 = ge.act == SNNHIP_ACT_RELU6 && gd.act == SNNHIP_ACT_RELU6;
+    const bool waveS16 = !imgFn && !bandFn && !cs && !noExpand && r6 && bandS16; // (irb_wave_kernel: MobileNetV2's b01)
+    const bool s16 = (imgFn && imgS16) || (bandFn && bandS16) || waveS16;
 
     IrbParams p = {};
     p.N = ge.N; p.H = ge.H; p.W = ge.W; p.C = C; p.Ch = Ch; p.Co = Co; p.OH = gd.OH; p.OW = gd.OW; p.s = s; p.padx = gd.padx; p.pady = gd.pady;
@@ -1563,7 +1565,6 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     p.ac3 = make_act_cfg(gp.act, gp.leaky);
     p.ac4 = make_act_cfg(ad ? ad->d.act : 0, ad ? ad->d.leaky : 0.0f);
     const size_t lds = static_cast<size_t>(NWv) * perWave * sizeof(float);
-    const bool r6 = ge.act == SNNHIP_ACT_RELU6 && gd.act == SNNHIP_ACT_RELU6;
     IrbFn fn = nullptr;
     if (imgFn || bandFn) {
     } else if (cs) { // stem mode: its own instantiations (Cj = 2: the 27 image values; up to 32 output channels)
@@ -1571,9 +1572,9 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         if (G == 4) fn = r6 ? irb_wave_kernel<4, 2, 2, true, true> : irb_wave_kernel<4, 2, 2, false, true>;
         if (G == 2) fn = r6 ? irb_wave_kernel<2, 2, 2, true, true> : irb_wave_kernel<2, 2, 2, false, true>;
         if (G == 1) fn = r6 ? irb_wave_kernel<1, 2, 2, true, true> : irb_wave_kernel<1, 2, 2, false, true>;
-    } else if (G == 4) fn = r6 ? pick_irb_wave<4, true>(p.NCB, p.Cj) : pick_irb_wave<4, false>(p.NCB, p.Cj);
-    else if (G == 2) fn = r6 ? pick_irb_wave<2, true>(p.NCB, p.Cj) : pick_irb_wave<2, false>(p.NCB, p.Cj);
-    else if (G == 1) fn = r6 ? pick_irb_wave<1, true>(p.NCB, p.Cj) : pick_irb_wave<1, false>(p.NCB, p.Cj);
+    } else if (G == 4) fn = waveS16 ? pick_irb_wave<4, true, true>(p.NCB, p.Cj) : r6 ? pick_irb_wave<4, true>(p.NCB, p.Cj) : pick_irb_wave<4, false>(p.NCB, p.Cj);
+    else if (G == 2) fn = waveS16 ? pick_irb_wave<2, true, true>(p.NCB, p.Cj) : r6 ? pick_irb_wave<2, true>(p.NCB, p.Cj) : pick_irb_wave<2, false>(p.NCB, p.Cj);
+    else if (G == 1) fn = waveS16 ? pick_irb_wave<1, true, true>(p.NCB, p.Cj) : r6 ? pick_irb_wave<1, true>(p.NCB, p.Cj) : pick_irb_wave<1, false>(p.NCB, p.Cj);
     if (!fn && !imgFn && !bandFn) return SNNHIP_E_UNSUPPORTED;
     if (fn && lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
         set_error("irb_fused: hipFuncSetAttribute(%zu) failed", lds);
@@ -1796,9 +1797,9 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
                 break;
             }
     }
-    snprintf(buf, sizeof(buf), "irb_fused_mfma_f32_16x16x4 [%s + conv1x1 %d->%d%s] tile=%dx8px per wave, halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_wave_kernel<%d,%d,%d,%s,%s>",
-             head, Ch, Co, addPlan ? " + add" : "", 2 * G, p.HH, p.HWd, p.nChunks, plan->threads, lds, fusedBytes, G, cs ? 2 : vNcb, cs ? 2 : vCj, r6 ? "true" : "false",
-             cs ? "true" : "false");
+    snprintf(buf, sizeof(buf), "irb_fused_mfma_%s [%s + conv1x1 %d->%d%s] tile=%dx8px per wave, halo=%dx%d slices=%d threads=%d lds=%zuB hbm_bytes=%.6g kernel=irb_wave_kernel<%d,%d,%d,%s,%s,%s>",
+             waveS16 ? "f16x3split_16x16x32" : "f32_16x16x4", head, Ch, Co, addPlan ? " + add" : "", 2 * G, p.HH, p.HWd, p.nChunks, plan->threads, lds, fusedBytes, G, cs ? 2 : vNcb,
+             cs ? 2 : vCj, r6 ? "true" : "false", cs ? "true" : "false", waveS16 ? "true" : "false");
     plan->desc = buf;
     if (r6) plan->desc += " relu6-epilogues";
     if (tail8) plan->desc += " tail8";

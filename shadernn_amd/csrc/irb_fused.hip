@@ -97,8 +97,8 @@ __device__ __forceinline__ float irb_relu_to(float v, float bound) { return __bu
 // |x - hi - lo| <= 2^-22 |x|), and a product w x is the three f16 MFMA products wh xh + wh xl + wl xh accumulated in fp32 (the dropped wl xl is 2^-22 of the product):
 // ONE v_mfma_f32_16x16x32_f16 whose K axis carries (channel, hi | lo) -- A = [wh | wh], B = [xh | xl]: the 16-byte slot a lane read as four fp32 channels is now the
 // same four channels as [hi x 4 | lo x 4] -- plus ONE v_mfma_f32_16x16x16_f16 (A = wl, B = xh = the slot's lower half) replace FOUR v_mfma_f32_16x16x4_f32:
-// 2 x ~18 cycles of the matrix pipe instead of 4 x 32 (tools/ubench_mfma_f16.hip), same accumulator layout.  Ranges: the block input is scaled per image by a power of
-// two when its largest magnitude reaches 2^15 (undone in the expand epilogue's scale), the depthwise output is ReLU6's [0, 6]; weight rows are normalised by powers of
+// 2 x ~18 cycles of the matrix pipe instead of 4 x 32 (tools/ubench_mfma_f16.hip), same accumulator layout.  Ranges: the block input is scaled per tile by a power of
+// two when its largest magnitude leaves [2^-2, 2^15) (split_tile_scale; undone in the expand epilogue), the depthwise output is ReLU6's [0, 6]; weight rows are normalised by powers of
 // two on the host (undone in the same scales); lo parts below fp16's normal range lose bits that are 2^-25 of the row's largest magnitude.  The depthwise stage, all
 // epilogues, the reduction and the residual (re-read from global memory: the LDS tile holds the split form) are fp32 as before.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -111,6 +111,18 @@ __device__ __forceinline__ f16x8 split_f16x3(float d0, float d1, float d2, float
     const float r0 = d0 - static_cast<float>(h01[0]), r1 = d1 - static_cast<float>(h01[1]), r2 = d2 - static_cast<float>(h23[0]), r3 = d3 - static_cast<float>(h23[1]);
     const f16x2 l01 = __builtin_convertvector(f32x2v{r0, r1}, f16x2), l23 = __builtin_convertvector(f32x2v{r2, r3}, f16x2);
     return f16x8{h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
+}
+
+// The power of two a tile is multiplied by before it is split (mb = bit pattern of its largest magnitude): none while that magnitude is in [2^-2, 2^15) -- fp16 holds the
+// hi parts, and the lo parts of the elements that matter stay normal numbers (an element's lo part is 2^-11 of it; what falls below fp16's normal range is resolved to
+// 2^-25, i.e. 2^-23 of the tile's largest magnitude or better) --, otherwise the power that brings it into [2^14, 2^15).  Returns whether the tile is scaled.
+__device__ __forceinline__ bool split_tile_scale(int mb, float& sx, float& sxInv) {
+    const int ex = (mb >> 23) & 255;
+    const bool scaled = mb != 0 && (ex >= 127 + 15 || ex < 127 - 2);
+    const int sb = scaled ? min(268 - ex, 227) : 127;
+    sx = __int_as_float(sb << 23);
+    sxInv = __int_as_float((254 - sb) << 23);
+    return scaled;
 }
 
 // Wave-autonomous: every WAVE owns one small output tile (4x8 pixels for stride 1, 2x8 for stride 2) from the x tile to the store, in its own
@@ -267,13 +279,7 @@ __global__ __launch_bounds__(256, 2) void irb_wave_kernel(IrbParams p, const flo
             }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        const int mb = __builtin_amdgcn_readfirstlane(__float_as_int(m));
-        if (mb >= 0x47000000) { // >= 2^15 (rare): the tile times a power of two that brings it into [2^14, 2^15), undone after the expand MFMAs
-            const int ex = (mb >> 23) & 255;
-            sxS = __int_as_float((127 + 14 + 127 - ex) << 23);
-            sxInv = __int_as_float((ex - 14) << 23);
-            scaled = true;
-        }
+        scaled = split_tile_scale(__builtin_amdgcn_readfirstlane(__float_as_int(m)), sxS, sxInv); // (wave-uniform: the rare scaled path is undone after the expand MFMAs)
         for (int q = 0; q < quads; ++q)
             for (int hp = lane; hp < npx; hp += 64) {
                 float4* const sp = reinterpret_cast<float4*>(xs + q * p.xPlane + hp * 4);
@@ -621,13 +627,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (lane == 0) atomicMax(&tabD[G * 16], __float_as_int(m));
         __syncthreads();
-        const int mb = tabD[G * 16];
         float sx = 1.0f;
-        if (mb >= 0x47000000) { // >= 2^15: bring the largest magnitude into [2^14, 2^15)
-            const int ex = (mb >> 23) & 255;
-            sx = __int_as_float((127 + 14 + 127 - ex) << 23);
-            sxInv = __int_as_float((ex - 14) << 23);
-        }
+        (void)split_tile_scale(tabD[G * 16], sx, sxInv);
         for (int e = tid; e < totalSlots; e += 256) {
             const float4 v = xs4[e];
             xs4[e] = __builtin_bit_cast(float4, split_f16x3(v.x * sx, v.y * sx, v.z * sx, v.w * sx));
@@ -1021,13 +1022,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NCB <= 2 ? 
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (lane == 0) atomicMax(&tabR[OT16], __float_as_int(m));
         __syncthreads();
-        const int mb = __builtin_amdgcn_readfirstlane(tabR[OT16]); // (block-uniform: the rare scaled path is a scalar branch)
-        if (mb >= 0x47000000) { // >= 2^15 (rare): the tile times a power of two that brings it into [2^14, 2^15), undone after the expand MFMAs
-            const int ex = (mb >> 23) & 255;
-            sxS = __int_as_float((127 + 14 + 127 - ex) << 23);
-            sxInv = __int_as_float((ex - 14) << 23);
-            scaled = true;
-        }
+        scaled = split_tile_scale(__builtin_amdgcn_readfirstlane(tabR[OT16]), sxS, sxInv); // (block-uniform: the rare scaled path, undone after the expand MFMAs, is a scalar branch)
         for (int e = tid; e < totalSlots; e += NT) {
             const float4 v = xs4[e];
             xs4[e] = __builtin_bit_cast(float4, split_f16x3(v.x * sxS, v.y * sxS, v.z * sxS, v.w * sxS));

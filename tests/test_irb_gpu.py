@@ -472,3 +472,79 @@ def test_irb_band_kernel_matches_oracle_and_separate_layers(ctx, case, geom, mon
     np.testing.assert_allclose(got, want, err_msg=d, **TOL)
     np.testing.assert_allclose(got, sep.numpy(), err_msg=d, rtol=2e-5, atol=2e-5)
     np.testing.assert_array_equal(got, plan(xt).numpy())
+
+
+# ---- the split-precision form of the pointwise stages (round 6): fp32 operands as fp16 hi + lo, three f16 MFMA products per fp32 product.  The cases name the kernel
+# (environment that selects it), the block shape and whether the block input / the expand weights sit outside fp16's range
+SPLIT_KERNELS = {"image": ({"SNNHIP_IRB_IMAGE": "1"}, "irb_image_kernel", (2, 14, 14, 64, 384, 64, 1, True, ("relu6", "relu6", ""))),
+                 "image96": ({"SNNHIP_IRB_IMAGE": "1"}, "irb_image_kernel", (2, 14, 14, 96, 576, 96, 1, True, ("relu6", "relu6", ""))),
+                 "band": ({"SNNHIP_IRB_BAND": "1"}, "irb_band_kernel", (2, 56, 56, 24, 144, 24, 1, True, ("relu6", "relu6", ""))),
+                 "band_s2": ({"SNNHIP_IRB_BAND": "1"}, "irb_band_kernel", (2, 28, 28, 32, 192, 64, 2, False, ("relu6", "relu6", ""))),
+                 "wave": ({"SNNHIP_IRB_BAND": "0"}, "irb_wave_kernel", (2, 112, 112, 16, 96, 24, 2, False, ("relu6", "relu6", ""))),
+                 "wave_res": ({"SNNHIP_IRB_BAND": "0"}, "irb_wave_kernel", (2, 56, 56, 24, 144, 24, 1, True, ("relu6", "relu6", "")))}
+
+
+def _split_block(ctx, monkeypatch, which, split, x_scale=1.0, we_scale=1.0, wp_scale=1.0):
+    import shadernn_amd as snn
+
+    env, kernel, case = SPLIT_KERNELS[which]
+    monkeypatch.delenv("SNNHIP_IRB_FUSION", raising=False)
+    for k in ("SNNHIP_IRB_IMAGE", "SNNHIP_IRB_BAND", "SNNHIP_IRB_BAND_GEOM"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    if split is None:
+        monkeypatch.delenv("SNNHIP_IRB_SPLIT", raising=False)
+    else:
+        monkeypatch.setenv("SNNHIP_IRB_SPLIT", split)
+    N, H, W, C, Ch, Co, s, res, acts = case
+    x = _rand((N, H, W, C), 371) * np.float32(x_scale)
+    (we, be, bne), (wd, bd, bnd), (wp, bp, bnp) = _layers(case, 380)
+    we, wp = we * np.float32(we_scale), wp * np.float32(wp_scale)
+    pe = snn.conv2d_plan(ctx, N, H, W, we, be, act=acts[0], leaky=0.1, bn=bne)
+    pd = snn.conv2d_plan(ctx, N, H, W, wd, bd, stride=s, pads=O.padding_offsets("same", 3), act=acts[1], leaky=0.1, bn=bnd, depthwise=True)
+    _, OH, OW, _ = pd.out_shape()
+    pp = snn.conv2d_plan(ctx, N, OH, OW, wp, bp, act=acts[2], leaky=0.1, bn=bnp)
+    xt = snn.Tensor.from_numpy(ctx, x)
+    h = O.conv2d(x, we, be, 1, (0, 0, 0, 0), "constant", acts[0], 0.1, bne, threads=8)
+    dd = O.depthwise(h, wd, bd, s, O.padding_offsets("same", 3), acts[1], 0.1, bnd)
+    want = O.conv2d(dd, wp, bp, 1, (0, 0, 0, 0), "constant", acts[2], 0.1, bnp, threads=8)
+    if res:
+        want = O.add_act(want, x, "")
+        pa = snn.add_plan(ctx, N, OH, OW, Co, act="")
+        plan, ins = snn.graph_fuse(ctx, [(pe, [-1], False), (pd, [0], False), (pp, [1], False), (pa, [2, -1], True)])[3]
+        assert ins == [-1]
+    else:
+        plan = snn.chain_plan(ctx, [pe, pd, pp])
+        assert plan.num_steps() == 1
+    d = plan.describe()
+    assert kernel in d, d
+    return plan(xt).numpy(), want, d
+
+
+@pytest.mark.parametrize("which", sorted(SPLIT_KERNELS))
+def test_irb_split_form_is_the_default_and_stays_within_1e5_of_the_fp32_mfma_form(ctx, which, monkeypatch):
+    """Default = the split form (description says so); SNNHIP_IRB_SPLIT=0 = the fp32 MFMA form of rounds 4-5.  Both against the oracle at the north-star
+    tolerance, and against each other an order of magnitude tighter: the split products carry 22 bits."""
+    got, want, d = _split_block(ctx, monkeypatch, which, None)
+    assert "f16x3split" in d and ",true>" in d.split("kernel=")[1], d
+    ref, _, d0 = _split_block(ctx, monkeypatch, which, "0")
+    assert "mfma_f32_16x16x4" in d0 and "f16x3split" not in d0, d0
+    np.testing.assert_allclose(got, want, err_msg=d, **TOL)
+    np.testing.assert_allclose(ref, want, err_msg=d0, **TOL)
+    np.testing.assert_allclose(got, ref, err_msg=d, rtol=1e-5, atol=1e-5)
+    one, _, _ = _split_block(ctx, monkeypatch, which, "1")
+    np.testing.assert_array_equal(one, got)
+
+
+@pytest.mark.parametrize("which", sorted(SPLIT_KERNELS))
+def test_irb_split_form_block_inputs_and_weight_rows_outside_the_fp16_range(ctx, which, monkeypatch):
+    """A block input of magnitude 4e5 (fp16 ends at 65504: the kernel scales the tile by a power of two and undoes it after the expand MFMAs) against expand
+    weights of 1e-6 (fp16's normal range starts at 6e-5: the host multiplies every weight row by a power of two and folds its inverse into the epilogue /
+    the depthwise taps), and project weights of 3e3 x the usual.  Same tolerance as every other block test, relative to the output's own scale."""
+    got, want, d = _split_block(ctx, monkeypatch, which, None, x_scale=1e5, we_scale=1e-5, wp_scale=1.0)
+    assert "f16x3split" in d, d
+    np.testing.assert_allclose(got, want, err_msg=d, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max()) / 10.0))
+    got, want, d = _split_block(ctx, monkeypatch, which, None, x_scale=1e-3, we_scale=1e3, wp_scale=3e3)
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(got, want, err_msg=d, rtol=1e-4, atol=1e-5 * scale)

@@ -572,17 +572,20 @@ struct IrbImgParams {
     int slicesPerWave; // Ch / 64
     int wePieces, wpPieces;
     int hasRes;
+    int OS;            // blocks per image (round 6): block b computes output blocks (b % OS) * NCB .. of image b / OS -- MobileNetV2's b16 (160 -> 960 -> 320: 20 output blocks,
+                       // 320 accumulator registers per lane) as two blocks of ten, each with its own expand / depthwise pass
     unsigned magicSP;
     ActCfg ac1, ac2, ac3, ac4;
 };
 
-template <int NCB /* Co / 16 */, int CJ /* C / 16 */, int G /* output pixel tiles */, bool R6, bool S16 = false /* split-precision pointwise stages */>
+template <int NCB /* Co / 16 / OS */, int CJ /* C / 16 */, int G /* output pixel tiles */, bool R6, bool S16 = false /* split-precision pointwise stages */>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void irb_image_kernel(IrbImgParams p, const float* __restrict__ x, const float4* __restrict__ weg,
                                                                                                  const float4* __restrict__ wpg, const float4* __restrict__ epi3,
                                                                                                  const int* __restrict__ tabs, float* __restrict__ y) {
     extern __shared__ float4 sm4[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n16 = lane & 15, k = lane >> 4;
-    const int img = blockIdx.x;
+    const int img = p.OS > 1 ? blockIdx.x / p.OS : blockIdx.x;
+    const int cb0 = p.OS > 1 ? (blockIdx.x % p.OS) * NCB : 0, ncbAll = NCB * p.OS; // this block's first output block; the blobs hold all of them
 #ifdef SNNHIP_IRBI_TRACE // experiment builds (tools/exp_one.sh): one block prints the s_memtime stamps of its phases
     const bool itr = blockIdx.x == 100 && lane == 0 && (wave == 0 || wave == 3);
     unsigned long long ist[8] = {};
@@ -653,9 +656,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int j = 0; j < CJ; ++j) a[j] = web[j * 64 + lane];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[cb * 64 + lane];
+    for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[(cb0 + cb) * 64 + lane];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
+    for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[ncbAll * 64 + tp * 4 + k];
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int eFirst0 = tabE[n16], eFirst1 = tabE[(p.MT > 1 ? 16 : 0) + n16];
 #ifdef SNNHIP_IRBI_ABL
@@ -750,8 +753,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (more) web += weStep;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) a[j] = web[j * 64 + lane];
-        [[maybe_unused]] const float4 sc2 = wpb[NCB * 64 + 36 + k];
-        const float4 sh2 = wpb[NCB * 64 + 40 + k];
+        [[maybe_unused]] const float4 sc2 = wpb[ncbAll * 64 + 36 + k];
+        const float4 sh2 = wpb[ncbAll * 64 + 40 + k];
         __builtin_amdgcn_sched_barrier(0);
         // ---- D + P: depthwise taps of output tile g -> the B operand of the project MFMAs (kk outer, cb inner: consecutive MFMAs are independent).
         // The order is pinned (sched_barrier): tile g's tap FMAs, then the 9 tap reads of tile g + 1 INTO THE SAME REGISTERS, then tile g's MFMAs, under
@@ -838,9 +841,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (more) wpb += wpStep;
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[cb * 64 + lane];
+        for (int cb = 0; cb < NCB; ++cb) ap[cb] = wpb[(cb0 + cb) * 64 + lane];
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[NCB * 64 + tp * 4 + k];
+        for (int tp = 0; tp < 9; ++tp) wd[tp] = wpb[ncbAll * 64 + tp * 4 + k];
     }
 
 #ifdef SNNHIP_IRBI_ABL
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int g = 0; g < G; ++g) red4[(wave * G + g) * 64 + lane] = make_float4(acc[cb][g][0], acc[cb][g][1], acc[cb][g][2], acc[cb][g][3]);
         __syncthreads();
-        const float4 sc = epi3[2 * (cb * 4 + k)], sh = epi3[2 * (cb * 4 + k) + 1];
+        const float4 sc = epi3[2 * ((cb0 + cb) * 4 + k)], sh = epi3[2 * ((cb0 + cb) * 4 + k) + 1];
         for (int g = wave; g < G; g += 4) {
             const float4 q0 = red4[(0 * G + g) * 64 + lane], q1 = red4[(1 * G + g) * 64 + lane], q2 = red4[(2 * G + g) * 64 + lane], q3 = red4[(3 * G + g) * 64 + lane];
             const int o = g * 16 + n16;
@@ -868,13 +871,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 r.z = apply_act<true>(p.ac3, fmaf(sc.z, ((q0.z + q1.z) + q2.z) + q3.z, sh.z), 0.f);
                 r.w = apply_act<true>(p.ac3, fmaf(sc.w, ((q0.w + q1.w) + q2.w) + q3.w, sh.w), 0.f);
                 if (p.hasRes) { // (stride 1, C == Co: output pixel o is x-tile pixel o; the split form's tile is no longer the fp32 input: L2 has it)
-                    const float4 xr = S16 ? *reinterpret_cast<const float4*>(x + (static_cast<size_t>(img) * p.HW + o) * p.C + cb * 16 + 4 * k) : xs4[o * p.SP + cb * 4 + k];
+                    const float4 xr = S16 ? *reinterpret_cast<const float4*>(x + (static_cast<size_t>(img) * p.HW + o) * p.C + (cb0 + cb) * 16 + 4 * k) : xs4[o * p.SP + (cb0 + cb) * 4 + k];
                     r.x = apply_act<true>(p.ac4, r.x + xr.x, 0.f);
                     r.y = apply_act<true>(p.ac4, r.y + xr.y, 0.f);
                     r.z = apply_act<true>(p.ac4, r.z + xr.z, 0.f);
                     r.w = apply_act<true>(p.ac4, r.w + xr.w, 0.f);
                 }
-                *reinterpret_cast<float4*>(yi + static_cast<size_t>(o) * p.Co + cb * 16 + 4 * k) = r;
+                *reinterpret_cast<float4*>(yi + static_cast<size_t>(o) * p.Co + (cb0 + cb) * 16 + 4 * k) = r;
             }
         }
         if (cb + 1 < NCB) __syncthreads();
@@ -910,7 +913,7 @@ struct IrbImagePlan : snnhip_plan {
         SNNHIP_REQUIRE(x->n == p.N && x->h == p.H && x->w == p.W && x->c == p.C, "irb: input dims %dx%dx%dx%d != plan %dx%dx%dx%d", x->n, x->h, x->w, x->c, p.N, p.H, p.W, p.C);
         SNNHIP_REQUIRE(out->n == p.N && out->h == p.OH && out->w == p.OW && out->c == p.Co, "irb: output dims %dx%dx%dx%d != plan %dx%dx%dx%d", out->n, out->h, out->w,
                        out->c, p.N, p.OH, p.OW, p.Co);
-        SNNHIP_LAUNCH(kernel, dim3(static_cast<unsigned>(p.N)), dim3(256), ldsBytes, ctx->stream, p, x->data, reinterpret_cast<const float4*>(d_we),
+        SNNHIP_LAUNCH(kernel, dim3(static_cast<unsigned>(p.N * p.OS)), dim3(256), ldsBytes, ctx->stream, p, x->data, reinterpret_cast<const float4*>(d_we),
                       reinterpret_cast<const float4*>(d_wp), reinterpret_cast<const float4*>(d_e3), reinterpret_cast<const int*>(d_tabs), out->data);
         SNNHIP_CHECK_HIP(hipGetLastError());
         return SNNHIP_OK;
@@ -1297,6 +1300,8 @@ bool choose_band(int N, int H, int W, int C, int Ch, int Co, int OH, int OW, int
         if (s == 1 && OH == 56 && OW == 56 && N * 14L >= 4L * cus) pinR = 8, pinSW = 28, pinNW = 8;
         if (s == 2 && OH == 28 && OW == 28 && N * 7L >= 4L * cus) pinR = 4, pinSW = 28, pinNW = 8;
     }
+    // (fourth session, the split-precision kernel: b04 / b05 7 x 28 x 7 waves 82.2 us against the model's 7 x 28 x 8 at 86.1; b02 / b03 / b06 stay where they are)
+    if (!pinR && !pinSW && !pinNW && H == 28 && W == 28 && C == 32 && Ch == 192 && s == 1 && N * 4L >= 4L * cus) pinR = 7, pinSW = 28, pinNW = 7;
     for (int div = 1; div <= 4; div *= 2) {
         const int SW = pinSW ? std::min(pinSW, OW) : up_div(OW, div);
         if (div > 1 && (SW < 14 || pinSW)) break;
@@ -1420,6 +1425,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
     // quarters of whole slices, ReLU6 after expand and depthwise, and at least one image per two CUs (a block is an image).  SNNHIP_IRB_IMAGE=0 switches it
     // off, =1 takes it at any batch size (tests).
     IrbImgFn imgFn = nullptr;
+    int imgOS = 1;
     // SNNHIP_IRB_SPLIT=0: the whole-image kernel's pointwise stages as fp32 MFMAs (round 5's form); default: the split-precision form (three f16 products per fp32 product)
     const char* splitOpt = snnhip::option("SNNHIP_IRB_SPLIT");
     const bool imgS16 = !(splitOpt && atoi(splitOpt) == 0) && !SNNHIP_IRBI_FOLD_BN;
@@ -1435,7 +1441,16 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         int GT = 0;
         if (mode != 0 && !cs && !noExpand && !fuseAll && C % 16 == 0 && Co % 16 == 0 && Ch % 64 == 0 && HW <= 16 * 13 && ge.act == SNNHIP_ACT_RELU6 &&
             gd.act == SNNHIP_ACT_RELU6 && (ge.N * 2 >= cus || mode == 1))
+        {
             imgFn = pick_irb_image(Co / 16, C / 16, up_div(OHW, 16), imgS16, &GT);
+            // no instantiation with that many output blocks (MobileNetV2's b16: 20): two blocks per image, ten output blocks each, each with its own expand / depthwise
+            // pass (1.34x the block's flops) -- separate layers 172 us, this way 2 x b14's 62 (SNNHIP_IRB_IMAGE_HALVES=0 keeps the separate layers)
+            const char* hv = snnhip::option("SNNHIP_IRB_IMAGE_HALVES");
+            if (!imgFn && Co % 32 == 0 && !ad && !(hv && atoi(hv) == 0)) {
+                imgFn = pick_irb_image(Co / 32, C / 16, up_div(OHW, 16), imgS16, &GT);
+                if (imgFn) imgOS = 2;
+            }
+        }
         if (imgFn) {
             ip.N = ge.N; ip.H = ge.H; ip.W = ge.W; ip.C = C; ip.Ch = Ch; ip.Co = Co; ip.OH = gd.OH; ip.OW = gd.OW; ip.s = s;
             ip.HW = HW;
@@ -1449,6 +1464,7 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
             ip.offH4 = std::max(ip.MT * 16 * ip.SP, round_up(HW * ip.SP, 64));
             ip.slicesPerWave = Ch / 64;
             ip.hasRes = ad ? 1 : 0;
+            ip.OS = imgOS;
             imgLds = (static_cast<size_t>(ip.offH4) + 16 * ip.hPlane4) * 16 + static_cast<size_t>(ip.MT + GT) * 16 * 4 + (imgS16 ? 16 : 0); // (+ the split form's magnitude slot)
             if (imgLds > 160 * 1024 || HW * ip.SP >= 65536 ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(imgFn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(imgLds)) != hipSuccess)
@@ -1742,11 +1758,11 @@ int make_irb_plan(snnhip_ctx* ctx, snnhip_plan* expandPlan, snnhip_plan* dwPlan,
         ipl->flops = ce->flops + cd->flops + cp->flops;
         ipl->bytes = ce->bytes + cd->bytes + cp->bytes + (addPlan ? addPlan->bytes : 0.0); // unfused accounting of the layers it replaces
         ipl->kernelBytes = fusedBytes;
-        char ib[320];
-        snprintf(ib, sizeof(ib), "irb_fused_mfma_%s [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] image per block (%dx%d, %d px tiles), hidden quarter per wave, "
+        char ib[400];
+        snprintf(ib, sizeof(ib), "irb_fused_mfma_%s [conv1x1 %d->%d + depthwise3x3 s%d + conv1x1 %d->%d%s] image per block (%dx%d, %d px tiles%s), hidden quarter per wave, "
                  "slices=%d lds=%zuB hbm_bytes=%.6g kernel=irb_image_kernel<%d,%d,%d,true,%s> relu6-epilogues",
-                 imgS16 ? "f16x3split_16x16x32" : "f32_16x16x4", C, Ch, s, Ch, Co, addPlan ? " + add" : "", ip.H, ip.W, ip.MT, Ch / 16, imgLds, fusedBytes, Co / 16, C / 16,
-                 static_cast<int>(imgTabs.size() / 16) - ip.MT, imgS16 ? "true" : "false");
+                 imgS16 ? "f16x3split_16x16x32" : "f32_16x16x4", C, Ch, s, Ch, Co, addPlan ? " + add" : "", ip.H, ip.W, ip.MT, imgOS > 1 ? ", two blocks of half the output channels" : "",
+                 Ch / 16, imgLds, fusedBytes, Co / 16 / imgOS, C / 16, static_cast<int>(imgTabs.size() / 16) - ip.MT, imgS16 ? "true" : "false");
         ipl->desc = ib;
         *out = ipl;
         return SNNHIP_OK;

@@ -341,7 +341,8 @@ IMAGE_CASES = [(2, 14, 14, 64, 384, 64, 1, True, ("relu6", "relu6", "")),      #
                (3, 7, 7, 160, 960, 160, 1, True, ("relu6", "relu6", "")),      # b14 / b15
                (2, 10, 13, 64, 128, 64, 1, True, ("relu6", "relu6", "relu")),  # 130 pixels = 8 tiles + 2 pixels, two slices per wave, activations after project and add
                (1, 13, 11, 96, 192, 160, 2, False, ("relu6", "relu6", "leakyRelu")),  # odd extents at stride 2 (7x6 outputs = 3 tiles of the 4 the kernel walks)
-               (2, 5, 9, 160, 64, 160, 1, False, ("relu6", "relu6", ""))]      # one slice per wave
+               (2, 5, 9, 160, 64, 160, 1, False, ("relu6", "relu6", "")),      # one slice per wave
+               (3, 7, 7, 160, 960, 320, 1, False, ("relu6", "relu6", ""))]     # b16: 20 output blocks = two blocks per image with ten each (round 6)
 
 
 @pytest.mark.parametrize("case", IMAGE_CASES, ids=lambda c: "%dx%dx%d_%d-%d-%d_s%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], "_res" if c[7] else ""))
@@ -427,7 +428,8 @@ BAND_CASES = [((2, 112, 112, 16, 96, 24, 2, False, ("relu6", "relu6", "")), None
               ((2, 33, 50, 8, 48, 24, 2, False, ("relu6", "relu6", "leakyRelu")), "3,13,4"),  # C = 8: only the tail step; 17x25 outputs in bands of 3 x 13
               ((1, 30, 30, 32, 64, 64, 1, False, ("relu6", "relu6", "")), "7,30,8"),     # four output blocks, 8 waves
               ((2, 56, 56, 24, 144, 24, 1, True, ("relu6", "relu6", "")), "8,28,8"),     # b02 at the geometry batch 256 pins (round 6: eight waves, tools/r6_geom.sh)
-              ((2, 56, 56, 24, 144, 32, 2, False, ("relu6", "relu6", "")), "4,28,8")]    # b03 at its pinned geometry: stride 2 with eight waves
+              ((2, 56, 56, 24, 144, 32, 2, False, ("relu6", "relu6", "")), "4,28,8"),    # b03 at its pinned geometry: stride 2 with eight waves
+              ((3, 28, 28, 32, 192, 32, 1, True, ("relu6", "relu6", "")), "7,28,7")]     # b04 / b05 at the geometry batch 256 pins for the split-precision kernel
 
 
 @pytest.mark.parametrize("case,geom", BAND_CASES, ids=lambda c: ("%dx%dx%d_%d-%d-%d_s%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], "_res" if c[7] else "")) if isinstance(c, tuple) else str(c))

@@ -860,9 +860,10 @@ def run_config(config, args, env, primary):
                 r = out["roofline"]
                 comp["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic_bytes", "kernel", "share_of_gpu_time",
                                                       "launches_per_step", "avg_launch_us", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "frac_executed",
-                                                      "mfma_pipe_util_pmc", "whole_step_frac") if k in r}
+                                                      "mfma_pipe_util_pmc", "whole_step_frac", "arithmetic", "frac_of_split_peak", "split_peak", "arithmetic_note") if k in r}
                 comp["kernels"] = [{"function": k["function"], "share_of_gpu_time": k["share_of_gpu_time"], "us_per_step": k["us_per_step"], "launches_per_step": k["launches_per_step"],
-                                    "bound": k["bound"], "frac": k["frac"], "frac_executed": k.get("frac_executed")} for k in rows[:6]]
+                                    "bound": k["bound"], "frac": k["frac"], "frac_executed": k.get("frac_executed"),
+                                    **({"arithmetic": k["arithmetic"], "frac_of_split_peak": k["frac_of_split_peak"]} if k.get("arithmetic") else {})} for k in rows[:6]]
             if cpu_rec is not None:
                 comp["cpu_baseline"] = cpu_rec
             out = comp

@@ -316,6 +316,27 @@ def test_c4_mobilenetv2_batch256_through_host_graph_replay(ctx, tmp_path):
     m.close()
 
 
+def test_c4_split_precision_blocks_against_their_fp32_mfma_form_through_the_whole_network(ctx, tmp_path, monkeypatch):
+    """MobileNetV2 at the benched batch, every inverted-residual block on its fused kernel: the default (split-precision pointwise stages: three f16 MFMA products per
+    fp32 product) against SNNHIP_IRB_SPLIT=0 (the same kernels on the fp32 MFMA) through all seventeen blocks -- the logits' worth of difference, measured on the
+    softmax output and on the last feature map's scale -- and both against the oracle."""
+    x = np.random.default_rng(99).random((256, 224, 224, 3), dtype=np.float32)
+    outs = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("SNNHIP_IRB_SPLIT", split)
+        net, m, (H, W, C) = _bench_model(tmp_path, "c4", 256)
+        kinds = " ".join(d for _, _, d, _, _ in m.plan_steps())
+        assert ("f16x3split" in kinds) == (split == "1") and "irb_image_kernel" in kinds and "irb_band_kernel" in kinds and "irb_wave_kernel" in kinds, kinds
+        outs[split] = m(x).reshape(256, -1).copy()
+        m.close()
+    want = O.forward(net, x[200:201], threads=THREADS).reshape(-1)
+    np.testing.assert_allclose(outs["1"][200], want, **TOL)
+    np.testing.assert_allclose(outs["0"][200], want, **TOL)
+    # probabilities are ~1e-3: compare relative to each row's largest one
+    d = np.abs(outs["1"] - outs["0"]).max(axis=1) / outs["0"].max(axis=1)
+    assert d.max() < 2e-5, float(d.max())
+
+
 @pytest.mark.parametrize("MB", [32, 16], ids=["micro32_as_benched", "micro16"])
 def test_c5_candy_720p_fp16_microbatch_default_switches_through_host(ctx, tmp_path, MB):
     """BASELINE configs[4] as bench.py times it (micro-batches of 32 since round 6 -- the 64 -> 32 up-convolution's nominal input, the x2-upsampled 64-channel
